@@ -1,0 +1,692 @@
+"""CPU oracle: a torch-CPU / numpy restatement of the sleap-nn hot path.
+
+TEST INFRASTRUCTURE ONLY -- imported by ``tests/``, ``__graft_entry__.smoke()`` and the
+``cpu_baseline`` leg of ``bench.py``; the product (``sleap_nn_amd``) never imports it.
+
+Parity status: PINNED.  ``tests/test_oracle_golden.py`` checks every function here against
+vectors produced by running the reference itself in the build container
+(``oracle/gen_golden.py`` -> ``tests/golden/*.npz``) and against the known-answer
+vectors of the reference's own tests (tests/inference/test_peak_finding.py,
+tests/inference/test_paf_grouping.py, tests/inference/parity_golden/bottomup.pkl).
+
+Each function cites the reference file:line (relative to the sleap-nn repo) it restates.
+Arithmetic is plain fp32 ATen-CPU / numpy, written independently of the reference code.
+Third-party pieces the reference itself delegates to are used as-is:
+``scipy.optimize.linear_sum_assignment`` (reference: inference/ops/paf.py:589).
+"""
+
+from __future__ import annotations
+
+import math
+from collections import deque
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from scipy.optimize import linear_sum_assignment
+
+# --------------------------------------------------------------------------------------
+# Network plan (architectures/unet.py:49-253, encoder_decoder.py:38-730, model.py:157-261)
+# --------------------------------------------------------------------------------------
+
+HEAD_ORDER = {
+    # model.py:92-148
+    "single_instance": [("SingleInstanceConfmapsHead", "confmaps")],
+    "centroid": [("CentroidConfmapsHead", "confmaps")],
+    "centered_instance": [("CenteredInstanceConfmapsHead", "confmaps")],
+    "bottomup": [("MultiInstanceConfmapsHead", "confmaps"), ("PartAffinityFieldsHead", "pafs")],
+    "multi_class_bottomup": [("MultiInstanceConfmapsHead", "confmaps"), ("ClassMapsHead", "class_maps")],
+}
+
+
+def head_channels(head_name: str, cfg: dict) -> int:
+    """heads.py:96-98,168-170,281-283,342-344,398-400."""
+    if head_name == "CentroidConfmapsHead":
+        return 1
+    if head_name == "PartAffinityFieldsHead":
+        return 2 * len(cfg["edges"])
+    if head_name == "ClassMapsHead":
+        return len(cfg["classes"])
+    return len(cfg["part_names"])
+
+
+def unet_plan(bb: dict) -> dict:
+    """Enumerate the conv layers of the reference UNet with checkpoint-compatible names.
+
+    unet.py:230-253 (from_config), :96-226 (blocks), encoder_decoder.py:274-316 (encoder),
+    :634-703 (decoder).  Only ``stacks == 1`` is meaningful in the reference.
+    """
+    filters = int(bb["filters"])
+    rate = bb["filters_rate"]
+    k = int(bb.get("kernel_size", 3))
+    stem_stride = bb.get("stem_stride", None)
+    stem_blocks = int(round(math.log2(stem_stride))) if stem_stride else 0
+    down = int(round(math.log2(bb["max_stride"]))) - stem_blocks
+    up = int(round(math.log2(bb["max_stride"] / bb["output_stride"]))) + stem_blocks
+    cpb = int(bb.get("convs_per_block", 2))
+    middle = bool(bb.get("middle_block", True))
+    interp = bool(bb.get("up_interpolate", True))
+    cin = int(bb["in_channels"])
+    assert stem_blocks == 0, "oracle covers stem_stride=None (the hot-path configs)"
+    assert int(bb.get("stacks", 1)) == 1
+
+    enc = []  # list of blocks: dict(pool=bool, convs=[(name, cin, cout)])
+    prev = cin
+    for b in range(down):
+        f = int(filters * (rate**b))
+        convs = []
+        for i in range(cpb):
+            convs.append((f"backbone.encoders.0.encoder_stack.{b}.blocks.stack0_enc{b}_conv{i}", prev if i == 0 else f, f))
+        enc.append({"pool": b > 0, "convs": convs})
+        prev = f
+    mid = []
+    enc_num = down + 1  # encoder_stack has down blocks + last pool
+    fmid = int(filters * (rate**down))
+    mb = 0
+    if middle:
+        if cpb > 1:
+            convs = []
+            for i in range(cpb - 1):
+                convs.append((f"backbone.middle_blocks.{mb}.blocks.stack0_enc{enc_num}_middle_expand_conv{i}", prev if i == 0 else fmid, fmid))
+            mid.append(convs)
+            enc_num += 1
+            mb += 1
+            prev = fmid
+        mid.append([(f"backbone.middle_blocks.{mb}.blocks.stack0_enc{enc_num}_middle_contract_conv0", fmid, fmid)])
+        prev = fmid
+    x_in = fmid  # decoder input channels (unet.py:198-206, block_contraction False)
+    dec = []
+    cur_stride = 2**down
+    stride_to_filters = {cur_stride: x_in}
+    pin = x_in
+    for b in range(up):
+        fout = int(filters * (rate ** max(0, down - 1 - b)))
+        nxt = cur_stride // 2
+        pfx = f"backbone.decoders.0.decoder_stack.{b}.blocks.stack0_dec{b}_s{cur_stride}_to_s{nxt}"
+        blk = {"interp": interp, "skip_c": fout, "convs": [], "stride": nxt}
+        if not interp:
+            blk["trans"] = (pfx + "_trans_conv", pin, fout)
+            first_in = fout + fout
+        else:
+            first_in = pin + fout
+        for i in range(cpb):
+            blk["convs"].append((pfx + f"_refine_conv{i}", first_in if i == 0 else fout, fout))
+        dec.append(blk)
+        stride_to_filters[nxt] = fout
+        pin = fout
+        cur_stride = nxt
+    return {"enc": enc, "mid": mid, "dec": dec, "stride_to_filters": stride_to_filters, "k": k, "down": down}
+
+
+def init_state(bb: dict, head_cfgs: dict, model_type: str, seed: int = 1234, head_scale: float = 0.05) -> Dict[str, torch.Tensor]:
+    """Synthetic weights: xavier-uniform convs, zero bias (training/utils.py:72-78), heads x0.05.
+
+    BASELINE.md section 3 synthetic-input definition.
+    """
+    plan = unet_plan(bb)
+    g = torch.Generator().manual_seed(seed)
+    sd: Dict[str, torch.Tensor] = {}
+    k = plan["k"]
+
+    def xavier(shape, fan_in, fan_out):
+        bound = math.sqrt(6.0 / (fan_in + fan_out))
+        return (torch.rand(shape, generator=g) * 2 - 1) * bound
+
+    def add_conv(name, ci, co, kk):
+        sd[name + ".weight"] = xavier((co, ci, kk, kk), ci * kk * kk, co * kk * kk)
+        sd[name + ".bias"] = torch.zeros(co)
+
+    for blk in plan["enc"]:
+        for n, ci, co in blk["convs"]:
+            add_conv(n, ci, co, k)
+    for convs in plan["mid"]:
+        for n, ci, co in convs:
+            add_conv(n, ci, co, k)
+    for blk in plan["dec"]:
+        if not blk["interp"]:
+            n, ci, co = blk["trans"]
+            sd[n + ".weight"] = xavier((ci, co, 3, 3), co * 9, ci * 9)
+            sd[n + ".bias"] = torch.zeros(co)
+        for n, ci, co in blk["convs"]:
+            add_conv(n, ci, co, k)
+    for i, (hname, key) in enumerate(HEAD_ORDER[model_type]):
+        hc = head_cfgs[key]
+        ci = plan["stride_to_filters"][hc["output_stride"]]
+        co = head_channels(hname, hc)
+        sd[f"head_layers.{i}.{hname}.0.weight"] = xavier((co, ci, 1, 1), ci, co) * head_scale
+        sd[f"head_layers.{i}.{hname}.0.bias"] = torch.zeros(co)
+    return sd
+
+
+def normalize_input(x: torch.Tensor) -> torch.Tensor:
+    """data/normalization.py:7-35 + the n_samples squeeze of lightning_modules.py:1840-1848."""
+    if x.dim() == 5:
+        x = x.squeeze(1)
+    if not torch.is_floating_point(x):
+        return x.float() / 255.0
+    x = x.float()
+    if x.max() > 1.0:
+        x = x / 255.0
+    return x
+
+
+def same_pool2(x: torch.Tensor) -> torch.Tensor:
+    """common.py:69-107: zero pad bottom/right when odd, then max_pool2d(2, 2)."""
+    h, w = x.shape[-2:]
+    ph, pw = h % 2, w % 2
+    if ph or pw:
+        x = F.pad(x, (0, pw, 0, ph))
+    return F.max_pool2d(x, 2, 2)
+
+
+def unet_forward(sd: Dict[str, torch.Tensor], bb: dict, x: torch.Tensor, collect: Optional[dict] = None) -> dict:
+    """unet.py:260-299 / encoder_decoder.py:318-336,522-558,705-730 as one functional pass."""
+    plan = unet_plan(bb)
+    pad = plan["k"] // 2
+
+    def conv(name, t):
+        y = F.relu(F.conv2d(t, sd[name + ".weight"], sd[name + ".bias"], padding=pad))
+        if collect is not None:
+            collect[name] = y
+        return y
+
+    feats = []
+    for blk in plan["enc"]:
+        if blk["pool"]:
+            x = same_pool2(x)
+        for n, _, _ in blk["convs"]:
+            x = conv(n, x)
+        feats.append(x)
+    x = same_pool2(x)
+    for convs in plan["mid"]:
+        for n, _, _ in convs:
+            x = conv(n, x)
+    middle = x
+    feats = feats[::-1]
+    outs, strides = [], []
+    for i, blk in enumerate(plan["dec"]):
+        if blk["interp"]:
+            x = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False)
+        else:
+            n, _, _ = blk["trans"]
+            x = F.relu(F.conv_transpose2d(x, sd[n + ".weight"], sd[n + ".bias"], stride=2, padding=1, output_padding=1))
+            if collect is not None:
+                collect[n] = x
+        if i < len(feats):
+            sk = feats[i]
+            if x.shape[-2:] != sk.shape[-2:]:
+                x = F.interpolate(x, size=sk.shape[-2:], mode="bilinear", align_corners=False)
+            x = torch.cat((sk, x), dim=1)  # skip first (encoder_decoder.py:545,556)
+        for n, _, _ in blk["convs"]:
+            x = conv(n, x)
+        outs.append(x)
+        strides.append(blk["stride"])
+    return {"outputs": outs, "strides": strides, "middle_output": middle}
+
+
+def model_forward(sd, bb: dict, head_cfgs: dict, model_type: str, image: torch.Tensor, collect: Optional[dict] = None) -> Dict[str, torch.Tensor]:
+    """model.py:237-261 with the LightningModule forward's normalisation in front."""
+    x = normalize_input(image)
+    cin = int(bb["in_channels"])
+    if x.shape[-3] != cin:
+        if x.shape[-3] == 1:
+            x = x.repeat(1, 3, 1, 1)
+        elif x.shape[-3] == 3:
+            # torchvision rgb_to_grayscale weights
+            r, g, b = x.unbind(dim=-3)
+            x = (0.2989 * r + 0.587 * g + 0.114 * b).unsqueeze(-3)
+    bo = unet_forward(sd, bb, x, collect)
+    out = {}
+    for i, (hname, key) in enumerate(HEAD_ORDER[model_type]):
+        hc = head_cfgs[key]
+        feat = bo["outputs"][bo["strides"].index(hc["output_stride"])] if bo["outputs"] else bo["middle_output"]
+        y = F.conv2d(feat, sd[f"head_layers.{i}.{hname}.0.weight"], sd[f"head_layers.{i}.{hname}.0.bias"])
+        if hname == "ClassMapsHead":
+            y = torch.sigmoid(y)
+        out[hname] = y
+    return out
+
+
+def conv_flops(bb: dict, head_cfgs: dict, model_type: str, h: int, w: int) -> float:
+    """Algorithmic forward FLOPs/frame: 2*Cin*Cout*k^2*Hout*Wout per conv."""
+    plan = unet_plan(bb)
+    k2 = plan["k"] ** 2
+    total = 0.0
+    ch, cw = h, w
+    for blk in plan["enc"]:
+        if blk["pool"]:
+            ch, cw = (ch + 1) // 2, (cw + 1) // 2
+        for _, ci, co in blk["convs"]:
+            total += 2.0 * ci * co * k2 * ch * cw
+    ch, cw = (ch + 1) // 2, (cw + 1) // 2
+    for convs in plan["mid"]:
+        for _, ci, co in convs:
+            total += 2.0 * ci * co * k2 * ch * cw
+    sizes = {}
+    for blk in plan["dec"]:
+        ch, cw = ch * 2, cw * 2
+        if not blk["interp"]:
+            _, ci, co = blk["trans"]
+            total += 2.0 * ci * co * 9 * (ch // 2) * (cw // 2)
+        for _, ci, co in blk["convs"]:
+            total += 2.0 * ci * co * k2 * ch * cw
+        sizes[blk["stride"]] = (ch, cw)
+    for hname, key in HEAD_ORDER[model_type]:
+        hc = head_cfgs[key]
+        s = hc["output_stride"]
+        hh, ww = sizes[s]
+        total += 2.0 * plan["stride_to_filters"][s] * head_channels(hname, hc) * hh * ww
+    return total
+
+
+# --------------------------------------------------------------------------------------
+# Peak finding (inference/ops/peaks.py, ops/crops.py, data/instance_cropping.py:129-171)
+# --------------------------------------------------------------------------------------
+
+
+def _neighbour_max(cms: torch.Tensor) -> torch.Tensor:
+    """peaks.py:26-63: max over the 8 neighbours, -inf outside the image."""
+    p = F.pad(cms, (1, 1, 1, 1), value=float("-inf"))
+    h, w = cms.shape[-2:]
+    best = None
+    for dy in (0, 1, 2):
+        for dx in (0, 1, 2):
+            if dy == 1 and dx == 1:
+                continue
+            s = p[..., dy : dy + h, dx : dx + w]
+            best = s if best is None else torch.maximum(best, s)
+    return best
+
+
+def local_peaks_rough(cms: torch.Tensor, threshold: float = 0.2):
+    """peaks.py:184-218.  Order = lexicographic (sample, y, x, channel)."""
+    mask = (cms > _neighbour_max(cms)) & (cms > threshold)
+    b, y, x, c = torch.nonzero(mask.permute(0, 2, 3, 1), as_tuple=True)
+    vals = cms[b, c, y, x]
+    pts = torch.stack([x, y], dim=1).to(torch.float32)
+    return pts, vals, b.to(torch.int32), c.to(torch.int32)
+
+
+def _integral_offsets(cms_flat: torch.Tensor, pts: torch.Tensor, map_inds: torch.Tensor, patch: int) -> torch.Tensor:
+    """Zero-padded patch around each integer peak, first moments / mass.
+
+    instance_cropping.py:129-171 (bbox = centre -/+ (patch-1)/2), crops.py:85-124 (top-left
+    ``trunc(tl + half) - half``; zero outside), peaks.py:66-86 (sum(g*crop)/sum(crop)).
+    ``cms_flat`` is (M, H, W).
+    """
+    n = pts.shape[0]
+    h, w = cms_flat.shape[-2:]
+    half = patch // 2
+    tl = pts - (patch - 1) / 2.0  # (n,2) x,y of top-left
+    tl = (tl + half).to(torch.long) - half
+    ar = torch.arange(patch)
+    xs = tl[:, 0:1] + ar[None, :]  # (n,p)
+    ys = tl[:, 1:2] + ar[None, :]
+    okx = (xs >= 0) & (xs < w)
+    oky = (ys >= 0) & (ys < h)
+    xc = xs.clamp(0, w - 1)
+    yc = ys.clamp(0, h - 1)
+    crops = cms_flat[map_inds.long()[:, None, None], yc[:, :, None], xc[:, None, :]]
+    crops = crops * (oky[:, :, None] & okx[:, None, :]).to(crops.dtype)
+    crops = crops.reshape(n, 1, patch, patch)
+    gv = torch.arange(patch, dtype=torch.float32) - (patch - 1) / 2
+    z = torch.sum(crops, dim=[2, 3])
+    dx = torch.sum(gv.view(1, 1, 1, -1) * crops, dim=[2, 3]) / z
+    dy = torch.sum(gv.view(1, 1, -1, 1) * crops, dim=[2, 3]) / z
+    return torch.cat([dx, dy], dim=1)
+
+
+def find_local_peaks(cms: torch.Tensor, threshold: float = 0.2, refinement: Optional[str] = None, integral_patch_size: int = 5):
+    """peaks.py:221-259."""
+    pts, vals, sb, sc = local_peaks_rough(cms, threshold)
+    if pts.shape[0] == 0 or refinement != "integral":
+        return pts, vals, sb, sc
+    bsz, ch = cms.shape[:2]
+    flat = cms.reshape(bsz * ch, cms.shape[2], cms.shape[3])
+    off = _integral_offsets(flat, pts, sb.long() * ch + sc.long(), integral_patch_size)
+    return pts + off, vals, sb, sc
+
+
+def global_peaks_rough(cms: torch.Tensor, threshold: float = 0.1):
+    """peaks.py:89-130: x = first column holding the max, y = first row holding it."""
+    colmax, _ = torch.max(cms, dim=2)  # (B,C,W): max over rows
+    vmax, xi = torch.max(colmax, dim=2)
+    rowmax, _ = torch.max(cms, dim=3)  # (B,C,H)
+    _, yi = torch.max(rowmax, dim=2)
+    pts = torch.stack([xi, yi], dim=-1).to(torch.float32)
+    below = vmax < threshold
+    pts = torch.where(below[..., None], torch.full_like(pts, float("nan")), pts)
+    vals = torch.where(below, torch.zeros_like(vmax), vmax)
+    return pts, vals
+
+
+def find_global_peaks(cms: torch.Tensor, threshold: float = 0.2, refinement: Optional[str] = None, integral_patch_size: int = 5):
+    """peaks.py:133-181."""
+    pts, vals = global_peaks_rough(cms, threshold)
+    if refinement != "integral" or torch.isnan(pts).all():
+        return pts, vals
+    b, c = cms.shape[:2]
+    flat_pts = pts.reshape(b * c, 2)
+    valid = torch.nonzero(~torch.isnan(flat_pts[:, 0]), as_tuple=True)[0]
+    off = _integral_offsets(cms.reshape(b * c, cms.shape[2], cms.shape[3]), flat_pts[valid], valid, integral_patch_size)
+    out = flat_pts.clone()
+    out[valid] += off
+    return out.reshape(b, c, 2), vals
+
+
+# --------------------------------------------------------------------------------------
+# PAF scoring (inference/ops/paf.py:84-497, inference/utils.py:29-130)
+# --------------------------------------------------------------------------------------
+
+
+def connection_candidates(chan: torch.Tensor, edges: Sequence[Tuple[int, int]], n_nodes: int):
+    """paf.py:84-130: per edge, all (src peak, dst peak) pairs, src-major."""
+    chan = chan.long()
+    per_node = [torch.nonzero(chan == k, as_tuple=True)[0] for k in range(n_nodes)]
+    e_inds, pairs = [], []
+    for k, (s, d) in enumerate(edges):
+        a, b = per_node[s], per_node[d]
+        pr = torch.stack([a.repeat_interleave(b.numel()), b.repeat(a.numel())], dim=1)
+        pairs.append(pr)
+        e_inds.append(torch.full((pr.shape[0],), k, dtype=torch.int32))
+    if not pairs:
+        return torch.zeros(0, dtype=torch.int32), torch.zeros(0, 2, dtype=torch.long)
+    return torch.cat(e_inds), torch.cat(pairs)
+
+
+def line_points(src: torch.Tensor, dst: torch.Tensor, n_points: int, stride: int, hw: Tuple[int, int]):
+    """paf.py:133-234 + utils.py:29-130 for x=[0,1]: y0 + ((y1-y0)/(eps+1)) * t.
+
+    Returns int rows, cols of shape (n, n_points).
+    """
+    t = torch.linspace(0, 1, steps=n_points)
+    den = torch.tensor(torch.finfo(torch.float32).eps) + 1  # fp32: 1 + 2^-23
+    sl = (dst - src) / den  # (n,2)
+    xy = src[:, :, None] + sl[:, :, None] * t[None, None, :]  # (n,2,P)
+    ij = (xy / stride).round().int()
+    rows = ij[:, 1].clamp(0, hw[0] - 1)
+    cols = ij[:, 0].clamp(0, hw[1] - 1)
+    return rows, cols
+
+
+def score_lines_sample(pafs_hwc: torch.Tensor, peaks: torch.Tensor, e_inds: torch.Tensor, pairs: torch.Tensor, n_points: int, stride: int, max_edge_length: float, dist_penalty_weight: float):
+    """paf.py:237-287 (gather) + :290-410 (score)."""
+    if pairs.shape[0] == 0:
+        return torch.zeros(0)
+    src = peaks[pairs[:, 0]].float()
+    dst = peaks[pairs[:, 1]].float()
+    rows, cols = line_points(src, dst, n_points, stride, pafs_hwc.shape[:2])
+    ch = e_inds.long()[:, None] * 2
+    fx = pafs_hwc[rows.long(), cols.long(), ch]
+    fy = pafs_hwc[rows.long(), cols.long(), ch + 1]
+    vec = dst - src
+    length = torch.norm(vec, dim=1, keepdim=True)
+    unit = vec / length
+    lines = torch.stack([fx, fy], dim=-1)  # (n,P,2)
+    dots = torch.squeeze(lines @ unit.unsqueeze(2), dim=-1)
+    pen = torch.clamp(max_edge_length / length - 1, max=0) * dist_penalty_weight
+    return dots.mean(dim=1) + pen.squeeze(1)
+
+
+def score_paf_lines_batch(pafs_bhwc: torch.Tensor, peaks: List[torch.Tensor], chans: List[torch.Tensor], edges, n_points: int, stride: int, max_edge_length_ratio: float, dist_penalty_weight: float, n_nodes: int):
+    """paf.py:413-497.  Note max() includes the channel dim (paf.py:457-461)."""
+    mel = max_edge_length_ratio * max(pafs_bhwc.shape[-1], pafs_bhwc.shape[-2], pafs_bhwc.shape[-3]) * stride
+    oe, op, os_ = [], [], []
+    for b in range(pafs_bhwc.shape[0]):
+        e, p = connection_candidates(chans[b], edges, n_nodes)
+        s = score_lines_sample(pafs_bhwc[b], peaks[b], e, p, n_points, stride, mel, dist_penalty_weight)
+        oe.append(e)
+        op.append(p)
+        os_.append(s)
+    return oe, op, os_
+
+
+# --------------------------------------------------------------------------------------
+# Matching + assembly (paf.py:500-1149)
+# --------------------------------------------------------------------------------------
+
+
+def toposort_edges(edges: Sequence[Tuple[int, int]]) -> Tuple[int, ...]:
+    """paf.py:890-912 without networkx: root = first node of a topological order
+    (networkx's generator yields zero-in-degree nodes in insertion order, so the first is
+    the first-inserted node with in-degree 0), then BFS edge order from it with neighbours
+    in insertion order."""
+    order: List[int] = []
+    adj: Dict[int, List[int]] = {}
+    indeg: Dict[int, int] = {}
+    seen_edges = set()
+    for s, d in edges:
+        for n in (s, d):
+            if n not in adj:
+                adj[n] = []
+                indeg[n] = 0
+                order.append(n)
+        if (s, d) not in seen_edges:
+            seen_edges.add((s, d))
+            adj[s].append(d)
+            indeg[d] += 1
+    if not order:
+        return tuple()
+    roots = [n for n in order if indeg[n] == 0]
+    if not roots:
+        raise ValueError("skeleton graph has a cycle")
+    root = roots[0]
+    out = []
+    visited = {root}
+    q = deque([root])
+    edge_list = [tuple(e) for e in edges]
+    while q:
+        u = q.popleft()
+        for v in adj[u]:
+            if v not in visited:
+                visited.add(v)
+                out.append(edge_list.index((u, v)))
+                q.append(v)
+    return tuple(out)
+
+
+def match_candidates_sample(e_inds: torch.Tensor, pairs: torch.Tensor, scores: torch.Tensor, n_edges: int):
+    """paf.py:500-619: per edge Hungarian on -score; NaN -> +inf."""
+    e = e_inds.numpy()
+    pr = pairs.numpy()
+    sc = scores.numpy().astype(np.float32)
+    me, ms, md, msc = [], [], [], []
+    for k in range(n_edges):
+        sel = np.nonzero(e == k)[0]
+        pk = pr[sel]
+        sk = sc[sel]
+        su = np.unique(pk[:, 0]) if sel.size else np.zeros(0, dtype=np.int64)
+        du = np.unique(pk[:, 1]) if sel.size else np.zeros(0, dtype=np.int64)
+        cost = np.full((su.size, du.size), np.inf, dtype=np.float32)
+        if sel.size:
+            cost[np.searchsorted(su, pk[:, 0]), np.searchsorted(du, pk[:, 1])] = -sk
+        cost[np.isnan(cost)] = np.inf
+        r, c = linear_sum_assignment(cost)
+        me.append(np.full(r.size, k, dtype=np.int32))
+        ms.append(r.astype(np.int32))
+        md.append(c.astype(np.int32))
+        msc.append((-cost[r, c]).astype(np.float32))
+    cat = lambda xs, dt: np.concatenate(xs).astype(dt) if xs else np.zeros(0, dtype=dt)
+    return cat(me, np.int32), cat(ms, np.int32), cat(md, np.int32), cat(msc, np.float32)
+
+
+def assemble_instances(peaks: np.ndarray, vals: np.ndarray, chans: np.ndarray, me, ms, md, msc, n_nodes: int, edges, sorted_edge_inds, min_instance_peaks=0, min_line_scores: float = 0.25):
+    """paf.py:915-1038 (group_instances_sample) + :705-820 + :823-887."""
+    keep = msc >= min_line_scores
+    me, ms, md, msc = me[keep], ms[keep], md[keep], msc[keep]
+    node_peaks = [peaks[chans == i] for i in range(n_nodes)]
+    node_vals = [vals[chans == i] for i in range(n_nodes)]
+    conns = []  # (edge_ind, [(src, dst, score)])
+    for ei in sorted_edge_inds:
+        sel = me == ei
+        conns.append((ei, list(zip(ms[sel].tolist(), md[sel].tolist(), msc[sel]))))
+    assign: Dict[Tuple[int, int], int] = {}
+    for ei, lst in conns:
+        sn, dn = edges[ei]
+        for s, d, _ in lst:
+            a, b = (sn, s), (dn, d)
+            ia, ib = assign.get(a), assign.get(b)
+            if ia is None and ib is None:
+                nid = max(assign.values(), default=-1) + 1
+                assign[a] = nid
+                assign[b] = nid
+            elif ia is not None and ib is None:
+                assign[b] = ia
+            elif ia is not None and ib is not None:
+                assign[b] = ia
+                na = {p[0] for p, v in assign.items() if v == ia}
+                nb = {p[0] for p, v in assign.items() if v == ib}
+                if not (na & nb):
+                    for p in assign:
+                        if assign[p] == ib:
+                            assign[p] = ia
+            # src unassigned & dst assigned: no-op
+    if min_instance_peaks > 0:
+        mip = min_instance_peaks
+        if isinstance(mip, float):
+            mip = int(mip * n_nodes)
+        ids, counts = np.unique(list(assign.values()), return_counts=True)
+        cnt = dict(zip(ids.tolist(), counts.tolist()))
+        assign = {p: v for p, v in assign.items() if cnt[v] >= mip}
+    ids, inv = np.unique(list(assign.values()), return_inverse=True)
+    for p, j in zip(list(assign.keys()), inv):
+        assign[p] = int(j)
+    n_inst = len(ids)
+    inst_scores = np.zeros(n_inst, dtype=np.float32)
+    for ei, lst in conns:
+        sn, _ = edges[ei]
+        for s, _, score in lst:
+            j = assign.get((sn, s))
+            if j is not None:
+                inst_scores[j] += np.float32(score)
+    inst = np.full((n_inst, n_nodes, 2), np.nan, dtype=np.float32)
+    inst_vals = np.full((n_inst, n_nodes), np.nan, dtype=np.float32)
+    for (node, pi), j in assign.items():
+        inst[j, node] = node_peaks[node][pi]
+        inst_vals[j, node] = node_vals[node][pi]
+    return inst, inst_vals, inst_scores
+
+
+class PAFScorerRef:
+    """paf.py:1152-1532 value bundle (defaults at :1207-1213)."""
+
+    def __init__(self, part_names, edges, pafs_stride, max_edge_length_ratio=0.25, dist_penalty_weight=1.0, n_points=10, min_instance_peaks=0, min_line_scores=0.25):
+        self.part_names = list(part_names)
+        self.edges = [tuple(e) for e in edges]
+        self.pafs_stride = pafs_stride
+        self.max_edge_length_ratio = max_edge_length_ratio
+        self.dist_penalty_weight = dist_penalty_weight
+        self.n_points = n_points
+        self.min_instance_peaks = min_instance_peaks
+        self.min_line_scores = min_line_scores
+        self.edge_inds = [(self.part_names.index(s), self.part_names.index(d)) for s, d in self.edges]
+        self.n_nodes = len(self.part_names)
+        self.n_edges = len(self.edges)
+        self.sorted_edge_inds = toposort_edges(self.edge_inds)
+
+    def predict(self, pafs_bhwc, peaks, vals, chans):
+        e, p, s = score_paf_lines_batch(pafs_bhwc, peaks, chans, self.edge_inds, self.n_points, self.pafs_stride, self.max_edge_length_ratio, self.dist_penalty_weight, self.n_nodes)
+        out = []
+        for b in range(len(peaks)):
+            m = match_candidates_sample(e[b], p[b], s[b], self.n_edges)
+            out.append(assemble_instances(peaks[b].numpy(), vals[b].numpy(), chans[b].numpy(), *m, self.n_nodes, self.edge_inds, self.sorted_edge_inds, self.min_instance_peaks, self.min_line_scores))
+        return out, (e, p, s)
+
+
+def bottomup_postprocess(cms: torch.Tensor, pafs: torch.Tensor, scorer: PAFScorerRef, cms_stride: int, peak_threshold: float = 0.2, refinement: Optional[str] = "integral", patch: int = 5, max_instances: Optional[int] = None, input_scale: float = 1.0, eff_scale: Optional[torch.Tensor] = None, max_peaks_per_node: Optional[int] = None):
+    """layers/bottomup.py:95-236 + streaming.py:147-255 -> NaN-padded (B,I,N,2),(B,I,N),(B,I)."""
+    pts, vals, sb, sc = find_local_peaks(cms, peak_threshold, refinement, patch)
+    pts = pts * cms_stride
+    bsz, n_nodes = cms.shape[:2]
+    pk, pv, pc = [], [], []
+    for b in range(bsz):
+        m = sb == b
+        pk.append(pts[m])
+        pv.append(vals[m].float())
+        pc.append(sc[m])
+    skip = False
+    if max_peaks_per_node is not None:
+        for c in pc:
+            if c.numel() and int(torch.bincount(c.long(), minlength=n_nodes).max()) > max_peaks_per_node:
+                skip = True
+    if skip:
+        mi = max_instances or 1
+        return (np.full((bsz, mi, n_nodes, 2), np.nan, np.float32), np.full((bsz, mi, n_nodes), np.nan, np.float32), np.full((bsz, mi), np.nan, np.float32))
+    res, _ = scorer.predict(pafs.permute(0, 2, 3, 1), pk, pv, pc)
+    insts = [r[0] for r in res]
+    if input_scale != 1.0:
+        insts = [i / np.float32(input_scale) for i in insts]
+    if eff_scale is not None and not bool(torch.all(eff_scale == 1.0)):
+        insts = [i / np.float32(eff_scale[b]) for b, i in enumerate(insts)]
+    mi = max_instances or max((i.shape[0] for i in insts), default=0)
+    if mi == 0:
+        mi = 1
+    k = np.full((bsz, mi, n_nodes, 2), np.nan, np.float32)
+    v = np.full((bsz, mi, n_nodes), np.nan, np.float32)
+    s = np.full((bsz, mi), np.nan, np.float32)
+    for b in range(bsz):
+        ib, vb, sb_ = insts[b], res[b][1], res[b][2]
+        if max_instances is not None and ib.shape[0] > mi:
+            order = np.argsort(sb_)[::-1]
+            ib, vb, sb_ = ib[order], vb[order], sb_[order]
+        n = min(ib.shape[0], mi)
+        k[b, :n], v[b, :n], s[b, :n] = ib[:n], vb[:n], sb_[:n]
+    return k, v, s
+
+
+def single_instance_postprocess(cms: torch.Tensor, output_stride: int, peak_threshold: float = 0.2, refinement: Optional[str] = "integral", patch: int = 5, input_scale: float = 1.0, eff_scale: Optional[torch.Tensor] = None):
+    """layers/single_instance.py:72-108 + ops/coord.py:27-76."""
+    pts, vals = find_global_peaks(cms, peak_threshold, refinement, patch)
+    if output_stride != 1:
+        pts = pts * output_stride
+    if input_scale != 1.0:
+        pts = pts / input_scale
+    if eff_scale is not None and not bool(torch.all(eff_scale == 1.0)):
+        pts = pts / eff_scale.view(-1, 1, 1)
+    return pts.unsqueeze(1), vals.unsqueeze(1)
+
+
+# --------------------------------------------------------------------------------------
+# Synthetic rendered heads for measurement (data/confidence_maps.py:96-166,
+# data/edge_maps.py:15-220 semantics)
+# --------------------------------------------------------------------------------------
+
+
+def render_instances(size: int, n_nodes: int, n_inst: int, seed: int) -> np.ndarray:
+    rng = np.random.RandomState(seed)
+    centres = rng.uniform(150, size - 150, size=(n_inst, 1, 2))
+    pts = centres + rng.normal(0, 40, size=(n_inst, n_nodes, 2))
+    return np.clip(pts, 8, size - 9).astype(np.float32)
+
+
+def render_confmaps(pts: np.ndarray, size: int, stride: int, sigma: float) -> torch.Tensor:
+    """Per-node max over instances of unit Gaussians sampled on the stride grid."""
+    g = torch.arange(0, size, stride, dtype=torch.float32)
+    p = torch.from_numpy(pts)  # (I,N,2)
+    dx = (g[None, None, :] - p[:, :, 0:1]) ** 2  # (I,N,W)
+    dy = (g[None, None, :] - p[:, :, 1:2]) ** 2
+    cm = torch.exp(-(dy[:, :, :, None] + dx[:, :, None, :]) / (2 * sigma**2))
+    return cm.max(dim=0)[0]
+
+
+def render_pafs(pts: np.ndarray, edges, size: int, stride: int, sigma: float) -> torch.Tensor:
+    """Summed edge fields: unit vector weighted by exp(-d^2/(2 sigma^2)), d = point-segment distance."""
+    g = torch.arange(0, size, stride, dtype=torch.float32)
+    yy, xx = torch.meshgrid(g, g, indexing="ij")
+    grid = torch.stack([xx, yy], dim=-1)  # (H,W,2)
+    p = torch.from_numpy(pts)
+    out = torch.zeros(len(edges) * 2, g.numel(), g.numel())
+    for e, (s, d) in enumerate(edges):
+        for i in range(p.shape[0]):
+            a, b = p[i, s], p[i, d]
+            ab = b - a
+            l2 = float(ab @ ab) + 1e-12
+            t = ((grid - a) @ ab / l2).clamp(0, 1)
+            proj = a + t[..., None] * ab
+            dist2 = ((grid - proj) ** 2).sum(-1)
+            wgt = torch.exp(-dist2 / (2 * sigma**2))
+            u = ab / math.sqrt(l2)
+            out[2 * e] += wgt * u[0]
+            out[2 * e + 1] += wgt * u[1]
+    return out

@@ -1,0 +1,277 @@
+"""Generate golden input/output vectors by RUNNING THE REFERENCE in the build container.
+
+TEST INFRASTRUCTURE ONLY.  Usage (container only; needs /root/reference)::
+
+    python oracle/gen_golden.py
+
+Writes ``tests/golden/*.npz`` (data only: inputs + the reference's outputs).  No reference
+source travels.  The fixtures pin ``oracle/cpu_ref.py`` (CPU tests) and the HIP path (GPU
+tests).  Contents:
+
+* ``ckpt_bottomup.npz`` / ``ckpt_single_instance.npz``: the reference's own fixture
+  checkpoints (tests/assets/model_ckpts/minimal_instance_*) re-saved as named arrays, the
+  uint8 input frames stored in the reference's own goldens
+  (tests/inference/parity_golden/{bottomup,single_instance}.pkl), the head outputs of the
+  reference ``Model`` on them, and the golden keypoints/scores those pickles hold.
+* ``unet_tiny_*.npz``: random-weight tiny UNets (bilinear / transposed-conv / 13-node
+  bottom-up) run through the reference ``Model`` incl. selected intermediate activations.
+* ``peaks.npz``: tests/assets/inference/minimal_cms.pt + randomized maps (ties, negatives,
+  borders) with the outputs of the reference find_local_peaks / find_global_peaks.
+* ``paf.npz``: randomized PAF/peak sets with the outputs of the reference candidate
+  enumeration, line scoring, matching and grouping.
+"""
+
+from __future__ import annotations
+
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+import yaml
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+
+from oracle import ref_harness as rh  # noqa: E402
+
+rh.install()
+from sleap_nn.architectures.model import Model  # noqa: E402
+from sleap_nn.inference.ops import paf as rpaf  # noqa: E402
+from sleap_nn.inference.ops import peaks as rpeaks  # noqa: E402
+
+REF = rh.REFERENCE_ROOT
+OUT = os.path.join(ROOT, "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+torch.set_num_threads(4)
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def save(name, **arrs):
+    path = os.path.join(OUT, name)
+    np.savez_compressed(path, **arrs)
+    print(f"wrote {path}  ({os.path.getsize(path) / 1024:.0f} KiB)")
+
+
+def ragged(prefix, lst):
+    """Encode a ragged list of arrays as concatenation + offsets."""
+    lst = [np.asarray(a) for a in lst]
+    lens = np.array([a.shape[0] for a in lst], dtype=np.int64)
+    cat = np.concatenate(lst, axis=0) if lst else np.zeros(0)
+    return {prefix + "_cat": cat, prefix + "_len": lens}
+
+
+# ---------------------------------------------------------------------------------------
+def ckpt_fixture(kind: str, model_type: str, n_frames: int):
+    d = f"{REF}/tests/assets/model_ckpts/minimal_instance_{kind}"
+    cfg = yaml.safe_load(open(f"{d}/training_config.yaml"))
+    bb = cfg["model_config"]["backbone_config"]["unet"]
+    heads = cfg["model_config"]["head_configs"][model_type]
+    m = Model("unet", rh.attrdict(bb), rh.attrdict(heads), model_type).eval()
+    sd = rh.load_lightning_ckpt_state(f"{d}/best.ckpt")
+    m.load_state_dict(sd, strict=True)
+    gold = rh.load_pickle_tolerant(f"{REF}/tests/inference/parity_golden/{kind}.pkl")
+    b0 = gold[0]
+    img = b0["image"][:n_frames]
+    with torch.inference_mode():
+        x = torch.from_numpy(img).squeeze(1).float() / 255
+        out = m(x)
+    arrs = {"w/" + k: _np(v) for k, v in sd.items()}
+    arrs["image"] = img
+    arrs["eff_scale"] = b0["eff_scale"][:n_frames]
+    for k, v in out.items():
+        arrs["out/" + k] = _np(v)
+    arrs["config_json"] = np.array(json.dumps({"backbone": bb, "heads": heads, "model_type": model_type, "preprocessing": cfg["data_config"]["preprocessing"]}))
+    if kind == "bottomup":
+        arrs.update(ragged("gold_peaks", [np.asarray(a).reshape(-1, 4) for a in b0["pred_instance_peaks"][:n_frames]]))
+        arrs.update(ragged("gold_vals", [np.asarray(a) for a in b0["pred_peak_values"][:n_frames]]))
+        arrs.update(ragged("gold_scores", [np.asarray(a) for a in b0["instance_scores"][:n_frames]]))
+    else:
+        arrs["gold_peaks"] = b0["pred_instance_peaks"][:n_frames]
+        arrs["gold_vals"] = b0["pred_peak_values"][:n_frames]
+    save(f"ckpt_{kind}.npz", **arrs)
+
+
+# ---------------------------------------------------------------------------------------
+def tiny_unet(name, bb, heads, model_type, hw, batch, seed, in_dtype="uint8"):
+    torch.manual_seed(seed)
+    m = Model("unet", rh.attrdict(bb), rh.attrdict(heads), model_type).eval()
+    with torch.no_grad():
+        for p_name, p in m.named_parameters():
+            if p.dim() > 1:
+                torch.nn.init.xavier_uniform_(p)
+            else:
+                p.uniform_(-0.1, 0.1)
+    g = torch.Generator().manual_seed(seed + 1)
+    img = torch.randint(0, 256, (batch, 1, bb["in_channels"], hw[0], hw[1]), dtype=torch.uint8, generator=g)
+    acts = {}
+    hooks = []
+    for mod_name, mod in m.named_modules():
+        if isinstance(mod, (torch.nn.ReLU,)):
+            continue
+        if isinstance(mod, (torch.nn.Conv2d, torch.nn.ConvTranspose2d)) and "head_layers" not in mod_name:
+            hooks.append(mod.register_forward_hook(lambda mo, i, o, n=mod_name: acts.__setitem__(n, torch.relu(o).detach().clone())))
+    with torch.inference_mode():
+        out = m(img.squeeze(1).float() / 255)
+    for h in hooks:
+        h.remove()
+    arrs = {"w/" + k: _np(v) for k, v in m.state_dict().items()}
+    arrs["image"] = _np(img)
+    for k, v in out.items():
+        arrs["out/" + k] = _np(v)
+    keep = list(acts.keys())
+    pick = [keep[0], keep[1], keep[len(keep) // 2], keep[-1]]
+    for k in pick:
+        arrs["act/" + k] = _np(acts[k])
+    arrs["config_json"] = np.array(json.dumps({"backbone": bb, "heads": heads, "model_type": model_type}))
+    save(name, **arrs)
+
+
+# ---------------------------------------------------------------------------------------
+def peaks_fixture():
+    arrs = {}
+    cms = torch.load(f"{REF}/tests/assets/inference/minimal_cms.pt", map_location="cpu")
+    arrs["minimal_cms"] = _np(cms)
+    cases = {"minimal": cms.unsqueeze(0) if cms.dim() == 3 else cms}
+    g = torch.Generator().manual_seed(7)
+    # smooth random maps with several peaks, negatives and border maxima
+    r = torch.randn(3, 5, 37, 53, generator=g)
+    r = torch.nn.functional.avg_pool2d(r, 3, 1, 1) * 2.0
+    r[0, 0, 0, 0] = 3.0  # corner peak
+    r[1, 2, 36, 52] = 2.5  # opposite corner
+    r[2, 4, 0, 20] = 2.0  # top edge
+    cases["random"] = r
+    # plateau ties: equal neighbours must NOT be peaks (strict >)
+    t = torch.zeros(1, 2, 16, 16)
+    t[0, 0, 4, 4] = 1.0
+    t[0, 0, 4, 5] = 1.0
+    t[0, 0, 10, 10] = 0.9
+    t[0, 1, 8, 8] = 0.21
+    t[0, 1, 8, 3] = 0.2  # == threshold -> dropped (strict >)
+    cases["ties"] = t
+    # quantised map: many exact ties for the global argmax (x/y independence)
+    q = (torch.rand(2, 3, 20, 24, generator=g) * 4).floor() / 4
+    cases["quant"] = q
+    cases["allbelow"] = torch.full((1, 2, 8, 8), 0.05)
+    for cname, c in cases.items():
+        arrs[f"{cname}/cms"] = _np(c)
+        for ref in (None, "integral"):
+            tag = "none" if ref is None else "integral"
+            for thr in (0.2,) if cname != "random" else (0.2, 0.5):
+                p, v, s, ch = rpeaks.find_local_peaks(c, threshold=thr, refinement=ref, integral_patch_size=5)
+                key = f"{cname}/local_{tag}_{thr}"
+                arrs[key + "/pts"], arrs[key + "/vals"], arrs[key + "/sb"], arrs[key + "/sc"] = _np(p), _np(v), _np(s), _np(ch)
+                gp, gv = rpeaks.find_global_peaks(c, threshold=thr, refinement=ref, integral_patch_size=5)
+                key = f"{cname}/global_{tag}_{thr}"
+                arrs[key + "/pts"], arrs[key + "/vals"] = _np(gp), _np(gv)
+    # patch size 3 and 7 on the random case
+    for ps in (3, 7):
+        p, v, s, ch = rpeaks.find_local_peaks(cases["random"], threshold=0.2, refinement="integral", integral_patch_size=ps)
+        arrs[f"random/local_integral_p{ps}/pts"] = _np(p)
+    save("peaks.npz", **arrs)
+
+
+# ---------------------------------------------------------------------------------------
+def paf_fixture():
+    sys.path.insert(0, ROOT)
+    from oracle import cpu_ref  # only for the synthetic renderers (inputs, not expectations)
+
+    arrs = {}
+    specs = [
+        # name, n_nodes, edges, size, n_inst, cm stride, paf stride, seed
+        ("chain5", 5, [(i, i + 1) for i in range(4)], 256, 3, 2, 4, 11),
+        ("tree6", 6, [(0, 1), (0, 2), (2, 3), (2, 4), (4, 5)], 320, 4, 4, 8, 12),
+        ("chain13", 13, [(i, i + 1) for i in range(12)], 384, 5, 4, 8, 13),
+        ("rev4", 4, [(2, 3), (1, 2), (0, 1)], 256, 3, 2, 4, 14),  # edge list not in BFS order
+    ]
+    meta = {}
+    for name, n_nodes, edges, size, n_inst, cs, ps, seed in specs:
+        bsz = 2
+        cms, pafs = [], []
+        for b in range(bsz):
+            pts = cpu_ref.render_instances(size, n_nodes, n_inst, seed * 100 + b)
+            cms.append(cpu_ref.render_confmaps(pts, size, cs, 2.5 * cs / 2))
+            pafs.append(cpu_ref.render_pafs(pts, edges, size, ps, 12.0))
+        cms = torch.stack(cms)
+        pafs = torch.stack(pafs)
+        g = torch.Generator().manual_seed(seed)
+        cms = cms + 0.02 * torch.randn(cms.shape, generator=g)
+        pafs = pafs + 0.05 * torch.randn(pafs.shape, generator=g)
+        names = [f"n{i}" for i in range(n_nodes)]
+        scorer = rpaf.PAFScorer(part_names=names, edges=[(names[s], names[d]) for s, d in edges], pafs_stride=ps, min_instance_peaks=0)
+        p, v, sb, sc = rpeaks.find_local_peaks(cms, threshold=0.2, refinement="integral", integral_patch_size=5)
+        p = p * cs
+        pk = [p[sb == b] for b in range(bsz)]
+        pv = [v[sb == b] for b in range(bsz)]
+        pc = [sc[sb == b] for b in range(bsz)]
+        pafs_hwc = pafs.permute(0, 2, 3, 1)
+        e, ep, ls = scorer.score_paf_lines(pafs_hwc, pk, pc)
+        me, ms, md, ml = scorer.match_candidates(e, ep, ls)
+        inst, ivals, iscores = scorer.group_instances(pk, pv, pc, me, ms, md, ml)
+        arrs[f"{name}/cms"] = _np(cms)
+        arrs[f"{name}/pafs"] = _np(pafs)
+        arrs.update(ragged(f"{name}/peaks", [_np(x) for x in pk]))
+        arrs.update(ragged(f"{name}/vals", [_np(x) for x in pv]))
+        arrs.update(ragged(f"{name}/chans", [_np(x) for x in pc]))
+        arrs.update(ragged(f"{name}/edge_inds", [_np(x) for x in e]))
+        arrs.update(ragged(f"{name}/edge_peak_inds", [_np(x) for x in ep]))
+        arrs.update(ragged(f"{name}/line_scores", [_np(x) for x in ls]))
+        arrs.update(ragged(f"{name}/match_edge", [_np(x) for x in me]))
+        arrs.update(ragged(f"{name}/match_src", [_np(x) for x in ms]))
+        arrs.update(ragged(f"{name}/match_dst", [_np(x) for x in md]))
+        arrs.update(ragged(f"{name}/match_score", [_np(x) for x in ml]))
+        arrs.update(ragged(f"{name}/inst", [_np(x).reshape(x.shape[0], -1) for x in inst]))
+        arrs.update(ragged(f"{name}/inst_vals", [_np(x) for x in ivals]))
+        arrs.update(ragged(f"{name}/inst_scores", [_np(x) for x in iscores]))
+        arrs[f"{name}/sorted_edge_inds"] = np.array(scorer.sorted_edge_inds, dtype=np.int32)
+        meta[name] = {"n_nodes": n_nodes, "edges": edges, "cms_stride": cs, "pafs_stride": ps, "size": size}
+        print(name, "peaks", [x.shape[0] for x in pk], "cands", [x.shape[0] for x in e], "inst", [x.shape[0] for x in inst])
+    # line_subs KAT on awkward coordinates (.5 rounding, negatives, clipping)
+    peaks_s = torch.tensor([[0.0, 0.0], [5.0, 9.0], [3.0, 1.0], [-2.0, 30.0], [7.0, 7.0], [1.0, 3.0]])
+    epi = torch.tensor([[0, 1], [2, 3], [4, 5], [5, 4], [1, 1]])
+    ei = torch.tensor([0, 1, 0, 1, 0], dtype=torch.int32)
+    ls_ = rpaf.make_line_subs(peaks_s, epi, ei, n_line_points=10, pafs_stride=2, pafs_hw=(12, 6))
+    arrs["linesubs/peaks"], arrs["linesubs/epi"], arrs["linesubs/ei"], arrs["linesubs/out"] = _np(peaks_s), _np(epi), _np(ei), _np(ls_)
+    # toposort cases
+    topo = {}
+    for nm, edges in {"chain": [(0, 1), (1, 2), (2, 3)], "rev": [(2, 3), (1, 2), (0, 1)], "tree": [(0, 1), (0, 2), (2, 3), (2, 4), (4, 5)], "star": [(3, 0), (3, 1), (3, 2)], "forest": [(0, 1), (2, 3)], "mix": [(1, 2), (0, 1), (1, 3), (3, 4)]}.items():
+        et = [rpaf.EdgeType(s, d) for s, d in edges]
+        topo[nm] = {"edges": edges, "order": list(rpaf.toposort_edges(et))}
+    arrs["meta_json"] = np.array(json.dumps({"specs": meta, "toposort": topo}))
+    save("paf.npz", **arrs)
+
+
+if __name__ == "__main__":
+    ckpt_fixture("bottomup", "bottomup", n_frames=2)
+    ckpt_fixture("single_instance", "single_instance", n_frames=2)
+    tiny_unet(
+        "unet_tiny_interp.npz",
+        {"in_channels": 1, "kernel_size": 3, "filters": 8, "filters_rate": 2, "max_stride": 8, "stem_stride": None, "middle_block": True, "up_interpolate": True, "stacks": 1, "convs_per_block": 2, "output_stride": 2},
+        {"confmaps": {"part_names": ["a", "b", "c", "d", "e"], "sigma": 2.5, "output_stride": 2, "loss_weight": 1.0}},
+        "single_instance", (64, 96), 2, 101,
+    )
+    tiny_unet(
+        "unet_tiny_trans.npz",
+        {"in_channels": 1, "kernel_size": 3, "filters": 8, "filters_rate": 1.5, "max_stride": 8, "stem_stride": None, "middle_block": True, "up_interpolate": False, "stacks": 1, "convs_per_block": 2, "output_stride": 2},
+        {"confmaps": {"part_names": ["a", "b", "c"], "sigma": 2.5, "output_stride": 2, "loss_weight": 1.0}, "pafs": {"edges": [["a", "b"], ["b", "c"]], "sigma": 15, "output_stride": 4, "loss_weight": 1.0}},
+        "bottomup", (48, 80), 2, 102,
+    )
+    tiny_unet(
+        "unet_tiny_bu13.npz",
+        {"in_channels": 1, "kernel_size": 3, "filters": 4, "filters_rate": 2, "max_stride": 32, "stem_stride": None, "middle_block": True, "up_interpolate": True, "stacks": 1, "convs_per_block": 2, "output_stride": 4},
+        {"confmaps": {"part_names": [f"n{i}" for i in range(13)], "sigma": 2.5, "output_stride": 4, "loss_weight": 1.0}, "pafs": {"edges": [[f"n{i}", f"n{i+1}"] for i in range(12)], "sigma": 75, "output_stride": 8, "loss_weight": 1.0}},
+        "bottomup", (64, 96), 1, 103,
+    )
+    tiny_unet(
+        "unet_tiny_rgb.npz",
+        {"in_channels": 3, "kernel_size": 3, "filters": 8, "filters_rate": 2, "max_stride": 4, "stem_stride": None, "middle_block": True, "up_interpolate": True, "stacks": 1, "convs_per_block": 2, "output_stride": 1},
+        {"confmaps": {"part_names": ["a", "b"], "sigma": 2.5, "output_stride": 1, "loss_weight": 1.0}},
+        "single_instance", (32, 40), 1, 104,
+    )
+    peaks_fixture()
+    paf_fixture()
