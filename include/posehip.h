@@ -1,0 +1,192 @@
+/*
+ * posehip.h -- C ABI of libposehip.so, the MI355X (gfx950) hot path that replaces the
+ * ATen/SciPy arithmetic behind sleap-nn's ModelBackend / inference ops seam.
+ *
+ * Every entry point is `extern "C"`, takes plain pointers + sizes + a hipStream_t passed
+ * as void*, returns 0 on success or a negative PH_E_* code (never throws); the text of
+ * the last error of the calling thread is available from ph_last_error().
+ * Device pointers ("dev") must be HIP device memory of the current device; "host"
+ * pointers are ordinary host memory.  The caller owns all inputs and outputs.
+ *
+ * Which reference interface each group replaces (paths relative to talmolab/sleap-nn):
+ *   ph_model_*          sleap_nn/inference/layers/backends/torch_backend.py:113-153
+ *                       (TorchBackend.__call__) -> training/lightning_modules.py:1840-1848
+ *                       (squeeze + normalize_on_gpu) -> architectures/model.py:237-261
+ *                       (Model.forward) -> architectures/unet.py:260-299 and
+ *                       encoder_decoder.py:130-141,318-336,522-558,705-730.
+ *   ph_local_peaks      inference/ops/peaks.py:184-259 (find_local_peaks[_rough]) with
+ *                       ops/crops.py:31-124 + data/instance_cropping.py:129-171.
+ *   ph_global_peaks     inference/ops/peaks.py:89-181 (find_global_peaks[_rough]).
+ *   ph_paf_score        inference/ops/paf.py:84-497 (get_connection_candidates,
+ *                       make_line_subs, get_paf_lines, score_paf_lines[_batch]) and
+ *                       inference/utils.py:29-130 (interp1d).
+ *   ph_lsap             scipy.optimize.linear_sum_assignment as called at
+ *                       inference/ops/paf.py:589.
+ *   ph_group_batch      inference/ops/paf.py:500-1149 (match_candidates_*,
+ *                       assign_connections_to_instances, make_predicted_instances,
+ *                       group_instances_*) + inference/streaming.py:147-255 padding.
+ *   ph_toposort_edges   inference/ops/paf.py:890-912.
+ */
+#ifndef POSEHIP_H
+#define POSEHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PH_VERSION 100
+
+/* error codes */
+#define PH_OK 0
+#define PH_E_INVALID -1     /* bad argument / unsupported configuration            */
+#define PH_E_HIP -2         /* a HIP runtime call failed                           */
+#define PH_E_CAPACITY -3    /* caller-provided output capacity too small           */
+#define PH_E_INFEASIBLE -4  /* assignment problem has no finite-cost solution      */
+#define PH_E_WORKSPACE -5   /* workspace too small                                 */
+
+const char* ph_last_error(void);
+int ph_version(void);
+
+/* ------------------------------------------------------------------------------------
+ * Network (encoder-decoder forward).  The host describes the network as a flat program of
+ * ops over numbered activation slots; weights are handed over in the reference's own
+ * state_dict layout (Conv2d: OIHW, ConvTranspose2d: IOHW, fp32, host memory) and are
+ * re-packed for the MFMA kernels at creation.
+ * ---------------------------------------------------------------------------------- */
+
+enum ph_op_kind {
+  PH_OP_INPUT_CONV = 1, /* uint8|float NCHW image -> /255 -> conv kxk "same" + bias + ReLU -> NHWC slot */
+  PH_OP_CONV = 2,       /* conv kxk "same" over concat(src0, src1) + bias (+ReLU) -> NHWC slot          */
+  PH_OP_POOL = 3,       /* 2x2/2 max pool, zero pad bottom/right when odd (architectures/common.py)     */
+  PH_OP_UPSAMPLE = 4,   /* bilinear x2, align_corners=False (encoder_decoder.py:431-435)                */
+  PH_OP_CONVT = 5,      /* ConvTranspose2d(k3,s2,p1,op1) + bias (+ReLU) (encoder_decoder.py:439-461)    */
+  PH_OP_HEAD = 6        /* 1x1 conv + bias (+sigmoid) -> NCHW fp32 output #out_index (heads.py:58-67)   */
+};
+
+#define PH_FLAG_RELU 1
+#define PH_FLAG_SIGMOID 2
+
+typedef struct ph_op_desc {
+  int32_t kind;      /* enum ph_op_kind                                              */
+  int32_t src0;      /* input slot (-1 = the network input image)                    */
+  int32_t src1;      /* second concat source slot or -1                              */
+  int32_t dst;       /* output slot (PH_OP_HEAD: ignored)                            */
+  int32_t cin0;      /* logical channels of src0                                     */
+  int32_t cin1;      /* logical channels of src1 (0 if none)                         */
+  int32_t cout;      /* logical output channels                                      */
+  int32_t ksize;     /* kernel size (PH_OP_CONV / INPUT_CONV: odd, <= 7)             */
+  int32_t flags;     /* PH_FLAG_*                                                    */
+  int32_t weight;    /* index into the weights[] array of ph_model_create, or -1     */
+  int32_t bias;      /* index into the weights[] array, or -1                        */
+  int32_t out_index; /* PH_OP_HEAD: which output pointer receives the result         */
+} ph_op_desc;
+
+typedef struct ph_model ph_model;
+
+/* Create a model on the current HIP device.  `weights[i]` are host fp32 arrays (layouts
+ * above); they are copied, the caller may free them afterwards.  Returns NULL on error. */
+ph_model* ph_model_create(const ph_op_desc* ops, int32_t n_ops, const float* const* weights,
+                          const int64_t* weight_numel, int32_t n_weights, int32_t n_slots,
+                          int32_t n_outputs);
+void ph_model_destroy(ph_model* m);
+
+/* Bytes of device workspace ph_model_forward needs for a (B, C, H, W) input. */
+int64_t ph_model_workspace_bytes(const ph_model* m, int32_t batch, int32_t height, int32_t width);
+
+/* Shape of output #i for an (H, W) input: writes channels/height/width. */
+int ph_model_output_shape(const ph_model* m, int32_t out_index, int32_t height, int32_t width,
+                          int32_t* c, int32_t* h, int32_t* w);
+
+/* Forward.  input_dev: (B, C, H, W) NCHW, dtype 0 = uint8 (divided by 255),
+ * 1 = float32 already in [0,1], 2 = float32 in [0,255] (divided by 255)
+ * (data/normalization.py:7-35; the data-dependent max()>1 test is resolved by the caller).
+ * out_dev[i]: (B, c_i, h_i, w_i) NCHW fp32.  Everything is enqueued on `stream`. */
+int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32_t batch,
+                     int32_t in_channels, int32_t height, int32_t width, void* workspace_dev,
+                     int64_t workspace_bytes, float* const* out_dev, void* stream);
+
+/* Debug/parity helper: copy activation slot `slot` of the last forward (NHWC, padded
+ * channels) into an NCHW fp32 device buffer of the logical channel count. */
+int ph_model_read_slot(ph_model* m, int32_t slot, float* out_dev, int64_t out_numel, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Peak finding
+ * ---------------------------------------------------------------------------------- */
+
+/* Local maxima (strict > over the 8 neighbours, -inf outside) above `threshold`, emitted in
+ * the reference's (sample, y, x, channel) order, optionally refined by the integral
+ * (first-moment) offset over a patch x patch zero-padded window (refine != 0).
+ * cms_dev: (B, C, H, W) fp32.  Outputs (device, capacity `cap` rows):
+ *   out_xy (cap,2) f32 [x,y]; out_val (cap) f32; out_sample (cap) i32; out_channel (cap) i32
+ *   out_count: device int32[2 + 2B]: [0] = total peaks found (may exceed cap: then only the
+ *   first cap rows are valid and the caller should retry), [1+b] = peaks of sample b,
+ *   [1+B+b] = exclusive offset of sample b (b = 0..B, last entry = total).
+ * scratch_dev: >= 4*(B*H + 1 + B) bytes. */
+int ph_local_peaks(const float* cms_dev, int32_t B, int32_t C, int32_t H, int32_t W,
+                   float threshold, int32_t refine, int32_t patch, float* out_xy, float* out_val,
+                   int32_t* out_sample, int32_t* out_channel, int32_t* out_count, int32_t cap,
+                   void* scratch_dev, int64_t scratch_bytes, void* stream);
+
+/* Global peak per (sample, channel): value = max; x = first column containing the max,
+ * y = first row containing the max (independent, as the reference); below `threshold`
+ * -> NaN coords and value 0.  out_xy (B,C,2), out_val (B,C). */
+int ph_global_peaks(const float* cms_dev, int32_t B, int32_t C, int32_t H, int32_t W,
+                    float threshold, int32_t refine, int32_t patch, float* out_xy, float* out_val,
+                    void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * PAF line-integral scoring (device)
+ * ---------------------------------------------------------------------------------- */
+
+/* pafs_dev: (B, 2E, H, W) NCHW fp32 (the head output; the reference's permute to
+ * (B,H,W,2E) is folded into the indexing).  peaks are the ph_local_peaks outputs ALREADY
+ * multiplied by the confmap stride (image-space x,y), grouped by sample:
+ * peak_offsets_dev int32[B+1].  edges_dev int32[E*2] (src node, dst node).
+ * t_dev: float[n_points] = torch.linspace(0,1,n_points) values.
+ * Outputs (device): cand_edge (cap) i32, cand_src/cand_dst (cap) i32 = peak indices LOCAL
+ * to the sample, cand_score (cap) f32, cand_offsets int32[B+1] (+ total in [B]).
+ * Candidates of one sample are ordered by edge, then src peak, then dst peak (ascending).
+ * scratch_dev: >= 4*(n_peaks_total + B*(n_nodes+1) + B*(E+1) + 16) bytes. */
+int ph_paf_score(const float* pafs_dev, int32_t B, int32_t E2, int32_t H, int32_t W,
+                 const float* peaks_xy_dev, const int32_t* peak_channel_dev,
+                 const int32_t* peak_offsets_dev, int32_t n_peaks_total, int32_t n_nodes,
+                 const int32_t* edges_dev, int32_t n_edges, const float* t_dev, int32_t n_points,
+                 int32_t pafs_stride, float max_edge_length, float dist_penalty_weight,
+                 int32_t* cand_edge, int32_t* cand_src, int32_t* cand_dst, float* cand_score,
+                 int32_t* cand_offsets, int32_t cap, void* scratch_dev, int64_t scratch_bytes,
+                 void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Host (CPU) stage: assignment + instance assembly.  Pure host code, no HIP calls.
+ * ---------------------------------------------------------------------------------- */
+
+/* Rectangular linear sum assignment (minimise), row-major cost (nr x nc) doubles; +inf =
+ * forbidden.  Writes min(nr,nc) pairs sorted by row.  Tie behaviour follows SciPy's
+ * rectangular_lsap (shortest augmenting path).  PH_E_INFEASIBLE if no finite solution. */
+int ph_lsap(const double* cost, int32_t nr, int32_t nc, int32_t* rows, int32_t* cols);
+
+/* BFS edge order from the topological root; out_order has room for n_edges entries;
+ * returns the number of entries written (>=0) or a negative error. */
+int ph_toposort_edges(const int32_t* edges, int32_t n_edges, int32_t* out_order);
+
+/* Match + assemble a batch (all host arrays).  Inputs mirror ScoredBatch
+ * (inference/streaming.py:43-112) in flattened form.  Outputs are NaN-padded:
+ *   out_kpts (B, max_inst, n_nodes, 2), out_vals (B, max_inst, n_nodes), out_scores (B, max_inst),
+ *   out_n_inst int32[B] = instances found per sample before truncation.
+ * If an instance count exceeds max_inst: truncate_by_score != 0 keeps the top max_inst by
+ * instance score (numpy argsort()[::-1] order), else keeps the first max_inst. */
+int ph_group_batch(int32_t B, int32_t n_nodes, const int32_t* edges, int32_t n_edges,
+                   const float* peaks_xy, const float* peak_vals, const int32_t* peak_channel,
+                   const int32_t* peak_offsets, const int32_t* cand_edge, const int32_t* cand_src,
+                   const int32_t* cand_dst, const float* cand_score, const int32_t* cand_offsets,
+                   float min_line_score, double min_instance_peaks, int32_t min_instance_peaks_is_fraction,
+                   int32_t max_inst, int32_t truncate_by_score, float* out_kpts, float* out_vals,
+                   float* out_scores, int32_t* out_n_inst);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* POSEHIP_H */

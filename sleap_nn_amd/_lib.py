@@ -1,0 +1,88 @@
+"""ctypes binding of libposehip.so (the C ABI declared in include/posehip.h).
+
+The HIP library is the product: if it cannot be loaded this module raises -- there is no
+CPU or PyTorch fallback anywhere in ``sleap_nn_amd``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libposehip.so")
+
+PH_OK = 0
+PH_E_INVALID, PH_E_HIP, PH_E_CAPACITY, PH_E_INFEASIBLE, PH_E_WORKSPACE = -1, -2, -3, -4, -5
+
+OP_INPUT_CONV, OP_CONV, OP_POOL, OP_UPSAMPLE, OP_CONVT, OP_HEAD = 1, 2, 3, 4, 5, 6
+FLAG_RELU, FLAG_SIGMOID = 1, 2
+
+
+class OpDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("kind", "src0", "src1", "dst", "cin0", "cin1", "cout", "ksize", "flags", "weight", "bias", "out_index")]
+
+
+class PosehipError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"libposehip error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+_vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+
+# name -> (restype, argtypes); mirrors include/posehip.h one to one
+SIGNATURES = {
+    "ph_last_error": (C.c_char_p, []),
+    "ph_version": (C.c_int, []),
+    "ph_model_create": (_vp, [C.POINTER(OpDesc), _i32, C.POINTER(_vp), C.POINTER(_i64), _i32, _i32, _i32]),
+    "ph_model_destroy": (None, [_vp]),
+    "ph_model_workspace_bytes": (_i64, [_vp, _i32, _i32, _i32]),
+    "ph_model_output_shape": (C.c_int, [_vp, _i32, _i32, _i32, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)]),
+    "ph_model_forward": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _i64, C.POINTER(_vp), _vp]),
+    "ph_model_read_slot": (C.c_int, [_vp, _i32, _vp, _i64, _vp]),
+    "ph_local_peaks": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _f32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i64, _vp]),
+    "ph_global_peaks": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _f32, _i32, _i32, _vp, _vp, _vp]),
+    "ph_paf_score": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _vp, _i32, _vp, _i32, _i32, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i64, _vp]),
+    "ph_lsap": (C.c_int, [_vp, _i32, _i32, _vp, _vp]),
+    "ph_toposort_edges": (C.c_int, [_vp, _i32, _vp]),
+    "ph_group_batch": (C.c_int, [_i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, C.c_double, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
+}
+
+
+def lib():
+    """Load (once) and return the bound library; raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -m sleap_nn_amd.build` "
+            "(hipcc --offload-arch=gfx950). sleap_nn_amd has no CPU fallback."
+        )
+    l = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(l, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = l
+    return l
+
+
+def check(rc: int) -> int:
+    if rc is not None and rc < 0:
+        raise PosehipError(int(rc), lib().ph_last_error().decode("utf-8", "replace"))
+    return rc
+
+
+def current_stream_ptr():
+    import torch
+
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_cuda(t, name="tensor"):
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must live on the GPU (got {t.device}); sleap_nn_amd runs on MI355X only")
+    return t

@@ -1,0 +1,206 @@
+"""``Model`` = backbone + heads, executed by libposehip on an MI355X.
+
+Drop-in for ``sleap_nn.architectures.model.Model`` (architectures/model.py:157-261): same
+constructor signature, same ``state_dict`` key names (so reference checkpoints load), same
+``forward(x) -> {head class name: (B, C, H/s, W/s) fp32 NCHW tensor}``.  There are no torch
+modules underneath: weights are re-packed once and the forward is one C-ABI call that
+enqueues hand-written gfx950 kernels on the current torch stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional
+
+import torch
+
+from sleap_nn_amd import _lib as L
+from sleap_nn_amd.architectures.heads import ClassMapsHead, Head, get_head
+from sleap_nn_amd.architectures.unet import OpSpec, UNet
+from sleap_nn_amd.utils import cfg_get, cfg_keys
+
+
+def get_backbone(backbone: str, backbone_config):
+    """architectures/model.py:36-67.  Only ``unet`` is built natively so far."""
+    if backbone == "unet":
+        return UNet.from_config(backbone_config)
+    if backbone in ("convnext", "swint", "pretrained"):
+        raise NotImplementedError(f"backbone '{backbone}' is not implemented on the MI355X path yet")
+    raise KeyError(f"Unsupported backbone: {backbone}. Supported backbones are: unet")
+
+
+class Model:
+    """Backbone + 1x1 heads (architectures/model.py:157-261)."""
+
+    def __init__(self, backbone_type: str, backbone_config, head_configs, model_type: str) -> None:
+        self.backbone_type = backbone_type
+        self.backbone_config = backbone_config
+        self.head_configs = head_configs
+        self.model_type = model_type
+        self.heads: List[Head] = get_head(model_type, head_configs)
+        self.backbone: UNet = get_backbone(backbone_type, backbone_config)
+        self.in_channels = int(cfg_get(backbone_config, "in_channels", 1))
+
+        self.ops: List[OpSpec] = list(self.backbone.ops)
+        self.param_shapes = dict(self.backbone.param_shapes)
+        for i, head in enumerate(self.heads):
+            s2f = self.backbone.decoder_stride_to_filters
+            if head.output_stride not in self.backbone.decoder_slot_of_stride:
+                if not self.backbone.decoder_slot_of_stride and head.output_stride in s2f:
+                    src = self.backbone.middle_slot
+                else:
+                    raise ValueError(
+                        f"Head '{head.name}' needs a feature map at output_stride {head.output_stride}, "
+                        f"backbone produces strides {sorted(self.backbone.decoder_slot_of_stride)}"
+                    )
+            else:
+                src = self.backbone.decoder_slot_of_stride[head.output_stride]
+            cin = s2f[head.output_stride]
+            name = f"head_layers.{i}.{head.name}.0"
+            self.param_shapes[name + ".weight"] = (head.channels, cin, 1, 1)
+            self.param_shapes[name + ".bias"] = (head.channels,)
+            flags = L.FLAG_SIGMOID if isinstance(head, ClassMapsHead) else 0
+            self.ops.append(OpSpec(L.OP_HEAD, src, -1, -1, cin, 0, head.channels, 1, flags, name + ".weight", name + ".bias", out_index=i, label=name))
+        self._state: Dict[str, torch.Tensor] = {k: torch.zeros(v, dtype=torch.float32) for k, v in self.param_shapes.items()}
+        self._handle = None
+        self._handle_device: Optional[torch.device] = None
+        self._workspace: Optional[torch.Tensor] = None
+        self.device = torch.device("cpu")
+
+    @classmethod
+    def from_config(cls, backbone_type, backbone_config, head_configs, model_type) -> "Model":
+        return cls(backbone_type, backbone_config, head_configs, model_type)
+
+    # -- parameters -----------------------------------------------------------------------
+    def state_dict(self) -> Dict[str, torch.Tensor]:
+        return dict(self._state)
+
+    def load_state_dict(self, state_dict: Dict[str, torch.Tensor], strict: bool = True):
+        """Accepts ``Model`` keys or LightningModule keys (``model.`` prefix, loaders.py:144-176)."""
+        sd = {}
+        for k, v in state_dict.items():
+            k = k[len("model.") :] if k.startswith("model.") else k
+            sd[k] = v
+        missing = [k for k in self.param_shapes if k not in sd]
+        unexpected = [k for k in sd if k not in self.param_shapes]
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"Error(s) in loading state_dict: missing {missing}, unexpected {unexpected}")
+        for k, shape in self.param_shapes.items():
+            if k in sd:
+                t = torch.as_tensor(sd[k]).detach().to("cpu", torch.float32).contiguous()
+                if tuple(t.shape) != tuple(shape):
+                    raise RuntimeError(f"size mismatch for {k}: checkpoint {tuple(t.shape)} vs model {tuple(shape)}")
+                self._state[k] = t
+        self._release()
+        return missing, unexpected
+
+    def num_parameters(self) -> int:
+        return sum(int(torch.tensor(s).prod()) for s in self.param_shapes.values())
+
+    def eval(self) -> "Model":
+        return self
+
+    def to(self, device) -> "Model":
+        self.device = torch.device(device)
+        return self
+
+    # -- native handle ----------------------------------------------------------------------
+    def _release(self) -> None:
+        if self._handle is not None:
+            L.lib().ph_model_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self._release()
+        except Exception:
+            pass
+
+    def _compile(self, device: torch.device) -> None:
+        lib = L.lib()
+        keys = list(self.param_shapes.keys())
+        index = {k: i for i, k in enumerate(keys)}
+        descs = (L.OpDesc * len(self.ops))()
+        for i, op in enumerate(self.ops):
+            d = descs[i]
+            d.kind, d.src0, d.src1, d.dst = op.kind, op.src0, op.src1, op.dst
+            d.cin0, d.cin1, d.cout, d.ksize, d.flags = op.cin0, op.cin1, op.cout, op.ksize, op.flags
+            d.weight = index[op.weight] if op.weight else -1
+            d.bias = index[op.bias] if op.bias else -1
+            d.out_index = op.out_index
+        tensors = [self._state[k].contiguous() for k in keys]
+        ptrs = (C.c_void_p * len(keys))(*[t.data_ptr() for t in tensors])
+        numel = (C.c_int64 * len(keys))(*[t.numel() for t in tensors])
+        with torch.cuda.device(device):
+            h = lib.ph_model_create(descs, len(self.ops), ptrs, numel, len(keys), self.backbone.n_slots, len(self.heads))
+        if not h:
+            raise L.PosehipError(L.PH_E_INVALID, lib.ph_last_error().decode())
+        self._handle = C.c_void_p(h)
+        self._handle_device = device
+
+    def _ensure(self, device: torch.device) -> None:
+        if self._handle is None or self._handle_device != device:
+            self._release()
+            self._compile(device)
+
+    def output_shapes(self, height: int, width: int):
+        lib = L.lib()
+        out = []
+        for i in range(len(self.heads)):
+            c, h, w = C.c_int32(), C.c_int32(), C.c_int32()
+            L.check(lib.ph_model_output_shape(self._handle, i, height, width, C.byref(c), C.byref(h), C.byref(w)))
+            out.append((c.value, h.value, w.value))
+        return out
+
+    # -- forward --------------------------------------------------------------------------
+    def forward(self, x: torch.Tensor, in_dtype: Optional[int] = None) -> Dict[str, torch.Tensor]:
+        """``x``: (B, C, H, W) on the GPU.  uint8 is divided by 255 inside the first kernel;
+        float input is taken as already normalised unless ``in_dtype == 2`` (0..255 floats)."""
+        if x.dim() != 4:
+            raise ValueError(f"expected (B, C, H, W), got {tuple(x.shape)}")
+        if not x.is_cuda:
+            dev = self.device if self.device.type == "cuda" else torch.device("cuda", torch.cuda.current_device())
+            x = x.to(dev, non_blocking=True)
+        device = x.device
+        if x.dtype == torch.uint8:
+            code = 0
+        else:
+            x = x.to(torch.float32)
+            code = 1 if in_dtype is None else in_dtype
+        if x.shape[1] != self.in_channels:
+            # architectures/model.py:239-245 (gray <-> rgb); rare path, done with torch plumbing
+            xf = x.float() / 255.0 if code in (0, 2) else x
+            if x.shape[1] == 1:
+                xf = xf.repeat(1, 3, 1, 1)
+            elif x.shape[1] == 3:
+                r, g, b = xf.unbind(dim=1)
+                xf = (0.2989 * r + 0.587 * g + 0.114 * b).unsqueeze(1)
+            x, code = xf, 1
+        x = x.contiguous()
+        B, Cin, H, W = x.shape
+        self._ensure(device)
+        lib = L.lib()
+        with torch.cuda.device(device):
+            need = L.check(lib.ph_model_workspace_bytes(self._handle, B, H, W))
+            if self._workspace is None or self._workspace.numel() < need or self._workspace.device != device:
+                self._workspace = None
+                self._workspace = torch.empty(int(need), dtype=torch.uint8, device=device)
+            outs = [torch.empty((B, c, h, w), dtype=torch.float32, device=device) for (c, h, w) in self.output_shapes(H, W)]
+            optrs = (C.c_void_p * len(outs))(*[o.data_ptr() for o in outs])
+            L.check(
+                lib.ph_model_forward(
+                    self._handle, C.c_void_p(x.data_ptr()), code, B, Cin, H, W, C.c_void_p(self._workspace.data_ptr()),
+                    self._workspace.numel(), optrs, L.current_stream_ptr(),
+                )
+            )
+        return {head.name: o for head, o in zip(self.heads, outs)}
+
+    __call__ = forward
+
+    def read_activation(self, conv_name: str, batch: int, height_width) -> torch.Tensor:
+        """Debug/parity: NCHW copy of the activation a named conv produced in the last forward."""
+        slot = self.backbone.labels[conv_name]
+        op = next(o for o in self.ops if o.dst == slot)
+        h, w = height_width
+        out = torch.empty((batch, op.cout, h, w), dtype=torch.float32, device=self._handle_device)
+        L.check(L.lib().ph_model_read_slot(self._handle, slot, C.c_void_p(out.data_ptr()), out.numel(), L.current_stream_ptr()))
+        return out

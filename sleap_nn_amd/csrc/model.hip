@@ -1,0 +1,381 @@
+// Host runtime of the network path: op program, weight re-packing, workspace planning and
+// the forward launch sequence (C ABI: ph_model_*).  Replaces TorchBackend.__call__ ->
+// LightningModule.forward -> Model.forward -> UNet.forward of the reference
+// (sleap_nn/inference/layers/backends/torch_backend.py:113-153,
+//  training/lightning_modules.py:1840-1848, architectures/model.py:237-261,
+//  architectures/unet.py:260-299).
+#include <cmath>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+#include "common.h"
+#include "net_kernels.h"
+
+namespace ph {
+
+static thread_local std::string g_err;
+
+void set_error(const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+}
+
+struct PackedOp {
+  ph_op_desc d;
+  float* w_dev = nullptr;
+  float* b_dev = nullptr;
+  int bn = 0;
+};
+
+struct SlotShape {
+  int c = 0, cp = 0, h = 0, w = 0;
+  int64_t offset = -1;
+};
+
+struct Plan {
+  std::vector<SlotShape> slots;
+  int64_t tmp_offset = 0, tmp_bytes = 0, total = 0;
+};
+
+}  // namespace ph
+
+struct ph_model {
+  std::vector<ph::PackedOp> ops;
+  int n_slots = 0, n_outputs = 0;
+  std::vector<void*> allocs;
+  // last forward (for ph_model_read_slot)
+  ph::Plan last_plan;
+  char* last_ws = nullptr;
+  int last_batch = 0;
+};
+
+namespace ph {
+
+static int upload(ph_model* m, const std::vector<float>& host, float** dev) {
+  void* p = nullptr;
+  PH_HIP_CHECK(hipMalloc(&p, std::max<size_t>(host.size(), 4) * sizeof(float)));
+  m->allocs.push_back(p);
+  PH_HIP_CHECK(hipMemcpy(p, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
+  *dev = static_cast<float*>(p);
+  return PH_OK;
+}
+
+// Conv2d OIHW (cout, cin0+cin1, 3, 3) or ConvTranspose2d IOHW (cin0, cout, 3, 3) ->
+// [n_tile][chunk][tap][bn][16] with channel/row padding zeros.
+static void pack_conv(const float* w, bool transposed, int cin0, int cin1, int cout, int bn, std::vector<float>& out) {
+  const int c0p = pad16(cin0), c1p = cin1 > 0 ? pad16(cin1) : 0;
+  const int coutp = pad16(cout);
+  const int ntiles = (coutp + bn - 1) / bn;
+  const int ch0 = c0p / 16, ch1 = c1p / 16, nch = ch0 + ch1;
+  const int cin = cin0 + cin1;
+  out.assign((size_t)ntiles * nch * 9 * bn * 16, 0.f);
+  for (int nt = 0; nt < ntiles; ++nt)
+    for (int ch = 0; ch < nch; ++ch)
+      for (int tap = 0; tap < 9; ++tap) {
+        const int ky = tap / 3, kx = tap % 3;
+        for (int n = 0; n < bn; ++n) {
+          const int co = nt * bn + n;
+          if (co >= cout) continue;
+          for (int kc = 0; kc < 16; ++kc) {
+            int ci;
+            if (ch < ch0) {
+              const int c = ch * 16 + kc;
+              if (c >= cin0) continue;
+              ci = c;
+            } else {
+              const int c = (ch - ch0) * 16 + kc;
+              if (c >= cin1) continue;
+              ci = cin0 + c;
+            }
+            float v;
+            if (!transposed)
+              v = w[(((size_t)co * cin + ci) * 3 + ky) * 3 + kx];
+            else  // flipped, in/out swapped: Wc[co][ci][ky][kx] = Wt[ci][co][2-ky][2-kx]
+              v = w[(((size_t)ci * cout + co) * 3 + (2 - ky)) * 3 + (2 - kx)];
+            out[((((size_t)nt * nch + ch) * 9 + tap) * bn + n) * 16 + kc] = v;
+          }
+        }
+      }
+}
+
+static int choose_bn(int coutp) { return coutp >= 64 ? 64 : 32; }
+
+static int build_plan(const ph_model* m, int B, int H, int W, Plan& plan) {
+  plan.slots.assign(m->n_slots, SlotShape());
+  int64_t off = 0, tmp = 0;
+  for (const PackedOp& op : m->ops) {
+    const ph_op_desc& d = op.d;
+    int h, w;
+    if (d.src0 < 0) {
+      h = H;
+      w = W;
+    } else {
+      PH_REQUIRE(d.src0 < m->n_slots && plan.slots[d.src0].offset >= 0, "op reads slot %d before it is written", d.src0);
+      h = plan.slots[d.src0].h;
+      w = plan.slots[d.src0].w;
+    }
+    if (d.kind == PH_OP_HEAD) continue;
+    int oh = h, ow = w;
+    if (d.kind == PH_OP_POOL) {
+      oh = (h + 1) / 2;
+      ow = (w + 1) / 2;
+    } else if (d.kind == PH_OP_UPSAMPLE || d.kind == PH_OP_CONVT) {
+      oh = 2 * h;
+      ow = 2 * w;
+    }
+    if (d.kind == PH_OP_CONV && d.src1 >= 0) {
+      const SlotShape& s1 = plan.slots[d.src1];
+      PH_REQUIRE(s1.offset >= 0, "op reads slot %d before it is written", d.src1);
+      PH_REQUIRE(s1.h == h && s1.w == w,
+                 "concat sources differ in size (%dx%d vs %dx%d): input H,W must be multiples of the model max stride",
+                 h, w, s1.h, s1.w);
+    }
+    if (d.kind == PH_OP_CONVT) tmp = std::max<int64_t>(tmp, (int64_t)B * oh * ow * pad16(d.cin0) * 4);
+    PH_REQUIRE(d.dst >= 0 && d.dst < m->n_slots, "bad dst slot %d", d.dst);
+    SlotShape& s = plan.slots[d.dst];
+    s.c = (d.kind == PH_OP_POOL || d.kind == PH_OP_UPSAMPLE) ? d.cin0 : d.cout;
+    s.cp = pad16(s.c);
+    s.h = oh;
+    s.w = ow;
+    s.offset = off;
+    off += align_up((int64_t)B * oh * ow * s.cp * 4, 256);
+  }
+  plan.tmp_offset = off;
+  plan.tmp_bytes = align_up(tmp, 256);
+  plan.total = off + plan.tmp_bytes;
+  return PH_OK;
+}
+
+}  // namespace ph
+
+using namespace ph;
+
+extern "C" {
+
+const char* ph_last_error(void) { return ph::g_err.c_str(); }
+int ph_version(void) { return PH_VERSION; }
+
+ph_model* ph_model_create(const ph_op_desc* ops, int32_t n_ops, const float* const* weights, const int64_t* weight_numel,
+                          int32_t n_weights, int32_t n_slots, int32_t n_outputs) {
+  if (!ops || n_ops <= 0 || n_slots <= 0) {
+    set_error("ph_model_create: empty program");
+    return nullptr;
+  }
+  if (prepare_kernels() != PH_OK) return nullptr;
+  ph_model* m = new ph_model();
+  m->n_slots = n_slots;
+  m->n_outputs = n_outputs;
+  auto fail = [&](const char* msg, int i) -> ph_model* {
+    set_error("ph_model_create: op %d: %s", i, msg);
+    ph_model_destroy(m);
+    return nullptr;
+  };
+  for (int i = 0; i < n_ops; ++i) {
+    PackedOp op;
+    op.d = ops[i];
+    const ph_op_desc& d = op.d;
+    const bool has_w = d.kind == PH_OP_INPUT_CONV || d.kind == PH_OP_CONV || d.kind == PH_OP_CONVT || d.kind == PH_OP_HEAD;
+    if (has_w) {
+      if (d.weight < 0 || d.weight >= n_weights || d.bias >= n_weights) return fail("weight index out of range", i);
+      const float* w = weights[d.weight];
+      const float* b = d.bias >= 0 ? weights[d.bias] : nullptr;
+      const int64_t wn = weight_numel[d.weight];
+      if (b && weight_numel[d.bias] != d.cout) return fail("bias size mismatch", i);
+      std::vector<float> pw, pb;
+      if (d.kind == PH_OP_CONV || d.kind == PH_OP_CONVT) {
+        if (d.ksize != 3) return fail("only kernel_size 3 is supported by the MFMA convolution", i);
+        if (d.kind == PH_OP_CONVT && d.cin1 != 0) return fail("transposed conv takes one source", i);
+        if (wn != (int64_t)(d.cin0 + d.cin1) * d.cout * 9) return fail("weight size mismatch", i);
+        const int coutp = pad16(d.cout);
+        op.bn = choose_bn(coutp);
+        pack_conv(w, d.kind == PH_OP_CONVT, d.cin0, d.cin1, d.cout, op.bn, pw);
+        pb.assign((size_t)((coutp + op.bn - 1) / op.bn) * op.bn, 0.f);
+        if (b) std::memcpy(pb.data(), b, d.cout * sizeof(float));
+      } else if (d.kind == PH_OP_INPUT_CONV) {
+        if (d.ksize != 3) return fail("only kernel_size 3 is supported", i);
+        if (wn != (int64_t)d.cin0 * d.cout * 9) return fail("weight size mismatch", i);
+        const int coutp = pad16(d.cout);
+        pw.assign((size_t)9 * d.cin0 * coutp, 0.f);
+        for (int co = 0; co < d.cout; ++co)
+          for (int ci = 0; ci < d.cin0; ++ci)
+            for (int tap = 0; tap < 9; ++tap) pw[((size_t)tap * d.cin0 + ci) * coutp + co] = w[((size_t)co * d.cin0 + ci) * 9 + tap];
+        pb.assign(coutp, 0.f);
+        if (b) std::memcpy(pb.data(), b, d.cout * sizeof(float));
+      } else {  // HEAD
+        if (wn != (int64_t)d.cin0 * d.cout) return fail("weight size mismatch", i);
+        const int cp = pad16(d.cin0);
+        pw.assign((size_t)d.cout * cp, 0.f);
+        for (int co = 0; co < d.cout; ++co)
+          for (int ci = 0; ci < d.cin0; ++ci) pw[(size_t)co * cp + ci] = w[(size_t)co * d.cin0 + ci];
+        pb.assign(d.cout, 0.f);
+        if (b) std::memcpy(pb.data(), b, d.cout * sizeof(float));
+        if (d.out_index < 0 || d.out_index >= n_outputs) return fail("bad out_index", i);
+      }
+      if (upload(m, pw, &op.w_dev) != PH_OK || upload(m, pb, &op.b_dev) != PH_OK) {
+        ph_model_destroy(m);
+        return nullptr;
+      }
+    } else if (d.kind != PH_OP_POOL && d.kind != PH_OP_UPSAMPLE) {
+      return fail("unknown op kind", i);
+    }
+    m->ops.push_back(op);
+  }
+  return m;
+}
+
+void ph_model_destroy(ph_model* m) {
+  if (!m) return;
+  for (void* p : m->allocs) (void)hipFree(p);
+  delete m;
+}
+
+int64_t ph_model_workspace_bytes(const ph_model* m, int32_t batch, int32_t height, int32_t width) {
+  if (!m || batch <= 0 || height <= 0 || width <= 0) {
+    set_error("ph_model_workspace_bytes: bad arguments");
+    return PH_E_INVALID;
+  }
+  Plan plan;
+  int rc = build_plan(m, batch, height, width, plan);
+  if (rc != PH_OK) return rc;
+  return plan.total;
+}
+
+int ph_model_output_shape(const ph_model* m, int32_t out_index, int32_t height, int32_t width, int32_t* c, int32_t* h, int32_t* w) {
+  PH_REQUIRE(m && c && h && w, "ph_model_output_shape: null argument");
+  Plan plan;
+  int rc = build_plan(m, 1, height, width, plan);
+  if (rc != PH_OK) return rc;
+  for (const PackedOp& op : m->ops)
+    if (op.d.kind == PH_OP_HEAD && op.d.out_index == out_index) {
+      *c = op.d.cout;
+      *h = plan.slots[op.d.src0].h;
+      *w = plan.slots[op.d.src0].w;
+      return PH_OK;
+    }
+  set_error("no head writes output %d", out_index);
+  return PH_E_INVALID;
+}
+
+int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32_t batch, int32_t in_channels, int32_t height,
+                     int32_t width, void* workspace_dev, int64_t workspace_bytes, float* const* out_dev, void* stream) {
+  PH_REQUIRE(m && input_dev && workspace_dev && out_dev, "ph_model_forward: null argument");
+  PH_REQUIRE(in_dtype >= 0 && in_dtype <= 2, "ph_model_forward: bad in_dtype %d", in_dtype);
+  PH_REQUIRE(((uintptr_t)workspace_dev & 255) == 0, "workspace must be 256-byte aligned");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  Plan plan;
+  int rc = build_plan(m, batch, height, width, plan);
+  if (rc != PH_OK) return rc;
+  if (plan.total > workspace_bytes) {
+    set_error("workspace too small: need %lld bytes, got %lld", (long long)plan.total, (long long)workspace_bytes);
+    return PH_E_WORKSPACE;
+  }
+  char* ws = static_cast<char*>(workspace_dev);
+  auto slot_ptr = [&](int sidx) { return reinterpret_cast<float*>(ws + plan.slots[sidx].offset); };
+  for (const PackedOp& op : m->ops) {
+    const ph_op_desc& d = op.d;
+    switch (d.kind) {
+      case PH_OP_INPUT_CONV: {
+        PH_REQUIRE(d.cin0 == in_channels, "input has %d channels, network expects %d", in_channels, d.cin0);
+        InputConvArgs a;
+        a.src = input_dev;
+        a.w = op.w_dev;
+        a.bias = op.b_dev;
+        a.dst = slot_ptr(d.dst);
+        a.dtype = in_dtype;
+        a.cin = d.cin0;
+        a.coutp = pad16(d.cout);
+        a.B = batch;
+        a.H = height;
+        a.W = width;
+        a.relu = (d.flags & PH_FLAG_RELU) ? 1 : 0;
+        rc = launch_input_conv(a, s);
+        break;
+      }
+      case PH_OP_CONV: {
+        const SlotShape& s0 = plan.slots[d.src0];
+        ConvArgs a;
+        a.src0 = slot_ptr(d.src0);
+        a.c0p = s0.cp;
+        a.src1 = d.src1 >= 0 ? slot_ptr(d.src1) : nullptr;
+        a.c1p = d.src1 >= 0 ? plan.slots[d.src1].cp : 0;
+        PH_REQUIRE(s0.c == d.cin0 && (d.src1 < 0 || plan.slots[d.src1].c == d.cin1), "conv channel mismatch");
+        a.wpack = op.w_dev;
+        a.bias = op.b_dev;
+        a.dst = slot_ptr(d.dst);
+        a.coutp = pad16(d.cout);
+        a.B = batch;
+        a.H = s0.h;
+        a.W = s0.w;
+        a.relu = (d.flags & PH_FLAG_RELU) ? 1 : 0;
+        a.bn = op.bn;
+        rc = launch_conv3x3(a, s);
+        break;
+      }
+      case PH_OP_POOL: {
+        const SlotShape& s0 = plan.slots[d.src0];
+        rc = launch_pool(slot_ptr(d.src0), slot_ptr(d.dst), batch, s0.h, s0.w, s0.cp, s);
+        break;
+      }
+      case PH_OP_UPSAMPLE: {
+        const SlotShape& s0 = plan.slots[d.src0];
+        rc = launch_upsample(slot_ptr(d.src0), slot_ptr(d.dst), batch, s0.h, s0.w, s0.cp, s);
+        break;
+      }
+      case PH_OP_CONVT: {
+        const SlotShape& s0 = plan.slots[d.src0];
+        PH_REQUIRE(s0.c == d.cin0, "convT channel mismatch");
+        float* tmp = reinterpret_cast<float*>(ws + plan.tmp_offset);
+        rc = launch_zero_stuff(slot_ptr(d.src0), tmp, batch, s0.h, s0.w, s0.cp, s);
+        if (rc != PH_OK) break;
+        ConvArgs a;
+        a.src0 = tmp;
+        a.c0p = s0.cp;
+        a.src1 = nullptr;
+        a.c1p = 0;
+        a.wpack = op.w_dev;
+        a.bias = op.b_dev;
+        a.dst = slot_ptr(d.dst);
+        a.coutp = pad16(d.cout);
+        a.B = batch;
+        a.H = 2 * s0.h;
+        a.W = 2 * s0.w;
+        a.relu = (d.flags & PH_FLAG_RELU) ? 1 : 0;
+        a.bn = op.bn;
+        rc = launch_conv3x3(a, s);
+        break;
+      }
+      case PH_OP_HEAD: {
+        const SlotShape& s0 = plan.slots[d.src0];
+        PH_REQUIRE(s0.c == d.cin0, "head channel mismatch");
+        PH_REQUIRE(out_dev[d.out_index] != nullptr, "output %d is null", d.out_index);
+        rc = launch_head(slot_ptr(d.src0), op.w_dev, op.b_dev, out_dev[d.out_index], batch, s0.h * s0.w, s0.cp, d.cout,
+                         (d.flags & PH_FLAG_SIGMOID) ? 1 : 0, s);
+        break;
+      }
+      default:
+        set_error("unknown op kind %d", d.kind);
+        rc = PH_E_INVALID;
+    }
+    if (rc != PH_OK) return rc;
+  }
+  m->last_plan = plan;
+  m->last_ws = ws;
+  m->last_batch = batch;
+  return PH_OK;
+}
+
+int ph_model_read_slot(ph_model* m, int32_t slot, float* out_dev, int64_t out_numel, void* stream) {
+  PH_REQUIRE(m && out_dev && m->last_ws, "ph_model_read_slot: no forward has run");
+  PH_REQUIRE(slot >= 0 && slot < m->n_slots && m->last_plan.slots[slot].offset >= 0, "bad slot %d", slot);
+  const SlotShape& s = m->last_plan.slots[slot];
+  PH_REQUIRE(out_numel == (int64_t)m->last_batch * s.c * s.h * s.w, "slot %d has %d x %d x %d x %d elements", slot, m->last_batch, s.c, s.h, s.w);
+  return launch_nhwc_to_nchw(reinterpret_cast<float*>(m->last_ws + s.offset), out_dev, m->last_batch, s.h * s.w, s.cp, s.c,
+                             static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

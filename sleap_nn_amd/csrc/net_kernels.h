@@ -1,0 +1,41 @@
+// Launcher declarations for the encoder-decoder kernels (net_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdint>
+
+namespace ph {
+
+struct ConvArgs {
+  const float* src0;   // NHWC, c0p channels
+  const float* src1;   // NHWC, c1p channels (nullptr / 0 when single-source)
+  const float* wpack;  // [n_tile][chunk][tap][bn][16]
+  const float* bias;   // [coutp_rounded_to_bn]
+  float* dst;          // NHWC, coutp channels
+  int c0p, c1p, coutp;
+  int B, H, W;
+  int relu;
+  int bn;              // N tile: 32 or 64
+};
+
+struct InputConvArgs {
+  const void* src;  // NCHW uint8 / float
+  const float* w;   // [tap][cin][coutp]
+  const float* bias;
+  float* dst;       // NHWC coutp
+  int dtype;        // 0 u8 (/255), 1 f32 as-is, 2 f32 (/255)
+  int cin, coutp, B, H, W, relu;
+};
+
+int prepare_kernels();
+int conv_lds_bytes(int bn);
+int launch_conv3x3(const ConvArgs& a, hipStream_t s);
+int launch_input_conv(const InputConvArgs& a, hipStream_t s);
+int launch_pool(const float* src, float* dst, int B, int H, int W, int cp, hipStream_t s);
+int launch_upsample(const float* src, float* dst, int B, int H, int W, int cp, hipStream_t s);
+int launch_zero_stuff(const float* src, float* dst, int B, int H, int W, int cp, hipStream_t s);
+int launch_head(const float* src, const float* w, const float* bias, float* dst, int B, int HW, int cp, int cout, int sigmoid, hipStream_t s);
+int launch_nhwc_to_nchw(const float* src, float* dst, int B, int HW, int cp, int c, hipStream_t s);
+
+}  // namespace ph

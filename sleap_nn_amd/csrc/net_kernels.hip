@@ -1,0 +1,419 @@
+// Encoder-decoder forward kernels for gfx950 (MI355X, CDNA4).
+//
+// Activations live in HBM as NHWC fp32 with the channel count padded to a multiple of 16
+// ("Cp"); pad channels are always written as exact zeros (zero weights, zero bias), so no
+// buffer ever needs clearing.  All dense convolutions run as implicit GEMMs on the matrix
+// cores through v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 accumulate), which is
+// what lets the confidence maps stay within 1e-4 of the reference's ATen-CPU results.
+//
+// Reference semantics implemented here (paths relative to talmolab/sleap-nn):
+//   conv3x3 + bias + ReLU ............ architectures/encoder_decoder.py:108-121,494-510
+//   concat(skip, upsampled) .......... encoder_decoder.py:545,556 (two K-panels, no copy)
+//   2x2 max pool "same" .............. architectures/common.py:69-107 (zero pad if odd)
+//   bilinear x2 (align_corners=False)  encoder_decoder.py:431-435
+//   ConvTranspose2d(k3,s2,p1,op1) .... encoder_decoder.py:439-461
+//   1x1 head conv .................... architectures/heads.py:58-67
+//   uint8 -> float /255 .............. data/normalization.py:7-35
+#include "common.h"
+#include "net_kernels.h"
+
+namespace ph {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------------------
+// K1: 3x3 "same" convolution as implicit GEMM on MFMA.
+//   GEMM view: M = pixels (tile 8 rows x 32 cols), N = BN output channels, K = 9 * Cin_p.
+//   256 threads = 4 waves; wave w owns image rows 2w, 2w+1 of the tile (two 32-pixel M
+//   tiles) times all BN/32 N tiles -> 2*(BN/32) accumulators of 16 VGPRs.
+//   K loop: 16-channel chunks; per chunk the (8+2)x(32+2) input halo and the 9 x BN x 16
+//   weight panel are staged in LDS with rows padded from 16 to 20 dwords, which makes the
+//   ds_read_b128 fragment reads bank-conflict free (20*i mod 64 hits 16 distinct 16-B slots).
+//   One ds_read_b128 feeds four MFMAs: lanes 0-31 hold channels c..c+3 of "their" pixel /
+//   output channel, lanes 32-63 channels c+4..c+7, i.e. MFMA j contracts channels
+//   {c+j, c+4+j} -- the same pairing on the A and the B side.
+// ---------------------------------------------------------------------------------------
+constexpr int TH = 8, TW = 32, KC = 16, LROW = 20;
+constexpr int HALO_W = TW + 2, HALO_H = TH + 2;
+
+template <int BN>
+__global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* ldsA = lds;                            // HALO_H*HALO_W rows of LROW
+  float* ldsB = lds + HALO_H * HALO_W * LROW;   // 9*BN rows of LROW
+  constexpr int NT = BN / 32;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int tiles_x = (a.W + TW - 1) / TW;
+  const int tiles_y = (a.H + TH - 1) / TH;
+  int t = blockIdx.x;
+  const int tx = t % tiles_x;
+  t /= tiles_x;
+  const int ty = t % tiles_y;
+  const int b = t / tiles_y;
+  const int ntile = blockIdx.y;
+  const int x0 = tx * TW, y0 = ty * TH;
+
+  f32x16 acc[2][NT];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+  const int chunks0 = a.c0p / KC;
+  const int chunks1 = a.c1p / KC;
+  const int nchunks = chunks0 + chunks1;
+  const float* wbase = a.wpack + (size_t)ntile * nchunks * (9 * BN * KC);
+
+  const int lx = lane & 31;
+  const int lh = lane >> 5;
+
+  for (int ch = 0; ch < nchunks; ++ch) {
+    const float* src;
+    int cp, coff;
+    if (ch < chunks0) {
+      src = a.src0;
+      cp = a.c0p;
+      coff = ch * KC;
+    } else {
+      src = a.src1;
+      cp = a.c1p;
+      coff = (ch - chunks0) * KC;
+    }
+    // ---- stage input halo (zero outside the image)
+    for (int i = tid; i < HALO_H * HALO_W * 4; i += 256) {
+      const int pix = i >> 2, q = i & 3;
+      const int hy = pix / HALO_W, hx = pix - hy * HALO_W;
+      const int gy = y0 + hy - 1, gx = x0 + hx - 1;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
+        v = *reinterpret_cast<const f32x4*>(src + ((size_t)(b * a.H + gy) * a.W + gx) * cp + coff + q * 4);
+      *reinterpret_cast<f32x4*>(ldsA + pix * LROW + q * 4) = v;
+    }
+    // ---- stage weight panel [tap][n][16]
+    const float* wsrc = wbase + (size_t)ch * (9 * BN * KC);
+    for (int i = tid; i < 9 * BN * 4; i += 256) {
+      const int row = i >> 2, q = i & 3;
+      *reinterpret_cast<f32x4*>(ldsB + row * LROW + q * 4) = *reinterpret_cast<const f32x4*>(wsrc + i * 4);
+    }
+    __syncthreads();
+    // ---- 9 taps x 2 channel groups x 4 MFMA k-steps
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int ky = tap / 3, kx = tap - ky * 3;
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        f32x4 af[2], bf[NT];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+          af[m] = *reinterpret_cast<const f32x4*>(ldsA + ((2 * wave + m + ky) * HALO_W + lx + kx) * LROW + g * 8 + lh * 4);
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+          bf[n] = *reinterpret_cast<const f32x4*>(ldsB + (tap * BN + n * 32 + lx) * LROW + g * 8 + lh * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+              acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m][j], bf[n][j], acc[m][n], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: bias (+ReLU), NHWC store.  C/D map: col = lane&31 (channel),
+  // row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (pixel x inside the 32-wide tile).
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    const int co = ntile * BN + n * 32 + lx;
+    if (co >= a.coutp) continue;
+    const float bias = a.bias[co];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const int y = y0 + 2 * wave + m;
+      if (y >= a.H) continue;
+      float* drow = a.dst + ((size_t)(b * a.H + y) * a.W) * a.coutp + co;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int x = x0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (x < a.W) {
+          float v = acc[m][n][r] + bias;
+          if (a.relu) v = fmaxf(v, 0.f);
+          drow[(size_t)x * a.coutp] = v;
+        }
+      }
+    }
+  }
+}
+
+int launch_conv3x3(const ConvArgs& a, hipStream_t s) {
+  const int tiles = ((a.W + TW - 1) / TW) * ((a.H + TH - 1) / TH) * a.B;
+  if (a.bn == 64) {
+    const size_t lds = (HALO_H * HALO_W + 9 * 64) * LROW * sizeof(float);
+    dim3 grid(tiles, (a.coutp + 63) / 64);
+    hipLaunchKernelGGL(conv3x3_mfma_kernel<64>, grid, dim3(256), lds, s, a);
+  } else {
+    const size_t lds = (HALO_H * HALO_W + 9 * 32) * LROW * sizeof(float);
+    dim3 grid(tiles, (a.coutp + 31) / 32);
+    hipLaunchKernelGGL(conv3x3_mfma_kernel<32>, grid, dim3(256), lds, s, a);
+  }
+  PH_HIP_CHECK(hipGetLastError());
+  return PH_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// K0: first convolution straight from the NCHW image (uint8 or float), normalisation fused.
+// One thread = one output pixel x 4 output channels (16-B store; a wave writes 1 KiB
+// contiguous when Cp == 16).  Cin is 1 or 3 so K = 9..27: VALU work, HBM-bound.
+// Weights: [tap][ci][Cp] fp32.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void input_conv3x3_kernel(InputConvArgs a) {
+  const int groups = a.coutp >> 2;
+  const size_t total = (size_t)a.B * a.H * a.W * groups;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int gq = (int)(idx % groups);
+    size_t p = idx / groups;
+    const int x = (int)(p % a.W);
+    p /= a.W;
+    const int y = (int)(p % a.H);
+    const int b = (int)(p / a.H);
+    f32x4 acc = *reinterpret_cast<const f32x4*>(a.bias + gq * 4);
+    for (int ci = 0; ci < a.cin; ++ci) {
+      const size_t plane = ((size_t)b * a.cin + ci) * a.H * a.W;
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const int yy = y + ky - 1;
+        if (yy < 0 || yy >= a.H) continue;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const int xx = x + kx - 1;
+          if (xx < 0 || xx >= a.W) continue;
+          float v;
+          if (a.dtype == 0)
+            v = (float)reinterpret_cast<const uint8_t*>(a.src)[plane + (size_t)yy * a.W + xx] / 255.0f;
+          else {
+            v = reinterpret_cast<const float*>(a.src)[plane + (size_t)yy * a.W + xx];
+            if (a.dtype == 2) v = v / 255.0f;
+          }
+          const f32x4 w = *reinterpret_cast<const f32x4*>(a.w + ((size_t)(ky * 3 + kx) * a.cin + ci) * a.coutp + gq * 4);
+          acc += v * w;
+        }
+      }
+    }
+    if (a.relu) {
+      acc[0] = fmaxf(acc[0], 0.f);
+      acc[1] = fmaxf(acc[1], 0.f);
+      acc[2] = fmaxf(acc[2], 0.f);
+      acc[3] = fmaxf(acc[3], 0.f);
+    }
+    *reinterpret_cast<f32x4*>(a.dst + (((size_t)b * a.H + y) * a.W + x) * a.coutp + gq * 4) = acc;
+  }
+}
+
+int launch_input_conv(const InputConvArgs& a, hipStream_t s) {
+  const size_t total = (size_t)a.B * a.H * a.W * (a.coutp / 4);
+  const int blocks = (int)std::min<size_t>((total + 255) / 256, 256 * 32);
+  hipLaunchKernelGGL(input_conv3x3_kernel, dim3(blocks), dim3(256), 0, s, a);
+  PH_HIP_CHECK(hipGetLastError());
+  return PH_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// K3: 2x2 stride-2 max pool, NHWC, float4 per thread.  Odd sizes: the missing right/bottom
+// element is the reference's zero pad (common.py:93-96), i.e. max(v, 0).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pool2x2_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, int H, int W, int cp) {
+  const int Ho = (H + 1) / 2, Wo = (W + 1) / 2, groups = cp >> 2;
+  const size_t total = (size_t)B * Ho * Wo * groups;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int gq = (int)(idx % groups);
+    size_t p = idx / groups;
+    const int x = (int)(p % Wo);
+    p /= Wo;
+    const int y = (int)(p % Ho);
+    const int b = (int)(p / Ho);
+    const int y1 = 2 * y + 1, x1 = 2 * x + 1;
+    const float* base = src + ((size_t)b * H * W) * cp + gq * 4;
+    f32x4 v = *reinterpret_cast<const f32x4*>(base + ((size_t)(2 * y) * W + 2 * x) * cp);
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    f32x4 v01 = (x1 < W) ? *reinterpret_cast<const f32x4*>(base + ((size_t)(2 * y) * W + x1) * cp) : z;
+    f32x4 v10 = (y1 < H) ? *reinterpret_cast<const f32x4*>(base + ((size_t)y1 * W + 2 * x) * cp) : z;
+    f32x4 v11 = (y1 < H && x1 < W) ? *reinterpret_cast<const f32x4*>(base + ((size_t)y1 * W + x1) * cp) : z;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = fmaxf(fmaxf(v[k], v01[k]), fmaxf(v10[k], v11[k]));
+    *reinterpret_cast<f32x4*>(dst + (((size_t)b * Ho + y) * Wo + x) * cp + gq * 4) = v;
+  }
+}
+
+int launch_pool(const float* src, float* dst, int B, int H, int W, int cp, hipStream_t s) {
+  const size_t total = (size_t)B * ((H + 1) / 2) * ((W + 1) / 2) * (cp / 4);
+  const int blocks = (int)std::min<size_t>((total + 255) / 256, 256 * 32);
+  hipLaunchKernelGGL(pool2x2_kernel, dim3(blocks), dim3(256), 0, s, src, dst, B, H, W, cp);
+  PH_HIP_CHECK(hipGetLastError());
+  return PH_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// K4: bilinear x2 upsample, align_corners=False (ATen upsample_bilinear2d semantics:
+// src = max(0, (dst + 0.5) * 0.5 - 0.5), i1 = min(i0 + 1, in - 1), lambda = src - i0).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void upsample2x_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, int H, int W, int cp) {
+  const int Ho = 2 * H, Wo = 2 * W, groups = cp >> 2;
+  const size_t total = (size_t)B * Ho * Wo * groups;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int gq = (int)(idx % groups);
+    size_t p = idx / groups;
+    const int x = (int)(p % Wo);
+    p /= Wo;
+    const int y = (int)(p % Ho);
+    const int b = (int)(p / Ho);
+    const float sy = fmaxf((y + 0.5f) * 0.5f - 0.5f, 0.f);
+    const float sx = fmaxf((x + 0.5f) * 0.5f - 0.5f, 0.f);
+    const int iy0 = (int)sy, ix0 = (int)sx;
+    const int iy1 = min(iy0 + 1, H - 1), ix1 = min(ix0 + 1, W - 1);
+    const float ly = sy - iy0, lx = sx - ix0;
+    const float hy = 1.f - ly, hx = 1.f - lx;
+    const float* base = src + ((size_t)b * H * W) * cp + gq * 4;
+    const f32x4 v00 = *reinterpret_cast<const f32x4*>(base + ((size_t)iy0 * W + ix0) * cp);
+    const f32x4 v01 = *reinterpret_cast<const f32x4*>(base + ((size_t)iy0 * W + ix1) * cp);
+    const f32x4 v10 = *reinterpret_cast<const f32x4*>(base + ((size_t)iy1 * W + ix0) * cp);
+    const f32x4 v11 = *reinterpret_cast<const f32x4*>(base + ((size_t)iy1 * W + ix1) * cp);
+    f32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = hy * (hx * v00[k] + lx * v01[k]) + ly * (hx * v10[k] + lx * v11[k]);
+    *reinterpret_cast<f32x4*>(dst + (((size_t)b * Ho + y) * Wo + x) * cp + gq * 4) = o;
+  }
+}
+
+int launch_upsample(const float* src, float* dst, int B, int H, int W, int cp, hipStream_t s) {
+  const size_t total = (size_t)B * 4 * H * W * (cp / 4);
+  const int blocks = (int)std::min<size_t>((total + 255) / 256, 256 * 32);
+  hipLaunchKernelGGL(upsample2x_kernel, dim3(blocks), dim3(256), 0, s, src, dst, B, H, W, cp);
+  PH_HIP_CHECK(hipGetLastError());
+  return PH_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// K5a: zero-stuff for the transposed convolution: Z[2i,2j] = X[i,j], zeros elsewhere
+// (size 2H x 2W: the trailing zero row/col is output_padding=1).  The transposed conv is
+// then the 3x3 "same" MFMA conv of Z with the flipped, in/out-transposed kernel.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void zero_stuff_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, int H, int W, int cp) {
+  const int Ho = 2 * H, Wo = 2 * W, groups = cp >> 2;
+  const size_t total = (size_t)B * Ho * Wo * groups;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int gq = (int)(idx % groups);
+    size_t p = idx / groups;
+    const int x = (int)(p % Wo);
+    p /= Wo;
+    const int y = (int)(p % Ho);
+    const int b = (int)(p / Ho);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (!(x & 1) && !(y & 1)) v = *reinterpret_cast<const f32x4*>(src + (((size_t)b * H + (y >> 1)) * W + (x >> 1)) * cp + gq * 4);
+    *reinterpret_cast<f32x4*>(dst + idx * 4) = v;
+  }
+}
+
+int launch_zero_stuff(const float* src, float* dst, int B, int H, int W, int cp, hipStream_t s) {
+  const size_t total = (size_t)B * 4 * H * W * (cp / 4);
+  const int blocks = (int)std::min<size_t>((total + 255) / 256, 256 * 32);
+  hipLaunchKernelGGL(zero_stuff_kernel, dim3(blocks), dim3(256), 0, s, src, dst, B, H, W, cp);
+  PH_HIP_CHECK(hipGetLastError());
+  return PH_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// K2: 1x1 head convolution, NHWC(Cp) -> NCHW(Cout) fp32 (+ optional sigmoid).
+// Block = 64 pixels; the 64 x Cp activation tile and the Cout x Cp weights sit in LDS
+// (pixel rows padded by 1 dword: column reads conflict-free); thread (p, j) computes
+// output channels j, j+4, ... of pixel p.  HBM-bound: Cp*4 B read + Cout*4 B written/pixel.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void head1x1_kernel(const float* __restrict__ src, const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ dst, int B, int HW, int cp, int cout, int sigmoid) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* sa = lds;                    // 64 x (cp+1)
+  float* sw = lds + 64 * (cp + 1);    // cout x cp
+  const size_t npix = (size_t)B * HW;
+  const size_t p0 = (size_t)blockIdx.x * 64;
+  for (int i = threadIdx.x; i < cout * cp; i += 256) sw[i] = w[i];
+  for (int i = threadIdx.x; i < 64 * cp; i += 256) {
+    const int pp = i / cp, c = i - pp * cp;
+    sa[pp * (cp + 1) + c] = (p0 + pp < npix) ? src[(p0 + pp) * cp + c] : 0.f;
+  }
+  __syncthreads();
+  const int pp = threadIdx.x & 63, j0 = threadIdx.x >> 6;
+  const size_t p = p0 + pp;
+  if (p >= npix) return;
+  const size_t b = p / HW, hw = p - b * HW;
+  for (int j = j0; j < cout; j += 4) {
+    float acc = bias[j];
+    const float* wr = sw + j * cp;
+    const float* ar = sa + pp * (cp + 1);
+    for (int c = 0; c < cp; ++c) acc += ar[c] * wr[c];
+    if (sigmoid) acc = 1.f / (1.f + expf(-acc));
+    dst[(b * cout + j) * HW + hw] = acc;
+  }
+}
+
+int launch_head(const float* src, const float* w, const float* bias, float* dst, int B, int HW, int cp, int cout, int sigmoid, hipStream_t s) {
+  const size_t npix = (size_t)B * HW;
+  const size_t lds = (64 * (cp + 1) + (size_t)cout * cp) * sizeof(float);
+  if (lds > 160 * 1024) {
+    set_error("head1x1: LDS tile too large (cp=%d cout=%d)", cp, cout);
+    return PH_E_INVALID;
+  }
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(head1x1_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+      set_error("hipFuncSetAttribute(head1x1) failed: %s", hipGetErrorString(e));
+      return PH_E_HIP;
+    }
+  }
+  hipLaunchKernelGGL(head1x1_kernel, dim3((unsigned)((npix + 63) / 64)), dim3(256), lds, s, src, w, bias, dst, B, HW, cp, cout, sigmoid);
+  PH_HIP_CHECK(hipGetLastError());
+  return PH_OK;
+}
+
+// NHWC(Cp) -> NCHW(C) copy for the debug/parity read-back of intermediate slots.
+__global__ void nhwc_to_nchw_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, int HW, int cp, int c) {
+  const size_t total = (size_t)B * c * HW;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const size_t hw = idx % HW;
+    size_t r = idx / HW;
+    const int ch = (int)(r % c);
+    const size_t b = r / c;
+    dst[idx] = src[(b * HW + hw) * cp + ch];
+  }
+}
+
+int launch_nhwc_to_nchw(const float* src, float* dst, int B, int HW, int cp, int c, hipStream_t s) {
+  const size_t total = (size_t)B * c * HW;
+  const int blocks = (int)std::min<size_t>((total + 255) / 256, 8192);
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(blocks), dim3(256), 0, s, src, dst, B, HW, cp, c);
+  PH_HIP_CHECK(hipGetLastError());
+  return PH_OK;
+}
+
+int conv_lds_bytes(int bn) { return (HALO_H * HALO_W + 9 * bn) * LROW * (int)sizeof(float); }
+
+int prepare_kernels() {
+  // 73 KiB of dynamic LDS for the BN=64 variant exceeds the 64 KiB default cap.
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_mfma_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, conv_lds_bytes(64));
+  if (e != hipSuccess) {
+    set_error("hipFuncSetAttribute(conv64) failed: %s", hipGetErrorString(e));
+    return PH_E_HIP;
+  }
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_mfma_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, conv_lds_bytes(32));
+  if (e != hipSuccess) {
+    set_error("hipFuncSetAttribute(conv32) failed: %s", hipGetErrorString(e));
+    return PH_E_HIP;
+  }
+  return PH_OK;
+}
+
+}  // namespace ph

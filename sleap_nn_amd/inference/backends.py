@@ -1,0 +1,76 @@
+"""Runtime backends: the reference's ``ModelBackend`` protocol and its MI355X implementation.
+
+``ModelBackend`` restates the 4-member protocol of
+``sleap_nn/inference/layers/backends/base.py:18-79``; ``HipBackend`` is the counterpart of
+``TorchBackend`` (``torch_backend.py:46-266``): it owns the model, moves the batch to the
+device, resolves the LightningModule-forward preamble (squeeze the n_samples axis,
+uint8 -> /255, ``normalize_on_gpu``'s ``max() > 1`` test for float input --
+training/lightning_modules.py:1840-1848, data/normalization.py:7-35) and returns a dict of
+fp32 NCHW tensors keyed by head class name.
+"""
+from __future__ import annotations
+
+from typing import Dict, Protocol, Tuple, runtime_checkable
+
+import torch
+
+from sleap_nn_amd import _lib as L
+
+
+@runtime_checkable
+class ModelBackend(Protocol):
+    @property
+    def device(self) -> str: ...
+
+    @property
+    def does_baked_postproc(self) -> bool: ...
+
+    def __call__(self, x: torch.Tensor) -> Dict[str, torch.Tensor]: ...
+
+    def warmup(self, input_shape: Tuple[int, ...]) -> None: ...
+
+
+class HipBackend:
+    """Hand-written-HIP forward behind the ``ModelBackend`` protocol."""
+
+    def __init__(self, model, device: str = "cuda") -> None:
+        L.lib()  # fail loudly right here if the native library is missing
+        if not torch.cuda.is_available():
+            raise RuntimeError("HipBackend needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
+        dev = torch.device(device)
+        if dev.type != "cuda":
+            raise ValueError(f"HipBackend runs on the GPU only, got device={device!r}")
+        if dev.index is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
+        self._device = dev
+        self.model = model.to(dev).eval()
+
+    @property
+    def device(self) -> str:
+        return str(self._device)
+
+    @property
+    def does_baked_postproc(self) -> bool:
+        return False
+
+    def __call__(self, x: torch.Tensor) -> Dict[str, torch.Tensor]:
+        if not isinstance(x, torch.Tensor):
+            raise TypeError(f"backend input must be a torch.Tensor, got {type(x).__name__}")
+        x = x.to(self._device, non_blocking=True)
+        if x.dim() == 5:
+            x = x.squeeze(1)
+        code = None
+        if x.dtype != torch.uint8:
+            x = x.to(torch.float32)
+            code = 2 if bool(x.max() > 1.0) else 1  # normalize_on_gpu's data-dependent branch
+        out = self.model.forward(x, in_dtype=code)
+        if isinstance(out, torch.Tensor):
+            out = {"output": out}
+        if not isinstance(out, dict):
+            raise TypeError(f"unexpected model output type {type(out).__name__}")
+        return out
+
+    def warmup(self, input_shape: Tuple[int, ...]) -> None:
+        x = torch.zeros(tuple(input_shape), dtype=torch.uint8, device=self._device)
+        self(x)
+        torch.cuda.synchronize(self._device)

@@ -1,0 +1,4 @@
+from sleap_nn_amd.inference.layers.base import InferenceLayer  # noqa: F401
+from sleap_nn_amd.inference.layers.bottomup import BottomUpLayer  # noqa: F401
+from sleap_nn_amd.inference.layers.configs import PostprocessConfig, PreprocessConfig  # noqa: F401
+from sleap_nn_amd.inference.layers.single_instance import SingleInstanceLayer  # noqa: F401

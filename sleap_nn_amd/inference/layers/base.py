@@ -1,0 +1,133 @@
+"""``InferenceLayer`` base: preprocess -> backend -> postprocess
+(sleap_nn/inference/layers/base.py:30-374)."""
+from __future__ import annotations
+
+from abc import ABC, abstractmethod
+from typing import Tuple, Union
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from sleap_nn_amd.inference.backends import ModelBackend
+from sleap_nn_amd.inference.layers.configs import PostprocessConfig, PreprocessConfig
+from sleap_nn_amd.inference.outputs import Outputs
+from sleap_nn_amd.inference.preprocess_info import PreprocInfo
+
+ImageInput = Union[np.ndarray, torch.Tensor]
+
+
+def apply_pad_to_stride(image: torch.Tensor, max_stride: int) -> torch.Tensor:
+    """Zero pad bottom/right to a multiple of ``max_stride`` (data/resizing.py:35-67)."""
+    if max_stride > 1:
+        h, w = image.shape[-2:]
+        ph, pw = (max_stride - h % max_stride) % max_stride, (max_stride - w % max_stride) % max_stride
+        if ph > 0 or pw > 0:
+            image = F.pad(image, (0, pw, 0, ph), mode="constant")
+    return image
+
+
+class InferenceLayer(ABC):
+    _HEAD_OUTPUT_KEY: str = ""
+    _TORCH_OUTPUT_KEY: str = "output"
+
+    def __init__(self, backend: ModelBackend, preprocess_config: PreprocessConfig, postprocess_config: PostprocessConfig, output_stride: int, max_stride: int = 1) -> None:
+        if not isinstance(backend, ModelBackend):
+            raise TypeError(f"backend must satisfy ModelBackend, got {type(backend).__name__}")
+        self.backend = backend
+        self.preprocess_config = preprocess_config
+        self.postprocess_config = postprocess_config
+        self.output_stride = output_stride
+        self.max_stride = max_stride
+
+    def preprocess(self, image: ImageInput) -> Tuple[torch.Tensor, PreprocInfo]:
+        x = self._to_4d_tensor(image)
+        scaled, eff_scale, orig_hw = self._apply_full_preprocess(x, max_stride=self.max_stride, unsqueeze_n_samples=True)
+        info = PreprocInfo(
+            original_size=orig_hw, processed_size=tuple(scaled.shape[-2:]), eff_scale=eff_scale,
+            input_scale=self.preprocess_config.scale, output_stride=self.output_stride,
+        )
+        return scaled, info
+
+    @abstractmethod
+    def postprocess(self, raw_out: dict, info: PreprocInfo) -> Outputs: ...
+
+    def predict(self, image: ImageInput) -> Outputs:
+        x, info = self.preprocess(image)
+        raw = self.backend(x)
+        return self.postprocess(raw, info)
+
+    __call__ = predict
+
+    def warmup(self, sample_shape=None) -> None:
+        if sample_shape is not None:
+            self.backend.warmup(sample_shape)
+            return
+        cfg = self.preprocess_config
+        h, w = min(cfg.max_height or 96, 256), min(cfg.max_width or 96, 256)
+        try:
+            self.predict(np.zeros((h, w, 3), dtype=np.uint8))
+        except Exception:  # warmup is best-effort, as in the reference (base.py:156-159)
+            pass
+        torch.cuda.synchronize()
+
+    def _extract_confmaps(self, raw_out: dict) -> torch.Tensor:
+        if self._TORCH_OUTPUT_KEY in raw_out:
+            return raw_out[self._TORCH_OUTPUT_KEY]
+        if self._HEAD_OUTPUT_KEY and self._HEAD_OUTPUT_KEY in raw_out:
+            return raw_out[self._HEAD_OUTPUT_KEY]
+        tensors = [v for v in raw_out.values() if isinstance(v, torch.Tensor)]
+        if len(tensors) == 1:
+            return tensors[0]
+        raise KeyError(
+            f"{type(self).__name__}.postprocess could not find confmaps in raw_out keys={list(raw_out.keys())}; "
+            f"expected '{self._TORCH_OUTPUT_KEY}' or '{self._HEAD_OUTPUT_KEY or '(not set)'}'."
+        )
+
+    @staticmethod
+    def _to_4d_tensor(image: ImageInput) -> torch.Tensor:
+        """Coerce to (B, C, H, W) keeping the dtype (base.py:212-253 heuristics)."""
+        if isinstance(image, np.ndarray):
+            t = torch.from_numpy(image)
+        elif isinstance(image, torch.Tensor):
+            t = image
+        else:
+            raise TypeError(f"image must be np.ndarray or torch.Tensor, got {type(image).__name__}")
+        if t.ndim == 2:
+            t = t[None, None]
+        elif t.ndim == 3:
+            t = t.permute(2, 0, 1)[None] if (t.shape[-1] <= 4 and t.shape[0] > 4) else t[None]
+        elif t.ndim == 4:
+            if t.shape[-1] <= 4 and t.shape[1] > 4:
+                t = t.permute(0, 3, 1, 2)
+        else:
+            raise ValueError(f"unexpected image rank {t.ndim}: shape {tuple(t.shape)}")
+        return t
+
+    def _apply_full_preprocess(self, x: torch.Tensor, *, max_stride: int = 1, unsqueeze_n_samples: bool = True):
+        """Channel coercion -> (sizematcher) -> (input scale) -> pad to stride -> n_samples axis
+        (base.py:270-374).  Sizematcher / input-scale resizes are data-pipeline features outside
+        the MI355X hot path: frames must arrive at model resolution."""
+        cfg = self.preprocess_config
+        B, _c, H, W = x.shape
+        if cfg.ensure_rgb and x.shape[-3] != 3:
+            x = x.repeat(1, 3, 1, 1) if x.shape[-3] == 1 else x
+        elif cfg.ensure_grayscale and x.shape[-3] != 1:
+            r, g, b = x.float().unbind(dim=-3)
+            x = (0.2989 * r + 0.587 * g + 0.114 * b).unsqueeze(-3)
+        if (cfg.max_height is not None and H > cfg.max_height) or (cfg.max_width is not None and W > cfg.max_width):
+            raise NotImplementedError("sizematcher downscaling is not part of the MI355X hot path; resize frames upstream")
+        if cfg.scale != 1.0:
+            raise NotImplementedError("input scale != 1.0 is not part of the MI355X hot path; resize frames upstream")
+        eff_scale = torch.ones(B, dtype=torch.float32)
+        if cfg.max_height is not None or cfg.max_width is not None:
+            # sizematcher with a frame that already fits: pad bottom/right to (max_h, max_w), scale 1
+            ph = (cfg.max_height - H) if cfg.max_height else 0
+            pw = (cfg.max_width - W) if cfg.max_width else 0
+            if ph > 0 or pw > 0:
+                x = F.pad(x, (0, max(pw, 0), 0, max(ph, 0)))
+        if max_stride != 1:
+            x = apply_pad_to_stride(x, max_stride)
+        if unsqueeze_n_samples:
+            x = x.unsqueeze(1)
+        return x, eff_scale, (H, W)

@@ -1,0 +1,216 @@
+"""CPU-side checks of the product: C-ABI surface, host (C++) assignment + assembly, host logic.
+No GPU compute is called here."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+from scipy.optimize import linear_sum_assignment as scipy_lsa
+
+from oracle import cpu_ref as O
+from sleap_nn_amd import _lib as L
+from sleap_nn_amd.inference.ops import paf as P
+from tests import _golden as G
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "posehip.h")).read()
+    declared = set(re.findall(r"\b(ph_[a-z_0-9]+)\s*\(", hdr))
+    declared -= {"ph_op_desc", "ph_model"}
+    assert len(declared) >= 14
+    lib = ctypes.CDLL(L.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in posehip.h but not exported"
+    assert set(L.SIGNATURES) == declared
+    assert L.lib().ph_version() == 100
+
+
+def test_product_does_not_import_oracle():
+    for dp, _, files in os.walk(os.path.join(ROOT, "sleap_nn_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dp, f)).read()
+                assert "oracle" not in src.replace("# oracle", ""), f"{f} references the oracle"
+
+
+def _same_assignment(cost):
+    r0, c0 = scipy_lsa(cost)
+    r1, c1 = P.linear_sum_assignment(cost)
+    assert np.array_equal(r0, r1) and np.array_equal(c0, c1), (cost, r0, c0, r1, c1)
+
+
+def test_lsap_matches_scipy_including_ties():
+    rng = np.random.RandomState(0)
+    n = 0
+    for trial in range(4000):
+        nr, nc = rng.randint(1, 9), rng.randint(1, 9)
+        kind = trial % 5
+        if kind == 0:
+            cost = rng.randn(nr, nc)
+        elif kind == 1:  # heavy ties
+            cost = rng.randint(0, 3, size=(nr, nc)).astype(np.float64)
+        elif kind == 2:  # constant
+            cost = np.full((nr, nc), float(rng.randint(-2, 3)))
+        elif kind == 3:  # float32 scores negated, as the reference builds them
+            cost = (-rng.rand(nr, nc).astype(np.float32)).astype(np.float64)
+        else:  # some forbidden entries but feasible (a finite diagonal band)
+            cost = rng.randint(0, 4, size=(nr, nc)).astype(np.float64)
+            mask = rng.rand(nr, nc) < 0.3
+            for i in range(min(nr, nc)):
+                mask[i, i] = False
+            cost[mask] = np.inf
+        _same_assignment(cost)
+        n += 1
+    assert n == 4000
+    # larger problems
+    for s in range(50):
+        cost = np.random.RandomState(100 + s).randint(0, 10, size=(40, 37)).astype(np.float64)
+        _same_assignment(cost)
+        _same_assignment(cost.T.copy())
+
+
+def test_lsap_edge_cases():
+    r, c = P.linear_sum_assignment(np.zeros((0, 3)))
+    assert r.size == 0 and c.size == 0
+    with pytest.raises(ValueError):
+        P.linear_sum_assignment(np.array([[np.inf, np.inf], [1.0, np.inf]]))  # infeasible, like scipy
+    with pytest.raises(ValueError):
+        scipy_lsa(np.array([[np.inf, np.inf], [1.0, np.inf]]))
+    with pytest.raises(ValueError):
+        P.linear_sum_assignment(np.array([[np.nan, 1.0]]))
+
+
+def test_toposort_matches_reference_vectors():
+    z = G.load("paf.npz")
+    meta = json.loads(str(z["meta_json"]))
+    for nm, t in meta["toposort"].items():
+        assert list(P.toposort_edges([tuple(e) for e in t["edges"]])) == t["order"], nm
+    # KAT of the reference's own test (tests/inference/test_paf_grouping.py:202-239 style): chain
+    assert P.toposort_edges([(0, 1), (1, 2), (2, 3)]) == (0, 1, 2)
+
+
+def _flat(lst, dtype, width=None):
+    if width:
+        return np.concatenate([np.asarray(a).reshape(-1, width) for a in lst]).astype(dtype)
+    return np.concatenate([np.asarray(a).reshape(-1) for a in lst]).astype(dtype)
+
+
+@pytest.mark.parametrize("name", ["chain5", "tree6", "chain13", "rev4"])
+def test_group_batch_matches_reference_on_golden_candidates(name):
+    """Feed the REFERENCE's peaks + scored candidates to the C++ matcher/assembler and compare
+    with the reference's grouped instances (bit-exact membership, exact values)."""
+    z = G.load("paf.npz")
+    meta = json.loads(str(z["meta_json"]))["specs"][name]
+    edges = [tuple(e) for e in meta["edges"]]
+    n_nodes = meta["n_nodes"]
+    pk, pv, pc = G.ragged(z, f"{name}/peaks"), G.ragged(z, f"{name}/vals"), G.ragged(z, f"{name}/chans")
+    ce, cp, cs = G.ragged(z, f"{name}/edge_inds"), G.ragged(z, f"{name}/edge_peak_inds"), G.ragged(z, f"{name}/line_scores")
+    B = len(pk)
+    po = np.concatenate([[0], np.cumsum([len(a) for a in pk])]).astype(np.int32)
+    co = np.concatenate([[0], np.cumsum([len(a) for a in ce])]).astype(np.int32)
+    pairs = _flat(cp, np.int32, 2)
+    kp, vals, scores, n_inst = P.group_batch_host(
+        n_nodes, edges, _flat(pk, np.float32, 2), _flat(pv, np.float32), _flat(pc, np.int32), po, _flat(ce, np.int32), pairs[:, 0], pairs[:, 1],
+        _flat(cs, np.float32), co, 0.25, 0, 32, False,
+    )
+    for b in range(B):
+        ref = G.ragged(z, f"{name}/inst")[b].reshape(-1, n_nodes, 2)
+        assert n_inst[b] == ref.shape[0]
+        got = kp[b, : n_inst[b]]
+        assert np.array_equal(np.isnan(got), np.isnan(ref))
+        assert np.array_equal(np.nan_to_num(got), np.nan_to_num(ref))
+        assert np.array_equal(np.nan_to_num(vals[b, : n_inst[b]]), np.nan_to_num(G.ragged(z, f"{name}/inst_vals")[b]))
+        assert np.array_equal(scores[b, : n_inst[b]], G.ragged(z, f"{name}/inst_scores")[b])
+        assert np.isnan(kp[b, n_inst[b] :]).all()
+
+
+def test_group_batch_matches_oracle_on_random_graphs():
+    """Randomised differential test vs the oracle (ties, low scores, merges, min_instance_peaks)."""
+    rng = np.random.RandomState(3)
+    for trial in range(200):
+        n_nodes = rng.randint(2, 7)
+        # random tree or chain, shuffled edge list
+        edges = [(int(rng.randint(0, i)), i) for i in range(1, n_nodes)]
+        rng.shuffle(edges)
+        if trial % 4 == 0:
+            edges = edges[: max(1, len(edges) - 1)]
+        n_peaks = rng.randint(0, 14)
+        chans = rng.randint(0, n_nodes, size=n_peaks).astype(np.int32)
+        peaks = rng.rand(n_peaks, 2).astype(np.float32) * 100
+        vals = rng.rand(n_peaks).astype(np.float32)
+        e, pr = O.connection_candidates(torch.from_numpy(chans), edges, n_nodes)
+        quant = trial % 3 == 0
+        sc = rng.rand(e.shape[0]).astype(np.float32)
+        if quant:
+            sc = (np.round(sc * 4) / 4).astype(np.float32)  # exact ties
+        mip = [0, 2, 0.5][trial % 3]
+        try:
+            m = O.match_candidates_sample(e, pr, torch.from_numpy(sc), len(edges))
+            topo = O.toposort_edges(edges)
+        except ValueError:
+            continue
+        ref = O.assemble_instances(peaks, vals, chans, *m, n_nodes, edges, topo, mip, 0.25)
+        prn = pr.numpy().astype(np.int32).reshape(-1, 2)
+        kp, v, s, n_inst = P.group_batch_host(
+            n_nodes, edges, peaks, vals, chans, np.array([0, n_peaks], np.int32), e.numpy(), prn[:, 0], prn[:, 1], sc,
+            np.array([0, e.shape[0]], np.int32), 0.25, mip, 16, False,
+        )
+        assert n_inst[0] == ref[0].shape[0], (trial, edges)
+        assert np.array_equal(np.nan_to_num(kp[0, : n_inst[0]], nan=-1), np.nan_to_num(ref[0], nan=-1)), trial
+        assert np.array_equal(np.nan_to_num(v[0, : n_inst[0]], nan=-1), np.nan_to_num(ref[1], nan=-1))
+        assert np.array_equal(s[0, : n_inst[0]], ref[2])
+
+
+def test_model_plan_names_and_param_count():
+    from sleap_nn_amd.architectures.model import Model
+
+    z = G.load("ckpt_bottomup.npz")
+    cfg = G.config(z)
+    m = Model("unet", cfg["backbone"], cfg["heads"], "bottomup")
+    w = G.weights(z)
+    assert set(m.param_shapes) == set(w)  # checkpoint-compatible names
+    for k, v in w.items():
+        assert tuple(m.param_shapes[k]) == tuple(v.shape), k
+    m.load_state_dict({"model." + k: v for k, v in w.items()}, strict=True)
+    with pytest.raises(RuntimeError):
+        m.load_state_dict({k: v for k, v in list(w.items())[:-1]}, strict=True)
+    bb = {"in_channels": 1, "kernel_size": 3, "filters": 16, "filters_rate": 2, "max_stride": 32, "stem_stride": None, "middle_block": True, "up_interpolate": True, "stacks": 1, "convs_per_block": 2, "output_stride": 4}
+    heads = {"confmaps": {"part_names": [str(i) for i in range(13)], "output_stride": 4}, "pafs": {"edges": [[str(i), str(i + 1)] for i in range(12)], "output_stride": 8}}
+    m3 = Model("unet", bb, heads, "bottomup")
+    assert m3.num_parameters() == 7819861
+    assert [h.name for h in m3.heads] == ["MultiInstanceConfmapsHead", "PartAffinityFieldsHead"]
+
+
+def test_backend_protocol_and_layer_type_checks():
+    from sleap_nn_amd.inference.backends import HipBackend, ModelBackend
+    from sleap_nn_amd.inference.layers import PostprocessConfig, PreprocessConfig, SingleInstanceLayer
+
+    class Fake:
+        device = "cuda:0"
+        does_baked_postproc = False
+
+        def __call__(self, x):
+            return {}
+
+        def warmup(self, s):
+            pass
+
+    assert isinstance(Fake(), ModelBackend)
+    with pytest.raises(TypeError):
+        SingleInstanceLayer(backend=object(), output_stride=2)
+    with pytest.raises(ValueError):
+        PreprocessConfig(ensure_rgb=True, ensure_grayscale=True)
+    assert PostprocessConfig(refinement="none").effective_refinement is None
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError):
+            HipBackend(model=None)  # fails loudly without a GPU: no CPU fallback
+    layer = SingleInstanceLayer(backend=Fake(), output_stride=2, max_stride=16)
+    x, info = layer.preprocess(np.zeros((100, 70), dtype=np.uint8))
+    assert tuple(x.shape) == (1, 1, 1, 112, 80) and info.original_size == (100, 70)
+    with pytest.raises(KeyError):
+        layer._extract_confmaps({"a": torch.zeros(1), "b": torch.zeros(1)})
