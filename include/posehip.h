@@ -108,6 +108,14 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
                      int32_t in_channels, int32_t height, int32_t width, void* workspace_dev,
                      int64_t workspace_bytes, float* const* out_dev, void* stream);
 
+/* Per-op timing with HIP events recorded on the forward's own stream (used by bench.py for
+ * the roofline object).  While enabled every forward records one event before each op and
+ * one after the last; ph_model_profile_read waits for the last recorded forward, returns
+ * the milliseconds accumulated per op since profiling was enabled and the number of
+ * forwards they cover. */
+int ph_model_set_profiling(ph_model* m, int32_t enabled);
+int ph_model_profile_read(ph_model* m, double* op_ms, int32_t n_ops, int32_t* n_forwards);
+
 /* Debug/parity helper: copy activation slot `slot` of the last forward (NHWC, padded
  * channels) into an NCHW fp32 device buffer of the logical channel count. */
 int ph_model_read_slot(ph_model* m, int32_t slot, float* out_dev, int64_t out_numel, void* stream);

@@ -41,6 +41,8 @@ SIGNATURES = {
     "ph_model_workspace_bytes": (_i64, [_vp, _i32, _i32, _i32]),
     "ph_model_output_shape": (C.c_int, [_vp, _i32, _i32, _i32, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)]),
     "ph_model_forward": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _i64, C.POINTER(_vp), _vp]),
+    "ph_model_set_profiling": (C.c_int, [_vp, _i32]),
+    "ph_model_profile_read": (C.c_int, [_vp, C.POINTER(C.c_double), _i32, C.POINTER(_i32)]),
     "ph_model_read_slot": (C.c_int, [_vp, _i32, _vp, _i64, _vp]),
     "ph_local_peaks": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _f32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i64, _vp]),
     "ph_global_peaks": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _f32, _i32, _i32, _vp, _vp, _vp]),
@@ -61,6 +63,14 @@ def lib():
             f"{LIB_PATH} is missing: build it with `python -m sleap_nn_amd.build` "
             "(hipcc --offload-arch=gfx950). sleap_nn_amd has no CPU fallback."
         )
+    # libposehip must share ONE HIP runtime with torch (torch bundles its own libamdhip64 with the
+    # same SONAME as /opt/rocm's): load torch's copy first, globally, so the loader binds
+    # libposehip's libamdhip64.so.7 dependency to it whatever the import order was.
+    import torch
+
+    bundled = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+    if os.path.exists(bundled):
+        C.CDLL(bundled, mode=C.RTLD_GLOBAL)
     l = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(l, name)

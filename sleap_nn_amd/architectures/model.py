@@ -196,6 +196,48 @@ class Model:
 
     __call__ = forward
 
+    # -- measurement support ------------------------------------------------------------
+    def set_profiling(self, enabled: bool) -> None:
+        """Per-op HIP-event timing on the forward's stream (bench.py roofline)."""
+        L.check(L.lib().ph_model_set_profiling(self._handle, 1 if enabled else 0))
+
+    def read_profile(self):
+        """-> (list of accumulated ms per op, number of forwards covered)."""
+        n = len(self.ops)
+        arr = (C.c_double * n)()
+        k = C.c_int32()
+        L.check(L.lib().ph_model_profile_read(self._handle, arr, n, C.byref(k)))
+        return list(arr), k.value
+
+    def op_table(self, batch: int, height: int, width: int):
+        """Per op: label, kind, algorithmic FLOPs (2*Cin*Cout*k*k*Hout*Wout*B for convolutions, SURVEY
+        section 8d) and algorithmic HBM bytes (input read once + output written once, logical channels)."""
+        hw = {-1: (height, width)}
+        ch = {-1: self.in_channels}
+        rows = []
+        for op in self.ops:
+            h, w = hw[op.src0]
+            oh, ow = h, w
+            if op.kind == L.OP_POOL:
+                oh, ow = (h + 1) // 2, (w + 1) // 2
+            elif op.kind in (L.OP_UPSAMPLE, L.OP_CONVT):
+                oh, ow = 2 * h, 2 * w
+            cin = op.cin0 + op.cin1
+            cout = op.cout if op.kind not in (L.OP_POOL, L.OP_UPSAMPLE) else op.cin0
+            flops = 0.0
+            if op.kind in (L.OP_CONV, L.OP_INPUT_CONV):
+                flops = 2.0 * cin * cout * op.ksize * op.ksize * oh * ow * batch
+            elif op.kind == L.OP_CONVT:
+                flops = 2.0 * cin * cout * 9 * h * w * batch
+            elif op.kind == L.OP_HEAD:
+                flops = 2.0 * cin * cout * oh * ow * batch
+            in_bytes = (1 if op.src0 < 0 else 4) * op.cin0 * h * w * batch + 4 * op.cin1 * h * w * batch
+            out_bytes = 4 * cout * oh * ow * batch
+            rows.append({"label": op.label.split(".")[-1], "kind": op.kind, "flops": flops, "bytes": float(in_bytes + out_bytes)})
+            if op.kind != L.OP_HEAD:
+                hw[op.dst] = (oh, ow)
+        return rows
+
     def read_activation(self, conv_name: str, batch: int, height_width) -> torch.Tensor:
         """Debug/parity: NCHW copy of the activation a named conv produced in the last forward."""
         slot = self.backbone.labels[conv_name]

@@ -52,6 +52,12 @@ struct ph_model {
   ph::Plan last_plan;
   char* last_ws = nullptr;
   int last_batch = 0;
+  // optional per-op HIP-event timing (ph_model_set_profiling)
+  bool profiling = false;
+  bool events_pending = false;
+  std::vector<hipEvent_t> ev;      // n_ops + 1 events: ev[i] before op i, ev[n_ops] after the last
+  std::vector<double> op_ms;       // accumulated per op
+  int profiled_forwards = 0;
 };
 
 namespace ph {
@@ -151,6 +157,20 @@ static int build_plan(const ph_model* m, int B, int H, int W, Plan& plan) {
   return PH_OK;
 }
 
+static int drain_events(ph_model* m) {
+  if (!m->events_pending) return PH_OK;
+  const size_t n = m->ops.size();
+  PH_HIP_CHECK(hipEventSynchronize(m->ev[n]));
+  for (size_t i = 0; i < n; ++i) {
+    float ms = 0.f;
+    PH_HIP_CHECK(hipEventElapsedTime(&ms, m->ev[i], m->ev[i + 1]));
+    m->op_ms[i] += ms;
+  }
+  m->profiled_forwards += 1;
+  m->events_pending = false;
+  return PH_OK;
+}
+
 }  // namespace ph
 
 using namespace ph;
@@ -231,6 +251,7 @@ ph_model* ph_model_create(const ph_op_desc* ops, int32_t n_ops, const float* con
 void ph_model_destroy(ph_model* m) {
   if (!m) return;
   for (void* p : m->allocs) (void)hipFree(p);
+  for (hipEvent_t e : m->ev) (void)hipEventDestroy(e);
   delete m;
 }
 
@@ -276,8 +297,15 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
   }
   char* ws = static_cast<char*>(workspace_dev);
   auto slot_ptr = [&](int sidx) { return reinterpret_cast<float*>(ws + plan.slots[sidx].offset); };
+  if (m->profiling) {
+    rc = drain_events(m);
+    if (rc != PH_OK) return rc;
+  }
+  size_t op_index = 0;
   for (const PackedOp& op : m->ops) {
     const ph_op_desc& d = op.d;
+    if (m->profiling) PH_HIP_CHECK(hipEventRecord(m->ev[op_index], s));
+    ++op_index;
     switch (d.kind) {
       case PH_OP_INPUT_CONV: {
         PH_REQUIRE(d.cin0 == in_channels, "input has %d channels, network expects %d", in_channels, d.cin0);
@@ -363,9 +391,38 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
     }
     if (rc != PH_OK) return rc;
   }
+  if (m->profiling) {
+    PH_HIP_CHECK(hipEventRecord(m->ev[m->ops.size()], s));
+    m->events_pending = true;
+  }
   m->last_plan = plan;
   m->last_ws = ws;
   m->last_batch = batch;
+  return PH_OK;
+}
+
+int ph_model_set_profiling(ph_model* m, int32_t enabled) {
+  PH_REQUIRE(m, "ph_model_set_profiling: null model");
+  if (enabled && m->ev.empty()) {
+    m->ev.resize(m->ops.size() + 1);
+    for (auto& e : m->ev) PH_HIP_CHECK(hipEventCreate(&e));
+  }
+  if (enabled) {
+    m->op_ms.assign(m->ops.size(), 0.0);
+    m->profiled_forwards = 0;
+    m->events_pending = false;
+  }
+  m->profiling = enabled != 0;
+  return PH_OK;
+}
+
+int ph_model_profile_read(ph_model* m, double* op_ms, int32_t n_ops, int32_t* n_forwards) {
+  PH_REQUIRE(m && op_ms && n_forwards, "ph_model_profile_read: null argument");
+  PH_REQUIRE(n_ops == (int32_t)m->ops.size(), "ph_model_profile_read: model has %d ops", (int)m->ops.size());
+  int rc = drain_events(m);
+  if (rc != PH_OK) return rc;
+  for (int i = 0; i < n_ops; ++i) op_ms[i] = i < (int)m->op_ms.size() ? m->op_ms[i] : 0.0;
+  *n_forwards = m->profiled_forwards;
   return PH_OK;
 }
 

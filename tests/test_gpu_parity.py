@@ -1,0 +1,331 @@
+"""GPU parity tests: the HIP path (through the C ABI) vs the oracle and the golden fixtures.
+
+Tolerances: confidence maps / PAFs within 1e-4 absolute of the reference (north_star);
+peak indices, channels, sample ids, values and grouping membership bit-exact; refined
+coordinates within 1e-5 px (25-term fp32 sums, different summation order than ATen).
+"""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cpu_ref as O
+from tests import _golden as G
+
+pytestmark = pytest.mark.gpu
+
+CMS_ATOL = 1e-4
+DEV = "cuda:0"
+
+
+def _model(cfg, weights):
+    from sleap_nn_amd.architectures.model import Model
+
+    m = Model("unet", cfg["backbone"], cfg["heads"], cfg["model_type"])
+    m.load_state_dict(weights, strict=True)
+    return m.to(DEV)
+
+
+@pytest.mark.parametrize("name", ["unet_tiny_interp.npz", "unet_tiny_trans.npz", "unet_tiny_bu13.npz", "unet_tiny_rgb.npz", "ckpt_bottomup.npz", "ckpt_single_instance.npz"])
+def test_forward_matches_reference_golden(name):
+    z = G.load(name)
+    cfg = G.config(z)
+    m = _model(cfg, G.weights(z))
+    img = torch.from_numpy(z["image"]).squeeze(1).to(DEV)
+    out = m(img)
+    torch.cuda.synchronize()
+    for k in [f for f in z.files if f.startswith("out/")]:
+        ref = torch.from_numpy(z[k])
+        got = out[k[4:]].cpu()
+        assert got.shape == ref.shape
+        err = (got - ref).abs().max().item()
+        assert err <= CMS_ATOL, (k, err)
+    for k in [f for f in z.files if f.startswith("act/")]:
+        ref = torch.from_numpy(z[k])
+        got = m.read_activation(k[4:], ref.shape[0], ref.shape[-2:]).cpu()
+        err = (got - ref).abs().max().item()
+        assert err <= CMS_ATOL, (k, err)
+
+
+def test_forward_float_inputs_and_odd_batch():
+    z = G.load("unet_tiny_interp.npz")
+    cfg = G.config(z)
+    sd = G.weights(z)
+    m = _model(cfg, sd)
+    g = torch.Generator().manual_seed(5)
+    img = torch.randint(0, 256, (3, 1, 40, 56), dtype=torch.uint8, generator=g)
+    ref = O.model_forward(sd, cfg["backbone"], cfg["heads"], cfg["model_type"], img)
+    from sleap_nn_amd.inference.backends import HipBackend
+
+    be = HipBackend(m, DEV)
+    for x in (img.unsqueeze(1), img.float(), img.float() / 255):  # uint8 5-D, float 0..255, float 0..1
+        out = be(x)
+        for k, v in ref.items():
+            assert (out[k].cpu() - v).abs().max().item() <= CMS_ATOL
+
+
+def test_forward_rejects_unaligned_sizes():
+    from sleap_nn_amd._lib import PosehipError
+
+    z = G.load("unet_tiny_interp.npz")
+    m = _model(G.config(z), G.weights(z))
+    with pytest.raises(PosehipError):
+        m(torch.zeros((1, 1, 36, 44), dtype=torch.uint8, device=DEV))  # 36/8 not integral -> concat mismatch
+
+
+def _refine_tol(cms, pts_int, map_inds, patch=5):
+    """Per-peak tolerance for integral refinement: the offsets are ratios of 25-term fp32 sums whose
+    summation order differs from ATen's (which itself depends on the host's SIMD width), so the
+    admissible error grows with the conditioning sum|v| / |sum v| of the patch (maps with negative
+    values can make it large; for real confidence maps it is ~1)."""
+    flat = cms.reshape(-1, cms.shape[-2], cms.shape[-1]).cpu()
+    pad = torch.nn.functional.pad(flat, (patch, patch, patch, patch))
+    tol = []
+    h = patch // 2
+    for (x, y), mi in zip(pts_int.tolist(), map_inds.tolist()):
+        crop = pad[int(mi), int(y) + patch - h : int(y) + patch + h + 1, int(x) + patch - h : int(x) + patch + h + 1]
+        cond = float(crop.abs().sum() / crop.sum().abs().clamp_min(1e-30))
+        tol.append(1e-5 + 4e-6 * cond)
+    return np.asarray(tol)[:, None]
+
+
+def test_local_and_global_peaks_match_reference():
+    from sleap_nn_amd.inference.ops import peaks as HP
+
+    z = G.load("peaks.npz")
+    cases = sorted({k.split("/")[0] for k in z.files if "/" in k})
+    n_checked = 0
+    for c in cases:
+        cms = torch.from_numpy(z[f"{c}/cms"]).to(DEV)
+        for key in sorted({k.rsplit("/", 1)[0] for k in z.files if k.startswith(c + "/local_") or k.startswith(c + "/global_")}):
+            parts = key.split("/")[1].split("_")
+            if parts[0] == "local":
+                if parts[2].startswith("p"):
+                    ps = int(parts[2][1:])
+                    pts, _, sb, sc = HP.find_local_peaks(cms, 0.2, "integral", ps)
+                    rough = z[f"{c}/local_none_0.2/pts"]
+                    tol = _refine_tol(cms, torch.from_numpy(rough), sb.cpu().long() * cms.shape[1] + sc.cpu().long(), ps)
+                    assert (np.abs(pts.cpu().numpy() - z[key + "/pts"]) <= tol + 1e-4 * np.abs(z[key + "/pts"])).all(), key
+                    continue
+                ref = None if parts[1] == "none" else "integral"
+                pts, vals, sb, sc = HP.find_local_peaks(cms, float(parts[2]), ref, 5)
+                assert np.array_equal(sb.cpu().numpy(), z[key + "/sb"]), key
+                assert np.array_equal(sc.cpu().numpy(), z[key + "/sc"]), key
+                assert np.array_equal(vals.cpu().numpy(), z[key + "/vals"]), key
+                if ref is None:
+                    assert np.array_equal(pts.cpu().numpy(), z[key + "/pts"]), key
+                else:
+                    rough = z[key.replace("integral", "none") + "/pts"]
+                    tol = _refine_tol(cms, torch.from_numpy(rough), sb.cpu().long() * cms.shape[1] + sc.cpu().long())
+                    # (+ a relative term: an ill-conditioned patch also inflates the offset itself)
+                    assert (np.abs(pts.cpu().numpy() - z[key + "/pts"]) <= tol + 1e-4 * np.abs(z[key + "/pts"])).all(), key
+            else:
+                ref = None if parts[1] == "none" else "integral"
+                pts, vals = HP.find_global_peaks(cms, float(parts[2]), ref, 5)
+                assert np.array_equal(vals.cpu().numpy(), z[key + "/vals"]), key
+                if ref is None:
+                    assert np.array_equal(pts.cpu().numpy(), z[key + "/pts"], equal_nan=True), key
+                else:
+                    rough = z[key.replace("integral", "none") + "/pts"].reshape(-1, 2)
+                    ok = ~np.isnan(rough[:, 0])
+                    tol = np.full((rough.shape[0], 1), 1e-5)
+                    tol[ok] = _refine_tol(cms, torch.from_numpy(rough[ok]), torch.nonzero(torch.from_numpy(ok)).flatten())
+                    d = np.abs(pts.cpu().numpy().reshape(-1, 2) - z[key + "/pts"].reshape(-1, 2))
+                    assert (np.isnan(d) == np.isnan(rough)).all() and (np.nan_to_num(d) <= tol + 1e-4 * np.abs(np.nan_to_num(z[key + "/pts"].reshape(-1, 2)))).all(), key
+            n_checked += 1
+    assert n_checked >= 20
+
+
+def test_local_peaks_capacity_retry_and_empty():
+    from sleap_nn_amd.inference.ops import peaks as HP
+
+    g = torch.Generator().manual_seed(1)
+    cms = torch.rand((2, 3, 64, 64), generator=g)
+    ref = O.find_local_peaks(cms, 0.2, "integral", 5)
+    xy, vals, sb, sc, counts, _ = HP.find_local_peaks_device(cms.to(DEV), 0.2, "integral", 5, capacity=16)
+    assert int(counts[0]) == ref[0].shape[0] > 16  # overflow is reported, not hidden
+    pts, vals, sb, sc = HP.find_local_peaks(cms.to(DEV), 0.2, "integral", 5)  # retries internally
+    assert np.array_equal(sc.cpu().numpy(), ref[3].numpy()) and np.array_equal(vals.cpu().numpy(), ref[1].numpy())
+    assert np.allclose(pts.cpu().numpy(), ref[0].numpy(), atol=1e-5)
+    e = HP.find_local_peaks(torch.zeros((1, 2, 8, 8), device=DEV), 0.2, "integral", 5)
+    assert e[0].shape == (0, 2) and e[1].shape == (0,)
+
+
+@pytest.mark.parametrize("name", ["chain5", "tree6", "chain13", "rev4"])
+def test_paf_scoring_and_grouping_match_reference(name):
+    from sleap_nn_amd.inference.ops.paf import PAFScorer
+    from sleap_nn_amd.inference.ops.peaks import find_local_peaks
+
+    z = G.load("paf.npz")
+    meta = json.loads(str(z["meta_json"]))["specs"][name]
+    edges = [tuple(e) for e in meta["edges"]]
+    n_nodes = meta["n_nodes"]
+    names = [f"n{i}" for i in range(n_nodes)]
+    sc = PAFScorer(names, [(names[s], names[d]) for s, d in edges], meta["pafs_stride"])
+    assert list(sc.sorted_edge_inds) == z[f"{name}/sorted_edge_inds"].tolist()
+    cms = torch.from_numpy(z[f"{name}/cms"]).to(DEV)
+    pafs = torch.from_numpy(z[f"{name}/pafs"]).to(DEV)
+    pts, vals, sb, ch = find_local_peaks(cms, 0.2, "integral", 5)
+    pts = pts * meta["cms_stride"]
+    B = cms.shape[0]
+    pk = [pts[sb == b] for b in range(B)]
+    pv = [vals[sb == b] for b in range(B)]
+    pc = [ch[sb == b] for b in range(B)]
+    inst, ivals, iscores, e, p, s = sc.predict(pafs.permute(0, 2, 3, 1), pk, pv, pc)
+    for b in range(B):
+        re_, rp_, rs_ = (G.ragged(z, f"{name}/{k}")[b] for k in ("edge_inds", "edge_peak_inds", "line_scores"))
+        pe, pp, ps = e[b].cpu().numpy(), p[b].cpu().numpy(), s[b].cpu().numpy()
+        ob = np.lexsort((rp_[:, 1], rp_[:, 0], re_))  # reference order inside an edge is machine dependent
+        assert np.array_equal(pe, re_[ob]) and np.array_equal(pp, rp_[ob])
+        assert np.allclose(ps, rs_[ob], atol=2e-6, equal_nan=True)
+        ref = G.ragged(z, f"{name}/inst")[b].reshape(-1, n_nodes, 2)
+        got = inst[b].numpy()
+        assert got.shape == ref.shape
+        assert np.array_equal(np.isnan(got), np.isnan(ref))  # grouping membership bit-exact
+        assert np.allclose(got, ref, atol=1e-4, equal_nan=True)
+        assert np.array_equal(np.nan_to_num(ivals[b].numpy()), np.nan_to_num(G.ragged(z, f"{name}/inst_vals")[b]))
+        assert np.allclose(iscores[b].numpy(), G.ragged(z, f"{name}/inst_scores")[b], atol=1e-5)
+
+
+def test_line_sampling_bit_exact_on_awkward_coordinates():
+    """Round-half-even, negative coordinates and clipping (paf.py:177-234 vector from the reference)."""
+    from sleap_nn_amd.inference.ops.paf import PAFScorer
+
+    z = G.load("paf.npz")
+    pk = torch.from_numpy(z["linesubs/peaks"])
+    out = z["linesubs/out"]  # (n, 10, 2, 3) rows, cols, channel
+    H, W = 12, 6
+    # a PAF whose value encodes its own (row, col): x-channel = row*W+col, y-channel = 0
+    base = torch.arange(H * W, dtype=torch.float32).reshape(H, W)
+    # build one sample per candidate pair so that each pair is the only candidate of edge 0
+    epi = z["linesubs/epi"]
+    sc = PAFScorer(["a", "b"], [("a", "b")], pafs_stride=2, max_edge_length_ratio=1e9)
+    for i in range(epi.shape[0]):
+        s, d = int(epi[i, 0]), int(epi[i, 1])
+        if s == d:
+            continue
+        pafs = torch.zeros((1, 2, H, W))
+        pafs[0, 0] = base
+        peaks = [torch.stack([pk[s], pk[d]]).to(DEV)]
+        ch = [torch.tensor([0, 1], dtype=torch.int32, device=DEV)]
+        _, _, ls = sc.score_paf_lines(pafs.to(DEV).permute(0, 2, 3, 1), peaks, ch)
+        vec = pk[d] - pk[s]
+        ux = float(vec[0] / torch.norm(vec))
+        expect = np.mean([float(base[out[i, k, 0, 0], out[i, k, 0, 1]]) * ux for k in range(10)])
+        assert abs(float(ls[0][0]) - expect) <= 1e-4 * max(1.0, abs(expect)), (i, float(ls[0][0]), expect)
+
+
+def _bottomup_layer(cfg, weights, **kw):
+    from sleap_nn_amd.inference.backends import HipBackend
+    from sleap_nn_amd.inference.layers import BottomUpLayer, PostprocessConfig
+    from sleap_nn_amd.inference.ops.paf import PAFScorer
+
+    m = _model(cfg, weights)
+    hc = cfg["heads"]
+    sc = PAFScorer.from_config(hc)
+    return BottomUpLayer(HipBackend(m, DEV), sc, hc["confmaps"]["output_stride"], hc["pafs"]["output_stride"], max_stride=cfg["backbone"]["max_stride"], **kw)
+
+
+def test_bottomup_layer_reproduces_reference_golden():
+    """End to end on the reference's own fixture checkpoint + golden frames
+    (tests/inference/parity_golden/bottomup.pkl)."""
+    z = G.load("ckpt_bottomup.npz")
+    cfg = G.config(z)
+    layer = _bottomup_layer(cfg, G.weights(z))
+    out = layer.predict(torch.from_numpy(z["image"]).squeeze(1))
+    k, v, s = out.pred_keypoints.numpy(), out.pred_peak_values.numpy(), out.instance_scores.numpy()
+    gp, gv, gs = G.ragged(z, "gold_peaks"), G.ragged(z, "gold_vals"), G.ragged(z, "gold_scores")
+    assert k.shape[0] == len(gp)
+    for b in range(k.shape[0]):
+        n = gp[b].shape[0]
+        ref = gp[b].reshape(n, -1, 2)
+        assert np.array_equal(np.isnan(k[b, :n]), np.isnan(ref))
+        assert np.allclose(k[b, :n], ref, atol=1e-3, equal_nan=True)
+        assert np.isnan(k[b, n:]).all()
+        assert np.allclose(v[b, :n], gv[b], atol=CMS_ATOL, equal_nan=True)
+        assert np.allclose(s[b, :n], gs[b], atol=1e-4)
+
+
+def test_single_instance_layer_reproduces_reference_golden():
+    from sleap_nn_amd.inference.backends import HipBackend
+    from sleap_nn_amd.inference.layers import SingleInstanceLayer
+
+    z = G.load("ckpt_single_instance.npz")
+    cfg = G.config(z)
+    m = _model(cfg, G.weights(z))
+    hc = cfg["heads"]["confmaps"]
+    layer = SingleInstanceLayer(HipBackend(m, DEV), hc["output_stride"], max_stride=cfg["backbone"]["max_stride"])
+    out = layer.predict(torch.from_numpy(z["image"]).squeeze(1))
+    # the golden was captured with input scale 0.5 (frames in the fixture are already scaled)
+    k = out.pred_keypoints[:, 0].cpu().numpy() / cfg["preprocessing"]["scale"]
+    assert np.allclose(k, z["gold_peaks"], atol=1e-3, equal_nan=True)
+    assert np.allclose(out.pred_peak_values[:, 0].cpu().numpy(), z["gold_vals"], atol=CMS_ATOL)
+
+
+def test_bottomup_vs_oracle_on_rendered_heads_full_size():
+    """cfg3-sized post-process (13 nodes / 12 edges, 256x256 confmaps, 128x128 PAFs) vs the oracle."""
+    from sleap_nn_amd.inference.layers.bottomup import BottomUpLayer
+    from sleap_nn_amd.inference.ops.paf import PAFScorer
+    from sleap_nn_amd.inference.preprocess_info import PreprocInfo
+
+    n_nodes, size = 13, 1024
+    edges = [(i, i + 1) for i in range(12)]
+    names = [str(i) for i in range(n_nodes)]
+    B = 3
+    cms = torch.stack([O.render_confmaps(O.render_instances(size, n_nodes, 6, 777 + b), size, 4, 2.5 * 4 / 2) for b in range(B)])
+    pafs = torch.stack([O.render_pafs(O.render_instances(size, n_nodes, 6, 777 + b), edges, size, 8, 30.0) for b in range(B)])
+    ref_sc = O.PAFScorerRef(names, [(names[s], names[d]) for s, d in edges], 8)
+    rk, rv, rs = O.bottomup_postprocess(cms, pafs, ref_sc, 4)
+
+    class _NoBackend:
+        device = DEV
+        does_baked_postproc = False
+
+        def __call__(self, x):
+            raise AssertionError
+
+        def warmup(self, s):
+            pass
+
+    layer = BottomUpLayer(_NoBackend(), PAFScorer(names, [(names[s], names[d]) for s, d in edges], 8), 4, 8)
+    out = layer.postprocess({"MultiInstanceConfmapsHead": cms.to(DEV), "PartAffinityFieldsHead": pafs.to(DEV)}, PreprocInfo(eff_scale=torch.ones(B)))
+    k = out.pred_keypoints.numpy()
+    assert k.shape == rk.shape
+    assert np.array_equal(np.isnan(k), np.isnan(rk))
+    assert np.allclose(k, rk, atol=1e-4, equal_nan=True)
+    assert np.array_equal(np.nan_to_num(out.pred_peak_values.numpy()), np.nan_to_num(rv))
+    assert np.allclose(out.instance_scores.numpy(), rs, atol=1e-5, equal_nan=True)
+
+
+def test_max_instances_and_skip_guard():
+    z = G.load("ckpt_bottomup.npz")
+    cfg = G.config(z)
+    img = torch.from_numpy(z["image"]).squeeze(1)
+    layer = _bottomup_layer(cfg, G.weights(z), max_instances=1)
+    out = layer.predict(img)
+    assert out.pred_keypoints.shape[1] == 1
+    full = _bottomup_layer(cfg, G.weights(z)).predict(img)
+    best = np.nanargmax(full.instance_scores.numpy(), axis=1)
+    for b in range(img.shape[0]):
+        assert np.allclose(out.pred_keypoints[b, 0].numpy(), full.pred_keypoints[b, best[b]].numpy(), equal_nan=True)
+    skip = _bottomup_layer(cfg, G.weights(z), max_peaks_per_node=0).predict(img)
+    assert np.isnan(skip.pred_keypoints.numpy()).all()
+
+
+def test_cfg3_network_vs_oracle_one_frame():
+    """The bench network (7.8 M params) on a 256x256 crop: confmaps/PAFs within 1e-4 of the oracle."""
+    from sleap_nn_amd.architectures.model import Model
+
+    bb = {"in_channels": 1, "kernel_size": 3, "filters": 16, "filters_rate": 2, "max_stride": 32, "stem_stride": None, "middle_block": True, "up_interpolate": True, "stacks": 1, "convs_per_block": 2, "output_stride": 4}
+    heads = {"confmaps": {"part_names": [str(i) for i in range(13)], "output_stride": 4}, "pafs": {"edges": [[str(i), str(i + 1)] for i in range(12)], "output_stride": 8}}
+    sd = O.init_state(bb, heads, "bottomup")
+    m = Model("unet", bb, heads, "bottomup")
+    m.load_state_dict(sd)
+    g = torch.Generator().manual_seed(4321)
+    img = torch.randint(0, 256, (2, 1, 256, 256), dtype=torch.uint8, generator=g)
+    ref = O.model_forward(sd, bb, heads, "bottomup", img)
+    out = m.to(DEV)(img.to(DEV))
+    for k, v in ref.items():
+        err = (out[k].cpu() - v).abs().max().item()
+        assert err <= CMS_ATOL, (k, err, v.abs().max().item())
