@@ -1,0 +1,69 @@
+"""Data-parallel sharding of a frame stream across the GPUs of one node.
+
+The hot path has no cross-frame state, so multi-GPU inference is *replicas + sharding*: one
+process per GPU (``torch.distributed``; backend ``nccl`` = RCCL on ROCm, ``gloo`` in CPU tests),
+every rank holds the full weights (31 MB at cfg3), rank r processes the contiguous chunk
+``[r*ceil(n/G), (r+1)*ceil(n/G))`` of each global batch, and results are gathered on the host in
+rank order.  No collective sits on the data path; the gather moves only the final NaN-padded
+keypoints.  The reference has no multi-GPU inference (predictor.py:925-931).
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+from sleap_nn_amd.inference.outputs import Outputs
+
+
+def shard_bounds(n_items: int, world_size: int, rank: int) -> Tuple[int, int]:
+    """Contiguous, balanced (sizes differ by at most 1) chunk of ``range(n_items)`` for ``rank``."""
+    if world_size <= 0 or not (0 <= rank < world_size):
+        raise ValueError(f"bad rank/world_size {rank}/{world_size}")
+    base, rem = divmod(n_items, world_size)
+    start = rank * base + min(rank, rem)
+    return start, start + base + (1 if rank < rem else 0)
+
+
+def _pad_instances(t: torch.Tensor, n_inst: int) -> torch.Tensor:
+    if t.shape[1] == n_inst:
+        return t
+    pad = torch.full((t.shape[0], n_inst - t.shape[1], *t.shape[2:]), float("nan"), dtype=t.dtype)
+    return torch.cat([t, pad], dim=1)
+
+
+def gather_outputs(local: Optional[Outputs], group=None) -> Optional[List[Outputs]]:
+    """Gather per-rank ``Outputs`` (slimmed, host tensors) to rank 0 in rank order."""
+    payload = local.slim() if local is not None else None
+    if not dist.is_available() or not dist.is_initialized():
+        return [payload]
+    world = dist.get_world_size(group)
+    gathered = [None] * world if dist.get_rank(group) == 0 else None
+    dist.gather_object(payload, gathered, dst=0, group=group)
+    return gathered
+
+
+def merge_outputs(parts: List[Optional[Outputs]]) -> Outputs:
+    """Concatenate rank-ordered shards along the batch axis, NaN-padding the instance axis."""
+    parts = [p for p in parts if p is not None and p.pred_keypoints is not None and p.pred_keypoints.shape[0] > 0]
+    if not parts:
+        return Outputs()
+    n_inst = max(p.pred_keypoints.shape[1] for p in parts)
+    kp = torch.cat([_pad_instances(p.pred_keypoints, n_inst) for p in parts])
+    vals = torch.cat([_pad_instances(p.pred_peak_values, n_inst) for p in parts])
+    scores = None
+    if all(p.instance_scores is not None for p in parts):
+        scores = torch.cat([_pad_instances(p.instance_scores, n_inst) for p in parts])
+    return Outputs(pred_keypoints=kp, pred_peak_values=vals, instance_scores=scores)
+
+
+def predict_sharded(layer, frames, group=None) -> Optional[Outputs]:
+    """Run ``layer.predict`` on this rank's shard of ``frames`` (B, ...) and return the merged
+    result on rank 0 (``None`` elsewhere)."""
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    a, b = shard_bounds(len(frames), world, rank)
+    local = layer.predict(frames[a:b]) if b > a else None
+    parts = gather_outputs(local, group)
+    return merge_outputs(parts) if rank == 0 else None

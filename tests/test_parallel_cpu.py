@@ -1,0 +1,74 @@
+"""World-size-2 gloo test of the frame sharding + rank-ordered gather (no GPU needed: the layer is
+a host-side stand-in; the data path itself has no collective)."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from sleap_nn_amd.inference.outputs import Outputs
+from sleap_nn_amd.parallel import merge_outputs, predict_sharded, shard_bounds
+
+
+def test_shard_bounds_cover_and_balance():
+    for n in (0, 1, 7, 32, 33):
+        for w in (1, 2, 3, 8):
+            spans = [shard_bounds(n, w, r) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+class _FakeLayer:
+    """Deterministic stand-in: frame value v -> v instances-worth of keypoints."""
+
+    def predict(self, frames):
+        B = frames.shape[0]
+        n_inst = int(frames.reshape(B, -1)[:, 0].max().item()) + 1
+        kp = torch.full((B, n_inst, 3, 2), float("nan"))
+        for b in range(B):
+            k = int(frames[b].reshape(-1)[0])
+            kp[b, : k + 1] = float(k)
+        return Outputs(pred_keypoints=kp, pred_peak_values=kp[..., 0].clone(), instance_scores=kp[..., 0, 0].clone())
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    frames = torch.arange(7).reshape(7, 1, 1, 1).float()
+    out = predict_sharded(_FakeLayer(), frames)
+    if rank == 0:
+        q.put(out.pred_keypoints.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_predict_sharded_world2_gloo():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    kp = q.get()
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    ref = _FakeLayer().predict(torch.arange(7).reshape(7, 1, 1, 1).float()).pred_keypoints.numpy()
+    assert kp.shape == ref.shape
+    assert np.array_equal(np.nan_to_num(kp, nan=-1), np.nan_to_num(ref, nan=-1))  # rank order == frame order
+
+
+def test_merge_outputs_pads_instances():
+    a = Outputs(pred_keypoints=torch.zeros(2, 1, 3, 2), pred_peak_values=torch.zeros(2, 1, 3), instance_scores=torch.zeros(2, 1))
+    b = Outputs(pred_keypoints=torch.ones(1, 3, 3, 2), pred_peak_values=torch.ones(1, 3, 3), instance_scores=torch.ones(1, 3))
+    m = merge_outputs([a, None, b])
+    assert m.pred_keypoints.shape == (3, 3, 3, 2)
+    assert torch.isnan(m.pred_keypoints[:2, 1:]).all() and (m.pred_keypoints[2] == 1).all()
