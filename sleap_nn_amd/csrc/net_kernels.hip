@@ -43,6 +43,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(ConvArgs a) {
   float* ldsA = lds;                            // HALO_H*HALO_W rows of LROW
   float* ldsB = lds + HALO_H * HALO_W * LROW;   // 9*BN rows of LROW
   constexpr int NT = BN / 32;
+  constexpr int A_ITEMS = HALO_H * HALO_W * 4;        // 16-B pieces of the input halo per chunk
+  constexpr int A_SLOTS = (A_ITEMS + 255) / 256;      // 6
+  constexpr int B_ITEMS = 9 * BN * 4;                 // 16-B pieces of the weight panel per chunk
+  constexpr int B_SLOTS = (B_ITEMS + 255) / 256;      // 9 (BN=64) / 5 (BN=32)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -70,10 +74,26 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(ConvArgs a) {
   const int nchunks = chunks0 + chunks1;
   const float* wbase = a.wpack + (size_t)ntile * nchunks * (9 * BN * KC);
 
-  const int lx = lane & 31;
-  const int lh = lane >> 5;
+  // ---- per-thread staging plan, fixed for the whole K loop.  Item i = tid + 256*s is the
+  // 16-B piece q = i&3 (= tid&3) of halo pixel i>>2.  Out-of-image pixels load a clamped
+  // (valid) address and are zeroed by a select afterwards: no branch around any load, so all
+  // loads of a chunk are in flight together (a branch per load would serialise them).
+  const int q4 = (tid & 3) * 4;
+  int a_pix[A_SLOTS];      // clamped pixel index (b*H + y)*W + x
+  unsigned a_ok = 0;       // bit s: pixel inside the image
+#pragma unroll
+  for (int s = 0; s < A_SLOTS; ++s) {
+    const int pix = (tid >> 2) + 64 * s;
+    const int hy = pix / HALO_W, hx = pix - hy * HALO_W;
+    const int gy = y0 + hy - 1, gx = x0 + hx - 1;
+    const bool in = (pix < HALO_H * HALO_W) && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+    a_ok |= (in ? 1u : 0u) << s;
+    const int cy = min(max(gy, 0), a.H - 1), cx = min(max(gx, 0), a.W - 1);
+    a_pix[s] = (b * a.H + cy) * a.W + cx;
+  }
 
-  for (int ch = 0; ch < nchunks; ++ch) {
+  f32x4 ra[A_SLOTS], rb[B_SLOTS];
+  auto prefetch = [&](int ch) {
     const float* src;
     int cp, coff;
     if (ch < chunks0) {
@@ -85,23 +105,38 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(ConvArgs a) {
       cp = a.c1p;
       coff = (ch - chunks0) * KC;
     }
-    // ---- stage input halo (zero outside the image)
-    for (int i = tid; i < HALO_H * HALO_W * 4; i += 256) {
-      const int pix = i >> 2, q = i & 3;
-      const int hy = pix / HALO_W, hx = pix - hy * HALO_W;
-      const int gy = y0 + hy - 1, gx = x0 + hx - 1;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
-        v = *reinterpret_cast<const f32x4*>(src + ((size_t)(b * a.H + gy) * a.W + gx) * cp + coff + q * 4);
-      *reinterpret_cast<f32x4*>(ldsA + pix * LROW + q * 4) = v;
-    }
-    // ---- stage weight panel [tap][n][16]
+#pragma unroll
+    for (int s = 0; s < A_SLOTS; ++s) ra[s] = *reinterpret_cast<const f32x4*>(src + (size_t)a_pix[s] * cp + coff + q4);
     const float* wsrc = wbase + (size_t)ch * (9 * BN * KC);
-    for (int i = tid; i < 9 * BN * 4; i += 256) {
-      const int row = i >> 2, q = i & 3;
-      *reinterpret_cast<f32x4*>(ldsB + row * LROW + q * 4) = *reinterpret_cast<const f32x4*>(wsrc + i * 4);
+#pragma unroll
+    for (int s = 0; s < B_SLOTS; ++s) {
+      const int i = min(tid + 256 * s, B_ITEMS - 1);
+      rb[s] = *reinterpret_cast<const f32x4*>(wsrc + i * 4);
     }
+  };
+  auto commit = [&]() {
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < A_SLOTS; ++s) {
+      const int pix = (tid >> 2) + 64 * s;
+      if (A_ITEMS % 256 == 0 || pix < HALO_H * HALO_W)
+        *reinterpret_cast<f32x4*>(ldsA + pix * LROW + q4) = ((a_ok >> s) & 1u) ? ra[s] : z;
+    }
+#pragma unroll
+    for (int s = 0; s < B_SLOTS; ++s) {
+      const int row = (tid >> 2) + 64 * s;
+      if (B_ITEMS % 256 == 0 || row < 9 * BN) *reinterpret_cast<f32x4*>(ldsB + row * LROW + q4) = rb[s];
+    }
+  };
+
+  const int lx = lane & 31;
+  const int lh = lane >> 5;
+
+  prefetch(0);
+  for (int ch = 0; ch < nchunks; ++ch) {
+    commit();          // waits for the chunk's loads, fills LDS
     __syncthreads();
+    if (ch + 1 < nchunks) prefetch(ch + 1);  // next chunk's HBM/L2 latency hides under the MFMAs below
     // ---- 9 taps x 2 channel groups x 4 MFMA k-steps
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
