@@ -63,7 +63,11 @@ enum ph_op_kind {
   PH_OP_POOL = 3,       /* 2x2/2 max pool, zero pad bottom/right when odd (architectures/common.py)     */
   PH_OP_UPSAMPLE = 4,   /* bilinear x2, align_corners=False (encoder_decoder.py:431-435)                */
   PH_OP_CONVT = 5,      /* ConvTranspose2d(k3,s2,p1,op1) + bias (+ReLU) (encoder_decoder.py:439-461)    */
-  PH_OP_HEAD = 6        /* 1x1 conv + bias (+sigmoid) -> NCHW fp32 output #out_index (heads.py:58-67)   */
+  PH_OP_HEAD = 6,       /* 1x1 conv + bias (+sigmoid) -> NCHW fp32 output #out_index (heads.py:58-67)   */
+  PH_OP_STEM = 7        /* fused first encoder block: image -> /255 -> conv3x3+ReLU (weight/bias) ->
+                           conv3x3+ReLU (weight2/bias2, cout <= 16) -> [full-res NHWC slot dst, if >= 0]
+                           -> 2x2 max pool -> NHWC slot dst2.  One launch, the two full-resolution
+                           activations never touch HBM unless dst >= 0.                               */
 };
 
 #define PH_FLAG_RELU 1
@@ -82,6 +86,10 @@ typedef struct ph_op_desc {
   int32_t weight;    /* index into the weights[] array of ph_model_create, or -1     */
   int32_t bias;      /* index into the weights[] array, or -1                        */
   int32_t out_index; /* PH_OP_HEAD: which output pointer receives the result         */
+  int32_t dst2;      /* PH_OP_STEM: pooled output slot                               */
+  int32_t weight2;   /* PH_OP_STEM: second conv weight index                         */
+  int32_t bias2;     /* PH_OP_STEM: second conv bias index                           */
+  int32_t cmid;      /* PH_OP_STEM: channels between the two convs (<= 16)           */
 } ph_op_desc;
 
 typedef struct ph_model ph_model;

@@ -14,12 +14,12 @@ LIB_PATH = os.path.join(_HERE, "lib", "libposehip.so")
 PH_OK = 0
 PH_E_INVALID, PH_E_HIP, PH_E_CAPACITY, PH_E_INFEASIBLE, PH_E_WORKSPACE = -1, -2, -3, -4, -5
 
-OP_INPUT_CONV, OP_CONV, OP_POOL, OP_UPSAMPLE, OP_CONVT, OP_HEAD = 1, 2, 3, 4, 5, 6
+OP_INPUT_CONV, OP_CONV, OP_POOL, OP_UPSAMPLE, OP_CONVT, OP_HEAD, OP_STEM = 1, 2, 3, 4, 5, 6, 7
 FLAG_RELU, FLAG_SIGMOID = 1, 2
 
 
 class OpDesc(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in ("kind", "src0", "src1", "dst", "cin0", "cin1", "cout", "ksize", "flags", "weight", "bias", "out_index")]
+    _fields_ = [(n, C.c_int32) for n in ("kind", "src0", "src1", "dst", "cin0", "cin1", "cout", "ksize", "flags", "weight", "bias", "out_index", "dst2", "weight2", "bias2", "cmid")]
 
 
 class PosehipError(RuntimeError):

@@ -42,6 +42,7 @@ class Model:
 
         self.ops: List[OpSpec] = list(self.backbone.ops)
         self.param_shapes = dict(self.backbone.param_shapes)
+        self._head_ops_start = len(self.ops)
         for i, head in enumerate(self.heads):
             s2f = self.backbone.decoder_stride_to_filters
             if head.output_stride not in self.backbone.decoder_slot_of_stride:
@@ -60,11 +61,36 @@ class Model:
             self.param_shapes[name + ".bias"] = (head.channels,)
             flags = L.FLAG_SIGMOID if isinstance(head, ClassMapsHead) else 0
             self.ops.append(OpSpec(L.OP_HEAD, src, -1, -1, cin, 0, head.channels, 1, flags, name + ".weight", name + ".bias", out_index=i, label=name))
+        self.unfused_ops = list(self.ops)
+        self.ops = self._fuse_stem(self.ops)
         self._state: Dict[str, torch.Tensor] = {k: torch.zeros(v, dtype=torch.float32) for k, v in self.param_shapes.items()}
         self._handle = None
         self._handle_device: Optional[torch.device] = None
         self._workspace: Optional[torch.Tensor] = None
         self.device = torch.device("cpu")
+
+    @staticmethod
+    def _fuse_stem(ops: List[OpSpec]) -> List[OpSpec]:
+        """Plan-level fusion of the first encoder block: INPUT_CONV -> CONV -> POOL becomes one
+        PH_OP_STEM launch when both convs have <= 16 filters (the full-resolution activations then
+        never round-trip through HBM; the full-res output is still written if a decoder block or a
+        head reads it)."""
+        if len(ops) < 3:
+            return ops
+        a, b, c = ops[0], ops[1], ops[2]
+        ok = (
+            a.kind == L.OP_INPUT_CONV and b.kind == L.OP_CONV and c.kind == L.OP_POOL and b.src0 == a.dst and b.src1 < 0
+            and c.src0 == b.dst and a.cout <= 16 and b.cout <= 16 and a.cin0 in (1, 3) and a.ksize == 3 and b.ksize == 3
+            and not any(o.src0 == a.dst or o.src1 == a.dst for o in ops[2:])
+        )
+        if not ok:
+            return ops
+        full_needed = any(o.src0 == b.dst or o.src1 == b.dst for o in ops[3:])
+        fused = OpSpec(
+            L.OP_STEM, -1, -1, b.dst if full_needed else -1, a.cin0, 0, b.cout, 3, L.FLAG_RELU, a.weight, a.bias,
+            label=b.label + "+pool(fused stem)", dst2=c.dst, weight2=b.weight, bias2=b.bias, cmid=a.cout,
+        )
+        return [fused] + ops[3:]
 
     @classmethod
     def from_config(cls, backbone_type, backbone_config, head_configs, model_type) -> "Model":
@@ -127,6 +153,9 @@ class Model:
             d.weight = index[op.weight] if op.weight else -1
             d.bias = index[op.bias] if op.bias else -1
             d.out_index = op.out_index
+            d.dst2, d.cmid = op.dst2, op.cmid
+            d.weight2 = index[op.weight2] if op.weight2 else -1
+            d.bias2 = index[op.bias2] if op.bias2 else -1
         tensors = [self._state[k].contiguous() for k in keys]
         ptrs = (C.c_void_p * len(keys))(*[t.data_ptr() for t in tensors])
         numel = (C.c_int64 * len(keys))(*[t.numel() for t in tensors])
@@ -217,6 +246,16 @@ class Model:
         rows = []
         for op in self.ops:
             h, w = hw[op.src0]
+            if op.kind == L.OP_STEM:
+                f0 = 2.0 * op.cin0 * op.cmid * 9 * h * w * batch
+                f1 = 2.0 * op.cmid * op.cout * 9 * h * w * batch
+                ph, pw = (h + 1) // 2, (w + 1) // 2
+                byt = op.cin0 * h * w * batch + 4 * op.cout * ph * pw * batch + (4 * op.cout * h * w * batch if op.dst >= 0 else 0)
+                rows.append({"label": op.label.split(".")[-1], "kind": op.kind, "flops": f0 + f1, "mfma_flops": f1, "bytes": float(byt)})
+                if op.dst >= 0:
+                    hw[op.dst] = (h, w)
+                hw[op.dst2] = (ph, pw)
+                continue
             oh, ow = h, w
             if op.kind == L.OP_POOL:
                 oh, ow = (h + 1) // 2, (w + 1) // 2
@@ -241,7 +280,9 @@ class Model:
     def read_activation(self, conv_name: str, batch: int, height_width) -> torch.Tensor:
         """Debug/parity: NCHW copy of the activation a named conv produced in the last forward."""
         slot = self.backbone.labels[conv_name]
-        op = next(o for o in self.ops if o.dst == slot)
+        op = next((o for o in self.ops if o.dst == slot), None)
+        if op is None:
+            raise KeyError(f"activation of {conv_name} is fused away (it never exists in HBM)")
         h, w = height_width
         out = torch.empty((batch, op.cout, h, w), dtype=torch.float32, device=self._handle_device)
         L.check(L.lib().ph_model_read_slot(self._handle, slot, C.c_void_p(out.data_ptr()), out.numel(), L.current_stream_ptr()))

@@ -30,6 +30,10 @@ class OpSpec:
     bias: Optional[str] = None
     out_index: int = -1
     label: str = ""
+    dst2: int = -1
+    weight2: Optional[str] = None
+    bias2: Optional[str] = None
+    cmid: int = 0
 
 
 @dataclass

@@ -29,6 +29,8 @@ struct PackedOp {
   ph_op_desc d;
   float* w_dev = nullptr;
   float* b_dev = nullptr;
+  float* w2_dev = nullptr;
+  float* b2_dev = nullptr;
   int bn = 0;
 };
 
@@ -126,6 +128,19 @@ static int build_plan(const ph_model* m, int B, int H, int W, Plan& plan) {
       w = plan.slots[d.src0].w;
     }
     if (d.kind == PH_OP_HEAD) continue;
+    if (d.kind == PH_OP_STEM) {
+      PH_REQUIRE(d.src0 < 0, "stem op must read the network input");
+      PH_REQUIRE(d.dst2 >= 0 && d.dst2 < m->n_slots && d.dst < m->n_slots, "bad stem slots");
+      if (d.dst >= 0) {
+        SlotShape& f = plan.slots[d.dst];
+        f.c = d.cout; f.cp = 16; f.h = h; f.w = w; f.offset = off;
+        off += align_up((int64_t)B * h * w * 16 * 4, 256);
+      }
+      SlotShape& p = plan.slots[d.dst2];
+      p.c = d.cout; p.cp = 16; p.h = (h + 1) / 2; p.w = (w + 1) / 2; p.offset = off;
+      off += align_up((int64_t)B * p.h * p.w * 16 * 4, 256);
+      continue;
+    }
     int oh = h, ow = w;
     if (d.kind == PH_OP_POOL) {
       oh = (h + 1) / 2;
@@ -200,7 +215,31 @@ ph_model* ph_model_create(const ph_op_desc* ops, int32_t n_ops, const float* con
     op.d = ops[i];
     const ph_op_desc& d = op.d;
     const bool has_w = d.kind == PH_OP_INPUT_CONV || d.kind == PH_OP_CONV || d.kind == PH_OP_CONVT || d.kind == PH_OP_HEAD;
-    if (has_w) {
+    if (d.kind == PH_OP_STEM) {
+      if (d.ksize != 3 || d.cmid < 1 || d.cmid > 16 || d.cout < 1 || d.cout > 16 || (d.cin0 != 1 && d.cin0 != 3))
+        return fail("fused stem needs kernel 3, 1 or 3 input channels and <= 16 filters", i);
+      const int idx[4] = {d.weight, d.bias, d.weight2, d.bias2};
+      for (int k : idx)
+        if (k < 0 || k >= n_weights) return fail("weight index out of range", i);
+      if (weight_numel[d.weight] != (int64_t)d.cmid * d.cin0 * 9 || weight_numel[d.bias] != d.cmid ||
+          weight_numel[d.weight2] != (int64_t)d.cout * d.cmid * 9 || weight_numel[d.bias2] != d.cout)
+        return fail("stem weight size mismatch", i);
+      const float *w0 = weights[d.weight], *b0 = weights[d.bias], *w1 = weights[d.weight2], *b1 = weights[d.bias2];
+      std::vector<float> p0((size_t)9 * d.cin0 * 16, 0.f), pb0(16, 0.f), p1((size_t)9 * 16 * 16, 0.f), pb1(16, 0.f);
+      for (int co = 0; co < d.cmid; ++co)
+        for (int ci = 0; ci < d.cin0; ++ci)
+          for (int tap = 0; tap < 9; ++tap) p0[((size_t)tap * d.cin0 + ci) * 16 + co] = w0[((size_t)co * d.cin0 + ci) * 9 + tap];
+      for (int co = 0; co < d.cout; ++co)
+        for (int ci = 0; ci < d.cmid; ++ci)
+          for (int tap = 0; tap < 9; ++tap) p1[((size_t)tap * 16 + co) * 16 + ci] = w1[((size_t)co * d.cmid + ci) * 9 + tap];
+      std::memcpy(pb0.data(), b0, d.cmid * sizeof(float));
+      std::memcpy(pb1.data(), b1, d.cout * sizeof(float));
+      if (upload(m, p0, &op.w_dev) != PH_OK || upload(m, pb0, &op.b_dev) != PH_OK || upload(m, p1, &op.w2_dev) != PH_OK ||
+          upload(m, pb1, &op.b2_dev) != PH_OK) {
+        ph_model_destroy(m);
+        return nullptr;
+      }
+    } else if (has_w) {
       if (d.weight < 0 || d.weight >= n_weights || d.bias >= n_weights) return fail("weight index out of range", i);
       const float* w = weights[d.weight];
       const float* b = d.bias >= 0 ? weights[d.bias] : nullptr;
@@ -322,6 +361,24 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
         a.W = width;
         a.relu = (d.flags & PH_FLAG_RELU) ? 1 : 0;
         rc = launch_input_conv(a, s);
+        break;
+      }
+      case PH_OP_STEM: {
+        PH_REQUIRE(d.cin0 == in_channels, "input has %d channels, network expects %d", in_channels, d.cin0);
+        StemArgs a;
+        a.src = input_dev;
+        a.w0 = op.w_dev;
+        a.b0 = op.b_dev;
+        a.w1 = op.w2_dev;
+        a.b1 = op.b2_dev;
+        a.dst_full = d.dst >= 0 ? slot_ptr(d.dst) : nullptr;
+        a.dst_pool = slot_ptr(d.dst2);
+        a.dtype = in_dtype;
+        a.cin = d.cin0;
+        a.B = batch;
+        a.H = height;
+        a.W = width;
+        rc = launch_stem(a, s);
         break;
       }
       case PH_OP_CONV: {

@@ -28,6 +28,18 @@ struct InputConvArgs {
   int cin, coutp, B, H, W, relu;
 };
 
+struct StemArgs {
+  const void* src;     // NCHW uint8 / float image
+  const float* w0;     // [tap][cin][16] first conv (channels padded to 16)
+  const float* b0;     // [16]
+  const float* w1;     // [tap][n=16][16] second conv, k contiguous
+  const float* b1;     // [16]
+  float* dst_full;     // NHWC 16 full resolution or nullptr
+  float* dst_pool;     // NHWC 16, ceil(H/2) x ceil(W/2)
+  int dtype, cin, B, H, W;
+};
+
+int launch_stem(const StemArgs& a, hipStream_t s);
 int prepare_kernels();
 int conv_lds_bytes(int bn);
 int launch_conv3x3(const ConvArgs& a, hipStream_t s);

@@ -203,6 +203,161 @@ int launch_conv3x3(const ConvArgs& a, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------------------
+// K0f: fused first encoder block (the HBM-heaviest part of the network, 16 channels at full
+// resolution): image tile -> /255 -> conv3x3(Cin->16)+ReLU computed straight into the LDS A
+// tile (it never exists in HBM) -> conv3x3(16->16) on v_mfma_f32_16x16x4_f32 (N = 16 exactly:
+// no padded half tile) -> bias + ReLU -> optional full-res store -> 2x2 max pool in registers
+// -> pooled NHWC store.  Per frame this reads 1 B/px and writes 16 B/px instead of the
+// unfused 64+64+64+64+16 B/px.
+//   Tile: 8 rows x 32 cols of conv outputs per 256-thread block; wave w owns rows 2w, 2w+1 as
+//   four 16-pixel M tiles.  16x16x4 maps: A[i = lane&15][k = lane>>4], B[k = lane>>4][n = lane&15],
+//   D: col = lane&15 (channel), row = 4*(lane>>4) + reg (pixel).  One ds_read_b128 per operand
+//   feeds 4 MFMAs (lane group g reads channels 4g..4g+3; MFMA j contracts {j, 4+j, 8+j, 12+j}).
+// ---------------------------------------------------------------------------------------
+template <int CIN>
+__global__ __launch_bounds__(256, 2) void stem_fused_kernel(StemArgs a) {
+  constexpr int IMG_W = TW + 4, IMG_H = TH + 4;   // image patch incl. both halos
+  __shared__ __attribute__((aligned(16))) float sA[HALO_H * HALO_W * LROW];   // conv0 output (conv1 input halo)
+  __shared__ __attribute__((aligned(16))) float sB[9 * 16 * LROW];            // conv1 weights [tap][n][16+pad]
+  __shared__ float sImg[CIN * IMG_H * IMG_W];
+  __shared__ float sW0[9 * CIN * 16 + 16];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;
+  int t = blockIdx.x;
+  const int tx = t % tiles_x;
+  t /= tiles_x;
+  const int ty = t % tiles_y;
+  const int b = t / tiles_y;
+  const int x0 = tx * TW, y0 = ty * TH;
+
+  // ---- stage: image patch (normalised, zero outside), conv0 weights+bias, conv1 weights
+  for (int i = tid; i < CIN * IMG_H * IMG_W; i += 256) {
+    const int c = i / (IMG_H * IMG_W), r = i - c * (IMG_H * IMG_W);
+    const int iy = r / IMG_W, ix = r - iy * IMG_W;
+    const int gy = y0 + iy - 2, gx = x0 + ix - 2;
+    float v = 0.f;
+    if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
+      const size_t o = (((size_t)b * CIN + c) * a.H + gy) * a.W + gx;
+      if (a.dtype == 0)
+        v = (float)reinterpret_cast<const uint8_t*>(a.src)[o] / 255.0f;
+      else {
+        v = reinterpret_cast<const float*>(a.src)[o];
+        if (a.dtype == 2) v = v / 255.0f;
+      }
+    }
+    sImg[i] = v;
+  }
+  for (int i = tid; i < 9 * CIN * 16; i += 256) sW0[i] = a.w0[i];
+  if (tid < 16) sW0[9 * CIN * 16 + tid] = a.b0[tid];
+  for (int i = tid; i < 9 * 16 * 4; i += 256) {
+    const int row = i >> 2, q = i & 3;
+    *reinterpret_cast<f32x4*>(sB + row * LROW + q * 4) = *reinterpret_cast<const f32x4*>(a.w1 + i * 4);
+  }
+  __syncthreads();
+
+  // ---- conv0 + ReLU into the A tile; item = (halo pixel, 4-channel group q = tid&3)
+  {
+    const int q4 = (tid & 3) * 4;
+    for (int pix = tid >> 2; pix < HALO_H * HALO_W; pix += 64) {
+      const int hy = pix / HALO_W, hx = pix - hy * HALO_W;
+      const int gy = y0 + hy - 1, gx = x0 + hx - 1;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {  // outside the image = conv1's zero padding
+        acc = *reinterpret_cast<const f32x4*>(sW0 + 9 * CIN * 16 + q4);
+#pragma unroll
+        for (int c = 0; c < CIN; ++c)
+#pragma unroll
+          for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+              const float v = sImg[(c * IMG_H + hy + ky) * IMG_W + hx + kx];
+              const f32x4 w = *reinterpret_cast<const f32x4*>(sW0 + ((ky * 3 + kx) * CIN + c) * 16 + q4);
+              acc += v * w;
+            }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[k] = fmaxf(acc[k], 0.f);
+      }
+      *reinterpret_cast<f32x4*>(sA + pix * LROW + q4) = acc;
+    }
+  }
+  __syncthreads();
+
+  // ---- conv1 on the matrix cores
+  const int li = lane & 15, lg = lane >> 4;
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) acc[m][h] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) {
+    const int ky = tap / 3, kx = tap - ky * 3;
+    const f32x4 bf = *reinterpret_cast<const f32x4*>(sB + (tap * 16 + li) * LROW + lg * 4);
+    f32x4 af[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+        af[m][h] = *reinterpret_cast<const f32x4*>(sA + ((2 * wave + m + ky) * HALO_W + h * 16 + li + kx) * LROW + lg * 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) acc[m][h] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m][h][j], bf[j], acc[m][h], 0, 0, 0);
+  }
+
+  // ---- epilogue: bias + ReLU, optional full-res store, 2x2 max pool (out-of-image = 0, the
+  // reference's zero pad; values are >= 0 after ReLU so max() is unaffected)
+  const float bias = a.b1[li];
+  const int Hp = (a.H + 1) / 2, Wp = (a.W + 1) / 2;
+  float v[2][2][4];
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    const int y = y0 + 2 * wave + m;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int x = x0 + h * 16 + 4 * lg + r;
+        float o = fmaxf(acc[m][h][r] + bias, 0.f);
+        const bool in = (y < a.H) && (x < a.W);
+        if (in && a.dst_full) a.dst_full[(((size_t)b * a.H + y) * a.W + x) * 16 + li] = o;
+        v[m][h][r] = in ? o : 0.f;
+      }
+  }
+  const int py = (y0 >> 1) + wave;
+  if (py < Hp) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int pr = 0; pr < 2; ++pr) {
+        const int px = (x0 >> 1) + h * 8 + 2 * lg + pr;
+        if (px < Wp) {
+          const float o = fmaxf(fmaxf(v[0][h][2 * pr], v[0][h][2 * pr + 1]), fmaxf(v[1][h][2 * pr], v[1][h][2 * pr + 1]));
+          a.dst_pool[(((size_t)b * Hp + py) * Wp + px) * 16 + li] = o;
+        }
+      }
+  }
+}
+
+int launch_stem(const StemArgs& a, hipStream_t s) {
+  const int tiles = ((a.W + TW - 1) / TW) * ((a.H + TH - 1) / TH) * a.B;
+  if (a.cin == 1)
+    hipLaunchKernelGGL(stem_fused_kernel<1>, dim3(tiles), dim3(256), 0, s, a);
+  else if (a.cin == 3)
+    hipLaunchKernelGGL(stem_fused_kernel<3>, dim3(tiles), dim3(256), 0, s, a);
+  else {
+    set_error("fused stem supports 1 or 3 input channels, got %d", a.cin);
+    return PH_E_INVALID;
+  }
+  PH_HIP_CHECK(hipGetLastError());
+  return PH_OK;
+}
+
+// ---------------------------------------------------------------------------------------
 // K0: first convolution straight from the NCHW image (uint8 or float), normalisation fused.
 // One thread = one output pixel x 4 output channels (16-B store; a wave writes 1 KiB
 // contiguous when Cp == 16).  Cin is 1 or 3 so K = 9..27: VALU work, HBM-bound.

@@ -41,11 +41,55 @@ def test_forward_matches_reference_golden(name):
         assert got.shape == ref.shape
         err = (got - ref).abs().max().item()
         assert err <= CMS_ATOL, (k, err)
+    n_act = 0
+    for k in [f for f in z.files if f.startswith("act/")]:
+        ref = torch.from_numpy(z[k])
+        try:
+            got = m.read_activation(k[4:], ref.shape[0], ref.shape[-2:]).cpu()
+        except KeyError:
+            continue  # fused away by the stem kernel: never materialised in HBM
+        err = (got - ref).abs().max().item()
+        assert err <= CMS_ATOL, (k, err)
+        n_act += 1
+    assert n_act >= 2 or not any(f.startswith("act/") for f in z.files)
+
+
+@pytest.mark.parametrize("name", ["unet_tiny_interp.npz", "unet_tiny_rgb.npz", "ckpt_bottomup.npz"])
+def test_unfused_program_matches_too(name):
+    """The plan-level stem fusion is optional: the op-by-op program must give the same maps."""
+    z = G.load(name)
+    cfg = G.config(z)
+    m = _model(cfg, G.weights(z))
+    m.ops = list(m.unfused_ops)
+    img = torch.from_numpy(z["image"]).squeeze(1).to(DEV)
+    out = m(img)
+    for k in [f for f in z.files if f.startswith("out/")]:
+        assert (out[k[4:]].cpu() - torch.from_numpy(z[k])).abs().max().item() <= CMS_ATOL
     for k in [f for f in z.files if f.startswith("act/")]:
         ref = torch.from_numpy(z[k])
         got = m.read_activation(k[4:], ref.shape[0], ref.shape[-2:]).cpu()
-        err = (got - ref).abs().max().item()
-        assert err <= CMS_ATOL, (k, err)
+        assert (got - ref).abs().max().item() <= CMS_ATOL, k
+
+
+def test_stem_fusion_odd_sizes_vs_unfused():
+    """Odd H/W exercise the zero-padded pooling and partial tiles of the fused stem (compared with
+    the unfused kernels, which the golden tests pin)."""
+    from sleap_nn_amd.architectures.model import Model
+
+    bb = {"in_channels": 1, "kernel_size": 3, "filters": 12, "filters_rate": 2, "max_stride": 2, "stem_stride": None, "middle_block": True, "up_interpolate": True, "stacks": 1, "convs_per_block": 2, "output_stride": 2}
+    heads = {"confmaps": {"part_names": ["a", "b", "c"], "output_stride": 2}}
+    sd = O.init_state(bb, heads, "single_instance", seed=3, head_scale=1.0)
+    for hw in ((37, 45), (8, 32), (9, 33), (64, 70)):
+        g = torch.Generator().manual_seed(hw[0])
+        img = torch.randint(0, 256, (2, 1, hw[0], hw[1]), dtype=torch.uint8, generator=g)
+        ref = O.model_forward(sd, bb, heads, "single_instance", img)["SingleInstanceConfmapsHead"]
+        m = Model("unet", bb, heads, "single_instance")
+        m.load_state_dict(sd)
+        assert m.ops[0].kind == 7  # fused stem in the plan
+        # output_stride 2 with max_stride 2: the head sits on the middle block (no decoder) -> only the pooled path
+        out = m.to(DEV)(img.to(DEV))["SingleInstanceConfmapsHead"].cpu()
+        assert out.shape == ref.shape
+        assert (out - ref).abs().max().item() <= CMS_ATOL, hw
 
 
 def test_forward_float_inputs_and_odd_batch():
