@@ -93,25 +93,29 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(ConvArgs a) {
   }
 
   f32x4 ra[A_SLOTS], rb[B_SLOTS];
-  auto prefetch = [&](int ch) {
-    const float* src;
-    int cp, coff;
+  // source of chunk `ch`: (pointer, padded channel count, channel offset) + its weight panel
+  const float* p_src;
+  const float* p_w;
+  int p_cp, p_coff;
+  auto select_chunk = [&](int ch) {
     if (ch < chunks0) {
-      src = a.src0;
-      cp = a.c0p;
-      coff = ch * KC;
+      p_src = a.src0;
+      p_cp = a.c0p;
+      p_coff = ch * KC;
     } else {
-      src = a.src1;
-      cp = a.c1p;
-      coff = (ch - chunks0) * KC;
+      p_src = a.src1;
+      p_cp = a.c1p;
+      p_coff = (ch - chunks0) * KC;
     }
-#pragma unroll
-    for (int s = 0; s < A_SLOTS; ++s) ra[s] = *reinterpret_cast<const f32x4*>(src + (size_t)a_pix[s] * cp + coff + q4);
-    const float* wsrc = wbase + (size_t)ch * (9 * BN * KC);
-#pragma unroll
-    for (int s = 0; s < B_SLOTS; ++s) {
-      const int i = min(tid + 256 * s, B_ITEMS - 1);
-      rb[s] = *reinterpret_cast<const f32x4*>(wsrc + i * 4);
+    p_w = wbase + (size_t)ch * (9 * BN * KC);
+  };
+  auto load_slot = [&](int slot) {  // slot < A_SLOTS: input halo piece, else weight piece
+    if (slot < A_SLOTS) {
+      ra[slot] = *reinterpret_cast<const f32x4*>(p_src + (size_t)a_pix[slot] * p_cp + p_coff + q4);
+    } else {
+      const int sb = slot - A_SLOTS;
+      const int i = min(tid + 256 * sb, B_ITEMS - 1);
+      rb[sb] = *reinterpret_cast<const f32x4*>(p_w + i * 4);
     }
   };
   auto commit = [&]() {
@@ -132,32 +136,51 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(ConvArgs a) {
   const int lx = lane & 31;
   const int lh = lane >> 5;
 
-  prefetch(0);
+  select_chunk(0);
+#pragma unroll
+  for (int sl = 0; sl < A_SLOTS + B_SLOTS; ++sl) load_slot(sl);
   for (int ch = 0; ch < nchunks; ++ch) {
     commit();          // waits for the chunk's loads, fills LDS
     __syncthreads();
-    if (ch + 1 < nchunks) prefetch(ch + 1);  // next chunk's HBM/L2 latency hides under the MFMAs below
-    // ---- 9 taps x 2 channel groups x 4 MFMA k-steps
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
+    // Next chunk's loads are issued ONE PER MFMA STEP below (a burst of 15 loads per wave would
+    // block the wave in the vector-memory issue queue while the matrix pipe idles).  On the last
+    // chunk the same chunk is fetched again (harmless, keeps the loop branch-free).
+    select_chunk(min(ch + 1, nchunks - 1));
+    // ---- 18 steps (9 taps x 2 channel groups) x 4 MFMA k-steps.  Fragments are double
+    // buffered in registers: the ds_read_b128s of step i+1 are issued before the MFMAs of
+    // step i, so a wave that has its SIMD to itself still issues MFMAs back to back.
+    f32x4 af[2][2], bf[2][NT];
+    auto load_frags = [&](int step, int buf) {
+      const int tap = step >> 1, g = step & 1;
       const int ky = tap / 3, kx = tap - ky * 3;
 #pragma unroll
-      for (int g = 0; g < 2; ++g) {
-        f32x4 af[2], bf[NT];
+      for (int m = 0; m < 2; ++m)
+        af[buf][m] = *reinterpret_cast<const f32x4*>(ldsA + ((2 * wave + m + ky) * HALO_W + lx + kx) * LROW + g * 8 + lh * 4);
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+        bf[buf][n] = *reinterpret_cast<const f32x4*>(ldsB + (tap * BN + n * 32 + lx) * LROW + g * 8 + lh * 4);
+    };
+    load_frags(0, 0);
+#pragma unroll
+    for (int step = 0; step < 18; ++step) {
+      const int cur = step & 1;
+      if (step + 1 < 18) load_frags(step + 1, cur ^ 1);
+      if (step < A_SLOTS + B_SLOTS) load_slot(step);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int m = 0; m < 2; ++m)
-          af[m] = *reinterpret_cast<const f32x4*>(ldsA + ((2 * wave + m + ky) * HALO_W + lx + kx) * LROW + g * 8 + lh * 4);
 #pragma unroll
-        for (int n = 0; n < NT; ++n)
-          bf[n] = *reinterpret_cast<const f32x4*>(ldsB + (tap * BN + n * 32 + lx) * LROW + g * 8 + lh * 4);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int m = 0; m < 2; ++m)
-#pragma unroll
-            for (int n = 0; n < NT; ++n)
-              acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m][j], bf[n][j], acc[m][n], 0, 0, 0);
-      }
+          for (int n = 0; n < NT; ++n)
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][m][j], bf[cur][n][j], acc[m][n], 0, 0, 0);
+      // pin the step boundary: next step's fragment reads + one prefetch load, then this step's
+      // MFMAs (without the fence the scheduler sinks all prefetch loads behind the last MFMA)
+      __builtin_amdgcn_sched_group_barrier(0x100, 2 + NT, 0);   // next step's fragment reads first
+      __builtin_amdgcn_sched_group_barrier(0x008, 2 * NT, 0);   // a few MFMAs
+      __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);        // address arithmetic of the prefetch load
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);        // one prefetch load
+      __builtin_amdgcn_sched_group_barrier(0x008, 6 * NT, 0);   // rest of the MFMAs
+      __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
   }
