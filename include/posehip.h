@@ -124,6 +124,12 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
 int ph_model_set_profiling(ph_model* m, int32_t enabled);
 int ph_model_profile_read(ph_model* m, double* op_ms, int32_t n_ops, int32_t* n_forwards);
 
+/* Diagnostic: when buf_dev != NULL every conv3x3 workgroup writes {delta s_memtime, delta
+ * s_memrealtime} (2 x uint64 per workgroup, indexed by linear block id; the buffer must hold
+ * the largest conv grid) so the shader clock under load can be read as
+ * d_memtime / d_memrealtime * 100 MHz.  NULL turns it off (default). */
+int ph_model_set_clock_probe(ph_model* m, void* buf_dev);
+
 /* Debug/parity helper: copy activation slot `slot` of the last forward (NHWC, padded
  * channels) into an NCHW fp32 device buffer of the logical channel count. */
 int ph_model_read_slot(ph_model* m, int32_t slot, float* out_dev, int64_t out_numel, void* stream);

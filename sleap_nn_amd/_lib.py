@@ -43,6 +43,7 @@ SIGNATURES = {
     "ph_model_forward": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _i64, C.POINTER(_vp), _vp]),
     "ph_model_set_profiling": (C.c_int, [_vp, _i32]),
     "ph_model_profile_read": (C.c_int, [_vp, C.POINTER(C.c_double), _i32, C.POINTER(_i32)]),
+    "ph_model_set_clock_probe": (C.c_int, [_vp, _vp]),
     "ph_model_read_slot": (C.c_int, [_vp, _i32, _vp, _i64, _vp]),
     "ph_local_peaks": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _f32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i64, _vp]),
     "ph_global_peaks": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _f32, _i32, _i32, _vp, _vp, _vp]),

@@ -46,6 +46,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         if not force and _newer(obj, [sp] + hdrs):
             continue
         cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c", sp, "-o", obj, "-I", os.path.join(HERE, "..", "include")]
+        cmd += os.environ.get("PH_EXTRA_HIPCC_FLAGS", "").split()  # diagnostic builds, e.g. -DPH_STAMP
         if src.endswith(".cpp"):
             cmd = [_hipcc(), "-O3", "-std=c++17", "-fPIC", "-x", "c++", "-c", sp, "-o", obj]
         jobs.append(cmd)

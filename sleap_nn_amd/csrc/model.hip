@@ -31,6 +31,7 @@ struct PackedOp {
   float* b_dev = nullptr;
   float* w2_dev = nullptr;
   float* b2_dev = nullptr;
+  float* w_dma_dev = nullptr;  // conv weights in the LDS-DMA (quad-major piece) layout
   int bn = 0;
 };
 
@@ -60,6 +61,9 @@ struct ph_model {
   std::vector<hipEvent_t> ev;      // n_ops + 1 events: ev[i] before op i, ev[n_ops] after the last
   std::vector<double> op_ms;       // accumulated per op
   int profiled_forwards = 0;
+  unsigned long long* clock_probe = nullptr;  // diagnostic buffer (ph_model_set_clock_probe)
+  float* zeros_dev = nullptr;                 // zero page for LDS-DMA halo padding
+  bool use_dma = true;                        // PH_CONV_IMPL=reg selects the register-staged kernel
 };
 
 namespace ph {
@@ -108,6 +112,19 @@ static void pack_conv(const float* w, bool transposed, int cin0, int cin1, int c
             out[((((size_t)nt * nch + ch) * 9 + tap) * bn + n) * 16 + kc] = v;
           }
         }
+      }
+}
+
+// [n_tile][chunk][tap][bn][16] -> [n_tile][chunk][piece = (tap*bn + n)/16][quad q][row r = (tap*bn+n)%16][4]
+// (the order in which one LDS-DMA wave-instruction writes a 1-KiB piece, see conv3x3_mfma_dma_kernel)
+static void repack_dma(const std::vector<float>& in, int bn, std::vector<float>& out) {
+  out.resize(in.size());
+  const size_t panel = (size_t)9 * bn * 16;
+  for (size_t base = 0; base < in.size(); base += panel)
+    for (int row = 0; row < 9 * bn; ++row)
+      for (int k = 0; k < 16; ++k) {
+        const int piece = row >> 4, r = row & 15, q = k >> 2, e = k & 3;
+        out[base + (size_t)piece * 256 + q * 64 + r * 4 + e] = in[base + (size_t)row * 16 + k];
       }
 }
 
@@ -205,6 +222,15 @@ ph_model* ph_model_create(const ph_op_desc* ops, int32_t n_ops, const float* con
   ph_model* m = new ph_model();
   m->n_slots = n_slots;
   m->n_outputs = n_outputs;
+  {
+    const char* impl = getenv("PH_CONV_IMPL");
+    m->use_dma = !(impl && std::string(impl) == "reg");
+    std::vector<float> z(64, 0.f);
+    if (upload(m, z, &m->zeros_dev) != PH_OK) {
+      ph_model_destroy(m);
+      return nullptr;
+    }
+  }
   auto fail = [&](const char* msg, int i) -> ph_model* {
     set_error("ph_model_create: op %d: %s", i, msg);
     ph_model_destroy(m);
@@ -253,6 +279,14 @@ ph_model* ph_model_create(const ph_op_desc* ops, int32_t n_ops, const float* con
         const int coutp = pad16(d.cout);
         op.bn = choose_bn(coutp);
         pack_conv(w, d.kind == PH_OP_CONVT, d.cin0, d.cin1, d.cout, op.bn, pw);
+        {
+          std::vector<float> pd;
+          repack_dma(pw, op.bn, pd);
+          if (upload(m, pd, &op.w_dma_dev) != PH_OK) {
+            ph_model_destroy(m);
+            return nullptr;
+          }
+        }
         pb.assign((size_t)((coutp + op.bn - 1) / op.bn) * op.bn, 0.f);
         if (b) std::memcpy(pb.data(), b, d.cout * sizeof(float));
       } else if (d.kind == PH_OP_INPUT_CONV) {
@@ -398,7 +432,10 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
         a.W = s0.w;
         a.relu = (d.flags & PH_FLAG_RELU) ? 1 : 0;
         a.bn = op.bn;
-        rc = launch_conv3x3(a, s);
+        a.clock_probe = m->clock_probe;
+        a.wpack_dma = op.w_dma_dev;
+        a.zeros = m->zeros_dev;
+        rc = (m->use_dma && a.bn == 64) ? launch_conv3x3_dma(a, s) : launch_conv3x3(a, s);  // BN=32 layers: the register-staged kernel is faster
         break;
       }
       case PH_OP_POOL: {
@@ -431,7 +468,10 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
         a.W = 2 * s0.w;
         a.relu = (d.flags & PH_FLAG_RELU) ? 1 : 0;
         a.bn = op.bn;
-        rc = launch_conv3x3(a, s);
+        a.clock_probe = nullptr;
+        a.wpack_dma = op.w_dma_dev;
+        a.zeros = m->zeros_dev;
+        rc = (m->use_dma && a.bn == 64) ? launch_conv3x3_dma(a, s) : launch_conv3x3(a, s);  // BN=32 layers: the register-staged kernel is faster
         break;
       }
       case PH_OP_HEAD: {
@@ -480,6 +520,12 @@ int ph_model_profile_read(ph_model* m, double* op_ms, int32_t n_ops, int32_t* n_
   if (rc != PH_OK) return rc;
   for (int i = 0; i < n_ops; ++i) op_ms[i] = i < (int)m->op_ms.size() ? m->op_ms[i] : 0.0;
   *n_forwards = m->profiled_forwards;
+  return PH_OK;
+}
+
+int ph_model_set_clock_probe(ph_model* m, void* buf_dev) {
+  PH_REQUIRE(m, "ph_model_set_clock_probe: null model");
+  m->clock_probe = static_cast<unsigned long long*>(buf_dev);
   return PH_OK;
 }
 

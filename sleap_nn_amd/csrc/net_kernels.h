@@ -17,6 +17,9 @@ struct ConvArgs {
   int B, H, W;
   int relu;
   int bn;              // N tile: 32 or 64
+  unsigned long long* clock_probe;  // diagnostic: per block {d s_memtime, d s_memrealtime}; nullptr = off
+  const float* wpack_dma;  // weights in the LDS-DMA layout (quad-major 16-row pieces), or nullptr
+  const float* zeros;      // >= 64 B of zeros in HBM (source of out-of-image halo pixels for LDS-DMA)
 };
 
 struct InputConvArgs {
@@ -43,6 +46,7 @@ int launch_stem(const StemArgs& a, hipStream_t s);
 int prepare_kernels();
 int conv_lds_bytes(int bn);
 int launch_conv3x3(const ConvArgs& a, hipStream_t s);
+int launch_conv3x3_dma(const ConvArgs& a, hipStream_t s);
 int launch_input_conv(const InputConvArgs& a, hipStream_t s);
 int launch_pool(const float* src, float* dst, int B, int H, int W, int cp, hipStream_t s);
 int launch_upsample(const float* src, float* dst, int B, int H, int W, int cp, hipStream_t s);

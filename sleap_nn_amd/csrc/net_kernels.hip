@@ -136,12 +136,32 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(ConvArgs a) {
   const int lx = lane & 31;
   const int lh = lane >> 5;
 
+  unsigned long long t0 = 0, r0 = 0;
+  if (a.clock_probe) {
+    t0 = __builtin_amdgcn_s_memtime();
+    r0 = __builtin_amdgcn_s_memrealtime();
+  }
   select_chunk(0);
 #pragma unroll
   for (int sl = 0; sl < A_SLOTS + B_SLOTS; ++sl) load_slot(sl);
+#ifdef PH_STAMP
+  unsigned long long st_commit = 0, st_bar1 = 0, st_mfma = 0, st_bar2 = 0, st_prev = __builtin_amdgcn_s_memtime();
+#define PH_STAMP_AT(acc)                                         \
+  {                                                              \
+    __builtin_amdgcn_sched_barrier(0);                           \
+    const unsigned long long _t = __builtin_amdgcn_s_memtime();  \
+    acc += _t - st_prev;                                         \
+    st_prev = _t;                                                \
+    __builtin_amdgcn_sched_barrier(0);                           \
+  }
+#else
+#define PH_STAMP_AT(acc)
+#endif
   for (int ch = 0; ch < nchunks; ++ch) {
     commit();          // waits for the chunk's loads, fills LDS
+    PH_STAMP_AT(st_commit)
     __syncthreads();
+    PH_STAMP_AT(st_bar1)
     // Next chunk's loads are issued ONE PER MFMA STEP below (a burst of 15 loads per wave would
     // block the wave in the vector-memory issue queue while the matrix pipe idles).  On the last
     // chunk the same chunk is fetched again (harmless, keeps the loop branch-free).
@@ -182,44 +202,310 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(ConvArgs a) {
       __builtin_amdgcn_sched_group_barrier(0x008, 6 * NT, 0);   // rest of the MFMAs
       __builtin_amdgcn_sched_barrier(0);
     }
+    PH_STAMP_AT(st_mfma)
     __syncthreads();
+    PH_STAMP_AT(st_bar2)
   }
-
-  // ---- epilogue: bias (+ReLU), NHWC store.  C/D map: col = lane&31 (channel),
-  // row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (pixel x inside the 32-wide tile).
+#ifdef PH_STAMP
+  if (a.clock_probe && lane == 0) {
+    const size_t bi = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave;
+    a.clock_probe[4 * bi + 0] = st_commit;
+    a.clock_probe[4 * bi + 1] = st_bar1;
+    a.clock_probe[4 * bi + 2] = st_mfma;
+    a.clock_probe[4 * bi + 3] = st_bar2;
+  }
+#else
+  unsigned long long t_loop = 0;
+  if (a.clock_probe) t_loop = __builtin_amdgcn_s_memtime();
+#endif
+  // ---- epilogue: bias (+ReLU) in place in the accumulators, then NHWC stores straight from
+  // them.  C/D map: col = lane&31 (channel), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (pixel x
+  // inside the 32-wide tile).  Interior tiles take a branch-free path: 64 stores issued back
+  // to back (a guarded store per element makes hipcc wait vmcnt(0) between stores, which
+  // serialises ~64 HBM round trips per wave).
 #pragma unroll
   for (int n = 0; n < NT; ++n) {
-    const int co = ntile * BN + n * 32 + lx;
-    if (co >= a.coutp) continue;
-    const float bias = a.bias[co];
+    const float bias = a.bias[ntile * BN + n * 32 + lx];  // bias is padded to a multiple of BN
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
-      const int y = y0 + 2 * wave + m;
-      if (y >= a.H) continue;
-      float* drow = a.dst + ((size_t)(b * a.H + y) * a.W) * a.coutp + co;
+    for (int m = 0; m < 2; ++m)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int x = x0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (x < a.W) {
-          float v = acc[m][n][r] + bias;
-          if (a.relu) v = fmaxf(v, 0.f);
-          drow[(size_t)x * a.coutp] = v;
+        const float v = acc[m][n][r] + bias;
+        acc[m][n][r] = a.relu ? fmaxf(v, 0.f) : v;
+      }
+  }
+  const bool interior = (x0 + TW <= a.W) && (y0 + TH <= a.H) && ((ntile + 1) * BN <= a.coutp);
+  if (interior) {
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        float* drow = a.dst + ((size_t)(b * a.H + y0 + 2 * wave + m) * a.W + x0 + 4 * lh) * a.coutp + ntile * BN + n * 32 + lx;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) drow[(size_t)((r & 3) + 8 * (r >> 2)) * a.coutp] = acc[m][n][r];
+      }
+  } else {
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      const int co = ntile * BN + n * 32 + lx;
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const int y = y0 + 2 * wave + m;
+        float* drow = a.dst + ((size_t)(b * a.H + min(y, a.H - 1)) * a.W) * a.coutp + min(co, a.coutp - 1);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int x = x0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (x < a.W && y < a.H && co < a.coutp) drow[(size_t)x * a.coutp] = acc[m][n][r];
         }
       }
     }
   }
+#ifndef PH_STAMP
+  if (a.clock_probe && lane == 0) {  // shader clock = dt_memtime / dt_memrealtime * 100 MHz
+    __builtin_amdgcn_s_waitcnt(0);  // include the store drain
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    const size_t bi = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave;
+    a.clock_probe[4 * bi + 0] = t_loop - t0;   // kernel entry -> end of K loop
+    a.clock_probe[4 * bi + 1] = t1 - t0;       // kernel entry -> stores drained
+    a.clock_probe[4 * bi + 2] = r1 - r0;       // same span on the 100 MHz counter
+    a.clock_probe[4 * bi + 3] = t0;            // absolute start (for occupancy timelines)
+  }
+#endif
+}
+
+static size_t debug_lds_pad() {  // experiment knob: PH_CONV_LDS_PAD=<bytes> lowers workgroups/CU
+  static long pad = -1;
+  if (pad < 0) {
+    const char* e = getenv("PH_CONV_LDS_PAD");
+    pad = e ? atol(e) : 0;
+  }
+  return (size_t)pad;
 }
 
 int launch_conv3x3(const ConvArgs& a, hipStream_t s) {
   const int tiles = ((a.W + TW - 1) / TW) * ((a.H + TH - 1) / TH) * a.B;
   if (a.bn == 64) {
-    const size_t lds = (HALO_H * HALO_W + 9 * 64) * LROW * sizeof(float);
+    const size_t lds = (HALO_H * HALO_W + 9 * 64) * LROW * sizeof(float) + debug_lds_pad();
     dim3 grid(tiles, (a.coutp + 63) / 64);
     hipLaunchKernelGGL(conv3x3_mfma_kernel<64>, grid, dim3(256), lds, s, a);
   } else {
     const size_t lds = (HALO_H * HALO_W + 9 * 32) * LROW * sizeof(float);
     dim3 grid(tiles, (a.coutp + 31) / 32);
     hipLaunchKernelGGL(conv3x3_mfma_kernel<32>, grid, dim3(256), lds, s, a);
+  }
+  PH_HIP_CHECK(hipGetLastError());
+  return PH_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// K1d: the same implicit GEMM with LDS-DMA staging and a double-buffered LDS ring.
+//   512 threads = 8 waves (two per SIMD), tile 16 rows x 32 cols x BN channels; wave w owns rows
+//   2w, 2w+1.  Per 16-channel chunk the (16+2)x(32+2) halo and the 9 x BN x 16 weight panel go
+//   global -> LDS directly (global_load_lds_dwordx4: no VGPR staging, no ds_write pass), one
+//   1-KiB piece per MFMA step, into the buffer that is NOT being read; one barrier per chunk.
+//   LDS image ("quad-major pieces"): rows (halo pixels / weight rows) are grouped in pieces of
+//   16; inside a 1-KiB piece the four 16-B channel quads are stored quad-major:
+//       byte(row r, quad q) = (r >> 4) * 1024 + q * 256 + (r & 15) * 16.
+//   A DMA wave-instruction writes 64 x 16 B contiguously, so the permutation costs nothing (it
+//   is applied to the per-lane SOURCE address), and a ds_read_b128 of 16 rows that are distinct
+//   mod 16 (any 16 consecutive pixels; the b128 lane groups {0-3,12-15,20-27} too) touches all
+//   16 slots of the 256-B bank row exactly once: conflict-free without padding.
+// ---------------------------------------------------------------------------------------
+constexpr int D_TH = 16, D_HALO_H = D_TH + 2;
+constexpr int D_NPIX = D_HALO_H * HALO_W;            // 612
+constexpr int D_A_PIECES = (D_NPIX + 15) / 16;       // 39
+constexpr int D_A_BYTES = D_A_PIECES * 1024;
+
+template <int BN>
+__global__ __launch_bounds__(512, 2) void conv3x3_mfma_dma_kernel(ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int NT = BN / 32;
+  constexpr int B_PIECES = 9 * BN / 16;
+  constexpr int PIECES = D_A_PIECES + B_PIECES;
+  constexpr int A_SLOTS = (D_A_PIECES + 7) / 8;   // 5: input pieces  p = min(w + 8 s, last)
+  constexpr int B_SLOTS = (B_PIECES + 7) / 8;     // 5 / 3: weight pieces
+  constexpr int SLOTS = A_SLOTS + B_SLOTS;
+  constexpr int BUF_FLOATS = PIECES * 256;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tiles_x = (a.W + TW - 1) / TW;
+  const int tiles_y = (a.H + D_TH - 1) / D_TH;
+  int t = blockIdx.x;
+  const int tx = t % tiles_x;
+  t /= tiles_x;
+  const int ty = t % tiles_y;
+  const int b = t / tiles_y;
+  const int ntile = blockIdx.y;
+  const int x0 = tx * TW, y0 = ty * D_TH;
+
+  f32x16 acc[2][NT];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+  const int chunks0 = a.c0p / KC;
+  const int chunks1 = a.c1p / KC;
+  const int nchunks = chunks0 + chunks1;
+  const float* wbase = a.wpack_dma + (size_t)ntile * nchunks * (9 * BN * KC);
+
+  // ---- DMA plan (branch-free: slot kinds are compile-time, surplus slots repeat the last
+  // piece, out-of-image pixels read a zero page).  Lane L of a piece holds quad q = L >> 4 of
+  // row (p*16 + (L & 15)).
+  const int dq = lane >> 4, dr = lane & 15;
+  int a_pix[A_SLOTS];
+  unsigned a_ok = 0;
+#pragma unroll
+  for (int s = 0; s < A_SLOTS; ++s) {
+    const int p = min(wave + 8 * s, D_A_PIECES - 1);
+    const int pix = p * 16 + dr;
+    const int hy = pix / HALO_W, hx = pix - hy * HALO_W;
+    const int gy = y0 + hy - 1, gx = x0 + hx - 1;
+    const bool in = (pix < D_NPIX) && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+    a_ok |= (in ? 1u : 0u) << s;
+    const int cy = min(max(gy, 0), a.H - 1), cx = min(max(gx, 0), a.W - 1);
+    a_pix[s] = (b * a.H + cy) * a.W + cx;
+  }
+  const float* p_src;
+  const float* p_w;
+  int p_cp, p_coff;
+  auto select_chunk = [&](int ch) {
+    if (ch < chunks0) {
+      p_src = a.src0;
+      p_cp = a.c0p;
+      p_coff = ch * KC;
+    } else {
+      p_src = a.src1;
+      p_cp = a.c1p;
+      p_coff = (ch - chunks0) * KC;
+    }
+    p_w = wbase + (size_t)ch * (9 * BN * KC);
+  };
+  auto dma_slot = [&](int s, float* buf) {
+    const float* g;
+    int p;
+    if (s < A_SLOTS) {  // compile-time after unrolling
+      p = min(wave + 8 * s, D_A_PIECES - 1);
+      const float* real = p_src + (size_t)a_pix[s] * p_cp + p_coff + dq * 4;
+      const float* zero = a.zeros + dq * 4;
+      g = ((a_ok >> s) & 1u) ? real : zero;
+    } else {
+      const int pb = min(wave + 8 * (s - A_SLOTS), B_PIECES - 1);
+      p = D_A_PIECES + pb;
+      g = p_w + pb * 256 + lane * 4;  // weights are packed in LDS order
+    }
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)(buf + p * 256), 16, 0, 0);
+  };
+
+  // ---- fragment read offsets (floats, buffer-relative)
+  const int lx = lane & 31, lh = lane >> 5;
+  int offA[4][3];  // [row 2w + rr][kx] for q = lh
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int pix = (2 * wave + rr) * HALO_W + lx + kx;
+      offA[rr][kx] = (pix >> 4) * 256 + lh * 64 + (pix & 15) * 4;
+    }
+  const int offB = D_A_PIECES * 256 + (lx >> 4) * 256 + lh * 64 + (lx & 15) * 4;  // + tap*(BN/16)*256 + nt*512 + g*128
+
+  float* buf0 = lds;
+  float* buf1 = lds + BUF_FLOATS;
+
+  select_chunk(0);
+#pragma unroll
+  for (int s = 0; s < SLOTS; ++s) dma_slot(s, buf0);
+  __syncthreads();  // drains the DMA (vmcnt(0)) and publishes the buffer
+
+  for (int ch = 0; ch < nchunks; ++ch) {
+    float* cur = (ch & 1) ? buf1 : buf0;
+    float* nxt = (ch & 1) ? buf0 : buf1;
+    select_chunk(min(ch + 1, nchunks - 1));  // last chunk: refetch itself into the idle buffer (harmless, branch-free)
+    f32x4 af[2][2], bf[2][NT];
+    auto load_frags = [&](int step, int fb) {
+      const int tap = step >> 1, g = step & 1;
+      const int ky = tap / 3, kx = tap - ky * 3;
+#pragma unroll
+      for (int m = 0; m < 2; ++m) af[fb][m] = *reinterpret_cast<const f32x4*>(cur + offA[m + ky][kx] + g * 128);
+#pragma unroll
+      for (int n = 0; n < NT; ++n) bf[fb][n] = *reinterpret_cast<const f32x4*>(cur + offB + tap * (BN / 16) * 256 + n * 512 + g * 128);
+    };
+    load_frags(0, 0);
+#pragma unroll
+    for (int step = 0; step < 18; ++step) {
+      const int fcur = step & 1;
+      if (step + 1 < 18) load_frags(step + 1, fcur ^ 1);
+      if (step < SLOTS) dma_slot(step, nxt);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int n = 0; n < NT; ++n)
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[fcur][m][j], bf[fcur][n][j], acc[m][n], 0, 0, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2 + NT, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 2 * NT, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 6 * NT, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();  // vmcnt(0) + barrier: next buffer landed everywhere, this one is free again
+  }
+
+  // ---- epilogue (same C/D map as the register-staged kernel)
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    const float bias = a.bias[ntile * BN + n * 32 + lx];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float v = acc[m][n][r] + bias;
+        acc[m][n][r] = a.relu ? fmaxf(v, 0.f) : v;
+      }
+  }
+  const bool interior = (x0 + TW <= a.W) && (y0 + D_TH <= a.H) && ((ntile + 1) * BN <= a.coutp);
+  if (interior) {
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        float* drow = a.dst + ((size_t)(b * a.H + y0 + 2 * wave + m) * a.W + x0 + 4 * lh) * a.coutp + ntile * BN + n * 32 + lx;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) drow[(size_t)((r & 3) + 8 * (r >> 2)) * a.coutp] = acc[m][n][r];
+      }
+  } else {
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      const int co = ntile * BN + n * 32 + lx;
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const int y = y0 + 2 * wave + m;
+        float* drow = a.dst + ((size_t)(b * a.H + min(y, a.H - 1)) * a.W) * a.coutp + min(co, a.coutp - 1);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int x = x0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (x < a.W && y < a.H && co < a.coutp) drow[(size_t)x * a.coutp] = acc[m][n][r];
+        }
+      }
+    }
+  }
+}
+
+int launch_conv3x3_dma(const ConvArgs& a, hipStream_t s) {
+  const int tiles = ((a.W + TW - 1) / TW) * ((a.H + D_TH - 1) / D_TH) * a.B;
+  if (a.bn == 64) {
+    const size_t lds = (size_t)2 * (D_A_PIECES + 9 * 64 / 16) * 1024;
+    hipLaunchKernelGGL(conv3x3_mfma_dma_kernel<64>, dim3(tiles, (a.coutp + 63) / 64), dim3(512), lds, s, a);
+  } else {
+    const size_t lds = (size_t)2 * (D_A_PIECES + 9 * 32 / 16) * 1024;
+    hipLaunchKernelGGL(conv3x3_mfma_dma_kernel<32>, dim3(tiles, (a.coutp + 31) / 32), dim3(512), lds, s, a);
   }
   PH_HIP_CHECK(hipGetLastError());
   return PH_OK;
@@ -616,7 +902,7 @@ int conv_lds_bytes(int bn) { return (HALO_H * HALO_W + 9 * bn) * LROW * (int)siz
 
 int prepare_kernels() {
   // 73 KiB of dynamic LDS for the BN=64 variant exceeds the 64 KiB default cap.
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_mfma_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, conv_lds_bytes(64));
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_mfma_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e != hipSuccess) {
     set_error("hipFuncSetAttribute(conv64) failed: %s", hipGetErrorString(e));
     return PH_E_HIP;
@@ -624,6 +910,13 @@ int prepare_kernels() {
   e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_mfma_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, conv_lds_bytes(32));
   if (e != hipSuccess) {
     set_error("hipFuncSetAttribute(conv32) failed: %s", hipGetErrorString(e));
+    return PH_E_HIP;
+  }
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_mfma_dma_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e == hipSuccess)
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_mfma_dma_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e != hipSuccess) {
+    set_error("hipFuncSetAttribute(conv dma) failed: %s", hipGetErrorString(e));
     return PH_E_HIP;
   }
   return PH_OK;
