@@ -159,6 +159,22 @@ int ph_global_peaks(const float* cms_dev, int32_t B, int32_t C, int32_t H, int32
                     float threshold, int32_t refine, int32_t patch, float* out_xy, float* out_val,
                     void* stream);
 
+/* Crop gather (top-down stage 2 pick-up; inference/ops/crops.py:31-124): n crops of
+ * crop_h x crop_w from (B, C, H, W) images (dtype 0 = uint8, 1 = float32), zero outside the image.
+ * topleft_xy_dev: (n, 2) float32 bbox top-left corners (x, y) as produced by make_centered_bboxes;
+ * the integer origin is trunc(tl + half) - half with half = (crop_w/2, crop_h/2) (crops.py:85-90).
+ * out_dev: (n, C, crop_h, crop_w), same dtype as the images. */
+int ph_crop_bboxes(const void* images_dev, int32_t dtype, int32_t B, int32_t C, int32_t H, int32_t W,
+                   const float* topleft_xy_dev, const int32_t* sample_inds_dev, int32_t n,
+                   int32_t crop_h, int32_t crop_w, void* out_dev, void* stream);
+
+/* Class-map sampling for multi-class bottom-up (inference/ops/identity.py:86-101): for each peak
+ * gather the K class probabilities at (round-half-even(y), round-half-even(x)) clamped to the map.
+ * class_maps_dev (B, K, H, W) fp32; peaks_xy_dev (n, 2) in class-map pixels; out_probs_dev (n, K). */
+int ph_sample_class_maps(const float* class_maps_dev, int32_t B, int32_t K, int32_t H, int32_t W,
+                         const float* peaks_xy_dev, const int32_t* sample_inds_dev, int32_t n,
+                         float* out_probs_dev, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * PAF line-integral scoring (device)
  * ---------------------------------------------------------------------------------- */
@@ -207,6 +223,14 @@ int ph_group_batch(int32_t B, int32_t n_nodes, const int32_t* edges, int32_t n_e
                    float min_line_score, double min_instance_peaks, int32_t min_instance_peaks_is_fraction,
                    int32_t max_inst, int32_t truncate_by_score, float* out_kpts, float* out_vals,
                    float* out_scores, int32_t* out_n_inst);
+
+/* Host: Hungarian matching of peaks to classes per (sample, channel)
+ * (inference/ops/identity.py:13-76).  probs (n, K) fp32, sample/channel (n) int32.
+ * Writes matched (peak index, class index) pairs that also are the peak's arg-max class
+ * (is_best filter, identity.py:61-66) in (sample, channel) order; returns the pair count. */
+int ph_group_class_peaks(const float* probs, const int32_t* sample_inds, const int32_t* channel_inds,
+                         int32_t n, int32_t n_samples, int32_t n_channels, int32_t K,
+                         int32_t* out_peak_inds, int32_t* out_class_inds);
 
 #ifdef __cplusplus
 }

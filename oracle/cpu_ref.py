@@ -690,3 +690,143 @@ def render_pafs(pts: np.ndarray, edges, size: int, stride: int, sigma: float) ->
             out[2 * e] += wgt * u[0]
             out[2 * e + 1] += wgt * u[1]
     return out
+
+
+# --------------------------------------------------------------------------------------
+# Top-down glue (layers/centroid.py:195-261, layers/topdown.py:183-300,
+# layers/centered_instance.py:199-230, ops/crops.py:31-124, data/instance_cropping.py:129-171)
+# --------------------------------------------------------------------------------------
+
+
+def make_centered_bboxes(centroids: torch.Tensor, box_height: int, box_width: int) -> torch.Tensor:
+    """instance_cropping.py:129-171: corners TL, TR, BR, BL of a box centred on each point."""
+    hw, hh = box_width / 2, box_height / 2
+    x, y = centroids[..., 0], centroids[..., 1]
+    tl = torch.stack([x - hw, y - hh], -1)
+    tr = torch.stack([x + hw, y - hh], -1)
+    br = torch.stack([x + hw, y + hh], -1)
+    bl = torch.stack([x - hw, y + hh], -1)
+    corners = torch.stack([tl, tr, br, bl], dim=-2)
+    return corners + torch.tensor([[0.5, 0.5], [-0.5, 0.5], [-0.5, -0.5], [0.5, -0.5]])
+
+
+def crop_bboxes(images: torch.Tensor, bboxes: torch.Tensor, sample_inds: torch.Tensor) -> torch.Tensor:
+    """crops.py:31-124: zero-padded integer crops; origin = trunc(tl + half) - half."""
+    n = bboxes.shape[0]
+    if n == 0:
+        return torch.empty(0, images.shape[1], 0, 0, dtype=images.dtype)
+    h = int(abs(bboxes[0, 3, 1] - bboxes[0, 0, 1]).item()) + 1
+    w = int(abs(bboxes[0, 1, 0] - bboxes[0, 0, 0]).item()) + 1
+    half = torch.tensor([w // 2, h // 2], dtype=bboxes.dtype)
+    org = (bboxes[:, 0, :] + half).to(torch.long) - half.long()
+    H, W = images.shape[-2:]
+    out = torch.zeros((n, images.shape[1], h, w), dtype=images.dtype)
+    for k in range(n):
+        ox, oy = int(org[k, 0]), int(org[k, 1])
+        x0, x1 = max(ox, 0), min(ox + w, W)
+        y0, y1 = max(oy, 0), min(oy + h, H)
+        if x1 > x0 and y1 > y0:
+            out[k, :, y0 - oy : y1 - oy, x0 - ox : x1 - ox] = images[int(sample_inds[k]), :, y0:y1, x0:x1]
+    return out
+
+
+def centroid_postprocess(cms: torch.Tensor, output_stride: int, peak_threshold: float = 0.2, refinement: Optional[str] = "integral", patch: int = 5, max_instances: Optional[int] = None, input_scale: float = 1.0, eff_scale: Optional[torch.Tensor] = None):
+    """layers/centroid.py:195-261 -> (B, I, 2) NaN-padded centroids, (B, I) values (top-k by value)."""
+    pts, vals, sb, _ = find_local_peaks(cms, peak_threshold, refinement, patch)
+    if output_stride != 1:
+        pts = pts * output_stride
+    if input_scale != 1.0:
+        pts = pts / input_scale
+    B = cms.shape[0]
+    mi = max_instances or (int(torch.bincount(sb.long()).max()) if sb.numel() else 0)
+    if mi == 0:
+        mi = 1
+    cp = torch.full((B, mi, 2), float("nan"))
+    cv = torch.full((B, mi), float("nan"))
+    for b in range(B):
+        m = sb == b
+        p, v = pts[m], vals[m]
+        if p.numel() == 0:
+            continue
+        if p.shape[0] > mi:
+            v, idx = torch.topk(v, mi)
+            p = p[idx]
+        cp[b, : p.shape[0]] = p
+        cv[b, : p.shape[0]] = v
+    if eff_scale is not None and not bool(torch.all(eff_scale == 1.0)):
+        cp = cp / eff_scale.view(-1, 1, 1)
+    return cp, cv
+
+
+def topdown_stage2(image: torch.Tensor, centroids: torch.Tensor, crop_hw, forward_fn, output_stride: int, peak_threshold: float = 0.2, refinement: Optional[str] = "integral", patch: int = 5):
+    """layers/topdown.py:183-300 with eff_scale == 1: crop valid centroids, run the centered-instance
+    model (``forward_fn(crops uint8) -> confmaps``), global peaks, add the crop offset."""
+    B, I, _ = centroids.shape
+    valid = ~torch.isnan(centroids).any(dim=-1)
+    idx = torch.nonzero(valid, as_tuple=False)
+    vc = centroids[idx[:, 0], idx[:, 1]]
+    bboxes = make_centered_bboxes(vc, crop_hw[0], crop_hw[1])
+    crops = crop_bboxes(image, bboxes, idx[:, 0])
+    cms = forward_fn(crops)
+    pts, vals = find_global_peaks(cms, peak_threshold, refinement, patch)
+    if output_stride != 1:
+        pts = pts * output_stride
+    n_nodes = pts.shape[1]
+    kp = torch.full((B, I, n_nodes, 2), float("nan"))
+    kv = torch.full((B, I, n_nodes), float("nan"))
+    kp[idx[:, 0], idx[:, 1]] = pts + bboxes[:, 0, :].view(-1, 1, 2)
+    kv[idx[:, 0], idx[:, 1]] = vals
+    return kp, kv, crops, bboxes, pts
+
+
+# --------------------------------------------------------------------------------------
+# Multi-class bottom-up (ops/identity.py:13-146, layers/bottomup_multiclass.py:76-150)
+# --------------------------------------------------------------------------------------
+
+
+def group_class_peaks(probs: torch.Tensor, sb: torch.Tensor, sc: torch.Tensor, n_samples: int, n_channels: int):
+    """identity.py:13-76."""
+    pi_l, ci_l = [], []
+    for s in range(n_samples):
+        for c in range(n_channels):
+            members = torch.nonzero((sb == s) & (sc == c), as_tuple=True)[0]
+            if members.numel() == 0:
+                continue
+            r, k = linear_sum_assignment(-probs[members].numpy())
+            pi_l.append(members[torch.from_numpy(r)])
+            ci_l.append(torch.from_numpy(k).long())
+    if not pi_l:
+        return torch.zeros(0, dtype=torch.long), torch.zeros(0, dtype=torch.long)
+    pi, ci = torch.cat(pi_l), torch.cat(ci_l)
+    keep = probs[pi, ci] == probs[pi].max(dim=1).values
+    return pi[keep], ci[keep]
+
+
+def classify_peaks_from_maps(class_maps: torch.Tensor, pts: torch.Tensor, vals: torch.Tensor, sb: torch.Tensor, sc: torch.Tensor, n_channels: int):
+    """identity.py:79-146."""
+    B, K, H, W = class_maps.shape
+    rc = torch.round(pts).to(torch.int32)
+    col = rc[:, 0].clamp(0, W - 1).long()
+    row = rc[:, 1].clamp(0, H - 1).long()
+    probs = class_maps[sb.long(), :, row, col]
+    pi, ci = group_class_peaks(probs, sb, sc, B, n_channels)
+    points = torch.full((B, K, n_channels, 2), float("nan"))
+    pvals = torch.full((B, K, n_channels), float("nan"))
+    cprobs = torch.full((B, K, n_channels), float("nan"))
+    points[sb[pi].long(), ci, sc[pi].long()] = pts[pi]
+    pvals[sb[pi].long(), ci, sc[pi].long()] = vals[pi]
+    cprobs[sb[pi].long(), ci, sc[pi].long()] = probs[pi, ci]
+    return points, pvals, cprobs
+
+
+def multiclass_postprocess(cms: torch.Tensor, class_maps: torch.Tensor, cms_stride: int, cm_stride: int, peak_threshold: float = 0.2, refinement: Optional[str] = "integral", patch: int = 5, input_scale: float = 1.0, eff_scale: Optional[torch.Tensor] = None):
+    """layers/bottomup_multiclass.py:76-127 (no max_instances cap)."""
+    pts, vals, sb, sc = find_local_peaks(cms, peak_threshold, refinement, patch)
+    pts = pts * cms_stride
+    inst, pvals, cprobs = classify_peaks_from_maps(class_maps, pts / cm_stride, vals, sb, sc, cms.shape[1])
+    inst = inst * cm_stride
+    if input_scale != 1.0:
+        inst = inst / input_scale
+    if eff_scale is not None and not bool(torch.all(eff_scale == 1.0)):
+        inst = inst / eff_scale.view(-1, 1, 1, 1)
+    return inst, pvals, torch.nanmean(pvals, dim=-1), torch.nanmean(cprobs, dim=-1)

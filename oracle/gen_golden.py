@@ -246,7 +246,7 @@ def paf_fixture():
     save("paf.npz", **arrs)
 
 
-if __name__ == "__main__":
+def core_fixtures():
     ckpt_fixture("bottomup", "bottomup", n_frames=2)
     ckpt_fixture("single_instance", "single_instance", n_frames=2)
     tiny_unet(
@@ -275,3 +275,125 @@ if __name__ == "__main__":
     )
     peaks_fixture()
     paf_fixture()
+
+
+# ---------------------------------------------------------------------------------------
+def _load_ckpt_model(kind, model_type):
+    d = f"{REF}/tests/assets/model_ckpts/minimal_instance_{kind}"
+    cfg = yaml.safe_load(open(f"{d}/training_config.yaml"))
+    bb = cfg["model_config"]["backbone_config"]["unet"]
+    heads = cfg["model_config"]["head_configs"][model_type]
+    m = Model("unet", rh.attrdict(bb), rh.attrdict(heads), model_type).eval()
+    sd = rh.load_lightning_ckpt_state(f"{d}/best.ckpt")
+    m.load_state_dict(sd, strict=True)
+    return m, sd, bb, heads, cfg
+
+
+def topdown_fixture():
+    """Centroid + centered-instance fixture checkpoints on the frames of the reference's own
+    tests/inference/parity_golden/topdown.pkl, stage by stage through the reference ops."""
+    from sleap_nn.inference.ops.crops import crop_bboxes, make_centered_bboxes
+
+    mc, sdc, bbc, hc, cfgc = _load_ckpt_model("centroid", "centroid")
+    mi, sdi, bbi, hi, cfgi = _load_ckpt_model("centered_instance", "centered_instance")
+    gold = rh.load_pickle_tolerant(f"{REF}/tests/inference/parity_golden/topdown.pkl")
+    frames = np.stack([gold[0]["image"][0], gold[1]["image"][0]])  # two distinct frames (rows of a batch repeat the frame)
+    arrs = {"wc/" + k: _np(v) for k, v in sdc.items()}
+    arrs.update({"wi/" + k: _np(v) for k, v in sdi.items()})
+    arrs["image"] = frames
+    with torch.inference_mode():
+        img = torch.from_numpy(frames)
+        cms = mc(img.float() / 255)["CentroidConfmapsHead"]
+        # thresholds of the reference's golden capture (tests/utils/parity_goldens.py:125-134): 0.03, max_instances 6
+        p, v, sb, _ = rpeaks.find_local_peaks(cms, threshold=0.03, refinement="integral", integral_patch_size=5)
+        p = p * hc["confmaps"]["output_stride"]
+        B = frames.shape[0]
+        mi_ = 6
+        cent = torch.full((B, mi_, 2), float("nan"))
+        cval = torch.full((B, mi_), float("nan"))
+        for b in range(B):
+            m = sb == b
+            pb, vb = p[m], v[m]
+            if pb.shape[0] > mi_:
+                vb, ix = torch.topk(vb, mi_)
+                pb = pb[ix]
+            cent[b, : pb.shape[0]] = pb
+            cval[b, : pb.shape[0]] = vb
+        valid = ~torch.isnan(cent).any(-1)
+        idx = valid.nonzero()
+        vc = cent[idx[:, 0], idx[:, 1]]
+        crop = int(cfgi["data_config"]["preprocessing"]["crop_size"])
+        bboxes = make_centered_bboxes(vc, crop, crop)
+        crops = crop_bboxes(img, bboxes, idx[:, 0])
+        cms2 = mi(crops.float() / 255)["CenteredInstanceConfmapsHead"]
+        gp, gv = rpeaks.find_global_peaks(cms2, threshold=0.03, refinement="integral", integral_patch_size=5)
+        gp = gp * hi["confmaps"]["output_stride"]
+    # cross-check against the reference's own golden (first frame, its instances)
+    g0 = gold[0]
+    d = np.abs(np.nan_to_num(_np(cent[0]), nan=1e9)[:, None, :] - g0["pred_centroids"][None, :, :]).sum(-1)
+    assert d.min(axis=0).max() < 1e-3, d
+    arrs.update({"out/CentroidConfmapsHead": _np(cms), "centroids": _np(cent), "centroid_vals": _np(cval), "valid_idx": _np(idx), "bboxes": _np(bboxes),
+                 "crops": _np(crops), "out/CenteredInstanceConfmapsHead": _np(cms2), "crop_peaks": _np(gp), "crop_peak_vals": _np(gv),
+                 "gold0_pred_centroids": g0["pred_centroids"], "gold0_pred_instance_peaks": g0["pred_instance_peaks"], "gold0_instance_image": g0["instance_image"],
+                 "gold0_instance_bbox": g0["instance_bbox"]})
+    arrs["config_json"] = np.array(json.dumps({"centroid": {"backbone": bbc, "heads": hc, "model_type": "centroid"}, "centered": {"backbone": bbi, "heads": hi, "model_type": "centered_instance"}, "crop_size": crop}))
+    # randomized crop KAT (fractional, negative and out-of-frame corners; float and uint8 images)
+    g = torch.Generator().manual_seed(3)
+    im = torch.randint(0, 256, (3, 2, 40, 52), dtype=torch.uint8, generator=g)
+    pts = torch.tensor([[5.3, 4.1], [0.0, 0.0], [51.0, 39.0], [-3.6, 12.2], [25.5, -2.5], [60.0, 20.0], [26.49, 20.51]])
+    si = torch.tensor([0, 1, 2, 0, 1, 2, 1])
+    for hw in ((8, 8), (7, 11), (16, 12)):
+        bb = make_centered_bboxes(pts, hw[0], hw[1])
+        arrs[f"cropkat/{hw[0]}x{hw[1]}/u8"] = _np(crop_bboxes(im, bb, si))
+        arrs[f"cropkat/{hw[0]}x{hw[1]}/f32"] = _np(crop_bboxes(im.float() / 7, bb, si))
+        arrs[f"cropkat/{hw[0]}x{hw[1]}/bboxes"] = _np(bb)
+    arrs["cropkat/image"], arrs["cropkat/pts"], arrs["cropkat/si"] = _np(im), _np(pts), _np(si)
+    save("topdown.npz", **arrs)
+
+
+def multiclass_fixture():
+    from sleap_nn.inference.ops.identity import classify_peaks_from_maps
+
+    m, sd, bb, heads, cfg = _load_ckpt_model("multiclass_bottomup", "multi_class_bottomup")
+    gold = rh.load_pickle_tolerant(f"{REF}/tests/inference/parity_golden/multiclass_bottomup.pkl")
+    b0 = gold[0]
+    img = b0["image"][:3]
+    arrs = {"w/" + k: _np(v) for k, v in sd.items()}
+    arrs["image"] = img
+    with torch.inference_mode():
+        out = m(torch.from_numpy(img).squeeze(1).float() / 255)
+        cms, cmaps = out["MultiInstanceConfmapsHead"], out["ClassMapsHead"]
+        cs, ks = heads["confmaps"]["output_stride"], heads["class_maps"]["output_stride"]
+        p, v, sb, sc = rpeaks.find_local_peaks(cms, threshold=0.05, refinement="integral", integral_patch_size=5)  # parity_goldens.py:141-146
+        p = p * cs
+        inst, pv, cp = classify_peaks_from_maps(cmaps, p / ks, v, sb, sc, n_channels=cms.shape[1])
+        inst = inst * ks / cfg["data_config"]["preprocessing"]["scale"]
+    gk = np.stack([np.asarray(a) for a in b0["pred_instance_peaks"][:3]])
+    assert np.allclose(_np(inst), gk, atol=1e-3, equal_nan=True), (inst, gk)  # reproduces the reference golden
+    for k, t in out.items():
+        arrs["out/" + k] = _np(t)
+    arrs.update({"inst": _np(inst), "peak_vals": _np(pv), "class_probs": _np(cp), "gold_peaks": gk, "gold_vals": b0["pred_peak_values"][:3]})
+    arrs["config_json"] = np.array(json.dumps({"backbone": bb, "heads": heads, "model_type": "multi_class_bottomup", "preprocessing": cfg["data_config"]["preprocessing"]}))
+    # randomized KAT with many peaks per (sample, node) and probability ties
+    g = torch.Generator().manual_seed(11)
+    cm = torch.rand((2, 3, 24, 30), generator=g)
+    cm = (cm * 8).round() / 8  # ties
+    n = 60
+    pts = torch.rand((n, 2), generator=g) * torch.tensor([34.0, 28.0]) - 2.0
+    pts[::7] = pts[::7].round() + 0.5  # exact .5 -> round-half-even
+    vals = torch.rand((n,), generator=g)
+    sb = torch.randint(0, 2, (n,), generator=g).to(torch.int32).sort().values
+    sc = torch.randint(0, 4, (n,), generator=g).to(torch.int32)
+    ki, kv, kp = classify_peaks_from_maps(cm, pts, vals, sb, sc, n_channels=4)
+    arrs.update({"kat/class_maps": _np(cm), "kat/pts": _np(pts), "kat/vals": _np(vals), "kat/sb": _np(sb), "kat/sc": _np(sc), "kat/points": _np(ki), "kat/point_vals": _np(kv), "kat/class_probs": _np(kp)})
+    save("multiclass.npz", **arrs)
+
+
+if __name__ == "__main__":
+    only = sys.argv[1:]
+    if not only or "core" in only:
+        core_fixtures()
+    if not only or "topdown" in only:
+        topdown_fixture()
+    if not only or "multiclass" in only:
+        multiclass_fixture()

@@ -48,6 +48,9 @@ SIGNATURES = {
     "ph_local_peaks": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _f32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i64, _vp]),
     "ph_global_peaks": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _f32, _i32, _i32, _vp, _vp, _vp]),
     "ph_paf_score": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _vp, _i32, _vp, _i32, _i32, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i64, _vp]),
+    "ph_crop_bboxes": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _vp, _vp]),
+    "ph_sample_class_maps": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp]),
+    "ph_group_class_peaks": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "ph_lsap": (C.c_int, [_vp, _i32, _i32, _vp, _vp]),
     "ph_toposort_edges": (C.c_int, [_vp, _i32, _vp]),
     "ph_group_batch": (C.c_int, [_i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, C.c_double, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),

@@ -204,6 +204,49 @@ int ph_toposort_edges(const int32_t* edges, int32_t n_edges, int32_t* out_order)
   return rc;
 }
 
+int ph_group_class_peaks(const float* probs, const int32_t* sample_inds, const int32_t* channel_inds, int32_t n, int32_t n_samples,
+                         int32_t n_channels, int32_t K, int32_t* out_peak_inds, int32_t* out_class_inds) {
+  if (n < 0 || n_samples <= 0 || n_channels <= 0 || K <= 0 || (n > 0 && (!probs || !sample_inds || !channel_inds || !out_peak_inds || !out_class_inds))) {
+    ph::set_error("ph_group_class_peaks: bad arguments");
+    return PH_E_INVALID;
+  }
+  int n_out = 0;
+  std::vector<int> members;
+  std::vector<double> cost;
+  std::vector<int> rows, cols;
+  for (int smp = 0; smp < n_samples; ++smp)
+    for (int chn = 0; chn < n_channels; ++chn) {
+      members.clear();
+      for (int i = 0; i < n; ++i)
+        if (sample_inds[i] == smp && channel_inds[i] == chn) members.push_back(i);
+      if (members.empty()) continue;
+      const int nr = (int)members.size();
+      cost.resize((size_t)nr * K);
+      for (int r = 0; r < nr; ++r)
+        for (int k = 0; k < K; ++k) cost[(size_t)r * K + k] = -(double)probs[(size_t)members[r] * K + k];
+      const int nm = std::min(nr, (int)K);
+      rows.resize(nm);
+      cols.resize(nm);
+      const int rc = lsap(cost.data(), nr, K, rows.data(), cols.data());
+      if (rc < 0) {
+        ph::set_error(rc == PH_E_INFEASIBLE ? "cost matrix is infeasible" : "matrix contains invalid numeric entries");
+        return rc;
+      }
+      for (int k = 0; k < nm; ++k) {
+        const int pi = members[rows[k]];
+        const float matched = probs[(size_t)pi * K + cols[k]];
+        float best = probs[(size_t)pi * K];
+        for (int c = 1; c < K; ++c) best = std::max(best, probs[(size_t)pi * K + c]);
+        if (matched == best) {  // keep only matches that are the peak's arg-max class (identity.py:61-66)
+          out_peak_inds[n_out] = pi;
+          out_class_inds[n_out] = cols[k];
+          ++n_out;
+        }
+      }
+    }
+  return n_out;
+}
+
 int ph_group_batch(int32_t B, int32_t n_nodes, const int32_t* edges, int32_t n_edges, const float* peaks_xy, const float* peak_vals,
                    const int32_t* peak_channel, const int32_t* peak_offsets, const int32_t* cand_edge, const int32_t* cand_src,
                    const int32_t* cand_dst, const float* cand_score, const int32_t* cand_offsets, float min_line_score,

@@ -10,6 +10,8 @@
 //   get_connection_candidates .... sleap_nn/inference/ops/paf.py:84-130
 //   make_line_subs / interp1d .... paf.py:133-234, sleap_nn/inference/utils.py:29-130
 //   score_paf_lines .............. paf.py:290-410
+#include <algorithm>
+
 #include "common.h"
 
 namespace ph {
@@ -405,11 +407,75 @@ int launch_paf_score(PafScoreArgs a, const int* chan, int n_peaks_total, int* sc
   return PH_OK;
 }
 
+// ---------------------------------------------------------------------------------------
+// Crop gather + class-map sampling (top-down / multi-class glue)
+// ---------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void crop_kernel(const T* __restrict__ img, int C, int H, int W, const float* __restrict__ tl, const int* __restrict__ sidx,
+                                                   int n, int ch, int cw, T* __restrict__ out) {
+  const size_t total = (size_t)n * C * ch * cw;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int x = (int)(i % cw);
+    size_t r = i / cw;
+    const int y = (int)(r % ch);
+    r /= ch;
+    const int c = (int)(r % C);
+    const int k = (int)(r / C);
+    const int hx = cw / 2, hy = ch / 2;
+    const int ox = (int)(tl[2 * k] + (float)hx) - hx;      // trunc toward zero, as .to(torch.long)
+    const int oy = (int)(tl[2 * k + 1] + (float)hy) - hy;
+    const int gx = ox + x, gy = oy + y;
+    T v = (T)0;
+    if (gx >= 0 && gx < W && gy >= 0 && gy < H) v = img[(((size_t)sidx[k] * C + c) * H + gy) * W + gx];
+    out[i] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void sample_class_maps_kernel(const float* __restrict__ maps, int K, int H, int W, const float* __restrict__ xy,
+                                                                const int* __restrict__ sidx, int n, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * K) return;
+  const int p = i / K, k = i - p * K;
+  int col = (int)rintf(xy[2 * p]), row = (int)rintf(xy[2 * p + 1]);
+  col = min(max(col, 0), W - 1);
+  row = min(max(row, 0), H - 1);
+  out[i] = maps[(((size_t)sidx[p] * K + k) * H + row) * W + col];
+}
+
 }  // namespace ph
 
 using namespace ph;
 
 extern "C" {
+
+int ph_crop_bboxes(const void* images_dev, int32_t dtype, int32_t B, int32_t C, int32_t H, int32_t W, const float* topleft_xy_dev,
+                   const int32_t* sample_inds_dev, int32_t n, int32_t crop_h, int32_t crop_w, void* out_dev, void* stream) {
+  PH_REQUIRE(images_dev && out_dev && (n == 0 || (topleft_xy_dev && sample_inds_dev)), "ph_crop_bboxes: null argument");
+  PH_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && n >= 0 && crop_h > 0 && crop_w > 0 && (dtype == 0 || dtype == 1), "ph_crop_bboxes: bad shape/dtype");
+  if (n == 0) return PH_OK;
+  const size_t total = (size_t)n * C * crop_h * crop_w;
+  const int blocks = (int)std::min<size_t>((total + 255) / 256, 65535);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (dtype == 0)
+    hipLaunchKernelGGL(crop_kernel<uint8_t>, dim3(blocks), dim3(256), 0, s, static_cast<const uint8_t*>(images_dev), C, H, W, topleft_xy_dev,
+                       sample_inds_dev, n, crop_h, crop_w, static_cast<uint8_t*>(out_dev));
+  else
+    hipLaunchKernelGGL(crop_kernel<float>, dim3(blocks), dim3(256), 0, s, static_cast<const float*>(images_dev), C, H, W, topleft_xy_dev,
+                       sample_inds_dev, n, crop_h, crop_w, static_cast<float*>(out_dev));
+  PH_HIP_CHECK(hipGetLastError());
+  return PH_OK;
+}
+
+int ph_sample_class_maps(const float* class_maps_dev, int32_t B, int32_t K, int32_t H, int32_t W, const float* peaks_xy_dev,
+                         const int32_t* sample_inds_dev, int32_t n, float* out_probs_dev, void* stream) {
+  PH_REQUIRE(class_maps_dev && (n == 0 || (peaks_xy_dev && sample_inds_dev && out_probs_dev)), "ph_sample_class_maps: null argument");
+  PH_REQUIRE(B > 0 && K > 0 && H > 0 && W > 0 && n >= 0, "ph_sample_class_maps: bad shape");
+  if (n == 0) return PH_OK;
+  hipLaunchKernelGGL(sample_class_maps_kernel, dim3((n * K + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), class_maps_dev, K, H, W,
+                     peaks_xy_dev, sample_inds_dev, n, out_probs_dev);
+  PH_HIP_CHECK(hipGetLastError());
+  return PH_OK;
+}
 
 int ph_local_peaks(const float* cms_dev, int32_t B, int32_t C, int32_t H, int32_t W, float threshold, int32_t refine, int32_t patch, float* out_xy,
                    float* out_val, int32_t* out_sample, int32_t* out_channel, int32_t* out_count, int32_t cap, void* scratch_dev,

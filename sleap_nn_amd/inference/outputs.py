@@ -27,6 +27,8 @@ class Outputs:
     pred_centroid_values: Optional[torch.Tensor] = None
     instance_scores: Optional[torch.Tensor] = None  # (B, I)
     instance_valid: Optional[torch.Tensor] = None
+    instance_bboxes: Optional[torch.Tensor] = None  # (B, I, 4, 2)
+    instance_tracking_scores: Optional[torch.Tensor] = None  # (B, I)
     pred_class_maps: Optional[torch.Tensor] = None
     pred_paf_graph: Optional[Tuple[torch.Tensor, ...]] = None
     preprocess_info: Optional[PreprocInfo] = None

@@ -373,3 +373,78 @@ def test_cfg3_network_vs_oracle_one_frame():
     for k, v in ref.items():
         err = (out[k].cpu() - v).abs().max().item()
         assert err <= CMS_ATOL, (k, err, v.abs().max().item())
+
+
+def _wz(z, prefix):
+    return {k[len(prefix):]: torch.from_numpy(z[k]) for k in z.files if k.startswith(prefix)}
+
+
+def test_crop_gather_matches_reference():
+    from sleap_nn_amd.inference.ops.crops import crop_bboxes, make_centered_bboxes
+
+    z = G.load("topdown.npz")
+    im, pts, si = torch.from_numpy(z["cropkat/image"]), torch.from_numpy(z["cropkat/pts"]), torch.from_numpy(z["cropkat/si"])
+    for hw in ((8, 8), (7, 11), (16, 12)):
+        bb = make_centered_bboxes(pts, hw[0], hw[1])
+        assert np.allclose(bb.numpy(), z[f"cropkat/{hw[0]}x{hw[1]}/bboxes"])
+        assert np.array_equal(crop_bboxes(im.to(DEV), bb, si).cpu().numpy(), z[f"cropkat/{hw[0]}x{hw[1]}/u8"])
+        assert np.array_equal(crop_bboxes((im.float() / 7).to(DEV), bb, si).cpu().numpy(), z[f"cropkat/{hw[0]}x{hw[1]}/f32"])
+    assert crop_bboxes(im.to(DEV), torch.zeros(0, 4, 2), torch.zeros(0)).shape[0] == 0
+
+
+def test_topdown_layer_reproduces_reference():
+    from sleap_nn_amd.architectures.model import Model
+    from sleap_nn_amd.inference.backends import HipBackend
+    from sleap_nn_amd.inference.layers import CenteredInstanceLayer, CentroidLayer, PostprocessConfig, TopDownLayer
+
+    z = G.load("topdown.npz")
+    cfg = G.config(z)
+    cc, ci = cfg["centroid"], cfg["centered"]
+    mc = Model("unet", cc["backbone"], cc["heads"], "centroid")
+    mc.load_state_dict(_wz(z, "wc/"))
+    mi = Model("unet", ci["backbone"], ci["heads"], "centered_instance")
+    mi.load_state_dict(_wz(z, "wi/"))
+    pc = PostprocessConfig(peak_threshold=0.03, max_instances=6)
+    cl = CentroidLayer(HipBackend(mc, DEV), cc["heads"]["confmaps"]["output_stride"], max_instances=6, max_stride=cc["backbone"]["max_stride"], postprocess_config=pc)
+    il = CenteredInstanceLayer(HipBackend(mi, DEV), ci["heads"]["confmaps"]["output_stride"], max_stride=ci["backbone"]["max_stride"], postprocess_config=PostprocessConfig(peak_threshold=0.03))
+    td = TopDownLayer(cl, il, (cfg["crop_size"], cfg["crop_size"]), return_crops=True)
+    img = torch.from_numpy(z["image"])
+    out = td.predict(img)
+    assert np.allclose(out.pred_centroids.cpu().numpy(), z["centroids"], atol=1e-3, equal_nan=True)
+    assert np.allclose(out.pred_centroid_values.cpu().numpy(), z["centroid_vals"], atol=CMS_ATOL, equal_nan=True)
+    idx = z["valid_idx"]
+    crops = out.crops.cpu().numpy()[idx[:, 0], idx[:, 1]]
+    assert np.array_equal(crops, z["crops"])  # bit-exact uint8 crops
+    ck = out.pred_crop_keypoints.cpu().numpy()[idx[:, 0], idx[:, 1]]
+    assert np.allclose(ck, z["crop_peaks"], atol=1e-3, equal_nan=True)
+    kimg = out.pred_keypoints.cpu().numpy()[idx[:, 0], idx[:, 1]]
+    assert np.allclose(kimg, z["crop_peaks"] + z["bboxes"][:, 0][:, None, :], atol=1e-3, equal_nan=True)
+    assert np.allclose(out.pred_peak_values.cpu().numpy()[idx[:, 0], idx[:, 1]], z["crop_peak_vals"], atol=CMS_ATOL)
+
+
+def test_multiclass_bottomup_layer_reproduces_reference_golden():
+    from sleap_nn_amd.architectures.model import Model
+    from sleap_nn_amd.inference.backends import HipBackend
+    from sleap_nn_amd.inference.layers import BottomUpMultiClassLayer, PostprocessConfig
+    from sleap_nn_amd.inference.ops.identity import classify_peaks_from_maps
+
+    z = G.load("multiclass.npz")
+    cfg = G.config(z)
+    m = Model("unet", cfg["backbone"], cfg["heads"], "multi_class_bottomup")
+    m.load_state_dict(G.weights(z))
+    h = cfg["heads"]
+    layer = BottomUpMultiClassLayer(HipBackend(m, DEV), h["confmaps"]["output_stride"], h["class_maps"]["output_stride"], max_stride=cfg["backbone"]["max_stride"],
+                                    postprocess_config=PostprocessConfig(peak_threshold=0.05))
+    raw = layer.backend(torch.from_numpy(z["image"]))
+    for k in ("MultiInstanceConfmapsHead", "ClassMapsHead"):
+        assert (raw[k].cpu() - torch.from_numpy(z["out/" + k])).abs().max().item() <= CMS_ATOL  # sigmoid head included
+    out = layer.predict(torch.from_numpy(z["image"]).squeeze(1))
+    k = out.pred_keypoints.numpy() / cfg["preprocessing"]["scale"]  # golden captured with input scale 0.5
+    assert np.array_equal(np.isnan(k), np.isnan(z["gold_peaks"]))
+    assert np.allclose(k, z["gold_peaks"], atol=1e-3, equal_nan=True)
+    assert np.allclose(out.pred_peak_values.numpy(), z["peak_vals"], atol=CMS_ATOL, equal_nan=True)
+    # randomized KAT (ties, .5 coordinates) straight through the ops
+    p, v, c = classify_peaks_from_maps(torch.from_numpy(z["kat/class_maps"]).to(DEV), torch.from_numpy(z["kat/pts"]).to(DEV), torch.from_numpy(z["kat/vals"]).to(DEV),
+                                       torch.from_numpy(z["kat/sb"]).to(DEV), torch.from_numpy(z["kat/sc"]).to(DEV), 4)
+    assert np.array_equal(np.nan_to_num(p.numpy(), nan=-9), np.nan_to_num(z["kat/points"], nan=-9))
+    assert np.array_equal(np.nan_to_num(c.numpy(), nan=-9), np.nan_to_num(z["kat/class_probs"], nan=-9))

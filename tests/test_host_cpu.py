@@ -214,3 +214,20 @@ def test_backend_protocol_and_layer_type_checks():
     assert tuple(x.shape) == (1, 1, 1, 112, 80) and info.original_size == (100, 70)
     with pytest.raises(KeyError):
         layer._extract_confmaps({"a": torch.zeros(1), "b": torch.zeros(1)})
+
+
+def test_group_class_peaks_matches_oracle():
+    """C++ Hungarian class matching vs the oracle (which uses SciPy, like the reference)."""
+    from sleap_nn_amd.inference.ops.identity import group_class_peaks
+
+    rng = np.random.RandomState(5)
+    for trial in range(100):
+        n, K, B, N = rng.randint(0, 30), rng.randint(1, 5), rng.randint(1, 4), rng.randint(1, 4)
+        probs = rng.rand(n, K).astype(np.float32)
+        if trial % 2:
+            probs = (np.round(probs * 4) / 4).astype(np.float32)
+        sb = np.sort(rng.randint(0, B, size=n)).astype(np.int32)
+        sc = rng.randint(0, N, size=n).astype(np.int32)
+        rp, rc = O.group_class_peaks(torch.from_numpy(probs).reshape(n, K), torch.from_numpy(sb), torch.from_numpy(sc), B, N)
+        gp, gc = group_class_peaks(torch.from_numpy(probs).reshape(n, K), sb, sc, B, N)
+        assert np.array_equal(rp.numpy(), gp.numpy()) and np.array_equal(rc.numpy(), gc.numpy()), trial
