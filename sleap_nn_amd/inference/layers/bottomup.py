@@ -67,8 +67,12 @@ class BottomUpLayer(InferenceLayer):
         self._peak_cap, self._cand_cap = peak_cap, cand_cap
         peak_offsets = head[1 + B : 2 + 2 * B].astype(np.int32)
         cand_offsets = head[2 + 2 * B :].astype(np.int32)
-        fl = torch.cat([xy[:n_peaks].reshape(-1), vals[:n_peaks], score[:n_cand]]).cpu().numpy()
-        il = torch.cat([ch[:n_peaks], ce[:n_cand], cs[:n_cand], cd[:n_cand]]).cpu().numpy()
+        # one packed D2H for all payload arrays (int32 rows travel bit-cast as float32)
+        packed = torch.cat([xy[:n_peaks].reshape(-1), vals[:n_peaks], score[:n_cand],
+                            torch.cat([ch[:n_peaks], ce[:n_cand], cs[:n_cand], cd[:n_cand]]).view(torch.float32)]).cpu().numpy()
+        n_fl = 3 * n_peaks + n_cand
+        fl = packed[:n_fl]
+        il = packed[n_fl:].view(np.int32)
         peaks_xy = fl[: 2 * n_peaks].reshape(-1, 2)
         peak_vals = fl[2 * n_peaks : 3 * n_peaks]
         cand_score = fl[3 * n_peaks :]

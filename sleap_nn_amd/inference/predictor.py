@@ -1,0 +1,121 @@
+"""``Predictor``: run directories -> layer -> batched prediction.
+
+Surface mirror of ``sleap_nn/inference/predictor.py`` (``from_model_paths`` :925, ``predict`` :1582,
+``_batch_iter`` :1948, ``_predict_streaming_pipelined`` :2009-2074) for in-memory frame arrays
+(the reference's ``NumpyProvider`` case); video decoding, ``.slp`` writing, filters and tracking
+are outside the hot path.  The bottom-up pipeline overlaps the C++ grouping of batch *i* (a
+worker thread; the ctypes call releases the GIL) with the GPU work of batch *i+1*.
+"""
+from __future__ import annotations
+
+from concurrent.futures import ThreadPoolExecutor
+from typing import Iterator, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from sleap_nn_amd.inference.backends import HipBackend
+from sleap_nn_amd.inference.layers import (BottomUpLayer, BottomUpMultiClassLayer, CenteredInstanceLayer, CentroidLayer, PostprocessConfig,
+                                           PreprocessConfig, SingleInstanceLayer, TopDownLayer)
+from sleap_nn_amd.inference.loaders import LoadedAssets, load_model_assets
+from sleap_nn_amd.inference.ops.paf import PAFScorer
+from sleap_nn_amd.inference.outputs import Outputs
+from sleap_nn_amd.inference.streaming import group_scored_batch
+
+
+def _select_layer(assets: Sequence[LoadedAssets], device: str, post: PostprocessConfig, max_instances: Optional[int], **paf_kw):
+    """predictor.py:600 (``_select_layer``) for the model types of the hot path."""
+    by_type = {a.model_type: a for a in assets}
+
+    def backend(a):
+        return HipBackend(a.build_model(), device)
+
+    def pre(a):
+        p = a.preprocessing
+        # frames must arrive model-sized (scale / sizematcher resizes are upstream of the hot path)
+        return PreprocessConfig(ensure_rgb=p.get("ensure_rgb") or None, ensure_grayscale=p.get("ensure_grayscale") or None)
+
+    if "bottomup" in by_type:
+        a = by_type["bottomup"]
+        h = a.head_config
+        return BottomUpLayer(backend(a), PAFScorer.from_config(h, **paf_kw), h["confmaps"]["output_stride"], h["pafs"]["output_stride"],
+                             max_instances=max_instances, max_stride=a.backbone_config["max_stride"], preprocess_config=pre(a), postprocess_config=post)
+    if "single_instance" in by_type:
+        a = by_type["single_instance"]
+        return SingleInstanceLayer(backend(a), a.head_config["confmaps"]["output_stride"], max_stride=a.backbone_config["max_stride"],
+                                   preprocess_config=pre(a), postprocess_config=post)
+    if "multi_class_bottomup" in by_type:
+        a = by_type["multi_class_bottomup"]
+        h = a.head_config
+        return BottomUpMultiClassLayer(backend(a), h["confmaps"]["output_stride"], h["class_maps"]["output_stride"], max_instances=max_instances,
+                                       max_stride=a.backbone_config["max_stride"], preprocess_config=pre(a), postprocess_config=post)
+    if "centroid" in by_type and "centered_instance" in by_type:
+        c, i = by_type["centroid"], by_type["centered_instance"]
+        cl = CentroidLayer(backend(c), c.head_config["confmaps"]["output_stride"], max_instances=max_instances, max_stride=c.backbone_config["max_stride"],
+                           preprocess_config=pre(c), postprocess_config=post)
+        il = CenteredInstanceLayer(backend(i), i.head_config["confmaps"]["output_stride"], max_stride=i.backbone_config["max_stride"], postprocess_config=post)
+        crop = int(i.preprocessing.get("crop_size") or 0)
+        if crop <= 0:
+            raise ValueError("centered-instance run directory has no preprocessing.crop_size")
+        return TopDownLayer(cl, il, (crop, crop))
+    if "centroid" in by_type:
+        c = by_type["centroid"]
+        return CentroidLayer(backend(c), c.head_config["confmaps"]["output_stride"], max_instances=max_instances, max_stride=c.backbone_config["max_stride"],
+                             preprocess_config=pre(c), postprocess_config=post)
+    raise ValueError(f"unsupported combination of model types: {sorted(by_type)}")
+
+
+class Predictor:
+    def __init__(self, layer, batch_size: int = 4) -> None:
+        self.layer = layer  # any object exposing predict(image) -> Outputs (predictor.py:852-853)
+        self.batch_size = batch_size
+
+    @classmethod
+    def from_model_paths(cls, model_paths: Sequence[str], device: str = "cuda", batch_size: int = 4, peak_threshold: float = 0.2,
+                         integral_refinement: Optional[str] = "integral", integral_patch_size: int = 5, max_instances: Optional[int] = None,
+                         return_confmaps: bool = False, **paf_kw) -> "Predictor":
+        assets = [load_model_assets(p) for p in model_paths]
+        post = PostprocessConfig(peak_threshold=peak_threshold, refinement=integral_refinement or "none", integral_patch_size=integral_patch_size,
+                                 max_instances=max_instances, return_confmaps=return_confmaps)
+        return cls(_select_layer(assets, device, post, max_instances, **paf_kw), batch_size)
+
+    def _batch_iter(self, frames) -> Iterator:
+        n = len(frames)
+        for s in range(0, n, self.batch_size):
+            yield s, frames[s : s + self.batch_size]
+
+    def predict(self, frames, pipelined: bool = True) -> List[Outputs]:
+        """``frames``: (N, H, W[, C]) or (N, C, H, W) uint8/float array or tensor. One ``Outputs`` per batch."""
+        if isinstance(frames, np.ndarray):
+            frames = torch.from_numpy(frames)
+        if pipelined and isinstance(self.layer, BottomUpLayer):
+            return self._predict_streaming_pipelined(frames)
+        outs = []
+        for s, batch in self._batch_iter(frames):
+            o = self.layer.predict(batch)
+            o.frame_indices = torch.arange(s, s + len(batch))
+            outs.append(o)
+        return outs
+
+    def _predict_streaming_pipelined(self, frames) -> List[Outputs]:
+        """predictor.py:2009-2074: GPU stage inline, CPU grouping in a worker with a bounded window."""
+        layer = self.layer
+        params = layer.grouping_params()
+        outs: List[Optional[Outputs]] = []
+        pending = []
+        with ThreadPoolExecutor(max_workers=1) as pool:
+            for s, batch in self._batch_iter(frames):
+                x, info = layer.preprocess(batch)
+                raw = layer.backend(x)
+                scored = layer._score_pafs_on_gpu(raw, info)
+                pending.append((s, len(batch), pool.submit(group_scored_batch, scored, params)))
+                while len(pending) > 2:
+                    s0, n0, fut = pending.pop(0)
+                    o = fut.result()
+                    o.frame_indices = torch.arange(s0, s0 + n0)
+                    outs.append(o)
+            for s0, n0, fut in pending:
+                o = fut.result()
+                o.frame_indices = torch.arange(s0, s0 + n0)
+                outs.append(o)
+        return outs

@@ -448,3 +448,27 @@ def test_multiclass_bottomup_layer_reproduces_reference_golden():
                                        torch.from_numpy(z["kat/sb"]).to(DEV), torch.from_numpy(z["kat/sc"]).to(DEV), 4)
     assert np.array_equal(np.nan_to_num(p.numpy(), nan=-9), np.nan_to_num(z["kat/points"], nan=-9))
     assert np.array_equal(np.nan_to_num(c.numpy(), nan=-9), np.nan_to_num(z["kat/class_probs"], nan=-9))
+
+
+def test_predictor_from_run_directory_matches_golden():
+    import os
+
+    from sleap_nn_amd.inference.predictor import Predictor
+
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ckpt_dirs")
+    z = G.load("ckpt_bottomup.npz")
+    p = Predictor.from_model_paths([os.path.join(root, "minimal_instance_bottomup")], device=DEV, batch_size=1, peak_threshold=0.05)
+    frames = torch.from_numpy(z["image"]).squeeze(1)  # (2, 1, 384, 384)
+    gp = G.ragged(z, "gold_peaks")
+    for pipelined in (True, False):
+        outs = p.predict(frames, pipelined=pipelined)
+        assert len(outs) == 2 and [int(o.frame_indices[0]) for o in outs] == [0, 1]
+        for b, o in enumerate(outs):
+            n = gp[b].shape[0]
+            k = o.pred_keypoints.numpy()[0]
+            assert k.shape[0] >= n
+            assert np.allclose(k[:n], gp[b].reshape(n, -1, 2), atol=1e-3, equal_nan=True)
+    zs = G.load("ckpt_single_instance.npz")
+    ps = Predictor.from_model_paths([os.path.join(root, "minimal_instance_single_instance")], device=DEV, batch_size=2, peak_threshold=0.3)
+    o = ps.predict(torch.from_numpy(zs["image"]).squeeze(1))[0]
+    assert np.allclose(o.pred_keypoints[:, 0].cpu().numpy() / 0.5, zs["gold_peaks"], atol=1e-3, equal_nan=True)

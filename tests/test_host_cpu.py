@@ -231,3 +231,22 @@ def test_group_class_peaks_matches_oracle():
         rp, rc = O.group_class_peaks(torch.from_numpy(probs).reshape(n, K), torch.from_numpy(sb), torch.from_numpy(sc), B, N)
         gp, gc = group_class_peaks(torch.from_numpy(probs).reshape(n, K), sb, sc, B, N)
         assert np.array_equal(rp.numpy(), gp.numpy()) and np.array_equal(rc.numpy(), gc.numpy()), trial
+
+
+def test_run_directory_ingestion():
+    """Lightning ``best.ckpt`` + ``training_config.yaml`` of the reference's fixture run directories
+    (copied as data under tests/golden/ckpt_dirs) load without lightning / omegaconf installed."""
+    from sleap_nn_amd.inference.loaders import load_model_assets
+
+    d = os.path.join(ROOT, "tests", "golden", "ckpt_dirs", "minimal_instance_bottomup")
+    a = load_model_assets(d)
+    assert a.model_type == "bottomup" and a.backbone_type == "unet"
+    assert a.node_names == ["A", "B"] and a.edges == [("A", "B")]
+    m = a.build_model()
+    z = G.load("ckpt_bottomup.npz")
+    for k, v in G.weights(z).items():
+        assert torch.equal(m.state_dict()[k], v), k
+    s = load_model_assets(os.path.join(ROOT, "tests", "golden", "ckpt_dirs", "minimal_instance_single_instance"))
+    assert s.model_type == "single_instance" and s.backbone_config["in_channels"] == 3
+    with pytest.raises(FileNotFoundError):
+        load_model_assets(os.path.join(ROOT, "tests"))
