@@ -86,7 +86,7 @@ typedef struct ph_op_desc {
   int32_t weight;    /* index into the weights[] array of ph_model_create, or -1     */
   int32_t bias;      /* index into the weights[] array, or -1                        */
   int32_t out_index; /* PH_OP_HEAD: which output pointer receives the result         */
-  int32_t dst2;      /* PH_OP_STEM: pooled output slot                               */
+  int32_t dst2;      /* PH_OP_STEM: pooled output slot; PH_OP_CONV (ReLU): optional fused 2x2 max-pool slot, -1 = none */
   int32_t weight2;   /* PH_OP_STEM: second conv weight index                         */
   int32_t bias2;     /* PH_OP_STEM: second conv bias index                           */
   int32_t cmid;      /* PH_OP_STEM: channels between the two convs (<= 16)           */

@@ -62,7 +62,7 @@ class Model:
             flags = L.FLAG_SIGMOID if isinstance(head, ClassMapsHead) else 0
             self.ops.append(OpSpec(L.OP_HEAD, src, -1, -1, cin, 0, head.channels, 1, flags, name + ".weight", name + ".bias", out_index=i, label=name))
         self.unfused_ops = list(self.ops)
-        self.ops = self._fuse_stem(self.ops)
+        self.ops = self._fuse_pools(self._fuse_stem(self.ops))
         self._state: Dict[str, torch.Tensor] = {k: torch.zeros(v, dtype=torch.float32) for k, v in self.param_shapes.items()}
         self._handle = None
         self._handle_device: Optional[torch.device] = None
@@ -91,6 +91,28 @@ class Model:
             label=b.label + "+pool(fused stem)", dst2=c.dst, weight2=b.weight, bias2=b.bias, cmid=a.cout,
         )
         return [fused] + ops[3:]
+
+    @staticmethod
+    def _fuse_pools(ops: List[OpSpec]) -> List[OpSpec]:
+        """CONV(+ReLU) followed by the POOL of its output -> the conv's epilogue also writes the
+        pooled tensor (``dst2``); the full-resolution output is still written (it is the skip)."""
+        import copy
+
+        out: List[OpSpec] = []
+        i = 0
+        while i < len(ops):
+            op = ops[i]
+            nxt = ops[i + 1] if i + 1 < len(ops) else None
+            if op.kind == L.OP_CONV and (op.flags & L.FLAG_RELU) and op.dst2 < 0 and nxt is not None and nxt.kind == L.OP_POOL and nxt.src0 == op.dst:
+                f = copy.copy(op)
+                f.dst2 = nxt.dst
+                f.label = op.label + "+pool"
+                out.append(f)
+                i += 2
+                continue
+            out.append(op)
+            i += 1
+        return out
 
     @classmethod
     def from_config(cls, backbone_type, backbone_config, head_configs, model_type) -> "Model":
@@ -275,6 +297,8 @@ class Model:
             rows.append({"label": op.label.split(".")[-1], "kind": op.kind, "flops": flops, "bytes": float(in_bytes + out_bytes)})
             if op.kind != L.OP_HEAD:
                 hw[op.dst] = (oh, ow)
+            if op.kind == L.OP_CONV and op.dst2 >= 0:
+                hw[op.dst2] = ((oh + 1) // 2, (ow + 1) // 2)
         return rows
 
     def read_activation(self, conv_name: str, batch: int, height_width) -> torch.Tensor:

@@ -182,6 +182,16 @@ static int build_plan(const ph_model* m, int B, int H, int W, Plan& plan) {
     s.w = ow;
     s.offset = off;
     off += align_up((int64_t)B * oh * ow * s.cp * 4, 256);
+    if (d.kind == PH_OP_CONV && d.dst2 >= 0) {  // fused 2x2 max pool of the conv output
+      PH_REQUIRE(d.dst2 < m->n_slots && (d.flags & PH_FLAG_RELU), "fused pool needs a valid slot and a ReLU conv");
+      SlotShape& p = plan.slots[d.dst2];
+      p.c = d.cout;
+      p.cp = pad16(d.cout);
+      p.h = (oh + 1) / 2;
+      p.w = (ow + 1) / 2;
+      p.offset = off;
+      off += align_up((int64_t)B * p.h * p.w * p.cp * 4, 256);
+    }
   }
   plan.tmp_offset = off;
   plan.tmp_bytes = align_up(tmp, 256);
@@ -433,6 +443,7 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
         a.relu = (d.flags & PH_FLAG_RELU) ? 1 : 0;
         a.bn = op.bn;
         a.clock_probe = m->clock_probe;
+        a.dst_pool = d.dst2 >= 0 ? slot_ptr(d.dst2) : nullptr;
         a.wpack_dma = op.w_dma_dev;
         a.zeros = m->zeros_dev;
         rc = (m->use_dma && a.bn == 64) ? launch_conv3x3_dma(a, s) : launch_conv3x3(a, s);  // BN=32 layers: the register-staged kernel is faster
@@ -469,6 +480,7 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
         a.relu = (d.flags & PH_FLAG_RELU) ? 1 : 0;
         a.bn = op.bn;
         a.clock_probe = nullptr;
+        a.dst_pool = nullptr;
         a.wpack_dma = op.w_dma_dev;
         a.zeros = m->zeros_dev;
         rc = (m->use_dma && a.bn == 64) ? launch_conv3x3_dma(a, s) : launch_conv3x3(a, s);  // BN=32 layers: the register-staged kernel is faster

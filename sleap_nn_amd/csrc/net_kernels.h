@@ -20,6 +20,7 @@ struct ConvArgs {
   unsigned long long* clock_probe;  // diagnostic: per block {d s_memtime, d s_memrealtime}; nullptr = off
   const float* wpack_dma;  // weights in the LDS-DMA layout (quad-major 16-row pieces), or nullptr
   const float* zeros;      // >= 64 B of zeros in HBM (source of out-of-image halo pixels for LDS-DMA)
+  float* dst_pool;         // optional fused 2x2/2 max pool of the (ReLU'd) output, NHWC ceil(H/2) x ceil(W/2); nullptr = off
 };
 
 struct InputConvArgs {

@@ -37,6 +37,55 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int TH = 8, TW = 32, KC = 16, LROW = 20;
 constexpr int HALO_W = TW + 2, HALO_H = TH + 2;
 
+// 1-D grid of tiles * n_tiles workgroups.  Workgroups are dealt round-robin over the 8 XCDs
+// (ids b and b+8 share an XCD and its private L2), so the N tiles of one pixel tile are given
+// ids 8 apart: they run at the same time on the same XCD and their identical input-halo reads
+// hit in L2 instead of going out to HBM once per N tile.  (Speed only; any placement is correct.)
+__device__ __forceinline__ void decode_block(int tiles, int nt_count, int* tile, int* ntile) {
+  const int id = blockIdx.x;
+  if ((tiles & 7) == 0) {
+    const int xcd = id & 7, j = id >> 3;
+    *ntile = j % nt_count;
+    *tile = (j / nt_count) * 8 + xcd;
+  } else {
+    *ntile = id % nt_count;
+    *tile = id / nt_count;
+  }
+}
+
+// Fused 2x2/2 max pool of a wave's two accumulator rows (rows 2w, 2w+1 of the tile; C/D map
+// x = (r&3) + 8*(r>>2) + 4*(lane>>5)): x pairs are register pairs, y pairs the two M tiles.
+// Out-of-image elements count as 0 = the reference's zero pad (values are >= 0 after ReLU).
+template <int NT>
+__device__ __forceinline__ void store_pooled(const ConvArgs& a, f32x16 (&acc)[2][NT], int b, int x0, int y_top, int ntile_base, int lx, int lh, bool interior) {
+  const int Hp = (a.H + 1) >> 1, Wp = (a.W + 1) >> 1;
+  const int py = y_top >> 1;
+  if (py >= Hp) return;
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    const int co = ntile_base + n * 32 + lx;
+    if (co >= a.coutp) continue;
+    float* prow = a.dst_pool + ((size_t)(b * Hp + py) * Wp) * a.coutp + co;
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq)
+#pragma unroll
+      for (int pr = 0; pr < 2; ++pr) {
+        const int px = (x0 >> 1) + 4 * rq + 2 * lh + pr;
+        const int r0 = 4 * rq + 2 * pr;
+        float v00 = acc[0][n][r0], v01 = acc[0][n][r0 + 1], v10 = acc[1][n][r0], v11 = acc[1][n][r0 + 1];
+        if (!interior) {
+          const int x = x0 + 2 * pr + 8 * rq + 4 * lh;
+          const bool xa = x < a.W, xb = x + 1 < a.W, ya = y_top < a.H, yb = y_top + 1 < a.H;
+          v00 = (xa && ya) ? v00 : 0.f;
+          v01 = (xb && ya) ? v01 : 0.f;
+          v10 = (xa && yb) ? v10 : 0.f;
+          v11 = (xb && yb) ? v11 : 0.f;
+        }
+        if (px < Wp) prow[(size_t)px * a.coutp] = fmaxf(fmaxf(v00, v01), fmaxf(v10, v11));
+      }
+  }
+}
+
 template <int BN>
 __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -53,12 +102,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(ConvArgs a) {
   const int wave = tid >> 6;
   const int tiles_x = (a.W + TW - 1) / TW;
   const int tiles_y = (a.H + TH - 1) / TH;
-  int t = blockIdx.x;
+  int t, ntile;
+  decode_block(tiles_x * tiles_y * a.B, (a.coutp + BN - 1) / BN, &t, &ntile);
   const int tx = t % tiles_x;
   t /= tiles_x;
   const int ty = t % tiles_y;
   const int b = t / tiles_y;
-  const int ntile = blockIdx.y;
   const int x0 = tx * TW, y0 = ty * TH;
 
   f32x16 acc[2][NT];
@@ -208,7 +257,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(ConvArgs a) {
   }
 #ifdef PH_STAMP
   if (a.clock_probe && lane == 0) {
-    const size_t bi = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave;
+    const size_t bi = ((size_t)blockIdx.x) * 4 + wave;
     a.clock_probe[4 * bi + 0] = st_commit;
     a.clock_probe[4 * bi + 1] = st_bar1;
     a.clock_probe[4 * bi + 2] = st_mfma;
@@ -235,6 +284,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(ConvArgs a) {
       }
   }
   const bool interior = (x0 + TW <= a.W) && (y0 + TH <= a.H) && ((ntile + 1) * BN <= a.coutp);
+  if (a.dst_pool) store_pooled<NT>(a, acc, b, x0, y0 + 2 * wave, ntile * BN, lx, lh, interior);
   if (interior) {
 #pragma unroll
     for (int n = 0; n < NT; ++n)
@@ -264,7 +314,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(ConvArgs a) {
   if (a.clock_probe && lane == 0) {  // shader clock = dt_memtime / dt_memrealtime * 100 MHz
     __builtin_amdgcn_s_waitcnt(0);  // include the store drain
     const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
-    const size_t bi = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave;
+    const size_t bi = ((size_t)blockIdx.x) * 4 + wave;
     a.clock_probe[4 * bi + 0] = t_loop - t0;   // kernel entry -> end of K loop
     a.clock_probe[4 * bi + 1] = t1 - t0;       // kernel entry -> stores drained
     a.clock_probe[4 * bi + 2] = r1 - r0;       // same span on the 100 MHz counter
@@ -286,11 +336,11 @@ int launch_conv3x3(const ConvArgs& a, hipStream_t s) {
   const int tiles = ((a.W + TW - 1) / TW) * ((a.H + TH - 1) / TH) * a.B;
   if (a.bn == 64) {
     const size_t lds = (HALO_H * HALO_W + 9 * 64) * LROW * sizeof(float) + debug_lds_pad();
-    dim3 grid(tiles, (a.coutp + 63) / 64);
+    dim3 grid(tiles * ((a.coutp + 63) / 64));
     hipLaunchKernelGGL(conv3x3_mfma_kernel<64>, grid, dim3(256), lds, s, a);
   } else {
     const size_t lds = (HALO_H * HALO_W + 9 * 32) * LROW * sizeof(float);
-    dim3 grid(tiles, (a.coutp + 31) / 32);
+    dim3 grid(tiles * ((a.coutp + 31) / 32));
     hipLaunchKernelGGL(conv3x3_mfma_kernel<32>, grid, dim3(256), lds, s, a);
   }
   PH_HIP_CHECK(hipGetLastError());
@@ -332,12 +382,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mfma_dma_kernel(ConvArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tiles_x = (a.W + TW - 1) / TW;
   const int tiles_y = (a.H + D_TH - 1) / D_TH;
-  int t = blockIdx.x;
+  int t, ntile;
+  decode_block(tiles_x * tiles_y * a.B, (a.coutp + BN - 1) / BN, &t, &ntile);
   const int tx = t % tiles_x;
   t /= tiles_x;
   const int ty = t % tiles_y;
   const int b = t / tiles_y;
-  const int ntile = blockIdx.y;
   const int x0 = tx * TW, y0 = ty * D_TH;
 
   f32x16 acc[2][NT];
@@ -471,6 +521,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mfma_dma_kernel(ConvArgs a) {
       }
   }
   const bool interior = (x0 + TW <= a.W) && (y0 + D_TH <= a.H) && ((ntile + 1) * BN <= a.coutp);
+  if (a.dst_pool) store_pooled<NT>(a, acc, b, x0, y0 + 2 * wave, ntile * BN, lx, lh, interior);
   if (interior) {
 #pragma unroll
     for (int n = 0; n < NT; ++n)
@@ -502,10 +553,10 @@ int launch_conv3x3_dma(const ConvArgs& a, hipStream_t s) {
   const int tiles = ((a.W + TW - 1) / TW) * ((a.H + D_TH - 1) / D_TH) * a.B;
   if (a.bn == 64) {
     const size_t lds = (size_t)2 * (D_A_PIECES + 9 * 64 / 16) * 1024;
-    hipLaunchKernelGGL(conv3x3_mfma_dma_kernel<64>, dim3(tiles, (a.coutp + 63) / 64), dim3(512), lds, s, a);
+    hipLaunchKernelGGL(conv3x3_mfma_dma_kernel<64>, dim3(tiles * ((a.coutp + 63) / 64)), dim3(512), lds, s, a);
   } else {
     const size_t lds = (size_t)2 * (D_A_PIECES + 9 * 32 / 16) * 1024;
-    hipLaunchKernelGGL(conv3x3_mfma_dma_kernel<32>, dim3(tiles, (a.coutp + 31) / 32), dim3(512), lds, s, a);
+    hipLaunchKernelGGL(conv3x3_mfma_dma_kernel<32>, dim3(tiles * ((a.coutp + 31) / 32)), dim3(512), lds, s, a);
   }
   PH_HIP_CHECK(hipGetLastError());
   return PH_OK;

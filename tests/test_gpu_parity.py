@@ -472,3 +472,25 @@ def test_predictor_from_run_directory_matches_golden():
     ps = Predictor.from_model_paths([os.path.join(root, "minimal_instance_single_instance")], device=DEV, batch_size=2, peak_threshold=0.3)
     o = ps.predict(torch.from_numpy(zs["image"]).squeeze(1))[0]
     assert np.allclose(o.pred_keypoints[:, 0].cpu().numpy() / 0.5, zs["gold_peaks"], atol=1e-3, equal_nan=True)
+
+
+def test_fused_pool_epilogue_odd_sizes_and_unfused_equivalence():
+    """Encoder-only nets (head on the middle block) accept any input size: exercises the zero-padded
+    odd-size pooling of the fused conv+pool epilogue in both conv kernels, against the oracle."""
+    from sleap_nn_amd import _lib as L
+    from sleap_nn_amd.architectures.model import Model
+
+    for filters, hw in ((32, (36, 44)), (64, (72, 52)), (20, (17, 33))):
+        bb = {"in_channels": 1, "kernel_size": 3, "filters": filters, "filters_rate": 2, "max_stride": 8, "stem_stride": None, "middle_block": True,
+              "up_interpolate": True, "stacks": 1, "convs_per_block": 2, "output_stride": 8}
+        heads = {"confmaps": {"part_names": ["a", "b", "c"], "output_stride": 8}}
+        sd = O.init_state(bb, heads, "single_instance", seed=filters, head_scale=1.0)
+        g = torch.Generator().manual_seed(filters)
+        img = torch.randint(0, 256, (2, 1, hw[0], hw[1]), dtype=torch.uint8, generator=g)
+        ref = O.model_forward(sd, bb, heads, "single_instance", img)["SingleInstanceConfmapsHead"]
+        m = Model("unet", bb, heads, "single_instance")
+        m.load_state_dict(sd)
+        assert any(o.kind == L.OP_CONV and o.dst2 >= 0 for o in m.ops) and not any(o.kind == L.OP_POOL for o in m.ops)
+        out = m.to(DEV)(img.to(DEV))["SingleInstanceConfmapsHead"].cpu()
+        assert out.shape == ref.shape
+        assert (out - ref).abs().max().item() <= CMS_ATOL * max(1.0, ref.abs().max().item()), (filters, hw)
