@@ -206,6 +206,21 @@ def main():
         stack_ms = sum(ms for _, ms in stack_rows)
         fwd_ms = sum(op_ms) / max(n_fw, 1)
         achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+        # HBM traffic of the conv launches: measured with rocprofv3 PMC passes (FETCH_SIZE x2 gfx950
+        # correction, WRITE_SIZE; tools/summarize_pmc.py) on this same command and committed under
+        # profiles/; bench.py itself cannot read PMCs, so it reports the newest committed figure.
+        traffic, traffic_src = None, None
+        import glob
+
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_conv_traffic.json")))
+        if cands and B == 32:
+            try:
+                tj = json.load(open(cands[-1]))["conv3x3_mfma"]
+                if int(round(tj["launches_per_forward"])) == len(conv_rows):
+                    traffic, traffic_src = tj["hbm_bytes_per_launch"], os.path.relpath(cands[-1], ROOT)
+            except Exception:
+                pass
+        conv_bytes = sum(r["bytes"] for r, _ in conv_rows)
         frames_total = B * world * args.steps
         res = {
             "metric": "frames/sec bottom-up UNet 1024x1024 inference",
@@ -229,7 +244,8 @@ def main():
             "roofline": {
                 "bound": "mfma", "kernel": f"conv3x3_mfma_kernel ({len(conv_rows)} launches/forward; the first encoder block runs in the fused stem kernel)",
                 "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS,
-                "traffic": None,
+                "traffic": traffic, "traffic_unit": "HBM bytes per conv launch (PMC, avg over the launches of one forward)",
+                "traffic_source": traffic_src, "algorithmic_bytes_per_launch": conv_bytes / max(len(conv_rows), 1),
                 "algorithmic_gflop_per_forward": conv_flops / 1e9, "kernel_ms_per_forward": conv_ms,
                 "avg_launch_ms": conv_ms / max(len(conv_rows), 1), "launches_per_forward": len(conv_rows),
                 "conv_stack_tflops": stack_flops / (stack_ms * 1e-3) / 1e12 if stack_ms > 0 else 0.0,
