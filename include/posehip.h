@@ -116,6 +116,38 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
                      int32_t in_channels, int32_t height, int32_t width, void* workspace_dev,
                      int64_t workspace_bytes, float* const* out_dev, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * Training step pieces (forward = ph_model_forward on the UNFUSED program with bilinear
+ * up-sampling; reference: training/lightning_modules.py:1850-1922, training/losses.py:8-63,
+ * torch.optim.Adam as configured at lightning_modules.py:752-763).
+ * The "canonical parameter arena" is weights[] of ph_model_create concatenated in order
+ * (each in the reference's state_dict layout), fp32, on the device.
+ * ---------------------------------------------------------------------------------- */
+int64_t ph_model_num_params(const ph_model* m);
+
+/* Rebuild every packed weight buffer of the model from the canonical arena (device gather). */
+int ph_model_set_params(ph_model* m, const float* params_flat_dev, void* stream);
+
+int64_t ph_model_backward_workspace_bytes(const ph_model* m, int32_t batch, int32_t height, int32_t width);
+
+/* Loss + backward of the last ph_model_forward (same input, shapes and activation workspace).
+ *   head_out_dev[i] / target_dev[i]: (B, c_i, h_i, w_i) NCHW fp32 predictions and targets.
+ *   loss = sum_i loss_weights[i] * (MSE_i [+ OHKM_i]);  loss_dev: float[1 + n_outputs] = {total, per head}.
+ *   grads_flat_dev: d loss / d params in the canonical arena layout (every entry is written).
+ * Deterministic (fixed-order reductions, no float atomics). */
+int ph_model_backward(ph_model* m, const void* input_dev, int32_t in_dtype, int32_t batch, int32_t in_channels,
+                      int32_t height, int32_t width, const void* act_workspace_dev, void* grad_workspace_dev,
+                      int64_t grad_workspace_bytes, const float* const* head_out_dev, const float* const* target_dev,
+                      const float* loss_weights_host, int32_t ohkm_enabled, float hard_to_easy_ratio,
+                      int32_t min_hard_keypoints, int32_t max_hard_keypoints, float ohkm_loss_scale,
+                      float* loss_dev, float* grads_flat_dev, void* stream);
+
+/* torch.optim.Adam step (weight_decay = 0) on flat device arrays; max_exp_avg_sq_dev != NULL enables
+ * amsgrad.  grad_scale multiplies the gradient first (1/world_size after a sum all-reduce). */
+int ph_adam_step(float* params_dev, const float* grads_dev, float* exp_avg_dev, float* exp_avg_sq_dev,
+                 float* max_exp_avg_sq_dev, int64_t n, float lr, float beta1, float beta2, float eps,
+                 int32_t step, float grad_scale, void* stream);
+
 /* Per-op timing with HIP events recorded on the forward's own stream (used by bench.py for
  * the roofline object).  While enabled every forward records one event before each op and
  * one after the last; ph_model_profile_read waits for the last recorded forward, returns

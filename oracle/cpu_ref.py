@@ -830,3 +830,50 @@ def multiclass_postprocess(cms: torch.Tensor, class_maps: torch.Tensor, cms_stri
     if eff_scale is not None and not bool(torch.all(eff_scale == 1.0)):
         inst = inst / eff_scale.view(-1, 1, 1, 1)
     return inst, pvals, torch.nanmean(pvals, dim=-1), torch.nanmean(cprobs, dim=-1)
+
+
+# --------------------------------------------------------------------------------------
+# Training step (training/lightning_modules.py:490-545,1850-1922, training/losses.py:8-63,
+# torch.optim.Adam at lightning_modules.py:752-763) -- torch autograd on the CPU.
+# --------------------------------------------------------------------------------------
+
+
+def ohkm_loss(y_gt: torch.Tensor, y_pr: torch.Tensor, hard_to_easy_ratio=2.0, min_hard_keypoints=2, max_hard_keypoints=None, loss_scale=5.0) -> torch.Tensor:
+    """losses.py:8-63."""
+    loss = (y_pr - y_gt) ** 2
+    shp = loss.shape
+    per_ch = torch.sum(loss, dim=(0, 2, 3))
+    best = torch.min(per_ch)
+    n_hard = int(torch.sum(((per_ch / best) >= hard_to_easy_ratio).to(torch.int32)))
+    mx = per_ch.shape[0] if (max_hard_keypoints is None or max_hard_keypoints < 0) else min(max_hard_keypoints, per_ch.shape[0])
+    k = min(max(n_hard, min_hard_keypoints), mx)
+    k_vals, _ = torch.topk(per_ch, k=k, largest=True, sorted=False)
+    return torch.sum(k_vals * loss_scale) / (shp[0] * shp[2] * shp[3] * k)
+
+
+def training_step(sd: Dict[str, torch.Tensor], bb: dict, head_cfgs: dict, model_type: str, image: torch.Tensor, targets: Dict[str, torch.Tensor],
+                  loss_weights: Sequence[float], ohkm: Optional[dict] = None):
+    """Forward + weighted per-head MSE (+OHKM) + autograd backward.  Returns (losses [total, heads...], grads dict)."""
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    out = model_forward(params, bb, head_cfgs, model_type, image)
+    heads = [h for h, _ in HEAD_ORDER[model_type]]
+    hl = []
+    for h in heads:
+        l = F.mse_loss(out[h], targets[h])
+        if ohkm:
+            l = l + ohkm_loss(targets[h], out[h], **ohkm)
+        hl.append(l)
+    total = sum(w * l for w, l in zip(loss_weights, hl))
+    total.backward()
+    return [float(total.detach())] + [float(l.detach()) for l in hl], {k: p.grad for k, p in params.items()}
+
+
+def adam_reference(sd: Dict[str, torch.Tensor], grads_per_step: List[Dict[str, torch.Tensor]], lr=1e-4, amsgrad=False):
+    """torch.optim.Adam itself, stepped with the given gradients."""
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    opt = torch.optim.Adam(list(params.values()), lr=lr, amsgrad=amsgrad)
+    for g in grads_per_step:
+        for k, p in params.items():
+            p.grad = g[k].clone()
+        opt.step()
+    return {k: p.detach() for k, p in params.items()}

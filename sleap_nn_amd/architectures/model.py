@@ -62,7 +62,8 @@ class Model:
             flags = L.FLAG_SIGMOID if isinstance(head, ClassMapsHead) else 0
             self.ops.append(OpSpec(L.OP_HEAD, src, -1, -1, cin, 0, head.channels, 1, flags, name + ".weight", name + ".bias", out_index=i, label=name))
         self.unfused_ops = list(self.ops)
-        self.ops = self._fuse_pools(self._fuse_stem(self.ops))
+        self.fused_ops = self._fuse_pools(self._fuse_stem(self.ops))
+        self.ops = self.fused_ops
         self._state: Dict[str, torch.Tensor] = {k: torch.zeros(v, dtype=torch.float32) for k, v in self.param_shapes.items()}
         self._handle = None
         self._handle_device: Optional[torch.device] = None
@@ -145,7 +146,34 @@ class Model:
         return sum(int(torch.tensor(s).prod()) for s in self.param_shapes.values())
 
     def eval(self) -> "Model":
+        return self.set_fusion(True)
+
+    def train(self, mode: bool = True) -> "Model":
+        """Training keeps every activation: the op-by-op (unfused) program runs."""
+        return self.set_fusion(not mode)
+
+    def set_fusion(self, fused: bool) -> "Model":
+        want = self.fused_ops if fused else self.unfused_ops
+        if want is not self.ops:
+            self.ops = want
+            self._release()
         return self
+
+    def param_keys(self) -> List[str]:
+        """Order of the canonical flat parameter arena (= ph_model_create's weights[])."""
+        return list(self.param_shapes.keys())
+
+    def flat_params(self) -> torch.Tensor:
+        return torch.cat([self._state[k].reshape(-1) for k in self.param_keys()])
+
+    def load_flat_params(self, flat: torch.Tensor) -> None:
+        """Host copy of the arena back into the state dict (e.g. for checkpointing)."""
+        flat = flat.detach().to("cpu", torch.float32)
+        o = 0
+        for k in self.param_keys():
+            n = self._state[k].numel()
+            self._state[k] = flat[o : o + n].reshape(self.param_shapes[k]).clone()
+            o += n
 
     def to(self, device) -> "Model":
         self.device = torch.device(device)

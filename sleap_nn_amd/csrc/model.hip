@@ -9,8 +9,7 @@
 #include <mutex>
 #include <vector>
 
-#include "common.h"
-#include "net_kernels.h"
+#include "model_internal.h"
 
 namespace ph {
 
@@ -25,50 +24,11 @@ void set_error(const char* fmt, ...) {
   g_err = buf;
 }
 
-struct PackedOp {
-  ph_op_desc d;
-  float* w_dev = nullptr;
-  float* b_dev = nullptr;
-  float* w2_dev = nullptr;
-  float* b2_dev = nullptr;
-  float* w_dma_dev = nullptr;  // conv weights in the LDS-DMA (quad-major piece) layout
-  int bn = 0;
-};
-
-struct SlotShape {
-  int c = 0, cp = 0, h = 0, w = 0;
-  int64_t offset = -1;
-};
-
-struct Plan {
-  std::vector<SlotShape> slots;
-  int64_t tmp_offset = 0, tmp_bytes = 0, total = 0;
-};
-
 }  // namespace ph
-
-struct ph_model {
-  std::vector<ph::PackedOp> ops;
-  int n_slots = 0, n_outputs = 0;
-  std::vector<void*> allocs;
-  // last forward (for ph_model_read_slot)
-  ph::Plan last_plan;
-  char* last_ws = nullptr;
-  int last_batch = 0;
-  // optional per-op HIP-event timing (ph_model_set_profiling)
-  bool profiling = false;
-  bool events_pending = false;
-  std::vector<hipEvent_t> ev;      // n_ops + 1 events: ev[i] before op i, ev[n_ops] after the last
-  std::vector<double> op_ms;       // accumulated per op
-  int profiled_forwards = 0;
-  unsigned long long* clock_probe = nullptr;  // diagnostic buffer (ph_model_set_clock_probe)
-  float* zeros_dev = nullptr;                 // zero page for LDS-DMA halo padding
-  bool use_dma = true;                        // PH_CONV_IMPL=reg selects the register-staged kernel
-};
 
 namespace ph {
 
-static int upload(ph_model* m, const std::vector<float>& host, float** dev) {
+int upload(ph_model* m, const std::vector<float>& host, float** dev) {
   void* p = nullptr;
   PH_HIP_CHECK(hipMalloc(&p, std::max<size_t>(host.size(), 4) * sizeof(float)));
   m->allocs.push_back(p);
@@ -77,9 +37,45 @@ static int upload(ph_model* m, const std::vector<float>& host, float** dev) {
   return PH_OK;
 }
 
+int upload_ints(ph_model* m, const std::vector<int>& host, int** dev) {
+  void* p = nullptr;
+  PH_HIP_CHECK(hipMalloc(&p, std::max<size_t>(host.size(), 4) * sizeof(int)));
+  m->allocs.push_back(p);
+  PH_HIP_CHECK(hipMemcpy(p, host.data(), host.size() * sizeof(int), hipMemcpyHostToDevice));
+  *dev = static_cast<int*>(p);
+  return PH_OK;
+}
+
+// Upload a packed value array together with its gather map.  `packed_idx` is the SAME packing
+// applied to an array holding (canonical index + 1) as floats (exact below 2^24 parameters).
+static int upload_packed(ph_model* m, const std::vector<float>& packed_val, const std::vector<float>& packed_idx, float** dev) {
+  int rc = upload(m, packed_val, dev);
+  if (rc != PH_OK) return rc;
+  std::vector<int> map(packed_idx.size());
+  for (size_t i = 0; i < packed_idx.size(); ++i) map[i] = (int)packed_idx[i] - 1;
+  PackedBuffer pb;
+  pb.dst = *dev;
+  pb.n = packed_val.size();
+  rc = upload_ints(m, map, &pb.map);
+  if (rc != PH_OK) return rc;
+  m->packed.push_back(pb);
+  return PH_OK;
+}
+
+// OIHW (cout, cin_total, 3, 3) -> the conv weight of the data gradient wrt channels
+// [ci_off, ci_off + cin_part): Wd[o = ci][i = co][ky][kx] = W[co][ci_off + ci][2-ky][2-kx].
+static void dgrad_weight(const float* w, int cout, int cin_total, int ci_off, int cin_part, std::vector<float>& out) {
+  out.assign((size_t)cin_part * cout * 9, 0.f);
+  for (int ci = 0; ci < cin_part; ++ci)
+    for (int co = 0; co < cout; ++co)
+      for (int ky = 0; ky < 3; ++ky)
+        for (int kx = 0; kx < 3; ++kx)
+          out[(((size_t)ci * cout + co) * 3 + ky) * 3 + kx] = w[(((size_t)co * cin_total + ci_off + ci) * 3 + (2 - ky)) * 3 + (2 - kx)];
+}
+
 // Conv2d OIHW (cout, cin0+cin1, 3, 3) or ConvTranspose2d IOHW (cin0, cout, 3, 3) ->
 // [n_tile][chunk][tap][bn][16] with channel/row padding zeros.
-static void pack_conv(const float* w, bool transposed, int cin0, int cin1, int cout, int bn, std::vector<float>& out) {
+void pack_conv(const float* w, bool transposed, int cin0, int cin1, int cout, int bn, std::vector<float>& out) {
   const int c0p = pad16(cin0), c1p = cin1 > 0 ? pad16(cin1) : 0;
   const int coutp = pad16(cout);
   const int ntiles = (coutp + bn - 1) / bn;
@@ -117,7 +113,7 @@ static void pack_conv(const float* w, bool transposed, int cin0, int cin1, int c
 
 // [n_tile][chunk][tap][bn][16] -> [n_tile][chunk][piece = (tap*bn + n)/16][quad q][row r = (tap*bn+n)%16][4]
 // (the order in which one LDS-DMA wave-instruction writes a 1-KiB piece, see conv3x3_mfma_dma_kernel)
-static void repack_dma(const std::vector<float>& in, int bn, std::vector<float>& out) {
+void repack_dma(const std::vector<float>& in, int bn, std::vector<float>& out) {
   out.resize(in.size());
   const size_t panel = (size_t)9 * bn * 16;
   for (size_t base = 0; base < in.size(); base += panel)
@@ -128,9 +124,9 @@ static void repack_dma(const std::vector<float>& in, int bn, std::vector<float>&
       }
 }
 
-static int choose_bn(int coutp) { return coutp >= 64 ? 64 : 32; }
+int choose_bn(int coutp) { return coutp >= 64 ? 64 : 32; }
 
-static int build_plan(const ph_model* m, int B, int H, int W, Plan& plan) {
+int build_plan(const ph_model* m, int B, int H, int W, Plan& plan) {
   plan.slots.assign(m->n_slots, SlotShape());
   int64_t off = 0, tmp = 0;
   for (const PackedOp& op : m->ops) {
@@ -246,11 +242,25 @@ ph_model* ph_model_create(const ph_op_desc* ops, int32_t n_ops, const float* con
     ph_model_destroy(m);
     return nullptr;
   };
+  // canonical parameter arena = weights[] concatenated in the given order
+  m->weight_offset.resize(n_weights);
+  m->weight_numel.assign(weight_numel, weight_numel + n_weights);
+  for (int i = 0; i < n_weights; ++i) {
+    m->weight_offset[i] = m->n_params;
+    m->n_params += weight_numel[i];
+  }
+  if (m->n_params >= (int64_t)1 << 24) return (set_error("models with >= 2^24 parameters are not supported yet (gather maps are built through fp32)"), ph_model_destroy(m), nullptr);
+  auto index_array = [&](int wi) {
+    std::vector<float> v((size_t)(wi >= 0 ? weight_numel[wi] : 0));
+    for (size_t k = 0; k < v.size(); ++k) v[k] = (float)(m->weight_offset[wi] + (int64_t)k + 1);
+    return v;
+  };
   for (int i = 0; i < n_ops; ++i) {
     PackedOp op;
     op.d = ops[i];
     const ph_op_desc& d = op.d;
     const bool has_w = d.kind == PH_OP_INPUT_CONV || d.kind == PH_OP_CONV || d.kind == PH_OP_CONVT || d.kind == PH_OP_HEAD;
+    bool ok = true;
     if (d.kind == PH_OP_STEM) {
       if (d.ksize != 3 || d.cmid < 1 || d.cmid > 16 || d.cout < 1 || d.cout > 16 || (d.cin0 != 1 && d.cin0 != 3))
         return fail("fused stem needs kernel 3, 1 or 3 input channels and <= 16 filters", i);
@@ -260,71 +270,104 @@ ph_model* ph_model_create(const ph_op_desc* ops, int32_t n_ops, const float* con
       if (weight_numel[d.weight] != (int64_t)d.cmid * d.cin0 * 9 || weight_numel[d.bias] != d.cmid ||
           weight_numel[d.weight2] != (int64_t)d.cout * d.cmid * 9 || weight_numel[d.bias2] != d.cout)
         return fail("stem weight size mismatch", i);
-      const float *w0 = weights[d.weight], *b0 = weights[d.bias], *w1 = weights[d.weight2], *b1 = weights[d.bias2];
-      std::vector<float> p0((size_t)9 * d.cin0 * 16, 0.f), pb0(16, 0.f), p1((size_t)9 * 16 * 16, 0.f), pb1(16, 0.f);
-      for (int co = 0; co < d.cmid; ++co)
-        for (int ci = 0; ci < d.cin0; ++ci)
-          for (int tap = 0; tap < 9; ++tap) p0[((size_t)tap * d.cin0 + ci) * 16 + co] = w0[((size_t)co * d.cin0 + ci) * 9 + tap];
-      for (int co = 0; co < d.cout; ++co)
-        for (int ci = 0; ci < d.cmid; ++ci)
-          for (int tap = 0; tap < 9; ++tap) p1[((size_t)tap * 16 + co) * 16 + ci] = w1[((size_t)co * d.cmid + ci) * 9 + tap];
-      std::memcpy(pb0.data(), b0, d.cmid * sizeof(float));
-      std::memcpy(pb1.data(), b1, d.cout * sizeof(float));
-      if (upload(m, p0, &op.w_dev) != PH_OK || upload(m, pb0, &op.b_dev) != PH_OK || upload(m, p1, &op.w2_dev) != PH_OK ||
-          upload(m, pb1, &op.b2_dev) != PH_OK) {
-        ph_model_destroy(m);
-        return nullptr;
-      }
+      auto pack_stem = [&](const float* w0, const float* b0, const float* w1, const float* b1, std::vector<float>& p0, std::vector<float>& pb0,
+                           std::vector<float>& p1, std::vector<float>& pb1) {
+        p0.assign((size_t)9 * d.cin0 * 16, 0.f);
+        pb0.assign(16, 0.f);
+        p1.assign((size_t)9 * 16 * 16, 0.f);
+        pb1.assign(16, 0.f);
+        for (int co = 0; co < d.cmid; ++co)
+          for (int ci = 0; ci < d.cin0; ++ci)
+            for (int tap = 0; tap < 9; ++tap) p0[((size_t)tap * d.cin0 + ci) * 16 + co] = w0[((size_t)co * d.cin0 + ci) * 9 + tap];
+        for (int co = 0; co < d.cout; ++co)
+          for (int ci = 0; ci < d.cmid; ++ci)
+            for (int tap = 0; tap < 9; ++tap) p1[((size_t)tap * 16 + co) * 16 + ci] = w1[((size_t)co * d.cmid + ci) * 9 + tap];
+        std::memcpy(pb0.data(), b0, d.cmid * sizeof(float));
+        std::memcpy(pb1.data(), b1, d.cout * sizeof(float));
+      };
+      std::vector<float> v[4], x[4];
+      pack_stem(weights[d.weight], weights[d.bias], weights[d.weight2], weights[d.bias2], v[0], v[1], v[2], v[3]);
+      const std::vector<float> i0 = index_array(d.weight), i1 = index_array(d.bias), i2 = index_array(d.weight2), i3 = index_array(d.bias2);
+      pack_stem(i0.data(), i1.data(), i2.data(), i3.data(), x[0], x[1], x[2], x[3]);
+      ok = upload_packed(m, v[0], x[0], &op.w_dev) == PH_OK && upload_packed(m, v[1], x[1], &op.b_dev) == PH_OK &&
+           upload_packed(m, v[2], x[2], &op.w2_dev) == PH_OK && upload_packed(m, v[3], x[3], &op.b2_dev) == PH_OK;
     } else if (has_w) {
       if (d.weight < 0 || d.weight >= n_weights || d.bias >= n_weights) return fail("weight index out of range", i);
-      const float* w = weights[d.weight];
-      const float* b = d.bias >= 0 ? weights[d.bias] : nullptr;
       const int64_t wn = weight_numel[d.weight];
-      if (b && weight_numel[d.bias] != d.cout) return fail("bias size mismatch", i);
-      std::vector<float> pw, pb;
+      if (d.bias >= 0 && weight_numel[d.bias] != d.cout) return fail("bias size mismatch", i);
+      const std::vector<float> iw = index_array(d.weight), ib = index_array(d.bias);
+      const float* wsrc[2] = {weights[d.weight], iw.data()};
+      const float* bsrc[2] = {d.bias >= 0 ? weights[d.bias] : nullptr, d.bias >= 0 ? ib.data() : nullptr};
       if (d.kind == PH_OP_CONV || d.kind == PH_OP_CONVT) {
         if (d.ksize != 3) return fail("only kernel_size 3 is supported by the MFMA convolution", i);
         if (d.kind == PH_OP_CONVT && d.cin1 != 0) return fail("transposed conv takes one source", i);
         if (wn != (int64_t)(d.cin0 + d.cin1) * d.cout * 9) return fail("weight size mismatch", i);
         const int coutp = pad16(d.cout);
         op.bn = choose_bn(coutp);
-        pack_conv(w, d.kind == PH_OP_CONVT, d.cin0, d.cin1, d.cout, op.bn, pw);
-        {
-          std::vector<float> pd;
-          repack_dma(pw, op.bn, pd);
-          if (upload(m, pd, &op.w_dma_dev) != PH_OK) {
-            ph_model_destroy(m);
-            return nullptr;
+        std::vector<float> pw[2], pd[2], pb[2];
+        for (int k = 0; k < 2; ++k) {
+          pack_conv(wsrc[k], d.kind == PH_OP_CONVT, d.cin0, d.cin1, d.cout, op.bn, pw[k]);
+          repack_dma(pw[k], op.bn, pd[k]);
+          pb[k].assign((size_t)((coutp + op.bn - 1) / op.bn) * op.bn, 0.f);
+          if (bsrc[k]) std::memcpy(pb[k].data(), bsrc[k], d.cout * sizeof(float));
+        }
+        ok = upload_packed(m, pw[0], pw[1], &op.w_dev) == PH_OK && upload_packed(m, pd[0], pd[1], &op.w_dma_dev) == PH_OK &&
+             upload_packed(m, pb[0], pb[1], &op.b_dev) == PH_OK;
+        if (ok && d.kind == PH_OP_CONV) {  // data-gradient weights (training)
+          const int cin_total = d.cin0 + d.cin1;
+          const int parts[2] = {d.cin0, d.cin1}, offs[2] = {0, d.cin0};
+          int max_bn = 32;
+          for (int part = 0; part < 2 && ok; ++part) {
+            if (parts[part] <= 0) continue;
+            op.bn_d[part] = choose_bn(pad16(parts[part]));
+            max_bn = std::max(max_bn, op.bn_d[part]);
+            std::vector<float> dw[2], pk[2], pkd[2];
+            for (int k = 0; k < 2; ++k) {
+              dgrad_weight(wsrc[k], d.cout, cin_total, offs[part], parts[part], dw[k]);
+              pack_conv(dw[k].data(), false, d.cout, 0, parts[part], op.bn_d[part], pk[k]);
+              repack_dma(pk[k], op.bn_d[part], pkd[k]);
+            }
+            ok = upload_packed(m, pk[0], pk[1], &op.wd_dev[part]) == PH_OK && upload_packed(m, pkd[0], pkd[1], &op.wd_dma_dev[part]) == PH_OK;
+          }
+          if (ok) {
+            std::vector<float> zb((size_t)pad16(std::max(d.cin0, d.cin1)) + max_bn, 0.f);
+            ok = upload(m, zb, &op.zero_bias_dev) == PH_OK;
           }
         }
-        pb.assign((size_t)((coutp + op.bn - 1) / op.bn) * op.bn, 0.f);
-        if (b) std::memcpy(pb.data(), b, d.cout * sizeof(float));
       } else if (d.kind == PH_OP_INPUT_CONV) {
         if (d.ksize != 3) return fail("only kernel_size 3 is supported", i);
         if (wn != (int64_t)d.cin0 * d.cout * 9) return fail("weight size mismatch", i);
         const int coutp = pad16(d.cout);
-        pw.assign((size_t)9 * d.cin0 * coutp, 0.f);
-        for (int co = 0; co < d.cout; ++co)
-          for (int ci = 0; ci < d.cin0; ++ci)
-            for (int tap = 0; tap < 9; ++tap) pw[((size_t)tap * d.cin0 + ci) * coutp + co] = w[((size_t)co * d.cin0 + ci) * 9 + tap];
-        pb.assign(coutp, 0.f);
-        if (b) std::memcpy(pb.data(), b, d.cout * sizeof(float));
+        std::vector<float> pw[2], pb[2];
+        for (int k = 0; k < 2; ++k) {
+          pw[k].assign((size_t)9 * d.cin0 * coutp, 0.f);
+          for (int co = 0; co < d.cout; ++co)
+            for (int ci = 0; ci < d.cin0; ++ci)
+              for (int tap = 0; tap < 9; ++tap) pw[k][((size_t)tap * d.cin0 + ci) * coutp + co] = wsrc[k][((size_t)co * d.cin0 + ci) * 9 + tap];
+          pb[k].assign(coutp, 0.f);
+          if (bsrc[k]) std::memcpy(pb[k].data(), bsrc[k], d.cout * sizeof(float));
+        }
+        ok = upload_packed(m, pw[0], pw[1], &op.w_dev) == PH_OK && upload_packed(m, pb[0], pb[1], &op.b_dev) == PH_OK;
       } else {  // HEAD
         if (wn != (int64_t)d.cin0 * d.cout) return fail("weight size mismatch", i);
-        const int cp = pad16(d.cin0);
-        pw.assign((size_t)d.cout * cp, 0.f);
-        for (int co = 0; co < d.cout; ++co)
-          for (int ci = 0; ci < d.cin0; ++ci) pw[(size_t)co * cp + ci] = w[(size_t)co * d.cin0 + ci];
-        pb.assign(d.cout, 0.f);
-        if (b) std::memcpy(pb.data(), b, d.cout * sizeof(float));
         if (d.out_index < 0 || d.out_index >= n_outputs) return fail("bad out_index", i);
-      }
-      if (upload(m, pw, &op.w_dev) != PH_OK || upload(m, pb, &op.b_dev) != PH_OK) {
-        ph_model_destroy(m);
-        return nullptr;
+        const int cp = pad16(d.cin0);
+        std::vector<float> pw[2], pb[2];
+        for (int k = 0; k < 2; ++k) {
+          pw[k].assign((size_t)d.cout * cp, 0.f);
+          for (int co = 0; co < d.cout; ++co)
+            for (int ci = 0; ci < d.cin0; ++ci) pw[k][(size_t)co * cp + ci] = wsrc[k][(size_t)co * d.cin0 + ci];
+          pb[k].assign(d.cout, 0.f);
+          if (bsrc[k]) std::memcpy(pb[k].data(), bsrc[k], d.cout * sizeof(float));
+        }
+        ok = upload_packed(m, pw[0], pw[1], &op.w_dev) == PH_OK && upload_packed(m, pb[0], pb[1], &op.b_dev) == PH_OK;
       }
     } else if (d.kind != PH_OP_POOL && d.kind != PH_OP_UPSAMPLE) {
       return fail("unknown op kind", i);
+    }
+    if (!ok) {
+      ph_model_destroy(m);
+      return nullptr;
     }
     m->ops.push_back(op);
   }
@@ -392,7 +435,7 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
     switch (d.kind) {
       case PH_OP_INPUT_CONV: {
         PH_REQUIRE(d.cin0 == in_channels, "input has %d channels, network expects %d", in_channels, d.cin0);
-        InputConvArgs a;
+        InputConvArgs a{};
         a.src = input_dev;
         a.w = op.w_dev;
         a.bias = op.b_dev;
@@ -409,7 +452,7 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
       }
       case PH_OP_STEM: {
         PH_REQUIRE(d.cin0 == in_channels, "input has %d channels, network expects %d", in_channels, d.cin0);
-        StemArgs a;
+        StemArgs a{};
         a.src = input_dev;
         a.w0 = op.w_dev;
         a.b0 = op.b_dev;
@@ -427,7 +470,7 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
       }
       case PH_OP_CONV: {
         const SlotShape& s0 = plan.slots[d.src0];
-        ConvArgs a;
+        ConvArgs a{};
         a.src0 = slot_ptr(d.src0);
         a.c0p = s0.cp;
         a.src1 = d.src1 >= 0 ? slot_ptr(d.src1) : nullptr;
@@ -465,7 +508,7 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
         float* tmp = reinterpret_cast<float*>(ws + plan.tmp_offset);
         rc = launch_zero_stuff(slot_ptr(d.src0), tmp, batch, s0.h, s0.w, s0.cp, s);
         if (rc != PH_OK) break;
-        ConvArgs a;
+        ConvArgs a{};
         a.src0 = tmp;
         a.c0p = s0.cp;
         a.src1 = nullptr;

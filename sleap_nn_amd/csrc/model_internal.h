@@ -1,0 +1,77 @@
+// Internal structures of the network runtime shared by model.hip (forward) and train.hip (backward).
+#pragma once
+#include <string>
+#include <vector>
+
+#include "common.h"
+#include "net_kernels.h"
+
+namespace ph {
+
+struct PackedOp {
+  ph_op_desc d;
+  float* w_dev = nullptr;
+  float* b_dev = nullptr;
+  float* w2_dev = nullptr;
+  float* b2_dev = nullptr;
+  float* w_dma_dev = nullptr;  // conv weights in the LDS-DMA (quad-major piece) layout
+  int bn = 0;
+  // data-gradient weights of a 3x3 conv (flipped taps, in/out swapped), one set per concat source
+  float* wd_dev[2] = {nullptr, nullptr};
+  float* wd_dma_dev[2] = {nullptr, nullptr};
+  float* zero_bias_dev = nullptr;
+  int bn_d[2] = {0, 0};
+};
+
+// One packed device buffer and the gather map that rebuilds it from the canonical parameter arena
+// (map[i] = index into the arena, -1 = structural zero).
+struct PackedBuffer {
+  float* dst = nullptr;
+  int* map = nullptr;
+  size_t n = 0;
+};
+
+struct SlotShape {
+  int c = 0, cp = 0, h = 0, w = 0;
+  int64_t offset = -1;
+};
+
+struct Plan {
+  std::vector<SlotShape> slots;
+  int64_t tmp_offset = 0, tmp_bytes = 0, total = 0;
+};
+
+}  // namespace ph
+
+struct ph_model {
+  std::vector<ph::PackedOp> ops;
+  int n_slots = 0, n_outputs = 0;
+  std::vector<void*> allocs;
+  // last forward (for ph_model_read_slot)
+  ph::Plan last_plan;
+  char* last_ws = nullptr;
+  int last_batch = 0;
+  // optional per-op HIP-event timing (ph_model_set_profiling)
+  bool profiling = false;
+  bool events_pending = false;
+  std::vector<hipEvent_t> ev;      // n_ops + 1 events: ev[i] before op i, ev[n_ops] after the last
+  std::vector<double> op_ms;       // accumulated per op
+  int profiled_forwards = 0;
+  unsigned long long* clock_probe = nullptr;  // diagnostic buffer (ph_model_set_clock_probe)
+  float* zeros_dev = nullptr;                 // zero page for LDS-DMA halo padding
+  std::vector<int64_t> weight_offset;          // canonical arena offset of weights[i] (ph_model_create order)
+  std::vector<int64_t> weight_numel;
+  int64_t n_params = 0;
+  std::vector<ph::PackedBuffer> packed;        // every packed weight buffer, for ph_model_set_params
+  bool use_dma = true;                        // PH_CONV_IMPL=reg selects the register-staged kernel
+};
+
+
+namespace ph {
+int build_plan(const ph_model* m, int B, int H, int W, Plan& plan);
+int upload(ph_model* m, const std::vector<float>& host, float** dev);
+int upload_ints(ph_model* m, const std::vector<int>& host, int** dev);
+void pack_conv(const float* w, bool transposed, int cin0, int cin1, int cout, int bn, std::vector<float>& out);
+void repack_dma(const std::vector<float>& in, int bn, std::vector<float>& out);
+int choose_bn(int coutp);
+}  // namespace ph

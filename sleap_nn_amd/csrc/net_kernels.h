@@ -17,10 +17,11 @@ struct ConvArgs {
   int B, H, W;
   int relu;
   int bn;              // N tile: 32 or 64
-  unsigned long long* clock_probe;  // diagnostic: per block {d s_memtime, d s_memrealtime}; nullptr = off
-  const float* wpack_dma;  // weights in the LDS-DMA layout (quad-major 16-row pieces), or nullptr
-  const float* zeros;      // >= 64 B of zeros in HBM (source of out-of-image halo pixels for LDS-DMA)
-  float* dst_pool;         // optional fused 2x2/2 max pool of the (ReLU'd) output, NHWC ceil(H/2) x ceil(W/2); nullptr = off
+  unsigned long long* clock_probe = nullptr;  // diagnostic: per block {d s_memtime, d s_memrealtime}; nullptr = off
+  const float* wpack_dma = nullptr;  // weights in the LDS-DMA layout (quad-major 16-row pieces), or nullptr
+  const float* zeros = nullptr;      // >= 64 B of zeros in HBM (source of out-of-image halo pixels for LDS-DMA)
+  int accumulate = 0;      // epilogue adds the existing dst value (gradient accumulation in the backward pass)
+  float* dst_pool = nullptr;  // optional fused 2x2/2 max pool of the (ReLU'd) output, NHWC ceil(H/2) x ceil(W/2); nullptr = off
 };
 
 struct InputConvArgs {

@@ -291,8 +291,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(ConvArgs a) {
 #pragma unroll
       for (int m = 0; m < 2; ++m) {
         float* drow = a.dst + ((size_t)(b * a.H + y0 + 2 * wave + m) * a.W + x0 + 4 * lh) * a.coutp + ntile * BN + n * 32 + lx;
+        if (!a.accumulate) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) drow[(size_t)((r & 3) + 8 * (r >> 2)) * a.coutp] = acc[m][n][r];
+          for (int r = 0; r < 16; ++r) drow[(size_t)((r & 3) + 8 * (r >> 2)) * a.coutp] = acc[m][n][r];
+        } else {  // backward pass: add to the gradient already in dst
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[m][n][r] += drow[(size_t)((r & 3) + 8 * (r >> 2)) * a.coutp];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) drow[(size_t)((r & 3) + 8 * (r >> 2)) * a.coutp] = acc[m][n][r];
+        }
       }
   } else {
 #pragma unroll
@@ -305,7 +312,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(ConvArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int x = x0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          if (x < a.W && y < a.H && co < a.coutp) drow[(size_t)x * a.coutp] = acc[m][n][r];
+          if (x < a.W && y < a.H && co < a.coutp) {
+            float* dp = drow + (size_t)x * a.coutp;
+            *dp = a.accumulate ? (*dp + acc[m][n][r]) : acc[m][n][r];
+          }
         }
       }
     }
@@ -528,8 +538,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mfma_dma_kernel(ConvArgs a) {
 #pragma unroll
       for (int m = 0; m < 2; ++m) {
         float* drow = a.dst + ((size_t)(b * a.H + y0 + 2 * wave + m) * a.W + x0 + 4 * lh) * a.coutp + ntile * BN + n * 32 + lx;
+        if (!a.accumulate) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) drow[(size_t)((r & 3) + 8 * (r >> 2)) * a.coutp] = acc[m][n][r];
+          for (int r = 0; r < 16; ++r) drow[(size_t)((r & 3) + 8 * (r >> 2)) * a.coutp] = acc[m][n][r];
+        } else {  // backward pass: add to the gradient already in dst
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[m][n][r] += drow[(size_t)((r & 3) + 8 * (r >> 2)) * a.coutp];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) drow[(size_t)((r & 3) + 8 * (r >> 2)) * a.coutp] = acc[m][n][r];
+        }
       }
   } else {
 #pragma unroll
@@ -542,7 +559,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mfma_dma_kernel(ConvArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int x = x0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          if (x < a.W && y < a.H && co < a.coutp) drow[(size_t)x * a.coutp] = acc[m][n][r];
+          if (x < a.W && y < a.H && co < a.coutp) {
+            float* dp = drow + (size_t)x * a.coutp;
+            *dp = a.accumulate ? (*dp + acc[m][n][r]) : acc[m][n][r];
+          }
         }
       }
     }

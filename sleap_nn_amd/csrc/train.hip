@@ -1,0 +1,240 @@
+// Backward pass + parameter management of the network runtime (C ABI: ph_model_backward,
+// ph_model_set_params, ph_model_num_params).  Together with ph_model_forward and ph_adam_step this
+// is one training step of the reference's LightningModule.training_step
+// (sleap_nn/training/lightning_modules.py:1850-1922: forward, per-head MSE (+OHKM), weighted sum,
+// autograd backward) for UNet models with bilinear up-sampling; gradients come out in the
+// reference's state_dict layout (OIHW arena) so that a flat RCCL all-reduce + Adam apply directly.
+#include <algorithm>
+
+#include "model_internal.h"
+#include "train_kernels.h"
+
+using namespace ph;
+
+namespace {
+
+struct BwdPlan {
+  Plan act;                         // activation slots (same layout as the forward workspace)
+  std::vector<int64_t> head_dy_off; // per output: NCHW dY buffer offset in the grad workspace
+  int64_t scratch_off = 0, scratch_bytes = 0, total = 0;
+};
+
+int build_bwd_plan(const ph_model* m, int B, int H, int W, BwdPlan& bp) {
+  int rc = build_plan(m, B, H, W, bp.act);
+  if (rc != PH_OK) return rc;
+  int64_t off = bp.act.total;  // gradient slots mirror the activation slots one to one
+  bp.head_dy_off.assign(m->n_outputs, -1);
+  int64_t scratch = 0;
+  for (const PackedOp& op : m->ops) {
+    const ph_op_desc& d = op.d;
+    if (d.kind == PH_OP_STEM || d.kind == PH_OP_CONVT || (d.kind == PH_OP_CONV && d.dst2 >= 0)) {
+      set_error("backward needs the unfused program with bilinear up-sampling (no stem / conv+pool fusion / transposed conv)");
+      return PH_E_INVALID;
+    }
+    if (d.kind == PH_OP_HEAD) {
+      const SlotShape& s0 = bp.act.slots[d.src0];
+      bp.head_dy_off[d.out_index] = off;
+      off += align_up((int64_t)B * d.cout * s0.h * s0.w * 4, 256);
+      scratch = std::max<int64_t>(scratch, head_bwd_scratch_floats(s0.cp, d.cout));
+      scratch = std::max<int64_t>(scratch, (int64_t)d.cout * 64 + d.cout + 64);
+    } else if (d.kind == PH_OP_CONV) {
+      const SlotShape& s0 = bp.act.slots[d.src0];
+      scratch = std::max<int64_t>(scratch, wgrad_slab_floats(d.cin0, d.cout, B, s0.h, s0.w));
+      if (d.cin1 > 0) scratch = std::max<int64_t>(scratch, wgrad_slab_floats(d.cin1, d.cout, B, s0.h, s0.w));
+      scratch = std::max<int64_t>(scratch, bias_scratch_floats(pad16(d.cout)));
+    } else if (d.kind == PH_OP_INPUT_CONV) {
+      scratch = std::max<int64_t>(scratch, input_wgrad_scratch_floats(d.cin0, d.cout));
+      scratch = std::max<int64_t>(scratch, bias_scratch_floats(pad16(d.cout)));
+    }
+  }
+  bp.scratch_off = off;
+  bp.scratch_bytes = align_up(scratch * 4, 256);
+  bp.total = off + bp.scratch_bytes;
+  return PH_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t ph_model_num_params(const ph_model* m) {
+  if (!m) {
+    set_error("ph_model_num_params: null model");
+    return PH_E_INVALID;
+  }
+  return m->n_params;
+}
+
+int ph_model_set_params(ph_model* m, const float* params_flat_dev, void* stream) {
+  PH_REQUIRE(m && params_flat_dev, "ph_model_set_params: null argument");
+  for (const PackedBuffer& pb : m->packed) {
+    int rc = launch_gather(params_flat_dev, pb.map, pb.n, pb.dst, static_cast<hipStream_t>(stream));
+    if (rc != PH_OK) return rc;
+  }
+  return PH_OK;
+}
+
+int64_t ph_model_backward_workspace_bytes(const ph_model* m, int32_t batch, int32_t height, int32_t width) {
+  if (!m || batch <= 0 || height <= 0 || width <= 0) {
+    set_error("ph_model_backward_workspace_bytes: bad arguments");
+    return PH_E_INVALID;
+  }
+  BwdPlan bp;
+  int rc = build_bwd_plan(m, batch, height, width, bp);
+  if (rc != PH_OK) return rc;
+  return bp.total;
+}
+
+int ph_model_backward(ph_model* m, const void* input_dev, int32_t in_dtype, int32_t batch, int32_t in_channels, int32_t height, int32_t width,
+                      const void* act_workspace_dev, void* grad_workspace_dev, int64_t grad_workspace_bytes, const float* const* head_out_dev,
+                      const float* const* target_dev, const float* loss_weights_host, int32_t ohkm_enabled, float hard_to_easy_ratio,
+                      int32_t min_hard_keypoints, int32_t max_hard_keypoints, float ohkm_loss_scale, float* loss_dev, float* grads_flat_dev, void* stream) {
+  PH_REQUIRE(m && input_dev && act_workspace_dev && grad_workspace_dev && head_out_dev && target_dev && loss_weights_host && loss_dev && grads_flat_dev,
+             "ph_model_backward: null argument");
+  PH_REQUIRE(((uintptr_t)grad_workspace_dev & 255) == 0, "gradient workspace must be 256-byte aligned");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  BwdPlan bp;
+  int rc = build_bwd_plan(m, batch, height, width, bp);
+  if (rc != PH_OK) return rc;
+  if (bp.total > grad_workspace_bytes) {
+    set_error("gradient workspace too small: need %lld bytes, got %lld", (long long)bp.total, (long long)grad_workspace_bytes);
+    return PH_E_WORKSPACE;
+  }
+  const char* aws = static_cast<const char*>(act_workspace_dev);
+  char* gws = static_cast<char*>(grad_workspace_dev);
+  auto A = [&](int slot) { return reinterpret_cast<const float*>(aws + bp.act.slots[slot].offset); };
+  auto G = [&](int slot) { return reinterpret_cast<float*>(gws + bp.act.slots[slot].offset); };
+  float* scratch = reinterpret_cast<float*>(gws + bp.scratch_off);
+  std::vector<char> init(m->n_slots, 0);
+  OhkmParams ok;
+  ok.enabled = ohkm_enabled;
+  ok.hard_to_easy_ratio = hard_to_easy_ratio;
+  ok.min_hard = min_hard_keypoints;
+  ok.max_hard = max_hard_keypoints;
+  ok.loss_scale = ohkm_loss_scale;
+
+  // ---- losses and head-output gradients (loss_dev: [0] = total, [1 + i] = head i)
+  std::vector<float> lw(loss_weights_host, loss_weights_host + m->n_outputs);
+  for (const PackedOp& op : m->ops) {
+    const ph_op_desc& d = op.d;
+    if (d.kind != PH_OP_HEAD) continue;
+    const SlotShape& s0 = bp.act.slots[d.src0];
+    PH_REQUIRE(head_out_dev[d.out_index] && target_dev[d.out_index], "head %d: null output/target", d.out_index);
+    float* dy = reinterpret_cast<float*>(gws + bp.head_dy_off[d.out_index]);
+    rc = launch_loss(head_out_dev[d.out_index], target_dev[d.out_index], batch, d.cout, s0.h, s0.w, lw[d.out_index], ok, scratch, dy, loss_dev + 1 + d.out_index, s);
+    if (rc != PH_OK) return rc;
+  }
+  {  // total = sum_h w_h * loss_h; the weights ride in the scratch area
+    float* wdev = scratch;
+    PH_HIP_CHECK(hipMemcpyAsync(wdev, lw.data(), lw.size() * sizeof(float), hipMemcpyHostToDevice, s));
+    rc = launch_total_loss(loss_dev + 1, wdev, m->n_outputs, loss_dev, s);
+    if (rc != PH_OK) return rc;
+  }
+
+  // ---- reverse sweep
+  for (int oi = (int)m->ops.size() - 1; oi >= 0; --oi) {
+    const PackedOp& op = m->ops[oi];
+    const ph_op_desc& d = op.d;
+    switch (d.kind) {
+      case PH_OP_HEAD: {
+        const SlotShape& s0 = bp.act.slots[d.src0];
+        const float* dy = reinterpret_cast<const float*>(gws + bp.head_dy_off[d.out_index]);
+        rc = launch_head_bwd(dy, head_out_dev[d.out_index], (d.flags & PH_FLAG_SIGMOID) ? 1 : 0, A(d.src0), op.w_dev, batch, s0.h * s0.w, d.cin0, s0.cp, d.cout,
+                             init[d.src0], G(d.src0), grads_flat_dev + m->weight_offset[d.weight], d.bias >= 0 ? grads_flat_dev + m->weight_offset[d.bias] : nullptr,
+                             scratch, s);
+        init[d.src0] = 1;
+        break;
+      }
+      case PH_OP_CONV: {
+        const SlotShape& so = bp.act.slots[d.dst];
+        PH_REQUIRE(init[d.dst], "conv output slot %d received no gradient", d.dst);
+        const size_t npix = (size_t)batch * so.h * so.w;
+        if (d.flags & PH_FLAG_RELU) {
+          rc = launch_relu_mask(G(d.dst), A(d.dst), npix * so.cp, s);
+          if (rc != PH_OK) return rc;
+        }
+        if (d.bias >= 0) {
+          rc = launch_bias_grad(G(d.dst), npix, so.cp, d.cout, grads_flat_dev + m->weight_offset[d.bias], scratch, s);
+          if (rc != PH_OK) return rc;
+        }
+        const int srcs[2] = {d.src0, d.src1}, parts[2] = {d.cin0, d.cin1}, offs[2] = {0, d.cin0};
+        for (int part = 0; part < 2; ++part) {
+          if (parts[part] <= 0 || srcs[part] < 0) continue;
+          const SlotShape& si = bp.act.slots[srcs[part]];
+          WgradArgs w{};
+          w.x = A(srcs[part]);
+          w.dy = G(d.dst);
+          w.slab = scratch;
+          w.cxp = si.cp;
+          w.coutp = so.cp;
+          w.B = batch;
+          w.H = so.h;
+          w.W = so.w;
+          rc = launch_wgrad(w, parts[part], d.cout, d.cin0 + d.cin1, offs[part], grads_flat_dev + m->weight_offset[d.weight], s);
+          if (rc != PH_OK) return rc;
+          // data gradient: conv3x3 of the masked output gradient with the flipped, swapped weights
+          ConvArgs a{};
+          a.src0 = G(d.dst);
+          a.c0p = so.cp;
+          a.src1 = nullptr;
+          a.c1p = 0;
+          a.wpack = op.wd_dev[part];
+          a.wpack_dma = op.wd_dma_dev[part];
+          a.bias = op.zero_bias_dev;
+          a.dst = G(srcs[part]);
+          a.coutp = si.cp;
+          a.B = batch;
+          a.H = so.h;
+          a.W = so.w;
+          a.relu = 0;
+          a.bn = op.bn_d[part];
+          a.clock_probe = nullptr;
+          a.zeros = m->zeros_dev;
+          a.dst_pool = nullptr;
+          a.accumulate = init[srcs[part]];
+          rc = (m->use_dma && a.bn == 64) ? launch_conv3x3_dma(a, s) : launch_conv3x3(a, s);
+          if (rc != PH_OK) return rc;
+          init[srcs[part]] = 1;
+        }
+        break;
+      }
+      case PH_OP_INPUT_CONV: {
+        const SlotShape& so = bp.act.slots[d.dst];
+        PH_REQUIRE(init[d.dst], "first conv output received no gradient");
+        PH_REQUIRE(d.cin0 == in_channels, "input has %d channels, network expects %d", in_channels, d.cin0);
+        const size_t npix = (size_t)batch * so.h * so.w;
+        if (d.flags & PH_FLAG_RELU) {
+          rc = launch_relu_mask(G(d.dst), A(d.dst), npix * so.cp, s);
+          if (rc != PH_OK) return rc;
+        }
+        if (d.bias >= 0) {
+          rc = launch_bias_grad(G(d.dst), npix, so.cp, d.cout, grads_flat_dev + m->weight_offset[d.bias], scratch, s);
+          if (rc != PH_OK) return rc;
+        }
+        rc = launch_input_wgrad(input_dev, in_dtype, G(d.dst), batch, d.cin0, height, width, so.cp, d.cout, grads_flat_dev + m->weight_offset[d.weight], scratch, s);
+        break;
+      }
+      case PH_OP_POOL: {
+        const SlotShape& si = bp.act.slots[d.src0];
+        PH_REQUIRE(init[d.dst], "pool output slot %d received no gradient", d.dst);
+        rc = launch_pool_bwd(G(d.dst), A(d.src0), batch, si.h, si.w, si.cp, init[d.src0], G(d.src0), s);
+        init[d.src0] = 1;
+        break;
+      }
+      case PH_OP_UPSAMPLE: {
+        const SlotShape& si = bp.act.slots[d.src0];
+        PH_REQUIRE(init[d.dst], "upsample output slot %d received no gradient", d.dst);
+        rc = launch_upsample_bwd(G(d.dst), batch, si.h, si.w, si.cp, init[d.src0], G(d.src0), s);
+        init[d.src0] = 1;
+        break;
+      }
+      default:
+        set_error("backward: unsupported op kind %d", d.kind);
+        rc = PH_E_INVALID;
+    }
+    if (rc != PH_OK) return rc;
+  }
+  return PH_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,42 @@
+// Launcher declarations for the training-path kernels (train_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace ph {
+
+struct OhkmParams {
+  int enabled = 0;
+  float hard_to_easy_ratio = 2.0f;
+  int min_hard = 2;
+  int max_hard = -1;
+  float loss_scale = 5.0f;
+};
+
+struct WgradArgs {
+  const float* x;    // NHWC source activation, cxp channels
+  const float* dy;   // NHWC output gradient (already ReLU-masked), coutp channels
+  float* slab;       // scratch: [slices][blocks][9][32][32]
+  int cxp, coutp, B, H, W;
+};
+
+int launch_loss(const float* pred, const float* tgt, int B, int C, int H, int W, float loss_weight, const OhkmParams& ok, float* scratch, float* dy,
+                float* loss_out, hipStream_t s);
+int launch_total_loss(const float* head_loss, const float* w_dev, int n, float* out, hipStream_t s);
+int launch_head_bwd(const float* dy, const float* y_out, int sigmoid, const float* x, const float* w_packed, int B, int HW, int cin, int cp, int cout,
+                    int accumulate, float* dx, float* gw, float* gb, float* scratch, hipStream_t s);
+int64_t head_bwd_scratch_floats(int cp, int cout);
+int launch_relu_mask(float* g, const float* y, size_t n, hipStream_t s);
+int launch_pool_bwd(const float* gp, const float* x, int B, int H, int W, int cp, int accumulate, float* gx, hipStream_t s);
+int launch_upsample_bwd(const float* gy, int B, int H, int W, int cp, int accumulate, float* gx, hipStream_t s);
+int launch_bias_grad(const float* g, size_t npix, int cp, int cout, float* gb, float* scratch, hipStream_t s);
+int64_t bias_scratch_floats(int cp);
+int wgrad_slices(int B, int H, int W);
+int64_t wgrad_slab_floats(int cin_part, int cout, int B, int H, int W);
+int launch_wgrad(const WgradArgs& a, int cin_part, int cout, int cin_total, int ci_off, float* grad, hipStream_t s);
+int launch_input_wgrad(const void* img, int dtype, const float* dy, int B, int cin, int H, int W, int coutp, int cout, float* gw, float* scratch, hipStream_t s);
+int64_t input_wgrad_scratch_floats(int cin, int cout);
+int launch_gather(const float* canon, const int* map, size_t n, float* out, hipStream_t s);
+
+}  // namespace ph

@@ -1,0 +1,666 @@
+// Training-path kernels for gfx950: MSE(+OHKM) loss and its gradient, backward of the encoder-
+// decoder ops (ReLU mask, 3x3 conv weight gradient on MFMA, bias gradient, 2x2 max-pool and
+// bilinear-x2 backward, 1x1 head backward, first-conv weight gradient), Adam, and the gather that
+// re-packs the canonical (state_dict-ordered) parameter arena into the kernels' weight layouts.
+// Data gradients of the 3x3 convolutions reuse the forward MFMA kernels with flipped,
+// in/out-swapped weights (net_kernels.hip).
+//
+// Reference semantics (paths relative to talmolab/sleap-nn):
+//   nn.MSELoss per head, total = sum_h loss_weight_h * loss_h ... training/lightning_modules.py:526,1850-1895
+//   compute_ohkm_loss ........................................ training/losses.py:8-63
+//   autograd of Conv2d / ReLU / max_pool2d / Upsample(bilinear) = ATen backward semantics
+//   torch.optim.Adam (lr, betas (0.9, 0.999), eps 1e-8, amsgrad optional) lightning_modules.py:752-763
+//
+// All reductions are two-stage with a fixed order (no float atomics): results are bitwise
+// reproducible from run to run.
+#include <algorithm>
+
+#include "common.h"
+#include "train_kernels.h"
+
+namespace ph {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float block_sum_256(float v, float* red /* >= 4 floats */) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  const float t = (red[0] + red[1]) + (red[2] + red[3]);
+  __syncthreads();
+  return t;
+}
+
+// ---------------------------------------------------------------------------------------
+// Loss: per-channel sum of squared errors (NCHW), two stage.
+// ---------------------------------------------------------------------------------------
+constexpr int SSE_SLICES = 64;
+
+__global__ __launch_bounds__(256) void sse_partial_kernel(const float* __restrict__ pred, const float* __restrict__ tgt, int B, int C, int HW,
+                                                          float* __restrict__ partial /* C x SSE_SLICES */) {
+  __shared__ float red[4];
+  const int c = blockIdx.x, sl = blockIdx.y;
+  const size_t n = (size_t)B * HW;
+  const size_t per = (n + SSE_SLICES - 1) / SSE_SLICES;
+  const size_t lo = (size_t)sl * per, hi = std::min(n, lo + per);
+  float acc = 0.f;
+  for (size_t i = lo + threadIdx.x; i < hi; i += 256) {
+    const size_t b = i / HW, hw = i - b * HW;
+    const size_t o = (b * C + c) * HW + hw;
+    const float d = pred[o] - tgt[o];
+    acc += d * d;
+  }
+  const float t = block_sum_256(acc, red);
+  if (threadIdx.x == 0) partial[c * SSE_SLICES + sl] = t;
+}
+
+// One thread: per-channel SSE -> head loss (MSE + optional OHKM) and the per-channel gradient
+// coefficient  coeff[c] = loss_weight * (2/N + [c is hard] * 2*loss_scale/n_elements).
+__global__ void loss_coeff_kernel(const float* __restrict__ partial, int C, double n_total /* B*C*H*W */, double n_per_channel /* B*H*W */,
+                                  float loss_weight, int ohkm, float hard_to_easy_ratio, int min_hard, int max_hard, float loss_scale,
+                                  float* __restrict__ coeff, float* __restrict__ loss_out /* [0] = this head's loss */) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float sse[256];
+  float total = 0.f;
+  for (int c = 0; c < C; ++c) {
+    float s = 0.f;
+    for (int k = 0; k < SSE_SLICES; ++k) s += partial[c * SSE_SLICES + k];
+    sse[c] = s;
+    total += s;
+  }
+  float loss = (float)((double)total / n_total);
+  const float base = (float)(2.0 / n_total);
+  for (int c = 0; c < C; ++c) coeff[c] = loss_weight * base;
+  if (ohkm) {
+    float best = sse[0];
+    for (int c = 1; c < C; ++c) best = fminf(best, sse[c]);
+    int n_hard = 0;
+    for (int c = 0; c < C; ++c) n_hard += ((sse[c] / best) >= hard_to_easy_ratio) ? 1 : 0;
+    int mx = max_hard < 0 ? C : min(max_hard, C);
+    const int k = min(max(n_hard, min_hard), mx);
+    // top-k channels by SSE (ties: lowest channel index first)
+    bool used[256];
+    for (int c = 0; c < C; ++c) used[c] = false;
+    float ksum = 0.f;
+    const double n_el = n_per_channel * (double)k;
+    for (int j = 0; j < k; ++j) {
+      int bi = -1;
+      for (int c = 0; c < C; ++c)
+        if (!used[c] && (bi < 0 || sse[c] > sse[bi])) bi = c;
+      used[bi] = true;
+      ksum += sse[bi] * loss_scale;
+      coeff[bi] += loss_weight * (float)(2.0 * (double)loss_scale / n_el);
+    }
+    loss += (float)((double)ksum / n_el);
+  }
+  loss_out[0] = loss;
+}
+
+__global__ void total_loss_kernel(const float* __restrict__ head_loss, const float* __restrict__ w, int n, float* __restrict__ out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    float t = 0.f;
+    for (int i = 0; i < n; ++i) t += w[i] * head_loss[i];
+    out[0] = t;
+  }
+}
+
+__global__ __launch_bounds__(256) void mse_grad_kernel(const float* __restrict__ pred, const float* __restrict__ tgt, const float* __restrict__ coeff, int C,
+                                                       int HW, size_t n, float* __restrict__ dy) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const int c = (int)((i / HW) % C);
+    dy[i] = coeff[c] * (pred[i] - tgt[i]);
+  }
+}
+
+int launch_loss(const float* pred, const float* tgt, int B, int C, int H, int W, float loss_weight, const OhkmParams& ok, float* scratch /* C*64 + C */,
+                float* dy, float* loss_out, hipStream_t s) {
+  if (C > 256) {
+    set_error("loss: more than 256 channels");
+    return PH_E_INVALID;
+  }
+  float* partial = scratch;
+  float* coeff = scratch + (size_t)C * SSE_SLICES;
+  const int HW = H * W;
+  hipLaunchKernelGGL(sse_partial_kernel, dim3(C, SSE_SLICES), dim3(256), 0, s, pred, tgt, B, C, HW, partial);
+  hipLaunchKernelGGL(loss_coeff_kernel, dim3(1), dim3(1), 0, s, partial, C, (double)B * C * HW, (double)B * HW, loss_weight, ok.enabled, ok.hard_to_easy_ratio,
+                     ok.min_hard, ok.max_hard, ok.loss_scale, coeff, loss_out);
+  const size_t n = (size_t)B * C * HW;
+  hipLaunchKernelGGL(mse_grad_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 16384)), dim3(256), 0, s, pred, tgt, coeff, C, HW, n, dy);
+  PH_HIP_CHECK(hipGetLastError());
+  return PH_OK;
+}
+
+int launch_total_loss(const float* head_loss, const float* w_dev, int n, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(total_loss_kernel, dim3(1), dim3(1), 0, s, head_loss, w_dev, n, out);
+  PH_HIP_CHECK(hipGetLastError());
+  return PH_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// 1x1 head backward.  dY: NCHW (B, Cout, HW); X: NHWC (cp); W: [Cout][cp].
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void head_bwd_dx_kernel(const float* __restrict__ dy, const float* __restrict__ w, int cout, int cp, int HW, size_t npix,
+                                                          const float* __restrict__ y_out /* NCHW post-activation, or nullptr */, int sigmoid, int accumulate,
+                                                          float* __restrict__ dx) {
+  // thread = (pixel, 4-channel group)
+  const int groups = cp >> 2;
+  const size_t total = npix * groups;
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+    const int g = (int)(idx % groups);
+    const size_t p = idx / groups;
+    const size_t b = p / HW, hw = p - b * HW;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int co = 0; co < cout; ++co) {
+      float d = dy[(b * cout + co) * HW + hw];
+      if (sigmoid) {
+        const float yv = y_out[(b * cout + co) * HW + hw];
+        d *= yv * (1.f - yv);
+      }
+      acc += d * *reinterpret_cast<const f32x4*>(w + (size_t)co * cp + g * 4);
+    }
+    f32x4* o = reinterpret_cast<f32x4*>(dx + p * cp + g * 4);
+    if (accumulate) acc += *o;
+    *o = acc;
+  }
+}
+
+constexpr int HEAD_SLICES = 128;
+// partial[(co*cp + ci)][slice] and bias partial: block = (co, slice), threads over ci (looping pixels)
+__global__ __launch_bounds__(256) void head_bwd_dw_partial_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ y_out,
+                                                                  int sigmoid, int cout, int cp, int HW, size_t npix, float* __restrict__ partial_w,
+                                                                  float* __restrict__ partial_b) {
+  __shared__ float red[4];
+  const int co = blockIdx.x, sl = blockIdx.y;
+  const size_t per = (npix + HEAD_SLICES - 1) / HEAD_SLICES;
+  const size_t lo = (size_t)sl * per, hi = std::min(npix, lo + per);
+  // threads: ci = tid % cpq ... use tid over ci when cp <= 256
+  float bsum = 0.f;
+  for (int ci = threadIdx.x; ci < cp; ci += 256) {
+    float acc = 0.f;
+    for (size_t p = lo; p < hi; ++p) {
+      const size_t b = p / HW, hw = p - b * HW;
+      float d = dy[(b * cout + co) * HW + hw];
+      if (sigmoid) {
+        const float yv = y_out[(b * cout + co) * HW + hw];
+        d *= yv * (1.f - yv);
+      }
+      acc += d * x[p * cp + ci];
+    }
+    partial_w[((size_t)co * cp + ci) * HEAD_SLICES + sl] = acc;
+  }
+  for (size_t p = lo + threadIdx.x; p < hi; p += 256) {
+    const size_t b = p / HW, hw = p - b * HW;
+    float d = dy[(b * cout + co) * HW + hw];
+    if (sigmoid) {
+      const float yv = y_out[(b * cout + co) * HW + hw];
+      d *= yv * (1.f - yv);
+    }
+    bsum += d;
+  }
+  const float t = block_sum_256(bsum, red);
+  if (threadIdx.x == 0) partial_b[co * HEAD_SLICES + sl] = t;
+}
+
+__global__ void head_bwd_dw_final_kernel(const float* __restrict__ partial_w, const float* __restrict__ partial_b, int cout, int cin, int cp,
+                                         float* __restrict__ gw /* [cout][cin] */, float* __restrict__ gb /* [cout] or nullptr */) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < cout * cin) {
+    const int co = i / cin, ci = i - co * cin;
+    float s = 0.f;
+    for (int k = 0; k < HEAD_SLICES; ++k) s += partial_w[((size_t)co * cp + ci) * HEAD_SLICES + k];
+    gw[i] = s;
+  }
+  if (gb && i < cout) {
+    float s = 0.f;
+    for (int k = 0; k < HEAD_SLICES; ++k) s += partial_b[i * HEAD_SLICES + k];
+    gb[i] = s;
+  }
+}
+
+int launch_head_bwd(const float* dy, const float* y_out, int sigmoid, const float* x, const float* w_packed, int B, int HW, int cin, int cp, int cout,
+                    int accumulate, float* dx, float* gw, float* gb, float* scratch, hipStream_t s) {
+  const size_t npix = (size_t)B * HW;
+  const size_t total = npix * (cp / 4);
+  hipLaunchKernelGGL(head_bwd_dx_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 16384)), dim3(256), 0, s, dy, w_packed, cout, cp, HW, npix, y_out,
+                     sigmoid, accumulate, dx);
+  float* pw = scratch;
+  float* pb = scratch + (size_t)cout * cp * HEAD_SLICES;
+  hipLaunchKernelGGL(head_bwd_dw_partial_kernel, dim3(cout, HEAD_SLICES), dim3(256), 0, s, dy, x, y_out, sigmoid, cout, cp, HW, npix, pw, pb);
+  hipLaunchKernelGGL(head_bwd_dw_final_kernel, dim3((cout * cin + 255) / 256), dim3(256), 0, s, pw, pb, cout, cin, cp, gw, gb);
+  PH_HIP_CHECK(hipGetLastError());
+  return PH_OK;
+}
+
+int64_t head_bwd_scratch_floats(int cp, int cout) { return (int64_t)cout * cp * HEAD_SLICES + (int64_t)cout * HEAD_SLICES; }
+
+// ---------------------------------------------------------------------------------------
+// Elementwise backward pieces (NHWC, float4)
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void relu_mask_kernel(float* __restrict__ g, const float* __restrict__ y, size_t n4) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    f32x4 gv = reinterpret_cast<f32x4*>(g)[i];
+    const f32x4 yv = reinterpret_cast<const f32x4*>(y)[i];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) gv[k] = yv[k] > 0.f ? gv[k] : 0.f;
+    reinterpret_cast<f32x4*>(g)[i] = gv;
+  }
+}
+
+int launch_relu_mask(float* g, const float* y, size_t n, hipStream_t s) {
+  const size_t n4 = n / 4;
+  hipLaunchKernelGGL(relu_mask_kernel, dim3((unsigned)std::min<size_t>((n4 + 255) / 256, 16384)), dim3(256), 0, s, g, y, n4);
+  PH_HIP_CHECK(hipGetLastError());
+  return PH_OK;
+}
+
+// max_pool2d(2,2) backward: the gradient goes to the FIRST maximum of each window in row-major
+// order (ATen); windows reaching past an odd edge see the zero pad last, so a real element wins ties.
+__global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__ gp, const float* __restrict__ x, int B, int H, int W, int cp, int accumulate,
+                                                       float* __restrict__ gx) {
+  const int Ho = (H + 1) / 2, Wo = (W + 1) / 2, groups = cp >> 2;
+  const size_t total = (size_t)B * Ho * Wo * groups;
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+    const int gq = (int)(idx % groups);
+    size_t p = idx / groups;
+    const int xo = (int)(p % Wo);
+    p /= Wo;
+    const int yo = (int)(p % Ho);
+    const int b = (int)(p / Ho);
+    const f32x4 g = *reinterpret_cast<const f32x4*>(gp + idx * 4);
+    f32x4 v[4];
+    bool ok[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int yy = 2 * yo + (k >> 1), xx = 2 * xo + (k & 1);
+      ok[k] = yy < H && xx < W;
+      v[k] = ok[k] ? *reinterpret_cast<const f32x4*>(x + (((size_t)b * H + yy) * W + xx) * cp + gq * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    f32x4 o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      // first max among the in-image elements; the zero pad (if any) can only win when all real elements are < 0
+      int best = -1;
+      float bv = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (ok[k] && (best < 0 || v[k][e] > bv)) {
+          best = k;
+          bv = v[k][e];
+        }
+      const bool pad_wins = (!(ok[1] && ok[2] && ok[3])) && (bv < 0.f);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) o[k][e] = (k == best && !pad_wins) ? g[e] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (ok[k]) {
+        const int yy = 2 * yo + (k >> 1), xx = 2 * xo + (k & 1);
+        f32x4* dst = reinterpret_cast<f32x4*>(gx + (((size_t)b * H + yy) * W + xx) * cp + gq * 4);
+        *dst = accumulate ? (*dst + o[k]) : o[k];
+      }
+  }
+}
+
+int launch_pool_bwd(const float* gp, const float* x, int B, int H, int W, int cp, int accumulate, float* gx, hipStream_t s) {
+  const size_t total = (size_t)B * ((H + 1) / 2) * ((W + 1) / 2) * (cp / 4);
+  hipLaunchKernelGGL(pool_bwd_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 16384)), dim3(256), 0, s, gp, x, B, H, W, cp, accumulate, gx);
+  PH_HIP_CHECK(hipGetLastError());
+  return PH_OK;
+}
+
+// bilinear x2 (align_corners=False) backward, gather form: input i receives from outputs
+// 2i-1 (w 0.25), 2i (0.75), 2i+1 (0.75), 2i+2 (0.25); at the borders the clamped taps fold onto
+// the edge input (output 0 and output 2n-1 give weight 1.0 to inputs 0 and n-1).
+__device__ __forceinline__ void up_taps(int i, int n, int* o, float* w) {
+  // outputs 2i-1..2i+2; weight of input i in output o: forward weights
+  o[0] = 2 * i - 1;
+  o[1] = 2 * i;
+  o[2] = 2 * i + 1;
+  o[3] = 2 * i + 2;
+  w[0] = 0.25f;
+  w[1] = 0.75f;
+  w[2] = 0.75f;
+  w[3] = 0.25f;
+  if (i == 0) {
+    w[0] = 0.f;   // no output -1
+    w[1] = 1.0f;  // output 0: src clamps to 0 -> all weight on input 0
+  }
+  if (i == n - 1) {
+    w[3] = 0.f;   // no output 2n
+    w[2] = 1.0f;  // output 2n-1: i1 clamps to n-1 -> 0.75 + 0.25
+  }
+}
+
+__global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restrict__ gy, int B, int H, int W, int cp, int accumulate, float* __restrict__ gx) {
+  const int groups = cp >> 2, Ho = 2 * H, Wo = 2 * W;
+  const size_t total = (size_t)B * H * W * groups;
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+    const int gq = (int)(idx % groups);
+    size_t p = idx / groups;
+    const int x = (int)(p % W);
+    p /= W;
+    const int y = (int)(p % H);
+    const int b = (int)(p / H);
+    int oy[4], ox[4];
+    float wy[4], wx[4];
+    up_taps(y, H, oy, wy);
+    up_taps(x, W, ox, wx);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (wy[j] == 0.f || oy[j] < 0 || oy[j] >= Ho) continue;
+      f32x4 row = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (wx[i] == 0.f || ox[i] < 0 || ox[i] >= Wo) continue;
+        row += wx[i] * *reinterpret_cast<const f32x4*>(gy + (((size_t)b * Ho + oy[j]) * Wo + ox[i]) * cp + gq * 4);
+      }
+      acc += wy[j] * row;
+    }
+    f32x4* dst = reinterpret_cast<f32x4*>(gx + idx * 4);
+    *dst = accumulate ? (*dst + acc) : acc;
+  }
+}
+
+int launch_upsample_bwd(const float* gy, int B, int H, int W, int cp, int accumulate, float* gx, hipStream_t s) {
+  const size_t total = (size_t)B * H * W * (cp / 4);
+  hipLaunchKernelGGL(upsample_bwd_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 16384)), dim3(256), 0, s, gy, B, H, W, cp, accumulate, gx);
+  PH_HIP_CHECK(hipGetLastError());
+  return PH_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// Bias gradient: column sums of an NHWC tensor, two stage.
+// ---------------------------------------------------------------------------------------
+constexpr int BIAS_SLICES = 256;
+__global__ __launch_bounds__(256) void bias_partial_kernel(const float* __restrict__ g, size_t npix, int cp, float* __restrict__ partial /* BIAS_SLICES x cp */) {
+  const int sl = blockIdx.x;
+  const size_t per = (npix + BIAS_SLICES - 1) / BIAS_SLICES;
+  const size_t lo = (size_t)sl * per, hi = std::min(npix, lo + per);
+  for (int c = threadIdx.x; c < cp; c += 256) {
+    float acc = 0.f;
+    for (size_t p = lo; p < hi; ++p) acc += g[p * cp + c];
+    partial[(size_t)sl * cp + c] = acc;
+  }
+}
+__global__ void bias_final_kernel(const float* __restrict__ partial, int cp, int cout, float* __restrict__ gb) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cout) return;
+  float s = 0.f;
+  for (int k = 0; k < BIAS_SLICES; ++k) s += partial[(size_t)k * cp + c];
+  gb[c] = s;
+}
+int launch_bias_grad(const float* g, size_t npix, int cp, int cout, float* gb, float* scratch, hipStream_t s) {
+  hipLaunchKernelGGL(bias_partial_kernel, dim3(BIAS_SLICES), dim3(256), 0, s, g, npix, cp, scratch);
+  hipLaunchKernelGGL(bias_final_kernel, dim3((cout + 255) / 256), dim3(256), 0, s, scratch, cp, cout, gb);
+  PH_HIP_CHECK(hipGetLastError());
+  return PH_OK;
+}
+int64_t bias_scratch_floats(int cp) { return (int64_t)BIAS_SLICES * cp; }
+
+// ---------------------------------------------------------------------------------------
+// 3x3 conv weight gradient on MFMA.
+//   dW[tap][ci][co] = sum_pixels X[p + tap][ci] * dY[p][co]  ->  GEMM with M = ci, N = co, K = pixels.
+//   Workgroup (256 thr) owns a 32(ci) x 32(co) tile for all 9 taps over a K slice of pixel
+//   tiles (8 x 32 pixels each).  A[i = ci][k = pixel pair], B[k][j = co]: both fragments are
+//   single dwords read from LDS images [pixel][32 channels] (lanes run over the channel: no bank
+//   conflicts).  Waves split the taps {0,4,8} {1,5} {2,6} {3,7}.  Partial sums go to a slab per
+//   K slice; wgrad_reduce_kernel adds the slabs in a fixed order into the canonical OIHW gradient.
+// ---------------------------------------------------------------------------------------
+constexpr int WG_TH = 8, WG_TW = 32, WG_HW = WG_TW + 2, WG_HH = WG_TH + 2;
+
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
+  __shared__ float sX[WG_HH * WG_HW * 32];
+  __shared__ float sY[WG_TH * WG_TW * 32];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lx = lane & 31, lh = lane >> 5;
+  const int n_co_t = (a.coutp + 31) / 32;
+  const int ci_t = blockIdx.x / n_co_t, co_t = blockIdx.x - ci_t * n_co_t;
+  const int slice = blockIdx.y, n_slices = gridDim.y;
+  const int tiles_x = (a.W + WG_TW - 1) / WG_TW, tiles_y = (a.H + WG_TH - 1) / WG_TH;
+  const int n_tiles = tiles_x * tiles_y * a.B;
+  const int ntaps = (wave == 0) ? 3 : 2;
+
+  f32x16 acc[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  for (int tile = slice; tile < n_tiles; tile += n_slices) {
+    int t = tile;
+    const int tx = t % tiles_x;
+    t /= tiles_x;
+    const int ty = t % tiles_y;
+    const int b = t / tiles_y;
+    const int x0 = tx * WG_TW, y0 = ty * WG_TH;
+    // stage X halo [pix][32 ci] and dY [pix][32 co]; zero outside the image / beyond the channels
+    for (int i = tid; i < WG_HH * WG_HW * 8; i += 256) {
+      const int pix = i >> 3, q = i & 7;
+      const int hy = pix / WG_HW, hx = pix - hy * WG_HW;
+      const int gy = y0 + hy - 1, gx = x0 + hx - 1;
+      const int c = ci_t * 32 + q * 4;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && c < a.cxp) v = *reinterpret_cast<const f32x4*>(a.x + ((size_t)(b * a.H + gy) * a.W + gx) * a.cxp + c);
+      *reinterpret_cast<f32x4*>(sX + pix * 32 + q * 4) = v;
+    }
+    for (int i = tid; i < WG_TH * WG_TW * 8; i += 256) {
+      const int pix = i >> 3, q = i & 7;
+      const int py = pix / WG_TW, px = pix - py * WG_TW;
+      const int gy = y0 + py, gx = x0 + px;
+      const int c = co_t * 32 + q * 4;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (gy < a.H && gx < a.W && c < a.coutp) v = *reinterpret_cast<const f32x4*>(a.dy + ((size_t)(b * a.H + gy) * a.W + gx) * a.coutp + c);
+      *reinterpret_cast<f32x4*>(sY + pix * 32 + q * 4) = v;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int s2 = 0; s2 < WG_TH * WG_TW / 2; ++s2) {
+      const int p = 2 * s2 + lh;
+      const int py = p >> 5, px = p & 31;
+      const float bv = sY[p * 32 + lx];
+#pragma unroll
+      for (int t3 = 0; t3 < 3; ++t3) {
+        if (t3 < ntaps) {
+          const int tap = wave + 4 * t3;
+          const int ky = tap / 3, kx = tap - ky * 3;
+          const float av = sX[((py + ky) * WG_HW + px + kx) * 32 + lx];
+          acc[t3] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t3], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  // slab[slice][tile pair][tap][ci 32][co 32];  D: row(ci) = (r&3) + 8*(r>>2) + 4*lh, col(co) = lx
+  float* slab = a.slab + (((size_t)slice * gridDim.x + blockIdx.x) * 9) * 1024;
+#pragma unroll
+  for (int t3 = 0; t3 < 3; ++t3) {
+    if (t3 < ntaps) {
+      const int tap = wave + 4 * t3;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) slab[(size_t)tap * 1024 + ((r & 3) + 8 * (r >> 2) + 4 * lh) * 32 + lx] = acc[t3][r];
+    }
+  }
+}
+
+// grad[(co*cin_total + ci_off + ci)*9 + tap] = sum_slices slab[...]
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, int n_slices, int n_blocks, int n_co_t, int cin, int cout, int cin_total,
+                                                           int ci_off, float* __restrict__ grad) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= cin * cout * 9) return;
+  const int tap = i % 9;
+  int r = i / 9;
+  const int ci = r % cin, co = r / cin;
+  const int blk = (ci >> 5) * n_co_t + (co >> 5);
+  float s = 0.f;
+  for (int k = 0; k < n_slices; ++k) s += slab[(((size_t)k * n_blocks + blk) * 9 + tap) * 1024 + (ci & 31) * 32 + (co & 31)];
+  grad[((size_t)co * cin_total + ci_off + ci) * 9 + tap] = s;
+}
+
+int wgrad_slices(int B, int H, int W) {
+  const int n_tiles = ((W + WG_TW - 1) / WG_TW) * ((H + WG_TH - 1) / WG_TH) * B;
+  return std::max(1, std::min(n_tiles, 16));
+}
+int64_t wgrad_slab_floats(int cin_part, int cout, int B, int H, int W) {
+  const int64_t blocks = (int64_t)((pad16(cin_part) + 31) / 32) * ((pad16(cout) + 31) / 32);
+  return (int64_t)wgrad_slices(B, H, W) * blocks * 9 * 1024;
+}
+
+int launch_wgrad(const WgradArgs& a0, int cin_part, int cout, int cin_total, int ci_off, float* grad, hipStream_t s) {
+  WgradArgs a = a0;
+  const int n_ci_t = (a.cxp + 31) / 32, n_co_t = (a.coutp + 31) / 32;
+  const int n_slices = wgrad_slices(a.B, a.H, a.W);
+  hipLaunchKernelGGL(wgrad_kernel, dim3(n_ci_t * n_co_t, n_slices), dim3(256), 0, s, a);
+  const int n = cin_part * cout * 9;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, s, a.slab, n_slices, n_ci_t * n_co_t, n_co_t, cin_part, cout, cin_total, ci_off, grad);
+  PH_HIP_CHECK(hipGetLastError());
+  return PH_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// First-conv weight gradient (Cin 1 or 3 image, NCHW uint8/float):
+//   dW[co][ci][tap] = sum_{b,p} dY[b,p,co] * img[b,ci,p+tap] (normalised).  Persistent blocks walk
+//   pixel tiles; thread = (co, tap-ci) pair keeps one partial in a register.
+// ---------------------------------------------------------------------------------------
+constexpr int ICW_BLOCKS = 1024;
+__global__ __launch_bounds__(256) void input_wgrad_partial_kernel(const void* __restrict__ img, int dtype, const float* __restrict__ dy, int B, int cin, int H, int W,
+                                                                  int coutp, int cout, float* __restrict__ partial /* ICW_BLOCKS x (cout*cin*9) */) {
+  __shared__ float sImg[3 * 10 * 34];
+  __shared__ float sDy[8 * 32 * 16];
+  const int n_out = cout * cin * 9;
+  const int tiles_x = (W + 31) / 32, tiles_y = (H + 7) / 8;
+  const int n_tiles = tiles_x * tiles_y * B;
+  float acc[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+  for (int cbase = 0; cbase < cout; cbase += 16) {  // 16 output channels at a time
+    const int ncb = min(16, cout - cbase);
+    for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+      int t = tile;
+      const int tx = t % tiles_x;
+      t /= tiles_x;
+      const int ty = t % tiles_y;
+      const int b = t / tiles_y;
+      const int x0 = tx * 32, y0 = ty * 8;
+      for (int i = threadIdx.x; i < cin * 340; i += 256) {
+        const int c = i / 340, r = i - c * 340;
+        const int hy = r / 34, hx = r - hy * 34;
+        const int gy = y0 + hy - 1, gx = x0 + hx - 1;
+        float v = 0.f;
+        if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+          const size_t o = (((size_t)b * cin + c) * H + gy) * W + gx;
+          if (dtype == 0)
+            v = (float)reinterpret_cast<const uint8_t*>(img)[o] / 255.0f;
+          else {
+            v = reinterpret_cast<const float*>(img)[o];
+            if (dtype == 2) v = v / 255.0f;
+          }
+        }
+        sImg[i] = v;
+      }
+      for (int i = threadIdx.x; i < 256 * 16; i += 256) {
+        const int pix = i >> 4, c = i & 15;
+        const int gy = y0 + (pix >> 5), gx = x0 + (pix & 31);
+        float v = 0.f;
+        if (gy < H && gx < W && c < ncb) v = dy[(((size_t)b * H + gy) * W + gx) * coutp + cbase + c];
+        sDy[i] = v;
+      }
+      __syncthreads();
+      // work items: (co_local 0..15) x (ci*9 + tap) <= 16*27 = 432 -> up to 2 per thread
+      for (int k = 0, item = threadIdx.x; item < 16 * cin * 9; item += 256, ++k) {
+        const int col = item & 15, ct = item >> 4;
+        const int ci = ct / 9, tap = ct - ci * 9;
+        const int ky = tap / 3, kx = tap - ky * 3;
+        float s = 0.f;
+        for (int pix = 0; pix < 256; ++pix) s += sDy[pix * 16 + col] * sImg[ci * 340 + ((pix >> 5) + ky) * 34 + (pix & 31) + kx];
+        acc[k] += s;
+      }
+      __syncthreads();
+    }
+    for (int k = 0, item = threadIdx.x; item < 16 * cin * 9; item += 256, ++k) {
+      const int col = item & 15, ct = item >> 4;
+      if (col < ncb) partial[(size_t)blockIdx.x * n_out + (size_t)(cbase + col) * cin * 9 + ct] = acc[k];
+    }
+  }
+}
+__global__ void input_wgrad_final_kernel(const float* __restrict__ partial, int n_blocks, int n_out, float* __restrict__ gw) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_out) return;
+  float s = 0.f;
+  for (int k = 0; k < n_blocks; ++k) s += partial[(size_t)k * n_out + i];
+  gw[i] = s;
+}
+int launch_input_wgrad(const void* img, int dtype, const float* dy, int B, int cin, int H, int W, int coutp, int cout, float* gw, float* scratch, hipStream_t s) {
+  if (cin > 3) {
+    set_error("input wgrad: more than 3 input channels");
+    return PH_E_INVALID;
+  }
+  const int n_tiles = ((W + 31) / 32) * ((H + 7) / 8) * B;
+  const int blocks = std::min(n_tiles, ICW_BLOCKS);
+  hipLaunchKernelGGL(input_wgrad_partial_kernel, dim3(blocks), dim3(256), 0, s, img, dtype, dy, B, cin, H, W, coutp, cout, scratch);
+  const int n_out = cout * cin * 9;
+  hipLaunchKernelGGL(input_wgrad_final_kernel, dim3((n_out + 255) / 256), dim3(256), 0, s, scratch, blocks, n_out, gw);
+  PH_HIP_CHECK(hipGetLastError());
+  return PH_OK;
+}
+int64_t input_wgrad_scratch_floats(int cin, int cout) { return (int64_t)ICW_BLOCKS * cout * cin * 9; }
+
+// ---------------------------------------------------------------------------------------
+// Adam (torch.optim.Adam, weight_decay 0) and the canonical -> packed weight gather.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                   float* __restrict__ vmax, size_t n, float lr, float b1, float b2, float eps, float bc1, float bc2_sqrt,
+                                                   float grad_scale) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const float gi = g[i] * grad_scale;
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    float vv = vi;
+    if (vmax) {
+      vv = fmaxf(vmax[i], vi);
+      vmax[i] = vv;
+    }
+    const float denom = sqrtf(vv) / bc2_sqrt + eps;
+    p[i] = p[i] - (lr / bc1) * (mi / denom);
+  }
+}
+
+__global__ __launch_bounds__(256) void gather_kernel(const float* __restrict__ canon, const int* __restrict__ map, size_t n, float* __restrict__ out) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const int j = map[i];
+    out[i] = j >= 0 ? canon[j] : 0.f;
+  }
+}
+
+int launch_gather(const float* canon, const int* map, size_t n, float* out, hipStream_t s) {
+  if (n == 0) return PH_OK;
+  hipLaunchKernelGGL(gather_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 16384)), dim3(256), 0, s, canon, map, n, out);
+  PH_HIP_CHECK(hipGetLastError());
+  return PH_OK;
+}
+
+}  // namespace ph
+
+using namespace ph;
+
+extern "C" {
+
+int ph_adam_step(float* params_dev, const float* grads_dev, float* exp_avg_dev, float* exp_avg_sq_dev, float* max_exp_avg_sq_dev, int64_t n, float lr,
+                 float beta1, float beta2, float eps, int32_t step, float grad_scale, void* stream) {
+  PH_REQUIRE(params_dev && grads_dev && exp_avg_dev && exp_avg_sq_dev && n >= 0 && step >= 1, "ph_adam_step: bad arguments");
+  if (n == 0) return PH_OK;
+  const float bc1 = 1.f - powf(beta1, (float)step);
+  const float bc2 = 1.f - powf(beta2, (float)step);
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 16384)), dim3(256), 0, static_cast<hipStream_t>(stream), params_dev, grads_dev,
+                     exp_avg_dev, exp_avg_sq_dev, max_exp_avg_sq_dev, (size_t)n, lr, beta1, beta2, eps, bc1, sqrtf(bc2), grad_scale);
+  PH_HIP_CHECK(hipGetLastError());
+  return PH_OK;
+}
+
+}  // extern "C"

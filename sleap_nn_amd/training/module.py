@@ -1,0 +1,151 @@
+"""One data-parallel training step on the MI355X: forward, per-head MSE (+OHKM), backward,
+gradient all-reduce (RCCL over xGMI through ``torch.distributed``), Adam.
+
+Mirrors the step semantics of the reference's LightningModules
+(``sleap_nn/training/lightning_modules.py``: ``training_step`` :1850-1922 for bottom-up,
+``_compute_negative_weighted_loss`` :490-545 = ``nn.MSELoss`` per head, loss = sum of
+``loss_weight`` x head loss, ``compute_ohkm_loss`` ``training/losses.py:8-63``,
+``configure_optimizers`` :750-763 = ``torch.optim.Adam(lr, amsgrad)``) and DDP's gradient averaging.
+Parameters, gradients and Adam moments live in flat fp32 arenas in the reference's state_dict
+order, so the all-reduce is ONE collective over one contiguous buffer (31 MB at cfg3).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence
+
+import torch
+import torch.distributed as dist
+
+from sleap_nn_amd import _lib as L
+from sleap_nn_amd.architectures.model import Model
+
+
+@dataclass
+class OHKMConfig:
+    """trainer_config.online_hard_keypoint_mining (losses.py:8-15 defaults)."""
+
+    online_mining: bool = False
+    hard_to_easy_ratio: float = 2.0
+    min_hard_keypoints: int = 2
+    max_hard_keypoints: Optional[int] = None
+    loss_scale: float = 5.0
+
+
+class TrainingModule:
+    """Owns the device arenas of one model replica and runs training steps."""
+
+    def __init__(self, model: Model, device: str = "cuda", lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8, amsgrad: bool = False,
+                 loss_weights: Optional[Sequence[float]] = None, ohkm: Optional[OHKMConfig] = None) -> None:
+        L.lib()
+        if not torch.cuda.is_available():
+            raise RuntimeError("TrainingModule needs an MI355X; there is no CPU fallback")
+        dev = torch.device(device)
+        if dev.index is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
+        self.device = dev
+        self.model = model.train(True).to(dev)
+        self.lr, self.betas, self.eps, self.amsgrad = lr, betas, eps, amsgrad
+        self.loss_weights = [float(w) for w in (loss_weights if loss_weights is not None else [h.loss_weight for h in model.heads])]
+        self.ohkm = ohkm or OHKMConfig()
+        self.params = model.flat_params().to(dev)
+        self.grads = torch.zeros_like(self.params)
+        self.exp_avg = torch.zeros_like(self.params)
+        self.exp_avg_sq = torch.zeros_like(self.params)
+        self.max_exp_avg_sq = torch.zeros_like(self.params) if amsgrad else None
+        self.step_count = 0
+        self._grad_ws: Optional[torch.Tensor] = None
+        self._loss = torch.zeros(1 + len(model.heads), dtype=torch.float32, device=dev)
+        self.model._ensure(dev)
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.broadcast(self.params, src=0)  # identical initial weights on every rank (DDP semantics)
+            self._push_params()
+
+    # ------------------------------------------------------------------------------
+    def _push_params(self) -> None:
+        with torch.cuda.device(self.device):
+            L.check(L.lib().ph_model_set_params(self.model._handle, C.c_void_p(self.params.data_ptr()), L.current_stream_ptr()))
+
+    def forward_backward(self, image: torch.Tensor, targets: Dict[str, torch.Tensor]) -> torch.Tensor:
+        """Forward + loss + backward.  ``image``: (B[,1],C,H,W) uint8/float; ``targets``: head name ->
+        (B, c, h, w) fp32.  Fills ``self.grads`` (local gradients) and returns the loss tensor
+        ``[total, head_0, head_1, ...]`` (device, no sync)."""
+        x = image.to(self.device, non_blocking=True)
+        if x.dim() == 5:
+            x = x.squeeze(1)
+        code = 0
+        if x.dtype != torch.uint8:
+            x = x.to(torch.float32)
+            code = 2 if bool(x.max() > 1.0) else 1
+        x = x.contiguous()
+        out = self.model.forward(x, in_dtype=None if code == 0 else code)
+        B, Cin, H, W = x.shape
+        lib = L.lib()
+        m = self.model
+        with torch.cuda.device(self.device):
+            need = L.check(lib.ph_model_backward_workspace_bytes(m._handle, B, H, W))
+            if self._grad_ws is None or self._grad_ws.numel() < need:
+                self._grad_ws = None
+                self._grad_ws = torch.empty(int(need), dtype=torch.uint8, device=self.device)
+            outs = [out[h.name].contiguous() for h in m.heads]
+            tg = [targets[h.name].to(self.device, torch.float32).contiguous() for h in m.heads]
+            for o, t in zip(outs, tg):
+                if tuple(o.shape) != tuple(t.shape):
+                    raise ValueError(f"target shape {tuple(t.shape)} != prediction shape {tuple(o.shape)}")
+            optr = (C.c_void_p * len(outs))(*[o.data_ptr() for o in outs])
+            tptr = (C.c_void_p * len(tg))(*[t.data_ptr() for t in tg])
+            lw = (C.c_float * len(self.loss_weights))(*self.loss_weights)
+            k = self.ohkm
+            L.check(
+                lib.ph_model_backward(
+                    m._handle, C.c_void_p(x.data_ptr()), code, B, Cin, H, W, C.c_void_p(m._workspace.data_ptr()), C.c_void_p(self._grad_ws.data_ptr()),
+                    self._grad_ws.numel(), optr, tptr, lw, 1 if k.online_mining else 0, float(k.hard_to_easy_ratio), int(k.min_hard_keypoints),
+                    -1 if k.max_hard_keypoints is None else int(k.max_hard_keypoints), float(k.loss_scale), C.c_void_p(self._loss.data_ptr()),
+                    C.c_void_p(self.grads.data_ptr()), L.current_stream_ptr(),
+                )
+            )
+        self._last_out = out
+        return self._loss
+
+    def all_reduce_grads(self) -> float:
+        """Sum the flat gradient arena over the ranks (one RCCL all-reduce); returns the scale that
+        turns the sum into DDP's mean."""
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(self.grads, op=dist.ReduceOp.SUM)
+            return 1.0 / dist.get_world_size()
+        return 1.0
+
+    def optimizer_step(self, grad_scale: float = 1.0) -> None:
+        self.step_count += 1
+        with torch.cuda.device(self.device):
+            L.check(
+                L.lib().ph_adam_step(
+                    C.c_void_p(self.params.data_ptr()), C.c_void_p(self.grads.data_ptr()), C.c_void_p(self.exp_avg.data_ptr()),
+                    C.c_void_p(self.exp_avg_sq.data_ptr()), C.c_void_p(self.max_exp_avg_sq.data_ptr()) if self.max_exp_avg_sq is not None else None,
+                    self.params.numel(), float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps), self.step_count, float(grad_scale),
+                    L.current_stream_ptr(),
+                )
+            )
+        self._push_params()
+
+    def training_step(self, batch: Dict[str, torch.Tensor]) -> torch.Tensor:
+        """``batch``: {"image": ..., <head name>: target, ...}.  Returns the loss tensor (device)."""
+        loss = self.forward_backward(batch["image"], {k: v for k, v in batch.items() if k != "image"})
+        scale = self.all_reduce_grads()
+        self.optimizer_step(scale)
+        return loss
+
+    # ------------------------------------------------------------------------------
+    def named_grads(self) -> Dict[str, torch.Tensor]:
+        out, o = {}, 0
+        g = self.grads.detach().cpu()
+        for k in self.model.param_keys():
+            n = int(torch.tensor(self.model.param_shapes[k]).prod())
+            out[k] = g[o : o + n].reshape(self.model.param_shapes[k])
+            o += n
+        return out
+
+    def state_dict(self) -> Dict[str, torch.Tensor]:
+        self.model.load_flat_params(self.params)
+        return self.model.state_dict()
