@@ -67,3 +67,12 @@ def predict_sharded(layer, frames, group=None) -> Optional[Outputs]:
     local = layer.predict(frames[a:b]) if b > a else None
     parts = gather_outputs(local, group)
     return merge_outputs(parts) if rank == 0 else None
+
+
+def allreduce_mean_(flat: torch.Tensor, group=None) -> torch.Tensor:
+    """DDP gradient semantics on one contiguous arena: sum over ranks (one collective), divide by
+    the world size.  With the ``nccl`` backend on ROCm this is a single RCCL all-reduce over xGMI."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        flat.div_(dist.get_world_size(group))
+    return flat

@@ -114,3 +114,21 @@ def test_training_reduces_loss():
     sd, img, targets, lw, tm = _setup(bb, heads, mt, (32, 32), 4, seed=9, lr=3e-3)
     losses = [float(tm.training_step({"image": img, **targets})[0]) for _ in range(30)]
     assert losses[-1] < 0.5 * losses[0], losses[::5]
+
+
+def test_data_parallel_gradient_equivalence():
+    """DDP semantics without a second GPU: the mean of the gradients of two equal shards (what the
+    flat all-reduce + 1/world_size produces) equals the gradient of the full batch, because every
+    head loss is a mean over all elements."""
+    bb, heads, mt = _cfg(8, 8, 2)
+    sd, img, targets, lw, tm = _setup(bb, heads, mt, (48, 64), 4, seed=21)
+    tm.forward_backward(img, targets)
+    full = tm.grads.clone()
+    acc = torch.zeros_like(full)
+    for r in range(2):
+        sl = slice(2 * r, 2 * r + 2)
+        tm.forward_backward(img[sl], {k: v[sl] for k, v in targets.items()})
+        acc += tm.grads
+    acc /= 2
+    scale = float(full.abs().max())
+    assert float((acc - full).abs().max()) <= 1e-5 * scale

@@ -9,7 +9,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from sleap_nn_amd.inference.outputs import Outputs
-from sleap_nn_amd.parallel import merge_outputs, predict_sharded, shard_bounds
+from sleap_nn_amd.parallel import allreduce_mean_, merge_outputs, predict_sharded, shard_bounds
 
 
 def test_shard_bounds_cover_and_balance():
@@ -41,6 +41,9 @@ def _worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     frames = torch.arange(7).reshape(7, 1, 1, 1).float()
     out = predict_sharded(_FakeLayer(), frames)
+    g = torch.full((1000,), float(rank + 1))
+    allreduce_mean_(g)  # gradient-arena semantics: mean over ranks
+    assert torch.allclose(g, torch.full((1000,), 1.5))
     if rank == 0:
         q.put(out.pred_keypoints.numpy())
     dist.barrier()
