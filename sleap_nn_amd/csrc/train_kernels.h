@@ -32,7 +32,7 @@ int launch_pool_bwd(const float* gp, const float* x, int B, int H, int W, int cp
 int launch_upsample_bwd(const float* gy, int B, int H, int W, int cp, int accumulate, float* gx, hipStream_t s);
 int launch_bias_grad(const float* g, size_t npix, int cp, int cout, float* gb, float* scratch, hipStream_t s);
 int64_t bias_scratch_floats(int cp);
-int wgrad_slices(int B, int H, int W);
+int wgrad_slices(int B, int H, int W, int blocks);
 int64_t wgrad_slab_floats(int cin_part, int cout, int B, int H, int W);
 int launch_wgrad(const WgradArgs& a, int cin_part, int cout, int cin_total, int ci_off, float* grad, hipStream_t s);
 int launch_input_wgrad(const void* img, int dtype, const float* dy, int B, int cin, int H, int W, int coutp, int cout, float* gw, float* scratch, hipStream_t s);

@@ -375,15 +375,29 @@ int launch_upsample_bwd(const float* gy, int B, int H, int W, int cp, int accumu
 // ---------------------------------------------------------------------------------------
 // Bias gradient: column sums of an NHWC tensor, two stage.
 // ---------------------------------------------------------------------------------------
-constexpr int BIAS_SLICES = 256;
+constexpr int BIAS_SLICES = 1024;
 __global__ __launch_bounds__(256) void bias_partial_kernel(const float* __restrict__ g, size_t npix, int cp, float* __restrict__ partial /* BIAS_SLICES x cp */) {
+  // thread = (pixel row r, channel c): 256/min(cp,256) pixels are summed side by side, then the
+  // rows are combined in a fixed order through LDS (deterministic).
+  __shared__ float red[256];
   const int sl = blockIdx.x;
   const size_t per = (npix + BIAS_SLICES - 1) / BIAS_SLICES;
   const size_t lo = (size_t)sl * per, hi = std::min(npix, lo + per);
-  for (int c = threadIdx.x; c < cp; c += 256) {
+  const int cw = min(cp, 256), rows = 256 / cw;
+  const int c0 = threadIdx.x % cw, r = threadIdx.x / cw;
+  for (int cb = 0; cb < cp; cb += cw) {
+    const int c = cb + c0;
     float acc = 0.f;
-    for (size_t p = lo; p < hi; ++p) acc += g[p * cp + c];
-    partial[(size_t)sl * cp + c] = acc;
+    if (r < rows && c < cp)
+      for (size_t p = lo + r; p < hi; p += rows) acc += g[p * cp + c];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if (r == 0 && c < cp) {
+      float s = 0.f;
+      for (int k = 0; k < rows; ++k) s += red[k * cw + c0];
+      partial[(size_t)sl * cp + c] = s;
+    }
+    __syncthreads();
   }
 }
 __global__ void bias_final_kernel(const float* __restrict__ partial, int cp, int cout, float* __restrict__ gb) {
@@ -500,19 +514,21 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   grad[((size_t)co * cin_total + ci_off + ci) * 9 + tap] = s;
 }
 
-int wgrad_slices(int B, int H, int W) {
+// K slices per (ci, co) tile: enough workgroups to fill 256 CUs x 2, never more than pixel tiles
+int wgrad_slices(int B, int H, int W, int blocks) {
   const int n_tiles = ((W + WG_TW - 1) / WG_TW) * ((H + WG_TH - 1) / WG_TH) * B;
-  return std::max(1, std::min(n_tiles, 16));
+  const int want = (1024 + blocks - 1) / blocks;
+  return std::max(1, std::min(n_tiles, std::max(want, 4)));
 }
 int64_t wgrad_slab_floats(int cin_part, int cout, int B, int H, int W) {
-  const int64_t blocks = (int64_t)((pad16(cin_part) + 31) / 32) * ((pad16(cout) + 31) / 32);
-  return (int64_t)wgrad_slices(B, H, W) * blocks * 9 * 1024;
+  const int blocks = ((pad16(cin_part) + 31) / 32) * ((pad16(cout) + 31) / 32);
+  return (int64_t)wgrad_slices(B, H, W, blocks) * blocks * 9 * 1024;
 }
 
 int launch_wgrad(const WgradArgs& a0, int cin_part, int cout, int cin_total, int ci_off, float* grad, hipStream_t s) {
   WgradArgs a = a0;
   const int n_ci_t = (a.cxp + 31) / 32, n_co_t = (a.coutp + 31) / 32;
-  const int n_slices = wgrad_slices(a.B, a.H, a.W);
+  const int n_slices = wgrad_slices(a.B, a.H, a.W, n_ci_t * n_co_t);
   hipLaunchKernelGGL(wgrad_kernel, dim3(n_ci_t * n_co_t, n_slices), dim3(256), 0, s, a);
   const int n = cin_part * cout * 9;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, s, a.slab, n_slices, n_ci_t * n_co_t, n_co_t, cin_part, cout, cin_total, ci_off, grad);
