@@ -123,6 +123,8 @@ def main():
     dev = torch.device("cuda", local_rank)
     if world > 1:
         dist.init_process_group(backend="nccl", device_id=dev)
+        # ranks share the host: keep torch's CPU pool (synthetic-input rendering only) to a fair share
+        torch.set_num_threads(max(1, (os.cpu_count() or world) // world))
 
     from oracle import cpu_ref as O  # synthetic weights come from the oracle's seeded initialiser
     from sleap_nn_amd.architectures.model import Model

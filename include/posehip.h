@@ -148,6 +148,16 @@ int ph_adam_step(float* params_dev, const float* grads_dev, float* exp_avg_dev, 
                  float* max_exp_avg_sq_dev, int64_t n, float lr, float beta1, float beta2, float eps,
                  int32_t step, float grad_scale, void* stream);
 
+/* On-device rendering of the training targets (reference: data/confidence_maps.py:96-166
+ * generate_multiconfmaps; data/edge_maps.py:15-78,120-220,250-323 generate_pafs).
+ * points_dev: (B, I, N, 2) fp32 (x, y) image coordinates, NaN = missing.  Grids are
+ * arange(0, size, stride).  Confmaps: (B, N, h, w), Gaussian sigma*stride, max over instances.
+ * PAFs: (B, 2E, h, w) channel 2e = x, 2e+1 = y, summed over instances; edges_dev int32 (E, 2). */
+int ph_render_confmaps(const float* points_dev, int32_t B, int32_t I, int32_t N, int32_t img_h, int32_t img_w,
+                       int32_t stride, float sigma, float* out_dev, void* stream);
+int ph_render_pafs(const float* points_dev, const int32_t* edges_dev, int32_t B, int32_t I, int32_t N, int32_t E,
+                   int32_t img_h, int32_t img_w, int32_t stride, float sigma, float* out_dev, void* stream);
+
 /* Per-op timing with HIP events recorded on the forward's own stream (used by bench.py for
  * the roofline object).  While enabled every forward records one event before each op and
  * one after the last; ph_model_profile_read waits for the last recorded forward, returns

@@ -877,3 +877,50 @@ def adam_reference(sd: Dict[str, torch.Tensor], grads_per_step: List[Dict[str, t
             p.grad = g[k].clone()
         opt.step()
     return {k: p.detach() for k, p in params.items()}
+
+
+# --------------------------------------------------------------------------------------
+# Training targets (data/confidence_maps.py:36-166, data/edge_maps.py:15-323, data/utils.py:55-125)
+# --------------------------------------------------------------------------------------
+
+
+def make_multiconfmaps(points: torch.Tensor, img_hw, sigma: float, stride: int) -> torch.Tensor:
+    """(B, I, N, 2) -> (B, N, h, w): max over instances of the unit Gaussian, NaN points ignored."""
+    xv = torch.arange(0, img_hw[1], step=stride, dtype=torch.float32)
+    yv = torch.arange(0, img_hw[0], step=stride, dtype=torch.float32)
+    s = sigma * stride
+    B, I, N, _ = points.shape
+    out = torch.zeros((B, N, yv.numel(), xv.numel()))
+    for i in range(I):
+        x = points[:, i, :, 0].reshape(B, N, 1, 1)
+        y = points[:, i, :, 1].reshape(B, N, 1, 1)
+        cm = torch.exp(-((xv.view(1, 1, 1, -1) - x) ** 2 + (yv.view(1, 1, -1, 1) - y) ** 2) / (2 * s**2))
+        out = torch.maximum(out, torch.nan_to_num(cm))
+    return out
+
+
+def make_pafs_sample(inst: torch.Tensor, edges, img_hw, sigma: float, stride: int) -> torch.Tensor:
+    """One sample (I, N, 2) -> (2E, h, w), restating generate_pafs incl. its quirks (squared distance fed
+    to the Gaussian, in-image instance filter, NaN -> 0, sum over instances)."""
+    xv = torch.arange(0, img_hw[1], step=stride, dtype=torch.float32)
+    yv = torch.arange(0, img_hw[0], step=stride, dtype=torch.float32)
+    lim = torch.stack([xv[-1], yv[-1]]).view(1, 1, 2)
+    keep = ((inst > 0) & (inst < lim)).all(dim=-1).any(dim=1)
+    inst = inst[keep]
+    yy, xx = torch.meshgrid(yv, xv, indexing="ij")
+    grid = torch.stack((xx, yy), dim=-1)
+    out = torch.zeros((len(edges) * 2, yv.numel(), xv.numel()))
+    for i in range(inst.shape[0]):
+        for e, (s, d) in enumerate(edges):
+            a, b = inst[i, s], inst[i, d]
+            v = b - a
+            l2 = torch.maximum((v * v).sum(), torch.tensor(1.0))
+            rel = grid - a
+            t = ((rel * v).sum(-1) / l2).clamp(0, 1)
+            d2 = ((t.unsqueeze(-1) * v - rel) ** 2).sum(-1)
+            g = torch.exp(-(d2**2) / (2 * sigma**2))
+            u = v / torch.norm(v)
+            px, py = g * u[0], g * u[1]
+            out[2 * e] += torch.nan_to_num(px, nan=0.0)
+            out[2 * e + 1] += torch.nan_to_num(py, nan=0.0)
+    return out

@@ -389,6 +389,34 @@ def multiclass_fixture():
     save("multiclass.npz", **arrs)
 
 
+
+
+
+def targets_fixture():
+    """Reference target rendering (generate_multiconfmaps / generate_pafs) on random instance sets."""
+    from sleap_nn.data.confidence_maps import generate_multiconfmaps
+    from sleap_nn.data.edge_maps import generate_pafs
+
+    arrs = {}
+    g = torch.Generator().manual_seed(17)
+    hw = (96, 128)
+    edges = [(0, 1), (1, 2), (1, 3)]
+    pts = torch.rand((3, 4, 4, 2), generator=g) * torch.tensor([140.0, 110.0]) - 8.0  # some out of frame
+    pts[0, 1, 2] = float("nan")  # missing node
+    pts[1, 3] = float("nan")  # missing instance
+    pts[2, 0] = torch.tensor([[-5.0, -5.0], [-3.0, 200.0], [300.0, 2.0], [-1.0, -1.0]])  # instance fully outside
+    pts[2, 1, 1] = pts[2, 1, 0]  # zero-length edge
+    arrs["points"] = _np(pts)
+    for stride, sigma in ((2, 1.5), (4, 2.5)):
+        cm = torch.cat([generate_multiconfmaps(pts[b : b + 1], hw, num_instances=4, sigma=sigma, output_stride=stride) for b in range(3)])
+        arrs[f"confmaps_s{stride}"] = _np(cm)
+    for stride, sigma in ((4, 15.0), (8, 50.0)):
+        pf = torch.stack([generate_pafs(pts[b : b + 1].clone(), hw, sigma=sigma, output_stride=stride, edge_inds=torch.tensor(edges), flatten_channels=True) for b in range(3)])
+        arrs[f"pafs_s{stride}"] = _np(pf)
+    arrs["meta_json"] = np.array(json.dumps({"hw": hw, "edges": edges, "confmaps": [[2, 1.5], [4, 2.5]], "pafs": [[4, 15.0], [8, 50.0]]}))
+    save("targets.npz", **arrs)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     if not only or "core" in only:
@@ -397,3 +425,5 @@ if __name__ == "__main__":
         topdown_fixture()
     if not only or "multiclass" in only:
         multiclass_fixture()
+    if not only or "targets" in only:
+        targets_fixture()

@@ -661,11 +661,109 @@ int launch_gather(const float* canon, const int* map, size_t n, float* out, hipS
   return PH_OK;
 }
 
+// ---------------------------------------------------------------------------------------
+// On-device training targets (the reference renders them per sample on the CPU in the Dataset).
+//   confidence maps: per node, max over instances of exp(-((x-px)^2 + (y-py)^2) / (2 (sigma*stride)^2)),
+//     NaN points contribute 0            (data/confidence_maps.py:36-41,96-166)
+//   part-affinity fields: per edge, sum over instances of exp(-(d2)^2 / (2 sigma^2)) * unit(dst-src), with
+//     d2 = SQUARED distance to the segment (the reference feeds the squared distance to its Gaussian,
+//     data/edge_maps.py:15-78,120-220 -- kept as is); instances with no node strictly inside
+//     (0, grid_max) are dropped, NaN contributions are zeroed (edge_maps.py:286-290,213).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void render_confmaps_kernel(const float* __restrict__ pts /* B,I,N,2 */, int B, int I, int N, int h, int w, int stride, float sigma,
+                                                              float* __restrict__ out /* B,N,h,w */) {
+  const size_t total = (size_t)B * N * h * w;
+  const float inv = 1.0f / (2.0f * sigma * sigma);
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+    const int x = (int)(idx % w);
+    size_t r = idx / w;
+    const int y = (int)(r % h);
+    r /= h;
+    const int n = (int)(r % N);
+    const int b = (int)(r / N);
+    const float gx = (float)(x * stride), gy = (float)(y * stride);
+    float best = 0.f;
+    for (int i = 0; i < I; ++i) {
+      const float px = pts[(((size_t)b * I + i) * N + n) * 2], py = pts[(((size_t)b * I + i) * N + n) * 2 + 1];
+      const float dx = gx - px, dy = gy - py;
+      const float v = expf(-(dx * dx + dy * dy) * inv);
+      if (v == v) best = fmaxf(best, v);  // NaN -> 0 (nan_to_num), then maximum with the zero init
+    }
+    out[idx] = best;
+  }
+}
+
+__global__ __launch_bounds__(256) void render_pafs_kernel(const float* __restrict__ pts /* B,I,N,2 */, const int* __restrict__ edges /* E,2 */, int B, int I, int N, int E,
+                                                          int h, int w, int stride, float sigma, float* __restrict__ out /* B,2E,h,w */) {
+  const size_t total = (size_t)B * E * h * w;
+  const float inv = 1.0f / (2.0f * sigma * sigma);
+  const float xmax = (float)((w - 1) * stride), ymax = (float)((h - 1) * stride);
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+    const int x = (int)(idx % w);
+    size_t r = idx / w;
+    const int y = (int)(r % h);
+    r /= h;
+    const int e = (int)(r % E);
+    const int b = (int)(r / E);
+    const float gx = (float)(x * stride), gy = (float)(y * stride);
+    const int sn = edges[2 * e], dn = edges[2 * e + 1];
+    float ax = 0.f, ay = 0.f;
+    for (int i = 0; i < I; ++i) {
+      const float* ip = pts + ((size_t)b * I + i) * N * 2;
+      bool any_in = false;
+      for (int n = 0; n < N; ++n) {
+        const float qx = ip[2 * n], qy = ip[2 * n + 1];
+        any_in = any_in || (qx > 0.f && qy > 0.f && qx < xmax && qy < ymax);
+      }
+      if (!any_in) continue;
+      const float sx = ip[2 * sn], sy = ip[2 * sn + 1], tx = ip[2 * dn], ty = ip[2 * dn + 1];
+      const float vx = tx - sx, vy = ty - sy;
+      const float len2 = fmaxf(vx * vx + vy * vy, 1.0f);
+      const float rx = gx - sx, ry = gy - sy;
+      float t = (rx * vx + ry * vy) / len2;
+      t = fminf(fmaxf(t, 0.f), 1.f);
+      const float ex = t * vx - rx, ey = t * vy - ry;
+      const float d2 = ex * ex + ey * ey;
+      const float g = expf(-(d2 * d2) * inv);
+      const float norm = sqrtf(vx * vx + vy * vy);
+      const float px = g * (vx / norm), py = g * (vy / norm);
+      if (px == px) ax += px;
+      if (py == py) ay += py;
+    }
+    const size_t plane = (size_t)h * w;
+    float* o = out + ((size_t)b * 2 * E + 2 * e) * plane + (size_t)y * w + x;
+    o[0] = ax;
+    o[plane] = ay;
+  }
+}
+
 }  // namespace ph
 
 using namespace ph;
 
 extern "C" {
+
+int ph_render_confmaps(const float* points_dev, int32_t B, int32_t I, int32_t N, int32_t img_h, int32_t img_w, int32_t stride, float sigma, float* out_dev,
+                       void* stream) {
+  PH_REQUIRE(points_dev && out_dev && B > 0 && I >= 0 && N > 0 && img_h > 0 && img_w > 0 && stride > 0, "ph_render_confmaps: bad arguments");
+  const int h = (img_h + stride - 1) / stride, w = (img_w + stride - 1) / stride;  // len(arange(0, size, stride))
+  const size_t total = (size_t)B * N * h * w;
+  hipLaunchKernelGGL(render_confmaps_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 16384)), dim3(256), 0, static_cast<hipStream_t>(stream), points_dev, B,
+                     I, N, h, w, stride, sigma * (float)stride, out_dev);
+  PH_HIP_CHECK(hipGetLastError());
+  return PH_OK;
+}
+
+int ph_render_pafs(const float* points_dev, const int32_t* edges_dev, int32_t B, int32_t I, int32_t N, int32_t E, int32_t img_h, int32_t img_w, int32_t stride,
+                   float sigma, float* out_dev, void* stream) {
+  PH_REQUIRE(points_dev && edges_dev && out_dev && B > 0 && I >= 0 && N > 0 && E > 0 && img_h > 0 && img_w > 0 && stride > 0, "ph_render_pafs: bad arguments");
+  const int h = (img_h + stride - 1) / stride, w = (img_w + stride - 1) / stride;
+  const size_t total = (size_t)B * E * h * w;
+  hipLaunchKernelGGL(render_pafs_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 16384)), dim3(256), 0, static_cast<hipStream_t>(stream), points_dev,
+                     edges_dev, B, I, N, E, h, w, stride, sigma, out_dev);
+  PH_HIP_CHECK(hipGetLastError());
+  return PH_OK;
+}
 
 int ph_adam_step(float* params_dev, const float* grads_dev, float* exp_avg_dev, float* exp_avg_sq_dev, float* max_exp_avg_sq_dev, int64_t n, float lr,
                  float beta1, float beta2, float eps, int32_t step, float grad_scale, void* stream) {

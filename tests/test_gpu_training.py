@@ -132,3 +132,36 @@ def test_data_parallel_gradient_equivalence():
     acc /= 2
     scale = float(full.abs().max())
     assert float((acc - full).abs().max()) <= 1e-5 * scale
+
+
+def test_target_rendering_matches_reference_and_oracle():
+    """ph_render_confmaps / ph_render_pafs vs the reference fixture (tests/golden/targets.npz) and, on a
+    larger random case with many instances, vs the oracle.  fp32 tolerance 2e-6 abs (expf vs torch.exp)."""
+    import json
+
+    from sleap_nn_amd.data.targets import generate_multiconfmaps, generate_pafs
+    from tests import _golden as G
+
+    g = G.load("targets.npz")
+    meta = json.loads(str(g["meta_json"]))
+    pts = torch.from_numpy(g["points"]).cuda()
+    for stride, sigma in meta["confmaps"]:
+        out = generate_multiconfmaps(pts, meta["hw"], sigma=sigma, output_stride=stride).cpu().numpy()
+        np.testing.assert_allclose(out, g[f"confmaps_s{stride}"], rtol=0, atol=2e-6)
+    for stride, sigma in meta["pafs"]:
+        out = generate_pafs(pts, meta["hw"], sigma=sigma, output_stride=stride, edge_inds=meta["edges"]).cpu().numpy()
+        np.testing.assert_allclose(out, g[f"pafs_s{stride}"], rtol=0, atol=5e-6)
+
+    gen = torch.Generator().manual_seed(5)
+    big = torch.rand((4, 9, 13, 2), generator=gen) * torch.tensor([300.0, 260.0]) - 20.0
+    big[torch.rand((4, 9, 13), generator=gen) < 0.15] = float("nan")
+    edges = [(i, i + 1) for i in range(12)]
+    hw = (250, 282)  # not a multiple of the stride: grid = ceil(size / stride)
+    cm = generate_multiconfmaps(big.cuda(), hw, sigma=2.0, output_stride=4).cpu()
+    torch.testing.assert_close(cm, O.make_multiconfmaps(big, hw, 2.0, 4), rtol=0, atol=2e-6)
+    pf = generate_pafs(big.cuda(), hw, sigma=20.0, output_stride=8, edge_inds=edges).cpu()
+    ref = torch.stack([O.make_pafs_sample(big[b], edges, hw, 20.0, 8) for b in range(4)])
+    torch.testing.assert_close(pf, ref, rtol=0, atol=1e-5)
+    # centroid form (B, I, 2) -> one channel
+    cen = generate_multiconfmaps(big[:, :, 0].cuda(), hw, sigma=2.0, output_stride=2).cpu()
+    torch.testing.assert_close(cen, O.make_multiconfmaps(big[:, :, :1], hw, 2.0, 2), rtol=0, atol=2e-6)
