@@ -64,14 +64,25 @@ enum ph_op_kind {
   PH_OP_UPSAMPLE = 4,   /* bilinear x2, align_corners=False (encoder_decoder.py:431-435)                */
   PH_OP_CONVT = 5,      /* ConvTranspose2d(k3,s2,p1,op1) + bias (+ReLU) (encoder_decoder.py:439-461)    */
   PH_OP_HEAD = 6,       /* 1x1 conv + bias (+sigmoid) -> NCHW fp32 output #out_index (heads.py:58-67)   */
-  PH_OP_STEM = 7        /* fused first encoder block: image -> /255 -> conv3x3+ReLU (weight/bias) ->
+  PH_OP_STEM = 7,       /* fused first encoder block: image -> /255 -> conv3x3+ReLU (weight/bias) ->
                            conv3x3+ReLU (weight2/bias2, cout <= 16) -> [full-res NHWC slot dst, if >= 0]
                            -> 2x2 max pool -> NHWC slot dst2.  One launch, the two full-resolution
                            activations never touch HBM unless dst >= 0.                               */
+  /* ConvNeXt encoder (architectures/convnext.py:19-130; CNBlock / LayerNorm2d are torchvision's) */
+  PH_OP_PATCH_STEM = 8, /* image -> /255 -> Conv2d(k = ksize, stride = cmid, padding 1) + bias -> NHWC slot
+                           (convnext.py:73-84; the LayerNorm2d that follows is a PH_OP_LAYERNORM)       */
+  PH_OP_DWCONV = 9,     /* depthwise 7x7 "same" conv + bias, weight (C,1,7,7)  (CNBlock.block[0])       */
+  PH_OP_LAYERNORM = 10, /* LayerNorm over channels, eps 1e-6, weight/bias = affine (LayerNorm2d, block[2]) */
+  PH_OP_LINEAR = 11,    /* per-pixel Linear(cin0 -> cout), weight (cout, cin0) + bias; PH_FLAG_GELU: erf-GELU
+                           epilogue (block[3..4]); PH_FLAG_SCALE_RESIDUAL: dst = weight2[c] * (acc + bias) +
+                           src1 (block[5], layer_scale, residual add)                                    */
+  PH_OP_PATCH_CONV = 12 /* Conv2d(k2, s2) + bias, weight (cout, cin0, 2, 2)  (convnext.py:101-110)      */
 };
 
 #define PH_FLAG_RELU 1
 #define PH_FLAG_SIGMOID 2
+#define PH_FLAG_GELU 4
+#define PH_FLAG_SCALE_RESIDUAL 8
 
 typedef struct ph_op_desc {
   int32_t kind;      /* enum ph_op_kind                                              */
@@ -87,9 +98,9 @@ typedef struct ph_op_desc {
   int32_t bias;      /* index into the weights[] array, or -1                        */
   int32_t out_index; /* PH_OP_HEAD: which output pointer receives the result         */
   int32_t dst2;      /* PH_OP_STEM: pooled output slot; PH_OP_CONV (ReLU): optional fused 2x2 max-pool slot, -1 = none */
-  int32_t weight2;   /* PH_OP_STEM: second conv weight index                         */
+  int32_t weight2;   /* PH_OP_STEM: second conv weight index; PH_OP_LINEAR: layer_scale index */
   int32_t bias2;     /* PH_OP_STEM: second conv bias index                           */
-  int32_t cmid;      /* PH_OP_STEM: channels between the two convs (<= 16)           */
+  int32_t cmid;      /* PH_OP_STEM: channels between the two convs (<= 16); PH_OP_PATCH_STEM: stride */
 } ph_op_desc;
 
 typedef struct ph_model ph_model;

@@ -159,6 +159,230 @@ def init_state(bb: dict, head_cfgs: dict, model_type: str, seed: int = 1234, hea
     return sd
 
 
+CONVNEXT_ARCHS = {
+    # convnext.py:187-192
+    "tiny": {"depths": [3, 3, 9, 3], "channels": [96, 192, 384, 768]},
+    "small": {"depths": [3, 3, 27, 3], "channels": [96, 192, 384, 768]},
+    "base": {"depths": [3, 3, 27, 3], "channels": [128, 256, 512, 1024]},
+    "large": {"depths": [3, 3, 27, 3], "channels": [192, 384, 768, 1536]},
+}
+LN_EPS = 1e-6  # convnext.py:67 (LayerNorm2d) and torchvision CNBlock's nn.LayerNorm
+
+
+def convnext_plan(bb: dict) -> dict:
+    """Layer enumeration of ConvNextWrapper with checkpoint-compatible names.
+
+    convnext.py:19-130 (encoder: ``features`` = [stem, stage0, down0, stage1, down1, stage2, down2,
+    stage3]), :133-361 (wrapper: extra max pool, middle expand/contract, Decoder with
+    ``encoder_channels``); encoder_decoder.py:634-703 (decoder filters).  CNBlock / LayerNorm2d /
+    Conv2dNormActivation are torchvision's (not vendored by the reference, torchvision is absent from
+    this image): restated from the public definition -- dwconv7x7(groups=C) -> LayerNorm(C) ->
+    Linear(C,4C) -> GELU -> Linear(4C,C), times ``layer_scale``, plus the input.  PARITY OF THE
+    CNBlock ARITHMETIC IS UNPINNED (self-consistent only); the wrapper's middle/decoder half is pinned
+    against the reference's own Decoder / SimpleConvBlock.
+    """
+    mt = bb.get("model_type", None)
+    arch = CONVNEXT_ARCHS[mt] if mt in CONVNEXT_ARCHS else (bb.get("arch", None) or CONVNEXT_ARCHS["tiny"])
+    depths, channels = [int(d) for d in arch["depths"]], [int(c) for c in arch["channels"]]
+    cin = int(bb.get("in_channels", 1))
+    k = int(bb.get("kernel_size", 3))
+    sk = int(bb.get("stem_patch_kernel", 4))
+    ss = int(bb.get("stem_patch_stride", 2))
+    rate = bb.get("filters_rate", 2)
+    cpb = int(bb.get("convs_per_block", 2))
+    interp = bool(bb.get("up_interpolate", True))
+    contraction = bool(bb.get("block_contraction", False))
+    os_ = int(bb["output_stride"])
+    assert not contraction, "oracle covers block_contraction=False"
+    max_stride = ss * 8 * 2
+    up = int(math.log2(max_stride / (ss * os_))) + int(math.log2(ss))
+    down = len(channels) - 1
+    pfx = "backbone.enc.features"
+    enc = [{"kind": "stem", "name": f"{pfx}.0", "cin": cin, "cout": channels[0], "k": sk, "stride": ss}]
+    fi = 1
+    for si, (d, c) in enumerate(zip(depths, channels)):
+        enc.append({"kind": "stage", "blocks": [f"{pfx}.{fi}.{j}" for j in range(d)], "c": c})
+        fi += 1
+        if si + 1 < len(channels):
+            enc.append({"kind": "down", "name": f"{pfx}.{fi}", "cin": c, "cout": channels[si + 1]})
+            fi += 1
+    last = channels[-1]
+    fmid = int(last * rate)
+    mid = []
+    mb = 0
+    if cpb > 1:
+        mid.append([(f"backbone.middle_blocks.{mb}.blocks.convnext_middle_expand_conv{i}", last if i == 0 else fmid, fmid) for i in range(cpb - 1)])
+        mb += 1
+    mid.append([(f"backbone.middle_blocks.{mb}.blocks.convnext_middle_contract_conv0", fmid, fmid)])
+    dec = []
+    cur = max_stride
+    stride_to_filters = {cur: fmid}
+    pin = fmid
+    enc_ch = channels[::-1]
+    for b in range(up):
+        fout = int(channels[0] * (rate ** max(0, down + 1 - 1 - b)))
+        nxt = cur // 2
+        name = f"backbone.dec.decoder_stack.{b}.blocks.dec{b}_s{cur}_to_s{nxt}"
+        concat = not (b >= down + 1)  # encoder_decoder.py:659 (stem_blocks = 1)
+        skip_c = enc_ch[b] if b < len(enc_ch) else fout
+        blk = {"interp": interp, "skip_c": skip_c if concat else 0, "convs": [], "stride": nxt, "concat": concat}
+        nconv = 2 if concat else 1  # convnext.py:288-301 does not forward convs_per_block: Decoder default 2
+        if not interp:
+            blk["trans"] = (name + "_trans_conv", pin, fout)
+            first_in = fout + (skip_c if concat else 0)
+        else:
+            first_in = pin + (skip_c if concat else 0)
+        for i in range(nconv):
+            blk["convs"].append((name + f"_refine_conv{i}", first_in if i == 0 else fout, fout))
+        dec.append(blk)
+        stride_to_filters[nxt] = fout
+        pin = fout
+        cur = nxt
+    return {"enc": enc, "mid": mid, "dec": dec, "stride_to_filters": stride_to_filters, "k": k, "channels": channels, "depths": depths, "max_stride": max_stride}
+
+
+def init_state_convnext(bb: dict, head_cfgs: dict, model_type: str, seed: int = 1234, head_scale: float = 0.05, layer_scale: float = 1e-6,
+                        randomize_affine: bool = False) -> Dict[str, torch.Tensor]:
+    """Synthetic ConvNeXt weights: xavier-uniform Conv2d/Linear weights and zero biases
+    (training/utils.py:72-78), LayerNorm weight 1 / bias 0, ``layer_scale`` constant (torchvision
+    default 1e-6 via convnext.py:46).  ``randomize_affine`` perturbs biases / LayerNorm affine / layer
+    scale so that parity tests exercise every parameter."""
+    plan = convnext_plan(bb)
+    g = torch.Generator().manual_seed(seed)
+    sd: Dict[str, torch.Tensor] = {}
+
+    def xavier(shape, fan_in, fan_out):
+        bound = math.sqrt(6.0 / (fan_in + fan_out))
+        return (torch.rand(shape, generator=g) * 2 - 1) * bound
+
+    def vec(n, base, spread):
+        return torch.full((n,), float(base)) + ((torch.rand(n, generator=g) * 2 - 1) * spread if randomize_affine else 0.0)
+
+    for e in plan["enc"]:
+        if e["kind"] == "stem":
+            n, ci, co, kk = e["name"], e["cin"], e["cout"], e["k"]
+            sd[n + ".0.weight"] = xavier((co, ci, kk, kk), ci * kk * kk, co * kk * kk)
+            sd[n + ".0.bias"] = vec(co, 0.0, 0.1)
+            sd[n + ".1.weight"] = vec(co, 1.0, 0.3)
+            sd[n + ".1.bias"] = vec(co, 0.0, 0.1)
+        elif e["kind"] == "stage":
+            c = e["c"]
+            for n in e["blocks"]:
+                sd[n + ".layer_scale"] = (vec(c, layer_scale, 0.5 * layer_scale)).reshape(c, 1, 1)
+                sd[n + ".block.0.weight"] = xavier((c, 1, 7, 7), 49, c * 49)
+                sd[n + ".block.0.bias"] = vec(c, 0.0, 0.1)
+                sd[n + ".block.2.weight"] = vec(c, 1.0, 0.3)
+                sd[n + ".block.2.bias"] = vec(c, 0.0, 0.1)
+                sd[n + ".block.3.weight"] = xavier((4 * c, c), c, 4 * c)
+                sd[n + ".block.3.bias"] = vec(4 * c, 0.0, 0.1)
+                sd[n + ".block.5.weight"] = xavier((c, 4 * c), 4 * c, c)
+                sd[n + ".block.5.bias"] = vec(c, 0.0, 0.1)
+        else:
+            n, ci, co = e["name"], e["cin"], e["cout"]
+            sd[n + ".0.weight"] = vec(ci, 1.0, 0.3)
+            sd[n + ".0.bias"] = vec(ci, 0.0, 0.1)
+            sd[n + ".1.weight"] = xavier((co, ci, 2, 2), ci * 4, co * 4)
+            sd[n + ".1.bias"] = vec(co, 0.0, 0.1)
+    k = plan["k"]
+    for convs in plan["mid"]:
+        for n, ci, co in convs:
+            sd[n + ".weight"] = xavier((co, ci, k, k), ci * k * k, co * k * k)
+            sd[n + ".bias"] = vec(co, 0.0, 0.05)
+    for blk in plan["dec"]:
+        if not blk["interp"]:
+            n, ci, co = blk["trans"]
+            sd[n + ".weight"] = xavier((ci, co, 3, 3), co * 9, ci * 9)
+            sd[n + ".bias"] = vec(co, 0.0, 0.05)
+        for n, ci, co in blk["convs"]:
+            sd[n + ".weight"] = xavier((co, ci, k, k), ci * k * k, co * k * k)
+            sd[n + ".bias"] = vec(co, 0.0, 0.05)
+    for i, (hname, key) in enumerate(HEAD_ORDER[model_type]):
+        hc = head_cfgs[key]
+        ci = plan["stride_to_filters"][hc["output_stride"]]
+        co = head_channels(hname, hc)
+        sd[f"head_layers.{i}.{hname}.0.weight"] = xavier((co, ci, 1, 1), ci, co) * head_scale
+        sd[f"head_layers.{i}.{hname}.0.bias"] = torch.zeros(co)
+    return sd
+
+
+def layer_norm_2d(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """torchvision LayerNorm2d: permute to NHWC, F.layer_norm over C, permute back."""
+    return F.layer_norm(x.permute(0, 2, 3, 1), (x.shape[1],), w, b, LN_EPS).permute(0, 3, 1, 2)
+
+
+def cn_block(sd: Dict[str, torch.Tensor], n: str, x: torch.Tensor) -> torch.Tensor:
+    """torchvision CNBlock.forward (stochastic depth p = 0: convnext.py:45 default, identity)."""
+    c = x.shape[1]
+    y = F.conv2d(x, sd[n + ".block.0.weight"], sd[n + ".block.0.bias"], padding=3, groups=c)
+    y = y.permute(0, 2, 3, 1)
+    y = F.layer_norm(y, (c,), sd[n + ".block.2.weight"], sd[n + ".block.2.bias"], LN_EPS)
+    y = F.linear(y, sd[n + ".block.3.weight"], sd[n + ".block.3.bias"])
+    y = F.gelu(y)
+    y = F.linear(y, sd[n + ".block.5.weight"], sd[n + ".block.5.bias"])
+    y = y.permute(0, 3, 1, 2)
+    return sd[n + ".layer_scale"] * y + x
+
+
+def decoder_forward(sd, plan: dict, x: torch.Tensor, feats: List[torch.Tensor], collect: Optional[dict] = None):
+    """encoder_decoder.py:522-558,705-730 (shared by the UNet and ConvNeXt wrappers)."""
+    pad = plan["k"] // 2
+    outs, strides = [], []
+    for i, blk in enumerate(plan["dec"]):
+        if blk["interp"]:
+            x = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False)
+        else:
+            n, _, _ = blk["trans"]
+            x = F.relu(F.conv_transpose2d(x, sd[n + ".weight"], sd[n + ".bias"], stride=2, padding=1, output_padding=1))
+            if collect is not None:
+                collect[n] = x
+        if i < len(feats) and blk.get("concat", True):
+            skf = feats[i]
+            if x.shape[-2:] != skf.shape[-2:]:
+                x = F.interpolate(x, size=skf.shape[-2:], mode="bilinear", align_corners=False)
+            x = torch.cat((skf, x), dim=1)
+        for n, _, _ in blk["convs"]:
+            x = F.relu(F.conv2d(x, sd[n + ".weight"], sd[n + ".bias"], padding=pad))
+            if collect is not None:
+                collect[n] = x
+        outs.append(x)
+        strides.append(blk["stride"])
+    return outs, strides
+
+
+def convnext_forward(sd: Dict[str, torch.Tensor], bb: dict, x: torch.Tensor, collect: Optional[dict] = None) -> dict:
+    """ConvNextWrapper.forward (convnext.py:334-361) over ConvNeXtEncoder._forward_impl (:112-117)."""
+    plan = convnext_plan(bb)
+    pad = plan["k"] // 2
+    enc_out = []
+    for e in plan["enc"]:
+        if e["kind"] == "stem":
+            n = e["name"]
+            x = F.conv2d(x, sd[n + ".0.weight"], sd[n + ".0.bias"], stride=e["stride"], padding=1)
+            x = layer_norm_2d(x, sd[n + ".1.weight"], sd[n + ".1.bias"])
+        elif e["kind"] == "stage":
+            for n in e["blocks"]:
+                x = cn_block(sd, n, x)
+                if collect is not None:
+                    collect[n] = x
+        else:
+            n = e["name"]
+            x = layer_norm_2d(x, sd[n + ".0.weight"], sd[n + ".0.bias"])
+            x = F.conv2d(x, sd[n + ".1.weight"], sd[n + ".1.bias"], stride=2)
+        if collect is not None and e["kind"] != "stage":
+            collect[e["name"]] = x
+        enc_out.append(x)
+    feats = enc_out[::2][::-1]
+    x = same_pool2(enc_out[-1])
+    for convs in plan["mid"]:
+        for n, _, _ in convs:
+            x = F.relu(F.conv2d(x, sd[n + ".weight"], sd[n + ".bias"], padding=pad))
+            if collect is not None:
+                collect[n] = x
+    middle = x
+    outs, strides = decoder_forward(sd, plan, x, feats, collect)
+    return {"outputs": outs, "strides": strides, "middle_output": middle}
+
+
 def normalize_input(x: torch.Tensor) -> torch.Tensor:
     """data/normalization.py:7-35 + the n_samples squeeze of lightning_modules.py:1840-1848."""
     if x.dim() == 5:
@@ -225,7 +449,7 @@ def unet_forward(sd: Dict[str, torch.Tensor], bb: dict, x: torch.Tensor, collect
     return {"outputs": outs, "strides": strides, "middle_output": middle}
 
 
-def model_forward(sd, bb: dict, head_cfgs: dict, model_type: str, image: torch.Tensor, collect: Optional[dict] = None) -> Dict[str, torch.Tensor]:
+def model_forward(sd, bb: dict, head_cfgs: dict, model_type: str, image: torch.Tensor, collect: Optional[dict] = None, backbone: str = "unet") -> Dict[str, torch.Tensor]:
     """model.py:237-261 with the LightningModule forward's normalisation in front."""
     x = normalize_input(image)
     cin = int(bb["in_channels"])
@@ -236,7 +460,7 @@ def model_forward(sd, bb: dict, head_cfgs: dict, model_type: str, image: torch.T
             # torchvision rgb_to_grayscale weights
             r, g, b = x.unbind(dim=-3)
             x = (0.2989 * r + 0.587 * g + 0.114 * b).unsqueeze(-3)
-    bo = unet_forward(sd, bb, x, collect)
+    bo = convnext_forward(sd, bb, x, collect) if backbone == "convnext" else unet_forward(sd, bb, x, collect)
     out = {}
     for i, (hname, key) in enumerate(HEAD_ORDER[model_type]):
         hc = head_cfgs[key]

@@ -417,6 +417,63 @@ def targets_fixture():
     save("targets.npz", **arrs)
 
 
+def convnext_decoder_fixture():
+    """The importable half of ConvNextWrapper: the reference's own MaxPool2dWithSamePadding ->
+    middle SimpleConvBlocks -> Decoder(encoder_channels=...) constructed exactly as
+    convnext.py:216-301 does, on random encoder features.  (The encoder half needs torchvision,
+    which this image does not have -- see oracle/cpu_ref.py:convnext_plan.)"""
+    from sleap_nn.architectures.common import MaxPool2dWithSamePadding
+    from sleap_nn.architectures.encoder_decoder import Decoder, SimpleConvBlock
+
+    arrs = {}
+    cases = {
+        "a": dict(channels=[8, 16, 32, 64], stem_stride=2, output_stride=2, rate=2, cpb=2, hw=(64, 96)),
+        "b": dict(channels=[8, 16, 32, 64], stem_stride=4, output_stride=1, rate=2, cpb=2, hw=(64, 64)),
+        "c": dict(channels=[6, 12, 24, 48], stem_stride=2, output_stride=4, rate=1.5, cpb=3, hw=(64, 64)),
+    }
+    for tag, c in cases.items():
+        torch.manual_seed(31 + ord(tag))
+        ch, ss, os_ = c["channels"], c["stem_stride"], c["output_stride"]
+        last = ch[-1]
+        max_stride = ss * 8 * 2
+        up_blocks = int(np.log2(max_stride / (ss * os_)).astype(int) + np.log2(ss).astype(int))
+        mods = torch.nn.ModuleDict()
+        middle = torch.nn.ModuleList()
+        if c["cpb"] > 1:
+            middle.append(SimpleConvBlock(in_channels=last, pool=False, pool_before_convs=False, pooling_stride=2, num_convs=c["cpb"] - 1,
+                                          filters=int(last * c["rate"]), kernel_size=3, use_bias=True, batch_norm=False, activation="relu",
+                                          prefix="convnext_middle_expand"))
+        middle.append(SimpleConvBlock(in_channels=int(last * c["rate"]), pool=False, pool_before_convs=False, pooling_stride=2, num_convs=1,
+                                      filters=int(last * c["rate"]), kernel_size=3, use_bias=True, batch_norm=False, activation="relu",
+                                      prefix="convnext_middle_contract"))
+        # convnext.py:288-301: convs_per_block is NOT forwarded, the Decoder keeps its default of 2
+        dec = Decoder(x_in_shape=int(last * c["rate"]), current_stride=max_stride, filters=ch[0], up_blocks=up_blocks, down_blocks=len(ch) - 1,
+                      filters_rate=c["rate"], kernel_size=3, stem_blocks=1, block_contraction=False, output_stride=os_, up_interpolate=True,
+                      encoder_channels=ch[::-1])
+        mods["middle_blocks"] = middle
+        mods["dec"] = dec
+        pool = MaxPool2dWithSamePadding(kernel_size=2, stride=2, padding="same")
+        H, W = c["hw"]
+        feats = [torch.randn(2, ch[i], H // (ss * 2**i), W // (ss * 2**i)) for i in range(4)]  # enc_output[::2]
+        x_last = torch.randn(2, last, H // (ss * 8), W // (ss * 8))  # enc_output[-1]
+        with torch.no_grad():
+            x = pool(x_last)
+            for blk in middle:
+                x = blk(x)
+            out = dec(x, feats[::-1])
+        for k, v in mods.state_dict().items():
+            arrs[f"{tag}/w/backbone.{k}"] = _np(v)
+        for i, f in enumerate(feats):
+            arrs[f"{tag}/feat{i}"] = _np(f)
+        arrs[f"{tag}/x_last"] = _np(x_last)
+        arrs[f"{tag}/middle"] = _np(x)
+        for i, o in enumerate(out["outputs"]):
+            arrs[f"{tag}/out{i}"] = _np(o)
+        arrs[f"{tag}/meta_json"] = np.array(json.dumps({**c, "strides": [int(v) for v in out["strides"]],
+                                                        "stride_to_filters": {int(k): int(v) for k, v in dec.stride_to_filters.items()}}))
+    save("convnext_decoder.npz", **arrs)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     if not only or "core" in only:
@@ -427,3 +484,5 @@ if __name__ == "__main__":
         multiclass_fixture()
     if not only or "targets" in only:
         targets_fixture()
+    if not only or "convnext" in only:
+        convnext_decoder_fixture()

@@ -15,17 +15,20 @@ import torch
 
 from sleap_nn_amd import _lib as L
 from sleap_nn_amd.architectures.heads import ClassMapsHead, Head, get_head
+from sleap_nn_amd.architectures.convnext import ConvNextWrapper
 from sleap_nn_amd.architectures.unet import OpSpec, UNet
 from sleap_nn_amd.utils import cfg_get, cfg_keys
 
 
 def get_backbone(backbone: str, backbone_config):
-    """architectures/model.py:36-67.  Only ``unet`` is built natively so far."""
+    """architectures/model.py:36-67.  ``unet`` and ``convnext`` are built natively."""
     if backbone == "unet":
         return UNet.from_config(backbone_config)
-    if backbone in ("convnext", "swint", "pretrained"):
+    if backbone == "convnext":
+        return ConvNextWrapper.from_config(backbone_config)
+    if backbone in ("swint", "pretrained"):
         raise NotImplementedError(f"backbone '{backbone}' is not implemented on the MI355X path yet")
-    raise KeyError(f"Unsupported backbone: {backbone}. Supported backbones are: unet")
+    raise KeyError(f"Unsupported backbone: {backbone}. Supported backbones are: unet, convnext")
 
 
 class Model:
@@ -307,19 +310,27 @@ class Model:
                 hw[op.dst2] = (ph, pw)
                 continue
             oh, ow = h, w
+            if op.kind == L.OP_PATCH_STEM:
+                oh, ow = (h + 2 - op.ksize) // op.cmid + 1, (w + 2 - op.ksize) // op.cmid + 1
+            elif op.kind == L.OP_PATCH_CONV:
+                oh, ow = h // 2, w // 2
             if op.kind == L.OP_POOL:
                 oh, ow = (h + 1) // 2, (w + 1) // 2
             elif op.kind in (L.OP_UPSAMPLE, L.OP_CONVT):
                 oh, ow = 2 * h, 2 * w
-            cin = op.cin0 + op.cin1
+            cin = op.cin0 + (op.cin1 if op.kind != L.OP_LINEAR else 0)
             cout = op.cout if op.kind not in (L.OP_POOL, L.OP_UPSAMPLE) else op.cin0
             flops = 0.0
             if op.kind in (L.OP_CONV, L.OP_INPUT_CONV):
                 flops = 2.0 * cin * cout * op.ksize * op.ksize * oh * ow * batch
             elif op.kind == L.OP_CONVT:
                 flops = 2.0 * cin * cout * 9 * h * w * batch
-            elif op.kind == L.OP_HEAD:
+            elif op.kind in (L.OP_HEAD, L.OP_LINEAR):
                 flops = 2.0 * cin * cout * oh * ow * batch
+            elif op.kind in (L.OP_PATCH_STEM, L.OP_PATCH_CONV):
+                flops = 2.0 * cin * cout * op.ksize * op.ksize * oh * ow * batch
+            elif op.kind == L.OP_DWCONV:
+                flops = 2.0 * cout * 49 * oh * ow * batch
             in_bytes = (1 if op.src0 < 0 else 4) * op.cin0 * h * w * batch + 4 * op.cin1 * h * w * batch
             out_bytes = 4 * cout * oh * ow * batch
             rows.append({"label": op.label.split(".")[-1], "kind": op.kind, "flops": flops, "bytes": float(in_bytes + out_bytes)})

@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstring>
 #include <mutex>
+#include <type_traits>
 #include <vector>
 
 #include "model_internal.h"
@@ -47,12 +48,12 @@ int upload_ints(ph_model* m, const std::vector<int>& host, int** dev) {
 }
 
 // Upload a packed value array together with its gather map.  `packed_idx` is the SAME packing
-// applied to an array holding (canonical index + 1) as floats (exact below 2^24 parameters).
-static int upload_packed(ph_model* m, const std::vector<float>& packed_val, const std::vector<float>& packed_idx, float** dev) {
+// applied to an array holding (canonical index + 1) as doubles (exact for any arena size).
+static int upload_packed(ph_model* m, const std::vector<float>& packed_val, const std::vector<double>& packed_idx, float** dev) {
   int rc = upload(m, packed_val, dev);
   if (rc != PH_OK) return rc;
   std::vector<int> map(packed_idx.size());
-  for (size_t i = 0; i < packed_idx.size(); ++i) map[i] = (int)packed_idx[i] - 1;
+  for (size_t i = 0; i < packed_idx.size(); ++i) map[i] = (int)((int64_t)packed_idx[i] - 1);
   PackedBuffer pb;
   pb.dst = *dev;
   pb.n = packed_val.size();
@@ -62,10 +63,21 @@ static int upload_packed(ph_model* m, const std::vector<float>& packed_val, cons
   return PH_OK;
 }
 
+// Run one packing routine twice -- on the weight values and on their canonical indices -- and upload both.
+template <typename PackFn>
+static int pack_upload(ph_model* m, PackFn&& pack, const float* values, const std::vector<double>& indices, float** dev) {
+  std::vector<float> v;
+  std::vector<double> x;
+  pack(values, v);
+  pack(indices.data(), x);
+  return upload_packed(m, v, x, dev);
+}
+
 // OIHW (cout, cin_total, 3, 3) -> the conv weight of the data gradient wrt channels
 // [ci_off, ci_off + cin_part): Wd[o = ci][i = co][ky][kx] = W[co][ci_off + ci][2-ky][2-kx].
-static void dgrad_weight(const float* w, int cout, int cin_total, int ci_off, int cin_part, std::vector<float>& out) {
-  out.assign((size_t)cin_part * cout * 9, 0.f);
+template <typename T>
+static void dgrad_weight(const T* w, int cout, int cin_total, int ci_off, int cin_part, std::vector<T>& out) {
+  out.assign((size_t)cin_part * cout * 9, T(0));
   for (int ci = 0; ci < cin_part; ++ci)
     for (int co = 0; co < cout; ++co)
       for (int ky = 0; ky < 3; ++ky)
@@ -75,13 +87,14 @@ static void dgrad_weight(const float* w, int cout, int cin_total, int ci_off, in
 
 // Conv2d OIHW (cout, cin0+cin1, 3, 3) or ConvTranspose2d IOHW (cin0, cout, 3, 3) ->
 // [n_tile][chunk][tap][bn][16] with channel/row padding zeros.
-void pack_conv(const float* w, bool transposed, int cin0, int cin1, int cout, int bn, std::vector<float>& out) {
+template <typename T>
+static void pack_conv(const T* w, bool transposed, int cin0, int cin1, int cout, int bn, std::vector<T>& out) {
   const int c0p = pad16(cin0), c1p = cin1 > 0 ? pad16(cin1) : 0;
   const int coutp = pad16(cout);
   const int ntiles = (coutp + bn - 1) / bn;
   const int ch0 = c0p / 16, ch1 = c1p / 16, nch = ch0 + ch1;
   const int cin = cin0 + cin1;
-  out.assign((size_t)ntiles * nch * 9 * bn * 16, 0.f);
+  out.assign((size_t)ntiles * nch * 9 * bn * 16, T(0));
   for (int nt = 0; nt < ntiles; ++nt)
     for (int ch = 0; ch < nch; ++ch)
       for (int tap = 0; tap < 9; ++tap) {
@@ -100,7 +113,7 @@ void pack_conv(const float* w, bool transposed, int cin0, int cin1, int cout, in
               if (c >= cin1) continue;
               ci = cin0 + c;
             }
-            float v;
+            T v;
             if (!transposed)
               v = w[(((size_t)co * cin + ci) * 3 + ky) * 3 + kx];
             else  // flipped, in/out swapped: Wc[co][ci][ky][kx] = Wt[ci][co][2-ky][2-kx]
@@ -113,7 +126,8 @@ void pack_conv(const float* w, bool transposed, int cin0, int cin1, int cout, in
 
 // [n_tile][chunk][tap][bn][16] -> [n_tile][chunk][piece = (tap*bn + n)/16][quad q][row r = (tap*bn+n)%16][4]
 // (the order in which one LDS-DMA wave-instruction writes a 1-KiB piece, see conv3x3_mfma_dma_kernel)
-void repack_dma(const std::vector<float>& in, int bn, std::vector<float>& out) {
+template <typename T>
+static void repack_dma(const std::vector<T>& in, int bn, std::vector<T>& out) {
   out.resize(in.size());
   const size_t panel = (size_t)9 * bn * 16;
   for (size_t base = 0; base < in.size(); base += panel)
@@ -121,6 +135,32 @@ void repack_dma(const std::vector<float>& in, int bn, std::vector<float>& out) {
       for (int k = 0; k < 16; ++k) {
         const int piece = row >> 4, r = row & 15, q = k >> 2, e = k & 3;
         out[base + (size_t)piece * 256 + q * 64 + r * 4 + e] = in[base + (size_t)row * 16 + k];
+      }
+}
+
+// Row-GEMM weights (gemm_mfma_dma_kernel): Linear (cout, cin) [segs = 1] or Conv2d k2 s2 (cout, cin, 2, 2)
+// [segs = 4, segment = dy * 2 + dx] -> [n_tile][chunk of 32][half][piece = n / 16][quad][row n % 16][4],
+// K index = segment * Cp + channel, zero-padded.
+template <typename T>
+static void pack_gemm(const T* w, int cout, int cin, int segs, int bn, std::vector<T>& out) {
+  const int cp = pad16(cin), coutp = pad16(cout);
+  const int ntiles = (coutp + bn - 1) / bn;
+  const int hps = cp / 16, total_halves = segs * hps, nchunks = (total_halves + 1) / 2, bp = bn / 16;
+  out.assign((size_t)ntiles * nchunks * 2 * bp * 256, T(0));
+  for (int nt = 0; nt < ntiles; ++nt)
+    for (int ch = 0; ch < nchunks; ++ch)
+      for (int h = 0; h < 2; ++h) {
+        const int hc = 2 * ch + h;
+        if (hc >= total_halves) continue;
+        const int seg = hc / hps, c0 = (hc % hps) * 16;
+        for (int pb = 0; pb < bp; ++pb)
+          for (int q = 0; q < 4; ++q)
+            for (int r = 0; r < 16; ++r)
+              for (int e = 0; e < 4; ++e) {
+                const int co = nt * bn + pb * 16 + r, c = c0 + q * 4 + e;
+                if (co >= cout || c >= cin) continue;
+                out[((((size_t)nt * nchunks + ch) * 2 + h) * bp + pb) * 256 + q * 64 + r * 4 + e] = w[((size_t)co * cin + c) * segs + seg];
+              }
       }
 }
 
@@ -155,6 +195,20 @@ int build_plan(const ph_model* m, int B, int H, int W, Plan& plan) {
       continue;
     }
     int oh = h, ow = w;
+    if (d.kind == PH_OP_PATCH_STEM) {
+      PH_REQUIRE(d.src0 < 0, "patch stem must read the network input");
+      oh = (h + 2 - d.ksize) / d.cmid + 1;
+      ow = (w + 2 - d.ksize) / d.cmid + 1;
+      PH_REQUIRE(oh > 0 && ow > 0, "input %dx%d is too small for the %dx%d patch stem", h, w, d.ksize, d.ksize);
+    } else if (d.kind == PH_OP_PATCH_CONV) {
+      oh = h / 2;
+      ow = w / 2;
+      PH_REQUIRE(oh > 0 && ow > 0, "input of a 2x2/stride-2 convolution is smaller than 2x2");
+    } else if (d.kind == PH_OP_LINEAR && (d.flags & PH_FLAG_SCALE_RESIDUAL)) {
+      PH_REQUIRE(d.src1 >= 0 && d.src1 < m->n_slots && plan.slots[d.src1].offset >= 0, "residual slot %d is not written yet", d.src1);
+      const SlotShape& s1 = plan.slots[d.src1];
+      PH_REQUIRE(s1.h == h && s1.w == w && s1.c == d.cout, "residual shape mismatch");
+    }
     if (d.kind == PH_OP_POOL) {
       oh = (h + 1) / 2;
       ow = (w + 1) / 2;
@@ -224,7 +278,7 @@ ph_model* ph_model_create(const ph_op_desc* ops, int32_t n_ops, const float* con
     set_error("ph_model_create: empty program");
     return nullptr;
   }
-  if (prepare_kernels() != PH_OK) return nullptr;
+  if (prepare_kernels() != PH_OK || prepare_convnext_kernels() != PH_OK) return nullptr;
   ph_model* m = new ph_model();
   m->n_slots = n_slots;
   m->n_outputs = n_outputs;
@@ -249,70 +303,73 @@ ph_model* ph_model_create(const ph_op_desc* ops, int32_t n_ops, const float* con
     m->weight_offset[i] = m->n_params;
     m->n_params += weight_numel[i];
   }
-  if (m->n_params >= (int64_t)1 << 24) return (set_error("models with >= 2^24 parameters are not supported yet (gather maps are built through fp32)"), ph_model_destroy(m), nullptr);
+  if (m->n_params >= (int64_t)1 << 31) return (set_error("models with >= 2^31 parameters are not supported"), ph_model_destroy(m), nullptr);
   auto index_array = [&](int wi) {
-    std::vector<float> v((size_t)(wi >= 0 ? weight_numel[wi] : 0));
-    for (size_t k = 0; k < v.size(); ++k) v[k] = (float)(m->weight_offset[wi] + (int64_t)k + 1);
+    std::vector<double> v((size_t)(wi >= 0 ? weight_numel[wi] : 0));
+    for (size_t k = 0; k < v.size(); ++k) v[k] = (double)(m->weight_offset[wi] + (int64_t)k + 1);
     return v;
+  };
+  // zero-padded copy of a per-channel vector (bias, LayerNorm affine, layer scale)
+  auto pad_vec = [](size_t padded, int n) {
+    return [padded, n](const auto* src, auto& out) {
+      out.assign(padded, 0);
+      for (int k = 0; k < n; ++k) out[k] = src[k];
+    };
   };
   for (int i = 0; i < n_ops; ++i) {
     PackedOp op;
     op.d = ops[i];
     const ph_op_desc& d = op.d;
-    const bool has_w = d.kind == PH_OP_INPUT_CONV || d.kind == PH_OP_CONV || d.kind == PH_OP_CONVT || d.kind == PH_OP_HEAD;
+    auto widx_ok = [&](int k) { return k >= 0 && k < n_weights; };
     bool ok = true;
-    if (d.kind == PH_OP_STEM) {
-      if (d.ksize != 3 || d.cmid < 1 || d.cmid > 16 || d.cout < 1 || d.cout > 16 || (d.cin0 != 1 && d.cin0 != 3))
-        return fail("fused stem needs kernel 3, 1 or 3 input channels and <= 16 filters", i);
-      const int idx[4] = {d.weight, d.bias, d.weight2, d.bias2};
-      for (int k : idx)
-        if (k < 0 || k >= n_weights) return fail("weight index out of range", i);
-      if (weight_numel[d.weight] != (int64_t)d.cmid * d.cin0 * 9 || weight_numel[d.bias] != d.cmid ||
-          weight_numel[d.weight2] != (int64_t)d.cout * d.cmid * 9 || weight_numel[d.bias2] != d.cout)
-        return fail("stem weight size mismatch", i);
-      auto pack_stem = [&](const float* w0, const float* b0, const float* w1, const float* b1, std::vector<float>& p0, std::vector<float>& pb0,
-                           std::vector<float>& p1, std::vector<float>& pb1) {
-        p0.assign((size_t)9 * d.cin0 * 16, 0.f);
-        pb0.assign(16, 0.f);
-        p1.assign((size_t)9 * 16 * 16, 0.f);
-        pb1.assign(16, 0.f);
-        for (int co = 0; co < d.cmid; ++co)
-          for (int ci = 0; ci < d.cin0; ++ci)
-            for (int tap = 0; tap < 9; ++tap) p0[((size_t)tap * d.cin0 + ci) * 16 + co] = w0[((size_t)co * d.cin0 + ci) * 9 + tap];
-        for (int co = 0; co < d.cout; ++co)
-          for (int ci = 0; ci < d.cmid; ++ci)
-            for (int tap = 0; tap < 9; ++tap) p1[((size_t)tap * 16 + co) * 16 + ci] = w1[((size_t)co * d.cmid + ci) * 9 + tap];
-        std::memcpy(pb0.data(), b0, d.cmid * sizeof(float));
-        std::memcpy(pb1.data(), b1, d.cout * sizeof(float));
-      };
-      std::vector<float> v[4], x[4];
-      pack_stem(weights[d.weight], weights[d.bias], weights[d.weight2], weights[d.bias2], v[0], v[1], v[2], v[3]);
-      const std::vector<float> i0 = index_array(d.weight), i1 = index_array(d.bias), i2 = index_array(d.weight2), i3 = index_array(d.bias2);
-      pack_stem(i0.data(), i1.data(), i2.data(), i3.data(), x[0], x[1], x[2], x[3]);
-      ok = upload_packed(m, v[0], x[0], &op.w_dev) == PH_OK && upload_packed(m, v[1], x[1], &op.b_dev) == PH_OK &&
-           upload_packed(m, v[2], x[2], &op.w2_dev) == PH_OK && upload_packed(m, v[3], x[3], &op.b2_dev) == PH_OK;
-    } else if (has_w) {
-      if (d.weight < 0 || d.weight >= n_weights || d.bias >= n_weights) return fail("weight index out of range", i);
-      const int64_t wn = weight_numel[d.weight];
-      if (d.bias >= 0 && weight_numel[d.bias] != d.cout) return fail("bias size mismatch", i);
-      const std::vector<float> iw = index_array(d.weight), ib = index_array(d.bias);
-      const float* wsrc[2] = {weights[d.weight], iw.data()};
-      const float* bsrc[2] = {d.bias >= 0 ? weights[d.bias] : nullptr, d.bias >= 0 ? ib.data() : nullptr};
-      if (d.kind == PH_OP_CONV || d.kind == PH_OP_CONVT) {
+    switch (d.kind) {
+      case PH_OP_POOL:
+      case PH_OP_UPSAMPLE:
+        break;
+      case PH_OP_STEM: {
+        if (d.ksize != 3 || d.cmid < 1 || d.cmid > 16 || d.cout < 1 || d.cout > 16 || (d.cin0 != 1 && d.cin0 != 3))
+          return fail("fused stem needs kernel 3, 1 or 3 input channels and <= 16 filters", i);
+        if (!widx_ok(d.weight) || !widx_ok(d.bias) || !widx_ok(d.weight2) || !widx_ok(d.bias2)) return fail("weight index out of range", i);
+        if (weight_numel[d.weight] != (int64_t)d.cmid * d.cin0 * 9 || weight_numel[d.bias] != d.cmid ||
+            weight_numel[d.weight2] != (int64_t)d.cout * d.cmid * 9 || weight_numel[d.bias2] != d.cout)
+          return fail("stem weight size mismatch", i);
+        auto pack_w0 = [&](const auto* w0, auto& p0) {
+          p0.assign((size_t)9 * d.cin0 * 16, 0);
+          for (int co = 0; co < d.cmid; ++co)
+            for (int ci = 0; ci < d.cin0; ++ci)
+              for (int tap = 0; tap < 9; ++tap) p0[((size_t)tap * d.cin0 + ci) * 16 + co] = w0[((size_t)co * d.cin0 + ci) * 9 + tap];
+        };
+        auto pack_w1 = [&](const auto* w1, auto& p1) {
+          p1.assign((size_t)9 * 16 * 16, 0);
+          for (int co = 0; co < d.cout; ++co)
+            for (int ci = 0; ci < d.cmid; ++ci)
+              for (int tap = 0; tap < 9; ++tap) p1[((size_t)tap * 16 + co) * 16 + ci] = w1[((size_t)co * d.cmid + ci) * 9 + tap];
+        };
+        ok = pack_upload(m, pack_w0, weights[d.weight], index_array(d.weight), &op.w_dev) == PH_OK &&
+             pack_upload(m, pad_vec(16, d.cmid), weights[d.bias], index_array(d.bias), &op.b_dev) == PH_OK &&
+             pack_upload(m, pack_w1, weights[d.weight2], index_array(d.weight2), &op.w2_dev) == PH_OK &&
+             pack_upload(m, pad_vec(16, d.cout), weights[d.bias2], index_array(d.bias2), &op.b2_dev) == PH_OK;
+        break;
+      }
+      case PH_OP_CONV:
+      case PH_OP_CONVT: {
+        if (!widx_ok(d.weight) || !widx_ok(d.bias)) return fail("weight index out of range", i);
+        if (weight_numel[d.bias] != d.cout) return fail("bias size mismatch", i);
         if (d.ksize != 3) return fail("only kernel_size 3 is supported by the MFMA convolution", i);
         if (d.kind == PH_OP_CONVT && d.cin1 != 0) return fail("transposed conv takes one source", i);
-        if (wn != (int64_t)(d.cin0 + d.cin1) * d.cout * 9) return fail("weight size mismatch", i);
+        if (weight_numel[d.weight] != (int64_t)(d.cin0 + d.cin1) * d.cout * 9) return fail("weight size mismatch", i);
         const int coutp = pad16(d.cout);
         op.bn = choose_bn(coutp);
-        std::vector<float> pw[2], pd[2], pb[2];
-        for (int k = 0; k < 2; ++k) {
-          pack_conv(wsrc[k], d.kind == PH_OP_CONVT, d.cin0, d.cin1, d.cout, op.bn, pw[k]);
-          repack_dma(pw[k], op.bn, pd[k]);
-          pb[k].assign((size_t)((coutp + op.bn - 1) / op.bn) * op.bn, 0.f);
-          if (bsrc[k]) std::memcpy(pb[k].data(), bsrc[k], d.cout * sizeof(float));
-        }
-        ok = upload_packed(m, pw[0], pw[1], &op.w_dev) == PH_OK && upload_packed(m, pd[0], pd[1], &op.w_dma_dev) == PH_OK &&
-             upload_packed(m, pb[0], pb[1], &op.b_dev) == PH_OK;
+        const bool tr = d.kind == PH_OP_CONVT;
+        const std::vector<double> iw = index_array(d.weight), ib = index_array(d.bias);
+        auto pack_reg = [&](const auto* w, auto& out) { pack_conv(w, tr, d.cin0, d.cin1, d.cout, op.bn, out); };
+        auto pack_dma = [&](const auto* w, auto& out) {
+          std::remove_reference_t<decltype(out)> tmp;
+          pack_conv(w, tr, d.cin0, d.cin1, d.cout, op.bn, tmp);
+          repack_dma(tmp, op.bn, out);
+        };
+        ok = pack_upload(m, pack_reg, weights[d.weight], iw, &op.w_dev) == PH_OK && pack_upload(m, pack_dma, weights[d.weight], iw, &op.w_dma_dev) == PH_OK &&
+             pack_upload(m, pad_vec((size_t)((coutp + op.bn - 1) / op.bn) * op.bn, d.cout), weights[d.bias], ib, &op.b_dev) == PH_OK;
         if (ok && d.kind == PH_OP_CONV) {  // data-gradient weights (training)
           const int cin_total = d.cin0 + d.cin1;
           const int parts[2] = {d.cin0, d.cin1}, offs[2] = {0, d.cin0};
@@ -321,49 +378,104 @@ ph_model* ph_model_create(const ph_op_desc* ops, int32_t n_ops, const float* con
             if (parts[part] <= 0) continue;
             op.bn_d[part] = choose_bn(pad16(parts[part]));
             max_bn = std::max(max_bn, op.bn_d[part]);
-            std::vector<float> dw[2], pk[2], pkd[2];
-            for (int k = 0; k < 2; ++k) {
-              dgrad_weight(wsrc[k], d.cout, cin_total, offs[part], parts[part], dw[k]);
-              pack_conv(dw[k].data(), false, d.cout, 0, parts[part], op.bn_d[part], pk[k]);
-              repack_dma(pk[k], op.bn_d[part], pkd[k]);
-            }
-            ok = upload_packed(m, pk[0], pk[1], &op.wd_dev[part]) == PH_OK && upload_packed(m, pkd[0], pkd[1], &op.wd_dma_dev[part]) == PH_OK;
+            auto pack_d = [&](const auto* w, auto& out) {
+              std::remove_reference_t<decltype(out)> dw;
+              dgrad_weight(w, d.cout, cin_total, offs[part], parts[part], dw);
+              pack_conv(dw.data(), false, d.cout, 0, parts[part], op.bn_d[part], out);
+            };
+            auto pack_dd = [&](const auto* w, auto& out) {
+              std::remove_reference_t<decltype(out)> tmp;
+              pack_d(w, tmp);
+              repack_dma(tmp, op.bn_d[part], out);
+            };
+            ok = pack_upload(m, pack_d, weights[d.weight], iw, &op.wd_dev[part]) == PH_OK &&
+                 pack_upload(m, pack_dd, weights[d.weight], iw, &op.wd_dma_dev[part]) == PH_OK;
           }
           if (ok) {
             std::vector<float> zb((size_t)pad16(std::max(d.cin0, d.cin1)) + max_bn, 0.f);
             ok = upload(m, zb, &op.zero_bias_dev) == PH_OK;
           }
         }
-      } else if (d.kind == PH_OP_INPUT_CONV) {
-        if (d.ksize != 3) return fail("only kernel_size 3 is supported", i);
-        if (wn != (int64_t)d.cin0 * d.cout * 9) return fail("weight size mismatch", i);
+        break;
+      }
+      case PH_OP_INPUT_CONV:
+      case PH_OP_PATCH_STEM: {
+        // [tap][ci][Cp] from OIHW (cout, cin, k, k); the patch stem (k x k, stride = cmid, padding 1) shares the layout
+        if (!widx_ok(d.weight) || !widx_ok(d.bias)) return fail("weight index out of range", i);
+        if (weight_numel[d.bias] != d.cout) return fail("bias size mismatch", i);
+        if (d.kind == PH_OP_INPUT_CONV && d.ksize != 3) return fail("only kernel_size 3 is supported", i);
+        if (d.kind == PH_OP_PATCH_STEM && (d.ksize < 2 || d.ksize > 8 || d.cmid < 1 || d.cmid > d.ksize)) return fail("patch stem needs 2 <= kernel <= 8 and 1 <= stride <= kernel", i);
+        const int kk = d.ksize * d.ksize;
+        if (weight_numel[d.weight] != (int64_t)d.cin0 * d.cout * kk) return fail("weight size mismatch", i);
         const int coutp = pad16(d.cout);
-        std::vector<float> pw[2], pb[2];
-        for (int k = 0; k < 2; ++k) {
-          pw[k].assign((size_t)9 * d.cin0 * coutp, 0.f);
+        auto pack_in = [&](const auto* w, auto& out) {
+          out.assign((size_t)kk * d.cin0 * coutp, 0);
           for (int co = 0; co < d.cout; ++co)
             for (int ci = 0; ci < d.cin0; ++ci)
-              for (int tap = 0; tap < 9; ++tap) pw[k][((size_t)tap * d.cin0 + ci) * coutp + co] = wsrc[k][((size_t)co * d.cin0 + ci) * 9 + tap];
-          pb[k].assign(coutp, 0.f);
-          if (bsrc[k]) std::memcpy(pb[k].data(), bsrc[k], d.cout * sizeof(float));
-        }
-        ok = upload_packed(m, pw[0], pw[1], &op.w_dev) == PH_OK && upload_packed(m, pb[0], pb[1], &op.b_dev) == PH_OK;
-      } else {  // HEAD
-        if (wn != (int64_t)d.cin0 * d.cout) return fail("weight size mismatch", i);
+              for (int tap = 0; tap < kk; ++tap) out[((size_t)tap * d.cin0 + ci) * coutp + co] = w[((size_t)co * d.cin0 + ci) * kk + tap];
+        };
+        ok = pack_upload(m, pack_in, weights[d.weight], index_array(d.weight), &op.w_dev) == PH_OK &&
+             pack_upload(m, pad_vec(coutp, d.cout), weights[d.bias], index_array(d.bias), &op.b_dev) == PH_OK;
+        break;
+      }
+      case PH_OP_HEAD: {
+        if (!widx_ok(d.weight) || !widx_ok(d.bias)) return fail("weight index out of range", i);
+        if (weight_numel[d.bias] != d.cout) return fail("bias size mismatch", i);
+        if (weight_numel[d.weight] != (int64_t)d.cin0 * d.cout) return fail("weight size mismatch", i);
         if (d.out_index < 0 || d.out_index >= n_outputs) return fail("bad out_index", i);
         const int cp = pad16(d.cin0);
-        std::vector<float> pw[2], pb[2];
-        for (int k = 0; k < 2; ++k) {
-          pw[k].assign((size_t)d.cout * cp, 0.f);
+        auto pack_head = [&](const auto* w, auto& out) {
+          out.assign((size_t)d.cout * cp, 0);
           for (int co = 0; co < d.cout; ++co)
-            for (int ci = 0; ci < d.cin0; ++ci) pw[k][(size_t)co * cp + ci] = wsrc[k][(size_t)co * d.cin0 + ci];
-          pb[k].assign(d.cout, 0.f);
-          if (bsrc[k]) std::memcpy(pb[k].data(), bsrc[k], d.cout * sizeof(float));
-        }
-        ok = upload_packed(m, pw[0], pw[1], &op.w_dev) == PH_OK && upload_packed(m, pb[0], pb[1], &op.b_dev) == PH_OK;
+            for (int ci = 0; ci < d.cin0; ++ci) out[(size_t)co * cp + ci] = w[(size_t)co * d.cin0 + ci];
+        };
+        ok = pack_upload(m, pack_head, weights[d.weight], index_array(d.weight), &op.w_dev) == PH_OK &&
+             pack_upload(m, pad_vec(d.cout, d.cout), weights[d.bias], index_array(d.bias), &op.b_dev) == PH_OK;
+        break;
       }
-    } else if (d.kind != PH_OP_POOL && d.kind != PH_OP_UPSAMPLE) {
-      return fail("unknown op kind", i);
+      case PH_OP_DWCONV: {
+        // (C, 1, 7, 7) -> [tap][Cp]
+        if (!widx_ok(d.weight) || !widx_ok(d.bias)) return fail("weight index out of range", i);
+        if (d.ksize != 7 || d.cin0 != d.cout) return fail("depthwise conv must be 7x7 with cin == cout", i);
+        if (weight_numel[d.weight] != (int64_t)d.cout * 49 || weight_numel[d.bias] != d.cout) return fail("weight size mismatch", i);
+        const int cp = pad16(d.cout);
+        auto pack_dw = [&](const auto* w, auto& out) {
+          out.assign((size_t)49 * cp, 0);
+          for (int c = 0; c < d.cout; ++c)
+            for (int tap = 0; tap < 49; ++tap) out[(size_t)tap * cp + c] = w[(size_t)c * 49 + tap];
+        };
+        ok = pack_upload(m, pack_dw, weights[d.weight], index_array(d.weight), &op.w_dev) == PH_OK &&
+             pack_upload(m, pad_vec(cp, d.cout), weights[d.bias], index_array(d.bias), &op.b_dev) == PH_OK;
+        break;
+      }
+      case PH_OP_LAYERNORM: {
+        if (!widx_ok(d.weight) || !widx_ok(d.bias)) return fail("weight index out of range", i);
+        if (d.cin0 != d.cout || weight_numel[d.weight] != d.cout || weight_numel[d.bias] != d.cout) return fail("LayerNorm affine size mismatch", i);
+        const int cp = pad16(d.cout);
+        ok = pack_upload(m, pad_vec(cp, d.cout), weights[d.weight], index_array(d.weight), &op.w_dev) == PH_OK &&
+             pack_upload(m, pad_vec(cp, d.cout), weights[d.bias], index_array(d.bias), &op.b_dev) == PH_OK;
+        break;
+      }
+      case PH_OP_LINEAR:
+      case PH_OP_PATCH_CONV: {
+        if (!widx_ok(d.weight) || !widx_ok(d.bias)) return fail("weight index out of range", i);
+        const int segs = d.kind == PH_OP_PATCH_CONV ? 4 : 1;
+        if (d.kind == PH_OP_PATCH_CONV && d.ksize != 2) return fail("patch conv must be 2x2 stride 2", i);
+        if (weight_numel[d.weight] != (int64_t)d.cin0 * d.cout * segs || weight_numel[d.bias] != d.cout) return fail("weight size mismatch", i);
+        const int coutp = pad16(d.cout);
+        op.bn = gemm_choose_bn(coutp);
+        const size_t npad = (size_t)((coutp + op.bn - 1) / op.bn) * op.bn;
+        auto pack_g = [&](const auto* w, auto& out) { pack_gemm(w, d.cout, d.cin0, segs, op.bn, out); };
+        ok = pack_upload(m, pack_g, weights[d.weight], index_array(d.weight), &op.w_dma_dev) == PH_OK &&
+             pack_upload(m, pad_vec(npad, d.cout), weights[d.bias], index_array(d.bias), &op.b_dev) == PH_OK;
+        if (ok && (d.flags & PH_FLAG_SCALE_RESIDUAL)) {
+          if (!widx_ok(d.weight2) || weight_numel[d.weight2] != d.cout || d.src1 < 0) return fail("layer-scale epilogue needs weight2 (C) and a residual source", i);
+          ok = pack_upload(m, pad_vec(npad, d.cout), weights[d.weight2], index_array(d.weight2), &op.w2_dev) == PH_OK;
+        }
+        break;
+      }
+      default:
+        return fail("unknown op kind", i);
     }
     if (!ok) {
       ph_model_destroy(m);
@@ -527,6 +639,74 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
         a.wpack_dma = op.w_dma_dev;
         a.zeros = m->zeros_dev;
         rc = (m->use_dma && a.bn == 64) ? launch_conv3x3_dma(a, s) : launch_conv3x3(a, s);  // BN=32 layers: the register-staged kernel is faster
+        break;
+      }
+      case PH_OP_PATCH_STEM: {
+        PH_REQUIRE(d.cin0 == in_channels, "input has %d channels, network expects %d", in_channels, d.cin0);
+        const SlotShape& so = plan.slots[d.dst];
+        PatchStemArgs a{};
+        a.src = input_dev;
+        a.w = op.w_dev;
+        a.bias = op.b_dev;
+        a.dst = slot_ptr(d.dst);
+        a.dtype = in_dtype;
+        a.cin = d.cin0;
+        a.coutp = so.cp;
+        a.B = batch;
+        a.H = height;
+        a.W = width;
+        a.OH = so.h;
+        a.OW = so.w;
+        a.k = d.ksize;
+        a.stride = d.cmid;
+        rc = launch_patch_stem(a, s);
+        break;
+      }
+      case PH_OP_DWCONV: {
+        const SlotShape& s0 = plan.slots[d.src0];
+        PH_REQUIRE(s0.c == d.cin0, "depthwise conv channel mismatch");
+        DwConvArgs a{};
+        a.src = slot_ptr(d.src0);
+        a.w = op.w_dev;
+        a.bias = op.b_dev;
+        a.dst = slot_ptr(d.dst);
+        a.cp = s0.cp;
+        a.B = batch;
+        a.H = s0.h;
+        a.W = s0.w;
+        rc = launch_dwconv7(a, s);
+        break;
+      }
+      case PH_OP_LAYERNORM: {
+        const SlotShape& s0 = plan.slots[d.src0];
+        PH_REQUIRE(s0.c == d.cin0, "LayerNorm channel mismatch");
+        rc = launch_layernorm(slot_ptr(d.src0), op.w_dev, op.b_dev, slot_ptr(d.dst), s0.c, s0.cp, (size_t)batch * s0.h * s0.w, s);
+        break;
+      }
+      case PH_OP_LINEAR:
+      case PH_OP_PATCH_CONV: {
+        const SlotShape& s0 = plan.slots[d.src0];
+        const SlotShape& so = plan.slots[d.dst];
+        PH_REQUIRE(s0.c == d.cin0, "GEMM channel mismatch");
+        GemmArgs a{};
+        a.src = slot_ptr(d.src0);
+        a.wpack = op.w_dma_dev;
+        a.bias = op.b_dev;
+        a.dst = slot_ptr(d.dst);
+        a.zeros = m->zeros_dev;
+        a.cp = s0.cp;
+        a.coutp = so.cp;
+        a.bn = op.bn;
+        a.M = batch * so.h * so.w;
+        a.segs = d.kind == PH_OP_PATCH_CONV ? 4 : 1;
+        a.H = s0.h;
+        a.W = s0.w;
+        a.gelu = (d.flags & PH_FLAG_GELU) ? 1 : 0;
+        if (d.flags & PH_FLAG_SCALE_RESIDUAL) {
+          a.scale = op.w2_dev;
+          a.residual = slot_ptr(d.src1);
+        }
+        rc = launch_gemm(a, s);
         break;
       }
       case PH_OP_HEAD: {

@@ -71,7 +71,5 @@ namespace ph {
 int build_plan(const ph_model* m, int B, int H, int W, Plan& plan);
 int upload(ph_model* m, const std::vector<float>& host, float** dev);
 int upload_ints(ph_model* m, const std::vector<int>& host, int** dev);
-void pack_conv(const float* w, bool transposed, int cin0, int cin1, int cout, int bn, std::vector<float>& out);
-void repack_dma(const std::vector<float>& in, int bn, std::vector<float>& out);
 int choose_bn(int coutp);
 }  // namespace ph

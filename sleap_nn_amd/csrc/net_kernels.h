@@ -44,6 +44,43 @@ struct StemArgs {
   int dtype, cin, B, H, W;
 };
 
+struct PatchStemArgs {
+  const void* src;  // NCHW uint8 / float image
+  const float* w;   // [tap][cin][coutp]
+  const float* bias;
+  float* dst;       // NHWC coutp, OH x OW
+  int dtype, cin, coutp, B, H, W, OH, OW, k, stride;
+};
+
+struct DwConvArgs {
+  const float* src;   // NHWC cp
+  const float* w;     // [49][cp]
+  const float* bias;  // [cp]
+  float* dst;
+  int cp, B, H, W;
+};
+
+struct GemmArgs {
+  const float* src;            // NHWC activations, cp channels
+  const float* wpack;          // pack_gemm layout
+  const float* bias;           // padded to n_tiles * bn
+  const float* scale = nullptr;     // layer_scale (padded) or nullptr
+  const float* residual = nullptr;  // (M, coutp) or nullptr
+  float* dst = nullptr;        // (M, coutp)
+  const float* zeros = nullptr;
+  int cp = 0, coutp = 0, bn = 0;
+  int M = 0;                   // output rows
+  int segs = 1;                // 1: row = pixel; 4: row = 2x2/stride-2 patch (K = 4 taps x cp)
+  int H = 0, W = 0;            // input spatial size (patch mode)
+  int gelu = 0;
+};
+
+int launch_patch_stem(const PatchStemArgs& a, hipStream_t s);
+int launch_dwconv7(const DwConvArgs& a, hipStream_t s);
+int launch_layernorm(const float* src, const float* gamma, const float* beta, float* dst, int c, int cp, size_t npix, hipStream_t s);
+int launch_gemm(const GemmArgs& a, hipStream_t s);
+int gemm_choose_bn(int coutp);
+int prepare_convnext_kernels();
 int launch_stem(const StemArgs& a, hipStream_t s);
 int prepare_kernels();
 int conv_lds_bytes(int bn);

@@ -31,6 +31,10 @@ int build_bwd_plan(const ph_model* m, int B, int H, int W, BwdPlan& bp) {
       set_error("backward needs the unfused program with bilinear up-sampling (no stem / conv+pool fusion / transposed conv)");
       return PH_E_INVALID;
     }
+    if (d.kind >= PH_OP_PATCH_STEM) {
+      set_error("backward of the ConvNeXt encoder ops (kind %d) is not implemented yet", d.kind);
+      return PH_E_INVALID;
+    }
     if (d.kind == PH_OP_HEAD) {
       const SlotShape& s0 = bp.act.slots[d.src0];
       bp.head_dy_off[d.out_index] = off;

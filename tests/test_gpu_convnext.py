@@ -1,0 +1,90 @@
+"""GPU parity of the ConvNeXt encoder-decoder path vs the oracle.
+
+The oracle's CNBlock / LayerNorm2d arithmetic restates torchvision's public definition (torchvision
+is absent from this image: parity of that half is self-consistent, see oracle/cpu_ref.py:convnext_plan);
+its pool / middle / decoder half is pinned against the reference's own modules
+(tests/test_oracle_golden.py::test_convnext_wrapper_decoder_half_matches_reference).
+Tolerance: 1e-4 absolute on head outputs and intermediate activations (north_star).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cpu_ref as O
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+ATOL = 1e-4
+
+
+def _bb(**kw):
+    bb = {"model_type": None, "arch": None, "in_channels": 1, "kernel_size": 3, "filters_rate": 2, "convs_per_block": 2, "up_interpolate": True,
+          "stem_patch_kernel": 4, "stem_patch_stride": 2, "output_stride": 2, "max_stride": 32}
+    bb.update(kw)
+    return bb
+
+
+def _heads(n, stride):
+    return {"confmaps": {"part_names": [str(i) for i in range(n)], "sigma": 2.5, "output_stride": stride}}
+
+
+def _run(bb, heads, model_type, img, seed=7, layer_scale=0.5, check_blocks=True):
+    from sleap_nn_amd.architectures.model import Model
+
+    sd = O.init_state_convnext(bb, heads, model_type, seed=seed, head_scale=1.0, layer_scale=layer_scale, randomize_affine=True)
+    m = Model("convnext", bb, heads, model_type)
+    m.load_state_dict(sd, strict=True)
+    m.to(DEV)
+    collect = {}
+    ref = O.model_forward(sd, bb, heads, model_type, img, collect=collect, backbone="convnext")
+    out = m(img.to(DEV))
+    torch.cuda.synchronize()
+    worst = {}
+    if check_blocks:
+        for name, t in collect.items():
+            if name not in m.backbone.labels:
+                continue
+            got = m.read_activation(name, t.shape[0], t.shape[-2:]).cpu()
+            scale = max(1.0, t.abs().max().item())
+            err = (got - t).abs().max().item() / scale
+            worst[name] = err
+            assert err <= ATOL, (name, err, scale)
+    for k, t in ref.items():
+        got = out[k].cpu()
+        assert got.shape == t.shape
+        err = (got - t).abs().max().item() / max(1.0, t.abs().max().item())
+        assert err <= ATOL, (k, err)
+    return worst
+
+
+@pytest.mark.parametrize(
+    "channels,depths,stem_stride,os_,hw,batch",
+    [
+        ([16, 32, 64, 128], [1, 2, 1, 1], 2, 2, (64, 96), 2),      # multiples of 16
+        ([24, 40, 72, 136], [2, 1, 1, 1], 2, 4, (64, 64), 3),      # padded channels: LayerNorm must ignore the pad lanes
+        ([32, 64, 128, 256], [1, 1, 2, 1], 4, 1, (128, 64), 1),    # stem stride 4: two decoder blocks without a skip
+        ([96, 192, 384, 768], [1, 1, 1, 1], 2, 2, (96, 160), 2),   # the tiny variant's widths (BN = 96 / 128 GEMM tiles)
+    ],
+)
+def test_convnext_forward_matches_oracle(channels, depths, stem_stride, os_, hw, batch):
+    bb = _bb(arch={"depths": depths, "channels": channels}, stem_patch_stride=stem_stride, output_stride=os_)
+    g = torch.Generator().manual_seed(11)
+    img = torch.randint(0, 256, (batch, 1, hw[0], hw[1]), dtype=torch.uint8, generator=g)
+    _run(bb, _heads(5, os_), "single_instance", img)
+
+
+def test_convnext_tiny_centered_instance_rgb_float():
+    """Full ConvNeXt-tiny (87.9 M parameters: exercises the > 2^24-parameter gather maps) on a float RGB crop."""
+    bb = _bb(model_type="tiny", in_channels=3, output_stride=2)
+    g = torch.Generator().manual_seed(3)
+    img = torch.rand((1, 3, 96, 96), generator=g)
+    _run(bb, _heads(13, 2), "centered_instance", img, layer_scale=0.3, check_blocks=False)
+
+
+def test_convnext_rows_not_multiple_of_tile_and_gray_to_rgb():
+    """M (pixels) not a multiple of the 256-row GEMM tile at every stage; gray input into an RGB model."""
+    bb = _bb(arch={"depths": [1, 1, 1, 1], "channels": [16, 32, 64, 128]}, in_channels=3)
+    g = torch.Generator().manual_seed(5)
+    img = torch.randint(0, 256, (1, 1, 32, 96), dtype=torch.uint8, generator=g)
+    _run(bb, _heads(3, 2), "single_instance", img)
