@@ -214,25 +214,44 @@ int launch_layernorm(const float* src, const float* gamma, const float* beta, fl
 
 // ---------------------------------------------------------------------------------------
 // K23: row GEMM on MFMA with LDS-DMA staging: dst[m, n] = epilogue(sum_k A[m, k] * Wt[n, k] + bias[n]).
-//   A rows are pixels of an NHWC tensor: `segs` == 1 -> row m is pixel m (Linear / 1x1 conv);
-//   `segs` == 4 -> row m is output pixel (b, oy, ox) of a 2x2/stride-2 convolution and K runs
-//   over the four taps (dy, dx) x Cp channels, each tap a contiguous Cp-float run of the input.
-//   512 threads = 8 waves, tile 256 rows x BN columns (BN = 32 * NT_TOTAL), K chunks of 32
-//   channels = two 16-channel halves; waves are arranged (8 / WN) x WN and each owns WN 32-row
-//   tiles x (NT_TOTAL / WN) 32-column tiles.  Staging and LDS image are those of the 3x3 DMA
-//   convolution (quad-major 1-KiB pieces written by global_load_lds_dwordx4, double-buffered,
-//   one barrier per chunk); one ds_read_b128 per operand tile feeds four MFMAs.
-//   Epilogues: bias; bias + GELU(erf); layer_scale * (acc + bias) + residual.
+//   A rows are pixels of one or two NHWC tensors (a channel concat is two K panels); K runs
+//   over sources x 16-channel slices x taps, the taps innermost so that the re-read of a row's
+//   neighbours is one 16-KiB step away (L2 / L1 hits):
+//     mode 0  Linear / 1x1 conv ....... 1 tap, row m = pixel m
+//     mode 1  Conv2d k2 s2 ............ 4 taps (dy, dx), row m = output pixel (b, oy, ox)
+//     mode 2  Conv2d 3x3 "same" ....... 9 taps, out-of-image taps read a zero page.  Used for
+//             feature maps too small to fill the 16x32-pixel tiles of the halo-tiled kernel K1d.
+//   512 threads = 8 waves, tile 256 rows x BN columns (BN = 32 * NT_TOTAL); waves are arranged
+//   (8 / WN) x WN and each owns WN 32-row tiles x (NT_TOTAL / WN) 32-column tiles.
+//   Pipeline: a ring of three LDS stages of 16 K-values each (256 x 16 A slice + BN x 16 weight
+//   slice, quad-major 1-KiB pieces written by global_load_lds_dwordx4).  The DMA for stage s+2
+//   is issued while stage s is multiplied; the only synchronisation per stage is
+//   s_waitcnt vmcnt(3) (this wave's three pieces of stage s+1 have landed; the three of stage
+//   s+2 stay in flight) + s_barrier.  72 KiB of LDS at BN = 128, so two workgroups share a CU
+//   and one's epilogue overlaps the other's main loop.
+//   Epilogues: bias; + ReLU; + GELU (erf form); layer_scale * (acc + bias) + residual.
 // ---------------------------------------------------------------------------------------
+// erf as ATen's vectorised CPU kernels compute it (Abramowitz-Stegun 7.1.26, |err| <= 1.5e-7):
+// branch-free, and the same approximation the reference's GELU runs through on the CPU.
+__device__ __forceinline__ float erf_as(float x) {
+  const float ax = fabsf(x);
+  const float t = 1.0f / (1.0f + 0.3275911f * ax);
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float r = 1.0f - p * t * expf(-x * x);
+  return copysignf(r, x);
+}
+
 template <int NT_TOTAL, int WN>
-__global__ __launch_bounds__(512, 2) void gemm_mfma_dma_kernel(GemmArgs a) {
+__global__ __launch_bounds__(512, 4) void gemm_mfma_dma_kernel(GemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int BN = NT_TOTAL * 32;
   constexpr int MT = WN;
   constexpr int NTW = NT_TOTAL / WN;
-  constexpr int B_PIECES = BN / 16;          // per 16-channel half
-  constexpr int HALF_PIECES = 16 + B_PIECES; // 256 A rows = 16 pieces, then the weight rows
-  constexpr int BUF_FLOATS = 2 * HALF_PIECES * 256;
+  constexpr int B_PIECES = BN / 16;
+  constexpr int STAGE_FLOATS = (16 + B_PIECES) * 256;
   static_assert(NT_TOTAL % WN == 0 && (8 / WN) * MT * 32 == 256, "wave arrangement must tile 256 x BN");
 
   const int tid = threadIdx.x;
@@ -252,71 +271,78 @@ __global__ __launch_bounds__(512, 2) void gemm_mfma_dma_kernel(GemmArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
-  const int halves_per_seg = a.cp / 16;
-  const int total_halves = a.segs * halves_per_seg;
-  const int nchunks = (total_halves + 1) / 2;
-  const float* wbase = a.wpack + (size_t)ntile * nchunks * (2 * B_PIECES * 256);
+  const int ntaps = a.mode == 0 ? 1 : (a.mode == 1 ? 4 : 9);
+  const int total = ((a.c0p + a.c1p) / 16) * ntaps;  // stages of 16 K-values
+  const float* wbase = a.wpack + (size_t)ntile * total * (B_PIECES * 256);
 
   // ---- DMA plan: lane L of piece p moves quad q = L >> 4 of row p * 16 + (L & 15)
   const int dq = lane >> 4, dr = lane & 15;
-  const float* a_row[2];
+  long long a_pix[2];
+  unsigned a_mask[2];
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
     const int row = min(m0 + (wave + 8 * s) * 16 + dr, a.M - 1);
-    size_t pix;
-    if (a.segs == 1) {
-      pix = (size_t)row;
-    } else {
+    unsigned mask = 0x1ffu;
+    long long pix = row;
+    if (a.mode == 1) {
       const int ow = a.W >> 1, oh = a.H >> 1;
       const int ox = row % ow;
       const int r2 = row / ow;
       const int oy = r2 % oh;
-      const int b = r2 / oh;
-      pix = ((size_t)b * a.H + 2 * oy) * a.W + 2 * ox;
-    }
-    a_row[s] = a.src + pix * a.cp + dq * 4;
-  }
-  // position of the two halves of the chunk being fetched: tap segment and channel offset
-  int f_seg[2] = {0, 0}, f_coff[2] = {0, 16};
-  if (f_coff[1] >= a.cp) {
-    f_coff[1] -= a.cp;
-    f_seg[1] = 1;
-  }
-  int f_chunk = 0;
-  auto advance_fetch = [&]() {
+      pix = ((long long)(r2 / oh) * a.H + 2 * oy) * a.W + 2 * ox;
+    } else if (a.mode == 2) {
+      const int x = row % a.W;
+      const int y = (row / a.W) % a.H;
+      mask = 0;
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      f_coff[h] += 32;
-      if (f_coff[h] >= a.cp) {
-        f_coff[h] -= a.cp;
-        f_seg[h] += 1;
-      }
-      if (f_coff[h] >= a.cp) {
-        f_coff[h] -= a.cp;
-        f_seg[h] += 1;
+      for (int tap = 0; tap < 9; ++tap) {
+        const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+        mask |= (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) ? (1u << tap) : 0u;
       }
     }
-    f_chunk += 1;
-  };
-  auto dma_slot = [&](int slot, float* buf) {  // slot is compile-time after unrolling: (half, kind)
-    const int h = slot / 3, k = slot % 3;
-    const float* g;
-    int p;
-    if (k < 2) {
-      p = h * HALF_PIECES + wave + 8 * k;
-      const size_t segoff = ((size_t)(f_seg[h] >> 1) * a.W + (f_seg[h] & 1)) * a.cp;
-      const float* real = a_row[k] + segoff + f_coff[h];
-      g = (f_seg[h] < a.segs) ? real : a.zeros + dq * 4;
-    } else {
+    a_pix[s] = pix;
+    a_mask[s] = mask;
+  }
+  // fetch cursor (wave-uniform): which source / 16-channel slice / tap the next stage to fetch is
+  int f_idx = 0, f_tap = 0, f_coff = 0, f_src = 0;
+  auto issue_stage = [&](float* buf) {
+    const float* sp = f_src ? a.src1 : a.src0;
+    const int cp = f_src ? a.c1p : a.c0p;
+    int toff;  // pixel offset of the tap
+    if (a.mode == 0)
+      toff = 0;
+    else if (a.mode == 1)
+      toff = (f_tap >> 1) * a.W + (f_tap & 1);
+    else
+      toff = (f_tap / 3 - 1) * a.W + (f_tap % 3 - 1);
+    const bool live = f_idx < total;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const float* real = sp + (a_pix[k] + toff) * cp + f_coff + dq * 4;
+      const float* g = (live && ((a_mask[k] >> f_tap) & 1u)) ? real : a.zeros + dq * 4;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                       (__attribute__((address_space(3))) void*)(buf + (wave + 8 * k) * 256), 16, 0, 0);
+    }
+    {
       const int pb = min(wave, B_PIECES - 1);
-      p = h * HALF_PIECES + 16 + pb;
-      g = wbase + ((size_t)(min(f_chunk, nchunks - 1) * 2 + h) * B_PIECES + pb) * 256 + lane * 4;
+      const float* g = wbase + ((size_t)min(f_idx, total - 1) * B_PIECES + pb) * 256 + lane * 4;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)(buf + (16 + pb) * 256),
+                                       16, 0, 0);
     }
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)(buf + p * 256), 16, 0,
-                                     0);
+    // advance: taps innermost, then 16-channel slices, then the second source
+    f_idx += 1;
+    f_tap += 1;
+    if (f_tap == ntaps) {
+      f_tap = 0;
+      f_coff += 16;
+      if (f_coff >= cp && f_src == 0 && a.c1p > 0) {
+        f_coff = 0;
+        f_src = 1;
+      }
+    }
   };
 
-  // ---- fragment read offsets (floats, relative to the half)
+  // ---- fragment read offsets (floats, stage-relative)
   const int lx = lane & 31, lh = lane >> 5;
   int offA[MT], offB[NTW];
 #pragma unroll
@@ -330,57 +356,41 @@ __global__ __launch_bounds__(512, 2) void gemm_mfma_dma_kernel(GemmArgs a) {
     offB[n] = (16 + (col >> 4)) * 256 + lh * 64 + (col & 15) * 4;
   }
 
-  float* buf0 = lds;
-  float* buf1 = lds + BUF_FLOATS;
-#pragma unroll
-  for (int s = 0; s < 6; ++s) dma_slot(s, buf0);
-  advance_fetch();
-  __syncthreads();
-
-  for (int ch = 0; ch < nchunks; ++ch) {
-    float* cur = (ch & 1) ? buf1 : buf0;
-    float* nxt = (ch & 1) ? buf0 : buf1;
+  auto stage = [&](const float* cur, float* fill) {
     f32x4 af[2][MT], bf[2][NTW];
-    auto load_frags = [&](int step, int fb) {
-      const int base = (step >> 1) * (HALF_PIECES * 256) + (step & 1) * 128;
 #pragma unroll
-      for (int m = 0; m < MT; ++m) af[fb][m] = *reinterpret_cast<const f32x4*>(cur + base + offA[m]);
+    for (int g = 0; g < 2; ++g) {
 #pragma unroll
-      for (int n = 0; n < NTW; ++n) bf[fb][n] = *reinterpret_cast<const f32x4*>(cur + base + offB[n]);
-    };
-    load_frags(0, 0);
+      for (int m = 0; m < MT; ++m) af[g][m] = *reinterpret_cast<const f32x4*>(cur + g * 128 + offA[m]);
 #pragma unroll
-    for (int step = 0; step < 4; ++step) {
-      const int fcur = step & 1;
-      if (step + 1 < 4) load_frags(step + 1, fcur ^ 1);
-      // the next chunk's six pieces, spread 2/2/1/1 over the steps
-      if (step == 0) {
-        dma_slot(0, nxt);
-        dma_slot(1, nxt);
-      } else if (step == 1) {
-        dma_slot(3, nxt);
-        dma_slot(4, nxt);
-      } else if (step == 2) {
-        dma_slot(2, nxt);
-      } else {
-        dma_slot(5, nxt);
-      }
+      for (int n = 0; n < NTW; ++n) bf[g][n] = *reinterpret_cast<const f32x4*>(cur + g * 128 + offB[n]);
+    }
+    issue_stage(fill);
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
-          for (int n = 0; n < NTW; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[fcur][m][j], bf[fcur][n][j], acc[m][n], 0, 0, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, MT + NTW, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, MT * NTW, 0);
-      __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
-      __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 3 * MT * NTW, 0);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    advance_fetch();
-    __syncthreads();  // vmcnt(0) + barrier: the next buffer has landed everywhere, this one is free
+          for (int n = 0; n < NTW; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g][m][j], bf[g][n][j], acc[m][n], 0, 0, 0);
+    __builtin_amdgcn_s_waitcnt(0x0F73);  // vmcnt(3): everything but the three pieces just issued has landed
+    __builtin_amdgcn_s_barrier();
+  };
+
+  float* b0 = lds;
+  float* b1 = lds + STAGE_FLOATS;
+  float* b2 = lds + 2 * STAGE_FLOATS;
+  issue_stage(b0);
+  issue_stage(b1);
+  __builtin_amdgcn_s_waitcnt(0x0F73);
+  __builtin_amdgcn_s_barrier();
+  for (int st = 0; st < total; st += 3) {
+    stage(b0, b2);
+    if (st + 1 < total) stage(b1, b0);
+    if (st + 2 < total) stage(b2, b1);
   }
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // drain the (dummy) tail fetches before the LDS is released
 
   // ---- epilogue.  C/D map of v_mfma_f32_32x32x2_f32: column = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
   const bool interior = (m0 + 256 <= a.M) && ((ntile + 1) * BN <= a.coutp);
@@ -395,7 +405,8 @@ __global__ __launch_bounds__(512, 2) void gemm_mfma_dma_kernel(GemmArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         float v = acc[m][n][r] + bias;
-        if (a.gelu) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+        if (a.act == 1) v = fmaxf(v, 0.f);
+        if (a.act == 2) v = 0.5f * v * (1.0f + erf_as(v * 0.70710678118654752440f));
         acc[m][n][r] = v * scale;
       }
       if (interior) {
@@ -435,7 +446,7 @@ int gemm_choose_bn(int coutp) {
   return best;
 }
 
-static size_t gemm_lds_bytes(int bn) { return (size_t)2 * 2 * (16 + bn / 16) * 1024; }
+static size_t gemm_lds_bytes(int bn) { return (size_t)3 * (16 + bn / 16) * 1024; }
 
 int prepare_convnext_kernels() {
   PH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mfma_dma_kernel<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_lds_bytes(128)));
@@ -446,8 +457,10 @@ int prepare_convnext_kernels() {
 }
 
 int launch_gemm(const GemmArgs& a, hipStream_t s) {
-  PH_REQUIRE(a.M > 0 && a.cp % 16 == 0 && a.coutp % 16 == 0 && (a.segs == 1 || a.segs == 4), "launch_gemm: bad shape");
-  PH_REQUIRE(a.segs == 1 || (a.H >= 2 && a.W >= 2), "launch_gemm: 2x2 patches need H, W >= 2");
+  PH_REQUIRE(a.M > 0 && a.c0p > 0 && a.c0p % 16 == 0 && a.c1p % 16 == 0 && a.coutp % 16 == 0 && a.mode >= 0 && a.mode <= 2, "launch_gemm: bad shape");
+  PH_REQUIRE(a.c1p == 0 || a.src1, "launch_gemm: second source missing");
+  PH_REQUIRE(a.mode != 1 || (a.H >= 2 && a.W >= 2), "launch_gemm: 2x2 patches need H, W >= 2");
+  PH_REQUIRE(a.mode != 2 || a.M % (a.H * a.W) == 0, "launch_gemm: conv rows must be whole images");
   const int mtiles = (a.M + 255) / 256;
   const int ntiles = (a.coutp + a.bn - 1) / a.bn;
   const dim3 grid((unsigned)(mtiles * ntiles));

@@ -138,30 +138,31 @@ static void repack_dma(const std::vector<T>& in, int bn, std::vector<T>& out) {
       }
 }
 
-// Row-GEMM weights (gemm_mfma_dma_kernel): Linear (cout, cin) [segs = 1] or Conv2d k2 s2 (cout, cin, 2, 2)
-// [segs = 4, segment = dy * 2 + dx] -> [n_tile][chunk of 32][half][piece = n / 16][quad][row n % 16][4],
-// K index = segment * Cp + channel, zero-padded.
+// Row-GEMM weights (gemm_mfma_dma_kernel): Linear (cout, cin) [taps = 1], Conv2d k2 s2 (cout, cin, 2, 2)
+// [taps = 4] or Conv2d 3x3 over concat(cin0, cin1) (cout, cin0 + cin1, 3, 3) [taps = 9] ->
+// [n_tile][stage][piece = n / 16][quad][row n % 16][4]; stage order = source, 16-channel slice, tap
+// (taps innermost), zero-padded channels / rows.
 template <typename T>
-static void pack_gemm(const T* w, int cout, int cin, int segs, int bn, std::vector<T>& out) {
-  const int cp = pad16(cin), coutp = pad16(cout);
+static void pack_gemm(const T* w, int cout, int cin0, int cin1, int taps, int bn, std::vector<T>& out) {
+  const int c0p = pad16(cin0), c1p = cin1 > 0 ? pad16(cin1) : 0, coutp = pad16(cout);
   const int ntiles = (coutp + bn - 1) / bn;
-  const int hps = cp / 16, total_halves = segs * hps, nchunks = (total_halves + 1) / 2, bp = bn / 16;
-  out.assign((size_t)ntiles * nchunks * 2 * bp * 256, T(0));
+  const int total = ((c0p + c1p) / 16) * taps, bp = bn / 16, cin = cin0 + cin1;
+  out.assign((size_t)ntiles * total * bp * 256, T(0));
   for (int nt = 0; nt < ntiles; ++nt)
-    for (int ch = 0; ch < nchunks; ++ch)
-      for (int h = 0; h < 2; ++h) {
-        const int hc = 2 * ch + h;
-        if (hc >= total_halves) continue;
-        const int seg = hc / hps, c0 = (hc % hps) * 16;
-        for (int pb = 0; pb < bp; ++pb)
-          for (int q = 0; q < 4; ++q)
-            for (int r = 0; r < 16; ++r)
-              for (int e = 0; e < 4; ++e) {
-                const int co = nt * bn + pb * 16 + r, c = c0 + q * 4 + e;
-                if (co >= cout || c >= cin) continue;
-                out[((((size_t)nt * nchunks + ch) * 2 + h) * bp + pb) * 256 + q * 64 + r * 4 + e] = w[((size_t)co * cin + c) * segs + seg];
-              }
-      }
+    for (int st = 0; st < total; ++st) {
+      const int slice = st / taps, tap = st % taps;
+      const bool second = slice >= c0p / 16;
+      const int c0 = (second ? slice - c0p / 16 : slice) * 16;
+      for (int pb = 0; pb < bp; ++pb)
+        for (int q = 0; q < 4; ++q)
+          for (int r = 0; r < 16; ++r)
+            for (int e = 0; e < 4; ++e) {
+              const int co = nt * bn + pb * 16 + r, c = c0 + q * 4 + e;
+              if (co >= cout || c >= (second ? cin1 : cin0)) continue;
+              const int ci = second ? cin0 + c : c;
+              out[(((size_t)nt * total + st) * bp + pb) * 256 + q * 64 + r * 4 + e] = w[((size_t)co * cin + ci) * taps + tap];
+            }
+    }
 }
 
 int choose_bn(int coutp) { return coutp >= 64 ? 64 : 32; }
@@ -285,6 +286,7 @@ ph_model* ph_model_create(const ph_op_desc* ops, int32_t n_ops, const float* con
   {
     const char* impl = getenv("PH_CONV_IMPL");
     m->use_dma = !(impl && std::string(impl) == "reg");
+    if (const char* th = getenv("PH_CONV_GEMM_FILL")) m->gemm_fill_threshold = atof(th);  // experiment knob: 0 disables the row-GEMM form
     std::vector<float> z(64, 0.f);
     if (upload(m, z, &m->zeros_dev) != PH_OK) {
       ph_model_destroy(m);
@@ -370,6 +372,12 @@ ph_model* ph_model_create(const ph_op_desc* ops, int32_t n_ops, const float* con
         };
         ok = pack_upload(m, pack_reg, weights[d.weight], iw, &op.w_dev) == PH_OK && pack_upload(m, pack_dma, weights[d.weight], iw, &op.w_dma_dev) == PH_OK &&
              pack_upload(m, pad_vec((size_t)((coutp + op.bn - 1) / op.bn) * op.bn, d.cout), weights[d.bias], ib, &op.b_dev) == PH_OK;
+        if (ok && !tr) {  // row-GEMM form for feature maps too small for the 16x32-pixel tiles
+          op.bn_g = gemm_choose_bn(coutp);
+          auto pack_g = [&](const auto* w, auto& out) { pack_gemm(w, d.cout, d.cin0, d.cin1, 9, op.bn_g, out); };
+          ok = pack_upload(m, pack_g, weights[d.weight], iw, &op.w_gemm_dev) == PH_OK &&
+               pack_upload(m, pad_vec((size_t)((coutp + op.bn_g - 1) / op.bn_g) * op.bn_g, d.cout), weights[d.bias], ib, &op.b_gemm_dev) == PH_OK;
+        }
         if (ok && d.kind == PH_OP_CONV) {  // data-gradient weights (training)
           const int cin_total = d.cin0 + d.cin1;
           const int parts[2] = {d.cin0, d.cin1}, offs[2] = {0, d.cin0};
@@ -465,7 +473,7 @@ ph_model* ph_model_create(const ph_op_desc* ops, int32_t n_ops, const float* con
         const int coutp = pad16(d.cout);
         op.bn = gemm_choose_bn(coutp);
         const size_t npad = (size_t)((coutp + op.bn - 1) / op.bn) * op.bn;
-        auto pack_g = [&](const auto* w, auto& out) { pack_gemm(w, d.cout, d.cin0, segs, op.bn, out); };
+        auto pack_g = [&](const auto* w, auto& out) { pack_gemm(w, d.cout, d.cin0, 0, segs, op.bn, out); };
         ok = pack_upload(m, pack_g, weights[d.weight], index_array(d.weight), &op.w_dma_dev) == PH_OK &&
              pack_upload(m, pad_vec(npad, d.cout), weights[d.bias], index_array(d.bias), &op.b_dev) == PH_OK;
         if (ok && (d.flags & PH_FLAG_SCALE_RESIDUAL)) {
@@ -601,6 +609,28 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
         a.dst_pool = d.dst2 >= 0 ? slot_ptr(d.dst2) : nullptr;
         a.wpack_dma = op.w_dma_dev;
         a.zeros = m->zeros_dev;
+        const double fill = (double)s0.h * s0.w / ((double)((s0.h + 15) / 16 * 16) * ((s0.w + 31) / 32 * 32));
+        if (m->use_dma && d.dst2 < 0 && op.w_gemm_dev && fill < m->gemm_fill_threshold) {
+          // small feature map: the 16x32-pixel tiles of the halo kernel would be mostly padding -> 9-tap row GEMM
+          GemmArgs g{};
+          g.src0 = a.src0;
+          g.src1 = a.src1;
+          g.c0p = a.c0p;
+          g.c1p = a.c1p;
+          g.wpack = op.w_gemm_dev;
+          g.bias = op.b_gemm_dev;
+          g.dst = a.dst;
+          g.zeros = m->zeros_dev;
+          g.coutp = a.coutp;
+          g.bn = op.bn_g;
+          g.M = batch * s0.h * s0.w;
+          g.mode = 2;
+          g.H = s0.h;
+          g.W = s0.w;
+          g.act = a.relu ? 1 : 0;
+          rc = launch_gemm(g, s);
+          break;
+        }
         rc = (m->use_dma && a.bn == 64) ? launch_conv3x3_dma(a, s) : launch_conv3x3(a, s);  // BN=32 layers: the register-staged kernel is faster
         break;
       }
@@ -689,19 +719,19 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
         const SlotShape& so = plan.slots[d.dst];
         PH_REQUIRE(s0.c == d.cin0, "GEMM channel mismatch");
         GemmArgs a{};
-        a.src = slot_ptr(d.src0);
+        a.src0 = slot_ptr(d.src0);
         a.wpack = op.w_dma_dev;
         a.bias = op.b_dev;
         a.dst = slot_ptr(d.dst);
         a.zeros = m->zeros_dev;
-        a.cp = s0.cp;
+        a.c0p = s0.cp;
         a.coutp = so.cp;
         a.bn = op.bn;
         a.M = batch * so.h * so.w;
-        a.segs = d.kind == PH_OP_PATCH_CONV ? 4 : 1;
+        a.mode = d.kind == PH_OP_PATCH_CONV ? 1 : 0;
         a.H = s0.h;
         a.W = s0.w;
-        a.gelu = (d.flags & PH_FLAG_GELU) ? 1 : 0;
+        a.act = (d.flags & PH_FLAG_GELU) ? 2 : 0;
         if (d.flags & PH_FLAG_SCALE_RESIDUAL) {
           a.scale = op.w2_dev;
           a.residual = slot_ptr(d.src1);

@@ -16,6 +16,9 @@ struct PackedOp {
   float* b2_dev = nullptr;
   float* w_dma_dev = nullptr;  // conv weights in the LDS-DMA (quad-major piece) layout
   int bn = 0;
+  float* w_gemm_dev = nullptr;  // 3x3 conv weights in the row-GEMM layout (small feature maps)
+  float* b_gemm_dev = nullptr;
+  int bn_g = 0;
   // data-gradient weights of a 3x3 conv (flipped taps, in/out swapped), one set per concat source
   float* wd_dev[2] = {nullptr, nullptr};
   float* wd_dma_dev[2] = {nullptr, nullptr};
@@ -64,6 +67,7 @@ struct ph_model {
   int64_t n_params = 0;
   std::vector<ph::PackedBuffer> packed;        // every packed weight buffer, for ph_model_set_params
   bool use_dma = true;                        // PH_CONV_IMPL=reg selects the register-staged kernel
+  double gemm_fill_threshold = 0.7;           // 3x3 convs whose maps fill the 16x32 tiles less than this run as row GEMMs
 };
 
 

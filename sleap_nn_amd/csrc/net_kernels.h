@@ -61,18 +61,19 @@ struct DwConvArgs {
 };
 
 struct GemmArgs {
-  const float* src;            // NHWC activations, cp channels
-  const float* wpack;          // pack_gemm layout
-  const float* bias;           // padded to n_tiles * bn
+  const float* src0 = nullptr;      // NHWC activations, c0p channels
+  const float* src1 = nullptr;      // second concat source (c1p channels) or nullptr
+  const float* wpack = nullptr;     // pack_gemm layout
+  const float* bias = nullptr;      // padded to n_tiles * bn
   const float* scale = nullptr;     // layer_scale (padded) or nullptr
   const float* residual = nullptr;  // (M, coutp) or nullptr
-  float* dst = nullptr;        // (M, coutp)
-  const float* zeros = nullptr;
-  int cp = 0, coutp = 0, bn = 0;
-  int M = 0;                   // output rows
-  int segs = 1;                // 1: row = pixel; 4: row = 2x2/stride-2 patch (K = 4 taps x cp)
-  int H = 0, W = 0;            // input spatial size (patch mode)
-  int gelu = 0;
+  float* dst = nullptr;             // (M, coutp)
+  const float* zeros = nullptr;     // >= 64 B of zeros in HBM
+  int c0p = 0, c1p = 0, coutp = 0, bn = 0;
+  int M = 0;                        // output rows
+  int mode = 0;                     // 0: row = pixel (Linear); 1: 2x2/stride-2 patches; 2: 3x3 "same" conv
+  int H = 0, W = 0;                 // input spatial size (modes 1, 2)
+  int act = 0;                      // 0 none, 1 ReLU, 2 GELU
 };
 
 int launch_patch_stem(const PatchStemArgs& a, hipStream_t s);

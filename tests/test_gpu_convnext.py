@@ -88,3 +88,27 @@ def test_convnext_rows_not_multiple_of_tile_and_gray_to_rgb():
     g = torch.Generator().manual_seed(5)
     img = torch.randint(0, 256, (1, 1, 32, 96), dtype=torch.uint8, generator=g)
     _run(bb, _heads(3, 2), "single_instance", img)
+
+
+def test_small_map_convs_row_gemm_equals_halo_kernel(monkeypatch):
+    """3x3 convolutions on small feature maps run as 9-tap row GEMMs (two-source concat included);
+    the halo-tiled kernel must give the same maps (both vs the oracle, and vs each other)."""
+    from sleap_nn_amd.architectures.model import Model
+
+    bb = {"in_channels": 1, "kernel_size": 3, "filters": 16, "filters_rate": 2, "max_stride": 16, "output_stride": 2, "convs_per_block": 2,
+          "middle_block": True, "up_interpolate": True, "stacks": 1, "stem_stride": None}
+    heads = {"confmaps": {"part_names": ["a", "b", "c"], "sigma": 2.5, "output_stride": 2}}
+    sd = O.init_state(bb, heads, "single_instance", seed=21, head_scale=1.0)
+    g = torch.Generator().manual_seed(8)
+    img = torch.randint(0, 256, (3, 1, 80, 48), dtype=torch.uint8, generator=g)  # maps 80x48 ... 5x3
+    ref = O.model_forward(sd, bb, heads, "single_instance", img)["SingleInstanceConfmapsHead"]
+    outs = {}
+    for tag, thr in (("gemm", "2.0"), ("halo", "0")):
+        monkeypatch.setenv("PH_CONV_GEMM_FILL", thr)
+        m = Model("unet", bb, heads, "single_instance")
+        m.load_state_dict(sd)
+        m.to(DEV)
+        outs[tag] = m(img.to(DEV))["SingleInstanceConfmapsHead"].cpu()
+    for tag, o in outs.items():
+        assert (o - ref).abs().max().item() <= ATOL, tag
+    assert (outs["gemm"] - outs["halo"]).abs().max().item() <= 2e-5
