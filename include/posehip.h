@@ -169,6 +169,10 @@ int ph_render_confmaps(const float* points_dev, int32_t B, int32_t I, int32_t N,
 int ph_render_pafs(const float* points_dev, const int32_t* edges_dev, int32_t B, int32_t I, int32_t N, int32_t E,
                    int32_t img_h, int32_t img_w, int32_t stride, float sigma, float* out_dev, void* stream);
 
+/* Diagnostic (tools/gemm_bench.py): average milliseconds of one row-GEMM kernel variant on synthetic operands. */
+int ph_debug_gemm_bench(int32_t variant, int32_t M, int32_t K, int32_t N, int32_t mode, int32_t H, int32_t W,
+                        int32_t act, int32_t iters, float* ms_out);
+
 /* Per-op timing with HIP events recorded on the forward's own stream (used by bench.py for
  * the roofline object).  While enabled every forward records one event before each op and
  * one after the last; ph_model_profile_read waits for the last recorded forward, returns

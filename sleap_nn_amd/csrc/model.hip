@@ -140,27 +140,29 @@ static void repack_dma(const std::vector<T>& in, int bn, std::vector<T>& out) {
 
 // Row-GEMM weights (gemm_mfma_dma_kernel): Linear (cout, cin) [taps = 1], Conv2d k2 s2 (cout, cin, 2, 2)
 // [taps = 4] or Conv2d 3x3 over concat(cin0, cin1) (cout, cin0 + cin1, 3, 3) [taps = 9] ->
-// [n_tile][stage][piece = n / 16][quad][row n % 16][4]; stage order = source, 16-channel slice, tap
-// (taps innermost), zero-padded channels / rows.
+// [n_tile][stage][piece = n / 8][slot][row n % 8][4]; a stage is 32 channels of one source at one tap,
+// stage order = source, 32-channel slice, tap (taps innermost); slot = channel quad ^ (piece & 1)
+// (the LDS image the kernel's DMA writes); zero-padded channels / rows.
 template <typename T>
 static void pack_gemm(const T* w, int cout, int cin0, int cin1, int taps, int bn, std::vector<T>& out) {
   const int c0p = pad16(cin0), c1p = cin1 > 0 ? pad16(cin1) : 0, coutp = pad16(cout);
   const int ntiles = (coutp + bn - 1) / bn;
-  const int total = ((c0p + c1p) / 16) * taps, bp = bn / 16, cin = cin0 + cin1;
+  const int sl0 = (c0p + 31) / 32, sl1 = (c1p + 31) / 32;
+  const int total = (sl0 + sl1) * taps, bp = bn / 8, cin = cin0 + cin1;
   out.assign((size_t)ntiles * total * bp * 256, T(0));
   for (int nt = 0; nt < ntiles; ++nt)
     for (int st = 0; st < total; ++st) {
       const int slice = st / taps, tap = st % taps;
-      const bool second = slice >= c0p / 16;
-      const int c0 = (second ? slice - c0p / 16 : slice) * 16;
+      const bool second = slice >= sl0;
+      const int c0 = (second ? slice - sl0 : slice) * 32;
       for (int pb = 0; pb < bp; ++pb)
-        for (int q = 0; q < 4; ++q)
-          for (int r = 0; r < 16; ++r)
+        for (int slot = 0; slot < 8; ++slot)
+          for (int r = 0; r < 8; ++r)
             for (int e = 0; e < 4; ++e) {
-              const int co = nt * bn + pb * 16 + r, c = c0 + q * 4 + e;
+              const int co = nt * bn + pb * 8 + r, c = c0 + (slot ^ (pb & 1)) * 4 + e;
               if (co >= cout || c >= (second ? cin1 : cin0)) continue;
               const int ci = second ? cin0 + c : c;
-              out[(((size_t)nt * total + st) * bp + pb) * 256 + q * 64 + r * 4 + e] = w[((size_t)co * cin + ci) * taps + tap];
+              out[(((size_t)nt * total + st) * bp + pb) * 256 + slot * 32 + r * 4 + e] = w[((size_t)co * cin + ci) * taps + tap];
             }
     }
 }

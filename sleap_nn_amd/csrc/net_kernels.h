@@ -74,6 +74,8 @@ struct GemmArgs {
   int mode = 0;                     // 0: row = pixel (Linear); 1: 2x2/stride-2 patches; 2: 3x3 "same" conv
   int H = 0, W = 0;                 // input spatial size (modes 1, 2)
   int act = 0;                      // 0 none, 1 ReLU, 2 GELU
+  unsigned long long* probe = nullptr;  // diagnostic builds (PH_GEMM_STAMP) only
+  int late_split = 0;               // which waves issue their DMA pieces one step late (see gemm_mfma_dma_kernel)
 };
 
 int launch_patch_stem(const PatchStemArgs& a, hipStream_t s);
