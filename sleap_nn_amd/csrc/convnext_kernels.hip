@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "common.h"
+#include "device_math.h"
 #include "net_kernels.h"
 
 namespace ph {
@@ -235,23 +236,6 @@ int launch_layernorm(const float* src, const float* gamma, const float* beta, fl
 //   and one's epilogue overlaps the other's main loop.
 //   Epilogues: bias; + ReLU; + GELU (erf form); layer_scale * (acc + bias) + residual.
 // ---------------------------------------------------------------------------------------
-// erf as ATen's vectorised CPU kernels compute it (Abramowitz-Stegun 7.1.26, |err| <= 1.5e-7):
-// branch-free, and the same approximation the reference's GELU runs through on the CPU.  The
-// reciprocal and the exponential use the hardware v_rcp_f32 / v_exp_f32 (1 ulp; the exponent's
-// argument rounding adds <= 3e-7 absolute to erf for |x| <= 3 and less beyond): 14 instructions
-// instead of ~45 with IEEE division and libm expf, which matters in a GEMM epilogue.
-__device__ __forceinline__ float erf_as(float x) {
-  const float ax = fabsf(x);
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
-  float p = fmaf(1.061405429f, t, -1.453152027f);
-  p = fmaf(p, t, 1.421413741f);
-  p = fmaf(p, t, -0.284496736f);
-  p = fmaf(p, t, 0.254829592f);
-  const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * x * x);
-  const float r = fmaf(-p * t, e, 1.0f);
-  return copysignf(r, x);
-}
-
 template <int MODE, int MT, int NTW, int WM, int WN, int NSTAGE, int MINW>
 __global__ __launch_bounds__(WM* WN * 64, MINW) void gemm_mfma_dma_kernel(GemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -508,7 +492,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void gemm_mfma_dma_kernel(GemmAr
         for (int e = 0; e < 4; ++e) {
           float x = acc[m][n][4 * q + e] + bias4[q][e];
           if (a.act == 1) x = fmaxf(x, 0.f);
-          if (a.act == 2) x = 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752440f));
+          if (a.act == 2) x = gelu_f(x);
           v[e] = x * scale4[q][e];
         }
         const int col = cbase + 8 * q;

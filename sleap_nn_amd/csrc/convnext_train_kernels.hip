@@ -1,0 +1,473 @@
+// Backward / training kernels of the ConvNeXt encoder ops for gfx950 (MI355X, CDNA4).
+//
+// Autograd semantics restated (the reference trains these modules through torch autograd,
+// training/lightning_modules.py:1850-1922 over architectures/convnext.py:19-130):
+//   GELU (erf) ................ dx = dy * (Phi(x) + x * phi(x))
+//   layer_scale * u + x ....... du = dy * s;  dx += dy;  ds = sum_pixels dy * u
+//   LayerNorm over channels ... dx = rstd * (g*dy - mean_c(g*dy) - xhat * mean_c(g*dy*xhat)),
+//                               dg = sum_pixels dy * xhat,  db = sum_pixels dy
+//   depthwise 7x7 ............. dx = dwconv(dy, flipped kernel);  dw[c][tap] = sum_pixels dy[p] * x[p + tap]
+//   Linear / Conv2d(k2,s2) .... dx: the forward row GEMM on transposed weights;
+//                               dW[n][k] = sum_rows dY[m][n] * A[m][k]  (row-wgrad kernel, MFMA, K = rows)
+//   patch stem ................ dW[co][ci][tap] = sum_pixels dy[p][co] * image[ci, p*stride + tap - 1]
+// All reductions over pixels are two-stage with a fixed combination order (deterministic).
+#include <algorithm>
+
+#include "common.h"
+#include "device_math.h"
+#include "train_kernels.h"
+
+namespace ph {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr float LN_EPS_T = 1e-6f;
+constexpr int RED_SLICES = 1024;
+
+// ---------------------------------------------------------------------------------------
+// Elementwise forward ops of the training (unfused) program.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gelu_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n4) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+    f32x4 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[e] = gelu_f(v[e]);
+    reinterpret_cast<f32x4*>(y)[i] = r;
+  }
+}
+
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ x, float* __restrict__ gx, int accumulate, size_t n4) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+    const f32x4 g = reinterpret_cast<const f32x4*>(gy)[i];
+    f32x4 r = accumulate ? reinterpret_cast<const f32x4*>(gx)[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[e] += g[e] * gelu_grad_f(v[e]);
+    reinterpret_cast<f32x4*>(gx)[i] = r;
+  }
+}
+
+// y = scale[c] * u + x      (CNBlock: layer_scale * block(x) + x)
+__global__ __launch_bounds__(256) void scale_add_fwd_kernel(const float* __restrict__ u, const float* __restrict__ x, const float* __restrict__ scale, float* __restrict__ y,
+                                                            int cp4, size_t n4) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const f32x4 s = reinterpret_cast<const f32x4*>(scale)[i % cp4];
+    const f32x4 a = reinterpret_cast<const f32x4*>(u)[i], b = reinterpret_cast<const f32x4*>(x)[i];
+    reinterpret_cast<f32x4*>(y)[i] = a * s + b;
+  }
+}
+
+// du = dy * scale;  dx (+)= dy
+__global__ __launch_bounds__(256) void scale_add_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ scale, float* __restrict__ gu, float* __restrict__ gx,
+                                                            int acc_x, int cp4, size_t n4) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const f32x4 s = reinterpret_cast<const f32x4*>(scale)[i % cp4];
+    const f32x4 g = reinterpret_cast<const f32x4*>(gy)[i];
+    reinterpret_cast<f32x4*>(gu)[i] = g * s;
+    reinterpret_cast<f32x4*>(gx)[i] = acc_x ? reinterpret_cast<const f32x4*>(gx)[i] + g : g;
+  }
+}
+
+static inline unsigned ew_blocks(size_t n4) { return (unsigned)std::min<size_t>((n4 + 255) / 256, 256 * 64); }
+
+int launch_gelu_fwd(const float* x, float* y, size_t n, hipStream_t s) {
+  hipLaunchKernelGGL(gelu_fwd_kernel, dim3(ew_blocks(n / 4)), dim3(256), 0, s, x, y, n / 4);
+  PH_HIP_CHECK(hipGetLastError());
+  return PH_OK;
+}
+int launch_gelu_bwd(const float* gy, const float* x, float* gx, int accumulate, size_t n, hipStream_t s) {
+  hipLaunchKernelGGL(gelu_bwd_kernel, dim3(ew_blocks(n / 4)), dim3(256), 0, s, gy, x, gx, accumulate, n / 4);
+  PH_HIP_CHECK(hipGetLastError());
+  return PH_OK;
+}
+int launch_scale_add_fwd(const float* u, const float* x, const float* scale, float* y, int cp, size_t n, hipStream_t s) {
+  hipLaunchKernelGGL(scale_add_fwd_kernel, dim3(ew_blocks(n / 4)), dim3(256), 0, s, u, x, scale, y, cp / 4, n / 4);
+  PH_HIP_CHECK(hipGetLastError());
+  return PH_OK;
+}
+int launch_scale_add_bwd(const float* gy, const float* scale, float* gu, float* gx, int acc_x, int cp, size_t n, hipStream_t s) {
+  hipLaunchKernelGGL(scale_add_bwd_kernel, dim3(ew_blocks(n / 4)), dim3(256), 0, s, gy, scale, gu, gx, acc_x, cp / 4, n / 4);
+  PH_HIP_CHECK(hipGetLastError());
+  return PH_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// Per-channel reductions over pixels: out[c] = sum_p a[p][c] * b[p][c]   (b == nullptr: sum of a)
+// or, with per-pixel statistics, sum_p a[p][c] * (b[p][c] - mean[p]) * rstd[p]  (LayerNorm weight grad).
+// Two stage, fixed order.  Layout of `partial`: RED_SLICES x cp.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void chan_reduce_partial_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ stats /* npix x 2 or null */,
+                                                                  size_t npix, int cp, float* __restrict__ partial) {
+  __shared__ float red[256];
+  const int sl = blockIdx.x;
+  const size_t per = (npix + RED_SLICES - 1) / RED_SLICES;
+  const size_t lo = (size_t)sl * per, hi = std::min(npix, lo + per);
+  const int cw = min(cp, 256), rows = 256 / cw;
+  const int c0 = threadIdx.x % cw, r = threadIdx.x / cw;
+  for (int cb = 0; cb < cp; cb += cw) {
+    const int c = cb + c0;
+    float acc = 0.f;
+    if (r < rows && c < cp)
+      for (size_t p = lo + r; p < hi; p += rows) {
+        const float av = a[p * cp + c];
+        float bv = b ? b[p * cp + c] : 1.0f;
+        if (stats) bv = (bv - stats[2 * p]) * stats[2 * p + 1];
+        acc += av * bv;
+      }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if (r == 0 && c < cp) {
+      float s = 0.f;
+      for (int k = 0; k < rows; ++k) s += red[k * cw + c0];
+      partial[(size_t)sl * cp + c] = s;
+    }
+    __syncthreads();
+  }
+}
+__global__ void chan_reduce_final_kernel(const float* __restrict__ partial, int cp, int c, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= c) return;
+  float s = 0.f;
+  for (int k = 0; k < RED_SLICES; ++k) s += partial[(size_t)k * cp + i];
+  out[i] = s;
+}
+int launch_chan_reduce(const float* a, const float* b, const float* stats, size_t npix, int cp, int c, float* out, float* scratch, hipStream_t s) {
+  hipLaunchKernelGGL(chan_reduce_partial_kernel, dim3(RED_SLICES), dim3(256), 0, s, a, b, stats, npix, cp, scratch);
+  hipLaunchKernelGGL(chan_reduce_final_kernel, dim3((c + 255) / 256), dim3(256), 0, s, scratch, cp, c, out);
+  PH_HIP_CHECK(hipGetLastError());
+  return PH_OK;
+}
+int64_t chan_reduce_scratch_floats(int cp) { return (int64_t)RED_SLICES * cp; }
+
+// ---------------------------------------------------------------------------------------
+// LayerNorm backward (data gradient).  16 lanes per pixel as in the forward; mean / rstd are
+// recomputed from the saved input and also written to `stats` (npix x 2) for the weight gradient.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gy, const float* __restrict__ gamma,
+                                                            float* __restrict__ gx, float* __restrict__ stats, int accumulate, int c, int cp, size_t npix) {
+  const int sub = threadIdx.x & 15;
+  const int quads = cp >> 2;
+  const float inv_c = 1.0f / (float)c;
+  const size_t stride = (size_t)gridDim.x * 16;
+  const size_t rounds = (npix + stride - 1) / stride;
+  size_t pix = (size_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+  auto red16 = [](float v) {
+    v += __shfl_xor(v, 8, 16);
+    v += __shfl_xor(v, 4, 16);
+    v += __shfl_xor(v, 2, 16);
+    v += __shfl_xor(v, 1, 16);
+    return v;
+  };
+  for (size_t it = 0; it < rounds; ++it, pix += stride) {
+    const bool live = pix < npix;
+    const size_t pp = live ? pix : npix - 1;
+    const float* px = x + pp * cp;
+    const float* pg = gy + pp * cp;
+    float s = 0.f;
+    for (int q = sub; q < quads; q += 16) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(px + q * 4);
+      s += (v[0] + v[1]) + (v[2] + v[3]);
+    }
+    const float mean = red16(s) * inv_c;
+    float ss = 0.f;
+    for (int q = sub; q < quads; q += 16) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(px + q * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float d = v[e] - mean;
+        ss += (q * 4 + e < c) ? d * d : 0.f;
+      }
+    }
+    const float rstd = 1.0f / sqrtf(red16(ss) * inv_c + LN_EPS_T);
+    float s1 = 0.f, s2 = 0.f;  // sum_c g*dy, sum_c g*dy*xhat   (gamma is zero-padded: pad channels drop out)
+    for (int q = sub; q < quads; q += 16) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(px + q * 4);
+      const f32x4 g = *reinterpret_cast<const f32x4*>(pg + q * 4);
+      const f32x4 w = *reinterpret_cast<const f32x4*>(gamma + q * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float a = g[e] * w[e];
+        s1 += a;
+        s2 += a * ((v[e] - mean) * rstd);
+      }
+    }
+    const float m1 = red16(s1) * inv_c, m2 = red16(s2) * inv_c;
+    if (live) {
+      if (sub == 0) {
+        stats[2 * pix] = mean;
+        stats[2 * pix + 1] = rstd;
+      }
+      float* o = gx + pix * cp;
+      for (int q = sub; q < quads; q += 16) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(px + q * 4);
+        const f32x4 g = *reinterpret_cast<const f32x4*>(pg + q * 4);
+        const f32x4 w = *reinterpret_cast<const f32x4*>(gamma + q * 4);
+        f32x4 r = accumulate ? *reinterpret_cast<const f32x4*>(o + q * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float xh = (v[e] - mean) * rstd;
+          const float d = rstd * (g[e] * w[e] - m1 - xh * m2);
+          r[e] += (q * 4 + e < c) ? d : 0.f;
+        }
+        *reinterpret_cast<f32x4*>(o + q * 4) = r;
+      }
+    }
+  }
+}
+int launch_layernorm_bwd(const float* x, const float* gy, const float* gamma, float* gx, float* stats, int accumulate, int c, int cp, size_t npix, hipStream_t s) {
+  const int blocks = (int)std::min<size_t>((npix + 15) / 16, 256 * 32);
+  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks), dim3(256), 0, s, x, gy, gamma, gx, stats, accumulate, c, cp, npix);
+  PH_HIP_CHECK(hipGetLastError());
+  return PH_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// Depthwise 7x7 weight gradient.  One thread = one channel, marching along one image row with
+// the 7x7 input window in registers (7 new loads + 1 gradient load per 49 FMAs; lanes run over
+// channels, so every load is coalesced).  Workgroup = 64 channels x 4 rows; partial[slice][tap][cp].
+// ---------------------------------------------------------------------------------------
+constexpr int DWG_SLICES = 512;
+__global__ __launch_bounds__(256) void dwconv7_wgrad_partial_kernel(const float* __restrict__ x, const float* __restrict__ gy, int B, int H, int W, int cp,
+                                                                    float* __restrict__ partial) {
+  __shared__ float red[4][64];
+  const int lane_c = threadIdx.x & 63, rsub = threadIdx.x >> 6;
+  const int c = blockIdx.y * 64 + lane_c;
+  const bool cok = c < cp;
+  const int cc = cok ? c : cp - 1;
+  const int rows = B * H;
+  float acc[49];
+#pragma unroll
+  for (int t = 0; t < 49; ++t) acc[t] = 0.f;
+  for (int row = blockIdx.x * 4 + rsub; row < rows; row += gridDim.x * 4) {
+    const int b = row / H, y = row - b * H;
+    const float* xb = x + (size_t)b * H * W * cp + cc;
+    const float* gr = gy + ((size_t)row * W) * cp + cc;
+    float win[7][7];  // win[ky][j]: input at row y+ky-3, column (current x) + j - 3
+#pragma unroll
+    for (int ky = 0; ky < 7; ++ky)
+#pragma unroll
+      for (int j = 0; j < 7; ++j) {
+        const int iy = y + ky - 3, ix = j - 3 - 1;  // primed for x = -1: the loop shifts before use
+        win[ky][j] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? xb[((size_t)iy * W + ix) * cp] : 0.f;
+      }
+    for (int xx = 0; xx < W; ++xx) {
+#pragma unroll
+      for (int ky = 0; ky < 7; ++ky) {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) win[ky][j] = win[ky][j + 1];
+        const int iy = y + ky - 3, ix = xx + 3;
+        const int cy = min(max(iy, 0), H - 1), cx = min(ix, W - 1);
+        const float v = xb[((size_t)cy * W + cx) * cp];
+        win[ky][6] = (iy >= 0 && iy < H && ix < W) ? v : 0.f;
+      }
+      const float g = gr[(size_t)xx * cp];
+#pragma unroll
+      for (int ky = 0; ky < 7; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 7; ++kx) acc[ky * 7 + kx] = fmaf(g, win[ky][kx], acc[ky * 7 + kx]);
+    }
+  }
+  // combine the four row streams of the workgroup in a fixed order
+  for (int t = 0; t < 49; ++t) {
+    red[rsub][lane_c] = acc[t];
+    __syncthreads();
+    if (rsub == 0 && cok) partial[((size_t)blockIdx.x * 49 + t) * cp + c] = (red[0][lane_c] + red[1][lane_c]) + (red[2][lane_c] + red[3][lane_c]);
+    __syncthreads();
+  }
+}
+__global__ void dwconv7_wgrad_final_kernel(const float* __restrict__ partial, int n_slices, int cp, int c, float* __restrict__ gw /* (C,1,7,7) */) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= c * 49) return;
+  const int ch = i / 49, t = i - ch * 49;
+  float s = 0.f;
+  for (int k = 0; k < n_slices; ++k) s += partial[((size_t)k * 49 + t) * cp + ch];
+  gw[i] = s;
+}
+static int dwg_slices(int B, int H) { return std::max(1, std::min(DWG_SLICES, (B * H + 3) / 4)); }
+int launch_dwconv7_wgrad(const float* x, const float* gy, int B, int H, int W, int cp, int c, float* gw, float* scratch, hipStream_t s) {
+  const int slices = dwg_slices(B, H);
+  hipLaunchKernelGGL(dwconv7_wgrad_partial_kernel, dim3(slices, (cp + 63) / 64), dim3(256), 0, s, x, gy, B, H, W, cp, scratch);
+  hipLaunchKernelGGL(dwconv7_wgrad_final_kernel, dim3((c * 49 + 255) / 256), dim3(256), 0, s, scratch, slices, cp, c, gw);
+  PH_HIP_CHECK(hipGetLastError());
+  return PH_OK;
+}
+int64_t dwconv7_wgrad_scratch_floats(int B, int H, int cp) { return (int64_t)dwg_slices(B, H) * 49 * cp; }
+
+// ---------------------------------------------------------------------------------------
+// Row weight gradient on MFMA:  dW[n][k] = sum_m dY[m][n] * A[m][k]   (Linear: A row m = pixel m;
+// Conv2d k2 s2: A row m = pixel (b, 2oy + dy, 2ox + dx) of the input, one launch per tap).
+//   GEMM with M = n (dY channel), N = k (A channel), K = rows.  Both operands are read the way they
+//   lie in memory (row-major over channels), staged per 32-row chunk as [row][128 channels] in LDS;
+//   an MFMA fragment is ONE dword per lane (lane = channel, lane >> 5 = which of the two rows of the
+//   k-pair): ds_read_b32 with the lanes running over channels is conflict-free.
+//   Workgroup = 256 threads, tile 128 (n) x 128 (k), wave = 64 x 64; the row range is split over
+//   blockIdx.y slices so the grid fills the chip; partial tiles go to a slab, a second kernel adds
+//   the slices in a fixed order into the canonical gradient.
+// ---------------------------------------------------------------------------------------
+constexpr int RW_ROWS = 32;
+__global__ __launch_bounds__(256, 2) void row_wgrad_kernel(RowWgradArgs a) {
+  __shared__ __attribute__((aligned(16))) float sY[2][RW_ROWS * 128];
+  __shared__ __attribute__((aligned(16))) float sA[2][RW_ROWS * 128];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lx = lane & 31, lh = lane >> 5;
+  const int n_kt = (a.kp + 127) / 128;
+  const int nt = blockIdx.x / n_kt, kt = blockIdx.x - nt * n_kt;
+  const int slice = blockIdx.y, n_slices = gridDim.y;
+  const int wn = wave >> 1, wk = wave & 1;  // wave tile: n in [wn*64, +64), k in [wk*64, +64)
+  const int chunks = (a.M + RW_ROWS - 1) / RW_ROWS;
+  const int per = (chunks + n_slices - 1) / n_slices;
+  const int c_lo = slice * per, c_hi = min(chunks, c_lo + per);
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // staging: thread t moves float4 #(t & 31) of rows (t >> 5) + 8 * i, i = 0..3, of both operands
+  const int sq = tid & 31, sr = tid >> 5;
+  auto stage = [&](int chunk, int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = sr + 8 * i;
+      const int m = chunk * RW_ROWS + row;
+      const bool ok = m < a.M;
+      const int mm = ok ? m : a.M - 1;
+      const int cy = nt * 128 + sq * 4, ck = kt * 128 + sq * 4;
+      f32x4 vy = {0.f, 0.f, 0.f, 0.f}, va = {0.f, 0.f, 0.f, 0.f};
+      if (ok && cy < a.np) vy = *reinterpret_cast<const f32x4*>(a.dy + (size_t)mm * a.np + cy);
+      if (ok && ck < a.kp) {
+        size_t pix = (size_t)mm;
+        if (a.patch) {  // output pixel (b, oy, ox) -> input pixel (b, 2oy + dy, 2ox + dx)
+          const int ow = a.W >> 1, oh = a.H >> 1;
+          const int ox = mm % ow;
+          const int r2 = mm / ow;
+          const int oy = r2 % oh;
+          pix = ((size_t)(r2 / oh) * a.H + 2 * oy + (a.tap >> 1)) * a.W + 2 * ox + (a.tap & 1);
+        }
+        va = *reinterpret_cast<const f32x4*>(a.x + pix * a.kp + ck);
+      }
+      *reinterpret_cast<f32x4*>(&sY[buf][row * 128 + sq * 4]) = vy;
+      *reinterpret_cast<f32x4*>(&sA[buf][row * 128 + sq * 4]) = va;
+    }
+  };
+
+  if (c_lo < c_hi) stage(c_lo, 0);
+  __syncthreads();
+  for (int ch = c_lo; ch < c_hi; ++ch) {
+    const int buf = (ch - c_lo) & 1;
+    if (ch + 1 < c_hi) stage(ch + 1, buf ^ 1);
+#pragma unroll 4
+    for (int s2 = 0; s2 < RW_ROWS / 2; ++s2) {
+      const int row = 2 * s2 + lh;
+      float fy[2], fa[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) fy[i] = sY[buf][row * 128 + wn * 64 + i * 32 + lx];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) fa[j] = sA[buf][row * 128 + wk * 64 + j * 32 + lx];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fy[i], fa[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // slab[slice][block][128 n][128 k];  D: row(n) = (r&3) + 8*(r>>2) + 4*lh, col(k) = lx
+  float* slab = a.slab + ((size_t)slice * gridDim.x + blockIdx.x) * (128 * 128);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) slab[(size_t)(wn * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 128 + wk * 64 + j * 32 + lx] = acc[i][j][r];
+}
+
+// grad[(n * k_total + k) * taps + tap] = sum_slices slab[...]
+__global__ __launch_bounds__(256) void row_wgrad_reduce_kernel(const float* __restrict__ slab, int n_slices, int n_blocks, int n_kt, int n, int k, int taps, int tap,
+                                                               float* __restrict__ grad) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n * k) return;
+  const int kk = i % k, nn = i / k;
+  const int blk = (nn >> 7) * n_kt + (kk >> 7);
+  float s = 0.f;
+  for (int sl = 0; sl < n_slices; ++sl) s += slab[((size_t)sl * n_blocks + blk) * (128 * 128) + (size_t)(nn & 127) * 128 + (kk & 127)];
+  grad[((size_t)nn * k + kk) * taps + tap] = s;
+}
+
+static int rw_slices(int M, int blocks) {
+  const int chunks = (M + RW_ROWS - 1) / RW_ROWS;
+  const int want = (1024 + blocks - 1) / blocks;  // ~2 workgroups per CU x 2 rounds
+  return std::max(1, std::min(chunks, want));
+}
+int64_t row_wgrad_slab_floats(int M, int n, int k) {
+  const int blocks = ((pad16(n) + 127) / 128) * ((pad16(k) + 127) / 128);
+  return (int64_t)rw_slices(M, blocks) * blocks * 128 * 128;
+}
+int launch_row_wgrad(const RowWgradArgs& a0, int n, int k, int taps, float* grad, hipStream_t s) {
+  RowWgradArgs a = a0;
+  const int n_nt = (a.np + 127) / 128, n_kt = (a.kp + 127) / 128;
+  const int slices = rw_slices(a.M, n_nt * n_kt);
+  hipLaunchKernelGGL(row_wgrad_kernel, dim3(n_nt * n_kt, slices), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(row_wgrad_reduce_kernel, dim3((n * k + 255) / 256), dim3(256), 0, s, a.slab, slices, n_nt * n_kt, n_kt, n, k, taps, a.tap, grad);
+  PH_HIP_CHECK(hipGetLastError());
+  return PH_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// Patch-stem weight gradient: dW[co][ci][ky][kx] = sum_{b,oy,ox} dy[b,oy,ox,co] * img[b,ci,oy*s+ky-1,ox*s+kx-1].
+// Work item = (co, ci*k*k + tap); workgroups walk slices of output pixels; partial[slice][n_out].
+// ---------------------------------------------------------------------------------------
+constexpr int PSW_SLICES = 512;
+__global__ __launch_bounds__(256) void patch_stem_wgrad_partial_kernel(const void* __restrict__ img, int dtype, const float* __restrict__ dy, int B, int cin, int H, int W,
+                                                                      int OH, int OW, int k, int stride, int coutp, int cout, float* __restrict__ partial) {
+  const int kk = k * k;
+  const int n_items = cout * cin * kk;
+  const size_t npix = (size_t)B * OH * OW;
+  const size_t per = (npix + gridDim.x - 1) / gridDim.x;
+  const size_t lo = (size_t)blockIdx.x * per, hi = std::min(npix, lo + per);
+  for (int item = threadIdx.x; item < n_items; item += 256) {
+    const int co = item % cout, ct = item / cout;  // co fastest: the dy reads of a wave are contiguous
+    const int ci = ct / kk, tap = ct - ci * kk;
+    const int ky = tap / k, kx = tap - ky * k;
+    float acc = 0.f;
+    for (size_t p = lo; p < hi; ++p) {
+      const int ox = (int)(p % OW);
+      const size_t r = p / OW;
+      const int oy = (int)(r % OH), b = (int)(r / OH);
+      const int yy = oy * stride + ky - 1, xx = ox * stride + kx - 1;
+      if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+      const size_t o = (((size_t)b * cin + ci) * H + yy) * W + xx;
+      float v;
+      if (dtype == 0)
+        v = (float)reinterpret_cast<const uint8_t*>(img)[o] / 255.0f;
+      else {
+        v = reinterpret_cast<const float*>(img)[o];
+        if (dtype == 2) v = v / 255.0f;
+      }
+      acc = fmaf(v, dy[p * coutp + co], acc);
+    }
+    partial[(size_t)blockIdx.x * n_items + (size_t)co * cin * kk + ct] = acc;
+  }
+}
+__global__ void sum_slices_kernel(const float* __restrict__ partial, int n_slices, int n_out, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_out) return;
+  float s = 0.f;
+  for (int k = 0; k < n_slices; ++k) s += partial[(size_t)k * n_out + i];
+  out[i] = s;
+}
+int launch_patch_stem_wgrad(const void* img, int dtype, const float* dy, int B, int cin, int H, int W, int OH, int OW, int k, int stride, int coutp, int cout, float* gw,
+                            float* scratch, hipStream_t s) {
+  const int n_out = cout * cin * k * k;
+  hipLaunchKernelGGL(patch_stem_wgrad_partial_kernel, dim3(PSW_SLICES), dim3(256), 0, s, img, dtype, dy, B, cin, H, W, OH, OW, k, stride, coutp, cout, scratch);
+  hipLaunchKernelGGL(sum_slices_kernel, dim3((n_out + 255) / 256), dim3(256), 0, s, scratch, PSW_SLICES, n_out, gw);
+  PH_HIP_CHECK(hipGetLastError());
+  return PH_OK;
+}
+int64_t patch_stem_wgrad_scratch_floats(int cin, int cout, int k) { return (int64_t)PSW_SLICES * cout * cin * k * k; }
+
+}  // namespace ph

@@ -21,6 +21,7 @@ struct ConvArgs {
   const float* wpack_dma = nullptr;  // weights in the LDS-DMA layout (quad-major 16-row pieces), or nullptr
   const float* zeros = nullptr;      // >= 64 B of zeros in HBM (source of out-of-image halo pixels for LDS-DMA)
   int accumulate = 0;      // epilogue adds the existing dst value (gradient accumulation in the backward pass)
+  int dma_stagger = 1;     // LDS-DMA kernel: SIMD-partner waves issue their DMA piece at different points of a step
   float* dst_pool = nullptr;  // optional fused 2x2/2 max pool of the (ReLU'd) output, NHWC ceil(H/2) x ceil(W/2); nullptr = off
 };
 

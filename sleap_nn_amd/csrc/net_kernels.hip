@@ -14,6 +14,8 @@
 //   ConvTranspose2d(k3,s2,p1,op1) .... encoder_decoder.py:439-461
 //   1x1 head conv .................... architectures/heads.py:58-67
 //   uint8 -> float /255 .............. data/normalization.py:7-35
+#include <type_traits>
+
 #include "common.h"
 #include "net_kernels.h"
 
@@ -482,41 +484,52 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mfma_dma_kernel(ConvArgs a) {
   for (int s = 0; s < SLOTS; ++s) dma_slot(s, buf0);
   __syncthreads();  // drains the DMA (vmcnt(0)) and publishes the buffer
 
-  for (int ch = 0; ch < nchunks; ++ch) {
-    float* cur = (ch & 1) ? buf1 : buf0;
-    float* nxt = (ch & 1) ? buf0 : buf1;
-    select_chunk(min(ch + 1, nchunks - 1));  // last chunk: refetch itself into the idle buffer (harmless, branch-free)
-    f32x4 af[2][2], bf[2][NT];
-    auto load_frags = [&](int step, int fb) {
-      const int tap = step >> 1, g = step & 1;
-      const int ky = tap / 3, kx = tap - ky * 3;
+  // Waves i and i + 4 share SIMD i (measured); an LDS-DMA wave-instruction occupies its wave for
+  // 60-185 cycles, so the two partners must not issue theirs at the same point of a step: the
+  // upper four waves ("late") place the step's DMA piece after 6*NT of its MFMAs, the lower four
+  // after 2*NT -- while one partner feeds the DMA engine the other feeds the MFMA pipe.
+  auto k_loop = [&](auto late) {
+    constexpr bool LATE = decltype(late)::value;
+    for (int ch = 0; ch < nchunks; ++ch) {
+      float* cur = (ch & 1) ? buf1 : buf0;
+      float* nxt = (ch & 1) ? buf0 : buf1;
+      select_chunk(min(ch + 1, nchunks - 1));  // last chunk: refetch itself into the idle buffer (harmless, branch-free)
+      f32x4 af[2][2], bf[2][NT];
+      auto load_frags = [&](int step, int fb) {
+        const int tap = step >> 1, g = step & 1;
+        const int ky = tap / 3, kx = tap - ky * 3;
 #pragma unroll
-      for (int m = 0; m < 2; ++m) af[fb][m] = *reinterpret_cast<const f32x4*>(cur + offA[m + ky][kx] + g * 128);
+        for (int m = 0; m < 2; ++m) af[fb][m] = *reinterpret_cast<const f32x4*>(cur + offA[m + ky][kx] + g * 128);
 #pragma unroll
-      for (int n = 0; n < NT; ++n) bf[fb][n] = *reinterpret_cast<const f32x4*>(cur + offB + tap * (BN / 16) * 256 + n * 512 + g * 128);
-    };
-    load_frags(0, 0);
+        for (int n = 0; n < NT; ++n) bf[fb][n] = *reinterpret_cast<const f32x4*>(cur + offB + tap * (BN / 16) * 256 + n * 512 + g * 128);
+      };
+      load_frags(0, 0);
 #pragma unroll
-    for (int step = 0; step < 18; ++step) {
-      const int fcur = step & 1;
-      if (step + 1 < 18) load_frags(step + 1, fcur ^ 1);
-      if (step < SLOTS) dma_slot(step, nxt);
+      for (int step = 0; step < 18; ++step) {
+        const int fcur = step & 1;
+        if (step + 1 < 18) load_frags(step + 1, fcur ^ 1);
+        if (step < SLOTS) dma_slot(step, nxt);
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+          for (int m = 0; m < 2; ++m)
 #pragma unroll
-          for (int n = 0; n < NT; ++n)
-            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[fcur][m][j], bf[fcur][n][j], acc[m][n], 0, 0, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 2 + NT, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 2 * NT, 0);
-      __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
-      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 6 * NT, 0);
-      __builtin_amdgcn_sched_barrier(0);
+            for (int n = 0; n < NT; ++n)
+              acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[fcur][m][j], bf[fcur][n][j], acc[m][n], 0, 0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 + NT, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, LATE ? 6 * NT : 2 * NT, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, LATE ? 2 * NT : 6 * NT, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __syncthreads();  // vmcnt(0) + barrier: next buffer landed everywhere, this one is free again
     }
-    __syncthreads();  // vmcnt(0) + barrier: next buffer landed everywhere, this one is free again
-  }
+  };
+  if (a.dma_stagger && wave >= 4)  // wave-uniform; both paths execute the same barriers
+    k_loop(std::true_type{});
+  else
+    k_loop(std::false_type{});
 
   // ---- epilogue (same C/D map as the register-staged kernel)
 #pragma unroll
@@ -569,7 +582,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mfma_dma_kernel(ConvArgs a) {
   }
 }
 
-int launch_conv3x3_dma(const ConvArgs& a, hipStream_t s) {
+int launch_conv3x3_dma(const ConvArgs& a_in, hipStream_t s) {
+  ConvArgs a = a_in;
+  static const int stagger = getenv("PH_CONV_DMA_STAGGER") ? atoi(getenv("PH_CONV_DMA_STAGGER")) : 1;  // experiment knob
+  a.dma_stagger = stagger;
   const int tiles = ((a.W + TW - 1) / TW) * ((a.H + D_TH - 1) / D_TH) * a.B;
   if (a.bn == 64) {
     const size_t lds = (size_t)2 * (D_A_PIECES + 9 * 64 / 16) * 1024;
