@@ -76,7 +76,11 @@ enum ph_op_kind {
   PH_OP_LINEAR = 11,    /* per-pixel Linear(cin0 -> cout), weight (cout, cin0) + bias; PH_FLAG_GELU: erf-GELU
                            epilogue (block[3..4]); PH_FLAG_SCALE_RESIDUAL: dst = weight2[c] * (acc + bias) +
                            src1 (block[5], layer_scale, residual add)                                    */
-  PH_OP_PATCH_CONV = 12 /* Conv2d(k2, s2) + bias, weight (cout, cin0, 2, 2)  (convnext.py:101-110)      */
+  PH_OP_PATCH_CONV = 12, /* Conv2d(k2, s2) + bias, weight (cout, cin0, 2, 2)  (convnext.py:101-110)     */
+  /* the two epilogues of PH_OP_LINEAR as ops of their own: the training program keeps the
+     pre-activation tensors that autograd needs (GELU input, un-scaled block output)              */
+  PH_OP_GELU = 13,      /* dst = GELU_erf(src0)                                                          */
+  PH_OP_SCALE_ADD = 14  /* dst = weight[c] * src0 + src1   (layer_scale * block(x) + x)                  */
 };
 
 #define PH_FLAG_RELU 1

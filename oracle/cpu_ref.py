@@ -1076,10 +1076,10 @@ def ohkm_loss(y_gt: torch.Tensor, y_pr: torch.Tensor, hard_to_easy_ratio=2.0, mi
 
 
 def training_step(sd: Dict[str, torch.Tensor], bb: dict, head_cfgs: dict, model_type: str, image: torch.Tensor, targets: Dict[str, torch.Tensor],
-                  loss_weights: Sequence[float], ohkm: Optional[dict] = None):
+                  loss_weights: Sequence[float], ohkm: Optional[dict] = None, backbone: str = "unet"):
     """Forward + weighted per-head MSE (+OHKM) + autograd backward.  Returns (losses [total, heads...], grads dict)."""
     params = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
-    out = model_forward(params, bb, head_cfgs, model_type, image)
+    out = model_forward(params, bb, head_cfgs, model_type, image, backbone=backbone)
     heads = [h for h, _ in HEAD_ORDER[model_type]]
     hl = []
     for h in heads:

@@ -120,11 +120,14 @@ class ConvNextWrapper:
         y = self._layernorm(name + ".block.2", y, c)
         p[name + ".block.3.weight"] = (4 * c, c)
         p[name + ".block.3.bias"] = (4 * c,)
-        y = self._emit(OpSpec(L.OP_LINEAR, y, -1, self._new_slot(), c, 0, 4 * c, 1, L.FLAG_GELU, name + ".block.3.weight", name + ".block.3.bias", label=name + ".block.3"))
+        # unfused form (what training runs: autograd needs the GELU input and the un-scaled block output);
+        # Model._fuse_cnblocks folds GELU and layer-scale + residual into the GEMM epilogues for inference
+        y = self._emit(OpSpec(L.OP_LINEAR, y, -1, self._new_slot(), c, 0, 4 * c, 1, 0, name + ".block.3.weight", name + ".block.3.bias", label=name + ".block.3"))
+        y = self._emit(OpSpec(L.OP_GELU, y, -1, self._new_slot(), 4 * c, 0, 4 * c, 1, 0, label=name + ".block.4"))
         p[name + ".block.5.weight"] = (c, 4 * c)
         p[name + ".block.5.bias"] = (c,)
-        y = self._emit(OpSpec(L.OP_LINEAR, y, x, self._new_slot(), 4 * c, 0, c, 1, L.FLAG_SCALE_RESIDUAL, name + ".block.5.weight", name + ".block.5.bias",
-                              label=name, weight2=name + ".layer_scale"))
+        y = self._emit(OpSpec(L.OP_LINEAR, y, -1, self._new_slot(), 4 * c, 0, c, 1, 0, name + ".block.5.weight", name + ".block.5.bias", label=name + ".block.5"))
+        y = self._emit(OpSpec(L.OP_SCALE_ADD, y, x, self._new_slot(), c, 0, c, 1, 0, name + ".layer_scale", label=name))
         self.labels[name] = y
         return y
 

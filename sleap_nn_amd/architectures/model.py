@@ -65,7 +65,7 @@ class Model:
             flags = L.FLAG_SIGMOID if isinstance(head, ClassMapsHead) else 0
             self.ops.append(OpSpec(L.OP_HEAD, src, -1, -1, cin, 0, head.channels, 1, flags, name + ".weight", name + ".bias", out_index=i, label=name))
         self.unfused_ops = list(self.ops)
-        self.fused_ops = self._fuse_pools(self._fuse_stem(self.ops))
+        self.fused_ops = self._fuse_cnblocks(self._fuse_pools(self._fuse_stem(self.ops)))
         self.ops = self.fused_ops
         self._state: Dict[str, torch.Tensor] = {k: torch.zeros(v, dtype=torch.float32) for k, v in self.param_shapes.items()}
         self._handle = None
@@ -114,6 +114,38 @@ class Model:
                 out.append(f)
                 i += 2
                 continue
+            out.append(op)
+            i += 1
+        return out
+
+    @staticmethod
+    def _fuse_cnblocks(ops: List[OpSpec]) -> List[OpSpec]:
+        """LINEAR -> GELU and LINEAR -> SCALE_ADD pairs become one row GEMM with the activation /
+        ``layer_scale * u + x`` in its epilogue (the 4C-wide pre-activation and the un-scaled block
+        output then never exist in HBM)."""
+        import copy
+
+        def readers(slot, skip):
+            return [o for o in ops if o is not skip and (o.src0 == slot or o.src1 == slot)]
+
+        out: List[OpSpec] = []
+        i = 0
+        while i < len(ops):
+            op = ops[i]
+            nxt = ops[i + 1] if i + 1 < len(ops) else None
+            if op.kind == L.OP_LINEAR and op.flags == 0 and nxt is not None and nxt.src0 == op.dst and not readers(op.dst, nxt):
+                if nxt.kind == L.OP_GELU:
+                    f = copy.copy(op)
+                    f.flags, f.dst = L.FLAG_GELU, nxt.dst
+                    out.append(f)
+                    i += 2
+                    continue
+                if nxt.kind == L.OP_SCALE_ADD:
+                    f = copy.copy(op)
+                    f.flags, f.dst, f.src1, f.weight2, f.label = L.FLAG_SCALE_RESIDUAL, nxt.dst, nxt.src1, nxt.weight, nxt.label
+                    out.append(f)
+                    i += 2
+                    continue
             out.append(op)
             i += 1
         return out
@@ -318,7 +350,7 @@ class Model:
                 oh, ow = (h + 1) // 2, (w + 1) // 2
             elif op.kind in (L.OP_UPSAMPLE, L.OP_CONVT):
                 oh, ow = 2 * h, 2 * w
-            cin = op.cin0 + (op.cin1 if op.kind != L.OP_LINEAR else 0)
+            cin = op.cin0 + (op.cin1 if op.kind not in (L.OP_LINEAR, L.OP_SCALE_ADD) else 0)
             cout = op.cout if op.kind not in (L.OP_POOL, L.OP_UPSAMPLE) else op.cin0
             flops = 0.0
             if op.kind in (L.OP_CONV, L.OP_INPUT_CONV):

@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void dwconv7_kernel(DwConvArgs a) {
     const int y = (int)(p % a.H);
     const int b = (int)(p / a.H);
     const int x0 = st * DW_STRIP;
-    const f32x4 bias = *reinterpret_cast<const f32x4*>(a.bias + gq * 4);
+    const f32x4 bias = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + gq * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
     f32x4 acc[DW_STRIP];
 #pragma unroll
     for (int o = 0; o < DW_STRIP; ++o) acc[o] = bias;
@@ -141,7 +141,10 @@ __global__ __launch_bounds__(256) void dwconv7_kernel(DwConvArgs a) {
     float* drow = a.dst + ((size_t)(b * a.H + y) * a.W) * a.cp + gq * 4;
 #pragma unroll
     for (int o = 0; o < DW_STRIP; ++o)
-      if (x0 + o < a.W) *reinterpret_cast<f32x4*>(drow + (size_t)(x0 + o) * a.cp) = acc[o];
+      if (x0 + o < a.W) {
+        f32x4* dp = reinterpret_cast<f32x4*>(drow + (size_t)(x0 + o) * a.cp);
+        *dp = a.accumulate ? *dp + acc[o] : acc[o];
+      }
   }
 }
 
@@ -484,7 +487,16 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void gemm_mfma_dma_kernel(GemmAr
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
       const int row = m0 + (wm * MT + m) * 32 + lx;
-      const size_t rofs = (size_t)min(row, a.M - 1) * a.coutp;
+      size_t opix = (size_t)min(row, a.M - 1);
+      if (a.out_patch) {
+        const int ow = a.out_W >> 1, oh = a.out_H >> 1;
+        const int rr = (int)opix;
+        const int ox = rr % ow;
+        const int r2 = rr / ow;
+        const int oy = r2 % oh;
+        opix = ((size_t)(r2 / oh) * a.out_H + 2 * oy + (a.out_tap >> 1)) * a.out_W + 2 * ox + (a.out_tap & 1);
+      }
+      const size_t rofs = opix * a.coutp;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         f32x4 v;

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "model_internal.h"
+#include "train_kernels.h"
 
 namespace ph {
 
@@ -207,7 +208,7 @@ int build_plan(const ph_model* m, int B, int H, int W, Plan& plan) {
       oh = h / 2;
       ow = w / 2;
       PH_REQUIRE(oh > 0 && ow > 0, "input of a 2x2/stride-2 convolution is smaller than 2x2");
-    } else if (d.kind == PH_OP_LINEAR && (d.flags & PH_FLAG_SCALE_RESIDUAL)) {
+    } else if ((d.kind == PH_OP_LINEAR && (d.flags & PH_FLAG_SCALE_RESIDUAL)) || d.kind == PH_OP_SCALE_ADD) {
       PH_REQUIRE(d.src1 >= 0 && d.src1 < m->n_slots && plan.slots[d.src1].offset >= 0, "residual slot %d is not written yet", d.src1);
       const SlotShape& s1 = plan.slots[d.src1];
       PH_REQUIRE(s1.h == h && s1.w == w && s1.c == d.cout, "residual shape mismatch");
@@ -329,7 +330,13 @@ ph_model* ph_model_create(const ph_op_desc* ops, int32_t n_ops, const float* con
     switch (d.kind) {
       case PH_OP_POOL:
       case PH_OP_UPSAMPLE:
+      case PH_OP_GELU:
         break;
+      case PH_OP_SCALE_ADD: {
+        if (!widx_ok(d.weight) || weight_numel[d.weight] != d.cout || d.cin0 != d.cout || d.src1 < 0) return fail("scale-add needs a (C) scale and two sources", i);
+        ok = pack_upload(m, pad_vec(pad16(d.cout), d.cout), weights[d.weight], index_array(d.weight), &op.w_dev) == PH_OK;
+        break;
+      }
       case PH_OP_STEM: {
         if (d.ksize != 3 || d.cmid < 1 || d.cmid > 16 || d.cout < 1 || d.cout > 16 || (d.cin0 != 1 && d.cin0 != 3))
           return fail("fused stem needs kernel 3, 1 or 3 input channels and <= 16 filters", i);
@@ -454,8 +461,14 @@ ph_model* ph_model_create(const ph_op_desc* ops, int32_t n_ops, const float* con
           for (int c = 0; c < d.cout; ++c)
             for (int tap = 0; tap < 49; ++tap) out[(size_t)tap * cp + c] = w[(size_t)c * 49 + tap];
         };
+        auto pack_dw_flip = [&](const auto* w, auto& out) {  // data gradient = the same kernel on the spatially flipped taps
+          out.assign((size_t)49 * cp, 0);
+          for (int c = 0; c < d.cout; ++c)
+            for (int tap = 0; tap < 49; ++tap) out[(size_t)(48 - tap) * cp + c] = w[(size_t)c * 49 + tap];
+        };
         ok = pack_upload(m, pack_dw, weights[d.weight], index_array(d.weight), &op.w_dev) == PH_OK &&
-             pack_upload(m, pad_vec(cp, d.cout), weights[d.bias], index_array(d.bias), &op.b_dev) == PH_OK;
+             pack_upload(m, pad_vec(cp, d.cout), weights[d.bias], index_array(d.bias), &op.b_dev) == PH_OK &&
+             pack_upload(m, pack_dw_flip, weights[d.weight], index_array(d.weight), &op.dw_flip_dev) == PH_OK;
         break;
       }
       case PH_OP_LAYERNORM: {
@@ -478,6 +491,23 @@ ph_model* ph_model_create(const ph_op_desc* ops, int32_t n_ops, const float* con
         auto pack_g = [&](const auto* w, auto& out) { pack_gemm(w, d.cout, d.cin0, 0, segs, op.bn, out); };
         ok = pack_upload(m, pack_g, weights[d.weight], index_array(d.weight), &op.w_dma_dev) == PH_OK &&
              pack_upload(m, pad_vec(npad, d.cout), weights[d.bias], index_array(d.bias), &op.b_dev) == PH_OK;
+        if (ok) {  // data-gradient weights (training): dX = dY * W, one transposed matrix per tap, + a zero bias
+          const int cinp = pad16(d.cin0);
+          op.bn_dg = gemm_choose_bn(cinp);
+          for (int tap = 0; tap < segs && ok; ++tap) {
+            auto pack_t = [&](const auto* w, auto& out) {
+              std::remove_reference_t<decltype(out)> wt((size_t)d.cin0 * d.cout);
+              for (int co = 0; co < d.cout; ++co)
+                for (int ci = 0; ci < d.cin0; ++ci) wt[(size_t)ci * d.cout + co] = w[((size_t)co * d.cin0 + ci) * segs + tap];
+              pack_gemm(wt.data(), d.cin0, d.cout, 0, 1, op.bn_dg, out);
+            };
+            ok = pack_upload(m, pack_t, weights[d.weight], index_array(d.weight), &op.wd_gemm_dev[tap]) == PH_OK;
+          }
+          if (ok) {
+            std::vector<float> zb((size_t)cinp + 128, 0.f);
+            ok = upload(m, zb, &op.zero_bias_dev) == PH_OK;
+          }
+        }
         if (ok && (d.flags & PH_FLAG_SCALE_RESIDUAL)) {
           if (!widx_ok(d.weight2) || weight_numel[d.weight2] != d.cout || d.src1 < 0) return fail("layer-scale epilogue needs weight2 (C) and a residual source", i);
           ok = pack_upload(m, pad_vec(npad, d.cout), weights[d.weight2], index_array(d.weight2), &op.w2_dev) == PH_OK;
@@ -739,6 +769,17 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
           a.residual = slot_ptr(d.src1);
         }
         rc = launch_gemm(a, s);
+        break;
+      }
+      case PH_OP_GELU: {
+        const SlotShape& s0 = plan.slots[d.src0];
+        rc = launch_gelu_fwd(slot_ptr(d.src0), slot_ptr(d.dst), (size_t)batch * s0.h * s0.w * s0.cp, s);
+        break;
+      }
+      case PH_OP_SCALE_ADD: {
+        const SlotShape& s0 = plan.slots[d.src0];
+        PH_REQUIRE(s0.c == d.cin0, "scale-add channel mismatch");
+        rc = launch_scale_add_fwd(slot_ptr(d.src0), slot_ptr(d.src1), op.w_dev, slot_ptr(d.dst), s0.cp, (size_t)batch * s0.h * s0.w * s0.cp, s);
         break;
       }
       case PH_OP_HEAD: {

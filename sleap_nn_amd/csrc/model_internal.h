@@ -16,6 +16,9 @@ struct PackedOp {
   float* b2_dev = nullptr;
   float* w_dma_dev = nullptr;  // conv weights in the LDS-DMA (quad-major piece) layout
   int bn = 0;
+  float* wd_gemm_dev[4] = {nullptr, nullptr, nullptr, nullptr};  // Linear / 2x2 conv: transposed weights (per tap) for the data gradient
+  int bn_dg = 0;
+  float* dw_flip_dev = nullptr;  // depthwise conv: spatially flipped taps (data gradient)
   float* w_gemm_dev = nullptr;  // 3x3 conv weights in the row-GEMM layout (small feature maps)
   float* b_gemm_dev = nullptr;
   int bn_g = 0;

@@ -56,9 +56,10 @@ struct PatchStemArgs {
 struct DwConvArgs {
   const float* src;   // NHWC cp
   const float* w;     // [49][cp]
-  const float* bias;  // [cp]
+  const float* bias;  // [cp] or nullptr
   float* dst;
   int cp, B, H, W;
+  int accumulate = 0;  // dst += result (data gradient into a slot that already holds the residual branch's gradient)
 };
 
 struct GemmArgs {
@@ -77,6 +78,9 @@ struct GemmArgs {
   int act = 0;                      // 0 none, 1 ReLU, 2 GELU
   unsigned long long* probe = nullptr;  // diagnostic builds (PH_GEMM_STAMP) only
   int late_split = 0;               // which waves issue their DMA pieces one step late (see gemm_mfma_dma_kernel)
+  // output row mapping: 0 = row m; 1 = row m is output pixel (b, oy, ox) of a 2x2/stride-2 conv and the result is
+  // written to input pixel (b, 2oy + (out_tap >> 1), 2ox + (out_tap & 1)) of an out_H x out_W map (its data gradient)
+  int out_patch = 0, out_tap = 0, out_H = 0, out_W = 0;
 };
 
 int launch_patch_stem(const PatchStemArgs& a, hipStream_t s);

@@ -31,9 +31,25 @@ int build_bwd_plan(const ph_model* m, int B, int H, int W, BwdPlan& bp) {
       set_error("backward needs the unfused program with bilinear up-sampling (no stem / conv+pool fusion / transposed conv)");
       return PH_E_INVALID;
     }
-    if (d.kind >= PH_OP_PATCH_STEM) {
-      set_error("backward of the ConvNeXt encoder ops (kind %d) is not implemented yet", d.kind);
+    if (d.kind == PH_OP_LINEAR && (d.flags & (PH_FLAG_GELU | PH_FLAG_SCALE_RESIDUAL))) {
+      set_error("backward needs the unfused ConvNeXt program (GELU / layer-scale as ops of their own)");
       return PH_E_INVALID;
+    }
+    if (d.kind >= PH_OP_PATCH_STEM) {
+      const SlotShape& so = bp.act.slots[d.dst];
+      const int64_t npix = (int64_t)B * so.h * so.w;
+      int64_t need = bias_scratch_floats(so.cp);
+      switch (d.kind) {
+        case PH_OP_PATCH_STEM: need = std::max(need, patch_stem_wgrad_scratch_floats(d.cin0, d.cout, d.ksize)); break;
+        case PH_OP_DWCONV: need = std::max(need, dwconv7_wgrad_scratch_floats(B, so.h, so.cp)); break;
+        case PH_OP_LAYERNORM: need = std::max(need, 2 * npix + chan_reduce_scratch_floats(so.cp)); break;
+        case PH_OP_LINEAR:
+        case PH_OP_PATCH_CONV: need = std::max(need, row_wgrad_slab_floats((int)npix, d.cout, d.cin0)); break;
+        case PH_OP_SCALE_ADD: need = std::max(need, chan_reduce_scratch_floats(so.cp)); break;
+        default: break;
+      }
+      scratch = std::max(scratch, need);
+      continue;
     }
     if (d.kind == PH_OP_HEAD) {
       const SlotShape& s0 = bp.act.slots[d.src0];
@@ -230,6 +246,115 @@ int ph_model_backward(ph_model* m, const void* input_dev, int32_t in_dtype, int3
         PH_REQUIRE(init[d.dst], "upsample output slot %d received no gradient", d.dst);
         rc = launch_upsample_bwd(G(d.dst), batch, si.h, si.w, si.cp, init[d.src0], G(d.src0), s);
         init[d.src0] = 1;
+        break;
+      }
+      case PH_OP_SCALE_ADD: {  // y = s * u + x
+        const SlotShape& so = bp.act.slots[d.dst];
+        PH_REQUIRE(init[d.dst], "scale-add output slot %d received no gradient", d.dst);
+        const size_t npix = (size_t)batch * so.h * so.w;
+        rc = launch_chan_reduce(G(d.dst), A(d.src0), nullptr, npix, so.cp, d.cout, grads_flat_dev + m->weight_offset[d.weight], scratch, s);
+        if (rc != PH_OK) return rc;
+        PH_REQUIRE(!init[d.src0], "scale-add input slot %d already has a gradient", d.src0);
+        rc = launch_scale_add_bwd(G(d.dst), op.w_dev, G(d.src0), G(d.src1), init[d.src1], so.cp, npix * so.cp, s);
+        init[d.src0] = 1;
+        init[d.src1] = 1;
+        break;
+      }
+      case PH_OP_GELU: {
+        const SlotShape& so = bp.act.slots[d.dst];
+        PH_REQUIRE(init[d.dst], "GELU output slot %d received no gradient", d.dst);
+        rc = launch_gelu_bwd(G(d.dst), A(d.src0), G(d.src0), init[d.src0], (size_t)batch * so.h * so.w * so.cp, s);
+        init[d.src0] = 1;
+        break;
+      }
+      case PH_OP_LINEAR:
+      case PH_OP_PATCH_CONV: {
+        const SlotShape& so = bp.act.slots[d.dst];
+        const SlotShape& si = bp.act.slots[d.src0];
+        PH_REQUIRE(init[d.dst], "GEMM output slot %d received no gradient", d.dst);
+        PH_REQUIRE(!init[d.src0], "GEMM input slot %d already has a gradient (accumulation is not supported here)", d.src0);
+        const bool patch = d.kind == PH_OP_PATCH_CONV;
+        PH_REQUIRE(!patch || (si.h % 2 == 0 && si.w % 2 == 0), "2x2/stride-2 conv backward needs even input sizes");
+        const int M = batch * so.h * so.w;
+        const int taps = patch ? 4 : 1;
+        rc = launch_bias_grad(G(d.dst), (size_t)M, so.cp, d.cout, grads_flat_dev + m->weight_offset[d.bias], scratch, s);
+        for (int tap = 0; tap < taps && rc == PH_OK; ++tap) {
+          RowWgradArgs w{};
+          w.dy = G(d.dst);
+          w.x = A(d.src0);
+          w.slab = scratch;
+          w.np = so.cp;
+          w.kp = si.cp;
+          w.M = M;
+          w.patch = patch ? 1 : 0;
+          w.tap = tap;
+          w.H = si.h;
+          w.W = si.w;
+          rc = launch_row_wgrad(w, d.cout, d.cin0, taps, grads_flat_dev + m->weight_offset[d.weight], s);
+          if (rc != PH_OK) break;
+          GemmArgs g{};
+          g.src0 = G(d.dst);
+          g.c0p = so.cp;
+          g.wpack = op.wd_gemm_dev[tap];
+          g.bias = op.zero_bias_dev;
+          g.dst = G(d.src0);
+          g.zeros = m->zeros_dev;
+          g.coutp = si.cp;
+          g.bn = op.bn_dg;
+          g.M = M;
+          g.mode = 0;
+          g.out_patch = patch ? 1 : 0;
+          g.out_tap = tap;
+          g.out_H = si.h;
+          g.out_W = si.w;
+          rc = launch_gemm(g, s);
+        }
+        init[d.src0] = 1;
+        break;
+      }
+      case PH_OP_LAYERNORM: {
+        const SlotShape& so = bp.act.slots[d.dst];
+        PH_REQUIRE(init[d.dst], "LayerNorm output slot %d received no gradient", d.dst);
+        const size_t npix = (size_t)batch * so.h * so.w;
+        float* stats = scratch;
+        float* red = scratch + 2 * npix;
+        rc = launch_layernorm_bwd(A(d.src0), G(d.dst), op.w_dev, G(d.src0), stats, init[d.src0], so.c, so.cp, npix, s);
+        if (rc != PH_OK) return rc;
+        rc = launch_chan_reduce(G(d.dst), A(d.src0), stats, npix, so.cp, so.c, grads_flat_dev + m->weight_offset[d.weight], red, s);
+        if (rc != PH_OK) return rc;
+        rc = launch_chan_reduce(G(d.dst), nullptr, nullptr, npix, so.cp, so.c, grads_flat_dev + m->weight_offset[d.bias], red, s);
+        init[d.src0] = 1;
+        break;
+      }
+      case PH_OP_DWCONV: {
+        const SlotShape& so = bp.act.slots[d.dst];
+        PH_REQUIRE(init[d.dst], "depthwise conv output slot %d received no gradient", d.dst);
+        rc = launch_bias_grad(G(d.dst), (size_t)batch * so.h * so.w, so.cp, d.cout, grads_flat_dev + m->weight_offset[d.bias], scratch, s);
+        if (rc != PH_OK) return rc;
+        rc = launch_dwconv7_wgrad(A(d.src0), G(d.dst), batch, so.h, so.w, so.cp, d.cout, grads_flat_dev + m->weight_offset[d.weight], scratch, s);
+        if (rc != PH_OK) return rc;
+        DwConvArgs a{};
+        a.src = G(d.dst);
+        a.w = op.dw_flip_dev;
+        a.bias = nullptr;
+        a.dst = G(d.src0);
+        a.cp = so.cp;
+        a.B = batch;
+        a.H = so.h;
+        a.W = so.w;
+        a.accumulate = init[d.src0];
+        rc = launch_dwconv7(a, s);
+        init[d.src0] = 1;
+        break;
+      }
+      case PH_OP_PATCH_STEM: {
+        const SlotShape& so = bp.act.slots[d.dst];
+        PH_REQUIRE(init[d.dst], "stem output received no gradient");
+        PH_REQUIRE(d.cin0 == in_channels, "input has %d channels, network expects %d", in_channels, d.cin0);
+        rc = launch_bias_grad(G(d.dst), (size_t)batch * so.h * so.w, so.cp, d.cout, grads_flat_dev + m->weight_offset[d.bias], scratch, s);
+        if (rc != PH_OK) return rc;
+        rc = launch_patch_stem_wgrad(input_dev, in_dtype, G(d.dst), batch, d.cin0, height, width, so.h, so.w, d.ksize, d.cmid, so.cp, d.cout,
+                                     grads_flat_dev + m->weight_offset[d.weight], scratch, s);
         break;
       }
       default:

@@ -39,4 +39,27 @@ int launch_input_wgrad(const void* img, int dtype, const float* dy, int B, int c
 int64_t input_wgrad_scratch_floats(int cin, int cout);
 int launch_gather(const float* canon, const int* map, size_t n, float* out, hipStream_t s);
 
+// ---- ConvNeXt encoder ops (convnext_train_kernels.hip)
+struct RowWgradArgs {
+  const float* dy;  // (M, np) output gradient rows
+  const float* x;   // input activations, kp channels (rows = pixels; patch mode gathers 2x2/stride-2 taps)
+  float* slab;      // scratch: [slices][blocks][128][128]
+  int np, kp, M;
+  int patch = 0, tap = 0, H = 0, W = 0;  // patch mode: input spatial size and which (dy, dx) tap this launch is
+};
+int launch_gelu_fwd(const float* x, float* y, size_t n, hipStream_t s);
+int launch_gelu_bwd(const float* gy, const float* x, float* gx, int accumulate, size_t n, hipStream_t s);
+int launch_scale_add_fwd(const float* u, const float* x, const float* scale, float* y, int cp, size_t n, hipStream_t s);
+int launch_scale_add_bwd(const float* gy, const float* scale, float* gu, float* gx, int acc_x, int cp, size_t n, hipStream_t s);
+int launch_chan_reduce(const float* a, const float* b, const float* stats, size_t npix, int cp, int c, float* out, float* scratch, hipStream_t s);
+int64_t chan_reduce_scratch_floats(int cp);
+int launch_layernorm_bwd(const float* x, const float* gy, const float* gamma, float* gx, float* stats, int accumulate, int c, int cp, size_t npix, hipStream_t s);
+int launch_dwconv7_wgrad(const float* x, const float* gy, int B, int H, int W, int cp, int c, float* gw, float* scratch, hipStream_t s);
+int64_t dwconv7_wgrad_scratch_floats(int B, int H, int cp);
+int launch_row_wgrad(const RowWgradArgs& a, int n, int k, int taps, float* grad, hipStream_t s);
+int64_t row_wgrad_slab_floats(int M, int n, int k);
+int launch_patch_stem_wgrad(const void* img, int dtype, const float* dy, int B, int cin, int H, int W, int OH, int OW, int k, int stride, int coutp, int cout, float* gw,
+                            float* scratch, hipStream_t s);
+int64_t patch_stem_wgrad_scratch_floats(int cin, int cout, int k);
+
 }  // namespace ph

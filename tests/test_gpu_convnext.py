@@ -112,3 +112,74 @@ def test_small_map_convs_row_gemm_equals_halo_kernel(monkeypatch):
     for tag, o in outs.items():
         assert (o - ref).abs().max().item() <= ATOL, tag
     assert (outs["gemm"] - outs["halo"]).abs().max().item() <= 2e-5
+
+
+# ------------------------------------------------------------------------------------------
+# Training: forward + MSE + backward of the ConvNeXt program vs autograd over the oracle.
+# Tolerance: loss 1e-5 relative; every parameter gradient within 2e-4 of its tensor's max magnitude.
+# ------------------------------------------------------------------------------------------
+def _train_case(channels, depths, stem_stride, os_, hw, B, model_type="centered_instance", in_ch=1, seed=13):
+    from sleap_nn_amd.architectures.model import Model
+    from sleap_nn_amd.training.module import TrainingModule
+
+    bb = _bb(arch={"depths": depths, "channels": channels}, stem_patch_stride=stem_stride, output_stride=os_, in_channels=in_ch)
+    heads = {"confmaps": {"part_names": ["a", "b", "c"], "sigma": 2.5, "output_stride": os_, "loss_weight": 1.0, "anchor_part": None}}
+    sd = O.init_state_convnext(bb, heads, model_type, seed=seed, head_scale=1.0, layer_scale=0.6, randomize_affine=True)
+    g = torch.Generator().manual_seed(seed)
+    img = torch.randint(0, 256, (B, in_ch, hw[0], hw[1]), dtype=torch.uint8, generator=g)
+    ref_out = O.model_forward(sd, bb, heads, model_type, img, backbone="convnext")
+    targets = {k: torch.rand(v.shape, generator=g) * 0.5 for k, v in ref_out.items()}
+    m = Model("convnext", bb, heads, model_type)
+    m.load_state_dict(sd)
+    tm = TrainingModule(m, DEV, loss_weights=[1.0])
+    losses, ref_grads = O.training_step(sd, bb, heads, model_type, img, targets, [1.0], backbone="convnext")
+    loss = tm.forward_backward(img.to(DEV), {k: v.to(DEV) for k, v in targets.items()})
+    torch.cuda.synchronize()
+    assert abs(float(loss[0]) - losses[0]) <= 1e-5 * max(1.0, abs(losses[0]))
+    got = tm.named_grads()
+    assert set(got) == set(ref_grads)
+    worst = {}
+    for k, r in ref_grads.items():
+        scale = max(float(r.abs().max()), 1e-12)
+        err = float((got[k].cpu() - r).abs().max()) / scale
+        worst[k] = err
+    bad = {k: v for k, v in worst.items() if v > 2e-4}
+    assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:8]
+    return tm, sd, bb, heads, img, targets
+
+
+@pytest.mark.parametrize(
+    "channels,depths,stem_stride,os_,hw,B",
+    [
+        ([16, 32, 64, 128], [1, 2, 1, 1], 2, 2, (64, 96), 2),
+        ([24, 40, 72, 136], [2, 1, 1, 1], 2, 4, (64, 64), 3),   # padded channels in every reduction
+        ([32, 64, 128, 256], [1, 1, 1, 1], 4, 2, (128, 64), 1),  # stem stride 4
+    ],
+)
+def test_convnext_backward_matches_autograd(channels, depths, stem_stride, os_, hw, B):
+    _train_case(channels, depths, stem_stride, os_, hw, B)
+
+
+def test_convnext_adam_steps_reduce_loss_and_match_reference_optimizer():
+    tm, sd, bb, heads, img, targets = _train_case([16, 32, 64, 128], [1, 1, 1, 1], 2, 2, (64, 64), 2, seed=29)
+    # three full steps against torch.optim.Adam driven by the oracle's autograd gradients
+    cur = {k: v.clone() for k, v in sd.items()}
+    opt_params = {k: torch.nn.Parameter(v.clone()) for k, v in sd.items()}
+    opt = torch.optim.Adam(list(opt_params.values()), lr=1e-3)
+    tm.lr = 1e-3
+    batch = {"image": img.to(DEV), **{k: v.to(DEV) for k, v in targets.items()}}
+    first = None
+    for step in range(3):
+        _, grads = O.training_step({k: p.detach() for k, p in opt_params.items()}, bb, heads, "centered_instance", img, targets, [1.0], backbone="convnext")
+        for k, p in opt_params.items():
+            p.grad = grads[k]
+        opt.step()
+        loss = tm.training_step(batch)
+        first = float(loss[0]) if first is None else first
+    torch.cuda.synchronize()
+    got = tm.state_dict()
+    # an Adam step moves every parameter by at most ~lr whatever the gradient's size, so fp32 noise on tiny
+    # gradients shows up at a fixed fraction of lr: allow 2 % of the total possible movement (3 steps x lr)
+    for k, p in opt_params.items():
+        assert float((got[k].cpu() - p.detach()).abs().max()) <= 0.02 * 3 * 1e-3, k
+    assert float(loss[0]) < first
