@@ -126,16 +126,19 @@ __global__ __launch_bounds__(256) void chan_reduce_partial_kernel(const float* _
     __syncthreads();
   }
 }
-__global__ void chan_reduce_final_kernel(const float* __restrict__ partial, int cp, int c, float* __restrict__ out) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= c) return;
+// one wave per channel: lane l adds slices l, l + 64, ... and the 64 partial sums are combined by a fixed butterfly
+__global__ __launch_bounds__(256) void chan_reduce_final_kernel(const float* __restrict__ partial, int cp, int c, float* __restrict__ out) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   float s = 0.f;
-  for (int k = 0; k < RED_SLICES; ++k) s += partial[(size_t)k * cp + i];
-  out[i] = s;
+  if (i < c)
+    for (int k = lane; k < RED_SLICES; k += 64) s += partial[(size_t)k * cp + i];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+  if (i < c && lane == 0) out[i] = s;
 }
 int launch_chan_reduce(const float* a, const float* b, const float* stats, size_t npix, int cp, int c, float* out, float* scratch, hipStream_t s) {
   hipLaunchKernelGGL(chan_reduce_partial_kernel, dim3(RED_SLICES), dim3(256), 0, s, a, b, stats, npix, cp, scratch);
-  hipLaunchKernelGGL(chan_reduce_final_kernel, dim3((c + 255) / 256), dim3(256), 0, s, scratch, cp, c, out);
+  hipLaunchKernelGGL(chan_reduce_final_kernel, dim3((c + 3) / 4), dim3(256), 0, s, scratch, cp, c, out);
   PH_HIP_CHECK(hipGetLastError());
   return PH_OK;
 }
@@ -337,19 +340,26 @@ __global__ __launch_bounds__(256, 2) void row_wgrad_kernel(RowWgradArgs a) {
       const int m = chunk * RW_ROWS + row;
       const bool ok = m < a.M;
       const int mm = ok ? m : a.M - 1;
-      const int cy = nt * 128 + sq * 4, ck = kt * 128 + sq * 4;
+      const int cy = nt * 128 + sq * 4;
+      int ck = kt * 128 + sq * 4;
       f32x4 vy = {0.f, 0.f, 0.f, 0.f}, va = {0.f, 0.f, 0.f, 0.f};
       if (ok && cy < a.np) vy = *reinterpret_cast<const f32x4*>(a.dy + (size_t)mm * a.np + cy);
       if (ok && ck < a.kp) {
         size_t pix = (size_t)mm;
-        if (a.patch) {  // output pixel (b, oy, ox) -> input pixel (b, 2oy + dy, 2ox + dx)
+        if (a.patch == 2) {  // 3x3 "same" conv: input pixel = output pixel + (ky - 1, kx - 1), zero outside the image
+          const int x = mm % a.W, y = (mm / a.W) % a.H;
+          const int yy = y + a.tap / 3 - 1, xx = x + a.tap % 3 - 1;
+          const bool in = yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
+          pix = in ? (size_t)((long long)mm + (a.tap / 3 - 1) * a.W + (a.tap % 3 - 1)) : (size_t)mm;
+          if (!in) ck = a.kp;  // -> zeros
+        } else if (a.patch == 1) {  // output pixel (b, oy, ox) -> input pixel (b, 2oy + dy, 2ox + dx)
           const int ow = a.W >> 1, oh = a.H >> 1;
           const int ox = mm % ow;
           const int r2 = mm / ow;
           const int oy = r2 % oh;
           pix = ((size_t)(r2 / oh) * a.H + 2 * oy + (a.tap >> 1)) * a.W + 2 * ox + (a.tap & 1);
         }
-        va = *reinterpret_cast<const f32x4*>(a.x + pix * a.kp + ck);
+        if (ck < a.kp) va = *reinterpret_cast<const f32x4*>(a.x + pix * a.kp + ck);
       }
       *reinterpret_cast<f32x4*>(&sY[buf][row * 128 + sq * 4]) = vy;
       *reinterpret_cast<f32x4*>(&sA[buf][row * 128 + sq * 4]) = va;
@@ -387,15 +397,15 @@ __global__ __launch_bounds__(256, 2) void row_wgrad_kernel(RowWgradArgs a) {
 }
 
 // grad[(n * k_total + k) * taps + tap] = sum_slices slab[...]
-__global__ __launch_bounds__(256) void row_wgrad_reduce_kernel(const float* __restrict__ slab, int n_slices, int n_blocks, int n_kt, int n, int k, int taps, int tap,
-                                                               float* __restrict__ grad) {
+__global__ __launch_bounds__(256) void row_wgrad_reduce_kernel(const float* __restrict__ slab, int n_slices, int n_blocks, int n_kt, int n, int k, int k_total, int k_off,
+                                                               int taps, int tap, float* __restrict__ grad) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n * k) return;
   const int kk = i % k, nn = i / k;
   const int blk = (nn >> 7) * n_kt + (kk >> 7);
   float s = 0.f;
   for (int sl = 0; sl < n_slices; ++sl) s += slab[((size_t)sl * n_blocks + blk) * (128 * 128) + (size_t)(nn & 127) * 128 + (kk & 127)];
-  grad[((size_t)nn * k + kk) * taps + tap] = s;
+  grad[((size_t)nn * k_total + k_off + kk) * taps + tap] = s;
 }
 
 static int rw_slices(int M, int blocks) {
@@ -407,67 +417,73 @@ int64_t row_wgrad_slab_floats(int M, int n, int k) {
   const int blocks = ((pad16(n) + 127) / 128) * ((pad16(k) + 127) / 128);
   return (int64_t)rw_slices(M, blocks) * blocks * 128 * 128;
 }
-int launch_row_wgrad(const RowWgradArgs& a0, int n, int k, int taps, float* grad, hipStream_t s) {
+int launch_row_wgrad(const RowWgradArgs& a0, int n, int k, int taps, float* grad, hipStream_t s) { return launch_row_wgrad_part(a0, n, k, k, 0, taps, grad, s); }
+
+// k_total / k_off: the weight's input-channel axis is k_total wide and this operand covers [k_off, k_off + k) (concat sources)
+int launch_row_wgrad_part(const RowWgradArgs& a0, int n, int k, int k_total, int k_off, int taps, float* grad, hipStream_t s) {
   RowWgradArgs a = a0;
   const int n_nt = (a.np + 127) / 128, n_kt = (a.kp + 127) / 128;
   const int slices = rw_slices(a.M, n_nt * n_kt);
   hipLaunchKernelGGL(row_wgrad_kernel, dim3(n_nt * n_kt, slices), dim3(256), 0, s, a);
-  hipLaunchKernelGGL(row_wgrad_reduce_kernel, dim3((n * k + 255) / 256), dim3(256), 0, s, a.slab, slices, n_nt * n_kt, n_kt, n, k, taps, a.tap, grad);
+  hipLaunchKernelGGL(row_wgrad_reduce_kernel, dim3((n * k + 255) / 256), dim3(256), 0, s, a.slab, slices, n_nt * n_kt, n_kt, n, k, k_total, k_off, taps, a.tap, grad);
   PH_HIP_CHECK(hipGetLastError());
   return PH_OK;
 }
 
 // ---------------------------------------------------------------------------------------
 // Patch-stem weight gradient: dW[co][ci][ky][kx] = sum_{b,oy,ox} dy[b,oy,ox,co] * img[b,ci,oy*s+ky-1,ox*s+kx-1].
-// Work item = (co, ci*k*k + tap); workgroups walk slices of output pixels; partial[slice][n_out].
+// The image patches are written once as rows [pixel][ci*k*k + tap] (im2col, <= 48 floats per pixel, padded
+// to a multiple of 16) and the gradient is one row-wgrad GEMM over them.
 // ---------------------------------------------------------------------------------------
-constexpr int PSW_SLICES = 512;
-__global__ __launch_bounds__(256) void patch_stem_wgrad_partial_kernel(const void* __restrict__ img, int dtype, const float* __restrict__ dy, int B, int cin, int H, int W,
-                                                                      int OH, int OW, int k, int stride, int coutp, int cout, float* __restrict__ partial) {
-  const int kk = k * k;
-  const int n_items = cout * cin * kk;
-  const size_t npix = (size_t)B * OH * OW;
-  const size_t per = (npix + gridDim.x - 1) / gridDim.x;
-  const size_t lo = (size_t)blockIdx.x * per, hi = std::min(npix, lo + per);
-  for (int item = threadIdx.x; item < n_items; item += 256) {
-    const int co = item % cout, ct = item / cout;  // co fastest: the dy reads of a wave are contiguous
-    const int ci = ct / kk, tap = ct - ci * kk;
-    const int ky = tap / k, kx = tap - ky * k;
-    float acc = 0.f;
-    for (size_t p = lo; p < hi; ++p) {
+__global__ __launch_bounds__(256) void patch_im2col_kernel(const void* __restrict__ img, int dtype, int B, int cin, int H, int W, int OH, int OW, int k, int stride,
+                                                           int kp, float* __restrict__ out) {
+  const int kk = k * k, n_item = cin * kk;
+  const size_t total = (size_t)B * OH * OW * kp;
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+    const int item = (int)(idx % kp);
+    const size_t p = idx / kp;
+    float v = 0.f;
+    if (item < n_item) {
+      const int ci = item / kk, tap = item - ci * kk;
+      const int ky = tap / k, kx = tap - ky * k;
       const int ox = (int)(p % OW);
       const size_t r = p / OW;
       const int oy = (int)(r % OH), b = (int)(r / OH);
       const int yy = oy * stride + ky - 1, xx = ox * stride + kx - 1;
-      if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
-      const size_t o = (((size_t)b * cin + ci) * H + yy) * W + xx;
-      float v;
-      if (dtype == 0)
-        v = (float)reinterpret_cast<const uint8_t*>(img)[o] / 255.0f;
-      else {
-        v = reinterpret_cast<const float*>(img)[o];
-        if (dtype == 2) v = v / 255.0f;
+      if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+        const size_t o = (((size_t)b * cin + ci) * H + yy) * W + xx;
+        if (dtype == 0)
+          v = (float)reinterpret_cast<const uint8_t*>(img)[o] / 255.0f;
+        else {
+          v = reinterpret_cast<const float*>(img)[o];
+          if (dtype == 2) v = v / 255.0f;
+        }
       }
-      acc = fmaf(v, dy[p * coutp + co], acc);
     }
-    partial[(size_t)blockIdx.x * n_items + (size_t)co * cin * kk + ct] = acc;
+    out[idx] = v;
   }
-}
-__global__ void sum_slices_kernel(const float* __restrict__ partial, int n_slices, int n_out, float* __restrict__ out) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_out) return;
-  float s = 0.f;
-  for (int k = 0; k < n_slices; ++k) s += partial[(size_t)k * n_out + i];
-  out[i] = s;
 }
 int launch_patch_stem_wgrad(const void* img, int dtype, const float* dy, int B, int cin, int H, int W, int OH, int OW, int k, int stride, int coutp, int cout, float* gw,
                             float* scratch, hipStream_t s) {
-  const int n_out = cout * cin * k * k;
-  hipLaunchKernelGGL(patch_stem_wgrad_partial_kernel, dim3(PSW_SLICES), dim3(256), 0, s, img, dtype, dy, B, cin, H, W, OH, OW, k, stride, coutp, cout, scratch);
-  hipLaunchKernelGGL(sum_slices_kernel, dim3((n_out + 255) / 256), dim3(256), 0, s, scratch, PSW_SLICES, n_out, gw);
+  const int n_item = cin * k * k, kp = pad16(n_item);
+  const size_t npix = (size_t)B * OH * OW;
+  float* patches = scratch;
+  float* slab = scratch + align_up((int64_t)npix * kp, 64);
+  const size_t total = npix * kp;
+  hipLaunchKernelGGL(patch_im2col_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 256 * 64)), dim3(256), 0, s, img, dtype, B, cin, H, W, OH, OW, k, stride, kp, patches);
   PH_HIP_CHECK(hipGetLastError());
-  return PH_OK;
+  RowWgradArgs a{};
+  a.dy = dy;
+  a.x = patches;
+  a.slab = slab;
+  a.np = coutp;
+  a.kp = kp;
+  a.M = (int)npix;
+  return launch_row_wgrad(a, cout, n_item, 1, gw, s);  // canonical (cout, cin, k, k) == [co][ci*k*k + tap]
 }
-int64_t patch_stem_wgrad_scratch_floats(int cin, int cout, int k) { return (int64_t)PSW_SLICES * cout * cin * k * k; }
+int64_t patch_stem_wgrad_scratch_floats(int cin, int cout, int k, int64_t npix) {
+  const int kp = pad16(cin * k * k);
+  return align_up(npix * kp, 64) + row_wgrad_slab_floats((int)npix, cout, cin * k * k);
+}
 
 }  // namespace ph

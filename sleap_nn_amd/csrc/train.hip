@@ -40,7 +40,7 @@ int build_bwd_plan(const ph_model* m, int B, int H, int W, BwdPlan& bp) {
       const int64_t npix = (int64_t)B * so.h * so.w;
       int64_t need = bias_scratch_floats(so.cp);
       switch (d.kind) {
-        case PH_OP_PATCH_STEM: need = std::max(need, patch_stem_wgrad_scratch_floats(d.cin0, d.cout, d.ksize)); break;
+        case PH_OP_PATCH_STEM: need = std::max(need, patch_stem_wgrad_scratch_floats(d.cin0, d.cout, d.ksize, npix)); break;
         case PH_OP_DWCONV: need = std::max(need, dwconv7_wgrad_scratch_floats(B, so.h, so.cp)); break;
         case PH_OP_LAYERNORM: need = std::max(need, 2 * npix + chan_reduce_scratch_floats(so.cp)); break;
         case PH_OP_LINEAR:
@@ -61,6 +61,7 @@ int build_bwd_plan(const ph_model* m, int B, int H, int W, BwdPlan& bp) {
       const SlotShape& s0 = bp.act.slots[d.src0];
       scratch = std::max<int64_t>(scratch, wgrad_slab_floats(d.cin0, d.cout, B, s0.h, s0.w));
       if (d.cin1 > 0) scratch = std::max<int64_t>(scratch, wgrad_slab_floats(d.cin1, d.cout, B, s0.h, s0.w));
+      scratch = std::max<int64_t>(scratch, row_wgrad_slab_floats(B * s0.h * s0.w, d.cout, std::max(d.cin0, d.cin1)));
       scratch = std::max<int64_t>(scratch, bias_scratch_floats(pad16(d.cout)));
     } else if (d.kind == PH_OP_INPUT_CONV) {
       scratch = std::max<int64_t>(scratch, input_wgrad_scratch_floats(d.cin0, d.cout));
@@ -181,17 +182,37 @@ int ph_model_backward(ph_model* m, const void* input_dev, int32_t in_dtype, int3
         for (int part = 0; part < 2; ++part) {
           if (parts[part] <= 0 || srcs[part] < 0) continue;
           const SlotShape& si = bp.act.slots[srcs[part]];
-          WgradArgs w{};
-          w.x = A(srcs[part]);
-          w.dy = G(d.dst);
-          w.slab = scratch;
-          w.cxp = si.cp;
-          w.coutp = so.cp;
-          w.B = batch;
-          w.H = so.h;
-          w.W = so.w;
-          rc = launch_wgrad(w, parts[part], d.cout, d.cin0 + d.cin1, offs[part], grads_flat_dev + m->weight_offset[d.weight], s);
-          if (rc != PH_OK) return rc;
+          const double tile_fill = ((double)si.cp / ((si.cp + 127) / 128 * 128)) * ((double)so.cp / ((so.cp + 127) / 128 * 128));
+          if (m->wgrad_rows == 2 || (m->wgrad_rows == 1 && si.cp >= 128 && so.cp >= 128 && tile_fill >= 0.8)) {
+            // nine row-wgrad GEMMs (one per tap): 128x128 tiles on the MFMA instead of 32x32, for wide layers
+            for (int tap = 0; tap < 9; ++tap) {
+              RowWgradArgs w{};
+              w.dy = G(d.dst);
+              w.x = A(srcs[part]);
+              w.slab = scratch;
+              w.np = so.cp;
+              w.kp = si.cp;
+              w.M = (int)npix;
+              w.patch = 2;
+              w.tap = tap;
+              w.H = so.h;
+              w.W = so.w;
+              rc = launch_row_wgrad_part(w, d.cout, parts[part], d.cin0 + d.cin1, offs[part], 9, grads_flat_dev + m->weight_offset[d.weight], s);
+              if (rc != PH_OK) return rc;
+            }
+          } else {
+            WgradArgs w{};
+            w.x = A(srcs[part]);
+            w.dy = G(d.dst);
+            w.slab = scratch;
+            w.cxp = si.cp;
+            w.coutp = so.cp;
+            w.B = batch;
+            w.H = so.h;
+            w.W = so.w;
+            rc = launch_wgrad(w, parts[part], d.cout, d.cin0 + d.cin1, offs[part], grads_flat_dev + m->weight_offset[d.weight], s);
+            if (rc != PH_OK) return rc;
+          }
           // data gradient: conv3x3 of the masked output gradient with the flipped, swapped weights
           ConvArgs a{};
           a.src0 = G(d.dst);

@@ -45,7 +45,7 @@ struct RowWgradArgs {
   const float* x;   // input activations, kp channels (rows = pixels; patch mode gathers 2x2/stride-2 taps)
   float* slab;      // scratch: [slices][blocks][128][128]
   int np, kp, M;
-  int patch = 0, tap = 0, H = 0, W = 0;  // patch mode: input spatial size and which (dy, dx) tap this launch is
+  int patch = 0, tap = 0, H = 0, W = 0;  // patch 1: 2x2/stride-2 taps (dy, dx); patch 2: 3x3 "same" conv taps; H, W = input spatial size
 };
 int launch_gelu_fwd(const float* x, float* y, size_t n, hipStream_t s);
 int launch_gelu_bwd(const float* gy, const float* x, float* gx, int accumulate, size_t n, hipStream_t s);
@@ -57,9 +57,10 @@ int launch_layernorm_bwd(const float* x, const float* gy, const float* gamma, fl
 int launch_dwconv7_wgrad(const float* x, const float* gy, int B, int H, int W, int cp, int c, float* gw, float* scratch, hipStream_t s);
 int64_t dwconv7_wgrad_scratch_floats(int B, int H, int cp);
 int launch_row_wgrad(const RowWgradArgs& a, int n, int k, int taps, float* grad, hipStream_t s);
+int launch_row_wgrad_part(const RowWgradArgs& a, int n, int k, int k_total, int k_off, int taps, float* grad, hipStream_t s);
 int64_t row_wgrad_slab_floats(int M, int n, int k);
 int launch_patch_stem_wgrad(const void* img, int dtype, const float* dy, int B, int cin, int H, int W, int OH, int OW, int k, int stride, int coutp, int cout, float* gw,
                             float* scratch, hipStream_t s);
-int64_t patch_stem_wgrad_scratch_floats(int cin, int cout, int k);
+int64_t patch_stem_wgrad_scratch_floats(int cin, int cout, int k, int64_t npix);
 
 }  // namespace ph

@@ -400,16 +400,19 @@ __global__ __launch_bounds__(256) void bias_partial_kernel(const float* __restri
     __syncthreads();
   }
 }
-__global__ void bias_final_kernel(const float* __restrict__ partial, int cp, int cout, float* __restrict__ gb) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= cout) return;
+// one wave per channel: lane l adds slices l, l + 64, ... and the 64 partial sums are combined by a fixed butterfly
+__global__ __launch_bounds__(256) void bias_final_kernel(const float* __restrict__ partial, int cp, int cout, float* __restrict__ gb) {
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   float s = 0.f;
-  for (int k = 0; k < BIAS_SLICES; ++k) s += partial[(size_t)k * cp + c];
-  gb[c] = s;
+  if (c < cout)
+    for (int k = lane; k < BIAS_SLICES; k += 64) s += partial[(size_t)k * cp + c];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+  if (c < cout && lane == 0) gb[c] = s;
 }
 int launch_bias_grad(const float* g, size_t npix, int cp, int cout, float* gb, float* scratch, hipStream_t s) {
   hipLaunchKernelGGL(bias_partial_kernel, dim3(BIAS_SLICES), dim3(256), 0, s, g, npix, cp, scratch);
-  hipLaunchKernelGGL(bias_final_kernel, dim3((cout + 255) / 256), dim3(256), 0, s, scratch, cp, cout, gb);
+  hipLaunchKernelGGL(bias_final_kernel, dim3((cout + 3) / 4), dim3(256), 0, s, scratch, cp, cout, gb);
   PH_HIP_CHECK(hipGetLastError());
   return PH_OK;
 }
