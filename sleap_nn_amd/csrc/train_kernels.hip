@@ -430,6 +430,9 @@ int64_t bias_scratch_floats(int cp) { return (int64_t)BIAS_SLICES * cp; }
 constexpr int WG_TH = 8, WG_TW = 32, WG_HW = WG_TW + 2, WG_HH = WG_TH + 2;
 
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
+  // Every wave accumulates all nine taps over its quarter of each pixel tile (pixel rows 2w, 2w+1):
+  // nine accumulators per wave, perfectly balanced (a split of the taps over four waves is 3+2+2+2);
+  // the four partial sets are added through LDS once, after the K loop.
   __shared__ float sX[WG_HH * WG_HW * 32];
   __shared__ float sY[WG_TH * WG_TW * 32];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -439,11 +442,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
   const int slice = blockIdx.y, n_slices = gridDim.y;
   const int tiles_x = (a.W + WG_TW - 1) / WG_TW, tiles_y = (a.H + WG_TH - 1) / WG_TH;
   const int n_tiles = tiles_x * tiles_y * a.B;
-  const int ntaps = (wave == 0) ? 3 : 2;
 
-  f32x16 acc[3];
+  f32x16 acc[9];
 #pragma unroll
-  for (int t = 0; t < 3; ++t)
+  for (int t = 0; t < 9; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
@@ -460,46 +462,44 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
       const int hy = pix / WG_HW, hx = pix - hy * WG_HW;
       const int gy = y0 + hy - 1, gx = x0 + hx - 1;
       const int c = ci_t * 32 + q * 4;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && c < a.cxp) v = *reinterpret_cast<const f32x4*>(a.x + ((size_t)(b * a.H + gy) * a.W + gx) * a.cxp + c);
-      *reinterpret_cast<f32x4*>(sX + pix * 32 + q * 4) = v;
+      const bool ok = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && c < a.cxp;
+      const int cy = min(max(gy, 0), a.H - 1), cx = min(max(gx, 0), a.W - 1), cc = min(c, a.cxp - 4);
+      const f32x4 v = *reinterpret_cast<const f32x4*>(a.x + ((size_t)(b * a.H + cy) * a.W + cx) * a.cxp + cc);
+      *reinterpret_cast<f32x4*>(sX + pix * 32 + q * 4) = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
     }
     for (int i = tid; i < WG_TH * WG_TW * 8; i += 256) {
       const int pix = i >> 3, q = i & 7;
       const int py = pix / WG_TW, px = pix - py * WG_TW;
       const int gy = y0 + py, gx = x0 + px;
       const int c = co_t * 32 + q * 4;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (gy < a.H && gx < a.W && c < a.coutp) v = *reinterpret_cast<const f32x4*>(a.dy + ((size_t)(b * a.H + gy) * a.W + gx) * a.coutp + c);
-      *reinterpret_cast<f32x4*>(sY + pix * 32 + q * 4) = v;
+      const bool ok = gy < a.H && gx < a.W && c < a.coutp;
+      const int cy = min(gy, a.H - 1), cx = min(gx, a.W - 1), cc = min(c, a.coutp - 4);
+      const f32x4 v = *reinterpret_cast<const f32x4*>(a.dy + ((size_t)(b * a.H + cy) * a.W + cx) * a.coutp + cc);
+      *reinterpret_cast<f32x4*>(sY + pix * 32 + q * 4) = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
     }
     __syncthreads();
-#pragma unroll 4
-    for (int s2 = 0; s2 < WG_TH * WG_TW / 2; ++s2) {
-      const int p = 2 * s2 + lh;
-      const int py = p >> 5, px = p & 31;
-      const float bv = sY[p * 32 + lx];
+#pragma unroll 2
+    for (int s2 = 0; s2 < WG_TW; ++s2) {  // this wave's 64 pixels = rows 2w, 2w+1 of the tile, two per MFMA
+      const int py = 2 * wave + (s2 >> 4), px = 2 * (s2 & 15) + lh;
+      const float bv = sY[(py * WG_TW + px) * 32 + lx];
 #pragma unroll
-      for (int t3 = 0; t3 < 3; ++t3) {
-        if (t3 < ntaps) {
-          const int tap = wave + 4 * t3;
-          const int ky = tap / 3, kx = tap - ky * 3;
-          const float av = sX[((py + ky) * WG_HW + px + kx) * 32 + lx];
-          acc[t3] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t3], 0, 0, 0);
-        }
+      for (int tap = 0; tap < 9; ++tap) {
+        const int ky = tap / 3, kx = tap - ky * 3;
+        const float av = sX[((py + ky) * WG_HW + px + kx) * 32 + lx];
+        acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[tap], 0, 0, 0);
       }
     }
     __syncthreads();
   }
-  // slab[slice][tile pair][tap][ci 32][co 32];  D: row(ci) = (r&3) + 8*(r>>2) + 4*lh, col(co) = lx
+  // add the four waves' partial sets through LDS (sX is free now: 4 waves x 1024 floats per tap fit),
+  // fixed order, then slab[slice][block][tap][ci 32][co 32];  D: row(ci) = (r&3) + 8*(r>>2) + 4*lh, col(co) = lx
   float* slab = a.slab + (((size_t)slice * gridDim.x + blockIdx.x) * 9) * 1024;
+  for (int tap = 0; tap < 9; ++tap) {
 #pragma unroll
-  for (int t3 = 0; t3 < 3; ++t3) {
-    if (t3 < ntaps) {
-      const int tap = wave + 4 * t3;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) slab[(size_t)tap * 1024 + ((r & 3) + 8 * (r >> 2) + 4 * lh) * 32 + lx] = acc[t3][r];
-    }
+    for (int r = 0; r < 16; ++r) sX[wave * 1024 + ((r & 3) + 8 * (r >> 2) + 4 * lh) * 32 + lx] = acc[tap][r];
+    __syncthreads();
+    for (int i = tid; i < 1024; i += 256) slab[(size_t)tap * 1024 + i] = (sX[i] + sX[1024 + i]) + (sX[2048 + i] + sX[3072 + i]);
+    __syncthreads();
   }
 }
 
