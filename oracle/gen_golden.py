@@ -474,6 +474,41 @@ def convnext_decoder_fixture():
     save("convnext_decoder.npz", **arrs)
 
 
+def filters_fixture():
+    """Reference NMS / IoU / OKS helpers (inference/ops/filters.py, pure numpy) on random instance sets."""
+    import types
+
+    sys.modules.setdefault("sleap_io", types.ModuleType("sleap_io"))
+    from sleap_nn.inference.ops import filters as rf
+
+    rng = np.random.default_rng(41)
+    arrs = {}
+    n_cases = 24
+    for c in range(n_cases):
+        n_inst, n_nodes = int(rng.integers(1, 9)), int(rng.integers(2, 8))
+        centres = rng.uniform(20, 200, size=(n_inst, 1, 2))
+        if c % 3 == 0:  # clusters of near-duplicates
+            centres = centres[rng.integers(0, max(1, n_inst // 2), size=n_inst)] + rng.normal(0, 2.0, size=(n_inst, 1, 2))
+        pts = centres + rng.normal(0, 15.0, size=(n_inst, n_nodes, 2))
+        pts[rng.random((n_inst, n_nodes)) < 0.2] = np.nan
+        if c % 5 == 0:
+            pts[0] = np.nan if n_inst > 1 else pts[0]
+        scores = rng.uniform(0.1, 1.0, size=n_inst)
+        if c % 4 == 0 and n_inst > 1:
+            scores[1] = scores[0]  # tie
+        arrs[f"{c}/points"] = pts
+        arrs[f"{c}/scores"] = scores
+        boxes = np.array([rf._instance_bbox(types.SimpleNamespace(numpy=lambda p=p: p)) for p in pts])
+        arrs[f"{c}/bboxes"] = boxes
+        for thr in (0.1, 0.5, 0.8):
+            arrs[f"{c}/keep_iou_{thr}"] = np.array(rf._nms_greedy_iou(boxes, scores, thr), dtype=np.int64)
+            arrs[f"{c}/keep_oks_{thr}"] = np.array(rf._nms_greedy_oks([p for p in pts], scores, thr), dtype=np.int64)
+        arrs[f"{c}/oks_matrix"] = np.array([[rf._compute_oks(a, b) for b in pts] for a in pts])
+        arrs[f"{c}/iou_row0"] = rf._compute_iou_one_to_many(boxes[0], boxes)
+    arrs["n_cases"] = np.array(n_cases)
+    save("filters.npz", **arrs)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     if not only or "core" in only:
@@ -486,3 +521,5 @@ if __name__ == "__main__":
         targets_fixture()
     if not only or "convnext" in only:
         convnext_decoder_fixture()
+    if not only or "filters" in only:
+        filters_fixture()

@@ -250,3 +250,36 @@ def test_run_directory_ingestion():
     assert s.model_type == "single_instance" and s.backbone_config["in_channels"] == 3
     with pytest.raises(FileNotFoundError):
         load_model_assets(os.path.join(ROOT, "tests"))
+
+
+def test_post_inference_filters_match_reference():
+    """Host-side instance filters (inference/ops/filters.py) vs the reference's own NMS / IoU / OKS helpers
+    on random instance sets incl. missing nodes, all-NaN instances, near-duplicates and score ties."""
+    from sleap_nn_amd.inference.ops import filters as F
+    from sleap_nn_amd.inference.outputs import Outputs
+
+    g = G.load("filters.npz")
+    for c in range(int(g["n_cases"])):
+        pts, scores = g[f"{c}/points"], g[f"{c}/scores"]
+        boxes = np.array([F.instance_bbox(p) for p in pts])
+        np.testing.assert_array_equal(boxes, g[f"{c}/bboxes"])
+        np.testing.assert_allclose(F.iou_one_to_many(boxes[0], boxes), g[f"{c}/iou_row0"], rtol=0, atol=0)
+        got = np.array([[F.oks(a, b) for b in pts] for a in pts])
+        np.testing.assert_allclose(got, g[f"{c}/oks_matrix"], rtol=0, atol=1e-15)
+        for thr in (0.1, 0.5, 0.8):
+            assert F.nms_greedy(list(pts), scores, thr, "iou") == g[f"{c}/keep_iou_{thr}"].tolist()
+            assert F.nms_greedy(list(pts), scores, thr, "oks") == g[f"{c}/keep_oks_{thr}"].tolist()
+    # the Outputs wrapper: node-count, confidence and overlap filters in the reference's order
+    pts = g["3/points"]
+    n_inst, n_nodes = pts.shape[:2]
+    vals = np.where(np.isnan(pts).any(-1), np.nan, 0.5)
+    o = Outputs(pred_keypoints=torch.from_numpy(pts[None]).float(), pred_peak_values=torch.from_numpy(vals[None]).float(),
+                instance_scores=torch.from_numpy(g["3/scores"][None]).float())
+    out, keep = F.filter_outputs(o, min_visible_nodes=2, overlap_threshold=0.5, overlap_method="iou")
+    nv = (~np.isnan(pts).any(-1)).sum(-1)
+    cand = [i for i in range(n_inst) if nv[i] >= 2]
+    sc32 = g["3/scores"].astype(np.float32).astype(np.float64)
+    want = [cand[j] for j in F.nms_greedy([pts.astype(np.float32).astype(np.float64)[i] for i in cand], sc32[cand], 0.5, "iou")]
+    assert keep[0] == want
+    dropped = [i for i in range(n_inst) if i not in keep[0]]
+    assert torch.isnan(out.pred_keypoints[0, dropped]).all() and not torch.isnan(out.instance_scores[0, keep[0]]).any()
