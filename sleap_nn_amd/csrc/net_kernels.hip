@@ -656,25 +656,31 @@ __global__ __launch_bounds__(256, 2) void stem_fused_kernel(StemArgs a) {
   // ---- conv0 + ReLU into the A tile; item = (halo pixel, 4-channel group q = tid&3)
   {
     const int q4 = (tid & 3) * 4;
+    // a thread's four output channels are fixed: for a gray image its 9 weight quads live in registers
+    // (the inner loop is then one LDS broadcast read + 4 FMAs per tap instead of two LDS reads)
+    f32x4 wreg[CIN == 1 ? 9 : 1];
+    if (CIN == 1) {
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) wreg[tap] = *reinterpret_cast<const f32x4*>(sW0 + tap * 16 + q4);
+    }
+    const f32x4 b0 = *reinterpret_cast<const f32x4*>(sW0 + 9 * CIN * 16 + q4);
     for (int pix = tid >> 2; pix < HALO_H * HALO_W; pix += 64) {
       const int hy = pix / HALO_W, hx = pix - hy * HALO_W;
       const int gy = y0 + hy - 1, gx = x0 + hx - 1;
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-      if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {  // outside the image = conv1's zero padding
-        acc = *reinterpret_cast<const f32x4*>(sW0 + 9 * CIN * 16 + q4);
+      const bool in = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;  // outside the image = conv1's zero padding
+      f32x4 acc = b0;
 #pragma unroll
-        for (int c = 0; c < CIN; ++c)
+      for (int c = 0; c < CIN; ++c)
 #pragma unroll
-          for (int ky = 0; ky < 3; ++ky)
+        for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-              const float v = sImg[(c * IMG_H + hy + ky) * IMG_W + hx + kx];
-              const f32x4 w = *reinterpret_cast<const f32x4*>(sW0 + ((ky * 3 + kx) * CIN + c) * 16 + q4);
-              acc += v * w;
-            }
+          for (int kx = 0; kx < 3; ++kx) {
+            const float v = sImg[(c * IMG_H + hy + ky) * IMG_W + hx + kx];
+            const f32x4 w = CIN == 1 ? wreg[ky * 3 + kx] : *reinterpret_cast<const f32x4*>(sW0 + ((ky * 3 + kx) * CIN + c) * 16 + q4);
+            acc += v * w;
+          }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) acc[k] = fmaxf(acc[k], 0.f);
-      }
+      for (int k = 0; k < 4; ++k) acc[k] = in ? fmaxf(acc[k], 0.f) : 0.f;
       *reinterpret_cast<f32x4*>(sA + pix * LROW + q4) = acc;
     }
   }
