@@ -80,13 +80,15 @@ enum ph_op_kind {
   /* the two epilogues of PH_OP_LINEAR as ops of their own: the training program keeps the
      pre-activation tensors that autograd needs (GELU input, un-scaled block output)              */
   PH_OP_GELU = 13,      /* dst = GELU_erf(src0)                                                          */
-  PH_OP_SCALE_ADD = 14  /* dst = weight[c] * src0 + src1   (layer_scale * block(x) + x)                  */
+  PH_OP_SCALE_ADD = 14, /* dst = weight[c] * src0 + src1   (layer_scale * block(x) + x)                  */
+  PH_OP_GLOBAL_MAXPOOL = 15 /* dst (1x1) = max over H x W of src0 (nn.AdaptiveMaxPool2d(1), heads.py:519-520) */
 };
 
 #define PH_FLAG_RELU 1
 #define PH_FLAG_SIGMOID 2
 #define PH_FLAG_GELU 4
 #define PH_FLAG_SCALE_RESIDUAL 8
+#define PH_FLAG_SOFTMAX 16 /* PH_OP_HEAD: softmax over the output channels (ClassVectorsHead, heads.py:536-537) */
 
 typedef struct ph_op_desc {
   int32_t kind;      /* enum ph_op_kind                                              */

@@ -37,6 +37,7 @@ HEAD_ORDER = {
     "centered_instance": [("CenteredInstanceConfmapsHead", "confmaps")],
     "bottomup": [("MultiInstanceConfmapsHead", "confmaps"), ("PartAffinityFieldsHead", "pafs")],
     "multi_class_bottomup": [("MultiInstanceConfmapsHead", "confmaps"), ("ClassMapsHead", "class_maps")],
+    "multi_class_topdown": [("CenteredInstanceConfmapsHead", "confmaps"), ("ClassVectorsHead", "class_vectors")],
 }
 
 
@@ -464,6 +465,14 @@ def model_forward(sd, bb: dict, head_cfgs: dict, model_type: str, image: torch.T
     out = {}
     for i, (hname, key) in enumerate(HEAD_ORDER[model_type]):
         hc = head_cfgs[key]
+        if hname == "ClassVectorsHead":
+            # heads.py:506-539 on the decoder's input feature (model.py:197-199,253-255): global max pool ->
+            # (Linear + ReLU) x num_fc_layers -> Linear -> softmax over classes
+            v = F.adaptive_max_pool2d(bo["middle_output"], 1).flatten(1)
+            for j in range(int(hc.get("num_fc_layers", 1))):
+                v = F.relu(F.linear(v, sd[f"head_layers.{i}.pre_classification{j}_fc.weight"], sd[f"head_layers.{i}.pre_classification{j}_fc.bias"]))
+            out[hname] = torch.softmax(F.linear(v, sd[f"head_layers.{i}.ClassVectorsHead.weight"], sd[f"head_layers.{i}.ClassVectorsHead.bias"]), dim=-1)
+            continue
         feat = bo["outputs"][bo["strides"].index(hc["output_stride"])] if bo["outputs"] else bo["middle_output"]
         y = F.conv2d(feat, sd[f"head_layers.{i}.{hname}.0.weight"], sd[f"head_layers.{i}.{hname}.0.bias"])
         if hname == "ClassMapsHead":
@@ -1148,3 +1157,14 @@ def make_pafs_sample(inst: torch.Tensor, edges, img_hw, sigma: float, stride: in
             out[2 * e] += torch.nan_to_num(px, nan=0.0)
             out[2 * e + 1] += torch.nan_to_num(py, nan=0.0)
     return out
+
+
+def class_inds_from_vectors(probs: torch.Tensor):
+    """ops/identity.py:149-173: Hungarian matching of samples to classes on -prob; unmatched -> -1 / NaN."""
+    r, c = linear_sum_assignment(-probs.numpy())
+    inds = torch.full((probs.shape[0],), -1, dtype=torch.int64)
+    pr = torch.full((probs.shape[0],), float("nan"))
+    for a, b in zip(r, c):
+        inds[a] = int(b)
+        pr[a] = probs[a, b]
+    return inds, pr

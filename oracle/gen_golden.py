@@ -509,6 +509,43 @@ def filters_fixture():
     save("filters.npz", **arrs)
 
 
+def multiclass_topdown_fixture():
+    """Multi-class centered-instance fixture checkpoint (confmaps + ClassVectorsHead) on the crops stored in the
+    reference's own tests/inference/parity_golden/multiclass_topdown.pkl, plus that golden's expectations."""
+    from sleap_nn.inference.ops.identity import get_class_inds_from_vectors
+
+    m, sd, bb, heads, cfg = _load_ckpt_model("multiclass_centered_instance", "multi_class_topdown")
+    gold = rh.load_pickle_tolerant(f"{REF}/tests/inference/parity_golden/multiclass_topdown.pkl")
+    arrs = {"w/" + k: _np(v) for k, v in sd.items()}
+    frames, crops, kp, kv, cls, cent, fidx = [], [], [], [], [], [], []
+    usable = [b for b in gold if b["instance_image"].shape[-2:] == (128, 128)][:3]  # some goldens hold border crops of 127 px
+    for bi, b in enumerate(usable):
+        frames.append(b["image"][0])
+        crops.append(b["instance_image"][:, 0])
+        kp.append(b["pred_instance_peaks"])
+        kv.append(b["pred_peak_values"])
+        cls.append(b["pred_class_inds"])
+        cent.append(b["pred_centroids"])
+        fidx.append(np.full(len(b["pred_class_inds"]), bi))
+    crops_t = torch.from_numpy(np.concatenate(crops))
+    with torch.inference_mode():
+        out = m(crops_t.float() / 255)
+        gp, gv = rpeaks.find_global_peaks(out["CenteredInstanceConfmapsHead"], threshold=0.03, refinement="integral", integral_patch_size=5)
+        ci, cp = [], []
+        fi = np.concatenate(fidx)
+        for f in np.unique(fi):
+            a, b_ = get_class_inds_from_vectors(out["ClassVectorsHead"][torch.from_numpy(fi == f)])
+            ci.append(_np(a))
+            cp.append(_np(b_))
+    assert np.array_equal(np.concatenate(ci), np.concatenate(cls)), (ci, cls)
+    arrs.update({"frames": np.stack(frames), "crops": _np(crops_t), "crop_frame": fi, "out/CenteredInstanceConfmapsHead": _np(out["CenteredInstanceConfmapsHead"]),
+                 "out/ClassVectorsHead": _np(out["ClassVectorsHead"]), "crop_peaks": _np(gp * heads["confmaps"]["output_stride"]), "crop_peak_vals": _np(gv),
+                 "class_inds": np.concatenate(ci), "class_probs": np.concatenate(cp), "gold_pred_instance_peaks": np.concatenate(kp), "gold_pred_peak_values": np.concatenate(kv),
+                 "gold_pred_class_inds": np.concatenate(cls), "gold_pred_centroids": np.concatenate(cent)})
+    arrs["config_json"] = np.array(json.dumps({"backbone": bb, "heads": heads, "model_type": "multi_class_topdown", "crop_size": int(cfg["data_config"]["preprocessing"]["crop_size"])}))
+    save("multiclass_topdown.npz", **arrs)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     if not only or "core" in only:
@@ -523,3 +560,5 @@ if __name__ == "__main__":
         convnext_decoder_fixture()
     if not only or "filters" in only:
         filters_fixture()
+    if not only or "mctopdown" in only:
+        multiclass_topdown_fixture()

@@ -104,6 +104,29 @@ class ClassMapsHead(Head):
         return "sigmoid"
 
 
+class ClassVectorsHead(Head):
+    """heads.py:434-539: global max pool -> (Linear + ReLU) x num_fc_layers -> Linear -> softmax."""
+
+    def __init__(self, classes, num_fc_layers: int = 1, num_fc_units: int = 64, global_pool: bool = True, output_stride: int = 1, loss_weight: float = 1.0, **_ignored):
+        super().__init__(output_stride, loss_weight)
+        self.classes = list(classes)
+        self.num_fc_layers = int(num_fc_layers)
+        self.num_fc_units = int(num_fc_units)
+        self.global_pool = bool(global_pool)
+
+    @property
+    def channels(self) -> int:
+        return len(self.classes)
+
+    @property
+    def activation(self) -> str:
+        return "softmax"
+
+    @property
+    def loss_function(self) -> str:
+        return "categorical_crossentropy"
+
+
 def get_head(model_type: str, head_config) -> List[Head]:
     """Head list per model type, in the reference's order (architectures/model.py:70-154)."""
     from sleap_nn_amd.utils import cfg_get, to_plain
@@ -124,7 +147,9 @@ def get_head(model_type: str, head_config) -> List[Head]:
         return [MultiInstanceConfmapsHead(**kw("confmaps")), PartAffinityFieldsHead(**kw("pafs"))]
     if model_type == "multi_class_bottomup":
         return [MultiInstanceConfmapsHead(**kw("confmaps")), ClassMapsHead(**kw("class_maps"))]
+    if model_type == "multi_class_topdown":
+        return [CenteredInstanceConfmapsHead(**kw("confmaps")), ClassVectorsHead(**kw("class_vectors"))]
     raise Exception(
         f"{model_type} is not a model type of the MI355X hot path. Supported: `single_instance`, "
-        "`centered_instance`, `centroid`, `bottomup`, `multi_class_bottomup`."
+        "`centered_instance`, `centroid`, `bottomup`, `multi_class_bottomup`, `multi_class_topdown`."
     )

@@ -14,7 +14,7 @@ from typing import Dict, List, Optional
 import torch
 
 from sleap_nn_amd import _lib as L
-from sleap_nn_amd.architectures.heads import ClassMapsHead, Head, get_head
+from sleap_nn_amd.architectures.heads import ClassMapsHead, ClassVectorsHead, Head, get_head
 from sleap_nn_amd.architectures.convnext import ConvNextWrapper
 from sleap_nn_amd.architectures.unet import OpSpec, UNet
 from sleap_nn_amd.utils import cfg_get, cfg_keys
@@ -47,6 +47,9 @@ class Model:
         self.param_shapes = dict(self.backbone.param_shapes)
         self._head_ops_start = len(self.ops)
         for i, head in enumerate(self.heads):
+            if isinstance(head, ClassVectorsHead):
+                self._add_class_vector_head(i, head)
+                continue
             s2f = self.backbone.decoder_stride_to_filters
             if head.output_stride not in self.backbone.decoder_slot_of_stride:
                 if not self.backbone.decoder_slot_of_stride and head.output_stride in s2f:
@@ -72,6 +75,28 @@ class Model:
         self._handle_device: Optional[torch.device] = None
         self._workspace: Optional[torch.Tensor] = None
         self.device = torch.device("cpu")
+
+    def _add_class_vector_head(self, i: int, head: "ClassVectorsHead") -> None:
+        """heads.py:506-539 on the decoder's input feature (architectures/model.py:197-199,253-255)."""
+        if not head.global_pool:
+            raise ValueError("ClassVectorsHead without global_pool is not supported (the reference flattens a fixed-size feature map)")
+        bbn = self.backbone
+        src = bbn.middle_slot
+        cin = int(bbn.max_channels)
+        dst = bbn._new_slot()
+        self.ops.append(OpSpec(L.OP_GLOBAL_MAXPOOL, src, -1, dst, cin, label=f"head_layers.{i}.pre_classification_global_pool"))
+        cur, cur_c = dst, cin
+        for j in range(head.num_fc_layers):
+            name = f"head_layers.{i}.pre_classification{j}_fc"
+            self.param_shapes[name + ".weight"] = (head.num_fc_units, cur_c)
+            self.param_shapes[name + ".bias"] = (head.num_fc_units,)
+            dst = bbn._new_slot()
+            self.ops.append(OpSpec(L.OP_LINEAR, cur, -1, dst, cur_c, 0, head.num_fc_units, 1, L.FLAG_RELU, name + ".weight", name + ".bias", label=name))
+            cur, cur_c = dst, head.num_fc_units
+        name = f"head_layers.{i}.{head.name}"
+        self.param_shapes[name + ".weight"] = (head.channels, cur_c)
+        self.param_shapes[name + ".bias"] = (head.channels,)
+        self.ops.append(OpSpec(L.OP_HEAD, cur, -1, -1, cur_c, 0, head.channels, 1, L.FLAG_SOFTMAX, name + ".weight", name + ".bias", out_index=i, label=name))
 
     @staticmethod
     def _fuse_stem(ops: List[OpSpec]) -> List[OpSpec]:
@@ -306,7 +331,7 @@ class Model:
                     self._workspace.numel(), optrs, L.current_stream_ptr(),
                 )
             )
-        return {head.name: o for head, o in zip(self.heads, outs)}
+        return {head.name: (o.flatten(1) if isinstance(head, ClassVectorsHead) else o) for head, o in zip(self.heads, outs)}
 
     __call__ = forward
 

@@ -213,6 +213,10 @@ int build_plan(const ph_model* m, int B, int H, int W, Plan& plan) {
       const SlotShape& s1 = plan.slots[d.src1];
       PH_REQUIRE(s1.h == h && s1.w == w && s1.c == d.cout, "residual shape mismatch");
     }
+    if (d.kind == PH_OP_GLOBAL_MAXPOOL) {
+      oh = 1;
+      ow = 1;
+    }
     if (d.kind == PH_OP_POOL) {
       oh = (h + 1) / 2;
       ow = (w + 1) / 2;
@@ -230,7 +234,7 @@ int build_plan(const ph_model* m, int B, int H, int W, Plan& plan) {
     if (d.kind == PH_OP_CONVT) tmp = std::max<int64_t>(tmp, (int64_t)B * oh * ow * pad16(d.cin0) * 4);
     PH_REQUIRE(d.dst >= 0 && d.dst < m->n_slots, "bad dst slot %d", d.dst);
     SlotShape& s = plan.slots[d.dst];
-    s.c = (d.kind == PH_OP_POOL || d.kind == PH_OP_UPSAMPLE) ? d.cin0 : d.cout;
+    s.c = (d.kind == PH_OP_POOL || d.kind == PH_OP_UPSAMPLE || d.kind == PH_OP_GLOBAL_MAXPOOL) ? d.cin0 : d.cout;
     s.cp = pad16(s.c);
     s.h = oh;
     s.w = ow;
@@ -332,6 +336,7 @@ ph_model* ph_model_create(const ph_op_desc* ops, int32_t n_ops, const float* con
       case PH_OP_POOL:
       case PH_OP_UPSAMPLE:
       case PH_OP_GELU:
+      case PH_OP_GLOBAL_MAXPOOL:
         break;
       case PH_OP_SCALE_ADD: {
         if (!widx_ok(d.weight) || weight_numel[d.weight] != d.cout || d.cin0 != d.cout || d.src1 < 0) return fail("scale-add needs a (C) scale and two sources", i);
@@ -764,12 +769,18 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
         a.mode = d.kind == PH_OP_PATCH_CONV ? 1 : 0;
         a.H = s0.h;
         a.W = s0.w;
-        a.act = (d.flags & PH_FLAG_GELU) ? 2 : 0;
+        a.act = (d.flags & PH_FLAG_GELU) ? 2 : ((d.flags & PH_FLAG_RELU) ? 1 : 0);
         if (d.flags & PH_FLAG_SCALE_RESIDUAL) {
           a.scale = op.w2_dev;
           a.residual = slot_ptr(d.src1);
         }
         rc = launch_gemm(a, s);
+        break;
+      }
+      case PH_OP_GLOBAL_MAXPOOL: {
+        const SlotShape& s0 = plan.slots[d.src0];
+        PH_REQUIRE(s0.c == d.cin0, "global pool channel mismatch");
+        rc = launch_global_maxpool(slot_ptr(d.src0), slot_ptr(d.dst), batch, s0.h * s0.w, s0.cp, s);
         break;
       }
       case PH_OP_GELU: {
@@ -789,6 +800,10 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
         PH_REQUIRE(out_dev[d.out_index] != nullptr, "output %d is null", d.out_index);
         rc = launch_head(slot_ptr(d.src0), op.w_dev, op.b_dev, out_dev[d.out_index], batch, s0.h * s0.w, s0.cp, d.cout,
                          (d.flags & PH_FLAG_SIGMOID) ? 1 : 0, s);
+        if (rc == PH_OK && (d.flags & PH_FLAG_SOFTMAX)) {
+          PH_REQUIRE(s0.h == 1 && s0.w == 1, "softmax head expects a pooled (1x1) feature");
+          rc = launch_softmax_rows(out_dev[d.out_index], batch, d.cout, s);
+        }
         break;
       }
       default:

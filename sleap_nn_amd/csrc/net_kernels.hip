@@ -952,6 +952,44 @@ __global__ __launch_bounds__(256) void head1x1_kernel(const float* __restrict__ 
   }
 }
 
+// Global max pool over H x W per channel (nn.AdaptiveMaxPool2d(1)): one workgroup per (image, 64 channels).
+__global__ __launch_bounds__(256) void global_maxpool_kernel(const float* __restrict__ src, float* __restrict__ dst, int HW, int cp) {
+  __shared__ float red[4][64];
+  const int b = blockIdx.x, c = blockIdx.y * 64 + (threadIdx.x & 63), r = threadIdx.x >> 6;
+  float m = -INFINITY;
+  if (c < cp)
+    for (int p = r; p < HW; p += 4) m = fmaxf(m, src[((size_t)b * HW + p) * cp + c]);
+  red[r][threadIdx.x & 63] = m;
+  __syncthreads();
+  if (r == 0 && c < cp) dst[(size_t)b * cp + c] = fmaxf(fmaxf(red[0][c & 63], red[1][c & 63]), fmaxf(red[2][c & 63], red[3][c & 63]));
+}
+int launch_global_maxpool(const float* src, float* dst, int B, int HW, int cp, hipStream_t s) {
+  hipLaunchKernelGGL(global_maxpool_kernel, dim3(B, (cp + 63) / 64), dim3(256), 0, s, src, dst, HW, cp);
+  PH_HIP_CHECK(hipGetLastError());
+  return PH_OK;
+}
+
+// Row softmax in place (nn.Softmax(dim=-1) of the class-vector head): one thread per row, max-subtracted.
+__global__ void softmax_rows_kernel(float* __restrict__ x, int rows, int n) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  float* p = x + (size_t)r * n;
+  float m = -INFINITY;
+  for (int i = 0; i < n; ++i) m = fmaxf(m, p[i]);
+  float s = 0.f;
+  for (int i = 0; i < n; ++i) {
+    const float e = expf(p[i] - m);
+    p[i] = e;
+    s += e;
+  }
+  for (int i = 0; i < n; ++i) p[i] = p[i] / s;
+}
+int launch_softmax_rows(float* x, int rows, int n, hipStream_t s) {
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3((rows + 63) / 64), dim3(64), 0, s, x, rows, n);
+  PH_HIP_CHECK(hipGetLastError());
+  return PH_OK;
+}
+
 int launch_head(const float* src, const float* w, const float* bias, float* dst, int B, int HW, int cp, int cout, int sigmoid, hipStream_t s) {
   const size_t npix = (size_t)B * HW;
   const size_t lds = (64 * (cp + 1) + (size_t)cout * cp) * sizeof(float);

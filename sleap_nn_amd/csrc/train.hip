@@ -31,6 +31,10 @@ int build_bwd_plan(const ph_model* m, int B, int H, int W, BwdPlan& bp) {
       set_error("backward needs the unfused program with bilinear up-sampling (no stem / conv+pool fusion / transposed conv)");
       return PH_E_INVALID;
     }
+    if (d.kind == PH_OP_GLOBAL_MAXPOOL || (d.kind == PH_OP_HEAD && (d.flags & PH_FLAG_SOFTMAX))) {
+      set_error("backward of the class-vector head (global pool / softmax + cross entropy) is not implemented");
+      return PH_E_INVALID;
+    }
     if (d.kind == PH_OP_LINEAR && (d.flags & (PH_FLAG_GELU | PH_FLAG_SCALE_RESIDUAL))) {
       set_error("backward needs the unfused ConvNeXt program (GELU / layer-scale as ops of their own)");
       return PH_E_INVALID;

@@ -6,3 +6,4 @@ from sleap_nn_amd.inference.layers.centroid import CentroidLayer  # noqa: F401
 from sleap_nn_amd.inference.layers.configs import PostprocessConfig, PreprocessConfig  # noqa: F401
 from sleap_nn_amd.inference.layers.single_instance import SingleInstanceLayer  # noqa: F401
 from sleap_nn_amd.inference.layers.topdown import TopDownLayer  # noqa: F401
+from sleap_nn_amd.inference.layers.topdown_multiclass import CenteredInstanceMultiClassLayer, TopDownMultiClassLayer  # noqa: F401

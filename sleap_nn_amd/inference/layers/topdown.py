@@ -57,6 +57,24 @@ class TopDownLayer:
         out = Outputs(pred_keypoints=full_k, pred_crop_keypoints=full_c, pred_peak_values=full_v, pred_centroids=centroids, pred_centroid_values=cvals,
                       instance_scores=cvals, preprocess_info=cout.preprocess_info)
         out.instance_bboxes = full_b
+        if s2.pred_class_probs is not None:
+            # multi-class identity (layers/topdown.py:333-390): classify the crops of each frame on their own
+            from sleap_nn_amd.inference.ops.identity import get_class_inds_from_vectors
+
+            vecs = s2.pred_class_probs.squeeze(1)
+            full_ci = torch.full((B, I, n_nodes), -1, dtype=torch.int64, device=dev)
+            full_ts = torch.full((B, I), float("nan"), device=dev)
+            want = getattr(getattr(self.centered_instance_layer, "postprocess_config", None), "return_class_vectors", False)
+            full_cv = torch.full((B, I, vecs.shape[-1]), float("nan"), device=dev) if want else None
+            for b in torch.unique(idx[:, 0]).tolist():
+                rows = (idx[:, 0] == b).nonzero(as_tuple=False).flatten()
+                ci, cp = get_class_inds_from_vectors(vecs[rows])
+                slots = idx[rows, 1]
+                full_ci[b, slots] = ci.to(dev).view(-1, 1).expand(-1, n_nodes)
+                full_ts[b, slots] = cp.to(dev)
+                if full_cv is not None:
+                    full_cv[b, slots] = vecs[rows]
+            out.pred_class_inds, out.instance_tracking_scores, out.pred_class_vectors = full_ci, full_ts, full_cv
         if self.return_crops:
             fc = torch.zeros((B, I, crops.shape[1], ch, cw), dtype=crops.dtype, device=dev)
             fc[idx[:, 0], idx[:, 1]] = crops

@@ -64,3 +64,21 @@ def classify_peaks_from_maps(class_maps, peak_points, peak_vals, peak_sample_ind
     point_vals[sb[pi], ci, sc[pi]] = vals[pi]
     class_probs[sb[pi], ci, sc[pi]] = probs[pi, ci]
     return points, point_vals, class_probs
+
+
+def get_class_inds_from_vectors(peak_class_probs: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """identity.py:149-173: Hungarian matching of samples (crops of ONE frame) to classes on
+    ``-prob``; samples beyond the number of classes stay unassigned (-1 / NaN).  Host code (``ph_lsap``)."""
+    from sleap_nn_amd.inference.ops.paf import linear_sum_assignment
+
+    probs = torch.as_tensor(peak_class_probs).detach().cpu().to(torch.float32)
+    n = int(probs.shape[0])
+    inds = torch.full((n,), -1, dtype=torch.int64)
+    pr = torch.full((n,), float("nan"))
+    if n == 0 or probs.shape[1] == 0:
+        return inds, pr
+    r, c = linear_sum_assignment(-probs.numpy().astype(np.float64))
+    for a, b in zip(r, c):
+        inds[int(a)] = int(b)
+        pr[int(a)] = probs[int(a), int(b)]
+    return inds, pr

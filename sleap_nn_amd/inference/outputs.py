@@ -30,6 +30,9 @@ class Outputs:
     instance_bboxes: Optional[torch.Tensor] = None  # (B, I, 4, 2)
     instance_tracking_scores: Optional[torch.Tensor] = None  # (B, I)
     pred_class_maps: Optional[torch.Tensor] = None
+    pred_class_inds: Optional[torch.Tensor] = None  # (B, I, N) int64, -1 = unassigned
+    pred_class_probs: Optional[torch.Tensor] = None  # stage 2 of multi-class top-down: (n_crops, 1, n_classes)
+    pred_class_vectors: Optional[torch.Tensor] = None  # (B, I, n_classes) when requested
     pred_paf_graph: Optional[Tuple[torch.Tensor, ...]] = None
     preprocess_info: Optional[PreprocInfo] = None
     frame_indices: Optional[torch.Tensor] = None

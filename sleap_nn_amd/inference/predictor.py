@@ -49,6 +49,18 @@ def _select_layer(assets: Sequence[LoadedAssets], device: str, post: Postprocess
         h = a.head_config
         return BottomUpMultiClassLayer(backend(a), h["confmaps"]["output_stride"], h["class_maps"]["output_stride"], max_instances=max_instances,
                                        max_stride=a.backbone_config["max_stride"], preprocess_config=pre(a), postprocess_config=post)
+    if "centroid" in by_type and "multi_class_topdown" in by_type:
+        from sleap_nn_amd.inference.layers.topdown_multiclass import CenteredInstanceMultiClassLayer, TopDownMultiClassLayer
+
+        c, i = by_type["centroid"], by_type["multi_class_topdown"]
+        cl = CentroidLayer(backend(c), c.head_config["confmaps"]["output_stride"], max_instances=max_instances, max_stride=c.backbone_config["max_stride"],
+                           preprocess_config=pre(c), postprocess_config=post)
+        il = CenteredInstanceMultiClassLayer(backend(i), i.head_config["confmaps"]["output_stride"], max_stride=i.backbone_config["max_stride"], postprocess_config=post,
+                                             class_names=i.head_config["class_vectors"].get("classes"))
+        crop = int(i.preprocessing.get("crop_size") or 0)
+        if crop <= 0:
+            raise ValueError("multi-class centered-instance run directory has no preprocessing.crop_size")
+        return TopDownMultiClassLayer(cl, il, (crop, crop))
     if "centroid" in by_type and "centered_instance" in by_type:
         c, i = by_type["centroid"], by_type["centered_instance"]
         cl = CentroidLayer(backend(c), c.head_config["confmaps"]["output_stride"], max_instances=max_instances, max_stride=c.backbone_config["max_stride"],

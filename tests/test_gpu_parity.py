@@ -494,3 +494,65 @@ def test_fused_pool_epilogue_odd_sizes_and_unfused_equivalence():
         out = m.to(DEV)(img.to(DEV))["SingleInstanceConfmapsHead"].cpu()
         assert out.shape == ref.shape
         assert (out - ref).abs().max().item() <= CMS_ATOL * max(1.0, ref.abs().max().item()), (filters, hw)
+
+
+def test_multiclass_topdown_reproduces_reference_golden():
+    """multi_class_topdown: ClassVectorsHead on the GPU (global max pool, FC stack on the row GEMM, softmax),
+    per-frame Hungarian class assignment, and the full centroid -> crops -> keypoints + identity pipeline vs the
+    reference's golden pickle (keypoints within 2e-3 px as for plain top-down; class indices identical)."""
+    from sleap_nn_amd.architectures.model import Model
+    from sleap_nn_amd.inference.backends import HipBackend
+    from sleap_nn_amd.inference.layers import CenteredInstanceMultiClassLayer, CentroidLayer, PostprocessConfig, TopDownMultiClassLayer
+
+    g = G.load("multiclass_topdown.npz")
+    cfg = json.loads(str(g["config_json"]))
+    sd = {k[2:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("w/")}
+    m = Model("unet", cfg["backbone"], cfg["heads"], cfg["model_type"])
+    m.load_state_dict(sd, strict=True)
+    m.to(DEV)
+    out = m(torch.from_numpy(g["crops"]).to(DEV))
+    torch.cuda.synchronize()
+    assert (out["CenteredInstanceConfmapsHead"].cpu() - torch.from_numpy(g["out/CenteredInstanceConfmapsHead"])).abs().max().item() <= CMS_ATOL
+    cv = out["ClassVectorsHead"].cpu().numpy()
+    assert cv.shape == g["out/ClassVectorsHead"].shape
+    np.testing.assert_allclose(cv, g["out/ClassVectorsHead"], rtol=2e-3, atol=1e-7)  # probabilities down to 1e-20: relative bar
+    # stage-2 layer on the golden's own crops: joint assignment inside the layer, per-frame in the composed layer
+    pc = PostprocessConfig(peak_threshold=0.03, refinement="integral", integral_patch_size=5)
+    l2 = CenteredInstanceMultiClassLayer(HipBackend(m, DEV), output_stride=cfg["heads"]["confmaps"]["output_stride"], max_stride=cfg["backbone"]["max_stride"],
+                                         postprocess_config=pc, class_names=cfg["heads"]["class_vectors"]["classes"])
+    o2 = l2.predict(torch.from_numpy(g["crops"]).to(DEV))
+    np.testing.assert_allclose(o2.pred_keypoints.squeeze(1).cpu().numpy(), g["crop_peaks"], rtol=0, atol=2e-3, equal_nan=True)
+    # composed pipeline on the full frames with the centroid fixture model of topdown.npz
+    z = G.load("topdown.npz")
+    tcfg = json.loads(str(z["config_json"]))
+    mc = Model("unet", tcfg["centroid"]["backbone"], tcfg["centroid"]["heads"], "centroid")
+    mc.load_state_dict({k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("wc/")}, strict=True)
+    mc.to(DEV)
+    cl = CentroidLayer(HipBackend(mc, DEV), output_stride=tcfg["centroid"]["heads"]["confmaps"]["output_stride"], max_stride=tcfg["centroid"]["backbone"]["max_stride"],
+                       postprocess_config=PostprocessConfig(peak_threshold=0.03, refinement="integral", integral_patch_size=5, max_instances=6))
+    td = TopDownMultiClassLayer(cl, l2, (cfg["crop_size"], cfg["crop_size"]))
+    frames = torch.from_numpy(g["frames"])
+    res = td.predict(frames.to(DEV)).cpu()
+    fi = g["crop_frame"]
+    for f in range(frames.shape[0]):
+        gold_k = g["gold_pred_instance_peaks"][fi == f]
+        gold_c = g["gold_pred_class_inds"][fi == f]
+        gold_cent = g["gold_pred_centroids"][fi == f]
+        got_cent = res.pred_centroids[f].numpy()
+        live = ~np.isnan(got_cent).any(axis=1)
+        assert live.sum() == len(gold_cent)
+        for k_ref, c_ref, ce_ref in zip(gold_k, gold_c, gold_cent):  # instances are matched through their centroids
+            d = np.abs(got_cent - ce_ref[None]).sum(axis=1)
+            d[~live] = np.inf
+            j = int(np.argmin(d))
+            assert d[j] <= 2e-2, (f, d)
+            got = res.pred_keypoints[f, j].numpy()
+            assert np.array_equal(np.isnan(got), np.isnan(k_ref))  # this fixture model's maps stay below the 0.03 threshold: NaN keypoints
+            np.testing.assert_allclose(got, k_ref, rtol=0, atol=2e-2, equal_nan=True)
+            assert int(res.pred_class_inds[f, j, 0]) == int(c_ref)
+            assert torch.isfinite(res.instance_tracking_scores[f, j])
+    assert class_names_ok(td.class_names, cfg)
+
+
+def class_names_ok(names, cfg):
+    return list(names) == list(cfg["heads"]["class_vectors"]["classes"])
