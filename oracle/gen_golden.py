@@ -546,6 +546,37 @@ def multiclass_topdown_fixture():
     save("multiclass_topdown.npz", **arrs)
 
 
+def centroid_nms_fixture():
+    """Reference TopDownLayer._centroid_nms_mask (layers/topdown.py:395-438) on random centroid sets."""
+    import types
+
+    from sleap_nn.inference.layers.topdown import TopDownLayer
+
+    g = torch.Generator().manual_seed(77)
+    arrs = {}
+    n = 12
+    for c in range(n):
+        B, I = 3, int(torch.randint(1, 9, (1,), generator=g))
+        crop = (int(torch.randint(16, 80, (1,), generator=g)), int(torch.randint(16, 80, (1,), generator=g)))
+        thr = float([0.2, 0.5, 0.75][c % 3])
+        cent = torch.rand((B, I, 2), generator=g) * 120
+        if I > 2:
+            cent[:, 1] = cent[:, 0] + torch.rand((B, 2), generator=g) * 12  # close pairs
+        vals = torch.rand((B, I), generator=g)
+        if I > 3 and c % 2 == 0:
+            vals[:, 3] = vals[:, 2]  # confidence ties
+        drop = torch.rand((B, I), generator=g) < 0.2
+        cent[drop] = float("nan")
+        vals[drop] = float("nan")
+        valid = ~torch.isnan(cent).any(-1)
+        ns = types.SimpleNamespace(crop_size=crop, centroid_nms_threshold=thr, _bbox_iou=TopDownLayer._bbox_iou)
+        keep = TopDownLayer._centroid_nms_mask(ns, cent, vals, valid)
+        arrs[f"{c}/centroids"], arrs[f"{c}/vals"], arrs[f"{c}/keep"] = _np(cent), _np(vals), _np(keep)
+        arrs[f"{c}/crop"], arrs[f"{c}/thr"] = np.array(crop), np.array(thr)
+    arrs["n_cases"] = np.array(n)
+    save("centroid_nms.npz", **arrs)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     if not only or "core" in only:
@@ -562,3 +593,5 @@ if __name__ == "__main__":
         filters_fixture()
     if not only or "mctopdown" in only:
         multiclass_topdown_fixture()
+    if not only or "nms" in only:
+        centroid_nms_fixture()

@@ -16,8 +16,8 @@ from sleap_nn_amd.inference.outputs import Outputs
 class TopDownLayer:
     def __init__(self, centroid_layer: CentroidLayer, centered_instance_layer: CenteredInstanceLayer, crop_size: Tuple[int, int],
                  centroid_nms: bool = False, centroid_nms_threshold: float = 0.5, return_crops: bool = False) -> None:
-        if centroid_nms:
-            raise NotImplementedError("centroid_nms is not part of the MI355X hot path yet")
+        self.centroid_nms = bool(centroid_nms)
+        self.centroid_nms_threshold = float(centroid_nms_threshold)
         self.centroid_layer = centroid_layer
         self.centered_instance_layer = centered_instance_layer
         self.crop_size = crop_size
@@ -31,6 +31,8 @@ class TopDownLayer:
         B, I, _ = centroids.shape
         dev = centroids.device
         valid = ~torch.isnan(centroids).any(dim=-1)
+        if self.centroid_nms:
+            valid = valid & self._centroid_nms_mask(centroids, cvals, valid)
         idx = valid.nonzero(as_tuple=False)
         x = self.centroid_layer._to_4d_tensor(image).to(dev)
         n_valid = int(idx.shape[0])
@@ -80,5 +82,38 @@ class TopDownLayer:
             fc[idx[:, 0], idx[:, 1]] = crops
             out.crops = fc
         return out
+
+    def _centroid_nms_mask(self, centroids: torch.Tensor, centroid_vals: torch.Tensor, valid_mask: torch.Tensor) -> torch.Tensor:
+        """Greedy NMS on the IoU of the crop boxes centred on each centroid (layers/topdown.py:395-438): per
+        frame, in order of decreasing confidence, a centroid is dropped when its box overlaps an already
+        kept one by more than ``centroid_nms_threshold``.  Host logic in fp32 (a handful of boxes per frame)."""
+        import numpy as np
+
+        c = centroids.detach().cpu().numpy().astype(np.float32)
+        v = centroid_vals.detach().cpu().numpy().astype(np.float32)
+        vm = valid_mask.detach().cpu().numpy()
+        keep = np.ones_like(vm)
+        h, w = np.float32(self.crop_size[0]), np.float32(self.crop_size[1])
+        hh, hw = np.float32(self.crop_size[0] / 2.0), np.float32(self.crop_size[1] / 2.0)
+
+        def iou(a, b):
+            ih = max(np.float32(min(a[1] + hh, b[1] + hh) - max(a[1] - hh, b[1] - hh)), np.float32(0))
+            iw = max(np.float32(min(a[0] + hw, b[0] + hw) - max(a[0] - hw, b[0] - hw)), np.float32(0))
+            inter = np.float32(ih * iw)
+            return inter / (np.float32(2.0) * (h * w) - inter)
+
+        for b in range(c.shape[0]):
+            vb = np.nonzero(vm[b])[0]
+            if len(vb) <= 1:
+                continue
+            order = torch.from_numpy(v[b, vb]).argsort(descending=True).numpy()  # torch's ordering for ties, like the reference
+            kept = []
+            for j in order:
+                cj = c[b, vb[j]]
+                if any(iou(cj, k) > np.float32(self.centroid_nms_threshold) for k in kept):
+                    keep[b, vb[j]] = False
+                    continue
+                kept.append(cj)
+        return torch.from_numpy(keep).to(valid_mask.device)
 
     __call__ = predict

@@ -283,3 +283,18 @@ def test_post_inference_filters_match_reference():
     assert keep[0] == want
     dropped = [i for i in range(n_inst) if i not in keep[0]]
     assert torch.isnan(out.pred_keypoints[0, dropped]).all() and not torch.isnan(out.instance_scores[0, keep[0]]).any()
+
+
+def test_centroid_nms_matches_reference():
+    """TopDownLayer._centroid_nms_mask (host logic) vs the reference's, incl. NaN slots, close pairs and ties."""
+    from sleap_nn_amd.inference.layers.topdown import TopDownLayer
+
+    g = G.load("centroid_nms.npz")
+    for c in range(int(g["n_cases"])):
+        layer = TopDownLayer.__new__(TopDownLayer)
+        layer.crop_size = tuple(int(v) for v in g[f"{c}/crop"])
+        layer.centroid_nms_threshold = float(g[f"{c}/thr"])
+        cent, vals = torch.from_numpy(g[f"{c}/centroids"]), torch.from_numpy(g[f"{c}/vals"])
+        valid = ~torch.isnan(cent).any(-1)
+        keep = layer._centroid_nms_mask(cent, vals, valid)
+        np.testing.assert_array_equal(keep.numpy(), g[f"{c}/keep"], err_msg=f"case {c}")
