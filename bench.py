@@ -151,17 +151,23 @@ def main():
     params = layer.grouping_params()
     pending = []
 
+    inflight = []
+
     def step():
-        """Forward + peaks + PAF scoring on the GPU; the C++ grouping of this batch runs in a worker
-        thread and overlaps the next step's GPU work (Predictor._predict_streaming_pipelined).  Every
-        step's grouping is collected before the closing barrier of the timed region."""
+        """Forward + peaks + PAF scoring + async D2H are enqueued for this batch; then the PREVIOUS batch's
+        results (its D2H event fired long ago) are handed to the C++ grouping worker.  The GPU always has the
+        next batch queued and the grouping of batch k-1 overlaps the GPU work of batch k
+        (Predictor._predict_streaming_pipelined).  Every batch is grouped before the closing barrier."""
         raw = layer.backend(frames)  # uint8 frames -> {"MultiInstanceConfmapsHead", "PartAffinityFieldsHead"}
-        scored = layer._score_pafs_on_gpu({"MultiInstanceConfmapsHead": cms, "PartAffinityFieldsHead": pafs}, info)
-        pending.append(pool.submit(group_scored_batch, scored, params))
+        inflight.append(layer._enqueue_scoring({"MultiInstanceConfmapsHead": cms, "PartAffinityFieldsHead": pafs}, info))
+        if len(inflight) > 1:
+            pending.append(pool.submit(group_scored_batch, layer._finish_scoring(inflight.pop(0)), params))
         out = pending.pop(0).result() if len(pending) > 1 else None
         return raw, out
 
     def drain():
+        while inflight:
+            pending.append(pool.submit(group_scored_batch, layer._finish_scoring(inflight.pop(0)), params))
         outs = [f.result() for f in pending]
         pending.clear()
         return outs

@@ -36,7 +36,11 @@ class BottomUpLayer(InferenceLayer):
         self._cand_cap = 0
 
     # -- GPU stage ------------------------------------------------------------------------
-    def _score_pafs_on_gpu(self, raw_out: dict, info: PreprocInfo) -> ScoredBatch:
+    def _enqueue_scoring(self, raw_out: dict, info: PreprocInfo) -> dict:
+        """Enqueue peak finding + candidate scoring and ONE asynchronous D2H of the counts and of the
+        (capacity-sized) payload into pinned memory; no host sync.  ``_finish_scoring`` turns the
+        returned handle into a ``ScoredBatch`` once its event has fired, so a caller can keep the GPU
+        busy with the next batch while this one drains (HIP stream order does the rest)."""
         cms = raw_out["MultiInstanceConfmapsHead"]
         pafs = raw_out["PartAffinityFieldsHead"]  # (B, 2E, H, W); the permute is folded into the kernel
         pc = self.postprocess_config
@@ -45,40 +49,57 @@ class BottomUpLayer(InferenceLayer):
         dev = cms.device
         peak_cap = max(self._peak_cap, B * n_nodes * 32, 1024)
         cand_cap = max(self._cand_cap, B * sc.n_edges * 256, 4096)
-        while True:
-            xy, vals, sb, ch, counts, _ = find_local_peaks_device(cms, pc.peak_threshold, pc.effective_refinement, pc.integral_patch_size, peak_cap)
-            xy = xy * self.cms_output_stride  # peaks * cms_output_stride (bottomup.py:111)
-            offs = counts[1 + B : 2 + 2 * B]
-            ce, cs, cd, score, coff = score_paf_lines_device(
-                pafs, xy, ch, offs, peak_cap, sc.edges_on(dev), sc.n_nodes, sc.n_points, sc.pafs_stride, sc.max_edge_length_ratio,
-                sc.dist_penalty_weight, cand_cap,
-            )
-            # one packed D2H + one sync
-            head = torch.cat([counts, coff]).cpu().numpy()
-            n_peaks = int(head[0])
-            n_cand = int(head[2 + 2 * B + B])
-            if n_peaks > peak_cap or n_cand > cand_cap:
-                peak_cap = max(peak_cap, int(n_peaks * 1.25) + 16)
-                cand_cap = max(cand_cap, int(n_cand * 1.25) + 16)
-                if n_peaks > xy.shape[0]:
-                    continue  # peaks were truncated: candidates are incomplete, redo with room
-                continue
-            break
-        self._peak_cap, self._cand_cap = peak_cap, cand_cap
+        xy, vals, sb, ch, counts, _ = find_local_peaks_device(cms, pc.peak_threshold, pc.effective_refinement, pc.integral_patch_size, peak_cap)
+        xy = xy * self.cms_output_stride  # peaks * cms_output_stride (bottomup.py:111)
+        offs = counts[1 + B : 2 + 2 * B]
+        ce, cs, cd, score, coff = score_paf_lines_device(
+            pafs, xy, ch, offs, peak_cap, sc.edges_on(dev), sc.n_nodes, sc.n_points, sc.pafs_stride, sc.max_edge_length_ratio,
+            sc.dist_penalty_weight, cand_cap,
+        )
+        # one packed D2H (int32 rows travel bit-cast as float32): [head | xy | vals | score | ch | ce | cs | cd]
+        head = torch.cat([counts, coff])
+        packed = torch.cat([head.view(torch.float32), xy.reshape(-1), vals, score, torch.cat([ch, ce, cs, cd]).view(torch.float32)])
+        key = (int(packed.numel()), dev)
+        pool = self.__dict__.setdefault("_pinned", {})
+        host = pool.get(key, [])
+        buf = host.pop() if host else torch.empty(packed.numel(), dtype=torch.float32, pin_memory=True)
+        buf.copy_(packed, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dev))
+        return {"buf": buf, "key": key, "event": ev, "B": B, "n_nodes": n_nodes, "peak_cap": int(xy.shape[0]), "cand_cap": int(score.shape[0]), "n_head": int(head.numel()),
+                "raw": raw_out, "info": info, "keep": packed}
+
+    def _finish_scoring(self, h: dict) -> ScoredBatch:
+        h["event"].synchronize()
+        B, n_nodes, pcap, ccap = h["B"], h["n_nodes"], h["peak_cap"], h["cand_cap"]
+        arr = h["buf"].numpy()
+        head = arr[: h["n_head"]].view(np.int32)
+        n_peaks = int(head[0])
+        n_cand = int(head[2 + 2 * B + B])
+        if n_peaks > pcap or n_cand > ccap:  # rare: capacity too small -> grow and redo this batch synchronously
+            self._peak_cap = max(self._peak_cap, int(n_peaks * 1.25) + 16)
+            self._cand_cap = max(self._cand_cap, int(n_cand * 1.25) + 16)
+            self._pinned[h["key"]] = []
+            return self._finish_scoring(self._enqueue_scoring(h["raw"], h["info"]))
+        self._peak_cap, self._cand_cap = max(self._peak_cap, pcap), max(self._cand_cap, ccap)
         peak_offsets = head[1 + B : 2 + 2 * B].astype(np.int32)
         cand_offsets = head[2 + 2 * B :].astype(np.int32)
-        # one packed D2H for all payload arrays (int32 rows travel bit-cast as float32)
-        packed = torch.cat([xy[:n_peaks].reshape(-1), vals[:n_peaks], score[:n_cand],
-                            torch.cat([ch[:n_peaks], ce[:n_cand], cs[:n_cand], cd[:n_cand]]).view(torch.float32)]).cpu().numpy()
-        n_fl = 3 * n_peaks + n_cand
-        fl = packed[:n_fl]
-        il = packed[n_fl:].view(np.int32)
-        peaks_xy = fl[: 2 * n_peaks].reshape(-1, 2)
-        peak_vals = fl[2 * n_peaks : 3 * n_peaks]
-        cand_score = fl[3 * n_peaks :]
-        peak_channel = il[:n_peaks]
-        cand_edge, cand_src, cand_dst = il[n_peaks : n_peaks + n_cand], il[n_peaks + n_cand : n_peaks + 2 * n_cand], il[n_peaks + 2 * n_cand :]
+        o = h["n_head"]
+        peaks_xy = arr[o : o + 2 * n_peaks].reshape(-1, 2).copy()
+        o += 2 * pcap
+        peak_vals = arr[o : o + n_peaks].copy()
+        o += pcap
+        cand_score = arr[o : o + n_cand].copy()
+        o += ccap
+        il = arr[o:].view(np.int32)
+        peak_channel = il[:n_peaks].copy()
+        cand_edge = il[pcap : pcap + n_cand].copy()
+        cand_src = il[pcap + ccap : pcap + ccap + n_cand].copy()
+        cand_dst = il[pcap + 2 * ccap : pcap + 2 * ccap + n_cand].copy()
+        self._pinned.setdefault(h["key"], []).append(h["buf"])  # every view was copied out: the pinned buffer can be reused
 
+        pc = self.postprocess_config
+        cms, pafs = h["raw"]["MultiInstanceConfmapsHead"], h["raw"]["PartAffinityFieldsHead"]
         skip = False
         if self.max_peaks_per_node is not None:
             for b in range(B):
@@ -91,9 +112,13 @@ class BottomUpLayer(InferenceLayer):
         return ScoredBatch(
             peaks_xy=peaks_xy, peak_vals=peak_vals, peak_channel=peak_channel, peak_offsets=peak_offsets,
             cand_edge=cand_edge, cand_src=cand_src, cand_dst=cand_dst, cand_score=cand_score, cand_offsets=cand_offsets,
-            info=info.cpu(), n_samples=B, n_nodes=n_nodes, skip_paf=skip,
+            info=h["info"].cpu(), n_samples=B, n_nodes=n_nodes, skip_paf=skip,
             cms=cms.detach().cpu() if keep_cms else None, pafs=pafs.detach().cpu() if keep_pafs else None,
         )
+
+    def _score_pafs_on_gpu(self, raw_out: dict, info: PreprocInfo) -> ScoredBatch:
+        """layers/bottomup.py:95-195: GPU stage with one sync (enqueue + finish back to back)."""
+        return self._finish_scoring(self._enqueue_scoring(raw_out, info))
 
     def grouping_params(self) -> GroupingParams:
         max_instances = getattr(self.postprocess_config, "max_instances", None)

@@ -115,17 +115,26 @@ class Predictor:
         params = layer.grouping_params()
         outs: List[Optional[Outputs]] = []
         pending = []
+        inflight = []  # batches whose GPU stage is enqueued but whose results have not been collected yet
+
+        def collect(pool):
+            s1, n1, h = inflight.pop(0)
+            pending.append((s1, n1, pool.submit(group_scored_batch, layer._finish_scoring(h), params)))
+
         with ThreadPoolExecutor(max_workers=1) as pool:
             for s, batch in self._batch_iter(frames):
                 x, info = layer.preprocess(batch)
                 raw = layer.backend(x)
-                scored = layer._score_pafs_on_gpu(raw, info)
-                pending.append((s, len(batch), pool.submit(group_scored_batch, scored, params)))
+                inflight.append((s, len(batch), layer._enqueue_scoring(raw, info)))  # async D2H, no sync
+                if len(inflight) > 1:  # the GPU already has the next batch queued while this one's results are read
+                    collect(pool)
                 while len(pending) > 2:
                     s0, n0, fut = pending.pop(0)
                     o = fut.result()
                     o.frame_indices = torch.arange(s0, s0 + n0)
                     outs.append(o)
+            while inflight:
+                collect(pool)
             for s0, n0, fut in pending:
                 o = fut.result()
                 o.frame_indices = torch.arange(s0, s0 + n0)
