@@ -59,7 +59,7 @@ int build_bwd_plan(const ph_model* m, int B, int H, int W, BwdPlan& bp) {
       const SlotShape& s0 = bp.act.slots[d.src0];
       bp.head_dy_off[d.out_index] = off;
       off += align_up((int64_t)B * d.cout * s0.h * s0.w * 4, 256);
-      scratch = std::max<int64_t>(scratch, head_bwd_scratch_floats(s0.cp, d.cout));
+      scratch = std::max<int64_t>(scratch, head_bwd_scratch_floats(s0.cp, d.cout, (int64_t)B * s0.h * s0.w));
       scratch = std::max<int64_t>(scratch, (int64_t)d.cout * 64 + d.cout + 64);
     } else if (d.kind == PH_OP_CONV) {
       const SlotShape& s0 = bp.act.slots[d.src0];
@@ -174,13 +174,18 @@ int ph_model_backward(ph_model* m, const void* input_dev, int32_t in_dtype, int3
         const SlotShape& so = bp.act.slots[d.dst];
         PH_REQUIRE(init[d.dst], "conv output slot %d received no gradient", d.dst);
         const size_t npix = (size_t)batch * so.h * so.w;
-        if (d.flags & PH_FLAG_RELU) {
-          rc = launch_relu_mask(G(d.dst), A(d.dst), npix * so.cp, s);
+        if ((d.flags & PH_FLAG_RELU) && d.bias >= 0) {  // mask + bias gradient in one pass
+          rc = launch_relu_mask_bias_grad(G(d.dst), A(d.dst), npix, so.cp, d.cout, grads_flat_dev + m->weight_offset[d.bias], scratch, s);
           if (rc != PH_OK) return rc;
-        }
-        if (d.bias >= 0) {
-          rc = launch_bias_grad(G(d.dst), npix, so.cp, d.cout, grads_flat_dev + m->weight_offset[d.bias], scratch, s);
-          if (rc != PH_OK) return rc;
+        } else {
+          if (d.flags & PH_FLAG_RELU) {
+            rc = launch_relu_mask(G(d.dst), A(d.dst), npix * so.cp, s);
+            if (rc != PH_OK) return rc;
+          }
+          if (d.bias >= 0) {
+            rc = launch_bias_grad(G(d.dst), npix, so.cp, d.cout, grads_flat_dev + m->weight_offset[d.bias], scratch, s);
+            if (rc != PH_OK) return rc;
+          }
         }
         const int srcs[2] = {d.src0, d.src1}, parts[2] = {d.cin0, d.cin1}, offs[2] = {0, d.cin0};
         for (int part = 0; part < 2; ++part) {

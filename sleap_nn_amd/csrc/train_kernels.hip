@@ -167,74 +167,62 @@ __global__ __launch_bounds__(256) void head_bwd_dx_kernel(const float* __restric
   }
 }
 
-constexpr int HEAD_SLICES = 128;
-// partial[(co*cp + ci)][slice] and bias partial: block = (co, slice), threads over ci (looping pixels)
-__global__ __launch_bounds__(256) void head_bwd_dw_partial_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ y_out,
-                                                                  int sigmoid, int cout, int cp, int HW, size_t npix, float* __restrict__ partial_w,
-                                                                  float* __restrict__ partial_b) {
-  __shared__ float red[4];
-  const int co = blockIdx.x, sl = blockIdx.y;
-  const size_t per = (npix + HEAD_SLICES - 1) / HEAD_SLICES;
-  const size_t lo = (size_t)sl * per, hi = std::min(npix, lo + per);
-  // threads: ci = tid % cpq ... use tid over ci when cp <= 256
-  float bsum = 0.f;
-  for (int ci = threadIdx.x; ci < cp; ci += 256) {
-    float acc = 0.f;
-    for (size_t p = lo; p < hi; ++p) {
+// dY (NCHW, optionally times sigmoid'(y)) -> rows [pixel][cop] with zero pad channels, the operand layout of the
+// row weight-gradient GEMM and of the bias reduction.  Tile transpose through LDS: 64 pixels x cop channels.
+__global__ __launch_bounds__(256) void head_dy_rows_kernel(const float* __restrict__ dy, const float* __restrict__ y_out, int sigmoid, int cout, int cop, int HW,
+                                                           size_t npix, float* __restrict__ rows) {
+  extern __shared__ float tile[];  // [cop][65]
+  const size_t p0 = (size_t)blockIdx.x * 64;
+  for (int i = threadIdx.x; i < cop * 64; i += 256) {
+    const int co = i >> 6, pp = i & 63;
+    const size_t p = p0 + pp;
+    float d = 0.f;
+    if (co < cout && p < npix) {
       const size_t b = p / HW, hw = p - b * HW;
-      float d = dy[(b * cout + co) * HW + hw];
+      d = dy[(b * cout + co) * HW + hw];
       if (sigmoid) {
         const float yv = y_out[(b * cout + co) * HW + hw];
         d *= yv * (1.f - yv);
       }
-      acc += d * x[p * cp + ci];
     }
-    partial_w[((size_t)co * cp + ci) * HEAD_SLICES + sl] = acc;
+    tile[co * 65 + pp] = d;
   }
-  for (size_t p = lo + threadIdx.x; p < hi; p += 256) {
-    const size_t b = p / HW, hw = p - b * HW;
-    float d = dy[(b * cout + co) * HW + hw];
-    if (sigmoid) {
-      const float yv = y_out[(b * cout + co) * HW + hw];
-      d *= yv * (1.f - yv);
-    }
-    bsum += d;
-  }
-  const float t = block_sum_256(bsum, red);
-  if (threadIdx.x == 0) partial_b[co * HEAD_SLICES + sl] = t;
-}
-
-__global__ void head_bwd_dw_final_kernel(const float* __restrict__ partial_w, const float* __restrict__ partial_b, int cout, int cin, int cp,
-                                         float* __restrict__ gw /* [cout][cin] */, float* __restrict__ gb /* [cout] or nullptr */) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < cout * cin) {
-    const int co = i / cin, ci = i - co * cin;
-    float s = 0.f;
-    for (int k = 0; k < HEAD_SLICES; ++k) s += partial_w[((size_t)co * cp + ci) * HEAD_SLICES + k];
-    gw[i] = s;
-  }
-  if (gb && i < cout) {
-    float s = 0.f;
-    for (int k = 0; k < HEAD_SLICES; ++k) s += partial_b[i * HEAD_SLICES + k];
-    gb[i] = s;
+  __syncthreads();
+  for (int i = threadIdx.x; i < cop * 64; i += 256) {
+    const int pp = i / cop, co = i - pp * cop;
+    if (p0 + pp < npix) rows[(p0 + pp) * cop + co] = tile[co * 65 + pp];
   }
 }
 
+// Head weight / bias gradients through the row weight-gradient GEMM (MFMA, K = pixels) and the column-sum reduction.
 int launch_head_bwd(const float* dy, const float* y_out, int sigmoid, const float* x, const float* w_packed, int B, int HW, int cin, int cp, int cout,
                     int accumulate, float* dx, float* gw, float* gb, float* scratch, hipStream_t s) {
   const size_t npix = (size_t)B * HW;
   const size_t total = npix * (cp / 4);
   hipLaunchKernelGGL(head_bwd_dx_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 16384)), dim3(256), 0, s, dy, w_packed, cout, cp, HW, npix, y_out,
                      sigmoid, accumulate, dx);
-  float* pw = scratch;
-  float* pb = scratch + (size_t)cout * cp * HEAD_SLICES;
-  hipLaunchKernelGGL(head_bwd_dw_partial_kernel, dim3(cout, HEAD_SLICES), dim3(256), 0, s, dy, x, y_out, sigmoid, cout, cp, HW, npix, pw, pb);
-  hipLaunchKernelGGL(head_bwd_dw_final_kernel, dim3((cout * cin + 255) / 256), dim3(256), 0, s, pw, pb, cout, cin, cp, gw, gb);
+  const int cop = pad16(cout);
+  float* rows = scratch;
+  float* rest = scratch + align_up((int64_t)npix * cop, 64);
+  hipLaunchKernelGGL(head_dy_rows_kernel, dim3((unsigned)((npix + 63) / 64)), dim3(256), (size_t)cop * 65 * sizeof(float), s, dy, y_out, sigmoid, cout, cop, HW, npix, rows);
   PH_HIP_CHECK(hipGetLastError());
-  return PH_OK;
+  RowWgradArgs a{};
+  a.dy = rows;
+  a.x = x;
+  a.slab = rest;
+  a.np = cop;
+  a.kp = cp;
+  a.M = (int)npix;
+  int rc = launch_row_wgrad(a, cout, cin, 1, gw, s);  // canonical (cout, cin, 1, 1)
+  if (rc != PH_OK) return rc;
+  if (gb) rc = launch_bias_grad(rows, npix, cop, cout, gb, rest, s);
+  return rc;
 }
 
-int64_t head_bwd_scratch_floats(int cp, int cout) { return (int64_t)cout * cp * HEAD_SLICES + (int64_t)cout * HEAD_SLICES; }
+int64_t head_bwd_scratch_floats(int cp, int cout, int64_t npix) {
+  const int cop = pad16(cout);
+  return align_up(npix * cop, 64) + std::max<int64_t>(row_wgrad_slab_floats((int)npix, cout, cp), bias_scratch_floats(cop));
+}
 
 // ---------------------------------------------------------------------------------------
 // Elementwise backward pieces (NHWC, float4)
@@ -376,7 +364,9 @@ int launch_upsample_bwd(const float* gy, int B, int H, int W, int cp, int accumu
 // Bias gradient: column sums of an NHWC tensor, two stage.
 // ---------------------------------------------------------------------------------------
 constexpr int BIAS_SLICES = 1024;
-__global__ __launch_bounds__(256) void bias_partial_kernel(const float* __restrict__ g, size_t npix, int cp, float* __restrict__ partial /* BIAS_SLICES x cp */) {
+__global__ __launch_bounds__(256) void bias_partial_kernel(float* __restrict__ g, const float* __restrict__ y_mask, size_t npix, int cp,
+                                                           float* __restrict__ partial /* BIAS_SLICES x cp */) {
+  // y_mask != nullptr: the ReLU mask (g = 0 where the forward output y is 0) is applied on the way, in place
   // thread = (pixel row r, channel c): 256/min(cp,256) pixels are summed side by side, then the
   // rows are combined in a fixed order through LDS (deterministic).
   __shared__ float red[256];
@@ -389,7 +379,14 @@ __global__ __launch_bounds__(256) void bias_partial_kernel(const float* __restri
     const int c = cb + c0;
     float acc = 0.f;
     if (r < rows && c < cp)
-      for (size_t p = lo + r; p < hi; p += rows) acc += g[p * cp + c];
+      for (size_t p = lo + r; p < hi; p += rows) {
+        float v = g[p * cp + c];
+        if (y_mask) {
+          v = y_mask[p * cp + c] > 0.f ? v : 0.f;
+          g[p * cp + c] = v;
+        }
+        acc += v;
+      }
     red[threadIdx.x] = acc;
     __syncthreads();
     if (r == 0 && c < cp) {
@@ -411,7 +408,11 @@ __global__ __launch_bounds__(256) void bias_final_kernel(const float* __restrict
   if (c < cout && lane == 0) gb[c] = s;
 }
 int launch_bias_grad(const float* g, size_t npix, int cp, int cout, float* gb, float* scratch, hipStream_t s) {
-  hipLaunchKernelGGL(bias_partial_kernel, dim3(BIAS_SLICES), dim3(256), 0, s, g, npix, cp, scratch);
+  return launch_relu_mask_bias_grad(const_cast<float*>(g), nullptr, npix, cp, cout, gb, scratch, s);
+}
+// ReLU mask (in place, y_mask = forward output) + bias gradient in one pass over the gradient tensor
+int launch_relu_mask_bias_grad(float* g, const float* y_mask, size_t npix, int cp, int cout, float* gb, float* scratch, hipStream_t s) {
+  hipLaunchKernelGGL(bias_partial_kernel, dim3(BIAS_SLICES), dim3(256), 0, s, g, y_mask, npix, cp, scratch);
   hipLaunchKernelGGL(bias_final_kernel, dim3((cout + 3) / 4), dim3(256), 0, s, scratch, cp, cout, gb);
   PH_HIP_CHECK(hipGetLastError());
   return PH_OK;
