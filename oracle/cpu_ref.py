@@ -1092,6 +1092,9 @@ def training_step(sd: Dict[str, torch.Tensor], bb: dict, head_cfgs: dict, model_
     heads = [h for h, _ in HEAD_ORDER[model_type]]
     hl = []
     for h in heads:
+        if h == "ClassVectorsHead":  # lightning_modules.py:2655-2662: CrossEntropyLoss on the (already soft-maxed) head output
+            hl.append(F.cross_entropy(out[h], targets[h]))
+            continue
         l = F.mse_loss(out[h], targets[h])
         if ohkm:
             l = l + ohkm_loss(targets[h], out[h], **ohkm)

@@ -486,4 +486,78 @@ int64_t patch_stem_wgrad_scratch_floats(int cin, int cout, int k, int64_t npix) 
   return align_up(npix * kp, 64) + row_wgrad_slab_floats((int)npix, cout, cin * k * k);
 }
 
+// ---------------------------------------------------------------------------------------
+// Class-vector head loss (lightning_modules.py:2655-2677): nn.CrossEntropyLoss()(p, y) where p is ALREADY the
+// head's softmax output (the reference applies log_softmax on top of it) and y holds class probabilities:
+//   loss = mean_b( -sum_c y[b,c] * log_softmax(p[b,:])[c] ).
+// Gradient wrt the head's pre-softmax logits z:  dp = (softmax(p) - y) * w / B,  dz = p * (dp - sum_c dp[c] p[c]).
+// One thread per row; rows are few (crops of a batch) and classes a handful.
+// ---------------------------------------------------------------------------------------
+__global__ void class_ce_kernel(const float* __restrict__ p, const float* __restrict__ y, int B, int C, float weight, float* __restrict__ dz, float* __restrict__ loss_out) {
+  __shared__ float red[256];
+  float lsum = 0.f;
+  for (int b = threadIdx.x; b < B; b += blockDim.x) {
+    const float* pr = p + (size_t)b * C;
+    const float* yr = y + (size_t)b * C;
+    float m = -INFINITY;
+    for (int c = 0; c < C; ++c) m = fmaxf(m, pr[c]);
+    float se = 0.f;
+    for (int c = 0; c < C; ++c) se += expf(pr[c] - m);
+    const float lse = m + logf(se);
+    float dot = 0.f, l = 0.f;
+    for (int c = 0; c < C; ++c) {
+      const float q = expf(pr[c] - lse);
+      l -= yr[c] * (pr[c] - lse);
+      const float dp = (q - yr[c]) * weight / (float)B;
+      dot += dp * pr[c];
+    }
+    for (int c = 0; c < C; ++c) {
+      const float q = expf(pr[c] - lse);
+      const float dp = (q - yr[c]) * weight / (float)B;
+      dz[(size_t)b * C + c] = pr[c] * (dp - dot);
+    }
+    lsum += l;
+  }
+  red[threadIdx.x] = lsum;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int i = 0; i < (int)blockDim.x; ++i) t += red[i];
+    loss_out[0] = t / (float)B;
+  }
+}
+int launch_class_ce(const float* p, const float* y, int B, int C, float weight, float* dz, float* loss_out, hipStream_t s) {
+  hipLaunchKernelGGL(class_ce_kernel, dim3(1), dim3(256), 0, s, p, y, B, C, weight, dz, loss_out);
+  PH_HIP_CHECK(hipGetLastError());
+  return PH_OK;
+}
+
+// Global max pool backward: the gradient of channel c goes to the FIRST position holding the maximum (ATen's argmax).
+__global__ __launch_bounds__(256) void global_maxpool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gy, int HW, int cp, int accumulate, float* __restrict__ gx) {
+  const int b = blockIdx.x;
+  for (int c = threadIdx.x; c < cp; c += 256) {
+    const float* xp = x + (size_t)b * HW * cp + c;
+    float m = -INFINITY;
+    int arg = 0;
+    for (int p = 0; p < HW; ++p) {
+      const float v = xp[(size_t)p * cp];
+      if (v > m) {
+        m = v;
+        arg = p;
+      }
+    }
+    const float g = gy[(size_t)b * cp + c];
+    float* gp = gx + (size_t)b * HW * cp + c;
+    for (int p = 0; p < HW; ++p) {
+      const float add = p == arg ? g : 0.f;
+      gp[(size_t)p * cp] = accumulate ? gp[(size_t)p * cp] + add : add;
+    }
+  }
+}
+int launch_global_maxpool_bwd(const float* x, const float* gy, int B, int HW, int cp, int accumulate, float* gx, hipStream_t s) {
+  hipLaunchKernelGGL(global_maxpool_bwd_kernel, dim3(B), dim3(256), 0, s, x, gy, HW, cp, accumulate, gx);
+  PH_HIP_CHECK(hipGetLastError());
+  return PH_OK;
+}
+
 }  // namespace ph

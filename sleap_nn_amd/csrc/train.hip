@@ -31,10 +31,6 @@ int build_bwd_plan(const ph_model* m, int B, int H, int W, BwdPlan& bp) {
       set_error("backward needs the unfused program with bilinear up-sampling (no stem / conv+pool fusion / transposed conv)");
       return PH_E_INVALID;
     }
-    if (d.kind == PH_OP_GLOBAL_MAXPOOL || (d.kind == PH_OP_HEAD && (d.flags & PH_FLAG_SOFTMAX))) {
-      set_error("backward of the class-vector head (global pool / softmax + cross entropy) is not implemented");
-      return PH_E_INVALID;
-    }
     if (d.kind == PH_OP_LINEAR && (d.flags & (PH_FLAG_GELU | PH_FLAG_SCALE_RESIDUAL))) {
       set_error("backward needs the unfused ConvNeXt program (GELU / layer-scale as ops of their own)");
       return PH_E_INVALID;
@@ -146,7 +142,10 @@ int ph_model_backward(ph_model* m, const void* input_dev, int32_t in_dtype, int3
     const SlotShape& s0 = bp.act.slots[d.src0];
     PH_REQUIRE(head_out_dev[d.out_index] && target_dev[d.out_index], "head %d: null output/target", d.out_index);
     float* dy = reinterpret_cast<float*>(gws + bp.head_dy_off[d.out_index]);
-    rc = launch_loss(head_out_dev[d.out_index], target_dev[d.out_index], batch, d.cout, s0.h, s0.w, lw[d.out_index], ok, scratch, dy, loss_dev + 1 + d.out_index, s);
+    if (d.flags & PH_FLAG_SOFTMAX)  // class-vector head: cross entropy on the softmax output, gradient wrt the logits
+      rc = launch_class_ce(head_out_dev[d.out_index], target_dev[d.out_index], batch, d.cout, lw[d.out_index], dy, loss_dev + 1 + d.out_index, s);
+    else
+      rc = launch_loss(head_out_dev[d.out_index], target_dev[d.out_index], batch, d.cout, s0.h, s0.w, lw[d.out_index], ok, scratch, dy, loss_dev + 1 + d.out_index, s);
     if (rc != PH_OK) return rc;
   }
   {  // total = sum_h w_h * loss_h; the weights ride in the scratch area
@@ -307,7 +306,10 @@ int ph_model_backward(ph_model* m, const void* input_dev, int32_t in_dtype, int3
         PH_REQUIRE(!patch || (si.h % 2 == 0 && si.w % 2 == 0), "2x2/stride-2 conv backward needs even input sizes");
         const int M = batch * so.h * so.w;
         const int taps = patch ? 4 : 1;
-        rc = launch_bias_grad(G(d.dst), (size_t)M, so.cp, d.cout, grads_flat_dev + m->weight_offset[d.bias], scratch, s);
+        if (d.flags & PH_FLAG_RELU)
+          rc = launch_relu_mask_bias_grad(G(d.dst), A(d.dst), (size_t)M, so.cp, d.cout, grads_flat_dev + m->weight_offset[d.bias], scratch, s);
+        else
+          rc = launch_bias_grad(G(d.dst), (size_t)M, so.cp, d.cout, grads_flat_dev + m->weight_offset[d.bias], scratch, s);
         for (int tap = 0; tap < taps && rc == PH_OK; ++tap) {
           RowWgradArgs w{};
           w.dy = G(d.dst);
@@ -374,6 +376,13 @@ int ph_model_backward(ph_model* m, const void* input_dev, int32_t in_dtype, int3
         a.W = so.w;
         a.accumulate = init[d.src0];
         rc = launch_dwconv7(a, s);
+        init[d.src0] = 1;
+        break;
+      }
+      case PH_OP_GLOBAL_MAXPOOL: {
+        const SlotShape& si = bp.act.slots[d.src0];
+        PH_REQUIRE(init[d.dst], "global pool output slot %d received no gradient", d.dst);
+        rc = launch_global_maxpool_bwd(A(d.src0), G(d.dst), batch, si.h * si.w, si.cp, init[d.src0], G(d.src0), s);
         init[d.src0] = 1;
         break;
       }

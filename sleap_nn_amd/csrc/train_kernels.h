@@ -63,5 +63,7 @@ int64_t row_wgrad_slab_floats(int M, int n, int k);
 int launch_patch_stem_wgrad(const void* img, int dtype, const float* dy, int B, int cin, int H, int W, int OH, int OW, int k, int stride, int coutp, int cout, float* gw,
                             float* scratch, hipStream_t s);
 int64_t patch_stem_wgrad_scratch_floats(int cin, int cout, int k, int64_t npix);
+int launch_class_ce(const float* p, const float* y, int B, int C, float weight, float* dz, float* loss_out, hipStream_t s);
+int launch_global_maxpool_bwd(const float* x, const float* gy, int B, int HW, int cp, int accumulate, float* gx, hipStream_t s);
 
 }  // namespace ph

@@ -165,3 +165,37 @@ def test_target_rendering_matches_reference_and_oracle():
     # centroid form (B, I, 2) -> one channel
     cen = generate_multiconfmaps(big[:, :, 0].cuda(), hw, sigma=2.0, output_stride=2).cpu()
     torch.testing.assert_close(cen, O.make_multiconfmaps(big[:, :, :1], hw, 2.0, 2), rtol=0, atol=2e-6)
+
+
+def test_multiclass_topdown_training_matches_autograd():
+    """multi_class_topdown: MSE on the confidence maps + the reference's CrossEntropyLoss on the class-vector
+    head's softmax output (lightning_modules.py:2655-2677), backward through softmax, the FC stack (row GEMMs),
+    the global max pool and the encoder; vs autograd over the oracle."""
+    from sleap_nn_amd.architectures.model import Model
+    from sleap_nn_amd.training.module import TrainingModule
+
+    bb = {"in_channels": 1, "kernel_size": 3, "filters": 8, "filters_rate": 1.5, "max_stride": 16, "stem_stride": None, "middle_block": True,
+          "up_interpolate": True, "stacks": 1, "convs_per_block": 2, "output_stride": 2}
+    heads = {"confmaps": {"part_names": ["A", "B"], "anchor_part": "A", "sigma": 1.5, "output_stride": 2, "loss_weight": 1.0},
+             "class_vectors": {"classes": ["f", "m", "x"], "num_fc_layers": 2, "num_fc_units": 32, "global_pool": True, "output_stride": 16, "loss_weight": 0.3}}
+    mt = "multi_class_topdown"
+    g = torch.Generator().manual_seed(19)
+    m = Model("unet", bb, heads, mt)
+    sd = {}
+    for k, shape in m.param_shapes.items():
+        fan = int(np.prod(shape[1:])) if len(shape) > 1 else 1
+        sd[k] = (torch.rand(shape, generator=g) * 2 - 1) * (1.5 / np.sqrt(fan) if len(shape) > 1 else 0.1)
+    m.load_state_dict(sd)
+    B = 5
+    img = torch.randint(0, 256, (B, 1, 64, 48), dtype=torch.uint8, generator=g)
+    ref_out = O.model_forward(sd, bb, heads, mt, img)
+    targets = {"CenteredInstanceConfmapsHead": torch.rand(ref_out["CenteredInstanceConfmapsHead"].shape, generator=g) * 0.5,
+               "ClassVectorsHead": torch.nn.functional.one_hot(torch.randint(0, 3, (B,), generator=g), 3).float()}
+    lw = [1.0, 0.3]
+    tm = TrainingModule(m, DEV, loss_weights=lw)
+    losses, ref_grads = O.training_step(sd, bb, heads, mt, img, targets, lw)
+    loss = tm.forward_backward(img.to(DEV), {k: v.to(DEV) for k, v in targets.items()})
+    torch.cuda.synchronize()
+    got = loss.cpu().numpy()
+    np.testing.assert_allclose(got, np.array(losses), rtol=2e-5, atol=1e-6)
+    _check_grads(tm, ref_grads, rtol=2e-4)
