@@ -648,8 +648,14 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
         a.wpack_dma = op.w_dma_dev;
         a.zeros = m->zeros_dev;
         const double fill = (double)s0.h * s0.w / ((double)((s0.h + 15) / 16 * 16) * ((s0.w + 31) / 32 * 32));
-        if (m->use_dma && d.dst2 < 0 && op.w_gemm_dev && fill < m->gemm_fill_threshold) {
-          // small feature map: the 16x32-pixel tiles of the halo kernel would be mostly padding -> 9-tap row GEMM
+        // the halo kernel pads Cout to a multiple of its N tile (64): e.g. Cout = 96 does 33 % extra MFMA work there,
+        // none in the row GEMM (N tiles of 96 / 128)
+        const double n_fill = (double)a.coutp / ((a.coutp + op.bn - 1) / op.bn * op.bn);
+        const int bn_g = op.bn_g > 0 ? op.bn_g : 128;
+        const double n_fill_g = (double)a.coutp / ((a.coutp + bn_g - 1) / bn_g * bn_g);
+        if (m->use_dma && d.dst2 < 0 && op.w_gemm_dev && (fill < m->gemm_fill_threshold || n_fill * fill < 0.8 * n_fill_g)) {
+          // small feature map (the 16x32-pixel tiles of the halo kernel would be mostly padding) or a Cout that
+          // fits the halo kernel's N tile badly -> 9-tap row GEMM
           GemmArgs g{};
           g.src0 = a.src0;
           g.src1 = a.src1;

@@ -71,7 +71,7 @@ struct ph_model {
   std::vector<ph::PackedBuffer> packed;        // every packed weight buffer, for ph_model_set_params
   bool use_dma = true;                        // PH_CONV_IMPL=reg selects the register-staged kernel
   int wgrad_rows = 0;                         // 3x3 weight gradients of wide layers as nine row-wgrad GEMMs (off by default: measured slower than the 32x32-tile kernel; PH_WGRAD_IMPL=auto|rows)
-  double gemm_fill_threshold = 0.7;           // 3x3 convs whose maps fill the 16x32 tiles less than this run as row GEMMs
+  double gemm_fill_threshold = 0.8;           // 3x3 convs whose maps fill the 16x32 tiles less than this run as row GEMMs
 };
 
 
