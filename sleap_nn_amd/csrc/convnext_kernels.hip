@@ -97,27 +97,35 @@ int launch_patch_stem(const PatchStemArgs& a, hipStream_t s) {
 // read from a clamped address and zeroed with a select (no divergent branches around loads).
 // Weights: [tap][Cp].
 // ---------------------------------------------------------------------------------------
-constexpr int DW_STRIP = 8;
+constexpr int DW_STRIP = 8, DW_ROWS = 2;
 
+// One thread = 4 channels x a block of DW_ROWS x DW_STRIP output pixels.  It walks the DW_ROWS + 6 input rows
+// once, keeps the 14 input float4s of the current row in registers and applies them to every output row they
+// contribute to (1,568 float4 FMAs per 140 input + 196 weight loads; the one-row version needed 4 x 147 loads).
 __global__ __launch_bounds__(256) void dwconv7_kernel(DwConvArgs a) {
   const int groups = a.cp >> 2;
   const int strips = (a.W + DW_STRIP - 1) / DW_STRIP;
-  const size_t total = (size_t)a.B * a.H * strips * groups;
+  const int rblocks = (a.H + DW_ROWS - 1) / DW_ROWS;
+  const size_t total = (size_t)a.B * rblocks * strips * groups;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
     const int gq = (int)(idx % groups);
     size_t p = idx / groups;
     const int st = (int)(p % strips);
     p /= strips;
-    const int y = (int)(p % a.H);
-    const int b = (int)(p / a.H);
-    const int x0 = st * DW_STRIP;
+    const int rb = (int)(p % rblocks);
+    const int b = (int)(p / rblocks);
+    const int x0 = st * DW_STRIP, y0 = rb * DW_ROWS;
     const f32x4 bias = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + gq * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
-    f32x4 acc[DW_STRIP];
+    f32x4 acc[DW_ROWS][DW_STRIP];
 #pragma unroll
-    for (int o = 0; o < DW_STRIP; ++o) acc[o] = bias;
-    for (int ky = 0; ky < 7; ++ky) {
-      const int iy = y + ky - 3;
-      if (iy < 0 || iy >= a.H) continue;  // uniform across the lanes of a pixel row
+    for (int r = 0; r < DW_ROWS; ++r)
+#pragma unroll
+      for (int o = 0; o < DW_STRIP; ++o) acc[r][o] = bias;
+    const float* wq = a.w + gq * 4;
+#pragma unroll
+    for (int ir = 0; ir < DW_ROWS + 6; ++ir) {
+      const int iy = y0 + ir - 3;
+      if (iy < 0 || iy >= a.H) continue;
       const float* row = a.src + ((size_t)(b * a.H + iy) * a.W) * a.cp + gq * 4;
       f32x4 in[DW_STRIP + 6];
 #pragma unroll
@@ -132,24 +140,33 @@ __global__ __launch_bounds__(256) void dwconv7_kernel(DwConvArgs a) {
         in[i][3] = ok ? v[3] : 0.f;
       }
 #pragma unroll
-      for (int kx = 0; kx < 7; ++kx) {
-        const f32x4 w = *reinterpret_cast<const f32x4*>(a.w + (size_t)(ky * 7 + kx) * a.cp + gq * 4);
+      for (int r = 0; r < DW_ROWS; ++r) {
+        const int ky = ir - r;  // this input row is kernel row ky of output row r
+        if (ky < 0 || ky > 6) continue;
 #pragma unroll
-        for (int o = 0; o < DW_STRIP; ++o) acc[o] += in[o + kx] * w;
+        for (int kx = 0; kx < 7; ++kx) {
+          const f32x4 w = *reinterpret_cast<const f32x4*>(wq + (size_t)(ky * 7 + kx) * a.cp);
+#pragma unroll
+          for (int o = 0; o < DW_STRIP; ++o) acc[r][o] += in[o + kx] * w;
+        }
       }
     }
-    float* drow = a.dst + ((size_t)(b * a.H + y) * a.W) * a.cp + gq * 4;
 #pragma unroll
-    for (int o = 0; o < DW_STRIP; ++o)
-      if (x0 + o < a.W) {
-        f32x4* dp = reinterpret_cast<f32x4*>(drow + (size_t)(x0 + o) * a.cp);
-        *dp = a.accumulate ? *dp + acc[o] : acc[o];
-      }
+    for (int r = 0; r < DW_ROWS; ++r) {
+      if (y0 + r >= a.H) continue;
+      float* drow = a.dst + ((size_t)(b * a.H + y0 + r) * a.W) * a.cp + gq * 4;
+#pragma unroll
+      for (int o = 0; o < DW_STRIP; ++o)
+        if (x0 + o < a.W) {
+          f32x4* dp = reinterpret_cast<f32x4*>(drow + (size_t)(x0 + o) * a.cp);
+          *dp = a.accumulate ? *dp + acc[r][o] : acc[r][o];
+        }
+    }
   }
 }
 
 int launch_dwconv7(const DwConvArgs& a, hipStream_t s) {
-  const size_t total = (size_t)a.B * a.H * ((a.W + DW_STRIP - 1) / DW_STRIP) * (a.cp / 4);
+  const size_t total = (size_t)a.B * ((a.H + DW_ROWS - 1) / DW_ROWS) * ((a.W + DW_STRIP - 1) / DW_STRIP) * (a.cp / 4);
   const int blocks = (int)std::min<size_t>((total + 255) / 256, 256 * 64);
   hipLaunchKernelGGL(dwconv7_kernel, dim3(blocks), dim3(256), 0, s, a);
   PH_HIP_CHECK(hipGetLastError());
