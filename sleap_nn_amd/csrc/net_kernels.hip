@@ -856,35 +856,49 @@ int launch_pool(const float* src, float* dst, int B, int H, int W, int cp, hipSt
 // src = max(0, (dst + 0.5) * 0.5 - 0.5), i1 = min(i0 + 1, in - 1), lambda = src - i0).
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void upsample2x_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, int H, int W, int cp) {
+  // One thread = 4 channels x the 2x2 output pixels (2i+1..2i+2, 2j+1..2j+2) that lie between input pixels
+  // (i..i+1, j..j+1): four 16-B loads feed four 16-B stores (one load set per output pixel cost 4x the loads).
+  // i, j run from -1 so that output row / column 0 is produced too; every output evaluates the reference's own
+  // source-coordinate formula (half-pixel centres, clamped at 0), so the border weights are exactly its weights.
   const int Ho = 2 * H, Wo = 2 * W, groups = cp >> 2;
-  const size_t total = (size_t)B * Ho * Wo * groups;
+  const int nI = H + 1, nJ = W + 1;
+  const size_t total = (size_t)B * nI * nJ * groups;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
     const int gq = (int)(idx % groups);
     size_t p = idx / groups;
-    const int x = (int)(p % Wo);
-    p /= Wo;
-    const int y = (int)(p % Ho);
-    const int b = (int)(p / Ho);
-    const float sy = fmaxf((y + 0.5f) * 0.5f - 0.5f, 0.f);
-    const float sx = fmaxf((x + 0.5f) * 0.5f - 0.5f, 0.f);
-    const int iy0 = (int)sy, ix0 = (int)sx;
-    const int iy1 = min(iy0 + 1, H - 1), ix1 = min(ix0 + 1, W - 1);
-    const float ly = sy - iy0, lx = sx - ix0;
-    const float hy = 1.f - ly, hx = 1.f - lx;
+    const int j = (int)(p % nJ) - 1;
+    p /= nJ;
+    const int i = (int)(p % nI) - 1;
+    const int b = (int)(p / nI);
+    const int r0 = max(i, 0), r1 = min(i + 1, H - 1), c0 = max(j, 0), c1 = min(j + 1, W - 1);
     const float* base = src + ((size_t)b * H * W) * cp + gq * 4;
-    const f32x4 v00 = *reinterpret_cast<const f32x4*>(base + ((size_t)iy0 * W + ix0) * cp);
-    const f32x4 v01 = *reinterpret_cast<const f32x4*>(base + ((size_t)iy0 * W + ix1) * cp);
-    const f32x4 v10 = *reinterpret_cast<const f32x4*>(base + ((size_t)iy1 * W + ix0) * cp);
-    const f32x4 v11 = *reinterpret_cast<const f32x4*>(base + ((size_t)iy1 * W + ix1) * cp);
-    f32x4 o;
+    const f32x4 v00 = *reinterpret_cast<const f32x4*>(base + ((size_t)r0 * W + c0) * cp);
+    const f32x4 v01 = *reinterpret_cast<const f32x4*>(base + ((size_t)r0 * W + c1) * cp);
+    const f32x4 v10 = *reinterpret_cast<const f32x4*>(base + ((size_t)r1 * W + c0) * cp);
+    const f32x4 v11 = *reinterpret_cast<const f32x4*>(base + ((size_t)r1 * W + c1) * cp);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) o[k] = hy * (hx * v00[k] + lx * v01[k]) + ly * (hx * v10[k] + lx * v11[k]);
-    *reinterpret_cast<f32x4*>(dst + (((size_t)b * Ho + y) * Wo + x) * cp + gq * 4) = o;
+    for (int dy = 1; dy <= 2; ++dy) {
+      const int y = 2 * i + dy;
+      if (y < 0 || y >= Ho) continue;
+      const float sy = fmaxf((y + 0.5f) * 0.5f - 0.5f, 0.f);
+      const float ly = sy - (float)(int)sy, hy = 1.f - ly;
+#pragma unroll
+      for (int dx = 1; dx <= 2; ++dx) {
+        const int x = 2 * j + dx;
+        if (x < 0 || x >= Wo) continue;
+        const float sx = fmaxf((x + 0.5f) * 0.5f - 0.5f, 0.f);
+        const float lx = sx - (float)(int)sx, hx = 1.f - lx;
+        f32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = hy * (hx * v00[k] + lx * v01[k]) + ly * (hx * v10[k] + lx * v11[k]);
+        *reinterpret_cast<f32x4*>(dst + (((size_t)b * Ho + y) * Wo + x) * cp + gq * 4) = o;
+      }
+    }
   }
 }
 
 int launch_upsample(const float* src, float* dst, int B, int H, int W, int cp, hipStream_t s) {
-  const size_t total = (size_t)B * 4 * H * W * (cp / 4);
+  const size_t total = (size_t)B * (H + 1) * (W + 1) * (cp / 4);
   const int blocks = (int)std::min<size_t>((total + 255) / 256, 256 * 32);
   hipLaunchKernelGGL(upsample2x_kernel, dim3(blocks), dim3(256), 0, s, src, dst, B, H, W, cp);
   PH_HIP_CHECK(hipGetLastError());
