@@ -504,6 +504,72 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
   }
 }
 
+// 16-channel layers (the full-resolution first encoder block): the same computation on v_mfma_f32_16x16x4_f32,
+// a 16(ci) x 16(co) tile with four pixels per MFMA -- a 32x32 tile would be three quarters padding there.
+__global__ __launch_bounds__(256, 2) void wgrad16_kernel(WgradArgs a) {
+  __shared__ float sX[WG_HH * WG_HW * 16];
+  __shared__ float sY[WG_TH * WG_TW * 16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int slice = blockIdx.y, n_slices = gridDim.y;
+  const int tiles_x = (a.W + WG_TW - 1) / WG_TW, tiles_y = (a.H + WG_TH - 1) / WG_TH;
+  const int n_tiles = tiles_x * tiles_y * a.B;
+  f32x4 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int tile = slice; tile < n_tiles; tile += n_slices) {
+    int t = tile;
+    const int tx = t % tiles_x;
+    t /= tiles_x;
+    const int ty = t % tiles_y;
+    const int b = t / tiles_y;
+    const int x0 = tx * WG_TW, y0 = ty * WG_TH;
+    for (int i = tid; i < WG_HH * WG_HW * 4; i += 256) {
+      const int pix = i >> 2, q = i & 3;
+      const int hy = pix / WG_HW, hx = pix - hy * WG_HW;
+      const int gy = y0 + hy - 1, gx = x0 + hx - 1;
+      const bool ok = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+      const int cy = min(max(gy, 0), a.H - 1), cx = min(max(gx, 0), a.W - 1);
+      const f32x4 v = *reinterpret_cast<const f32x4*>(a.x + ((size_t)(b * a.H + cy) * a.W + cx) * 16 + q * 4);
+      *reinterpret_cast<f32x4*>(sX + pix * 16 + q * 4) = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (int i = tid; i < WG_TH * WG_TW * 4; i += 256) {
+      const int pix = i >> 2, q = i & 3;
+      const int py = pix / WG_TW, px = pix - py * WG_TW;
+      const int gy = y0 + py, gx = x0 + px;
+      const bool ok = gy < a.H && gx < a.W;
+      const int cy = min(gy, a.H - 1), cx = min(gx, a.W - 1);
+      const f32x4 v = *reinterpret_cast<const f32x4*>(a.dy + ((size_t)(b * a.H + cy) * a.W + cx) * 16 + q * 4);
+      *reinterpret_cast<f32x4*>(sY + pix * 16 + q * 4) = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    __syncthreads();
+#pragma unroll 2
+    for (int s2 = 0; s2 < 16; ++s2) {  // this wave's 64 pixels (rows 2w, 2w+1), four per MFMA
+      const int py = 2 * wave + (s2 >> 3), px = 4 * (s2 & 7) + lg;
+      const float bv = sY[(py * WG_TW + px) * 16 + li];
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int ky = tap / 3, kx = tap - ky * 3;
+        const float av = sX[((py + ky) * WG_HW + px + kx) * 16 + li];
+        acc[tap] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[tap], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  // D: row(ci) = 4*lg + r, col(co) = li; the slab slot keeps the 32x32 layout of wgrad_reduce_kernel
+  float* slab = a.slab + (((size_t)slice * gridDim.x + blockIdx.x) * 9) * 1024;
+  for (int tap = 0; tap < 9; ++tap) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sX[wave * 256 + (4 * lg + r) * 16 + li] = acc[tap][r];
+    __syncthreads();
+    {
+      const int ci = tid >> 4, co = tid & 15;
+      slab[(size_t)tap * 1024 + ci * 32 + co] = (sX[tid] + sX[256 + tid]) + (sX[512 + tid] + sX[768 + tid]);
+    }
+    __syncthreads();
+  }
+}
+
 // grad[(co*cin_total + ci_off + ci)*9 + tap] = sum_slices slab[...]
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, int n_slices, int n_blocks, int n_co_t, int cin, int cout, int cin_total,
                                                            int ci_off, float* __restrict__ grad) {
@@ -533,7 +599,10 @@ int launch_wgrad(const WgradArgs& a0, int cin_part, int cout, int cin_total, int
   WgradArgs a = a0;
   const int n_ci_t = (a.cxp + 31) / 32, n_co_t = (a.coutp + 31) / 32;
   const int n_slices = wgrad_slices(a.B, a.H, a.W, n_ci_t * n_co_t);
-  hipLaunchKernelGGL(wgrad_kernel, dim3(n_ci_t * n_co_t, n_slices), dim3(256), 0, s, a);
+  if (a.cxp == 16 && a.coutp == 16)
+    hipLaunchKernelGGL(wgrad16_kernel, dim3(1, n_slices), dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL(wgrad_kernel, dim3(n_ci_t * n_co_t, n_slices), dim3(256), 0, s, a);
   const int n = cin_part * cout * 9;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, s, a.slab, n_slices, n_ci_t * n_co_t, n_co_t, cin_part, cout, cin_total, ci_off, grad);
   PH_HIP_CHECK(hipGetLastError());
