@@ -33,7 +33,11 @@ class ModelBackend(Protocol):
 class HipBackend:
     """Hand-written-HIP forward behind the ``ModelBackend`` protocol."""
 
-    def __init__(self, model, device: str = "cuda") -> None:
+    def __init__(self, model, device: str = "cuda", use_graph: bool = False) -> None:
+        """``use_graph``: replay the forward of each (shape, dtype) as ONE hipGraph launch (captured on
+        first use through ``torch.cuda.CUDAGraph``): ~25 kernel launches become one, which is what bounds
+        small batches (a 256x256 frame is ~0.3 ms of kernels).  The returned tensors are the graph's static
+        outputs -- valid until the next call with the same shape."""
         L.lib()  # fail loudly right here if the native library is missing
         if not torch.cuda.is_available():
             raise RuntimeError("HipBackend needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
@@ -44,6 +48,8 @@ class HipBackend:
             dev = torch.device("cuda", torch.cuda.current_device())
         self._device = dev
         self.model = model.to(dev).eval()
+        self.use_graph = bool(use_graph)
+        self._graphs: Dict[tuple, tuple] = {}
 
     @property
     def device(self) -> str:
@@ -63,12 +69,33 @@ class HipBackend:
         if x.dtype != torch.uint8:
             x = x.to(torch.float32)
             code = 2 if bool(x.max() > 1.0) else 1  # normalize_on_gpu's data-dependent branch
-        out = self.model.forward(x, in_dtype=code)
+        out = self._forward_graph(x, code) if self.use_graph else self.model.forward(x, in_dtype=code)
         if isinstance(out, torch.Tensor):
             out = {"output": out}
         if not isinstance(out, dict):
             raise TypeError(f"unexpected model output type {type(out).__name__}")
         return out
+
+    def _forward_graph(self, x: torch.Tensor, code) -> Dict[str, torch.Tensor]:
+        key = (tuple(x.shape), x.dtype, code)
+        entry = self._graphs.get(key)
+        if entry is None:
+            static_in = x.clone()
+            stream = torch.cuda.Stream(self._device)
+            stream.wait_stream(torch.cuda.current_stream(self._device))
+            with torch.cuda.stream(stream):  # warm-up outside the capture: handle creation, workspace allocation
+                self.model.forward(static_in, in_dtype=code)
+            torch.cuda.current_stream(self._device).wait_stream(stream)
+            torch.cuda.synchronize(self._device)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                static_out = self.model.forward(static_in, in_dtype=code)
+            entry = (graph, static_in, static_out)
+            self._graphs[key] = entry
+        graph, static_in, static_out = entry
+        static_in.copy_(x, non_blocking=True)
+        graph.replay()
+        return static_out
 
     def warmup(self, input_shape: Tuple[int, ...]) -> None:
         x = torch.zeros(tuple(input_shape), dtype=torch.uint8, device=self._device)
