@@ -582,12 +582,264 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mfma_dma_kernel(ConvArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// K1p: the same kernel as a PERSISTENT workgroup (one per CU) that walks its share of the
+// (pixel tile, N tile) list.  During the last K chunk of a tile the idle LDS buffer receives the
+// first chunk of the NEXT tile, so a new tile starts with its data already in LDS (the one-tile
+// kernel pays an exposed ~2 us DMA round trip per tile: 5-10 % on layers with few input channels)
+// and the epilogue's stores overlap that fetch.
+// ---------------------------------------------------------------------------------------
+template <int BN>
+__global__ __launch_bounds__(512, 2) void conv3x3_mfma_dma_persist_kernel(ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int NT = BN / 32;
+  constexpr int B_PIECES = 9 * BN / 16;
+  constexpr int PIECES = D_A_PIECES + B_PIECES;
+  constexpr int A_SLOTS = (D_A_PIECES + 7) / 8;
+  constexpr int B_SLOTS = (B_PIECES + 7) / 8;
+  constexpr int SLOTS = A_SLOTS + B_SLOTS;
+  constexpr int BUF_FLOATS = PIECES * 256;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tiles_x = (a.W + TW - 1) / TW;
+  const int tiles_y = (a.H + D_TH - 1) / D_TH;
+  const int tiles = tiles_x * tiles_y * a.B;
+  const int ntc = (a.coutp + BN - 1) / BN;
+  const int total = tiles * ntc;
+  const int chunks0 = a.c0p / KC;
+  const int chunks1 = a.c1p / KC;
+  const int nchunks = chunks0 + chunks1;
+  const int dq = lane >> 4, dr = lane & 15;
+  const int lx = lane & 31, lh = lane >> 5;
+
+  struct Plan {
+    int a_pix[A_SLOTS];
+    unsigned a_ok;
+    int b, x0, y0, ntile;
+  };
+  auto setup = [&](int vid, Plan& P) {
+    int t, ntile;  // same XCD-aware dealing as decode_block, over virtual workgroup ids
+    if ((tiles & 7) == 0) {
+      const int xcd = vid & 7, j = vid >> 3;
+      ntile = j % ntc;
+      t = (j / ntc) * 8 + xcd;
+    } else {
+      ntile = vid % ntc;
+      t = vid / ntc;
+    }
+    const int tx = t % tiles_x;
+    t /= tiles_x;
+    const int ty = t % tiles_y;
+    P.b = t / tiles_y;
+    P.x0 = tx * TW;
+    P.y0 = ty * D_TH;
+    P.ntile = ntile;
+    P.a_ok = 0;
+#pragma unroll
+    for (int s = 0; s < A_SLOTS; ++s) {
+      const int p = min(wave + 8 * s, D_A_PIECES - 1);
+      const int pix = p * 16 + dr;
+      const int hy = pix / HALO_W, hx = pix - hy * HALO_W;
+      const int gy = P.y0 + hy - 1, gx = P.x0 + hx - 1;
+      const bool in = (pix < D_NPIX) && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+      P.a_ok |= (in ? 1u : 0u) << s;
+      const int cy = min(max(gy, 0), a.H - 1), cx = min(max(gx, 0), a.W - 1);
+      P.a_pix[s] = (P.b * a.H + cy) * a.W + cx;
+    }
+  };
+
+  // fetch state: which tile plan / chunk the DMA slots of the running chunk loop pull
+  int f_pix[A_SLOTS];
+  unsigned f_ok = 0;
+  const float* p_src = a.src0;
+  const float* p_w = a.wpack_dma;
+  int p_cp = a.c0p, p_coff = 0;
+  auto select_fetch = [&](const Plan& P, int ch) {
+#pragma unroll
+    for (int s = 0; s < A_SLOTS; ++s) f_pix[s] = P.a_pix[s];
+    f_ok = P.a_ok;
+    if (ch < chunks0) {
+      p_src = a.src0;
+      p_cp = a.c0p;
+      p_coff = ch * KC;
+    } else {
+      p_src = a.src1;
+      p_cp = a.c1p;
+      p_coff = (ch - chunks0) * KC;
+    }
+    p_w = a.wpack_dma + ((size_t)P.ntile * nchunks + ch) * (9 * BN * KC);
+  };
+  auto dma_slot = [&](int s, float* buf) {
+    const float* g;
+    int p;
+    if (s < A_SLOTS) {  // compile-time after unrolling
+      p = min(wave + 8 * s, D_A_PIECES - 1);
+      const float* real = p_src + (size_t)f_pix[s] * p_cp + p_coff + dq * 4;
+      const float* zero = a.zeros + dq * 4;
+      g = ((f_ok >> s) & 1u) ? real : zero;
+    } else {
+      const int pb = min(wave + 8 * (s - A_SLOTS), B_PIECES - 1);
+      p = D_A_PIECES + pb;
+      g = p_w + pb * 256 + lane * 4;
+    }
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)(buf + p * 256), 16, 0, 0);
+  };
+
+  int offA[4][3];
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int pix = (2 * wave + rr) * HALO_W + lx + kx;
+      offA[rr][kx] = (pix >> 4) * 256 + lh * 64 + (pix & 15) * 4;
+    }
+  const int offB = D_A_PIECES * 256 + (lx >> 4) * 256 + lh * 64 + (lx & 15) * 4;
+  float* buf0 = lds;
+  float* buf1 = lds + BUF_FLOATS;
+
+  auto run = [&](auto late) {
+    constexpr bool LATE = decltype(late)::value;
+    Plan P, Pn;
+    int vid = blockIdx.x;
+    setup(vid, P);
+    select_fetch(P, 0);
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) dma_slot(s, buf0);
+    __syncthreads();
+    int parity = 0;
+    while (true) {
+      const int nvid = vid + gridDim.x;
+      const bool has_next = nvid < total;  // workgroup-uniform
+      if (has_next) setup(nvid, Pn);
+      f32x16 acc[2][NT];
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+      for (int ch = 0; ch < nchunks; ++ch) {
+        float* cur = ((parity + ch) & 1) ? buf1 : buf0;
+        float* nxt = ((parity + ch) & 1) ? buf0 : buf1;
+        if (ch + 1 < nchunks)
+          select_fetch(P, ch + 1);
+        else if (has_next)
+          select_fetch(Pn, 0);  // the next tile's first chunk rides under this tile's last one
+        else
+          select_fetch(P, ch);  // nothing left: refetch (harmless, keeps the loop branch-free inside)
+        f32x4 af[2][2], bf[2][NT];
+        auto load_frags = [&](int step, int fb) {
+          const int tap = step >> 1, g = step & 1;
+          const int ky = tap / 3, kx = tap - ky * 3;
+#pragma unroll
+          for (int m = 0; m < 2; ++m) af[fb][m] = *reinterpret_cast<const f32x4*>(cur + offA[m + ky][kx] + g * 128);
+#pragma unroll
+          for (int n = 0; n < NT; ++n) bf[fb][n] = *reinterpret_cast<const f32x4*>(cur + offB + tap * (BN / 16) * 256 + n * 512 + g * 128);
+        };
+        load_frags(0, 0);
+#pragma unroll
+        for (int step = 0; step < 18; ++step) {
+          const int fcur = step & 1;
+          if (step + 1 < 18) load_frags(step + 1, fcur ^ 1);
+          if (step < SLOTS) dma_slot(step, nxt);
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+              for (int n = 0; n < NT; ++n)
+                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[fcur][m][j], bf[fcur][n][j], acc[m][n], 0, 0, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 2 + NT, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, LATE ? 6 * NT : 2 * NT, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, LATE ? 2 * NT : 6 * NT, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+      }
+      // ---- epilogue of this tile
+      const int b = P.b, x0 = P.x0, y0 = P.y0, ntile = P.ntile;
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const float bias = a.bias[ntile * BN + n * 32 + lx];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float v = acc[m][n][r] + bias;
+            acc[m][n][r] = a.relu ? fmaxf(v, 0.f) : v;
+          }
+      }
+      const bool interior = (x0 + TW <= a.W) && (y0 + D_TH <= a.H) && ((ntile + 1) * BN <= a.coutp);
+      if (a.dst_pool) store_pooled<NT>(a, acc, b, x0, y0 + 2 * wave, ntile * BN, lx, lh, interior);
+      if (interior) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+          for (int m = 0; m < 2; ++m) {
+            float* drow = a.dst + ((size_t)(b * a.H + y0 + 2 * wave + m) * a.W + x0 + 4 * lh) * a.coutp + ntile * BN + n * 32 + lx;
+            if (!a.accumulate) {
+#pragma unroll
+              for (int r = 0; r < 16; ++r) drow[(size_t)((r & 3) + 8 * (r >> 2)) * a.coutp] = acc[m][n][r];
+            } else {
+#pragma unroll
+              for (int r = 0; r < 16; ++r) acc[m][n][r] += drow[(size_t)((r & 3) + 8 * (r >> 2)) * a.coutp];
+#pragma unroll
+              for (int r = 0; r < 16; ++r) drow[(size_t)((r & 3) + 8 * (r >> 2)) * a.coutp] = acc[m][n][r];
+            }
+          }
+      } else {
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          const int co = ntile * BN + n * 32 + lx;
+#pragma unroll
+          for (int m = 0; m < 2; ++m) {
+            const int y = y0 + 2 * wave + m;
+            float* drow = a.dst + ((size_t)(b * a.H + min(y, a.H - 1)) * a.W) * a.coutp + min(co, a.coutp - 1);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int x = x0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+              if (x < a.W && y < a.H && co < a.coutp) {
+                float* dp = drow + (size_t)x * a.coutp;
+                *dp = a.accumulate ? (*dp + acc[m][n][r]) : acc[m][n][r];
+              }
+            }
+          }
+        }
+      }
+      if (!has_next) break;
+      parity = (parity + nchunks) & 1;
+      vid = nvid;
+      P = Pn;
+    }
+  };
+  if (a.dma_stagger && wave >= 4)
+    run(std::true_type{});
+  else
+    run(std::false_type{});
+}
+
 int launch_conv3x3_dma(const ConvArgs& a_in, hipStream_t s) {
   ConvArgs a = a_in;
   static const int stagger = getenv("PH_CONV_DMA_STAGGER") ? atoi(getenv("PH_CONV_DMA_STAGGER")) : 1;  // experiment knob
   a.dma_stagger = stagger;
   const int tiles = ((a.W + TW - 1) / TW) * ((a.H + D_TH - 1) / D_TH) * a.B;
-  if (a.bn == 64) {
+  static const int persist = getenv("PH_CONV_PERSIST") ? atoi(getenv("PH_CONV_PERSIST")) : 1;  // experiment knob: 0 = one tile per workgroup
+  if (a.bn == 64 && persist) {
+    static int n_cu = 0;
+    if (!n_cu) {
+      int dev = 0;
+      PH_HIP_CHECK(hipGetDevice(&dev));
+      PH_HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+    }
+    const size_t lds = (size_t)2 * (D_A_PIECES + 9 * 64 / 16) * 1024;
+    const int total = tiles * ((a.coutp + 63) / 64);
+    hipLaunchKernelGGL(conv3x3_mfma_dma_persist_kernel<64>, dim3(std::min(total, n_cu)), dim3(512), lds, s, a);
+  } else if (a.bn == 64) {
     const size_t lds = (size_t)2 * (D_A_PIECES + 9 * 64 / 16) * 1024;
     hipLaunchKernelGGL(conv3x3_mfma_dma_kernel<64>, dim3(tiles * ((a.coutp + 63) / 64)), dim3(512), lds, s, a);
   } else {
@@ -1060,6 +1312,8 @@ int prepare_kernels() {
   e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_mfma_dma_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e == hipSuccess)
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_mfma_dma_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e == hipSuccess)
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_mfma_dma_persist_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e != hipSuccess) {
     set_error("hipFuncSetAttribute(conv dma) failed: %s", hipGetErrorString(e));
     return PH_E_HIP;
