@@ -293,6 +293,7 @@ ph_model* ph_model_create(const ph_op_desc* ops, int32_t n_ops, const float* con
   {
     const char* impl = getenv("PH_CONV_IMPL");
     m->use_dma = !(impl && std::string(impl) == "reg");
+    if (const char* d32 = getenv("PH_CONV_DMA32")) m->dma32 = atoi(d32) != 0;  // experiment knob: LDS-DMA kernel for the 32-wide N tile too
     if (const char* wi = getenv("PH_WGRAD_IMPL")) m->wgrad_rows = std::string(wi) == "rows" ? 2 : (std::string(wi) == "auto" ? 1 : 0);
     if (const char* th = getenv("PH_CONV_GEMM_FILL")) m->gemm_fill_threshold = atof(th);  // experiment knob: 0 disables the row-GEMM form
     std::vector<float> z(64, 0.f);
@@ -675,7 +676,7 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
           rc = launch_gemm(g, s);
           break;
         }
-        rc = (m->use_dma && a.bn == 64) ? launch_conv3x3_dma(a, s) : launch_conv3x3(a, s);  // BN=32 layers: the register-staged kernel is faster
+        rc = (m->use_dma && (a.bn == 64 || m->dma32)) ? launch_conv3x3_dma(a, s) : launch_conv3x3(a, s);  // BN=32 layers: the register-staged kernel is faster
         break;
       }
       case PH_OP_POOL: {
@@ -712,7 +713,7 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
         a.dst_pool = nullptr;
         a.wpack_dma = op.w_dma_dev;
         a.zeros = m->zeros_dev;
-        rc = (m->use_dma && a.bn == 64) ? launch_conv3x3_dma(a, s) : launch_conv3x3(a, s);  // BN=32 layers: the register-staged kernel is faster
+        rc = (m->use_dma && (a.bn == 64 || m->dma32)) ? launch_conv3x3_dma(a, s) : launch_conv3x3(a, s);  // BN=32 layers: the register-staged kernel is faster
         break;
       }
       case PH_OP_PATCH_STEM: {

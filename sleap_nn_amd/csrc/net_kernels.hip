@@ -839,6 +839,16 @@ int launch_conv3x3_dma(const ConvArgs& a_in, hipStream_t s) {
     const size_t lds = (size_t)2 * (D_A_PIECES + 9 * 64 / 16) * 1024;
     const int total = tiles * ((a.coutp + 63) / 64);
     hipLaunchKernelGGL(conv3x3_mfma_dma_persist_kernel<64>, dim3(std::min(total, n_cu)), dim3(512), lds, s, a);
+  } else if (a.bn == 32 && persist) {
+    static int n_cu32 = 0;
+    if (!n_cu32) {
+      int dev = 0;
+      PH_HIP_CHECK(hipGetDevice(&dev));
+      PH_HIP_CHECK(hipDeviceGetAttribute(&n_cu32, hipDeviceAttributeMultiprocessorCount, dev));
+    }
+    const size_t lds = (size_t)2 * (D_A_PIECES + 9 * 32 / 16) * 1024;
+    const int total = tiles * ((a.coutp + 31) / 32);
+    hipLaunchKernelGGL(conv3x3_mfma_dma_persist_kernel<32>, dim3(std::min(total, n_cu32)), dim3(512), lds, s, a);
   } else if (a.bn == 64) {
     const size_t lds = (size_t)2 * (D_A_PIECES + 9 * 64 / 16) * 1024;
     hipLaunchKernelGGL(conv3x3_mfma_dma_kernel<64>, dim3(tiles * ((a.coutp + 63) / 64)), dim3(512), lds, s, a);
@@ -1314,6 +1324,8 @@ int prepare_kernels() {
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_mfma_dma_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e == hipSuccess)
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_mfma_dma_persist_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e == hipSuccess)
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_mfma_dma_persist_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e != hipSuccess) {
     set_error("hipFuncSetAttribute(conv dma) failed: %s", hipGetErrorString(e));
     return PH_E_HIP;

@@ -241,7 +241,7 @@ int ph_model_backward(ph_model* m, const void* input_dev, int32_t in_dtype, int3
           a.zeros = m->zeros_dev;
           a.dst_pool = nullptr;
           a.accumulate = init[srcs[part]];
-          rc = (m->use_dma && a.bn == 64) ? launch_conv3x3_dma(a, s) : launch_conv3x3(a, s);
+          rc = (m->use_dma && (a.bn == 64 || m->dma32)) ? launch_conv3x3_dma(a, s) : launch_conv3x3(a, s);
           if (rc != PH_OK) return rc;
           init[srcs[part]] = 1;
         }
