@@ -588,3 +588,24 @@ def test_graph_replay_equals_eager_and_cuts_latency():
         t[name] = (time.perf_counter() - t0) / 50
     print(f"latency per 64x64 frame: eager {t['eager'] * 1e3:.3f} ms, graph {t['graph'] * 1e3:.3f} ms")
     assert t["graph"] <= t["eager"] * 1.2
+
+
+def test_forward_is_bitwise_deterministic_and_stream_safe():
+    """Two forwards of the same batch give bit-identical maps (fixed reduction orders, no atomics), also when the
+    second one runs on a different stream and after other shapes have been through the same model handle
+    (persistent workgroups, LDS rings and workspace reuse leave no state behind)."""
+    z = G.load("unet_tiny_bu13.npz")
+    cfg = G.config(z)
+    m = _model(cfg, G.weights(z))
+    g = torch.Generator().manual_seed(9)
+    img = torch.randint(0, 256, (3, cfg["backbone"]["in_channels"], 96, 128), dtype=torch.uint8, generator=g).to(DEV)
+    a = {k: v.clone() for k, v in m(img).items()}
+    m(img[:1, :, :64, :64].contiguous())  # another shape in between
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        b = {k: v.clone() for k, v in m(img).items()}
+    s.synchronize()
+    torch.cuda.synchronize()
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
