@@ -41,25 +41,36 @@ SIZE = 1024
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32-input MFMA = 64 FLOP/clk/SIMD * 1024 SIMDs * 2.4 GHz
 
 
-def rendered_heads(batch: int, distinct: int = 8):
-    """Rendered confmaps (B,13,256,256) and PAFs (B,24,128,128), 6 instances per frame."""
-    from oracle import cpu_ref as O  # bench input generator + cpu_baseline only
-
-    edges = [(i, i + 1) for i in range(12)]
-    cms, pafs = [], []
+def synthetic_instances(batch: int, distinct: int = 8) -> torch.Tensor:
+    """(B, 6, 13, 2) keypoints: per frame 6 animals, centres U(150, S-150), node offsets N(0, 40 px), seed 777+b
+    (BASELINE.md section 3); `distinct` different frames, repeated to fill the batch."""
+    pts = []
     for b in range(min(batch, distinct)):
-        pts = O.render_instances(SIZE, 13, 6, 777 + b)
-        cms.append(O.render_confmaps(pts, SIZE, 4, 2.5 * 4 / 2))
-        pafs.append(O.render_pafs(pts, edges, SIZE, 8, 30.0))
-    reps = (batch + len(cms) - 1) // len(cms)
-    return torch.stack(cms).repeat(reps, 1, 1, 1)[:batch].contiguous(), torch.stack(pafs).repeat(reps, 1, 1, 1)[:batch].contiguous()
+        rng = np.random.RandomState(777 + b)
+        centres = rng.uniform(150, SIZE - 150, size=(6, 1, 2))
+        pts.append(np.clip(centres + rng.normal(0, 40, size=(6, 13, 2)), 8, SIZE - 9).astype(np.float32))
+    reps = (batch + len(pts) - 1) // len(pts)
+    return torch.from_numpy(np.stack(pts)).repeat(reps, 1, 1, 1)[:batch].contiguous()
 
 
-def cpu_baseline(budget_s: float = 20.0):
-    """Oracle (torch-CPU restatement of the reference, kind = "port") on the host cores."""
+def rendered_heads(batch: int, device):
+    """Rendered head outputs for the post-process stage, drawn by the product's own target renderers (the
+    reference's generate_multiconfmaps / generate_pafs semantics): confmaps (B,13,256,256) with sigma 2.5 at
+    stride 4, PAFs (B,24,128,128) with sigma 75 at stride 8, 6 instances per frame."""
+    from sleap_nn_amd.data.targets import generate_multiconfmaps, generate_pafs
+
+    pts = synthetic_instances(batch).to(device)
+    edges = [(i, i + 1) for i in range(12)]
+    cms = generate_multiconfmaps(pts, (SIZE, SIZE), sigma=2.5 * 4 / 2 / 4, output_stride=4)  # sigma * stride = 5 px
+    pafs = generate_pafs(pts, (SIZE, SIZE), sigma=75.0, output_stride=8, edge_inds=edges)
+    return cms, pafs
+
+
+def cpu_baseline(sd, cms, pafs, budget_s: float = 20.0):
+    """Oracle (torch-CPU restatement of the reference, kind = "port") on the host cores, on the same weights
+    and the same rendered heads as the GPU leg.  The only place bench.py touches oracle/."""
     from oracle import cpu_ref as O
 
-    sd = O.init_state(CFG3_BB, CFG3_HEADS, "bottomup")
     g = torch.Generator().manual_seed(4321)
     img = torch.randint(0, 256, (1, 1, SIZE, SIZE), dtype=torch.uint8, generator=g)
     # pick the fastest thread count among a few candidates (oneDNN degrades badly when
@@ -76,7 +87,6 @@ def cpu_baseline(budget_s: float = 20.0):
             if dt < best:
                 best, best_t = dt, th
     torch.set_num_threads(best_t)
-    cms, pafs = rendered_heads(2, 2)
     scorer = O.PAFScorerRef(NODES, [tuple(e) for e in CFG3_HEADS["pafs"]["edges"]], 8)
     with torch.inference_mode():
         O.model_forward(sd, CFG3_BB, CFG3_HEADS, "bottomup", img)  # warm-up
@@ -126,7 +136,6 @@ def main():
         # ranks share the host: keep torch's CPU pool (synthetic-input rendering only) to a fair share
         torch.set_num_threads(max(1, (os.cpu_count() or world) // world))
 
-    from oracle import cpu_ref as O  # synthetic weights come from the oracle's seeded initialiser
     from sleap_nn_amd.architectures.model import Model
     from sleap_nn_amd.inference.backends import HipBackend
     from sleap_nn_amd.inference.layers import BottomUpLayer
@@ -135,12 +144,11 @@ def main():
 
     B = args.batch
     model = Model("unet", CFG3_BB, CFG3_HEADS, "bottomup")
-    model.load_state_dict(O.init_state(CFG3_BB, CFG3_HEADS, "bottomup"))
+    model.init_xavier_(seed=1234, head_scale=0.05)  # the reference's xavier_init_weights; heads x0.05 keep outputs O(1)
     layer = BottomUpLayer(HipBackend(model, str(dev)), PAFScorer.from_config(CFG3_HEADS), 4, 8, max_stride=32)
     g = torch.Generator().manual_seed(4321 + rank)
     frames = torch.randint(0, 256, (B, 1, 1, SIZE, SIZE), dtype=torch.uint8, generator=g).to(dev)
-    cms, pafs = rendered_heads(B)
-    cms, pafs = cms.to(dev), pafs.to(dev)
+    cms, pafs = rendered_heads(B, dev)
     info = PreprocInfo(original_size=(SIZE, SIZE), processed_size=(SIZE, SIZE), eff_scale=torch.ones(B), output_stride=4)
 
     from concurrent.futures import ThreadPoolExecutor
@@ -247,7 +255,7 @@ def main():
                 "workload": "cfg3: bottom-up UNet f16/r2/max_stride32/output_stride4, 1024x1024x1 uint8 frames, 13 nodes / 12 edges",
                 "frames_per_gpu_per_step": B, "global_batch": B * world, "parallelism": f"dp{world} (frames sharded, no collective)",
                 "weights": "xavier-uniform seed 1234, head x0.05", "postprocess_input": "rendered heads, 6 instances/frame (BASELINE.md s3)",
-                "params": model.num_parameters(), "conv_gflop_per_frame": O.conv_flops(CFG3_BB, CFG3_HEADS, "bottomup", SIZE, SIZE) / 1e9,
+                "params": model.num_parameters(), "conv_gflop_per_frame": sum(r["flops"] for r in model.op_table(1, SIZE, SIZE)) / 1e9,
             },
             "roofline": {
                 "bound": "mfma", "kernel": f"conv3x3_mfma_kernel ({len(conv_rows)} launches/forward; the first encoder block runs in the fused stem kernel)",
@@ -263,7 +271,7 @@ def main():
             },
         }
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline()
+            res["cpu_baseline"] = cpu_baseline(model.state_dict(), cms[:2].cpu(), pafs[:2].cpu())
         print(json.dumps(res))
     if world > 1:
         dist.barrier()

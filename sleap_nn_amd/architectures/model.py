@@ -202,6 +202,32 @@ class Model:
         self._release()
         return missing, unexpected
 
+    def init_xavier_(self, seed: int = 0, head_scale: float = 1.0) -> "Model":
+        """Fresh weights the way the reference's trainer initialises a model (``xavier_init_weights``,
+        training/utils.py:72-78): Xavier-uniform Conv2d / Linear weights, zero biases; LayerNorm affine = (1, 0),
+        ConvNeXt ``layer_scale`` = 1e-6 (the module defaults).  ``head_scale`` shrinks the head weights (synthetic
+        benchmarks keep the raw outputs O(1) that way).  Deterministic in ``seed``."""
+        import math
+
+        g = torch.Generator().manual_seed(int(seed))
+        sd = {}
+        for k, shape in self.param_shapes.items():
+            if k.endswith(".layer_scale"):
+                sd[k] = torch.full(shape, 1e-6)
+            elif len(shape) == 1:
+                ln = k.endswith(".weight") and any(o.kind == L.OP_LAYERNORM and o.weight == k for o in self.unfused_ops)
+                sd[k] = torch.ones(shape) if ln else torch.zeros(shape)
+            else:
+                rf = 1
+                for d in shape[2:]:
+                    rf *= int(d)
+                fan_in, fan_out = int(shape[1]) * rf, int(shape[0]) * rf
+                bound = math.sqrt(6.0 / (fan_in + fan_out))
+                w = (torch.rand(shape, generator=g) * 2 - 1) * bound
+                sd[k] = w * head_scale if k.startswith("head_layers.") else w
+        self.load_state_dict(sd, strict=True)
+        return self
+
     def num_parameters(self) -> int:
         return sum(int(torch.tensor(s).prod()) for s in self.param_shapes.values())
 

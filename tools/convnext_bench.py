@@ -9,7 +9,6 @@ import time
 import torch
 
 sys.path.insert(0, ".")
-from oracle import cpu_ref as O  # synthetic weights only
 from sleap_nn_amd.architectures.model import Model
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
@@ -18,9 +17,8 @@ bb = {"model_type": "tiny", "arch": None, "in_channels": 1, "kernel_size": 3, "f
       "stem_patch_kernel": 4, "stem_patch_stride": 2, "output_stride": 2, "max_stride": 32}
 heads = {"confmaps": {"part_names": [str(i) for i in range(13)], "sigma": 2.5, "output_stride": 2}}
 t0 = time.time()
-sd = O.init_state_convnext(bb, heads, "centered_instance")
 m = Model("convnext", bb, heads, "centered_instance")
-m.load_state_dict(sd)
+m.init_xavier_(seed=1234, head_scale=0.05)
 m.to("cuda:0")
 img = torch.randint(0, 256, (B, 1, S, S), dtype=torch.uint8, device="cuda:0")
 m(img)

@@ -8,7 +8,6 @@ import time
 import torch
 
 sys.path.insert(0, ".")
-from oracle import cpu_ref as O  # synthetic weights only
 from sleap_nn_amd.architectures.model import Model
 from sleap_nn_amd.training.module import TrainingModule
 
@@ -17,9 +16,8 @@ S = int(sys.argv[2]) if len(sys.argv) > 2 else 384
 bb = {"model_type": "tiny", "arch": None, "in_channels": 1, "kernel_size": 3, "filters_rate": 2, "convs_per_block": 2, "up_interpolate": True,
       "stem_patch_kernel": 4, "stem_patch_stride": 2, "output_stride": 2, "max_stride": 32}
 heads = {"confmaps": {"part_names": [str(i) for i in range(13)], "sigma": 2.5, "output_stride": 2, "loss_weight": 1.0}}
-sd = O.init_state_convnext(bb, heads, "centered_instance")
 m = Model("convnext", bb, heads, "centered_instance")
-m.load_state_dict(sd)
+m.init_xavier_(seed=1234, head_scale=0.05)
 tm = TrainingModule(m, "cuda:0", loss_weights=[1.0])
 img = torch.randint(0, 256, (B, 1, S, S), dtype=torch.uint8, device="cuda:0")
 tgt = {"CenteredInstanceConfmapsHead": torch.rand((B, 13, S // 2, S // 2), device="cuda:0")}

@@ -3,14 +3,13 @@ import sys, time
 sys.path.insert(0, '.')
 import torch
 import bench
-from oracle import cpu_ref as O
 from sleap_nn_amd.architectures.model import Model
 from sleap_nn_amd.training.module import TrainingModule
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 S = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 m = Model("unet", bench.CFG3_BB, bench.CFG3_HEADS, "bottomup")
-m.load_state_dict(O.init_state(bench.CFG3_BB, bench.CFG3_HEADS, "bottomup"))
+m.init_xavier_(seed=1234, head_scale=0.05)
 tm = TrainingModule(m, "cuda:0", lr=1e-4)
 g = torch.Generator().manual_seed(0)
 img = torch.randint(0, 256, (B, 1, S, S), dtype=torch.uint8, generator=g).cuda()
@@ -24,5 +23,5 @@ for _ in range(n):
     loss = tm.training_step({"image": img, **tg})
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t) / n
-fl = 3 * O.conv_flops(bench.CFG3_BB, bench.CFG3_HEADS, "bottomup", S, S) * B
+fl = 3 * sum(r["flops"] for r in m.op_table(1, S, S)) * B
 print(f"train step B={B} {S}x{S}: {dt*1e3:.1f} ms = {B/dt:.1f} frames/s; ~{fl/dt/1e12:.1f} TFLOP/s (3x fwd conv FLOPs); loss {loss.cpu().numpy()}")
