@@ -152,6 +152,14 @@ def test_target_rendering_matches_reference_and_oracle():
         out = generate_pafs(pts, meta["hw"], sigma=sigma, output_stride=stride, edge_inds=meta["edges"]).cpu().numpy()
         np.testing.assert_allclose(out, g[f"pafs_s{stride}"], rtol=0, atol=5e-6)
 
+    # the reference's own known-answer vectors (tests/data/test_edge_maps.py:65-167)
+    from tests.test_oracle_golden import _PAF_KAT
+
+    inst = torch.tensor([[[[1.0, 0.5], [1.0, 1.5], [0.0, 0.0], [2.0, 2.0]]]]).cuda()
+    np.testing.assert_allclose(generate_pafs(inst, (3, 3), sigma=1.0, output_stride=1, edge_inds=[(0, 1), (2, 3)]).cpu().numpy().reshape(2, 2, 3, 3), _PAF_KAT, atol=1e-3)
+    np.testing.assert_allclose(generate_pafs(inst.repeat(1, 2, 1, 1), (3, 3), sigma=1.0, output_stride=1, edge_inds=[(0, 1), (2, 3)]).cpu().numpy().reshape(2, 2, 3, 3),
+                               2 * _PAF_KAT, atol=1e-3)
+
     gen = torch.Generator().manual_seed(5)
     big = torch.rand((4, 9, 13, 2), generator=gen) * torch.tensor([300.0, 260.0]) - 20.0
     big[torch.rand((4, 9, 13), generator=gen) < 0.15] = float("nan")

@@ -298,3 +298,46 @@ def test_centroid_nms_matches_reference():
         valid = ~torch.isnan(cent).any(-1)
         keep = layer._centroid_nms_mask(cent, vals, valid)
         np.testing.assert_array_equal(keep.numpy(), g[f"{c}/keep"], err_msg=f"case {c}")
+
+
+def test_coordinate_ladder_known_answers():
+    """Replays the known-answer vectors of the reference's tests/inference/ops/test_coord.py (identity
+    short-circuits return the same object; per-sample eff_scale broadcasting; crop offsets; round trip)."""
+    from sleap_nn_amd.inference.ops.coord import add_crop_offset, undo_eff_scale, undo_input_scale, undo_stride
+
+    c = torch.tensor([[1.0, 2.0], [3.0, 4.0]])
+    assert undo_stride(c, 1) is c and undo_input_scale(c, 1.0) is c
+    torch.testing.assert_close(undo_stride(torch.tensor([[2.0, 4.0]]), 4), torch.tensor([[8.0, 16.0]]))
+    assert undo_stride(torch.zeros(3, 5, 7, 2), 2).shape == (3, 5, 7, 2)
+    torch.testing.assert_close(undo_input_scale(torch.tensor([[2.0, 8.0]]), 0.5), torch.tensor([[4.0, 16.0]]))
+    c3 = torch.tensor([[[1.0, 2.0], [3.0, 4.0]]])
+    assert undo_eff_scale(c3, torch.ones(1)) is c3
+    coords = torch.tensor([[[2.0, 4.0], [6.0, 8.0]], [[1.0, 1.0], [2.0, 2.0]]])
+    torch.testing.assert_close(undo_eff_scale(coords, torch.tensor([2.0, 0.5])), torch.tensor([[[1.0, 2.0], [3.0, 4.0]], [[2.0, 2.0], [4.0, 4.0]]]))
+    out = undo_eff_scale(torch.ones(2, 3, 2, 2) * 4.0, torch.tensor([2.0, 4.0]))
+    torch.testing.assert_close(out[0], torch.full((3, 2, 2), 2.0))
+    torch.testing.assert_close(out[1], torch.full((3, 2, 2), 1.0))
+    torch.testing.assert_close(add_crop_offset(torch.tensor([[[1.0, 2.0], [3.0, 4.0]]]), torch.tensor([[10.0, 20.0]])), torch.tensor([[[11.0, 22.0], [13.0, 24.0]]]))
+    torch.testing.assert_close(add_crop_offset(torch.tensor([[[1.0, 1.0], [2.0, 2.0]], [[3.0, 3.0], [4.0, 4.0]]]), torch.tensor([[100.0, 0.0], [0.0, 100.0]])),
+                               torch.tensor([[[101.0, 1.0], [102.0, 2.0]], [[3.0, 103.0], [4.0, 104.0]]]))
+    rng = np.random.default_rng(0)
+    original = torch.tensor(rng.uniform(0, 100, size=(2, 3, 2)).astype(np.float32))
+    eff = torch.tensor([2.0, 1.5])
+    fwd = original * eff.view(2, 1, 1) * 0.5 / 4
+    torch.testing.assert_close(undo_eff_scale(undo_input_scale(undo_stride(fwd, 4), 0.5), eff), original)
+
+
+def test_unet_structure_known_answers():
+    """tests/architectures/test_unet.py:20-111 of the reference: a UNet(filters 16, rate 2, max_stride 16, output_stride 1)
+    + a 13-channel 1x1 head has 38 parameter tensors and 1,962,541 parameters; decoder strides / channels."""
+    from sleap_nn_amd.architectures.model import Model
+
+    bb = {"in_channels": 1, "kernel_size": 3, "filters": 16, "filters_rate": 2, "max_stride": 16, "convs_per_block": 2, "stacks": 1,
+          "stem_stride": None, "middle_block": True, "up_interpolate": True, "block_contraction": False, "output_stride": 1}
+    heads = {"confmaps": {"part_names": [str(i) for i in range(13)], "sigma": 5.0, "output_stride": 1}}
+    m = Model("unet", bb, heads, "single_instance")
+    assert len(m.param_shapes) == 38
+    assert m.num_parameters() == 1962541
+    assert m.backbone.decoder_stride_to_filters == {16: 256, 8: 128, 4: 64, 2: 32, 1: 16}
+    sd = O.init_state(bb, heads, "single_instance")
+    assert sorted(sd) == sorted(m.param_shapes) and sum(v.numel() for v in sd.values()) == 1962541
