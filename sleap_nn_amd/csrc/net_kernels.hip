@@ -1205,7 +1205,7 @@ int launch_zero_stuff(const float* src, float* dst, int B, int H, int W, int cp,
 __global__ __launch_bounds__(256) void head1x1_kernel(const float* __restrict__ src, const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ dst, int B, int HW, int cp, int cout, int sigmoid) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* sa = lds;                    // 64 x (cp+1)
-  float* sw = lds + 64 * (cp + 1);    // cout x cp
+  float* sw = lds + 64 * (cp + 1);    // cout x cp (16-B aligned rows: cp is a multiple of 16 and 64*(cp+1) of 4... see launch)
   const size_t npix = (size_t)B * HW;
   const size_t p0 = (size_t)blockIdx.x * 64;
   for (int i = threadIdx.x; i < cout * cp; i += 256) sw[i] = w[i];
@@ -1218,13 +1218,43 @@ __global__ __launch_bounds__(256) void head1x1_kernel(const float* __restrict__ 
   const size_t p = p0 + pp;
   if (p >= npix) return;
   const size_t b = p / HW, hw = p - b * HW;
-  for (int j = j0; j < cout; j += 4) {
-    float acc = bias[j];
-    const float* wr = sw + j * cp;
-    const float* ar = sa + pp * (cp + 1);
-    for (int c = 0; c < cp; ++c) acc += ar[c] * wr[c];
-    if (sigmoid) acc = 1.f / (1.f + expf(-acc));
-    dst[(b * cout + j) * HW + hw] = acc;
+  // thread (pixel pp, j0) owns output channels j0, j0+4, ...: the pixel's activations are pulled into registers
+  // 32 channels at a time (conflict-free column reads) and each weight quad is one broadcast ds_read_b128
+  constexpr int MAXJ = 16;  // up to 64 output channels per pass
+  const float* ar = sa + pp * (cp + 1);
+  for (int jb = j0; jb < cout; jb += 4 * MAXJ) {
+    float acc[MAXJ];
+#pragma unroll
+    for (int k = 0; k < MAXJ; ++k) acc[k] = (jb + 4 * k < cout) ? bias[jb + 4 * k] : 0.f;
+    for (int cb = 0; cb < cp; cb += 16) {
+      float xr[16];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) xr[c] = ar[cb + c];
+#pragma unroll
+      for (int k = 0; k < MAXJ; ++k) {
+        const int j = jb + 4 * k;
+        if (j < cout) {  // wave-uniform (j0 is per wave)
+          const float* wr = sw + j * cp + cb;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(wr + q * 4);
+            acc[k] += xr[4 * q] * wv[0];
+            acc[k] += xr[4 * q + 1] * wv[1];
+            acc[k] += xr[4 * q + 2] * wv[2];
+            acc[k] += xr[4 * q + 3] * wv[3];
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < MAXJ; ++k) {
+      const int j = jb + 4 * k;
+      if (j < cout) {
+        float v = acc[k];
+        if (sigmoid) v = 1.f / (1.f + expf(-v));
+        dst[(b * cout + j) * HW + hw] = v;
+      }
+    }
   }
 }
 
