@@ -366,33 +366,52 @@ int launch_upsample_bwd(const float* gy, int B, int H, int W, int cp, int accumu
 constexpr int BIAS_SLICES = 1024;
 __global__ __launch_bounds__(256) void bias_partial_kernel(float* __restrict__ g, const float* __restrict__ y_mask, size_t npix, int cp,
                                                            float* __restrict__ partial /* BIAS_SLICES x cp */) {
-  // y_mask != nullptr: the ReLU mask (g = 0 where the forward output y is 0) is applied on the way, in place
-  // thread = (pixel row r, channel c): 256/min(cp,256) pixels are summed side by side, then the
-  // rows are combined in a fixed order through LDS (deterministic).
-  __shared__ float red[256];
+  // y_mask != nullptr: the ReLU mask (g = 0 where the forward output y is 0) is applied on the way, in place.
+  // thread = (pixel row r, channel quad c): 256/min(cp/4,256) pixels are summed side by side, four pixels
+  // per trip with all loads issued before the first store (the pass is HBM-bound, not latency-bound);
+  // the rows are combined in a fixed order through LDS (deterministic).
+  __shared__ f32x4 red[256];
   const int sl = blockIdx.x;
   const size_t per = (npix + BIAS_SLICES - 1) / BIAS_SLICES;
   const size_t lo = (size_t)sl * per, hi = std::min(npix, lo + per);
-  const int cw = min(cp, 256), rows = 256 / cw;
+  const int cq = cp >> 2;  // cp is a multiple of 16
+  const int cw = min(cq, 256), rows = 256 / cw;
   const int c0 = threadIdx.x % cw, r = threadIdx.x / cw;
-  for (int cb = 0; cb < cp; cb += cw) {
+  f32x4* g4 = reinterpret_cast<f32x4*>(g);
+  const f32x4* y4 = reinterpret_cast<const f32x4*>(y_mask);
+  auto masked = [](f32x4 v, f32x4 y) __attribute__((always_inline)) {
+    return f32x4{y[0] > 0.f ? v[0] : 0.f, y[1] > 0.f ? v[1] : 0.f, y[2] > 0.f ? v[2] : 0.f, y[3] > 0.f ? v[3] : 0.f};
+  };
+  for (int cb = 0; cb < cq; cb += cw) {
     const int c = cb + c0;
-    float acc = 0.f;
-    if (r < rows && c < cp)
-      for (size_t p = lo + r; p < hi; p += rows) {
-        float v = g[p * cp + c];
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (r < rows && c < cq) {
+      size_t p = lo + r;
+      for (; p + 3 * (size_t)rows < hi; p += 4 * (size_t)rows) {
+        const size_t i0 = p * cq + c, st = (size_t)rows * cq;
+        f32x4 v0 = g4[i0], v1 = g4[i0 + st], v2 = g4[i0 + 2 * st], v3 = g4[i0 + 3 * st];
         if (y_mask) {
-          v = y_mask[p * cp + c] > 0.f ? v : 0.f;
-          g[p * cp + c] = v;
+          const f32x4 m0 = y4[i0], m1 = y4[i0 + st], m2 = y4[i0 + 2 * st], m3 = y4[i0 + 3 * st];
+          v0 = masked(v0, m0), v1 = masked(v1, m1), v2 = masked(v2, m2), v3 = masked(v3, m3);
+          g4[i0] = v0, g4[i0 + st] = v1, g4[i0 + 2 * st] = v2, g4[i0 + 3 * st] = v3;
+        }
+        acc += (v0 + v1) + (v2 + v3);
+      }
+      for (; p < hi; p += rows) {
+        f32x4 v = g4[p * cq + c];
+        if (y_mask) {
+          v = masked(v, y4[p * cq + c]);
+          g4[p * cq + c] = v;
         }
         acc += v;
       }
+    }
     red[threadIdx.x] = acc;
     __syncthreads();
-    if (r == 0 && c < cp) {
-      float s = 0.f;
+    if (r == 0 && c < cq) {
+      f32x4 s = {0.f, 0.f, 0.f, 0.f};
       for (int k = 0; k < rows; ++k) s += red[k * cw + c0];
-      partial[(size_t)sl * cp + c] = s;
+      *reinterpret_cast<f32x4*>(partial + (size_t)sl * cp + 4 * c) = s;
     }
     __syncthreads();
   }
@@ -428,20 +447,26 @@ int64_t bias_scratch_floats(int cp) { return (int64_t)BIAS_SLICES * cp; }
 //   conflicts).  Waves split the taps {0,4,8} {1,5} {2,6} {3,7}.  Partial sums go to a slab per
 //   K slice; wgrad_reduce_kernel adds the slabs in a fixed order into the canonical OIHW gradient.
 // ---------------------------------------------------------------------------------------
-constexpr int WG_TH = 8, WG_TW = 32, WG_HW = WG_TW + 2, WG_HH = WG_TH + 2;
+constexpr int WG_TH = 4, WG_TW = 32, WG_HW = WG_TW + 2, WG_HH = WG_TH + 2;  // wgrad16_kernel keeps 8-row tiles (W16_TH)
+constexpr int W16_TH = 8, W16_HH = W16_TH + 2;
 
+template <int TH>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
-  // Every wave accumulates all nine taps over its quarter of each pixel tile (pixel rows 2w, 2w+1):
-  // nine accumulators per wave, perfectly balanced (a split of the taps over four waves is 3+2+2+2);
-  // the four partial sets are added through LDS once, after the K loop.
-  __shared__ float sX[WG_HH * WG_HW * 32];
-  __shared__ float sY[WG_TH * WG_TW * 32];
+  // Every wave accumulates all nine taps over its quarter of each TH x 32 pixel tile: nine accumulators
+  // per wave, perfectly balanced (a split of the taps over four waves is 3+2+2+2); the four partial sets
+  // are added through LDS once, after the K loop.  The next tile's X halo and dY travel global -> registers
+  // while this tile's MFMAs run (fetch / commit below): the global latency never sits between two tiles.
+  constexpr int HH = TH + 2;
+  constexpr int NXQ = HH * WG_HW * 8, NYQ = TH * WG_TW * 8;  // float4 quads per tile image
+  constexpr int NX = (NXQ + 255) / 256, NY = NYQ / 256;
+  __shared__ float sX[(NXQ * 4 > 4096 ? NXQ * 4 : 4096)];
+  __shared__ float sY[NYQ * 4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lx = lane & 31, lh = lane >> 5;
   const int n_co_t = (a.coutp + 31) / 32;
   const int ci_t = blockIdx.x / n_co_t, co_t = blockIdx.x - ci_t * n_co_t;
   const int slice = blockIdx.y, n_slices = gridDim.y;
-  const int tiles_x = (a.W + WG_TW - 1) / WG_TW, tiles_y = (a.H + WG_TH - 1) / WG_TH;
+  const int tiles_x = (a.W + WG_TW - 1) / WG_TW, tiles_y = (a.H + TH - 1) / TH;
   const int n_tiles = tiles_x * tiles_y * a.B;
 
   f32x16 acc[9];
@@ -450,38 +475,56 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-  for (int tile = slice; tile < n_tiles; tile += n_slices) {
+  f32x4 rx[NX], ry[NY];
+  unsigned okx = 0, oky = 0;
+  const int cxq = min(ci_t * 32 + (tid & 7) * 4, a.cxp - 4), cyq = min(co_t * 32 + (tid & 7) * 4, a.coutp - 4);
+  const bool cx_ok = ci_t * 32 + (tid & 7) * 4 < a.cxp, cy_ok = co_t * 32 + (tid & 7) * 4 < a.coutp;
+  auto fetch = [&](int tile) __attribute__((always_inline)) {
     int t = tile;
     const int tx = t % tiles_x;
     t /= tiles_x;
     const int ty = t % tiles_y;
     const int b = t / tiles_y;
-    const int x0 = tx * WG_TW, y0 = ty * WG_TH;
-    // stage X halo [pix][32 ci] and dY [pix][32 co]; zero outside the image / beyond the channels
-    for (int i = tid; i < WG_HH * WG_HW * 8; i += 256) {
-      const int pix = i >> 3, q = i & 7;
+    const int x0 = tx * WG_TW, y0 = ty * TH;
+    okx = 0, oky = 0;
+#pragma unroll
+    for (int j = 0; j < NX; ++j) {  // X halo [pix][32 ci]; outside the image / beyond the channels -> 0 at commit
+      const int pix = min((tid + 256 * j) >> 3, HH * WG_HW - 1);
       const int hy = pix / WG_HW, hx = pix - hy * WG_HW;
       const int gy = y0 + hy - 1, gx = x0 + hx - 1;
-      const int c = ci_t * 32 + q * 4;
-      const bool ok = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && c < a.cxp;
-      const int cy = min(max(gy, 0), a.H - 1), cx = min(max(gx, 0), a.W - 1), cc = min(c, a.cxp - 4);
-      const f32x4 v = *reinterpret_cast<const f32x4*>(a.x + ((size_t)(b * a.H + cy) * a.W + cx) * a.cxp + cc);
-      *reinterpret_cast<f32x4*>(sX + pix * 32 + q * 4) = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+      const bool ok = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && cx_ok;
+      const int cy = min(max(gy, 0), a.H - 1), cx = min(max(gx, 0), a.W - 1);
+      rx[j] = *reinterpret_cast<const f32x4*>(a.x + ((size_t)(b * a.H + cy) * a.W + cx) * a.cxp + cxq);
+      okx |= ok ? (1u << j) : 0u;
     }
-    for (int i = tid; i < WG_TH * WG_TW * 8; i += 256) {
-      const int pix = i >> 3, q = i & 7;
+#pragma unroll
+    for (int j = 0; j < NY; ++j) {  // dY [pix][32 co]
+      const int pix = (tid + 256 * j) >> 3;
       const int py = pix / WG_TW, px = pix - py * WG_TW;
       const int gy = y0 + py, gx = x0 + px;
-      const int c = co_t * 32 + q * 4;
-      const bool ok = gy < a.H && gx < a.W && c < a.coutp;
-      const int cy = min(gy, a.H - 1), cx = min(gx, a.W - 1), cc = min(c, a.coutp - 4);
-      const f32x4 v = *reinterpret_cast<const f32x4*>(a.dy + ((size_t)(b * a.H + cy) * a.W + cx) * a.coutp + cc);
-      *reinterpret_cast<f32x4*>(sY + pix * 32 + q * 4) = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+      const bool ok = gy < a.H && gx < a.W && cy_ok;
+      const int cy = min(gy, a.H - 1), cx = min(gx, a.W - 1);
+      ry[j] = *reinterpret_cast<const f32x4*>(a.dy + ((size_t)(b * a.H + cy) * a.W + cx) * a.coutp + cyq);
+      oky |= ok ? (1u << j) : 0u;
     }
+  };
+  auto commit = [&]() __attribute__((always_inline)) {
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < NX; ++j)
+      if (tid + 256 * j < NXQ) *reinterpret_cast<f32x4*>(sX + (tid + 256 * j) * 4) = ((okx >> j) & 1u) ? rx[j] : z;
+#pragma unroll
+    for (int j = 0; j < NY; ++j) *reinterpret_cast<f32x4*>(sY + (tid + 256 * j) * 4) = ((oky >> j) & 1u) ? ry[j] : z;
+  };
+
+  if (slice < n_tiles) fetch(slice);
+  for (int tile = slice; tile < n_tiles; tile += n_slices) {
+    commit();
     __syncthreads();
+    if (tile + n_slices < n_tiles) fetch(tile + n_slices);
 #pragma unroll 2
-    for (int s2 = 0; s2 < WG_TW; ++s2) {  // this wave's 64 pixels = rows 2w, 2w+1 of the tile, two per MFMA
-      const int py = 2 * wave + (s2 >> 4), px = 2 * (s2 & 15) + lh;
+    for (int s2 = 0; s2 < TH * 4; ++s2) {  // this wave's TH*8 pixels (rows w*TH/4 ...), two per MFMA
+      const int py = wave * (TH / 4) + (s2 >> 4), px = 2 * (s2 & 15) + lh;
       const float bv = sY[(py * WG_TW + px) * 32 + lx];
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
@@ -507,12 +550,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
 // 16-channel layers (the full-resolution first encoder block): the same computation on v_mfma_f32_16x16x4_f32,
 // a 16(ci) x 16(co) tile with four pixels per MFMA -- a 32x32 tile would be three quarters padding there.
 __global__ __launch_bounds__(256, 2) void wgrad16_kernel(WgradArgs a) {
-  __shared__ float sX[WG_HH * WG_HW * 16];
-  __shared__ float sY[WG_TH * WG_TW * 16];
+  __shared__ float sX[W16_HH * WG_HW * 16];
+  __shared__ float sY[W16_TH * WG_TW * 16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lg = lane >> 4;
   const int slice = blockIdx.y, n_slices = gridDim.y;
-  const int tiles_x = (a.W + WG_TW - 1) / WG_TW, tiles_y = (a.H + WG_TH - 1) / WG_TH;
+  const int tiles_x = (a.W + WG_TW - 1) / WG_TW, tiles_y = (a.H + W16_TH - 1) / W16_TH;
   const int n_tiles = tiles_x * tiles_y * a.B;
   f32x4 acc[9];
 #pragma unroll
@@ -523,8 +566,8 @@ __global__ __launch_bounds__(256, 2) void wgrad16_kernel(WgradArgs a) {
     t /= tiles_x;
     const int ty = t % tiles_y;
     const int b = t / tiles_y;
-    const int x0 = tx * WG_TW, y0 = ty * WG_TH;
-    for (int i = tid; i < WG_HH * WG_HW * 4; i += 256) {
+    const int x0 = tx * WG_TW, y0 = ty * W16_TH;
+    for (int i = tid; i < W16_HH * WG_HW * 4; i += 256) {
       const int pix = i >> 2, q = i & 3;
       const int hy = pix / WG_HW, hx = pix - hy * WG_HW;
       const int gy = y0 + hy - 1, gx = x0 + hx - 1;
@@ -533,7 +576,7 @@ __global__ __launch_bounds__(256, 2) void wgrad16_kernel(WgradArgs a) {
       const f32x4 v = *reinterpret_cast<const f32x4*>(a.x + ((size_t)(b * a.H + cy) * a.W + cx) * 16 + q * 4);
       *reinterpret_cast<f32x4*>(sX + pix * 16 + q * 4) = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    for (int i = tid; i < WG_TH * WG_TW * 4; i += 256) {
+    for (int i = tid; i < W16_TH * WG_TW * 4; i += 256) {
       const int pix = i >> 2, q = i & 3;
       const int py = pix / WG_TW, px = pix - py * WG_TW;
       const int gy = y0 + py, gx = x0 + px;
@@ -570,18 +613,43 @@ __global__ __launch_bounds__(256, 2) void wgrad16_kernel(WgradArgs a) {
   }
 }
 
-// grad[(co*cin_total + ci_off + ci)*9 + tap] = sum_slices slab[...]
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, int n_slices, int n_blocks, int n_co_t, int cin, int cout, int cin_total,
-                                                           int ci_off, float* __restrict__ grad) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= cin * cout * 9) return;
-  const int tap = i % 9;
-  int r = i / 9;
-  const int ci = r % cin, co = r / cin;
-  const int blk = (ci >> 5) * n_co_t + (co >> 5);
-  float s = 0.f;
-  for (int k = 0; k < n_slices; ++k) s += slab[(((size_t)k * n_blocks + blk) * 9 + tap) * 1024 + (ci & 31) * 32 + (co & 31)];
-  grad[((size_t)co * cin_total + ci_off + ci) * 9 + tap] = s;
+// grad[(co*cin_total + ci_off + ci)*9 + tap] = sum_slices slab[...].  One workgroup per (tile, tap) slab slot
+// (1024 floats = 256 quads); 1024 threads = 256 quads x 4 slice parts, so the reads are whole 4 KiB slots
+// and a thread walks only a quarter of the slices, four loads in flight; the parts meet in LDS in a fixed order.
+__global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restrict__ slab, int n_slices, int n_blocks, int n_co_t, int cin, int cout, int cin_total,
+                                                            int ci_off, float* __restrict__ grad) {
+  __shared__ f32x4 red[3 * 256];
+  const int blk = blockIdx.x / 9, tap = blockIdx.x - blk * 9;
+  const int q = threadIdx.x & 255, part = threadIdx.x >> 8;
+  const f32x4* src = reinterpret_cast<const f32x4*>(slab) + ((size_t)blk * 9 + tap) * 256 + q;
+  const size_t st = (size_t)n_blocks * 9 * 256;  // quads per slice
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  int k = part;
+  for (; k + 12 < n_slices; k += 16) {
+    const f32x4 v0 = src[(size_t)k * st], v1 = src[(size_t)(k + 4) * st], v2 = src[(size_t)(k + 8) * st], v3 = src[(size_t)(k + 12) * st];
+    s += (v0 + v1) + (v2 + v3);
+  }
+  for (; k < n_slices; k += 4) s += src[(size_t)k * st];
+  if (part) red[(part - 1) * 256 + q] = s;
+  __syncthreads();
+  if (part) return;
+  s = (s + red[q]) + (red[256 + q] + red[512 + q]);
+  const int ci = (blk / n_co_t) * 32 + (q >> 3);
+  if (ci >= cin) return;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int co = (blk % n_co_t) * 32 + (q & 7) * 4 + j;
+    if (co < cout) grad[((size_t)co * cin_total + ci_off + ci) * 9 + tap] = s[j];
+  }
+}
+
+// pixel-tile rows of wgrad_kernel: 4 (default; 42 KiB LDS, three workgroups per CU) or 8 via PH_WGRAD_TILE_ROWS
+static int wgrad_tile_rows() {
+  static const int v = [] {
+    const char* e = getenv("PH_WGRAD_TILE_ROWS");
+    return (e && atoi(e) == 8) ? 8 : 4;
+  }();
+  return v;
 }
 
 // K slices per (ci, co) tile: enough workgroups to fill 256 CUs x 2, never more than pixel tiles
@@ -601,10 +669,11 @@ int launch_wgrad(const WgradArgs& a0, int cin_part, int cout, int cin_total, int
   const int n_slices = wgrad_slices(a.B, a.H, a.W, n_ci_t * n_co_t);
   if (a.cxp == 16 && a.coutp == 16)
     hipLaunchKernelGGL(wgrad16_kernel, dim3(1, n_slices), dim3(256), 0, s, a);
+  else if (wgrad_tile_rows() == 8)
+    hipLaunchKernelGGL(wgrad_kernel<8>, dim3(n_ci_t * n_co_t, n_slices), dim3(256), 0, s, a);
   else
-    hipLaunchKernelGGL(wgrad_kernel, dim3(n_ci_t * n_co_t, n_slices), dim3(256), 0, s, a);
-  const int n = cin_part * cout * 9;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, s, a.slab, n_slices, n_ci_t * n_co_t, n_co_t, cin_part, cout, cin_total, ci_off, grad);
+    hipLaunchKernelGGL(wgrad_kernel<4>, dim3(n_ci_t * n_co_t, n_slices), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(n_ci_t * n_co_t * 9), dim3(1024), 0, s, a.slab, n_slices, n_ci_t * n_co_t, n_co_t, cin_part, cout, cin_total, ci_off, grad);
   PH_HIP_CHECK(hipGetLastError());
   return PH_OK;
 }
