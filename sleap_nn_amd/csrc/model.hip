@@ -127,6 +127,15 @@ static void pack_conv(const T* w, bool transposed, int cin0, int cin1, int cout,
 
 // [n_tile][chunk][tap][bn][16] -> [n_tile][chunk][piece = (tap*bn + n)/16][quad q][row r = (tap*bn+n)%16][4]
 // (the order in which one LDS-DMA wave-instruction writes a 1-KiB piece, see conv3x3_mfma_dma_kernel)
+// [tap][ci 16][co 16] (zero padded) from OIHW, for conv3x3_c16_kernel
+template <typename T>
+static void pack_c16(const T* w, int cout, int cin, std::vector<T>& out) {
+  out.assign(9 * 256, T(0));
+  for (int co = 0; co < cout; ++co)
+    for (int ci = 0; ci < cin; ++ci)
+      for (int tap = 0; tap < 9; ++tap) out[(size_t)(tap * 16 + ci) * 16 + co] = w[((size_t)co * cin + ci) * 9 + tap];
+}
+
 template <typename T>
 static void repack_dma(const std::vector<T>& in, int bn, std::vector<T>& out) {
   out.resize(in.size());
@@ -394,6 +403,16 @@ ph_model* ph_model_create(const ph_op_desc* ops, int32_t n_ops, const float* con
           ok = pack_upload(m, pack_g, weights[d.weight], iw, &op.w_gemm_dev) == PH_OK &&
                pack_upload(m, pad_vec((size_t)((coutp + op.bn_g - 1) / op.bn_g) * op.bn_g, d.cout), weights[d.bias], ib, &op.b_gemm_dev) == PH_OK;
         }
+        const bool c16 = d.kind == PH_OP_CONV && d.cin1 == 0 && d.cin0 <= 16 && d.cout <= 16;
+        if (ok && c16) {
+          auto pack_16 = [&](const auto* w, auto& out) { pack_c16(w, d.cout, d.cin0, out); };
+          auto pack_16d = [&](const auto* w, auto& out) {
+            std::remove_reference_t<decltype(out)> dw;
+            dgrad_weight(w, d.cout, d.cin0, 0, d.cin0, dw);
+            pack_c16(dw.data(), d.cin0, d.cout, out);
+          };
+          ok = pack_upload(m, pack_16, weights[d.weight], iw, &op.w16_dev) == PH_OK && pack_upload(m, pack_16d, weights[d.weight], iw, &op.wd16_dev) == PH_OK;
+        }
         if (ok && d.kind == PH_OP_CONV) {  // data-gradient weights (training)
           const int cin_total = d.cin0 + d.cin1;
           const int parts[2] = {d.cin0, d.cin1}, offs[2] = {0, d.cin0};
@@ -647,6 +666,7 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
         a.clock_probe = m->clock_probe;
         a.dst_pool = d.dst2 >= 0 ? slot_ptr(d.dst2) : nullptr;
         a.wpack_dma = op.w_dma_dev;
+        a.w16 = op.w16_dev;
         a.zeros = m->zeros_dev;
         const double fill = (double)s0.h * s0.w / ((double)((s0.h + 15) / 16 * 16) * ((s0.w + 31) / 32 * 32));
         // the halo kernel pads Cout to a multiple of its N tile (64): e.g. Cout = 96 does 33 % extra MFMA work there,

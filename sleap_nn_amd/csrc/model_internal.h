@@ -27,6 +27,8 @@ struct PackedOp {
   float* wd_dma_dev[2] = {nullptr, nullptr};
   float* zero_bias_dev = nullptr;
   int bn_d[2] = {0, 0};
+  float* w16_dev = nullptr;   // 16 -> 16 channel 3x3 conv: [tap][ci][co] for conv3x3_c16_kernel
+  float* wd16_dev = nullptr;  // ... and of its data gradient
 };
 
 // One packed device buffer and the gather map that rebuilds it from the canonical parameter arena

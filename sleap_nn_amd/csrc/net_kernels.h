@@ -22,6 +22,7 @@ struct ConvArgs {
   const float* zeros = nullptr;      // >= 64 B of zeros in HBM (source of out-of-image halo pixels for LDS-DMA)
   int accumulate = 0;      // epilogue adds the existing dst value (gradient accumulation in the backward pass)
   int dma_stagger = 1;     // LDS-DMA kernel: SIMD-partner waves issue their DMA piece at different points of a step
+  const float* w16 = nullptr;  // [tap][ci 16][co 16] weights for conv3x3_c16_kernel (16 -> 16 channel layers), or nullptr
   float* dst_pool = nullptr;  // optional fused 2x2/2 max pool of the (ReLU'd) output, NHWC ceil(H/2) x ceil(W/2); nullptr = off
 };
 

@@ -823,8 +823,93 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mfma_dma_persist_kernel(ConvAr
     run(std::false_type{});
 }
 
+// ---------------------------------------------------------------------------------------
+// 16 -> 16 channel 3x3 conv (the full-resolution layer of a filters=16 encoder and its data gradient): the
+// 32/64-wide N tiles of the kernels above are half padding there.  v_mfma_f32_16x16x4_f32 computes the
+// transposed product D[co][pixel] = sum_k W[co][k] X[k][pixel]: the weights (A operand) live in 36 registers
+// for the whole launch, a lane's B operand for the four K steps of a tap is ONE ds_read_b128 (its pixel,
+// channels 4kg..4kg+3; 64 lanes read 1 KiB contiguous: no bank conflicts), and the accumulator is four
+// consecutive output channels of one pixel: bias, ReLU and a float4 NHWC store, 1 KiB contiguous per wave.
+//   Tile 8 x 32 pixels per 256-thread workgroup (halo 10 x 34 x 16 channels = 21.25 KiB LDS, four workgroups
+//   per CU cover each other's staging); wave w owns rows 2w, 2w+1 as four independent 16-pixel chains.
+//   Workgroups walk tiles with a grid stride so the weight registers are loaded once.
+// ---------------------------------------------------------------------------------------
+constexpr int C16_TH = 8, C16_TW = 32, C16_HH = C16_TH + 2, C16_HW = C16_TW + 2;
+__global__ __launch_bounds__(256, 4) void conv3x3_c16_kernel(ConvArgs a) {
+  __shared__ float sX[C16_HH * C16_HW * 16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = lane & 15, kg = lane >> 4;
+  float wr[9][4];  // A[i = co = n][k = kg] of K step ks <-> input channel 4*kg + ks
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) wr[tap][ks] = a.w16[(tap * 16 + 4 * kg + ks) * 16 + n];
+  const f32x4 bias4 = *reinterpret_cast<const f32x4*>(a.bias + 4 * kg);
+  const int tiles_x = (a.W + C16_TW - 1) / C16_TW, tiles_y = (a.H + C16_TH - 1) / C16_TH;
+  const int n_tiles = tiles_x * tiles_y * a.B;
+  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    int t = tile;
+    const int tx = t % tiles_x;
+    t /= tiles_x;
+    const int ty = t % tiles_y;
+    const int b = t / tiles_y;
+    const int x0 = tx * C16_TW, y0 = ty * C16_TH;
+    for (int i = tid; i < C16_HH * C16_HW * 4; i += 256) {
+      const int pix = i >> 2, q = i & 3;
+      const int hy = pix / C16_HW, hx = pix - hy * C16_HW;
+      const int gy = y0 + hy - 1, gx = x0 + hx - 1;
+      const bool ok = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+      const int cy = min(max(gy, 0), a.H - 1), cx = min(max(gx, 0), a.W - 1);
+      const f32x4 v = *reinterpret_cast<const f32x4*>(a.src0 + ((size_t)(b * a.H + cy) * a.W + cx) * 16 + q * 4);
+      *reinterpret_cast<f32x4*>(sX + pix * 16 + q * 4) = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    __syncthreads();
+    f32x4 acc[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) acc[g] = bias4;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int ky = tap / 3, kx = tap - ky * 3;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int py = 2 * wave + (g >> 1), px = (g & 1) * 16 + n;
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(sX + ((py + ky) * C16_HW + px + kx) * 16 + 4 * kg);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[tap][ks], xv[ks], acc[g], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int gy = y0 + 2 * wave + (g >> 1), gx = x0 + (g & 1) * 16 + n;
+      if (gy < a.H && gx < a.W) {
+        f32x4 v = acc[g];
+        if (a.relu) v = f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
+        f32x4* d = reinterpret_cast<f32x4*>(a.dst + ((size_t)(b * a.H + gy) * a.W + gx) * 16 + 4 * kg);
+        if (a.accumulate) v += *d;
+        *d = v;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+static int launch_conv3x3_c16(const ConvArgs& a, hipStream_t s) {
+  static int n_cu = 0;
+  if (!n_cu) {
+    int dev = 0;
+    PH_HIP_CHECK(hipGetDevice(&dev));
+    PH_HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+  }
+  const int tiles = ((a.W + C16_TW - 1) / C16_TW) * ((a.H + C16_TH - 1) / C16_TH) * a.B;
+  hipLaunchKernelGGL(conv3x3_c16_kernel, dim3(std::min(tiles, n_cu * 4)), dim3(256), 0, s, a);
+  PH_HIP_CHECK(hipGetLastError());
+  return PH_OK;
+}
+
 int launch_conv3x3_dma(const ConvArgs& a_in, hipStream_t s) {
   ConvArgs a = a_in;
+  static const int use_c16 = getenv("PH_CONV_C16") ? atoi(getenv("PH_CONV_C16")) : 1;  // experiment knob
+  if (use_c16 && a.w16 && a.c0p == 16 && a.coutp == 16 && !a.src1 && !a.dst_pool) return launch_conv3x3_c16(a, s);
   static const int stagger = getenv("PH_CONV_DMA_STAGGER") ? atoi(getenv("PH_CONV_DMA_STAGGER")) : 1;  // experiment knob
   a.dma_stagger = stagger;
   const int tiles = ((a.W + TW - 1) / TW) * ((a.H + D_TH - 1) / D_TH) * a.B;

@@ -229,6 +229,7 @@ int ph_model_backward(ph_model* m, const void* input_dev, int32_t in_dtype, int3
           a.c1p = 0;
           a.wpack = op.wd_dev[part];
           a.wpack_dma = op.wd_dma_dev[part];
+          a.w16 = op.wd16_dev;
           a.bias = op.zero_bias_dev;
           a.dst = G(srcs[part]);
           a.coutp = si.cp;
@@ -252,13 +253,18 @@ int ph_model_backward(ph_model* m, const void* input_dev, int32_t in_dtype, int3
         PH_REQUIRE(init[d.dst], "first conv output received no gradient");
         PH_REQUIRE(d.cin0 == in_channels, "input has %d channels, network expects %d", in_channels, d.cin0);
         const size_t npix = (size_t)batch * so.h * so.w;
-        if (d.flags & PH_FLAG_RELU) {
-          rc = launch_relu_mask(G(d.dst), A(d.dst), npix * so.cp, s);
+        if ((d.flags & PH_FLAG_RELU) && d.bias >= 0) {  // mask + bias gradient in one pass
+          rc = launch_relu_mask_bias_grad(G(d.dst), A(d.dst), npix, so.cp, d.cout, grads_flat_dev + m->weight_offset[d.bias], scratch, s);
           if (rc != PH_OK) return rc;
-        }
-        if (d.bias >= 0) {
-          rc = launch_bias_grad(G(d.dst), npix, so.cp, d.cout, grads_flat_dev + m->weight_offset[d.bias], scratch, s);
-          if (rc != PH_OK) return rc;
+        } else {
+          if (d.flags & PH_FLAG_RELU) {
+            rc = launch_relu_mask(G(d.dst), A(d.dst), npix * so.cp, s);
+            if (rc != PH_OK) return rc;
+          }
+          if (d.bias >= 0) {
+            rc = launch_bias_grad(G(d.dst), npix, so.cp, d.cout, grads_flat_dev + m->weight_offset[d.bias], scratch, s);
+            if (rc != PH_OK) return rc;
+          }
         }
         rc = launch_input_wgrad(input_dev, in_dtype, G(d.dst), batch, d.cin0, height, width, so.cp, d.cout, grads_flat_dev + m->weight_offset[d.weight], scratch, s);
         break;
