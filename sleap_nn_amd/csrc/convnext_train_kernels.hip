@@ -331,9 +331,12 @@ __global__ __launch_bounds__(256, 2) void row_wgrad_kernel(RowWgradArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // staging: thread t moves float4 #(t & 31) of rows (t >> 5) + 8 * i, i = 0..3, of both operands
+  // staging: thread t moves float4 #(t & 31) of rows (t >> 5) + 8 * i, i = 0..3, of both operands.  The next
+  // chunk travels global -> registers (fetch) while this chunk's MFMAs run and lands in the other LDS buffer
+  // afterwards (commit): the global latency is never exposed between two chunks.
   const int sq = tid & 31, sr = tid >> 5;
-  auto stage = [&](int chunk, int buf) {
+  f32x4 ry[4], ra[4];
+  auto fetch = [&](int chunk) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int row = sr + 8 * i;
@@ -361,16 +364,27 @@ __global__ __launch_bounds__(256, 2) void row_wgrad_kernel(RowWgradArgs a) {
         }
         if (ck < a.kp) va = *reinterpret_cast<const f32x4*>(a.x + pix * a.kp + ck);
       }
-      *reinterpret_cast<f32x4*>(&sY[buf][row * 128 + sq * 4]) = vy;
-      *reinterpret_cast<f32x4*>(&sA[buf][row * 128 + sq * 4]) = va;
+      ry[i] = vy;
+      ra[i] = va;
+    }
+  };
+  auto commit = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = sr + 8 * i;
+      *reinterpret_cast<f32x4*>(&sY[buf][row * 128 + sq * 4]) = ry[i];
+      *reinterpret_cast<f32x4*>(&sA[buf][row * 128 + sq * 4]) = ra[i];
     }
   };
 
-  if (c_lo < c_hi) stage(c_lo, 0);
+  if (c_lo < c_hi) {
+    fetch(c_lo);
+    commit(0);
+  }
   __syncthreads();
   for (int ch = c_lo; ch < c_hi; ++ch) {
     const int buf = (ch - c_lo) & 1;
-    if (ch + 1 < c_hi) stage(ch + 1, buf ^ 1);
+    if (ch + 1 < c_hi) fetch(ch + 1);
 #pragma unroll 4
     for (int s2 = 0; s2 < RW_ROWS / 2; ++s2) {
       const int row = 2 * s2 + lh;
@@ -384,6 +398,7 @@ __global__ __launch_bounds__(256, 2) void row_wgrad_kernel(RowWgradArgs a) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fy[i], fa[j], acc[i][j], 0, 0, 0);
     }
+    if (ch + 1 < c_hi) commit(buf ^ 1);
     __syncthreads();
   }
   // slab[slice][block][128 n][128 k];  D: row(n) = (r&3) + 8*(r>>2) + 4*lh, col(k) = lx
@@ -396,16 +411,30 @@ __global__ __launch_bounds__(256, 2) void row_wgrad_kernel(RowWgradArgs a) {
       for (int r = 0; r < 16; ++r) slab[(size_t)(wn * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 128 + wk * 64 + j * 32 + lx] = acc[i][j][r];
 }
 
-// grad[(n * k_total + k) * taps + tap] = sum_slices slab[...]
-__global__ __launch_bounds__(256) void row_wgrad_reduce_kernel(const float* __restrict__ slab, int n_slices, int n_blocks, int n_kt, int n, int k, int k_total, int k_off,
-                                                               int taps, int tap, float* __restrict__ grad) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n * k) return;
-  const int kk = i % k, nn = i / k;
+// grad[(n * k_total + k) * taps + tap] = sum_slices slab[...]; 1024 threads = 256 elements x 4 slice parts (a thread
+// walks a quarter of the slices, four loads in flight), the parts meet in LDS in a fixed order
+__global__ __launch_bounds__(1024) void row_wgrad_reduce_kernel(const float* __restrict__ slab, int n_slices, int n_blocks, int n_kt, int n, int k, int k_total, int k_off,
+                                                                int taps, int tap, float* __restrict__ grad) {
+  __shared__ float red[3 * 256];
+  const int e = threadIdx.x & 255, part = threadIdx.x >> 8;
+  const int i = blockIdx.x * 256 + e;
+  const bool ok = i < n * k;
+  const int ii = ok ? i : 0;
+  const int kk = ii % k, nn = ii / k;
   const int blk = (nn >> 7) * n_kt + (kk >> 7);
+  const float* src = slab + (size_t)blk * (128 * 128) + (size_t)(nn & 127) * 128 + (kk & 127);
+  const size_t st = (size_t)n_blocks * (128 * 128);
   float s = 0.f;
-  for (int sl = 0; sl < n_slices; ++sl) s += slab[((size_t)sl * n_blocks + blk) * (128 * 128) + (size_t)(nn & 127) * 128 + (kk & 127)];
-  grad[((size_t)nn * k_total + k_off + kk) * taps + tap] = s;
+  int sl = part;
+  for (; sl + 12 < n_slices; sl += 16) {
+    const float v0 = src[(size_t)sl * st], v1 = src[(size_t)(sl + 4) * st], v2 = src[(size_t)(sl + 8) * st], v3 = src[(size_t)(sl + 12) * st];
+    s += (v0 + v1) + (v2 + v3);
+  }
+  for (; sl < n_slices; sl += 4) s += src[(size_t)sl * st];
+  if (part) red[(part - 1) * 256 + e] = s;
+  __syncthreads();
+  if (part || !ok) return;
+  grad[((size_t)nn * k_total + k_off + kk) * taps + tap] = (s + red[e]) + (red[256 + e] + red[512 + e]);
 }
 
 static int rw_slices(int M, int blocks) {
@@ -425,7 +454,7 @@ int launch_row_wgrad_part(const RowWgradArgs& a0, int n, int k, int k_total, int
   const int n_nt = (a.np + 127) / 128, n_kt = (a.kp + 127) / 128;
   const int slices = rw_slices(a.M, n_nt * n_kt);
   hipLaunchKernelGGL(row_wgrad_kernel, dim3(n_nt * n_kt, slices), dim3(256), 0, s, a);
-  hipLaunchKernelGGL(row_wgrad_reduce_kernel, dim3((n * k + 255) / 256), dim3(256), 0, s, a.slab, slices, n_nt * n_kt, n_kt, n, k, k_total, k_off, taps, a.tap, grad);
+  hipLaunchKernelGGL(row_wgrad_reduce_kernel, dim3((n * k + 255) / 256), dim3(1024), 0, s, a.slab, slices, n_nt * n_kt, n_kt, n, k, k_total, k_off, taps, a.tap, grad);
   PH_HIP_CHECK(hipGetLastError());
   return PH_OK;
 }

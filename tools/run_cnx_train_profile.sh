@@ -1,0 +1,14 @@
+#!/bin/bash
+# ConvNeXt-tiny training-step kernel trace  (bash tools/run_cnx_train_profile.sh <tag> [B])
+TAG=${1:-r1u}
+B=${2:-32}
+cd /tmp && export TMPDIR=/tmp
+export PYTHONPATH=$GRAFT_REPO_ROOT
+O=$GRAFT_REPO_ROOT/gpurun_out/$TAG
+rm -rf $O; mkdir -p $O
+cd $GRAFT_REPO_ROOT
+rocprofv3 --output-format csv --kernel-trace --stats -d $O/trace -- python3 tools/convnext_train_bench.py $B 384 > $O/trace.log 2>&1
+cp $(find $O/trace -name "*kernel_stats.csv" | head -1) $O/train_kernel_stats.csv
+python3 tools/trace_launches.py $O/trace "" > $O/launch_classes.txt 2>&1
+find $O -name "*.db" -delete
+find $O -name "*kernel_trace.csv" -size +1M -delete
