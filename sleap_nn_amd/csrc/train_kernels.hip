@@ -442,23 +442,24 @@ int64_t bias_scratch_floats(int cp) { return (int64_t)BIAS_SLICES * cp; }
 // 3x3 conv weight gradient on MFMA.
 //   dW[tap][ci][co] = sum_pixels X[p + tap][ci] * dY[p][co]  ->  GEMM with M = ci, N = co, K = pixels.
 //   Workgroup (256 thr) owns a 32(ci) x 32(co) tile for all 9 taps over a K slice of pixel
-//   tiles (8 x 32 pixels each).  A[i = ci][k = pixel pair], B[k][j = co]: both fragments are
+//   tiles (4 x TW pixels each).  A[i = ci][k = pixel pair], B[k][j = co]: both fragments are
 //   single dwords read from LDS images [pixel][32 channels] (lanes run over the channel: no bank
 //   conflicts).  Waves split the taps {0,4,8} {1,5} {2,6} {3,7}.  Partial sums go to a slab per
 //   K slice; wgrad_reduce_kernel adds the slabs in a fixed order into the canonical OIHW gradient.
 // ---------------------------------------------------------------------------------------
-constexpr int WG_TH = 4, WG_TW = 32, WG_HW = WG_TW + 2, WG_HH = WG_TH + 2;  // wgrad16_kernel keeps 8-row tiles (W16_TH)
+constexpr int WG_TW = 32, WG_HW = WG_TW + 2;  // wgrad16_kernel: 8 x 32 pixel tiles
 constexpr int W16_TH = 8, W16_HH = W16_TH + 2;
 
-template <int TH>
+template <int TW>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
-  // Every wave accumulates all nine taps over its quarter of each TH x 32 pixel tile: nine accumulators
+  // Every wave accumulates all nine taps over its row of each 4 x TW pixel tile (TW in {32, 24, 16, 12}, picked
+  // per layer so that narrow feature maps are not mostly tile padding): nine accumulators
   // per wave, perfectly balanced (a split of the taps over four waves is 3+2+2+2); the four partial sets
   // are added through LDS once, after the K loop.  The next tile's X halo and dY travel global -> registers
   // while this tile's MFMAs run (fetch / commit below): the global latency never sits between two tiles.
-  constexpr int HH = TH + 2;
-  constexpr int NXQ = HH * WG_HW * 8, NYQ = TH * WG_TW * 8;  // float4 quads per tile image
-  constexpr int NX = (NXQ + 255) / 256, NY = NYQ / 256;
+  constexpr int TH = 4, HH = TH + 2, HW = TW + 2;
+  constexpr int NXQ = HH * HW * 8, NYQ = TH * TW * 8;  // float4 quads per tile image
+  constexpr int NX = (NXQ + 255) / 256, NY = (NYQ + 255) / 256;
   __shared__ float sX[(NXQ * 4 > 4096 ? NXQ * 4 : 4096)];
   __shared__ float sY[NYQ * 4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -466,7 +467,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
   const int n_co_t = (a.coutp + 31) / 32;
   const int ci_t = blockIdx.x / n_co_t, co_t = blockIdx.x - ci_t * n_co_t;
   const int slice = blockIdx.y, n_slices = gridDim.y;
-  const int tiles_x = (a.W + WG_TW - 1) / WG_TW, tiles_y = (a.H + TH - 1) / TH;
+  const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;
   const int n_tiles = tiles_x * tiles_y * a.B;
 
   f32x16 acc[9];
@@ -485,12 +486,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
     t /= tiles_x;
     const int ty = t % tiles_y;
     const int b = t / tiles_y;
-    const int x0 = tx * WG_TW, y0 = ty * TH;
+    const int x0 = tx * TW, y0 = ty * TH;
     okx = 0, oky = 0;
 #pragma unroll
     for (int j = 0; j < NX; ++j) {  // X halo [pix][32 ci]; outside the image / beyond the channels -> 0 at commit
-      const int pix = min((tid + 256 * j) >> 3, HH * WG_HW - 1);
-      const int hy = pix / WG_HW, hx = pix - hy * WG_HW;
+      const int pix = min((tid + 256 * j) >> 3, HH * HW - 1);
+      const int hy = pix / HW, hx = pix - hy * HW;
       const int gy = y0 + hy - 1, gx = x0 + hx - 1;
       const bool ok = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && cx_ok;
       const int cy = min(max(gy, 0), a.H - 1), cx = min(max(gx, 0), a.W - 1);
@@ -499,8 +500,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
     }
 #pragma unroll
     for (int j = 0; j < NY; ++j) {  // dY [pix][32 co]
-      const int pix = (tid + 256 * j) >> 3;
-      const int py = pix / WG_TW, px = pix - py * WG_TW;
+      const int pix = min((tid + 256 * j) >> 3, TH * TW - 1);
+      const int py = pix / TW, px = pix - py * TW;
       const int gy = y0 + py, gx = x0 + px;
       const bool ok = gy < a.H && gx < a.W && cy_ok;
       const int cy = min(gy, a.H - 1), cx = min(gx, a.W - 1);
@@ -514,7 +515,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
     for (int j = 0; j < NX; ++j)
       if (tid + 256 * j < NXQ) *reinterpret_cast<f32x4*>(sX + (tid + 256 * j) * 4) = ((okx >> j) & 1u) ? rx[j] : z;
 #pragma unroll
-    for (int j = 0; j < NY; ++j) *reinterpret_cast<f32x4*>(sY + (tid + 256 * j) * 4) = ((oky >> j) & 1u) ? ry[j] : z;
+    for (int j = 0; j < NY; ++j)
+      if (tid + 256 * j < NYQ) *reinterpret_cast<f32x4*>(sY + (tid + 256 * j) * 4) = ((oky >> j) & 1u) ? ry[j] : z;
   };
 
   if (slice < n_tiles) fetch(slice);
@@ -523,13 +525,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
     __syncthreads();
     if (tile + n_slices < n_tiles) fetch(tile + n_slices);
 #pragma unroll 2
-    for (int s2 = 0; s2 < TH * 4; ++s2) {  // this wave's TH*8 pixels (rows w*TH/4 ...), two per MFMA
-      const int py = wave * (TH / 4) + (s2 >> 4), px = 2 * (s2 & 15) + lh;
-      const float bv = sY[(py * WG_TW + px) * 32 + lx];
+    for (int s2 = 0; s2 < TW / 2; ++s2) {  // this wave's row of the tile, two pixels per MFMA
+      const int py = wave, px = 2 * s2 + lh;
+      const float bv = sY[(py * TW + px) * 32 + lx];
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
         const int ky = tap / 3, kx = tap - ky * 3;
-        const float av = sX[((py + ky) * WG_HW + px + kx) * 32 + lx];
+        const float av = sX[((py + ky) * HW + px + kx) * 32 + lx];
         acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[tap], 0, 0, 0);
       }
     }
@@ -643,18 +645,21 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restr
   }
 }
 
-// pixel-tile rows of wgrad_kernel: 4 (default; 42 KiB LDS, three workgroups per CU) or 8 via PH_WGRAD_TILE_ROWS
-static int wgrad_tile_rows() {
-  static const int v = [] {
-    const char* e = getenv("PH_WGRAD_TILE_ROWS");
-    return (e && atoi(e) == 8) ? 8 : 4;
-  }();
-  return v;
+// pixel-tile width of wgrad_kernel for a W-wide feature map: the candidate with the least padded columns (ties: wider)
+static int wgrad_tile_w(int W) {
+  const int cand[4] = {32, 24, 16, 12};
+  int best = 32, best_pad = (W + 31) / 32 * 32;
+  for (int i = 1; i < 4; ++i) {
+    const int pad = (W + cand[i] - 1) / cand[i] * cand[i];
+    if (pad < best_pad) best = cand[i], best_pad = pad;
+  }
+  return best;
 }
 
 // K slices per (ci, co) tile: enough workgroups to fill 256 CUs x 2, never more than pixel tiles
 int wgrad_slices(int B, int H, int W, int blocks) {
-  const int n_tiles = ((W + WG_TW - 1) / WG_TW) * ((H + WG_TH - 1) / WG_TH) * B;
+  const int tw = wgrad_tile_w(W);
+  const int n_tiles = ((W + tw - 1) / tw) * ((H + 3) / 4) * B;
   const int want = (1024 + blocks - 1) / blocks;
   return std::max(1, std::min(n_tiles, std::max(want, 4)));
 }
@@ -669,10 +674,13 @@ int launch_wgrad(const WgradArgs& a0, int cin_part, int cout, int cin_total, int
   const int n_slices = wgrad_slices(a.B, a.H, a.W, n_ci_t * n_co_t);
   if (a.cxp == 16 && a.coutp == 16)
     hipLaunchKernelGGL(wgrad16_kernel, dim3(1, n_slices), dim3(256), 0, s, a);
-  else if (wgrad_tile_rows() == 8)
-    hipLaunchKernelGGL(wgrad_kernel<8>, dim3(n_ci_t * n_co_t, n_slices), dim3(256), 0, s, a);
   else
-    hipLaunchKernelGGL(wgrad_kernel<4>, dim3(n_ci_t * n_co_t, n_slices), dim3(256), 0, s, a);
+    switch (wgrad_tile_w(a.W)) {
+      case 32: hipLaunchKernelGGL(wgrad_kernel<32>, dim3(n_ci_t * n_co_t, n_slices), dim3(256), 0, s, a); break;
+      case 24: hipLaunchKernelGGL(wgrad_kernel<24>, dim3(n_ci_t * n_co_t, n_slices), dim3(256), 0, s, a); break;
+      case 16: hipLaunchKernelGGL(wgrad_kernel<16>, dim3(n_ci_t * n_co_t, n_slices), dim3(256), 0, s, a); break;
+      default: hipLaunchKernelGGL(wgrad_kernel<12>, dim3(n_ci_t * n_co_t, n_slices), dim3(256), 0, s, a); break;
+    }
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(n_ci_t * n_co_t * 9), dim3(1024), 0, s, a.slab, n_slices, n_ci_t * n_co_t, n_co_t, cin_part, cout, cin_total, ci_off, grad);
   PH_HIP_CHECK(hipGetLastError());
   return PH_OK;
