@@ -773,22 +773,21 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void gemm_mfma_dma_kernel(GemmAr
         const size_t rofs = opix * a.coutp;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
+          const int col = cbase + 8 * q;
+          if (!interior && !(row < a.M && col < a.coutp)) continue;  // coutp is a multiple of 16: a quad is inside or outside as a whole
+          f32x4 z = {0.f, 0.f, 0.f, 0.f};
+          if (a.act == 3) z = *reinterpret_cast<const f32x4*>(a.aux + rofs + col);
           f32x4 v;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             float x = acc[m][n][4 * q + e] + bias4[q][e];
             if (a.act == 1) x = fmaxf(x, 0.f);
             if (a.act == 2) x = gelu_f(x);
+            if (a.act == 3) x *= gelu_grad_f(z[e]);  // data gradient straight through the GELU that produced this GEMM's input
             v[e] = x * scale4[q][e];
           }
-          const int col = cbase + 8 * q;
-          if (interior) {
-            if (a.residual) v += *reinterpret_cast<const f32x4*>(a.residual + rofs + col);
-            *reinterpret_cast<f32x4*>(a.dst + rofs + col) = v;
-          } else if (row < a.M && col < a.coutp) {  // coutp is a multiple of 16: a quad is inside or outside as a whole
-            if (a.residual) v += *reinterpret_cast<const f32x4*>(a.residual + rofs + col);
-            *reinterpret_cast<f32x4*>(a.dst + rofs + col) = v;
-          }
+          if (a.residual) v += *reinterpret_cast<const f32x4*>(a.residual + rofs + col);
+          *reinterpret_cast<f32x4*>(a.dst + rofs + col) = v;
         }
       }
     }

@@ -100,28 +100,44 @@ int launch_scale_add_bwd(const float* gy, const float* scale, float* gu, float* 
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void chan_reduce_partial_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ stats /* npix x 2 or null */,
                                                                   size_t npix, int cp, float* __restrict__ partial) {
-  __shared__ float red[256];
+  // thread = (pixel row r, channel quad c): float4 loads, four pixels per trip (all loads issued before the adds)
+  __shared__ f32x4 red[256];
   const int sl = blockIdx.x;
   const size_t per = (npix + RED_SLICES - 1) / RED_SLICES;
   const size_t lo = (size_t)sl * per, hi = std::min(npix, lo + per);
-  const int cw = min(cp, 256), rows = 256 / cw;
+  const int cq = cp >> 2;  // cp is a multiple of 16
+  const int cw = min(cq, 256), rows = 256 / cw;
   const int c0 = threadIdx.x % cw, r = threadIdx.x / cw;
-  for (int cb = 0; cb < cp; cb += cw) {
+  const f32x4* a4 = reinterpret_cast<const f32x4*>(a);
+  const f32x4* b4 = reinterpret_cast<const f32x4*>(b);
+  auto term = [&](size_t p, f32x4 av, f32x4 bv) __attribute__((always_inline)) {
+    if (stats) {
+      const float mean = stats[2 * p], rstd = stats[2 * p + 1];
+      bv = f32x4{(bv[0] - mean) * rstd, (bv[1] - mean) * rstd, (bv[2] - mean) * rstd, (bv[3] - mean) * rstd};
+    }
+    return av * bv;
+  };
+  const f32x4 one = {1.f, 1.f, 1.f, 1.f};
+  for (int cb = 0; cb < cq; cb += cw) {
     const int c = cb + c0;
-    float acc = 0.f;
-    if (r < rows && c < cp)
-      for (size_t p = lo + r; p < hi; p += rows) {
-        const float av = a[p * cp + c];
-        float bv = b ? b[p * cp + c] : 1.0f;
-        if (stats) bv = (bv - stats[2 * p]) * stats[2 * p + 1];
-        acc += av * bv;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (r < rows && c < cq) {
+      size_t p = lo + r;
+      const size_t st = (size_t)rows;
+      for (; p + 3 * st < hi; p += 4 * st) {
+        const f32x4 a0 = a4[p * cq + c], a1 = a4[(p + st) * cq + c], a2 = a4[(p + 2 * st) * cq + c], a3 = a4[(p + 3 * st) * cq + c];
+        f32x4 b0 = one, b1 = one, b2 = one, b3 = one;
+        if (b) b0 = b4[p * cq + c], b1 = b4[(p + st) * cq + c], b2 = b4[(p + 2 * st) * cq + c], b3 = b4[(p + 3 * st) * cq + c];
+        acc += (term(p, a0, b0) + term(p + st, a1, b1)) + (term(p + 2 * st, a2, b2) + term(p + 3 * st, a3, b3));
       }
+      for (; p < hi; p += st) acc += term(p, a4[p * cq + c], b ? b4[p * cq + c] : one);
+    }
     red[threadIdx.x] = acc;
     __syncthreads();
-    if (r == 0 && c < cp) {
-      float s = 0.f;
+    if (r == 0 && c < cq) {
+      f32x4 s = {0.f, 0.f, 0.f, 0.f};
       for (int k = 0; k < rows; ++k) s += red[k * cw + c0];
-      partial[(size_t)sl * cp + c] = s;
+      *reinterpret_cast<f32x4*>(partial + (size_t)sl * cp + 4 * c) = s;
     }
     __syncthreads();
   }

@@ -303,6 +303,7 @@ ph_model* ph_model_create(const ph_op_desc* ops, int32_t n_ops, const float* con
     const char* impl = getenv("PH_CONV_IMPL");
     m->use_dma = !(impl && std::string(impl) == "reg");
     if (const char* d32 = getenv("PH_CONV_DMA32")) m->dma32 = atoi(d32) != 0;  // experiment knob: LDS-DMA kernel for the 32-wide N tile too
+    if (const char* fg = getenv("PH_FUSE_GELU_BWD")) m->fuse_gelu_bwd = atoi(fg);
     if (const char* wi = getenv("PH_WGRAD_IMPL")) m->wgrad_rows = std::string(wi) == "rows" ? 2 : (std::string(wi) == "auto" ? 1 : 0);
     if (const char* th = getenv("PH_CONV_GEMM_FILL")) m->gemm_fill_threshold = atof(th);  // experiment knob: 0 disables the row-GEMM form
     std::vector<float> z(64, 0.f);

@@ -127,6 +127,7 @@ int ph_model_backward(ph_model* m, const void* input_dev, int32_t in_dtype, int3
   auto G = [&](int slot) { return reinterpret_cast<float*>(gws + bp.act.slots[slot].offset); };
   float* scratch = reinterpret_cast<float*>(gws + bp.scratch_off);
   std::vector<char> init(m->n_slots, 0);
+  std::vector<char> fused_away(m->ops.size(), 0);
   OhkmParams ok;
   ok.enabled = ohkm_enabled;
   ok.hard_to_easy_ratio = hard_to_easy_ratio;
@@ -296,6 +297,7 @@ int ph_model_backward(ph_model* m, const void* input_dev, int32_t in_dtype, int3
         break;
       }
       case PH_OP_GELU: {
+        if (fused_away[oi]) break;  // its consumer's data-gradient GEMM already wrote G(src0) through the GELU derivative
         const SlotShape& so = bp.act.slots[d.dst];
         PH_REQUIRE(init[d.dst], "GELU output slot %d received no gradient", d.dst);
         rc = launch_gelu_bwd(G(d.dst), A(d.src0), G(d.src0), init[d.src0], (size_t)batch * so.h * so.w * so.cp, s);
@@ -312,6 +314,19 @@ int ph_model_backward(ph_model* m, const void* input_dev, int32_t in_dtype, int3
         PH_REQUIRE(!patch || (si.h % 2 == 0 && si.w % 2 == 0), "2x2/stride-2 conv backward needs even input sizes");
         const int M = batch * so.h * so.w;
         const int taps = patch ? 4 : 1;
+        // Linear fed by a GELU whose output nobody else reads (CNBlock: Linear -> GELU -> Linear): the data-gradient
+        // GEMM multiplies by GELU'(pre-activation) in its epilogue and writes the GELU input's gradient directly,
+        // so the GELU output's gradient never exists in HBM
+        int gelu_op = -1;
+        if (!patch && m->fuse_gelu_bwd) {
+          int readers = 0;
+          for (size_t j = 0; j < m->ops.size(); ++j) {
+            const ph_op_desc& e = m->ops[j].d;
+            if (e.src0 == d.src0 || e.src1 == d.src0) readers += 1;
+            if ((int)j < oi && e.dst == d.src0 && e.kind == PH_OP_GELU) gelu_op = (int)j;
+          }
+          if (gelu_op >= 0 && (readers != 1 || init[m->ops[gelu_op].d.src0])) gelu_op = -1;
+        }
         if (d.flags & PH_FLAG_RELU)
           rc = launch_relu_mask_bias_grad(G(d.dst), A(d.dst), (size_t)M, so.cp, d.cout, grads_flat_dev + m->weight_offset[d.bias], scratch, s);
         else
@@ -345,9 +360,18 @@ int ph_model_backward(ph_model* m, const void* input_dev, int32_t in_dtype, int3
           g.out_tap = tap;
           g.out_H = si.h;
           g.out_W = si.w;
+          if (gelu_op >= 0) {
+            g.dst = G(m->ops[gelu_op].d.src0);
+            g.act = 3;
+            g.aux = A(m->ops[gelu_op].d.src0);
+          }
           rc = launch_gemm(g, s);
         }
         init[d.src0] = 1;
+        if (gelu_op >= 0) {
+          init[m->ops[gelu_op].d.src0] = 1;
+          fused_away[gelu_op] = 1;
+        }
         break;
       }
       case PH_OP_LAYERNORM: {
