@@ -781,6 +781,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void gemm_mfma_dma_kernel(GemmAr
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             float x = acc[m][n][4 * q + e] + bias4[q][e];
+            if (a.act != 3) z[e] = x;  // the pre-activation, for dst_pre
             if (a.act == 1) x = fmaxf(x, 0.f);
             if (a.act == 2) x = gelu_f(x);
             if (a.act == 3) x *= gelu_grad_f(z[e]);  // data gradient straight through the GELU that produced this GEMM's input
@@ -788,6 +789,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void gemm_mfma_dma_kernel(GemmAr
           }
           if (a.residual) v += *reinterpret_cast<const f32x4*>(a.residual + rofs + col);
           *reinterpret_cast<f32x4*>(a.dst + rofs + col) = v;
+          if (a.dst_pre) *reinterpret_cast<f32x4*>(a.dst_pre + rofs + col) = z;
         }
       }
     }

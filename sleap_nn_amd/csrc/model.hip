@@ -304,6 +304,7 @@ ph_model* ph_model_create(const ph_op_desc* ops, int32_t n_ops, const float* con
     m->use_dma = !(impl && std::string(impl) == "reg");
     if (const char* d32 = getenv("PH_CONV_DMA32")) m->dma32 = atoi(d32) != 0;  // experiment knob: LDS-DMA kernel for the 32-wide N tile too
     if (const char* fg = getenv("PH_FUSE_GELU_BWD")) m->fuse_gelu_bwd = atoi(fg);
+    if (const char* ff = getenv("PH_FUSE_GELU_FWD")) m->fuse_gelu_fwd = atoi(ff);
     if (const char* wi = getenv("PH_WGRAD_IMPL")) m->wgrad_rows = std::string(wi) == "rows" ? 2 : (std::string(wi) == "auto" ? 1 : 0);
     if (const char* th = getenv("PH_CONV_GEMM_FILL")) m->gemm_fill_threshold = atof(th);  // experiment knob: 0 disables the row-GEMM form
     std::vector<float> z(64, 0.f);
@@ -607,6 +608,7 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
     if (rc != PH_OK) return rc;
   }
   size_t op_index = 0;
+  bool skip_next_gelu = false;
   for (const PackedOp& op : m->ops) {
     const ph_op_desc& d = op.d;
     if (m->profiling) PH_HIP_CHECK(hipEventRecord(m->ev[op_index], s));
@@ -802,6 +804,17 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
           a.scale = op.w2_dev;
           a.residual = slot_ptr(d.src1);
         }
+        // training program (Linear and GELU as separate ops, the pre-activation is kept for the backward pass): the
+        // GEMM epilogue writes both the pre-activation and GELU(pre-activation), the GELU op after it becomes a no-op
+        if (m->fuse_gelu_fwd && a.mode == 0 && a.act == 0 && !a.residual && op_index < m->ops.size()) {
+          const ph_op_desc& nx = m->ops[op_index].d;
+          if (nx.kind == PH_OP_GELU && nx.src0 == d.dst && nx.dst != d.dst) {
+            a.act = 2;
+            a.dst_pre = a.dst;
+            a.dst = slot_ptr(nx.dst);
+            skip_next_gelu = true;
+          }
+        }
         rc = launch_gemm(a, s);
         break;
       }
@@ -812,6 +825,10 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
         break;
       }
       case PH_OP_GELU: {
+        if (skip_next_gelu) {  // already produced by the preceding Linear's epilogue
+          skip_next_gelu = false;
+          break;
+        }
         const SlotShape& s0 = plan.slots[d.src0];
         rc = launch_gelu_fwd(slot_ptr(d.src0), slot_ptr(d.dst), (size_t)batch * s0.h * s0.w * s0.cp, s);
         break;

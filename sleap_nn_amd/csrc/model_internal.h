@@ -73,6 +73,7 @@ struct ph_model {
   std::vector<ph::PackedBuffer> packed;        // every packed weight buffer, for ph_model_set_params
   bool use_dma = true;                        // PH_CONV_IMPL=reg selects the register-staged kernel
   bool dma32 = true;                          // Cout <= 48 layers on the LDS-DMA kernel (BN = 32) instead of the register-staged one
+  int fuse_gelu_fwd = 1;                      // Linear -> GELU op pair: one GEMM whose epilogue writes both tensors (PH_FUSE_GELU_FWD=0: two kernels)
   int fuse_gelu_bwd = 1;                      // Linear data gradient multiplies by GELU' in its epilogue (PH_FUSE_GELU_BWD=0: separate kernel)
   int wgrad_rows = 0;                         // 3x3 weight gradients of wide layers as nine row-wgrad GEMMs (off by default: measured slower than the 32x32-tile kernel; PH_WGRAD_IMPL=auto|rows)
   double gemm_fill_threshold = 0.8;           // 3x3 convs whose maps fill the 16x32 tiles less than this run as row GEMMs

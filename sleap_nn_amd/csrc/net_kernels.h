@@ -77,6 +77,7 @@ struct GemmArgs {
   int mode = 0;                     // 0: row = pixel (Linear); 1: 2x2/stride-2 patches; 2: 3x3 "same" conv
   int H = 0, W = 0;                 // input spatial size (modes 1, 2)
   int act = 0;                      // 0 none, 1 ReLU, 2 GELU, 3 multiply by GELU'(aux) (Linear modes only)
+  float* dst_pre = nullptr;         // optional second output (M, coutp): the value before the activation (training keeps it)
   const float* aux = nullptr;       // act 3: (M, coutp) pre-activation the GELU derivative is taken at
   unsigned long long* probe = nullptr;  // diagnostic builds (PH_GEMM_STAMP) only
   int late_split = 0;               // which waves issue their DMA pieces one step late (see gemm_mfma_dma_kernel)
