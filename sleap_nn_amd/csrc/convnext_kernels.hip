@@ -518,7 +518,8 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void gemm_mfma_dma_tile_kernel(G
   }
 }
 
-template <int MODE, int MT, int NTW, int WM, int WN, int NSTAGE, int MINW>
+// EPI = 1: the training epilogues (act 3, dst_pre) are compiled in; the inference kernels (EPI = 0) do not carry them
+template <int MODE, int MT, int NTW, int WM, int WN, int NSTAGE, int MINW, int EPI = 0>
 __global__ __launch_bounds__(WM* WN * 64, MINW) void gemm_mfma_dma_kernel(GemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int WAVES = WM * WN;
@@ -551,7 +552,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void gemm_mfma_dma_kernel(GemmAr
   // arithmetic, DMA issue and MFMAs.
   const int dr = lane & 7, dquad = (lane >> 3) ^ (wave & 1);  // p & 1 == wave & 1 (WAVES is even)
   struct Plan {
-    unsigned long long a_base[2][A_SLOTS];  // byte address of (row's pixel, channel quad dquad) in each source
+    unsigned a_pix[A_SLOTS];  // pixel index of the slot's row (the byte address is one v_mad_u64_u32 away at issue time)
     unsigned a_mask[A_SLOTS];
     unsigned long long w_lane;
     int m0, ntile;
@@ -590,8 +591,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void gemm_mfma_dma_kernel(GemmAr
           mask |= (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) ? (1u << tap) : 0u;
         }
       }
-      P.a_base[0][s] = (unsigned long long)(a.src0 + pix * a.c0p + dquad * 4);
-      P.a_base[1][s] = (unsigned long long)((a.src1 ? a.src1 : a.src0) + pix * a.c1p + dquad * 4);
+      P.a_pix[s] = (unsigned)pix;
       P.a_mask[s] = mask;
     }
   };
@@ -619,17 +619,18 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void gemm_mfma_dma_kernel(GemmAr
       const int ty = (f_tap * 11) >> 5;  // f_tap / 3 for 0..8
       toff = (ty - 1) * a.W + (f_tap - 3 * ty - 1);
     }
-    const long long soff = ((long long)toff * cp + f_coff) * 4;  // bytes, wave-uniform
+    // byte address of pixel 0's quad dquad for this (source, tap, channel slice); a row adds pix * cp * 4
+    const unsigned long long sbase = (unsigned long long)((f_src ? a.src1 : a.src0) + dquad * 4) + (unsigned long long)(((long long)toff * cp + f_coff) * 4);
+    const unsigned row_bytes = (unsigned)cp * 4u;
     // dummy fetches (padding stage, or no tile left) and quads past Cp (a slice may be half empty: Cp is a
     // multiple of 16, not 32) come from the zero page
     const unsigned tile_ok = f_next ? (unsigned)next_ok : 1u;
     const unsigned live = ((f_idx < nstages) & (f_coff + dquad * 4 < cp)) ? tile_ok : 0u;
 #pragma unroll
     for (int k = 0; k < A_SLOTS; ++k) {
-      const unsigned long long b0_ = f_next ? Pn.a_base[0][k] : Pc.a_base[0][k];
-      const unsigned long long b1_ = f_next ? Pn.a_base[1][k] : Pc.a_base[1][k];
+      const unsigned px_ = f_next ? Pn.a_pix[k] : Pc.a_pix[k];
       const unsigned mk = f_next ? Pn.a_mask[k] : Pc.a_mask[k];
-      const unsigned long long real = (f_src ? b1_ : b0_) + (unsigned long long)soff;
+      const unsigned long long real = sbase + (unsigned long long)px_ * row_bytes;
       const unsigned long long sel = 0ull - (unsigned long long)(live & (mk >> f_tap) & 1u);
       const unsigned long long g = (real & sel) | (zero_addr & ~sel);
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
@@ -774,22 +775,40 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void gemm_mfma_dma_kernel(GemmAr
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int col = cbase + 8 * q;
-          if (!interior && !(row < a.M && col < a.coutp)) continue;  // coutp is a multiple of 16: a quad is inside or outside as a whole
-          f32x4 z = {0.f, 0.f, 0.f, 0.f};
-          if (a.act == 3) z = *reinterpret_cast<const f32x4*>(a.aux + rofs + col);
-          f32x4 v;
+          if constexpr (EPI == 0) {
+            f32x4 v;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float x = acc[m][n][4 * q + e] + bias4[q][e];
-            if (a.act != 3) z[e] = x;  // the pre-activation, for dst_pre
-            if (a.act == 1) x = fmaxf(x, 0.f);
-            if (a.act == 2) x = gelu_f(x);
-            if (a.act == 3) x *= gelu_grad_f(z[e]);  // data gradient straight through the GELU that produced this GEMM's input
-            v[e] = x * scale4[q][e];
+            for (int e = 0; e < 4; ++e) {
+              float x = acc[m][n][4 * q + e] + bias4[q][e];
+              if (a.act == 1) x = fmaxf(x, 0.f);
+              if (a.act == 2) x = gelu_f(x);
+              v[e] = x * scale4[q][e];
+            }
+            if (interior) {
+              if (a.residual) v += *reinterpret_cast<const f32x4*>(a.residual + rofs + col);
+              *reinterpret_cast<f32x4*>(a.dst + rofs + col) = v;
+            } else if (row < a.M && col < a.coutp) {  // coutp is a multiple of 16: a quad is inside or outside as a whole
+              if (a.residual) v += *reinterpret_cast<const f32x4*>(a.residual + rofs + col);
+              *reinterpret_cast<f32x4*>(a.dst + rofs + col) = v;
+            }
+          } else {  // training epilogues: GELU' multiplier from aux (act 3), second output with the pre-activation (dst_pre)
+            if (!interior && !(row < a.M && col < a.coutp)) continue;
+            f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            if (a.act == 3) z = *reinterpret_cast<const f32x4*>(a.aux + rofs + col);
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float x = acc[m][n][4 * q + e] + bias4[q][e];
+              if (a.act != 3) z[e] = x;
+              if (a.act == 1) x = fmaxf(x, 0.f);
+              if (a.act == 2) x = gelu_f(x);
+              if (a.act == 3) x *= gelu_grad_f(z[e]);  // data gradient straight through the GELU that produced this GEMM's input
+              v[e] = x * scale4[q][e];
+            }
+            if (a.residual) v += *reinterpret_cast<const f32x4*>(a.residual + rofs + col);
+            *reinterpret_cast<f32x4*>(a.dst + rofs + col) = v;
+            if (a.dst_pre) *reinterpret_cast<f32x4*>(a.dst_pre + rofs + col) = z;
           }
-          if (a.residual) v += *reinterpret_cast<const f32x4*>(a.residual + rofs + col);
-          *reinterpret_cast<f32x4*>(a.dst + rofs + col) = v;
-          if (a.dst_pre) *reinterpret_cast<f32x4*>(a.dst_pre + rofs + col) = z;
         }
       }
     }
@@ -877,6 +896,10 @@ int prepare_convnext_kernels() {
   PH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mfma_dma_kernel<1, MT, NTW, WM, WN, S, W>), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                    (int)GemmCfg<MT, NTW, WM, WN, S, W>::LDS));                                                              \
   PH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mfma_dma_tile_kernel<2, MT, NTW, WM, WN, S, W>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                   (int)GemmCfg<MT, NTW, WM, WN, S, W>::LDS));                                                              \
+  PH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mfma_dma_kernel<2, MT, NTW, WM, WN, S, W>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                   (int)GemmCfg<MT, NTW, WM, WN, S, W>::LDS));                                                              \
+  PH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mfma_dma_kernel<0, MT, NTW, WM, WN, S, W, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                    (int)GemmCfg<MT, NTW, WM, WN, S, W>::LDS));
   PH_GEMM_VARIANTS(X)
 #undef X
@@ -897,8 +920,11 @@ int launch_gemm_variant(int variant, const GemmArgs& a_in, hipStream_t s) {
   GemmArgs a = a_in;
   static const int late_split = getenv("PH_GEMM_LATE_SPLIT") ? atoi(getenv("PH_GEMM_LATE_SPLIT")) : 0;  // experiment knob
   a.late_split = late_split;
+  static const int persist2 = getenv("PH_GEMM_PERSIST2") ? atoi(getenv("PH_GEMM_PERSIST2")) : 0;  // experiment knob: 1 = persistent workgroups for the 9-tap mode too (measured 3-4 % slower than one tile per workgroup)
   PH_REQUIRE(a.M > 0 && a.c0p > 0 && a.c0p % 16 == 0 && a.c1p % 16 == 0 && a.coutp % 16 == 0 && a.mode >= 0 && a.mode <= 2, "launch_gemm: bad shape");
   PH_REQUIRE(a.c1p == 0 || a.src1, "launch_gemm: second source missing");
+  PH_REQUIRE((a.act != 3 && !a.dst_pre) || a.mode == 0, "launch_gemm: the training epilogues exist for the Linear mode only");
+  PH_REQUIRE(a.act != 3 || a.aux, "launch_gemm: act 3 needs aux");
   PH_REQUIRE(a.mode != 1 || (a.H >= 2 && a.W >= 2), "launch_gemm: 2x2 patches need H, W >= 2");
   PH_REQUIRE(a.mode != 2 || a.M % (a.H * a.W) == 0, "launch_gemm: conv rows must be whole images");
   PH_REQUIRE(gemm_variant_bn(variant) == a.bn, "launch_gemm: variant %d does not match the N tile %d of the packed weights", variant, a.bn);
@@ -913,10 +939,14 @@ int launch_gemm_variant(int variant, const GemmArgs& a_in, hipStream_t s) {
   case id: {                                                                                                                   \
     using C = GemmCfg<MT, NTW, WM, WN, S, W>;                                                                                  \
     const dim3 grid((unsigned)std::min<long>((long)((a.M + C::TM - 1) / C::TM) * ((a.coutp + C::BN - 1) / C::BN), (long)n_cu)); \
-    if (a.mode == 0)                                                                                                           \
+    if (a.mode == 0 && (a.act == 3 || a.dst_pre))                                                                              \
+      hipLaunchKernelGGL((gemm_mfma_dma_kernel<0, MT, NTW, WM, WN, S, W, 1>), grid, dim3(C::THREADS), C::LDS, s, a);           \
+    else if (a.mode == 0)                                                                                                      \
       hipLaunchKernelGGL((gemm_mfma_dma_kernel<0, MT, NTW, WM, WN, S, W>), grid, dim3(C::THREADS), C::LDS, s, a);              \
     else if (a.mode == 1)                                                                                                      \
       hipLaunchKernelGGL((gemm_mfma_dma_kernel<1, MT, NTW, WM, WN, S, W>), grid, dim3(C::THREADS), C::LDS, s, a);              \
+    else if (persist2)                                                                                                         \
+      hipLaunchKernelGGL((gemm_mfma_dma_kernel<2, MT, NTW, WM, WN, S, W>), grid, dim3(C::THREADS), C::LDS, s, a);              \
     else {                                                                                                                     \
       const dim3 full((unsigned)(((a.M + C::TM - 1) / C::TM) * ((a.coutp + C::BN - 1) / C::BN)));                              \
       hipLaunchKernelGGL((gemm_mfma_dma_tile_kernel<2, MT, NTW, WM, WN, S, W>), full, dim3(C::THREADS), C::LDS, s, a);         \
