@@ -694,17 +694,29 @@ int launch_wgrad(const WgradArgs& a0, int cin_part, int cout, int cin_total, int
 constexpr int ICW_BLOCKS = 1024;
 __global__ __launch_bounds__(256) void input_wgrad_partial_kernel(const void* __restrict__ img, int dtype, const float* __restrict__ dy, int B, int cin, int H, int W,
                                                                   int coutp, int cout, float* __restrict__ partial /* ICW_BLOCKS x (cout*cin*9) */) {
-  __shared__ float sImg[3 * 10 * 34];
-  __shared__ float sDy[8 * 32 * 16];
-  const int n_out = cout * cin * 9;
+  // A tiny GEMM per pixel tile on v_mfma_f32_16x16x4_f32: D[co 16][(ci, tap) <= 32] += dY^T[co][4 pixels] * patch[4 pixels][(ci, tap)].
+  // Wave w owns pixel rows 2w, 2w+1 of the 8 x 32 tile; a lane's A operand is dY[pixel 4s + kg][co = lane & 15] (64 consecutive
+  // floats per wave), its B operand the image value under tap (lane & 15) of pixel 4s + kg.
+  __shared__ float sImg[3 * 10 * 34 + 4];
+  __shared__ __attribute__((aligned(16))) float sDy[8 * 32 * 16];
+  __shared__ float sRed[4 * 2 * 256];
+  const int n_out = cout * cin * 9, n_comb = cin * 9;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ln = lane & 15, kg = lane >> 4;
   const int tiles_x = (W + 31) / 32, tiles_y = (H + 7) / 8;
   const int n_tiles = tiles_x * tiles_y * B;
-  float acc[8];
+  int boff[2];
+  bool bok[2];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+  for (int nb = 0; nb < 2; ++nb) {
+    const int comb = nb * 16 + ln;
+    bok[nb] = comb < n_comb;
+    const int cc = bok[nb] ? comb : 0;
+    const int ci = cc / 9, tap = cc - ci * 9;
+    boff[nb] = ci * 340 + (tap / 3) * 34 + tap % 3;
+  }
   for (int cbase = 0; cbase < cout; cbase += 16) {  // 16 output channels at a time
-    const int ncb = min(16, cout - cbase);
-    for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
       int t = tile;
       const int tx = t % tiles_x;
@@ -712,7 +724,7 @@ __global__ __launch_bounds__(256) void input_wgrad_partial_kernel(const void* __
       const int ty = t % tiles_y;
       const int b = t / tiles_y;
       const int x0 = tx * 32, y0 = ty * 8;
-      for (int i = threadIdx.x; i < cin * 340; i += 256) {
+      for (int i = tid; i < cin * 340; i += 256) {
         const int c = i / 340, r = i - c * 340;
         const int hy = r / 34, hx = r - hy * 34;
         const int gy = y0 + hy - 1, gx = x0 + hx - 1;
@@ -728,37 +740,64 @@ __global__ __launch_bounds__(256) void input_wgrad_partial_kernel(const void* __
         }
         sImg[i] = v;
       }
-      for (int i = threadIdx.x; i < 256 * 16; i += 256) {
-        const int pix = i >> 4, c = i & 15;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {  // dY tile: 256 pixels x 16 channels, one float4 per thread per trip
+        const int i = tid + 256 * j;
+        const int pix = i >> 2, q = i & 3;
         const int gy = y0 + (pix >> 5), gx = x0 + (pix & 31);
-        float v = 0.f;
-        if (gy < H && gx < W && c < ncb) v = dy[(((size_t)b * H + gy) * W + gx) * coutp + cbase + c];
-        sDy[i] = v;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (gy < H && gx < W) v = *reinterpret_cast<const f32x4*>(dy + (((size_t)b * H + gy) * W + gx) * coutp + cbase + q * 4);  // coutp is a multiple of 16
+        *reinterpret_cast<f32x4*>(sDy + pix * 16 + q * 4) = v;
       }
       __syncthreads();
-      // work items: (co_local 0..15) x (ci*9 + tap) <= 16*27 = 432 -> up to 2 per thread
-      for (int k = 0, item = threadIdx.x; item < 16 * cin * 9; item += 256, ++k) {
-        const int col = item & 15, ct = item >> 4;
-        const int ci = ct / 9, tap = ct - ci * 9;
-        const int ky = tap / 3, kx = tap - ky * 3;
-        float s = 0.f;
-        for (int pix = 0; pix < 256; ++pix) s += sDy[pix * 16 + col] * sImg[ci * 340 + ((pix >> 5) + ky) * 34 + (pix & 31) + kx];
-        acc[k] += s;
+#pragma unroll 4
+      for (int s4 = 0; s4 < 16; ++s4) {
+        const int p = 4 * s4 + kg;
+        const int py = 2 * wave + (p >> 5), px = p & 31;
+        const float av = sDy[(py * 32 + px) * 16 + ln];
+        const int ib = py * 34 + px;
+        const float b0 = bok[0] ? sImg[boff[0] + ib] : 0.f;
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b0, acc[0], 0, 0, 0);
+        if (n_comb > 16) {
+          const float b1 = bok[1] ? sImg[boff[1] + ib] : 0.f;
+          acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b1, acc[1], 0, 0, 0);
+        }
       }
       __syncthreads();
     }
-    for (int k = 0, item = threadIdx.x; item < 16 * cin * 9; item += 256, ++k) {
-      const int col = item & 15, ct = item >> 4;
-      if (col < ncb) partial[(size_t)blockIdx.x * n_out + (size_t)(cbase + col) * cin * 9 + ct] = acc[k];
+    // D[i = co = 4 * kg + r][j = comb = ln]; the four waves' partial sums meet in LDS in a fixed order
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sRed[(wave * 2 + nb) * 256 + (4 * kg + r) * 16 + ln] = acc[nb][r];
+    __syncthreads();
+    for (int i = tid; i < 512; i += 256) {
+      const int nb = i >> 8, co = (i >> 4) & 15, comb = nb * 16 + (i & 15);
+      if (cbase + co < cout && comb < n_comb) {
+        const int e = (i & 255);
+        const float sum = (sRed[(0 * 2 + nb) * 256 + e] + sRed[(1 * 2 + nb) * 256 + e]) + (sRed[(2 * 2 + nb) * 256 + e] + sRed[(3 * 2 + nb) * 256 + e]);
+        partial[(size_t)blockIdx.x * n_out + (size_t)(cbase + co) * n_comb + comb] = sum;
+      }
     }
+    __syncthreads();
   }
 }
-__global__ void input_wgrad_final_kernel(const float* __restrict__ partial, int n_blocks, int n_out, float* __restrict__ gw) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_out) return;
+// 1024 threads = 256 outputs x 4 block parts (four loads in flight per thread); the parts meet in LDS in a fixed order
+__global__ __launch_bounds__(1024) void input_wgrad_final_kernel(const float* __restrict__ partial, int n_blocks, int n_out, float* __restrict__ gw) {
+  __shared__ float red[3 * 256];
+  const int e = threadIdx.x & 255, part = threadIdx.x >> 8;
+  const int i = blockIdx.x * 256 + e;
+  const bool ok = i < n_out;
+  const float* src = partial + (ok ? i : 0);
   float s = 0.f;
-  for (int k = 0; k < n_blocks; ++k) s += partial[(size_t)k * n_out + i];
-  gw[i] = s;
+  int k = part;
+  for (; k + 12 < n_blocks; k += 16)
+    s += (src[(size_t)k * n_out] + src[(size_t)(k + 4) * n_out]) + (src[(size_t)(k + 8) * n_out] + src[(size_t)(k + 12) * n_out]);
+  for (; k < n_blocks; k += 4) s += src[(size_t)k * n_out];
+  if (part) red[(part - 1) * 256 + e] = s;
+  __syncthreads();
+  if (part || !ok) return;
+  gw[i] = (s + red[e]) + (red[256 + e] + red[512 + e]);
 }
 int launch_input_wgrad(const void* img, int dtype, const float* dy, int B, int cin, int H, int W, int coutp, int cout, float* gw, float* scratch, hipStream_t s) {
   if (cin > 3) {
@@ -769,7 +808,7 @@ int launch_input_wgrad(const void* img, int dtype, const float* dy, int B, int c
   const int blocks = std::min(n_tiles, ICW_BLOCKS);
   hipLaunchKernelGGL(input_wgrad_partial_kernel, dim3(blocks), dim3(256), 0, s, img, dtype, dy, B, cin, H, W, coutp, cout, scratch);
   const int n_out = cout * cin * 9;
-  hipLaunchKernelGGL(input_wgrad_final_kernel, dim3((n_out + 255) / 256), dim3(256), 0, s, scratch, blocks, n_out, gw);
+  hipLaunchKernelGGL(input_wgrad_final_kernel, dim3((n_out + 255) / 256), dim3(1024), 0, s, scratch, blocks, n_out, gw);
   PH_HIP_CHECK(hipGetLastError());
   return PH_OK;
 }
