@@ -552,8 +552,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
 // 16-channel layers (the full-resolution first encoder block): the same computation on v_mfma_f32_16x16x4_f32,
 // a 16(ci) x 16(co) tile with four pixels per MFMA -- a 32x32 tile would be three quarters padding there.
 __global__ __launch_bounds__(256, 2) void wgrad16_kernel(WgradArgs a) {
-  __shared__ float sX[W16_HH * WG_HW * 16];
-  __shared__ float sY[W16_TH * WG_TW * 16];
+  constexpr int NXQ = W16_HH * WG_HW * 4, NYQ = W16_TH * WG_TW * 4;  // float4 quads per tile image
+  constexpr int NX = (NXQ + 255) / 256, NY = NYQ / 256;
+  __shared__ float sX[NXQ * 4];
+  __shared__ float sY[NYQ * 4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lg = lane >> 4;
   const int slice = blockIdx.y, n_slices = gridDim.y;
@@ -562,32 +564,53 @@ __global__ __launch_bounds__(256, 2) void wgrad16_kernel(WgradArgs a) {
   f32x4 acc[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int tile = slice; tile < n_tiles; tile += n_slices) {
+  // next tile: global -> registers while this tile's MFMAs run (fetch), registers -> LDS afterwards (commit)
+  f32x4 rx[NX], ry[NY];
+  unsigned okx = 0, oky = 0;
+  auto fetch = [&](int tile) __attribute__((always_inline)) {
     int t = tile;
     const int tx = t % tiles_x;
     t /= tiles_x;
     const int ty = t % tiles_y;
     const int b = t / tiles_y;
     const int x0 = tx * WG_TW, y0 = ty * W16_TH;
-    for (int i = tid; i < W16_HH * WG_HW * 4; i += 256) {
+    okx = 0, oky = 0;
+#pragma unroll
+    for (int j = 0; j < NX; ++j) {
+      const int i = min(tid + 256 * j, NXQ - 1);
       const int pix = i >> 2, q = i & 3;
       const int hy = pix / WG_HW, hx = pix - hy * WG_HW;
       const int gy = y0 + hy - 1, gx = x0 + hx - 1;
       const bool ok = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
       const int cy = min(max(gy, 0), a.H - 1), cx = min(max(gx, 0), a.W - 1);
-      const f32x4 v = *reinterpret_cast<const f32x4*>(a.x + ((size_t)(b * a.H + cy) * a.W + cx) * 16 + q * 4);
-      *reinterpret_cast<f32x4*>(sX + pix * 16 + q * 4) = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+      rx[j] = *reinterpret_cast<const f32x4*>(a.x + ((size_t)(b * a.H + cy) * a.W + cx) * 16 + q * 4);
+      okx |= ok ? (1u << j) : 0u;
     }
-    for (int i = tid; i < W16_TH * WG_TW * 4; i += 256) {
+#pragma unroll
+    for (int j = 0; j < NY; ++j) {
+      const int i = tid + 256 * j;
       const int pix = i >> 2, q = i & 3;
       const int py = pix / WG_TW, px = pix - py * WG_TW;
       const int gy = y0 + py, gx = x0 + px;
       const bool ok = gy < a.H && gx < a.W;
       const int cy = min(gy, a.H - 1), cx = min(gx, a.W - 1);
-      const f32x4 v = *reinterpret_cast<const f32x4*>(a.dy + ((size_t)(b * a.H + cy) * a.W + cx) * 16 + q * 4);
-      *reinterpret_cast<f32x4*>(sY + pix * 16 + q * 4) = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+      ry[j] = *reinterpret_cast<const f32x4*>(a.dy + ((size_t)(b * a.H + cy) * a.W + cx) * 16 + q * 4);
+      oky |= ok ? (1u << j) : 0u;
     }
+  };
+  auto commit = [&]() __attribute__((always_inline)) {
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < NX; ++j)
+      if (tid + 256 * j < NXQ) *reinterpret_cast<f32x4*>(sX + (tid + 256 * j) * 4) = ((okx >> j) & 1u) ? rx[j] : z;
+#pragma unroll
+    for (int j = 0; j < NY; ++j) *reinterpret_cast<f32x4*>(sY + (tid + 256 * j) * 4) = ((oky >> j) & 1u) ? ry[j] : z;
+  };
+  if (slice < n_tiles) fetch(slice);
+  for (int tile = slice; tile < n_tiles; tile += n_slices) {
+    commit();
     __syncthreads();
+    if (tile + n_slices < n_tiles) fetch(tile + n_slices);
 #pragma unroll 2
     for (int s2 = 0; s2 < 16; ++s2) {  // this wave's 64 pixels (rows 2w, 2w+1), four per MFMA
       const int py = 2 * wave + (s2 >> 3), px = 4 * (s2 & 7) + lg;
