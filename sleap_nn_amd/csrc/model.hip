@@ -399,6 +399,25 @@ ph_model* ph_model_create(const ph_op_desc* ops, int32_t n_ops, const float* con
         };
         ok = pack_upload(m, pack_reg, weights[d.weight], iw, &op.w_dev) == PH_OK && pack_upload(m, pack_dma, weights[d.weight], iw, &op.w_dma_dev) == PH_OK &&
              pack_upload(m, pad_vec((size_t)((coutp + op.bn - 1) / op.bn) * op.bn, d.cout), weights[d.bias], ib, &op.b_dev) == PH_OK;
+        // Winograd F(2,3) weights of an N-tile-64 conv: a linear combination of taps, so not a gather of parameters --
+        // computed on the device from the packed [tap] panels, again after every ph_model_set_params
+        auto derive_wino = [&](const float* src, int cin_a, int cin_b, int cout_, int bn, float** dst) {
+          if (bn != 64) return true;
+          const int panels = ((pad16(cout_) + bn - 1) / bn) * (pad16(cin_a) / 16 + (cin_b > 0 ? pad16(cin_b) / 16 : 0));
+          float* w = nullptr;
+          if (hipMalloc(&w, (size_t)wino_pack_floats(panels, bn) * sizeof(float)) != hipSuccess) return false;
+          m->allocs.push_back(w);
+          if (launch_wino_pack(src, w, panels, bn, nullptr) != PH_OK) return false;
+          DerivedBuffer db;
+          db.src = src;
+          db.dst = w;
+          db.panels = panels;
+          db.bn = bn;
+          m->derived.push_back(db);
+          *dst = w;
+          return true;
+        };
+        if (ok && !tr) ok = derive_wino(op.w_dev, d.cin0, d.cin1, d.cout, op.bn, &op.w_wino_dev);
         if (ok && !tr) {  // row-GEMM form for feature maps too small for the 16x32-pixel tiles
           op.bn_g = gemm_choose_bn(coutp);
           auto pack_g = [&](const auto* w, auto& out) { pack_gemm(w, d.cout, d.cin0, d.cin1, 9, op.bn_g, out); };
@@ -434,7 +453,8 @@ ph_model* ph_model_create(const ph_op_desc* ops, int32_t n_ops, const float* con
               repack_dma(tmp, op.bn_d[part], out);
             };
             ok = pack_upload(m, pack_d, weights[d.weight], iw, &op.wd_dev[part]) == PH_OK &&
-                 pack_upload(m, pack_dd, weights[d.weight], iw, &op.wd_dma_dev[part]) == PH_OK;
+                 pack_upload(m, pack_dd, weights[d.weight], iw, &op.wd_dma_dev[part]) == PH_OK &&
+                 derive_wino(op.wd_dev[part], d.cout, 0, parts[part], op.bn_d[part], &op.wd_wino_dev[part]);
           }
           if (ok) {
             std::vector<float> zb((size_t)pad16(std::max(d.cin0, d.cin1)) + max_bn, 0.f);
@@ -550,6 +570,11 @@ ph_model* ph_model_create(const ph_op_desc* ops, int32_t n_ops, const float* con
       return nullptr;
     }
     m->ops.push_back(op);
+  }
+  if (!m->derived.empty() && hipDeviceSynchronize() != hipSuccess) {  // the derived buffers were computed on the null stream
+    set_error("ph_model_create: device synchronisation failed");
+    ph_model_destroy(m);
+    return nullptr;
   }
   return m;
 }
@@ -669,6 +694,7 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
         a.clock_probe = m->clock_probe;
         a.dst_pool = d.dst2 >= 0 ? slot_ptr(d.dst2) : nullptr;
         a.wpack_dma = op.w_dma_dev;
+        a.wpack_wino = op.w_wino_dev;
         a.w16 = op.w16_dev;
         a.zeros = m->zeros_dev;
         const double fill = (double)s0.h * s0.w / ((double)((s0.h + 15) / 16 * 16) * ((s0.w + 31) / 32 * 32));

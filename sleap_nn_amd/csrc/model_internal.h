@@ -27,6 +27,8 @@ struct PackedOp {
   float* wd_dma_dev[2] = {nullptr, nullptr};
   float* zero_bias_dev = nullptr;
   int bn_d[2] = {0, 0};
+  float* w_wino_dev = nullptr;             // 3x3 conv, N tile 64: Winograd F(2,3) weights derived on the device from w_dev
+  float* wd_wino_dev[2] = {nullptr, nullptr};  // ... and from wd_dev (data gradient)
   float* w16_dev = nullptr;   // 16 -> 16 channel 3x3 conv: [tap][ci][co] for conv3x3_c16_kernel
   float* wd16_dev = nullptr;  // ... and of its data gradient
 };
@@ -37,6 +39,13 @@ struct PackedBuffer {
   float* dst = nullptr;
   int* map = nullptr;
   size_t n = 0;
+};
+
+// A buffer computed on the device from a packed buffer (not a pure gather of parameters): Winograd conv weights.
+struct DerivedBuffer {
+  const float* src = nullptr;
+  float* dst = nullptr;
+  int panels = 0, bn = 0;
 };
 
 struct SlotShape {
@@ -70,6 +79,7 @@ struct ph_model {
   std::vector<int64_t> weight_offset;          // canonical arena offset of weights[i] (ph_model_create order)
   std::vector<int64_t> weight_numel;
   int64_t n_params = 0;
+  std::vector<ph::DerivedBuffer> derived;      // refreshed after the gathers of ph_model_set_params
   std::vector<ph::PackedBuffer> packed;        // every packed weight buffer, for ph_model_set_params
   bool use_dma = true;                        // PH_CONV_IMPL=reg selects the register-staged kernel
   bool dma32 = true;                          // Cout <= 48 layers on the LDS-DMA kernel (BN = 32) instead of the register-staged one

@@ -22,6 +22,7 @@ struct ConvArgs {
   const float* zeros = nullptr;      // >= 64 B of zeros in HBM (source of out-of-image halo pixels for LDS-DMA)
   int accumulate = 0;      // epilogue adds the existing dst value (gradient accumulation in the backward pass)
   int dma_stagger = 1;     // LDS-DMA kernel: SIMD-partner waves issue their DMA piece at different points of a step
+  const float* wpack_wino = nullptr;  // Winograd F(2,3)-along-x weights in LDS order (conv3x3_wino_persist_kernel), or nullptr
   const float* w16 = nullptr;  // [tap][ci 16][co 16] weights for conv3x3_c16_kernel (16 -> 16 channel layers), or nullptr
   float* dst_pool = nullptr;  // optional fused 2x2/2 max pool of the (ReLU'd) output, NHWC ceil(H/2) x ceil(W/2); nullptr = off
 };
@@ -96,6 +97,9 @@ int launch_stem(const StemArgs& a, hipStream_t s);
 int prepare_kernels();
 int conv_lds_bytes(int bn);
 int launch_conv3x3(const ConvArgs& a, hipStream_t s);
+// wpack [panel][tap 9][bn][16] -> Winograd weights [panel][step 24][n tile][lh][lx][4] (see conv3x3_wino_persist_kernel)
+int launch_wino_pack(const float* wpack, float* wino, int panels, int bn, hipStream_t s);
+int64_t wino_pack_floats(int panels, int bn);
 int launch_conv3x3_dma(const ConvArgs& a, hipStream_t s);
 int launch_input_conv(const InputConvArgs& a, hipStream_t s);
 int launch_pool(const float* src, float* dst, int B, int H, int W, int cp, hipStream_t s);

@@ -824,6 +824,327 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mfma_dma_persist_kernel(ConvAr
 }
 
 // ---------------------------------------------------------------------------------------
+// K1w: the persistent LDS-DMA kernel with Winograd F(2,3) along x.  Two neighbouring outputs of a row,
+//   y0 = d0 g0 + d1 g1 + d2 g2,  y1 = d1 g0 + d2 g1 + d3 g2     (d = four input pixels, g = the row's three taps)
+// are  y0 = m0 + m1 + m2,  y1 = m1 - m2 - m3  with
+//   m0 = (d0 - d2) g0,  m1 = (d1 + d2)(g0 + g1 + g2)/2,  m2 = (d2 - d1)(g0 - g1 + g2)/2,  m3 = (d1 - d3) g2:
+// four multiplications instead of six -> 12 instead of 18 MFMA K-steps per (ky, channel): 1.5x less matrix work.
+//   * The GEMM's M index is an output PAIR: a wave's two rows x 32 pixels are ONE 32-row M tile (row = lane >> 4 & 1,
+//     pair t = lane & 15) with four accumulator sets (m0..m3); the output transform is register arithmetic in the epilogue.
+//   * The input transform happens on the fly: the raw halo tile is staged by LDS-DMA exactly as in K1p; per (ky, 8-channel
+//     group) a lane reads its four pixels d0..d3 (ds_read_b128 each) and forms the four A fragments with v_sub / v_add.
+//     LDS read bandwidth has ~8x headroom in K1p, the 2-way bank conflict of the stride-2 pixel reads is affordable.
+//   * The weights are pre-transformed (wino_pack_kernel) and stored in step order: step q = (ky, g, xi) reads pieces
+//     q * NT + n, each 32 rows x 2 quads, lane offset lh * 128 + lx * 4 floats (1 KiB contiguous per wave: conflict-free).
+//   * LDS: 12 weight panels per chunk are 48 KiB, twice that plus two 39-KiB halo buffers do not fit 160 KiB.  The weights
+//     live in THREE half-chunk slots (24 KiB each): a chunk reads (h, h+1), the next chunk's first half is fetched into h+2
+//     during steps 0..7, and after a mid-chunk barrier (every wave is done with h) its second half goes into h.  150 KiB.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void wino_pack_kernel(const float* __restrict__ src /* [panel][tap 9][bn][16] */, float* __restrict__ dst, int panels, int bn) {
+  const int nt = bn / 32;
+  const int per_panel = 24 * nt * 256;
+  const size_t total = (size_t)panels * per_panel;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int panel = (int)(i / per_panel);
+    int r = (int)(i - (size_t)panel * per_panel);
+    const int e = r & 3, lx = (r >> 2) & 31, lh = (r >> 7) & 1;
+    r >>= 8;  // piece index q * nt + n
+    const int n = r % nt, q = r / nt;
+    const int ky = q >> 3, g = (q >> 2) & 1, xi = q & 3;
+    const int row = n * 32 + lx, kc = (2 * g + lh) * 4 + e;
+    const float* w = src + (((size_t)panel * 9 + ky * 3) * bn + row) * 16 + kc;
+    const float g0 = w[0], g1 = w[(size_t)bn * 16], g2 = w[(size_t)2 * bn * 16];
+    float v;
+    if (xi == 0)
+      v = g0;
+    else if (xi == 1)
+      v = 0.5f * ((g0 + g2) + g1);
+    else if (xi == 2)
+      v = 0.5f * ((g0 + g2) - g1);
+    else
+      v = g2;
+    dst[i] = v;
+  }
+}
+int64_t wino_pack_floats(int panels, int bn) { return (int64_t)panels * 24 * (bn / 32) * 256; }
+int launch_wino_pack(const float* wpack, float* wino, int panels, int bn, hipStream_t s) {
+  const int64_t n = wino_pack_floats(panels, bn);
+  hipLaunchKernelGGL(wino_pack_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 4096)), dim3(256), 0, s, wpack, wino, panels, bn);
+  PH_HIP_CHECK(hipGetLastError());
+  return PH_OK;
+}
+
+template <int BN>
+__global__ __launch_bounds__(512, 2) void conv3x3_wino_persist_kernel(ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int NT = BN / 32;
+  constexpr int BH_PIECES = 12 * NT;  // weight pieces of half a chunk (12 steps)
+  constexpr int A_SLOTS = (D_A_PIECES + 7) / 8;
+  constexpr int BH_SLOTS = (BH_PIECES + 7) / 8;
+  constexpr int A_FLOATS = D_A_PIECES * 256, BH_FLOATS = BH_PIECES * 256;
+  static_assert(A_SLOTS + BH_SLOTS <= 12 && BH_SLOTS <= 12, "one DMA piece per step");
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tiles_x = (a.W + TW - 1) / TW;
+  const int tiles_y = (a.H + D_TH - 1) / D_TH;
+  const int tiles = tiles_x * tiles_y * a.B;
+  const int ntc = (a.coutp + BN - 1) / BN;
+  const int total = tiles * ntc;
+  const int chunks0 = a.c0p / KC;
+  const int chunks1 = a.c1p / KC;
+  const int nchunks = chunks0 + chunks1;
+  const int dq = lane >> 4, dr = lane & 15;
+  const int lx = lane & 31, lh = lane >> 5;
+
+  struct Plan {
+    int a_pix[A_SLOTS];
+    unsigned a_ok;
+    int b, x0, y0, ntile;
+  };
+  auto setup = [&](int vid, Plan& P) {
+    int t, ntile;
+    if ((tiles & 7) == 0) {
+      const int xcd = vid & 7, j = vid >> 3;
+      ntile = j % ntc;
+      t = (j / ntc) * 8 + xcd;
+    } else {
+      ntile = vid % ntc;
+      t = vid / ntc;
+    }
+    const int tx = t % tiles_x;
+    t /= tiles_x;
+    const int ty = t % tiles_y;
+    P.b = t / tiles_y;
+    P.x0 = tx * TW;
+    P.y0 = ty * D_TH;
+    P.ntile = ntile;
+    P.a_ok = 0;
+#pragma unroll
+    for (int s = 0; s < A_SLOTS; ++s) {
+      const int p = min(wave + 8 * s, D_A_PIECES - 1);
+      const int pix = p * 16 + dr;
+      const int hy = pix / HALO_W, hx = pix - hy * HALO_W;
+      const int gy = P.y0 + hy - 1, gx = P.x0 + hx - 1;
+      const bool in = (pix < D_NPIX) && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+      P.a_ok |= (in ? 1u : 0u) << s;
+      const int cy = min(max(gy, 0), a.H - 1), cx = min(max(gx, 0), a.W - 1);
+      P.a_pix[s] = (P.b * a.H + cy) * a.W + cx;
+    }
+  };
+
+  int f_pix[A_SLOTS];
+  unsigned f_ok = 0;
+  const float* p_src = a.src0;
+  const float* p_w = a.wpack_wino;
+  int p_cp = a.c0p, p_coff = 0;
+  auto select_fetch = [&](const Plan& P, int ch) {
+#pragma unroll
+    for (int s = 0; s < A_SLOTS; ++s) f_pix[s] = P.a_pix[s];
+    f_ok = P.a_ok;
+    if (ch < chunks0) {
+      p_src = a.src0;
+      p_cp = a.c0p;
+      p_coff = ch * KC;
+    } else {
+      p_src = a.src1;
+      p_cp = a.c1p;
+      p_coff = (ch - chunks0) * KC;
+    }
+    p_w = a.wpack_wino + ((size_t)P.ntile * nchunks + ch) * (2 * BH_FLOATS);
+  };
+  auto dma_a = [&](int s, float* abuf) {
+    const int p = min(wave + 8 * s, D_A_PIECES - 1);
+    const float* real = p_src + (size_t)f_pix[s] * p_cp + p_coff + dq * 4;
+    const float* zero = a.zeros + dq * 4;
+    const float* g = ((f_ok >> s) & 1u) ? real : zero;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)(abuf + p * 256), 16, 0, 0);
+  };
+  auto dma_b = [&](int s, int half, float* bhalf) {
+    const int pb = min(wave + 8 * s, BH_PIECES - 1);
+    const float* g = p_w + half * BH_FLOATS + pb * 256 + lane * 4;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)(bhalf + pb * 256), 16, 0, 0);
+  };
+
+  // A-side fragment offsets: lane (lx, lh) is output pair t = lx & 15 of the wave's row rr = lx >> 4; it needs halo pixels
+  // (2w + rr + ky, 2t + c), c = 0..3, quad lh (+ 2g)
+  int offD[3][4];
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int pix = (2 * wave + (lx >> 4) + ky) * HALO_W + 2 * (lx & 15) + c;
+      offD[ky][c] = (pix >> 4) * 256 + lh * 64 + (pix & 15) * 4;
+    }
+  const int offB = lh * 128 + lx * 4;
+  float* const abuf = lds;
+  float* const bbuf = lds + 2 * A_FLOATS;
+
+  auto run = [&](auto late) {
+    constexpr bool LATE = decltype(late)::value;
+    Plan P, Pn;
+    int vid = blockIdx.x;
+    setup(vid, P);
+    select_fetch(P, 0);
+#pragma unroll
+    for (int s = 0; s < A_SLOTS; ++s) dma_a(s, abuf);
+#pragma unroll
+    for (int s = 0; s < BH_SLOTS; ++s) dma_b(s, 0, bbuf);
+#pragma unroll
+    for (int s = 0; s < BH_SLOTS; ++s) dma_b(s, 1, bbuf + BH_FLOATS);
+    __syncthreads();
+    int apar = 0;  // A buffer of the running chunk
+    int hb = 0;    // weight half-slot of the running chunk's first half; the second half sits in (hb + 1) % 3
+    while (true) {
+      const int nvid = vid + gridDim.x;
+      const bool has_next = nvid < total;  // workgroup-uniform
+      if (has_next) setup(nvid, Pn);
+      f32x16 acc[4][NT];
+#pragma unroll
+      for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[x][n][r] = 0.f;
+      for (int ch = 0; ch < nchunks; ++ch) {
+        const float* acur = abuf + apar * A_FLOATS;
+        float* anxt = abuf + (apar ^ 1) * A_FLOATS;
+        const int h1 = hb == 2 ? 0 : hb + 1, h2 = h1 == 2 ? 0 : h1 + 1;
+        const float* b_first = bbuf + hb * BH_FLOATS;
+        const float* b_second = bbuf + h1 * BH_FLOATS;
+        float* bn_first = bbuf + h2 * BH_FLOATS;   // next chunk, first half: free since the previous chunk ended
+        float* bn_second = bbuf + hb * BH_FLOATS;  // next chunk, second half: free after this chunk's mid barrier
+        if (ch + 1 < nchunks)
+          select_fetch(P, ch + 1);
+        else if (has_next)
+          select_fetch(Pn, 0);  // the next tile's first chunk rides under this tile's last one
+        else
+          select_fetch(P, ch);  // nothing left: refetch (harmless)
+        f32x4 dd[2][4], bf[2][NT], af[2];
+        auto load_d = [&](int kyg, int db) {  // the four pixels of group (ky, g)
+          const int ky = kyg >> 1, g = kyg & 1;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) dd[db][c] = *reinterpret_cast<const f32x4*>(acur + offD[ky][c] + g * 128);
+        };
+        auto load_b = [&](int q, int fb) {
+          const float* base = (q < 12 ? b_first : b_second) + (q % 12) * NT * 256 + offB;
+#pragma unroll
+          for (int n = 0; n < NT; ++n) bf[fb][n] = *reinterpret_cast<const f32x4*>(base + n * 256);
+        };
+        auto make_a = [&](int q, int fa) {
+          const int db = (q >> 2) & 1, xi = q & 3;
+          if (xi == 0)
+            af[fa] = dd[db][0] - dd[db][2];
+          else if (xi == 1)
+            af[fa] = dd[db][1] + dd[db][2];
+          else if (xi == 2)
+            af[fa] = dd[db][2] - dd[db][1];
+          else
+            af[fa] = dd[db][1] - dd[db][3];
+        };
+        load_d(0, 0);
+        load_b(0, 0);
+        make_a(0, 0);
+#pragma unroll
+        for (int q = 0; q < 24; ++q) {
+          const int fcur = q & 1;
+          if (q + 1 < 24) load_b(q + 1, fcur ^ 1);
+          if ((q & 3) == 1 && (q >> 2) + 1 < 6) load_d((q >> 2) + 1, ((q >> 2) + 1) & 1);
+          // one DMA piece per step: the next chunk's halo and first weight half in steps 0.., its second weight half after the mid barrier
+          if (q < A_SLOTS)
+            dma_a(q, anxt);
+          else if (q < A_SLOTS + BH_SLOTS)
+            dma_b(q - A_SLOTS, 0, bn_first);
+          else if (q >= 12 && q < 12 + BH_SLOTS)
+            dma_b(q - 12, 1, bn_second);
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[q & 3][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[fcur][j], bf[fcur][n][j], acc[q & 3][n], 0, 0, 0);
+          if (q + 1 < 24) make_a(q + 1, fcur ^ 1);
+          const bool has_dma = q < A_SLOTS + BH_SLOTS || (q >= 12 && q < 12 + BH_SLOTS);
+          if ((q & 3) == 1 && (q >> 2) + 1 < 6)
+            __builtin_amdgcn_sched_group_barrier(0x100, NT + 4, 0);
+          else
+            __builtin_amdgcn_sched_group_barrier(0x100, NT, 0);
+          if (has_dma) {
+            __builtin_amdgcn_sched_group_barrier(0x008, LATE ? 3 * NT : NT, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, LATE ? NT : 3 * NT, 0);
+          } else {
+            __builtin_amdgcn_sched_group_barrier(0x008, 4 * NT, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          if (q == 11) __builtin_amdgcn_s_barrier();  // every wave is done reading the first weight half: its slot may be refilled
+        }
+        __syncthreads();
+        apar ^= 1;
+        hb = hb == 0 ? 2 : hb - 1;  // (hb + 2) % 3: the slot the next chunk's first half was fetched into
+      }
+      // ---- epilogue of this tile: output transform, bias, ReLU, stores.  D row (r & 3) + 8 (r >> 2) + 4 lh = pair index:
+      // r < 8 is the wave's first row, r >= 8 its second; the pair's outputs are pixels 2t, 2t + 1.
+      const int b = P.b, x0 = P.x0, y0 = P.y0, ntile = P.ntile;
+      const bool interior = (x0 + TW <= a.W) && (y0 + D_TH <= a.H) && ((ntile + 1) * BN <= a.coutp);
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const int co = ntile * BN + n * 32 + lx;
+        const float bias = a.bias[co];
+        f32x16 ya, yb;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float m1 = acc[1][n][r], m2 = acc[2][n][r];
+          float va = (acc[0][n][r] + m1) + m2 + bias;
+          float vb = (m1 - m2) - acc[3][n][r] + bias;
+          ya[r] = a.relu ? fmaxf(va, 0.f) : va;
+          yb[r] = a.relu ? fmaxf(vb, 0.f) : vb;
+        }
+        if (a.dst_pool) {  // fused 2x2/2 max pool ("same" padding: zeros beyond the image)
+          const int Hp = (a.H + 1) >> 1, Wp = (a.W + 1) >> 1;
+          const int yt = y0 + 2 * wave, py = yt >> 1;
+          if (py < Hp && co < a.coutp) {
+            float* prow = a.dst_pool + ((size_t)(b * Hp + py) * Wp) * a.coutp + co;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+              const int t = (r & 3) + 8 * (r >> 2) + 4 * lh;
+              const int x = x0 + 2 * t, px = x >> 1;
+              float v00 = ya[r], v01 = yb[r], v10 = ya[r + 8], v11 = yb[r + 8];
+              if (!interior) {
+                const bool xa = x < a.W, xb = x + 1 < a.W, yya = yt < a.H, yyb = yt + 1 < a.H;
+                v00 = (xa && yya) ? v00 : 0.f;
+                v01 = (xb && yya) ? v01 : 0.f;
+                v10 = (xa && yyb) ? v10 : 0.f;
+                v11 = (xb && yyb) ? v11 : 0.f;
+              }
+              if (px < Wp) prow[(size_t)px * a.coutp] = fmaxf(fmaxf(v00, v01), fmaxf(v10, v11));
+            }
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int y = y0 + 2 * wave + (r >> 3);
+          const int t = (r & 3) + 8 * ((r >> 2) & 1) + 4 * lh;
+          const int x = x0 + 2 * t;
+          if (interior || (y < a.H && co < a.coutp)) {
+            float* dp = a.dst + ((size_t)(b * a.H + y) * a.W + x) * a.coutp + co;
+            if (interior || x < a.W) dp[0] = a.accumulate ? dp[0] + ya[r] : ya[r];
+            if (interior || x + 1 < a.W) dp[a.coutp] = a.accumulate ? dp[a.coutp] + yb[r] : yb[r];
+          }
+        }
+      }
+      if (!has_next) break;
+      vid = nvid;
+      P = Pn;
+    }
+  };
+  if (a.dma_stagger && wave >= 4)
+    run(std::true_type{});
+  else
+    run(std::false_type{});
+}
+
+// ---------------------------------------------------------------------------------------
 // 16 -> 16 channel 3x3 conv (the full-resolution layer of a filters=16 encoder and its data gradient): the
 // 32/64-wide N tiles of the kernels above are half padding there.  v_mfma_f32_16x16x4_f32 computes the
 // transposed product D[co][pixel] = sum_k W[co][k] X[k][pixel]: the weights (A operand) live in 36 registers
@@ -914,12 +1235,20 @@ int launch_conv3x3_dma(const ConvArgs& a_in, hipStream_t s) {
   a.dma_stagger = stagger;
   const int tiles = ((a.W + TW - 1) / TW) * ((a.H + D_TH - 1) / D_TH) * a.B;
   static const int persist = getenv("PH_CONV_PERSIST") ? atoi(getenv("PH_CONV_PERSIST")) : 1;  // experiment knob: 0 = one tile per workgroup
+  static const int use_wino = getenv("PH_CONV_WINO") ? atoi(getenv("PH_CONV_WINO")) : 1;  // experiment knob: 0 = direct 9-tap kernel
   if (a.bn == 64 && persist) {
     static int n_cu = 0;
     if (!n_cu) {
       int dev = 0;
       PH_HIP_CHECK(hipGetDevice(&dev));
       PH_HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+    }
+    if (use_wino && a.wpack_wino) {
+      const size_t lds_w = (size_t)(2 * D_A_PIECES + 3 * 12 * (64 / 32)) * 1024;
+      const int total_w = tiles * ((a.coutp + 63) / 64);
+      hipLaunchKernelGGL(conv3x3_wino_persist_kernel<64>, dim3(std::min(total_w, n_cu)), dim3(512), lds_w, s, a);
+      PH_HIP_CHECK(hipGetLastError());
+      return PH_OK;
     }
     const size_t lds = (size_t)2 * (D_A_PIECES + 9 * 64 / 16) * 1024;
     const int total = tiles * ((a.coutp + 63) / 64);
@@ -1441,6 +1770,8 @@ int prepare_kernels() {
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_mfma_dma_persist_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e == hipSuccess)
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_mfma_dma_persist_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e == hipSuccess)
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wino_persist_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e != hipSuccess) {
     set_error("hipFuncSetAttribute(conv dma) failed: %s", hipGetErrorString(e));
     return PH_E_HIP;

@@ -92,6 +92,10 @@ int ph_model_set_params(ph_model* m, const float* params_flat_dev, void* stream)
     int rc = launch_gather(params_flat_dev, pb.map, pb.n, pb.dst, static_cast<hipStream_t>(stream));
     if (rc != PH_OK) return rc;
   }
+  for (const DerivedBuffer& db : m->derived) {
+    int rc = launch_wino_pack(db.src, db.dst, db.panels, db.bn, static_cast<hipStream_t>(stream));
+    if (rc != PH_OK) return rc;
+  }
   return PH_OK;
 }
 
@@ -230,6 +234,7 @@ int ph_model_backward(ph_model* m, const void* input_dev, int32_t in_dtype, int3
           a.c1p = 0;
           a.wpack = op.wd_dev[part];
           a.wpack_dma = op.wd_dma_dev[part];
+          a.wpack_wino = op.wd_wino_dev[part];
           a.w16 = op.wd16_dev;
           a.bias = op.zero_bias_dev;
           a.dst = G(srcs[part]);
