@@ -874,6 +874,9 @@ int launch_wino_pack(const float* wpack, float* wino, int panels, int bn, hipStr
   return PH_OK;
 }
 
+#ifndef PH_WINO_EXP
+#define PH_WINO_EXP 0  // timing experiments only (results are wrong): 1 no mid barrier, 2 no DMA in the K loop, 4 no input transform
+#endif
 template <int BN>
 __global__ __launch_bounds__(512, 2) void conv3x3_wino_persist_kernel(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -1034,6 +1037,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_persist_kernel(ConvArgs a
         };
         auto make_a = [&](int q, int fa) {
           const int db = (q >> 2) & 1, xi = q & 3;
+#if PH_WINO_EXP & 4
+          af[fa] = dd[db][xi];
+          return;
+#endif
           if (xi == 0)
             af[fa] = dd[db][0] - dd[db][2];
           else if (xi == 1)
@@ -1052,32 +1059,40 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_persist_kernel(ConvArgs a
           if (q + 1 < 24) load_b(q + 1, fcur ^ 1);
           if ((q & 3) == 1 && (q >> 2) + 1 < 6) load_d((q >> 2) + 1, ((q >> 2) + 1) & 1);
           // one DMA piece per step: the next chunk's halo and first weight half in steps 0.., its second weight half after the mid barrier
+#if !(PH_WINO_EXP & 2)
           if (q < A_SLOTS)
             dma_a(q, anxt);
           else if (q < A_SLOTS + BH_SLOTS)
             dma_b(q - A_SLOTS, 0, bn_first);
           else if (q >= 12 && q < 12 + BH_SLOTS)
             dma_b(q - 12, 1, bn_second);
+#endif
 #pragma unroll
           for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int n = 0; n < NT; ++n) acc[q & 3][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[fcur][j], bf[fcur][n][j], acc[q & 3][n], 0, 0, 0);
           if (q + 1 < 24) make_a(q + 1, fcur ^ 1);
           const bool has_dma = q < A_SLOTS + BH_SLOTS || (q >= 12 && q < 12 + BH_SLOTS);
+          // Pinned order: the step's first MFMAs, THEN the LDS reads of the next step.  The compiler's wait before the first MFMA is
+          // always lgkmcnt(0) here (an LDS-DMA instruction marks the counter out-of-order for its scoreboard), so reads issued
+          // before that MFMA would be drained on the spot -- their latency exposed in every step.
+          __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);
           if ((q & 3) == 1 && (q >> 2) + 1 < 6)
             __builtin_amdgcn_sched_group_barrier(0x100, NT + 4, 0);
           else
             __builtin_amdgcn_sched_group_barrier(0x100, NT, 0);
           if (has_dma) {
-            __builtin_amdgcn_sched_group_barrier(0x008, LATE ? 3 * NT : NT, 0);
+            if (LATE) __builtin_amdgcn_sched_group_barrier(0x008, 2 * NT, 0);
             __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
             __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, LATE ? NT : 3 * NT, 0);
           } else {
-            __builtin_amdgcn_sched_group_barrier(0x008, 4 * NT, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 3 * NT, 0);
           }
           __builtin_amdgcn_sched_barrier(0);
+#if !(PH_WINO_EXP & 1)
           if (q == 11) __builtin_amdgcn_s_barrier();  // every wave is done reading the first weight half: its slot may be refilled
+#endif
         }
         __syncthreads();
         apar ^= 1;
