@@ -402,7 +402,7 @@ ph_model* ph_model_create(const ph_op_desc* ops, int32_t n_ops, const float* con
         // Winograd F(2,3) weights of an N-tile-64 conv: a linear combination of taps, so not a gather of parameters --
         // computed on the device from the packed [tap] panels, again after every ph_model_set_params
         auto derive_wino = [&](const float* src, int cin_a, int cin_b, int cout_, int bn, float** dst) {
-          if (bn != 64) return true;
+          if (bn != 64 && bn != 32) return true;
           const int panels = ((pad16(cout_) + bn - 1) / bn) * (pad16(cin_a) / 16 + (cin_b > 0 ? pad16(cin_b) / 16 : 0));
           float* w = nullptr;
           if (hipMalloc(&w, (size_t)wino_pack_floats(panels, bn) * sizeof(float)) != hipSuccess) return false;

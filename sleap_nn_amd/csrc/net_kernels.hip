@@ -1275,6 +1275,14 @@ int launch_conv3x3_dma(const ConvArgs& a_in, hipStream_t s) {
       PH_HIP_CHECK(hipGetDevice(&dev));
       PH_HIP_CHECK(hipDeviceGetAttribute(&n_cu32, hipDeviceAttributeMultiprocessorCount, dev));
     }
+    static const int use_wino32 = getenv("PH_CONV_WINO32") ? atoi(getenv("PH_CONV_WINO32")) : 1;  // experiment knob
+    if (use_wino && use_wino32 && a.wpack_wino) {
+      const size_t lds_w = (size_t)(2 * D_A_PIECES + 3 * 12 * (32 / 32)) * 1024;
+      const int total_w = tiles * ((a.coutp + 31) / 32);
+      hipLaunchKernelGGL(conv3x3_wino_persist_kernel<32>, dim3(std::min(total_w, n_cu32)), dim3(512), lds_w, s, a);
+      PH_HIP_CHECK(hipGetLastError());
+      return PH_OK;
+    }
     const size_t lds = (size_t)2 * (D_A_PIECES + 9 * 32 / 16) * 1024;
     const int total = tiles * ((a.coutp + 31) / 32);
     hipLaunchKernelGGL(conv3x3_mfma_dma_persist_kernel<32>, dim3(std::min(total, n_cu32)), dim3(512), lds, s, a);
@@ -1787,6 +1795,8 @@ int prepare_kernels() {
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_mfma_dma_persist_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e == hipSuccess)
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wino_persist_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e == hipSuccess)
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wino_persist_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e != hipSuccess) {
     set_error("hipFuncSetAttribute(conv dma) failed: %s", hipGetErrorString(e));
     return PH_E_HIP;
