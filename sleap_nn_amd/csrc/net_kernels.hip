@@ -875,7 +875,7 @@ int launch_wino_pack(const float* wpack, float* wino, int panels, int bn, hipStr
 }
 
 #ifndef PH_WINO_EXP
-#define PH_WINO_EXP 0  // timing experiments only (results are wrong): 1 no mid barrier, 2 no DMA in the K loop, 4 no input transform
+#define PH_WINO_EXP 0  // timing experiments only (results are wrong): 1 no mid barrier, 2 no DMA in the K loop, 4 no input transform, 8 no epilogue, 16 no epilogue stores
 #endif
 template <int BN>
 __global__ __launch_bounds__(512, 2) void conv3x3_wino_persist_kernel(ConvArgs a) {
@@ -1102,6 +1102,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_persist_kernel(ConvArgs a
       // r < 8 is the wave's first row, r >= 8 its second; the pair's outputs are pixels 2t, 2t + 1.
       const int b = P.b, x0 = P.x0, y0 = P.y0, ntile = P.ntile;
       const bool interior = (x0 + TW <= a.W) && (y0 + D_TH <= a.H) && ((ntile + 1) * BN <= a.coutp);
+#if PH_WINO_EXP & 8
+      if (acc[0][0][0] != 12345.678f) {  // timing experiment: no epilogue (the accumulators stay live)
+        if (!has_next) break;
+        vid = nvid;
+        P = Pn;
+        continue;
+      }
+#endif
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
         const int co = ntile * BN + n * 32 + lx;
@@ -1132,7 +1140,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_persist_kernel(ConvArgs a
                 v10 = (xa && yyb) ? v10 : 0.f;
                 v11 = (xb && yyb) ? v11 : 0.f;
               }
-              if (px < Wp) prow[(size_t)px * a.coutp] = fmaxf(fmaxf(v00, v01), fmaxf(v10, v11));
+#if PH_WINO_EXP & 16
+              if (v00 == 12345.678f)
+#else
+              if (px < Wp)
+#endif
+                prow[(size_t)px * a.coutp] = fmaxf(fmaxf(v00, v01), fmaxf(v10, v11));
             }
           }
         }
@@ -1141,7 +1154,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_persist_kernel(ConvArgs a
           const int y = y0 + 2 * wave + (r >> 3);
           const int t = (r & 3) + 8 * ((r >> 2) & 1) + 4 * lh;
           const int x = x0 + 2 * t;
+#if PH_WINO_EXP & 16
+          if (ya[r] == 12345.678f && yb[r] == 4321.f) {  // timing experiment: (almost) no stores, the epilogue arithmetic stays
+#else
           if (interior || (y < a.H && co < a.coutp)) {
+#endif
             float* dp = a.dst + ((size_t)(b * a.H + y) * a.W + x) * a.coutp + co;
             if (interior || x < a.W) dp[0] = a.accumulate ? dp[0] + ya[r] : ya[r];
             if (interior || x + 1 < a.W) dp[a.coutp] = a.accumulate ? dp[a.coutp] + yb[r] : yb[r];
