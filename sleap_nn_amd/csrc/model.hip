@@ -378,6 +378,19 @@ ph_model* ph_model_create(const ph_op_desc* ops, int32_t n_ops, const float* con
              pack_upload(m, pad_vec(16, d.cmid), weights[d.bias], index_array(d.bias), &op.b_dev) == PH_OK &&
              pack_upload(m, pack_w1, weights[d.weight2], index_array(d.weight2), &op.w2_dev) == PH_OK &&
              pack_upload(m, pad_vec(16, d.cout), weights[d.bias2], index_array(d.bias2), &op.b2_dev) == PH_OK;
+        if (ok) {  // Winograd form of the second conv, derived on the device (refreshed by ph_model_set_params)
+          float* w = nullptr;
+          ok = hipMalloc(&w, 12 * 256 * sizeof(float)) == hipSuccess;
+          if (ok) {
+            m->allocs.push_back(w);
+            ok = launch_stem_wino_pack(op.w2_dev, w, nullptr) == PH_OK;
+            DerivedBuffer db;
+            db.src = op.w2_dev;
+            db.dst = w;
+            m->derived.push_back(db);
+            op.w_wino_dev = w;
+          }
+        }
         break;
       }
       case PH_OP_CONV:
@@ -663,6 +676,7 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
         a.w0 = op.w_dev;
         a.b0 = op.b_dev;
         a.w1 = op.w2_dev;
+        a.w1w = op.w_wino_dev;
         a.b1 = op.b2_dev;
         a.dst_full = d.dst >= 0 ? slot_ptr(d.dst) : nullptr;
         a.dst_pool = slot_ptr(d.dst2);

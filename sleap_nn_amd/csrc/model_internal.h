@@ -45,7 +45,7 @@ struct PackedBuffer {
 struct DerivedBuffer {
   const float* src = nullptr;
   float* dst = nullptr;
-  int panels = 0, bn = 0;
+  int panels = 0, bn = 0;  // bn == 0: the fused stem's second conv (launch_stem_wino_pack)
 };
 
 struct SlotShape {

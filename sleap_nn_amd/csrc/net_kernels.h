@@ -42,6 +42,7 @@ struct StemArgs {
   const float* b0;     // [16]
   const float* w1;     // [tap][n=16][16] second conv, k contiguous
   const float* b1;     // [16]
+  const float* w1w = nullptr;  // second conv, Winograd F(2,3) along x: [kernel row][m index 4][n=16][16], or nullptr
   float* dst_full;     // NHWC 16 full resolution or nullptr
   float* dst_pool;     // NHWC 16, ceil(H/2) x ceil(W/2)
   int dtype, cin, B, H, W;
@@ -100,6 +101,7 @@ int launch_conv3x3(const ConvArgs& a, hipStream_t s);
 // wpack [panel][tap 9][bn][16] -> Winograd weights [panel][step 24][n tile][lh][lx][4] (see conv3x3_wino_persist_kernel)
 int launch_wino_pack(const float* wpack, float* wino, int panels, int bn, hipStream_t s);
 int64_t wino_pack_floats(int panels, int bn);
+int launch_stem_wino_pack(const float* w1, float* w1w, hipStream_t s);  // [tap][co][ci] -> [kernel row][m index][co][ci]
 int launch_conv3x3_dma(const ConvArgs& a, hipStream_t s);
 int launch_input_conv(const InputConvArgs& a, hipStream_t s);
 int launch_pool(const float* src, float* dst, int B, int H, int W, int cp, hipStream_t s);

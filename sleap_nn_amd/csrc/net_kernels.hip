@@ -866,6 +866,20 @@ __global__ __launch_bounds__(256) void wino_pack_kernel(const float* __restrict_
     dst[i] = v;
   }
 }
+// fused stem: w1 [tap][co 16][ci 16] -> [kernel row][m index 4][co][ci]
+__global__ __launch_bounds__(256) void stem_wino_pack_kernel(const float* __restrict__ w1, float* __restrict__ w1w) {
+  for (int i = threadIdx.x; i < 12 * 256; i += 256) {
+    const int e = i & 255, p = i >> 8;
+    const int ky = p >> 2, xi = p & 3;
+    const float g0 = w1[(ky * 3 + 0) * 256 + e], g1 = w1[(ky * 3 + 1) * 256 + e], g2 = w1[(ky * 3 + 2) * 256 + e];
+    w1w[i] = xi == 0 ? g0 : (xi == 1 ? 0.5f * ((g0 + g2) + g1) : (xi == 2 ? 0.5f * ((g0 + g2) - g1) : g2));
+  }
+}
+int launch_stem_wino_pack(const float* w1, float* w1w, hipStream_t s) {
+  hipLaunchKernelGGL(stem_wino_pack_kernel, dim3(1), dim3(256), 0, s, w1, w1w);
+  PH_HIP_CHECK(hipGetLastError());
+  return PH_OK;
+}
 int64_t wino_pack_floats(int panels, int bn) { return (int64_t)panels * 24 * (bn / 32) * 256; }
 int launch_wino_pack(const float* wpack, float* wino, int panels, int bn, hipStream_t s) {
   const int64_t n = wino_pack_floats(panels, bn);
@@ -1326,7 +1340,9 @@ int launch_conv3x3_dma(const ConvArgs& a_in, hipStream_t s) {
 //   D: col = lane&15 (channel), row = 4*(lane>>4) + reg (pixel).  One ds_read_b128 per operand
 //   feeds 4 MFMAs (lane group g reads channels 4g..4g+3; MFMA j contracts {j, 4+j, 8+j, 12+j}).
 // ---------------------------------------------------------------------------------------
-template <int CIN>
+// WINO: conv1 as Winograd F(2,3) along x (see K1w): an M row of the 16x16x4 MFMA is an output PAIR, a wave's two rows are two M
+// tiles x four accumulators (m0..m3); 96 instead of 144 MFMAs per wave, the transform is four f32x4 adds per (kernel row, image row).
+template <int CIN, bool WINO>
 __global__ __launch_bounds__(256, 4) void stem_fused_kernel(StemArgs a) {
   constexpr int IMG_W = TW + 4, IMG_H = TH + 4;   // image patch incl. both halos
   __shared__ __attribute__((aligned(16))) float sA[HALO_H * HALO_W * LROW];   // conv0 output (conv1 input halo)
@@ -1399,6 +1415,63 @@ __global__ __launch_bounds__(256, 4) void stem_fused_kernel(StemArgs a) {
 
   // ---- conv1 on the matrix cores
   const int li = lane & 15, lg = lane >> 4;
+  if constexpr (WINO) {
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int xi = 0; xi < 4; ++xi) acc[m][xi] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      f32x4 bw[4];  // transformed weights of this kernel row: B[k = lg][n = li], element j = input channel 4 lg + j
+#pragma unroll
+      for (int xi = 0; xi < 4; ++xi) bw[xi] = *reinterpret_cast<const f32x4*>(a.w1w + (size_t)((ky * 4 + xi) * 16 + li) * 16 + lg * 4);
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        f32x4 d[4];  // the pair's four input pixels (halo columns 2t .. 2t+3), channels 4 lg .. 4 lg + 3
+#pragma unroll
+        for (int c = 0; c < 4; ++c) d[c] = *reinterpret_cast<const f32x4*>(sA + ((2 * wave + m + ky) * HALO_W + 2 * li + c) * LROW + lg * 4);
+        const f32x4 af[4] = {d[0] - d[2], d[1] + d[2], d[2] - d[1], d[1] - d[3]};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int xi = 0; xi < 4; ++xi) acc[m][xi] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[xi][j], bw[xi][j], acc[m][xi], 0, 0, 0);
+      }
+    }
+    // epilogue: D row 4 lg + r = pair t (pixels 2t, 2t+1), column li = channel; output transform, bias + ReLU, optional
+    // full-resolution store, 2x2 max pool (the pair is the pool column, the wave's two rows the pool rows)
+    const float bias = a.b1[li];
+    const int Hp = (a.H + 1) / 2, Wp = (a.W + 1) / 2;
+    float va[2][4], vb[2][4];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const int y = y0 + 2 * wave + m;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int x = x0 + 2 * (4 * lg + r);
+        const float m1 = acc[m][1][r], m2 = acc[m][2][r];
+        const float oa = fmaxf((acc[m][0][r] + m1) + m2 + bias, 0.f);
+        const float ob = fmaxf((m1 - m2) - acc[m][3][r] + bias, 0.f);
+        const bool ina = (y < a.H) && (x < a.W), inb = (y < a.H) && (x + 1 < a.W);
+        if (a.dst_full) {
+          float* dp = a.dst_full + (((size_t)b * a.H + y) * a.W + x) * 16 + li;
+          if (ina) dp[0] = oa;
+          if (inb) dp[16] = ob;
+        }
+        va[m][r] = ina ? oa : 0.f;
+        vb[m][r] = inb ? ob : 0.f;
+      }
+    }
+    const int py = (y0 >> 1) + wave;
+    if (py < Hp) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int px = (x0 >> 1) + 4 * lg + r;
+        if (px < Wp) a.dst_pool[(((size_t)b * Hp + py) * Wp + px) * 16 + li] = fmaxf(fmaxf(va[0][r], vb[0][r]), fmaxf(va[1][r], vb[1][r]));
+      }
+    }
+    return;
+  }
   // conv1's B fragments are the same for every tile: nine 16-B loads per lane straight into registers
   // (no LDS copy of the weights: 11.5 KiB less LDS per workgroup, five workgroups per CU instead of three)
   f32x4 bw[9];
@@ -1463,10 +1536,16 @@ __global__ __launch_bounds__(256, 4) void stem_fused_kernel(StemArgs a) {
 
 int launch_stem(const StemArgs& a, hipStream_t s) {
   const int tiles = ((a.W + TW - 1) / TW) * ((a.H + TH - 1) / TH) * a.B;
-  if (a.cin == 1)
-    hipLaunchKernelGGL(stem_fused_kernel<1>, dim3(tiles), dim3(256), 0, s, a);
+  static const int use_wino = getenv("PH_STEM_WINO") ? atoi(getenv("PH_STEM_WINO")) : 1;  // experiment knob: 0 = direct conv1
+  const bool wino = use_wino && a.w1w;
+  if (a.cin == 1 && wino)
+    hipLaunchKernelGGL((stem_fused_kernel<1, true>), dim3(tiles), dim3(256), 0, s, a);
+  else if (a.cin == 1)
+    hipLaunchKernelGGL((stem_fused_kernel<1, false>), dim3(tiles), dim3(256), 0, s, a);
+  else if (a.cin == 3 && wino)
+    hipLaunchKernelGGL((stem_fused_kernel<3, true>), dim3(tiles), dim3(256), 0, s, a);
   else if (a.cin == 3)
-    hipLaunchKernelGGL(stem_fused_kernel<3>, dim3(tiles), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((stem_fused_kernel<3, false>), dim3(tiles), dim3(256), 0, s, a);
   else {
     set_error("fused stem supports 1 or 3 input channels, got %d", a.cin);
     return PH_E_INVALID;

@@ -93,7 +93,8 @@ int ph_model_set_params(ph_model* m, const float* params_flat_dev, void* stream)
     if (rc != PH_OK) return rc;
   }
   for (const DerivedBuffer& db : m->derived) {
-    int rc = launch_wino_pack(db.src, db.dst, db.panels, db.bn, static_cast<hipStream_t>(stream));
+    int rc = db.bn == 0 ? launch_stem_wino_pack(db.src, db.dst, static_cast<hipStream_t>(stream))
+                        : launch_wino_pack(db.src, db.dst, db.panels, db.bn, static_cast<hipStream_t>(stream));
     if (rc != PH_OK) return rc;
   }
   return PH_OK;
