@@ -113,6 +113,9 @@ def cpu_baseline(sd, cms, pafs, budget_s: float = 20.0):
     }
 
 
+PROFILE_EVERY = 4  # steps of the timed region whose forward records per-op HIP events: 0, 4, 8, ...
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -193,10 +196,14 @@ def main():
     assert n_inst >= 5 * B, f"post-process found only {n_inst} instances in {B} frames"
     assert all(torch.isfinite(v).all() for v in raw.values())
 
+    # HIP-event timing of every op runs INSIDE the timed region, on every PROFILE_EVERY-th step (26 event records per forward
+    # cost ~0.6 ms of a 19 ms step; sampling a quarter of the steps keeps the roofline figures live at a quarter of that)
     model.set_profiling(True)
+    model.set_profiling(False)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        model.set_profiling(i % PROFILE_EVERY == 0, resume=True)
         step()
     drain()
     barrier()
@@ -280,6 +287,7 @@ def main():
                 "conv_stack_direct_equivalent_frac": (stack_flops / (stack_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS) if stack_ms > 0 else 0.0,
                 "forward_ms": fwd_ms, "forward_frames_per_s": B / (fwd_ms * 1e-3) if fwd_ms > 0 else 0.0,
                 "per_op_ms": {r["label"]: round(ms / max(n_fw, 1), 4) for r, ms in zip(table, op_ms)},
+                "profiled_forwards": n_fw,
             },
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -183,7 +183,9 @@ int ph_debug_gemm_bench(int32_t variant, int32_t M, int32_t K, int32_t N, int32_
  * the roofline object).  While enabled every forward records one event before each op and
  * one after the last; ph_model_profile_read waits for the last recorded forward, returns
  * the milliseconds accumulated per op since profiling was enabled and the number of
- * forwards they cover. */
+ * forwards they cover.  enabled: 1 = start (clears the accumulated times), 0 = stop recording
+ * (what was accumulated stays readable), 2 = resume without clearing -- so a caller can sample
+ * every n-th forward of a timed region instead of paying ~25 event records in each. */
 int ph_model_set_profiling(ph_model* m, int32_t enabled);
 int ph_model_profile_read(ph_model* m, double* op_ms, int32_t n_ops, int32_t* n_forwards);
 

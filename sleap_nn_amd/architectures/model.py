@@ -362,9 +362,10 @@ class Model:
     __call__ = forward
 
     # -- measurement support ------------------------------------------------------------
-    def set_profiling(self, enabled: bool) -> None:
-        """Per-op HIP-event timing on the forward's stream (bench.py roofline)."""
-        L.check(L.lib().ph_model_set_profiling(self._handle, 1 if enabled else 0))
+    def set_profiling(self, enabled, resume: bool = False) -> None:
+        """Per-op HIP-event timing on the forward's stream (bench.py roofline).  ``resume=True`` switches recording back on
+        without clearing what was accumulated (sampling every n-th forward of a timed region)."""
+        L.check(L.lib().ph_model_set_profiling(self._handle, (2 if resume else 1) if enabled else 0))
 
     def read_profile(self):
         """-> (list of accumulated ms per op, number of forwards covered)."""

@@ -913,7 +913,7 @@ int ph_model_set_profiling(ph_model* m, int32_t enabled) {
     m->ev.resize(m->ops.size() + 1);
     for (auto& e : m->ev) PH_HIP_CHECK(hipEventCreate(&e));
   }
-  if (enabled) {
+  if (enabled == 1 || m->op_ms.size() != m->ops.size()) {
     m->op_ms.assign(m->ops.size(), 0.0);
     m->profiled_forwards = 0;
     m->events_pending = false;
