@@ -1137,6 +1137,43 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_persist_kernel(ConvArgs a
           ya[r] = a.relu ? fmaxf(va, 0.f) : va;
           yb[r] = a.relu ? fmaxf(vb, 0.f) : vb;
         }
+#if !(PH_WINO_EXP & 16)
+        if (interior) {
+          // Interior tile (all but the image's last row / column of tiles): straight-line stores.  One lane-dependent base
+          // pointer; every store adds a wave-uniform offset -- no per-store bounds test, no exec-mask branch (the general
+          // path below costs ~30 cycles of branching per store, ~5k cycles per tile and wave).
+          if (a.dst_pool) {
+            const int Hp = (a.H + 1) >> 1, Wp = (a.W + 1) >> 1;
+            float* const pp = a.dst_pool + ((size_t)(b * Hp + ((y0 + 2 * wave) >> 1)) * Wp + (x0 >> 1) + 4 * lh) * a.coutp + co;
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+              pp[(size_t)((r & 3) + 8 * (r >> 2)) * a.coutp] = fmaxf(fmaxf(ya[r], yb[r]), fmaxf(ya[r + 8], yb[r + 8]));
+          }
+          float* const dp0 = a.dst + ((size_t)(b * a.H + y0 + 2 * wave) * a.W + x0 + 8 * lh) * a.coutp + co;
+          if (!a.accumulate) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              float* dp = dp0 + (size_t)((r >> 3) * a.W + 2 * (r & 3) + 16 * ((r >> 2) & 1)) * a.coutp;
+              dp[0] = ya[r];
+              dp[a.coutp] = yb[r];
+            }
+          } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              float* dp = dp0 + (size_t)((r >> 3) * a.W + 2 * (r & 3) + 16 * ((r >> 2) & 1)) * a.coutp;
+              ya[r] += dp[0];
+              yb[r] += dp[a.coutp];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              float* dp = dp0 + (size_t)((r >> 3) * a.W + 2 * (r & 3) + 16 * ((r >> 2) & 1)) * a.coutp;
+              dp[0] = ya[r];
+              dp[a.coutp] = yb[r];
+            }
+          }
+          continue;
+        }
+#endif
         if (a.dst_pool) {  // fused 2x2/2 max pool ("same" padding: zeros beyond the image)
           const int Hp = (a.H + 1) >> 1, Wp = (a.W + 1) >> 1;
           const int yt = y0 + 2 * wave, py = yt >> 1;
