@@ -609,3 +609,16 @@ def test_forward_is_bitwise_deterministic_and_stream_safe():
     torch.cuda.synchronize()
     for k in a:
         assert torch.equal(a[k], b[k]), k
+
+
+def test_direct_convolution_kernels_still_match_golden():
+    """The Winograd kernels are the default; the direct 9-tap kernels stay in the library (transposed convs, A/B runs).
+    The switch is read once per process, so the golden forward tests are re-run in a child process with it off."""
+    import os
+    import subprocess
+    import sys
+
+    env = dict(os.environ, PH_CONV_WINO="0", PH_STEM_WINO="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", f"{__file__}::test_forward_matches_reference_golden",
+                        f"{__file__}::test_fused_pool_epilogue_odd_sizes_and_unfused_equivalence"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

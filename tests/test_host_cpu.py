@@ -341,3 +341,18 @@ def test_unet_structure_known_answers():
     assert m.backbone.decoder_stride_to_filters == {16: 256, 8: 128, 4: 64, 2: 32, 1: 16}
     sd = O.init_state(bb, heads, "single_instance")
     assert sorted(sd) == sorted(m.param_shapes) and sum(v.numel() for v in sd.values()) == 1962541
+
+
+def test_winograd_f23_identity_used_by_the_conv_kernels():
+    """The algebra conv3x3_wino_persist_kernel / wino_pack_kernel rely on: two neighbouring outputs of a 3-tap row
+    from four multiplications, with exactly the transforms the kernels apply."""
+    rng = np.random.default_rng(0)
+    d = rng.standard_normal((1000, 4))
+    g = rng.standard_normal((1000, 3))
+    u = np.stack([g[:, 0], 0.5 * ((g[:, 0] + g[:, 2]) + g[:, 1]), 0.5 * ((g[:, 0] + g[:, 2]) - g[:, 1]), g[:, 2]], axis=1)  # wino_pack_kernel
+    v = np.stack([d[:, 0] - d[:, 2], d[:, 1] + d[:, 2], d[:, 2] - d[:, 1], d[:, 1] - d[:, 3]], axis=1)  # make_a
+    m = u * v
+    y0 = (m[:, 0] + m[:, 1]) + m[:, 2]  # epilogue
+    y1 = (m[:, 1] - m[:, 2]) - m[:, 3]
+    assert np.allclose(y0, (d[:, 0:3] * g).sum(1), atol=1e-12)
+    assert np.allclose(y1, (d[:, 1:4] * g).sum(1), atol=1e-12)
