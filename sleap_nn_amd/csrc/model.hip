@@ -307,6 +307,7 @@ ph_model* ph_model_create(const ph_op_desc* ops, int32_t n_ops, const float* con
     if (const char* ff = getenv("PH_FUSE_GELU_FWD")) m->fuse_gelu_fwd = atoi(ff);
     if (const char* wi = getenv("PH_WGRAD_IMPL")) m->wgrad_rows = std::string(wi) == "rows" ? 2 : (std::string(wi) == "auto" ? 1 : 0);
     if (const char* th = getenv("PH_CONV_GEMM_FILL")) m->gemm_fill_threshold = atof(th);  // experiment knob: 0 disables the row-GEMM form
+    if (const char* th = getenv("PH_CONV_GEMM_FILL_WINO")) m->gemm_fill_threshold_wino = std::max(atof(th), 1e-3);
     std::vector<float> z(64, 0.f);
     if (upload(m, z, &m->zeros_dev) != PH_OK) {
       ph_model_destroy(m);
@@ -717,7 +718,9 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
         const double n_fill = (double)a.coutp / ((a.coutp + op.bn - 1) / op.bn * op.bn);
         const int bn_g = op.bn_g > 0 ? op.bn_g : 128;
         const double n_fill_g = (double)a.coutp / ((a.coutp + bn_g - 1) / bn_g * bn_g);
-        if (m->use_dma && d.dst2 < 0 && op.w_gemm_dev && (fill < m->gemm_fill_threshold || n_fill * fill < 0.8 * n_fill_g)) {
+        // the halo kernel runs Winograd F(2,3) (2/3 of the MFMA work) where its weights exist: it wins down to ~0.5 tile fill (measured on the ConvNeXt decoder: 48x48 and 24x24 maps)
+        const double halo_gain = (op.w_wino_dev && m->use_dma) ? m->gemm_fill_threshold / m->gemm_fill_threshold_wino : 1.0;
+        if (m->use_dma && d.dst2 < 0 && op.w_gemm_dev && (fill * halo_gain < m->gemm_fill_threshold || n_fill * fill * halo_gain < 0.8 * n_fill_g)) {
           // small feature map (the 16x32-pixel tiles of the halo kernel would be mostly padding) or a Cout that
           // fits the halo kernel's N tile badly -> 9-tap row GEMM
           GemmArgs g{};

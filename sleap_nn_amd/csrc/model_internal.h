@@ -86,6 +86,7 @@ struct ph_model {
   int fuse_gelu_fwd = 1;                      // Linear -> GELU op pair: one GEMM whose epilogue writes both tensors (PH_FUSE_GELU_FWD=0: two kernels)
   int fuse_gelu_bwd = 1;                      // Linear data gradient multiplies by GELU' in its epilogue (PH_FUSE_GELU_BWD=0: separate kernel)
   int wgrad_rows = 0;                         // 3x3 weight gradients of wide layers as nine row-wgrad GEMMs (off by default: measured slower than the 32x32-tile kernel; PH_WGRAD_IMPL=auto|rows)
+  double gemm_fill_threshold_wino = 0.5;      // ... and the (lower) break-even when the halo kernel is the Winograd one (PH_CONV_GEMM_FILL_WINO)
   double gemm_fill_threshold = 0.8;           // 3x3 convs whose maps fill the 16x32 tiles less than this run as row GEMMs
 };
 
