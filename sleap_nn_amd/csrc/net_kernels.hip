@@ -891,21 +891,27 @@ int launch_wino_pack(const float* wpack, float* wino, int panels, int bn, hipStr
 #ifndef PH_WINO_EXP
 #define PH_WINO_EXP 0  // timing experiments only (results are wrong): 1 no mid barrier, 2 no DMA in the K loop, 4 no input transform, 8 no epilogue, 16 no epilogue stores
 #endif
-template <int BN>
-__global__ __launch_bounds__(512, 2) void conv3x3_wino_persist_kernel(ConvArgs a) {
+// WAVES = 8: one 512-thread workgroup per CU, tile 16 x 32 pixels (the default).  WAVES = 4 (N tile 32 only: 80 KiB of LDS): two
+// 256-thread workgroups per CU, tile 8 x 32, which drift apart so that one's epilogue runs under the other's MFMAs -- an
+// experiment (PH_CONV_WINO32_2WG=1) for the layers with one or two K chunks per tile; measured 2 % slower than one workgroup.
+template <int BN, int WAVES>
+__global__ __launch_bounds__(WAVES * 64, 2) void conv3x3_wino_persist_kernel(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int NT = BN / 32;
   constexpr int BH_PIECES = 12 * NT;  // weight pieces of half a chunk (12 steps)
-  constexpr int A_SLOTS = (D_A_PIECES + 7) / 8;
-  constexpr int BH_SLOTS = (BH_PIECES + 7) / 8;
-  constexpr int A_FLOATS = D_A_PIECES * 256, BH_FLOATS = BH_PIECES * 256;
+  constexpr int W_TH = 2 * WAVES;                      // tile rows: two per wave
+  constexpr int W_NPIX = (W_TH + 2) * HALO_W;          // halo pixels
+  constexpr int W_A_PIECES = (W_NPIX + 15) / 16;
+  constexpr int A_SLOTS = (W_A_PIECES + WAVES - 1) / WAVES;
+  constexpr int BH_SLOTS = (BH_PIECES + WAVES - 1) / WAVES;
+  constexpr int A_FLOATS = W_A_PIECES * 256, BH_FLOATS = BH_PIECES * 256;
   static_assert(A_SLOTS + BH_SLOTS <= 12 && BH_SLOTS <= 12, "one DMA piece per step");
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tiles_x = (a.W + TW - 1) / TW;
-  const int tiles_y = (a.H + D_TH - 1) / D_TH;
+  const int tiles_y = (a.H + W_TH - 1) / W_TH;
   const int tiles = tiles_x * tiles_y * a.B;
   const int ntc = (a.coutp + BN - 1) / BN;
   const int total = tiles * ntc;
@@ -935,16 +941,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_persist_kernel(ConvArgs a
     const int ty = t % tiles_y;
     P.b = t / tiles_y;
     P.x0 = tx * TW;
-    P.y0 = ty * D_TH;
+    P.y0 = ty * W_TH;
     P.ntile = ntile;
     P.a_ok = 0;
 #pragma unroll
     for (int s = 0; s < A_SLOTS; ++s) {
-      const int p = min(wave + 8 * s, D_A_PIECES - 1);
+      const int p = min(wave + WAVES * s, W_A_PIECES - 1);
       const int pix = p * 16 + dr;
       const int hy = pix / HALO_W, hx = pix - hy * HALO_W;
       const int gy = P.y0 + hy - 1, gx = P.x0 + hx - 1;
-      const bool in = (pix < D_NPIX) && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+      const bool in = (pix < W_NPIX) && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
       P.a_ok |= (in ? 1u : 0u) << s;
       const int cy = min(max(gy, 0), a.H - 1), cx = min(max(gx, 0), a.W - 1);
       P.a_pix[s] = (P.b * a.H + cy) * a.W + cx;
@@ -972,14 +978,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_persist_kernel(ConvArgs a
     p_w = a.wpack_wino + ((size_t)P.ntile * nchunks + ch) * (2 * BH_FLOATS);
   };
   auto dma_a = [&](int s, float* abuf) {
-    const int p = min(wave + 8 * s, D_A_PIECES - 1);
+    const int p = min(wave + WAVES * s, W_A_PIECES - 1);
     const float* real = p_src + (size_t)f_pix[s] * p_cp + p_coff + dq * 4;
     const float* zero = a.zeros + dq * 4;
     const float* g = ((f_ok >> s) & 1u) ? real : zero;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)(abuf + p * 256), 16, 0, 0);
   };
   auto dma_b = [&](int s, int half, float* bhalf) {
-    const int pb = min(wave + 8 * s, BH_PIECES - 1);
+    const int pb = min(wave + WAVES * s, BH_PIECES - 1);
     const float* g = p_w + half * BH_FLOATS + pb * 256 + lane * 4;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)(bhalf + pb * 256), 16, 0, 0);
   };
@@ -1115,7 +1121,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_persist_kernel(ConvArgs a
       // ---- epilogue of this tile: output transform, bias, ReLU, stores.  D row (r & 3) + 8 (r >> 2) + 4 lh = pair index:
       // r < 8 is the wave's first row, r >= 8 its second; the pair's outputs are pixels 2t, 2t + 1.
       const int b = P.b, x0 = P.x0, y0 = P.y0, ntile = P.ntile;
-      const bool interior = (x0 + TW <= a.W) && (y0 + D_TH <= a.H) && ((ntile + 1) * BN <= a.coutp);
+      const bool interior = (x0 + TW <= a.W) && (y0 + W_TH <= a.H) && ((ntile + 1) * BN <= a.coutp);
 #if PH_WINO_EXP & 8
       if (acc[0][0][0] != 12345.678f) {  // timing experiment: no epilogue (the accumulators stay live)
         if (!has_next) break;
@@ -1221,7 +1227,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_persist_kernel(ConvArgs a
       P = Pn;
     }
   };
-  if (a.dma_stagger && wave >= 4)
+  if (WAVES == 8 && a.dma_stagger && wave >= 4)
     run(std::true_type{});
   else
     run(std::false_type{});
@@ -1329,7 +1335,7 @@ int launch_conv3x3_dma(const ConvArgs& a_in, hipStream_t s) {
     if (use_wino && a.wpack_wino) {
       const size_t lds_w = (size_t)(2 * D_A_PIECES + 3 * 12 * (64 / 32)) * 1024;
       const int total_w = tiles * ((a.coutp + 63) / 64);
-      hipLaunchKernelGGL(conv3x3_wino_persist_kernel<64>, dim3(std::min(total_w, n_cu)), dim3(512), lds_w, s, a);
+      hipLaunchKernelGGL((conv3x3_wino_persist_kernel<64, 8>), dim3(std::min(total_w, n_cu)), dim3(512), lds_w, s, a);
       PH_HIP_CHECK(hipGetLastError());
       return PH_OK;
     }
@@ -1345,9 +1351,19 @@ int launch_conv3x3_dma(const ConvArgs& a_in, hipStream_t s) {
     }
     static const int use_wino32 = getenv("PH_CONV_WINO32") ? atoi(getenv("PH_CONV_WINO32")) : 1;  // experiment knob
     if (use_wino && use_wino32 && a.wpack_wino) {
+      static const int two_wg = getenv("PH_CONV_WINO32_2WG") ? atoi(getenv("PH_CONV_WINO32_2WG")) : 0;  // experiment knob: 1 = two 4-wave workgroups per CU (measured 2 % slower)
+      if (two_wg) {
+        constexpr int a_pieces = ((8 + 2) * HALO_W + 15) / 16;
+        const size_t lds_w = (size_t)(2 * a_pieces + 3 * 12) * 1024;  // 80 KiB: two workgroups per CU
+        const int tiles8 = ((a.W + TW - 1) / TW) * ((a.H + 7) / 8) * a.B;
+        const int total_w = tiles8 * ((a.coutp + 31) / 32);
+        hipLaunchKernelGGL((conv3x3_wino_persist_kernel<32, 4>), dim3(std::min(total_w, 2 * n_cu32)), dim3(256), lds_w, s, a);
+        PH_HIP_CHECK(hipGetLastError());
+        return PH_OK;
+      }
       const size_t lds_w = (size_t)(2 * D_A_PIECES + 3 * 12 * (32 / 32)) * 1024;
       const int total_w = tiles * ((a.coutp + 31) / 32);
-      hipLaunchKernelGGL(conv3x3_wino_persist_kernel<32>, dim3(std::min(total_w, n_cu32)), dim3(512), lds_w, s, a);
+      hipLaunchKernelGGL((conv3x3_wino_persist_kernel<32, 8>), dim3(std::min(total_w, n_cu32)), dim3(512), lds_w, s, a);
       PH_HIP_CHECK(hipGetLastError());
       return PH_OK;
     }
@@ -1927,9 +1943,11 @@ int prepare_kernels() {
   if (e == hipSuccess)
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_mfma_dma_persist_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e == hipSuccess)
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wino_persist_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wino_persist_kernel<64, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e == hipSuccess)
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wino_persist_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wino_persist_kernel<32, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e == hipSuccess)
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wino_persist_kernel<32, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
   if (e != hipSuccess) {
     set_error("hipFuncSetAttribute(conv dma) failed: %s", hipGetErrorString(e));
     return PH_E_HIP;
