@@ -233,6 +233,15 @@ int ph_crop_bboxes(const void* images_dev, int32_t dtype, int32_t B, int32_t C, 
                    const float* topleft_xy_dev, const int32_t* sample_inds_dev, int32_t n,
                    int32_t crop_h, int32_t crop_w, void* out_dev, void* stream);
 
+/* Antialiased bilinear resize of planes x H x W -> planes x OH x OW (uint8: dtype 0, float32: dtype 1), NCHW planes.
+ * Replaces torchvision.transforms.v2.functional.resize as called by resize_image (data/resizing.py:70-84, the input-scale step)
+ * and apply_sizematcher (data/resizing.py:136-175): for tensors that is torch's interpolate(mode="bilinear",
+ * align_corners=False, antialias=True).  uint8 results are bit-exact with the CPU operator (int16 fixed-point weights,
+ * horizontal pass first into a uint8 intermediate); float32 matches to fp32 rounding.  tmp_dev: planes * H * OW elements of the
+ * same dtype (only read/written when both axes change; may be NULL otherwise). */
+int ph_resize_bilinear_aa(const void* src_dev, int32_t dtype, int32_t planes, int32_t H, int32_t W,
+                          void* dst_dev, int32_t OH, int32_t OW, void* tmp_dev, void* stream);
+
 /* Class-map sampling for multi-class bottom-up (inference/ops/identity.py:86-101): for each peak
  * gather the K class probabilities at (round-half-even(y), round-half-even(x)) clamped to the map.
  * class_maps_dev (B, K, H, W) fp32; peaks_xy_dev (n, 2) in class-map pixels; out_probs_dev (n, K). */

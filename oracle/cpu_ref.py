@@ -1171,3 +1171,112 @@ def class_inds_from_vectors(probs: torch.Tensor):
         inds[a] = int(b)
         pr[a] = probs[a, b]
     return inds, pr
+
+
+# ---------------------------------------------------------------------------------------------
+# Preprocessing resizes (data/resizing.py:70-84 resize_image, :136-175 apply_sizematcher).  The reference calls
+# torchvision.transforms.v2.functional.resize (bilinear, antialias=True), i.e. torch's interpolate(..., antialias=True);
+# torchvision is not in the reference tree.  For uint8 frames (what the layers keep, layers/base.py:212-253) the arithmetic
+# below restates ATen's separable int16 fixed-point kernel (aten/src/ATen/native/cpu/UpSampleKernel.cpp:
+# _compute_indices_int16_weights_aa + the uint8 single-dim loop) and is pinned bit-exactly against torch's own CPU operator
+# in tests/test_oracle_golden.py; float frames go through torch's operator directly.
+# ---------------------------------------------------------------------------------------------
+def _aa_axis_table(in_size: int, out_size: int):
+    import math
+
+    scale = in_size / out_size
+    support = scale if scale >= 1.0 else 1.0
+    invscale = 1.0 / scale if scale >= 1.0 else 1.0
+    max_taps = int(math.ceil(support)) * 2 + 1
+    start = np.zeros(out_size, np.int64)
+    count = np.zeros(out_size, np.int64)
+    w = np.zeros((out_size, max_taps), np.float64)
+    for i in range(out_size):
+        center = scale * (i + 0.5)
+        lo = max(int(center - support + 0.5), 0)
+        n = min(int(center + support + 0.5), in_size) - lo
+        x = np.abs((np.arange(n) + lo - center + 0.5) * invscale)
+        v = np.where(x < 1.0, 1.0 - x, 0.0)
+        tot = 0.0
+        for t in v:  # sequential sum, as the C loop does
+            tot += t
+        w[i, :n] = v / tot if tot != 0.0 else v
+        start[i], count[i] = lo, n
+    w_max = float(w.max())
+    precision = 0
+    while precision < 22:
+        if int(0.5 + w_max * (1 << (precision + 1))) >= (1 << 15):
+            break
+        precision += 1
+    wi = np.where(w < 0, (-0.5 + w * (1 << precision)).astype(np.int64), (0.5 + w * (1 << precision)).astype(np.int64))
+    return start, count, wi, precision
+
+
+def resize_bilinear_aa(image: torch.Tensor, size) -> torch.Tensor:
+    """interpolate(image, size, mode="bilinear", align_corners=False, antialias=True) as torchvision's resize issues it."""
+    oh, ow = int(size[0]), int(size[1])
+    if image.dtype != torch.uint8:
+        x = image if image.dim() == 4 else image[None]
+        y = F.interpolate(x.float(), size=(oh, ow), mode="bilinear", align_corners=False, antialias=True)
+        return y if image.dim() == 4 else y[0]
+    x = image.numpy().astype(np.int64)
+    H, W = x.shape[-2:]
+    if ow != W:  # horizontal pass first, uint8 intermediate
+        start, count, wi, prec = _aa_axis_table(W, ow)
+        out = np.empty(x.shape[:-1] + (ow,), np.int64)
+        for i in range(ow):
+            acc = (1 << (prec - 1)) + (x[..., start[i] : start[i] + count[i]] * wi[i, : count[i]]).sum(-1)
+            out[..., i] = np.clip(acc >> prec, 0, 255)
+        x = out
+    if oh != H:
+        start, count, wi, prec = _aa_axis_table(H, oh)
+        out = np.empty(x.shape[:-2] + (oh, x.shape[-1]), np.int64)
+        for i in range(oh):
+            acc = (1 << (prec - 1)) + (x[..., start[i] : start[i] + count[i], :] * wi[i, : count[i], None]).sum(-2)
+            out[..., i, :] = np.clip(acc >> prec, 0, 255)
+        x = out
+    return torch.from_numpy(x.astype(np.uint8))
+
+
+def resize_image(image: torch.Tensor, scale: float) -> torch.Tensor:
+    """data/resizing.py:70-84."""
+    h, w = image.shape[-2:]
+    return resize_bilinear_aa(image, [int(h * scale), int(w * scale)])
+
+
+def apply_sizematcher(image: torch.Tensor, max_height: Optional[int] = None, max_width: Optional[int] = None):
+    """data/resizing.py:136-175: fit into (max_height, max_width) keeping the aspect ratio, zero pad bottom/right."""
+    h, w = image.shape[-2:]
+    max_height = h if max_height is None else max_height
+    max_width = w if max_width is None else max_width
+    if h == max_height and w == max_width:
+        return image, 1.0
+    hratio, wratio = max_height / h, max_width / w
+    if hratio > wratio:
+        eff, th, tw = wratio, int(round(h * wratio)), int(round(w * wratio))
+    else:
+        eff, tw, th = hratio, int(round(w * hratio)), int(round(h * hratio))
+    image = resize_bilinear_aa(image, (th, tw))
+    image = F.pad(image, (0, max_width - tw, 0, max_height - th), mode="constant")
+    return image, eff
+
+
+def full_preprocess(x: torch.Tensor, max_height=None, max_width=None, scale: float = 1.0, max_stride: int = 1):
+    """layers/base.py:270-374 steps 2-4 on a (B, C, H, W) tensor -> (processed, eff_scale (B,), original (H, W))."""
+    B, _c, H, W = x.shape
+    if max_height is not None or max_width is not None:
+        frames, effs = [], []
+        for b in range(B):
+            r, e = apply_sizematcher(x[b], max_height, max_width)
+            frames.append(r)
+            effs.append(float(e))
+        x = torch.stack(frames, 0)
+        eff = torch.tensor(effs, dtype=torch.float32)
+    else:
+        eff = torch.ones(B, dtype=torch.float32)
+    if scale != 1.0:
+        x = resize_image(x, scale)
+    if max_stride != 1:
+        h, w = x.shape[-2:]
+        x = F.pad(x, (0, (max_stride - w % max_stride) % max_stride, 0, (max_stride - h % max_stride) % max_stride), mode="constant")
+    return x, eff, (H, W)

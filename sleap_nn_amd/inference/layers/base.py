@@ -104,10 +104,12 @@ class InferenceLayer(ABC):
             raise ValueError(f"unexpected image rank {t.ndim}: shape {tuple(t.shape)}")
         return t
 
-    def _apply_full_preprocess(self, x: torch.Tensor, *, max_stride: int = 1, unsqueeze_n_samples: bool = True):
-        """Channel coercion -> (sizematcher) -> (input scale) -> pad to stride -> n_samples axis
-        (base.py:270-374).  Sizematcher / input-scale resizes are data-pipeline features outside
-        the MI355X hot path: frames must arrive at model resolution."""
+    def _apply_full_preprocess(self, x: torch.Tensor, *, max_stride: int = 1, unsqueeze_n_samples: bool = True, skip_sizematcher: bool = False):
+        """Channel coercion -> per-sample sizematcher (records eff_scale) -> input scale -> pad to stride -> n_samples axis
+        (base.py:270-374).  The resizes run on the GPU (``ph_resize_bilinear_aa``: bit-exact with the uint8 CPU operator the
+        reference's ``tvf.resize`` dispatches to); frames that need none stay where they are."""
+        from sleap_nn_amd.data.resizing import apply_sizematcher, resize_image
+
         cfg = self.preprocess_config
         B, _c, H, W = x.shape
         if cfg.ensure_rgb and x.shape[-3] != 3:
@@ -115,17 +117,19 @@ class InferenceLayer(ABC):
         elif cfg.ensure_grayscale and x.shape[-3] != 1:
             r, g, b = x.float().unbind(dim=-3)
             x = (0.2989 * r + 0.587 * g + 0.114 * b).unsqueeze(-3)
-        if (cfg.max_height is not None and H > cfg.max_height) or (cfg.max_width is not None and W > cfg.max_width):
-            raise NotImplementedError("sizematcher downscaling is not part of the MI355X hot path; resize frames upstream")
+        if not skip_sizematcher and (cfg.max_height is not None or cfg.max_width is not None):
+            frames, effs = [], []
+            for b in range(B):  # per sample, as the reference does (frames of one batch share a size here, the loop keeps its contract)
+                r, e = apply_sizematcher(x[b], cfg.max_height, cfg.max_width)
+                frames.append(r)
+                effs.append(float(e))
+            dev = next((f.device for f in frames if f.is_cuda), frames[0].device)
+            x = torch.stack([f.to(dev) for f in frames], dim=0)
+            eff_scale = torch.tensor(effs, dtype=torch.float32)
+        else:
+            eff_scale = torch.ones(B, dtype=torch.float32)
         if cfg.scale != 1.0:
-            raise NotImplementedError("input scale != 1.0 is not part of the MI355X hot path; resize frames upstream")
-        eff_scale = torch.ones(B, dtype=torch.float32)
-        if cfg.max_height is not None or cfg.max_width is not None:
-            # sizematcher with a frame that already fits: pad bottom/right to (max_h, max_w), scale 1
-            ph = (cfg.max_height - H) if cfg.max_height else 0
-            pw = (cfg.max_width - W) if cfg.max_width else 0
-            if ph > 0 or pw > 0:
-                x = F.pad(x, (0, max(pw, 0), 0, max(ph, 0)))
+            x = resize_image(x, cfg.scale)
         if max_stride != 1:
             x = apply_pad_to_stride(x, max_stride)
         if unsqueeze_n_samples:

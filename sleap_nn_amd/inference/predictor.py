@@ -32,8 +32,8 @@ def _select_layer(assets: Sequence[LoadedAssets], device: str, post: Postprocess
 
     def pre(a):
         p = a.preprocessing
-        # frames must arrive model-sized (scale / sizematcher resizes are upstream of the hot path)
-        return PreprocessConfig(ensure_rgb=p.get("ensure_rgb") or None, ensure_grayscale=p.get("ensure_grayscale") or None)
+        return PreprocessConfig(ensure_rgb=p.get("ensure_rgb") or None, ensure_grayscale=p.get("ensure_grayscale") or None,
+                                max_height=p.get("max_height") or None, max_width=p.get("max_width") or None, scale=float(p.get("scale") or 1.0))
 
     if "bottomup" in by_type:
         a = by_type["bottomup"]

@@ -470,6 +470,11 @@ def test_predictor_from_run_directory_matches_golden():
             assert np.allclose(k[:n], gp[b].reshape(n, -1, 2), atol=1e-3, equal_nan=True)
     zs = G.load("ckpt_single_instance.npz")
     ps = Predictor.from_model_paths([os.path.join(root, "minimal_instance_single_instance")], device=DEV, batch_size=2, peak_threshold=0.3)
+    pc = ps.layer.preprocess_config
+    assert (pc.max_height, pc.max_width, pc.scale) == (320, 560, 0.5)  # read from the run directory's training_config.yaml
+    from sleap_nn_amd.inference.layers import PreprocessConfig
+
+    ps.layer.preprocess_config = PreprocessConfig()  # the golden frames are the reference's ALREADY preprocessed 160x280 model inputs
     o = ps.predict(torch.from_numpy(zs["image"]).squeeze(1))[0]
     assert np.allclose(o.pred_keypoints[:, 0].cpu().numpy() / 0.5, zs["gold_peaks"], atol=1e-3, equal_nan=True)
 
@@ -622,3 +627,59 @@ def test_direct_convolution_kernels_still_match_golden():
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", f"{__file__}::test_forward_matches_reference_golden",
                         f"{__file__}::test_fused_pool_epilogue_odd_sizes_and_unfused_equivalence"], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_resize_kernel_matches_the_cpu_operator():
+    """ph_resize_bilinear_aa vs the oracle restatement (itself pinned bit-exactly against torch's uint8 operator on the CPU):
+    uint8 bit-exact, float32 to fp32 rounding; up- and down-scaling, one-axis and identity cases, sizematcher + input scale."""
+    from sleap_nn_amd.data.resizing import apply_sizematcher, resize_bilinear_aa, resize_image
+
+    rng = np.random.default_rng(5)
+    for t in range(24):
+        C, H, W = int(rng.choice([1, 3])), int(rng.integers(5, 120)), int(rng.integers(5, 120))
+        oh, ow = int(rng.integers(3, 160)), int(rng.integers(3, 160))
+        if t % 5 == 0:
+            oh = H
+        if t % 7 == 0:
+            ow = W
+        x = torch.from_numpy(rng.integers(0, 256, (2, C, H, W), dtype=np.uint8))
+        ref = O.resize_bilinear_aa(x, (oh, ow))
+        got = resize_bilinear_aa(x.to(DEV), (oh, ow)).cpu()
+        assert torch.equal(got, ref), (t, C, H, W, oh, ow, int((got != ref).sum()))
+        xf = torch.from_numpy(rng.random((1, C, H, W), dtype=np.float32) * 255)
+        reff = O.resize_bilinear_aa(xf, (oh, ow))
+        gotf = resize_bilinear_aa(xf.to(DEV), (oh, ow)).cpu()
+        assert (gotf - reff).abs().max().item() <= 2e-4, (t, float((gotf - reff).abs().max()))
+    frame = torch.from_numpy(rng.integers(0, 256, (3, 200, 310), dtype=np.uint8))
+    for mh, mw in ((160, 160), (256, 512), (200, 310), (400, None)):
+        r0, e0 = O.apply_sizematcher(frame, mh, mw)
+        r1, e1 = apply_sizematcher(frame.to(DEV), mh, mw)
+        assert e0 == e1 and torch.equal(r1.cpu(), r0), (mh, mw)
+    assert torch.equal(resize_image(frame[None].to(DEV), 0.5).cpu(), O.resize_image(frame[None], 0.5))
+
+
+def test_layer_preprocess_with_sizematcher_and_input_scale():
+    """SingleInstanceLayer with max_height / max_width / scale: frames of another size go through sizematcher + input scale +
+    stride padding on the GPU, and the keypoints come back in ORIGINAL frame coordinates -- against the oracle's chain."""
+    from sleap_nn_amd.architectures.model import Model
+    from sleap_nn_amd.inference.backends import HipBackend
+    from sleap_nn_amd.inference.layers import PostprocessConfig, PreprocessConfig, SingleInstanceLayer
+
+    bb = {"in_channels": 1, "kernel_size": 3, "filters": 8, "filters_rate": 2, "max_stride": 16, "stem_stride": None, "middle_block": True, "up_interpolate": True,
+          "stacks": 1, "convs_per_block": 2, "output_stride": 2}
+    heads = {"confmaps": {"part_names": ["a", "b", "c", "d"], "output_stride": 2}}
+    sd = O.init_state(bb, heads, "single_instance", seed=21, head_scale=1.0)
+    g = torch.Generator().manual_seed(21)
+    img = torch.randint(0, 256, (2, 1, 150, 230), dtype=torch.uint8, generator=g)
+    m = Model("unet", bb, heads, "single_instance")
+    m.load_state_dict(sd)
+    pre = PreprocessConfig(max_height=128, max_width=192, scale=0.75)
+    x_ref, eff, _ = O.full_preprocess(img, 128, 192, 0.75, 16)
+    cms = O.model_forward(sd, bb, heads, "single_instance", x_ref)["SingleInstanceConfmapsHead"]
+    thr = float(cms.mean())
+    layer = SingleInstanceLayer(HipBackend(m, DEV), 2, max_stride=16, preprocess_config=pre, postprocess_config=PostprocessConfig(peak_threshold=thr))
+    x, info = layer.preprocess(img)
+    assert torch.equal(x.squeeze(1).cpu(), x_ref) and torch.allclose(info.eff_scale, eff)
+    out = layer.predict(img)
+    rk, rv = O.single_instance_postprocess(cms, 2, peak_threshold=thr, input_scale=0.75, eff_scale=eff)
+    assert np.allclose(out.pred_keypoints.cpu().numpy().reshape(rk.shape), rk.numpy(), atol=2e-3, equal_nan=True)
