@@ -115,8 +115,9 @@ class InferenceLayer(ABC):
         if cfg.ensure_rgb and x.shape[-3] != 3:
             x = x.repeat(1, 3, 1, 1) if x.shape[-3] == 1 else x
         elif cfg.ensure_grayscale and x.shape[-3] != 1:
-            r, g, b = x.float().unbind(dim=-3)
-            x = (0.2989 * r + 0.587 * g + 0.114 * b).unsqueeze(-3)
+            # torchvision's rgb_to_grayscale (data/normalization.py:37-51): float32 weighted sum in this order, cast back to the input dtype
+            r, g, b = x.unbind(dim=-3)
+            x = r.mul(0.2989).add_(g, alpha=0.587).add_(b, alpha=0.114).unsqueeze(-3).to(x.dtype)
         if not skip_sizematcher and (cfg.max_height is not None or cfg.max_width is not None):
             frames, effs = [], []
             for b in range(B):  # per sample, as the reference does (frames of one batch share a size here, the loop keeps its contract)
