@@ -164,6 +164,11 @@ int ph_model_backward(ph_model* m, const void* input_dev, int32_t in_dtype, int3
 int ph_adam_step(float* params_dev, const float* grads_dev, float* exp_avg_dev, float* exp_avg_sq_dev,
                  float* max_exp_avg_sq_dev, int64_t n, float lr, float beta1, float beta2, float eps,
                  int32_t step, float grad_scale, void* stream);
+/* torch.optim.AdamW step (the reference's other optimizer choice, lightning_modules.py:752-755): decoupled weight decay
+ * param *= 1 - lr * weight_decay, then the Adam update above (torch's default weight_decay is 0.01). */
+int ph_adamw_step(float* params_dev, const float* grads_dev, float* exp_avg_dev, float* exp_avg_sq_dev,
+                  float* max_exp_avg_sq_dev, int64_t n, float lr, float beta1, float beta2, float eps,
+                  float weight_decay, int32_t step, float grad_scale, void* stream);
 
 /* On-device rendering of the training targets (reference: data/confidence_maps.py:96-166
  * generate_multiconfmaps; data/edge_maps.py:15-78,120-220,250-323 generate_pafs).

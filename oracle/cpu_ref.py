@@ -1104,10 +1104,10 @@ def training_step(sd: Dict[str, torch.Tensor], bb: dict, head_cfgs: dict, model_
     return [float(total.detach())] + [float(l.detach()) for l in hl], {k: p.grad for k, p in params.items()}
 
 
-def adam_reference(sd: Dict[str, torch.Tensor], grads_per_step: List[Dict[str, torch.Tensor]], lr=1e-4, amsgrad=False):
-    """torch.optim.Adam itself, stepped with the given gradients."""
+def adam_reference(sd: Dict[str, torch.Tensor], grads_per_step: List[Dict[str, torch.Tensor]], lr=1e-4, amsgrad=False, optimizer: str = "Adam"):
+    """torch.optim.Adam / AdamW themselves (lightning_modules.py:752-763), stepped with the given gradients."""
     params = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
-    opt = torch.optim.Adam(list(params.values()), lr=lr, amsgrad=amsgrad)
+    opt = (torch.optim.AdamW if optimizer == "AdamW" else torch.optim.Adam)(list(params.values()), lr=lr, amsgrad=amsgrad)
     for g in grads_per_step:
         for k, p in params.items():
             p.grad = g[k].clone()

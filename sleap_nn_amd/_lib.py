@@ -51,6 +51,7 @@ SIGNATURES = {
     "ph_render_confmaps": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp]),
     "ph_render_pafs": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp]),
     "ph_adam_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _i32, _f32, _vp]),
+    "ph_adamw_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i32, _f32, _vp]),
     "ph_model_set_profiling": (C.c_int, [_vp, _i32]),
     "ph_model_profile_read": (C.c_int, [_vp, C.POINTER(C.c_double), _i32, C.POINTER(_i32)]),
     "ph_model_set_clock_probe": (C.c_int, [_vp, _vp]),

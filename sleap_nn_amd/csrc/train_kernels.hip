@@ -842,7 +842,7 @@ int64_t input_wgrad_scratch_floats(int cin, int cout) { return (int64_t)ICW_BLOC
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                                    float* __restrict__ vmax, size_t n, float lr, float b1, float b2, float eps, float bc1, float bc2_sqrt,
-                                                   float grad_scale) {
+                                                   float grad_scale, float decay /* 1 - lr * weight_decay (AdamW), 1 for Adam */) {
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
     const float gi = g[i] * grad_scale;
     const float mi = b1 * m[i] + (1.f - b1) * gi;
@@ -855,7 +855,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
       vmax[i] = vv;
     }
     const float denom = sqrtf(vv) / bc2_sqrt + eps;
-    p[i] = p[i] - (lr / bc1) * (mi / denom);
+    p[i] = p[i] * decay - (lr / bc1) * (mi / denom);  // AdamW: param.mul_(1 - lr * weight_decay) first, then the Adam update
   }
 }
 
@@ -977,16 +977,21 @@ int ph_render_pafs(const float* points_dev, const int32_t* edges_dev, int32_t B,
   return PH_OK;
 }
 
-int ph_adam_step(float* params_dev, const float* grads_dev, float* exp_avg_dev, float* exp_avg_sq_dev, float* max_exp_avg_sq_dev, int64_t n, float lr,
-                 float beta1, float beta2, float eps, int32_t step, float grad_scale, void* stream) {
-  PH_REQUIRE(params_dev && grads_dev && exp_avg_dev && exp_avg_sq_dev && n >= 0 && step >= 1, "ph_adam_step: bad arguments");
+int ph_adamw_step(float* params_dev, const float* grads_dev, float* exp_avg_dev, float* exp_avg_sq_dev, float* max_exp_avg_sq_dev, int64_t n, float lr,
+                  float beta1, float beta2, float eps, float weight_decay, int32_t step, float grad_scale, void* stream) {
+  PH_REQUIRE(params_dev && grads_dev && exp_avg_dev && exp_avg_sq_dev && n >= 0 && step >= 1 && weight_decay >= 0.f, "ph_adamw_step: bad arguments");
   if (n == 0) return PH_OK;
   const float bc1 = 1.f - powf(beta1, (float)step);
   const float bc2 = 1.f - powf(beta2, (float)step);
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 16384)), dim3(256), 0, static_cast<hipStream_t>(stream), params_dev, grads_dev,
-                     exp_avg_dev, exp_avg_sq_dev, max_exp_avg_sq_dev, (size_t)n, lr, beta1, beta2, eps, bc1, sqrtf(bc2), grad_scale);
+                     exp_avg_dev, exp_avg_sq_dev, max_exp_avg_sq_dev, (size_t)n, lr, beta1, beta2, eps, bc1, sqrtf(bc2), grad_scale, 1.f - lr * weight_decay);
   PH_HIP_CHECK(hipGetLastError());
   return PH_OK;
+}
+
+int ph_adam_step(float* params_dev, const float* grads_dev, float* exp_avg_dev, float* exp_avg_sq_dev, float* max_exp_avg_sq_dev, int64_t n, float lr,
+                 float beta1, float beta2, float eps, int32_t step, float grad_scale, void* stream) {
+  return ph_adamw_step(params_dev, grads_dev, exp_avg_dev, exp_avg_sq_dev, max_exp_avg_sq_dev, n, lr, beta1, beta2, eps, 0.f, step, grad_scale, stream);
 }
 
 }  // extern "C"

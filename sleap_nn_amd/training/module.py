@@ -37,6 +37,7 @@ class TrainingModule:
     """Owns the device arenas of one model replica and runs training steps."""
 
     def __init__(self, model: Model, device: str = "cuda", lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8, amsgrad: bool = False,
+                 optimizer: str = "Adam", weight_decay: Optional[float] = None,
                  loss_weights: Optional[Sequence[float]] = None, ohkm: Optional[OHKMConfig] = None) -> None:
         L.lib()
         if not torch.cuda.is_available():
@@ -47,6 +48,13 @@ class TrainingModule:
         self.device = dev
         self.model = model.train(True).to(dev)
         self.lr, self.betas, self.eps, self.amsgrad = lr, betas, eps, amsgrad
+        if optimizer not in ("Adam", "AdamW"):
+            raise ValueError(f"optimizer must be 'Adam' or 'AdamW' (lightning_modules.py:752-755), got {optimizer!r}")
+        # torch's defaults, which is what the reference gets: Adam 0 (L2 form, unused here), AdamW 0.01 (decoupled)
+        self.optimizer = optimizer
+        self.weight_decay = (0.01 if optimizer == "AdamW" else 0.0) if weight_decay is None else float(weight_decay)
+        if optimizer == "Adam" and self.weight_decay != 0.0:
+            raise ValueError("Adam with L2 weight decay is not what the reference configures; use optimizer='AdamW'")
         self.loss_weights = [float(w) for w in (loss_weights if loss_weights is not None else [h.loss_weight for h in model.heads])]
         self.ohkm = ohkm or OHKMConfig()
         self.params = model.flat_params().to(dev)
@@ -120,11 +128,11 @@ class TrainingModule:
         self.step_count += 1
         with torch.cuda.device(self.device):
             L.check(
-                L.lib().ph_adam_step(
+                L.lib().ph_adamw_step(
                     C.c_void_p(self.params.data_ptr()), C.c_void_p(self.grads.data_ptr()), C.c_void_p(self.exp_avg.data_ptr()),
                     C.c_void_p(self.exp_avg_sq.data_ptr()), C.c_void_p(self.max_exp_avg_sq.data_ptr()) if self.max_exp_avg_sq is not None else None,
-                    self.params.numel(), float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps), self.step_count, float(grad_scale),
-                    L.current_stream_ptr(),
+                    self.params.numel(), float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.weight_decay), self.step_count,
+                    float(grad_scale), L.current_stream_ptr(),
                 )
             )
         self._push_params()

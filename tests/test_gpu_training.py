@@ -91,13 +91,13 @@ def test_ohkm_loss_and_grads():
 
 def test_adam_steps_match_torch_optim():
     bb, heads, mt = _cfg(8, 8, 2)
-    for amsgrad in (False, True):
-        sd, img, targets, lw, tm = _setup(bb, heads, mt, (48, 64), 2, seed=3, lr=1e-3, amsgrad=amsgrad)
+    for amsgrad, optimizer in ((False, "Adam"), (True, "Adam"), (False, "AdamW")):
+        sd, img, targets, lw, tm = _setup(bb, heads, mt, (48, 64), 2, seed=3, lr=1e-3, amsgrad=amsgrad, optimizer=optimizer)
         grads_seq, cur = [], {k: v.clone() for k, v in sd.items()}
         for step in range(3):
             _, g = O.training_step(cur, bb, heads, mt, img, targets, lw)
             grads_seq.append(g)
-            cur = O.adam_reference(sd, grads_seq, lr=1e-3, amsgrad=amsgrad)
+            cur = O.adam_reference(sd, grads_seq, lr=1e-3, amsgrad=amsgrad, optimizer=optimizer)
             tm.training_step({"image": img, **targets})
         got = tm.state_dict()
         for k, r in cur.items():
