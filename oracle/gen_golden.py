@@ -577,8 +577,43 @@ def centroid_nms_fixture():
     save("centroid_nms.npz", **arrs)
 
 
+def schedulers_fixture():
+    """The reference's two closed-form schedulers (training/schedulers.py) and torch's StepLR / ReduceLROnPlateau as
+    configure_optimizers builds them (lightning_modules.py:800-857): learning rate after each of 30 epochs."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("ref_schedulers", os.path.join(rh.REFERENCE_ROOT, "sleap_nn", "training", "schedulers.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    arrs = {}
+    g = torch.Generator().manual_seed(5)
+    losses = (torch.rand(30, generator=g) * 0.1 + torch.linspace(1.0, 0.6, 30).clamp(min=0.75)).tolist()  # plateaus after ~19 epochs
+
+    def run(make, use_loss=False):
+        p = [torch.nn.Parameter(torch.zeros(1))]
+        opt = torch.optim.Adam(p, lr=1e-3)
+        sch = make(opt)
+        out = [opt.param_groups[0]["lr"]]
+        for e in range(30):
+            opt.step()
+            sch.step(losses[e]) if use_loss else sch.step()
+            out.append(opt.param_groups[0]["lr"])
+        return np.array(out, dtype=np.float64)
+
+    arrs["cosine"] = run(lambda o: mod.LinearWarmupCosineAnnealingLR(o, warmup_epochs=4, max_epochs=25, warmup_start_lr=1e-5, eta_min=1e-6))
+    arrs["cosine_nowarm"] = run(lambda o: mod.LinearWarmupCosineAnnealingLR(o, warmup_epochs=0, max_epochs=20))
+    arrs["linear"] = run(lambda o: mod.LinearWarmupLinearDecayLR(o, warmup_epochs=5, max_epochs=28, warmup_start_lr=0.0, end_lr=2e-5))
+    arrs["step"] = run(lambda o: torch.optim.lr_scheduler.StepLR(o, step_size=7, gamma=0.3))
+    arrs["plateau_abs"] = run(lambda o: torch.optim.lr_scheduler.ReduceLROnPlateau(o, mode="min", threshold=1e-6, threshold_mode="abs", cooldown=3, patience=2, factor=0.5, min_lr=1e-8), True)
+    arrs["plateau_rel"] = run(lambda o: torch.optim.lr_scheduler.ReduceLROnPlateau(o, mode="min", threshold=0.05, threshold_mode="rel", cooldown=0, patience=1, factor=0.1, min_lr=2e-5), True)
+    arrs["losses"] = np.array(losses, dtype=np.float64)
+    save("schedulers.npz", **arrs)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
+    if not only or "schedulers" in only:
+        schedulers_fixture()
     if not only or "core" in only:
         core_fixtures()
     if not only or "topdown" in only:

@@ -356,3 +356,30 @@ def test_winograd_f23_identity_used_by_the_conv_kernels():
     y1 = (m[:, 1] - m[:, 2]) - m[:, 3]
     assert np.allclose(y0, (d[:, 0:3] * g).sum(1), atol=1e-12)
     assert np.allclose(y1, (d[:, 1:4] * g).sum(1), atol=1e-12)
+
+
+def test_lr_schedules_match_the_reference_and_torch():
+    """training/schedulers.py: the four policies of configure_optimizers, epoch by epoch, against learning-rate sequences
+    produced by the reference's own scheduler classes and torch.optim.lr_scheduler (tests/golden/schedulers.npz)."""
+    from sleap_nn_amd.training.schedulers import LRSchedule
+    from tests import _golden as G
+
+    z = G.load("schedulers.npz")
+    losses = z["losses"].tolist()
+    cases = {
+        "cosine": ({"cosine_annealing_warmup": {"warmup_epochs": 4, "max_epochs": 25, "warmup_start_lr": 1e-5, "eta_min": 1e-6}}, None),
+        "cosine_nowarm": ({"cosine_annealing_warmup": {"warmup_epochs": 0, "max_epochs": None}}, 20),
+        "linear": ({"linear_warmup_linear_decay": {"warmup_epochs": 5, "max_epochs": 28, "warmup_start_lr": 0.0, "end_lr": 2e-5}}, None),
+        "step": ({"step_lr": {"step_size": 7, "gamma": 0.3}}, None),
+        "plateau_abs": ({"reduce_lr_on_plateau": {"threshold": 1e-6, "threshold_mode": "abs", "cooldown": 3, "patience": 2, "factor": 0.5, "min_lr": 1e-8}}, None),
+        "plateau_rel": ({"reduce_lr_on_plateau": {"threshold": 0.05, "threshold_mode": "rel", "cooldown": 0, "patience": 1, "factor": 0.1, "min_lr": 2e-5}}, None),
+    }
+    for name, (cfg, max_epochs) in cases.items():
+        s = LRSchedule(1e-3, cfg, max_epochs=max_epochs)
+        got = [s.lr] + [s.step(losses[e]) for e in range(30)]
+        assert np.allclose(got, z[name], rtol=1e-12, atol=0), (name, got[:8], z[name][:8])
+    # priority when several are set, and the constant default
+    s = LRSchedule(1e-3, {"step_lr": {"step_size": 1, "gamma": 0.5}, "cosine_annealing_warmup": {"warmup_epochs": 0, "max_epochs": 10}, "reduce_lr_on_plateau": {}})
+    assert s.kind == "cosine_annealing_warmup"
+    s = LRSchedule(2e-4, None)
+    assert [s.step() for _ in range(3)] == [2e-4] * 3
