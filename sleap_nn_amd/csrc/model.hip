@@ -177,7 +177,11 @@ static void pack_gemm(const T* w, int cout, int cin0, int cin1, int taps, int bn
     }
 }
 
-int choose_bn(int coutp) { return coutp >= 64 ? 64 : 32; }
+int choose_bn(int coutp) {
+  static const int force = getenv("PH_CONV_BN") ? atoi(getenv("PH_CONV_BN")) : 0;  // experiment knob: 32 = N tile 32 for every 3x3 conv
+  if (force == 32) return 32;
+  return coutp >= 64 ? 64 : 32;
+}
 
 int build_plan(const ph_model* m, int B, int H, int W, Plan& plan) {
   plan.slots.assign(m->n_slots, SlotShape());
