@@ -1003,6 +1003,9 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv3x3_wino_persist_kernel(Con
   const int offB = lh * 128 + lx * 4;
   float* const abuf = lds;
   float* const bbuf = lds + 2 * A_FLOATS;
+#ifdef PH_WINO_EXTRA_VALU
+  unsigned extra_valu = 0;
+#endif
 
   auto run = [&](auto late) {
     constexpr bool LATE = decltype(late)::value;
@@ -1092,6 +1095,10 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv3x3_wino_persist_kernel(Con
 #pragma unroll
             for (int n = 0; n < NT; ++n) acc[q & 3][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[fcur][j], bf[fcur][n][j], acc[q & 3][n], 0, 0, 0);
           if (q + 1 < 24) make_a(q + 1, fcur ^ 1);
+#ifdef PH_WINO_EXTRA_VALU  // timing experiment: what does one more VALU instruction per step cost the MFMA stream?
+#pragma unroll
+          for (int e = 0; e < PH_WINO_EXTRA_VALU; ++e) asm volatile("v_add_u32 %0, %0, 1" : "+v"(extra_valu));
+#endif
           const bool has_dma = q < A_SLOTS + BH_SLOTS || (q >= 12 && q < 12 + BH_SLOTS);
           // Pinned order: the step's first MFMAs, THEN the LDS reads of the next step.  The compiler's wait before the first MFMA is
           // always lgkmcnt(0) here (an LDS-DMA instruction marks the counter out-of-order for its scoreboard), so reads issued
