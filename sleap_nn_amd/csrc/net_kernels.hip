@@ -888,6 +888,9 @@ int launch_wino_pack(const float* wpack, float* wino, int panels, int bn, hipStr
   return PH_OK;
 }
 
+#ifndef PH_WINO_BUF
+#define PH_WINO_BUF 0  // 1: halo pieces via buffer_load ... lds (32-bit per-lane offsets, hardware range check) instead of global_load_lds
+#endif
 #ifndef PH_WINO_EXP
 #define PH_WINO_EXP 0  // timing experiments only (results are wrong): 1 no mid barrier, 2 no DMA in the K loop, 4 no input transform, 8 no epilogue, 16 no epilogue stores
 #endif
@@ -957,11 +960,38 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv3x3_wino_persist_kernel(Con
     }
   };
 
-  int f_pix[A_SLOTS];
-  unsigned f_ok = 0;
   const float* p_src = a.src0;
   const float* p_w = a.wpack_wino;
   int p_cp = a.c0p, p_coff = 0;
+#if PH_WINO_BUF && defined(__HIP_DEVICE_COMPILE__)  // (the descriptor type exists in the device pass only; the host pass never runs this body)
+  // Halo pieces through a buffer descriptor: the per-lane part of the address is ONE 32-bit offset per slot, computed when the
+  // (tile, source) changes; the channel offset of the chunk travels in the scalar offset; out-of-image lanes carry an offset
+  // beyond the tensor, which the range check turns into zeros.  No per-piece VALU address arithmetic in the K loop (every VALU
+  // instruction there costs ~5 MFMA cycles).
+  unsigned f_off[A_SLOTS];
+  __amdgpu_buffer_rsrc_t p_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.src0, 0, (int)((unsigned)(a.B * a.H * a.W) * (unsigned)(a.c0p * 4)), 0x00020000);
+  auto select_fetch = [&](const Plan& P, int ch) {
+    if (ch < chunks0) {
+      p_src = a.src0;
+      p_cp = a.c0p;
+      p_coff = ch * KC;
+    } else {
+      p_src = a.src1;
+      p_cp = a.c1p;
+      p_coff = (ch - chunks0) * KC;
+    }
+    p_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p_src, 0, (int)((unsigned)(a.B * a.H * a.W) * (unsigned)(p_cp * 4)), 0x00020000);
+#pragma unroll
+    for (int s = 0; s < A_SLOTS; ++s) f_off[s] = ((P.a_ok >> s) & 1u) ? (unsigned)P.a_pix[s] * (unsigned)(p_cp * 4) + (unsigned)(dq * 16) : 0xFFFFFFFFu;
+    p_w = a.wpack_wino + ((size_t)P.ntile * nchunks + ch) * (2 * BH_FLOATS);
+  };
+  auto dma_a = [&](int s, float* abuf) {
+    const int p = min(wave + WAVES * s, W_A_PIECES - 1);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(p_rsrc, (__attribute__((address_space(3))) void*)(abuf + p * 256), 16, f_off[s], p_coff * 4, 0, 0);
+  };
+#else
+  int f_pix[A_SLOTS];
+  unsigned f_ok = 0;
   auto select_fetch = [&](const Plan& P, int ch) {
 #pragma unroll
     for (int s = 0; s < A_SLOTS; ++s) f_pix[s] = P.a_pix[s];
@@ -984,6 +1014,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv3x3_wino_persist_kernel(Con
     const float* g = ((f_ok >> s) & 1u) ? real : zero;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)(abuf + p * 256), 16, 0, 0);
   };
+#endif
   auto dma_b = [&](int s, int half, float* bhalf) {
     const int pb = min(wave + WAVES * s, BH_PIECES - 1);
     const float* g = p_w + half * BH_FLOATS + pb * 256 + lane * 4;
