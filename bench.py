@@ -1,27 +1,42 @@
 """Benchmark of the hot path: bottom-up UNet 1024x1024 inference (BASELINE.json cfg3).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--scaling weak|strong] [--mode infer|train]
 
-One *step* = one pass of the hot path over one per-GPU batch of synthetic frames that are
-already resident in HBM: uint8 frames -> UNet forward (random-init weights of the cfg3
-architecture, every kernel a hand-written gfx950 kernel) -> local peaks + integral refinement ->
-PAF line scoring -> D2H of the scored candidates -> C++ matching/assembly -> NaN-padded
-keypoints on the host.  Because random weights give meaningless peaks, the post-process stage
-consumes *rendered* heads with 6 animals/frame that are equally resident in
-HBM; forward and post-process both run in full inside every step, back to back on one stream.
+One *step* (``--mode infer``, the headline) = one pass of the hot path over one per-GPU batch of synthetic
+frames: uint8 frames -> UNet forward (random-init weights of the cfg3 architecture, every kernel a hand-written
+gfx950 kernel, replayed as one hipGraph) -> local peaks + integral refinement -> PAF line scoring -> D2H of the
+scored candidates -> C++ matching/assembly -> NaN-padded keypoints on the host.  Because random weights give
+meaningless peaks, the post-process stage consumes *rendered* heads with 6 animals/frame
+that are equally resident in HBM; forward and post-process both run in full inside every step, back to back on
+one stream.
 
-Multi-GPU: one process per GPU (torch.distributed / RCCL), frames sharded across ranks, no
-data-path collective (frames are independent) -> weak scaling, value = total frames / max time.
+``value`` is measured with the frames already resident in HBM (the bench contract).  The same number of steps is
+then timed a second time with the uint8 frames starting in pinned HOST memory, copied asynchronously on a copy
+stream under the previous step's kernels (double-buffered) -- SURVEY section 8(d)'s H2D-inclusive frame time; it
+is reported as ``h2d_inclusive`` and is never ``value``.
 
-Prints ONE JSON line on rank 0 with the contract fields plus `roofline` (dominant kernel =
-the MFMA conv3x3, HIP-event timed inside the timed region) and `cpu_baseline` (the oracle on
-the host cores, N=1 only).
+Multi-GPU: one process per GPU (torch.distributed / RCCL).  ``python bench.py --gpus N`` without a launcher
+starts the N ranks ITSELF (a child ``python -m torch.distributed.run``, before this process touches the GPU)
+and fails if the job ends up with a different number of ranks.  Frames are sharded across ranks, no data-path
+collective (frames are independent).  ``--scaling weak`` (default): ``--batch`` frames per GPU per step;
+``--scaling strong``: ``--global-batch`` (32 = BASELINE cfg3) frames per step split into contiguous chunks of
+32/G per rank.  value = total frames / max-over-ranks time.
+
+Prints ONE JSON line on rank 0 with the contract fields plus ``roofline`` (dominant kernel = the MFMA conv3x3,
+HIP-event timed inside the timed region), ``step_ms`` (median / p10 / p90 of the per-step GPU time) and, at N=1,
+``cpu_baseline`` (the oracle on the host cores at 1 and at all threads, with the parity of the HIP path against it
+on the very frames it timed).
+
+``--mode train`` times data-parallel training steps (forward + MSE + backward + gradient all-reduce + Adam) of the
+cfg3 UNet or the cfg4 ConvNeXt-tiny (``--train-config``); see run_train().
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -39,16 +54,21 @@ CFG3_HEADS = {"confmaps": {"part_names": NODES, "sigma": 2.5, "output_stride": 4
               "pafs": {"edges": [[NODES[i], NODES[i + 1]] for i in range(12)], "sigma": 75.0, "output_stride": 8, "loss_weight": 1.0}}
 SIZE = 1024
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32-input MFMA = 64 FLOP/clk/SIMD * 1024 SIMDs * 2.4 GHz
+MFMA_F16_PEAK_TFLOPS = 2516.6  # MI355X_MICROARCH.md: dense fp16/bf16 MFMA (no sparsity)
+
+CFG4_BB = {"in_channels": 1, "model_type": "tiny", "arch": None, "stem_patch_kernel": 4, "stem_patch_stride": 2, "kernel_size": 3, "filters_rate": 2,
+           "convs_per_block": 2, "up_interpolate": True, "output_stride": 2, "max_stride": 32}
+CFG4_HEADS = {"confmaps": {"part_names": NODES, "sigma": 2.5, "output_stride": 2, "loss_weight": 1.0, "anchor_part": None}}
 
 
-def synthetic_instances(batch: int, distinct: int = 8) -> torch.Tensor:
+def synthetic_instances(batch: int, distinct: int = 8, size: int = SIZE) -> torch.Tensor:
     """(B, 6, 13, 2) keypoints: per frame 6 animals, centres U(150, S-150), node offsets N(0, 40 px), seed 777+b
     (BASELINE.md section 3); `distinct` different frames, repeated to fill the batch."""
     pts = []
     for b in range(min(batch, distinct)):
         rng = np.random.RandomState(777 + b)
-        centres = rng.uniform(150, SIZE - 150, size=(6, 1, 2))
-        pts.append(np.clip(centres + rng.normal(0, 40, size=(6, 13, 2)), 8, SIZE - 9).astype(np.float32))
+        centres = rng.uniform(min(150, size / 4), size - min(150, size / 4), size=(6, 1, 2))
+        pts.append(np.clip(centres + rng.normal(0, 40, size=(6, 13, 2)), 8, size - 9).astype(np.float32))
     reps = (batch + len(pts) - 1) // len(pts)
     return torch.from_numpy(np.stack(pts)).repeat(reps, 1, 1, 1)[:batch].contiguous()
 
@@ -66,16 +86,42 @@ def rendered_heads(batch: int, device):
     return cms, pafs
 
 
-def cpu_baseline(sd, cms, pafs, budget_s: float = 20.0):
-    """Oracle (torch-CPU restatement of the reference, kind = "port") on the host cores, on the same weights
-    and the same rendered heads as the GPU leg.  The only place bench.py touches oracle/."""
+def cpu_baseline(model, layer, cms_dev, pafs_dev, dev, budget_s: float = 24.0):
+    """Oracle (torch-CPU restatement of the reference, kind = "port") on the host cores, on the same weights, the same
+    frame and the same rendered heads as the GPU leg -- and the parity of the HIP path against it on exactly those
+    inputs (SURVEY section 8d "CPU baseline timing").  The only place bench.py touches oracle/."""
     from oracle import cpu_ref as O
+    from sleap_nn_amd.inference.ops.peaks import find_local_peaks
+    from sleap_nn_amd.inference.preprocess_info import PreprocInfo
 
+    sd = model.state_dict()
     g = torch.Generator().manual_seed(4321)
     img = torch.randint(0, 256, (1, 1, SIZE, SIZE), dtype=torch.uint8, generator=g)
-    # pick the fastest thread count among a few candidates (oneDNN degrades badly when
-    # oversubscribed on big hosts): one probe forward each, bounded
+    cms, pafs = cms_dev[:2].cpu(), pafs_dev[:2].cpu()
+    scorer = O.PAFScorerRef(NODES, [tuple(e) for e in CFG3_HEADS["pafs"]["edges"]], 8)
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+
+    def timed(threads, fwd_budget, post_budget, max_n):
+        torch.set_num_threads(threads)
+        with torch.inference_mode():
+            O.model_forward(sd, CFG3_BB, CFG3_HEADS, "bottomup", img[:, :, :256, :256])  # thread-pool warm-up
+            t_f, n_f, ref = 0.0, 0, None
+            t0 = time.perf_counter()
+            while n_f < 2 or (time.perf_counter() - t0 < fwd_budget and n_f < max_n):
+                t = time.perf_counter()
+                ref = O.model_forward(sd, CFG3_BB, CFG3_HEADS, "bottomup", img)
+                t_f += time.perf_counter() - t
+                n_f += 1
+            t_p, n_p, post = 0.0, 0, None
+            t0 = time.perf_counter()
+            while n_p < 2 or (time.perf_counter() - t0 < post_budget and n_p < max_n):
+                t = time.perf_counter()
+                post = O.bottomup_postprocess(cms, pafs, scorer, 4)
+                t_p += time.perf_counter() - t
+                n_p += 1
+        return t_f / n_f, t_p / (n_p * cms.shape[0]), n_f, n_p, ref, post
+
+    # all threads: pick the best of a few pool sizes with one short probe each (oneDNN degrades when oversubscribed on big hosts)
     best_t, best = avail, float("inf")
     with torch.inference_mode():
         for th in sorted({min(avail, c) for c in (avail, 64, 32, 16, 8)}, reverse=True):
@@ -86,90 +132,146 @@ def cpu_baseline(sd, cms, pafs, budget_s: float = 20.0):
             dt = time.perf_counter() - t
             if dt < best:
                 best, best_t = dt, th
+    f_n, p_n, n_f, n_p, ref, post = timed(best_t, budget_s * 0.45, budget_s * 0.1, 20)
+    f_1, p_1, n_f1, n_p1, _, _ = timed(1, budget_s * 0.35, budget_s * 0.1, 4)
     torch.set_num_threads(best_t)
-    scorer = O.PAFScorerRef(NODES, [tuple(e) for e in CFG3_HEADS["pafs"]["edges"]], 8)
-    with torch.inference_mode():
-        O.model_forward(sd, CFG3_BB, CFG3_HEADS, "bottomup", img)  # warm-up
-        O.bottomup_postprocess(cms[:1], pafs[:1], scorer, 4)
-        t_f, n_f = 0.0, 0
-        t0 = time.perf_counter()
-        while n_f < 3 or (time.perf_counter() - t0 < budget_s * 0.7 and n_f < 20):
-            t = time.perf_counter()
-            O.model_forward(sd, CFG3_BB, CFG3_HEADS, "bottomup", img)
-            t_f += time.perf_counter() - t
-            n_f += 1
-        t_p, n_p = 0.0, 0
-        t0 = time.perf_counter()
-        while n_p < 2 or (time.perf_counter() - t0 < budget_s * 0.3 and n_p < 20):
-            t = time.perf_counter()
-            O.bottomup_postprocess(cms, pafs, scorer, 4)
-            t_p += time.perf_counter() - t
-            n_p += 1
-    per_frame = t_f / n_f + t_p / (n_p * cms.shape[0])
+
+    # ---- parity of the HIP path on the same inputs
+    out = model.forward(img.to(dev))
+    d_cms = float((out["MultiInstanceConfmapsHead"].cpu() - ref["MultiInstanceConfmapsHead"]).abs().max())
+    d_paf = float((out["PartAffinityFieldsHead"].cpu() - ref["PartAffinityFieldsHead"]).abs().max())
+    rp, rv, rb, rc = O.find_local_peaks(cms, 0.2, None)
+    gp, gv, gb, gc = [t.cpu() for t in find_local_peaks(cms_dev[:2], 0.2, None)]
+    peaks_equal = bool(gp.shape == rp.shape and torch.equal(gp, rp) and torch.equal(gv, rv) and torch.equal(gb, rb) and torch.equal(gc, rc))
+    got = layer.postprocess({"MultiInstanceConfmapsHead": cms_dev[:2], "PartAffinityFieldsHead": pafs_dev[:2]}, PreprocInfo(eff_scale=torch.ones(2)))
+    rk, rvals, rs = post
+    k = got.pred_keypoints.numpy()
+    grouping_equal = bool(k.shape == rk.shape and np.array_equal(np.isnan(k), np.isnan(rk)) and np.allclose(k, rk, atol=1e-3, equal_nan=True)
+                          and np.allclose(got.instance_scores.numpy(), rs, atol=1e-4, equal_nan=True))
     return {
-        "value": 1.0 / per_frame, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-        "sample": f"{n_f} forwards of 1 frame 1024x1024 ({1e3 * t_f / n_f:.0f} ms each) + {n_p} post-process passes over 2 rendered frames "
-                  f"({1e3 * t_p / (n_p * cms.shape[0]):.1f} ms/frame); oracle/cpu_ref.py, torch-CPU fp32",
+        "value": 1.0 / (f_n + p_n), "unit": "frames/s", "cores": best_t, "kind": "port",
+        "value_1thread": 1.0 / (f_1 + p_1),
+        "sample": f"{n_f} forwards of 1 frame 1024x1024 ({1e3 * f_n:.0f} ms each at {best_t} threads; {n_f1} at 1 thread: {1e3 * f_1:.0f} ms) + "
+                  f"{n_p} post-process passes over 2 rendered frames ({1e3 * p_n:.1f} ms/frame); oracle/cpu_ref.py, torch-CPU fp32",
+        "parity_on_this_sample": {"max_abs_confmap_diff": d_cms, "max_abs_paf_diff": d_paf, "peak_indices_equal": peaks_equal,
+                                  "n_peaks": int(rp.shape[0]), "grouping_equal": grouping_equal, "n_instances": int((~np.isnan(rs)).sum())},
     }
 
 
 PROFILE_EVERY = 4  # steps of the timed region whose forward records per-op HIP events: 0, 4, 8, ...
 
 
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(n: int) -> int:
+    """Start the N ranks as a CHILD torchrun job (this process has not touched the GPU; it only waits)."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def percentiles(ms):
+    a = np.asarray(ms, dtype=np.float64)
+    return {"median": float(np.median(a)), "p10": float(np.percentile(a, 10)), "p90": float(np.percentile(a, 90)), "n": int(a.size)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=32, help="frames per GPU per step")
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=32, help="frames per GPU per step (weak scaling)")
+    ap.add_argument("--global-batch", type=int, default=32, help="frames per step over all GPUs (strong scaling)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--mode", choices=["infer", "train"], default="infer")
+    ap.add_argument("--train-config", choices=["cfg3", "cfg4"], default="cfg3")
+    ap.add_argument("--dtype", choices=["f32", "f16"], default="f32", help="f16 = the autocast-equivalent fp16-MFMA mode, a separate measurement")
+    ap.add_argument("--no-graph", action="store_true", help="launch the forward kernel by kernel instead of replaying one hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-h2d-leg", action="store_true")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if torch.cuda.device_count() < world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but only {torch.cuda.device_count()} GPUs are visible")
     import torch.distributed as dist
 
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         dist.init_process_group(backend="nccl", device_id=dev)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"bench.py: RCCL sees {dist.get_world_size()} ranks, --gpus asked for {args.gpus}")
         # ranks share the host: keep torch's CPU pool (synthetic-input rendering only) to a fair share
         torch.set_num_threads(max(1, (os.cpu_count() or world) // world))
+    ctx = {"rank": rank, "world": world, "dev": dev, "dist": dist}
+    res = run_train(args, ctx) if args.mode == "train" else run_infer(args, ctx)
+    if rank == 0:
+        print(json.dumps(res))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def run_infer(args, ctx):
+    rank, world, dev, dist = ctx["rank"], ctx["world"], ctx["dev"], ctx["dist"]
+    from concurrent.futures import ThreadPoolExecutor
 
     from sleap_nn_amd.architectures.model import Model
     from sleap_nn_amd.inference.backends import HipBackend
     from sleap_nn_amd.inference.layers import BottomUpLayer
     from sleap_nn_amd.inference.ops.paf import PAFScorer
     from sleap_nn_amd.inference.preprocess_info import PreprocInfo
+    from sleap_nn_amd.inference.streaming import group_scored_batch
+    from sleap_nn_amd.parallel import shard_bounds
 
-    B = args.batch
+    if args.scaling == "strong":
+        lo, hi = shard_bounds(args.global_batch, world, rank)  # rank-contiguous chunk of the global batch
+        B, global_batch = hi - lo, args.global_batch
+        if B <= 0:
+            raise SystemExit(f"--global-batch {args.global_batch} leaves rank {rank} of {world} without frames")
+    else:
+        B, global_batch, lo = args.batch, args.batch * world, rank * args.batch
+    fp16 = args.dtype == "f16"
     model = Model("unet", CFG3_BB, CFG3_HEADS, "bottomup")
     model.init_xavier_(seed=1234, head_scale=0.05)  # the reference's xavier_init_weights; heads x0.05 keep outputs O(1)
-    layer = BottomUpLayer(HipBackend(model, str(dev)), PAFScorer.from_config(CFG3_HEADS), 4, 8, max_stride=32)
-    g = torch.Generator().manual_seed(4321 + rank)
-    frames = torch.randint(0, 256, (B, 1, 1, SIZE, SIZE), dtype=torch.uint8, generator=g).to(dev)
+    use_graph = not args.no_graph
+    backend = HipBackend(model, str(dev), use_graph=use_graph, **({"use_fp16": True} if fp16 else {}))
+    eager = HipBackend(model, str(dev), **({"use_fp16": True} if fp16 else {})) if use_graph else backend  # same model handle: the profiled steps launch kernel by kernel
+    layer = BottomUpLayer(backend, PAFScorer.from_config(CFG3_HEADS), 4, 8, max_stride=32)
+    g = torch.Generator().manual_seed(4321)
+    all_frames = torch.randint(0, 256, (max(global_batch, 1), 1, 1, SIZE, SIZE), dtype=torch.uint8, generator=g) if args.scaling == "strong" else None
+    if all_frames is not None:
+        host_frames = all_frames[lo:lo + B].contiguous().pin_memory()
+    else:
+        g = torch.Generator().manual_seed(4321 + rank)
+        host_frames = torch.randint(0, 256, (B, 1, 1, SIZE, SIZE), dtype=torch.uint8, generator=g).pin_memory()
+    frames = host_frames.to(dev)
     cms, pafs = rendered_heads(B, dev)
     info = PreprocInfo(original_size=(SIZE, SIZE), processed_size=(SIZE, SIZE), eff_scale=torch.ones(B), output_stride=4)
 
-    from concurrent.futures import ThreadPoolExecutor
-
-    from sleap_nn_amd.inference.streaming import group_scored_batch
-
     pool = ThreadPoolExecutor(max_workers=1)
     params = layer.grouping_params()
-    pending = []
+    pending, inflight = [], []
 
-    inflight = []
-
-    def step():
+    def step(x, profiled=False):
         """Forward + peaks + PAF scoring + async D2H are enqueued for this batch; then the PREVIOUS batch's
         results (its D2H event fired long ago) are handed to the C++ grouping worker.  The GPU always has the
         next batch queued and the grouping of batch k-1 overlaps the GPU work of batch k
         (Predictor._predict_streaming_pipelined).  Every batch is grouped before the closing barrier."""
-        raw = layer.backend(frames)  # uint8 frames -> {"MultiInstanceConfmapsHead", "PartAffinityFieldsHead"}
+        raw = (eager if profiled else backend)(x)  # uint8 frames -> {"MultiInstanceConfmapsHead", "PartAffinityFieldsHead"}
         inflight.append(layer._enqueue_scoring({"MultiInstanceConfmapsHead": cms, "PartAffinityFieldsHead": pafs}, info))
         if len(inflight) > 1:
             pending.append(pool.submit(group_scored_batch, layer._finish_scoring(inflight.pop(0)), params))
@@ -188,114 +290,158 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(max(args.warmup, 1)):
-        raw, out = step()
+    for i in range(max(args.warmup, 2)):
+        raw, out = step(frames, profiled=(i == 0))
     out = drain()[-1]
     torch.cuda.synchronize()
     n_inst = int((~torch.isnan(out.instance_scores)).sum())
     assert n_inst >= 5 * B, f"post-process found only {n_inst} instances in {B} frames"
     assert all(torch.isfinite(v).all() for v in raw.values())
 
-    # HIP-event timing of every op runs INSIDE the timed region, on every PROFILE_EVERY-th step (26 event records per forward
-    # cost ~0.6 ms of a 19 ms step; sampling a quarter of the steps keeps the roofline figures live at a quarter of that)
+    # ---- timed region 1 (the contract's `value`): frames resident in HBM.  HIP-event timing of every op runs INSIDE it, on
+    # every PROFILE_EVERY-th step (those steps launch the forward kernel by kernel with ~26 event records, the others replay
+    # the hipGraph); one event per step on the compute stream gives the per-step GPU times.
     model.set_profiling(True)
     model.set_profiling(False)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     barrier()
     t0 = time.perf_counter()
+    marks[0].record()
     for i in range(args.steps):
-        model.set_profiling(i % PROFILE_EVERY == 0, resume=True)
-        step()
+        prof = i % PROFILE_EVERY == 0
+        model.set_profiling(prof, resume=True)
+        step(frames, profiled=prof)
+        marks[i + 1].record()
     drain()
     barrier()
     elapsed = time.perf_counter() - t0
     op_ms, n_fw = model.read_profile()
     model.set_profiling(False)
+    step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    # ---- timed region 2: the same steps with the uint8 frames coming from pinned host memory (H2D on a copy stream, double
+    # buffered, overlapped with the previous step's kernels)
+    elapsed_h2d = None
+    if not args.no_h2d_leg:
+        copy_stream = torch.cuda.Stream(dev)
+        bufs = [torch.empty_like(frames), torch.empty_like(frames)]
+        landed = [torch.cuda.Event(), torch.cuda.Event()]
+        consumed = [torch.cuda.Event(), torch.cuda.Event()]
+
+        def upload(k):
+            with torch.cuda.stream(copy_stream):
+                copy_stream.wait_event(consumed[k & 1])  # the step that last read this buffer is done with it
+                bufs[k & 1].copy_(host_frames, non_blocking=True)
+                landed[k & 1].record(copy_stream)
+
+        for e in consumed:
+            e.record()
+        upload(0)
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            upload(i + 1)  # rides under step i's kernels
+            torch.cuda.current_stream().wait_event(landed[i & 1])
+            step(bufs[i & 1])
+            consumed[i & 1].record()
+        drain()
+        barrier()
+        elapsed_h2d = time.perf_counter() - t0
+
+    t = torch.tensor([elapsed, elapsed_h2d or 0.0], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    elapsed, elapsed_h2d = float(t[0].item()), (float(t[1].item()) if elapsed_h2d is not None else None)
+    if rank != 0:
+        return None
 
-    if rank == 0:
-        from sleap_nn_amd import _lib as L
+    from sleap_nn_amd import _lib as L
 
-        table = model.op_table(B, SIZE, SIZE)
-        conv_rows = [(r, ms / max(n_fw, 1)) for r, ms in zip(table, op_ms) if r["kind"] == L.OP_CONV]
-        conv_flops = sum(r["flops"] for r, _ in conv_rows)
-        conv_ms = sum(ms for _, ms in conv_rows)
-        # whole conv stack = those launches + the fused stem (conv0 on VALU + conv1 on MFMA 16x16x4 + pool)
-        stack_rows = [(r, ms / max(n_fw, 1)) for r, ms in zip(table, op_ms) if r["kind"] in (L.OP_CONV, L.OP_STEM, L.OP_INPUT_CONV)]
-        stack_flops = sum(r["flops"] for r, _ in stack_rows)
-        stack_ms = sum(ms for _, ms in stack_rows)
-        fwd_ms = sum(op_ms) / max(n_fw, 1)
-        # FLOP accounting.  `direct_tflops` prices a launch at the direct-convolution count 2*Cin*Cout*9*H*W.  The kernel
-        # that runs is Winograd F(2,3) along x: 4 multiplications per output pair and kernel row instead of 6, i.e. 2/3 of those
-        # FLOPs go through the matrix cores (the input/output transforms are VALU adds).  `achieved` is what the MFMA pipe executes --
-        # the figure a roofline against the MFMA peak is about; the direct-equivalent rate is reported next to it.
-        direct_tflops = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
-        wino = os.environ.get("PH_CONV_WINO", "1") != "0"
-        mfma_share = 2.0 / 3.0 if wino else 1.0
-        achieved = direct_tflops * mfma_share
-        # HBM traffic of the conv launches: measured with rocprofv3 PMC passes (FETCH_SIZE x2 gfx950
-        # correction, WRITE_SIZE; tools/summarize_pmc.py) on this same command and committed under
-        # profiles/; bench.py itself cannot read PMCs, so it reports the newest committed figure.
-        traffic, traffic_src = None, None
-        import glob
+    table = model.op_table(B, SIZE, SIZE)
+    conv_rows = [(r, ms / max(n_fw, 1)) for r, ms in zip(table, op_ms) if r["kind"] == L.OP_CONV]
+    conv_flops = sum(r["flops"] for r, _ in conv_rows)
+    conv_ms = sum(ms for _, ms in conv_rows)
+    # whole conv stack = those launches + the fused stem (conv0 on VALU + conv1 on MFMA 16x16x4 + pool)
+    stack_rows = [(r, ms / max(n_fw, 1)) for r, ms in zip(table, op_ms) if r["kind"] in (L.OP_CONV, L.OP_STEM, L.OP_INPUT_CONV)]
+    stack_flops = sum(r["flops"] for r, _ in stack_rows)
+    stack_ms = sum(ms for _, ms in stack_rows)
+    fwd_ms = sum(op_ms) / max(n_fw, 1)
+    # FLOP accounting.  `direct_tflops` prices a launch at the direct-convolution count 2*Cin*Cout*9*H*W.  The kernel
+    # that runs is Winograd F(2,3) along x: 4 multiplications per output pair and kernel row instead of 6, i.e. 2/3 of those
+    # FLOPs go through the matrix cores (the input/output transforms are VALU adds).  `achieved` is what the MFMA pipe executes --
+    # the figure a roofline against the MFMA peak is about; the direct-equivalent rate is reported next to it and is NOT a
+    # roofline fraction (it exceeds 1 by construction when the pipe is > 2/3 busy).
+    direct_tflops = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+    wino = model._options.get("conv_wino", 1.0) != 0.0
+    mfma_share = 2.0 / 3.0 if wino else 1.0
+    achieved = direct_tflops * mfma_share
+    peak = MFMA_F16_PEAK_TFLOPS if fp16 else MFMA_F32_PEAK_TFLOPS
+    # HBM traffic of the conv launches: measured with rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction, WRITE_SIZE;
+    # tools/summarize_pmc.py) on this same command and committed under profiles/; bench.py itself cannot read PMCs, so it
+    # reports the newest committed figure whose launch count matches this run.
+    traffic, traffic_src = None, None
+    import glob
 
-        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_conv_traffic.json")))
-        if cands and B == 32:
-            try:
-                tj = json.load(open(cands[-1]))["conv3x3_mfma"]
-                if int(round(tj["launches_per_forward"])) == len(conv_rows):
-                    traffic, traffic_src = tj["hbm_bytes_per_launch"], os.path.relpath(cands[-1], ROOT)
-            except Exception:
-                pass
-        conv_bytes = sum(r["bytes"] for r, _ in conv_rows)
-        frames_total = B * world * args.steps
-        res = {
-            "metric": "frames/sec bottom-up UNet 1024x1024 inference",
-            "value": frames_total / elapsed,
-            "unit": "frames/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f32",
-            "data": "synthetic",
-            "config": {
-                "workload": "cfg3: bottom-up UNet f16/r2/max_stride32/output_stride4, 1024x1024x1 uint8 frames, 13 nodes / 12 edges",
-                "frames_per_gpu_per_step": B, "global_batch": B * world, "parallelism": f"dp{world} (frames sharded, no collective)",
-                "weights": "xavier-uniform seed 1234, head x0.05", "postprocess_input": "rendered heads, 6 instances/frame (BASELINE.md s3)",
-                "params": model.num_parameters(), "conv_gflop_per_frame": sum(r["flops"] for r in model.op_table(1, SIZE, SIZE)) / 1e9,
-            },
-            "roofline": {
-                "bound": "mfma",
-                "kernel": (f"conv3x3_wino_persist_kernel<64|32> (Winograd F(2,3) along x, " if wino else f"conv3x3_mfma_dma_persist_kernel<64|32> (direct, ")
-                + f"{len(conv_rows)} launches/forward; the first encoder block runs in the fused stem kernel)",
-                "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS,
-                "flop_accounting": "achieved = FLOPs the MFMA pipe executes (Winograd: 2/3 of the direct-convolution count); "
-                                   "direct_equivalent_* = direct-convolution FLOPs (2*Cin*Cout*9*H*W) / time",
-                "direct_equivalent_tflops": direct_tflops, "direct_equivalent_frac": direct_tflops / MFMA_F32_PEAK_TFLOPS,
-                "traffic": traffic, "traffic_unit": "HBM bytes per conv launch (PMC, avg over the launches of one forward)",
-                "traffic_source": traffic_src, "algorithmic_bytes_per_launch": conv_bytes / max(len(conv_rows), 1),
-                "algorithmic_gflop_per_forward": conv_flops * mfma_share / 1e9, "direct_gflop_per_forward": conv_flops / 1e9, "kernel_ms_per_forward": conv_ms,
-                "avg_launch_ms": conv_ms / max(len(conv_rows), 1), "launches_per_forward": len(conv_rows),
-                "conv_stack_direct_equivalent_tflops": stack_flops / (stack_ms * 1e-3) / 1e12 if stack_ms > 0 else 0.0,
-                "conv_stack_direct_equivalent_frac": (stack_flops / (stack_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS) if stack_ms > 0 else 0.0,
-                "forward_ms": fwd_ms, "forward_frames_per_s": B / (fwd_ms * 1e-3) if fwd_ms > 0 else 0.0,
-                "per_op_ms": {r["label"]: round(ms / max(n_fw, 1), 4) for r, ms in zip(table, op_ms)},
-                "profiled_forwards": n_fw,
-            },
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(model.state_dict(), cms[:2].cpu(), pafs[:2].cpu())
-        print(json.dumps(res))
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_conv_traffic.json")))
+    if cands and B == 32 and not fp16:
+        try:
+            tj = json.load(open(cands[-1]))["conv3x3_mfma"]
+            if int(round(tj["launches_per_forward"])) == len(conv_rows):
+                traffic, traffic_src = tj["hbm_bytes_per_launch"], os.path.relpath(cands[-1], ROOT)
+        except Exception:
+            pass
+    conv_bytes = sum(r["bytes"] for r, _ in conv_rows)
+    frames_total = global_batch * args.steps
+    res = {
+        "metric": "frames/sec bottom-up UNet 1024x1024 inference",
+        "value": frames_total / elapsed,
+        "unit": "frames/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True,
+        "scaling": args.scaling,
+        "vs_baseline": None,
+        "dtype": args.dtype,
+        "data": "synthetic",
+        "config": {
+            "workload": "cfg3: bottom-up UNet f16/r2/max_stride32/output_stride4, 1024x1024x1 uint8 frames, 13 nodes / 12 edges",
+            "frames_per_gpu_per_step": B, "global_batch": global_batch, "parallelism": f"dp{world} (frames sharded, no collective)",
+            "weights": "xavier-uniform seed 1234, head x0.05", "postprocess_input": "rendered heads, 6 instances/frame (BASELINE.md s3)",
+            "params": model.num_parameters(), "conv_gflop_per_frame": sum(r["flops"] for r in model.op_table(1, SIZE, SIZE)) / 1e9,
+            "forward_launch": "hipGraph replay (steps with per-op events launch kernel by kernel)" if use_graph else "kernel by kernel",
+            "inputs": "uint8 frames resident in HBM when the timed region starts",
+        },
+        "step_ms": percentiles(step_ms),
+        "roofline": {
+            "bound": "mfma",
+            "kernel": (f"conv3x3_wino_persist_kernel<64|32> (Winograd F(2,3) along x, " if wino else f"conv3x3_mfma_dma_persist_kernel<64|32> (direct, ")
+            + f"{len(conv_rows)} launches/forward; the first encoder block runs in the fused stem kernel)",
+            "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+            "flop_accounting": "achieved = FLOPs the MFMA pipe executes (Winograd: 2/3 of the direct-convolution count); "
+                               "direct_equivalent_tflops = direct-convolution FLOPs (2*Cin*Cout*9*H*W) / time, a throughput figure, not a roofline fraction",
+            "direct_equivalent_tflops": direct_tflops,
+            "traffic": traffic, "traffic_unit": "HBM bytes per conv launch (PMC, avg over the launches of one forward)",
+            "traffic_source": traffic_src, "algorithmic_bytes_per_launch": conv_bytes / max(len(conv_rows), 1),
+            "algorithmic_gflop_per_forward": conv_flops * mfma_share / 1e9, "direct_gflop_per_forward": conv_flops / 1e9, "kernel_ms_per_forward": conv_ms,
+            "avg_launch_ms": conv_ms / max(len(conv_rows), 1), "launches_per_forward": len(conv_rows),
+            "conv_stack_direct_equivalent_tflops": stack_flops / (stack_ms * 1e-3) / 1e12 if stack_ms > 0 else 0.0,
+            "forward_ms": fwd_ms, "forward_frames_per_s": B / (fwd_ms * 1e-3) if fwd_ms > 0 else 0.0,
+            "per_op_ms": {r["label"]: round(ms / max(n_fw, 1), 4) for r, ms in zip(table, op_ms)},
+            "profiled_forwards": n_fw,
+        },
+    }
+    if elapsed_h2d is not None:
+        res["h2d_inclusive"] = {"value": frames_total / elapsed_h2d, "unit": "frames/s", "ms_per_step": 1e3 * elapsed_h2d / args.steps,
+                                "note": "same steps, uint8 frames start in pinned host memory; async H2D on a copy stream, double-buffered under the previous step"}
+    if world == 1 and not args.no_cpu_baseline and not fp16:
+        res["cpu_baseline"] = cpu_baseline(model, layer, cms, pafs, dev)
+    return res
+
+
+def run_train(args, ctx):
+    raise SystemExit("bench.py --mode train is not built yet")
 
 
 if __name__ == "__main__":

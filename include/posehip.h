@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define PH_VERSION 100
+#define PH_VERSION 101
 
 /* error codes */
 #define PH_OK 0
@@ -108,6 +108,10 @@ typedef struct ph_op_desc {
   int32_t bias2;     /* PH_OP_STEM: second conv bias index                           */
   int32_t cmid;      /* PH_OP_STEM: channels between the two convs (<= 16); PH_OP_PATCH_STEM: stride */
 } ph_op_desc;
+
+/* sizeof(ph_op_desc) as the library was compiled: a binding checks its own struct against it
+ * before handing arrays to ph_model_create (16 int32 fields = 64 bytes in PH_VERSION 101). */
+int32_t ph_op_desc_size(void);
 
 typedef struct ph_model ph_model;
 
@@ -183,6 +187,16 @@ int ph_render_pafs(const float* points_dev, const int32_t* edges_dev, int32_t B,
 /* Diagnostic (tools/gemm_bench.py): average milliseconds of one row-GEMM kernel variant on synthetic operands. */
 int ph_debug_gemm_bench(int32_t variant, int32_t M, int32_t K, int32_t N, int32_t mode, int32_t H, int32_t W,
                         int32_t act, int32_t iters, float* ms_out);
+
+/* Per-handle options (the library reads no environment variables and keeps no process-global
+ * tunables).  Every key selects between kernel variants that compute the same result; defaults
+ * are the measured-best ones.  Keys: "conv_wino" (1 Winograd F(2,3) 3x3 kernels | 2 only the
+ * N-tile-64 layers | 0 direct 9-tap kernels), "stem_wino", "conv_dma", "conv_dma32",
+ * "conv_persist", "conv_c16", "conv_dma_stagger", "fuse_gelu_fwd", "fuse_gelu_bwd", "wgrad_rows",
+ * "gemm_late_split", "gemm_persist2", "conv_gemm_fill", "conv_gemm_fill_wino" (DESIGN.md appendix).
+ * Unknown key -> PH_E_INVALID. */
+int ph_model_set_option(ph_model* m, const char* key, double value);
+int ph_model_get_option(const ph_model* m, const char* key, double* value);
 
 /* Per-op timing with HIP events recorded on the forward's own stream (used by bench.py for
  * the roofline object).  While enabled every forward records one event before each op and

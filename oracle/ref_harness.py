@@ -100,6 +100,7 @@ def install() -> None:
     ns("sleap_nn.inference", os.path.join(root, "inference"))
     ns("sleap_nn.inference.ops", os.path.join(root, "inference", "ops"))
     ns("sleap_nn.inference.layers", os.path.join(root, "inference", "layers"))
+    ns("sleap_nn.inference.layers.backends", os.path.join(root, "inference", "layers", "backends"))
     ns("sleap_nn.data", os.path.join(root, "data"))
     ns("sleap_nn.training", os.path.join(root, "training"))
     _installed = True

@@ -37,6 +37,9 @@ _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 SIGNATURES = {
     "ph_last_error": (C.c_char_p, []),
     "ph_version": (C.c_int, []),
+    "ph_op_desc_size": (_i32, []),
+    "ph_model_set_option": (C.c_int, [_vp, C.c_char_p, C.c_double]),
+    "ph_model_get_option": (C.c_int, [_vp, C.c_char_p, C.POINTER(C.c_double)]),
     "ph_model_create": (_vp, [C.POINTER(OpDesc), _i32, C.POINTER(_vp), C.POINTER(_i64), _i32, _i32, _i32]),
     "ph_model_destroy": (None, [_vp]),
     "ph_model_workspace_bytes": (_i64, [_vp, _i32, _i32, _i32]),
@@ -92,6 +95,8 @@ def lib():
         fn = getattr(l, name)
         fn.restype = res
         fn.argtypes = args
+    if l.ph_op_desc_size() != C.sizeof(OpDesc):
+        raise ImportError(f"{LIB_PATH}: struct ph_op_desc is {l.ph_op_desc_size()} bytes, this binding's OpDesc {C.sizeof(OpDesc)}: rebuild the library")
     _lib = l
     return l
 

@@ -75,6 +75,13 @@ class Model:
         self._handle_device: Optional[torch.device] = None
         self._workspace: Optional[torch.Tensor] = None
         self.device = torch.device("cpu")
+        # bumped whenever the native handle or the workspace is replaced: anything that captured raw pointers into them
+        # (HipBackend's hipGraphs) compares generations before replaying
+        self.generation = 0
+        self._options: Dict[str, float] = {}
+        # a TrainingModule registers its device parameter arena here; after any recompile the packed weights are
+        # re-gathered from it, so eval()/train() round trips never fall back to the host copy in _state
+        self._live_params: Optional[torch.Tensor] = None
 
     def _add_class_vector_head(self, i: int, head: "ClassVectorsHead") -> None:
         """heads.py:506-539 on the decoder's input feature (architectures/model.py:197-199,253-255)."""
@@ -199,6 +206,8 @@ class Model:
                 if tuple(t.shape) != tuple(shape):
                     raise RuntimeError(f"size mismatch for {k}: checkpoint {tuple(t.shape)} vs model {tuple(shape)}")
                 self._state[k] = t
+        if self._live_params is not None:  # a TrainingModule owns the parameters on the device: keep its arena in step
+            self._live_params.copy_(self.flat_params())
         self._release()
         return missing, unexpected
 
@@ -270,6 +279,25 @@ class Model:
         if self._handle is not None:
             L.lib().ph_model_destroy(self._handle)
             self._handle = None
+            self.generation += 1
+
+    def set_option(self, key: str, value: float) -> "Model":
+        """Per-handle kernel-variant option (``ph_model_set_option``; keys in include/posehip.h).  Remembered across recompiles."""
+        if self._handle is not None:
+            L.check(L.lib().ph_model_set_option(self._handle, str(key).encode(), float(value)))
+        self._options[str(key)] = float(value)
+        return self
+
+    def get_option(self, key: str) -> float:
+        if self._handle is None:
+            raise RuntimeError("get_option needs a compiled handle (run a forward first)")
+        v = C.c_double()
+        L.check(L.lib().ph_model_get_option(self._handle, str(key).encode(), C.byref(v)))
+        return v.value
+
+    def bind_live_params(self, flat_dev: Optional[torch.Tensor]) -> None:
+        """Device arena (canonical order) that owns the live parameters, or None to go back to the host state dict."""
+        self._live_params = flat_dev
 
     def __del__(self):
         try:
@@ -301,6 +329,14 @@ class Model:
             raise L.PosehipError(L.PH_E_INVALID, lib.ph_last_error().decode())
         self._handle = C.c_void_p(h)
         self._handle_device = device
+        self.generation += 1
+        for k, v in self._options.items():
+            L.check(lib.ph_model_set_option(self._handle, k.encode(), v))
+        if self._live_params is not None:  # the host copy in _state may be stale during training
+            if self._live_params.device != device or self._live_params.numel() != sum(t.numel() for t in tensors):
+                raise RuntimeError("live parameter arena does not match this model / device")
+            with torch.cuda.device(device):
+                L.check(lib.ph_model_set_params(self._handle, C.c_void_p(self._live_params.data_ptr()), L.current_stream_ptr()))
 
     def _ensure(self, device: torch.device) -> None:
         if self._handle is None or self._handle_device != device:
@@ -349,6 +385,7 @@ class Model:
             if self._workspace is None or self._workspace.numel() < need or self._workspace.device != device:
                 self._workspace = None
                 self._workspace = torch.empty(int(need), dtype=torch.uint8, device=device)
+                self.generation += 1
             outs = [torch.empty((B, c, h, w), dtype=torch.float32, device=device) for (c, h, w) in self.output_shapes(H, W)]
             optrs = (C.c_void_p * len(outs))(*[o.data_ptr() for o in outs])
             L.check(

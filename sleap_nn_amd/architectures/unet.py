@@ -137,9 +137,17 @@ class UNet:
             name = f"backbone.middle_blocks.{mb}.blocks.stack0_enc{enc_num}_middle_contract_conv0"
             cur = self._conv(name, cur, fmid, fmid)
             cur_c = fmid
+        elif cur_c != fmid:
+            # The reference declares the decoder input (and max_channels) as filters * rate**down_blocks whether or not the
+            # middle block exists (unet.py:196-205,256-258); without it the tensor that arrives has the last encoder block's
+            # channel count, and the reference's first decoder conv fails on the mismatch at forward time.  Same contract here,
+            # reported when the model is built.
+            raise ValueError(
+                f"middle_block=False leaves {cur_c} channels at the decoder input but the decoder is declared with {fmid} "
+                "(unet.py:196-205); only filters_rate=1 is runnable without a middle block, in the reference as well"
+            )
         self.middle_slot = cur
         x_in = fmid
-        stride = 2**self.down_blocks * 2 // 2  # after last pool: 2**down
         stride = 2**self.down_blocks
         self.decoder_stride_to_filters = {stride: x_in}
         skips = skips[::-1]

@@ -918,9 +918,7 @@ int gemm_variant_bn(int variant) {
 
 int launch_gemm_variant(int variant, const GemmArgs& a_in, hipStream_t s) {
   GemmArgs a = a_in;
-  static const int late_split = getenv("PH_GEMM_LATE_SPLIT") ? atoi(getenv("PH_GEMM_LATE_SPLIT")) : 0;  // experiment knob
-  a.late_split = late_split;
-  static const int persist2 = getenv("PH_GEMM_PERSIST2") ? atoi(getenv("PH_GEMM_PERSIST2")) : 0;  // experiment knob: 1 = persistent workgroups for the 9-tap mode too (measured 3-4 % slower than one tile per workgroup)
+  const int persist2 = a.persist2;  // handle option: persistent workgroups for the 9-tap mode too (measured 3-4 % slower than one tile per workgroup)
   PH_REQUIRE(a.M > 0 && a.c0p > 0 && a.c0p % 16 == 0 && a.c1p % 16 == 0 && a.coutp % 16 == 0 && a.mode >= 0 && a.mode <= 2, "launch_gemm: bad shape");
   PH_REQUIRE(a.c1p == 0 || a.src1, "launch_gemm: second source missing");
   PH_REQUIRE((a.act != 3 && !a.dst_pre) || a.mode == 0, "launch_gemm: the training epilogues exist for the Linear mode only");
@@ -1008,8 +1006,8 @@ int ph_debug_gemm_bench(int32_t variant, int32_t M, int32_t K, int32_t N, int32_
   {
     std::vector<float> h(std::max(std::max(n_src, n_w), n_b));
     unsigned st = 12345u;
-    const char* pat = getenv("PH_BENCH_DATA");  // rand (default) | relu (half zeros) | zeros
-    const int mode_d = !pat ? 0 : (pat[0] == 'z' ? 2 : (pat[0] == 'r' && pat[1] == 'e' ? 1 : 0));
+    const int mode_d = (act >> 8) & 3;  // operand pattern in bits 8-9 of `act`: 0 rand | 1 relu (half zeros) | 2 zeros
+    act &= 0xff;
     for (auto& v : h) {
       st = st * 1664525u + 1013904223u;
       v = ((st >> 8) & 0xffff) / 65536.0f - 0.5f;

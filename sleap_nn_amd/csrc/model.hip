@@ -177,10 +177,13 @@ static void pack_gemm(const T* w, int cout, int cin0, int cin1, int taps, int bn
     }
 }
 
-int choose_bn(int coutp) {
-  static const int force = getenv("PH_CONV_BN") ? atoi(getenv("PH_CONV_BN")) : 0;  // experiment knob: 32 = N tile 32 for every 3x3 conv
-  if (force == 32) return 32;
-  return coutp >= 64 ? 64 : 32;
+int choose_bn(int coutp) { return coutp >= 64 ? 64 : 32; }
+
+void apply_conv_options(const ph_model* m, ConvArgs& a) {
+  a.use_wino = m->conv_wino;
+  a.persist = m->conv_persist;
+  a.use_c16 = m->conv_c16;
+  a.dma_stagger = m->dma_stagger;
 }
 
 int build_plan(const ph_model* m, int B, int H, int W, Plan& plan) {
@@ -304,14 +307,6 @@ ph_model* ph_model_create(const ph_op_desc* ops, int32_t n_ops, const float* con
   m->n_slots = n_slots;
   m->n_outputs = n_outputs;
   {
-    const char* impl = getenv("PH_CONV_IMPL");
-    m->use_dma = !(impl && std::string(impl) == "reg");
-    if (const char* d32 = getenv("PH_CONV_DMA32")) m->dma32 = atoi(d32) != 0;  // experiment knob: LDS-DMA kernel for the 32-wide N tile too
-    if (const char* fg = getenv("PH_FUSE_GELU_BWD")) m->fuse_gelu_bwd = atoi(fg);
-    if (const char* ff = getenv("PH_FUSE_GELU_FWD")) m->fuse_gelu_fwd = atoi(ff);
-    if (const char* wi = getenv("PH_WGRAD_IMPL")) m->wgrad_rows = std::string(wi) == "rows" ? 2 : (std::string(wi) == "auto" ? 1 : 0);
-    if (const char* th = getenv("PH_CONV_GEMM_FILL")) m->gemm_fill_threshold = atof(th);  // experiment knob: 0 disables the row-GEMM form
-    if (const char* th = getenv("PH_CONV_GEMM_FILL_WINO")) m->gemm_fill_threshold_wino = std::max(atof(th), 1e-3);
     std::vector<float> z(64, 0.f);
     if (upload(m, z, &m->zeros_dev) != PH_OK) {
       ph_model_destroy(m);
@@ -690,6 +685,7 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
         a.B = batch;
         a.H = height;
         a.W = width;
+        a.wino = m->stem_wino;
         rc = launch_stem(a, s);
         break;
       }
@@ -716,6 +712,7 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
         a.wpack_wino = op.w_wino_dev;
         a.w16 = op.w16_dev;
         a.zeros = m->zeros_dev;
+        apply_conv_options(m, a);
         const double fill = (double)s0.h * s0.w / ((double)((s0.h + 15) / 16 * 16) * ((s0.w + 31) / 32 * 32));
         // the halo kernel pads Cout to a multiple of its N tile (64): e.g. Cout = 96 does 33 % extra MFMA work there,
         // none in the row GEMM (N tiles of 96 / 128)
@@ -743,10 +740,12 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
           g.H = s0.h;
           g.W = s0.w;
           g.act = a.relu ? 1 : 0;
+          g.late_split = m->gemm_late_split;
+          g.persist2 = m->gemm_persist2;
           rc = launch_gemm(g, s);
           break;
         }
-        rc = (m->use_dma && (a.bn == 64 || m->dma32)) ? launch_conv3x3_dma(a, s) : launch_conv3x3(a, s);  // BN=32 layers: the register-staged kernel is faster
+        rc = (m->use_dma && (a.bn == 64 || m->dma32)) ? launch_conv3x3_dma(a, s) : launch_conv3x3(a, s);
         break;
       }
       case PH_OP_POOL: {
@@ -783,7 +782,8 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
         a.dst_pool = nullptr;
         a.wpack_dma = op.w_dma_dev;
         a.zeros = m->zeros_dev;
-        rc = (m->use_dma && (a.bn == 64 || m->dma32)) ? launch_conv3x3_dma(a, s) : launch_conv3x3(a, s);  // BN=32 layers: the register-staged kernel is faster
+        apply_conv_options(m, a);
+        rc = (m->use_dma && (a.bn == 64 || m->dma32)) ? launch_conv3x3_dma(a, s) : launch_conv3x3(a, s);
         break;
       }
       case PH_OP_PATCH_STEM: {
@@ -851,6 +851,7 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
           a.scale = op.w2_dev;
           a.residual = slot_ptr(d.src1);
         }
+        a.late_split = m->gemm_late_split;
         // training program (Linear and GELU as separate ops, the pre-activation is kept for the backward pass): the
         // GEMM epilogue writes both the pre-activation and GELU(pre-activation), the GELU op after it becomes a no-op
         if (m->fuse_gelu_fwd && a.mode == 0 && a.act == 0 && !a.residual && op_index < m->ops.size()) {
@@ -912,6 +913,58 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
   m->last_ws = ws;
   m->last_batch = batch;
   return PH_OK;
+}
+
+int32_t ph_op_desc_size(void) { return (int32_t)sizeof(ph_op_desc); }
+
+namespace {
+struct OptionRef {
+  const char* key;
+  int* i;
+  double* d;
+};
+// every tunable of a handle; defaults are the measured-best variants (DESIGN.md, appendix "handle options")
+std::vector<OptionRef> option_table(ph_model* m) {
+  return {
+      {"conv_wino", &m->conv_wino, nullptr},            // 1 Winograd F(2,3) 3x3 kernels, 2 only N-tile-64 layers, 0 direct 9-tap kernels
+      {"stem_wino", &m->stem_wino, nullptr},            // second conv of the fused stem in Winograd form
+      {"conv_dma", &m->use_dma, nullptr},               // 0: register-staged 3x3 kernel instead of the LDS-DMA family
+      {"conv_dma32", &m->dma32, nullptr},               // 0: Cout <= 48 layers on the register-staged kernel
+      {"conv_persist", &m->conv_persist, nullptr},      // 0: one pixel tile per workgroup
+      {"conv_c16", &m->conv_c16, nullptr},              // 0: 16 -> 16 channel layers on the generic kernel
+      {"conv_dma_stagger", &m->dma_stagger, nullptr},   // 0: SIMD-partner waves issue DMA pieces at the same step
+      {"fuse_gelu_fwd", &m->fuse_gelu_fwd, nullptr},
+      {"fuse_gelu_bwd", &m->fuse_gelu_bwd, nullptr},
+      {"wgrad_rows", &m->wgrad_rows, nullptr},          // 0 32x32-tile wgrad kernel, 1 auto, 2 nine row-wgrad GEMMs
+      {"gemm_late_split", &m->gemm_late_split, nullptr},
+      {"gemm_persist2", &m->gemm_persist2, nullptr},
+      {"conv_gemm_fill", nullptr, &m->gemm_fill_threshold},            // tile fill below which a 3x3 conv runs as a row GEMM (0 disables)
+      {"conv_gemm_fill_wino", nullptr, &m->gemm_fill_threshold_wino},  // ... when the halo kernel is the Winograd one
+  };
+}
+}  // namespace
+
+int ph_model_set_option(ph_model* m, const char* key, double value) {
+  PH_REQUIRE(m && key, "ph_model_set_option: null argument");
+  for (const OptionRef& o : option_table(m))
+    if (!strcmp(o.key, key)) {
+      if (o.i) *o.i = (int)value;
+      if (o.d) *o.d = !strcmp(key, "conv_gemm_fill_wino") ? std::max(value, 1e-3) : value;
+      return PH_OK;
+    }
+  set_error("ph_model_set_option: unknown option '%s'", key);
+  return PH_E_INVALID;
+}
+
+int ph_model_get_option(const ph_model* m, const char* key, double* value) {
+  PH_REQUIRE(m && key && value, "ph_model_get_option: null argument");
+  for (const OptionRef& o : option_table(const_cast<ph_model*>(m)))
+    if (!strcmp(o.key, key)) {
+      *value = o.i ? (double)*o.i : *o.d;
+      return PH_OK;
+    }
+  set_error("ph_model_get_option: unknown option '%s'", key);
+  return PH_E_INVALID;
 }
 
 int ph_model_set_profiling(ph_model* m, int32_t enabled) {

@@ -81,12 +81,20 @@ struct ph_model {
   int64_t n_params = 0;
   std::vector<ph::DerivedBuffer> derived;      // refreshed after the gathers of ph_model_set_params
   std::vector<ph::PackedBuffer> packed;        // every packed weight buffer, for ph_model_set_params
-  bool use_dma = true;                        // PH_CONV_IMPL=reg selects the register-staged kernel
-  bool dma32 = true;                          // Cout <= 48 layers on the LDS-DMA kernel (BN = 32) instead of the register-staged one
-  int fuse_gelu_fwd = 1;                      // Linear -> GELU op pair: one GEMM whose epilogue writes both tensors (PH_FUSE_GELU_FWD=0: two kernels)
-  int fuse_gelu_bwd = 1;                      // Linear data gradient multiplies by GELU' in its epilogue (PH_FUSE_GELU_BWD=0: separate kernel)
-  int wgrad_rows = 0;                         // 3x3 weight gradients of wide layers as nine row-wgrad GEMMs (off by default: measured slower than the 32x32-tile kernel; PH_WGRAD_IMPL=auto|rows)
-  double gemm_fill_threshold_wino = 0.5;      // ... and the (lower) break-even when the halo kernel is the Winograd one (PH_CONV_GEMM_FILL_WINO)
+  // ---- per-handle options (ph_model_set_option); the library reads no environment variables
+  int use_dma = 1;                            // "conv_dma": 0 selects the register-staged 3x3 kernel
+  int dma32 = 1;                              // "conv_dma32": Cout <= 48 layers on the LDS-DMA kernel (BN = 32) instead of the register-staged one
+  int conv_wino = 1;                          // "conv_wino": Winograd F(2,3) 3x3 kernels (2: N-tile-64 layers only, 0: direct 9-tap kernels)
+  int stem_wino = 1;                          // "stem_wino"
+  int conv_persist = 1;                       // "conv_persist"
+  int conv_c16 = 1;                           // "conv_c16"
+  int dma_stagger = 1;                        // "conv_dma_stagger"
+  int gemm_late_split = 0;                    // "gemm_late_split"
+  int gemm_persist2 = 0;                      // "gemm_persist2"
+  int fuse_gelu_fwd = 1;                      // Linear -> GELU op pair: one GEMM whose epilogue writes both tensors (0: two kernels)
+  int fuse_gelu_bwd = 1;                      // Linear data gradient multiplies by GELU' in its epilogue (0: separate kernel)
+  int wgrad_rows = 0;                         // 3x3 weight gradients of wide layers as nine row-wgrad GEMMs (off by default: measured slower than the 32x32-tile kernel; 1 auto, 2 always)
+  double gemm_fill_threshold_wino = 0.5;      // ... and the (lower) break-even when the halo kernel is the Winograd one
   double gemm_fill_threshold = 0.8;           // 3x3 convs whose maps fill the 16x32 tiles less than this run as row GEMMs
 };
 
@@ -96,4 +104,5 @@ int build_plan(const ph_model* m, int B, int H, int W, Plan& plan);
 int upload(ph_model* m, const std::vector<float>& host, float** dev);
 int upload_ints(ph_model* m, const std::vector<int>& host, int** dev);
 int choose_bn(int coutp);
+void apply_conv_options(const ph_model* m, ConvArgs& a);
 }  // namespace ph

@@ -25,6 +25,10 @@ struct ConvArgs {
   const float* wpack_wino = nullptr;  // Winograd F(2,3)-along-x weights in LDS order (conv3x3_wino_persist_kernel), or nullptr
   const float* w16 = nullptr;  // [tap][ci 16][co 16] weights for conv3x3_c16_kernel (16 -> 16 channel layers), or nullptr
   float* dst_pool = nullptr;  // optional fused 2x2/2 max pool of the (ReLU'd) output, NHWC ceil(H/2) x ceil(W/2); nullptr = off
+  // kernel selection, filled from the model handle's options (ph_model_set_option)
+  int use_wino = 1;   // 1: Winograd F(2,3) kernel where wpack_wino exists; 2: only for the N-tile-64 layers; 0: direct 9-tap kernel
+  int persist = 1;    // persistent workgroups (one per CU) instead of one tile per workgroup
+  int use_c16 = 1;    // 16 -> 16 channel layers on conv3x3_c16_kernel
 };
 
 struct InputConvArgs {
@@ -46,6 +50,7 @@ struct StemArgs {
   float* dst_full;     // NHWC 16 full resolution or nullptr
   float* dst_pool;     // NHWC 16, ceil(H/2) x ceil(W/2)
   int dtype, cin, B, H, W;
+  int wino = 1;        // second conv in Winograd form (handle option "stem_wino")
 };
 
 struct PatchStemArgs {
@@ -83,6 +88,7 @@ struct GemmArgs {
   const float* aux = nullptr;       // act 3: (M, coutp) pre-activation the GELU derivative is taken at
   unsigned long long* probe = nullptr;  // diagnostic builds (PH_GEMM_STAMP) only
   int late_split = 0;               // which waves issue their DMA pieces one step late (see gemm_mfma_dma_kernel)
+  int persist2 = 0;                 // persistent workgroups for the 9-tap mode too (handle option "gemm_persist2")
   // output row mapping: 0 = row m; 1 = row m is output pixel (b, oy, ox) of a 2x2/stride-2 conv and the result is
   // written to input pixel (b, 2oy + (out_tap >> 1), 2ox + (out_tap & 1)) of an out_H x out_W map (its data gradient)
   int out_patch = 0, out_tap = 0, out_H = 0, out_W = 0;

@@ -335,19 +335,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(ConvArgs a) {
 #endif
 }
 
-static size_t debug_lds_pad() {  // experiment knob: PH_CONV_LDS_PAD=<bytes> lowers workgroups/CU
-  static long pad = -1;
-  if (pad < 0) {
-    const char* e = getenv("PH_CONV_LDS_PAD");
-    pad = e ? atol(e) : 0;
-  }
-  return (size_t)pad;
-}
-
 int launch_conv3x3(const ConvArgs& a, hipStream_t s) {
   const int tiles = ((a.W + TW - 1) / TW) * ((a.H + TH - 1) / TH) * a.B;
   if (a.bn == 64) {
-    const size_t lds = (HALO_H * HALO_W + 9 * 64) * LROW * sizeof(float) + debug_lds_pad();
+    const size_t lds = (HALO_H * HALO_W + 9 * 64) * LROW * sizeof(float);
     dim3 grid(tiles * ((a.coutp + 63) / 64));
     hipLaunchKernelGGL(conv3x3_mfma_kernel<64>, grid, dim3(256), lds, s, a);
   } else {
@@ -888,15 +879,8 @@ int launch_wino_pack(const float* wpack, float* wino, int panels, int bn, hipStr
   return PH_OK;
 }
 
-#ifndef PH_WINO_BUF
-#define PH_WINO_BUF 0  // 1: halo pieces via buffer_load ... lds (32-bit per-lane offsets, hardware range check) instead of global_load_lds
-#endif
-#ifndef PH_WINO_EXP
-#define PH_WINO_EXP 0  // timing experiments only (results are wrong): 1 no mid barrier, 2 no DMA in the K loop, 4 no input transform, 8 no epilogue, 16 no epilogue stores
-#endif
-// WAVES = 8: one 512-thread workgroup per CU, tile 16 x 32 pixels (the default).  WAVES = 4 (N tile 32 only: 80 KiB of LDS): two
-// 256-thread workgroups per CU, tile 8 x 32, which drift apart so that one's epilogue runs under the other's MFMAs -- an
-// experiment (PH_CONV_WINO32_2WG=1) for the layers with one or two K chunks per tile; measured 2 % slower than one workgroup.
+// WAVES = 8: one 512-thread workgroup per CU, tile 16 x 32 pixels -- the only instantiation (a WAVES = 4 variant with two
+// 256-thread workgroups per CU was measured 2 % slower in round 1 and is no longer built).
 template <int BN, int WAVES>
 __global__ __launch_bounds__(WAVES * 64, 2) void conv3x3_wino_persist_kernel(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -963,33 +947,6 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv3x3_wino_persist_kernel(Con
   const float* p_src = a.src0;
   const float* p_w = a.wpack_wino;
   int p_cp = a.c0p, p_coff = 0;
-#if PH_WINO_BUF && defined(__HIP_DEVICE_COMPILE__)  // (the descriptor type exists in the device pass only; the host pass never runs this body)
-  // Halo pieces through a buffer descriptor: the per-lane part of the address is ONE 32-bit offset per slot, computed when the
-  // (tile, source) changes; the channel offset of the chunk travels in the scalar offset; out-of-image lanes carry an offset
-  // beyond the tensor, which the range check turns into zeros.  No per-piece VALU address arithmetic in the K loop (every VALU
-  // instruction there costs ~5 MFMA cycles).
-  unsigned f_off[A_SLOTS];
-  __amdgpu_buffer_rsrc_t p_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.src0, 0, (int)((unsigned)(a.B * a.H * a.W) * (unsigned)(a.c0p * 4)), 0x00020000);
-  auto select_fetch = [&](const Plan& P, int ch) {
-    if (ch < chunks0) {
-      p_src = a.src0;
-      p_cp = a.c0p;
-      p_coff = ch * KC;
-    } else {
-      p_src = a.src1;
-      p_cp = a.c1p;
-      p_coff = (ch - chunks0) * KC;
-    }
-    p_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p_src, 0, (int)((unsigned)(a.B * a.H * a.W) * (unsigned)(p_cp * 4)), 0x00020000);
-#pragma unroll
-    for (int s = 0; s < A_SLOTS; ++s) f_off[s] = ((P.a_ok >> s) & 1u) ? (unsigned)P.a_pix[s] * (unsigned)(p_cp * 4) + (unsigned)(dq * 16) : 0xFFFFFFFFu;
-    p_w = a.wpack_wino + ((size_t)P.ntile * nchunks + ch) * (2 * BH_FLOATS);
-  };
-  auto dma_a = [&](int s, float* abuf) {
-    const int p = min(wave + WAVES * s, W_A_PIECES - 1);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(p_rsrc, (__attribute__((address_space(3))) void*)(abuf + p * 256), 16, f_off[s], p_coff * 4, 0, 0);
-  };
-#else
   int f_pix[A_SLOTS];
   unsigned f_ok = 0;
   auto select_fetch = [&](const Plan& P, int ch) {
@@ -1014,7 +971,6 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv3x3_wino_persist_kernel(Con
     const float* g = ((f_ok >> s) & 1u) ? real : zero;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)(abuf + p * 256), 16, 0, 0);
   };
-#endif
   auto dma_b = [&](int s, int half, float* bhalf) {
     const int pb = min(wave + WAVES * s, BH_PIECES - 1);
     const float* g = p_w + half * BH_FLOATS + pb * 256 + lane * 4;
@@ -1034,9 +990,6 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv3x3_wino_persist_kernel(Con
   const int offB = lh * 128 + lx * 4;
   float* const abuf = lds;
   float* const bbuf = lds + 2 * A_FLOATS;
-#ifdef PH_WINO_EXTRA_VALU
-  unsigned extra_valu = 0;
-#endif
 
   auto run = [&](auto late) {
     constexpr bool LATE = decltype(late)::value;
@@ -1091,10 +1044,6 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv3x3_wino_persist_kernel(Con
         };
         auto make_a = [&](int q, int fa) {
           const int db = (q >> 2) & 1, xi = q & 3;
-#if PH_WINO_EXP & 4
-          af[fa] = dd[db][xi];
-          return;
-#endif
           if (xi == 0)
             af[fa] = dd[db][0] - dd[db][2];
           else if (xi == 1)
@@ -1113,23 +1062,17 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv3x3_wino_persist_kernel(Con
           if (q + 1 < 24) load_b(q + 1, fcur ^ 1);
           if ((q & 3) == 1 && (q >> 2) + 1 < 6) load_d((q >> 2) + 1, ((q >> 2) + 1) & 1);
           // one DMA piece per step: the next chunk's halo and first weight half in steps 0.., its second weight half after the mid barrier
-#if !(PH_WINO_EXP & 2)
           if (q < A_SLOTS)
             dma_a(q, anxt);
           else if (q < A_SLOTS + BH_SLOTS)
             dma_b(q - A_SLOTS, 0, bn_first);
           else if (q >= 12 && q < 12 + BH_SLOTS)
             dma_b(q - 12, 1, bn_second);
-#endif
 #pragma unroll
           for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int n = 0; n < NT; ++n) acc[q & 3][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[fcur][j], bf[fcur][n][j], acc[q & 3][n], 0, 0, 0);
           if (q + 1 < 24) make_a(q + 1, fcur ^ 1);
-#ifdef PH_WINO_EXTRA_VALU  // timing experiment: what does one more VALU instruction per step cost the MFMA stream?
-#pragma unroll
-          for (int e = 0; e < PH_WINO_EXTRA_VALU; ++e) asm volatile("v_add_u32 %0, %0, 1" : "+v"(extra_valu));
-#endif
           const bool has_dma = q < A_SLOTS + BH_SLOTS || (q >= 12 && q < 12 + BH_SLOTS);
           // Pinned order: the step's first MFMAs, THEN the LDS reads of the next step.  The compiler's wait before the first MFMA is
           // always lgkmcnt(0) here (an LDS-DMA instruction marks the counter out-of-order for its scoreboard), so reads issued
@@ -1148,9 +1091,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv3x3_wino_persist_kernel(Con
             __builtin_amdgcn_sched_group_barrier(0x008, 3 * NT, 0);
           }
           __builtin_amdgcn_sched_barrier(0);
-#if !(PH_WINO_EXP & 1)
           if (q == 11) __builtin_amdgcn_s_barrier();  // every wave is done reading the first weight half: its slot may be refilled
-#endif
         }
         __syncthreads();
         apar ^= 1;
@@ -1160,14 +1101,6 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv3x3_wino_persist_kernel(Con
       // r < 8 is the wave's first row, r >= 8 its second; the pair's outputs are pixels 2t, 2t + 1.
       const int b = P.b, x0 = P.x0, y0 = P.y0, ntile = P.ntile;
       const bool interior = (x0 + TW <= a.W) && (y0 + W_TH <= a.H) && ((ntile + 1) * BN <= a.coutp);
-#if PH_WINO_EXP & 8
-      if (acc[0][0][0] != 12345.678f) {  // timing experiment: no epilogue (the accumulators stay live)
-        if (!has_next) break;
-        vid = nvid;
-        P = Pn;
-        continue;
-      }
-#endif
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
         const int co = ntile * BN + n * 32 + lx;
@@ -1181,7 +1114,6 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv3x3_wino_persist_kernel(Con
           ya[r] = a.relu ? fmaxf(va, 0.f) : va;
           yb[r] = a.relu ? fmaxf(vb, 0.f) : vb;
         }
-#if !(PH_WINO_EXP & 16)
         if (interior) {
           // Interior tile (all but the image's last row / column of tiles): straight-line stores.  One lane-dependent base
           // pointer; every store adds a wave-uniform offset -- no per-store bounds test, no exec-mask branch (the general
@@ -1217,7 +1149,6 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv3x3_wino_persist_kernel(Con
           }
           continue;
         }
-#endif
         if (a.dst_pool) {  // fused 2x2/2 max pool ("same" padding: zeros beyond the image)
           const int Hp = (a.H + 1) >> 1, Wp = (a.W + 1) >> 1;
           const int yt = y0 + 2 * wave, py = yt >> 1;
@@ -1235,11 +1166,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv3x3_wino_persist_kernel(Con
                 v10 = (xa && yyb) ? v10 : 0.f;
                 v11 = (xb && yyb) ? v11 : 0.f;
               }
-#if PH_WINO_EXP & 16
-              if (v00 == 12345.678f)
-#else
               if (px < Wp)
-#endif
                 prow[(size_t)px * a.coutp] = fmaxf(fmaxf(v00, v01), fmaxf(v10, v11));
             }
           }
@@ -1249,11 +1176,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv3x3_wino_persist_kernel(Con
           const int y = y0 + 2 * wave + (r >> 3);
           const int t = (r & 3) + 8 * ((r >> 2) & 1) + 4 * lh;
           const int x = x0 + 2 * t;
-#if PH_WINO_EXP & 16
-          if (ya[r] == 12345.678f && yb[r] == 4321.f) {  // timing experiment: (almost) no stores, the epilogue arithmetic stays
-#else
           if (interior || (y < a.H && co < a.coutp)) {
-#endif
             float* dp = a.dst + ((size_t)(b * a.H + y) * a.W + x) * a.coutp + co;
             if (interior || x < a.W) dp[0] = a.accumulate ? dp[0] + ya[r] : ya[r];
             if (interior || x + 1 < a.W) dp[a.coutp] = a.accumulate ? dp[a.coutp] + yb[r] : yb[r];
@@ -1341,79 +1264,57 @@ __global__ __launch_bounds__(256, 4) void conv3x3_c16_kernel(ConvArgs a) {
   }
 }
 
+static int cu_count(int* out);
 static int launch_conv3x3_c16(const ConvArgs& a, hipStream_t s) {
-  static int n_cu = 0;
-  if (!n_cu) {
-    int dev = 0;
-    PH_HIP_CHECK(hipGetDevice(&dev));
-    PH_HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-  }
+  int n_cu = 0;
+  const int rc = cu_count(&n_cu);
+  if (rc != PH_OK) return rc;
   const int tiles = ((a.W + C16_TW - 1) / C16_TW) * ((a.H + C16_TH - 1) / C16_TH) * a.B;
   hipLaunchKernelGGL(conv3x3_c16_kernel, dim3(std::min(tiles, n_cu * 4)), dim3(256), 0, s, a);
   PH_HIP_CHECK(hipGetLastError());
   return PH_OK;
 }
 
-int launch_conv3x3_dma(const ConvArgs& a_in, hipStream_t s) {
-  ConvArgs a = a_in;
-  static const int use_c16 = getenv("PH_CONV_C16") ? atoi(getenv("PH_CONV_C16")) : 1;  // experiment knob
-  if (use_c16 && a.w16 && a.c0p == 16 && a.coutp == 16 && !a.src1 && !a.dst_pool) return launch_conv3x3_c16(a, s);
-  static const int stagger = getenv("PH_CONV_DMA_STAGGER") ? atoi(getenv("PH_CONV_DMA_STAGGER")) : 1;  // experiment knob
-  a.dma_stagger = stagger;
+static int cu_count(int* out) {
+  static int n_cu = 0;
+  if (!n_cu) {
+    int dev = 0;
+    PH_HIP_CHECK(hipGetDevice(&dev));
+    PH_HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+  }
+  *out = n_cu;
+  return PH_OK;
+}
+
+// Kernel choice for a 3x3 "same" conv on the LDS-DMA family.  Which variant runs is decided by fields of `a` that the
+// model runtime fills from the handle's options (ph_model_set_option); there is no process-global state here.
+int launch_conv3x3_dma(const ConvArgs& a, hipStream_t s) {
+  if (a.use_c16 && a.w16 && a.c0p == 16 && a.coutp == 16 && !a.src1 && !a.dst_pool) return launch_conv3x3_c16(a, s);
   const int tiles = ((a.W + TW - 1) / TW) * ((a.H + D_TH - 1) / D_TH) * a.B;
-  static const int persist = getenv("PH_CONV_PERSIST") ? atoi(getenv("PH_CONV_PERSIST")) : 1;  // experiment knob: 0 = one tile per workgroup
-  static const int use_wino = getenv("PH_CONV_WINO") ? atoi(getenv("PH_CONV_WINO")) : 1;  // experiment knob: 0 = direct 9-tap kernel
-  if (a.bn == 64 && persist) {
-    static int n_cu = 0;
-    if (!n_cu) {
-      int dev = 0;
-      PH_HIP_CHECK(hipGetDevice(&dev));
-      PH_HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-    }
-    if (use_wino && a.wpack_wino) {
-      const size_t lds_w = (size_t)(2 * D_A_PIECES + 3 * 12 * (64 / 32)) * 1024;
-      const int total_w = tiles * ((a.coutp + 63) / 64);
-      hipLaunchKernelGGL((conv3x3_wino_persist_kernel<64, 8>), dim3(std::min(total_w, n_cu)), dim3(512), lds_w, s, a);
-      PH_HIP_CHECK(hipGetLastError());
-      return PH_OK;
-    }
-    const size_t lds = (size_t)2 * (D_A_PIECES + 9 * 64 / 16) * 1024;
-    const int total = tiles * ((a.coutp + 63) / 64);
-    hipLaunchKernelGGL(conv3x3_mfma_dma_persist_kernel<64>, dim3(std::min(total, n_cu)), dim3(512), lds, s, a);
-  } else if (a.bn == 32 && persist) {
-    static int n_cu32 = 0;
-    if (!n_cu32) {
-      int dev = 0;
-      PH_HIP_CHECK(hipGetDevice(&dev));
-      PH_HIP_CHECK(hipDeviceGetAttribute(&n_cu32, hipDeviceAttributeMultiprocessorCount, dev));
-    }
-    static const int use_wino32 = getenv("PH_CONV_WINO32") ? atoi(getenv("PH_CONV_WINO32")) : 1;  // experiment knob
-    if (use_wino && use_wino32 && a.wpack_wino) {
-      static const int two_wg = getenv("PH_CONV_WINO32_2WG") ? atoi(getenv("PH_CONV_WINO32_2WG")) : 0;  // experiment knob: 1 = two 4-wave workgroups per CU (measured 2 % slower)
-      if (two_wg) {
-        constexpr int a_pieces = ((8 + 2) * HALO_W + 15) / 16;
-        const size_t lds_w = (size_t)(2 * a_pieces + 3 * 12) * 1024;  // 80 KiB: two workgroups per CU
-        const int tiles8 = ((a.W + TW - 1) / TW) * ((a.H + 7) / 8) * a.B;
-        const int total_w = tiles8 * ((a.coutp + 31) / 32);
-        hipLaunchKernelGGL((conv3x3_wino_persist_kernel<32, 4>), dim3(std::min(total_w, 2 * n_cu32)), dim3(256), lds_w, s, a);
-        PH_HIP_CHECK(hipGetLastError());
-        return PH_OK;
-      }
-      const size_t lds_w = (size_t)(2 * D_A_PIECES + 3 * 12 * (32 / 32)) * 1024;
-      const int total_w = tiles * ((a.coutp + 31) / 32);
-      hipLaunchKernelGGL((conv3x3_wino_persist_kernel<32, 8>), dim3(std::min(total_w, n_cu32)), dim3(512), lds_w, s, a);
-      PH_HIP_CHECK(hipGetLastError());
-      return PH_OK;
-    }
-    const size_t lds = (size_t)2 * (D_A_PIECES + 9 * 32 / 16) * 1024;
-    const int total = tiles * ((a.coutp + 31) / 32);
-    hipLaunchKernelGGL(conv3x3_mfma_dma_persist_kernel<32>, dim3(std::min(total, n_cu32)), dim3(512), lds, s, a);
-  } else if (a.bn == 64) {
-    const size_t lds = (size_t)2 * (D_A_PIECES + 9 * 64 / 16) * 1024;
-    hipLaunchKernelGGL(conv3x3_mfma_dma_kernel<64>, dim3(tiles * ((a.coutp + 63) / 64)), dim3(512), lds, s, a);
+  const int ntc = (a.coutp + a.bn - 1) / a.bn;
+  const bool wino = a.use_wino && a.wpack_wino && (a.bn == 64 || a.use_wino != 2);  // use_wino 2: Winograd for the N-tile-64 layers only
+  int n_cu = 0;
+  if (a.persist) {
+    const int rc = cu_count(&n_cu);
+    if (rc != PH_OK) return rc;
+  }
+  const dim3 grid_p(std::min(tiles * ntc, n_cu)), grid_1(tiles * ntc);
+  const size_t lds_w = (size_t)(2 * D_A_PIECES + 3 * 12 * (a.bn / 32)) * 1024;
+  const size_t lds_d = (size_t)2 * (D_A_PIECES + 9 * a.bn / 16) * 1024;
+  if (a.bn == 64) {
+    if (a.persist && wino)
+      hipLaunchKernelGGL((conv3x3_wino_persist_kernel<64, 8>), grid_p, dim3(512), lds_w, s, a);
+    else if (a.persist)
+      hipLaunchKernelGGL(conv3x3_mfma_dma_persist_kernel<64>, grid_p, dim3(512), lds_d, s, a);
+    else
+      hipLaunchKernelGGL(conv3x3_mfma_dma_kernel<64>, grid_1, dim3(512), lds_d, s, a);
   } else {
-    const size_t lds = (size_t)2 * (D_A_PIECES + 9 * 32 / 16) * 1024;
-    hipLaunchKernelGGL(conv3x3_mfma_dma_kernel<32>, dim3(tiles * ((a.coutp + 31) / 32)), dim3(512), lds, s, a);
+    if (a.persist && wino)
+      hipLaunchKernelGGL((conv3x3_wino_persist_kernel<32, 8>), grid_p, dim3(512), lds_w, s, a);
+    else if (a.persist)
+      hipLaunchKernelGGL(conv3x3_mfma_dma_persist_kernel<32>, grid_p, dim3(512), lds_d, s, a);
+    else
+      hipLaunchKernelGGL(conv3x3_mfma_dma_kernel<32>, grid_1, dim3(512), lds_d, s, a);
   }
   PH_HIP_CHECK(hipGetLastError());
   return PH_OK;
@@ -1627,8 +1528,7 @@ __global__ __launch_bounds__(256, 4) void stem_fused_kernel(StemArgs a) {
 
 int launch_stem(const StemArgs& a, hipStream_t s) {
   const int tiles = ((a.W + TW - 1) / TW) * ((a.H + TH - 1) / TH) * a.B;
-  static const int use_wino = getenv("PH_STEM_WINO") ? atoi(getenv("PH_STEM_WINO")) : 1;  // experiment knob: 0 = direct conv1
-  const bool wino = use_wino && a.w1w;
+  const bool wino = a.wino && a.w1w;
   if (a.cin == 1 && wino)
     hipLaunchKernelGGL((stem_fused_kernel<1, true>), dim3(tiles), dim3(256), 0, s, a);
   else if (a.cin == 1)
@@ -1984,8 +1884,6 @@ int prepare_kernels() {
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wino_persist_kernel<64, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e == hipSuccess)
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wino_persist_kernel<32, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  if (e == hipSuccess)
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wino_persist_kernel<32, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
   if (e != hipSuccess) {
     set_error("hipFuncSetAttribute(conv dma) failed: %s", hipGetErrorString(e));
     return PH_E_HIP;

@@ -154,12 +154,9 @@ int ph_model_backward(ph_model* m, const void* input_dev, int32_t in_dtype, int3
       rc = launch_loss(head_out_dev[d.out_index], target_dev[d.out_index], batch, d.cout, s0.h, s0.w, lw[d.out_index], ok, scratch, dy, loss_dev + 1 + d.out_index, s);
     if (rc != PH_OK) return rc;
   }
-  {  // total = sum_h w_h * loss_h; the weights ride in the scratch area
-    float* wdev = scratch;
-    PH_HIP_CHECK(hipMemcpyAsync(wdev, lw.data(), lw.size() * sizeof(float), hipMemcpyHostToDevice, s));
-    rc = launch_total_loss(loss_dev + 1, wdev, m->n_outputs, loss_dev, s);
-    if (rc != PH_OK) return rc;
-  }
+  // total = sum_h w_h * loss_h (the weights are a by-value kernel argument)
+  rc = launch_total_loss(loss_dev + 1, lw.data(), m->n_outputs, loss_dev, s);
+  if (rc != PH_OK) return rc;
 
   // ---- reverse sweep
   for (int oi = (int)m->ops.size() - 1; oi >= 0; --oi) {
@@ -248,6 +245,7 @@ int ph_model_backward(ph_model* m, const void* input_dev, int32_t in_dtype, int3
           a.clock_probe = nullptr;
           a.zeros = m->zeros_dev;
           a.dst_pool = nullptr;
+          apply_conv_options(m, a);
           a.accumulate = init[srcs[part]];
           rc = (m->use_dma && (a.bn == 64 || m->dma32)) ? launch_conv3x3_dma(a, s) : launch_conv3x3(a, s);
           if (rc != PH_OK) return rc;

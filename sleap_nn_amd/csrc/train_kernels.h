@@ -23,7 +23,8 @@ struct WgradArgs {
 
 int launch_loss(const float* pred, const float* tgt, int B, int C, int H, int W, float loss_weight, const OhkmParams& ok, float* scratch, float* dy,
                 float* loss_out, hipStream_t s);
-int launch_total_loss(const float* head_loss, const float* w_dev, int n, float* out, hipStream_t s);
+constexpr int PH_MAX_OUTPUTS = 8;
+int launch_total_loss(const float* head_loss, const float* w_host, int n, float* out, hipStream_t s);
 int launch_head_bwd(const float* dy, const float* y_out, int sigmoid, const float* x, const float* w_packed, int B, int HW, int cin, int cp, int cout,
                     int accumulate, float* dx, float* gw, float* gb, float* scratch, hipStream_t s);
 int64_t head_bwd_scratch_floats(int cp, int cout, int64_t npix);

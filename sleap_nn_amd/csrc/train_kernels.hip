@@ -99,10 +99,14 @@ __global__ void loss_coeff_kernel(const float* __restrict__ partial, int C, doub
   loss_out[0] = loss;
 }
 
-__global__ void total_loss_kernel(const float* __restrict__ head_loss, const float* __restrict__ w, int n, float* __restrict__ out) {
+struct LossWeights {
+  float w[PH_MAX_OUTPUTS];
+};
+// the few loss weights travel by value as a kernel argument: no host->device copy on the step's stream (capturable)
+__global__ void total_loss_kernel(const float* __restrict__ head_loss, LossWeights w, int n, float* __restrict__ out) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     float t = 0.f;
-    for (int i = 0; i < n; ++i) t += w[i] * head_loss[i];
+    for (int i = 0; i < n; ++i) t += w.w[i] * head_loss[i];
     out[0] = t;
   }
 }
@@ -133,8 +137,14 @@ int launch_loss(const float* pred, const float* tgt, int B, int C, int H, int W,
   return PH_OK;
 }
 
-int launch_total_loss(const float* head_loss, const float* w_dev, int n, float* out, hipStream_t s) {
-  hipLaunchKernelGGL(total_loss_kernel, dim3(1), dim3(1), 0, s, head_loss, w_dev, n, out);
+int launch_total_loss(const float* head_loss, const float* w_host, int n, float* out, hipStream_t s) {
+  if (n > PH_MAX_OUTPUTS) {
+    set_error("loss: more than %d heads", PH_MAX_OUTPUTS);
+    return PH_E_INVALID;
+  }
+  LossWeights w{};
+  for (int i = 0; i < n; ++i) w.w[i] = w_host[i];
+  hipLaunchKernelGGL(total_loss_kernel, dim3(1), dim3(1), 0, s, head_loss, w, n, out);
   PH_HIP_CHECK(hipGetLastError());
   return PH_OK;
 }

@@ -50,6 +50,7 @@ class HipBackend:
         self.model = model.to(dev).eval()
         self.use_graph = bool(use_graph)
         self._graphs: Dict[tuple, tuple] = {}
+        self._graph_generation = -1
 
     @property
     def device(self) -> str:
@@ -77,6 +78,12 @@ class HipBackend:
         return out
 
     def _forward_graph(self, x: torch.Tensor, code) -> Dict[str, torch.Tensor]:
+        """A captured graph holds raw pointers into the model's workspace and packed weights.  Each entry therefore keeps
+        a reference to the workspace tensor it was captured on (so the allocator cannot hand that memory to anybody
+        else) and the model generation it saw; any reallocation / recompile / weight reload bumps the generation and
+        the stale entries are dropped and re-captured instead of being replayed into freed memory."""
+        if self._graph_generation != self.model.generation:
+            self._graphs.clear()
         key = (tuple(x.shape), x.dtype, code)
         entry = self._graphs.get(key)
         if entry is None:
@@ -87,12 +94,16 @@ class HipBackend:
                 self.model.forward(static_in, in_dtype=code)
             torch.cuda.current_stream(self._device).wait_stream(stream)
             torch.cuda.synchronize(self._device)
+            if self._graph_generation != self.model.generation:  # the warm-up grew the workspace / rebuilt the handle
+                self._graphs.clear()
+                self._graph_generation = self.model.generation
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 static_out = self.model.forward(static_in, in_dtype=code)
-            entry = (graph, static_in, static_out)
+            assert self.model.generation == self._graph_generation, "capture must not reallocate"
+            entry = (graph, static_in, static_out, self.model._workspace)
             self._graphs[key] = entry
-        graph, static_in, static_out = entry
+        graph, static_in, static_out, _ws = entry
         static_in.copy_(x, non_blocking=True)
         graph.replay()
         return static_out

@@ -72,37 +72,34 @@ class InferenceLayer(ABC):
         torch.cuda.synchronize()
 
     def _extract_confmaps(self, raw_out: dict) -> torch.Tensor:
-        if self._TORCH_OUTPUT_KEY in raw_out:
-            return raw_out[self._TORCH_OUTPUT_KEY]
-        if self._HEAD_OUTPUT_KEY and self._HEAD_OUTPUT_KEY in raw_out:
-            return raw_out[self._HEAD_OUTPUT_KEY]
-        tensors = [v for v in raw_out.values() if isinstance(v, torch.Tensor)]
-        if len(tensors) == 1:
-            return tensors[0]
-        raise KeyError(
-            f"{type(self).__name__}.postprocess could not find confmaps in raw_out keys={list(raw_out.keys())}; "
-            f"expected '{self._TORCH_OUTPUT_KEY}' or '{self._HEAD_OUTPUT_KEY or '(not set)'}'."
-        )
+        """Which entry of the backend's dict holds the confidence maps (contract of base.py:182-205): the wrapped
+        bare-tensor key wins, then the layer's own head name, then a dict with exactly one tensor; else ``KeyError``."""
+        for key in (self._TORCH_OUTPUT_KEY, self._HEAD_OUTPUT_KEY):
+            if key and key in raw_out:
+                return raw_out[key]
+        only = [v for v in raw_out.values() if torch.is_tensor(v)]
+        if len(only) != 1:
+            wanted = " or ".join(repr(k) for k in (self._TORCH_OUTPUT_KEY, self._HEAD_OUTPUT_KEY or "(not set)"))
+            raise KeyError(f"{type(self).__name__}.postprocess: no confidence maps among {sorted(raw_out)}; expected {wanted}")
+        return only[0]
 
     @staticmethod
     def _to_4d_tensor(image: ImageInput) -> torch.Tensor:
-        """Coerce to (B, C, H, W) keeping the dtype (base.py:212-253 heuristics)."""
+        """(H,W) / (H,W,C) / (C,H,W) / (B,H,W,C) / (B,C,H,W) -> (B,C,H,W) as a view, dtype untouched (uint8 frames must
+        reach the resize kernels as uint8).  Layout rule of base.py:212-253: an axis of <= 4 entries in the last
+        position, with more than 4 entries where channels-first would put the channels, means channels-last."""
         if isinstance(image, np.ndarray):
-            t = torch.from_numpy(image)
-        elif isinstance(image, torch.Tensor):
-            t = image
-        else:
+            image = torch.from_numpy(image)
+        if not torch.is_tensor(image):
             raise TypeError(f"image must be np.ndarray or torch.Tensor, got {type(image).__name__}")
-        if t.ndim == 2:
-            t = t[None, None]
-        elif t.ndim == 3:
-            t = t.permute(2, 0, 1)[None] if (t.shape[-1] <= 4 and t.shape[0] > 4) else t[None]
-        elif t.ndim == 4:
-            if t.shape[-1] <= 4 and t.shape[1] > 4:
-                t = t.permute(0, 3, 1, 2)
-        else:
-            raise ValueError(f"unexpected image rank {t.ndim}: shape {tuple(t.shape)}")
-        return t
+        if image.ndim not in (2, 3, 4):
+            raise ValueError(f"unexpected image rank {image.ndim}: shape {tuple(image.shape)}")
+        if image.ndim == 2:
+            return image.view(1, 1, *image.shape)
+        batched = image if image.ndim == 4 else image.unsqueeze(0)
+        ch_first_axis = image.shape[image.ndim - 3]
+        channels_last = image.shape[-1] <= 4 and ch_first_axis > 4
+        return batched.movedim(-1, 1) if channels_last else batched
 
     def _apply_full_preprocess(self, x: torch.Tensor, *, max_stride: int = 1, unsqueeze_n_samples: bool = True, skip_sizematcher: bool = False):
         """Channel coercion -> per-sample sizematcher (records eff_scale) -> input scale -> pad to stride -> n_samples axis

@@ -65,6 +65,9 @@ class TrainingModule:
         self.step_count = 0
         self._grad_ws: Optional[torch.Tensor] = None
         self._loss = torch.zeros(1 + len(model.heads), dtype=torch.float32, device=dev)
+        # from here on the device arena owns the parameters: every (re)compile of the model's handle -- eval() for a
+        # validation pass, train() afterwards, a fusion switch -- re-gathers its packed weights from self.params
+        self.model.bind_live_params(self.params)
         self.model._ensure(dev)
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             dist.broadcast(self.params, src=0)  # identical initial weights on every rank (DDP semantics)

@@ -90,7 +90,7 @@ def test_convnext_rows_not_multiple_of_tile_and_gray_to_rgb():
     _run(bb, _heads(3, 2), "single_instance", img)
 
 
-def test_small_map_convs_row_gemm_equals_halo_kernel(monkeypatch):
+def test_small_map_convs_row_gemm_equals_halo_kernel():
     """3x3 convolutions on small feature maps run as 9-tap row GEMMs (two-source concat included);
     the halo-tiled kernel must give the same maps (both vs the oracle, and vs each other)."""
     from sleap_nn_amd.architectures.model import Model
@@ -103,11 +103,10 @@ def test_small_map_convs_row_gemm_equals_halo_kernel(monkeypatch):
     img = torch.randint(0, 256, (3, 1, 80, 48), dtype=torch.uint8, generator=g)  # maps 80x48 ... 5x3
     ref = O.model_forward(sd, bb, heads, "single_instance", img)["SingleInstanceConfmapsHead"]
     outs = {}
-    for tag, thr in (("gemm", "2.0"), ("halo", "0")):
-        monkeypatch.setenv("PH_CONV_GEMM_FILL", thr)
+    for tag, thr in (("gemm", 2.0), ("halo", 0.0)):
         m = Model("unet", bb, heads, "single_instance")
         m.load_state_dict(sd)
-        m.to(DEV)
+        m.to(DEV).set_option("conv_gemm_fill", thr)  # per-handle option (the library reads no environment)
         outs[tag] = m(img.to(DEV))["SingleInstanceConfmapsHead"].cpu()
     for tag, o in outs.items():
         assert (o - ref).abs().max().item() <= ATOL, tag

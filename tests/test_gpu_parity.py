@@ -375,6 +375,33 @@ def test_cfg3_network_vs_oracle_one_frame():
         assert err <= CMS_ATOL, (k, err, v.abs().max().item())
 
 
+def test_cfg3_benched_workload_full_size_vs_oracle_and_batch_invariance():
+    """The workload bench.py times -- cfg3 network, bench.py's own weights (xavier seed 1234, heads x0.05), 1024x1024 uint8
+    frames -- under parity at FULL size: two frames against the oracle (confmaps / PAFs within 1e-4), and frame 0 of a
+    32-frame launch bit-identical to the same frame launched alone (persistent-workgroup tile walk, XCD dealing and
+    workspace offsets all change with the batch; the arithmetic per output must not)."""
+    import bench
+    from sleap_nn_amd.architectures.model import Model
+
+    m = Model("unet", bench.CFG3_BB, bench.CFG3_HEADS, "bottomup").init_xavier_(seed=1234, head_scale=0.05).to(DEV)
+    sd = m.state_dict()
+    g = torch.Generator().manual_seed(4321)
+    frames = torch.randint(0, 256, (32, 1, bench.SIZE, bench.SIZE), dtype=torch.uint8, generator=g)
+    ref = O.model_forward(sd, bench.CFG3_BB, bench.CFG3_HEADS, "bottomup", frames[:2])
+    dev_frames = frames.to(DEV)
+    out2 = {k: v.clone() for k, v in m(dev_frames[:2].contiguous()).items()}
+    for k, v in ref.items():
+        err = (out2[k].cpu() - v).abs().max().item()
+        assert err <= CMS_ATOL, (k, err, v.abs().max().item())
+    one = {k: v.clone() for k, v in m(dev_frames[:1].contiguous()).items()}
+    full = m(dev_frames)
+    torch.cuda.synchronize()
+    for k in one:
+        assert torch.equal(full[k][:1], one[k]), k
+        assert torch.equal(full[k][:2], out2[k]), k
+        assert torch.isfinite(full[k]).all()
+
+
 def _wz(z, prefix):
     return {k[len(prefix):]: torch.from_numpy(z[k]) for k in z.files if k.startswith(prefix)}
 
@@ -563,9 +590,10 @@ def class_names_ok(names, cfg):
     return list(names) == list(cfg["heads"]["class_vectors"]["classes"])
 
 
-def test_graph_replay_equals_eager_and_cuts_latency():
+def test_graph_replay_equals_eager():
     """HipBackend(use_graph=True): the forward of a shape is captured once into a hipGraph and replayed; outputs
-    must be bit-identical to the eager launches (same kernels, same order) for every replay, also after the input changes."""
+    must be bit-identical to the eager launches (same kernels, same order) for every replay, also after the input changes.
+    (Latency is reported, not asserted: wall-clock assertions flake.)"""
     import time
 
     from sleap_nn_amd.inference.backends import HipBackend
@@ -581,6 +609,7 @@ def test_graph_replay_equals_eager_and_cuts_latency():
         torch.cuda.synchronize()
         for k in a:
             assert torch.equal(a[k], b[k]), (rep, k)
+    assert len(graph._graphs) == 1
     t = {}
     for name, be in (("eager", eager), ("graph", graph)):
         for _ in range(5):
@@ -592,7 +621,41 @@ def test_graph_replay_equals_eager_and_cuts_latency():
         torch.cuda.synchronize()
         t[name] = (time.perf_counter() - t0) / 50
     print(f"latency per 64x64 frame: eager {t['eager'] * 1e3:.3f} ms, graph {t['graph'] * 1e3:.3f} ms")
-    assert t["graph"] <= t["eager"] * 1.2
+
+
+def test_graph_entries_survive_workspace_growth_and_weight_reload():
+    """A captured graph holds raw pointers into the model's workspace and packed weights.  Capture a small shape, then a
+    larger one (the workspace is reallocated), then replay the small one: it must equal eager -- stale entries are
+    re-captured, never replayed into freed memory.  Same after load_state_dict (the handle is rebuilt)."""
+    from sleap_nn_amd.inference.backends import HipBackend
+
+    z = G.load("unet_tiny_interp.npz")
+    cfg = G.config(z)
+    w = G.weights(z)
+    eager, graph = HipBackend(_model(cfg, w), DEV), HipBackend(_model(cfg, w), DEV, use_graph=True)
+    g = torch.Generator().manual_seed(5)
+    cin = cfg["backbone"]["in_channels"]
+    small = torch.randint(0, 256, (1, cin, 64, 64), dtype=torch.uint8, generator=g).to(DEV)
+    big = torch.randint(0, 256, (4, cin, 192, 256), dtype=torch.uint8, generator=g).to(DEV)
+
+    def same(x):
+        a, b = eager(x), graph(x)
+        torch.cuda.synchronize()
+        return all(torch.equal(a[k], b[k]) for k in a)
+
+    assert same(small)
+    gen0 = graph.model.generation
+    assert same(big)
+    assert graph.model.generation != gen0  # the workspace grew
+    junk = torch.full((graph.model._workspace.numel() // 4,), float("nan"), device=DEV)  # whatever the allocator recycles is poisoned
+    assert same(small) and same(big) and same(small)
+    del junk
+    w2 = {k: v * 0.5 for k, v in w.items()}
+    eager.model.load_state_dict(w2)
+    graph.model.load_state_dict(w2)
+    assert same(small) and same(big)
+    for e in graph._graphs.values():
+        assert e[3] is graph.model._workspace  # every live entry pins the workspace it was captured on
 
 
 def test_forward_is_bitwise_deterministic_and_stream_safe():
@@ -616,17 +679,19 @@ def test_forward_is_bitwise_deterministic_and_stream_safe():
         assert torch.equal(a[k], b[k]), k
 
 
-def test_direct_convolution_kernels_still_match_golden():
-    """The Winograd kernels are the default; the direct 9-tap kernels stay in the library (transposed convs, A/B runs).
-    The switch is read once per process, so the golden forward tests are re-run in a child process with it off."""
-    import os
-    import subprocess
-    import sys
-
-    env = dict(os.environ, PH_CONV_WINO="0", PH_STEM_WINO="0")
-    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", f"{__file__}::test_forward_matches_reference_golden",
-                        f"{__file__}::test_fused_pool_epilogue_odd_sizes_and_unfused_equivalence"], env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+@pytest.mark.parametrize("name", ["unet_tiny_interp.npz", "unet_tiny_bu13.npz", "ckpt_bottomup.npz"])
+def test_direct_convolution_kernels_still_match_golden(name):
+    """The Winograd kernels are the default; the direct 9-tap kernels stay in the library (transposed convs, A/B runs)
+    and are selected per handle with ``set_option`` -- the library has no process-global switches."""
+    z = G.load(name)
+    cfg = G.config(z)
+    m = _model(cfg, G.weights(z)).set_option("conv_wino", 0).set_option("stem_wino", 0)
+    out = m(torch.from_numpy(z["image"]).squeeze(1).to(DEV))
+    assert m.get_option("conv_wino") == 0.0
+    for k in out:
+        assert np.allclose(out[k].cpu().numpy(), z["out/" + k], atol=CMS_ATOL), k
+    with pytest.raises(Exception, match="unknown option"):
+        m.set_option("no_such_option", 1)
 
 
 def test_resize_kernel_matches_the_cpu_operator():

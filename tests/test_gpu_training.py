@@ -207,3 +207,68 @@ def test_multiclass_topdown_training_matches_autograd():
     got = loss.cpu().numpy()
     np.testing.assert_allclose(got, np.array(losses), rtol=2e-5, atol=1e-6)
     _check_grads(tm, ref_grads, rtol=2e-4)
+
+
+def test_backward_cfg3_network_with_interior_tiles():
+    """Backward parity of the benched network (cfg3, 7.8 M parameters) at a size whose feature maps have interior tiles in
+    every kernel (256x320, B=2; the cases above use small nets): every parameter gradient within 1e-4 of its tensor's scale."""
+    import bench
+
+    bb, heads, mt = dict(bench.CFG3_BB), {k: dict(v) for k, v in bench.CFG3_HEADS.items()}, "bottomup"
+    sd, img, targets, lw, tm = _setup(bb, heads, mt, (256, 320), 2, seed=3)
+    ref_losses, ref_grads = O.training_step(sd, bb, heads, mt, img, targets, lw)
+    loss = tm.forward_backward(img, targets).cpu().numpy()
+    assert np.allclose(loss, np.array(ref_losses, dtype=np.float32), rtol=1e-5, atol=1e-6)
+    _check_grads(tm, ref_grads)
+
+
+@pytest.mark.parametrize("seed", [0, 7])
+def test_backward_randomised_shapes(seed):
+    """A few draws of the randomised sweep (tools/stress_backward.py): awkward channel counts, odd tile counts, both model types."""
+    rng = np.random.default_rng(seed)
+    done = 0
+    while done < 3:
+        down = int(rng.integers(2, 5))
+        os_ = int(2 ** rng.integers(0, min(3, down)))
+        bb = {"in_channels": int(rng.choice([1, 3])), "kernel_size": 3, "filters": int(rng.choice([4, 8, 12, 16, 20, 24, 32])), "filters_rate": float(rng.choice([1.5, 2.0])),
+              "max_stride": 2**down, "stem_stride": None, "middle_block": True, "up_interpolate": True, "stacks": 1, "convs_per_block": 2, "output_stride": os_}
+        names = [f"n{i}" for i in range(int(rng.integers(2, 5)))]
+        mt = str(rng.choice(["single_instance", "bottomup"]))
+        heads = {"confmaps": {"part_names": names, "output_stride": os_, "loss_weight": 1.0}}
+        if mt == "bottomup":
+            heads["pafs"] = {"edges": [[names[i], names[i + 1]] for i in range(len(names) - 1)], "output_stride": min(2**down, os_ * 2), "loss_weight": 0.5}
+        mult = 2**down
+        B = int(rng.integers(1, 4))
+        hw = (mult * int(rng.integers(1, 7)), mult * int(rng.integers(1, 7)))
+        try:
+            sd, img, targets, lw, tm = _setup(bb, heads, mt, hw, B, seed=int(rng.integers(1 << 30)))
+        except ValueError:  # a PAF stride the decoder does not produce: not a valid reference config either
+            continue
+        ref_losses, ref_grads = O.training_step(sd, bb, heads, mt, img, targets, lw)
+        loss = tm.forward_backward(img, targets).cpu().numpy()
+        assert np.allclose(loss, np.array(ref_losses, dtype=np.float32), rtol=1e-5, atol=1e-6), (bb, heads, hw, B)
+        _check_grads(tm, ref_grads)
+        done += 1
+
+
+def test_eval_train_round_trip_keeps_trained_weights():
+    """After optimizer steps the live parameters exist only in the TrainingModule's device arena.  Wrapping the model in a
+    HipBackend for validation switches it to the fused program (handle rebuilt) and train() switches back: both
+    recompiles must pick the arena's CURRENT values up, not the initial host copy."""
+    from sleap_nn_amd.inference.backends import HipBackend
+
+    bb, heads, mt = _cfg(8, 8, 2)
+    sd, img, targets, lw, tm = _setup(bb, heads, mt, (48, 64), 2, seed=11, lr=1e-2)
+    for _ in range(3):
+        tm.training_step({"image": img, **targets})
+    trained = tm.state_dict()
+    assert any(not torch.equal(trained[k], sd[k]) for k in sd)
+    ref = O.model_forward({k: v.clone() for k, v in trained.items()}, bb, heads, mt, img)
+    val = HipBackend(tm.model, DEV)(img)  # eval(): fused program, new handle
+    for k, v in ref.items():
+        assert (val[k].cpu() - v).abs().max().item() <= 1e-4, k
+    tm.model.train(True)  # back to the training program: another new handle
+    ref_losses, ref_grads = O.training_step(trained, bb, heads, mt, img, targets, lw)
+    loss = tm.forward_backward(img, targets).cpu().numpy()
+    assert np.allclose(loss, np.array(ref_losses, dtype=np.float32), rtol=1e-5, atol=1e-6)
+    _check_grads(tm, ref_grads)
