@@ -153,7 +153,8 @@ def cpu_baseline(model, layer, cms_dev, pafs_dev, dev, budget_s: float = 24.0):
         "value_1thread": 1.0 / (f_1 + p_1),
         "sample": f"{n_f} forwards of 1 frame 1024x1024 ({1e3 * f_n:.0f} ms each at {best_t} threads; {n_f1} at 1 thread: {1e3 * f_1:.0f} ms) + "
                   f"{n_p} post-process passes over 2 rendered frames ({1e3 * p_n:.1f} ms/frame); oracle/cpu_ref.py, torch-CPU fp32",
-        "parity_on_this_sample": {"max_abs_confmap_diff": d_cms, "max_abs_paf_diff": d_paf, "peak_indices_equal": peaks_equal,
+        "parity_on_this_sample": {"max_abs_confmap_diff": d_cms, "max_abs_paf_diff": d_paf,
+                                  "confmap_abs_max": float(ref["MultiInstanceConfmapsHead"].abs().max()), "paf_abs_max": float(ref["PartAffinityFieldsHead"].abs().max()), "peak_indices_equal": peaks_equal,
                                   "n_peaks": int(rp.shape[0]), "grouping_equal": grouping_equal, "n_instances": int((~np.isnan(rs)).sum())},
     }
 

@@ -154,12 +154,15 @@ int64_t ph_model_backward_workspace_bytes(const ph_model* m, int32_t batch, int3
 /* Loss + backward of the last ph_model_forward (same input, shapes and activation workspace).
  *   head_out_dev[i] / target_dev[i]: (B, c_i, h_i, w_i) NCHW fp32 predictions and targets.
  *   loss = sum_i loss_weights[i] * (MSE_i [+ OHKM_i]);  loss_dev: float[1 + n_outputs] = {total, per head}.
+ *   sample_weights_dev: NULL (plain nn.MSELoss) or float[B] on the device: MSE_i becomes mean_b(w_b * mean_chw(diff^2)),
+ *   the negative-sample weighting of training/lightning_modules.py:526-545 (w_b = negative_loss_weight for negative
+ *   frames, 1 otherwise; train stage only -- the caller passes NULL for validation).  OHKM is not weighted (as there).
  *   grads_flat_dev: d loss / d params in the canonical arena layout (every entry is written).
  * Deterministic (fixed-order reductions, no float atomics). */
 int ph_model_backward(ph_model* m, const void* input_dev, int32_t in_dtype, int32_t batch, int32_t in_channels,
                       int32_t height, int32_t width, const void* act_workspace_dev, void* grad_workspace_dev,
                       int64_t grad_workspace_bytes, const float* const* head_out_dev, const float* const* target_dev,
-                      const float* loss_weights_host, int32_t ohkm_enabled, float hard_to_easy_ratio,
+                      const float* loss_weights_host, const float* sample_weights_dev, int32_t ohkm_enabled, float hard_to_easy_ratio,
                       int32_t min_hard_keypoints, int32_t max_hard_keypoints, float ohkm_loss_scale,
                       float* loss_dev, float* grads_flat_dev, void* stream);
 

@@ -453,6 +453,9 @@ def unet_forward(sd: Dict[str, torch.Tensor], bb: dict, x: torch.Tensor, collect
 def model_forward(sd, bb: dict, head_cfgs: dict, model_type: str, image: torch.Tensor, collect: Optional[dict] = None, backbone: str = "unet") -> Dict[str, torch.Tensor]:
     """model.py:237-261 with the LightningModule forward's normalisation in front."""
     x = normalize_input(image)
+    # float64 weights select a float64 evaluation (tolerance studies only: how far is fp32 autograd itself from the exact
+    # gradient?); with the reference's fp32 weights this is a no-op
+    x = x.to(next(iter(sd.values())).dtype)
     cin = int(bb["in_channels"])
     if x.shape[-3] != cin:
         if x.shape[-3] == 1:
@@ -1084,8 +1087,21 @@ def ohkm_loss(y_gt: torch.Tensor, y_pr: torch.Tensor, hard_to_easy_ratio=2.0, mi
     return torch.sum(k_vals * loss_scale) / (shp[0] * shp[2] * shp[3] * k)
 
 
+def negative_weighted_mse(y_pr: torch.Tensor, y_gt: torch.Tensor, is_negative: Optional[torch.Tensor], negative_loss_weight: float = 1.0, stage: str = "train") -> torch.Tensor:
+    """lightning_modules.py:490-545: plain nn.MSELoss without ``is_negative``; else the mean over samples of the per-sample
+    MSE, negatives weighted by ``negative_loss_weight`` in the train stage only."""
+    if is_negative is None:
+        return F.mse_loss(y_pr, y_gt)
+    per_sample = (y_pr - y_gt).pow(2).mean(dim=list(range(1, y_pr.ndim)))
+    if stage != "train" or negative_loss_weight == 1.0:
+        return per_sample.mean()
+    w = torch.where(is_negative.bool(), torch.tensor(float(negative_loss_weight), dtype=per_sample.dtype), torch.tensor(1.0, dtype=per_sample.dtype))
+    return (per_sample * w).mean()
+
+
 def training_step(sd: Dict[str, torch.Tensor], bb: dict, head_cfgs: dict, model_type: str, image: torch.Tensor, targets: Dict[str, torch.Tensor],
-                  loss_weights: Sequence[float], ohkm: Optional[dict] = None, backbone: str = "unet"):
+                  loss_weights: Sequence[float], ohkm: Optional[dict] = None, backbone: str = "unet", is_negative: Optional[torch.Tensor] = None,
+                  negative_loss_weight: float = 1.0, stage: str = "train"):
     """Forward + weighted per-head MSE (+OHKM) + autograd backward.  Returns (losses [total, heads...], grads dict)."""
     params = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
     out = model_forward(params, bb, head_cfgs, model_type, image, backbone=backbone)
@@ -1095,7 +1111,7 @@ def training_step(sd: Dict[str, torch.Tensor], bb: dict, head_cfgs: dict, model_
         if h == "ClassVectorsHead":  # lightning_modules.py:2655-2662: CrossEntropyLoss on the (already soft-maxed) head output
             hl.append(F.cross_entropy(out[h], targets[h]))
             continue
-        l = F.mse_loss(out[h], targets[h])
+        l = negative_weighted_mse(out[h], targets[h], is_negative, negative_loss_weight, stage)
         if ohkm:
             l = l + ohkm_loss(targets[h], out[h], **ohkm)
         hl.append(l)

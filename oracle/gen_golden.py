@@ -610,8 +610,105 @@ def schedulers_fixture():
     save("schedulers.npz", **arrs)
 
 
+def _reference_method(path: str, cls: str, name: str, extra_globals: dict):
+    """Compile ONE method of a reference class straight from its source file (the module itself cannot be imported here:
+    lightning_modules.py pulls in lightning / matplotlib / wandb).  The reference's own lines run unmodified, as a function
+    whose ``self`` the caller supplies; nothing is copied into this repository."""
+    import ast
+
+    src = open(path).read()
+    tree = ast.parse(src)
+    for node in tree.body:
+        if isinstance(node, ast.ClassDef) and node.name == cls:
+            for fn in node.body:
+                if isinstance(fn, ast.FunctionDef) and fn.name == name:
+                    mod = ast.Module(body=[fn], type_ignores=[])
+                    ns = dict(extra_globals)
+                    exec(compile(mod, path, "exec"), ns)
+                    return ns[name]
+    raise KeyError(f"{cls}.{name} not found in {path}")
+
+
+def losses_fixture():
+    """the reference's loss arithmetic and one training step's gradients.
+    * compute_ohkm_loss (training/losses.py:8-63) on random maps for several parameter sets (the reference has no numeric
+      test of it);
+    * LightningModel._compute_negative_weighted_loss (training/lightning_modules.py:490-545) for train / val stages;
+    * one bottom-up training step of the reference ``Model`` (training_step :1850-1895: negative-weighted MSE + OHKM per
+      head, loss-weight sum) with autograd gradients of every parameter."""
+    from types import SimpleNamespace
+    from typing import Dict
+
+    from sleap_nn.training.losses import compute_ohkm_loss
+
+    neg_loss = _reference_method(os.path.join(REF, "sleap_nn", "training", "lightning_modules.py"), "LightningModel", "_compute_negative_weighted_loss",
+                                 {"torch": torch, "nn": torch.nn, "Dict": Dict})
+    arrs = {}
+    g = torch.Generator().manual_seed(31)
+    ohkm_cases = [
+        dict(hard_to_easy_ratio=2.0, min_hard_keypoints=2, max_hard_keypoints=None, loss_scale=5.0),
+        dict(hard_to_easy_ratio=1.2, min_hard_keypoints=1, max_hard_keypoints=3, loss_scale=2.0),
+        dict(hard_to_easy_ratio=50.0, min_hard_keypoints=4, max_hard_keypoints=None, loss_scale=1.0),
+        dict(hard_to_easy_ratio=1.0, min_hard_keypoints=0, max_hard_keypoints=2, loss_scale=7.5),
+    ]
+    for i, kw in enumerate(ohkm_cases):
+        y = torch.rand(3, 6, 14, 11, generator=g)
+        p = y + torch.randn(3, 6, 14, 11, generator=g) * torch.linspace(0.02, 0.3, 6).view(1, 6, 1, 1)
+        arrs[f"ohkm{i}/y"], arrs[f"ohkm{i}/p"] = _np(y), _np(p)
+        arrs[f"ohkm{i}/params"] = np.array([kw["hard_to_easy_ratio"], kw["min_hard_keypoints"], -1 if kw["max_hard_keypoints"] is None else kw["max_hard_keypoints"], kw["loss_scale"]], dtype=np.float64)
+        arrs[f"ohkm{i}/loss"] = np.array(float(compute_ohkm_loss(y_gt=y, y_pr=p, **kw)), dtype=np.float64)
+    arrs["n_ohkm"] = np.array(len(ohkm_cases))
+    y = torch.rand(5, 4, 9, 13, generator=g)
+    p = y + 0.1 * torch.randn(5, 4, 9, 13, generator=g)
+    neg = torch.tensor([False, True, False, True, True])
+    arrs["neg/y"], arrs["neg/p"], arrs["neg/is_negative"] = _np(y), _np(p), _np(neg)
+    for tag, w, stage, batch in (("w0.25_train", 0.25, "train", {"is_negative": neg}), ("w3_train", 3.0, "train", {"is_negative": neg}), ("w0.25_val", 0.25, "val", {"is_negative": neg}),
+                                 ("w1_train", 1.0, "train", {"is_negative": neg}), ("absent", 0.25, "train", {})):
+        arrs[f"neg/loss_{tag}"] = np.array(float(neg_loss(SimpleNamespace(negative_loss_weight=w), p, y, batch, stage=stage)), dtype=np.float64)
+
+    # ---- one training step of the reference Model (bottom-up, bilinear decoder): loss + every parameter gradient
+    bb = {"in_channels": 1, "kernel_size": 3, "filters": 8, "filters_rate": 2, "max_stride": 8, "stem_stride": None, "middle_block": True,
+          "up_interpolate": True, "stacks": 1, "convs_per_block": 2, "output_stride": 2}
+    names = ["a", "b", "c"]
+    heads = {"confmaps": {"part_names": names, "sigma": 1.5, "output_stride": 2, "loss_weight": 1.0},
+             "pafs": {"edges": [["a", "b"], ["b", "c"]], "sigma": 4.0, "output_stride": 4, "loss_weight": 0.6}}
+    torch.manual_seed(77)
+    m = Model("unet", rh.attrdict(bb), rh.attrdict(heads), "bottomup").train()
+    with torch.no_grad():
+        for _, prm in m.named_parameters():
+            torch.nn.init.xavier_uniform_(prm) if prm.dim() > 1 else prm.uniform_(-0.1, 0.1)
+    img = torch.randint(0, 256, (4, 1, 48, 64), dtype=torch.uint8, generator=g)
+    is_neg = torch.tensor([False, True, False, False])
+    ohkm = dict(hard_to_easy_ratio=1.5, min_hard_keypoints=1, max_hard_keypoints=None, loss_scale=3.0)
+    nlw, lws = 0.3, [1.0, 0.6]
+    self_ = SimpleNamespace(negative_loss_weight=nlw)
+    preds = m(img.float() / 255.0)  # normalize_on_gpu of uint8 frames
+    tg = {k: torch.rand(v.shape, generator=g) * 0.5 for k, v in preds.items()}
+    hl = []
+    for k in ("MultiInstanceConfmapsHead", "PartAffinityFieldsHead"):  # lightning_modules.py:1860-1895
+        l = neg_loss(self_, preds[k], tg[k], {"is_negative": is_neg})
+        l = l + compute_ohkm_loss(y_gt=tg[k], y_pr=preds[k], **ohkm)
+        hl.append(l)
+    total = sum(s_ * l for s_, l in zip(lws, hl))
+    total.backward()
+    for k, v in m.state_dict().items():
+        arrs["step/w/" + k] = _np(v)
+    for k, prm in m.named_parameters():
+        arrs["step/g/" + k] = _np(prm.grad)
+    arrs["step/image"] = _np(img)
+    arrs["step/is_negative"] = _np(is_neg)
+    for k, v in tg.items():
+        arrs["step/target/" + k] = _np(v)
+    arrs["step/losses"] = np.array([float(total)] + [float(l) for l in hl], dtype=np.float64)
+    arrs["step/config_json"] = np.array(json.dumps({"backbone": bb, "heads": heads, "model_type": "bottomup", "negative_loss_weight": nlw, "loss_weights": lws,
+                                                    "ohkm": {**ohkm, "max_hard_keypoints": -1}}))
+    save("losses.npz", **arrs)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
+    if not only or "losses" in only:
+        losses_fixture()
     if not only or "schedulers" in only:
         schedulers_fixture()
     if not only or "core" in only:

@@ -56,7 +56,7 @@ int build_bwd_plan(const ph_model* m, int B, int H, int W, BwdPlan& bp) {
       bp.head_dy_off[d.out_index] = off;
       off += align_up((int64_t)B * d.cout * s0.h * s0.w * 4, 256);
       scratch = std::max<int64_t>(scratch, head_bwd_scratch_floats(s0.cp, d.cout, (int64_t)B * s0.h * s0.w));
-      scratch = std::max<int64_t>(scratch, (int64_t)d.cout * 64 + d.cout + 64);
+      scratch = std::max<int64_t>(scratch, loss_scratch_floats(d.cout) + 64);
     } else if (d.kind == PH_OP_CONV) {
       const SlotShape& s0 = bp.act.slots[d.src0];
       scratch = std::max<int64_t>(scratch, wgrad_slab_floats(d.cin0, d.cout, B, s0.h, s0.w));
@@ -113,7 +113,7 @@ int64_t ph_model_backward_workspace_bytes(const ph_model* m, int32_t batch, int3
 
 int ph_model_backward(ph_model* m, const void* input_dev, int32_t in_dtype, int32_t batch, int32_t in_channels, int32_t height, int32_t width,
                       const void* act_workspace_dev, void* grad_workspace_dev, int64_t grad_workspace_bytes, const float* const* head_out_dev,
-                      const float* const* target_dev, const float* loss_weights_host, int32_t ohkm_enabled, float hard_to_easy_ratio,
+                      const float* const* target_dev, const float* loss_weights_host, const float* sample_weights_dev, int32_t ohkm_enabled, float hard_to_easy_ratio,
                       int32_t min_hard_keypoints, int32_t max_hard_keypoints, float ohkm_loss_scale, float* loss_dev, float* grads_flat_dev, void* stream) {
   PH_REQUIRE(m && input_dev && act_workspace_dev && grad_workspace_dev && head_out_dev && target_dev && loss_weights_host && loss_dev && grads_flat_dev,
              "ph_model_backward: null argument");
@@ -151,7 +151,8 @@ int ph_model_backward(ph_model* m, const void* input_dev, int32_t in_dtype, int3
     if (d.flags & PH_FLAG_SOFTMAX)  // class-vector head: cross entropy on the softmax output, gradient wrt the logits
       rc = launch_class_ce(head_out_dev[d.out_index], target_dev[d.out_index], batch, d.cout, lw[d.out_index], dy, loss_dev + 1 + d.out_index, s);
     else
-      rc = launch_loss(head_out_dev[d.out_index], target_dev[d.out_index], batch, d.cout, s0.h, s0.w, lw[d.out_index], ok, scratch, dy, loss_dev + 1 + d.out_index, s);
+      rc = launch_loss(head_out_dev[d.out_index], target_dev[d.out_index], sample_weights_dev, batch, d.cout, s0.h, s0.w, lw[d.out_index], ok, scratch, dy,
+                       loss_dev + 1 + d.out_index, s);
     if (rc != PH_OK) return rc;
   }
   // total = sum_h w_h * loss_h (the weights are a by-value kernel argument)

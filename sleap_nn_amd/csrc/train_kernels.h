@@ -21,8 +21,9 @@ struct WgradArgs {
   int cxp, coutp, B, H, W;
 };
 
-int launch_loss(const float* pred, const float* tgt, int B, int C, int H, int W, float loss_weight, const OhkmParams& ok, float* scratch, float* dy,
-                float* loss_out, hipStream_t s);
+int launch_loss(const float* pred, const float* tgt, const float* sample_w, int B, int C, int H, int W, float loss_weight, const OhkmParams& ok, float* scratch,
+                float* dy, float* loss_out, hipStream_t s);
+int64_t loss_scratch_floats(int C);
 constexpr int PH_MAX_OUTPUTS = 8;
 int launch_total_loss(const float* head_loss, const float* w_host, int n, float* out, hipStream_t s);
 int launch_head_bwd(const float* dy, const float* y_out, int sigmoid, const float* x, const float* w_packed, int B, int HW, int cin, int cp, int cout,

@@ -39,41 +39,54 @@ __device__ __forceinline__ float block_sum_256(float v, float* red /* >= 4 float
 // ---------------------------------------------------------------------------------------
 constexpr int SSE_SLICES = 64;
 
-__global__ __launch_bounds__(256) void sse_partial_kernel(const float* __restrict__ pred, const float* __restrict__ tgt, int B, int C, int HW,
-                                                          float* __restrict__ partial /* C x SSE_SLICES */) {
+// sample_w (B floats or nullptr): per-sample weights of the MSE term (negative-sample weighting,
+// lightning_modules.py:526-545); the weighted sums go to partial_w, the plain ones (OHKM ranks channels by them) to partial.
+__global__ __launch_bounds__(256) void sse_partial_kernel(const float* __restrict__ pred, const float* __restrict__ tgt, const float* __restrict__ sample_w, int B, int C,
+                                                          int HW, float* __restrict__ partial /* C x SSE_SLICES */, float* __restrict__ partial_w /* same, or unused */) {
   __shared__ float red[4];
   const int c = blockIdx.x, sl = blockIdx.y;
   const size_t n = (size_t)B * HW;
   const size_t per = (n + SSE_SLICES - 1) / SSE_SLICES;
   const size_t lo = (size_t)sl * per, hi = std::min(n, lo + per);
-  float acc = 0.f;
+  float acc = 0.f, acc_w = 0.f;
   for (size_t i = lo + threadIdx.x; i < hi; i += 256) {
     const size_t b = i / HW, hw = i - b * HW;
     const size_t o = (b * C + c) * HW + hw;
     const float d = pred[o] - tgt[o];
     acc += d * d;
+    if (sample_w) acc_w += sample_w[b] * (d * d);
   }
   const float t = block_sum_256(acc, red);
   if (threadIdx.x == 0) partial[c * SSE_SLICES + sl] = t;
+  if (sample_w) {  // workgroup-uniform
+    const float tw = block_sum_256(acc_w, red);
+    if (threadIdx.x == 0) partial_w[c * SSE_SLICES + sl] = tw;
+  }
 }
 
-// One thread: per-channel SSE -> head loss (MSE + optional OHKM) and the per-channel gradient
-// coefficient  coeff[c] = loss_weight * (2/N + [c is hard] * 2*loss_scale/n_elements).
-__global__ void loss_coeff_kernel(const float* __restrict__ partial, int C, double n_total /* B*C*H*W */, double n_per_channel /* B*H*W */,
+// One thread: per-channel SSE -> head loss (MSE + optional OHKM) and the gradient coefficients: the MSE term's
+// coeff[C] = loss_weight * 2/N (multiplied by the sample's weight in mse_grad_kernel) and the per-channel OHKM extra
+// coeff[c] = loss_weight * [c is hard] * 2*loss_scale/n_elements.
+__global__ void loss_coeff_kernel(const float* __restrict__ partial, const float* __restrict__ partial_w /* weighted sums or nullptr */, int C,
+                                  double n_total /* B*C*H*W */, double n_per_channel /* B*H*W */,
                                   float loss_weight, int ohkm, float hard_to_easy_ratio, int min_hard, int max_hard, float loss_scale,
-                                  float* __restrict__ coeff, float* __restrict__ loss_out /* [0] = this head's loss */) {
+                                  float* __restrict__ coeff /* C + 1 */, float* __restrict__ loss_out /* [0] = this head's loss */) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   float sse[256];
   float total = 0.f;
   for (int c = 0; c < C; ++c) {
-    float s = 0.f;
-    for (int k = 0; k < SSE_SLICES; ++k) s += partial[c * SSE_SLICES + k];
+    float s = 0.f, sw = 0.f;
+    for (int k = 0; k < SSE_SLICES; ++k) {
+      s += partial[c * SSE_SLICES + k];
+      if (partial_w) sw += partial_w[c * SSE_SLICES + k];
+    }
     sse[c] = s;
-    total += s;
+    total += partial_w ? sw : s;
   }
   float loss = (float)((double)total / n_total);
   const float base = (float)(2.0 / n_total);
-  for (int c = 0; c < C; ++c) coeff[c] = loss_weight * base;
+  coeff[C] = loss_weight * base;
+  for (int c = 0; c < C; ++c) coeff[c] = 0.f;
   if (ohkm) {
     float best = sse[0];
     for (int c = 1; c < C; ++c) best = fminf(best, sse[c]);
@@ -111,31 +124,37 @@ __global__ void total_loss_kernel(const float* __restrict__ head_loss, LossWeigh
   }
 }
 
-__global__ __launch_bounds__(256) void mse_grad_kernel(const float* __restrict__ pred, const float* __restrict__ tgt, const float* __restrict__ coeff, int C,
-                                                       int HW, size_t n, float* __restrict__ dy) {
+__global__ __launch_bounds__(256) void mse_grad_kernel(const float* __restrict__ pred, const float* __restrict__ tgt, const float* __restrict__ coeff,
+                                                       const float* __restrict__ sample_w, int C, int HW, size_t n, float* __restrict__ dy) {
+  const float base = coeff[C];
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-    const int c = (int)((i / HW) % C);
-    dy[i] = coeff[c] * (pred[i] - tgt[i]);
+    const size_t bc = i / HW;
+    const int c = (int)(bc % C);
+    const float k = (sample_w ? base * sample_w[bc / C] : base) + coeff[c];
+    dy[i] = k * (pred[i] - tgt[i]);
   }
 }
 
-int launch_loss(const float* pred, const float* tgt, int B, int C, int H, int W, float loss_weight, const OhkmParams& ok, float* scratch /* C*64 + C */,
-                float* dy, float* loss_out, hipStream_t s) {
+int launch_loss(const float* pred, const float* tgt, const float* sample_w, int B, int C, int H, int W, float loss_weight, const OhkmParams& ok,
+                float* scratch /* loss_scratch_floats(C) */, float* dy, float* loss_out, hipStream_t s) {
   if (C > 256) {
     set_error("loss: more than 256 channels");
     return PH_E_INVALID;
   }
   float* partial = scratch;
-  float* coeff = scratch + (size_t)C * SSE_SLICES;
+  float* partial_w = scratch + (size_t)C * SSE_SLICES;
+  float* coeff = scratch + (size_t)2 * C * SSE_SLICES;
   const int HW = H * W;
-  hipLaunchKernelGGL(sse_partial_kernel, dim3(C, SSE_SLICES), dim3(256), 0, s, pred, tgt, B, C, HW, partial);
-  hipLaunchKernelGGL(loss_coeff_kernel, dim3(1), dim3(1), 0, s, partial, C, (double)B * C * HW, (double)B * HW, loss_weight, ok.enabled, ok.hard_to_easy_ratio,
-                     ok.min_hard, ok.max_hard, ok.loss_scale, coeff, loss_out);
+  hipLaunchKernelGGL(sse_partial_kernel, dim3(C, SSE_SLICES), dim3(256), 0, s, pred, tgt, sample_w, B, C, HW, partial, partial_w);
+  hipLaunchKernelGGL(loss_coeff_kernel, dim3(1), dim3(1), 0, s, partial, sample_w ? partial_w : nullptr, C, (double)B * C * HW, (double)B * HW, loss_weight, ok.enabled,
+                     ok.hard_to_easy_ratio, ok.min_hard, ok.max_hard, ok.loss_scale, coeff, loss_out);
   const size_t n = (size_t)B * C * HW;
-  hipLaunchKernelGGL(mse_grad_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 16384)), dim3(256), 0, s, pred, tgt, coeff, C, HW, n, dy);
+  hipLaunchKernelGGL(mse_grad_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 16384)), dim3(256), 0, s, pred, tgt, coeff, sample_w, C, HW, n, dy);
   PH_HIP_CHECK(hipGetLastError());
   return PH_OK;
 }
+
+int64_t loss_scratch_floats(int C) { return (int64_t)2 * C * SSE_SLICES + C + 1; }
 
 int launch_total_loss(const float* head_loss, const float* w_host, int n, float* out, hipStream_t s) {
   if (n > PH_MAX_OUTPUTS) {

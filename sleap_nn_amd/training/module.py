@@ -38,7 +38,11 @@ class TrainingModule:
 
     def __init__(self, model: Model, device: str = "cuda", lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8, amsgrad: bool = False,
                  optimizer: str = "Adam", weight_decay: Optional[float] = None,
-                 loss_weights: Optional[Sequence[float]] = None, ohkm: Optional[OHKMConfig] = None) -> None:
+                 loss_weights: Optional[Sequence[float]] = None, ohkm: Optional[OHKMConfig] = None,
+                 negative_loss_weight: float = 1.0, lr_scheduler=None, max_epochs: Optional[int] = None) -> None:
+        """``negative_loss_weight``: weight of frames flagged ``is_negative`` in the train-stage MSE (lightning_modules.py:149-153,
+        526-545).  ``lr_scheduler``: the reference's scheduler config (a name or ``{name: {...}}``, lightning_modules.py:765-857);
+        ``self.lr`` then follows it: one ``on_epoch_end(val_loss)`` per epoch, like Lightning steps the scheduler."""
         L.lib()
         if not torch.cuda.is_available():
             raise RuntimeError("TrainingModule needs an MI355X; there is no CPU fallback")
@@ -57,6 +61,14 @@ class TrainingModule:
             raise ValueError("Adam with L2 weight decay is not what the reference configures; use optimizer='AdamW'")
         self.loss_weights = [float(w) for w in (loss_weights if loss_weights is not None else [h.loss_weight for h in model.heads])]
         self.ohkm = ohkm or OHKMConfig()
+        self.negative_loss_weight = float(negative_loss_weight)
+        if isinstance(lr_scheduler, str):  # defaults of the named scheduler (lightning_modules.py:773-785)
+            lr_scheduler = {lr_scheduler: {}}
+        from sleap_nn_amd.training.schedulers import LRSchedule
+
+        self.schedule = LRSchedule(lr, lr_scheduler, max_epochs) if lr_scheduler else None
+        if self.schedule is not None:
+            self.lr = self.schedule.lr
         self.params = model.flat_params().to(dev)
         self.grads = torch.zeros_like(self.params)
         self.exp_avg = torch.zeros_like(self.params)
@@ -78,10 +90,13 @@ class TrainingModule:
         with torch.cuda.device(self.device):
             L.check(L.lib().ph_model_set_params(self.model._handle, C.c_void_p(self.params.data_ptr()), L.current_stream_ptr()))
 
-    def forward_backward(self, image: torch.Tensor, targets: Dict[str, torch.Tensor]) -> torch.Tensor:
+    def forward_backward(self, image: torch.Tensor, targets: Dict[str, torch.Tensor], is_negative: Optional[torch.Tensor] = None,
+                         stage: str = "train") -> torch.Tensor:
         """Forward + loss + backward.  ``image``: (B[,1],C,H,W) uint8/float; ``targets``: head name ->
         (B, c, h, w) fp32.  Fills ``self.grads`` (local gradients) and returns the loss tensor
-        ``[total, head_0, head_1, ...]`` (device, no sync)."""
+        ``[total, head_0, head_1, ...]`` (device, no sync).  ``is_negative`` (B,) bool: frames without instances; in the
+        train stage their MSE is weighted by ``negative_loss_weight`` (``_compute_negative_weighted_loss``), any other
+        stage stays unweighted so ``val/loss`` equals plain ``nn.MSELoss``."""
         x = image.to(self.device, non_blocking=True)
         if x.dim() == 5:
             x = x.squeeze(1)
@@ -107,11 +122,17 @@ class TrainingModule:
             optr = (C.c_void_p * len(outs))(*[o.data_ptr() for o in outs])
             tptr = (C.c_void_p * len(tg))(*[t.data_ptr() for t in tg])
             lw = (C.c_float * len(self.loss_weights))(*self.loss_weights)
+            sw = None
+            if is_negative is not None and stage == "train" and self.negative_loss_weight != 1.0:
+                neg = torch.as_tensor(is_negative).to(self.device).reshape(-1).bool()
+                if neg.numel() != B:
+                    raise ValueError(f"is_negative has {neg.numel()} entries for a batch of {B}")
+                sw = torch.where(neg, float(self.negative_loss_weight), 1.0).to(torch.float32).contiguous()
             k = self.ohkm
             L.check(
                 lib.ph_model_backward(
                     m._handle, C.c_void_p(x.data_ptr()), code, B, Cin, H, W, C.c_void_p(m._workspace.data_ptr()), C.c_void_p(self._grad_ws.data_ptr()),
-                    self._grad_ws.numel(), optr, tptr, lw, 1 if k.online_mining else 0, float(k.hard_to_easy_ratio), int(k.min_hard_keypoints),
+                    self._grad_ws.numel(), optr, tptr, lw, C.c_void_p(sw.data_ptr()) if sw is not None else None, 1 if k.online_mining else 0, float(k.hard_to_easy_ratio), int(k.min_hard_keypoints),
                     -1 if k.max_hard_keypoints is None else int(k.max_hard_keypoints), float(k.loss_scale), C.c_void_p(self._loss.data_ptr()),
                     C.c_void_p(self.grads.data_ptr()), L.current_stream_ptr(),
                 )
@@ -141,11 +162,24 @@ class TrainingModule:
         self._push_params()
 
     def training_step(self, batch: Dict[str, torch.Tensor]) -> torch.Tensor:
-        """``batch``: {"image": ..., <head name>: target, ...}.  Returns the loss tensor (device)."""
-        loss = self.forward_backward(batch["image"], {k: v for k, v in batch.items() if k != "image"})
+        """``batch``: {"image": ..., <head name>: target, ..., ["is_negative": (B,) bool]}.  Returns the loss tensor (device)."""
+        targets = {k: v for k, v in batch.items() if k not in ("image", "is_negative")}
+        loss = self.forward_backward(batch["image"], targets, batch.get("is_negative"))
         scale = self.all_reduce_grads()
         self.optimizer_step(scale)
         return loss
+
+    def validation_step(self, batch: Dict[str, torch.Tensor]) -> torch.Tensor:
+        """Loss of a validation batch on the current parameters: unweighted (``stage="val"``), no optimizer step.  The
+        gradients it leaves in ``self.grads`` are overwritten by the next training step."""
+        targets = {k: v for k, v in batch.items() if k not in ("image", "is_negative")}
+        return self.forward_backward(batch["image"], targets, batch.get("is_negative"), stage="val").clone()
+
+    def on_epoch_end(self, val_loss: Optional[float] = None) -> float:
+        """Step the learning-rate schedule once (Lightning: interval "epoch", monitor "val/loss"); returns the next epoch's lr."""
+        if self.schedule is not None:
+            self.lr = self.schedule.step(val_loss)
+        return self.lr
 
     # ------------------------------------------------------------------------------
     def named_grads(self) -> Dict[str, torch.Tensor]:

@@ -211,15 +211,28 @@ def test_multiclass_topdown_training_matches_autograd():
 
 def test_backward_cfg3_network_with_interior_tiles():
     """Backward parity of the benched network (cfg3, 7.8 M parameters) at a size whose feature maps have interior tiles in
-    every kernel (256x320, B=2; the cases above use small nets): every parameter gradient within 1e-4 of its tensor's scale."""
+    every kernel (256x320, B=2; the cases above use small nets).  At this depth fp32 autograd itself is up to ~6e-4 of a
+    tensor's scale away from the exact gradient (torch-CPU fp32 vs the same oracle evaluated in float64: summation order
+    over 160k pixels), so the yardstick here is the float64 oracle: every HIP gradient must be within 1e-4 of it, or at
+    least as close to it as twice torch's own fp32 error for that tensor."""
     import bench
 
     bb, heads, mt = dict(bench.CFG3_BB), {k: dict(v) for k, v in bench.CFG3_HEADS.items()}, "bottomup"
     sd, img, targets, lw, tm = _setup(bb, heads, mt, (256, 320), 2, seed=3)
-    ref_losses, ref_grads = O.training_step(sd, bb, heads, mt, img, targets, lw)
+    ref_losses, g32 = O.training_step(sd, bb, heads, mt, img, targets, lw)
+    _, g64 = O.training_step({k: v.double() for k, v in sd.items()}, bb, heads, mt, img, {k: v.double() for k, v in targets.items()}, lw)
     loss = tm.forward_backward(img, targets).cpu().numpy()
     assert np.allclose(loss, np.array(ref_losses, dtype=np.float32), rtol=1e-5, atol=1e-6)
-    _check_grads(tm, ref_grads)
+    got = tm.named_grads()
+    worst = []
+    for k, r in g64.items():
+        scale = max(float(r.abs().max()), 1e-30)
+        e_hip = float((got[k].double() - r).abs().max()) / scale
+        e_ref = float((g32[k].double() - r).abs().max()) / scale
+        worst.append((e_hip, e_ref, k))
+        assert e_hip <= max(1e-4, 2.0 * e_ref), (k, e_hip, e_ref)
+    worst.sort(reverse=True)
+    print("cfg3 256x320 backward vs float64 oracle: worst (hip err, torch-fp32 err, tensor)", worst[:3])
 
 
 @pytest.mark.parametrize("seed", [0, 7])
@@ -272,3 +285,58 @@ def test_eval_train_round_trip_keeps_trained_weights():
     loss = tm.forward_backward(img, targets).cpu().numpy()
     assert np.allclose(loss, np.array(ref_losses, dtype=np.float32), rtol=1e-5, atol=1e-6)
     _check_grads(tm, ref_grads)
+
+
+def test_training_step_matches_reference_fixture_with_negative_weighting_and_ohkm():
+    """losses.npz "step": loss and every parameter gradient of ONE training step of the reference ``Model`` itself
+    (negative-sample-weighted MSE + OHKM per head, loss weights 1.0 / 0.6), reproduced by ph_model_backward.  Also the
+    val stage (unweighted) and the is_negative-absent path against the oracle."""
+    import json
+
+    from sleap_nn_amd.architectures.model import Model
+    from sleap_nn_amd.training.module import OHKMConfig, TrainingModule
+    from tests import _golden as G
+
+    z = G.load("losses.npz")
+    cfg = json.loads(str(z["step/config_json"]))
+    sd = {k[len("step/w/"):]: torch.from_numpy(z[k]) for k in z.files if k.startswith("step/w/")}
+    tg = {k[len("step/target/"):]: torch.from_numpy(z[k]) for k in z.files if k.startswith("step/target/")}
+    img, neg = torch.from_numpy(z["step/image"]), torch.from_numpy(z["step/is_negative"])
+    m = Model("unet", cfg["backbone"], cfg["heads"], cfg["model_type"])
+    m.load_state_dict(sd)
+    ok = cfg["ohkm"]
+    tm = TrainingModule(m, DEV, loss_weights=cfg["loss_weights"], negative_loss_weight=cfg["negative_loss_weight"],
+                        ohkm=OHKMConfig(True, ok["hard_to_easy_ratio"], ok["min_hard_keypoints"], None if ok["max_hard_keypoints"] < 0 else ok["max_hard_keypoints"], ok["loss_scale"]))
+    loss = tm.forward_backward(img, tg, is_negative=neg).cpu().numpy()
+    assert np.allclose(loss, z["step/losses"], rtol=2e-5), (loss, z["step/losses"])
+    _check_grads(tm, {k[len("step/g/"):]: torch.from_numpy(z[k]) for k in z.files if k.startswith("step/g/")})
+    okd = dict(hard_to_easy_ratio=ok["hard_to_easy_ratio"], min_hard_keypoints=ok["min_hard_keypoints"], max_hard_keypoints=None, loss_scale=ok["loss_scale"])
+    for kw in (dict(is_negative=neg, stage="val"), dict(is_negative=None, stage="train")):
+        ref_l, ref_g = O.training_step(sd, cfg["backbone"], cfg["heads"], cfg["model_type"], img, tg, cfg["loss_weights"], ohkm=okd,
+                                       negative_loss_weight=cfg["negative_loss_weight"], **kw)
+        got = tm.forward_backward(img, tg, **kw).cpu().numpy()
+        assert np.allclose(got, np.array(ref_l, dtype=np.float32), rtol=2e-5), kw
+        _check_grads(tm, ref_g)
+
+
+def test_lr_schedule_drives_the_optimizer():
+    """TrainingModule(lr_scheduler=...): ``lr`` follows the reference's schedule, one step per epoch (schedulers.npz holds the
+    learning rates the reference's schedulers produce); the Adam update of the next step uses it."""
+    from tests import _golden as G
+
+    z = G.load("schedulers.npz")
+    bb, heads, mt = _cfg(8, 8, 2)
+    sd, img, targets, lw, tm = _setup(bb, heads, mt, (32, 32), 1, seed=5, lr=1e-3,
+                                      lr_scheduler={"cosine_annealing_warmup": {"warmup_epochs": 4, "max_epochs": 25, "warmup_start_lr": 1e-5, "eta_min": 1e-6}})
+    lrs = [tm.lr]
+    for _ in range(6):
+        lrs.append(tm.on_epoch_end(val_loss=1.0))
+    assert np.allclose(lrs, z["cosine"][:7], rtol=1e-12, atol=0)
+    before = tm.params.clone()
+    tm.training_step({"image": img, **targets})
+    step = (tm.params - before).abs().max().item()
+    assert 0.5 * tm.lr <= step <= 1.5 * tm.lr  # first Adam step moves every touched weight by ~lr
+    tm2 = _setup(bb, heads, mt, (32, 32), 1, seed=5, lr=1e-3, lr_scheduler="step_lr")[-1]
+    for e in range(10):
+        tm2.on_epoch_end()
+    assert abs(tm2.lr - 1e-4) < 1e-12  # StepLR defaults: step_size 10, gamma 0.1
