@@ -836,20 +836,23 @@ __global__ __launch_bounds__(256) void input_wgrad_partial_kernel(const void* __
 }
 // 1024 threads = 256 outputs x 4 block parts (four loads in flight per thread); the parts meet in LDS in a fixed order
 __global__ __launch_bounds__(1024) void input_wgrad_final_kernel(const float* __restrict__ partial, int n_blocks, int n_out, float* __restrict__ gw) {
-  __shared__ float red[3 * 256];
+  // The first layer's weight gradient is the worst-conditioned sum of the network (every pixel of the batch contributes a
+  // signed term to each of the 9 * cin * cout outputs and they largely cancel): the per-tile partials are combined in double
+  // (a few hundred adds per output, free) so that the result is as close to the exact gradient as ATen's own fp32 reduction.
+  __shared__ double red[3 * 256];
   const int e = threadIdx.x & 255, part = threadIdx.x >> 8;
   const int i = blockIdx.x * 256 + e;
   const bool ok = i < n_out;
   const float* src = partial + (ok ? i : 0);
-  float s = 0.f;
+  double s = 0.0;
   int k = part;
   for (; k + 12 < n_blocks; k += 16)
-    s += (src[(size_t)k * n_out] + src[(size_t)(k + 4) * n_out]) + (src[(size_t)(k + 8) * n_out] + src[(size_t)(k + 12) * n_out]);
-  for (; k < n_blocks; k += 4) s += src[(size_t)k * n_out];
+    s += ((double)src[(size_t)k * n_out] + (double)src[(size_t)(k + 4) * n_out]) + ((double)src[(size_t)(k + 8) * n_out] + (double)src[(size_t)(k + 12) * n_out]);
+  for (; k < n_blocks; k += 4) s += (double)src[(size_t)k * n_out];
   if (part) red[(part - 1) * 256 + e] = s;
   __syncthreads();
   if (part || !ok) return;
-  gw[i] = (s + red[e]) + (red[256 + e] + red[512 + e]);
+  gw[i] = (float)((s + red[e]) + (red[256 + e] + red[512 + e]));
 }
 int launch_input_wgrad(const void* img, int dtype, const float* dy, int B, int cin, int H, int W, int coutp, int cout, float* gw, float* scratch, hipStream_t s) {
   if (cin > 3) {
