@@ -20,6 +20,9 @@ from sleap_nn_amd.architectures.unet import OpSpec, UNet
 from sleap_nn_amd.utils import cfg_get, cfg_keys
 
 
+PRECISIONS = {"exact": 0, "split": 1, "fp16": 2}
+
+
 def get_backbone(backbone: str, backbone_config):
     """architectures/model.py:36-67.  ``unet`` and ``convnext`` are built natively."""
     if backbone == "unet":
@@ -79,6 +82,7 @@ class Model:
         # (HipBackend's hipGraphs) compares generations before replaying
         self.generation = 0
         self._options: Dict[str, float] = {}
+        self.precision = "exact"
         # a TrainingModule registers its device parameter arena here; after any recompile the packed weights are
         # re-gathered from it, so eval()/train() round trips never fall back to the host copy in _state
         self._live_params: Optional[torch.Tensor] = None
@@ -252,6 +256,22 @@ class Model:
         if want is not self.ops:
             self.ops = want
             self._release()
+        # the training program keeps fp32 activations for the backward pass; inference runs at `self.precision`
+        self.set_option("conv_precision", PRECISIONS[self.precision] if fused else 0)
+        return self
+
+    def set_precision(self, precision: str) -> "Model":
+        """Arithmetic of the inference forward's 3x3 convolutions (UNet programs; ConvNeXt programs always run exact):
+        ``"exact"``: fp32 products on the fp32 matrix pipe (bit-for-bit a k-ordered fmaf chain);
+        ``"split"``: every operand as a (hi, lo) pair of fp16 numbers, three fp16 MFMAs per product with fp32 accumulation --
+        22-bit products, ~1e-6 relative on the head outputs, 16/3 of the fp32 matrix rate;
+        ``"fp16"``: plain fp16 operands and storage, fp32 accumulation -- the reference's autocast mode
+        (torch_backend.py:113-143; its tolerance is 5e-3)."""
+        if precision not in PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(PRECISIONS)}, got {precision!r}")
+        self.precision = precision
+        if self.ops is self.fused_ops:
+            self.set_option("conv_precision", PRECISIONS[precision])
         return self
 
     def param_keys(self) -> List[str]:

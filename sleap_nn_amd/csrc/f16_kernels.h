@@ -1,0 +1,37 @@
+// Launcher declarations of f16_kernels.hip: the 3x3 convolution on the fp16 matrix pipe (split-fp16 and plain fp16
+// precisions) and the format-generic bilinear / pool / head / read-back kernels.  Formats: act_format.h.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace ph {
+
+struct ConvF16Args {
+  const float* src0 = nullptr;   // activations in FMT_SPLIT / FMT_F16 (addressed in 4-byte units)
+  const float* src1 = nullptr;   // second concat source or nullptr
+  int rs0 = 0, rs1 = 0;          // pixel stride of the sources in 4-byte units (split: Cp, plain: Cp / 2)
+  int chunks0 = 0, chunks1 = 0;  // K chunks (64 B per pixel each) of the sources
+  const float* wpack = nullptr;  // launch_f16_weight_pack output
+  const float* bias = nullptr;   // fp32, padded to a multiple of bn
+  void* dst = nullptr;           // FMT_SPLIT (prec 3) / FMT_F16 (prec 1)
+  void* dst_pool = nullptr;      // optional fused 2x2/2 max pool output, same format
+  int rs_dst = 0;                // pixel stride of dst / dst_pool in 4-byte units
+  int coutp = 0;                 // padded output channels (split: multiple of 16, plain: of 32)
+  int B = 0, H = 0, W = 0;
+  int relu = 0;
+  int bn = 64;                   // N tile (= the tile the weights were packed for)
+  int prec = 3;                  // 3 split fp16, 1 plain fp16
+  const float* zeros = nullptr;  // >= 64 B of zeros in HBM
+};
+
+int prepare_f16_kernels();
+int launch_conv3x3_f16(const ConvF16Args& a, hipStream_t s);
+int64_t f16_weight_pack_floats(int n_tiles, int chunks0, int chunks1, int bn, int plain);
+int launch_f16_weight_pack(const float* w_dma_f32, float* dst, int n_tiles, int chunks0, int chunks1, int bn, int plain, hipStream_t s);
+int launch_upsample_fmt(int fmt, const void* src, void* dst, int B, int H, int W, int cp, hipStream_t s);
+int launch_pool_fmt(int fmt, const void* src, void* dst, int B, int H, int W, int cp, hipStream_t s);
+int launch_head_fmt(int fmt, const void* src, const float* w, const float* bias, float* dst, int B, int HW, int cp, int wcp, int cout, int sigmoid, hipStream_t s);
+int launch_slot_to_nchw_fmt(int fmt, const void* src, float* dst, int B, int HW, int cp, int c, hipStream_t s);
+
+}  // namespace ph

@@ -1,0 +1,584 @@
+// 3x3 convolution on the fp16 matrix pipe of gfx950 (v_mfma_f32_32x32x16_f16, fp32 accumulate) and the format-generic
+// companions of the encoder-decoder forward (bilinear x2, 2x2 max pool, 1x1 heads, slot read-back).
+//
+// Two precisions share one kernel (activation formats: act_format.h):
+//   PREC 3  "split fp16": every operand is the pair (hi, lo' = (x - hi) 2^11) of fp16 numbers; a product is
+//           a_hi b_hi + (a_hi b_lo' + a_lo' b_hi) 2^-11 -- three MFMAs into two fp32 accumulators (main, cross) -- i.e.
+//           22-bit products with fp32 accumulation.  On the cfg3 network the heads differ from the exact-fp32 path by
+//           ~1e-6 of their scale (the same distance the exact path has from ATen's CPU kernels), far inside the 1e-4
+//           parity bar, at 16/3 of the fp32-MFMA rate: the convolution stack turns from MFMA-bound into
+//           LDS-fill / HBM-bound.
+//   PREC 1  plain fp16 operands (the reference's autocast mode; its tolerance is 5e-3): one MFMA per product, fp16 storage.
+//
+// Reference semantics: conv3x3 "same" + bias + ReLU (+ fused 2x2 max pool), concat(skip, x) as two K panels
+// (sleap_nn/architectures/encoder_decoder.py:108-121,494-510,545,556; common.py:69-107).
+//
+// Kernel structure = conv3x3_mfma_dma_persist_kernel (net_kernels.hip): persistent 512-thread workgroups, 16 x 32 pixel
+// tiles, LDS-DMA staging of the (16+2) x (32+2) halo and the 9 x BN weight rows of one K chunk into a double-buffered
+// ring, one barrier per chunk.  A K chunk is 64 B per pixel / weight row: 16 channels x (hi, lo') in split mode, 32
+// channels in plain mode, as four 16-B quads; lanes 0-31 read quad g*2, lanes 32-63 quad g*2 + 1 -- exactly the fragment
+// v_mfma_f32_32x32x16_f16 wants (lane l: row l & 31, k = 8 (l >> 5) .. + 7), so the conflict-free quad-major LDS image
+// of the fp32 kernel serves unchanged.  The product is accumulated TRANSPOSED (weights are the A operand): a lane owns
+// one pixel and each accumulator register quad is four consecutive output channels, which the epilogue converts and
+// stores as one 8-byte piece of the destination's format.
+#include <type_traits>
+
+#include "act_format.h"
+#include "common.h"
+#include "f16_kernels.h"
+
+namespace ph {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+constexpr int TW = 32, TH = 16, HALO_W = TW + 2, HALO_H = TH + 2;
+constexpr int NPIX = HALO_H * HALO_W;        // 612
+constexpr int A_PIECES = (NPIX + 15) / 16;   // 39
+}  // namespace
+
+__device__ __forceinline__ f16x8 as_h8(const f32x4& v) { return __builtin_bit_cast(f16x8, v); }
+
+// quad_perm(1, 0, 3, 2): the value of the neighbouring lane (x ^ 1)
+__device__ __forceinline__ float lane_xor1(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));
+}
+
+template <int BN, int PREC>
+__global__ __launch_bounds__(512, 2) void conv3x3_f16_persist_kernel(ConvF16Args a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int NT = BN / 32;
+  constexpr int B_PIECES = 9 * BN / 16;
+  constexpr int PIECES = A_PIECES + B_PIECES;
+  constexpr int A_SLOTS = (A_PIECES + 7) / 8;   // 5
+  constexpr int B_SLOTS = (B_PIECES + 7) / 8;   // 5 (BN 64) / 3 (BN 32)
+  constexpr int SLOTS = A_SLOTS + B_SLOTS;      // <= 10: one DMA piece per tap, the surplus ones ride in tap 0
+  constexpr int BUF_FLOATS = PIECES * 256;
+  constexpr int DST_FMT = PREC == 3 ? FMT_SPLIT : FMT_F16;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tiles_x = (a.W + TW - 1) / TW;
+  const int tiles_y = (a.H + TH - 1) / TH;
+  const int tiles = tiles_x * tiles_y * a.B;
+  const int ntc = (a.coutp + BN - 1) / BN;
+  const int total = tiles * ntc;
+  const int nchunks = a.chunks0 + a.chunks1;
+  const int dq = lane >> 4, dr = lane & 15;
+  const int lx = lane & 31, lh = lane >> 5;
+
+  struct Plan {
+    int a_pix[A_SLOTS];
+    unsigned a_ok;
+    int b, x0, y0, ntile;
+  };
+  auto setup = [&](int vid, Plan& P) {
+    int t, ntile;  // XCD-aware dealing: the N tiles of one pixel tile are 8 ids apart (same XCD, same time -> the halo is an L2 hit)
+    if ((tiles & 7) == 0) {
+      const int xcd = vid & 7, j = vid >> 3;
+      ntile = j % ntc;
+      t = (j / ntc) * 8 + xcd;
+    } else {
+      ntile = vid % ntc;
+      t = vid / ntc;
+    }
+    const int tx = t % tiles_x;
+    t /= tiles_x;
+    const int ty = t % tiles_y;
+    P.b = t / tiles_y;
+    P.x0 = tx * TW;
+    P.y0 = ty * TH;
+    P.ntile = ntile;
+    P.a_ok = 0;
+#pragma unroll
+    for (int s = 0; s < A_SLOTS; ++s) {
+      const int p = min(wave + 8 * s, A_PIECES - 1);
+      const int pix = p * 16 + dr;
+      const int hy = pix / HALO_W, hx = pix - hy * HALO_W;
+      const int gy = P.y0 + hy - 1, gx = P.x0 + hx - 1;
+      const bool in = (pix < NPIX) && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+      P.a_ok |= (in ? 1u : 0u) << s;
+      const int cy = min(max(gy, 0), a.H - 1), cx = min(max(gx, 0), a.W - 1);
+      P.a_pix[s] = (P.b * a.H + cy) * a.W + cx;
+    }
+  };
+
+  int f_pix[A_SLOTS];
+  unsigned f_ok = 0;
+  const float* p_src = a.src0;
+  const float* p_w = a.wpack;
+  int p_rs = a.rs0, p_coff = 0;
+  auto select_fetch = [&](const Plan& P, int ch) {
+#pragma unroll
+    for (int s = 0; s < A_SLOTS; ++s) f_pix[s] = P.a_pix[s];
+    f_ok = P.a_ok;
+    if (ch < a.chunks0) {
+      p_src = a.src0;
+      p_rs = a.rs0;
+      p_coff = ch * 16;
+    } else {
+      p_src = a.src1;
+      p_rs = a.rs1;
+      p_coff = (ch - a.chunks0) * 16;
+    }
+    p_w = a.wpack + ((size_t)P.ntile * nchunks + ch) * (9 * BN * 16);
+  };
+  auto dma_slot = [&](int s, float* buf) {
+    const float* g;
+    int p;
+    if (s < A_SLOTS) {  // compile-time after unrolling
+      p = min(wave + 8 * s, A_PIECES - 1);
+      const float* real = p_src + (size_t)f_pix[s] * p_rs + p_coff + dq * 4;
+      const float* zero = a.zeros + dq * 4;
+      g = ((f_ok >> s) & 1u) ? real : zero;
+    } else {
+      const int pb = min(wave + 8 * (s - A_SLOTS), B_PIECES - 1);
+      p = A_PIECES + pb;
+      g = p_w + pb * 256 + lane * 4;  // weights are packed in LDS order
+    }
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)(buf + p * 256), 16, 0, 0);
+  };
+
+  // fragment read offsets (floats, buffer-relative): pixel (row 2w + rr, x + kx) quad lh (+ 2 g)
+  int offA[4][3];
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int pix = (2 * wave + rr) * HALO_W + lx + kx;
+      offA[rr][kx] = (pix >> 4) * 256 + lh * 64 + (pix & 15) * 4;
+    }
+  const int offB = A_PIECES * 256 + (lx >> 4) * 256 + lh * 64 + (lx & 15) * 4;  // + tap*(BN/16)*256 + n*512 + g*128
+  float* buf0 = lds;
+  float* buf1 = lds + BUF_FLOATS;
+
+  Plan P, Pn;
+  int vid = blockIdx.x;
+  setup(vid, P);
+  select_fetch(P, 0);
+#pragma unroll
+  for (int s = 0; s < SLOTS; ++s) dma_slot(s, buf0);
+  __syncthreads();
+  int parity = 0;
+  while (true) {
+    const int nvid = vid + gridDim.x;
+    const bool has_next = nvid < total;  // workgroup-uniform
+    if (has_next) setup(nvid, Pn);
+    f32x16 acc[2][NT];   // main:  hi x hi   (plain mode: the only accumulator)
+    f32x16 accx[PREC == 3 ? 2 : 1][PREC == 3 ? NT : 1];  // cross: hi x lo' + lo' x hi, scaled by 2^11
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          acc[m][n][r] = 0.f;
+          if (PREC == 3) accx[m][n][r] = 0.f;
+        }
+    for (int ch = 0; ch < nchunks; ++ch) {
+      float* cur = ((parity + ch) & 1) ? buf1 : buf0;
+      float* nxt = ((parity + ch) & 1) ? buf0 : buf1;
+      if (ch + 1 < nchunks)
+        select_fetch(P, ch + 1);
+      else if (has_next)
+        select_fetch(Pn, 0);  // the next tile's first chunk rides under this tile's last one
+      else
+        select_fetch(P, ch);  // nothing left: refetch (harmless, keeps the loop branch-free inside)
+      f32x4 af[2][2][2], bf[2][NT][2];  // [buffer][m | n][g]: g = 0 hi / first 16 channels, g = 1 lo' / second 16 channels
+      auto load_frags = [&](int tap, int fb) {
+        const int ky = tap / 3, kx = tap - ky * 3;
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+#pragma unroll
+          for (int m = 0; m < 2; ++m) af[fb][m][g] = *reinterpret_cast<const f32x4*>(cur + offA[m + ky][kx] + g * 128);
+#pragma unroll
+          for (int n = 0; n < NT; ++n) bf[fb][n][g] = *reinterpret_cast<const f32x4*>(cur + offB + tap * (BN / 16) * 256 + n * 512 + g * 128);
+        }
+      };
+      load_frags(0, 0);
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int fc = tap & 1;
+        if (tap + 1 < 9) load_frags(tap + 1, fc ^ 1);
+        if (tap < SLOTS) dma_slot(tap, nxt);
+        if (tap == 0 && SLOTS > 9) dma_slot(9, nxt);
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int n = 0; n < NT; ++n) {
+            // transposed product: A = weight rows (output channels), B = pixels
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h8(bf[fc][n][0]), as_h8(af[fc][m][0]), acc[m][n], 0, 0, 0);
+            if (PREC == 3) {
+              accx[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h8(bf[fc][n][0]), as_h8(af[fc][m][1]), accx[m][n], 0, 0, 0);
+              accx[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h8(bf[fc][n][1]), as_h8(af[fc][m][0]), accx[m][n], 0, 0, 0);
+            } else {
+              acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h8(bf[fc][n][1]), as_h8(af[fc][m][1]), acc[m][n], 0, 0, 0);
+            }
+          }
+        // pinned order: a first MFMA, then the next tap's LDS reads (the wait in front of a tap's first MFMA is lgkmcnt(0)
+        // in a kernel that issues LDS-DMA, so reads issued before it would be drained on the spot), the DMA piece in the middle
+        constexpr int MF = (PREC == 3 ? 3 : 2) * 2 * NT;
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 4 + 2 * NT, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, MF / 2 - 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, MF - MF / 2, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __syncthreads();  // vmcnt(0) + barrier: the next buffer landed everywhere, this one is free again
+    }
+    // ---- epilogue: D row = channel (r & 3) + 8 (r >> 2) + 4 lh of the N tile, column = pixel lx of the wave's row
+    const int b = P.b, x0 = P.x0, y0 = P.y0, ntile = P.ntile;
+    const int x = x0 + lx;
+    const size_t rsb = (size_t)a.rs_dst * 4;  // destination bytes per pixel
+    const bool x_ok = x < a.W;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      const int cb = ntile * BN + n * 32 + 4 * lh;  // + 8 q: the lane's channel quads
+      f32x4 bias4[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) bias4[q] = *reinterpret_cast<const f32x4*>(a.bias + cb + 8 * q);  // bias is padded to a multiple of BN
+      float v[2][16];
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float t = acc[m][n][r];
+          if (PREC == 3) t += accx[m][n][r] * SPLIT_INV;
+          t += bias4[r >> 2][r & 3];
+          v[m][r] = a.relu ? fmaxf(t, 0.f) : t;
+        }
+      auto put = [&](void* base, size_t pix, int q, const float* src4) {  // four consecutive channels cb + 8 q .. + 3 of one pixel
+        const int c = cb + 8 * q;
+        char* p = reinterpret_cast<char*>(base) + pix * rsb;
+        if constexpr (DST_FMT == FMT_SPLIT) {
+          f16x4 hi, lo;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const _Float16 h = split_hi(src4[k]);
+            hi[k] = h;
+            lo[k] = split_lo(src4[k], h);
+          }
+          p += (c >> 4) * 64 + ((c >> 3) & 1) * 16 + (c & 7) * 2;
+          *reinterpret_cast<f16x4*>(p) = hi;
+          *reinterpret_cast<f16x4*>(p + 32) = lo;
+        } else {
+          f16x4 h;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) h[k] = (_Float16)src4[k];
+          *reinterpret_cast<f16x4*>(p + c * 2) = h;
+        }
+      };
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const int y = y0 + 2 * wave + m;
+        if (y < a.H && x_ok) {
+          const size_t pix = (size_t)(b * a.H + y) * a.W + x;
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (cb + 8 * q < a.coutp) put(a.dst, pix, q, &v[m][4 * q]);
+        }
+      }
+      if (a.dst_pool) {  // fused 2x2/2 max pool ("same": zeros beyond the image; values are >= 0 after the ReLU)
+        const int Hp = (a.H + 1) >> 1, Wp = (a.W + 1) >> 1;
+        const int yt = y0 + 2 * wave;
+        const bool y1_ok = yt + 1 < a.H;
+        float pv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float c0 = x_ok ? v[0][r] : 0.f, c1 = (x_ok && y1_ok) ? v[1][r] : 0.f;
+          const float col = fmaxf(c0, c1);
+          pv[r] = fmaxf(col, lane_xor1(col));
+        }
+        if (!(lx & 1) && yt < a.H && x_ok) {
+          const size_t ppix = (size_t)(b * Hp + (yt >> 1)) * Wp + (x >> 1);
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (cb + 8 * q < a.coutp) put(a.dst_pool, ppix, q, &pv[4 * q]);
+        }
+      }
+    }
+    if (!has_next) break;
+    parity = (parity + nchunks) & 1;
+    vid = nvid;
+    P = Pn;
+  }
+}
+
+// fp32 quad-major weight panels (the LDS-DMA layout of the fp32 kernels: [panel][piece = row / 16][quad k / 4][row % 16][4]) ->
+// fp16 panels in the same piece structure, quads = [hi k0-7][hi k8-15][lo' k0-7][lo' k8-15] (split) of one 16-channel
+// source panel, or [k0-7][k8-15][k16-23][k24-31] (plain) of two consecutive ones (`pair` = 1; an odd tail is zero filled).
+__global__ __launch_bounds__(256) void f16_weight_pack_kernel(const float* __restrict__ src, float* __restrict__ dst, int n_tiles, int src_chunks0, int src_chunks1, int rows,
+                                                              int plain) {
+  const int pieces = rows / 16;
+  const int src_chunks = src_chunks0 + src_chunks1;
+  const int d0 = plain ? (src_chunks0 + 1) / 2 : src_chunks0, d1 = plain ? (src_chunks1 + 1) / 2 : src_chunks1;
+  const int dst_chunks = d0 + d1;
+  const size_t total = (size_t)n_tiles * dst_chunks * pieces * 64;  // (piece row, quad) items
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int q = (int)(i & 3), r = (int)((i >> 2) & 15);
+    size_t t = i >> 6;
+    const int piece = (int)(t % pieces);
+    t /= pieces;
+    const int dch = (int)(t % dst_chunks), nt = (int)(t / dst_chunks);
+    // which fp32 source chunk and which 8 of its 16 channels feed this quad
+    int sch, k0, lo = 0;
+    bool valid = true;
+    if (!plain) {
+      sch = dch;
+      k0 = (q & 1) * 8;
+      lo = q >> 1;
+    } else {
+      const bool second = dch >= d0;
+      const int local = second ? dch - d0 : dch, base = second ? src_chunks0 : 0, cnt = second ? src_chunks1 : src_chunks0;
+      const int sl = 2 * local + (q >> 1);
+      valid = sl < cnt;
+      sch = base + min(sl, cnt - 1);
+      k0 = (q & 1) * 8;
+    }
+    const float* s = src + (((size_t)nt * src_chunks + sch) * pieces + piece) * 256 + r * 4;
+    f16x8 o;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int kk = k0 + k;
+      const float v = valid ? s[(kk >> 2) * 64 + (kk & 3)] : 0.f;
+      const _Float16 hi = split_hi(v);
+      o[k] = lo ? split_lo(v, hi) : hi;
+    }
+    *reinterpret_cast<f16x8*>(dst + (((size_t)nt * dst_chunks + dch) * pieces + piece) * 256 + q * 64 + r * 4) = o;
+  }
+}
+
+int64_t f16_weight_pack_floats(int n_tiles, int chunks0, int chunks1, int bn, int plain) {
+  const int d = plain ? (chunks0 + 1) / 2 + (chunks1 + 1) / 2 : chunks0 + chunks1;
+  return (int64_t)n_tiles * d * 9 * bn * 16;
+}
+
+int launch_f16_weight_pack(const float* w_dma_f32, float* dst, int n_tiles, int chunks0, int chunks1, int bn, int plain, hipStream_t s) {
+  const int64_t items = f16_weight_pack_floats(n_tiles, chunks0, chunks1, bn, plain) / 4;
+  hipLaunchKernelGGL(f16_weight_pack_kernel, dim3((unsigned)std::min<int64_t>((items + 255) / 256, 4096)), dim3(256), 0, s, w_dma_f32, dst, n_tiles, chunks0, chunks1, 9 * bn,
+                     plain);
+  PH_HIP_CHECK(hipGetLastError());
+  return PH_OK;
+}
+
+int launch_conv3x3_f16(const ConvF16Args& a, hipStream_t s) {
+  PH_REQUIRE(a.prec == 1 || a.prec == 3, "conv3x3_f16: precision must be 1 (fp16) or 3 (split fp16)");
+  PH_REQUIRE(a.bn == 32 || a.bn == 64, "conv3x3_f16: N tile must be 32 or 64");
+  PH_REQUIRE(a.chunks0 > 0 && (a.chunks1 == 0 || a.src1), "conv3x3_f16: bad sources");
+  static int n_cu = 0;  // a device property, not a tunable
+  if (!n_cu) {
+    int dev = 0;
+    PH_HIP_CHECK(hipGetDevice(&dev));
+    PH_HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+  }
+  const int tiles = ((a.W + TW - 1) / TW) * ((a.H + TH - 1) / TH) * a.B;
+  const int total = tiles * ((a.coutp + a.bn - 1) / a.bn);
+  const size_t lds = (size_t)2 * (A_PIECES + 9 * a.bn / 16) * 1024;
+  const dim3 grid(std::min(total, n_cu));
+  if (a.bn == 64 && a.prec == 3)
+    hipLaunchKernelGGL((conv3x3_f16_persist_kernel<64, 3>), grid, dim3(512), lds, s, a);
+  else if (a.bn == 32 && a.prec == 3)
+    hipLaunchKernelGGL((conv3x3_f16_persist_kernel<32, 3>), grid, dim3(512), lds, s, a);
+  else if (a.bn == 64)
+    hipLaunchKernelGGL((conv3x3_f16_persist_kernel<64, 1>), grid, dim3(512), lds, s, a);
+  else
+    hipLaunchKernelGGL((conv3x3_f16_persist_kernel<32, 1>), grid, dim3(512), lds, s, a);
+  PH_HIP_CHECK(hipGetLastError());
+  return PH_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// Format-generic companions (8 channels per thread through load8 / store8)
+// ---------------------------------------------------------------------------------------
+
+// bilinear x2, align_corners=False (ATen upsample_bilinear2d: src = max(0, (dst + 0.5) * 0.5 - 0.5)); one thread = 8 channels x
+// the 2x2 output pixels between input pixels (i..i+1, j..j+1), i, j from -1 (see upsample2x_kernel in net_kernels.hip)
+template <int FMT>
+__global__ __launch_bounds__(256) void upsample2x_fmt_kernel(const void* __restrict__ src, void* __restrict__ dst, int B, int H, int W, int cp) {
+  const int Ho = 2 * H, Wo = 2 * W, groups = cp >> 3;
+  const int nI = H + 1, nJ = W + 1;
+  const size_t total = (size_t)B * nI * nJ * groups;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int g = (int)(idx % groups);
+    size_t p = idx / groups;
+    const int j = (int)(p % nJ) - 1;
+    p /= nJ;
+    const int i = (int)(p % nI) - 1;
+    const int b = (int)(p / nI);
+    const int r0 = max(i, 0), r1 = min(i + 1, H - 1), c0 = max(j, 0), c1 = min(j + 1, W - 1);
+    const size_t base = (size_t)b * H * W;
+    float v00[8], v01[8], v10[8], v11[8];
+    load8<FMT>(src, base + (size_t)r0 * W + c0, cp, g, v00);
+    load8<FMT>(src, base + (size_t)r0 * W + c1, cp, g, v01);
+    load8<FMT>(src, base + (size_t)r1 * W + c0, cp, g, v10);
+    load8<FMT>(src, base + (size_t)r1 * W + c1, cp, g, v11);
+#pragma unroll
+    for (int dy = 1; dy <= 2; ++dy) {
+      const int y = 2 * i + dy;
+      if (y < 0 || y >= Ho) continue;
+      const float sy = fmaxf((y + 0.5f) * 0.5f - 0.5f, 0.f);
+      const float ly = sy - (float)(int)sy, hy = 1.f - ly;
+#pragma unroll
+      for (int dx = 1; dx <= 2; ++dx) {
+        const int x = 2 * j + dx;
+        if (x < 0 || x >= Wo) continue;
+        const float sx = fmaxf((x + 0.5f) * 0.5f - 0.5f, 0.f);
+        const float lx = sx - (float)(int)sx, hx = 1.f - lx;
+        float o[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = hy * (hx * v00[k] + lx * v01[k]) + ly * (hx * v10[k] + lx * v11[k]);
+        store8<FMT>(dst, ((size_t)b * Ho + y) * Wo + x, cp, g, o);
+      }
+    }
+  }
+}
+
+// 2x2/2 max pool, zero pad bottom/right when odd (common.py:93-96)
+template <int FMT>
+__global__ __launch_bounds__(256) void pool2x2_fmt_kernel(const void* __restrict__ src, void* __restrict__ dst, int B, int H, int W, int cp) {
+  const int Ho = (H + 1) / 2, Wo = (W + 1) / 2, groups = cp >> 3;
+  const size_t total = (size_t)B * Ho * Wo * groups;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int g = (int)(idx % groups);
+    size_t p = idx / groups;
+    const int x = (int)(p % Wo);
+    p /= Wo;
+    const int y = (int)(p % Ho);
+    const int b = (int)(p / Ho);
+    const int y1 = 2 * y + 1, x1 = 2 * x + 1;
+    const size_t base = (size_t)b * H * W;
+    float m[8], t[8];
+    load8<FMT>(src, base + (size_t)(2 * y) * W + 2 * x, cp, g, m);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const int yy = c == 0 ? 2 * y : y1, xx = c == 1 ? 2 * x : x1;
+      if (yy < H && xx < W) {
+        load8<FMT>(src, base + (size_t)yy * W + xx, cp, g, t);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) m[k] = fmaxf(m[k], t[k]);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) m[k] = fmaxf(m[k], 0.f);
+      }
+    }
+    store8<FMT>(dst, ((size_t)b * Ho + y) * Wo + x, cp, g, m);
+  }
+}
+
+// 1x1 head convolution, activations in FMT -> NCHW fp32 (+ optional sigmoid); same tiling as head1x1_kernel (net_kernels.hip)
+template <int FMT>
+__global__ __launch_bounds__(256) void head1x1_fmt_kernel(const void* __restrict__ src, const float* __restrict__ w /* [cout][wcp] */, const float* __restrict__ bias,
+                                                          float* __restrict__ dst, int B, int HW, int cp, int wcp, int cout, int sigmoid) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* sa = lds;                    // 64 x (cp + 1)
+  float* sw = lds + 64 * (cp + 1);    // cout x wcp
+  const size_t npix = (size_t)B * HW;
+  const size_t p0 = (size_t)blockIdx.x * 64;
+  for (int i = threadIdx.x; i < cout * wcp; i += 256) sw[i] = w[i];
+  const int groups = cp >> 3;
+  for (int i = threadIdx.x; i < 64 * groups; i += 256) {
+    const int pp = i / groups, g = i - pp * groups;
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (p0 + pp < npix) load8<FMT>(src, p0 + pp, cp, g, v);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) sa[pp * (cp + 1) + 8 * g + k] = v[k];
+  }
+  __syncthreads();
+  const int pp = threadIdx.x & 63, j0 = threadIdx.x >> 6;
+  const size_t p = p0 + pp;
+  if (p >= npix) return;
+  const size_t b = p / HW, hw = p - b * HW;
+  const float* ar = sa + pp * (cp + 1);
+  for (int j = j0; j < cout; j += 4) {  // wave-uniform j
+    float accv = bias[j];
+    const float* wr = sw + j * wcp;
+    for (int c = 0; c < wcp; c += 4) {
+      const f32x4 wv = *reinterpret_cast<const f32x4*>(wr + c);
+      accv += ar[c] * wv[0];
+      accv += ar[c + 1] * wv[1];
+      accv += ar[c + 2] * wv[2];
+      accv += ar[c + 3] * wv[3];
+    }
+    if (sigmoid) accv = 1.f / (1.f + expf(-accv));
+    dst[(b * cout + j) * HW + hw] = accv;
+  }
+}
+
+template <int FMT>
+__global__ void slot_to_nchw_fmt_kernel(const void* __restrict__ src, float* __restrict__ dst, int B, int HW, int cp, int c) {
+  const int groups = (c + 7) / 8;
+  const size_t total = (size_t)B * HW * groups;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const size_t pix = idx % ((size_t)B * HW);
+    const int g = (int)(idx / ((size_t)B * HW));
+    float v[8];
+    load8<FMT>(src, pix, cp, g, v);
+    const size_t b = pix / HW, hw = pix - b * HW;
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (8 * g + k < c) dst[(b * c + 8 * g + k) * HW + hw] = v[k];
+  }
+}
+
+#define PH_FMT_DISPATCH(fmt, CALL)                     \
+  switch (fmt) {                                       \
+    case FMT_SPLIT: { constexpr int F = FMT_SPLIT; CALL; break; } \
+    case FMT_F16: { constexpr int F = FMT_F16; CALL; break; }     \
+    default: { constexpr int F = FMT_F32; CALL; break; }          \
+  }
+
+int launch_upsample_fmt(int fmt, const void* src, void* dst, int B, int H, int W, int cp, hipStream_t s) {
+  const size_t total = (size_t)B * (H + 1) * (W + 1) * (cp / 8);
+  const int blocks = (int)std::min<size_t>((total + 255) / 256, 256 * 32);
+  PH_FMT_DISPATCH(fmt, hipLaunchKernelGGL(upsample2x_fmt_kernel<F>, dim3(blocks), dim3(256), 0, s, src, dst, B, H, W, cp));
+  PH_HIP_CHECK(hipGetLastError());
+  return PH_OK;
+}
+
+int launch_pool_fmt(int fmt, const void* src, void* dst, int B, int H, int W, int cp, hipStream_t s) {
+  const size_t total = (size_t)B * ((H + 1) / 2) * ((W + 1) / 2) * (cp / 8);
+  const int blocks = (int)std::min<size_t>((total + 255) / 256, 256 * 32);
+  PH_FMT_DISPATCH(fmt, hipLaunchKernelGGL(pool2x2_fmt_kernel<F>, dim3(blocks), dim3(256), 0, s, src, dst, B, H, W, cp));
+  PH_HIP_CHECK(hipGetLastError());
+  return PH_OK;
+}
+
+int launch_head_fmt(int fmt, const void* src, const float* w, const float* bias, float* dst, int B, int HW, int cp, int wcp, int cout, int sigmoid, hipStream_t s) {
+  const size_t npix = (size_t)B * HW;
+  const size_t lds = (64 * (cp + 1) + (size_t)cout * wcp) * sizeof(float);
+  PH_REQUIRE(lds <= 160 * 1024, "head1x1: LDS tile too large (cp=%d cout=%d)", cp, cout);
+  PH_REQUIRE(wcp <= cp, "head1x1: weight rows wider than the activation rows");
+  const dim3 grid((unsigned)((npix + 63) / 64));
+  if (lds > 64 * 1024) {
+    PH_FMT_DISPATCH(fmt, PH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(head1x1_fmt_kernel<F>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)));
+  }
+  PH_FMT_DISPATCH(fmt, hipLaunchKernelGGL(head1x1_fmt_kernel<F>, grid, dim3(256), lds, s, src, w, bias, dst, B, HW, cp, wcp, cout, sigmoid));
+  PH_HIP_CHECK(hipGetLastError());
+  return PH_OK;
+}
+
+int launch_slot_to_nchw_fmt(int fmt, const void* src, float* dst, int B, int HW, int cp, int c, hipStream_t s) {
+  const size_t total = (size_t)B * HW * ((c + 7) / 8);
+  const int blocks = (int)std::min<size_t>((total + 255) / 256, 8192);
+  PH_FMT_DISPATCH(fmt, hipLaunchKernelGGL(slot_to_nchw_fmt_kernel<F>, dim3(blocks), dim3(256), 0, s, src, dst, B, HW, cp, c));
+  PH_HIP_CHECK(hipGetLastError());
+  return PH_OK;
+}
+
+int prepare_f16_kernels() {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_f16_persist_kernel<64, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_f16_persist_kernel<32, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_f16_persist_kernel<64, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_f16_persist_kernel<32, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e != hipSuccess) {
+    set_error("hipFuncSetAttribute(conv f16) failed: %s", hipGetErrorString(e));
+    return PH_E_HIP;
+  }
+  return PH_OK;
+}
+
+}  // namespace ph

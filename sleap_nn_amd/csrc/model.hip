@@ -186,8 +186,37 @@ void apply_conv_options(const ph_model* m, ConvArgs& a) {
   a.dma_stagger = m->dma_stagger;
 }
 
-int build_plan(const ph_model* m, int B, int H, int W, Plan& plan) {
+// Programs made only of the UNet-style ops can run on the fp16 matrix pipe (handle option "conv_precision"); anything
+// else (ConvNeXt blocks, class-vector heads, non-3x3 kernels) and every training program stays in exact fp32.
+int forward_format(const ph_model* m) {
+  if (m->conv_precision != 1 && m->conv_precision != 2) return FMT_F32;
+  for (const PackedOp& op : m->ops) {
+    const ph_op_desc& d = op.d;
+    switch (d.kind) {
+      case PH_OP_STEM:
+      case PH_OP_INPUT_CONV:
+      case PH_OP_POOL:
+      case PH_OP_UPSAMPLE:
+        break;
+      case PH_OP_CONV:
+      case PH_OP_CONVT:
+        if (d.ksize != 3) return FMT_F32;
+        break;
+      case PH_OP_HEAD:
+        if (d.flags & PH_FLAG_SOFTMAX) return FMT_F32;
+        break;
+      default:
+        return FMT_F32;
+    }
+  }
+  return m->conv_precision == 1 ? FMT_SPLIT : FMT_F16;
+}
+
+int build_plan(const ph_model* m, int B, int H, int W, Plan& plan, int fmt) {
   plan.slots.assign(m->n_slots, SlotShape());
+  plan.fmt = fmt;
+  plan.bpc = fmt_bytes_per_channel(fmt);
+  const int bpc = plan.bpc;
   int64_t off = 0, tmp = 0;
   for (const PackedOp& op : m->ops) {
     const ph_op_desc& d = op.d;
@@ -206,12 +235,12 @@ int build_plan(const ph_model* m, int B, int H, int W, Plan& plan) {
       PH_REQUIRE(d.dst2 >= 0 && d.dst2 < m->n_slots && d.dst < m->n_slots, "bad stem slots");
       if (d.dst >= 0) {
         SlotShape& f = plan.slots[d.dst];
-        f.c = d.cout; f.cp = 16; f.h = h; f.w = w; f.offset = off;
-        off += align_up((int64_t)B * h * w * 16 * 4, 256);
+        f.c = d.cout; f.cp = fmt_cpad(fmt, 16); f.h = h; f.w = w; f.offset = off;
+        off += align_up((int64_t)B * h * w * f.cp * bpc, 256);
       }
       SlotShape& p = plan.slots[d.dst2];
-      p.c = d.cout; p.cp = 16; p.h = (h + 1) / 2; p.w = (w + 1) / 2; p.offset = off;
-      off += align_up((int64_t)B * p.h * p.w * 16 * 4, 256);
+      p.c = d.cout; p.cp = fmt_cpad(fmt, 16); p.h = (h + 1) / 2; p.w = (w + 1) / 2; p.offset = off;
+      off += align_up((int64_t)B * p.h * p.w * p.cp * bpc, 256);
       continue;
     }
     int oh = h, ow = w;
@@ -247,29 +276,59 @@ int build_plan(const ph_model* m, int B, int H, int W, Plan& plan) {
                  "concat sources differ in size (%dx%d vs %dx%d): input H,W must be multiples of the model max stride",
                  h, w, s1.h, s1.w);
     }
-    if (d.kind == PH_OP_CONVT) tmp = std::max<int64_t>(tmp, (int64_t)B * oh * ow * pad16(d.cin0) * 4);
+    if (d.kind == PH_OP_CONVT) tmp = std::max<int64_t>(tmp, (int64_t)B * oh * ow * fmt_cpad(fmt, d.cin0) * bpc);
     PH_REQUIRE(d.dst >= 0 && d.dst < m->n_slots, "bad dst slot %d", d.dst);
     SlotShape& s = plan.slots[d.dst];
     s.c = (d.kind == PH_OP_POOL || d.kind == PH_OP_UPSAMPLE || d.kind == PH_OP_GLOBAL_MAXPOOL) ? d.cin0 : d.cout;
-    s.cp = pad16(s.c);
+    s.cp = fmt_cpad(fmt, s.c);
     s.h = oh;
     s.w = ow;
     s.offset = off;
-    off += align_up((int64_t)B * oh * ow * s.cp * 4, 256);
+    off += align_up((int64_t)B * oh * ow * s.cp * bpc, 256);
     if (d.kind == PH_OP_CONV && d.dst2 >= 0) {  // fused 2x2 max pool of the conv output
       PH_REQUIRE(d.dst2 < m->n_slots && (d.flags & PH_FLAG_RELU), "fused pool needs a valid slot and a ReLU conv");
       SlotShape& p = plan.slots[d.dst2];
       p.c = d.cout;
-      p.cp = pad16(d.cout);
+      p.cp = fmt_cpad(fmt, d.cout);
       p.h = (oh + 1) / 2;
       p.w = (ow + 1) / 2;
       p.offset = off;
-      off += align_up((int64_t)B * p.h * p.w * p.cp * 4, 256);
+      off += align_up((int64_t)B * p.h * p.w * p.cp * bpc, 256);
     }
   }
   plan.tmp_offset = off;
   plan.tmp_bytes = align_up(tmp, 256);
   plan.total = off + plan.tmp_bytes;
+  return PH_OK;
+}
+
+// fp16 weight packs of every 3x3 conv / transposed conv, derived on the device from the fp32 LDS-DMA panels the first time a
+// forward needs them (and again after every ph_model_set_params, through m->derived).  Allocates: not capturable -- a
+// hipGraph user runs one eager forward first (HipBackend does).
+int ensure_f16_weights(ph_model* m, int plain, hipStream_t s) {
+  for (PackedOp& op : m->ops) {
+    const ph_op_desc& d = op.d;
+    if ((d.kind != PH_OP_CONV && d.kind != PH_OP_CONVT) || op.w_f16_dev[plain]) continue;
+    PH_REQUIRE(op.w_dma_dev && (op.bn == 32 || op.bn == 64), "conv op has no LDS-DMA weight panels");
+    const int chunks0 = pad16(d.cin0) / 16, chunks1 = d.cin1 > 0 ? pad16(d.cin1) / 16 : 0;
+    const int n_tiles = (pad16(d.cout) + op.bn - 1) / op.bn;
+    float* w = nullptr;
+    PH_HIP_CHECK(hipMalloc(&w, (size_t)f16_weight_pack_floats(n_tiles, chunks0, chunks1, op.bn, plain) * sizeof(float)));
+    m->allocs.push_back(w);
+    int rc = launch_f16_weight_pack(op.w_dma_dev, w, n_tiles, chunks0, chunks1, op.bn, plain, s);
+    if (rc != PH_OK) return rc;
+    DerivedBuffer db;
+    db.kind = 1;
+    db.src = op.w_dma_dev;
+    db.dst = w;
+    db.n_tiles = n_tiles;
+    db.chunks0 = chunks0;
+    db.chunks1 = chunks1;
+    db.bn = op.bn;
+    db.plain = plain;
+    m->derived.push_back(db);
+    op.w_f16_dev[plain] = w;
+  }
   return PH_OK;
 }
 
@@ -302,7 +361,7 @@ ph_model* ph_model_create(const ph_op_desc* ops, int32_t n_ops, const float* con
     set_error("ph_model_create: empty program");
     return nullptr;
   }
-  if (prepare_kernels() != PH_OK || prepare_convnext_kernels() != PH_OK) return nullptr;
+  if (prepare_kernels() != PH_OK || prepare_convnext_kernels() != PH_OK || prepare_f16_kernels() != PH_OK) return nullptr;
   ph_model* m = new ph_model();
   m->n_slots = n_slots;
   m->n_outputs = n_outputs;
@@ -605,7 +664,7 @@ int64_t ph_model_workspace_bytes(const ph_model* m, int32_t batch, int32_t heigh
     return PH_E_INVALID;
   }
   Plan plan;
-  int rc = build_plan(m, batch, height, width, plan);
+  int rc = build_plan(m, batch, height, width, plan, forward_format(m));
   if (rc != PH_OK) return rc;
   return plan.total;
 }
@@ -633,8 +692,14 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
   PH_REQUIRE(((uintptr_t)workspace_dev & 255) == 0, "workspace must be 256-byte aligned");
   hipStream_t s = static_cast<hipStream_t>(stream);
   Plan plan;
-  int rc = build_plan(m, batch, height, width, plan);
+  const int fmt = forward_format(m);
+  int rc = build_plan(m, batch, height, width, plan, fmt);
   if (rc != PH_OK) return rc;
+  if (fmt != FMT_F32) {
+    rc = ensure_f16_weights(m, fmt == FMT_F16 ? 1 : 0, s);
+    if (rc != PH_OK) return rc;
+  }
+  const int rs_div = 4 / plan.bpc;  // pixel stride in 4-byte units = cp / rs_div
   if (plan.total > workspace_bytes) {
     set_error("workspace too small: need %lld bytes, got %lld", (long long)plan.total, (long long)workspace_bytes);
     return PH_E_WORKSPACE;
@@ -666,6 +731,8 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
         a.H = height;
         a.W = width;
         a.relu = (d.flags & PH_FLAG_RELU) ? 1 : 0;
+        a.out_fmt = fmt;
+        a.dst_cp = plan.slots[d.dst].cp;
         rc = launch_input_conv(a, s);
         break;
       }
@@ -686,11 +753,41 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
         a.H = height;
         a.W = width;
         a.wino = m->stem_wino;
+        a.out_fmt = fmt;
         rc = launch_stem(a, s);
         break;
       }
       case PH_OP_CONV: {
         const SlotShape& s0 = plan.slots[d.src0];
+        if (fmt != FMT_F32) {
+          PH_REQUIRE(s0.c == d.cin0 && (d.src1 < 0 || plan.slots[d.src1].c == d.cin1), "conv channel mismatch");
+          const SlotShape& so = plan.slots[d.dst];
+          const int cdiv = fmt == FMT_F16 ? 32 : 16;
+          ConvF16Args f{};
+          f.src0 = slot_ptr(d.src0);
+          f.rs0 = s0.cp / rs_div;
+          f.chunks0 = s0.cp / cdiv;
+          if (d.src1 >= 0) {
+            f.src1 = slot_ptr(d.src1);
+            f.rs1 = plan.slots[d.src1].cp / rs_div;
+            f.chunks1 = plan.slots[d.src1].cp / cdiv;
+          }
+          f.wpack = op.w_f16_dev[fmt == FMT_F16 ? 1 : 0];
+          f.bias = op.b_dev;
+          f.dst = slot_ptr(d.dst);
+          f.dst_pool = d.dst2 >= 0 ? slot_ptr(d.dst2) : nullptr;
+          f.rs_dst = so.cp / rs_div;
+          f.coutp = so.cp;
+          f.B = batch;
+          f.H = s0.h;
+          f.W = s0.w;
+          f.relu = (d.flags & PH_FLAG_RELU) ? 1 : 0;
+          f.bn = op.bn;
+          f.prec = fmt == FMT_F16 ? 1 : 3;
+          f.zeros = m->zeros_dev;
+          rc = launch_conv3x3_f16(f, s);
+          break;
+        }
         ConvArgs a{};
         a.src0 = slot_ptr(d.src0);
         a.c0p = s0.cp;
@@ -750,20 +847,43 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
       }
       case PH_OP_POOL: {
         const SlotShape& s0 = plan.slots[d.src0];
-        rc = launch_pool(slot_ptr(d.src0), slot_ptr(d.dst), batch, s0.h, s0.w, s0.cp, s);
+        rc = fmt == FMT_F32 ? launch_pool(slot_ptr(d.src0), slot_ptr(d.dst), batch, s0.h, s0.w, s0.cp, s)
+                            : launch_pool_fmt(fmt, slot_ptr(d.src0), slot_ptr(d.dst), batch, s0.h, s0.w, s0.cp, s);
         break;
       }
       case PH_OP_UPSAMPLE: {
         const SlotShape& s0 = plan.slots[d.src0];
-        rc = launch_upsample(slot_ptr(d.src0), slot_ptr(d.dst), batch, s0.h, s0.w, s0.cp, s);
+        rc = fmt == FMT_F32 ? launch_upsample(slot_ptr(d.src0), slot_ptr(d.dst), batch, s0.h, s0.w, s0.cp, s)
+                            : launch_upsample_fmt(fmt, slot_ptr(d.src0), slot_ptr(d.dst), batch, s0.h, s0.w, s0.cp, s);
         break;
       }
       case PH_OP_CONVT: {
         const SlotShape& s0 = plan.slots[d.src0];
         PH_REQUIRE(s0.c == d.cin0, "convT channel mismatch");
         float* tmp = reinterpret_cast<float*>(ws + plan.tmp_offset);
-        rc = launch_zero_stuff(slot_ptr(d.src0), tmp, batch, s0.h, s0.w, s0.cp, s);
+        rc = launch_zero_stuff(slot_ptr(d.src0), tmp, batch, s0.h, s0.w, s0.cp / rs_div, s);  // 16-B quads: format-agnostic
         if (rc != PH_OK) break;
+        if (fmt != FMT_F32) {
+          const SlotShape& so = plan.slots[d.dst];
+          ConvF16Args f{};
+          f.src0 = tmp;
+          f.rs0 = s0.cp / rs_div;
+          f.chunks0 = s0.cp / (fmt == FMT_F16 ? 32 : 16);
+          f.wpack = op.w_f16_dev[fmt == FMT_F16 ? 1 : 0];
+          f.bias = op.b_dev;
+          f.dst = slot_ptr(d.dst);
+          f.rs_dst = so.cp / rs_div;
+          f.coutp = so.cp;
+          f.B = batch;
+          f.H = 2 * s0.h;
+          f.W = 2 * s0.w;
+          f.relu = (d.flags & PH_FLAG_RELU) ? 1 : 0;
+          f.bn = op.bn;
+          f.prec = fmt == FMT_F16 ? 1 : 3;
+          f.zeros = m->zeros_dev;
+          rc = launch_conv3x3_f16(f, s);
+          break;
+        }
         ConvArgs a{};
         a.src0 = tmp;
         a.c0p = s0.cp;
@@ -891,8 +1011,10 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
         const SlotShape& s0 = plan.slots[d.src0];
         PH_REQUIRE(s0.c == d.cin0, "head channel mismatch");
         PH_REQUIRE(out_dev[d.out_index] != nullptr, "output %d is null", d.out_index);
-        rc = launch_head(slot_ptr(d.src0), op.w_dev, op.b_dev, out_dev[d.out_index], batch, s0.h * s0.w, s0.cp, d.cout,
-                         (d.flags & PH_FLAG_SIGMOID) ? 1 : 0, s);
+        rc = fmt == FMT_F32 ? launch_head(slot_ptr(d.src0), op.w_dev, op.b_dev, out_dev[d.out_index], batch, s0.h * s0.w, s0.cp, d.cout,
+                                          (d.flags & PH_FLAG_SIGMOID) ? 1 : 0, s)
+                            : launch_head_fmt(fmt, slot_ptr(d.src0), op.w_dev, op.b_dev, out_dev[d.out_index], batch, s0.h * s0.w, s0.cp, pad16(d.cin0), d.cout,
+                                              (d.flags & PH_FLAG_SIGMOID) ? 1 : 0, s);
         if (rc == PH_OK && (d.flags & PH_FLAG_SOFTMAX)) {
           PH_REQUIRE(s0.h == 1 && s0.w == 1, "softmax head expects a pooled (1x1) feature");
           rc = launch_softmax_rows(out_dev[d.out_index], batch, d.cout, s);
@@ -936,6 +1058,7 @@ std::vector<OptionRef> option_table(ph_model* m) {
       {"fuse_gelu_fwd", &m->fuse_gelu_fwd, nullptr},
       {"fuse_gelu_bwd", &m->fuse_gelu_bwd, nullptr},
       {"wgrad_rows", &m->wgrad_rows, nullptr},          // 0 32x32-tile wgrad kernel, 1 auto, 2 nine row-wgrad GEMMs
+      {"conv_precision", &m->conv_precision, nullptr},  // 0 exact fp32 MFMA, 1 split-fp16 MFMA (22-bit products), 2 plain fp16 (autocast-equivalent)
       {"gemm_late_split", &m->gemm_late_split, nullptr},
       {"gemm_persist2", &m->gemm_persist2, nullptr},
       {"conv_gemm_fill", nullptr, &m->gemm_fill_threshold},            // tile fill below which a 3x3 conv runs as a row GEMM (0 disables)
@@ -1003,6 +1126,8 @@ int ph_model_read_slot(ph_model* m, int32_t slot, float* out_dev, int64_t out_nu
   PH_REQUIRE(slot >= 0 && slot < m->n_slots && m->last_plan.slots[slot].offset >= 0, "bad slot %d", slot);
   const SlotShape& s = m->last_plan.slots[slot];
   PH_REQUIRE(out_numel == (int64_t)m->last_batch * s.c * s.h * s.w, "slot %d has %d x %d x %d x %d elements", slot, m->last_batch, s.c, s.h, s.w);
+  if (m->last_plan.fmt != FMT_F32)
+    return launch_slot_to_nchw_fmt(m->last_plan.fmt, m->last_ws + s.offset, out_dev, m->last_batch, s.h * s.w, s.cp, s.c, static_cast<hipStream_t>(stream));
   return launch_nhwc_to_nchw(reinterpret_cast<float*>(m->last_ws + s.offset), out_dev, m->last_batch, s.h * s.w, s.cp, s.c,
                              static_cast<hipStream_t>(stream));
 }

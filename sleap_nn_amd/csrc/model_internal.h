@@ -3,7 +3,9 @@
 #include <string>
 #include <vector>
 
+#include "act_format.h"
 #include "common.h"
+#include "f16_kernels.h"
 #include "net_kernels.h"
 
 namespace ph {
@@ -29,6 +31,7 @@ struct PackedOp {
   int bn_d[2] = {0, 0};
   float* w_wino_dev = nullptr;             // 3x3 conv, N tile 64: Winograd F(2,3) weights derived on the device from w_dev
   float* wd_wino_dev[2] = {nullptr, nullptr};  // ... and from wd_dev (data gradient)
+  float* w_f16_dev[2] = {nullptr, nullptr};  // 3x3 conv / transposed conv on the fp16 matrix pipe: [0] split-fp16, [1] plain fp16 weights (derived lazily from w_dma_dev)
   float* w16_dev = nullptr;   // 16 -> 16 channel 3x3 conv: [tap][ci][co] for conv3x3_c16_kernel
   float* wd16_dev = nullptr;  // ... and of its data gradient
 };
@@ -46,16 +49,20 @@ struct DerivedBuffer {
   const float* src = nullptr;
   float* dst = nullptr;
   int panels = 0, bn = 0;  // bn == 0: the fused stem's second conv (launch_stem_wino_pack)
+  int kind = 0;            // 0: Winograd transform of src; 1: fp16 weight pack of the LDS-DMA panels (launch_f16_weight_pack)
+  int n_tiles = 0, chunks0 = 0, chunks1 = 0, plain = 0;  // kind 1
 };
 
 struct SlotShape {
-  int c = 0, cp = 0, h = 0, w = 0;
+  int c = 0, cp = 0, h = 0, w = 0;  // cp: channels padded for the plan's format
   int64_t offset = -1;
 };
 
 struct Plan {
   std::vector<SlotShape> slots;
   int64_t tmp_offset = 0, tmp_bytes = 0, total = 0;
+  int fmt = FMT_F32;  // activation format of every slot (act_format.h)
+  int bpc = 4;        // bytes per channel in that format
 };
 
 }  // namespace ph
@@ -96,11 +103,14 @@ struct ph_model {
   int wgrad_rows = 0;                         // 3x3 weight gradients of wide layers as nine row-wgrad GEMMs (off by default: measured slower than the 32x32-tile kernel; 1 auto, 2 always)
   double gemm_fill_threshold_wino = 0.5;      // ... and the (lower) break-even when the halo kernel is the Winograd one
   double gemm_fill_threshold = 0.8;           // 3x3 convs whose maps fill the 16x32 tiles less than this run as row GEMMs
+  int conv_precision = 0;                     // "conv_precision": 0 exact fp32 MFMA; 1 split-fp16 MFMA (22-bit products, fp32 accumulate); 2 plain fp16 (autocast-equivalent)
 };
 
 
 namespace ph {
-int build_plan(const ph_model* m, int B, int H, int W, Plan& plan);
+int build_plan(const ph_model* m, int B, int H, int W, Plan& plan, int fmt = FMT_F32);
+int forward_format(const ph_model* m);
+int ensure_f16_weights(ph_model* m, int plain, hipStream_t s);  // format the forward of this program runs in under the handle's conv_precision
 int upload(ph_model* m, const std::vector<float>& host, float** dev);
 int upload_ints(ph_model* m, const std::vector<int>& host, int** dev);
 int choose_bn(int coutp);

@@ -35,9 +35,11 @@ struct InputConvArgs {
   const void* src;  // NCHW uint8 / float
   const float* w;   // [tap][cin][coutp]
   const float* bias;
-  float* dst;       // NHWC coutp
+  void* dst;        // NHWC coutp (format out_fmt)
   int dtype;        // 0 u8 (/255), 1 f32 as-is, 2 f32 (/255)
   int cin, coutp, B, H, W, relu;
+  int out_fmt = 0;  // ActFmt of dst (act_format.h)
+  int dst_cp = 0;   // padded channels of dst in its format (FMT_F16 pads to 32)
 };
 
 struct StemArgs {
@@ -47,9 +49,10 @@ struct StemArgs {
   const float* w1;     // [tap][n=16][16] second conv, k contiguous
   const float* b1;     // [16]
   const float* w1w = nullptr;  // second conv, Winograd F(2,3) along x: [kernel row][m index 4][n=16][16], or nullptr
-  float* dst_full;     // NHWC 16 full resolution or nullptr
-  float* dst_pool;     // NHWC 16, ceil(H/2) x ceil(W/2)
+  void* dst_full;      // NHWC 16 full resolution or nullptr (format out_fmt)
+  void* dst_pool;      // NHWC 16, ceil(H/2) x ceil(W/2)
   int dtype, cin, B, H, W;
+  int out_fmt = 0;     // ActFmt of the outputs (act_format.h)
   int wino = 1;        // second conv in Winograd form (handle option "stem_wino")
 };
 

@@ -16,6 +16,7 @@
 //   uint8 -> float /255 .............. data/normalization.py:7-35
 #include <type_traits>
 
+#include "act_format.h"
 #include "common.h"
 #include "net_kernels.h"
 
@@ -1334,6 +1335,18 @@ int launch_conv3x3_dma(const ConvArgs& a, hipStream_t s) {
 // ---------------------------------------------------------------------------------------
 // WINO: conv1 as Winograd F(2,3) along x (see K1w): an M row of the 16x16x4 MFMA is an output PAIR, a wave's two rows are two M
 // tiles x four accumulators (m0..m3); 96 instead of 144 MFMAs per wave, the transform is four f32x4 adds per (kernel row, image row).
+// One output channel of one pixel in the stem's output format (16 logical channels; the plain-fp16 format pads to 32
+// channels and nobody else would write the upper 16, so they are written as zeros here).
+__device__ __forceinline__ void stem_store(const StemArgs& a, void* base, size_t pix, int c, float v) {
+  if (a.out_fmt == FMT_SPLIT)
+    store1<FMT_SPLIT>(base, pix, 16, c, v);
+  else if (a.out_fmt == FMT_F16) {
+    store1<FMT_F16>(base, pix, 32, c, v);
+    store1<FMT_F16>(base, pix, 32, c + 16, 0.f);
+  } else
+    store1<FMT_F32>(base, pix, 16, c, v);
+}
+
 template <int CIN, bool WINO>
 __global__ __launch_bounds__(256, 4) void stem_fused_kernel(StemArgs a) {
   constexpr int IMG_W = TW + 4, IMG_H = TH + 4;   // image patch incl. both halos
@@ -1446,9 +1459,9 @@ __global__ __launch_bounds__(256, 4) void stem_fused_kernel(StemArgs a) {
         const float ob = fmaxf((m1 - m2) - acc[m][3][r] + bias, 0.f);
         const bool ina = (y < a.H) && (x < a.W), inb = (y < a.H) && (x + 1 < a.W);
         if (a.dst_full) {
-          float* dp = a.dst_full + (((size_t)b * a.H + y) * a.W + x) * 16 + li;
-          if (ina) dp[0] = oa;
-          if (inb) dp[16] = ob;
+          const size_t pix = ((size_t)b * a.H + y) * a.W + x;
+          if (ina) stem_store(a, a.dst_full, pix, li, oa);
+          if (inb) stem_store(a, a.dst_full, pix + 1, li, ob);
         }
         va[m][r] = ina ? oa : 0.f;
         vb[m][r] = inb ? ob : 0.f;
@@ -1459,7 +1472,7 @@ __global__ __launch_bounds__(256, 4) void stem_fused_kernel(StemArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int px = (x0 >> 1) + 4 * lg + r;
-        if (px < Wp) a.dst_pool[(((size_t)b * Hp + py) * Wp + px) * 16 + li] = fmaxf(fmaxf(va[0][r], vb[0][r]), fmaxf(va[1][r], vb[1][r]));
+        if (px < Wp) stem_store(a, a.dst_pool, ((size_t)b * Hp + py) * Wp + px, li, fmaxf(fmaxf(va[0][r], vb[0][r]), fmaxf(va[1][r], vb[1][r])));
       }
     }
     return;
@@ -1507,7 +1520,7 @@ __global__ __launch_bounds__(256, 4) void stem_fused_kernel(StemArgs a) {
         const int x = x0 + h * 16 + 4 * lg + r;
         float o = fmaxf(acc[m][h][r] + bias, 0.f);
         const bool in = (y < a.H) && (x < a.W);
-        if (in && a.dst_full) a.dst_full[(((size_t)b * a.H + y) * a.W + x) * 16 + li] = o;
+        if (in && a.dst_full) stem_store(a, a.dst_full, ((size_t)b * a.H + y) * a.W + x, li, o);
         v[m][h][r] = in ? o : 0.f;
       }
   }
@@ -1520,7 +1533,7 @@ __global__ __launch_bounds__(256, 4) void stem_fused_kernel(StemArgs a) {
         const int px = (x0 >> 1) + h * 8 + 2 * lg + pr;
         if (px < Wp) {
           const float o = fmaxf(fmaxf(v[0][h][2 * pr], v[0][h][2 * pr + 1]), fmaxf(v[1][h][2 * pr], v[1][h][2 * pr + 1]));
-          a.dst_pool[(((size_t)b * Hp + py) * Wp + px) * 16 + li] = o;
+          stem_store(a, a.dst_pool, ((size_t)b * Hp + py) * Wp + px, li, o);
         }
       }
   }
@@ -1590,7 +1603,22 @@ __global__ __launch_bounds__(256) void input_conv3x3_kernel(InputConvArgs a) {
       acc[2] = fmaxf(acc[2], 0.f);
       acc[3] = fmaxf(acc[3], 0.f);
     }
-    *reinterpret_cast<f32x4*>(a.dst + (((size_t)b * a.H + y) * a.W + x) * a.coutp + gq * 4) = acc;
+    const size_t pix = ((size_t)b * a.H + y) * a.W + x;
+    if (a.out_fmt == FMT_F32)
+      *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.dst) + pix * a.coutp + gq * 4) = acc;
+    else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (a.out_fmt == FMT_SPLIT)
+          store1<FMT_SPLIT>(a.dst, pix, a.coutp, gq * 4 + k, acc[k]);
+        else
+          store1<FMT_F16>(a.dst, pix, a.dst_cp, gq * 4 + k, acc[k]);
+      }
+      if (a.out_fmt == FMT_F16 && a.dst_cp > a.coutp && gq < (a.dst_cp - a.coutp) / 4) {  // zero the pad channels [coutp, dst_cp)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) store1<FMT_F16>(a.dst, pix, a.dst_cp, a.coutp + gq * 4 + k, 0.f);
+      }
+    }
   }
 }
 

@@ -93,8 +93,9 @@ int ph_model_set_params(ph_model* m, const float* params_flat_dev, void* stream)
     if (rc != PH_OK) return rc;
   }
   for (const DerivedBuffer& db : m->derived) {
-    int rc = db.bn == 0 ? launch_stem_wino_pack(db.src, db.dst, static_cast<hipStream_t>(stream))
-                        : launch_wino_pack(db.src, db.dst, db.panels, db.bn, static_cast<hipStream_t>(stream));
+    int rc = db.kind == 1 ? launch_f16_weight_pack(db.src, db.dst, db.n_tiles, db.chunks0, db.chunks1, db.bn, db.plain, static_cast<hipStream_t>(stream))
+             : db.bn == 0 ? launch_stem_wino_pack(db.src, db.dst, static_cast<hipStream_t>(stream))
+                          : launch_wino_pack(db.src, db.dst, db.panels, db.bn, static_cast<hipStream_t>(stream));
     if (rc != PH_OK) return rc;
   }
   return PH_OK;
@@ -119,6 +120,7 @@ int ph_model_backward(ph_model* m, const void* input_dev, int32_t in_dtype, int3
              "ph_model_backward: null argument");
   PH_REQUIRE(((uintptr_t)grad_workspace_dev & 255) == 0, "gradient workspace must be 256-byte aligned");
   hipStream_t s = static_cast<hipStream_t>(stream);
+  PH_REQUIRE(m->last_plan.fmt == FMT_F32, "backward needs the activations of an exact-fp32 forward (handle option conv_precision = 0)");
   BwdPlan bp;
   int rc = build_bwd_plan(m, batch, height, width, bp);
   if (rc != PH_OK) return rc;

@@ -33,7 +33,7 @@ class ModelBackend(Protocol):
 class HipBackend:
     """Hand-written-HIP forward behind the ``ModelBackend`` protocol."""
 
-    def __init__(self, model, device: str = "cuda", use_graph: bool = False) -> None:
+    def __init__(self, model, device: str = "cuda", use_graph: bool = False, precision: str = None, use_fp16: bool = False) -> None:
         """``use_graph``: replay the forward of each (shape, dtype) as ONE hipGraph launch (captured on
         first use through ``torch.cuda.CUDAGraph``): ~25 kernel launches become one, which is what bounds
         small batches (a 256x256 frame is ~0.3 ms of kernels).  The returned tensors are the graph's static
@@ -47,6 +47,14 @@ class HipBackend:
         if dev.index is None:
             dev = torch.device("cuda", torch.cuda.current_device())
         self._device = dev
+        # ``use_fp16`` mirrors TorchBackend(use_fp16=True) (torch_backend.py:113-143: autocast); ``precision`` selects among
+        # "exact" / "split" / "fp16" explicitly (Model.set_precision); None keeps what the model is set to
+        if use_fp16:
+            if precision not in (None, "fp16"):
+                raise ValueError("use_fp16=True contradicts precision=%r" % (precision,))
+            precision = "fp16"
+        if precision is not None:
+            model.set_precision(precision)
         self.model = model.to(dev).eval()
         self.use_graph = bool(use_graph)
         self._graphs: Dict[tuple, tuple] = {}
