@@ -81,6 +81,30 @@ __device__ __forceinline__ void store8(void* __restrict__ base, size_t pix, int 
   }
 }
 
+// four consecutive channels c0 .. c0 + 3 (c0 a multiple of 4) of one pixel: one 16-byte (fp32) or 8-byte piece per half
+template <int FMT>
+__device__ __forceinline__ void store4(void* __restrict__ base, size_t pix, int cp, int c0, const float (&v)[4]) {
+  if constexpr (FMT == FMT_F32) {
+    *reinterpret_cast<f32x4_t*>(reinterpret_cast<float*>(base) + pix * cp + c0) = f32x4_t{v[0], v[1], v[2], v[3]};
+  } else if constexpr (FMT == FMT_SPLIT) {
+    char* p = reinterpret_cast<char*>(base) + (pix * cp + (size_t)(c0 >> 4) * 16) * 4 + ((c0 >> 3) & 1) * 16 + (c0 & 7) * 2;
+    f16x4 hi, lo;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const _Float16 h = split_hi(v[k]);
+      hi[k] = h;
+      lo[k] = split_lo(v[k], h);
+    }
+    *reinterpret_cast<f16x4*>(p) = hi;
+    *reinterpret_cast<f16x4*>(p + 32) = lo;
+  } else {
+    f16x4 h;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) h[k] = (_Float16)v[k];
+    *reinterpret_cast<f16x4*>(reinterpret_cast<char*>(base) + (pix * cp + c0) * 2) = h;
+  }
+}
+
 // one channel of one pixel (scalar access for kernels whose lanes run along channels)
 template <int FMT>
 __device__ __forceinline__ void store1(void* __restrict__ base, size_t pix, int cp, int c, float v) {

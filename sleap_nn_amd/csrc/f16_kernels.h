@@ -23,6 +23,7 @@ struct ConvF16Args {
   int bn = 64;                   // N tile (= the tile the weights were packed for)
   int prec = 3;                  // 3 split fp16, 1 plain fp16
   const float* zeros = nullptr;  // >= 64 B of zeros in HBM
+  unsigned long long* clock_probe = nullptr;  // diagnostic (ph_model_set_clock_probe): per workgroup {d s_memtime, d s_memrealtime}; nullptr = off
 };
 
 int prepare_f16_kernels();

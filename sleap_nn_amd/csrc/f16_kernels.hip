@@ -68,6 +68,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16_persist_kernel(ConvF16Args
   const int nchunks = a.chunks0 + a.chunks1;
   const int dq = lane >> 4, dr = lane & 15;
   const int lx = lane & 31, lh = lane >> 5;
+  unsigned long long probe_t0 = 0, probe_r0 = 0;
+  if (a.clock_probe) {
+    probe_t0 = __builtin_amdgcn_s_memtime();
+    probe_r0 = __builtin_amdgcn_s_memrealtime();
+  }
 
   struct Plan {
     int a_pix[A_SLOTS];
@@ -154,6 +159,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16_persist_kernel(ConvF16Args
   float* buf0 = lds;
   float* buf1 = lds + BUF_FLOATS;
 
+  // Waves i and i + 4 share SIMD i, and an LDS-DMA wave-instruction blocks its wave for 60-450 cycles (the CU's address path
+  // takes ~56 cycles per 1-KiB piece): partners must not issue theirs at the same point of a tap, or the SIMD's matrix pipe
+  // idles meanwhile.  The upper four waves ("late") place the tap's piece after 2/3 of its MFMAs, the lower four after 1/6.
+  auto run = [&](auto late) {
+  constexpr bool LATE = decltype(late)::value;
   Plan P, Pn;
   int vid = blockIdx.x;
   setup(vid, P);
@@ -220,12 +230,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16_persist_kernel(ConvF16Args
         // pinned order: a first MFMA, then the next tap's LDS reads (the wait in front of a tap's first MFMA is lgkmcnt(0)
         // in a kernel that issues LDS-DMA, so reads issued before it would be drained on the spot), the DMA piece in the middle
         constexpr int MF = (PREC == 3 ? 3 : 2) * 2 * NT;
+        constexpr int BEFORE = LATE ? (2 * MF) / 3 : MF / 6;  // MFMAs between the LDS reads and the DMA piece
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x100, 4 + 2 * NT, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, MF / 2 - 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, BEFORE, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);
         __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, MF - MF / 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, MF - 1 - BEFORE, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
       __syncthreads();  // vmcnt(0) + barrier: the next buffer landed everywhere, this one is free again
@@ -305,6 +316,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16_persist_kernel(ConvF16Args
     parity = (parity + nchunks) & 1;
     vid = nvid;
     P = Pn;
+  }
+  };
+  if (wave >= 4)  // wave-uniform; both variants execute the same barriers
+    run(std::true_type{});
+  else
+    run(std::false_type{});
+  if (a.clock_probe && tid == 0) {  // shader clock under this load = d memtime / d memrealtime * 100 MHz
+    a.clock_probe[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - probe_t0;
+    a.clock_probe[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - probe_r0;
   }
 }
 

@@ -785,6 +785,7 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
           f.bn = op.bn;
           f.prec = fmt == FMT_F16 ? 1 : 3;
           f.zeros = m->zeros_dev;
+          f.clock_probe = m->clock_probe ? m->clock_probe + 2 * 1024 * (op_index - 1) : nullptr;  // one 1024-workgroup record block per op
           rc = launch_conv3x3_f16(f, s);
           break;
         }
@@ -881,6 +882,7 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
           f.bn = op.bn;
           f.prec = fmt == FMT_F16 ? 1 : 3;
           f.zeros = m->zeros_dev;
+          f.clock_probe = m->clock_probe ? m->clock_probe + 2 * 1024 * (op_index - 1) : nullptr;  // one 1024-workgroup record block per op
           rc = launch_conv3x3_f16(f, s);
           break;
         }

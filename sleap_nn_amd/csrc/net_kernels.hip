@@ -1347,6 +1347,18 @@ __device__ __forceinline__ void stem_store(const StemArgs& a, void* base, size_t
     store1<FMT_F32>(base, pix, 16, c, v);
 }
 
+// four consecutive channels (c0 a multiple of 4) of one pixel in the stem's output format
+__device__ __forceinline__ void stem_store4(const StemArgs& a, void* base, size_t pix, int c0, const float (&v)[4]) {
+  if (a.out_fmt == FMT_SPLIT)
+    store4<FMT_SPLIT>(base, pix, 16, c0, v);
+  else if (a.out_fmt == FMT_F16) {
+    const float z[4] = {0.f, 0.f, 0.f, 0.f};
+    store4<FMT_F16>(base, pix, 32, c0, v);
+    store4<FMT_F16>(base, pix, 32, c0 + 16, z);
+  } else
+    store4<FMT_F32>(base, pix, 16, c0, v);
+}
+
 template <int CIN, bool WINO>
 __global__ __launch_bounds__(256, 4) void stem_fused_kernel(StemArgs a) {
   constexpr int IMG_W = TW + 4, IMG_H = TH + 4;   // image patch incl. both halos
@@ -1421,6 +1433,9 @@ __global__ __launch_bounds__(256, 4) void stem_fused_kernel(StemArgs a) {
   // ---- conv1 on the matrix cores
   const int li = lane & 15, lg = lane >> 4;
   if constexpr (WINO) {
+    // The product is accumulated TRANSPOSED (the transformed weights are the A operand, the pixel pairs the B operand): D row
+    // 4 lg + r = output channel, column li = output pair t (pixels 2t, 2t + 1), so a lane owns four consecutive channels of
+    // its pair -- one 16-byte (fp32) or 8-byte (fp16 formats) store per pixel, and the 2x2 max pool is in-lane arithmetic.
     f32x4 acc[2][4];
 #pragma unroll
     for (int m = 0; m < 2; ++m)
@@ -1428,7 +1443,7 @@ __global__ __launch_bounds__(256, 4) void stem_fused_kernel(StemArgs a) {
       for (int xi = 0; xi < 4; ++xi) acc[m][xi] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky) {
-      f32x4 bw[4];  // transformed weights of this kernel row: B[k = lg][n = li], element j = input channel 4 lg + j
+      f32x4 bw[4];  // transformed weights of this kernel row: A[i = li (output channel)][k = lg], element j = input channel 4 lg + j
 #pragma unroll
       for (int xi = 0; xi < 4; ++xi) bw[xi] = *reinterpret_cast<const f32x4*>(a.w1w + (size_t)((ky * 4 + xi) * 16 + li) * 16 + lg * 4);
 #pragma unroll
@@ -1440,41 +1455,34 @@ __global__ __launch_bounds__(256, 4) void stem_fused_kernel(StemArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-          for (int xi = 0; xi < 4; ++xi) acc[m][xi] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[xi][j], bw[xi][j], acc[m][xi], 0, 0, 0);
+          for (int xi = 0; xi < 4; ++xi) acc[m][xi] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[xi][j], af[xi][j], acc[m][xi], 0, 0, 0);
       }
     }
-    // epilogue: D row 4 lg + r = pair t (pixels 2t, 2t+1), column li = channel; output transform, bias + ReLU, optional
-    // full-resolution store, 2x2 max pool (the pair is the pool column, the wave's two rows the pool rows)
-    const float bias = a.b1[li];
+    const f32x4 bias4 = *reinterpret_cast<const f32x4*>(a.b1 + 4 * lg);
     const int Hp = (a.H + 1) / 2, Wp = (a.W + 1) / 2;
-    float va[2][4], vb[2][4];
+    const int x = x0 + 2 * li;
+    float pooled[4] = {0.f, 0.f, 0.f, 0.f};  // values are >= 0 after the ReLU; out-of-image elements count as the reference's zero pad
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
       const int y = y0 + 2 * wave + m;
+      float oa[4], ob[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int x = x0 + 2 * (4 * lg + r);
         const float m1 = acc[m][1][r], m2 = acc[m][2][r];
-        const float oa = fmaxf((acc[m][0][r] + m1) + m2 + bias, 0.f);
-        const float ob = fmaxf((m1 - m2) - acc[m][3][r] + bias, 0.f);
-        const bool ina = (y < a.H) && (x < a.W), inb = (y < a.H) && (x + 1 < a.W);
-        if (a.dst_full) {
-          const size_t pix = ((size_t)b * a.H + y) * a.W + x;
-          if (ina) stem_store(a, a.dst_full, pix, li, oa);
-          if (inb) stem_store(a, a.dst_full, pix + 1, li, ob);
-        }
-        va[m][r] = ina ? oa : 0.f;
-        vb[m][r] = inb ? ob : 0.f;
+        oa[r] = fmaxf((acc[m][0][r] + m1) + m2 + bias4[r], 0.f);
+        ob[r] = fmaxf((m1 - m2) - acc[m][3][r] + bias4[r], 0.f);
       }
-    }
-    const int py = (y0 >> 1) + wave;
-    if (py < Hp) {
+      const bool ina = (y < a.H) && (x < a.W), inb = (y < a.H) && (x + 1 < a.W);
+      if (a.dst_full) {
+        const size_t pix = ((size_t)b * a.H + y) * a.W + x;
+        if (ina) stem_store4(a, a.dst_full, pix, 4 * lg, oa);
+        if (inb) stem_store4(a, a.dst_full, pix + 1, 4 * lg, ob);
+      }
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int px = (x0 >> 1) + 4 * lg + r;
-        if (px < Wp) stem_store(a, a.dst_pool, ((size_t)b * Hp + py) * Wp + px, li, fmaxf(fmaxf(va[0][r], vb[0][r]), fmaxf(va[1][r], vb[1][r])));
-      }
+      for (int r = 0; r < 4; ++r) pooled[r] = fmaxf(pooled[r], fmaxf(ina ? oa[r] : 0.f, inb ? ob[r] : 0.f));
     }
+    const int py = (y0 >> 1) + wave, px = (x0 >> 1) + li;
+    if (py < Hp && px < Wp) stem_store4(a, a.dst_pool, ((size_t)b * Hp + py) * Wp + px, 4 * lg, pooled);
     return;
   }
   // conv1's B fragments are the same for every tile: nine 16-B loads per lane straight into registers
