@@ -375,7 +375,11 @@ def test_cfg3_network_vs_oracle_one_frame():
         assert err <= CMS_ATOL, (k, err, v.abs().max().item())
 
 
-def test_cfg3_benched_workload_full_size_vs_oracle_and_batch_invariance():
+_CFG3_REF = {}
+
+
+@pytest.mark.parametrize("precision", ["exact", "split"])
+def test_cfg3_benched_workload_full_size_vs_oracle_and_batch_invariance(precision):
     """The workload bench.py times -- cfg3 network, bench.py's own weights (xavier seed 1234, heads x0.05), 1024x1024 uint8
     frames -- under parity at FULL size: two frames against the oracle (confmaps / PAFs within 1e-4), and frame 0 of a
     32-frame launch bit-identical to the same frame launched alone (persistent-workgroup tile walk, XCD dealing and
@@ -383,16 +387,19 @@ def test_cfg3_benched_workload_full_size_vs_oracle_and_batch_invariance():
     import bench
     from sleap_nn_amd.architectures.model import Model
 
-    m = Model("unet", bench.CFG3_BB, bench.CFG3_HEADS, "bottomup").init_xavier_(seed=1234, head_scale=0.05).to(DEV)
+    m = Model("unet", bench.CFG3_BB, bench.CFG3_HEADS, "bottomup").init_xavier_(seed=1234, head_scale=0.05).to(DEV).set_precision(precision)
     sd = m.state_dict()
     g = torch.Generator().manual_seed(4321)
     frames = torch.randint(0, 256, (32, 1, bench.SIZE, bench.SIZE), dtype=torch.uint8, generator=g)
-    ref = O.model_forward(sd, bench.CFG3_BB, bench.CFG3_HEADS, "bottomup", frames[:2])
+    ref = _CFG3_REF.get("ref")
+    if ref is None:
+        ref = _CFG3_REF["ref"] = O.model_forward(sd, bench.CFG3_BB, bench.CFG3_HEADS, "bottomup", frames[:2])
     dev_frames = frames.to(DEV)
     out2 = {k: v.clone() for k, v in m(dev_frames[:2].contiguous()).items()}
     for k, v in ref.items():
         err = (out2[k].cpu() - v).abs().max().item()
         assert err <= CMS_ATOL, (k, err, v.abs().max().item())
+        assert err <= 1e-5 * v.abs().max().item(), (k, err, v.abs().max().item())  # these heads are O(1e-3): relative bar as well
     one = {k: v.clone() for k, v in m(dev_frames[:1].contiguous()).items()}
     full = m(dev_frames)
     torch.cuda.synchronize()
@@ -400,6 +407,160 @@ def test_cfg3_benched_workload_full_size_vs_oracle_and_batch_invariance():
         assert torch.equal(full[k][:1], one[k]), k
         assert torch.equal(full[k][:2], out2[k]), k
         assert torch.isfinite(full[k]).all()
+
+
+# ------------------------------------------------------------------------------------------
+# fp16-matrix-pipe precisions (Model.set_precision): "split" = every operand a (hi, lo) pair of fp16 numbers, three MFMAs per
+# product, fp32 accumulation -- must meet the SAME 1e-4 bar as the exact path; "fp16" = the reference's autocast mode, whose
+# own tolerance is 5e-3 (reference tests/inference/test_cuda.py:54-55).
+# ------------------------------------------------------------------------------------------
+FP16_ATOL = 5e-3
+
+
+@pytest.mark.parametrize("name", ["unet_tiny_interp.npz", "unet_tiny_trans.npz", "unet_tiny_bu13.npz", "unet_tiny_rgb.npz", "ckpt_bottomup.npz", "ckpt_single_instance.npz"])
+@pytest.mark.parametrize("precision,atol", [("split", CMS_ATOL), ("fp16", FP16_ATOL)])
+def test_forward_matches_reference_golden_on_the_fp16_pipe(name, precision, atol):
+    """All six reference goldens (bilinear and transposed-conv decoders, RGB input, the two fixture checkpoints) through the
+    fp16-pipe kernels, head outputs AND the intermediate activations that exist in HBM (read back from the split / fp16
+    activation formats)."""
+    z = G.load(name)
+    cfg = G.config(z)
+    m = _model(cfg, G.weights(z)).set_precision(precision)
+    out = m(torch.from_numpy(z["image"]).squeeze(1).to(DEV))
+    torch.cuda.synchronize()
+    assert m.get_option("conv_precision") == {"split": 1.0, "fp16": 2.0}[precision]
+    for k in [f for f in z.files if f.startswith("out/")]:
+        err = (out[k[4:]].cpu() - torch.from_numpy(z[k])).abs().max().item()
+        assert err <= atol, (k, err)
+    n_act = 0
+    for k in [f for f in z.files if f.startswith("act/")]:
+        ref = torch.from_numpy(z[k])
+        try:
+            got = m.read_activation(k[4:], ref.shape[0], ref.shape[-2:]).cpu()
+        except KeyError:
+            continue
+        assert (got - ref).abs().max().item() <= atol * max(1.0, ref.abs().max().item()), k
+        n_act += 1
+    assert n_act >= 2 or not any(f.startswith("act/") for f in z.files)
+
+
+def test_split_precision_is_fp32_equivalent_on_the_benched_network():
+    """cfg3 network at 256x384 with O(1) head outputs (head_scale 1): the split-fp16 path must be as close to the oracle as
+    the exact-fp32 path is (within 2x of its error, both far inside 1e-4), odd sizes and the unfused program included."""
+    import bench
+    from sleap_nn_amd.architectures.model import Model
+
+    sd = O.init_state(bench.CFG3_BB, bench.CFG3_HEADS, "bottomup", seed=11, head_scale=1.0)
+    g = torch.Generator().manual_seed(5)
+    img = torch.randint(0, 256, (3, 1, 256, 384), dtype=torch.uint8, generator=g)
+    ref = O.model_forward(sd, bench.CFG3_BB, bench.CFG3_HEADS, "bottomup", img)
+    errs = {}
+    for prec in ("exact", "split"):
+        m = Model("unet", bench.CFG3_BB, bench.CFG3_HEADS, "bottomup")
+        m.load_state_dict(sd)
+        out = m.to(DEV).set_precision(prec)(img.to(DEV))
+        errs[prec] = {k: (out[k].cpu() - v).abs().max().item() / v.abs().max().item() for k, v in ref.items()}
+    for k in ref:
+        assert errs["split"][k] <= max(2.0 * errs["exact"][k], 2e-6), (k, errs)
+        assert errs["split"][k] * ref[k].abs().max().item() <= CMS_ATOL
+
+
+def test_fp16_pipe_odd_sizes_pool_padding_and_bitwise_determinism():
+    """Odd feature-map sizes (the fused pool's zero padding, partial tiles) and a second launch on another stream in split precision."""
+    from sleap_nn_amd.architectures.model import Model
+
+    bb = {"in_channels": 1, "kernel_size": 3, "filters": 12, "filters_rate": 1.5, "max_stride": 8, "stem_stride": None, "middle_block": True, "up_interpolate": True,
+          "stacks": 1, "convs_per_block": 2, "output_stride": 2}
+    heads = {"confmaps": {"part_names": ["a", "b", "c"], "output_stride": 2}}
+    sd = O.init_state(bb, heads, "single_instance", seed=3, head_scale=1.0)
+    g = torch.Generator().manual_seed(6)
+    img = torch.randint(0, 256, (2, 1, 104, 72), dtype=torch.uint8, generator=g)
+    ref = O.model_forward(sd, bb, heads, "single_instance", img)["SingleInstanceConfmapsHead"]
+    for prec, atol in (("split", CMS_ATOL), ("fp16", FP16_ATOL)):
+        m = Model("unet", bb, heads, "single_instance")
+        m.load_state_dict(sd)
+        m.to(DEV).set_precision(prec)
+        a = m(img.to(DEV))["SingleInstanceConfmapsHead"].clone()
+        assert (a.cpu() - ref).abs().max().item() <= atol, prec
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            b = m(img.to(DEV))["SingleInstanceConfmapsHead"].clone()
+        s.synchronize()
+        assert torch.equal(a, b), prec
+
+
+def test_training_module_keeps_exact_fp32_while_inference_runs_split():
+    """A model set to "split" for inference switches to the exact fp32 program for training (the backward needs fp32
+    activations) and back; ph_model_backward refuses activations of an fp16-pipe forward."""
+    from sleap_nn_amd.architectures.model import Model
+
+    z = G.load("unet_tiny_interp.npz")
+    cfg = G.config(z)
+    m = _model(cfg, G.weights(z)).set_precision("split")
+    img = torch.from_numpy(z["image"]).squeeze(1).to(DEV)
+    m(img)
+    assert m.get_option("conv_precision") == 1.0
+    m.train(True)
+    m(img)
+    assert m.get_option("conv_precision") == 0.0
+    m.eval()
+    m(img)
+    assert m.get_option("conv_precision") == 1.0
+
+
+def test_cfg5_multiclass_bottomup_768_fp16_network_and_full_size_postprocess():
+    """BASELINE cfg5: multi-class bottom-up, 768x768, 4 classes x 17 keypoints, fp16 MFMA.  The reference has no HRNet
+    (SURVEY section 0), so the backbone is its UNet; what cfg5 adds to the path is (1) the fp16 (autocast-equivalent) forward --
+    head outputs incl. the sigmoid class maps within the reference's own fp16 tolerance 5e-3 of the fp32 oracle, and the
+    keypoints it yields within 1e-3 px of the oracle's on the same maps -- and (2) the multi-class post-process at FULL
+    size: 16 frames of (17, 192, 192) confidence maps + (4, 96, 96) class maps, identical to the oracle's."""
+    import bench
+    from sleap_nn_amd.architectures.model import Model
+    from sleap_nn_amd.inference.backends import HipBackend
+    from sleap_nn_amd.inference.layers import BottomUpMultiClassLayer, PostprocessConfig
+    from sleap_nn_amd.inference.preprocess_info import PreprocInfo
+
+    S, N, K = 768, 17, 4
+    names = [f"k{i}" for i in range(N)]
+    heads = {"confmaps": {"part_names": names, "sigma": 2.5, "output_stride": 4, "loss_weight": 1.0},
+             "class_maps": {"classes": [f"id{i}" for i in range(K)], "sigma": 12.5, "output_stride": 8, "loss_weight": 1.0}}
+    bb = dict(bench.CFG3_BB)
+    sd = O.init_state(bb, heads, "multi_class_bottomup", seed=17, head_scale=1.0)
+    g = torch.Generator().manual_seed(55)
+    img = torch.randint(0, 256, (2, 1, S, S), dtype=torch.uint8, generator=g)
+    ref = O.model_forward(sd, bb, heads, "multi_class_bottomup", img)
+    m = Model("unet", bb, heads, "multi_class_bottomup")
+    m.load_state_dict(sd)
+    backend = HipBackend(m, DEV, use_fp16=True)  # TorchBackend(use_fp16=True) counterpart
+    raw = backend(img)
+    assert m.get_option("conv_precision") == 2.0 and all(v.dtype == torch.float32 for v in raw.values())
+    for k, v in ref.items():
+        err = (raw[k].cpu() - v).abs().max().item()
+        assert err <= FP16_ATOL * max(1.0, v.abs().max().item()), (k, err, v.abs().max().item())
+
+    # ---- full-size post-process on rendered heads: 16 frames, 4 animals (one per class), 17 nodes
+    B = 16
+    rng = np.random.RandomState(3)
+    pts = np.stack([np.clip(rng.uniform(120, S - 120, size=(K, 1, 2)) + rng.normal(0, 35, size=(K, N, 2)), 6, S - 7) for _ in range(B)]).astype(np.float32)
+    cms = torch.stack([O.render_confmaps(pts[b], S, 4, 2.5 * 4 / 2) for b in range(B)])
+    yy, xx = torch.meshgrid(torch.arange(0, S, 8, dtype=torch.float32), torch.arange(0, S, 8, dtype=torch.float32), indexing="ij")
+    cmaps = torch.zeros(B, K, S // 8, S // 8)
+    for b in range(B):
+        for k in range(K):  # a class map = blobs (sigma 50 px) around that animal's nodes (data/identity.py:34-85 semantics)
+            d2 = (xx[None] - torch.from_numpy(pts[b, k, :, 0])[:, None, None]) ** 2 + (yy[None] - torch.from_numpy(pts[b, k, :, 1])[:, None, None]) ** 2
+            cmaps[b, k] = torch.exp(-d2 / (2 * 50.0**2)).amax(0)
+    layer = BottomUpMultiClassLayer(backend, 4, 8, max_stride=32, postprocess_config=PostprocessConfig(peak_threshold=0.2))
+    out = layer.postprocess({"MultiInstanceConfmapsHead": cms.to(DEV), "ClassMapsHead": cmaps.to(DEV)}, PreprocInfo(eff_scale=torch.ones(B)))
+    rk, rv, rs, rt = O.multiclass_postprocess(cms, cmaps, 4, 8, peak_threshold=0.2)
+    k = out.pred_keypoints.numpy()
+    assert k.shape == tuple(rk.shape) == (B, K, N, 2)
+    assert np.array_equal(np.isnan(k), np.isnan(rk.numpy()))
+    assert int((~np.isnan(k[..., 0])).sum()) >= 0.9 * B * K * N  # nearly every rendered keypoint is found and assigned
+    assert np.allclose(k, rk.numpy(), atol=1e-4, equal_nan=True)
+    assert np.array_equal(np.nan_to_num(out.pred_peak_values.numpy()), np.nan_to_num(rv.numpy()))  # peak values bit-exact
+    assert np.allclose(out.instance_scores.numpy(), rs.numpy(), atol=1e-6, equal_nan=True)
+    assert np.allclose(out.instance_tracking_scores.numpy(), rt.numpy(), atol=1e-6, equal_nan=True)
 
 
 def _wz(z, prefix):
