@@ -305,6 +305,8 @@ class Model:
         """Per-handle kernel-variant option (``ph_model_set_option``; keys in include/posehip.h).  Remembered across recompiles."""
         if self._handle is not None:
             L.check(L.lib().ph_model_set_option(self._handle, str(key).encode(), float(value)))
+        if self._options.get(str(key)) != float(value):
+            self.generation += 1  # a captured hipGraph replays the kernels it was captured with: stale after a variant change
         self._options[str(key)] = float(value)
         return self
 
