@@ -62,7 +62,8 @@ enum ph_op_kind {
   PH_OP_CONV = 2,       /* conv kxk "same" over concat(src0, src1) + bias (+ReLU) -> NHWC slot          */
   PH_OP_POOL = 3,       /* 2x2/2 max pool, zero pad bottom/right when odd (architectures/common.py)     */
   PH_OP_UPSAMPLE = 4,   /* bilinear x2, align_corners=False (encoder_decoder.py:431-435)                */
-  PH_OP_CONVT = 5,      /* ConvTranspose2d(k3,s2,p1,op1) + bias (+ReLU) (encoder_decoder.py:439-461)    */
+  PH_OP_CONVT = 5,      /* ConvTranspose2d(k3,s2,p1,op1) + bias [-> folded BatchNorm: * weight2[c] + bias2[c]] (+ReLU | SiLU)
+                           (encoder_decoder.py:439-461; the reference's decoder builds it with batch_norm=False, ReLU) */
   PH_OP_HEAD = 6,       /* 1x1 conv + bias (+sigmoid) -> NCHW fp32 output #out_index (heads.py:58-67)   */
   PH_OP_STEM = 7,       /* fused first encoder block: image -> /255 -> conv3x3+ReLU (weight/bias) ->
                            conv3x3+ReLU (weight2/bias2, cout <= 16) -> [full-res NHWC slot dst, if >= 0]
@@ -89,6 +90,7 @@ enum ph_op_kind {
 #define PH_FLAG_GELU 4
 #define PH_FLAG_SCALE_RESIDUAL 8
 #define PH_FLAG_SOFTMAX 16 /* PH_OP_HEAD: softmax over the output channels (ClassVectorsHead, heads.py:536-537) */
+#define PH_FLAG_SILU 32    /* PH_OP_CONVT: SiLU instead of ReLU (the activation is an epilogue parameter of the phase GEMMs) */
 
 typedef struct ph_op_desc {
   int32_t kind;      /* enum ph_op_kind                                              */
@@ -104,8 +106,8 @@ typedef struct ph_op_desc {
   int32_t bias;      /* index into the weights[] array, or -1                        */
   int32_t out_index; /* PH_OP_HEAD: which output pointer receives the result         */
   int32_t dst2;      /* PH_OP_STEM: pooled output slot; PH_OP_CONV (ReLU): optional fused 2x2 max-pool slot, -1 = none */
-  int32_t weight2;   /* PH_OP_STEM: second conv weight index; PH_OP_LINEAR: layer_scale index */
-  int32_t bias2;     /* PH_OP_STEM: second conv bias index                           */
+  int32_t weight2;   /* PH_OP_STEM: second conv weight index; PH_OP_LINEAR: layer_scale index; PH_OP_CONVT: folded-BN scale or -1 */
+  int32_t bias2;     /* PH_OP_STEM: second conv bias index; PH_OP_CONVT: folded-BN shift or -1 */
   int32_t cmid;      /* PH_OP_STEM: channels between the two convs (<= 16); PH_OP_PATCH_STEM: stride */
 } ph_op_desc;
 
@@ -195,7 +197,8 @@ int ph_debug_gemm_bench(int32_t variant, int32_t M, int32_t K, int32_t N, int32_
  * tunables).  Every key selects between kernel variants that compute the same result; defaults
  * are the measured-best ones.  Keys: "conv_wino" (1 Winograd F(2,3) 3x3 kernels | 2 only the
  * N-tile-64 layers | 0 direct 9-tap kernels), "stem_wino", "conv_dma", "conv_dma32",
- * "conv_persist", "conv_c16", "conv_dma_stagger", "fuse_gelu_fwd", "fuse_gelu_bwd", "wgrad_rows",
+ * "conv_persist", "conv_c16", "conv_dma_stagger", "fuse_gelu_fwd", "fuse_gelu_bwd", "wgrad_rows", "convt_phase",
+ * "conv_precision" (0 exact fp32 MFMA | 1 split-fp16 MFMA, 22-bit products | 2 plain fp16, the reference's autocast mode),
  * "gemm_late_split", "gemm_persist2", "conv_gemm_fill", "conv_gemm_fill_wino" (DESIGN.md appendix).
  * Unknown key -> PH_E_INVALID. */
 int ph_model_set_option(ph_model* m, const char* key, double value);

@@ -16,7 +16,7 @@ PH_E_INVALID, PH_E_HIP, PH_E_CAPACITY, PH_E_INFEASIBLE, PH_E_WORKSPACE = -1, -2,
 
 OP_INPUT_CONV, OP_CONV, OP_POOL, OP_UPSAMPLE, OP_CONVT, OP_HEAD, OP_STEM = 1, 2, 3, 4, 5, 6, 7
 OP_PATCH_STEM, OP_DWCONV, OP_LAYERNORM, OP_LINEAR, OP_PATCH_CONV, OP_GELU, OP_SCALE_ADD, OP_GLOBAL_MAXPOOL = 8, 9, 10, 11, 12, 13, 14, 15
-FLAG_RELU, FLAG_SIGMOID, FLAG_GELU, FLAG_SCALE_RESIDUAL, FLAG_SOFTMAX = 1, 2, 4, 8, 16
+FLAG_RELU, FLAG_SIGMOID, FLAG_GELU, FLAG_SCALE_RESIDUAL, FLAG_SOFTMAX, FLAG_SILU = 1, 2, 4, 8, 16, 32
 
 
 class OpDesc(C.Structure):

@@ -246,6 +246,10 @@ int launch_layernorm(const float* src, const float* gamma, const float* beta, fl
 //     mode 1  Conv2d k2 s2 ............ 4 taps (dy, dx), row m = output pixel (b, oy, ox)
 //     mode 2  Conv2d 3x3 "same" ....... 9 taps, out-of-image taps read a zero page.  Used for
 //             feature maps too small to fill the 16x32-pixel tiles of the halo-tiled kernel K1d.
+//     mode 3  one output phase (oy & 1, ox & 1) of ConvTranspose2d(k3, s2, p1, op1): 1, 2, 2 or 4 taps over the INPUT
+//             grid, rows = input pixels, results scattered to output pixel (2y + py, 2x + px) (encoder_decoder.py:439-461);
+//             the four phases together do 9 taps per input pixel = 2.25 per output pixel, no zero-stuffed tensor.
+//     mode 4  Conv2d 3x3 stride 2 pad 1 (the data gradient of that transposed conv): 9 taps gathered from a 2H x 2W map.
 //   512 threads = 8 waves, tile 256 rows x BN columns (BN = 32 * NT_TOTAL); waves are arranged
 //   (8 / WN) x WN and each owns WN 32-row tiles x (NT_TOTAL / WN) 32-column tiles.
 //   Pipeline: a ring of three LDS stages of 16 K-values each (256 x 16 A slice + BN x 16 weight
@@ -269,7 +273,8 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void gemm_mfma_dma_tile_kernel(G
   constexpr int NDMA = A_SLOTS + B_SLOTS;  // DMA instructions per wave per stage
   constexpr int STAGE_FLOATS = (A_PIECES + B_PIECES) * 256;
   static_assert((NSTAGE - 2) * NDMA < 64 && NSTAGE >= 2 && WAVES % 2 == 0, "vmcnt field overflow / odd wave count");
-  constexpr int NTAPS = MODE == 0 ? 1 : (MODE == 1 ? 4 : 9);
+  constexpr int NTAPS_C = MODE == 0 ? 1 : (MODE == 1 ? 4 : 9);
+  const int NTAPS = MODE == 3 ? a.ntaps : NTAPS_C;  // mode 3: 1, 2 or 4 taps, by output phase
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -322,6 +327,29 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void gemm_mfma_dma_tile_kernel(G
         const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
         mask |= (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) ? (1u << tap) : 0u;
       }
+    } else if (MODE == 3) {  // transposed-conv phase: taps reach (y + dy, x + dx), dy, dx in {0, 1}; beyond the image = zero
+      const int x = row % a.W;
+      const int y = (row / a.W) % a.H;
+      const int py = a.out_tap >> 1, px = a.out_tap & 1;
+      mask = 0;
+#pragma unroll
+      for (int tap = 0; tap < 4; ++tap) {
+        const int ty = px ? tap >> 1 : tap, tx = px ? tap & 1 : 0;
+        const int dy = py ? 1 - ty : 0, dx = px ? 1 - tx : 0;
+        mask |= (y + dy < a.H && x + dx < a.W) ? (1u << tap) : 0u;
+      }
+    } else if (MODE == 4) {  // 3x3 stride-2 pad-1 gather over an a.H x a.W map; row = (b, oy, ox) on the (a.H / 2) x (a.W / 2) grid
+      const int ow = a.W >> 1, oh = a.H >> 1;
+      const int ox = row % ow;
+      const int r2 = row / ow;
+      const int oy = r2 % oh;
+      pix = ((long long)(r2 / oh) * a.H + 2 * oy) * a.W + 2 * ox;
+      mask = 0;
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int yy = 2 * oy + tap / 3 - 1, xx = 2 * ox + tap % 3 - 1;
+        mask |= (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) ? (1u << tap) : 0u;
+      }
     }
     a_base[0][s] = (unsigned long long)(a.src0 + pix * a.c0p + dquad * 4);
     a_base[1][s] = (unsigned long long)((a.src1 ? a.src1 : a.src0) + pix * a.c1p + dquad * 4);
@@ -338,6 +366,10 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void gemm_mfma_dma_tile_kernel(G
       toff = 0;
     } else if (MODE == 1) {
       toff = (f_tap >> 1) * a.W + (f_tap & 1);
+    } else if (MODE == 3) {
+      const int py = a.out_tap >> 1, px = a.out_tap & 1;
+      const int ty = px ? f_tap >> 1 : f_tap, tx = px ? f_tap & 1 : 0;
+      toff = (py ? 1 - ty : 0) * a.W + (px ? 1 - tx : 0);
     } else {
       const int ty = (f_tap * 11) >> 5;  // f_tap / 3 for 0..8
       toff = (ty - 1) * a.W + (f_tap - 3 * ty - 1);
@@ -476,11 +508,12 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void gemm_mfma_dma_tile_kernel(G
 #pragma unroll
   for (int n = 0; n < NTW; ++n) {
     const int cbase = ntile * BN + (wn * NTW + n) * 32 + 4 * lh;  // + 8 * q
-    f32x4 bias4[4], scale4[4];
+    f32x4 bias4[4], scale4[4], shift4[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       bias4[q] = *reinterpret_cast<const f32x4*>(a.bias + cbase + 8 * q);
       scale4[q] = a.scale ? *reinterpret_cast<const f32x4*>(a.scale + cbase + 8 * q) : f32x4{1.f, 1.f, 1.f, 1.f};
+      shift4[q] = a.shift ? *reinterpret_cast<const f32x4*>(a.shift + cbase + 8 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
@@ -501,9 +534,11 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void gemm_mfma_dma_tile_kernel(G
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           float x = acc[m][n][4 * q + e] + bias4[q][e];
+          if (a.affine_first) x = x * scale4[q][e] + shift4[q][e];  // folded BatchNorm (eval): before the activation
           if (a.act == 1) x = fmaxf(x, 0.f);
           if (a.act == 2) x = gelu_f(x);
-          v[e] = x * scale4[q][e];
+          if (a.act == 4) x = x / (1.f + expf(-x));                 // SiLU
+          v[e] = a.affine_first ? x : x * scale4[q][e];
         }
         const int col = cbase + 8 * q;
         if (interior) {
@@ -897,6 +932,10 @@ int prepare_convnext_kernels() {
                                    (int)GemmCfg<MT, NTW, WM, WN, S, W>::LDS));                                                              \
   PH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mfma_dma_tile_kernel<2, MT, NTW, WM, WN, S, W>), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                    (int)GemmCfg<MT, NTW, WM, WN, S, W>::LDS));                                                              \
+  PH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mfma_dma_tile_kernel<3, MT, NTW, WM, WN, S, W>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                   (int)GemmCfg<MT, NTW, WM, WN, S, W>::LDS));                                                              \
+  PH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mfma_dma_tile_kernel<4, MT, NTW, WM, WN, S, W>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                   (int)GemmCfg<MT, NTW, WM, WN, S, W>::LDS));                                                              \
   PH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mfma_dma_kernel<2, MT, NTW, WM, WN, S, W>), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                    (int)GemmCfg<MT, NTW, WM, WN, S, W>::LDS));                                                              \
   PH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mfma_dma_kernel<0, MT, NTW, WM, WN, S, W, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, \
@@ -919,7 +958,11 @@ int gemm_variant_bn(int variant) {
 int launch_gemm_variant(int variant, const GemmArgs& a_in, hipStream_t s) {
   GemmArgs a = a_in;
   const int persist2 = a.persist2;  // handle option: persistent workgroups for the 9-tap mode too (measured 3-4 % slower than one tile per workgroup)
-  PH_REQUIRE(a.M > 0 && a.c0p > 0 && a.c0p % 16 == 0 && a.c1p % 16 == 0 && a.coutp % 16 == 0 && a.mode >= 0 && a.mode <= 2, "launch_gemm: bad shape");
+  PH_REQUIRE(a.M > 0 && a.c0p > 0 && a.c0p % 16 == 0 && a.c1p % 16 == 0 && a.coutp % 16 == 0 && a.mode >= 0 && a.mode <= 4, "launch_gemm: bad shape");
+  PH_REQUIRE(a.mode != 3 || ((a.ntaps == 1 || a.ntaps == 2 || a.ntaps == 4) && a.ntaps == (1 + (a.out_tap >> 1)) * (1 + (a.out_tap & 1)) && a.out_patch && a.M % (a.H * a.W) == 0),
+             "launch_gemm: transposed-conv phase needs ntaps matching the phase, out_patch and whole images");
+  PH_REQUIRE(a.mode != 4 || (a.H % 2 == 0 && a.W % 2 == 0 && a.M % ((a.H / 2) * (a.W / 2)) == 0), "launch_gemm: stride-2 gather needs even map sizes and whole images");
+  PH_REQUIRE(a.mode >= 3 || (!a.affine_first && a.act != 4 && !a.shift), "launch_gemm: affine-first / SiLU epilogues exist for modes 3 and 4 only");
   PH_REQUIRE(a.c1p == 0 || a.src1, "launch_gemm: second source missing");
   PH_REQUIRE((a.act != 3 && !a.dst_pre) || a.mode == 0, "launch_gemm: the training epilogues exist for the Linear mode only");
   PH_REQUIRE(a.act != 3 || a.aux, "launch_gemm: act 3 needs aux");
@@ -943,11 +986,16 @@ int launch_gemm_variant(int variant, const GemmArgs& a_in, hipStream_t s) {
       hipLaunchKernelGGL((gemm_mfma_dma_kernel<0, MT, NTW, WM, WN, S, W>), grid, dim3(C::THREADS), C::LDS, s, a);              \
     else if (a.mode == 1)                                                                                                      \
       hipLaunchKernelGGL((gemm_mfma_dma_kernel<1, MT, NTW, WM, WN, S, W>), grid, dim3(C::THREADS), C::LDS, s, a);              \
-    else if (persist2)                                                                                                         \
+    else if (a.mode == 2 && persist2)                                                                                          \
       hipLaunchKernelGGL((gemm_mfma_dma_kernel<2, MT, NTW, WM, WN, S, W>), grid, dim3(C::THREADS), C::LDS, s, a);              \
     else {                                                                                                                     \
       const dim3 full((unsigned)(((a.M + C::TM - 1) / C::TM) * ((a.coutp + C::BN - 1) / C::BN)));                              \
-      hipLaunchKernelGGL((gemm_mfma_dma_tile_kernel<2, MT, NTW, WM, WN, S, W>), full, dim3(C::THREADS), C::LDS, s, a);         \
+      if (a.mode == 2)                                                                                                         \
+        hipLaunchKernelGGL((gemm_mfma_dma_tile_kernel<2, MT, NTW, WM, WN, S, W>), full, dim3(C::THREADS), C::LDS, s, a);       \
+      else if (a.mode == 3)                                                                                                    \
+        hipLaunchKernelGGL((gemm_mfma_dma_tile_kernel<3, MT, NTW, WM, WN, S, W>), full, dim3(C::THREADS), C::LDS, s, a);       \
+      else                                                                                                                     \
+        hipLaunchKernelGGL((gemm_mfma_dma_tile_kernel<4, MT, NTW, WM, WN, S, W>), full, dim3(C::THREADS), C::LDS, s, a);       \
     }                                                                                                                          \
     break;                                                                                                                     \
   }

@@ -377,6 +377,15 @@ __global__ __launch_bounds__(256, 2) void row_wgrad_kernel(RowWgradArgs a) {
           const int r2 = mm / ow;
           const int oy = r2 % oh;
           pix = ((size_t)(r2 / oh) * a.H + 2 * oy + (a.tap >> 1)) * a.W + 2 * ox + (a.tap & 1);
+        } else if (a.patch == 3) {  // 3x3 stride-2 pad-1 gather: row (b, oy, ox) on the (H/2 x W/2) grid -> pixel (2oy + ky - 1, 2ox + kx - 1) of the H x W map
+          const int ow = a.W >> 1, oh = a.H >> 1;
+          const int ox = mm % ow;
+          const int r2 = mm / ow;
+          const int oy = r2 % oh;
+          const int yy = 2 * oy + a.tap / 3 - 1, xx = 2 * ox + a.tap % 3 - 1;
+          const bool in = yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
+          pix = in ? ((size_t)(r2 / oh) * a.H + yy) * a.W + xx : 0;
+          if (!in) ck = a.kp;  // -> zeros
         }
         if (ck < a.kp) va = *reinterpret_cast<const f32x4*>(a.x + pix * a.kp + ck);
       }

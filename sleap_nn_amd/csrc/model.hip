@@ -506,6 +506,41 @@ ph_model* ph_model_create(const ph_op_desc* ops, int32_t n_ops, const float* con
           };
           ok = pack_upload(m, pack_16, weights[d.weight], iw, &op.w16_dev) == PH_OK && pack_upload(m, pack_16d, weights[d.weight], iw, &op.wd16_dev) == PH_OK;
         }
+        if (ok && tr) {
+          // ConvTranspose2d(k3, s2, p1, op1): output (oy, ox) = (2y - 1 + ky, 2x - 1 + kx).  Even output rows see only ky = 1
+          // (input row y), odd rows ky = 0 (input row y + 1) and ky = 2 (row y) -- likewise in x: four output phases with
+          // 1, 2, 2, 4 taps.  Each phase is one row GEMM over the input grid (mode 3) whose tap t reads input pixel
+          // (y + dy, x + dx); weights per phase: wp[co][ci][t] = Wt[ci][co][ky(t)][kx(t)].
+          op.bn_t = gemm_choose_bn(coutp);
+          const size_t npad_t = (size_t)((coutp + op.bn_t - 1) / op.bn_t) * op.bn_t;
+          for (int ph = 0; ph < 4 && ok; ++ph) {
+            const int py = ph >> 1, px = ph & 1, nt = (1 + py) * (1 + px);
+            auto pack_p = [&](const auto* w, auto& out) {
+              std::remove_reference_t<decltype(out)> wp((size_t)d.cout * d.cin0 * nt);
+              for (int t = 0; t < nt; ++t) {
+                const int ty = px ? t >> 1 : t, tx = px ? t & 1 : 0;
+                const int ky = py ? 2 * ty : 1, kx = px ? 2 * tx : 1;  // tap t reads (y + 1 - ty, x + 1 - tx): ky = 0 <-> dy = 1
+                for (int co = 0; co < d.cout; ++co)
+                  for (int ci = 0; ci < d.cin0; ++ci) wp[((size_t)co * d.cin0 + ci) * nt + t] = w[(((size_t)ci * d.cout + co) * 3 + ky) * 3 + kx];
+              }
+              pack_gemm(wp.data(), d.cout, d.cin0, 0, nt, op.bn_t, out);
+            };
+            ok = pack_upload(m, pack_p, weights[d.weight], iw, &op.wt_phase_dev[ph]) == PH_OK;
+          }
+          if (ok) ok = pack_upload(m, pad_vec(npad_t, d.cout), weights[d.bias], ib, &op.bt_dev) == PH_OK;
+          if (ok && d.weight2 >= 0) {  // folded BatchNorm (eval): y = act(scale * (conv + bias) + shift)
+            if (!widx_ok(d.weight2) || !widx_ok(d.bias2) || weight_numel[d.weight2] != d.cout || weight_numel[d.bias2] != d.cout) return fail("transposed conv: scale / shift must be (cout)", i);
+            ok = pack_upload(m, pad_vec(npad_t, d.cout), weights[d.weight2], index_array(d.weight2), &op.wt_scale_dev) == PH_OK &&
+                 pack_upload(m, pad_vec(npad_t, d.cout), weights[d.bias2], index_array(d.bias2), &op.wt_shift_dev) == PH_OK;
+          }
+          if (ok) {  // data gradient = Conv2d(dY, Wt as (out = cin0, in = cout, 3, 3), stride 2, pad 1): the ConvTranspose2d weight as it lies in memory
+            const int cinp = pad16(d.cin0);
+            op.bn_td = gemm_choose_bn(cinp);
+            auto pack_dg = [&](const auto* w, auto& out) { pack_gemm(w, d.cin0, d.cout, 0, 9, op.bn_td, out); };
+            std::vector<float> zb((size_t)cinp + 128, 0.f);
+            ok = pack_upload(m, pack_dg, weights[d.weight], iw, &op.wt_dgrad_dev) == PH_OK && upload(m, zb, &op.zero_bias_dev) == PH_OK;
+          }
+        }
         if (ok && d.kind == PH_OP_CONV) {  // data-gradient weights (training)
           const int cin_total = d.cin0 + d.cin1;
           const int parts[2] = {d.cin0, d.cin1}, offs[2] = {0, d.cin0};
@@ -861,6 +896,37 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
       case PH_OP_CONVT: {
         const SlotShape& s0 = plan.slots[d.src0];
         PH_REQUIRE(s0.c == d.cin0, "convT channel mismatch");
+        if (fmt == FMT_F32 && m->convt_phase && op.wt_phase_dev[0]) {  // four output-phase GEMMs: 9 taps per INPUT pixel, no zero-stuffed tensor
+          const SlotShape& so = plan.slots[d.dst];
+          for (int ph = 0; ph < 4 && rc == PH_OK; ++ph) {
+            GemmArgs g{};
+            g.src0 = slot_ptr(d.src0);
+            g.c0p = s0.cp;
+            g.wpack = op.wt_phase_dev[ph];
+            g.bias = op.bt_dev;
+            g.dst = slot_ptr(d.dst);
+            g.zeros = m->zeros_dev;
+            g.coutp = so.cp;
+            g.bn = op.bn_t;
+            g.M = batch * s0.h * s0.w;
+            g.mode = 3;
+            g.ntaps = (1 + (ph >> 1)) * (1 + (ph & 1));
+            g.H = s0.h;
+            g.W = s0.w;
+            g.out_patch = 1;
+            g.out_tap = ph;
+            g.out_H = 2 * s0.h;
+            g.out_W = 2 * s0.w;
+            g.act = (d.flags & PH_FLAG_SILU) ? 4 : ((d.flags & PH_FLAG_RELU) ? 1 : 0);
+            g.scale = op.wt_scale_dev;
+            g.shift = op.wt_shift_dev;
+            g.affine_first = op.wt_scale_dev ? 1 : 0;
+            g.late_split = m->gemm_late_split;
+            rc = launch_gemm(g, s);
+          }
+          break;
+        }
+        PH_REQUIRE(!op.wt_scale_dev && !(d.flags & PH_FLAG_SILU), "folded BatchNorm / SiLU on a transposed conv need the phase GEMMs (exact precision, convt_phase = 1)");
         float* tmp = reinterpret_cast<float*>(ws + plan.tmp_offset);
         rc = launch_zero_stuff(slot_ptr(d.src0), tmp, batch, s0.h, s0.w, s0.cp / rs_div, s);  // 16-B quads: format-agnostic
         if (rc != PH_OK) break;
@@ -1060,6 +1126,7 @@ std::vector<OptionRef> option_table(ph_model* m) {
       {"fuse_gelu_fwd", &m->fuse_gelu_fwd, nullptr},
       {"fuse_gelu_bwd", &m->fuse_gelu_bwd, nullptr},
       {"wgrad_rows", &m->wgrad_rows, nullptr},          // 0 32x32-tile wgrad kernel, 1 auto, 2 nine row-wgrad GEMMs
+      {"convt_phase", &m->convt_phase, nullptr},        // 0: transposed convs by zero-stuffing + 3x3 conv (4x the FLOPs; A/B reference)
       {"conv_precision", &m->conv_precision, nullptr},  // 0 exact fp32 MFMA, 1 split-fp16 MFMA (22-bit products), 2 plain fp16 (autocast-equivalent)
       {"gemm_late_split", &m->gemm_late_split, nullptr},
       {"gemm_persist2", &m->gemm_persist2, nullptr},

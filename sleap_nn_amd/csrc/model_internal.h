@@ -31,6 +31,13 @@ struct PackedOp {
   int bn_d[2] = {0, 0};
   float* w_wino_dev = nullptr;             // 3x3 conv, N tile 64: Winograd F(2,3) weights derived on the device from w_dev
   float* wd_wino_dev[2] = {nullptr, nullptr};  // ... and from wd_dev (data gradient)
+  // ConvTranspose2d(k3, s2, p1, op1) as four output-phase row GEMMs (mode 3) + its data gradient (mode 4)
+  float* wt_phase_dev[4] = {nullptr, nullptr, nullptr, nullptr};
+  float* bt_dev = nullptr;       // bias padded to the GEMM's N tiles
+  float* wt_dgrad_dev = nullptr; // 3x3 stride-2 conv weights (out = cin0, in = cout) in the row-GEMM layout
+  float* wt_scale_dev = nullptr; // optional folded-BatchNorm scale / shift (weight2 / bias2), padded like bt_dev
+  float* wt_shift_dev = nullptr;
+  int bn_t = 0, bn_td = 0;
   float* w_f16_dev[2] = {nullptr, nullptr};  // 3x3 conv / transposed conv on the fp16 matrix pipe: [0] split-fp16, [1] plain fp16 weights (derived lazily from w_dma_dev)
   float* w16_dev = nullptr;   // 16 -> 16 channel 3x3 conv: [tap][ci][co] for conv3x3_c16_kernel
   float* wd16_dev = nullptr;  // ... and of its data gradient
@@ -103,6 +110,7 @@ struct ph_model {
   int wgrad_rows = 0;                         // 3x3 weight gradients of wide layers as nine row-wgrad GEMMs (off by default: measured slower than the 32x32-tile kernel; 1 auto, 2 always)
   double gemm_fill_threshold_wino = 0.5;      // ... and the (lower) break-even when the halo kernel is the Winograd one
   double gemm_fill_threshold = 0.8;           // 3x3 convs whose maps fill the 16x32 tiles less than this run as row GEMMs
+  int convt_phase = 1;                        // "convt_phase": transposed convs as four phase GEMMs (0: zero-stuffing + 3x3 conv, 4x the FLOPs; A/B)
   int conv_precision = 0;                     // "conv_precision": 0 exact fp32 MFMA; 1 split-fp16 MFMA (22-bit products, fp32 accumulate); 2 plain fp16 (autocast-equivalent)
 };
 

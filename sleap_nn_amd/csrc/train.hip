@@ -27,9 +27,19 @@ int build_bwd_plan(const ph_model* m, int B, int H, int W, BwdPlan& bp) {
   int64_t scratch = 0;
   for (const PackedOp& op : m->ops) {
     const ph_op_desc& d = op.d;
-    if (d.kind == PH_OP_STEM || d.kind == PH_OP_CONVT || (d.kind == PH_OP_CONV && d.dst2 >= 0)) {
-      set_error("backward needs the unfused program with bilinear up-sampling (no stem / conv+pool fusion / transposed conv)");
+    if (d.kind == PH_OP_STEM || (d.kind == PH_OP_CONV && d.dst2 >= 0)) {
+      set_error("backward needs the unfused program (no stem / conv+pool fusion)");
       return PH_E_INVALID;
+    }
+    if (d.kind == PH_OP_CONVT) {
+      if (!op.wt_dgrad_dev || op.wt_scale_dev || (d.flags & PH_FLAG_SILU)) {
+        set_error("backward of a transposed conv supports bias + ReLU (the reference's decoder); folded BatchNorm / SiLU are inference-only");
+        return PH_E_INVALID;
+      }
+      const SlotShape& si = bp.act.slots[d.src0];
+      scratch = std::max<int64_t>(scratch, row_wgrad_slab_floats(B * si.h * si.w, d.cin0, d.cout));
+      scratch = std::max<int64_t>(scratch, bias_scratch_floats(pad16(d.cout)));
+      continue;
     }
     if (d.kind == PH_OP_LINEAR && (d.flags & (PH_FLAG_GELU | PH_FLAG_SCALE_RESIDUAL))) {
       set_error("backward needs the unfused ConvNeXt program (GELU / layer-scale as ops of their own)");
@@ -254,6 +264,52 @@ int ph_model_backward(ph_model* m, const void* input_dev, int32_t in_dtype, int3
           if (rc != PH_OK) return rc;
           init[srcs[part]] = 1;
         }
+        break;
+      }
+      case PH_OP_CONVT: {  // y = ReLU(ConvTranspose2d(x; Wt) + b), encoder_decoder.py:439-461
+        const SlotShape& so = bp.act.slots[d.dst];
+        const SlotShape& si = bp.act.slots[d.src0];
+        PH_REQUIRE(init[d.dst], "transposed conv output slot %d received no gradient", d.dst);
+        const size_t npix = (size_t)batch * so.h * so.w;
+        if (d.flags & PH_FLAG_RELU)
+          rc = launch_relu_mask_bias_grad(G(d.dst), A(d.dst), npix, so.cp, d.cout, grads_flat_dev + m->weight_offset[d.bias], scratch, s);
+        else
+          rc = launch_bias_grad(G(d.dst), npix, so.cp, d.cout, grads_flat_dev + m->weight_offset[d.bias], scratch, s);
+        // dWt[ci][co][ky][kx] = sum over input pixels (y, x) of x[y, x, ci] * dY[2y - 1 + ky, 2x - 1 + kx, co]: one row-wgrad GEMM per tap,
+        // rows = input pixels, the dY operand gathered with stride 2 (patch 3); the result lands in the IOHW layout directly
+        for (int tap = 0; tap < 9 && rc == PH_OK; ++tap) {
+          RowWgradArgs w{};
+          w.dy = A(d.src0);  // the "n" operand: input channels
+          w.np = si.cp;
+          w.x = G(d.dst);    // the gathered "k" operand: output channels
+          w.kp = so.cp;
+          w.slab = scratch;
+          w.M = batch * si.h * si.w;
+          w.patch = 3;
+          w.tap = tap;
+          w.H = so.h;
+          w.W = so.w;
+          rc = launch_row_wgrad(w, d.cin0, d.cout, 9, grads_flat_dev + m->weight_offset[d.weight], s);
+        }
+        if (rc != PH_OK) return rc;
+        // dX = Conv2d(dY, Wt viewed as (out = cin0, in = cout, 3, 3), stride 2, pad 1): row GEMM mode 4
+        GemmArgs g{};
+        g.src0 = G(d.dst);
+        g.c0p = so.cp;
+        g.wpack = op.wt_dgrad_dev;
+        g.bias = op.zero_bias_dev;
+        g.dst = G(d.src0);
+        g.residual = init[d.src0] ? G(d.src0) : nullptr;  // accumulate into a gradient that is already there
+        g.zeros = m->zeros_dev;
+        g.coutp = si.cp;
+        g.bn = op.bn_td;
+        g.M = batch * si.h * si.w;
+        g.mode = 4;
+        g.H = so.h;
+        g.W = so.w;
+        g.late_split = m->gemm_late_split;
+        rc = launch_gemm(g, s);
+        init[d.src0] = 1;
         break;
       }
       case PH_OP_INPUT_CONV: {

@@ -48,7 +48,7 @@ struct RowWgradArgs {
   const float* x;   // input activations, kp channels (rows = pixels; patch mode gathers 2x2/stride-2 taps)
   float* slab;      // scratch: [slices][blocks][128][128]
   int np, kp, M;
-  int patch = 0, tap = 0, H = 0, W = 0;  // patch 1: 2x2/stride-2 taps (dy, dx); patch 2: 3x3 "same" conv taps; H, W = input spatial size
+  int patch = 0, tap = 0, H = 0, W = 0;  // patch 1: 2x2/stride-2 taps (dy, dx); patch 2: 3x3 "same" conv taps; patch 3: 3x3 stride-2 pad-1 taps (rows on the H/2 x W/2 grid); H, W = size of the gathered map
 };
 int launch_gelu_fwd(const float* x, float* y, size_t n, hipStream_t s);
 int launch_gelu_bwd(const float* gy, const float* x, float* gx, int accumulate, size_t n, hipStream_t s);

@@ -563,6 +563,67 @@ def test_cfg5_multiclass_bottomup_768_fp16_network_and_full_size_postprocess():
     assert np.allclose(out.instance_tracking_scores.numpy(), rt.numpy(), atol=1e-6, equal_nan=True)
 
 
+def test_transposed_conv_phase_gemms_equal_zero_stuffing_and_carry_epilogue_parameters():
+    """(1) The four output-phase GEMMs of ConvTranspose2d(k3, s2, p1, op1) against the zero-stuff + 3x3-conv formulation
+    (handle option convt_phase = 0) and the reference golden, odd input sizes included.  (2) The activation and a folded
+    BatchNorm are epilogue parameters of those GEMMs (north_star's "ConvTranspose + BN + SiLU decoder stage"; the reference
+    builds its decoder with batch_norm=False + ReLU): a hand-built op program through the C ABI vs torch."""
+    import ctypes as C
+
+    import torch.nn.functional as F
+
+    from sleap_nn_amd import _lib as L
+
+    z = G.load("unet_tiny_trans.npz")
+    cfg = G.config(z)
+    img = torch.from_numpy(z["image"]).squeeze(1)[:, :, :40, :56].contiguous().to(DEV)  # 5x7 maps at the deepest level
+    outs = {}
+    for phase in (1, 0):
+        m = _model(cfg, G.weights(z)).set_option("convt_phase", phase)
+        outs[phase] = {k: v.clone() for k, v in m(img).items()}
+    ref = O.model_forward(G.weights(z), cfg["backbone"], cfg["heads"], cfg["model_type"], img.cpu())
+    for k, v in ref.items():
+        assert (outs[1][k].cpu() - v).abs().max().item() <= CMS_ATOL
+        assert (outs[1][k] - outs[0][k]).abs().max().item() <= 2e-5
+
+    # ---- hand-built program: image -> conv3x3(1 -> 24) + ReLU -> ConvT(24 -> 40) * scale + shift -> SiLU -> head 1x1 (40 -> 3)
+    lib = L.lib()
+    g = torch.Generator().manual_seed(8)
+    w0, b0 = torch.randn(24, 1, 3, 3, generator=g) * 0.3, torch.randn(24, generator=g) * 0.1
+    wt, bt = torch.randn(24, 40, 3, 3, generator=g) * 0.1, torch.randn(40, generator=g) * 0.1
+    sc, sh = torch.rand(40, generator=g) + 0.5, torch.randn(40, generator=g) * 0.2
+    wh, bh = torch.randn(3, 40, 1, 1, generator=g) * 0.2, torch.randn(3, generator=g) * 0.1
+    tensors = [t.contiguous() for t in (w0, b0, wt, bt, sc, sh, wh, bh)]
+    ops = (L.OpDesc * 3)()
+    for i, (kind, src0, dst, cin0, cout, ks, flags, w, b, w2, b2, oi) in enumerate([
+        (L.OP_INPUT_CONV, -1, 0, 1, 24, 3, L.FLAG_RELU, 0, 1, -1, -1, -1),
+        (L.OP_CONVT, 0, 1, 24, 40, 3, L.FLAG_SILU, 2, 3, 4, 5, -1),
+        (L.OP_HEAD, 1, -1, 40, 3, 1, 0, 6, 7, -1, -1, 0),
+    ]):
+        d = ops[i]
+        d.kind, d.src0, d.src1, d.dst, d.cin0, d.cin1, d.cout, d.ksize, d.flags = kind, src0, -1, dst, cin0, 0, cout, ks, flags
+        d.weight, d.bias, d.out_index, d.dst2, d.weight2, d.bias2, d.cmid = w, b, oi, -1, w2, b2, 0
+    ptrs = (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+    numel = (C.c_int64 * len(tensors))(*[t.numel() for t in tensors])
+    with torch.cuda.device(DEV):
+        h = C.c_void_p(lib.ph_model_create(ops, 3, ptrs, numel, len(tensors), 2, 1))
+        assert h, lib.ph_last_error()
+        x = torch.randint(0, 256, (2, 1, 21, 34), dtype=torch.uint8, generator=g)
+        xd = x.to(DEV)
+        need = L.check(lib.ph_model_workspace_bytes(h, 2, 21, 34))
+        ws = torch.empty(int(need), dtype=torch.uint8, device=DEV)
+        out = torch.empty((2, 3, 42, 68), dtype=torch.float32, device=DEV)
+        optr = (C.c_void_p * 1)(out.data_ptr())
+        L.check(lib.ph_model_forward(h, C.c_void_p(xd.data_ptr()), 0, 2, 1, 21, 34, C.c_void_p(ws.data_ptr()), ws.numel(), optr, L.current_stream_ptr()))
+        torch.cuda.synchronize()
+        lib.ph_model_destroy(h)
+    y = F.relu(F.conv2d(x.float() / 255.0, w0, b0, padding=1))
+    y = F.conv_transpose2d(y, wt, bt, stride=2, padding=1, output_padding=1)
+    y = F.silu(y * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))  # BatchNorm2d.eval() folded to scale / shift, then SiLU
+    y = F.conv2d(y, wh, bh)
+    assert (out.cpu() - y).abs().max().item() <= CMS_ATOL
+
+
 def _wz(z, prefix):
     return {k[len(prefix):]: torch.from_numpy(z[k]) for k in z.files if k.startswith(prefix)}
 

@@ -344,3 +344,49 @@ def test_lr_schedule_drives_the_optimizer():
     for e in range(10):
         tm2.on_epoch_end()
     assert abs(tm2.lr - 1e-4) < 1e-12  # StepLR defaults: step_size 10, gamma 0.1
+
+
+@pytest.mark.parametrize("case", ["tiny_trans", "wide_trans_odd"])
+def test_backward_with_transposed_conv_decoder(case):
+    """up_interpolate=False (ConvTranspose2d(k3, s2, p1, op1) + ReLU up-sampling, encoder_decoder.py:439-461): forward through
+    the four output-phase GEMMs, weight gradient by nine stride-2-gathered row GEMMs, data gradient as a 3x3 stride-2 conv --
+    loss and every parameter gradient vs autograd over the oracle."""
+    if case == "tiny_trans":
+        bb, heads, mt = _cfg(8, 8, 2)
+        bb["filters_rate"] = 1.5
+        hw, B = (48, 80), 2
+    else:
+        bb, heads, mt = _cfg(24, 16, 4, n_nodes=4)
+        hw, B = (96, 112), 3
+    bb["up_interpolate"] = False
+    sd, img, targets, lw, tm = _setup(bb, heads, mt, hw, B, seed=23)
+    assert any("trans_conv" in k for k in sd)
+    ref_losses, ref_grads = O.training_step(sd, bb, heads, mt, img, targets, lw)
+    loss = tm.forward_backward(img, targets).cpu().numpy()
+    assert np.allclose(loss, np.array(ref_losses, dtype=np.float32), rtol=1e-5, atol=1e-6)
+    _check_grads(tm, ref_grads)
+
+
+def test_fine_tuning_the_reference_bottomup_fixture_checkpoint():
+    """The reference's own bottom-up fixture checkpoint (minimal_instance_bottomup, up_interpolate: false) takes training
+    steps: gradients of the first step vs autograd over the oracle on its golden frames, then three Adam steps lower the loss."""
+    from sleap_nn_amd.architectures.model import Model
+    from sleap_nn_amd.training.module import TrainingModule
+    from tests import _golden as G
+
+    z = G.load("ckpt_bottomup.npz")
+    cfg = G.config(z)
+    bb, heads, mt = cfg["backbone"], cfg["heads"], cfg["model_type"]
+    sd = G.weights(z)
+    img = torch.from_numpy(z["image"]).squeeze(1)[:, :, :192, :256].contiguous()
+    tg = {k[4:]: torch.from_numpy(z[k])[:, :, : 192 // (2 if "Confmaps" in k else 4), : 256 // (2 if "Confmaps" in k else 4)].contiguous() * 0.9 + 0.01 for k in z.files if k.startswith("out/")}
+    m = Model("unet", bb, heads, mt)
+    m.load_state_dict(sd)
+    lw = [h.loss_weight for h in m.heads]
+    tm = TrainingModule(m, DEV, lr=1e-4, loss_weights=lw)
+    ref_losses, ref_grads = O.training_step(sd, bb, heads, mt, img, tg, lw)
+    first = tm.forward_backward(img, tg).cpu().numpy()
+    assert np.allclose(first, np.array(ref_losses, dtype=np.float32), rtol=1e-5, atol=1e-7)
+    _check_grads(tm, ref_grads)
+    losses = [float(tm.training_step({"image": img, **tg})[0]) for _ in range(4)]
+    assert losses[-1] < losses[0]
