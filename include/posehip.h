@@ -168,6 +168,15 @@ int ph_model_backward(ph_model* m, const void* input_dev, int32_t in_dtype, int3
                       int32_t min_hard_keypoints, int32_t max_hard_keypoints, float ohkm_loss_scale,
                       float* loss_dev, float* grads_flat_dev, void* stream);
 
+/* Two gradient buckets for overlapping the data-parallel all-reduce with the backward sweep (DDP's bucketing,
+ * training/model_trainer.py:1751-1813 runs the reference under Lightning's DDP strategy).  The sweep runs heads -> decoder ->
+ * middle -> encoder and the arena is in program order, so its tail becomes final first: ph_model_grad_bucket_split returns the
+ * offset B (closest to the middle at which the arena splits cleanly between two ops; n_params if it never does), and an event
+ * handed to ph_model_set_bucket_event (a hipEvent_t; NULL = off) is recorded on the backward's stream as soon as every gradient
+ * in [B, n_params) is final -- a collective on another stream can wait on it while the rest of the backward still runs. */
+int64_t ph_model_grad_bucket_split(const ph_model* m);
+int ph_model_set_bucket_event(ph_model* m, void* hip_event);
+
 /* torch.optim.Adam step (weight_decay = 0) on flat device arrays; max_exp_avg_sq_dev != NULL enables
  * amsgrad.  grad_scale multiplies the gradient first (1/world_size after a sum all-reduce). */
 int ph_adam_step(float* params_dev, const float* grads_dev, float* exp_avg_dev, float* exp_avg_sq_dev,

@@ -47,6 +47,8 @@ SIGNATURES = {
     "ph_model_forward": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _i64, C.POINTER(_vp), _vp]),
     "ph_model_num_params": (_i64, [_vp]),
     "ph_model_set_params": (C.c_int, [_vp, _vp, _vp]),
+    "ph_model_grad_bucket_split": (_i64, [_vp]),
+    "ph_model_set_bucket_event": (C.c_int, [_vp, _vp]),
     "ph_model_backward_workspace_bytes": (_i64, [_vp, _i32, _i32, _i32]),
     "ph_model_backward": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i64, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_f32), _vp, _i32, _f32,
                                     _i32, _i32, _f32, _vp, _vp, _vp]),

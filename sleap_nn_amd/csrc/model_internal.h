@@ -89,6 +89,7 @@ struct ph_model {
   std::vector<double> op_ms;       // accumulated per op
   int profiled_forwards = 0;
   unsigned long long* clock_probe = nullptr;  // diagnostic buffer (ph_model_set_clock_probe)
+  hipEvent_t bucket_event = nullptr;          // recorded mid-backward when the arena tail is final (ph_model_set_bucket_event)
   float* zeros_dev = nullptr;                 // zero page for LDS-DMA halo padding
   std::vector<int64_t> weight_offset;          // canonical arena offset of weights[i] (ph_model_create order)
   std::vector<int64_t> weight_numel;

@@ -111,6 +111,53 @@ int ph_model_set_params(ph_model* m, const float* params_flat_dev, void* stream)
   return PH_OK;
 }
 
+// Smallest arena offset an op's parameters start at (-1: the op has none).
+static int64_t op_param_offset(const ph_model* m, const ph_op_desc& d) {
+  int64_t lo = -1;
+  for (int idx : {d.weight, d.bias, d.weight2, d.bias2})
+    if (idx >= 0 && idx < (int)m->weight_offset.size()) lo = lo < 0 ? m->weight_offset[idx] : std::min(lo, m->weight_offset[idx]);
+  return lo;
+}
+
+// The op (forward order) whose completion in the reverse sweep makes the arena tail [offset, n_params) final: the program's
+// parameters lie in op order, so the candidates are the ops at which the arena splits cleanly; the one closest to the middle wins.
+static int bucket_split_op(const ph_model* m, int64_t* offset_out) {
+  const int n = (int)m->ops.size();
+  std::vector<int64_t> off(n);
+  for (int i = 0; i < n; ++i) off[i] = op_param_offset(m, m->ops[i].d);
+  int best = -1;
+  int64_t best_off = m->n_params;
+  for (int k = 1; k < n; ++k) {
+    if (off[k] <= 0) continue;
+    bool clean = true;
+    for (int i = 0; i < n && clean; ++i)
+      if (off[i] >= 0) clean = i < k ? off[i] < off[k] : off[i] >= off[k];
+    if (!clean) continue;
+    if (best < 0 || std::llabs(2 * off[k] - m->n_params) < std::llabs(2 * best_off - m->n_params)) {
+      best = k;
+      best_off = off[k];
+    }
+  }
+  if (offset_out) *offset_out = best_off;
+  return best;
+}
+
+int64_t ph_model_grad_bucket_split(const ph_model* m) {
+  if (!m) {
+    set_error("ph_model_grad_bucket_split: null model");
+    return PH_E_INVALID;
+  }
+  int64_t off = m->n_params;
+  bucket_split_op(m, &off);
+  return off;
+}
+
+int ph_model_set_bucket_event(ph_model* m, void* hip_event) {
+  PH_REQUIRE(m, "ph_model_set_bucket_event: null model");
+  m->bucket_event = static_cast<hipEvent_t>(hip_event);
+  return PH_OK;
+}
+
 int64_t ph_model_backward_workspace_bytes(const ph_model* m, int32_t batch, int32_t height, int32_t width) {
   if (!m || batch <= 0 || height <= 0 || width <= 0) {
     set_error("ph_model_backward_workspace_bytes: bad arguments");
@@ -172,6 +219,7 @@ int ph_model_backward(ph_model* m, const void* input_dev, int32_t in_dtype, int3
   if (rc != PH_OK) return rc;
 
   // ---- reverse sweep
+  const int split_op = m->bucket_event ? bucket_split_op(m, nullptr) : -1;
   for (int oi = (int)m->ops.size() - 1; oi >= 0; --oi) {
     const PackedOp& op = m->ops[oi];
     const ph_op_desc& d = op.d;
@@ -494,7 +542,9 @@ int ph_model_backward(ph_model* m, const void* input_dev, int32_t in_dtype, int3
         rc = PH_E_INVALID;
     }
     if (rc != PH_OK) return rc;
+    if (oi == split_op) PH_HIP_CHECK(hipEventRecord(m->bucket_event, s));  // gradients [bucket split, n_params) are final from here on
   }
+  if (m->bucket_event && split_op < 0) PH_HIP_CHECK(hipEventRecord(m->bucket_event, s));
   return PH_OK;
 }
 

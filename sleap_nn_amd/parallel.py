@@ -76,3 +76,33 @@ def allreduce_mean_(flat: torch.Tensor, group=None) -> torch.Tensor:
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
         flat.div_(dist.get_world_size(group))
     return flat
+
+
+def all_reduce_buckets_(flat: torch.Tensor, split: Optional[int], group=None, tail_ready=None, comm_stream=None) -> float:
+    """Sum ``flat`` over the ranks as two buckets -- the tail ``[split:]`` first, then the head ``[:split]`` -- and return the
+    factor (1 / world) that turns the sum into DDP's mean (it is folded into the optimizer kernel, not applied here).
+
+    On the GPU the caller passes the event the backward records when the tail is final (``tail_ready``) and a side stream:
+    the tail's collective then overlaps the rest of the backward (``TrainingModule.all_reduce_grads``).  On host tensors
+    (gloo, CPU tests) the two collectives simply run in that order; the result is the same as one all-reduce of the arena."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) <= 1:
+        return 1.0
+    world = dist.get_world_size(group)
+    if split is None or split <= 0 or split >= flat.numel():
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        return 1.0 / world
+    if flat.is_cuda and comm_stream is not None:
+        main = torch.cuda.current_stream(flat.device)
+        with torch.cuda.stream(comm_stream):
+            if tail_ready is not None:
+                comm_stream.wait_event(tail_ready)
+            else:
+                comm_stream.wait_stream(main)
+            dist.all_reduce(flat[split:], op=dist.ReduceOp.SUM, group=group)
+            comm_stream.wait_stream(main)  # the rest of the backward
+            dist.all_reduce(flat[:split], op=dist.ReduceOp.SUM, group=group)
+        main.wait_stream(comm_stream)
+    else:
+        dist.all_reduce(flat[split:], op=dist.ReduceOp.SUM, group=group)
+        dist.all_reduce(flat[:split], op=dist.ReduceOp.SUM, group=group)
+    return 1.0 / world

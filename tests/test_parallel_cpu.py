@@ -97,3 +97,62 @@ def test_bench_launches_its_own_ranks_and_fails_loudly_without_gpus():
     assert r.stderr.count("--gpus 2 but only 0 GPUs are visible") == 2, r.stderr[-1500:]
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4"], env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr
+
+
+def _dp_worker(rank, world, port, q):
+    """One rank of a data-parallel training step on HOST tensors (gloo): the oracle supplies forward/backward, the product's
+    bucketed all-reduce + the 1/world scale give DDP's averaged gradient, torch's Adam applies it."""
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    from oracle import cpu_ref as O
+    from sleap_nn_amd.parallel import all_reduce_buckets_, shard_bounds
+
+    bb = {"in_channels": 1, "kernel_size": 3, "filters": 4, "filters_rate": 2, "max_stride": 4, "stem_stride": None, "middle_block": True, "up_interpolate": True,
+          "stacks": 1, "convs_per_block": 2, "output_stride": 2}
+    heads = {"confmaps": {"part_names": ["a", "b"], "output_stride": 2, "loss_weight": 1.0}}
+    sd = O.init_state(bb, heads, "single_instance", seed=5, head_scale=1.0)
+    g = torch.Generator().manual_seed(9)
+    img = torch.randint(0, 256, (4, 1, 16, 24), dtype=torch.uint8, generator=g)
+    tgt = {"SingleInstanceConfmapsHead": torch.rand(4, 2, 8, 12, generator=g)}
+    lo, hi = shard_bounds(4, world, rank)  # disjoint, equal shards (DistributedSampler semantics)
+    _, grads = O.training_step(sd, bb, heads, "single_instance", img[lo:hi], {k: v[lo:hi] for k, v in tgt.items()}, [1.0])
+    keys = list(sd.keys())
+    flat = torch.cat([grads[k].reshape(-1) for k in keys])
+    split = sum(sd[k].numel() for k in keys[: len(keys) // 2])  # any clean boundary: the result must not depend on it
+    scale = all_reduce_buckets_(flat, split)
+    whole = torch.cat([grads[k].reshape(-1) for k in keys])
+    dist.all_reduce(whole)
+    q.put((rank, (flat * scale).numpy(), (whole / world).numpy(), scale))
+    dist.destroy_process_group()
+
+
+def test_data_parallel_gradient_semantics_world2_gloo():
+    """Two ranks with disjoint halves of a batch: bucketed all-reduce x (1 / world) == DDP's mean gradient == the gradient of the
+    global batch on one rank (MSE is a mean over equal shards), independent of where the bucket boundary sits."""
+    from oracle import cpu_ref as O
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][3] == 0.5
+    assert np.array_equal(res[0][1], res[1][1]) and np.allclose(res[0][1], res[0][2], rtol=0, atol=0)
+    bb = {"in_channels": 1, "kernel_size": 3, "filters": 4, "filters_rate": 2, "max_stride": 4, "stem_stride": None, "middle_block": True, "up_interpolate": True,
+          "stacks": 1, "convs_per_block": 2, "output_stride": 2}
+    heads = {"confmaps": {"part_names": ["a", "b"], "output_stride": 2, "loss_weight": 1.0}}
+    sd = O.init_state(bb, heads, "single_instance", seed=5, head_scale=1.0)
+    g = torch.Generator().manual_seed(9)
+    img = torch.randint(0, 256, (4, 1, 16, 24), dtype=torch.uint8, generator=g)
+    tgt = {"SingleInstanceConfmapsHead": torch.rand(4, 2, 8, 12, generator=g)}
+    _, full = O.training_step(sd, bb, heads, "single_instance", img, tgt, [1.0])
+    ref = torch.cat([full[k].reshape(-1) for k in sd.keys()]).numpy()
+    assert np.allclose(res[0][1], ref, rtol=1e-5, atol=1e-8)
