@@ -69,21 +69,26 @@ def unet_plan(bb: dict) -> dict:
     middle = bool(bb.get("middle_block", True))
     interp = bool(bb.get("up_interpolate", True))
     cin = int(bb["in_channels"])
-    assert stem_blocks == 0, "oracle covers stem_stride=None (the hot-path configs)"
+    assert stem_blocks <= 1, "stem_stride > 2 does not run in the reference (unet.py:287-288 vs encoder_decoder.py:652-676)"
     assert int(bb.get("stacks", 1)) == 1
 
-    enc = []  # list of blocks: dict(pool=bool, convs=[(name, cin, cout)])
+    stem = []  # StemBlock (encoder_decoder.py:144-225): 7x7 convs (stem_kernel_size = 7, never configured), pool before convs from block 1 on
     prev = cin
-    for b in range(down):
+    for b in range(stem_blocks):
         f = int(filters * (rate**b))
+        stem.append({"pool": b > 0, "convs": [(f"backbone.stem.stem_stack.{b}.blocks.stem{b}_conv{i}", prev if i == 0 else f, f) for i in range(cpb)]})
+        prev = f
+    enc = []  # list of blocks: dict(pool=bool, convs=[(name, cin, cout)])
+    for b in range(down):
+        f = int(filters * (rate ** (b + stem_blocks)))
         convs = []
         for i in range(cpb):
             convs.append((f"backbone.encoders.0.encoder_stack.{b}.blocks.stack0_enc{b}_conv{i}", prev if i == 0 else f, f))
-        enc.append({"pool": b > 0, "convs": convs})
+        enc.append({"pool": b + stem_blocks > 0, "convs": convs})
         prev = f
     mid = []
     enc_num = down + 1  # encoder_stack has down blocks + last pool
-    fmid = int(filters * (rate**down))
+    fmid = int(filters * (rate ** (down + stem_blocks)))
     mb = 0
     if middle:
         if cpb > 1:
@@ -98,11 +103,11 @@ def unet_plan(bb: dict) -> dict:
         prev = fmid
     x_in = fmid  # decoder input channels (unet.py:198-206, block_contraction False)
     dec = []
-    cur_stride = 2**down
+    cur_stride = 2 ** (down + stem_blocks + (1 if stem_blocks else 0))  # unet.py:178-191: the stem's own final pool counts too
     stride_to_filters = {cur_stride: x_in}
     pin = x_in
     for b in range(up):
-        fout = int(filters * (rate ** max(0, down - 1 - b)))
+        fout = int(filters * (rate ** max(0, down + stem_blocks - 1 - b)))
         nxt = cur_stride // 2
         pfx = f"backbone.decoders.0.decoder_stack.{b}.blocks.stack0_dec{b}_s{cur_stride}_to_s{nxt}"
         blk = {"interp": interp, "skip_c": fout, "convs": [], "stride": nxt}
@@ -117,7 +122,7 @@ def unet_plan(bb: dict) -> dict:
         stride_to_filters[nxt] = fout
         pin = fout
         cur_stride = nxt
-    return {"enc": enc, "mid": mid, "dec": dec, "stride_to_filters": stride_to_filters, "k": k, "down": down}
+    return {"stem": stem, "enc": enc, "mid": mid, "dec": dec, "stride_to_filters": stride_to_filters, "k": k, "down": down}
 
 
 def init_state(bb: dict, head_cfgs: dict, model_type: str, seed: int = 1234, head_scale: float = 0.05) -> Dict[str, torch.Tensor]:
@@ -138,6 +143,9 @@ def init_state(bb: dict, head_cfgs: dict, model_type: str, seed: int = 1234, hea
         sd[name + ".weight"] = xavier((co, ci, kk, kk), ci * kk * kk, co * kk * kk)
         sd[name + ".bias"] = torch.zeros(co)
 
+    for blk in plan["stem"]:
+        for n, ci, co in blk["convs"]:
+            add_conv(n, ci, co, 7)
     for blk in plan["enc"]:
         for n, ci, co in blk["convs"]:
             add_conv(n, ci, co, k)
@@ -410,12 +418,21 @@ def unet_forward(sd: Dict[str, torch.Tensor], bb: dict, x: torch.Tensor, collect
     plan = unet_plan(bb)
     pad = plan["k"] // 2
 
-    def conv(name, t):
-        y = F.relu(F.conv2d(t, sd[name + ".weight"], sd[name + ".bias"], padding=pad))
+    def conv(name, t, p=pad):
+        y = F.relu(F.conv2d(t, sd[name + ".weight"], sd[name + ".bias"], padding=p))
         if collect is not None:
             collect[name] = y
         return y
 
+    stem_out = None
+    for blk in plan["stem"]:
+        if blk["pool"]:
+            x = same_pool2(x)
+        for n, _, _ in blk["convs"]:
+            x = conv(n, x, 3)
+    if plan["stem"]:
+        x = same_pool2(x)
+        stem_out = x
     feats = []
     for blk in plan["enc"]:
         if blk["pool"]:
@@ -429,6 +446,8 @@ def unet_forward(sd: Dict[str, torch.Tensor], bb: dict, x: torch.Tensor, collect
             x = conv(n, x)
     middle = x
     feats = feats[::-1]
+    if stem_out is not None:
+        feats.append(stem_out)  # unet.py:287-288
     outs, strides = [], []
     for i, blk in enumerate(plan["dec"]):
         if blk["interp"]:
@@ -490,6 +509,13 @@ def conv_flops(bb: dict, head_cfgs: dict, model_type: str, h: int, w: int) -> fl
     k2 = plan["k"] ** 2
     total = 0.0
     ch, cw = h, w
+    for blk in plan["stem"]:
+        if blk["pool"]:
+            ch, cw = (ch + 1) // 2, (cw + 1) // 2
+        for _, ci, co in blk["convs"]:
+            total += 2.0 * ci * co * 49 * ch * cw
+    if plan["stem"]:
+        ch, cw = (ch + 1) // 2, (cw + 1) // 2
     for blk in plan["enc"]:
         if blk["pool"]:
             ch, cw = (ch + 1) // 2, (cw + 1) // 2

@@ -246,6 +246,19 @@ def paf_fixture():
     save("paf.npz", **arrs)
 
 
+def stem_and_kernel_fixtures():
+    """UNet variants outside the hot-path configs that a reference checkpoint may use: a stem block (stem_stride 2: 7x7 stem convs,
+    the deepest feature at 2 x max_stride, the stem output as the last skip) and kernel_size 5."""
+    bb = {"in_channels": 1, "kernel_size": 3, "filters": 8, "filters_rate": 1.5, "max_stride": 8, "stem_stride": 2, "middle_block": True, "up_interpolate": True,
+          "stacks": 1, "convs_per_block": 2, "output_stride": 2}
+    heads = {"confmaps": {"part_names": ["a", "b", "c"], "sigma": 1.5, "output_stride": 2, "loss_weight": 1.0}}
+    tiny_unet("unet_tiny_stem.npz", bb, heads, "single_instance", (64, 96), 2, seed=41)
+    bb5 = dict(bb, kernel_size=5, stem_stride=None, in_channels=3, up_interpolate=False)
+    heads5 = {"confmaps": {"part_names": ["a", "b"], "sigma": 1.5, "output_stride": 2, "loss_weight": 1.0},
+              "pafs": {"edges": [["a", "b"]], "sigma": 4.0, "output_stride": 4, "loss_weight": 1.0}}
+    tiny_unet("unet_tiny_k5.npz", bb5, heads5, "bottomup", (40, 56), 2, seed=43)
+
+
 def core_fixtures():
     ckpt_fixture("bottomup", "bottomup", n_frames=2)
     ckpt_fixture("single_instance", "single_instance", n_frames=2)
@@ -709,6 +722,8 @@ if __name__ == "__main__":
     only = sys.argv[1:]
     if not only or "losses" in only:
         losses_fixture()
+    if not only or "stem" in only:
+        stem_and_kernel_fixtures()
     if not only or "schedulers" in only:
         schedulers_fixture()
     if not only or "core" in only:

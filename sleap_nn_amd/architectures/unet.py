@@ -88,9 +88,9 @@ class UNet:
         self.n_slots += 1
         return self.n_slots - 1
 
-    def _conv(self, name: str, src0: int, cin0: int, cout: int, src1: int = -1, cin1: int = 0, first: bool = False) -> int:
+    def _conv(self, name: str, src0: int, cin0: int, cout: int, src1: int = -1, cin1: int = 0, first: bool = False, k: Optional[int] = None) -> int:
         dst = self._new_slot()
-        k = self.kernel_size
+        k = self.kernel_size if k is None else k
         self.param_shapes[name + ".weight"] = (cout, cin0 + cin1, k, k)
         self.param_shapes[name + ".bias"] = (cout,)
         self.ops.append(
@@ -99,32 +99,46 @@ class UNet:
         self.labels[name] = dst
         return dst
 
+    def _pool(self, cur: int, cur_c: int, label: str) -> int:
+        dst = self._new_slot()
+        self.ops.append(OpSpec(L.OP_POOL, cur, -1, dst, cur_c, label=label))
+        return dst
+
     def _build(self) -> None:
-        if self.stem_blocks != 0:
-            raise ValueError("stem_stride is not supported by the MI355X hot path (reference default: null)")
+        if self.stem_blocks > 1:
+            # unet.py:287-288 appends ONE stem feature, the decoder (encoder_decoder.py:652-676) then builds its last blocks for
+            # a concat that never arrives: the reference's forward fails with a channel mismatch for stem_stride >= 4
+            raise ValueError("stem_stride > 2 does not run in the reference either (decoder / feature-list mismatch, unet.py:287-288)")
         if self.stacks != 1:
             raise ValueError("only stacks=1 is supported (the reference's multi-stack path is non-functional, unet.py:120,277)")
-        if self.kernel_size != 3:
-            raise ValueError("only kernel_size=3 is supported by the MFMA convolution kernels")
-        f, r = self.filters, self.filters_rate
+        if self.kernel_size % 2 != 1 or not (1 <= self.kernel_size <= 9):
+            raise ValueError("kernel_size must be odd and <= 9")
+        f, r, sb = self.filters, self.filters_rate, self.stem_blocks
         cur, cur_c = -1, self.in_channels
-        skips: List[Tuple[int, int]] = []
-        for b in range(self.down_blocks):
+        stem_out: Optional[Tuple[int, int]] = None
+        for b in range(sb):  # StemBlock (encoder_decoder.py:144-225): 7x7 convs (stem_kernel_size is never configured, unet.py:51), pool, ...
             bf = int(f * (r**b))
             if b > 0:
-                dst = self._new_slot()
-                self.ops.append(OpSpec(L.OP_POOL, cur, -1, dst, cur_c, label=f"stack0_enc{b}_pool"))
-                cur = dst
+                cur = self._pool(cur, cur_c, f"stem{b}_pool")
+            for i in range(self.convs_per_block):
+                cur = self._conv(f"backbone.stem.stem_stack.{b}.blocks.stem{b}_conv{i}", cur, cur_c, bf, first=(b == 0 and i == 0), k=7)
+                cur_c = bf
+        if sb > 0:
+            cur = self._pool(cur, cur_c, f"stem{sb}_last_pool")
+            stem_out = (cur, cur_c)
+        skips: List[Tuple[int, int]] = []
+        for b in range(self.down_blocks):
+            bf = int(f * (r ** (b + sb)))
+            if b + sb > 0:
+                cur = self._pool(cur, cur_c, f"stack0_enc{b}_pool")
             for i in range(self.convs_per_block):
                 name = f"backbone.encoders.0.encoder_stack.{b}.blocks.stack0_enc{b}_conv{i}"
-                cur = self._conv(name, cur, cur_c, bf, first=(b == 0 and i == 0))
+                cur = self._conv(name, cur, cur_c, bf, first=(b + sb == 0 and i == 0))
                 cur_c = bf
             skips.append((cur, cur_c))
-        dst = self._new_slot()
-        self.ops.append(OpSpec(L.OP_POOL, cur, -1, dst, cur_c, label=f"stack0_enc{self.down_blocks}_last_pool"))
-        cur = dst
+        cur = self._pool(cur, cur_c, f"stack0_enc{self.down_blocks}_last_pool")
         enc_num = self.down_blocks + 1
-        fmid = int(f * (r**self.down_blocks))
+        fmid = int(f * (r ** (self.down_blocks + sb)))
         mb = 0
         if self.middle_block:
             if self.convs_per_block > 1:
@@ -148,11 +162,15 @@ class UNet:
             )
         self.middle_slot = cur
         x_in = fmid
-        stride = 2**self.down_blocks
+        # pools so far: one per encoder block but the very first conv block of the network, plus the final one; a stem adds its own
+        # final pool, so with a stem the deepest feature sits at 2 * max_stride (unet.py:178-191)
+        stride = 2 ** (self.down_blocks + sb + (1 if sb > 0 else 0))
         self.decoder_stride_to_filters = {stride: x_in}
         skips = skips[::-1]
+        if stem_out is not None:
+            skips.append(stem_out)  # unet.py:287-288: the stem output is the last decoder block's skip
         for b in range(self.up_blocks):
-            fout = int(f * (r ** max(0, self.down_blocks - 1 - b)))
+            fout = int(f * (r ** max(0, self.down_blocks + sb - 1 - b)))
             nxt = stride // 2
             pfx = f"backbone.decoders.0.decoder_stack.{b}.blocks.stack0_dec{b}_s{stride}_to_s{nxt}"
             dst = self._new_slot()
@@ -181,4 +199,4 @@ class UNet:
 
     @property
     def max_channels(self) -> int:
-        return int(self.filters * (self.filters_rate**self.down_blocks))
+        return int(self.filters * (self.filters_rate ** (self.down_blocks + self.stem_blocks)))

@@ -250,6 +250,8 @@ int launch_layernorm(const float* src, const float* gamma, const float* beta, fl
 //             grid, rows = input pixels, results scattered to output pixel (2y + py, 2x + px) (encoder_decoder.py:439-461);
 //             the four phases together do 9 taps per input pixel = 2.25 per output pixel, no zero-stuffed tensor.
 //     mode 4  Conv2d 3x3 stride 2 pad 1 (the data gradient of that transposed conv): 9 taps gathered from a 2H x 2W map.
+//     mode 5  Conv2d k x k "same", odd k <= 9 (kernel_size 5 / 7 backbones, the 7x7 convs of a UNet stem block,
+//             encoder_decoder.py:144-225): k^2 taps, validity computed per tap from the row's (y, x).
 //   512 threads = 8 waves, tile 256 rows x BN columns (BN = 32 * NT_TOTAL); waves are arranged
 //   (8 / WN) x WN and each owns WN 32-row tiles x (NT_TOTAL / WN) 32-column tiles.
 //   Pipeline: a ring of three LDS stages of 16 K-values each (256 x 16 A slice + BN x 16 weight
@@ -274,7 +276,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void gemm_mfma_dma_tile_kernel(G
   constexpr int STAGE_FLOATS = (A_PIECES + B_PIECES) * 256;
   static_assert((NSTAGE - 2) * NDMA < 64 && NSTAGE >= 2 && WAVES % 2 == 0, "vmcnt field overflow / odd wave count");
   constexpr int NTAPS_C = MODE == 0 ? 1 : (MODE == 1 ? 4 : 9);
-  const int NTAPS = MODE == 3 ? a.ntaps : NTAPS_C;  // mode 3: 1, 2 or 4 taps, by output phase
+  const int NTAPS = MODE == 3 ? a.ntaps : (MODE == 5 ? a.ksize * a.ksize : NTAPS_C);  // mode 3: 1, 2 or 4 taps by output phase; mode 5: k x k
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -306,12 +308,13 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void gemm_mfma_dma_tile_kernel(G
   // arithmetic, DMA issue and MFMAs.
   const int dr = lane & 7, dquad = (lane >> 3) ^ (wave & 1);  // p & 1 == wave & 1 (WAVES is even)
   unsigned long long a_base[2][A_SLOTS];  // byte address of (row's pixel, channel quad dquad) in each source
-  unsigned a_mask[A_SLOTS];
+  unsigned a_mask[A_SLOTS];               // mode 5: (y << 16) | x of the row's pixel instead of a tap mask (k x k taps do not fit 32 bits)
 #pragma unroll
   for (int s = 0; s < A_SLOTS; ++s) {
     const int row = min(m0 + min(wave + WAVES * s, A_PIECES - 1) * 8 + dr, a.M - 1);
     unsigned mask = 0x1ffu;
     long long pix = row;
+    if (MODE == 5) mask = ((unsigned)((row / a.W) % a.H) << 16) | (unsigned)(row % a.W);
     if (MODE == 1) {
       const int ow = a.W >> 1, oh = a.H >> 1;
       const int ox = row % ow;
@@ -359,11 +362,14 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void gemm_mfma_dma_tile_kernel(G
   const unsigned long long w_lane = (unsigned long long)(wbase + lane * 4);
   // fetch cursor (wave-uniform scalars): index of the next stage, its tap, channel offset, source
   int f_idx = 0, f_tap = 0, f_coff = 0, f_src = 0;
+  int f_ty = 0, f_tx = 0;  // mode 5: the tap's kernel row / column
   auto issue_stage = [&](float* buf) {
     const int cp = f_src ? a.c1p : a.c0p;
     int toff;  // pixel offset of the tap
     if (MODE == 0) {
       toff = 0;
+    } else if (MODE == 5) {
+      toff = (f_ty - (a.ksize >> 1)) * a.W + (f_tx - (a.ksize >> 1));
     } else if (MODE == 1) {
       toff = (f_tap >> 1) * a.W + (f_tap & 1);
     } else if (MODE == 3) {
@@ -380,7 +386,14 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void gemm_mfma_dma_tile_kernel(G
 #pragma unroll
     for (int k = 0; k < A_SLOTS; ++k) {
       const unsigned long long real = (f_src ? a_base[1][k] : a_base[0][k]) + (unsigned long long)soff;
-      const unsigned long long sel = 0ull - (unsigned long long)(live & (a_mask[k] >> f_tap) & 1u);
+      unsigned tap_ok;
+      if (MODE == 5) {
+        const int yy = (int)(a_mask[k] >> 16) + f_ty - (a.ksize >> 1), xx = (int)(a_mask[k] & 0xffffu) + f_tx - (a.ksize >> 1);
+        tap_ok = ((unsigned)yy < (unsigned)a.H) & ((unsigned)xx < (unsigned)a.W) ? 1u : 0u;
+      } else {
+        tap_ok = (a_mask[k] >> f_tap) & 1u;
+      }
+      const unsigned long long sel = 0ull - (unsigned long long)(live & tap_ok);
       const unsigned long long g = (real & sel) | (zero_addr & ~sel);
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                        (__attribute__((address_space(3))) void*)(buf + min(wave + WAVES * k, A_PIECES - 1) * 256), 16, 0, 0);
@@ -395,6 +408,11 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void gemm_mfma_dma_tile_kernel(G
     // advance (integer arithmetic only): taps innermost, then 32-channel slices, then the second source
     f_idx += 1;
     const int wrap = (f_tap + 1 == NTAPS) ? 1 : 0;
+    if (MODE == 5) {
+      const int xw = (f_tx + 1 == a.ksize) ? 1 : 0;
+      f_tx = (f_tx + 1) * (1 - xw);
+      f_ty = (f_ty + xw) * (1 - wrap);
+    }
     f_tap = (f_tap + 1) * (1 - wrap);
     f_coff += 32 * wrap;
     const int sw = wrap & (f_coff >= cp ? 1 : 0) & (f_src == 0 ? 1 : 0) & (a.c1p > 0 ? 1 : 0);
@@ -936,6 +954,8 @@ int prepare_convnext_kernels() {
                                    (int)GemmCfg<MT, NTW, WM, WN, S, W>::LDS));                                                              \
   PH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mfma_dma_tile_kernel<4, MT, NTW, WM, WN, S, W>), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                    (int)GemmCfg<MT, NTW, WM, WN, S, W>::LDS));                                                              \
+  PH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mfma_dma_tile_kernel<5, MT, NTW, WM, WN, S, W>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                   (int)GemmCfg<MT, NTW, WM, WN, S, W>::LDS));                                                              \
   PH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mfma_dma_kernel<2, MT, NTW, WM, WN, S, W>), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                    (int)GemmCfg<MT, NTW, WM, WN, S, W>::LDS));                                                              \
   PH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mfma_dma_kernel<0, MT, NTW, WM, WN, S, W, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, \
@@ -958,7 +978,8 @@ int gemm_variant_bn(int variant) {
 int launch_gemm_variant(int variant, const GemmArgs& a_in, hipStream_t s) {
   GemmArgs a = a_in;
   const int persist2 = a.persist2;  // handle option: persistent workgroups for the 9-tap mode too (measured 3-4 % slower than one tile per workgroup)
-  PH_REQUIRE(a.M > 0 && a.c0p > 0 && a.c0p % 16 == 0 && a.c1p % 16 == 0 && a.coutp % 16 == 0 && a.mode >= 0 && a.mode <= 4, "launch_gemm: bad shape");
+  PH_REQUIRE(a.M > 0 && a.c0p > 0 && a.c0p % 16 == 0 && a.c1p % 16 == 0 && a.coutp % 16 == 0 && a.mode >= 0 && a.mode <= 5, "launch_gemm: bad shape");
+  PH_REQUIRE(a.mode != 5 || ((a.ksize & 1) && a.ksize >= 1 && a.ksize <= 9 && a.M % (a.H * a.W) == 0 && a.H < 65536 && a.W < 65536), "launch_gemm: k x k conv needs an odd kernel <= 9 and whole images");
   PH_REQUIRE(a.mode != 3 || ((a.ntaps == 1 || a.ntaps == 2 || a.ntaps == 4) && a.ntaps == (1 + (a.out_tap >> 1)) * (1 + (a.out_tap & 1)) && a.out_patch && a.M % (a.H * a.W) == 0),
              "launch_gemm: transposed-conv phase needs ntaps matching the phase, out_patch and whole images");
   PH_REQUIRE(a.mode != 4 || (a.H % 2 == 0 && a.W % 2 == 0 && a.M % ((a.H / 2) * (a.W / 2)) == 0), "launch_gemm: stride-2 gather needs even map sizes and whole images");
@@ -994,6 +1015,8 @@ int launch_gemm_variant(int variant, const GemmArgs& a_in, hipStream_t s) {
         hipLaunchKernelGGL((gemm_mfma_dma_tile_kernel<2, MT, NTW, WM, WN, S, W>), full, dim3(C::THREADS), C::LDS, s, a);       \
       else if (a.mode == 3)                                                                                                    \
         hipLaunchKernelGGL((gemm_mfma_dma_tile_kernel<3, MT, NTW, WM, WN, S, W>), full, dim3(C::THREADS), C::LDS, s, a);       \
+      else if (a.mode == 5)                                                                                                    \
+        hipLaunchKernelGGL((gemm_mfma_dma_tile_kernel<5, MT, NTW, WM, WN, S, W>), full, dim3(C::THREADS), C::LDS, s, a);       \
       else                                                                                                                     \
         hipLaunchKernelGGL((gemm_mfma_dma_tile_kernel<4, MT, NTW, WM, WN, S, W>), full, dim3(C::THREADS), C::LDS, s, a);       \
     }                                                                                                                          \

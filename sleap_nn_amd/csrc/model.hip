@@ -456,7 +456,18 @@ ph_model* ph_model_create(const ph_op_desc* ops, int32_t n_ops, const float* con
       case PH_OP_CONVT: {
         if (!widx_ok(d.weight) || !widx_ok(d.bias)) return fail("weight index out of range", i);
         if (weight_numel[d.bias] != d.cout) return fail("bias size mismatch", i);
-        if (d.ksize != 3) return fail("only kernel_size 3 is supported by the MFMA convolution", i);
+        if (d.kind == PH_OP_CONVT && d.ksize != 3) return fail("transposed conv: only kernel 3 (stride 2, padding 1, output padding 1)", i);
+        if (d.ksize != 3) {
+          // kernel_size 5 / 7 / 9 (and the 7x7 convs of a stem block): k x k "same" conv as a k^2-tap row GEMM (mode 5); inference only
+          if (!(d.ksize & 1) || d.ksize < 1 || d.ksize > 9) return fail("kernel_size must be odd and <= 9", i);
+          if (weight_numel[d.weight] != (int64_t)(d.cin0 + d.cin1) * d.cout * d.ksize * d.ksize) return fail("weight size mismatch", i);
+          const int coutp_k = pad16(d.cout);
+          op.bn_g = gemm_choose_bn(coutp_k);
+          auto pack_k = [&](const auto* w, auto& out) { pack_gemm(w, d.cout, d.cin0, d.cin1, d.ksize * d.ksize, op.bn_g, out); };
+          ok = pack_upload(m, pack_k, weights[d.weight], index_array(d.weight), &op.w_gemm_dev) == PH_OK &&
+               pack_upload(m, pad_vec((size_t)((coutp_k + op.bn_g - 1) / op.bn_g) * op.bn_g, d.cout), weights[d.bias], index_array(d.bias), &op.b_gemm_dev) == PH_OK;
+          break;
+        }
         if (d.kind == PH_OP_CONVT && d.cin1 != 0) return fail("transposed conv takes one source", i);
         if (weight_numel[d.weight] != (int64_t)(d.cin0 + d.cin1) * d.cout * 9) return fail("weight size mismatch", i);
         const int coutp = pad16(d.cout);
@@ -575,7 +586,7 @@ ph_model* ph_model_create(const ph_op_desc* ops, int32_t n_ops, const float* con
         // [tap][ci][Cp] from OIHW (cout, cin, k, k); the patch stem (k x k, stride = cmid, padding 1) shares the layout
         if (!widx_ok(d.weight) || !widx_ok(d.bias)) return fail("weight index out of range", i);
         if (weight_numel[d.bias] != d.cout) return fail("bias size mismatch", i);
-        if (d.kind == PH_OP_INPUT_CONV && d.ksize != 3) return fail("only kernel_size 3 is supported", i);
+        if (d.kind == PH_OP_INPUT_CONV && (!(d.ksize & 1) || d.ksize < 1 || d.ksize > 9)) return fail("kernel_size must be odd and <= 9", i);
         if (d.kind == PH_OP_PATCH_STEM && (d.ksize < 2 || d.ksize > 8 || d.cmid < 1 || d.cmid > d.ksize)) return fail("patch stem needs 2 <= kernel <= 8 and 1 <= stride <= kernel", i);
         const int kk = d.ksize * d.ksize;
         if (weight_numel[d.weight] != (int64_t)d.cin0 * d.cout * kk) return fail("weight size mismatch", i);
@@ -766,6 +777,7 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
         a.H = height;
         a.W = width;
         a.relu = (d.flags & PH_FLAG_RELU) ? 1 : 0;
+        a.ksize = d.ksize;
         a.out_fmt = fmt;
         a.dst_cp = plan.slots[d.dst].cp;
         rc = launch_input_conv(a, s);
@@ -822,6 +834,30 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
           f.zeros = m->zeros_dev;
           f.clock_probe = m->clock_probe ? m->clock_probe + 2 * 1024 * (op_index - 1) : nullptr;  // one 1024-workgroup record block per op
           rc = launch_conv3x3_f16(f, s);
+          break;
+        }
+        if (d.ksize != 3) {  // k x k "same" conv: k^2-tap row GEMM
+          PH_REQUIRE(s0.c == d.cin0 && (d.src1 < 0 || plan.slots[d.src1].c == d.cin1), "conv channel mismatch");
+          GemmArgs g{};
+          g.src0 = slot_ptr(d.src0);
+          g.c0p = s0.cp;
+          g.src1 = d.src1 >= 0 ? slot_ptr(d.src1) : nullptr;
+          g.c1p = d.src1 >= 0 ? plan.slots[d.src1].cp : 0;
+          g.wpack = op.w_gemm_dev;
+          g.bias = op.b_gemm_dev;
+          g.dst = slot_ptr(d.dst);
+          g.zeros = m->zeros_dev;
+          g.coutp = pad16(d.cout);
+          g.bn = op.bn_g;
+          g.M = batch * s0.h * s0.w;
+          g.mode = 5;
+          g.ksize = d.ksize;
+          g.H = s0.h;
+          g.W = s0.w;
+          g.act = (d.flags & PH_FLAG_RELU) ? 1 : 0;
+          g.late_split = m->gemm_late_split;
+          rc = launch_gemm(g, s);
+          if (rc == PH_OK && d.dst2 >= 0) rc = launch_pool(slot_ptr(d.dst), slot_ptr(d.dst2), batch, s0.h, s0.w, g.coutp, s);  // the fused-pool flag of the plan, unfused here
           break;
         }
         ConvArgs a{};

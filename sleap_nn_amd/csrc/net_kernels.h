@@ -38,6 +38,7 @@ struct InputConvArgs {
   void* dst;        // NHWC coutp (format out_fmt)
   int dtype;        // 0 u8 (/255), 1 f32 as-is, 2 f32 (/255)
   int cin, coutp, B, H, W, relu;
+  int ksize = 3;    // odd kernel size, "same" padding; weights [tap k*k][cin][coutp]
   int out_fmt = 0;  // ActFmt of dst (act_format.h)
   int dst_cp = 0;   // padded channels of dst in its format (FMT_F16 pads to 32)
 };
@@ -84,7 +85,7 @@ struct GemmArgs {
   const float* zeros = nullptr;     // >= 64 B of zeros in HBM
   int c0p = 0, c1p = 0, coutp = 0, bn = 0;
   int M = 0;                        // output rows
-  int mode = 0;                     // 0: row = pixel (Linear); 1: 2x2/stride-2 patches; 2: 3x3 "same" conv; 3: transposed-conv phase; 4: 3x3 stride-2 gather
+  int mode = 0;                     // 0: row = pixel (Linear); 1: 2x2/stride-2 patches; 2: 3x3 "same" conv; 3: transposed-conv phase; 4: 3x3 stride-2 gather; 5: k x k "same" conv
   int H = 0, W = 0;                 // input spatial size (modes 1, 2)
   int act = 0;                      // 0 none, 1 ReLU, 2 GELU, 3 multiply by GELU'(aux) (Linear modes only), 4 SiLU (modes 3, 4)
   float* dst_pre = nullptr;         // optional second output (M, coutp): the value before the activation (training keeps it)
@@ -93,6 +94,7 @@ struct GemmArgs {
   int late_split = 0;               // which waves issue their DMA pieces one step late (see gemm_mfma_dma_kernel)
   int persist2 = 0;                 // persistent workgroups for the 9-tap mode too (handle option "gemm_persist2")
   int ntaps = 0;                    // mode 3: taps of this output phase (1, 2 or 4)
+  int ksize = 0;                    // mode 5: odd kernel size (k x k "same" conv)
   const float* shift = nullptr;     // modes 3, 4 with affine_first: per-channel shift (folded BatchNorm), padded like bias
   int affine_first = 0;             // modes 3, 4: dst = act(scale * (acc + bias) + shift) instead of act(acc + bias) * scale
   // output row mapping: 0 = row m; 1 = row m is output pixel (b, oy, ox) of a 2x2/stride-2 conv and the result is

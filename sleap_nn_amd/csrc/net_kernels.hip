@@ -1583,15 +1583,14 @@ __global__ __launch_bounds__(256) void input_conv3x3_kernel(InputConvArgs a) {
     const int y = (int)(p % a.H);
     const int b = (int)(p / a.H);
     f32x4 acc = *reinterpret_cast<const f32x4*>(a.bias + gq * 4);
+    const int k = a.ksize, kh = a.ksize >> 1;
     for (int ci = 0; ci < a.cin; ++ci) {
       const size_t plane = ((size_t)b * a.cin + ci) * a.H * a.W;
-#pragma unroll
-      for (int ky = 0; ky < 3; ++ky) {
-        const int yy = y + ky - 1;
+      for (int ky = 0; ky < k; ++ky) {
+        const int yy = y + ky - kh;
         if (yy < 0 || yy >= a.H) continue;
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-          const int xx = x + kx - 1;
+        for (int kx = 0; kx < k; ++kx) {
+          const int xx = x + kx - kh;
           if (xx < 0 || xx >= a.W) continue;
           float v;
           if (a.dtype == 0)
@@ -1600,7 +1599,7 @@ __global__ __launch_bounds__(256) void input_conv3x3_kernel(InputConvArgs a) {
             v = reinterpret_cast<const float*>(a.src)[plane + (size_t)yy * a.W + xx];
             if (a.dtype == 2) v = v / 255.0f;
           }
-          const f32x4 w = *reinterpret_cast<const f32x4*>(a.w + ((size_t)(ky * 3 + kx) * a.cin + ci) * a.coutp + gq * 4);
+          const f32x4 w = *reinterpret_cast<const f32x4*>(a.w + ((size_t)(ky * k + kx) * a.cin + ci) * a.coutp + gq * 4);
           acc += v * w;
         }
       }

@@ -31,6 +31,10 @@ int build_bwd_plan(const ph_model* m, int B, int H, int W, BwdPlan& bp) {
       set_error("backward needs the unfused program (no stem / conv+pool fusion)");
       return PH_E_INVALID;
     }
+    if ((d.kind == PH_OP_CONV || d.kind == PH_OP_INPUT_CONV) && d.ksize != 3) {
+      set_error("backward supports kernel_size 3 only (kernel_size %d and stem blocks are inference-only)", d.ksize);
+      return PH_E_INVALID;
+    }
     if (d.kind == PH_OP_CONVT) {
       if (!op.wt_dgrad_dev || op.wt_scale_dev || (d.flags & PH_FLAG_SILU)) {
         set_error("backward of a transposed conv supports bias + ReLU (the reference's decoder); folded BatchNorm / SiLU are inference-only");

@@ -97,6 +97,27 @@ def test_unet_without_middle_block_follows_the_reference_contract():
         UNet.from_config({**base, "filters_rate": 2})
 
 
+def test_unet_with_stem_block_and_wide_kernels_follows_the_reference_structure():
+    """stem_stride 2 (StemBlock, encoder_decoder.py:144-225): 7x7 stem convs, reference parameter names and shapes (taken from the
+    golden the reference Model produced), the deepest feature at 2 x max_stride, the stem output as the last skip; kernel_size 5;
+    stem_stride 4 is refused like the reference's forward refuses it."""
+    from sleap_nn_amd.architectures.model import Model
+    from sleap_nn_amd.architectures.unet import UNet
+
+    for name in ("unet_tiny_stem.npz", "unet_tiny_k5.npz"):
+        z = G.load(name)
+        cfg = G.config(z)
+        m = Model("unet", cfg["backbone"], cfg["heads"], cfg["model_type"])
+        want = {k[2:]: tuple(z[k].shape) for k in z.files if k.startswith("w/")}
+        assert {k: tuple(v) for k, v in m.param_shapes.items()} == want
+        m.load_state_dict(G.weights(z), strict=True)
+    stem = UNet.from_config(G.config(G.load("unet_tiny_stem.npz"))["backbone"])
+    assert sorted(stem.decoder_stride_to_filters) == [2, 4, 8, 16] and stem.decoder_stride_to_filters[16] == 27 and stem.max_channels == 27
+    assert sum(1 for o in stem.ops if o.ksize == 7 and o.kind in (L.OP_CONV, L.OP_INPUT_CONV)) == 2
+    with pytest.raises(ValueError, match="stem_stride"):
+        UNet.from_config({"in_channels": 1, "kernel_size": 3, "filters": 8, "filters_rate": 1.5, "max_stride": 16, "stem_stride": 4, "output_stride": 4})
+
+
 def test_product_does_not_import_oracle():
     for dp, _, files in os.walk(os.path.join(ROOT, "sleap_nn_amd")):
         for f in files:
