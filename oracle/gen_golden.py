@@ -246,6 +246,67 @@ def paf_fixture():
     save("paf.npz", **arrs)
 
 
+def evaluation_fixture():
+    """Pose metrics of the reference (sleap_nn/evaluation.py) on random frames: compute_oks, match_instances / compute_dists through
+    duck-typed frames (the functions only touch .instances / .numpy() / .score / .frame_idx), and the Evaluator's own
+    voc_metrics / mOKS / distance_metrics / pck_metrics methods on those matches."""
+    import importlib
+
+    ev = importlib.import_module("sleap_nn.evaluation")
+
+    class Inst:
+        def __init__(self, pts, score=None):
+            self._p = pts
+            if score is not None:
+                self.score = score
+
+        def numpy(self):
+            return self._p
+
+    class Frame:
+        def __init__(self, idx, insts):
+            self.frame_idx, self.instances, self.video = idx, insts, None
+
+    rng = np.random.RandomState(12)
+    arrs = {}
+    n_frames, N = 12, 7
+    pairs = []
+    for f in range(n_frames):
+        n_gt = rng.randint(1, 5)
+        gt = rng.uniform(20, 300, size=(n_gt, 1, 2)) + rng.normal(0, 25, size=(n_gt, N, 2))
+        gt[rng.rand(n_gt, N) < 0.1] = np.nan
+        n_pr = max(1, n_gt + rng.randint(-1, 2))
+        pr = np.stack([gt[i % n_gt] + rng.normal(0, [0.5, 2.0, 6.0][rng.randint(3)], size=(N, 2)) for i in range(n_pr)])
+        pr[rng.rand(n_pr, N) < 0.08] = np.nan
+        if f == 3:
+            pr[0] = gt[0] + 400  # a far-off prediction: no match above the threshold
+        scores = rng.uniform(0.2, 1.0, size=n_pr)
+        gt, pr = gt.astype(np.float32), pr.astype(np.float32)
+        arrs[f"f{f}/gt"], arrs[f"f{f}/pr"], arrs[f"f{f}/scores"] = gt, pr, scores
+        # one prediction at a time: the reference masks invisible ground truth with a (n_gt, 1, n_nodes) boolean index, which only
+        # fits n_pr == 1 -- the way match_instances calls it
+        arrs[f"f{f}/oks"] = np.concatenate([ev.compute_oks(gt, pr[j : j + 1]) for j in range(n_pr)], axis=1)
+        arrs[f"f{f}/oks_paper"] = np.concatenate([ev.compute_oks(gt, pr[j : j + 1], use_cocoeval=False, stddev=0.05, scale=900.0) for j in range(n_pr)], axis=1)
+        pairs.append((Frame(f, [Inst(g) for g in gt]), Frame(f, [Inst(p, float(s)) for p, s in zip(pr, scores)])))
+    arrs["n_frames"] = np.array(n_frames)
+    E = ev.Evaluator.__new__(ev.Evaluator)
+    E.positive_pairs, E.false_negatives = ev.match_frame_pairs(pairs, stddev=0.025, scale=None, threshold=0)
+    E.dists_dict = ev.compute_dists(E.positive_pairs)
+    arrs["pair_oks"] = np.array([o for _, _, o in E.positive_pairs])
+    arrs["n_false_negatives"] = np.array(len(E.false_negatives))
+    arrs["dists"] = E.dists_dict["dists"]
+    voc = E.voc_metrics()
+    for k in ("oks_voc.AP", "oks_voc.AR", "oks_voc.mAP", "oks_voc.mAR", "oks_voc.precisions", "oks_voc.match_scores"):
+        arrs["voc/" + k] = np.asarray(voc[k])
+    arrs["mOKS"] = np.array(E.mOKS()["mOKS"])
+    dm = E.distance_metrics()
+    arrs["dist/summary"] = np.array([dm[k] for k in ("avg", "p50", "p75", "p90", "p95", "p99")])
+    pk = E.pck_metrics()
+    arrs["pck/summary"] = np.array([pk["mPCK"], pk["PCK@5"], pk["PCK@10"]])
+    arrs["pck/mPCK_parts"] = pk["mPCK_parts"]
+    save("evaluation.npz", **arrs)
+
+
 def stem_and_kernel_fixtures():
     """UNet variants outside the hot-path configs that a reference checkpoint may use: a stem block (stem_stride 2: 7x7 stem convs,
     the deepest feature at 2 x max_stride, the stem output as the last skip) and kernel_size 5."""
@@ -724,6 +785,8 @@ if __name__ == "__main__":
         losses_fixture()
     if not only or "stem" in only:
         stem_and_kernel_fixtures()
+    if not only or "evaluation" in only:
+        evaluation_fixture()
     if not only or "schedulers" in only:
         schedulers_fixture()
     if not only or "core" in only:

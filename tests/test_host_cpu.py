@@ -118,6 +118,52 @@ def test_unet_with_stem_block_and_wide_kernels_follows_the_reference_structure()
         UNet.from_config({"in_channels": 1, "kernel_size": 3, "filters": 8, "filters_rate": 1.5, "max_stride": 16, "stem_stride": 4, "output_stride": 4})
 
 
+def test_evaluation_metrics_match_reference():
+    """evaluation.npz: the reference's compute_oks (both normalisations), its greedy instance matching and the Evaluator's
+    VOC / OKS / distance / PCK metrics on 12 random frames (missing points, a far-off prediction, fewer / more predictions than
+    ground truth); then the epoch-end hook on the same data handed over batch-wise in preprocessed coordinates."""
+    from sleap_nn_amd.evaluation import EpochEndEvaluator, Evaluator, compute_oks
+    from sleap_nn_amd.inference.outputs import Outputs
+
+    z = G.load("evaluation.npz")
+    n = int(z["n_frames"])
+    gts, prs, scs = [z[f"f{f}/gt"] for f in range(n)], [z[f"f{f}/pr"] for f in range(n)], [z[f"f{f}/scores"] for f in range(n)]
+    for f in range(n):
+        assert np.allclose(compute_oks(gts[f], prs[f]), z[f"f{f}/oks"], rtol=1e-6, atol=1e-12)
+        assert np.allclose(compute_oks(gts[f], prs[f], use_cocoeval=False, stddev=0.05, scale=900.0), z[f"f{f}/oks_paper"], rtol=1e-6, atol=1e-12)
+    E = Evaluator(gts, prs, scs)
+    assert np.allclose(E.pair_oks, z["pair_oks"], rtol=1e-6) and E.n_false_negatives == int(z["n_false_negatives"])
+    assert np.allclose(E.dists, z["dists"], rtol=1e-6, equal_nan=True)
+    m = E.evaluate()
+    for k in ("oks_voc.AP", "oks_voc.AR", "oks_voc.mAP", "oks_voc.mAR", "oks_voc.precisions", "oks_voc.match_scores"):
+        assert np.allclose(m["voc_metrics"][k], z["voc/" + k], rtol=1e-6), k
+    assert abs(m["mOKS"]["mOKS"] - float(z["mOKS"])) < 1e-7
+    assert np.allclose([m["distance_metrics"][k] for k in ("avg", "p50", "p75", "p90", "p95", "p99")], z["dist/summary"], rtol=1e-6)
+    assert np.allclose([m["pck_metrics"][k] for k in ("mPCK", "PCK@5", "PCK@10")], z["pck/summary"], rtol=1e-6)
+    assert np.allclose(m["pck_metrics"]["mPCK_parts"], z["pck/mPCK_parts"], rtol=1e-6)
+    # epoch-end hook: batches of 4 frames, NaN-padded to a common instance count, ground truth in preprocessed space (x eff_scale)
+    hook, hook1 = EpochEndEvaluator(eval_frequency=2), EpochEndEvaluator(eval_frequency=1)
+    N = gts[0].shape[1]
+    for lo in range(0, n, 4):
+        idx = list(range(lo, min(lo + 4, n)))
+        mi = max(max(len(prs[f]) for f in idx), max(len(gts[f]) for f in idx))
+        kp = np.full((len(idx), mi, N, 2), np.nan, np.float32)
+        vals = np.full((len(idx), mi, N), np.nan, np.float32)
+        gt = np.full((len(idx), 1, mi, N, 2), np.nan, np.float32)
+        eff = np.array([0.5, 1.0, 2.0, 0.75][: len(idx)], np.float32)
+        for j, f in enumerate(idx):
+            kp[j, : len(prs[f])] = prs[f]
+            vals[j, : len(prs[f])] = scs[f][:, None]  # every node carries the instance score: its nan-mean is that score again
+            gt[j, 0, : len(gts[f])] = gts[f] * eff[j]
+        for h in (hook, hook1):
+            h.add_batch(Outputs(pred_keypoints=torch.from_numpy(kp), pred_peak_values=torch.from_numpy(vals)), gt, eff, [len(gts[f]) for f in idx])
+    assert hook.compute(epoch=0) is None  # eval_frequency 2: epoch 0 is skipped and the lists are cleared
+    assert hook.compute(epoch=1) is None and not hook._pred
+    m1 = hook1.compute(epoch=0)
+    assert abs(m1["mOKS"]["mOKS"] - float(z["mOKS"])) < 1e-5 and abs(m1["voc_metrics"]["oks_voc.mAP"] - float(z["voc/oks_voc.mAP"])) < 1e-6
+    assert np.allclose([m1["pck_metrics"][k] for k in ("mPCK", "PCK@5", "PCK@10")], z["pck/summary"], atol=1e-6)
+
+
 def test_product_does_not_import_oracle():
     for dp, _, files in os.walk(os.path.join(ROOT, "sleap_nn_amd")):
         for f in files:
