@@ -489,42 +489,88 @@ __global__ __launch_bounds__(256) void pool2x2_fmt_kernel(const void* __restrict
   }
 }
 
-// 1x1 head convolution, activations in FMT -> NCHW fp32 (+ optional sigmoid); same tiling as head1x1_kernel (net_kernels.hip)
-template <int FMT>
-__global__ __launch_bounds__(256) void head1x1_fmt_kernel(const void* __restrict__ src, const float* __restrict__ w /* [cout][wcp] */, const float* __restrict__ bias,
-                                                          float* __restrict__ dst, int B, int HW, int cp, int wcp, int cout, int sigmoid) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* sa = lds;                    // 64 x (cp + 1)
-  float* sw = lds + 64 * (cp + 1);    // cout x wcp
-  const size_t npix = (size_t)B * HW;
-  const size_t p0 = (size_t)blockIdx.x * 64;
-  for (int i = threadIdx.x; i < cout * wcp; i += 256) sw[i] = w[i];
-  const int groups = cp >> 3;
-  for (int i = threadIdx.x; i < 64 * groups; i += 256) {
-    const int pp = i / groups, g = i - pp * groups;
-    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (p0 + pp < npix) load8<FMT>(src, p0 + pp, cp, g, v);
-#pragma unroll
-    for (int k = 0; k < 8; ++k) sa[pp * (cp + 1) + 8 * g + k] = v[k];
+// 1x1 head convolution on the fp32 matrix pipe (exact fp32 products whatever the activation format), activations in FMT ->
+// NCHW fp32 (+ optional sigmoid) (architectures/heads.py:58-67).  Transposed product D[channel][pixel] = sum_c W[channel][c]
+// X[pixel][c]: the weights (A operand) sit in LDS, a lane's B operand is 16 B of "its" pixel (channels 8g + 4 lh .. + 3) read
+// straight from the activation tensor -- every 128-B line of a pixel is touched by four consecutive K groups of the same
+// lanes, L1 hits -- and the result lands with a lane per pixel and a register per channel: each register is stored as 32
+// consecutive floats of one NCHW channel plane.  HBM-bound: Cp * bytes/channel read + Cout * 4 B written per pixel.
+//   256 threads = 4 waves; a wave owns 64 pixels (two 32-pixel N tiles) per trip and all ceil(cout / 32) M tiles.
+template <int FMT, int MT>
+__global__ __launch_bounds__(256) void head1x1_mfma_kernel(const void* __restrict__ src, const float* __restrict__ w /* [cout][wcp] */, const float* __restrict__ bias,
+                                                           float* __restrict__ dst, int B, int HW, int cp, int wcp, int cout, int sigmoid) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // MT * 32 rows x (wcp + 4): the row pad keeps the b128 fragment reads conflict-free
+  const int ldw = wcp + 4;
+  for (int i = threadIdx.x; i < MT * 32 * (wcp / 4); i += 256) {
+    const int row = i / (wcp / 4), q = i - row * (wcp / 4);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (row < cout) v = *reinterpret_cast<const f32x4*>(w + (size_t)row * wcp + q * 4);
+    *reinterpret_cast<f32x4*>(lds + row * ldw + q * 4) = v;
   }
   __syncthreads();
-  const int pp = threadIdx.x & 63, j0 = threadIdx.x >> 6;
-  const size_t p = p0 + pp;
-  if (p >= npix) return;
-  const size_t b = p / HW, hw = p - b * HW;
-  const float* ar = sa + pp * (cp + 1);
-  for (int j = j0; j < cout; j += 4) {  // wave-uniform j
-    float accv = bias[j];
-    const float* wr = sw + j * wcp;
-    for (int c = 0; c < wcp; c += 4) {
-      const f32x4 wv = *reinterpret_cast<const f32x4*>(wr + c);
-      accv += ar[c] * wv[0];
-      accv += ar[c + 1] * wv[1];
-      accv += ar[c + 2] * wv[2];
-      accv += ar[c + 3] * wv[3];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lx = lane & 31, lh = lane >> 5;
+  const size_t npix = (size_t)B * HW;
+  const size_t n_groups = (npix + 63) / 64;
+  for (size_t grp = (size_t)blockIdx.x * 4 + wave; grp < n_groups; grp += (size_t)gridDim.x * 4) {
+    f32x16 acc[MT][2];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+    size_t pix[2];
+    bool ok[2];
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      pix[n] = grp * 64 + n * 32 + lx;
+      ok[n] = pix[n] < npix;
+      pix[n] = ok[n] ? pix[n] : npix - 1;
     }
-    if (sigmoid) accv = 1.f / (1.f + expf(-accv));
-    dst[(b * cout + j) * HW + hw] = accv;
+    for (int g = 0; g < wcp / 8; ++g) {
+      f32x4 xb[2];
+#pragma unroll
+      for (int n = 0; n < 2; ++n) {
+        const int c0 = 8 * g + 4 * lh;
+        if constexpr (FMT == FMT_F32) {
+          xb[n] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(src) + pix[n] * cp + c0);
+        } else if constexpr (FMT == FMT_SPLIT) {
+          const char* p = reinterpret_cast<const char*>(src) + (pix[n] * cp + (size_t)(c0 >> 4) * 16) * 4 + ((c0 >> 3) & 1) * 16 + (c0 & 7) * 2;
+          const f16x4 hi = *reinterpret_cast<const f16x4*>(p), lo = *reinterpret_cast<const f16x4*>(p + 32);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) xb[n][k] = (float)hi[k] + (float)lo[k] * SPLIT_INV;
+        } else {
+          const f16x4 h = *reinterpret_cast<const f16x4*>(reinterpret_cast<const char*>(src) + (pix[n] * cp + c0) * 2);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) xb[n][k] = (float)h[k];
+        }
+      }
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const f32x4 wa = *reinterpret_cast<const f32x4*>(lds + (m * 32 + lx) * ldw + 8 * g + 4 * lh);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int n = 0; n < 2; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[j], xb[n][j], acc[m][n], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      if (!ok[n]) continue;
+      const size_t b = pix[n] / HW, hw = pix[n] - b * HW;
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (co < cout) {
+            float v = acc[m][n][r] + bias[co];
+            if (sigmoid) v = 1.f / (1.f + expf(-v));
+            dst[(b * cout + co) * HW + hw] = v;
+          }
+        }
+    }
   }
 }
 
@@ -568,15 +614,28 @@ int launch_pool_fmt(int fmt, const void* src, void* dst, int B, int H, int W, in
 }
 
 int launch_head_fmt(int fmt, const void* src, const float* w, const float* bias, float* dst, int B, int HW, int cp, int wcp, int cout, int sigmoid, hipStream_t s) {
-  const size_t npix = (size_t)B * HW;
-  const size_t lds = (64 * (cp + 1) + (size_t)cout * wcp) * sizeof(float);
-  PH_REQUIRE(lds <= 160 * 1024, "head1x1: LDS tile too large (cp=%d cout=%d)", cp, cout);
-  PH_REQUIRE(wcp <= cp, "head1x1: weight rows wider than the activation rows");
-  const dim3 grid((unsigned)((npix + 63) / 64));
-  if (lds > 64 * 1024) {
-    PH_FMT_DISPATCH(fmt, PH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(head1x1_fmt_kernel<F>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)));
+  PH_REQUIRE(wcp % 8 == 0 && wcp <= cp && cout >= 1 && cout <= 128, "head1x1: unsupported shape (cp=%d, weight row=%d, cout=%d)", cp, wcp, cout);
+  const int mt = (cout + 31) / 32;
+  const size_t lds = (size_t)mt * 32 * (wcp + 4) * sizeof(float);
+  PH_REQUIRE(lds <= 160 * 1024, "head1x1: weights do not fit the LDS (cin=%d cout=%d)", wcp, cout);
+  const size_t n_groups = ((size_t)B * HW + 63) / 64;
+  const dim3 grid((unsigned)std::min<size_t>((n_groups + 3) / 4, 256 * 8));
+#define PH_HEAD_LAUNCH(F, M)                                                                                                              \
+  {                                                                                                                                       \
+    if (lds > 64 * 1024)                                                                                                                  \
+      PH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(head1x1_mfma_kernel<F, M>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    hipLaunchKernelGGL((head1x1_mfma_kernel<F, M>), grid, dim3(256), lds, s, src, w, bias, dst, B, HW, cp, wcp, cout, sigmoid);            \
   }
-  PH_FMT_DISPATCH(fmt, hipLaunchKernelGGL(head1x1_fmt_kernel<F>, grid, dim3(256), lds, s, src, w, bias, dst, B, HW, cp, wcp, cout, sigmoid));
+#define PH_HEAD_MT(F)                 \
+  switch (mt) {                       \
+    case 1: PH_HEAD_LAUNCH(F, 1) break; \
+    case 2: PH_HEAD_LAUNCH(F, 2) break; \
+    case 3: PH_HEAD_LAUNCH(F, 3) break; \
+    default: PH_HEAD_LAUNCH(F, 4) break; \
+  }
+  PH_FMT_DISPATCH(fmt, PH_HEAD_MT(F));
+#undef PH_HEAD_MT
+#undef PH_HEAD_LAUNCH
   PH_HIP_CHECK(hipGetLastError());
   return PH_OK;
 }

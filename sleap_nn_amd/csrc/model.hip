@@ -1115,10 +1115,8 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
         const SlotShape& s0 = plan.slots[d.src0];
         PH_REQUIRE(s0.c == d.cin0, "head channel mismatch");
         PH_REQUIRE(out_dev[d.out_index] != nullptr, "output %d is null", d.out_index);
-        rc = fmt == FMT_F32 ? launch_head(slot_ptr(d.src0), op.w_dev, op.b_dev, out_dev[d.out_index], batch, s0.h * s0.w, s0.cp, d.cout,
-                                          (d.flags & PH_FLAG_SIGMOID) ? 1 : 0, s)
-                            : launch_head_fmt(fmt, slot_ptr(d.src0), op.w_dev, op.b_dev, out_dev[d.out_index], batch, s0.h * s0.w, s0.cp, pad16(d.cin0), d.cout,
-                                              (d.flags & PH_FLAG_SIGMOID) ? 1 : 0, s);
+        rc = launch_head_fmt(fmt, slot_ptr(d.src0), op.w_dev, op.b_dev, out_dev[d.out_index], batch, s0.h * s0.w, s0.cp, pad16(d.cin0), d.cout,
+                             (d.flags & PH_FLAG_SIGMOID) ? 1 : 0, s);
         if (rc == PH_OK && (d.flags & PH_FLAG_SOFTMAX)) {
           PH_REQUIRE(s0.h == 1 && s0.w == 1, "softmax head expects a pooled (1x1) feature");
           rc = launch_softmax_rows(out_dev[d.out_index], batch, d.cout, s);
@@ -1154,6 +1152,7 @@ std::vector<OptionRef> option_table(ph_model* m) {
   return {
       {"conv_wino", &m->conv_wino, nullptr},            // 1 Winograd F(2,3) 3x3 kernels, 2 only N-tile-64 layers, 0 direct 9-tap kernels
       {"stem_wino", &m->stem_wino, nullptr},            // second conv of the fused stem in Winograd form
+      {"dgrad_wino", &m->dgrad_wino, nullptr},          // 0: direct 9-tap kernels for the backward's data-gradient convs
       {"conv_dma", &m->use_dma, nullptr},               // 0: register-staged 3x3 kernel instead of the LDS-DMA family
       {"conv_dma32", &m->dma32, nullptr},               // 0: Cout <= 48 layers on the register-staged kernel
       {"conv_persist", &m->conv_persist, nullptr},      // 0: one pixel tile per workgroup

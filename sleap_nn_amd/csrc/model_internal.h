@@ -100,6 +100,7 @@ struct ph_model {
   int use_dma = 1;                            // "conv_dma": 0 selects the register-staged 3x3 kernel
   int dma32 = 1;                              // "conv_dma32": Cout <= 48 layers on the LDS-DMA kernel (BN = 32) instead of the register-staged one
   int conv_wino = 1;                          // "conv_wino": Winograd F(2,3) 3x3 kernels (2: N-tile-64 layers only, 0: direct 9-tap kernels)
+  int dgrad_wino = 1;                         // "dgrad_wino": 0 = direct 9-tap kernels for the backward's data-gradient convs (A/B: ~7 % slower cfg3 step, same gradients to the digit)
   int stem_wino = 1;                          // "stem_wino"
   int conv_persist = 1;                       // "conv_persist"
   int conv_c16 = 1;                           // "conv_c16"

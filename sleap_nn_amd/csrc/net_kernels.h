@@ -121,7 +121,6 @@ int launch_input_conv(const InputConvArgs& a, hipStream_t s);
 int launch_pool(const float* src, float* dst, int B, int H, int W, int cp, hipStream_t s);
 int launch_upsample(const float* src, float* dst, int B, int H, int W, int cp, hipStream_t s);
 int launch_zero_stuff(const float* src, float* dst, int B, int H, int W, int cp, hipStream_t s);
-int launch_head(const float* src, const float* w, const float* bias, float* dst, int B, int HW, int cp, int cout, int sigmoid, hipStream_t s);
 int launch_global_maxpool(const float* src, float* dst, int B, int HW, int cp, hipStream_t s);
 int launch_softmax_rows(float* x, int rows, int n, hipStream_t s);
 int launch_nhwc_to_nchw(const float* src, float* dst, int B, int HW, int cp, int c, hipStream_t s);

@@ -12,7 +12,7 @@
 //   2x2 max pool "same" .............. architectures/common.py:69-107 (zero pad if odd)
 //   bilinear x2 (align_corners=False)  encoder_decoder.py:431-435
 //   ConvTranspose2d(k3,s2,p1,op1) .... encoder_decoder.py:439-461
-//   1x1 head conv .................... architectures/heads.py:58-67
+//   1x1 head conv .................... architectures/heads.py:58-67 (head1x1_mfma_kernel, f16_kernels.hip)
 //   uint8 -> float /255 .............. data/normalization.py:7-35
 #include <type_traits>
 
@@ -1755,68 +1755,6 @@ int launch_zero_stuff(const float* src, float* dst, int B, int H, int W, int cp,
   return PH_OK;
 }
 
-// ---------------------------------------------------------------------------------------
-// K2: 1x1 head convolution, NHWC(Cp) -> NCHW(Cout) fp32 (+ optional sigmoid).
-// Block = 64 pixels; the 64 x Cp activation tile and the Cout x Cp weights sit in LDS
-// (pixel rows padded by 1 dword: column reads conflict-free); thread (p, j) computes
-// output channels j, j+4, ... of pixel p.  HBM-bound: Cp*4 B read + Cout*4 B written/pixel.
-// ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void head1x1_kernel(const float* __restrict__ src, const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ dst, int B, int HW, int cp, int cout, int sigmoid) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* sa = lds;                    // 64 x (cp+1)
-  float* sw = lds + 64 * (cp + 1);    // cout x cp (16-B aligned rows: cp is a multiple of 16 and 64*(cp+1) of 4... see launch)
-  const size_t npix = (size_t)B * HW;
-  const size_t p0 = (size_t)blockIdx.x * 64;
-  for (int i = threadIdx.x; i < cout * cp; i += 256) sw[i] = w[i];
-  for (int i = threadIdx.x; i < 64 * cp; i += 256) {
-    const int pp = i / cp, c = i - pp * cp;
-    sa[pp * (cp + 1) + c] = (p0 + pp < npix) ? src[(p0 + pp) * cp + c] : 0.f;
-  }
-  __syncthreads();
-  const int pp = threadIdx.x & 63, j0 = threadIdx.x >> 6;
-  const size_t p = p0 + pp;
-  if (p >= npix) return;
-  const size_t b = p / HW, hw = p - b * HW;
-  // thread (pixel pp, j0) owns output channels j0, j0+4, ...: the pixel's activations are pulled into registers
-  // 32 channels at a time (conflict-free column reads) and each weight quad is one broadcast ds_read_b128
-  constexpr int MAXJ = 16;  // up to 64 output channels per pass
-  const float* ar = sa + pp * (cp + 1);
-  for (int jb = j0; jb < cout; jb += 4 * MAXJ) {
-    float acc[MAXJ];
-#pragma unroll
-    for (int k = 0; k < MAXJ; ++k) acc[k] = (jb + 4 * k < cout) ? bias[jb + 4 * k] : 0.f;
-    for (int cb = 0; cb < cp; cb += 16) {
-      float xr[16];
-#pragma unroll
-      for (int c = 0; c < 16; ++c) xr[c] = ar[cb + c];
-#pragma unroll
-      for (int k = 0; k < MAXJ; ++k) {
-        const int j = jb + 4 * k;
-        if (j < cout) {  // wave-uniform (j0 is per wave)
-          const float* wr = sw + j * cp + cb;
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const f32x4 wv = *reinterpret_cast<const f32x4*>(wr + q * 4);
-            acc[k] += xr[4 * q] * wv[0];
-            acc[k] += xr[4 * q + 1] * wv[1];
-            acc[k] += xr[4 * q + 2] * wv[2];
-            acc[k] += xr[4 * q + 3] * wv[3];
-          }
-        }
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < MAXJ; ++k) {
-      const int j = jb + 4 * k;
-      if (j < cout) {
-        float v = acc[k];
-        if (sigmoid) v = 1.f / (1.f + expf(-v));
-        dst[(b * cout + j) * HW + hw] = v;
-      }
-    }
-  }
-}
-
 // Global max pool over H x W per channel (nn.AdaptiveMaxPool2d(1)): one workgroup per (image, 64 channels).
 __global__ __launch_bounds__(256) void global_maxpool_kernel(const float* __restrict__ src, float* __restrict__ dst, int HW, int cp) {
   __shared__ float red[4][64];
@@ -1851,25 +1789,6 @@ __global__ void softmax_rows_kernel(float* __restrict__ x, int rows, int n) {
 }
 int launch_softmax_rows(float* x, int rows, int n, hipStream_t s) {
   hipLaunchKernelGGL(softmax_rows_kernel, dim3((rows + 63) / 64), dim3(64), 0, s, x, rows, n);
-  PH_HIP_CHECK(hipGetLastError());
-  return PH_OK;
-}
-
-int launch_head(const float* src, const float* w, const float* bias, float* dst, int B, int HW, int cp, int cout, int sigmoid, hipStream_t s) {
-  const size_t npix = (size_t)B * HW;
-  const size_t lds = (64 * (cp + 1) + (size_t)cout * cp) * sizeof(float);
-  if (lds > 160 * 1024) {
-    set_error("head1x1: LDS tile too large (cp=%d cout=%d)", cp, cout);
-    return PH_E_INVALID;
-  }
-  if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(head1x1_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) {
-      set_error("hipFuncSetAttribute(head1x1) failed: %s", hipGetErrorString(e));
-      return PH_E_HIP;
-    }
-  }
-  hipLaunchKernelGGL(head1x1_kernel, dim3((unsigned)((npix + 63) / 64)), dim3(256), lds, s, src, w, bias, dst, B, HW, cp, cout, sigmoid);
   PH_HIP_CHECK(hipGetLastError());
   return PH_OK;
 }

@@ -311,6 +311,7 @@ int ph_model_backward(ph_model* m, const void* input_dev, int32_t in_dtype, int3
           a.zeros = m->zeros_dev;
           a.dst_pool = nullptr;
           apply_conv_options(m, a);
+          if (!m->dgrad_wino) a.use_wino = 0;
           a.accumulate = init[srcs[part]];
           rc = (m->use_dma && (a.bn == 64 || m->dma32)) ? launch_conv3x3_dma(a, s) : launch_conv3x3(a, s);
           if (rc != PH_OK) return rc;
