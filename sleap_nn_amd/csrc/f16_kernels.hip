@@ -241,18 +241,27 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16_persist_kernel(ConvF16Args
       }
       __syncthreads();  // vmcnt(0) + barrier: the next buffer landed everywhere, this one is free again
     }
-    // ---- epilogue: D row = channel (r & 3) + 8 (r >> 2) + 4 lh of the N tile, column = pixel lx of the wave's row
+    // ---- epilogue: D row = channel (r & 3) + 8 (r >> 2) + 4 lh of the N tile, column = pixel lx of the wave's row.
+    // A lane holds 4-channel pieces of ONE pixel; stored directly, a wave-instruction would touch 32 different cache lines with
+    // 16 B each (measured: 3.1 of the 8.5 ms conv time at cfg3 was this store pattern).  The pieces are therefore first laid
+    // out in LDS exactly as the tile lies in memory (the K loop's last buffer is free; every wave has a private 32-pixel region,
+    // rows padded by 16 B against bank conflicts), read back 16 B per lane and stored with 64 lanes covering whole 128-B lines.
     const int b = P.b, x0 = P.x0, y0 = P.y0, ntile = P.ntile;
     const int x = x0 + lx;
     const size_t rsb = (size_t)a.rs_dst * 4;  // destination bytes per pixel
     const bool x_ok = x < a.W;
+    constexpr int SEG = DST_FMT == FMT_SPLIT ? BN * 4 : BN * 2;  // bytes of this N tile per pixel
+    constexpr int SEGP = SEG + 16;
+    constexpr int PER = SEG / 16;                                // 16-B units per pixel
+    static_assert(8 * 32 * SEGP <= PIECES * 1024, "epilogue staging must fit one ring buffer");
+    char* const my = reinterpret_cast<char*>(((parity + nchunks - 1) & 1) ? buf1 : buf0) + wave * (32 * SEGP);
+    float v[2][NT][16];
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
       const int cb = ntile * BN + n * 32 + 4 * lh;  // + 8 q: the lane's channel quads
       f32x4 bias4[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) bias4[q] = *reinterpret_cast<const f32x4*>(a.bias + cb + 8 * q);  // bias is padded to a multiple of BN
-      float v[2][16];
 #pragma unroll
       for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -260,58 +269,78 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16_persist_kernel(ConvF16Args
           float t = acc[m][n][r];
           if (PREC == 3) t += accx[m][n][r] * SPLIT_INV;
           t += bias4[r >> 2][r & 3];
-          v[m][r] = a.relu ? fmaxf(t, 0.f) : t;
+          v[m][n][r] = a.relu ? fmaxf(t, 0.f) : t;
         }
-      auto put = [&](void* base, size_t pix, int q, const float* src4) {  // four consecutive channels cb + 8 q .. + 3 of one pixel
-        const int c = cb + 8 * q;
-        char* p = reinterpret_cast<char*>(base) + pix * rsb;
-        if constexpr (DST_FMT == FMT_SPLIT) {
-          f16x4 hi, lo;
+    }
+    auto convert4 = [&](const float* src4, f16x4& hi, f16x4& lo) {
 #pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const _Float16 h = split_hi(src4[k]);
-            hi[k] = h;
-            lo[k] = split_lo(src4[k], h);
-          }
-          p += (c >> 4) * 64 + ((c >> 3) & 1) * 16 + (c & 7) * 2;
-          *reinterpret_cast<f16x4*>(p) = hi;
-          *reinterpret_cast<f16x4*>(p + 32) = lo;
-        } else {
-          f16x4 h;
-#pragma unroll
-          for (int k = 0; k < 4; ++k) h[k] = (_Float16)src4[k];
-          *reinterpret_cast<f16x4*>(p + c * 2) = h;
-        }
-      };
-#pragma unroll
-      for (int m = 0; m < 2; ++m) {
-        const int y = y0 + 2 * wave + m;
-        if (y < a.H && x_ok) {
-          const size_t pix = (size_t)(b * a.H + y) * a.W + x;
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-            if (cb + 8 * q < a.coutp) put(a.dst, pix, q, &v[m][4 * q]);
-        }
+      for (int k = 0; k < 4; ++k) {
+        const _Float16 h = split_hi(src4[k]);
+        hi[k] = h;
+        if constexpr (DST_FMT == FMT_SPLIT) lo[k] = split_lo(src4[k], h);
       }
-      if (a.dst_pool) {  // fused 2x2/2 max pool ("same": zeros beyond the image; values are >= 0 after the ReLU)
-        const int Hp = (a.H + 1) >> 1, Wp = (a.W + 1) >> 1;
-        const int yt = y0 + 2 * wave;
-        const bool y1_ok = yt + 1 < a.H;
-        float pv[16];
+    };
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float c0 = x_ok ? v[0][r] : 0.f, c1 = (x_ok && y1_ok) ? v[1][r] : 0.f;
-          const float col = fmaxf(c0, c1);
-          pv[r] = fmaxf(col, lane_xor1(col));
-        }
-        if (!(lx & 1) && yt < a.H && x_ok) {
-          const size_t ppix = (size_t)(b * Hp + (yt >> 1)) * Wp + (x >> 1);
+    for (int m = 0; m < 2; ++m) {
+      const int y = y0 + 2 * wave + m;
 #pragma unroll
-          for (int q = 0; q < 4; ++q)
-            if (cb + 8 * q < a.coutp) put(a.dst_pool, ppix, q, &pv[4 * q]);
+      for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          f16x4 hi, lo;
+          convert4(&v[m][n][4 * q], hi, lo);
+          if constexpr (DST_FMT == FMT_SPLIT) {
+            char* p = my + lx * SEGP + (2 * n + (q >> 1)) * 64 + (q & 1) * 16 + lh * 8;
+            *reinterpret_cast<f16x4*>(p) = hi;
+            *reinterpret_cast<f16x4*>(p + 32) = lo;
+          } else {
+            *reinterpret_cast<f16x4*>(my + lx * SEGP + (n * 32 + 8 * q + 4 * lh) * 2) = hi;
+          }
         }
+      const bool y_ok = y < a.H;
+      char* const drow = reinterpret_cast<char*>(a.dst) + ((size_t)(b * a.H + (y_ok ? y : 0)) * a.W + x0) * rsb + (size_t)ntile * SEG;
+#pragma unroll
+      for (int it = 0; it < 32 * PER / 64; ++it) {
+        const int idx = it * 64 + lane;
+        const int pp = idx / PER, j = idx - pp * PER;
+        const f32x4 piece = *reinterpret_cast<const f32x4*>(my + pp * SEGP + j * 16);
+        const int c_first = ntile * BN + (DST_FMT == FMT_SPLIT ? (j >> 2) * 16 : j * 8);  // first channel the 16-B unit belongs to
+        // non-temporal: the tile's output is not read again by this launch, and kept in L2 it would evict the weight panels the K loop re-reads
+        if (y_ok && x0 + pp < a.W && c_first < a.coutp) __builtin_nontemporal_store(piece, reinterpret_cast<f32x4*>(drow + (size_t)pp * rsb + j * 16));
       }
     }
+    if (a.dst_pool) {  // fused 2x2/2 max pool ("same": zeros beyond the image; values are >= 0 after the ReLU)
+      const int Hp = (a.H + 1) >> 1, Wp = (a.W + 1) >> 1;
+      const int yt = y0 + 2 * wave;
+      const bool y1_ok = yt + 1 < a.H;
+      const bool p_ok = !(lx & 1) && yt < a.H && x_ok;
+      char* const prow = reinterpret_cast<char*>(a.dst_pool) + ((size_t)(b * Hp + (yt >> 1)) * Wp + (x >> 1)) * rsb;
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float pv[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float c0 = x_ok ? v[0][n][4 * q + k] : 0.f, c1 = (x_ok && y1_ok) ? v[1][n][4 * q + k] : 0.f;
+            const float col = fmaxf(c0, c1);
+            pv[k] = fmaxf(col, lane_xor1(col));
+          }
+          const int c = ntile * BN + n * 32 + 8 * q + 4 * lh;
+          if (p_ok && c < a.coutp) {
+            f16x4 hi, lo;
+            convert4(pv, hi, lo);
+            if constexpr (DST_FMT == FMT_SPLIT) {
+              char* p = prow + (c >> 4) * 64 + ((c >> 3) & 1) * 16 + (c & 7) * 2;
+              *reinterpret_cast<f16x4*>(p) = hi;
+              *reinterpret_cast<f16x4*>(p + 32) = lo;
+            } else {
+              *reinterpret_cast<f16x4*>(prow + c * 2) = hi;
+            }
+          }
+        }
+    }
+    __builtin_amdgcn_s_barrier();  // every wave has read its staging region back: the buffer may take the next tile's DMA pieces
     if (!has_next) break;
     parity = (parity + nchunks) & 1;
     vid = nvid;
