@@ -206,7 +206,7 @@ int ph_debug_gemm_bench(int32_t variant, int32_t M, int32_t K, int32_t N, int32_
  * tunables).  Every key selects between kernel variants that compute the same result; defaults
  * are the measured-best ones.  Keys: "conv_wino" (1 Winograd F(2,3) 3x3 kernels | 2 only the
  * N-tile-64 layers | 0 direct 9-tap kernels), "stem_wino", "dgrad_wino" (0: direct kernels for the backward's data-gradient convs), "conv_dma", "conv_dma32",
- * "conv_persist", "conv_c16", "conv_dma_stagger", "fuse_gelu_fwd", "fuse_gelu_bwd", "wgrad_rows", "convt_phase",
+ * "conv_persist", "conv_c16", "conv_dma_stagger", "fuse_gelu_fwd", "fuse_gelu_bwd", "wgrad_rows", "convt_phase", "workspace_reuse" (1: activation slots of an inference forward share memory by lifetime),
  * "conv_precision" (0 exact fp32 MFMA | 1 split-fp16 MFMA, 22-bit products | 2 plain fp16, the reference's autocast mode),
  * "gemm_late_split", "gemm_persist2", "conv_gemm_fill", "conv_gemm_fill_wino" (DESIGN.md appendix).
  * Unknown key -> PH_E_INVALID. */

@@ -83,9 +83,11 @@ class Model:
         self.generation = 0
         self._options: Dict[str, float] = {}
         self.precision = "exact"
+        self.keep_activations = False
         # a TrainingModule registers its device parameter arena here; after any recompile the packed weights are
         # re-gathered from it, so eval()/train() round trips never fall back to the host copy in _state
         self._live_params: Optional[torch.Tensor] = None
+        self._options["workspace_reuse"] = 1.0  # the model starts in the inference (fused) program
 
     def _add_class_vector_head(self, i: int, head: "ClassVectorsHead") -> None:
         """heads.py:506-539 on the decoder's input feature (architectures/model.py:197-199,253-255)."""
@@ -256,8 +258,18 @@ class Model:
         if want is not self.ops:
             self.ops = want
             self._release()
-        # the training program keeps fp32 activations for the backward pass; inference runs at `self.precision`
+        # the training program keeps fp32 activations for the backward pass; inference runs at `self.precision` and lets
+        # activation slots share memory once their last reader has run (unless somebody wants to read them back)
         self.set_option("conv_precision", PRECISIONS[self.precision] if fused else 0)
+        self.set_option("workspace_reuse", 1 if (fused and not self.keep_activations) else 0)
+        return self
+
+    def set_keep_activations(self, keep: bool) -> "Model":
+        """``True``: every activation of an inference forward stays readable (``read_activation``) at the price of one memory
+        range per slot (9.0 instead of 3.6 GB at cfg3 x 32 frames)."""
+        self.keep_activations = bool(keep)
+        if self.ops is self.fused_ops:
+            self.set_option("workspace_reuse", 0 if self.keep_activations else 1)
         return self
 
     def set_precision(self, precision: str) -> "Model":
@@ -485,6 +497,8 @@ class Model:
 
     def read_activation(self, conv_name: str, batch: int, height_width) -> torch.Tensor:
         """Debug/parity: NCHW copy of the activation a named conv produced in the last forward."""
+        if self.ops is self.fused_ops and not self.keep_activations:
+            raise RuntimeError("activation slots are recycled during an inference forward: call set_keep_activations(True) before the forward")
         slot = self.backbone.labels[conv_name]
         op = next((o for o in self.ops if o.dst == slot), None)
         if op is None:

@@ -4,6 +4,7 @@
 // (sleap_nn/inference/layers/backends/torch_backend.py:113-153,
 //  training/lightning_modules.py:1840-1848, architectures/model.py:237-261,
 //  architectures/unet.py:260-299).
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <mutex>
@@ -218,8 +219,64 @@ int build_plan(const ph_model* m, int B, int H, int W, Plan& plan, int fmt) {
   plan.bpc = fmt_bytes_per_channel(fmt);
   const int bpc = plan.bpc;
   int64_t off = 0, tmp = 0;
+  // Slot allocation.  Default: every slot gets its own range (training keeps every activation; ph_model_read_slot can read any of
+  // them back).  With the handle option "workspace_reuse" (inference programs) a slot's range returns to a free list after its
+  // last reader and later slots take the best-fitting free block: 9.0 -> 3.6 GB at cfg3 x 32 frames, and a layer's output is
+  // written where an older tensor has just left the caches.
+  const bool reuse = m->workspace_reuse != 0;
+  plan.reuse = reuse;
+  const int n_ops = (int)m->ops.size();
+  std::vector<int> last_use(m->n_slots, -1);
+  std::vector<int64_t> slot_bytes(m->n_slots, 0);
+  std::vector<char> released(m->n_slots, 0);
+  if (reuse)
+    for (int j = 0; j < n_ops; ++j) {
+      const ph_op_desc& e = m->ops[j].d;
+      if (e.src0 >= 0 && e.src0 < m->n_slots) last_use[e.src0] = j;
+      if (e.src1 >= 0 && e.src1 < m->n_slots) last_use[e.src1] = j;
+    }
+  std::vector<std::pair<int64_t, int64_t>> free_list;  // (offset, bytes), kept sorted and coalesced
+  auto release = [&](int slot) {
+    free_list.emplace_back(plan.slots[slot].offset, slot_bytes[slot]);
+    std::sort(free_list.begin(), free_list.end());
+    for (size_t k = 0; k + 1 < free_list.size();)
+      if (free_list[k].first + free_list[k].second == free_list[k + 1].first) {
+        free_list[k].second += free_list[k + 1].second;
+        free_list.erase(free_list.begin() + k + 1);
+      } else
+        ++k;
+    released[slot] = 1;
+  };
+  auto alloc = [&](int slot, int64_t bytes) {
+    bytes = align_up(bytes, 256);
+    slot_bytes[slot] = bytes;
+    int best = -1;
+    for (size_t k = 0; k < free_list.size(); ++k)
+      if (free_list[k].second >= bytes && (best < 0 || free_list[k].second < free_list[best].second)) best = (int)k;
+    if (best >= 0) {
+      const int64_t o = free_list[best].first;
+      free_list[best].first += bytes;
+      free_list[best].second -= bytes;
+      if (free_list[best].second == 0) free_list.erase(free_list.begin() + best);
+      return o;
+    }
+    if (!free_list.empty() && free_list.back().first + free_list.back().second == off) {  // grow the trailing free block
+      const int64_t o = free_list.back().first;
+      free_list.pop_back();
+      off = o + bytes;
+      return o;
+    }
+    const int64_t o = off;
+    off += bytes;
+    return o;
+  };
+  int op_i = -1;
   for (const PackedOp& op : m->ops) {
     const ph_op_desc& d = op.d;
+    ++op_i;
+    if (reuse)  // slots whose last reader ran before this op (a slot nobody reads is released right after the op that wrote it)
+      for (int sl = 0; sl < m->n_slots; ++sl)
+        if (!released[sl] && plan.slots[sl].offset >= 0 && slot_bytes[sl] > 0 && std::max(last_use[sl], plan.slots[sl].def_op) < op_i) release(sl);
     int h, w;
     if (d.src0 < 0) {
       h = H;
@@ -235,12 +292,12 @@ int build_plan(const ph_model* m, int B, int H, int W, Plan& plan, int fmt) {
       PH_REQUIRE(d.dst2 >= 0 && d.dst2 < m->n_slots && d.dst < m->n_slots, "bad stem slots");
       if (d.dst >= 0) {
         SlotShape& f = plan.slots[d.dst];
-        f.c = d.cout; f.cp = fmt_cpad(fmt, 16); f.h = h; f.w = w; f.offset = off;
-        off += align_up((int64_t)B * h * w * f.cp * bpc, 256);
+        f.c = d.cout; f.cp = fmt_cpad(fmt, 16); f.h = h; f.w = w; f.def_op = op_i;
+        f.offset = alloc(d.dst, (int64_t)B * h * w * f.cp * bpc);
       }
       SlotShape& p = plan.slots[d.dst2];
-      p.c = d.cout; p.cp = fmt_cpad(fmt, 16); p.h = (h + 1) / 2; p.w = (w + 1) / 2; p.offset = off;
-      off += align_up((int64_t)B * p.h * p.w * p.cp * bpc, 256);
+      p.c = d.cout; p.cp = fmt_cpad(fmt, 16); p.h = (h + 1) / 2; p.w = (w + 1) / 2; p.def_op = op_i;
+      p.offset = alloc(d.dst2, (int64_t)B * p.h * p.w * p.cp * bpc);
       continue;
     }
     int oh = h, ow = w;
@@ -283,8 +340,8 @@ int build_plan(const ph_model* m, int B, int H, int W, Plan& plan, int fmt) {
     s.cp = fmt_cpad(fmt, s.c);
     s.h = oh;
     s.w = ow;
-    s.offset = off;
-    off += align_up((int64_t)B * oh * ow * s.cp * bpc, 256);
+    s.def_op = op_i;
+    s.offset = alloc(d.dst, (int64_t)B * oh * ow * s.cp * bpc);
     if (d.kind == PH_OP_CONV && d.dst2 >= 0) {  // fused 2x2 max pool of the conv output
       PH_REQUIRE(d.dst2 < m->n_slots && (d.flags & PH_FLAG_RELU), "fused pool needs a valid slot and a ReLU conv");
       SlotShape& p = plan.slots[d.dst2];
@@ -292,8 +349,8 @@ int build_plan(const ph_model* m, int B, int H, int W, Plan& plan, int fmt) {
       p.cp = fmt_cpad(fmt, d.cout);
       p.h = (oh + 1) / 2;
       p.w = (ow + 1) / 2;
-      p.offset = off;
-      off += align_up((int64_t)B * p.h * p.w * p.cp * bpc, 256);
+      p.def_op = op_i;
+      p.offset = alloc(d.dst2, (int64_t)B * p.h * p.w * p.cp * bpc);
     }
   }
   plan.tmp_offset = off;
@@ -1161,6 +1218,7 @@ std::vector<OptionRef> option_table(ph_model* m) {
       {"fuse_gelu_fwd", &m->fuse_gelu_fwd, nullptr},
       {"fuse_gelu_bwd", &m->fuse_gelu_bwd, nullptr},
       {"wgrad_rows", &m->wgrad_rows, nullptr},          // 0 32x32-tile wgrad kernel, 1 auto, 2 nine row-wgrad GEMMs
+      {"workspace_reuse", &m->workspace_reuse, nullptr},  // 1: activation slots share memory once their last reader has run (inference programs only)
       {"convt_phase", &m->convt_phase, nullptr},        // 0: transposed convs by zero-stuffing + 3x3 conv (4x the FLOPs; A/B reference)
       {"conv_precision", &m->conv_precision, nullptr},  // 0 exact fp32 MFMA, 1 split-fp16 MFMA (22-bit products), 2 plain fp16 (autocast-equivalent)
       {"gemm_late_split", &m->gemm_late_split, nullptr},
@@ -1228,6 +1286,7 @@ int ph_model_set_clock_probe(ph_model* m, void* buf_dev) {
 int ph_model_read_slot(ph_model* m, int32_t slot, float* out_dev, int64_t out_numel, void* stream) {
   PH_REQUIRE(m && out_dev && m->last_ws, "ph_model_read_slot: no forward has run");
   PH_REQUIRE(slot >= 0 && slot < m->n_slots && m->last_plan.slots[slot].offset >= 0, "bad slot %d", slot);
+  PH_REQUIRE(!m->last_plan.reuse, "activations are recycled in this plan: set the handle option workspace_reuse to 0 before the forward to read a slot back");
   const SlotShape& s = m->last_plan.slots[slot];
   PH_REQUIRE(out_numel == (int64_t)m->last_batch * s.c * s.h * s.w, "slot %d has %d x %d x %d x %d elements", slot, m->last_batch, s.c, s.h, s.w);
   if (m->last_plan.fmt != FMT_F32)

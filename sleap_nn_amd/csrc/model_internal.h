@@ -63,11 +63,13 @@ struct DerivedBuffer {
 struct SlotShape {
   int c = 0, cp = 0, h = 0, w = 0;  // cp: channels padded for the plan's format
   int64_t offset = -1;
+  int def_op = -1;                  // index of the op that writes the slot
 };
 
 struct Plan {
   std::vector<SlotShape> slots;
   int64_t tmp_offset = 0, tmp_bytes = 0, total = 0;
+  bool reuse = false;  // slots share memory by lifetime (handle option workspace_reuse)
   int fmt = FMT_F32;  // activation format of every slot (act_format.h)
   int bpc = 4;        // bytes per channel in that format
 };
@@ -112,6 +114,7 @@ struct ph_model {
   int wgrad_rows = 0;                         // 3x3 weight gradients of wide layers as nine row-wgrad GEMMs (off by default: measured slower than the 32x32-tile kernel; 1 auto, 2 always)
   double gemm_fill_threshold_wino = 0.5;      // ... and the (lower) break-even when the halo kernel is the Winograd one
   double gemm_fill_threshold = 0.8;           // 3x3 convs whose maps fill the 16x32 tiles less than this run as row GEMMs
+  int workspace_reuse = 0;                    // "workspace_reuse": 1 = slots of an inference program share memory by lifetime (no read-back, no backward)
   int convt_phase = 1;                        // "convt_phase": transposed convs as four phase GEMMs (0: zero-stuffing + 3x3 conv, 4x the FLOPs; A/B)
   int conv_precision = 0;                     // "conv_precision": 0 exact fp32 MFMA; 1 split-fp16 MFMA (22-bit products, fp32 accumulate); 2 plain fp16 (autocast-equivalent)
 };

@@ -182,6 +182,7 @@ int ph_model_backward(ph_model* m, const void* input_dev, int32_t in_dtype, int3
   PH_REQUIRE(((uintptr_t)grad_workspace_dev & 255) == 0, "gradient workspace must be 256-byte aligned");
   hipStream_t s = static_cast<hipStream_t>(stream);
   PH_REQUIRE(m->last_plan.fmt == FMT_F32, "backward needs the activations of an exact-fp32 forward (handle option conv_precision = 0)");
+  PH_REQUIRE(!m->last_plan.reuse, "backward needs every activation of the forward (handle option workspace_reuse = 0)");
   BwdPlan bp;
   int rc = build_bwd_plan(m, batch, height, width, bp);
   if (rc != PH_OK) return rc;

@@ -35,7 +35,7 @@ def _run(bb, heads, model_type, img, seed=7, layer_scale=0.5, check_blocks=True)
     sd = O.init_state_convnext(bb, heads, model_type, seed=seed, head_scale=1.0, layer_scale=layer_scale, randomize_affine=True)
     m = Model("convnext", bb, heads, model_type)
     m.load_state_dict(sd, strict=True)
-    m.to(DEV)
+    m.to(DEV).set_keep_activations(check_blocks)
     collect = {}
     ref = O.model_forward(sd, bb, heads, model_type, img, collect=collect, backbone="convnext")
     out = m(img.to(DEV))

@@ -32,7 +32,7 @@ def _model(cfg, weights):
 def test_forward_matches_reference_golden(name):
     z = G.load(name)
     cfg = G.config(z)
-    m = _model(cfg, G.weights(z))
+    m = _model(cfg, G.weights(z)).set_keep_activations(True)  # intermediate activations are read back below
     img = torch.from_numpy(z["image"]).squeeze(1).to(DEV)
     out = m(img)
     torch.cuda.synchronize()
@@ -60,8 +60,7 @@ def test_unfused_program_matches_too(name):
     """The plan-level stem fusion is optional: the op-by-op program must give the same maps."""
     z = G.load(name)
     cfg = G.config(z)
-    m = _model(cfg, G.weights(z))
-    m.ops = list(m.unfused_ops)
+    m = _model(cfg, G.weights(z)).set_fusion(False)
     img = torch.from_numpy(z["image"]).squeeze(1).to(DEV)
     out = m(img)
     for k in [f for f in z.files if f.startswith("out/")]:
@@ -426,7 +425,7 @@ def test_forward_matches_reference_golden_on_the_fp16_pipe(name, precision, atol
     activation formats)."""
     z = G.load(name)
     cfg = G.config(z)
-    m = _model(cfg, G.weights(z)).set_precision(precision)
+    m = _model(cfg, G.weights(z)).set_precision(precision).set_keep_activations(True)
     out = m(torch.from_numpy(z["image"]).squeeze(1).to(DEV))
     torch.cuda.synchronize()
     assert m.get_option("conv_precision") == {"split": 1.0, "fp16": 2.0}[precision]
@@ -623,6 +622,47 @@ def test_transposed_conv_phase_gemms_equal_zero_stuffing_and_carry_epilogue_para
     y = F.silu(y * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))  # BatchNorm2d.eval() folded to scale / shift, then SiLU
     y = F.conv2d(y, wh, bh)
     assert (out.cpu() - y).abs().max().item() <= CMS_ATOL
+
+
+def test_cfg2_single_instance_512_network_and_full_size_global_peaks():
+    """BASELINE cfg2 at full size: single-instance UNet f16/r2/max_stride 16/output_stride 2, 512x512, 13 keypoints, batch 8.
+    Network: two frames vs the oracle (1e-4).  Post-process at the full (8, 13, 256, 256) size on rendered single-animal maps plus
+    engineered ties (global-peak x / y are taken independently, first maximum each: SURVEY Q5): coordinates and values vs the oracle."""
+    from sleap_nn_amd.architectures.model import Model
+    from sleap_nn_amd.inference.backends import HipBackend
+    from sleap_nn_amd.inference.layers import SingleInstanceLayer
+    from sleap_nn_amd.inference.preprocess_info import PreprocInfo
+
+    S, N, B = 512, 13, 8
+    bb = {"in_channels": 1, "kernel_size": 3, "filters": 16, "filters_rate": 2, "max_stride": 16, "stem_stride": None, "middle_block": True, "up_interpolate": True,
+          "stacks": 1, "convs_per_block": 2, "output_stride": 2}
+    heads = {"confmaps": {"part_names": [f"k{i}" for i in range(N)], "sigma": 2.5, "output_stride": 2, "loss_weight": 1.0}}
+    sd = O.init_state(bb, heads, "single_instance", seed=2, head_scale=1.0)
+    g = torch.Generator().manual_seed(77)
+    img = torch.randint(0, 256, (B, 1, S, S), dtype=torch.uint8, generator=g)
+    m = Model("unet", bb, heads, "single_instance")
+    m.load_state_dict(sd)
+    layer = SingleInstanceLayer(HipBackend(m, DEV), 2, max_stride=16)
+    raw = layer.backend(img)["SingleInstanceConfmapsHead"]
+    ref = O.model_forward(sd, bb, heads, "single_instance", img[:2])["SingleInstanceConfmapsHead"]
+    assert tuple(raw.shape) == (B, N, 256, 256)
+    assert (raw[:2].cpu() - ref).abs().max().item() <= CMS_ATOL
+    rng = np.random.RandomState(4)
+    pts = np.stack([np.clip(rng.uniform(120, S - 120, size=(1, 1, 2)) + rng.normal(0, 45, size=(1, N, 2)), 4, S - 5) for _ in range(B)]).astype(np.float32)
+    cms = torch.stack([O.render_confmaps(pts[b], S, 2, 2.5 * 2 / 2) for b in range(B)])
+    cms[0, 0] = 0.05  # below threshold everywhere -> NaN
+    cms[1, 1, 40:42, 90:93] = 2.0  # a plateau: first column / first row containing the maximum
+    cms[2, 2, 255, 255] = 3.0  # the very last pixel
+    cms[3, 3, 10, 200] = cms[3, 3, 200, 10] = 4.0  # two equal maxima: x from one, y from the other (independent arg-maxes)
+    out = layer.postprocess({"SingleInstanceConfmapsHead": cms.to(DEV)}, PreprocInfo(eff_scale=torch.ones(B), output_stride=2))
+    rk, rv = O.single_instance_postprocess(cms, 2)
+    k = out.pred_keypoints.cpu().numpy()
+    assert k.shape == tuple(rk.shape) == (B, 1, N, 2)
+    assert np.array_equal(np.isnan(k), np.isnan(rk.numpy())) and np.isnan(k[0, 0, 0]).all()
+    assert np.allclose(k, rk.numpy(), atol=1e-4, equal_nan=True)
+    assert np.array_equal(out.pred_peak_values.cpu().numpy(), rv.numpy())
+    rough, _ = O.find_global_peaks(cms, 0.2, None)
+    assert tuple(rough[3, 3].tolist()) == (10.0, 10.0)  # x of the first column holding the maximum, y of the first row: a point that is no maximum at all
 
 
 def _wz(z, prefix):
@@ -971,3 +1011,35 @@ def test_layer_preprocess_with_sizematcher_and_input_scale():
     out = layer.predict(img)
     rk, rv = O.single_instance_postprocess(cms, 2, peak_threshold=thr, input_scale=0.75, eff_scale=eff)
     assert np.allclose(out.pred_keypoints.cpu().numpy().reshape(rk.shape), rk.numpy(), atol=2e-3, equal_nan=True)
+
+
+def test_workspace_reuse_shrinks_the_footprint_and_changes_no_bit():
+    """Inference programs recycle activation slots after their last reader (handle option workspace_reuse, on by default in eval):
+    the workspace of the cfg3 network shrinks by more than half, every head output is bit-identical to the one-range-per-slot plan
+    (bilinear and transposed-conv decoders, all three precisions), and reading a slot back is refused while slots are shared."""
+    import ctypes as C
+
+    import bench
+    from sleap_nn_amd import _lib as L
+    from sleap_nn_amd.architectures.model import Model
+
+    for name in ("unet_tiny_bu13.npz", "unet_tiny_trans.npz", "ckpt_bottomup.npz"):
+        z = G.load(name)
+        cfg = G.config(z)
+        img = torch.from_numpy(z["image"]).squeeze(1).to(DEV)
+        for prec in ("exact", "split", "fp16"):
+            a = {k: v.clone() for k, v in _model(cfg, G.weights(z)).set_precision(prec).set_keep_activations(True)(img).items()}
+            m = _model(cfg, G.weights(z)).set_precision(prec)
+            b = m(img)
+            assert m.get_option("workspace_reuse") == 1.0
+            for k in a:
+                assert torch.equal(a[k], b[k]), (name, prec, k)
+    with pytest.raises(RuntimeError, match="recycled"):
+        m.read_activation(next(iter(m.backbone.labels)), 1, (8, 8))
+    big = Model("unet", bench.CFG3_BB, bench.CFG3_HEADS, "bottomup").init_xavier_(seed=1).to(DEV)
+    big(torch.zeros((1, 1, 64, 64), dtype=torch.uint8, device=DEV))
+    shared = L.check(L.lib().ph_model_workspace_bytes(big._handle, 32, 1024, 1024))
+    big.set_keep_activations(True)
+    full = L.check(L.lib().ph_model_workspace_bytes(big._handle, 32, 1024, 1024))
+    print(f"cfg3 x 32 frames workspace: {full / 2**30:.2f} GiB one range per slot, {shared / 2**30:.2f} GiB shared")
+    assert shared < 0.5 * full
