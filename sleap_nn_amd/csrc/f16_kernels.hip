@@ -80,11 +80,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16_persist_kernel(ConvF16Args
     int b, x0, y0, ntile;
   };
   auto setup = [&](int vid, Plan& P) {
-    int t, ntile;  // XCD-aware dealing: the N tiles of one pixel tile are 8 ids apart (same XCD, same time -> the halo is an L2 hit)
+    int t, ntile;  // XCD-aware dealing (see deal_tile in net_kernels.hip): every XCD walks a contiguous range of pixel tiles
     if ((tiles & 7) == 0) {
       const int xcd = vid & 7, j = vid >> 3;
       ntile = j % ntc;
-      t = (j / ntc) * 8 + xcd;
+      t = xcd * (tiles >> 3) + j / ntc;
     } else {
       ntile = vid % ntc;
       t = vid / ntc;

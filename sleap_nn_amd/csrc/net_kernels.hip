@@ -40,21 +40,23 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int TH = 8, TW = 32, KC = 16, LROW = 20;
 constexpr int HALO_W = TW + 2, HALO_H = TH + 2;
 
-// 1-D grid of tiles * n_tiles workgroups.  Workgroups are dealt round-robin over the 8 XCDs
-// (ids b and b+8 share an XCD and its private L2), so the N tiles of one pixel tile are given
-// ids 8 apart: they run at the same time on the same XCD and their identical input-halo reads
-// hit in L2 instead of going out to HBM once per N tile.  (Speed only; any placement is correct.)
-__device__ __forceinline__ void decode_block(int tiles, int nt_count, int* tile, int* ntile) {
-  const int id = blockIdx.x;
+// Work item `id` (a workgroup id, or a persistent workgroup's virtual id) -> (pixel tile, N tile).  Workgroups are dealt
+// round-robin over the 8 XCDs, each with a private L2 (ids b and b + 8 share an XCD).  Every XCD gets a CONTIGUOUS range of pixel
+// tiles, walked in order with the N tiles of one pixel tile on consecutive local ids: at any time an XCD works on neighbouring
+// tiles, so the N tiles' identical halo reads AND the one-to-two-pixel halo overlap between neighbouring tiles hit in its L2
+// instead of going out to HBM once per tile (round 1 dealt tile t to XCD t % 8: neighbours never met; 1.56x over-fetch on the
+// 512x512 layers).  (Speed only; any placement is correct.)
+__device__ __forceinline__ void deal_tile(int id, int tiles, int nt_count, int* tile, int* ntile) {
   if ((tiles & 7) == 0) {
     const int xcd = id & 7, j = id >> 3;
     *ntile = j % nt_count;
-    *tile = (j / nt_count) * 8 + xcd;
+    *tile = xcd * (tiles >> 3) + j / nt_count;
   } else {
     *ntile = id % nt_count;
     *tile = id / nt_count;
   }
 }
+__device__ __forceinline__ void decode_block(int tiles, int nt_count, int* tile, int* ntile) { deal_tile(blockIdx.x, tiles, nt_count, tile, ntile); }
 
 // Fused 2x2/2 max pool of a wave's two accumulator rows (rows 2w, 2w+1 of the tile; C/D map
 // x = (r&3) + 8*(r>>2) + 4*(lane>>5)): x pairs are register pairs, y pairs the two M tiles.
@@ -612,15 +614,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mfma_dma_persist_kernel(ConvAr
     int b, x0, y0, ntile;
   };
   auto setup = [&](int vid, Plan& P) {
-    int t, ntile;  // same XCD-aware dealing as decode_block, over virtual workgroup ids
-    if ((tiles & 7) == 0) {
-      const int xcd = vid & 7, j = vid >> 3;
-      ntile = j % ntc;
-      t = (j / ntc) * 8 + xcd;
-    } else {
-      ntile = vid % ntc;
-      t = vid / ntc;
-    }
+    int t, ntile;
+    deal_tile(vid, tiles, ntc, &t, &ntile);  // XCD-aware dealing over virtual workgroup ids
     const int tx = t % tiles_x;
     t /= tiles_x;
     const int ty = t % tiles_y;
@@ -916,14 +911,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv3x3_wino_persist_kernel(Con
   };
   auto setup = [&](int vid, Plan& P) {
     int t, ntile;
-    if ((tiles & 7) == 0) {
-      const int xcd = vid & 7, j = vid >> 3;
-      ntile = j % ntc;
-      t = (j / ntc) * 8 + xcd;
-    } else {
-      ntile = vid % ntc;
-      t = vid / ntc;
-    }
+    deal_tile(vid, tiles, ntc, &t, &ntile);
     const int tx = t % tiles_x;
     t /= tiles_x;
     const int ty = t % tiles_y;
