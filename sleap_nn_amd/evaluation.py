@@ -11,6 +11,7 @@ Host-side NumPy by design: a few hundred instances per epoch, nothing for a GPU 
 """
 from __future__ import annotations
 
+import warnings
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -176,8 +177,8 @@ class EpochEndEvaluator:
             if g.ndim == 4:
                 g = g[0]  # the n_samples axis
             self._pred.append(k)
-            with np.errstate(invalid="ignore"), __import__("warnings").catch_warnings():
-                __import__("warnings").simplefilter("ignore", RuntimeWarning)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore", RuntimeWarning)  # an all-NaN (padding) instance: nanmean -> NaN, dropped by the Evaluator
                 self._score.append(np.nanmean(v, axis=-1))  # instance score = mean peak value (callbacks.py:1366-1370)
             self._gt.append((g / eff[i])[: int(num_instances[i])])
 
