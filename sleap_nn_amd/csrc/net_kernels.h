@@ -23,6 +23,8 @@ struct ConvArgs {
   int accumulate = 0;      // epilogue adds the existing dst value (gradient accumulation in the backward pass)
   int dma_stagger = 1;     // LDS-DMA kernel: SIMD-partner waves issue their DMA piece at different points of a step
   const float* wpack_wino = nullptr;  // Winograd F(2,3)-along-x weights in LDS order (conv3x3_wino_persist_kernel), or nullptr
+  const float* wpack_wino2 = nullptr; // Winograd F(2x2,3x3) weights in LDS order (conv3x3_wino2d_kernel, N tile 64), or nullptr
+  int use_wino2d = 1;  // N-tile-64 layers on the F(2x2,3x3) kernel where wpack_wino2 exists (handle option "conv_wino2d")
   const float* w16 = nullptr;  // [tap][ci 16][co 16] weights for conv3x3_c16_kernel (16 -> 16 channel layers), or nullptr
   float* dst_pool = nullptr;  // optional fused 2x2/2 max pool of the (ReLU'd) output, NHWC ceil(H/2) x ceil(W/2); nullptr = off
   // kernel selection, filled from the model handle's options (ph_model_set_option)
@@ -117,6 +119,11 @@ int launch_wino_pack(const float* wpack, float* wino, int panels, int bn, hipStr
 int64_t wino_pack_floats(int panels, int bn);
 int launch_stem_wino_pack(const float* w1, float* w1w, hipStream_t s);  // [tap][co][ci] -> [kernel row][m index][co][ci]
 int launch_conv3x3_dma(const ConvArgs& a, hipStream_t s);
+// wpack [panel][tap 9][bn][16] -> F(2x2,3x3) weights [panel][g 2][xi 4][nu 4][n tile][lh][lx][4] (see conv3x3_wino2d_kernel)
+int launch_wino2d_pack(const float* wpack, float* wino, int panels, int bn, hipStream_t s);
+int64_t wino2d_pack_floats(int panels, int bn);
+int launch_conv3x3_wino2d(const ConvArgs& a, hipStream_t s);
+int prepare_wino2d_kernels();
 int launch_input_conv(const InputConvArgs& a, hipStream_t s);
 int launch_pool(const float* src, float* dst, int B, int H, int W, int cp, hipStream_t s);
 int launch_upsample(const float* src, float* dst, int B, int H, int W, int cp, hipStream_t s);
