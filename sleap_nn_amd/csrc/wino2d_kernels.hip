@@ -38,13 +38,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int W2_T = 16;                                   // output tile edge
 constexpr int W2_HW = W2_T + 2;                            // halo edge
 constexpr int W2_NPIX = W2_HW * W2_HW;                     // 324 halo pixels
-constexpr int W2_A_PIECES = (W2_NPIX + 15) / 16;           // 21 pieces of 16 pixels x 16 channels (1 KiB)
-constexpr int W2_A_FLOATS = W2_A_PIECES * 256;             // 5376
-constexpr int W2_A1_OFF = 8192;                            // second halo buffer; [5376, 8192) is spare, so that either halo buffer
-                                                           // plus the spare is a contiguous 32-KiB exchange area
-constexpr int W2_B_OFF = W2_A1_OFF + W2_A_FLOATS;          // 13568
+constexpr int W2_AH_PIECES = (W2_NPIX + 31) / 32;          // 11 pieces of 32 pixels x 8 channels (1 KiB) per half chunk
+constexpr int W2_AH_FLOATS = W2_AH_PIECES * 256;           // 2816: one halo half-slot
 constexpr int W2_BH_FLOATS = 8192;                         // half a chunk of weights (N tile 64): 32 pieces
-constexpr int W2_LDS_FLOATS = W2_B_OFF + 3 * W2_BH_FLOATS; // 38144 floats = 149 KiB
+constexpr int W2_B_OFF = 4 * W2_AH_FLOATS;                 // 11264: four halo half-slots, then three weight half-slots
+constexpr int W2_S_OFF = W2_B_OFF + 3 * W2_BH_FLOATS;      // 35840: 20 KiB spare (epilogue exchange overflow)
+constexpr int W2_LDS_FLOATS = W2_S_OFF + 5120;             // 40960 floats = 160 KiB
 
 __device__ __forceinline__ void w2_deal_tile(int id, int tiles, int nt_count, int* tile, int* ntile) {
   // same dealing as deal_tile (net_kernels.hip): every XCD walks a contiguous range of pixel tiles
@@ -91,13 +90,19 @@ int launch_wino2d_pack(const float* wpack, float* wino, int panels, int bn, hipS
   return PH_OK;
 }
 
+// The K loop runs in HALF chunks (8 input channels).  Half k of the workgroup's running count reads weight half-slot k % 3 and
+// the A fragments that were transformed during half k - 1 from halo half-slot k % 4; during half k the waves transform the
+// fragments of half k + 1 (slot (k + 1) % 4) and issue the LDS-DMA of the weights of half k + 2 (slot (k + 2) % 3, read
+// last in half k - 1) and of the halo of half k + 3 (slot (k + 3) % 4, read last in half k - 2): six DMA instructions per
+// wave and half.  A half ends with s_waitcnt vmcnt(6) + s_barrier: every wave has then retired what it issued during the
+// PREVIOUS half, so whatever half k + 1 reads is in LDS and visible -- each transfer has between one and two halves
+// (1.7 - 3.4 us) to land, and nothing issued recently is ever waited for.  The counters run on across tiles (persistent
+// workgroup): the fetch cursors walk into the next tile while the current one is still being multiplied.
 template <int BN>
 __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_kernel(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int NT = BN / 32;
   static_assert(BN == 64, "N tile 64");
-  constexpr int A_SLOTS = (W2_A_PIECES + 7) / 8;  // 3 halo pieces per wave
-  constexpr int B_SLOTS = 32 * NT / 2 / 8;        // 4 weight pieces per wave and half chunk
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -111,12 +116,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_kernel(ConvArgs a) {
   const int chunks0 = a.c0p / 16;
   const int chunks1 = a.c1p / 16;
   const int nchunks = chunks0 + chunks1;
-  const int dq = lane >> 4, dr = lane & 15;
   const int lx = lane & 31, lh = lane >> 5;
 
-  struct Plan {
-    int a_pix[A_SLOTS];
-    unsigned a_ok;
+  struct Plan {  // workgroup-uniform
     int b, x0, y0, ntile;
   };
   auto setup = [&](int vid, Plan& P) {
@@ -129,55 +131,92 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_kernel(ConvArgs a) {
     P.x0 = tx * W2_T;
     P.y0 = ty * W2_T;
     P.ntile = ntile;
-    P.a_ok = 0;
-#pragma unroll
-    for (int s = 0; s < A_SLOTS; ++s) {
-      const int p = min(wave + 8 * s, W2_A_PIECES - 1);
-      const int pix = p * 16 + dr;
-      const int hy = pix / W2_HW, hx = pix - hy * W2_HW;
-      const int gy = P.y0 + hy - 1, gx = P.x0 + hx - 1;
-      const bool in = (pix < W2_NPIX) && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-      P.a_ok |= (in ? 1u : 0u) << s;
-      const int cy = min(max(gy, 0), a.H - 1), cx = min(max(gx, 0), a.W - 1);
-      P.a_pix[s] = (P.b * a.H + cy) * a.W + cx;
-    }
   };
 
-  const float* p_src = a.src0;
-  const float* p_w = a.wpack_wino2;
-  int p_cp = a.c0p, p_coff = 0;
-  int f_pix[A_SLOTS];
-  unsigned f_ok = 0;
-  auto select_fetch = [&](const Plan& P, int ch) {
+  Plan P, Pn;
+  bool has_next = false;
+
+  // ---- halo fetch cursor (three halves ahead of the multiplication): per-lane source pointers of its two pieces
+  const float* fa[2];
+  unsigned fa_ok = 0;  // bit s: the lane's pixel of piece s is inside the image (else it reads the zero page and never advances)
+  int fa_left = 0, fa_src = 0;
+  bool fa_more = false;
+  Plan FA;
+  auto a_point = [&](const float* src, int cp) {  // this lane's halo pixel in DMA pieces (wave, min(wave + 8, 10)) of tile FA
+    fa_ok = 0;
 #pragma unroll
-    for (int s = 0; s < A_SLOTS; ++s) f_pix[s] = P.a_pix[s];
-    f_ok = P.a_ok;
-    if (ch < chunks0) {
-      p_src = a.src0;
-      p_cp = a.c0p;
-      p_coff = ch * 16;
-    } else {
-      p_src = a.src1;
-      p_cp = a.c1p;
-      p_coff = (ch - chunks0) * 16;
+    for (int s = 0; s < 2; ++s) {
+      const int p = s == 0 ? wave : min(wave + 8, W2_AH_PIECES - 1);
+      const int pix = p * 32 + lx;
+      const int hy = pix / W2_HW, hx = pix - hy * W2_HW;
+      const int gy = FA.y0 + hy - 1, gx = FA.x0 + hx - 1;
+      const bool in = src != a.zeros && (pix < W2_NPIX) && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+      fa_ok |= (in ? 1u : 0u) << s;
+      fa[s] = in ? src + ((size_t)(FA.b * a.H + gy) * a.W + gx) * cp + lh * 4 : a.zeros + lh * 4;
     }
-    p_w = a.wpack_wino2 + ((size_t)P.ntile * nchunks + ch) * (2 * W2_BH_FLOATS);
   };
-  auto dma_a = [&](int s, float* abuf) {
-    const int p = min(wave + 8 * s, W2_A_PIECES - 1);
-    const float* real = p_src + (size_t)f_pix[s] * p_cp + p_coff + dq * 4;
-    const float* zero = a.zeros + dq * 4;
-    const float* g = ((f_ok >> s) & 1u) ? real : zero;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)(abuf + p * 256), 16, 0, 0);
+  auto a_enter_tile = [&](const Plan& Q) {
+    FA = Q;
+    fa_src = 0;
+    fa_left = 2 * chunks0;
+    a_point(a.src0, a.c0p);
   };
-  auto dma_b = [&](int s, int half, float* bhalf) {  // wave w moves pieces 4w .. 4w+3 of a half chunk
-    const int pb = wave * B_SLOTS + s;
-    const float* g = p_w + half * W2_BH_FLOATS + pb * 256 + lane * 4;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)(bhalf + pb * 256), 16, 0, 0);
+  auto a_advance = [&]() {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) fa[s] += ((fa_ok >> s) & 1u) ? 8 : 0;
+    if (--fa_left == 0) {  // workgroup-uniform
+      if (fa_src == 0 && chunks1 > 0) {
+        fa_src = 1;
+        fa_left = 2 * chunks1;
+        a_point(a.src1, a.c1p);
+      } else if (fa_more) {
+        fa_more = false;
+        a_enter_tile(Pn);
+      } else {  // nothing left to fetch: keep issuing (the vmcnt bookkeeping wants six per half) from the zero page
+        fa_left = 0x40000000;
+        a_point(a.zeros, 0);
+      }
+    }
+  };
+  auto a_issue = [&](int s, float* slot) {
+    const int p = s == 0 ? wave : min(wave + 8, W2_AH_PIECES - 1);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)fa[s], (__attribute__((address_space(3))) void*)(slot + p * 256), 16, 0, 0);
+  };
+  // ---- weight fetch cursor (two halves ahead): wave w moves pieces 4w .. 4w+3 of a half (one address, immediate offsets)
+  const float* fb = a.wpack_wino2;
+  int fb_left = 0;
+  bool fb_more = false;
+  const int fb_lane = wave * 1024 + lane * 4;
+  auto b_enter_tile = [&](const Plan& Q) {
+    fb = a.wpack_wino2 + (size_t)Q.ntile * nchunks * (2 * W2_BH_FLOATS);
+    fb_left = 2 * nchunks;
+  };
+  auto b_advance = [&]() {
+    fb += W2_BH_FLOATS;
+    if (--fb_left == 0) {
+      if (fb_more) {
+        fb_more = false;
+        b_enter_tile(Pn);
+      } else {
+        fb = a.wpack_wino2;
+        fb_left = 0x40000000;
+      }
+    }
+  };
+  auto b_issue2 = [&](int pair, float* slot) {  // pieces 4w + 2 pair, + 1
+    const float* g = fb + fb_lane;
+    float* l = slot + wave * 1024;
+    if (pair == 0) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 1024, 0);
+    } else {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 2048, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 3072, 0);
+    }
   };
 
   // A side: lane (lx, lh) is Winograd tile (ty = 4 mh + (lx >> 3), tx = lx & 7); wave xi combines patch rows (ra, rb):
-  // xi 0: d0 - d2, xi 1: d1 + d2, xi 2: d2 - d1, xi 3: d1 - d3.  Quad lh (+ 2g) of the pixel.
+  // xi 0: d0 - d2, xi 1: d1 + d2, xi 2: d2 - d1, xi 3: d1 - d3.  Channel quad lh of the half.
   const int ra = xi == 0 ? 0 : (xi == 2 ? 2 : 1);
   const int rb = xi == 0 ? 2 : (xi == 1 ? 2 : (xi == 2 ? 1 : 3));
   const float sgn = xi == 1 ? 1.f : -1.f;
@@ -187,28 +226,63 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_kernel(ConvArgs a) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const int pix = (2 * (4 * mh + (lx >> 3)) + (rr ? rb : ra)) * W2_HW + 2 * (lx & 7) + c;
-      offD[rr][c] = (pix >> 4) * 256 + lh * 64 + (pix & 15) * 4;
+      offD[rr][c] = (pix >> 5) * 256 + lh * 128 + (pix & 31) * 4;
     }
   const int offB = xi * 4 * NT * 256 + lh * 128 + lx * 4;
+  float* const abuf = lds;
   float* const bbuf = lds + W2_B_OFF;
+  float* const spare = lds + W2_S_OFF;
 
-  Plan P, Pn;
+  f32x4 av[4], tt[4];  // fragments of the running half; row xi of B^T d of the next one
+  auto ypass = [&](const float* aslot, int c) {
+    const f32x4 da = *reinterpret_cast<const f32x4*>(aslot + offD[0][c]);
+    const f32x4 db = *reinterpret_cast<const f32x4*>(aslot + offD[1][c]);
+    tt[c] = da + sgn * db;
+    asm volatile("" : "+v"(tt[c]));  // pin: computed here, not sunk to its use in the next half
+  };
+  auto xpass = [&](int nu) {  // fragment nu of the next half replaces the one whose MFMAs have just been issued
+    if (nu == 0)
+      av[0] = tt[0] - tt[2];
+    else if (nu == 1)
+      av[1] = tt[1] + tt[2];
+    else if (nu == 2)
+      av[2] = tt[2] - tt[1];
+    else
+      av[3] = tt[1] - tt[3];
+    asm volatile("" : "+v"(av[nu]));
+  };
+
+  // ---- prologue: halo halves 0..2 and weight halves 0..1 of the first tile, fragments of half 0
   int vid = blockIdx.x;
   setup(vid, P);
-  select_fetch(P, 0);
-#pragma unroll
-  for (int s = 0; s < A_SLOTS; ++s) dma_a(s, lds);
-#pragma unroll
-  for (int s = 0; s < B_SLOTS; ++s) dma_b(s, 0, bbuf);
-#pragma unroll
-  for (int s = 0; s < B_SLOTS; ++s) dma_b(s, 1, bbuf + W2_BH_FLOATS);
-  __syncthreads();
-  int apar = 0;  // halo buffer of the running chunk
-  int hb = 0;    // weight half-slot of the running chunk's first half; the second half sits in (hb + 1) % 3
-  while (true) {
+  {
     const int nvid = vid + gridDim.x;
-    const bool has_next = nvid < total;  // workgroup-uniform
+    has_next = nvid < total;
     if (has_next) setup(nvid, Pn);
+    fa_more = fb_more = has_next;
+  }
+  a_enter_tile(P);
+  b_enter_tile(P);
+#pragma unroll
+  for (int h = 0; h < 3; ++h) {
+    a_issue(0, abuf + h * W2_AH_FLOATS);
+    a_issue(1, abuf + h * W2_AH_FLOATS);
+    a_advance();
+  }
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    b_issue2(0, bbuf + h * W2_BH_FLOATS);
+    b_issue2(1, bbuf + h * W2_BH_FLOATS);
+    b_advance();
+  }
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < 4; ++c) ypass(abuf, c);
+#pragma unroll
+  for (int nu = 0; nu < 4; ++nu) xpass(nu);
+  int ka = 0;  // halo half-slot of the running half (its fragments are already in av)
+  int kb = 0;  // weight half-slot of the running half
+  while (true) {
     f32x16 acc[4][NT];
 #pragma unroll
     for (int x = 0; x < 4; ++x)
@@ -217,69 +291,65 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_kernel(ConvArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[x][n][r] = 0.f;
     for (int ch = 0; ch < nchunks; ++ch) {
-      const float* acur = lds + (apar ? W2_A1_OFF : 0);
-      float* anxt = lds + (apar ? 0 : W2_A1_OFF);
-      const int h1 = hb == 2 ? 0 : hb + 1, h2 = h1 == 2 ? 0 : h1 + 1;
-      const float* b_first = bbuf + hb * W2_BH_FLOATS;
-      const float* b_second = bbuf + h1 * W2_BH_FLOATS;
-      float* bn_first = bbuf + h2 * W2_BH_FLOATS;   // next chunk, first half: free since the previous chunk ended
-      float* bn_second = bbuf + hb * W2_BH_FLOATS;  // next chunk, second half: free after this chunk's mid barrier
-      if (ch + 1 < nchunks)
-        select_fetch(P, ch + 1);
-      else if (has_next)
-        select_fetch(Pn, 0);  // the next tile's first chunk rides under this tile's last one
-      else
-        select_fetch(P, ch);  // nothing left: refetch (harmless)
-      f32x4 av[2][4], bf[2][NT];
-      auto make_a = [&](int g, int slot) {
-        f32x4 t[4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const f32x4 da = *reinterpret_cast<const f32x4*>(acur + offD[0][c] + g * 128);
-          const f32x4 db = *reinterpret_cast<const f32x4*>(acur + offD[1][c] + g * 128);
-          t[c] = da + sgn * db;
-        }
-        av[slot][0] = t[0] - t[2];
-        av[slot][1] = t[1] + t[2];
-        av[slot][2] = t[2] - t[1];
-        av[slot][3] = t[1] - t[3];
-      };
-      auto load_b = [&](int q, int fb) {
-        const float* base = ((q >> 2) == 0 ? b_first : b_second) + (q & 3) * NT * 256 + offB;
+      for (int g = 0; g < 2; ++g) {
+        const float* bcur = bbuf + kb * W2_BH_FLOATS + offB;
+        float* bdst = bbuf + (kb == 0 ? 2 : kb - 1) * W2_BH_FLOATS;   // (kb + 2) % 3
+        const float* atr = abuf + ((ka + 1) & 3) * W2_AH_FLOATS;      // halo of the next half
+        float* adst = abuf + ((ka + 3) & 3) * W2_AH_FLOATS;
+        f32x4 bf[2][NT];
+        auto load_b = [&](int nu, int fbuf) {
 #pragma unroll
-        for (int n = 0; n < NT; ++n) bf[fb][n] = *reinterpret_cast<const f32x4*>(base + n * 256);
-      };
-      make_a(0, 0);
-      load_b(0, 0);
+          for (int n = 0; n < NT; ++n) bf[fbuf][n] = *reinterpret_cast<const f32x4*>(bcur + (nu * NT + n) * 256);
+        };
+        load_b(0, 0);
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int g = q >> 2, nu = q & 3, fcur = q & 1;
-        if (q + 1 < 8) load_b(q + 1, fcur ^ 1);
-        if (q == 1) make_a(1, 1);
-        // DMA: next chunk's halo and first weight half during the first half, its second weight half after the mid barrier
-        if (q < A_SLOTS) dma_a(q, anxt);
-        if (q < B_SLOTS) dma_b(q, 0, bn_first);
-        if (q >= 4 && q < 4 + B_SLOTS) dma_b(q - 4, 1, bn_second);
+        for (int nu = 0; nu < 4; ++nu) {
+          const int fcur = nu & 1;
+          if (nu + 1 < 4) load_b(nu + 1, fcur ^ 1);
+          if (nu == 0) {
+            ypass(atr, 0);
+            ypass(atr, 2);
+            b_issue2(0, bdst);
+          } else if (nu == 1) {
+            ypass(atr, 1);
+            ypass(atr, 3);
+            b_issue2(1, bdst);
+          } else if (nu == 2) {
+            a_issue(0, adst);
+          } else {
+            a_issue(1, adst);
+          }
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+          for (int j = 0; j < 4; ++j)
 #pragma unroll
-          for (int n = 0; n < NT; ++n) acc[nu][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g][nu][j], bf[fcur][n][j], acc[nu][n], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (q == 3) {
-          __builtin_amdgcn_s_barrier();  // every wave is done reading the first weight half: its slot may be refilled
+            for (int n = 0; n < NT; ++n) acc[nu][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[nu][j], bf[fcur][n][j], acc[nu][n], 0, 0, 0);
+          xpass(nu);
           __builtin_amdgcn_sched_barrier(0);
         }
+        a_advance();
+        b_advance();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(0xF76);  // vmcnt(6)
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        ka = (ka + 1) & 3;
+        kb = kb == 2 ? 0 : kb + 1;
       }
-      __syncthreads();
-      apar ^= 1;
-      hb = hb == 0 ? 2 : hb - 1;  // (hb + 2) % 3: the slot the next chunk's first half was fetched into
     }
     // ---- epilogue.  In lane (lx, lh) accumulator register r is tile (ty = 4 mh + (r >> 2), tx = (r & 3) + 4 lh), channel n * 32 + lx.
-    // Free LDS now: weight slot (hb + 2) % 3 and the halo buffer of the finished chunk (+ the spare next to it).
+    // Free LDS until the next half's DMA: weight slot (kb + 2) % 3, halo slots (ka + 3) % 4 ("X") and ka ("Y": the next tile's
+    // first half, already transformed) and the spare.  Slot X and the weight slot are DMA targets of the NEXT half, slot Y of
+    // the one after.
     const int b = P.b, x0 = P.x0, y0 = P.y0, ntile = P.ntile;
     const bool interior = (x0 + W2_T <= a.W) && (y0 + W2_T <= a.H) && ((ntile + 1) * BN <= a.coutp);
-    float* const r1 = bbuf + (hb == 0 ? 2 : hb - 1) * W2_BH_FLOATS;  // (hb + 2) % 3
-    float* const r2 = lds + (apar ? 0 : W2_A_FLOATS);                 // finished buffer A0 -> [0, 8192); A1 -> [5376, 13568)
+    float* const r1 = bbuf + (kb == 0 ? 2 : kb - 1) * W2_BH_FLOATS;
+    float* const slot_x = abuf + ((ka + 3) & 3) * W2_AH_FLOATS;
+    float* const slot_y = abuf + ka * W2_AH_FLOATS;
+    // exchange area of wave xi = 2: 16 groups of 1 KiB per M half -- 11 in a halo slot, 5 in the spare
+    float* const r2a = mh ? slot_y : slot_x;
+    float* const r2b = spare + mh * 5 * 256;
+    auto r2 = [&](int idx) -> float* { return idx < 11 ? r2a + idx * 256 : r2b + (idx - 11) * 256; };
 #pragma unroll
     for (int n = 0; n < NT; ++n)
 #pragma unroll
@@ -289,7 +359,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_kernel(ConvArgs a) {
         acc[1][n][r] = (m1 - m2) - m3;
       }
     if (xi == 1 || xi == 2) {
-      float* const rg = (xi == 1 ? r1 : r2) + lane * 4;
 #pragma unroll
       for (int bb = 0; bb < 2; ++bb)
 #pragma unroll
@@ -301,22 +370,24 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_kernel(ConvArgs a) {
             v[1] = acc[bb][n][4 * k + 1];
             v[2] = acc[bb][n][4 * k + 2];
             v[3] = acc[bb][n][4 * k + 3];
-            *reinterpret_cast<f32x4*>(rg + (((mh * 2 + bb) * NT + n) * 4 + k) * 256) = v;
+            const int idx = (bb * NT + n) * 4 + k;
+            float* dstp = xi == 1 ? r1 + (mh * 16 + idx) * 256 : r2(idx);
+            *reinterpret_cast<f32x4*>(dstp + lane * 4) = v;
           }
     }
-    __syncthreads();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
     if (xi == 0 || xi == 3) {
-      const float* const g1 = r1 + lane * 4;
-      const float* const g2 = r2 + lane * 4;
 #pragma unroll
       for (int bb = 0; bb < 2; ++bb)
 #pragma unroll
         for (int n = 0; n < NT; ++n)
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
-            const int o = (((mh * 2 + bb) * NT + n) * 4 + k) * 256;
-            const f32x4 p1 = *reinterpret_cast<const f32x4*>(g1 + o);
-            const f32x4 p2 = *reinterpret_cast<const f32x4*>(g2 + o);
+            const int idx = (bb * NT + n) * 4 + k;
+            const f32x4 p1 = *reinterpret_cast<const f32x4*>(r1 + (mh * 16 + idx) * 256 + lane * 4);
+            const f32x4 p2 = *reinterpret_cast<const f32x4*>(r2(idx) + lane * 4);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               const float mine = acc[bb][n][4 * k + e];
@@ -324,7 +395,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_kernel(ConvArgs a) {
             }
           }
     }
-    __syncthreads();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
     const int arow = xi == 3 ? 1 : 0;  // output row of the tile this wave finishes
     if (xi == 0 || xi == 3) {
 #pragma unroll
@@ -340,8 +413,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_kernel(ConvArgs a) {
           }
       }
     }
-    if (a.dst_pool) {  // fused 2x2/2 max pool ("same" padding: zeros beyond the image)
-      float* const rp = r1 + lane * 4;
+    if (a.dst_pool) {  // fused 2x2/2 max pool ("same" padding: zeros beyond the image): wave 0's row maxima hop to wave 3
+      float* const rp = (mh ? spare + 10 * 256 : slot_y) + lane * 4;  // 8 groups per M half; neither is a DMA target of the next half
       f32x16 rm[NT];
       if (xi == 0 || xi == 3) {
 #pragma unroll
@@ -367,10 +440,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_kernel(ConvArgs a) {
             v[1] = rm[n][4 * k + 1];
             v[2] = rm[n][4 * k + 2];
             v[3] = rm[n][4 * k + 3];
-            *reinterpret_cast<f32x4*>(rp + ((mh * NT + n) * 4 + k) * 256) = v;
+            *reinterpret_cast<f32x4*>(rp + (n * 4 + k) * 256) = v;
           }
       }
-      __syncthreads();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
       if (xi == 3) {
         const int Hp = (a.H + 1) >> 1, Wp = (a.W + 1) >> 1;
 #pragma unroll
@@ -378,7 +453,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_kernel(ConvArgs a) {
           const int co = ntile * BN + n * 32 + lx;
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
-            const f32x4 top = *reinterpret_cast<const f32x4*>(rp + ((mh * NT + n) * 4 + k) * 256);
+            const f32x4 top = *reinterpret_cast<const f32x4*>(rp + (n * 4 + k) * 256);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               const int r = 4 * k + e;
@@ -388,7 +463,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_kernel(ConvArgs a) {
           }
         }
       }
-      __syncthreads();  // the pool hop's LDS is the next chunk's first DMA target
     }
     if (xi == 0 || xi == 3) {
 #pragma unroll
@@ -416,8 +490,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_kernel(ConvArgs a) {
       }
     }
     if (!has_next) break;
-    vid = nvid;
+    vid += gridDim.x;
     P = Pn;
+    {
+      const int nvid = vid + gridDim.x;
+      has_next = nvid < total;
+      if (has_next) setup(nvid, Pn);
+      fa_more = fb_more = has_next;
+    }
   }
 }
 
@@ -443,7 +523,7 @@ int prepare_wino2d_kernels() {
 
 // 3x3 conv, N tile 64, no accumulation into dst: the caller (launch_conv3x3_dma) checks those.
 int launch_conv3x3_wino2d(const ConvArgs& a, hipStream_t s) {
-  PH_REQUIRE(a.bn == 64 && a.wpack_wino2 && !a.accumulate, "wino2d: N tile 64, transformed weights, no accumulate");
+  PH_REQUIRE(a.bn == 64 && a.wpack_wino2 && !a.accumulate && a.c0p + a.c1p >= 32, "wino2d: N tile 64, transformed weights, no accumulate, at least 32 input channels");
   int n_cu = 0;
   const int rc = w2_cu_count(&n_cu);
   if (rc != PH_OK) return rc;
