@@ -123,6 +123,7 @@ int launch_conv3x3_dma(const ConvArgs& a, hipStream_t s);
 int launch_wino2d_pack(const float* wpack, float* wino, int panels, int bn, hipStream_t s);
 int64_t wino2d_pack_floats(int panels, int bn);
 int launch_conv3x3_wino2d(const ConvArgs& a, hipStream_t s);
+bool wino2d_fits(const ConvArgs& a);  // sources addressable through the kernel's 32-bit buffer descriptors
 int prepare_wino2d_kernels();
 int launch_input_conv(const InputConvArgs& a, hipStream_t s);
 int launch_pool(const float* src, float* dst, int B, int H, int W, int cp, hipStream_t s);

@@ -38,12 +38,14 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int W2_T = 16;                                   // output tile edge
 constexpr int W2_HW = W2_T + 2;                            // halo edge
 constexpr int W2_NPIX = W2_HW * W2_HW;                     // 324 halo pixels
-constexpr int W2_AH_PIECES = (W2_NPIX + 31) / 32;          // 11 pieces of 32 pixels x 8 channels (1 KiB) per half chunk
-constexpr int W2_AH_FLOATS = W2_AH_PIECES * 256;           // 2816: one halo half-slot
+constexpr int W2_PL_PIECES = (W2_NPIX + 63) / 64;          // 6 DMA pieces (64 pixels x one 4-channel quad, 1 KiB) per quad plane
+constexpr int W2_PL_FLOATS = W2_PL_PIECES * 256;           // 1536: a half-slot is two planes [quad][pixel hy * 18 + hx][4]
+constexpr int W2_AH_PIECES = 2 * W2_PL_PIECES;             // 12 pieces per half chunk (8 channels)
+constexpr int W2_AH_FLOATS = W2_AH_PIECES * 256;           // 3072: one halo half-slot
 constexpr int W2_BH_FLOATS = 8192;                         // half a chunk of weights (N tile 64): 32 pieces
-constexpr int W2_B_OFF = 4 * W2_AH_FLOATS;                 // 11264: four halo half-slots, then three weight half-slots
-constexpr int W2_S_OFF = W2_B_OFF + 3 * W2_BH_FLOATS;      // 35840: 20 KiB spare (epilogue exchange overflow)
-constexpr int W2_LDS_FLOATS = W2_S_OFF + 5120;             // 40960 floats = 160 KiB
+constexpr int W2_B_OFF = 4 * W2_AH_FLOATS;                 // 12288: four halo half-slots, then three weight half-slots
+constexpr int W2_S_OFF = W2_B_OFF + 3 * W2_BH_FLOATS;      // 36864: 16 KiB spare (epilogue exchange overflow)
+constexpr int W2_LDS_FLOATS = W2_S_OFF + 4096;             // 40960 floats = 160 KiB
 
 __device__ __forceinline__ void w2_deal_tile(int id, int tiles, int nt_count, int* tile, int* ntile) {
   // same dealing as deal_tile (net_kernels.hip): every XCD walks a contiguous range of pixel tiles
@@ -136,23 +138,27 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_kernel(ConvArgs a) {
   Plan P, Pn;
   bool has_next = false;
 
-  // ---- halo fetch cursor (three halves ahead of the multiplication): per-lane source pointers of its two pieces
-  const float* fa[2];
-  unsigned fa_ok = 0;  // bit s: the lane's pixel of piece s is inside the image (else it reads the zero page and never advances)
-  int fa_left = 0, fa_src = 0;
+  // ---- halo fetch cursor (three halves ahead of the multiplication).  Pieces go through a buffer descriptor of the source
+  // tensor: the per-lane part of the address is one 32-bit byte offset per piece, fixed for a (tile, source); the half's channel
+  // offset rides in the scalar offset, so a half costs no vector instruction; out-of-image pixels (and the unused tail of a
+  // plane) get an offset beyond the descriptor's range and the hardware returns zeros ("same" padding).
+  unsigned fa_off[2];
+  int fa_soff = 0, fa_left = 0, fa_src = 0;
   bool fa_more = false;
   Plan FA;
-  auto a_point = [&](const float* src, int cp) {  // this lane's halo pixel in DMA pieces (wave, min(wave + 8, 10)) of tile FA
-    fa_ok = 0;
+  __amdgpu_buffer_rsrc_t fa_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.src0, 0, (int)((unsigned)(a.B * a.H * a.W) * (unsigned)(a.c0p * 4)), 0x00020000);
+  auto a_point = [&](const float* src, int cp) {  // this lane's halo pixel in DMA pieces (wave, min(wave + 8, 11)) of tile FA
+    fa_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, (int)((unsigned)(a.B * a.H * a.W) * (unsigned)(cp * 4)), 0x00020000);
+    fa_soff = 0;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       const int p = s == 0 ? wave : min(wave + 8, W2_AH_PIECES - 1);
-      const int pix = p * 32 + lx;
+      const int q2 = p >= W2_PL_PIECES ? 1 : 0;
+      const int pix = (p - q2 * W2_PL_PIECES) * 64 + lane;
       const int hy = pix / W2_HW, hx = pix - hy * W2_HW;
       const int gy = FA.y0 + hy - 1, gx = FA.x0 + hx - 1;
-      const bool in = src != a.zeros && (pix < W2_NPIX) && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-      fa_ok |= (in ? 1u : 0u) << s;
-      fa[s] = in ? src + ((size_t)(FA.b * a.H + gy) * a.W + gx) * cp + lh * 4 : a.zeros + lh * 4;
+      const bool in = cp > 0 && (pix < W2_NPIX) && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+      fa_off[s] = in ? ((unsigned)((FA.b * a.H + gy) * a.W + gx) * (unsigned)cp + q2 * 4) * 4u : 0xFFFFFF00u;
     }
   };
   auto a_enter_tile = [&](const Plan& Q) {
@@ -161,9 +167,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_kernel(ConvArgs a) {
     fa_left = 2 * chunks0;
     a_point(a.src0, a.c0p);
   };
-  auto a_advance = [&]() {
-#pragma unroll
-    for (int s = 0; s < 2; ++s) fa[s] += ((fa_ok >> s) & 1u) ? 8 : 0;
+  auto a_advance = [&]() {  // scalar only
+    fa_soff += 32;
     if (--fa_left == 0) {  // workgroup-uniform
       if (fa_src == 0 && chunks1 > 0) {
         fa_src = 1;
@@ -172,83 +177,81 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_kernel(ConvArgs a) {
       } else if (fa_more) {
         fa_more = false;
         a_enter_tile(Pn);
-      } else {  // nothing left to fetch: keep issuing (the vmcnt bookkeeping wants six per half) from the zero page
+      } else {  // nothing left to fetch: keep issuing (the vmcnt bookkeeping wants six per half), every lane out of range
         fa_left = 0x40000000;
-        a_point(a.zeros, 0);
+        a_point(a.src0, 0);
       }
     }
   };
   auto a_issue = [&](int s, float* slot) {
     const int p = s == 0 ? wave : min(wave + 8, W2_AH_PIECES - 1);
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)fa[s], (__attribute__((address_space(3))) void*)(slot + p * 256), 16, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(fa_rsrc, (__attribute__((address_space(3))) void*)(slot + p * 256), 16, fa_off[s], fa_soff, 0, 0);
   };
-  // ---- weight fetch cursor (two halves ahead): wave w moves pieces 4w .. 4w+3 of a half (one address, immediate offsets)
-  const float* fb = a.wpack_wino2;
-  int fb_left = 0;
+  // ---- weight fetch cursor (two halves ahead): wave w moves pieces 4w .. 4w+3 of a half (one lane offset, immediate offsets)
+  const __amdgpu_buffer_rsrc_t fb_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.wpack_wino2, 0, (int)((unsigned)ntc * (unsigned)nchunks * (unsigned)(2 * W2_BH_FLOATS * 4)), 0x00020000);
+  int fb_soff = 0, fb_left = 0;
   bool fb_more = false;
-  const int fb_lane = wave * 1024 + lane * 4;
+  const unsigned fb_lane = (unsigned)(wave * 1024 + lane * 4) * 4u;
   auto b_enter_tile = [&](const Plan& Q) {
-    fb = a.wpack_wino2 + (size_t)Q.ntile * nchunks * (2 * W2_BH_FLOATS);
+    fb_soff = Q.ntile * nchunks * (2 * W2_BH_FLOATS * 4);
     fb_left = 2 * nchunks;
   };
   auto b_advance = [&]() {
-    fb += W2_BH_FLOATS;
+    fb_soff += W2_BH_FLOATS * 4;
     if (--fb_left == 0) {
       if (fb_more) {
         fb_more = false;
         b_enter_tile(Pn);
       } else {
-        fb = a.wpack_wino2;
+        fb_soff = 0;
         fb_left = 0x40000000;
       }
     }
   };
   auto b_issue2 = [&](int pair, float* slot) {  // pieces 4w + 2 pair, + 1
-    const float* g = fb + fb_lane;
-    float* l = slot + wave * 1024;
+    __attribute__((address_space(3))) void* l = (__attribute__((address_space(3))) void*)(slot + wave * 1024);
     if (pair == 0) {
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 1024, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(fb_rsrc, l, 16, fb_lane, fb_soff, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(fb_rsrc, l, 16, fb_lane, fb_soff, 1024, 0);
     } else {
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 2048, 0);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 3072, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(fb_rsrc, l, 16, fb_lane, fb_soff, 2048, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(fb_rsrc, l, 16, fb_lane, fb_soff, 3072, 0);
     }
   };
 
   // A side: lane (lx, lh) is Winograd tile (ty = 4 mh + (lx >> 3), tx = lx & 7); wave xi combines patch rows (ra, rb):
-  // xi 0: d0 - d2, xi 1: d1 + d2, xi 2: d2 - d1, xi 3: d1 - d3.  Channel quad lh of the half.
+  // xi 0: d0 - d2, xi 1: d1 + d2, xi 2: d2 - d1, xi 3: d1 - d3.  Channel quad lh of the half = plane lh of the slot; the four
+  // columns of a patch row are 16 B apart (immediate offsets of the ds_read).
   const int ra = xi == 0 ? 0 : (xi == 2 ? 2 : 1);
   const int rb = xi == 0 ? 2 : (xi == 1 ? 2 : (xi == 2 ? 1 : 3));
-  const float sgn = xi == 1 ? 1.f : -1.f;
-  int offD[2][4];
-#pragma unroll
-  for (int rr = 0; rr < 2; ++rr)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const int pix = (2 * (4 * mh + (lx >> 3)) + (rr ? rb : ra)) * W2_HW + 2 * (lx & 7) + c;
-      offD[rr][c] = (pix >> 5) * 256 + lh * 128 + (pix & 31) * 4;
-    }
+  float sgn = xi == 1 ? 1.f : -1.f;
+  float m1 = -1.f;
+  asm volatile("" : "+v"(m1));  // opaque: keeps x - y as fma(y, m1, x), which packs two lanes per instruction (v_pk_fma_f32)
+  const int lbase = lh * W2_PL_FLOATS + ((2 * (4 * mh + (lx >> 3))) * W2_HW + 2 * (lx & 7)) * 4;
+  const int offRA = lbase + ra * W2_HW * 4, offRB = lbase + rb * W2_HW * 4;
   const int offB = xi * 4 * NT * 256 + lh * 128 + lx * 4;
   float* const abuf = lds;
   float* const bbuf = lds + W2_B_OFF;
   float* const spare = lds + W2_S_OFF;
 
-  f32x4 av[4], tt[4];  // fragments of the running half; row xi of B^T d of the next one
-  auto ypass = [&](const float* aslot, int c) {
-    const f32x4 da = *reinterpret_cast<const f32x4*>(aslot + offD[0][c]);
-    const f32x4 db = *reinterpret_cast<const f32x4*>(aslot + offD[1][c]);
-    tt[c] = da + sgn * db;
+  f32x4 av[4], tt[4], da[2], db[2];  // fragments of the running half; row xi of B^T d of the next one; raw patch rows in flight
+  auto aread = [&](const float* aslot, int i, int c) {
+    da[i] = *reinterpret_cast<const f32x4*>(aslot + offRA + c * 4);
+    db[i] = *reinterpret_cast<const f32x4*>(aslot + offRB + c * 4);
+  };
+  auto ypass = [&](int i, int c) {
+    tt[c] = da[i] + sgn * db[i];
     asm volatile("" : "+v"(tt[c]));  // pin: computed here, not sunk to its use in the next half
   };
   auto xpass = [&](int nu) {  // fragment nu of the next half replaces the one whose MFMAs have just been issued
     if (nu == 0)
-      av[0] = tt[0] - tt[2];
+      av[0] = tt[2] * m1 + tt[0];
     else if (nu == 1)
       av[1] = tt[1] + tt[2];
     else if (nu == 2)
-      av[2] = tt[2] - tt[1];
+      av[2] = tt[1] * m1 + tt[2];
     else
-      av[3] = tt[1] - tt[3];
+      av[3] = tt[3] * m1 + tt[1];
     asm volatile("" : "+v"(av[nu]));
   };
 
@@ -277,7 +280,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_kernel(ConvArgs a) {
   }
   __syncthreads();
 #pragma unroll
-  for (int c = 0; c < 4; ++c) ypass(abuf, c);
+  for (int c = 0; c < 4; ++c) {
+    aread(abuf, 0, c);
+    ypass(0, c);
+  }
 #pragma unroll
   for (int nu = 0; nu < 4; ++nu) xpass(nu);
   int ka = 0;  // halo half-slot of the running half (its fragments are already in av)
@@ -303,30 +309,52 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_kernel(ConvArgs a) {
           for (int n = 0; n < NT; ++n) bf[fbuf][n] = *reinterpret_cast<const f32x4*>(bcur + (nu * NT + n) * 256);
         };
         load_b(0, 0);
+        // Pinned order inside a step: its first MFMAs, THEN the LDS reads of the next step (the compiler's wait before a step's
+        // first MFMA is lgkmcnt(0): reads issued before it would be drained on the spot), then the transform arithmetic of patch
+        // rows read one step earlier and the DMA issue, then the remaining MFMAs.
 #pragma unroll
         for (int nu = 0; nu < 4; ++nu) {
           const int fcur = nu & 1;
+#pragma unroll
+          for (int n = 0; n < NT; ++n) acc[nu][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[nu][0], bf[fcur][n][0], acc[nu][n], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
           if (nu + 1 < 4) load_b(nu + 1, fcur ^ 1);
           if (nu == 0) {
-            ypass(atr, 0);
-            ypass(atr, 2);
+            aread(atr, 0, 0);
+            aread(atr, 1, 2);
+          } else if (nu == 1) {
+            ypass(0, 0);
+            ypass(1, 2);
+            __builtin_amdgcn_sched_barrier(0);
+            aread(atr, 0, 1);
+            aread(atr, 1, 3);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int n = 0; n < NT; ++n) acc[nu][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[nu][1], bf[fcur][n][1], acc[nu][n], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          if (nu == 0) {
             b_issue2(0, bdst);
           } else if (nu == 1) {
-            ypass(atr, 1);
-            ypass(atr, 3);
+            xpass(0);
             b_issue2(1, bdst);
           } else if (nu == 2) {
+            ypass(0, 1);
+            ypass(1, 3);
+            xpass(1);
             a_issue(0, adst);
           } else {
+            xpass(2);
             a_issue(1, adst);
           }
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int j = 0; j < 4; ++j)
+          for (int j = 2; j < 4; ++j)
 #pragma unroll
             for (int n = 0; n < NT; ++n) acc[nu][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[nu][j], bf[fcur][n][j], acc[nu][n], 0, 0, 0);
-          xpass(nu);
           __builtin_amdgcn_sched_barrier(0);
         }
+        xpass(3);
         a_advance();
         b_advance();
         __builtin_amdgcn_sched_barrier(0);
@@ -346,10 +374,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_kernel(ConvArgs a) {
     float* const r1 = bbuf + (kb == 0 ? 2 : kb - 1) * W2_BH_FLOATS;
     float* const slot_x = abuf + ((ka + 3) & 3) * W2_AH_FLOATS;
     float* const slot_y = abuf + ka * W2_AH_FLOATS;
-    // exchange area of wave xi = 2: 16 groups of 1 KiB per M half -- 11 in a halo slot, 5 in the spare
+    // exchange area of wave xi = 2: 16 groups of 1 KiB per M half -- 12 in a halo slot, 4 in the spare
     float* const r2a = mh ? slot_y : slot_x;
-    float* const r2b = spare + mh * 5 * 256;
-    auto r2 = [&](int idx) -> float* { return idx < 11 ? r2a + idx * 256 : r2b + (idx - 11) * 256; };
+    float* const r2b = spare + mh * 4 * 256;
+    auto r2 = [&](int idx) -> float* { return idx < 12 ? r2a + idx * 256 : r2b + (idx - 12) * 256; };
 #pragma unroll
     for (int n = 0; n < NT; ++n)
 #pragma unroll
@@ -414,7 +442,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_kernel(ConvArgs a) {
       }
     }
     if (a.dst_pool) {  // fused 2x2/2 max pool ("same" padding: zeros beyond the image): wave 0's row maxima hop to wave 3
-      float* const rp = (mh ? spare + 10 * 256 : slot_y) + lane * 4;  // 8 groups per M half; neither is a DMA target of the next half
+      float* const rp = (mh ? spare + 8 * 256 : slot_y) + lane * 4;  // 8 groups per M half; neither is a DMA target of the next half
       f32x16 rm[NT];
       if (xi == 0 || xi == 3) {
 #pragma unroll
@@ -521,9 +549,14 @@ int prepare_wino2d_kernels() {
   return PH_OK;
 }
 
+// The halo DMA addresses a source through a 32-bit buffer descriptor: each source tensor must stay below 4 GiB.
+bool wino2d_fits(const ConvArgs& a) {
+  const uint64_t px = (uint64_t)a.B * a.H * a.W;
+  return px * (uint64_t)a.c0p * 4 < 0xFFFFFF00ull && px * (uint64_t)a.c1p * 4 < 0xFFFFFF00ull && px < 0x7FFFFFFFull;
+}
 // 3x3 conv, N tile 64, no accumulation into dst: the caller (launch_conv3x3_dma) checks those.
 int launch_conv3x3_wino2d(const ConvArgs& a, hipStream_t s) {
-  PH_REQUIRE(a.bn == 64 && a.wpack_wino2 && !a.accumulate && a.c0p + a.c1p >= 32, "wino2d: N tile 64, transformed weights, no accumulate, at least 32 input channels");
+  PH_REQUIRE(a.bn == 64 && a.wpack_wino2 && !a.accumulate && a.c0p + a.c1p >= 32 && wino2d_fits(a), "wino2d: N tile 64, transformed weights, no accumulate, at least 32 input channels, sources below 4 GiB");
   int n_cu = 0;
   const int rc = w2_cu_count(&n_cu);
   if (rc != PH_OK) return rc;
