@@ -397,19 +397,44 @@ def run_infer(args, ctx):
     stack_flops = sum(r["flops"] for r, _ in stack_rows)
     stack_ms = sum(ms for _, ms in stack_rows)
     fwd_ms = sum(op_ms) / max(n_fw, 1)
-    # FLOP accounting.  `direct_tflops` prices a launch at the direct-convolution count 2*Cin*Cout*9*H*W.  The kernel
-    # that runs is Winograd F(2,3) along x: 4 multiplications per output pair and kernel row instead of 6, i.e. 2/3 of those
-    # FLOPs go through the matrix cores (the input/output transforms are VALU adds).  `achieved` is what the MFMA pipe executes --
-    # the figure a roofline against the MFMA peak is about; the direct-equivalent rate is reported next to it and is NOT a
-    # roofline fraction (it exceeds 1 by construction when the pipe is > 2/3 busy).
-    direct_tflops = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+    # FLOP accounting.  `direct_tflops` prices a launch at the direct-convolution count 2*Cin*Cout*9*H*W.  The kernels
+    # that run are Winograd forms: conv3x3_wino2d_kernel<64> (F(2x2,3x3): 16 multiplications per four outputs instead of 36, i.e.
+    # 4/9 of those FLOPs go through the matrix cores) for the N-tile-64 layers with >= 32 input channels, and
+    # conv3x3_wino_persist_kernel (F(2,3) along x: 2/3) for the rest; the input / output transforms are VALU adds.  `achieved` is
+    # what the MFMA pipe EXECUTES in the launches of the dominant kernel over their duration -- the figure a roofline against the
+    # MFMA peak is about; the direct-equivalent rate is reported next to it and is NOT a roofline fraction.
+    pad16 = lambda c: (c + 15) // 16 * 16
     wino = model._options.get("conv_wino", 1.0) != 0.0
-    mfma_share = 2.0 / 3.0 if wino else 1.0
-    achieved = direct_tflops * mfma_share
+    wino2d = wino and model._options.get("conv_wino2d", 1.0) != 0.0
+
+    def conv_kernel(r):
+        if fp16:
+            return "f16", (3.0 if precision == "split" else 1.0)
+        if not wino:
+            return "direct", 1.0
+        if wino2d and pad16(r["cout"]) >= 64 and pad16(r["cin0"]) + (pad16(r["cin1"]) if r["cin1"] else 0) >= 32:
+            return "wino2d", 4.0 / 9.0
+        return "wino1d", 2.0 / 3.0
+
+    by_kernel = {}
+    for r, ms in conv_rows:
+        kname, share = conv_kernel(r)
+        e = by_kernel.setdefault(kname, {"launches": 0, "ms": 0.0, "direct_flops": 0.0, "executed_flops": 0.0, "bytes": 0.0})
+        e["launches"] += 1
+        e["ms"] += ms
+        e["direct_flops"] += r["flops"]
+        e["executed_flops"] += r["flops"] * share
+        e["bytes"] += r["bytes"]
+    dom = max(by_kernel, key=lambda k: by_kernel[k]["ms"]) if by_kernel else "direct"
+    D = by_kernel.get(dom, {"launches": 0, "ms": 0.0, "direct_flops": 0.0, "executed_flops": 0.0, "bytes": 0.0})
+    direct_tflops = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+    achieved = D["executed_flops"] / (D["ms"] * 1e-3) / 1e12 if D["ms"] > 0 else 0.0
+    executed_all = sum(e["executed_flops"] for e in by_kernel.values())
     peak = MFMA_F16_PEAK_TFLOPS if fp16 else MFMA_F32_PEAK_TFLOPS
-    if fp16:  # direct convolution on the fp16 pipe: 3 (split) or 1 (plain) MFMA products per multiply-add
-        wino, mfma_share = False, (3.0 if precision == "split" else 1.0)
-        achieved = direct_tflops * mfma_share
+    KERNEL_NAMES = {"wino2d": "conv3x3_wino2d_kernel<64> (Winograd F(2x2,3x3), 4/9 of the direct MFMA work)",
+                    "wino1d": "conv3x3_wino_persist_kernel<64|32> (Winograd F(2,3) along x, 2/3 of the direct MFMA work)",
+                    "direct": "conv3x3_mfma_dma_persist_kernel<64|32> (direct)",
+                    "f16": f"conv3x3_f16_persist_kernel<64|32, {3 if precision == 'split' else 1}> (direct, fp16 matrix pipe)"}
     # HBM traffic of the conv launches: measured with rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction, WRITE_SIZE;
     # tools/summarize_pmc.py) on this same command and committed under profiles/; bench.py itself cannot read PMCs, so it
     # reports the newest committed figure whose launch count matches this run.
@@ -450,17 +475,20 @@ def run_infer(args, ctx):
         "step_ms": percentiles(step_ms),
         "roofline": {
             "bound": "mfma",
-            "kernel": (f"conv3x3_f16_persist_kernel<64|32, {3 if precision == 'split' else 1}> (direct, fp16 matrix pipe, " if fp16 else
-                       f"conv3x3_wino_persist_kernel<64|32> (Winograd F(2,3) along x, " if wino else f"conv3x3_mfma_dma_persist_kernel<64|32> (direct, ")
-            + f"{len(conv_rows)} launches/forward; the first encoder block runs in the fused stem kernel)",
+            "kernel": KERNEL_NAMES[dom] + f", {D['launches']} of the {len(conv_rows)} conv launches of a forward; the first encoder block runs in the fused stem kernel",
             "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-            "flop_accounting": "achieved = FLOPs the MFMA pipe executes (Winograd: 2/3 of the direct-convolution count); "
-                               "direct_equivalent_tflops = direct-convolution FLOPs (2*Cin*Cout*9*H*W) / time, a throughput figure, not a roofline fraction",
+            "flop_accounting": "achieved = FLOPs the MFMA pipe executes in the launches of `kernel` / their summed duration (HIP events inside the timed region); "
+                               "direct_equivalent_tflops = direct-convolution FLOPs (2*Cin*Cout*9*H*W) of ALL conv launches / their time, a throughput figure, not a roofline fraction",
             "direct_equivalent_tflops": direct_tflops,
+            "kernels": {KERNEL_NAMES[k].split(" ")[0]: {"launches_per_forward": e["launches"], "ms_per_forward": e["ms"], "direct_gflop": e["direct_flops"] / 1e9,
+                                                          "executed_gflop": e["executed_flops"] / 1e9, "executed_tflops": e["executed_flops"] / (e["ms"] * 1e-3) / 1e12 if e["ms"] > 0 else 0.0,
+                                                          "frac_of_peak": e["executed_flops"] / (e["ms"] * 1e-3) / 1e12 / peak if e["ms"] > 0 else 0.0,
+                                                          "algorithmic_bytes": e["bytes"]} for k, e in by_kernel.items()},
             "traffic": traffic, "traffic_unit": "HBM bytes per conv launch (PMC, avg over the launches of one forward)",
             "traffic_source": traffic_src, "algorithmic_bytes_per_launch": conv_bytes / max(len(conv_rows), 1),
-            "algorithmic_gflop_per_forward": conv_flops * mfma_share / 1e9, "direct_gflop_per_forward": conv_flops / 1e9, "kernel_ms_per_forward": conv_ms,
+            "algorithmic_gflop_per_forward": executed_all / 1e9, "direct_gflop_per_forward": conv_flops / 1e9, "kernel_ms_per_forward": conv_ms,
             "avg_launch_ms": conv_ms / max(len(conv_rows), 1), "launches_per_forward": len(conv_rows),
+            "dominant_kernel_ms_per_forward": D["ms"], "dominant_kernel_avg_launch_ms": D["ms"] / max(D["launches"], 1),
             "conv_stack_direct_equivalent_tflops": stack_flops / (stack_ms * 1e-3) / 1e12 if stack_ms > 0 else 0.0,
             "forward_ms": fwd_ms, "forward_frames_per_s": B / (fwd_ms * 1e-3) if fwd_ms > 0 else 0.0,
             "per_op_ms": {r["label"]: round(ms / max(n_fw, 1), 4) for r, ms in zip(table, op_ms)},

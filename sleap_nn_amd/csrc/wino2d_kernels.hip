@@ -12,19 +12,23 @@
 //
 //   * GEMM view: M = 2x2 output tiles, N = output channels, K = input channels, once per Winograd position (xi, nu) -- sixteen
 //     independent GEMMs that share nothing but the raw input patch.  A register-resident accumulator set for all sixteen would be
-//     512 VGPRs per wave at M 32 x N 64, so the positions are split over the waves of a workgroup: wave w owns row xi = w & 3 of
-//     the transformed patch (all four nu: 4 x 2 accumulators of 16 registers, as many as the 1-D kernel holds) for M half
-//     w >> 2.  A workgroup tile is 8 x 8 Winograd tiles = 16 x 16 output pixels x 64 channels.
+//     512 VGPRs per wave at M 32 x N 64, so the positions are split over the waves of a workgroup: a wave owns row xi of the
+//     transformed patch (all four nu: 4 x 2 accumulators of 16 registers, as many as the 1-D kernel holds) for one M half.
+//     A workgroup tile is 8 x 8 Winograd tiles = 16 x 16 output pixels x 64 channels; 512 threads, one workgroup per CU, persistent.
 //   * Input transform on the fly from the raw 18 x 18 halo tile that LDS-DMA stages: a lane reads the two patch rows its xi
-//     combines (four ds_read_b128 each), one add/sub per column gives row xi of B^T d, four more give the four A fragments
-//     (row xi of B^T d B); each feeds 8 MFMAs.
+//     combines (four ds_read_b128 each, columns at immediate offsets), one fma per column gives row xi of B^T d, four more give
+//     the four A fragments (row xi of B^T d B); each feeds 8 MFMAs -- one VALU instruction per MFMA, the floor of this form.
 //   * Weights are transformed on the device (wino2d_pack_kernel) into LDS order [g][xi][nu][n tile][lh][lx][4]: 64 KiB per
-//     16-channel chunk.  As in the 1-D kernel they live in three half-chunk slots of 32 KiB (a chunk reads slots (h, h+1); the
-//     next chunk's first half streams into h+2, its second half into h after a mid-chunk barrier).
+//     16-channel chunk, handled in HALVES (8 channels): three weight half-slots (32 KiB) and four halo half-slots (12 KiB) form
+//     the software pipeline described at the kernel; every transfer goes through a buffer descriptor (no per-transfer address
+//     arithmetic, out-of-image pixels come back as zeros from the range check).
 //   * Epilogue: a wave holds, for its xi, P[b] = sum_nu M[xi][nu] A[nu][b]; output row a = 0 is P0 + P1 + P2 and row a = 1 is
-//     P1 - P2 - P3 over xi, i.e. over waves: waves xi = 1, 2 pass their P through LDS (the free weight slot and the free halo
-//     buffer), wave 0 finishes the even output rows and wave 3 the odd ones (bias, ReLU, stores); the fused 2x2 max pool takes
-//     one more hop (wave 0's row maxima to wave 3).
+//     P1 - P2 - P3 over xi, i.e. over waves: waves xi = 1, 2 pass their P through LDS (the free weight slot, the two free halo
+//     slots and a 16-KiB spare), wave xi = 0 finishes the even output rows and wave xi = 3 the odd ones (ReLU, stores; the bias
+//     rides in on wave xi = 1's P); the fused 2x2 max pool takes one more hop (wave 0's row maxima to wave 3).
+//   Measured (MI355X, cfg3, 32 frames): the 14 N-tile-64 layers take 10.7 ms instead of 13.8 ms with the 1-D kernel; the 768 -> 256
+//   layer executes 128 TFLOP/s = 0.81 of the fp32 MFMA peak (288 TFLOP/s in direct-convolution FLOPs).  In-kernel stamps
+//   (-DPH_W2_STAMP, tools/w2_stamp.py): a half costs ~4850 cycles for 4096 cycles of MFMA work per SIMD; a tile's epilogue ~9000.
 #include <type_traits>
 
 #include "common.h"
@@ -38,8 +42,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int W2_T = 16;                                   // output tile edge
 constexpr int W2_HW = W2_T + 2;                            // halo edge
 constexpr int W2_NPIX = W2_HW * W2_HW;                     // 324 halo pixels
-constexpr int W2_PL_PIECES = (W2_NPIX + 63) / 64;          // 6 DMA pieces (64 pixels x one 4-channel quad, 1 KiB) per quad plane
-constexpr int W2_PL_FLOATS = W2_PL_PIECES * 256;           // 1536: a half-slot is two planes [quad][pixel hy * 18 + hx][4]
+constexpr int W2_PP_PIECES = (W2_HW * W2_HW / 2 + 63) / 64; // 3 DMA pieces (64 pixels x one 4-channel quad, 1 KiB) per column-parity plane
+constexpr int W2_PP_FLOATS = W2_PP_PIECES * 256;           // 768
+constexpr int W2_PL_PIECES = 2 * W2_PP_PIECES;             // 6 per quad plane: a half-slot is [quad][column parity][hy * 9 + hx / 2][4] --
+constexpr int W2_PL_FLOATS = W2_PL_PIECES * 256;           // 1536   lanes tx = 0..7 of a patch read then hit eight consecutive 16-B bank groups
 constexpr int W2_AH_PIECES = 2 * W2_PL_PIECES;             // 12 pieces per half chunk (8 channels)
 constexpr int W2_AH_FLOATS = W2_AH_PIECES * 256;           // 3072: one halo half-slot
 constexpr int W2_BH_FLOATS = 8192;                         // half a chunk of weights (N tile 64): 32 pieces
@@ -109,7 +115,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_kernel(ConvArgs a) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int xi = wave & 3, mh = wave >> 2;
+  // wave w runs on SIMD w & 3.  The two waves that own the same row xi (M halves 0 and 1) sit on DIFFERENT SIMDs (xi = (w + 2 mh) & 3):
+  // the epilogue's finishing work (waves xi = 0 and 3 of both halves) then spreads over all four SIMDs instead of two.
+  const int mh = wave >> 2, xi = (wave + 2 * mh) & 3;
   const int tiles_x = (a.W + W2_T - 1) / W2_T;
   const int tiles_y = (a.H + W2_T - 1) / W2_T;
   const int tiles = tiles_x * tiles_y * a.B;
@@ -154,10 +162,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_kernel(ConvArgs a) {
     for (int s = 0; s < 2; ++s) {
       const int p = s == 0 ? wave : min(wave + 8, W2_AH_PIECES - 1);
       const int q2 = p >= W2_PL_PIECES ? 1 : 0;
-      const int pix = (p - q2 * W2_PL_PIECES) * 64 + lane;
-      const int hy = pix / W2_HW, hx = pix - hy * W2_HW;
+      const int pp = p - q2 * W2_PL_PIECES;                 // piece within the quad plane: parity plane pp / 3, entries (pp % 3) * 64 + lane
+      const int par = pp >= W2_PP_PIECES ? 1 : 0;
+      const int e = (pp - par * W2_PP_PIECES) * 64 + lane;  // entry hy * 9 + hx / 2
+      const int hy = e / 9, hx = 2 * (e - hy * 9) + par;
       const int gy = FA.y0 + hy - 1, gx = FA.x0 + hx - 1;
-      const bool in = cp > 0 && (pix < W2_NPIX) && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+      const bool in = cp > 0 && (hy < W2_HW) && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
       fa_off[s] = in ? ((unsigned)((FA.b * a.H + gy) * a.W + gx) * (unsigned)cp + q2 * 4) * 4u : 0xFFFFFF00u;
     }
   };
@@ -227,8 +237,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_kernel(ConvArgs a) {
   float sgn = xi == 1 ? 1.f : -1.f;
   float m1 = -1.f;
   asm volatile("" : "+v"(m1));  // opaque: keeps x - y as fma(y, m1, x), which packs two lanes per instruction (v_pk_fma_f32)
-  const int lbase = lh * W2_PL_FLOATS + ((2 * (4 * mh + (lx >> 3))) * W2_HW + 2 * (lx & 7)) * 4;
-  const int offRA = lbase + ra * W2_HW * 4, offRB = lbase + rb * W2_HW * 4;
+  const int lbase = lh * W2_PL_FLOATS + ((2 * (4 * mh + (lx >> 3))) * 9 + (lx & 7)) * 4;
+  const int offRA = lbase + ra * 9 * 4, offRB = lbase + rb * 9 * 4;
   const int offB = xi * 4 * NT * 256 + lh * 128 + lx * 4;
   float* const abuf = lds;
   float* const bbuf = lds + W2_B_OFF;
@@ -236,8 +246,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_kernel(ConvArgs a) {
 
   f32x4 av[4], tt[4], da[2], db[2];  // fragments of the running half; row xi of B^T d of the next one; raw patch rows in flight
   auto aread = [&](const float* aslot, int i, int c) {
-    da[i] = *reinterpret_cast<const f32x4*>(aslot + offRA + c * 4);
-    db[i] = *reinterpret_cast<const f32x4*>(aslot + offRB + c * 4);
+    const int co = (c & 1) * W2_PP_FLOATS + (c >> 1) * 4;  // column 2 tx + c: parity plane c & 1, entry tx + (c >> 1)
+    da[i] = *reinterpret_cast<const f32x4*>(aslot + offRA + co);
+    db[i] = *reinterpret_cast<const f32x4*>(aslot + offRB + co);
   };
   auto ypass = [&](int i, int c) {
     tt[c] = da[i] + sgn * db[i];
@@ -286,19 +297,26 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_kernel(ConvArgs a) {
   }
 #pragma unroll
   for (int nu = 0; nu < 4; ++nu) xpass(nu);
+#ifdef PH_W2_STAMP
+  unsigned long long st_loop = 0, st_e1 = 0, st_e2 = 0, st_e3 = 0, st_tiles = 0;
+  const unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
+  unsigned long long st_mark = st_t0;
+#define W2_STAMP(acc)                                              \
+  {                                                                \
+    const unsigned long long t_ = __builtin_amdgcn_s_memtime();    \
+    acc += t_ - st_mark;                                           \
+    st_mark = t_;                                                  \
+  }
+#else
+#define W2_STAMP(acc)
+#endif
   int ka = 0;  // halo half-slot of the running half (its fragments are already in av)
   int kb = 0;  // weight half-slot of the running half
   while (true) {
     f32x16 acc[4][NT];
-#pragma unroll
-    for (int x = 0; x < 4; ++x)
-#pragma unroll
-      for (int n = 0; n < NT; ++n)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[x][n][r] = 0.f;
-    for (int ch = 0; ch < nchunks; ++ch) {
-#pragma unroll
-      for (int g = 0; g < 2; ++g) {
+    auto half = [&](auto first_tag) {
+      constexpr bool FIRST = decltype(first_tag)::value;
+      {
         const float* bcur = bbuf + kb * W2_BH_FLOATS + offB;
         float* bdst = bbuf + (kb == 0 ? 2 : kb - 1) * W2_BH_FLOATS;   // (kb + 2) % 3
         const float* atr = abuf + ((ka + 1) & 3) * W2_AH_FLOATS;      // halo of the next half
@@ -316,7 +334,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_kernel(ConvArgs a) {
         for (int nu = 0; nu < 4; ++nu) {
           const int fcur = nu & 1;
 #pragma unroll
-          for (int n = 0; n < NT; ++n) acc[nu][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[nu][0], bf[fcur][n][0], acc[nu][n], 0, 0, 0);
+          for (int n = 0; n < NT; ++n) {
+            if (FIRST) {
+              f32x16 z;
+#pragma unroll
+              for (int r = 0; r < 16; ++r) z[r] = 0.f;
+              acc[nu][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[nu][0], bf[fcur][n][0], z, 0, 0, 0);
+            } else {
+              acc[nu][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[nu][0], bf[fcur][n][0], acc[nu][n], 0, 0, 0);
+            }
+          }
           __builtin_amdgcn_sched_barrier(0);
           if (nu + 1 < 4) load_b(nu + 1, fcur ^ 1);
           if (nu == 0) {
@@ -358,13 +385,19 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_kernel(ConvArgs a) {
         a_advance();
         b_advance();
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_waitcnt(0xF76);  // vmcnt(6)
+        // Every wave has now retired what it issued during the PREVIOUS half (all but the six transfers of this half).  A
+        // tile's first half skips the wait: the epilogue before it already retired everything, and waiting here would drain
+        // the epilogue's 64 global stores (vmcnt counts them in the same queue) -- a microsecond of HBM write latency per tile.
+        if (!FIRST) __builtin_amdgcn_s_waitcnt(0xF76);  // vmcnt(6)
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         ka = (ka + 1) & 3;
         kb = kb == 2 ? 0 : kb + 1;
       }
-    }
+    };
+    half(std::true_type{});
+    for (int h = 1; h < 2 * nchunks; ++h) half(std::false_type{});
+    W2_STAMP(st_loop)
     // ---- epilogue.  In lane (lx, lh) accumulator register r is tile (ty = 4 mh + (r >> 2), tx = (r & 3) + 4 lh), channel n * 32 + lx.
     // Free LDS until the next half's DMA: weight slot (kb + 2) % 3, halo slots (ka + 3) % 4 ("X") and ka ("Y": the next tile's
     // first half, already transformed) and the spare.  Slot X and the weight slot are DMA targets of the NEXT half, slot Y of
@@ -379,13 +412,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_kernel(ConvArgs a) {
     float* const r2b = spare + mh * 4 * 256;
     auto r2 = [&](int idx) -> float* { return idx < 12 ? r2a + idx * 256 : r2b + (idx - 12) * 256; };
 #pragma unroll
-    for (int n = 0; n < NT; ++n)
+    for (int n = 0; n < NT; ++n) {
+      const float bias = xi == 1 ? a.bias[ntile * BN + n * 32 + lx] : 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const float m0 = acc[0][n][r], m1 = acc[1][n][r], m2 = acc[2][n][r], m3 = acc[3][n][r];
-        acc[0][n][r] = (m0 + m1) + m2;
-        acc[1][n][r] = (m1 - m2) - m3;
+        acc[0][n][r] = ((m0 + m1) + m2) + bias;
+        acc[1][n][r] = ((m1 - m2) - m3) + bias;
       }
+    }
     if (xi == 1 || xi == 2) {
 #pragma unroll
       for (int bb = 0; bb < 2; ++bb)
@@ -406,6 +441,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_kernel(ConvArgs a) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
+    W2_STAMP(st_e1)
     if (xi == 0 || xi == 3) {
 #pragma unroll
       for (int bb = 0; bb < 2; ++bb)
@@ -426,19 +462,20 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_kernel(ConvArgs a) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
+    // The transfers issued during the tile's last half (the next tile's halves 1 and 2) retire HERE, a few thousand cycles after
+    // their issue and before the stores enter the queue, so that the next tile's first half needs no vmcnt wait at all.
+    __builtin_amdgcn_s_waitcnt(0xF70);  // vmcnt(0)
+    __builtin_amdgcn_sched_barrier(0);
+    W2_STAMP(st_e2)
     const int arow = xi == 3 ? 1 : 0;  // output row of the tile this wave finishes
     if (xi == 0 || xi == 3) {
+      if (a.relu) {
 #pragma unroll
-      for (int n = 0; n < NT; ++n) {
-        const int co = ntile * BN + n * 32 + lx;
-        const float bias = a.bias[co];
+        for (int n = 0; n < NT; ++n)
 #pragma unroll
-        for (int bb = 0; bb < 2; ++bb)
+          for (int bb = 0; bb < 2; ++bb)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const float v = acc[bb][n][r] + bias;
-            acc[bb][n][r] = a.relu ? fmaxf(v, 0.f) : v;
-          }
+            for (int r = 0; r < 16; ++r) acc[bb][n][r] = fmaxf(acc[bb][n][r], 0.f);
       }
     }
     if (a.dst_pool) {  // fused 2x2/2 max pool ("same" padding: zeros beyond the image): wave 0's row maxima hop to wave 3
@@ -517,6 +554,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_kernel(ConvArgs a) {
         }
       }
     }
+    W2_STAMP(st_e3)
+#ifdef PH_W2_STAMP
+    ++st_tiles;
+#endif
     if (!has_next) break;
     vid += gridDim.x;
     P = Pn;
@@ -527,6 +568,19 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_kernel(ConvArgs a) {
       fa_more = fb_more = has_next;
     }
   }
+#ifdef PH_W2_STAMP
+  if (a.clock_probe && lane == 0) {
+    unsigned long long* o = a.clock_probe + ((size_t)blockIdx.x * 8 + wave) * 8;
+    o[0] = st_loop;
+    o[1] = st_e1;
+    o[2] = st_e2;
+    o[3] = st_e3;
+    o[4] = __builtin_amdgcn_s_memtime() - st_t0;
+    o[5] = st_tiles;
+    o[6] = __builtin_amdgcn_s_memrealtime() - st_r0;
+    o[7] = 2 * nchunks;
+  }
+#endif
 }
 
 static int w2_cu_count(int* out) {

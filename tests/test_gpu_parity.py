@@ -942,6 +942,42 @@ def test_forward_is_bitwise_deterministic_and_stream_safe():
         assert torch.equal(a[k], b[k]), k
 
 
+@pytest.mark.parametrize("filters,max_stride,hw,out_stride", [(32, 8, (64, 64), None), (64, 8, (72, 52), None), (32, 8, (36, 44), None),
+                                                             (32, 16, (128, 160), 2), (48, 8, (80, 48), 4), (64, 4, (50, 70), None)])
+def test_winograd_2d_kernel_matches_oracle_and_the_other_conv_kernels(filters, max_stride, hw, out_stride):
+    """conv3x3_wino2d_kernel (F(2x2,3x3), every 3x3 conv with >= 64 output and >= 32 input channels) against the oracle at the
+    confmap bar, and against the F(2,3)-along-x and the direct kernels of the same handle options: tiles cut by the image border
+    (sizes that are no multiple of 16), the fused pool epilogue with odd sizes, N tiles cut by Cout (48 * 2 = 96 channels), the
+    two-source concat convs of a decoder, several tiles per workgroup (persistent walk) -- all three kernels agree to a few ulp
+    of the tensor's scale."""
+    from sleap_nn_amd.architectures.model import Model
+
+    os_ = out_stride or max_stride
+    bb = {"in_channels": 1, "kernel_size": 3, "filters": filters, "filters_rate": 2, "max_stride": max_stride, "stem_stride": None, "middle_block": True,
+          "up_interpolate": True, "stacks": 1, "convs_per_block": 2, "output_stride": os_}
+    heads = {"confmaps": {"part_names": ["a", "b", "c"], "output_stride": os_}}
+    sd = O.init_state(bb, heads, "single_instance", seed=filters + hw[0], head_scale=1.0)
+    g = torch.Generator().manual_seed(hw[1])
+    img = torch.randint(0, 256, (3, 1, hw[0], hw[1]), dtype=torch.uint8, generator=g)
+    ref = O.model_forward(sd, bb, heads, "single_instance", img)["SingleInstanceConfmapsHead"]
+    outs = {}
+    for name, opts in (("w2d", {}), ("w1d", {"conv_wino2d": 0}), ("direct", {"conv_wino2d": 0, "conv_wino": 0})):
+        m = Model("unet", bb, heads, "single_instance")
+        m.load_state_dict(sd)
+        for k, v in opts.items():
+            m.set_option(k, v)
+        outs[name] = m.to(DEV)(img.to(DEV))["SingleInstanceConfmapsHead"].cpu()
+        if name == "w2d":
+            assert m.get_option("conv_wino2d") == 1.0  # the default
+    scale = max(1.0, ref.abs().max().item())
+    assert (outs["w2d"] - ref).abs().max().item() <= CMS_ATOL * scale
+    for other in ("w1d", "direct"):
+        assert (outs["w2d"] - outs[other]).abs().max().item() <= 2e-5 * ref.abs().max().item(), other
+    again = Model("unet", bb, heads, "single_instance")
+    again.load_state_dict(sd)
+    assert torch.equal(again.to(DEV)(img.to(DEV))["SingleInstanceConfmapsHead"].cpu(), outs["w2d"])  # run-to-run bitwise
+
+
 @pytest.mark.parametrize("name", ["unet_tiny_interp.npz", "unet_tiny_bu13.npz", "ckpt_bottomup.npz"])
 def test_direct_convolution_kernels_still_match_golden(name):
     """The Winograd kernels are the default; the direct 9-tap kernels stay in the library (transposed convs, A/B runs)
