@@ -159,7 +159,7 @@ def cpu_baseline(model, layer, cms_dev, pafs_dev, dev, budget_s: float = 24.0):
     }
 
 
-PROFILE_EVERY = 4  # steps of the timed region whose forward records per-op HIP events: 0, 4, 8, ...
+PROFILE_EVERY = 10
 
 
 def _free_port() -> int:
