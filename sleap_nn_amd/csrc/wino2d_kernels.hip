@@ -314,25 +314,41 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_kernel(ConvArgs a) {
   int kb = 0;  // weight half-slot of the running half
   while (true) {
     f32x16 acc[4][NT];
-    auto half = [&](auto first_tag) {
+    f32x4 bf[2][NT];
+    auto half = [&](auto first_tag, bool last) {
       constexpr bool FIRST = decltype(first_tag)::value;
       {
         const float* bcur = bbuf + kb * W2_BH_FLOATS + offB;
+        const float* bnxt = bbuf + (kb == 2 ? 0 : kb + 1) * W2_BH_FLOATS + offB;
         float* bdst = bbuf + (kb == 0 ? 2 : kb - 1) * W2_BH_FLOATS;   // (kb + 2) % 3
         const float* atr = abuf + ((ka + 1) & 3) * W2_AH_FLOATS;      // halo of the next half
         float* adst = abuf + ((ka + 3) & 3) * W2_AH_FLOATS;
-        f32x4 bf[2][NT];
-        auto load_b = [&](int nu, int fbuf) {
+        auto load_b = [&](const float* bslot, int nu, int fbuf) {
 #pragma unroll
-          for (int n = 0; n < NT; ++n) bf[fbuf][n] = *reinterpret_cast<const f32x4*>(bcur + (nu * NT + n) * 256);
+          for (int n = 0; n < NT; ++n) bf[fbuf][n] = *reinterpret_cast<const f32x4*>(bslot + (nu * NT + n) * 256);
         };
-        load_b(0, 0);
+        if (FIRST) load_b(bcur, 0, 0);  // a tile's first half reads its first fragments after the epilogue's barrier; later halves get them in step 3 of the half before
         // Pinned order inside a step: its first MFMAs, THEN the LDS reads of the next step (the compiler's wait before a step's
         // first MFMA is lgkmcnt(0): reads issued before it would be drained on the spot), then the transform arithmetic of patch
         // rows read one step earlier and the DMA issue, then the remaining MFMAs.
 #pragma unroll
         for (int nu = 0; nu < 4; ++nu) {
           const int fcur = nu & 1;
+          if (nu == 3) {
+            // The half's barrier sits BEFORE its last step, not after it: by now this wave has issued (and, after the lgkmcnt
+            // wait, received) every LDS read of the half, so once all waves are here the slots it read may be refilled -- which
+            // only happens from the next half's first step on -- and everything any wave issued during the PREVIOUS half has
+            // landed (vmcnt(5): all but this half's five transfers so far).  The next half's first fragments are then read under
+            // this step's MFMAs instead of after a barrier with the matrix pipe drained.  A tile's first half skips the vmcnt
+            // wait: the epilogue before it retired everything, and waiting here would drain the epilogue's 64 global stores
+            // (vmcnt counts them in the same queue).
+            if (FIRST)
+              __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+            else
+              __builtin_amdgcn_s_waitcnt(0x0075);  // vmcnt(5) lgkmcnt(0)
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+          }
 #pragma unroll
           for (int n = 0; n < NT; ++n) {
             if (FIRST) {
@@ -345,7 +361,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_kernel(ConvArgs a) {
             }
           }
           __builtin_amdgcn_sched_barrier(0);
-          if (nu + 1 < 4) load_b(nu + 1, fcur ^ 1);
+          if (nu + 1 < 4) load_b(bcur, nu + 1, fcur ^ 1);
+          if (nu == 3 && !last) load_b(bnxt, 0, 0);  // visible since the barrier above
           if (nu == 0) {
             aread(atr, 0, 0);
             aread(atr, 1, 2);
@@ -373,6 +390,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_kernel(ConvArgs a) {
           } else {
             xpass(2);
             a_issue(1, adst);
+            a_advance();
+            b_advance();
           }
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -382,21 +401,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_kernel(ConvArgs a) {
           __builtin_amdgcn_sched_barrier(0);
         }
         xpass(3);
-        a_advance();
-        b_advance();
-        __builtin_amdgcn_sched_barrier(0);
-        // Every wave has now retired what it issued during the PREVIOUS half (all but the six transfers of this half).  A
-        // tile's first half skips the wait: the epilogue before it already retired everything, and waiting here would drain
-        // the epilogue's 64 global stores (vmcnt counts them in the same queue) -- a microsecond of HBM write latency per tile.
-        if (!FIRST) __builtin_amdgcn_s_waitcnt(0xF76);  // vmcnt(6)
-        __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         ka = (ka + 1) & 3;
         kb = kb == 2 ? 0 : kb + 1;
       }
     };
-    half(std::true_type{});
-    for (int h = 1; h < 2 * nchunks; ++h) half(std::false_type{});
+    half(std::true_type{}, false);
+    for (int h = 1; h < 2 * nchunks; ++h) half(std::false_type{}, h + 1 == 2 * nchunks);
     W2_STAMP(st_loop)
     // ---- epilogue.  In lane (lx, lh) accumulator register r is tile (ty = 4 mh + (r >> 2), tx = (r & 3) + 4 lh), channel n * 32 + lx.
     // Free LDS until the next half's DMA: weight slot (kb + 2) % 3, halo slots (ka + 3) % 4 ("X") and ka ("Y": the next tile's
