@@ -559,23 +559,25 @@ ph_model* ph_model_create(const ph_op_desc* ops, int32_t n_ops, const float* con
           return true;
         };
         if (ok && !tr) ok = derive_wino(op.w_dev, d.cin0, d.cin1, d.cout, op.bn, &op.w_wino_dev);
-        if (ok && !tr && op.bn == 64) {  // F(2x2,3x3) weights of the forward conv (the data-gradient convs stay on the 1-D form)
-          const int panels = ((coutp + 63) / 64) * (pad16(d.cin0) / 16 + (d.cin1 > 0 ? pad16(d.cin1) / 16 : 0));
+        // F(2x2,3x3) weights (conv3x3_wino2d_kernel, N tile 64): the forward conv's, and below the data-gradient convs'
+        auto derive_wino2 = [&](const float* src, int cin_a, int cin_b, int cout_, int bn, float** dst) {
+          if (bn != 64) return true;
+          const int panels = ((pad16(cout_) + 63) / 64) * (pad16(cin_a) / 16 + (cin_b > 0 ? pad16(cin_b) / 16 : 0));
           float* w = nullptr;
-          ok = hipMalloc(&w, (size_t)wino2d_pack_floats(panels, 64) * sizeof(float)) == hipSuccess;
-          if (ok) {
-            m->allocs.push_back(w);
-            ok = launch_wino2d_pack(op.w_dev, w, panels, 64, nullptr) == PH_OK;
-            DerivedBuffer db;
-            db.src = op.w_dev;
-            db.dst = w;
-            db.panels = panels;
-            db.bn = 64;
-            db.kind = 2;
-            m->derived.push_back(db);
-            op.w_wino2_dev = w;
-          }
-        }
+          if (hipMalloc(&w, (size_t)wino2d_pack_floats(panels, 64) * sizeof(float)) != hipSuccess) return false;
+          m->allocs.push_back(w);
+          if (launch_wino2d_pack(src, w, panels, 64, nullptr) != PH_OK) return false;
+          DerivedBuffer db;
+          db.src = src;
+          db.dst = w;
+          db.panels = panels;
+          db.bn = 64;
+          db.kind = 2;
+          m->derived.push_back(db);
+          *dst = w;
+          return true;
+        };
+        if (ok && !tr) ok = derive_wino2(op.w_dev, d.cin0, d.cin1, d.cout, op.bn, &op.w_wino2_dev);
         if (ok && !tr) {  // row-GEMM form for feature maps too small for the 16x32-pixel tiles
           op.bn_g = gemm_choose_bn(coutp);
           auto pack_g = [&](const auto* w, auto& out) { pack_gemm(w, d.cout, d.cin0, d.cin1, 9, op.bn_g, out); };
@@ -647,7 +649,8 @@ ph_model* ph_model_create(const ph_op_desc* ops, int32_t n_ops, const float* con
             };
             ok = pack_upload(m, pack_d, weights[d.weight], iw, &op.wd_dev[part]) == PH_OK &&
                  pack_upload(m, pack_dd, weights[d.weight], iw, &op.wd_dma_dev[part]) == PH_OK &&
-                 derive_wino(op.wd_dev[part], d.cout, 0, parts[part], op.bn_d[part], &op.wd_wino_dev[part]);
+                 derive_wino(op.wd_dev[part], d.cout, 0, parts[part], op.bn_d[part], &op.wd_wino_dev[part]) &&
+                 derive_wino2(op.wd_dev[part], d.cout, 0, parts[part], op.bn_d[part], &op.wd_wino2_dev[part]);
           }
           if (ok) {
             std::vector<float> zb((size_t)pad16(std::max(d.cin0, d.cin1)) + max_bn, 0.f);

@@ -1282,7 +1282,7 @@ int launch_conv3x3_dma(const ConvArgs& a, hipStream_t s) {
   const int tiles = ((a.W + TW - 1) / TW) * ((a.H + D_TH - 1) / D_TH) * a.B;
   const int ntc = (a.coutp + a.bn - 1) / a.bn;
   const bool wino = a.use_wino && a.wpack_wino && (a.bn == 64 || a.use_wino != 2);  // use_wino 2: Winograd for the N-tile-64 layers only
-  if (wino && a.persist && a.use_wino2d && a.wpack_wino2 && a.bn == 64 && !a.accumulate && a.c0p + a.c1p >= 32 && wino2d_fits(a)) return launch_conv3x3_wino2d(a, s);
+  if (wino && a.persist && a.use_wino2d && a.wpack_wino2 && a.bn == 64 && a.c0p + a.c1p >= 32 && wino2d_fits(a)) return launch_conv3x3_wino2d(a, s);
   int n_cu = 0;
   if (a.persist) {
     const int rc = cu_count(&n_cu);

@@ -300,6 +300,7 @@ int ph_model_backward(ph_model* m, const void* input_dev, int32_t in_dtype, int3
           a.wpack = op.wd_dev[part];
           a.wpack_dma = op.wd_dma_dev[part];
           a.wpack_wino = op.wd_wino_dev[part];
+          a.wpack_wino2 = op.wd_wino2_dev[part];
           a.w16 = op.wd16_dev;
           a.bias = op.zero_bias_dev;
           a.dst = G(srcs[part]);

@@ -546,6 +546,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_kernel(ConvArgs a) {
         const int co = ntile * BN + n * 32 + lx;
         if (interior) {
           float* const dp0 = a.dst + ((size_t)(b * a.H + y0 + 8 * mh + arow) * a.W + x0 + 8 * lh) * a.coutp + co;
+          if (a.accumulate) {  // gradient accumulation (the second data-gradient launch into a concat source's gradient)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const float* dp = dp0 + ((size_t)(2 * (r >> 2)) * a.W + 2 * (r & 3)) * a.coutp;
+              acc[0][n][r] += dp[0];
+              acc[1][n][r] += dp[a.coutp];
+            }
+          }
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             float* dp = dp0 + ((size_t)(2 * (r >> 2)) * a.W + 2 * (r & 3)) * a.coutp;
@@ -558,8 +566,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_kernel(ConvArgs a) {
             const int y = y0 + 2 * (4 * mh + (r >> 2)) + arow, x = x0 + 2 * ((r & 3) + 4 * lh);
             if (y < a.H && co < a.coutp) {
               float* dp = a.dst + ((size_t)(b * a.H + y) * a.W + x) * a.coutp + co;
-              if (x < a.W) dp[0] = acc[0][n][r];
-              if (x + 1 < a.W) dp[a.coutp] = acc[1][n][r];
+              if (x < a.W) dp[0] = a.accumulate ? dp[0] + acc[0][n][r] : acc[0][n][r];
+              if (x + 1 < a.W) dp[a.coutp] = a.accumulate ? dp[a.coutp] + acc[1][n][r] : acc[1][n][r];
             }
           }
         }
@@ -619,9 +627,9 @@ bool wino2d_fits(const ConvArgs& a) {
   const uint64_t px = (uint64_t)a.B * a.H * a.W;
   return px * (uint64_t)a.c0p * 4 < 0xFFFFFF00ull && px * (uint64_t)a.c1p * 4 < 0xFFFFFF00ull && px < 0x7FFFFFFFull;
 }
-// 3x3 conv, N tile 64, no accumulation into dst: the caller (launch_conv3x3_dma) checks those.
+// 3x3 conv, N tile 64: the caller (launch_conv3x3_dma) checks the preconditions.
 int launch_conv3x3_wino2d(const ConvArgs& a, hipStream_t s) {
-  PH_REQUIRE(a.bn == 64 && a.wpack_wino2 && !a.accumulate && a.c0p + a.c1p >= 32 && wino2d_fits(a), "wino2d: N tile 64, transformed weights, no accumulate, at least 32 input channels, sources below 4 GiB");
+  PH_REQUIRE(a.bn == 64 && a.wpack_wino2 && a.c0p + a.c1p >= 32 && wino2d_fits(a), "wino2d: N tile 64, transformed weights, at least 32 input channels, sources below 4 GiB");
   int n_cu = 0;
   const int rc = w2_cu_count(&n_cu);
   if (rc != PH_OK) return rc;
