@@ -968,8 +968,14 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
         const int bn_g = op.bn_g > 0 ? op.bn_g : 128;
         const double n_fill_g = (double)a.coutp / ((a.coutp + bn_g - 1) / bn_g * bn_g);
         // the halo kernel runs Winograd F(2,3) (2/3 of the MFMA work) where its weights exist: it wins down to ~0.5 tile fill (measured on the ConvNeXt decoder: 48x48 and 24x24 maps)
-        const double halo_gain = (op.w_wino_dev && m->use_dma) ? m->gemm_fill_threshold / m->gemm_fill_threshold_wino : 1.0;
-        if (m->use_dma && d.dst2 < 0 && op.w_gemm_dev && (fill * halo_gain < m->gemm_fill_threshold || n_fill * fill * halo_gain < 0.8 * n_fill_g)) {
+        double halo_gain = (op.w_wino_dev && m->use_dma) ? m->gemm_fill_threshold / m->gemm_fill_threshold_wino : 1.0;
+        double halo_fill = fill;
+        if (m->use_dma && m->conv_wino && m->conv_wino2d && m->conv_persist && op.w_wino2_dev && a.bn == 64 && a.c0p + a.c1p >= 32 && wino2d_fits(a)) {
+          // the F(2x2,3x3) kernel: 16x16-pixel tiles and 4/9 of the MFMA work -- it beats the 9-tap row GEMM down to ~0.4 tile fill
+          halo_fill = (double)s0.h * s0.w / ((double)((s0.h + 15) / 16 * 16) * ((s0.w + 15) / 16 * 16));
+          halo_gain = m->gemm_fill_threshold / m->gemm_fill_threshold_wino2d;
+        }
+        if (m->use_dma && d.dst2 < 0 && op.w_gemm_dev && (halo_fill * halo_gain < m->gemm_fill_threshold || n_fill * halo_fill * halo_gain < 0.8 * n_fill_g)) {
           // small feature map (the 16x32-pixel tiles of the halo kernel would be mostly padding) or a Cout that
           // fits the halo kernel's N tile badly -> 9-tap row GEMM
           GemmArgs g{};
@@ -1248,6 +1254,7 @@ std::vector<OptionRef> option_table(ph_model* m) {
       {"gemm_persist2", &m->gemm_persist2, nullptr},
       {"conv_gemm_fill", nullptr, &m->gemm_fill_threshold},            // tile fill below which a 3x3 conv runs as a row GEMM (0 disables)
       {"conv_gemm_fill_wino", nullptr, &m->gemm_fill_threshold_wino},  // ... when the halo kernel is the Winograd one
+      {"conv_gemm_fill_wino2d", nullptr, &m->gemm_fill_threshold_wino2d},  // ... when it is the F(2x2,3x3) kernel (16x16-pixel tiles)
   };
 }
 }  // namespace
@@ -1257,7 +1264,7 @@ int ph_model_set_option(ph_model* m, const char* key, double value) {
   for (const OptionRef& o : option_table(m))
     if (!strcmp(o.key, key)) {
       if (o.i) *o.i = (int)value;
-      if (o.d) *o.d = !strcmp(key, "conv_gemm_fill_wino") ? std::max(value, 1e-3) : value;
+      if (o.d) *o.d = (!strcmp(key, "conv_gemm_fill_wino") || !strcmp(key, "conv_gemm_fill_wino2d")) ? std::max(value, 1e-3) : value;
       return PH_OK;
     }
   set_error("ph_model_set_option: unknown option '%s'", key);

@@ -115,6 +115,7 @@ struct ph_model {
   int fuse_gelu_fwd = 1;                      // Linear -> GELU op pair: one GEMM whose epilogue writes both tensors (0: two kernels)
   int fuse_gelu_bwd = 1;                      // Linear data gradient multiplies by GELU' in its epilogue (0: separate kernel)
   int wgrad_rows = 0;                         // 3x3 weight gradients of wide layers as nine row-wgrad GEMMs (off by default: measured slower than the 32x32-tile kernel; 1 auto, 2 always)
+  double gemm_fill_threshold_wino2d = 0.4;    // ... and when it is the F(2x2,3x3) kernel (fill counted on its 16x16-pixel tiles)
   double gemm_fill_threshold_wino = 0.5;      // ... and the (lower) break-even when the halo kernel is the Winograd one
   double gemm_fill_threshold = 0.8;           // 3x3 convs whose maps fill the 16x32 tiles less than this run as row GEMMs
   int workspace_reuse = 0;                    // "workspace_reuse": 1 = slots of an inference program share memory by lifetime (no read-back, no backward)
