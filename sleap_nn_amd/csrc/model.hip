@@ -236,6 +236,9 @@ int build_plan(const ph_model* m, int B, int H, int W, Plan& plan, int fmt) {
       if (e.src0 >= 0 && e.src0 < m->n_slots) last_use[e.src0] = j;
       if (e.src1 >= 0 && e.src1 < m->n_slots) last_use[e.src1] = j;
     }
+  plan.unread.assign(m->n_slots, 0);
+  if (reuse)
+    for (int sl = 0; sl < m->n_slots; ++sl) plan.unread[sl] = last_use[sl] < 0;
   std::vector<std::pair<int64_t, int64_t>> free_list;  // (offset, bytes), kept sorted and coalesced
   auto release = [&](int slot) {
     free_list.emplace_back(plan.slots[slot].offset, slot_bytes[slot]);
@@ -955,6 +958,7 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
         a.bn = op.bn;
         a.clock_probe = m->clock_probe;
         a.dst_pool = d.dst2 >= 0 ? slot_ptr(d.dst2) : nullptr;
+        a.skip_dst = (a.dst_pool && plan.reuse && !plan.unread.empty() && plan.unread[d.dst]) ? 1 : 0;  // e.g. cfg3's second encoder block: 1 GiB per 32 frames nobody reads
         a.wpack_dma = op.w_dma_dev;
         a.wpack_wino = op.w_wino_dev;
         a.wpack_wino2 = op.w_wino2_dev;

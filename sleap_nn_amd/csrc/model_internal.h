@@ -72,6 +72,7 @@ struct Plan {
   std::vector<SlotShape> slots;
   int64_t tmp_offset = 0, tmp_bytes = 0, total = 0;
   bool reuse = false;  // slots share memory by lifetime (handle option workspace_reuse)
+  std::vector<char> unread;  // reuse plans: slot has no reader in the program (a fused conv+pool's full-resolution output the decoder never taps)
   int fmt = FMT_F32;  // activation format of every slot (act_format.h)
   int bpc = 4;        // bytes per channel in that format
 };

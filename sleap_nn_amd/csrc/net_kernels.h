@@ -26,6 +26,7 @@ struct ConvArgs {
   const float* wpack_wino2 = nullptr; // Winograd F(2x2,3x3) weights in LDS order (conv3x3_wino2d_kernel, N tile 64), or nullptr
   int use_wino2d = 1;  // N-tile-64 layers on the F(2x2,3x3) kernel where wpack_wino2 exists (handle option "conv_wino2d")
   const float* w16 = nullptr;  // [tap][ci 16][co 16] weights for conv3x3_c16_kernel (16 -> 16 channel layers), or nullptr
+  int skip_dst = 0;           // the full-resolution output is never read (inference plan, fused pool): only dst_pool is written (Winograd kernels; others ignore it)
   float* dst_pool = nullptr;  // optional fused 2x2/2 max pool of the (ReLU'd) output, NHWC ceil(H/2) x ceil(W/2); nullptr = off
   // kernel selection, filled from the model handle's options (ph_model_set_option)
   int use_wino = 1;   // 1: Winograd F(2,3) kernel where wpack_wino exists; 2: only for the N-tile-64 layers; 0: direct 9-tap kernel

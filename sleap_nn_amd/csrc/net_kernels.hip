@@ -1114,6 +1114,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv3x3_wino_persist_kernel(Con
             for (int r = 0; r < 8; ++r)
               pp[(size_t)((r & 3) + 8 * (r >> 2)) * a.coutp] = fmaxf(fmaxf(ya[r], yb[r]), fmaxf(ya[r + 8], yb[r + 8]));
           }
+          if (a.skip_dst) continue;  // only the pooled output is read
           float* const dp0 = a.dst + ((size_t)(b * a.H + y0 + 2 * wave) * a.W + x0 + 8 * lh) * a.coutp + co;
           if (!a.accumulate) {
 #pragma unroll
@@ -1160,6 +1161,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv3x3_wino_persist_kernel(Con
             }
           }
         }
+        if (a.skip_dst) continue;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int y = y0 + 2 * wave + (r >> 3);

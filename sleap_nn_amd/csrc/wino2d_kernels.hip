@@ -540,7 +540,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_kernel(ConvArgs a) {
         }
       }
     }
-    if (xi == 0 || xi == 3) {
+    if ((xi == 0 || xi == 3) && !a.skip_dst) {
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
         const int co = ntile * BN + n * 32 + lx;
