@@ -406,6 +406,7 @@ def run_infer(args, ctx):
     pad16 = lambda c: (c + 15) // 16 * 16
     wino = model._options.get("conv_wino", 1.0) != 0.0
     wino2d = wino and model._options.get("conv_wino2d", 1.0) != 0.0
+    w16 = wino and model._options.get("conv_w16", 1.0) != 0.0
 
     def conv_kernel(r):
         if fp16:
@@ -414,6 +415,8 @@ def run_infer(args, ctx):
             return "direct", 1.0
         if wino2d and pad16(r["cout"]) >= 64 and pad16(r["cin0"]) + (pad16(r["cin1"]) if r["cin1"] else 0) >= 32:
             return "wino2d", 4.0 / 9.0
+        if w16 and pad16(r["cout"]) == 32 and not r["cin1"] and pad16(r["cin0"]) in (16, 32):
+            return "w16", 4.0 / 9.0
         return "wino1d", 2.0 / 3.0
 
     by_kernel = {}
@@ -432,6 +435,7 @@ def run_infer(args, ctx):
     executed_all = sum(e["executed_flops"] for e in by_kernel.values())
     peak = MFMA_F16_PEAK_TFLOPS if fp16 else MFMA_F32_PEAK_TFLOPS
     KERNEL_NAMES = {"wino2d": "conv3x3_wino2d_kernel<64> (Winograd F(2x2,3x3), 4/9 of the direct MFMA work)",
+                    "w16": "conv3x3_w16_kernel<1|2> (wave-private Winograd F(2x2,3x3) on the 16x16x4 MFMA, Cout 32, 4/9 of the direct MFMA work)",
                     "wino1d": "conv3x3_wino_persist_kernel<64|32> (Winograd F(2,3) along x, 2/3 of the direct MFMA work)",
                     "direct": "conv3x3_mfma_dma_persist_kernel<64|32> (direct)",
                     "f16": f"conv3x3_f16_persist_kernel<64|32, {3 if precision == 'split' else 1}> (direct, fp16 matrix pipe)"}

@@ -183,6 +183,7 @@ int choose_bn(int coutp) { return coutp >= 64 ? 64 : 32; }
 void apply_conv_options(const ph_model* m, ConvArgs& a) {
   a.use_wino = m->conv_wino;
   a.use_wino2d = m->conv_wino2d;
+  a.use_w16 = m->conv_w16;
   a.persist = m->conv_persist;
   a.use_c16 = m->conv_c16;
   a.dma_stagger = m->dma_stagger;
@@ -581,6 +582,22 @@ ph_model* ph_model_create(const ph_op_desc* ops, int32_t n_ops, const float* con
           return true;
         };
         if (ok && !tr) ok = derive_wino2(op.w_dev, d.cin0, d.cin1, d.cout, op.bn, &op.w_wino2_dev);
+        if (ok && !tr && op.bn == 32 && coutp == 32 && d.cin1 == 0 && (pad16(d.cin0) == 16 || pad16(d.cin0) == 32)) {  // conv3x3_w16_kernel
+          const int chunks = pad16(d.cin0) / 16;
+          float* w = nullptr;
+          ok = hipMalloc(&w, (size_t)w16_pack_floats(chunks) * sizeof(float)) == hipSuccess;
+          if (ok) {
+            m->allocs.push_back(w);
+            ok = launch_w16_pack(op.w_dev, w, chunks, nullptr) == PH_OK;
+            DerivedBuffer db;
+            db.src = op.w_dev;
+            db.dst = w;
+            db.panels = chunks;
+            db.kind = 3;
+            m->derived.push_back(db);
+            op.w_w16_dev = w;
+          }
+        }
         if (ok && !tr) {  // row-GEMM form for feature maps too small for the 16x32-pixel tiles
           op.bn_g = gemm_choose_bn(coutp);
           auto pack_g = [&](const auto* w, auto& out) { pack_gemm(w, d.cout, d.cin0, d.cin1, 9, op.bn_g, out); };
@@ -962,6 +979,7 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
         a.wpack_dma = op.w_dma_dev;
         a.wpack_wino = op.w_wino_dev;
         a.wpack_wino2 = op.w_wino2_dev;
+        a.wpack_w16 = op.w_w16_dev;
         a.w16 = op.w16_dev;
         a.zeros = m->zeros_dev;
         apply_conv_options(m, a);
@@ -1240,6 +1258,7 @@ struct OptionRef {
 std::vector<OptionRef> option_table(ph_model* m) {
   return {
       {"conv_wino", &m->conv_wino, nullptr},            // 1 Winograd F(2,3) 3x3 kernels, 2 only N-tile-64 layers, 0 direct 9-tap kernels
+      {"conv_w16", &m->conv_w16, nullptr},              // 1: Cout-32 / Cin-16-or-32 3x3 convs on the wave-private F(2x2,3x3) kernel; 0: F(2,3) along x
       {"conv_wino2d", &m->conv_wino2d, nullptr},        // 1: N-tile-64 3x3 convs on the F(2x2,3x3) kernel; 0: F(2,3) along x only
       {"stem_wino", &m->stem_wino, nullptr},            // second conv of the fused stem in Winograd form
       {"dgrad_wino", &m->dgrad_wino, nullptr},          // 0: direct 9-tap kernels for the backward's data-gradient convs

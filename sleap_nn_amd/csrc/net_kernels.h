@@ -24,6 +24,8 @@ struct ConvArgs {
   int dma_stagger = 1;     // LDS-DMA kernel: SIMD-partner waves issue their DMA piece at different points of a step
   const float* wpack_wino = nullptr;  // Winograd F(2,3)-along-x weights in LDS order (conv3x3_wino_persist_kernel), or nullptr
   const float* wpack_wino2 = nullptr; // Winograd F(2x2,3x3) weights in LDS order (conv3x3_wino2d_kernel, N tile 64), or nullptr
+  const float* wpack_w16 = nullptr;   // wave-private F(2x2,3x3) weights (conv3x3_w16_kernel: Cout 32, Cin 16 / 32), or nullptr
+  int use_w16 = 1;     // handle option "conv_w16"
   int use_wino2d = 1;  // N-tile-64 layers on the F(2x2,3x3) kernel where wpack_wino2 exists (handle option "conv_wino2d")
   const float* w16 = nullptr;  // [tap][ci 16][co 16] weights for conv3x3_c16_kernel (16 -> 16 channel layers), or nullptr
   int skip_dst = 0;           // the full-resolution output is never read (inference plan, fused pool): only dst_pool is written (Winograd kernels; others ignore it)
@@ -126,6 +128,12 @@ int64_t wino2d_pack_floats(int panels, int bn);
 int launch_conv3x3_wino2d(const ConvArgs& a, hipStream_t s);
 bool wino2d_fits(const ConvArgs& a);  // sources addressable through the kernel's 32-bit buffer descriptors
 int prepare_wino2d_kernels();
+// wpack [chunk][tap 9][32][16] -> wave-private F(2x2,3x3) weights [chunk][position][N block][kq][n][4] (see conv3x3_w16_kernel)
+int launch_w16_pack(const float* wpack, float* w16, int chunks, hipStream_t s);
+int64_t w16_pack_floats(int chunks);
+int launch_conv3x3_w16(const ConvArgs& a, hipStream_t s);
+bool w16_fits(const ConvArgs& a);
+int prepare_w16_kernels();
 int launch_input_conv(const InputConvArgs& a, hipStream_t s);
 int launch_pool(const float* src, float* dst, int B, int H, int W, int cp, hipStream_t s);
 int launch_upsample(const float* src, float* dst, int B, int H, int W, int cp, hipStream_t s);

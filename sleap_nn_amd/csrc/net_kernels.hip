@@ -1284,6 +1284,7 @@ int launch_conv3x3_dma(const ConvArgs& a, hipStream_t s) {
   const int tiles = ((a.W + TW - 1) / TW) * ((a.H + D_TH - 1) / D_TH) * a.B;
   const int ntc = (a.coutp + a.bn - 1) / a.bn;
   const bool wino = a.use_wino && a.wpack_wino && (a.bn == 64 || a.use_wino != 2);  // use_wino 2: Winograd for the N-tile-64 layers only
+  if (wino && a.persist && a.use_w16 && w16_fits(a)) return launch_conv3x3_w16(a, s);
   if (wino && a.persist && a.use_wino2d && a.wpack_wino2 && a.bn == 64 && a.c0p + a.c1p >= 32 && wino2d_fits(a)) return launch_conv3x3_wino2d(a, s);
   int n_cu = 0;
   if (a.persist) {
@@ -1838,7 +1839,8 @@ int prepare_kernels() {
     set_error("hipFuncSetAttribute(conv dma) failed: %s", hipGetErrorString(e));
     return PH_E_HIP;
   }
-  return prepare_wino2d_kernels();
+  const int rc2 = prepare_wino2d_kernels();
+  return rc2 != PH_OK ? rc2 : prepare_w16_kernels();
 }
 
 }  // namespace ph

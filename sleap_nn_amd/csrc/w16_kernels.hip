@@ -1,0 +1,301 @@
+// 3x3 "same" convolution with 32 output channels and 16 or 32 input channels (the second encoder block of a filters = 16
+// UNet at half resolution: 2 of cfg3's 16 conv launches) as Winograd F(2x2, 3x3) on v_mfma_f32_16x16x4_f32.
+//
+// Reference semantics: SimpleConvBlock's Conv2d(k3, "same") + bias + ReLU and the 2x2 max pool behind it
+// (architectures/encoder_decoder.py:108-121, architectures/common.py:69-107), as conv3x3_wino2d_kernel (wino2d_kernels.hip).
+//
+// With K this short (one or two 16-channel chunks per tile) the wave-split form of conv3x3_wino2d_kernel would spend more
+// time in its cross-wave epilogue than in the K loop.  Here a wave keeps ALL sixteen Winograd positions of its own tiles:
+// the 16x16x4 MFMA's accumulator is 4 registers, so 16 positions x 2 N blocks of 16 channels are the same 128 accumulator
+// registers, for M = 16 Winograd tiles (8 x 2 tiles = 16 x 4 pixels) per wave.  The output transform, bias, ReLU and the 2x2
+// max pool (a Winograd tile IS a pool window) are then lane-local register arithmetic -- no exchange, no epilogue barrier.
+//   * Workgroup = 8 waves = 16 x 32 pixels; the transformed weights (32 KiB per chunk) stay in LDS for the whole launch
+//     (persistent workgroups); the raw halo (18 x 34 pixels x 16 channels, 40 KiB) is double-buffered per (tile, chunk) unit
+//     and arrives by buffer-descriptor LDS-DMA one unit ahead (out-of-image pixels: the range check's zeros).
+//   * Halo layout [column parity][hy * 9 + hx / 2][16 channels]: the 64 lanes of a fragment read (tile, channel quad) cover
+//     contiguous 512-byte runs.  Per Winograd row xi a lane reads the two patch rows it combines (8 ds_read_b128), 8 VALU ops
+//     give the four A fragments, each feeding 8 MFMAs (2 N blocks x 4 channel groups).
+#include <type_traits>
+
+#include "common.h"
+#include "net_kernels.h"
+
+namespace ph {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int V_TW = 16, V_TH = 32;                     // workgroup tile in pixels
+constexpr int V_HW = V_TW + 2, V_HH = V_TH + 2;         // halo 18 x 34
+constexpr int V_PLANE_E = V_HH * 9;                     // 306 entries per column-parity plane
+constexpr int V_PLANE_PIECES = (V_PLANE_E + 15) / 16;   // 20 DMA pieces (16 entries x 64 B) per plane
+constexpr int V_PLANE_FLOATS = V_PLANE_PIECES * 256;    // 5120
+constexpr int V_HALO_FLOATS = 2 * V_PLANE_FLOATS;       // 10240 per buffer (40 KiB)
+constexpr int V_W_FLOATS = 16 * 2 * 256;                // 8192 per chunk (32 KiB): [position][N block][lane][4]
+
+// wpack [chunk][tap 9][32][16] (pack_conv, N tile 32) -> U = G g G^T as [chunk][position xi * 4 + nu][N block][kq][n][4]
+__global__ __launch_bounds__(256) void w16_pack_kernel(const float* __restrict__ src, float* __restrict__ dst, int chunks) {
+  const int total = chunks * V_W_FLOATS;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const int e = i & 3, n = (i >> 2) & 15, kq = (i >> 6) & 3, nb = (i >> 8) & 1, pos = (i >> 9) & 15, chunk = i >> 13;
+    const int xi = pos >> 2, nu = pos & 3;
+    const int row = nb * 16 + n, kc = 4 * kq + e;
+    const float* w = src + ((size_t)chunk * 9 * 32 + row) * 16 + kc;
+    const int ts = 32 * 16;  // tap stride
+    float h[3];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const float g0 = w[(0 * 3 + kx) * ts], g1 = w[(1 * 3 + kx) * ts], g2 = w[(2 * 3 + kx) * ts];
+      h[kx] = xi == 0 ? g0 : (xi == 1 ? 0.5f * ((g0 + g2) + g1) : (xi == 2 ? 0.5f * ((g0 + g2) - g1) : g2));
+    }
+    dst[i] = nu == 0 ? h[0] : (nu == 1 ? 0.5f * ((h[0] + h[2]) + h[1]) : (nu == 2 ? 0.5f * ((h[0] + h[2]) - h[1]) : h[2]));
+  }
+}
+int64_t w16_pack_floats(int chunks) { return (int64_t)chunks * V_W_FLOATS; }
+int launch_w16_pack(const float* wpack, float* w16, int chunks, hipStream_t s) {
+  hipLaunchKernelGGL(w16_pack_kernel, dim3(std::min(chunks * V_W_FLOATS / 256, 256)), dim3(256), 0, s, wpack, w16, chunks);
+  PH_HIP_CHECK(hipGetLastError());
+  return PH_OK;
+}
+
+template <int CHUNKS>
+__global__ __launch_bounds__(512, 2) void conv3x3_w16_kernel(ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* const wl = lds;                           // transformed weights, resident
+  float* const hbuf = lds + CHUNKS * V_W_FLOATS;   // two halo buffers
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, kq = lane >> 4;
+  const int tiles_x = (a.W + V_TW - 1) / V_TW;
+  const int tiles_y = (a.H + V_TH - 1) / V_TH;
+  const int total = tiles_x * tiles_y * a.B;
+
+  // ---- halo DMA: piece p = wave + 8 s (s = 0..4) of a buffer; lane -> entry (p % 20) * 16 + (lane >> 2) of parity plane p / 20, quad lane & 3
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.src0, 0, (int)((unsigned)(a.B * a.H * a.W) * (unsigned)(a.c0p * 4)), 0x00020000);
+  int hyx[5];  // the lane's halo pixel (hy << 8) | hx in DMA slot s, or -1 beyond the plane
+#pragma unroll
+  for (int s = 0; s < 5; ++s) {
+    const int p = wave + 8 * s;
+    const int par = p >= V_PLANE_PIECES ? 1 : 0;
+    const int e = (p - par * V_PLANE_PIECES) * 16 + (lane >> 2);
+    const int hy = e / 9, hx = 2 * (e - hy * 9) + par;
+    hyx[s] = e < V_PLANE_E ? (hy << 8) | hx : -1;
+  }
+  unsigned fvo[5];
+  // workgroup ids are dealt round-robin over the 8 XCDs: every XCD walks a contiguous range of tiles (neighbours' halo overlap meets in its L2)
+  auto tile_of = [&](int vid) { return (total & 7) == 0 ? (vid & 7) * (total >> 3) + (vid >> 3) : vid; };
+  auto point = [&](int vid) {  // per-lane offsets of tile vid's halo
+    int t = tile_of(vid);
+    const int tx = t % tiles_x;
+    t /= tiles_x;
+    const int ty = t % tiles_y;
+    const int b = t / tiles_y;
+    const int x0 = tx * V_TW, y0 = ty * V_TH;
+    const int base = ((b * a.H + y0) * a.W + x0) * a.c0p * 4;
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+      const int hy = hyx[s] >> 8, hx = hyx[s] & 255;
+      const int gy = y0 + hy - 1, gx = x0 + hx - 1;
+      const bool in = hyx[s] >= 0 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+      fvo[s] = in ? (unsigned)(base + ((hy - 1) * a.W + (hx - 1)) * a.c0p * 4 + (lane & 3) * 16) : 0xFFFFFF00u;
+    }
+  };
+  auto dma = [&](float* buf, int chunk) {
+#pragma unroll
+    for (int s = 0; s < 5; ++s)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(buf + (wave + 8 * s) * 256), 16, fvo[s], chunk * 64, 0, 0);
+  };
+
+  // ---- A side: lane (li, kq) is Winograd tile (tile row 2 wave + (li >> 3), column li & 7), channel quad kq of the chunk
+  const int lbase = ((4 * wave + 2 * (li >> 3)) * 9 + (li & 7)) * 16 + kq * 4;
+  auto a_off = [&](int r, int c) { return lbase + r * 9 * 16 + (c >> 1) * 16 + (c & 1) * V_PLANE_FLOATS; };
+  const int boff = lane * 4;
+
+  // ---- prologue: weights (CHUNKS * 32 pieces of 1 KiB), first unit's halo
+  {
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)a.wpack_w16, 0, CHUNKS * V_W_FLOATS * 4, 0x00020000);
+#pragma unroll
+    for (int s = 0; s < CHUNKS * 4; ++s)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (__attribute__((address_space(3))) void*)(wl + (wave * CHUNKS * 4 + s) * 256), 16, (unsigned)lane * 16u,
+                                               (wave * CHUNKS * 4 + s) * 1024, 0, 0);
+  }
+  int vid = blockIdx.x;
+  point(vid);
+  dma(hbuf, 0);
+  __syncthreads();
+  int par = 0;  // halo buffer of the running unit
+  while (true) {
+    const int nvid = vid + gridDim.x;
+    const bool has_next = nvid < total;
+    f32x4 acc[16][2];
+#pragma unroll
+    for (int p = 0; p < 16; ++p)
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[p][nb][e] = 0.f;
+#pragma unroll 1
+    for (int ch = 0; ch < CHUNKS; ++ch) {  // (one copy of the body: unrolled, the two-chunk variant spills)
+      // the next unit's halo streams into the other buffer under this unit's MFMAs
+      if (ch + 1 < CHUNKS) {
+        dma(hbuf + (par ^ 1) * V_HALO_FLOATS, ch + 1);
+      } else if (has_next) {
+        point(nvid);
+        dma(hbuf + (par ^ 1) * V_HALO_FLOATS, 0);
+      }
+      const float* hb = hbuf + par * V_HALO_FLOATS;
+      const float* wc = wl + ch * V_W_FLOATS + boff;
+      f32x4 da[4], db[4], av[4], bf[2][2];
+      auto read_rows = [&](int xi) {  // the two patch rows Winograd row xi combines
+        const int ra = xi == 0 ? 0 : (xi == 2 ? 2 : 1), rb = xi == 0 ? 2 : (xi == 1 ? 2 : (xi == 2 ? 1 : 3));
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          da[c] = *reinterpret_cast<const f32x4*>(hb + a_off(ra, c));
+          db[c] = *reinterpret_cast<const f32x4*>(hb + a_off(rb, c));
+        }
+      };
+      auto load_b = [&](int pos, int fb) {
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) bf[fb][nb] = *reinterpret_cast<const f32x4*>(wc + (pos * 2 + nb) * 256);
+      };
+      read_rows(0);
+      load_b(0, 0);
+#pragma unroll
+      for (int xi = 0; xi < 4; ++xi) {
+        f32x4 t[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) t[c] = xi == 1 ? da[c] + db[c] : da[c] - db[c];
+        av[0] = t[0] - t[2];
+        av[1] = t[1] + t[2];
+        av[2] = t[2] - t[1];
+        av[3] = t[1] - t[3];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) asm volatile("" : "+v"(av[c]));
+        // Pinned order of a step (one position, 8 MFMAs): its first MFMAs, then the LDS reads of the next step (and, in a row's first
+        // step, the next row's patch rows), then the rest -- a read is never waited for in the step that issues it.
+#pragma unroll
+        for (int nu = 0; nu < 4; ++nu) {
+          const int pos = xi * 4 + nu, cur = pos & 1;
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb) acc[pos][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[cur][nb][0], av[nu][0], acc[pos][nb], 0, 0, 0);  // D[channel][tile]
+          __builtin_amdgcn_sched_barrier(0);
+          if (pos + 1 < 16) load_b(pos + 1, cur ^ 1);
+          if (nu == 0 && xi + 1 < 4) read_rows(xi + 1);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int j = 1; j < 4; ++j)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) acc[pos][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[cur][nb][j], av[nu][j], acc[pos][nb], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      __syncthreads();  // the next unit's halo has landed (vmcnt(0)) and every wave is done with this buffer
+      par ^= 1;
+    }
+    // ---- epilogue, lane-local.  The product is accumulated transposed (weights = A operand): lane (li, kq) holds tile li of the
+    // wave's 16 (tile row li >> 3, column li & 7) and register e is channel nb * 16 + 4 kq + e -- four consecutive channels per
+    // lane, so an output pixel's 16 channels of an N block leave as one 16-byte store per lane (64 contiguous bytes per tile).
+    {
+      int t = tile_of(vid);
+      const int tx = t % tiles_x;
+      t /= tiles_x;
+      const int ty = t % tiles_y;
+      const int b = t / tiles_y;
+      const int x0 = tx * V_TW, y0 = ty * V_TH + 4 * wave;
+      const bool interior = (x0 + V_TW <= a.W) && (y0 + 4 <= a.H);
+      const int Hp = (a.H + 1) >> 1, Wp = (a.W + 1) >> 1;
+      const int oy = y0 + 2 * (li >> 3), ox = x0 + 2 * (li & 7);
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) {
+        const int co = nb * 16 + 4 * kq;
+        const f32x4 bias = *reinterpret_cast<const f32x4*>(a.bias + co);
+        f32x4 y[2][2];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float P[4][2];
+#pragma unroll
+          for (int xi = 0; xi < 4; ++xi) {
+            const float m0 = acc[xi * 4 + 0][nb][e], m1 = acc[xi * 4 + 1][nb][e], m2 = acc[xi * 4 + 2][nb][e], m3 = acc[xi * 4 + 3][nb][e];
+            P[xi][0] = (m0 + m1) + m2;
+            P[xi][1] = (m1 - m2) - m3;
+          }
+#pragma unroll
+          for (int bb = 0; bb < 2; ++bb) {
+            const float v0 = ((P[0][bb] + P[1][bb]) + P[2][bb]) + bias[e], v1 = ((P[1][bb] - P[2][bb]) - P[3][bb]) + bias[e];
+            y[0][bb][e] = a.relu ? fmaxf(v0, 0.f) : v0;
+            y[1][bb][e] = a.relu ? fmaxf(v1, 0.f) : v1;
+          }
+        }
+        if (!a.skip_dst) {
+#pragma unroll
+          for (int aa = 0; aa < 2; ++aa)
+#pragma unroll
+            for (int bb = 0; bb < 2; ++bb)
+              if (interior || (oy + aa < a.H && ox + bb < a.W)) *reinterpret_cast<f32x4*>(a.dst + ((size_t)(b * a.H + oy + aa) * a.W + ox + bb) * a.coutp + co) = y[aa][bb];
+        }
+        if (a.dst_pool) {  // "same" padding: zeros beyond the image
+          f32x4 pm;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float v00 = y[0][0][e], v01 = y[0][1][e], v10 = y[1][0][e], v11 = y[1][1][e];
+            if (!interior) {
+              v00 = (oy < a.H && ox < a.W) ? v00 : 0.f;
+              v01 = (oy < a.H && ox + 1 < a.W) ? v01 : 0.f;
+              v10 = (oy + 1 < a.H && ox < a.W) ? v10 : 0.f;
+              v11 = (oy + 1 < a.H && ox + 1 < a.W) ? v11 : 0.f;
+            }
+            pm[e] = fmaxf(fmaxf(v00, v01), fmaxf(v10, v11));
+          }
+          const int py = oy >> 1, px = ox >> 1;
+          if (interior || (py < Hp && px < Wp)) *reinterpret_cast<f32x4*>(a.dst_pool + ((size_t)(b * Hp + py) * Wp + px) * a.coutp + co) = pm;
+        }
+      }
+    }
+    if (!has_next) break;
+    vid = nvid;
+  }
+}
+
+static int v_cu_count(int* out) {
+  static int n_cu = 0;
+  if (!n_cu) {
+    int dev = 0;
+    PH_HIP_CHECK(hipGetDevice(&dev));
+    PH_HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+  }
+  *out = n_cu;
+  return PH_OK;
+}
+
+int prepare_w16_kernels() {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_w16_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_w16_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e != hipSuccess) {
+    set_error("hipFuncSetAttribute(w16) failed: %s", hipGetErrorString(e));
+    return PH_E_HIP;
+  }
+  return PH_OK;
+}
+
+bool w16_fits(const ConvArgs& a) {
+  const uint64_t px = (uint64_t)a.B * a.H * a.W;
+  return a.wpack_w16 && a.coutp == 32 && a.bn == 32 && !a.src1 && a.c1p == 0 && (a.c0p == 16 || a.c0p == 32) && !a.accumulate && px * (uint64_t)a.c0p * 4 < 0x7FFFFF00ull;
+}
+
+int launch_conv3x3_w16(const ConvArgs& a, hipStream_t s) {
+  PH_REQUIRE(w16_fits(a), "w16: Cout 32 (one N tile), 16 or 32 input channels from one source, no accumulate, source below 2 GiB");
+  int n_cu = 0;
+  const int rc = v_cu_count(&n_cu);
+  if (rc != PH_OK) return rc;
+  const int tiles = ((a.W + V_TW - 1) / V_TW) * ((a.H + V_TH - 1) / V_TH) * a.B;
+  const int chunks = a.c0p / 16;
+  const size_t ldsb = (size_t)(chunks * V_W_FLOATS + 2 * V_HALO_FLOATS) * sizeof(float);
+  if (chunks == 1)
+    hipLaunchKernelGGL(conv3x3_w16_kernel<1>, dim3(std::min(tiles, n_cu)), dim3(512), ldsb, s, a);
+  else
+    hipLaunchKernelGGL(conv3x3_w16_kernel<2>, dim3(std::min(tiles, n_cu)), dim3(512), ldsb, s, a);
+  PH_HIP_CHECK(hipGetLastError());
+  return PH_OK;
+}
+
+}  // namespace ph

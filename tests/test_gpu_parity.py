@@ -978,6 +978,30 @@ def test_winograd_2d_kernel_matches_oracle_and_the_other_conv_kernels(filters, m
     assert torch.equal(again.to(DEV)(img.to(DEV))["SingleInstanceConfmapsHead"].cpu(), outs["w2d"])  # run-to-run bitwise
 
 
+@pytest.mark.parametrize("hw,max_stride", [((64, 64), 8), ((36, 44), 8), ((17, 33), 4), ((96, 80), 4), ((130, 70), 4)])
+def test_wave_private_winograd_kernel_matches_oracle_and_the_1d_kernel(hw, max_stride):
+    """conv3x3_w16_kernel (Cout 32, Cin 16 / 32: the second encoder block of a filters = 16 UNet -- 16 -> 32 and 32 -> 32 + fused pool)
+    on sizes that cut its 16x32-pixel workgroup tiles and its waves' 16x4 strips, with odd sizes through the zero-padded pool,
+    against the oracle and against the F(2,3) kernel the same layers run with ``conv_w16 = 0``."""
+    from sleap_nn_amd.architectures.model import Model
+
+    bb = {"in_channels": 1, "kernel_size": 3, "filters": 16, "filters_rate": 2, "max_stride": max_stride, "stem_stride": None, "middle_block": True,
+          "up_interpolate": True, "stacks": 1, "convs_per_block": 2, "output_stride": max_stride}
+    heads = {"confmaps": {"part_names": ["a", "b", "c"], "output_stride": max_stride}}
+    sd = O.init_state(bb, heads, "single_instance", seed=hw[0], head_scale=1.0)
+    g = torch.Generator().manual_seed(hw[1])
+    img = torch.randint(0, 256, (3, 1, hw[0], hw[1]), dtype=torch.uint8, generator=g)
+    ref = O.model_forward(sd, bb, heads, "single_instance", img)["SingleInstanceConfmapsHead"]
+    outs = {}
+    for name, v in (("w16", 1), ("w1d", 0)):
+        m = Model("unet", bb, heads, "single_instance")
+        m.load_state_dict(sd)
+        m.set_option("conv_w16", v)
+        outs[name] = m.to(DEV)(img.to(DEV))["SingleInstanceConfmapsHead"].cpu()
+    assert (outs["w16"] - ref).abs().max().item() <= CMS_ATOL * max(1.0, ref.abs().max().item())
+    assert (outs["w16"] - outs["w1d"]).abs().max().item() <= 2e-5 * ref.abs().max().item()
+
+
 @pytest.mark.parametrize("name", ["unet_tiny_interp.npz", "unet_tiny_bu13.npz", "ckpt_bottomup.npz"])
 def test_direct_convolution_kernels_still_match_golden(name):
     """The Winograd kernels are the default; the direct 9-tap kernels stay in the library (transposed convs, A/B runs)
