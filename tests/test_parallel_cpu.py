@@ -80,7 +80,7 @@ def test_merge_outputs_pads_instances():
 
 def test_bench_launches_its_own_ranks_and_fails_loudly_without_gpus():
     """`python bench.py --gpus 2` with no launcher must start two rank processes itself (a child torchrun, before any GPU
-    call) and must not quietly measure fewer GPUs than asked: on this GPU-less host both ranks report the shortfall and
+    call) and must not quietly measure fewer GPUs than asked: on this GPU-less host the ranks report the shortfall and
     the command exits non-zero.  A mismatching WORLD_SIZE from an outer launcher is refused as well."""
     import os
     import subprocess
@@ -94,7 +94,8 @@ def test_bench_launches_its_own_ranks_and_fails_loudly_without_gpus():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1"], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0
-    assert r.stderr.count("--gpus 2 but only 0 GPUs are visible") == 2, r.stderr[-1500:]
+    # every rank that gets to speak reports the shortfall (the launcher may tear the second one down as soon as the first has failed)
+    assert 1 <= r.stderr.count("--gpus 2 but only 0 GPUs are visible") <= 2, r.stderr[-1500:]
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4"], env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr
 
