@@ -355,9 +355,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_kernel(ConvArgs a) {
               f32x16 z;
 #pragma unroll
               for (int r = 0; r < 16; ++r) z[r] = 0.f;
-              acc[nu][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[nu][0], bf[fcur][n][0], z, 0, 0, 0);
+              acc[nu][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[fcur][n][0], av[nu][0], z, 0, 0, 0);
             } else {
-              acc[nu][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[nu][0], bf[fcur][n][0], acc[nu][n], 0, 0, 0);
+              acc[nu][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[fcur][n][0], av[nu][0], acc[nu][n], 0, 0, 0);
             }
           }
           __builtin_amdgcn_sched_barrier(0);
@@ -375,7 +375,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_kernel(ConvArgs a) {
           }
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int n = 0; n < NT; ++n) acc[nu][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[nu][1], bf[fcur][n][1], acc[nu][n], 0, 0, 0);
+          for (int n = 0; n < NT; ++n) acc[nu][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[fcur][n][1], av[nu][1], acc[nu][n], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
           if (nu == 0) {
             b_issue2(0, bdst);
@@ -397,7 +397,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_kernel(ConvArgs a) {
 #pragma unroll
           for (int j = 2; j < 4; ++j)
 #pragma unroll
-            for (int n = 0; n < NT; ++n) acc[nu][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[nu][j], bf[fcur][n][j], acc[nu][n], 0, 0, 0);
+            for (int n = 0; n < NT; ++n) acc[nu][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[fcur][n][j], av[nu][j], acc[nu][n], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
         }
         xpass(3);
@@ -409,7 +409,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_kernel(ConvArgs a) {
     half(std::true_type{}, false);
     for (int h = 1; h < 2 * nchunks; ++h) half(std::false_type{}, h + 1 == 2 * nchunks);
     W2_STAMP(st_loop)
-    // ---- epilogue.  In lane (lx, lh) accumulator register r is tile (ty = 4 mh + (r >> 2), tx = (r & 3) + 4 lh), channel n * 32 + lx.
+    // ---- epilogue.  The product is accumulated TRANSPOSED (weights = A operand): lane (lx, lh) is tile (ty = 4 mh + (lx >> 3), tx = lx & 7)
+    // and accumulator register r is channel n * 32 + (r & 3) + 8 (r >> 2) + 4 lh -- four consecutive channels per register quad, so an
+    // output pixel leaves as 16-byte stores (16 per finishing wave instead of 64 four-byte ones).
     // Free LDS until the next half's DMA: weight slot (kb + 2) % 3, halo slots (ka + 3) % 4 ("X") and ka ("Y": the next tile's
     // first half, already transformed) and the spare.  Slot X and the weight slot are DMA targets of the NEXT half, slot Y of
     // the one after.
@@ -424,12 +426,17 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_kernel(ConvArgs a) {
     auto r2 = [&](int idx) -> float* { return idx < 12 ? r2a + idx * 256 : r2b + (idx - 12) * 256; };
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
-      const float bias = xi == 1 ? a.bias[ntile * BN + n * 32 + lx] : 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float m0 = acc[0][n][r], m1 = acc[1][n][r], m2 = acc[2][n][r], m3 = acc[3][n][r];
-        acc[0][n][r] = ((m0 + m1) + m2) + bias;
-        acc[1][n][r] = ((m1 - m2) - m3) + bias;
+      for (int q = 0; q < 4; ++q) {
+        f32x4 bias = {0.f, 0.f, 0.f, 0.f};
+        if (xi == 1) bias = *reinterpret_cast<const f32x4*>(a.bias + ntile * BN + n * 32 + 8 * q + 4 * lh);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * q + e;
+          const float m0 = acc[0][n][r], m1 = acc[1][n][r], m2 = acc[2][n][r], m3 = acc[3][n][r];
+          acc[0][n][r] = ((m0 + m1) + m2) + bias[e];
+          acc[1][n][r] = ((m1 - m2) - m3) + bias[e];
+        }
       }
     }
     if (xi == 1 || xi == 2) {
@@ -492,6 +499,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_kernel(ConvArgs a) {
     if (a.dst_pool) {  // fused 2x2/2 max pool ("same" padding: zeros beyond the image): wave 0's row maxima hop to wave 3
       float* const rp = (mh ? spare + 8 * 256 : slot_y) + lane * 4;  // 8 groups per M half; neither is a DMA target of the next half
       f32x16 rm[NT];
+      const int oy = y0 + 2 * (4 * mh + (lx >> 3)) + arow, ox = x0 + 2 * (lx & 7);  // this lane's output pixel pair (ox, ox + 1) in row oy
       if (xi == 0 || xi == 3) {
 #pragma unroll
         for (int n = 0; n < NT; ++n)
@@ -499,9 +507,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_kernel(ConvArgs a) {
           for (int r = 0; r < 16; ++r) {
             float v0 = acc[0][n][r], v1 = acc[1][n][r];
             if (!interior) {
-              const int y = y0 + 2 * (4 * mh + (r >> 2)) + arow, x = x0 + 2 * ((r & 3) + 4 * lh);
-              v0 = (y < a.H && x < a.W) ? v0 : 0.f;
-              v1 = (y < a.H && x + 1 < a.W) ? v1 : 0.f;
+              v0 = (oy < a.H && ox < a.W) ? v0 : 0.f;
+              v1 = (oy < a.H && ox + 1 < a.W) ? v1 : 0.f;
             }
             rm[n][r] = fmaxf(v0, v1);
           }
@@ -524,53 +531,40 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_kernel(ConvArgs a) {
       __builtin_amdgcn_sched_barrier(0);
       if (xi == 3) {
         const int Hp = (a.H + 1) >> 1, Wp = (a.W + 1) >> 1;
+        const int py = oy >> 1, px = ox >> 1;
 #pragma unroll
-        for (int n = 0; n < NT; ++n) {
-          const int co = ntile * BN + n * 32 + lx;
+        for (int n = 0; n < NT; ++n)
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
             const f32x4 top = *reinterpret_cast<const f32x4*>(rp + (n * 4 + k) * 256);
+            const int co = ntile * BN + n * 32 + 8 * k + 4 * lh;
+            f32x4 v;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const int r = 4 * k + e;
-              const int py = (y0 >> 1) + 4 * mh + (r >> 2), px = (x0 >> 1) + (r & 3) + 4 * lh;
-              if (interior || (py < Hp && px < Wp && co < a.coutp)) a.dst_pool[((size_t)(b * Hp + py) * Wp + px) * a.coutp + co] = fmaxf(top[e], rm[n][r]);
-            }
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(top[e], rm[n][4 * k + e]);
+            if (interior || (py < Hp && px < Wp && co < a.coutp)) *reinterpret_cast<f32x4*>(a.dst_pool + ((size_t)(b * Hp + py) * Wp + px) * a.coutp + co) = v;
           }
-        }
       }
     }
     if ((xi == 0 || xi == 3) && !a.skip_dst) {
+      const int oy = y0 + 2 * (4 * mh + (lx >> 3)) + arow, ox = x0 + 2 * (lx & 7);
+      if (interior || oy < a.H) {
 #pragma unroll
-      for (int n = 0; n < NT; ++n) {
-        const int co = ntile * BN + n * 32 + lx;
-        if (interior) {
-          float* const dp0 = a.dst + ((size_t)(b * a.H + y0 + 8 * mh + arow) * a.W + x0 + 8 * lh) * a.coutp + co;
-          if (a.accumulate) {  // gradient accumulation (the second data-gradient launch into a concat source's gradient)
+        for (int n = 0; n < NT; ++n)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const float* dp = dp0 + ((size_t)(2 * (r >> 2)) * a.W + 2 * (r & 3)) * a.coutp;
-              acc[0][n][r] += dp[0];
-              acc[1][n][r] += dp[a.coutp];
+          for (int k = 0; k < 4; ++k) {
+            const int co = ntile * BN + n * 32 + 8 * k + 4 * lh;
+            if (!interior && co >= a.coutp) continue;
+            float* const dp = a.dst + ((size_t)(b * a.H + oy) * a.W + ox) * a.coutp + co;
+#pragma unroll
+            for (int bb = 0; bb < 2; ++bb) {
+              if (!interior && ox + bb >= a.W) continue;
+              f32x4 v;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = acc[bb][n][4 * k + e];
+              if (a.accumulate) v += *reinterpret_cast<const f32x4*>(dp + bb * a.coutp);  // gradient accumulation (the second data-gradient launch into a concat source's gradient)
+              *reinterpret_cast<f32x4*>(dp + bb * a.coutp) = v;
             }
           }
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            float* dp = dp0 + ((size_t)(2 * (r >> 2)) * a.W + 2 * (r & 3)) * a.coutp;
-            dp[0] = acc[0][n][r];
-            dp[a.coutp] = acc[1][n][r];
-          }
-        } else {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int y = y0 + 2 * (4 * mh + (r >> 2)) + arow, x = x0 + 2 * ((r & 3) + 4 * lh);
-            if (y < a.H && co < a.coutp) {
-              float* dp = a.dst + ((size_t)(b * a.H + y) * a.W + x) * a.coutp + co;
-              if (x < a.W) dp[0] = a.accumulate ? dp[0] + acc[0][n][r] : acc[0][n][r];
-              if (x + 1 < a.W) dp[a.coutp] = a.accumulate ? dp[a.coutp] + acc[1][n][r] : acc[1][n][r];
-            }
-          }
-        }
       }
     }
     W2_STAMP(st_e3)
