@@ -38,7 +38,7 @@ def main():
             e["calls"] = calls
             e[key + "_per_launch"] = tot / calls
             e[key + "_per_forward"] = tot / n_fw
-    conv = [v for k, v in res["kernels"].items() if "conv3x3_mfma" in k or "conv3x3_wino" in k]
+    conv = [v for k, v in res["kernels"].items() if "conv3x3_mfma" in k or "conv3x3_wino" in k or "conv3x3_w16" in k]
     res["conv3x3_mfma"] = {
         "launches_per_forward": sum(v["calls"] for v in conv) / n_fw,
         "hbm_bytes_per_forward": sum(v.get("fetch_bytes_per_forward", 0) + v.get("write_bytes_per_forward", 0) for v in conv),
