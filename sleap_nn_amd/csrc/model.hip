@@ -512,6 +512,20 @@ ph_model* ph_model_create(const ph_op_desc* ops, int32_t n_ops, const float* con
             op.w_wino_dev = w;
           }
         }
+        if (ok) {  // ... and its F(2x2,3x3) form (the default)
+          float* w = nullptr;
+          ok = hipMalloc(&w, 16 * 256 * sizeof(float)) == hipSuccess;
+          if (ok) {
+            m->allocs.push_back(w);
+            ok = launch_stem_wino2d_pack(op.w2_dev, w, nullptr) == PH_OK;
+            DerivedBuffer db;
+            db.src = op.w2_dev;
+            db.dst = w;
+            db.kind = 4;
+            m->derived.push_back(db);
+            op.w_stem2_dev = w;
+          }
+        }
         break;
       }
       case PH_OP_CONV:
@@ -889,6 +903,7 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
         a.b0 = op.b_dev;
         a.w1 = op.w2_dev;
         a.w1w = op.w_wino_dev;
+        a.w1w2 = op.w_stem2_dev;
         a.b1 = op.b2_dev;
         a.dst_full = d.dst >= 0 ? slot_ptr(d.dst) : nullptr;
         a.dst_pool = slot_ptr(d.dst2);

@@ -31,6 +31,7 @@ struct PackedOp {
   int bn_d[2] = {0, 0};
   float* w_wino_dev = nullptr;             // 3x3 conv, N tile 64: Winograd F(2,3) weights derived on the device from w_dev
   float* wd_wino_dev[2] = {nullptr, nullptr};  // ... and from wd_dev (data gradient)
+  float* w_stem2_dev = nullptr;            // fused stem: F(2x2,3x3) weights of the second conv
   float* w_w16_dev = nullptr;              // 3x3 conv, Cout 32, Cin 16 / 32: wave-private F(2x2,3x3) weights derived from w_dev
   float* w_wino2_dev = nullptr;            // 3x3 conv, N tile 64: Winograd F(2x2,3x3) weights derived from w_dev
   float* wd_wino2_dev[2] = {nullptr, nullptr};  // ... and from wd_dev (data gradient)
@@ -59,7 +60,7 @@ struct DerivedBuffer {
   const float* src = nullptr;
   float* dst = nullptr;
   int panels = 0, bn = 0;  // bn == 0: the fused stem's second conv (launch_stem_wino_pack)
-  int kind = 0;            // 0: Winograd transform of src; 1: fp16 weight pack of the LDS-DMA panels (launch_f16_weight_pack); 2: F(2x2,3x3) transform; 3: wave-private F(2x2,3x3) transform (panels = chunks)
+  int kind = 0;            // 0: Winograd transform of src; 1: fp16 weight pack of the LDS-DMA panels (launch_f16_weight_pack); 2: F(2x2,3x3) transform; 3: wave-private F(2x2,3x3) transform (panels = chunks); 4: the fused stem's F(2x2,3x3) transform
   int n_tiles = 0, chunks0 = 0, chunks1 = 0, plain = 0;  // kind 1
 };
 
@@ -109,7 +110,7 @@ struct ph_model {
   int conv_w16 = 1;                           // "conv_w16": Cout-32 / Cin-16-or-32 3x3 convs on the wave-private F(2x2,3x3) kernel
   int conv_wino2d = 1;                        // "conv_wino2d": N-tile-64 3x3 convs on the F(2x2,3x3) kernel (0: the F(2,3)-along-x kernel)
   int dgrad_wino = 1;                         // "dgrad_wino": 0 = direct 9-tap kernels for the backward's data-gradient convs (A/B: ~7 % slower cfg3 step, same gradients to the digit)
-  int stem_wino = 1;                          // "stem_wino"
+  int stem_wino = 2;                          // "stem_wino"
   int conv_persist = 1;                       // "conv_persist"
   int conv_c16 = 1;                           // "conv_c16"
   int dma_stagger = 1;                        // "conv_dma_stagger"

@@ -55,11 +55,12 @@ struct StemArgs {
   const float* w1;     // [tap][n=16][16] second conv, k contiguous
   const float* b1;     // [16]
   const float* w1w = nullptr;  // second conv, Winograd F(2,3) along x: [kernel row][m index 4][n=16][16], or nullptr
+  const float* w1w2 = nullptr; // second conv, Winograd F(2x2,3x3): [position 16][n=16][16], or nullptr
   void* dst_full;      // NHWC 16 full resolution or nullptr (format out_fmt)
   void* dst_pool;      // NHWC 16, ceil(H/2) x ceil(W/2)
   int dtype, cin, B, H, W;
   int out_fmt = 0;     // ActFmt of the outputs (act_format.h)
-  int wino = 1;        // second conv in Winograd form (handle option "stem_wino")
+  int wino = 2;        // second conv: 2 Winograd F(2x2,3x3), 1 F(2,3) along x, 0 direct (handle option "stem_wino")
 };
 
 struct PatchStemArgs {
@@ -120,7 +121,8 @@ int launch_conv3x3(const ConvArgs& a, hipStream_t s);
 // wpack [panel][tap 9][bn][16] -> Winograd weights [panel][step 24][n tile][lh][lx][4] (see conv3x3_wino_persist_kernel)
 int launch_wino_pack(const float* wpack, float* wino, int panels, int bn, hipStream_t s);
 int64_t wino_pack_floats(int panels, int bn);
-int launch_stem_wino_pack(const float* w1, float* w1w, hipStream_t s);  // [tap][co][ci] -> [kernel row][m index][co][ci]
+int launch_stem_wino_pack(const float* w1, float* w1w, hipStream_t s);
+int launch_stem_wino2d_pack(const float* w1, float* w2, hipStream_t s);  // [tap][co][ci] -> [position 16][co][ci]  // [tap][co][ci] -> [kernel row][m index][co][ci]
 int launch_conv3x3_dma(const ConvArgs& a, hipStream_t s);
 // wpack [panel][tap 9][bn][16] -> F(2x2,3x3) weights [panel][g 2][xi 4][nu 4][n tile][lh][lx][4] (see conv3x3_wino2d_kernel)
 int launch_wino2d_pack(const float* wpack, float* wino, int panels, int bn, hipStream_t s);

@@ -862,6 +862,25 @@ __global__ __launch_bounds__(256) void stem_wino_pack_kernel(const float* __rest
     w1w[i] = xi == 0 ? g0 : (xi == 1 ? 0.5f * ((g0 + g2) + g1) : (xi == 2 ? 0.5f * ((g0 + g2) - g1) : g2));
   }
 }
+// fused stem, F(2x2,3x3): w1 [tap][co 16][ci 16] -> U = G g G^T as [position xi * 4 + nu][co][ci]
+__global__ __launch_bounds__(256) void stem_wino2d_pack_kernel(const float* __restrict__ w1, float* __restrict__ w2) {
+  for (int i = threadIdx.x; i < 16 * 256; i += 256) {
+    const int e = i & 255, pos = i >> 8;
+    const int xi = pos >> 2, nu = pos & 3;
+    float h[3];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const float g0 = w1[(0 * 3 + kx) * 256 + e], g1 = w1[(1 * 3 + kx) * 256 + e], g2 = w1[(2 * 3 + kx) * 256 + e];
+      h[kx] = xi == 0 ? g0 : (xi == 1 ? 0.5f * ((g0 + g2) + g1) : (xi == 2 ? 0.5f * ((g0 + g2) - g1) : g2));
+    }
+    w2[i] = nu == 0 ? h[0] : (nu == 1 ? 0.5f * ((h[0] + h[2]) + h[1]) : (nu == 2 ? 0.5f * ((h[0] + h[2]) - h[1]) : h[2]));
+  }
+}
+int launch_stem_wino2d_pack(const float* w1, float* w2, hipStream_t s) {
+  hipLaunchKernelGGL(stem_wino2d_pack_kernel, dim3(1), dim3(256), 0, s, w1, w2);
+  PH_HIP_CHECK(hipGetLastError());
+  return PH_OK;
+}
 int launch_stem_wino_pack(const float* w1, float* w1w, hipStream_t s) {
   hipLaunchKernelGGL(stem_wino_pack_kernel, dim3(1), dim3(256), 0, s, w1, w1w);
   PH_HIP_CHECK(hipGetLastError());
@@ -1351,7 +1370,7 @@ __device__ __forceinline__ void stem_store4(const StemArgs& a, void* base, size_
     store4<FMT_F32>(base, pix, 16, c0, v);
 }
 
-template <int CIN, bool WINO>
+template <int CIN, int WINO>  // WINO: 0 direct second conv, 1 Winograd F(2,3) along x, 2 Winograd F(2x2,3x3)
 __global__ __launch_bounds__(256, 4) void stem_fused_kernel(StemArgs a) {
   constexpr int IMG_W = TW + 4, IMG_H = TH + 4;   // image patch incl. both halos
   __shared__ __attribute__((aligned(16))) float sA[HALO_H * HALO_W * LROW];   // conv0 output (conv1 input halo)
@@ -1428,7 +1447,67 @@ __global__ __launch_bounds__(256, 4) void stem_fused_kernel(StemArgs a) {
 
   // ---- conv1 on the matrix cores
   const int li = lane & 15, lg = lane >> 4;
-  if constexpr (WINO) {
+  if constexpr (WINO == 2) {
+    // F(2x2,3x3), wave-private (as conv3x3_w16_kernel): the wave's two image rows are ONE row of 16 Winograd tiles (tile li = output
+    // columns 2 li, 2 li + 1), all sixteen positions in the wave (16 accumulators of 4 registers), 64 MFMAs instead of the 96 of the
+    // 1-D form; transposed product (weights = A operand): lane (li, lg) ends with channels 4 lg .. 4 lg + 3 of its tile's four pixels,
+    // so bias, ReLU, the stores and the 2x2 max pool are lane-local.
+    f32x4 acc[16];
+#pragma unroll
+    for (int p = 0; p < 16; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int xi = 0; xi < 4; ++xi) {
+      constexpr int RA[4] = {0, 1, 2, 1}, RB[4] = {2, 2, 1, 3};
+      f32x4 t[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const f32x4 da = *reinterpret_cast<const f32x4*>(sA + ((2 * wave + RA[xi]) * HALO_W + 2 * li + c) * LROW + lg * 4);
+        const f32x4 db = *reinterpret_cast<const f32x4*>(sA + ((2 * wave + RB[xi]) * HALO_W + 2 * li + c) * LROW + lg * 4);
+        t[c] = xi == 1 ? da + db : da - db;
+      }
+      const f32x4 av[4] = {t[0] - t[2], t[1] + t[2], t[2] - t[1], t[1] - t[3]};
+#pragma unroll
+      for (int nu = 0; nu < 4; ++nu) {
+        const int pos = xi * 4 + nu;
+        const f32x4 bw = *reinterpret_cast<const f32x4*>(a.w1w2 + (size_t)(pos * 16 + li) * 16 + lg * 4);  // A[i = li (output channel)][k = lg], element j = input channel 4 lg + j
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[pos] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[j], av[nu][j], acc[pos], 0, 0, 0);
+      }
+    }
+    const f32x4 bias4 = *reinterpret_cast<const f32x4*>(a.b1 + 4 * lg);
+    const int Hp = (a.H + 1) / 2, Wp = (a.W + 1) / 2;
+    const int x = x0 + 2 * li, y = y0 + 2 * wave;
+    float o[2][2][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float P[4][2];
+#pragma unroll
+      for (int xi = 0; xi < 4; ++xi) {
+        const float m0 = acc[xi * 4 + 0][r], m1 = acc[xi * 4 + 1][r], m2 = acc[xi * 4 + 2][r], m3 = acc[xi * 4 + 3][r];
+        P[xi][0] = (m0 + m1) + m2;
+        P[xi][1] = (m1 - m2) - m3;
+      }
+#pragma unroll
+      for (int bb = 0; bb < 2; ++bb) {
+        o[0][bb][r] = fmaxf(((P[0][bb] + P[1][bb]) + P[2][bb]) + bias4[r], 0.f);
+        o[1][bb][r] = fmaxf(((P[1][bb] - P[2][bb]) - P[3][bb]) + bias4[r], 0.f);
+      }
+    }
+    float pooled[4] = {0.f, 0.f, 0.f, 0.f};  // values are >= 0 after the ReLU; out-of-image elements count as the reference's zero pad
+#pragma unroll
+    for (int aa = 0; aa < 2; ++aa)
+#pragma unroll
+      for (int bb = 0; bb < 2; ++bb) {
+        const bool in = (y + aa < a.H) && (x + bb < a.W);
+        if (in && a.dst_full) stem_store4(a, a.dst_full, ((size_t)b * a.H + y + aa) * a.W + x + bb, 4 * lg, o[aa][bb]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pooled[r] = fmaxf(pooled[r], in ? o[aa][bb][r] : 0.f);
+      }
+    const int py = (y0 >> 1) + wave, px = (x0 >> 1) + li;
+    if (py < Hp && px < Wp) stem_store4(a, a.dst_pool, ((size_t)b * Hp + py) * Wp + px, 4 * lg, pooled);
+    return;
+  }
+  if constexpr (WINO == 1) {
     // The product is accumulated TRANSPOSED (the transformed weights are the A operand, the pixel pairs the B operand): D row
     // 4 lg + r = output channel, column li = output pair t (pixels 2t, 2t + 1), so a lane owns four consecutive channels of
     // its pair -- one 16-byte (fp32) or 8-byte (fp16 formats) store per pixel, and the 2x2 max pool is in-lane arithmetic.
@@ -1546,15 +1625,19 @@ __global__ __launch_bounds__(256, 4) void stem_fused_kernel(StemArgs a) {
 int launch_stem(const StemArgs& a, hipStream_t s) {
   const int tiles = ((a.W + TW - 1) / TW) * ((a.H + TH - 1) / TH) * a.B;
   const int grid = 8 * ((tiles + 7) / 8);  // the kernel deals tiles to XCDs in contiguous ranges
-  const bool wino = a.wino && a.w1w;
-  if (a.cin == 1 && wino)
-    hipLaunchKernelGGL((stem_fused_kernel<1, true>), dim3(grid), dim3(256), 0, s, a);
+  const int wino = (a.wino >= 2 && a.w1w2) ? 2 : ((a.wino && a.w1w) ? 1 : 0);
+  if (a.cin == 1 && wino == 2)
+    hipLaunchKernelGGL((stem_fused_kernel<1, 2>), dim3(grid), dim3(256), 0, s, a);
+  else if (a.cin == 1 && wino == 1)
+    hipLaunchKernelGGL((stem_fused_kernel<1, 1>), dim3(grid), dim3(256), 0, s, a);
   else if (a.cin == 1)
-    hipLaunchKernelGGL((stem_fused_kernel<1, false>), dim3(grid), dim3(256), 0, s, a);
-  else if (a.cin == 3 && wino)
-    hipLaunchKernelGGL((stem_fused_kernel<3, true>), dim3(grid), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((stem_fused_kernel<1, 0>), dim3(grid), dim3(256), 0, s, a);
+  else if (a.cin == 3 && wino == 2)
+    hipLaunchKernelGGL((stem_fused_kernel<3, 2>), dim3(grid), dim3(256), 0, s, a);
+  else if (a.cin == 3 && wino == 1)
+    hipLaunchKernelGGL((stem_fused_kernel<3, 1>), dim3(grid), dim3(256), 0, s, a);
   else if (a.cin == 3)
-    hipLaunchKernelGGL((stem_fused_kernel<3, false>), dim3(grid), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((stem_fused_kernel<3, 0>), dim3(grid), dim3(256), 0, s, a);
   else {
     set_error("fused stem supports 1 or 3 input channels, got %d", a.cin);
     return PH_E_INVALID;

@@ -110,6 +110,7 @@ int ph_model_set_params(ph_model* m, const float* params_flat_dev, void* stream)
     int rc = db.kind == 1 ? launch_f16_weight_pack(db.src, db.dst, db.n_tiles, db.chunks0, db.chunks1, db.bn, db.plain, static_cast<hipStream_t>(stream))
              : db.kind == 2 ? launch_wino2d_pack(db.src, db.dst, db.panels, db.bn, static_cast<hipStream_t>(stream))
              : db.kind == 3 ? launch_w16_pack(db.src, db.dst, db.panels, static_cast<hipStream_t>(stream))
+             : db.kind == 4 ? launch_stem_wino2d_pack(db.src, db.dst, static_cast<hipStream_t>(stream))
              : db.bn == 0 ? launch_stem_wino_pack(db.src, db.dst, static_cast<hipStream_t>(stream))
                           : launch_wino_pack(db.src, db.dst, db.panels, db.bn, static_cast<hipStream_t>(stream));
     if (rc != PH_OK) return rc;
