@@ -83,13 +83,15 @@ def test_stem_fusion_odd_sizes_vs_unfused():
         g = torch.Generator().manual_seed(hw[0])
         img = torch.randint(0, 256, (2, 1, hw[0], hw[1]), dtype=torch.uint8, generator=g)
         ref = O.model_forward(sd, bb, heads, "single_instance", img)["SingleInstanceConfmapsHead"]
-        m = Model("unet", bb, heads, "single_instance")
-        m.load_state_dict(sd)
-        assert m.ops[0].kind == 7  # fused stem in the plan
-        # output_stride 2 with max_stride 2: the head sits on the middle block (no decoder) -> only the pooled path
-        out = m.to(DEV)(img.to(DEV))["SingleInstanceConfmapsHead"].cpu()
-        assert out.shape == ref.shape
-        assert (out - ref).abs().max().item() <= CMS_ATOL, hw
+        for stem_wino in (2, 1, 0):  # second conv as Winograd F(2x2,3x3) (the default), F(2,3) along x, direct
+            m = Model("unet", bb, heads, "single_instance")
+            m.load_state_dict(sd)
+            m.set_option("stem_wino", stem_wino)
+            assert m.ops[0].kind == 7  # fused stem in the plan
+            # output_stride 2 with max_stride 2: the head sits on the middle block (no decoder) -> only the pooled path
+            out = m.to(DEV)(img.to(DEV))["SingleInstanceConfmapsHead"].cpu()
+            assert out.shape == ref.shape
+            assert (out - ref).abs().max().item() <= CMS_ATOL, (hw, stem_wino)
 
 
 def test_forward_float_inputs_and_odd_batch():
