@@ -199,6 +199,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch the forward kernel by kernel instead of replaying one hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-h2d-leg", action="store_true")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="REHEARSAL of the multi-rank code path on a one-GPU box: all ranks share cuda:0 and synchronise over gloo "
+                         "(RCCL refuses two ranks on one device).  The line it prints is marked as such and is not a measurement.")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -208,13 +211,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
-    if torch.cuda.device_count() < world:
+    if torch.cuda.device_count() < world and not (args.rehearse_on_one_gpu and torch.cuda.device_count() >= 1):
         raise SystemExit(f"bench.py: --gpus {args.gpus} but only {torch.cuda.device_count()} GPUs are visible")
     import torch.distributed as dist
 
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 and args.rehearse_on_one_gpu:
+        dist.init_process_group(backend="gloo")
+    elif world > 1:
         dist.init_process_group(backend="nccl", device_id=dev)
         if dist.get_world_size() != args.gpus:
             raise SystemExit(f"bench.py: RCCL sees {dist.get_world_size()} ranks, --gpus asked for {args.gpus}")
@@ -223,6 +230,8 @@ def main():
     ctx = {"rank": rank, "world": world, "dev": dev, "dist": dist}
     res = run_train(args, ctx) if args.mode == "train" else run_infer(args, ctx)
     if rank == 0:
+        if args.rehearse_on_one_gpu:
+            res["data"] = "REHEARSAL: %d ranks on one GPU over gloo -- not a measurement" % world
         print(json.dumps(res))
     if world > 1:
         dist.barrier()

@@ -1,0 +1,35 @@
+"""bench.py's multi-rank code path, rehearsed on the one GPU of the test box: the self-launch (a child torchrun), the frame sharding
+of weak and strong scaling, the max-over-ranks timing and the rank-0 JSON line.  All ranks share cuda:0 and synchronise over gloo
+(RCCL refuses two ranks on one device), so the numbers mean nothing -- the structure of the line is what is checked."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(*args):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, r.stdout[-1000:]  # exactly one line, from rank 0
+    return json.loads(lines[0])
+
+
+@pytest.mark.skipif(not torch.cuda.is_available(), reason="needs a GPU")
+def test_two_ranks_weak_and_three_ranks_strong_rehearsal():
+    d = _run("--gpus", "2", "--rehearse-on-one-gpu", "--steps", "3", "--warmup", "1", "--batch", "4", "--no-alt-precisions", "--no-h2d-leg")
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 3 and d["warmup"] == 1
+    assert d["config"]["frames_per_gpu_per_step"] == 4 and d["config"]["global_batch"] == 8
+    assert d["value"] > 0 and abs(d["value"] - 8 * 3 / (d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]  # whole-job frames / max-over-ranks time
+    assert "cpu_baseline" not in d and "REHEARSAL" in d["data"]  # the CPU leg belongs to N = 1
+    assert d["roofline"]["kernel"].startswith("conv3x3_wino2d_kernel") and 0 < d["roofline"]["frac"] < 1
+    d = _run("--gpus", "3", "--rehearse-on-one-gpu", "--steps", "2", "--warmup", "1", "--scaling", "strong", "--global-batch", "8", "--no-alt-precisions", "--no-h2d-leg")
+    assert d["n_gpus"] == 3 and d["scaling"] == "strong" and d["config"]["global_batch"] == 8
+    assert d["config"]["frames_per_gpu_per_step"] in (2, 3)  # rank 0's contiguous chunk of 8 frames over 3 ranks
