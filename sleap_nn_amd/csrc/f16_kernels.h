@@ -16,6 +16,7 @@ struct ConvF16Args {
   const float* bias = nullptr;   // fp32, padded to a multiple of bn
   void* dst = nullptr;           // FMT_SPLIT (prec 3) / FMT_F16 (prec 1)
   void* dst_pool = nullptr;      // optional fused 2x2/2 max pool output, same format
+  int skip_dst = 0;              // the full-resolution output is never read (inference plan): only dst_pool is written
   int rs_dst = 0;                // pixel stride of dst / dst_pool in 4-byte units
   int coutp = 0;                 // padded output channels (split: multiple of 16, plain: of 32)
   int B = 0, H = 0, W = 0;

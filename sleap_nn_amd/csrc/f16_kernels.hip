@@ -282,6 +282,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16_persist_kernel(ConvF16Args
     };
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
+      if (a.skip_dst) break;  // nobody reads the full-resolution output: only the pooled one below
       const int y = y0 + 2 * wave + m;
 #pragma unroll
       for (int n = 0; n < NT; ++n)

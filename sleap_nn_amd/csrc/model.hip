@@ -936,6 +936,7 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
           f.bias = op.b_dev;
           f.dst = slot_ptr(d.dst);
           f.dst_pool = d.dst2 >= 0 ? slot_ptr(d.dst2) : nullptr;
+          f.skip_dst = (f.dst_pool && plan.reuse && !plan.unread.empty() && plan.unread[d.dst]) ? 1 : 0;
           f.rs_dst = so.cp / rs_div;
           f.coutp = so.cp;
           f.B = batch;
