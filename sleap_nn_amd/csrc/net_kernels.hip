@@ -1447,6 +1447,66 @@ __global__ __launch_bounds__(256, 4) void stem_fused_kernel(StemArgs a) {
 
   // ---- conv1 on the matrix cores
   const int li = lane & 15, lg = lane >> 4;
+  if constexpr (WINO == 3) {
+    // Plain-fp16 precision (the reference's autocast mode, output format FMT_F16): the second conv on v_mfma_f32_16x16x16_f16 -- all 16
+    // input channels of a tap are ONE MFMA per 16 pixels (36 MFMAs per wave instead of 64 fp32 ones plus their Winograd transforms).
+    // The first conv's fp32 output is rounded to fp16 as it is read (autocast's conv-to-conv tensor is fp16 too); fp32 accumulation.
+    // Transposed product: D[channel 4 lg + e][pixel li] per (row m, half h of the 32 columns).
+    f16x4 wa[9];  // A[i = li (output channel)][k = 4 lg .. 4 lg + 3 (input channels)] per tap
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const f32x4 w = *reinterpret_cast<const f32x4*>(a.w1 + (size_t)(tap * 16 + li) * 16 + lg * 4);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) wa[tap][k] = (_Float16)w[k];
+    }
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) acc[m][h] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int ky = tap / 3, kx = tap - ky * 3;
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const f32x4 x = *reinterpret_cast<const f32x4*>(sA + ((2 * wave + m + ky) * HALO_W + h * 16 + li + kx) * LROW + lg * 4);
+          f16x4 xb;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) xb[k] = (_Float16)x[k];
+          acc[m][h] = __builtin_amdgcn_mfma_f32_16x16x16f16(wa[tap], xb, acc[m][h], 0, 0, 0);
+        }
+    }
+    const f32x4 bias4 = *reinterpret_cast<const f32x4*>(a.b1 + 4 * lg);
+    const int Hp = (a.H + 1) / 2, Wp = (a.W + 1) / 2;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int x = x0 + h * 16 + li;
+      float pooled[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pooled[r] = 0.f;  // values are >= 0 after the ReLU; out-of-image elements count as the reference's zero pad
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const int y = y0 + 2 * wave + m;
+        const bool in = (y < a.H) && (x < a.W);
+        float o[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = fmaxf(acc[m][h][r] + bias4[r], 0.f);
+        if (in && a.dst_full) stem_store4(a, a.dst_full, ((size_t)b * a.H + y) * a.W + x, 4 * lg, o);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pooled[r] = fmaxf(pooled[r], in ? o[r] : 0.f);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {  // the x neighbour of the pool window sits in lane li ^ 1
+        const int pi = __builtin_bit_cast(int, pooled[r]);
+        pooled[r] = fmaxf(pooled[r], __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(pi, pi, 0xB1, 0xF, 0xF, false)));
+      }
+      const int py = (y0 >> 1) + wave, px = (x0 >> 1) + h * 8 + (li >> 1);
+      if (!(li & 1) && py < Hp && px < Wp) stem_store4(a, a.dst_pool, ((size_t)b * Hp + py) * Wp + px, 4 * lg, pooled);
+    }
+    return;
+  }
   if constexpr (WINO == 2) {
     // F(2x2,3x3), wave-private (as conv3x3_w16_kernel): the wave's two image rows are ONE row of 16 Winograd tiles (tile li = output
     // columns 2 li, 2 li + 1), all sixteen positions in the wave (16 accumulators of 4 registers), 64 MFMAs instead of the 96 of the
@@ -1625,8 +1685,12 @@ __global__ __launch_bounds__(256, 4) void stem_fused_kernel(StemArgs a) {
 int launch_stem(const StemArgs& a, hipStream_t s) {
   const int tiles = ((a.W + TW - 1) / TW) * ((a.H + TH - 1) / TH) * a.B;
   const int grid = 8 * ((tiles + 7) / 8);  // the kernel deals tiles to XCDs in contiguous ranges
-  const int wino = (a.wino >= 2 && a.w1w2) ? 2 : ((a.wino && a.w1w) ? 1 : 0);
-  if (a.cin == 1 && wino == 2)
+  const int wino = (a.out_fmt == FMT_F16 && a.wino >= 2) ? 3 : (a.wino >= 2 && a.w1w2) ? 2 : ((a.wino && a.w1w) ? 1 : 0);
+  if (a.cin == 1 && wino == 3)
+    hipLaunchKernelGGL((stem_fused_kernel<1, 3>), dim3(grid), dim3(256), 0, s, a);
+  else if (a.cin == 3 && wino == 3)
+    hipLaunchKernelGGL((stem_fused_kernel<3, 3>), dim3(grid), dim3(256), 0, s, a);
+  else if (a.cin == 1 && wino == 2)
     hipLaunchKernelGGL((stem_fused_kernel<1, 2>), dim3(grid), dim3(256), 0, s, a);
   else if (a.cin == 1 && wino == 1)
     hipLaunchKernelGGL((stem_fused_kernel<1, 1>), dim3(grid), dim3(256), 0, s, a);
