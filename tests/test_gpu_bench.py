@@ -33,3 +33,15 @@ def test_two_ranks_weak_and_three_ranks_strong_rehearsal():
     d = _run("--gpus", "3", "--rehearse-on-one-gpu", "--steps", "2", "--warmup", "1", "--scaling", "strong", "--global-batch", "8", "--no-alt-precisions", "--no-h2d-leg")
     assert d["n_gpus"] == 3 and d["scaling"] == "strong" and d["config"]["global_batch"] == 8
     assert d["config"]["frames_per_gpu_per_step"] in (2, 3)  # rank 0's contiguous chunk of 8 frames over 3 ranks
+
+
+@pytest.mark.skipif(not torch.cuda.is_available(), reason="needs a GPU")
+def test_two_ranks_training_rehearsal():
+    """--mode train with two ranks: identical initial arenas, disjoint shards, the two-bucket gradient all-reduce overlapped with the
+    backward (gloo here), Adam on every rank -- the loss must be finite and move, the line must say what it measured."""
+    d = _run("--gpus", "2", "--rehearse-on-one-gpu", "--mode", "train", "--steps", "3", "--warmup", "1", "--batch", "2")
+    assert d["n_gpus"] == 2 and d["config"]["samples_per_gpu_per_step"] == 2 and d["config"]["global_batch"] == 4
+    first, last = d["loss_first_last"]
+    assert first > 0 and last > 0 and first == first and last == last and last != first
+    assert d["allreduce"]["bucket_split"] is not None and d["allreduce"]["arena_mb"] > 30  # 7.8 M parameters in one flat arena
+    assert "REHEARSAL" in d["data"] and 0 < d["roofline"]["frac"] < 1
