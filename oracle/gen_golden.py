@@ -320,6 +320,17 @@ def stem_and_kernel_fixtures():
     tiny_unet("unet_tiny_k5.npz", bb5, heads5, "bottomup", (40, 56), 2, seed=43)
 
 
+def winograd_kernel_fixture():
+    """A filters = 16 UNet (channels 16 / 32 / 64 / 128 / 256, bottom-up heads) small enough to commit: the reference Model's outputs and a
+    few activations for the layers the MI355X build runs on its Winograd F(2x2,3x3) kernels -- 16 -> 32 and 32 -> 32 + pool (wave-private
+    kernel), 32 -> 64 ... 256 -> 256 and the two-source decoder convs (wave-split kernel) -- on a frame size that cuts their tiles."""
+    bb = {"in_channels": 1, "kernel_size": 3, "filters": 16, "filters_rate": 2, "max_stride": 8, "stem_stride": None, "middle_block": True, "up_interpolate": True,
+          "stacks": 1, "convs_per_block": 2, "output_stride": 2}
+    heads = {"confmaps": {"part_names": ["a", "b", "c", "d"], "sigma": 2.5, "output_stride": 2, "loss_weight": 1.0},
+             "pafs": {"edges": [["a", "b"], ["b", "c"], ["c", "d"]], "sigma": 15, "output_stride": 4, "loss_weight": 1.0}}
+    tiny_unet("unet_f16_wino.npz", bb, heads, "bottomup", (56, 88), 2, seed=47)
+
+
 def core_fixtures():
     ckpt_fixture("bottomup", "bottomup", n_frames=2)
     ckpt_fixture("single_instance", "single_instance", n_frames=2)
@@ -785,6 +796,8 @@ if __name__ == "__main__":
         losses_fixture()
     if not only or "stem" in only:
         stem_and_kernel_fixtures()
+    if not only or "wino" in only:
+        winograd_kernel_fixture()
     if not only or "evaluation" in only:
         evaluation_fixture()
     if not only or "schedulers" in only:

@@ -28,7 +28,7 @@ def _model(cfg, weights):
 
 
 @pytest.mark.parametrize("name", ["unet_tiny_interp.npz", "unet_tiny_trans.npz", "unet_tiny_bu13.npz", "unet_tiny_rgb.npz", "ckpt_bottomup.npz", "ckpt_single_instance.npz",
-                                  "unet_tiny_stem.npz", "unet_tiny_k5.npz"])
+                                  "unet_tiny_stem.npz", "unet_tiny_k5.npz", "unet_f16_wino.npz"])
 def test_forward_matches_reference_golden(name):
     z = G.load(name)
     cfg = G.config(z)
