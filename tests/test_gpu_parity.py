@@ -419,7 +419,7 @@ def test_cfg3_benched_workload_full_size_vs_oracle_and_batch_invariance(precisio
 FP16_ATOL = 5e-3
 
 
-@pytest.mark.parametrize("name", ["unet_tiny_interp.npz", "unet_tiny_trans.npz", "unet_tiny_bu13.npz", "unet_tiny_rgb.npz", "ckpt_bottomup.npz", "ckpt_single_instance.npz"])
+@pytest.mark.parametrize("name", ["unet_tiny_interp.npz", "unet_tiny_trans.npz", "unet_tiny_bu13.npz", "unet_tiny_rgb.npz", "ckpt_bottomup.npz", "ckpt_single_instance.npz", "unet_f16_wino.npz"])
 @pytest.mark.parametrize("precision,atol", [("split", CMS_ATOL), ("fp16", FP16_ATOL)])
 def test_forward_matches_reference_golden_on_the_fp16_pipe(name, precision, atol):
     """All six reference goldens (bilinear and transposed-conv decoders, RGB input, the two fixture checkpoints) through the
