@@ -25,7 +25,8 @@
 //   * Epilogue: a wave holds, for its xi, P[b] = sum_nu M[xi][nu] A[nu][b]; output row a = 0 is P0 + P1 + P2 and row a = 1 is
 //     P1 - P2 - P3 over xi, i.e. over waves: waves xi = 1, 2 pass their P through LDS (the free weight slot, the two free halo
 //     slots and a 16-KiB spare), wave xi = 0 finishes the even output rows and wave xi = 3 the odd ones (ReLU, stores; the bias
-//     rides in on wave xi = 1's P); the fused 2x2 max pool takes one more hop (wave 0's row maxima to wave 3).
+//     rides in on wave xi = 1's P); the fused 2x2 max pool takes one more hop (wave 0's row maxima to wave 3).  The product is
+//     accumulated transposed (weights = A operand): a lane is a tile, a register quad four consecutive channels -- 16-byte stores.
 //   Measured (MI355X, cfg3, 32 frames): the 14 N-tile-64 layers take 10.7 ms instead of 13.8 ms with the 1-D kernel; the 768 -> 256
 //   layer executes 128 TFLOP/s = 0.81 of the fp32 MFMA peak (288 TFLOP/s in direct-convolution FLOPs).  In-kernel stamps
 //   (-DPH_W2_STAMP, tools/w2_stamp.py): a half costs ~4850 cycles for 4096 cycles of MFMA work per SIMD; a tile's epilogue ~9000.
