@@ -187,8 +187,9 @@ def convnext_plan(bb: dict) -> dict:
     Conv2dNormActivation are torchvision's (not vendored by the reference, torchvision is absent from
     this image): restated from the public definition -- dwconv7x7(groups=C) -> LayerNorm(C) ->
     Linear(C,4C) -> GELU -> Linear(4C,C), times ``layer_scale``, plus the input.  PARITY OF THE
-    CNBlock ARITHMETIC IS UNPINNED (self-consistent only); the wrapper's middle/decoder half is pinned
-    against the reference's own Decoder / SimpleConvBlock.
+    CNBlock ARITHMETIC IS UNPINNED (self-consistent only; cross-checked against HuggingFace transformers'
+    independent ConvNeXt stage in tests/test_oracle_golden.py, which is not a torchvision pin); the wrapper's
+    middle/decoder half is pinned against the reference's own Decoder / SimpleConvBlock.
     """
     mt = bb.get("model_type", None)
     arch = CONVNEXT_ARCHS[mt] if mt in CONVNEXT_ARCHS else (bb.get("arch", None) or CONVNEXT_ARCHS["tiny"])
