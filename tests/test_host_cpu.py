@@ -517,3 +517,30 @@ def test_lr_schedules_match_the_reference_and_torch():
     assert s.kind == "cosine_annealing_warmup"
     s = LRSchedule(2e-4, None)
     assert [s.step() for _ in range(3)] == [2e-4] * 3
+
+
+def test_host_grouping_under_sanitizers(tmp_path):
+    """The host half of the hot path (csrc/group_host.cpp: assignment, toposort, assembly, class grouping) compiled ALONE by g++ with
+    AddressSanitizer + UndefinedBehaviorSanitizer and driven through the same differential tests as the product library (scipy ties,
+    the reference's golden candidates, 200 random graphs with empty / ragged inputs): any out-of-bounds access, use-after-free or
+    undefined arithmetic aborts the child.  (GPU sanitizers are not available on this pool; the device kernels have their own
+    bounds reasoning and the repeatability screen of tools/race_screen.py.)"""
+    import shutil
+    import subprocess
+    import sys
+
+    gxx = shutil.which("g++")
+    if gxx is None:
+        pytest.skip("no g++")
+    asan = subprocess.run([gxx, "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    if not os.path.isabs(asan) or not os.path.exists(asan):
+        pytest.skip("no libasan")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = str(tmp_path / "libgroup_san.so")
+    r = subprocess.run([gxx, "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer", "-fPIC",
+                        "-shared", os.path.join(root, "sleap_nn_amd", "csrc", "group_host.cpp"), os.path.join(root, "tests", "san_stub.cpp"), "-o", so],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1")  # the interpreter itself "leaks" by design
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "sanitize_host.py"), so], capture_output=True, text=True, env=env, timeout=900, cwd=root)
+    assert r.returncode == 0 and "sanitized host grouping: OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
