@@ -715,9 +715,10 @@ int wgrad_slices(int B, int H, int W, int blocks) {
   const int want = (1024 + blocks - 1) / blocks;
   return std::max(1, std::min(n_tiles, std::max(want, 4)));
 }
+static int64_t wgw_slab_floats(int cxp, int coutp, int B, int H, int W);
 int64_t wgrad_slab_floats(int cin_part, int cout, int B, int H, int W) {
   const int blocks = ((pad16(cin_part) + 31) / 32) * ((pad16(cout) + 31) / 32);
-  return (int64_t)wgrad_slices(B, H, W, blocks) * blocks * 9 * 1024;
+  return std::max((int64_t)wgrad_slices(B, H, W, blocks) * blocks * 9 * 1024, wgw_slab_floats(pad16(cin_part), pad16(cout), B, H, W));
 }
 
 int launch_wgrad(const WgradArgs& a0, int cin_part, int cout, int cin_total, int ci_off, float* grad, hipStream_t s) {
@@ -734,6 +735,231 @@ int launch_wgrad(const WgradArgs& a0, int cin_part, int cout, int cin_total, int
       default: hipLaunchKernelGGL(wgrad_kernel<12>, dim3(n_ci_t * n_co_t, n_slices), dim3(256), 0, s, a); break;
     }
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(n_ci_t * n_co_t * 9), dim3(1024), 0, s, a.slab, n_slices, n_ci_t * n_co_t, n_co_t, cin_part, cout, cin_total, ci_off, grad);
+  PH_HIP_CHECK(hipGetLastError());
+  return PH_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// 3x3 conv weight gradient in the Winograd F(2x2,3x3) domain (the same identity the forward / data-gradient kernels use,
+// differentiated):  Y = A^T [(G g G^T) (.) (B^T d B)] A  =>  dL/dg = G^T [ sum_tiles (B^T d B) (.) (A dY A^T) ] G.
+//   Per Winograd position (xi, nu) one GEMM  U[pos][ci][co] = sum over 2x2 output tiles of V[pos][tile][ci] * Z[pos][tile][co]
+//   with V = B^T d B of the tile's 4x4 input patch and Z = A dY A^T of its 2x2 output gradient: 16 MFMA products per tile
+//   and (ci, co) instead of the 36 of the direct form (4/9 of the matrix work).  Both operands are transformed on the fly
+//   from the raw LDS images (lanes run over the channel: conflict-free dword reads, every address an immediate offset of
+//   one per-lane base): wave xi combines the two patch rows of "its" row of B^T d (4 VALU), takes the four column
+//   combinations (4 VALU) and forms its row of A dY (0 - 2 VALU per output-channel tile) and the column combinations (2);
+//   the signs of row / column 3 (-dY) are applied by the finishing kernel instead of in the loop.
+//   Workgroup (256 thr) = a 32(ci) x 32 NCO(co) tile, wave = xi, 4 x NCO accumulators per wave, over a K slice of 4 x TW
+//   pixel tiles (two tile rows; a K step of the 32x32x2 MFMA is a PAIR of tiles, lane half lh = which one).  The waves own
+//   disjoint positions: no cross-wave reduction; the slab keeps [slice][block][pos 16][ci 32][co]; wgrad_wino_reduce_kernel
+//   adds the slices in a fixed order, wgrad_wino_finish_kernel applies G^T . G and writes the canonical OIHW gradient.
+// ---------------------------------------------------------------------------------------
+template <int XI, int TW, int NCO>
+__device__ __forceinline__ void wgw_tile_steps(const float* __restrict__ sX, const float* __restrict__ sY, int lx, int lh, f32x16 (&acc)[4][NCO]) {
+  constexpr int HW = TW + 2, CO = 32 * NCO, HTC = TW / 4;  // HTC: K steps per tile row (TW / 2 tile columns, two per step)
+  constexpr int RA = XI == 0 ? 0 : XI == 2 ? 2 : 1, RB = XI == 0 ? 2 : XI == 1 ? 2 : XI == 2 ? 1 : 3;
+  const float* bx = sX + (2 * lh) * 32 + lx;
+  const float* by = sY + (2 * lh) * CO + lx;
+#pragma unroll
+  for (int s = 0; s < TW / 2; ++s) {
+    const int tr = s / HTC, c0 = 4 * (s % HTC);  // compile-time after unrolling
+    float t[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float da = bx[((2 * tr + RA) * HW + c0 + c) * 32], db = bx[((2 * tr + RB) * HW + c0 + c) * 32];
+      t[c] = XI == 1 ? da + db : da - db;
+    }
+    const float v[4] = {t[0] - t[2], t[1] + t[2], t[2] - t[1], t[1] - t[3]};
+#pragma unroll
+    for (int n = 0; n < NCO; ++n) {
+      float r[2];
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const float y0 = XI == 3 ? 0.f : by[((2 * tr) * TW + c0 + b) * CO + n * 32];
+        const float y1 = XI == 0 ? 0.f : by[((2 * tr + 1) * TW + c0 + b) * CO + n * 32];
+        r[b] = XI == 0 ? y0 : XI == 1 ? y0 + y1 : XI == 2 ? y0 - y1 : y1;  // row 3 of A dY is -dY[1]: sign applied by the finishing kernel
+      }
+      const float z[4] = {r[0], r[0] + r[1], r[0] - r[1], r[1]};  // column 3 is -r[1]: sign applied by the finishing kernel
+#pragma unroll
+      for (int nu = 0; nu < 4; ++nu) acc[nu][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[nu], z[nu], acc[nu][n], 0, 0, 0);
+    }
+  }
+}
+
+template <int TW, int NCO>
+__global__ __launch_bounds__(256, 2) void wgrad_wino_kernel(WgradArgs a) {
+  constexpr int TH = 4, HH = TH + 2, HW = TW + 2, CO = 32 * NCO, QY = CO / 4;
+  constexpr int NXQ = HH * HW * 8, NYQ = TH * TW * QY;  // float4 quads per tile image
+  constexpr int NX = (NXQ + 255) / 256, NY = (NYQ + 255) / 256;
+  __shared__ float sX[NXQ * 4];
+  __shared__ float sY[NYQ * 4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lx = lane & 31, lh = lane >> 5;
+  const int n_co_t = (a.coutp + CO - 1) / CO;
+  const int ci_t = blockIdx.x / n_co_t, co_t = blockIdx.x - ci_t * n_co_t;
+  const int slice = blockIdx.y, n_slices = gridDim.y;
+  const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;
+  const int n_tiles = tiles_x * tiles_y * a.B;
+
+  f32x16 acc[4][NCO];
+#pragma unroll
+  for (int nu = 0; nu < 4; ++nu)
+#pragma unroll
+    for (int n = 0; n < NCO; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[nu][n][r] = 0.f;
+
+  // next tile: global -> registers while this tile's MFMAs run (fetch), registers -> LDS afterwards (commit), as wgrad_kernel
+  f32x4 rx[NX], ry[NY];
+  unsigned okx = 0, oky = 0;
+  const int cxq = min(ci_t * 32 + (tid & 7) * 4, a.cxp - 4), cyq = min(co_t * CO + (tid & (QY - 1)) * 4, a.coutp - 4);
+  const bool cx_ok = ci_t * 32 + (tid & 7) * 4 < a.cxp, cy_ok = co_t * CO + (tid & (QY - 1)) * 4 < a.coutp;
+  auto fetch = [&](int tile) __attribute__((always_inline)) {
+    int t = tile;
+    const int tx = t % tiles_x;
+    t /= tiles_x;
+    const int ty = t % tiles_y;
+    const int b = t / tiles_y;
+    const int x0 = tx * TW, y0 = ty * TH;
+    okx = 0, oky = 0;
+#pragma unroll
+    for (int j = 0; j < NX; ++j) {  // X halo [pix][32 ci]; outside the image ("same" padding) / beyond the channels -> 0 at commit
+      const int pix = min((tid + 256 * j) >> 3, HH * HW - 1);
+      const int hy = pix / HW, hx = pix - hy * HW;
+      const int gy = y0 + hy - 1, gx = x0 + hx - 1;
+      const bool ok = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && cx_ok;
+      const int cy = min(max(gy, 0), a.H - 1), cx = min(max(gx, 0), a.W - 1);
+      rx[j] = *reinterpret_cast<const f32x4*>(a.x + ((size_t)(b * a.H + cy) * a.W + cx) * a.cxp + cxq);
+      okx |= ok ? (1u << j) : 0u;
+    }
+#pragma unroll
+    for (int j = 0; j < NY; ++j) {  // dY [pix][CO]; tiles cut by the image edge carry zeros
+      const int pix = min((tid + 256 * j) / QY, TH * TW - 1);
+      const int py = pix / TW, px = pix - py * TW;
+      const int gy = y0 + py, gx = x0 + px;
+      const bool ok = gy < a.H && gx < a.W && cy_ok;
+      const int cy = min(gy, a.H - 1), cx = min(gx, a.W - 1);
+      ry[j] = *reinterpret_cast<const f32x4*>(a.dy + ((size_t)(b * a.H + cy) * a.W + cx) * a.coutp + cyq);
+      oky |= ok ? (1u << j) : 0u;
+    }
+  };
+  auto commit = [&]() __attribute__((always_inline)) {
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < NX; ++j)
+      if (tid + 256 * j < NXQ) *reinterpret_cast<f32x4*>(sX + (tid + 256 * j) * 4) = ((okx >> j) & 1u) ? rx[j] : z;
+#pragma unroll
+    for (int j = 0; j < NY; ++j)
+      if (tid + 256 * j < NYQ) *reinterpret_cast<f32x4*>(sY + (tid + 256 * j) * 4) = ((oky >> j) & 1u) ? ry[j] : z;
+  };
+
+  if (slice < n_tiles) fetch(slice);
+  for (int tile = slice; tile < n_tiles; tile += n_slices) {
+    commit();
+    __syncthreads();
+    if (tile + n_slices < n_tiles) fetch(tile + n_slices);
+    switch (wave) {  // wave-uniform: wave xi owns row xi of the transformed patch
+      case 0: wgw_tile_steps<0, TW, NCO>(sX, sY, lx, lh, acc); break;
+      case 1: wgw_tile_steps<1, TW, NCO>(sX, sY, lx, lh, acc); break;
+      case 2: wgw_tile_steps<2, TW, NCO>(sX, sY, lx, lh, acc); break;
+      default: wgw_tile_steps<3, TW, NCO>(sX, sY, lx, lh, acc); break;
+    }
+    __syncthreads();
+  }
+  // slab[slice][block][pos = 4 xi + nu][ci 32][co CO];  D: row(ci) = (r&3) + 8*(r>>2) + 4*lh, col(co) = lx
+  float* slab = a.slab + (((size_t)slice * gridDim.x + blockIdx.x) * 16 + wave * 4) * (32 * CO);
+#pragma unroll
+  for (int nu = 0; nu < 4; ++nu)
+#pragma unroll
+    for (int n = 0; n < NCO; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) slab[(size_t)nu * (32 * CO) + ((r & 3) + 8 * (r >> 2) + 4 * lh) * CO + n * 32 + lx] = acc[nu][n][r];
+}
+
+// usum[slot][256 quads] = sum over slices of slab[slice][slot][...] in a fixed order; slot = 256-quad piece of a (block, position) image.
+// 1024 threads = 256 quads x 4 slice parts (four loads in flight per thread), the parts meet in LDS.
+__global__ __launch_bounds__(1024) void wgrad_wino_reduce_kernel(const float* __restrict__ slab, int n_slices, size_t slice_quads, float* __restrict__ usum) {
+  __shared__ f32x4 red[3 * 256];
+  const int q = threadIdx.x & 255, part = threadIdx.x >> 8;
+  const f32x4* src = reinterpret_cast<const f32x4*>(slab) + (size_t)blockIdx.x * 256 + q;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  int k = part;
+  for (; k + 12 < n_slices; k += 16) {
+    const f32x4 v0 = src[(size_t)k * slice_quads], v1 = src[(size_t)(k + 4) * slice_quads], v2 = src[(size_t)(k + 8) * slice_quads], v3 = src[(size_t)(k + 12) * slice_quads];
+    s += (v0 + v1) + (v2 + v3);
+  }
+  for (; k < n_slices; k += 4) s += src[(size_t)k * slice_quads];
+  if (part) red[(part - 1) * 256 + q] = s;
+  __syncthreads();
+  if (part) return;
+  reinterpret_cast<f32x4*>(usum)[(size_t)blockIdx.x * 256 + q] = (s + red[q]) + (red[256 + q] + red[512 + q]);
+}
+
+// dg = G^T U' G per (ci, co), U'[xi][nu] = s(xi) s(nu) U[xi][nu] with s(3) = -1 (the loop used +dY where A dY A^T has -dY);
+// grad[(co * cin_total + ci_off + ci) * 9 + ky * 3 + kx].  One thread per (block, ci, co).
+__global__ __launch_bounds__(256) void wgrad_wino_finish_kernel(const float* __restrict__ usum, int n_blocks, int n_co_t, int co_w /* 32 NCO */, int cin, int cout,
+                                                                int cin_total, int ci_off, float* __restrict__ grad) {
+  const int per = 32 * co_w;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= n_blocks * per) return;
+  const int blk = idx / per, e = idx - blk * per;
+  const int ci = (blk / n_co_t) * 32 + e / co_w, co = (blk % n_co_t) * co_w + e % co_w;
+  if (ci >= cin || co >= cout) return;
+  float u[4][4];
+#pragma unroll
+  for (int xi = 0; xi < 4; ++xi)
+#pragma unroll
+    for (int nu = 0; nu < 4; ++nu) {
+      const float v = usum[((size_t)blk * 16 + xi * 4 + nu) * per + e];
+      u[xi][nu] = ((xi == 3) != (nu == 3)) ? -v : v;
+    }
+  float w[3][4];
+#pragma unroll
+  for (int nu = 0; nu < 4; ++nu) {
+    const float h = 0.5f * (u[1][nu] + u[2][nu]);
+    w[0][nu] = u[0][nu] + h;
+    w[1][nu] = 0.5f * (u[1][nu] - u[2][nu]);
+    w[2][nu] = h + u[3][nu];
+  }
+  float* g = grad + ((size_t)co * cin_total + ci_off + ci) * 9;
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+    const float h = 0.5f * (w[ky][1] + w[ky][2]);
+    g[ky * 3 + 0] = w[ky][0] + h;
+    g[ky * 3 + 1] = 0.5f * (w[ky][1] - w[ky][2]);
+    g[ky * 3 + 2] = h + w[ky][3];
+  }
+}
+
+static int wgw_nco(int coutp) { return coutp >= 64 ? 2 : 1; }
+static int64_t wgw_slab_floats(int cxp, int coutp, int B, int H, int W) {
+  const int co_w = 32 * wgw_nco(coutp);
+  const int blocks = ((cxp + 31) / 32) * ((coutp + co_w - 1) / co_w);
+  return ((int64_t)wgrad_slices(B, H, W, blocks) + 1) * blocks * 16 * 32 * co_w;  // + 1: the slice sums (usum)
+}
+
+int launch_wgrad_wino(const WgradArgs& a, int cin_part, int cout, int cin_total, int ci_off, float* grad, hipStream_t s) {
+  const int nco = wgw_nco(a.coutp), co_w = 32 * nco;
+  const int n_ci_t = (a.cxp + 31) / 32, n_co_t = (a.coutp + co_w - 1) / co_w, blocks = n_ci_t * n_co_t;
+  const int n_slices = wgrad_slices(a.B, a.H, a.W, blocks);
+  const dim3 grid(blocks, n_slices);
+#define PH_WGW(T, N) hipLaunchKernelGGL((wgrad_wino_kernel<T, N>), grid, dim3(256), 0, s, a)
+  switch (wgrad_tile_w(a.W) * 4 + nco) {
+    case 32 * 4 + 2: PH_WGW(32, 2); break;
+    case 32 * 4 + 1: PH_WGW(32, 1); break;
+    case 24 * 4 + 2: PH_WGW(24, 2); break;
+    case 24 * 4 + 1: PH_WGW(24, 1); break;
+    case 16 * 4 + 2: PH_WGW(16, 2); break;
+    case 16 * 4 + 1: PH_WGW(16, 1); break;
+    case 12 * 4 + 2: PH_WGW(12, 2); break;
+    default: PH_WGW(12, 1); break;
+  }
+#undef PH_WGW
+  const size_t slice_quads = (size_t)blocks * 16 * 8 * co_w;  // quads per slice = blocks * 16 * 32 * co_w / 4
+  float* usum = a.slab + (size_t)n_slices * slice_quads * 4;
+  hipLaunchKernelGGL(wgrad_wino_reduce_kernel, dim3((unsigned)(slice_quads / 256)), dim3(1024), 0, s, a.slab, n_slices, slice_quads, usum);
+  const int n_el = blocks * 32 * co_w;
+  hipLaunchKernelGGL(wgrad_wino_finish_kernel, dim3((n_el + 255) / 256), dim3(256), 0, s, usum, blocks, n_co_t, co_w, cin_part, cout, cin_total, ci_off, grad);
   PH_HIP_CHECK(hipGetLastError());
   return PH_OK;
 }
