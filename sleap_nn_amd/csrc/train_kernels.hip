@@ -750,38 +750,45 @@ int launch_wgrad(const WgradArgs& a0, int cin_part, int cout, int cin_total, int
 //   combinations (4 VALU) and forms its row of A dY (0 - 2 VALU per output-channel tile) and the column combinations (2);
 //   the signs of row / column 3 (-dY) are applied by the finishing kernel instead of in the loop.
 //   Workgroup (256 thr) = a 32(ci) x 32 NCO(co) tile, wave = xi, 4 x NCO accumulators per wave, over a K slice of 4 x TW
-//   pixel tiles (two tile rows; a K step of the 32x32x2 MFMA is a PAIR of tiles, lane half lh = which one).  The waves own
+//   pixel tiles (two tile rows; a K step of the 32x32x2 MFMA is a PAIR of tiles, lane half lh = left / right half of the row).  The waves own
 //   disjoint positions: no cross-wave reduction; the slab keeps [slice][block][pos 16][ci 32][co]; wgrad_wino_reduce_kernel
 //   adds the slices in a fixed order, wgrad_wino_finish_kernel applies G^T . G and writes the canonical OIHW gradient.
 // ---------------------------------------------------------------------------------------
 template <int XI, int TW, int NCO>
 __device__ __forceinline__ void wgw_tile_steps(const float* __restrict__ sX, const float* __restrict__ sY, int lx, int lh, f32x16 (&acc)[4][NCO]) {
+  // A K step is a PAIR of tiles: lane half lh = 0 walks the left half of a tile row, lh = 1 the right half, so that a lane's
+  // consecutive steps are ADJACENT tiles -- their 4-column patches overlap by two columns and the row combinations t[2], t[3] of one
+  // step are t[0], t[1] of the next (two new columns per step: 4 LDS reads + 2 VALU instead of 8 + 4).
   constexpr int HW = TW + 2, CO = 32 * NCO, HTC = TW / 4;  // HTC: K steps per tile row (TW / 2 tile columns, two per step)
   constexpr int RA = XI == 0 ? 0 : XI == 2 ? 2 : 1, RB = XI == 0 ? 2 : XI == 1 ? 2 : XI == 2 ? 1 : 3;
-  const float* bx = sX + (2 * lh) * 32 + lx;
-  const float* by = sY + (2 * lh) * CO + lx;
+  const float* bx = sX + (2 * HTC * lh) * 32 + lx;
+  const float* by = sY + (2 * HTC * lh) * CO + lx;
+  auto tcol = [&](int tr, int col) __attribute__((always_inline)) {
+    const float da = bx[((2 * tr + RA) * HW + col) * 32], db = bx[((2 * tr + RB) * HW + col) * 32];
+    return XI == 1 ? da + db : da - db;
+  };
 #pragma unroll
-  for (int s = 0; s < TW / 2; ++s) {
-    const int tr = s / HTC, c0 = 4 * (s % HTC);  // compile-time after unrolling
-    float t[4];
+  for (int tr = 0; tr < 2; ++tr) {
+    float t0 = tcol(tr, 0), t1 = tcol(tr, 1);
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const float da = bx[((2 * tr + RA) * HW + c0 + c) * 32], db = bx[((2 * tr + RB) * HW + c0 + c) * 32];
-      t[c] = XI == 1 ? da + db : da - db;
-    }
-    const float v[4] = {t[0] - t[2], t[1] + t[2], t[2] - t[1], t[1] - t[3]};
+    for (int s = 0; s < HTC; ++s) {
+      const int c0 = 2 * s;  // compile-time after unrolling
+      const float t2 = tcol(tr, c0 + 2), t3 = tcol(tr, c0 + 3);
+      const float v[4] = {t0 - t2, t1 + t2, t2 - t1, t1 - t3};
+      t0 = t2, t1 = t3;
 #pragma unroll
-    for (int n = 0; n < NCO; ++n) {
-      float r[2];
+      for (int n = 0; n < NCO; ++n) {
+        float r[2];
 #pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        const float y0 = XI == 3 ? 0.f : by[((2 * tr) * TW + c0 + b) * CO + n * 32];
-        const float y1 = XI == 0 ? 0.f : by[((2 * tr + 1) * TW + c0 + b) * CO + n * 32];
-        r[b] = XI == 0 ? y0 : XI == 1 ? y0 + y1 : XI == 2 ? y0 - y1 : y1;  // row 3 of A dY is -dY[1]: sign applied by the finishing kernel
+        for (int b = 0; b < 2; ++b) {
+          const float y0 = XI == 3 ? 0.f : by[((2 * tr) * TW + c0 + b) * CO + n * 32];
+          const float y1 = XI == 0 ? 0.f : by[((2 * tr + 1) * TW + c0 + b) * CO + n * 32];
+          r[b] = XI == 0 ? y0 : XI == 1 ? y0 + y1 : XI == 2 ? y0 - y1 : y1;  // row 3 of A dY is -dY[1]: sign applied by the finishing kernel
+        }
+        const float z[4] = {r[0], r[0] + r[1], r[0] - r[1], r[1]};  // column 3 is -r[1]: sign applied by the finishing kernel
+#pragma unroll
+        for (int nu = 0; nu < 4; ++nu) acc[nu][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[nu], z[nu], acc[nu][n], 0, 0, 0);
       }
-      const float z[4] = {r[0], r[0] + r[1], r[0] - r[1], r[1]};  // column 3 is -r[1]: sign applied by the finishing kernel
-#pragma unroll
-      for (int nu = 0; nu < 4; ++nu) acc[nu][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[nu], z[nu], acc[nu][n], 0, 0, 0);
     }
   }
 }
@@ -809,11 +816,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_wino_kernel(WgradArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[nu][n][r] = 0.f;
 
-  // next tile: global -> registers while this tile's MFMAs run (fetch), registers -> LDS afterwards (commit), as wgrad_kernel
+  // next tile: global -> registers while this tile's MFMAs run (fetch), registers -> LDS afterwards (commit), as wgrad_kernel; quads
+  // outside the image ("same" padding; tiles cut by the edge) or beyond the channels are read from the zero page
   f32x4 rx[NX], ry[NY];
-  unsigned okx = 0, oky = 0;
-  const int cxq = min(ci_t * 32 + (tid & 7) * 4, a.cxp - 4), cyq = min(co_t * CO + (tid & (QY - 1)) * 4, a.coutp - 4);
-  const bool cx_ok = ci_t * 32 + (tid & 7) * 4 < a.cxp, cy_ok = co_t * CO + (tid & (QY - 1)) * 4 < a.coutp;
+  const int cxq = ci_t * 32 + (tid & 7) * 4, cyq = co_t * CO + (tid & (QY - 1)) * 4;
+  const bool cx_ok = cxq < a.cxp, cy_ok = cyq < a.coutp;
   auto fetch = [&](int tile) __attribute__((always_inline)) {
     int t = tile;
     const int tx = t % tiles_x;
@@ -821,36 +828,30 @@ __global__ __launch_bounds__(256, 2) void wgrad_wino_kernel(WgradArgs a) {
     const int ty = t % tiles_y;
     const int b = t / tiles_y;
     const int x0 = tx * TW, y0 = ty * TH;
-    okx = 0, oky = 0;
 #pragma unroll
-    for (int j = 0; j < NX; ++j) {  // X halo [pix][32 ci]; outside the image ("same" padding) / beyond the channels -> 0 at commit
+    for (int j = 0; j < NX; ++j) {  // X halo [pix][32 ci]
       const int pix = min((tid + 256 * j) >> 3, HH * HW - 1);
       const int hy = pix / HW, hx = pix - hy * HW;
       const int gy = y0 + hy - 1, gx = x0 + hx - 1;
       const bool ok = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && cx_ok;
-      const int cy = min(max(gy, 0), a.H - 1), cx = min(max(gx, 0), a.W - 1);
-      rx[j] = *reinterpret_cast<const f32x4*>(a.x + ((size_t)(b * a.H + cy) * a.W + cx) * a.cxp + cxq);
-      okx |= ok ? (1u << j) : 0u;
+      rx[j] = *reinterpret_cast<const f32x4*>(ok ? a.x + ((size_t)(b * a.H + gy) * a.W + gx) * a.cxp + cxq : a.zeros);
     }
 #pragma unroll
-    for (int j = 0; j < NY; ++j) {  // dY [pix][CO]; tiles cut by the image edge carry zeros
+    for (int j = 0; j < NY; ++j) {  // dY [pix][CO]
       const int pix = min((tid + 256 * j) / QY, TH * TW - 1);
       const int py = pix / TW, px = pix - py * TW;
       const int gy = y0 + py, gx = x0 + px;
       const bool ok = gy < a.H && gx < a.W && cy_ok;
-      const int cy = min(gy, a.H - 1), cx = min(gx, a.W - 1);
-      ry[j] = *reinterpret_cast<const f32x4*>(a.dy + ((size_t)(b * a.H + cy) * a.W + cx) * a.coutp + cyq);
-      oky |= ok ? (1u << j) : 0u;
+      ry[j] = *reinterpret_cast<const f32x4*>(ok ? a.dy + ((size_t)(b * a.H + gy) * a.W + gx) * a.coutp + cyq : a.zeros);
     }
   };
   auto commit = [&]() __attribute__((always_inline)) {
-    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < NX; ++j)
-      if (tid + 256 * j < NXQ) *reinterpret_cast<f32x4*>(sX + (tid + 256 * j) * 4) = ((okx >> j) & 1u) ? rx[j] : z;
+      if (tid + 256 * j < NXQ) *reinterpret_cast<f32x4*>(sX + (tid + 256 * j) * 4) = rx[j];
 #pragma unroll
     for (int j = 0; j < NY; ++j)
-      if (tid + 256 * j < NYQ) *reinterpret_cast<f32x4*>(sY + (tid + 256 * j) * 4) = ((oky >> j) & 1u) ? ry[j] : z;
+      if (tid + 256 * j < NYQ) *reinterpret_cast<f32x4*>(sY + (tid + 256 * j) * 4) = ry[j];
   };
 
   if (slice < n_tiles) fetch(slice);

@@ -90,23 +90,41 @@ def test_ohkm_loss_and_grads():
 
 
 def test_adam_steps_match_torch_optim():
+    """Three optimizer steps against the oracle's torch.optim restatement, two ways.
+    (a) End to end -- oracle gradients -> oracle Adam vs device gradients -> device Adam -- at 2e-6, with the direct nine-tap
+        weight-gradient kernel (wgrad_wino = 0).  Adam's first steps are lr * g / (|g| + 1e-8): an element whose gradient is
+        within ~1e-7 of zero moves by a visible fraction of lr when the gradient changes by 1e-8, so this comparison measures the
+        conv kernels' ABSOLUTE rounding noise, not the optimizer.  The Winograd-domain weight gradient (default; 4/9 of the
+        matrix work) is as close to the float64 gradient as the direct kernel on every tensor (tools/wgrad_accuracy.py: same
+        errors to three digits) but its noise floor on near-zero elements is ~1e-8 of the tensor scale instead of ~1e-10
+        (sums of transformed, i.e. 4 - 16x larger, products that cancel in G^T . G).
+    (b) Default kernels: the Adam arithmetic itself on the DEVICE's own gradients (exactly what the optimizer kernel consumed) at
+        the same 2e-6, and the end-to-end parameters within 1e-4 = a tenth of one lr step (measured worst 4.5e-5)."""
     bb, heads, mt = _cfg(8, 8, 2)
     for amsgrad, optimizer in ((False, "Adam"), (True, "Adam"), (False, "AdamW")):
-        sd, img, targets, lw, tm = _setup(bb, heads, mt, (48, 64), 2, seed=3, lr=1e-3, amsgrad=amsgrad, optimizer=optimizer)
-        grads_seq, cur = [], {k: v.clone() for k, v in sd.items()}
-        for step in range(3):
-            _, g = O.training_step(cur, bb, heads, mt, img, targets, lw)
-            grads_seq.append(g)
-            cur = O.adam_reference(sd, grads_seq, lr=1e-3, amsgrad=amsgrad, optimizer=optimizer)
-            tm.training_step({"image": img, **targets})
-        got = tm.state_dict()
-        for k, r in cur.items():
-            assert torch.allclose(got[k], r, atol=2e-6, rtol=1e-4), (k, float((got[k] - r).abs().max()))
-        # the re-packed device weights are what the next forward uses
-        out = tm.model.forward(img.to(DEV))
-        ref = O.model_forward(cur, bb, heads, mt, img)
-        for k, v in ref.items():
-            assert (out[k].cpu() - v).abs().max().item() <= 1e-4
+        for wgrad_wino in (0, 1):
+            sd, img, targets, lw, tm = _setup(bb, heads, mt, (48, 64), 2, seed=3, lr=1e-3, amsgrad=amsgrad, optimizer=optimizer)
+            tm.model.set_option("wgrad_wino", wgrad_wino)
+            grads_seq, dev_seq, cur = [], [], {k: v.clone() for k, v in sd.items()}
+            for step in range(3):
+                _, g = O.training_step(cur, bb, heads, mt, img, targets, lw)
+                grads_seq.append(g)
+                cur = O.adam_reference(sd, grads_seq, lr=1e-3, amsgrad=amsgrad, optimizer=optimizer)
+                tm.training_step({"image": img, **targets})
+                dev_seq.append({k: v.clone() for k, v in tm.named_grads().items()})
+            got = tm.state_dict()
+            own = O.adam_reference(sd, dev_seq, lr=1e-3, amsgrad=amsgrad, optimizer=optimizer)
+            for k, r in cur.items():
+                assert torch.allclose(got[k], own[k], atol=2e-6, rtol=1e-4), (k, float((got[k] - own[k]).abs().max()))
+                if wgrad_wino == 0:
+                    assert torch.allclose(got[k], r, atol=2e-6, rtol=1e-4), (k, float((got[k] - r).abs().max()))
+                else:
+                    assert torch.allclose(got[k], r, atol=1e-4, rtol=1e-4), (k, float((got[k] - r).abs().max()))
+            # the re-packed device weights are what the next forward uses
+            out = tm.model.forward(img.to(DEV))
+            ref = O.model_forward(cur, bb, heads, mt, img)
+            for k, v in ref.items():
+                assert (out[k].cpu() - v).abs().max().item() <= 1e-4
 
 
 def test_training_reduces_loss():
