@@ -290,7 +290,6 @@ int ph_model_backward(ph_model* m, const void* input_dev, int32_t in_dtype, int3
             w.B = batch;
             w.H = so.h;
             w.W = so.w;
-            w.zeros = m->zeros_dev;
             if (m->wgrad_wino && w.coutp >= 32)
               rc = launch_wgrad_wino(w, parts[part], d.cout, d.cin0 + d.cin1, offs[part], grads_flat_dev + m->weight_offset[d.weight], s);
             else

@@ -19,7 +19,6 @@ struct WgradArgs {
   const float* dy;   // NHWC output gradient (already ReLU-masked), coutp channels
   float* slab;       // scratch: [slices][blocks][9][32][32]
   int cxp, coutp, B, H, W;
-  const float* zeros = nullptr;  // >= 16 B of zeros in HBM (wgrad_wino_kernel reads out-of-image / beyond-the-channels quads from it)
 };
 
 int launch_loss(const float* pred, const float* tgt, const float* sample_w, int B, int C, int H, int W, float loss_weight, const OhkmParams& ok, float* scratch,

@@ -22,6 +22,7 @@ namespace ph {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float block_sum_256(float v, float* red /* >= 4 floats */) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -797,7 +798,10 @@ template <int TW, int NCO>
 __global__ __launch_bounds__(256, 2) void wgrad_wino_kernel(WgradArgs a) {
   constexpr int TH = 4, HH = TH + 2, HW = TW + 2, CO = 32 * NCO, QY = CO / 4;
   constexpr int NXQ = HH * HW * 8, NYQ = TH * TW * QY;  // float4 quads per tile image
-  constexpr int NX = (NXQ + 255) / 256, NY = (NYQ + 255) / 256;
+  // fetch passes: X = one halo row of <= 32 columns x 8 quads per pass (+ one pass for columns 32, 33 of all rows when TW = 32);
+  // dY = one tile row of 256 / QY pixels x QY quads per pass
+  constexpr int NXE = HW > 32 ? 1 : 0, NX = HH + NXE, YPP = 256 / QY, YH = (TW + YPP - 1) / YPP, NY = TH * YH;
+  static_assert(HH * (HW - 32) * 8 <= 256, "the extra halo columns must fit one pass");
   __shared__ float sX[NXQ * 4];
   __shared__ float sY[NYQ * 4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -816,11 +820,19 @@ __global__ __launch_bounds__(256, 2) void wgrad_wino_kernel(WgradArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[nu][n][r] = 0.f;
 
-  // next tile: global -> registers while this tile's MFMAs run (fetch), registers -> LDS afterwards (commit), as wgrad_kernel; quads
-  // outside the image ("same" padding; tiles cut by the edge) or beyond the channels are read from the zero page
-  f32x4 rx[NX], ry[NY];
-  const int cxq = ci_t * 32 + (tid & 7) * 4, cyq = co_t * CO + (tid & (QY - 1)) * 4;
-  const bool cx_ok = cxq < a.cxp, cy_ok = cyq < a.coutp;
+  // Next tile: global -> registers while this tile's MFMAs run (fetch), registers -> LDS afterwards (commit).  The loads go through
+  // a per-frame buffer descriptor: a quad's address is one v_add of a wave-uniform row offset to a per-thread constant, and quads
+  // outside the image ("same" padding; tiles cut by the edge) or beyond the channels get an out-of-range offset -- the hardware's
+  // range check returns zeros (no per-quad index arithmetic, no select on the data).
+  constexpr unsigned OOB = 0xFFFFFF00u;
+  u32x4 rx[NX], ry[NY];
+  const int xq = tid & 7, xc = tid >> 3;                       // X pass: quad, halo column
+  const int xe_r = tid >> 4, xe_c = 32 + ((tid >> 3) & 1);     // extra pass (TW = 32): halo row, halo column 32 / 33
+  const int yq = tid & (QY - 1), yc = tid / QY;                // dY pass: quad, pixel column within the pass
+  const bool cx_ok = ci_t * 32 + xq * 4 < a.cxp, cy_ok = co_t * CO + yq * 4 < a.coutp;
+  const unsigned x_thr = (unsigned)(xc * a.cxp + ci_t * 32 + xq * 4) * 4u, y_thr = (unsigned)(yc * a.coutp + co_t * CO + yq * 4) * 4u;
+  const unsigned xe_thr = (unsigned)((xe_r * a.W + xe_c) * a.cxp + ci_t * 32 + xq * 4) * 4u;
+  const unsigned x_frame = (unsigned)(a.H * a.W) * (unsigned)(a.cxp * 4), y_frame = (unsigned)(a.H * a.W) * (unsigned)(a.coutp * 4);  // bytes per frame (< 4 GiB: checked at launch)
   auto fetch = [&](int tile) __attribute__((always_inline)) {
     int t = tile;
     const int tx = t % tiles_x;
@@ -828,30 +840,45 @@ __global__ __launch_bounds__(256, 2) void wgrad_wino_kernel(WgradArgs a) {
     const int ty = t % tiles_y;
     const int b = t / tiles_y;
     const int x0 = tx * TW, y0 = ty * TH;
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x) + (size_t)b * (x_frame / 4), 0, (int)x_frame, 0x00020000);
+    const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy) + (size_t)b * (y_frame / 4), 0, (int)y_frame, 0x00020000);
+    const int gx = x0 + xc - 1;
+    const bool x_ok = cx_ok && xc < HW && gx >= 0 && gx < a.W;
 #pragma unroll
-    for (int j = 0; j < NX; ++j) {  // X halo [pix][32 ci]
-      const int pix = min((tid + 256 * j) >> 3, HH * HW - 1);
-      const int hy = pix / HW, hx = pix - hy * HW;
-      const int gy = y0 + hy - 1, gx = x0 + hx - 1;
-      const bool ok = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && cx_ok;
-      rx[j] = *reinterpret_cast<const f32x4*>(ok ? a.x + ((size_t)(b * a.H + gy) * a.W + gx) * a.cxp + cxq : a.zeros);
+    for (int j = 0; j < HH; ++j) {  // halo row j, columns 0 .. 31
+      const int gy = y0 + j - 1;                                                  // wave-uniform
+      const unsigned row = (unsigned)((gy * a.W + x0 - 1) * a.cxp) * 4u;          // wave-uniform; wraps harmlessly when the row is not used
+      rx[j] = __builtin_amdgcn_raw_buffer_load_b128(xr, (x_ok && gy >= 0 && gy < a.H) ? x_thr + row : OOB, 0, 0);
+    }
+    if constexpr (NXE) {  // halo columns 32, 33 of all six rows
+      const int gy = y0 + xe_r - 1, gxe = x0 + xe_c - 1;
+      const bool ok = cx_ok && xe_r < HH && gy >= 0 && gy < a.H && gxe < a.W;
+      rx[HH] = __builtin_amdgcn_raw_buffer_load_b128(xr, ok ? xe_thr + (unsigned)(((y0 - 1) * a.W + x0 - 1) * a.cxp) * 4u : OOB, 0, 0);
     }
 #pragma unroll
-    for (int j = 0; j < NY; ++j) {  // dY [pix][CO]
-      const int pix = min((tid + 256 * j) / QY, TH * TW - 1);
-      const int py = pix / TW, px = pix - py * TW;
-      const int gy = y0 + py, gx = x0 + px;
-      const bool ok = gy < a.H && gx < a.W && cy_ok;
-      ry[j] = *reinterpret_cast<const f32x4*>(ok ? a.dy + ((size_t)(b * a.H + gy) * a.W + gx) * a.coutp + cyq : a.zeros);
+    for (int h = 0; h < YH; ++h) {
+      const bool y_ok = cy_ok && h * YPP + yc < TW && x0 + h * YPP + yc < a.W;
+#pragma unroll
+      for (int py = 0; py < TH; ++py) {
+        const unsigned row = (unsigned)(((y0 + py) * a.W + x0 + h * YPP) * a.coutp) * 4u;  // wave-uniform
+        ry[py * YH + h] = __builtin_amdgcn_raw_buffer_load_b128(yr, (y_ok && y0 + py < a.H) ? y_thr + row : OOB, 0, 0);
+      }
     }
   };
   auto commit = [&]() __attribute__((always_inline)) {
+    if (xc < HW) {
 #pragma unroll
-    for (int j = 0; j < NX; ++j)
-      if (tid + 256 * j < NXQ) *reinterpret_cast<f32x4*>(sX + (tid + 256 * j) * 4) = rx[j];
+      for (int j = 0; j < HH; ++j) *reinterpret_cast<u32x4*>(sX + ((j * HW + xc) * 8 + xq) * 4) = rx[j];
+    }
+    if constexpr (NXE) {
+      if (xe_r < HH) *reinterpret_cast<u32x4*>(sX + ((xe_r * HW + xe_c) * 8 + xq) * 4) = rx[HH];
+    }
 #pragma unroll
-    for (int j = 0; j < NY; ++j)
-      if (tid + 256 * j < NYQ) *reinterpret_cast<f32x4*>(sY + (tid + 256 * j) * 4) = ry[j];
+    for (int h = 0; h < YH; ++h)
+      if (h * YPP + yc < TW) {
+#pragma unroll
+        for (int py = 0; py < TH; ++py) *reinterpret_cast<u32x4*>(sY + ((py * TW + h * YPP + yc) * QY + yq) * 4) = ry[py * YH + h];
+      }
   };
 
   if (slice < n_tiles) fetch(slice);
@@ -940,6 +967,7 @@ static int64_t wgw_slab_floats(int cxp, int coutp, int B, int H, int W) {
 }
 
 int launch_wgrad_wino(const WgradArgs& a, int cin_part, int cout, int cin_total, int ci_off, float* grad, hipStream_t s) {
+  PH_REQUIRE((uint64_t)a.H * a.W * std::max(a.cxp, a.coutp) * 4 < 0xFFFFFF00ull, "wgrad: a %d x %d x %d frame does not fit a 32-bit buffer descriptor", a.H, a.W, std::max(a.cxp, a.coutp));
   const int nco = wgw_nco(a.coutp), co_w = 32 * nco;
   const int n_ci_t = (a.cxp + 31) / 32, n_co_t = (a.coutp + co_w - 1) / co_w, blocks = n_ci_t * n_co_t;
   const int n_slices = wgrad_slices(a.B, a.H, a.W, blocks);
