@@ -1285,6 +1285,7 @@ std::vector<OptionRef> option_table(ph_model* m) {
       {"conv_dma_stagger", &m->dma_stagger, nullptr},   // 0: SIMD-partner waves issue DMA pieces at the same step
       {"fuse_gelu_fwd", &m->fuse_gelu_fwd, nullptr},
       {"fuse_gelu_bwd", &m->fuse_gelu_bwd, nullptr},
+      {"mask_fold", &m->mask_fold, nullptr},            // ReLU mask applied by the pool backward that completes a conv output's gradient
       {"wgrad_wino", &m->wgrad_wino, nullptr},          // 3x3 weight gradients: 1 Winograd F(2x2,3x3) domain, 0 direct nine-tap kernel
       {"wgrad_rows", &m->wgrad_rows, nullptr},          // 0 32x32-tile wgrad kernel, 1 auto, 2 nine row-wgrad GEMMs
       {"workspace_reuse", &m->workspace_reuse, nullptr},  // 1: activation slots share memory once their last reader has run (inference programs only)

@@ -200,6 +200,17 @@ int ph_model_backward(ph_model* m, const void* input_dev, int32_t in_dtype, int3
   float* scratch = reinterpret_cast<float*>(gws + bp.scratch_off);
   std::vector<char> init(m->n_slots, 0);
   std::vector<char> fused_away(m->ops.size(), 0);
+  // ReLU-mask folding: the gradient of a conv + ReLU output is complete when its FIRST consumer (program order = last in this sweep)
+  // has added its share; when that consumer is a max pool, pool_bwd applies the mask itself (it reads the activation anyway) and the
+  // conv's own step only reduces the bias gradient (handle option "mask_fold")
+  std::vector<int> first_consumer(m->n_slots, -1), producer(m->n_slots, -1);
+  std::vector<char> masked(m->n_slots, 0);
+  for (int oi = (int)m->ops.size() - 1; oi >= 0; --oi) {
+    const ph_op_desc& d = m->ops[oi].d;
+    if (d.src0 >= 0) first_consumer[d.src0] = oi;
+    if (d.src1 >= 0) first_consumer[d.src1] = oi;
+    if (d.dst >= 0) producer[d.dst] = oi;
+  }
   OhkmParams ok;
   ok.enabled = ohkm_enabled;
   ok.hard_to_easy_ratio = hard_to_easy_ratio;
@@ -245,7 +256,12 @@ int ph_model_backward(ph_model* m, const void* input_dev, int32_t in_dtype, int3
         const SlotShape& so = bp.act.slots[d.dst];
         PH_REQUIRE(init[d.dst], "conv output slot %d received no gradient", d.dst);
         const size_t npix = (size_t)batch * so.h * so.w;
-        if ((d.flags & PH_FLAG_RELU) && d.bias >= 0) {  // mask + bias gradient in one pass
+        if (masked[d.dst]) {  // the last contributor applied the ReLU mask already
+          if (d.bias >= 0) {
+            rc = launch_bias_grad(G(d.dst), npix, so.cp, d.cout, grads_flat_dev + m->weight_offset[d.bias], scratch, s);
+            if (rc != PH_OK) return rc;
+          }
+        } else if ((d.flags & PH_FLAG_RELU) && d.bias >= 0) {  // mask + bias gradient in one pass
           rc = launch_relu_mask_bias_grad(G(d.dst), A(d.dst), npix, so.cp, d.cout, grads_flat_dev + m->weight_offset[d.bias], scratch, s);
           if (rc != PH_OK) return rc;
         } else {
@@ -378,7 +394,12 @@ int ph_model_backward(ph_model* m, const void* input_dev, int32_t in_dtype, int3
         PH_REQUIRE(init[d.dst], "first conv output received no gradient");
         PH_REQUIRE(d.cin0 == in_channels, "input has %d channels, network expects %d", in_channels, d.cin0);
         const size_t npix = (size_t)batch * so.h * so.w;
-        if ((d.flags & PH_FLAG_RELU) && d.bias >= 0) {  // mask + bias gradient in one pass
+        if (masked[d.dst]) {  // the last contributor applied the ReLU mask already
+          if (d.bias >= 0) {
+            rc = launch_bias_grad(G(d.dst), npix, so.cp, d.cout, grads_flat_dev + m->weight_offset[d.bias], scratch, s);
+            if (rc != PH_OK) return rc;
+          }
+        } else if ((d.flags & PH_FLAG_RELU) && d.bias >= 0) {  // mask + bias gradient in one pass
           rc = launch_relu_mask_bias_grad(G(d.dst), A(d.dst), npix, so.cp, d.cout, grads_flat_dev + m->weight_offset[d.bias], scratch, s);
           if (rc != PH_OK) return rc;
         } else {
@@ -397,8 +418,11 @@ int ph_model_backward(ph_model* m, const void* input_dev, int32_t in_dtype, int3
       case PH_OP_POOL: {
         const SlotShape& si = bp.act.slots[d.src0];
         PH_REQUIRE(init[d.dst], "pool output slot %d received no gradient", d.dst);
-        rc = launch_pool_bwd(G(d.dst), A(d.src0), batch, si.h, si.w, si.cp, init[d.src0], G(d.src0), s);
+        const int pr = producer[d.src0];
+        const bool fold = m->mask_fold && first_consumer[d.src0] == oi && pr >= 0 && m->ops[pr].d.kind == PH_OP_CONV && (m->ops[pr].d.flags & PH_FLAG_RELU);
+        rc = launch_pool_bwd(G(d.dst), A(d.src0), batch, si.h, si.w, si.cp, init[d.src0], fold ? 1 : 0, G(d.src0), s);
         init[d.src0] = 1;
+        masked[d.src0] = fold ? 1 : 0;
         break;
       }
       case PH_OP_UPSAMPLE: {

@@ -30,7 +30,7 @@ int launch_head_bwd(const float* dy, const float* y_out, int sigmoid, const floa
                     int accumulate, float* dx, float* gw, float* gb, float* scratch, hipStream_t s);
 int64_t head_bwd_scratch_floats(int cp, int cout, int64_t npix);
 int launch_relu_mask(float* g, const float* y, size_t n, hipStream_t s);
-int launch_pool_bwd(const float* gp, const float* x, int B, int H, int W, int cp, int accumulate, float* gx, hipStream_t s);
+int launch_pool_bwd(const float* gp, const float* x, int B, int H, int W, int cp, int accumulate, int relu_mask, float* gx, hipStream_t s);
 int launch_upsample_bwd(const float* gy, int B, int H, int W, int cp, int accumulate, float* gx, hipStream_t s);
 int launch_bias_grad(const float* g, size_t npix, int cp, int cout, float* gb, float* scratch, hipStream_t s);
 int launch_relu_mask_bias_grad(float* g, const float* y_mask, size_t npix, int cp, int cout, float* gb, float* scratch, hipStream_t s);

@@ -276,8 +276,10 @@ int launch_relu_mask(float* g, const float* y, size_t n, hipStream_t s) {
 
 // max_pool2d(2,2) backward: the gradient goes to the FIRST maximum of each window in row-major
 // order (ATen); windows reaching past an odd edge see the zero pad last, so a real element wins ties.
+// relu_mask: x is the output of a conv + ReLU and this is the LAST contribution to its gradient: the ReLU mask (x > 0) is applied to the
+// finished sum here, on values this kernel reads anyway, instead of in a separate read-modify-write pass over the gradient tensor.
 __global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__ gp, const float* __restrict__ x, int B, int H, int W, int cp, int accumulate,
-                                                       float* __restrict__ gx) {
+                                                       int relu_mask, float* __restrict__ gx) {
   const int Ho = (H + 1) / 2, Wo = (W + 1) / 2, groups = cp >> 2;
   const size_t total = (size_t)B * Ho * Wo * groups;
   for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
@@ -317,14 +319,19 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__
       if (ok[k]) {
         const int yy = 2 * yo + (k >> 1), xx = 2 * xo + (k & 1);
         f32x4* dst = reinterpret_cast<f32x4*>(gx + (((size_t)b * H + yy) * W + xx) * cp + gq * 4);
-        *dst = accumulate ? (*dst + o[k]) : o[k];
+        f32x4 r = accumulate ? (*dst + o[k]) : o[k];
+        if (relu_mask) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) r[e] = v[k][e] > 0.f ? r[e] : 0.f;
+        }
+        *dst = r;
       }
   }
 }
 
-int launch_pool_bwd(const float* gp, const float* x, int B, int H, int W, int cp, int accumulate, float* gx, hipStream_t s) {
+int launch_pool_bwd(const float* gp, const float* x, int B, int H, int W, int cp, int accumulate, int relu_mask, float* gx, hipStream_t s) {
   const size_t total = (size_t)B * ((H + 1) / 2) * ((W + 1) / 2) * (cp / 4);
-  hipLaunchKernelGGL(pool_bwd_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 16384)), dim3(256), 0, s, gp, x, B, H, W, cp, accumulate, gx);
+  hipLaunchKernelGGL(pool_bwd_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 16384)), dim3(256), 0, s, gp, x, B, H, W, cp, accumulate, relu_mask, gx);
   PH_HIP_CHECK(hipGetLastError());
   return PH_OK;
 }
