@@ -596,22 +596,27 @@ ph_model* ph_model_create(const ph_op_desc* ops, int32_t n_ops, const float* con
           return true;
         };
         if (ok && !tr) ok = derive_wino2(op.w_dev, d.cin0, d.cin1, d.cout, op.bn, &op.w_wino2_dev);
-        if (ok && !tr && op.bn == 32 && coutp == 32 && d.cin1 == 0 && (pad16(d.cin0) == 16 || pad16(d.cin0) == 32)) {  // conv3x3_w16_kernel
-          const int chunks = pad16(d.cin0) / 16;
+        // wave-private F(2x2,3x3) weights (conv3x3_w16_kernel: 16 / 32 output channels, 16 / 32 input channels, one source): the forward
+        // conv's, and below the data-gradient convs'
+        auto derive_w16 = [&](const float* src, int cin_, int cout_, int bn, float** dst) {
+          const int cip = pad16(cin_), cop = pad16(cout_);
+          if (bn != 32 || (cop != 16 && cop != 32) || (cip != 16 && cip != 32)) return true;
+          const int chunks = cip / 16, nbs = cop / 16;
           float* w = nullptr;
-          ok = hipMalloc(&w, (size_t)w16_pack_floats(chunks) * sizeof(float)) == hipSuccess;
-          if (ok) {
-            m->allocs.push_back(w);
-            ok = launch_w16_pack(op.w_dev, w, chunks, nullptr) == PH_OK;
-            DerivedBuffer db;
-            db.src = op.w_dev;
-            db.dst = w;
-            db.panels = chunks;
-            db.kind = 3;
-            m->derived.push_back(db);
-            op.w_w16_dev = w;
-          }
-        }
+          if (hipMalloc(&w, (size_t)w16_pack_floats(chunks, nbs) * sizeof(float)) != hipSuccess) return false;
+          m->allocs.push_back(w);
+          if (launch_w16_pack(src, w, chunks, nbs, nullptr) != PH_OK) return false;
+          DerivedBuffer db;
+          db.src = src;
+          db.dst = w;
+          db.panels = chunks;
+          db.bn = nbs;
+          db.kind = 3;
+          m->derived.push_back(db);
+          *dst = w;
+          return true;
+        };
+        if (ok && !tr && d.cin1 == 0) ok = derive_w16(op.w_dev, d.cin0, d.cout, op.bn, &op.w_w16_dev);
         if (ok && !tr) {  // row-GEMM form for feature maps too small for the 16x32-pixel tiles
           op.bn_g = gemm_choose_bn(coutp);
           auto pack_g = [&](const auto* w, auto& out) { pack_gemm(w, d.cout, d.cin0, d.cin1, 9, op.bn_g, out); };
@@ -684,7 +689,8 @@ ph_model* ph_model_create(const ph_op_desc* ops, int32_t n_ops, const float* con
             ok = pack_upload(m, pack_d, weights[d.weight], iw, &op.wd_dev[part]) == PH_OK &&
                  pack_upload(m, pack_dd, weights[d.weight], iw, &op.wd_dma_dev[part]) == PH_OK &&
                  derive_wino(op.wd_dev[part], d.cout, 0, parts[part], op.bn_d[part], &op.wd_wino_dev[part]) &&
-                 derive_wino2(op.wd_dev[part], d.cout, 0, parts[part], op.bn_d[part], &op.wd_wino2_dev[part]);
+                 derive_wino2(op.wd_dev[part], d.cout, 0, parts[part], op.bn_d[part], &op.wd_wino2_dev[part]) &&
+                 derive_w16(op.wd_dev[part], d.cout, parts[part], op.bn_d[part], &op.wd_w16_dev[part]);
           }
           if (ok) {
             std::vector<float> zb((size_t)pad16(std::max(d.cin0, d.cin1)) + max_bn, 0.f);

@@ -32,7 +32,8 @@ struct PackedOp {
   float* w_wino_dev = nullptr;             // 3x3 conv, N tile 64: Winograd F(2,3) weights derived on the device from w_dev
   float* wd_wino_dev[2] = {nullptr, nullptr};  // ... and from wd_dev (data gradient)
   float* w_stem2_dev = nullptr;            // fused stem: F(2x2,3x3) weights of the second conv
-  float* w_w16_dev = nullptr;              // 3x3 conv, Cout 32, Cin 16 / 32: wave-private F(2x2,3x3) weights derived from w_dev
+  float* w_w16_dev = nullptr;              // 3x3 conv, Cout 16 / 32, Cin 16 / 32: wave-private F(2x2,3x3) weights derived from w_dev
+  float* wd_w16_dev[2] = {nullptr, nullptr};  // ... and from wd_dev (data gradient)
   float* w_wino2_dev = nullptr;            // 3x3 conv, N tile 64: Winograd F(2x2,3x3) weights derived from w_dev
   float* wd_wino2_dev[2] = {nullptr, nullptr};  // ... and from wd_dev (data gradient)
   // ConvTranspose2d(k3, s2, p1, op1) as four output-phase row GEMMs (mode 3) + its data gradient (mode 4)

@@ -24,11 +24,12 @@ struct ConvArgs {
   int dma_stagger = 1;     // LDS-DMA kernel: SIMD-partner waves issue their DMA piece at different points of a step
   const float* wpack_wino = nullptr;  // Winograd F(2,3)-along-x weights in LDS order (conv3x3_wino_persist_kernel), or nullptr
   const float* wpack_wino2 = nullptr; // Winograd F(2x2,3x3) weights in LDS order (conv3x3_wino2d_kernel, N tile 64), or nullptr
-  const float* wpack_w16 = nullptr;   // wave-private F(2x2,3x3) weights (conv3x3_w16_kernel: Cout 32, Cin 16 / 32), or nullptr
+  const float* wpack_w16 = nullptr;   // wave-private F(2x2,3x3) weights (conv3x3_w16_kernel: Cout 16 / 32, Cin 16 / 32), or nullptr
   int use_w16 = 1;     // handle option "conv_w16"
   int use_wino2d = 1;  // N-tile-64 layers on the F(2x2,3x3) kernel where wpack_wino2 exists (handle option "conv_wino2d")
   const float* w16 = nullptr;  // [tap][ci 16][co 16] weights for conv3x3_c16_kernel (16 -> 16 channel layers), or nullptr
   int skip_dst = 0;           // the full-resolution output is never read (inference plan, fused pool): only dst_pool is written (Winograd kernels; others ignore it)
+  const float* relu_mask_src = nullptr;  // backward: NHWC tensor shaped like dst (the forward activation this gradient belongs to); the stored value is zeroed where it is <= 0 (conv3x3_w16_kernel only: ask conv3x3_dma_honours_mask)
   float* dst_pool = nullptr;  // optional fused 2x2/2 max pool of the (ReLU'd) output, NHWC ceil(H/2) x ceil(W/2); nullptr = off
   // kernel selection, filled from the model handle's options (ph_model_set_option)
   int use_wino = 1;   // 1: Winograd F(2,3) kernel where wpack_wino exists; 2: only for the N-tile-64 layers; 0: direct 9-tap kernel
@@ -124,6 +125,7 @@ int64_t wino_pack_floats(int panels, int bn);
 int launch_stem_wino_pack(const float* w1, float* w1w, hipStream_t s);
 int launch_stem_wino2d_pack(const float* w1, float* w2, hipStream_t s);  // [tap][co][ci] -> [position 16][co][ci]  // [tap][co][ci] -> [kernel row][m index][co][ci]
 int launch_conv3x3_dma(const ConvArgs& a, hipStream_t s);
+bool conv3x3_dma_honours_mask(const ConvArgs& a);  // launch_conv3x3_dma would run a kernel that applies relu_mask_src
 // wpack [panel][tap 9][bn][16] -> F(2x2,3x3) weights [panel][g 2][xi 4][nu 4][n tile][lh][lx][4] (see conv3x3_wino2d_kernel)
 int launch_wino2d_pack(const float* wpack, float* wino, int panels, int bn, hipStream_t s);
 int64_t wino2d_pack_floats(int panels, int bn);
@@ -131,8 +133,8 @@ int launch_conv3x3_wino2d(const ConvArgs& a, hipStream_t s);
 bool wino2d_fits(const ConvArgs& a);  // sources addressable through the kernel's 32-bit buffer descriptors
 int prepare_wino2d_kernels();
 // wpack [chunk][tap 9][32][16] -> wave-private F(2x2,3x3) weights [chunk][position][N block][kq][n][4] (see conv3x3_w16_kernel)
-int launch_w16_pack(const float* wpack, float* w16, int chunks, hipStream_t s);
-int64_t w16_pack_floats(int chunks);
+int launch_w16_pack(const float* wpack, float* w16, int chunks, int nbs, hipStream_t s);  // nbs: N blocks of 16 output channels (1 or 2)
+int64_t w16_pack_floats(int chunks, int nbs);
 int launch_conv3x3_w16(const ConvArgs& a, hipStream_t s);
 bool w16_fits(const ConvArgs& a);
 int prepare_w16_kernels();

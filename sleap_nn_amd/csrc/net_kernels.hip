@@ -1298,13 +1298,25 @@ static int cu_count(int* out) {
 
 // Kernel choice for a 3x3 "same" conv on the LDS-DMA family.  Which variant runs is decided by fields of `a` that the
 // model runtime fills from the handle's options (ph_model_set_option); there is no process-global state here.
+// which kernel launch_conv3x3_dma picks: 1 wave-private F(2x2,3x3), 0 conv3x3_c16, 2 wave-split F(2x2,3x3), 3 the F(2,3) / direct halo kernels
+static int conv3x3_dma_route(const ConvArgs& a) {
+  const bool wino = a.use_wino && a.wpack_wino && (a.bn == 64 || a.use_wino != 2);  // use_wino 2: Winograd for the N-tile-64 layers only
+  if (wino && a.persist && a.use_w16 && w16_fits(a)) return 1;
+  if (a.use_c16 && a.w16 && a.c0p == 16 && a.coutp == 16 && !a.src1 && !a.dst_pool) return 0;
+  if (wino && a.persist && a.use_wino2d && a.wpack_wino2 && a.bn == 64 && a.c0p + a.c1p >= 32 && wino2d_fits(a)) return 2;
+  return 3;
+}
+bool conv3x3_dma_honours_mask(const ConvArgs& a) { return conv3x3_dma_route(a) == 1; }
+
 int launch_conv3x3_dma(const ConvArgs& a, hipStream_t s) {
-  if (a.use_c16 && a.w16 && a.c0p == 16 && a.coutp == 16 && !a.src1 && !a.dst_pool) return launch_conv3x3_c16(a, s);
+  const int route = conv3x3_dma_route(a);
+  PH_REQUIRE(!a.relu_mask_src || route == 1, "relu_mask_src is only applied by conv3x3_w16_kernel (ask conv3x3_dma_honours_mask first)");
+  if (route == 1) return launch_conv3x3_w16(a, s);
+  if (route == 0) return launch_conv3x3_c16(a, s);
+  if (route == 2) return launch_conv3x3_wino2d(a, s);
   const int tiles = ((a.W + TW - 1) / TW) * ((a.H + D_TH - 1) / D_TH) * a.B;
   const int ntc = (a.coutp + a.bn - 1) / a.bn;
-  const bool wino = a.use_wino && a.wpack_wino && (a.bn == 64 || a.use_wino != 2);  // use_wino 2: Winograd for the N-tile-64 layers only
-  if (wino && a.persist && a.use_w16 && w16_fits(a)) return launch_conv3x3_w16(a, s);
-  if (wino && a.persist && a.use_wino2d && a.wpack_wino2 && a.bn == 64 && a.c0p + a.c1p >= 32 && wino2d_fits(a)) return launch_conv3x3_wino2d(a, s);
+  const bool wino = a.use_wino && a.wpack_wino && (a.bn == 64 || a.use_wino != 2);
   int n_cu = 0;
   if (a.persist) {
     const int rc = cu_count(&n_cu);

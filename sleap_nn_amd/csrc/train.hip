@@ -109,7 +109,7 @@ int ph_model_set_params(ph_model* m, const float* params_flat_dev, void* stream)
   for (const DerivedBuffer& db : m->derived) {
     int rc = db.kind == 1 ? launch_f16_weight_pack(db.src, db.dst, db.n_tiles, db.chunks0, db.chunks1, db.bn, db.plain, static_cast<hipStream_t>(stream))
              : db.kind == 2 ? launch_wino2d_pack(db.src, db.dst, db.panels, db.bn, static_cast<hipStream_t>(stream))
-             : db.kind == 3 ? launch_w16_pack(db.src, db.dst, db.panels, static_cast<hipStream_t>(stream))
+             : db.kind == 3 ? launch_w16_pack(db.src, db.dst, db.panels, db.bn, static_cast<hipStream_t>(stream))
              : db.kind == 4 ? launch_stem_wino2d_pack(db.src, db.dst, static_cast<hipStream_t>(stream))
              : db.bn == 0 ? launch_stem_wino_pack(db.src, db.dst, static_cast<hipStream_t>(stream))
                           : launch_wino_pack(db.src, db.dst, db.panels, db.bn, static_cast<hipStream_t>(stream));
@@ -322,6 +322,7 @@ int ph_model_backward(ph_model* m, const void* input_dev, int32_t in_dtype, int3
           a.wpack_dma = op.wd_dma_dev[part];
           a.wpack_wino = op.wd_wino_dev[part];
           a.wpack_wino2 = op.wd_wino2_dev[part];
+          a.wpack_w16 = op.wd_w16_dev[part];
           a.w16 = op.wd16_dev;
           a.bias = op.zero_bias_dev;
           a.dst = G(srcs[part]);
@@ -337,7 +338,17 @@ int ph_model_backward(ph_model* m, const void* input_dev, int32_t in_dtype, int3
           apply_conv_options(m, a);
           if (!m->dgrad_wino) a.use_wino = 0;
           a.accumulate = init[srcs[part]];
-          rc = (m->use_dma && (a.bn == 64 || m->dma32)) ? launch_conv3x3_dma(a, s) : launch_conv3x3(a, s);
+          const bool dma = m->use_dma && (a.bn == 64 || m->dma32);
+          {  // this launch completes the gradient of a conv + ReLU output and its kernel has a lane-local epilogue: that ReLU's mask rides there
+            const int pr = producer[srcs[part]];
+            const int pk = pr >= 0 ? m->ops[pr].d.kind : -1;
+            if (m->mask_fold && dma && first_consumer[srcs[part]] == oi && (pk == PH_OP_CONV || pk == PH_OP_INPUT_CONV) && (m->ops[pr].d.flags & PH_FLAG_RELU) &&
+                d.src0 != d.src1 && conv3x3_dma_honours_mask(a)) {
+              a.relu_mask_src = A(srcs[part]);
+              masked[srcs[part]] = 1;
+            }
+          }
+          rc = dma ? launch_conv3x3_dma(a, s) : launch_conv3x3(a, s);
           if (rc != PH_OK) return rc;
           init[srcs[part]] = 1;
         }

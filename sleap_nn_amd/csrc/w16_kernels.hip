@@ -1,5 +1,6 @@
-// 3x3 "same" convolution with 32 output channels and 16 or 32 input channels (the second encoder block of a filters = 16
-// UNet at half resolution: 2 of cfg3's 16 conv launches) as Winograd F(2x2, 3x3) on v_mfma_f32_16x16x4_f32.
+// 3x3 "same" convolution with 32 (NB = 2) or 16 (NB = 1) output channels and 16 or 32 input channels (the second encoder block of a
+// filters = 16 UNet at half resolution: 2 of cfg3's 16 conv launches; in training also the first block's 16 -> 16 conv and the data
+// gradients of both) as Winograd F(2x2, 3x3) on v_mfma_f32_16x16x4_f32.
 //
 // Reference semantics: SimpleConvBlock's Conv2d(k3, "same") + bias + ReLU and the 2x2 max pool behind it
 // (architectures/encoder_decoder.py:108-121, architectures/common.py:69-107), as conv3x3_wino2d_kernel (wino2d_kernels.hip).
@@ -30,13 +31,14 @@ constexpr int V_PLANE_E = V_HH * 9;                     // 306 entries per colum
 constexpr int V_PLANE_PIECES = (V_PLANE_E + 15) / 16;   // 20 DMA pieces (16 entries x 64 B) per plane
 constexpr int V_PLANE_FLOATS = V_PLANE_PIECES * 256;    // 5120
 constexpr int V_HALO_FLOATS = 2 * V_PLANE_FLOATS;       // 10240 per buffer (40 KiB)
-constexpr int V_W_FLOATS = 16 * 2 * 256;                // 8192 per chunk (32 KiB): [position][N block][lane][4]
+constexpr int v_w_floats(int nb) { return 16 * nb * 256; }  // per chunk: [position][N block][lane][4] (32 KiB for two N blocks of 16 channels)
 
-// wpack [chunk][tap 9][32][16] (pack_conv, N tile 32) -> U = G g G^T as [chunk][position xi * 4 + nu][N block][kq][n][4]
-__global__ __launch_bounds__(256) void w16_pack_kernel(const float* __restrict__ src, float* __restrict__ dst, int chunks) {
-  const int total = chunks * V_W_FLOATS;
+// wpack [chunk][tap 9][32][16] (pack_conv, N tile 32) -> U = G g G^T as [chunk][position xi * 4 + nu][N block < nbs][kq][n][4]
+__global__ __launch_bounds__(256) void w16_pack_kernel(const float* __restrict__ src, float* __restrict__ dst, int chunks, int nbs) {
+  const int per = v_w_floats(nbs), total = chunks * per;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
-    const int e = i & 3, n = (i >> 2) & 15, kq = (i >> 6) & 3, nb = (i >> 8) & 1, pos = (i >> 9) & 15, chunk = i >> 13;
+    const int chunk = i / per, r = i - chunk * per;
+    const int e = r & 3, n = (r >> 2) & 15, kq = (r >> 6) & 3, nb = (r >> 8) % nbs, pos = (r >> 8) / nbs;
     const int xi = pos >> 2, nu = pos & 3;
     const int row = nb * 16 + n, kc = 4 * kq + e;
     const float* w = src + ((size_t)chunk * 9 * 32 + row) * 16 + kc;
@@ -50,15 +52,17 @@ __global__ __launch_bounds__(256) void w16_pack_kernel(const float* __restrict__
     dst[i] = nu == 0 ? h[0] : (nu == 1 ? 0.5f * ((h[0] + h[2]) + h[1]) : (nu == 2 ? 0.5f * ((h[0] + h[2]) - h[1]) : h[2]));
   }
 }
-int64_t w16_pack_floats(int chunks) { return (int64_t)chunks * V_W_FLOATS; }
-int launch_w16_pack(const float* wpack, float* w16, int chunks, hipStream_t s) {
-  hipLaunchKernelGGL(w16_pack_kernel, dim3(std::min(chunks * V_W_FLOATS / 256, 256)), dim3(256), 0, s, wpack, w16, chunks);
+int64_t w16_pack_floats(int chunks, int nbs) { return (int64_t)chunks * v_w_floats(nbs); }
+int launch_w16_pack(const float* wpack, float* w16, int chunks, int nbs, hipStream_t s) {
+  PH_REQUIRE(nbs == 1 || nbs == 2, "w16 pack: one or two N blocks of 16 channels");
+  hipLaunchKernelGGL(w16_pack_kernel, dim3(std::min(chunks * v_w_floats(nbs) / 256, 256)), dim3(256), 0, s, wpack, w16, chunks, nbs);
   PH_HIP_CHECK(hipGetLastError());
   return PH_OK;
 }
 
-template <int CHUNKS>
+template <int CHUNKS, int NB>
 __global__ __launch_bounds__(512, 2) void conv3x3_w16_kernel(ConvArgs a) {
+  constexpr int V_W_FLOATS = v_w_floats(NB);
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* const wl = lds;                           // transformed weights, resident
   float* const hbuf = lds + CHUNKS * V_W_FLOATS;   // two halo buffers
@@ -91,13 +95,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_w16_kernel(ConvArgs a) {
     const int ty = t % tiles_y;
     const int b = t / tiles_y;
     const int x0 = tx * V_TW, y0 = ty * V_TH;
-    const int base = ((b * a.H + y0) * a.W + x0) * a.c0p * 4;
+    const unsigned base = (unsigned)((b * a.H + y0) * a.W + x0) * (unsigned)(a.c0p * 4);  // < 4 GiB (w16_fits); the halo terms below wrap consistently
 #pragma unroll
     for (int s = 0; s < 5; ++s) {
       const int hy = hyx[s] >> 8, hx = hyx[s] & 255;
       const int gy = y0 + hy - 1, gx = x0 + hx - 1;
       const bool in = hyx[s] >= 0 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-      fvo[s] = in ? (unsigned)(base + ((hy - 1) * a.W + (hx - 1)) * a.c0p * 4 + (lane & 3) * 16) : 0xFFFFFF00u;
+      fvo[s] = in ? base + (unsigned)(((hy - 1) * a.W + (hx - 1)) * a.c0p * 4 + (lane & 3) * 16) : 0xFFFFFF00u;
     }
   };
   auto dma = [&](float* buf, int chunk) {
@@ -111,13 +115,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_w16_kernel(ConvArgs a) {
   auto a_off = [&](int r, int c) { return lbase + r * 9 * 16 + (c >> 1) * 16 + (c & 1) * V_PLANE_FLOATS; };
   const int boff = lane * 4;
 
-  // ---- prologue: weights (CHUNKS * 32 pieces of 1 KiB), first unit's halo
+  // ---- prologue: weights (CHUNKS * 16 NB pieces of 1 KiB), first unit's halo
   {
     const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)a.wpack_w16, 0, CHUNKS * V_W_FLOATS * 4, 0x00020000);
+    constexpr int WP = CHUNKS * 2 * NB;  // 1-KiB pieces per wave
 #pragma unroll
-    for (int s = 0; s < CHUNKS * 4; ++s)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (__attribute__((address_space(3))) void*)(wl + (wave * CHUNKS * 4 + s) * 256), 16, (unsigned)lane * 16u,
-                                               (wave * CHUNKS * 4 + s) * 1024, 0, 0);
+    for (int s = 0; s < WP; ++s)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (__attribute__((address_space(3))) void*)(wl + (wave * WP + s) * 256), 16, (unsigned)lane * 16u, (wave * WP + s) * 1024, 0, 0);
   }
   int vid = blockIdx.x;
   point(vid);
@@ -127,11 +131,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_w16_kernel(ConvArgs a) {
   while (true) {
     const int nvid = vid + gridDim.x;
     const bool has_next = nvid < total;
-    f32x4 acc[16][2];
+    f32x4 acc[16][NB];
 #pragma unroll
     for (int p = 0; p < 16; ++p)
 #pragma unroll
-      for (int nb = 0; nb < 2; ++nb)
+      for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[p][nb][e] = 0.f;
 #pragma unroll 1
@@ -145,7 +149,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_w16_kernel(ConvArgs a) {
       }
       const float* hb = hbuf + par * V_HALO_FLOATS;
       const float* wc = wl + ch * V_W_FLOATS + boff;
-      f32x4 da[4], db[4], av[4], bf[2][2];
+      f32x4 da[4], db[4], av[4], bf[2][NB];
       auto read_rows = [&](int xi) {  // the two patch rows Winograd row xi combines
         const int ra = xi == 0 ? 0 : (xi == 2 ? 2 : 1), rb = xi == 0 ? 2 : (xi == 1 ? 2 : (xi == 2 ? 1 : 3));
 #pragma unroll
@@ -156,7 +160,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_w16_kernel(ConvArgs a) {
       };
       auto load_b = [&](int pos, int fb) {
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb) bf[fb][nb] = *reinterpret_cast<const f32x4*>(wc + (pos * 2 + nb) * 256);
+        for (int nb = 0; nb < NB; ++nb) bf[fb][nb] = *reinterpret_cast<const f32x4*>(wc + (pos * NB + nb) * 256);
       };
       read_rows(0);
       load_b(0, 0);
@@ -177,7 +181,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_w16_kernel(ConvArgs a) {
         for (int nu = 0; nu < 4; ++nu) {
           const int pos = xi * 4 + nu, cur = pos & 1;
 #pragma unroll
-          for (int nb = 0; nb < 2; ++nb) acc[pos][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[cur][nb][0], av[nu][0], acc[pos][nb], 0, 0, 0);  // D[channel][tile]
+          for (int nb = 0; nb < NB; ++nb) acc[pos][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[cur][nb][0], av[nu][0], acc[pos][nb], 0, 0, 0);  // D[channel][tile]
           __builtin_amdgcn_sched_barrier(0);
           if (pos + 1 < 16) load_b(pos + 1, cur ^ 1);
           if (nu == 0 && xi + 1 < 4) read_rows(xi + 1);
@@ -185,7 +189,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_w16_kernel(ConvArgs a) {
 #pragma unroll
           for (int j = 1; j < 4; ++j)
 #pragma unroll
-            for (int nb = 0; nb < 2; ++nb) acc[pos][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[cur][nb][j], av[nu][j], acc[pos][nb], 0, 0, 0);
+            for (int nb = 0; nb < NB; ++nb) acc[pos][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[cur][nb][j], av[nu][j], acc[pos][nb], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -206,7 +210,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_w16_kernel(ConvArgs a) {
       const int Hp = (a.H + 1) >> 1, Wp = (a.W + 1) >> 1;
       const int oy = y0 + 2 * (li >> 3), ox = x0 + 2 * (li & 7);
 #pragma unroll
-      for (int nb = 0; nb < 2; ++nb) {
+      for (int nb = 0; nb < NB; ++nb) {
         const int co = nb * 16 + 4 * kq;
         const f32x4 bias = *reinterpret_cast<const f32x4*>(a.bias + co);
         f32x4 y[2][2];
@@ -231,7 +235,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_w16_kernel(ConvArgs a) {
           for (int aa = 0; aa < 2; ++aa)
 #pragma unroll
             for (int bb = 0; bb < 2; ++bb)
-              if (interior || (oy + aa < a.H && ox + bb < a.W)) *reinterpret_cast<f32x4*>(a.dst + ((size_t)(b * a.H + oy + aa) * a.W + ox + bb) * a.coutp + co) = y[aa][bb];
+              if (interior || (oy + aa < a.H && ox + bb < a.W)) {
+                const size_t o = ((size_t)(b * a.H + oy + aa) * a.W + ox + bb) * a.coutp + co;
+                f32x4 v = y[aa][bb];
+                if (a.relu_mask_src) {  // backward: this launch completes the gradient of a conv + ReLU output -- that ReLU's mask rides in the (lane-local) epilogue
+                  const f32x4 f = *reinterpret_cast<const f32x4*>(a.relu_mask_src + o);
+#pragma unroll
+                  for (int e = 0; e < 4; ++e) v[e] = f[e] > 0.f ? v[e] : 0.f;
+                }
+                *reinterpret_cast<f32x4*>(a.dst + o) = v;
+              }
         }
         if (a.dst_pool) {  // "same" padding: zeros beyond the image
           f32x4 pm;
@@ -268,32 +281,41 @@ static int v_cu_count(int* out) {
 }
 
 int prepare_w16_kernels() {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_w16_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_w16_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  if (e != hipSuccess) {
-    set_error("hipFuncSetAttribute(w16) failed: %s", hipGetErrorString(e));
-    return PH_E_HIP;
+  const void* ks[4] = {reinterpret_cast<const void*>(conv3x3_w16_kernel<1, 1>), reinterpret_cast<const void*>(conv3x3_w16_kernel<2, 1>),
+                       reinterpret_cast<const void*>(conv3x3_w16_kernel<1, 2>), reinterpret_cast<const void*>(conv3x3_w16_kernel<2, 2>)};
+  for (const void* k : ks) {
+    const hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) {
+      set_error("hipFuncSetAttribute(w16) failed: %s", hipGetErrorString(e));
+      return PH_E_HIP;
+    }
   }
   return PH_OK;
 }
 
 bool w16_fits(const ConvArgs& a) {
   const uint64_t px = (uint64_t)a.B * a.H * a.W;
-  return a.wpack_w16 && a.coutp == 32 && a.bn == 32 && !a.src1 && a.c1p == 0 && (a.c0p == 16 || a.c0p == 32) && !a.accumulate && px * (uint64_t)a.c0p * 4 < 0x7FFFFF00ull;
+  return a.wpack_w16 && (a.coutp == 32 || a.coutp == 16) && a.bn == 32 && !a.src1 && a.c1p == 0 && (a.c0p == 16 || a.c0p == 32) && !a.accumulate &&
+         px * (uint64_t)a.c0p * 4 < 0xFFFFFF00ull && px < 0x7FFFFFFFull;
 }
 
 int launch_conv3x3_w16(const ConvArgs& a, hipStream_t s) {
-  PH_REQUIRE(w16_fits(a), "w16: Cout 32 (one N tile), 16 or 32 input channels from one source, no accumulate, source below 2 GiB");
+  PH_REQUIRE(w16_fits(a), "w16: Cout 16 or 32 (one N tile), 16 or 32 input channels from one source, no accumulate, source below 4 GiB");
   int n_cu = 0;
   const int rc = v_cu_count(&n_cu);
   if (rc != PH_OK) return rc;
   const int tiles = ((a.W + V_TW - 1) / V_TW) * ((a.H + V_TH - 1) / V_TH) * a.B;
-  const int chunks = a.c0p / 16;
-  const size_t ldsb = (size_t)(chunks * V_W_FLOATS + 2 * V_HALO_FLOATS) * sizeof(float);
-  if (chunks == 1)
-    hipLaunchKernelGGL(conv3x3_w16_kernel<1>, dim3(std::min(tiles, n_cu)), dim3(512), ldsb, s, a);
+  const int chunks = a.c0p / 16, nbs = a.coutp / 16;
+  const size_t ldsb = (size_t)(chunks * v_w_floats(nbs) + 2 * V_HALO_FLOATS) * sizeof(float);
+  const dim3 grid(std::min(tiles, n_cu));
+  if (chunks == 1 && nbs == 1)
+    hipLaunchKernelGGL((conv3x3_w16_kernel<1, 1>), grid, dim3(512), ldsb, s, a);
+  else if (chunks == 2 && nbs == 1)
+    hipLaunchKernelGGL((conv3x3_w16_kernel<2, 1>), grid, dim3(512), ldsb, s, a);
+  else if (chunks == 1)
+    hipLaunchKernelGGL((conv3x3_w16_kernel<1, 2>), grid, dim3(512), ldsb, s, a);
   else
-    hipLaunchKernelGGL(conv3x3_w16_kernel<2>, dim3(std::min(tiles, n_cu)), dim3(512), ldsb, s, a);
+    hipLaunchKernelGGL((conv3x3_w16_kernel<2, 2>), grid, dim3(512), ldsb, s, a);
   PH_HIP_CHECK(hipGetLastError());
   return PH_OK;
 }
