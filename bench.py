@@ -603,19 +603,27 @@ def run_train(args, ctx):
     fwd_flops = sum(r["flops"] for r in mm)
     conv3 = sum(r["flops"] for r in table if r["kind"] == L.OP_CONV)
     # executed on the matrix pipe per step: forward + data gradient run the Winograd kernels where they exist -- F(2x2,3x3) (4/9 of a
-    # 3x3 conv's direct FLOPs) for N tiles of 64 output channels with >= 32 input channels, F(2,3) along x (2/3) otherwise --
-    # weight gradients and the row GEMMs run direct
+    # 3x3 conv's direct FLOPs) for N tiles of 64 output channels with >= 32 input channels (conv3x3_wino2d_kernel) and for one-source
+    # layers with 16 / 32 channels on both sides (conv3x3_w16_kernel), F(2,3) along x (2/3) otherwise -- the 3x3 weight gradients run in
+    # the F(2x2,3x3) domain (4/9) for >= 32 padded output channels (wgrad_wino_kernel); row GEMMs and the rest run direct
     pad16 = lambda c: (c + 15) // 16 * 16
-    share = lambda cin, cout: 4.0 / 9.0 if (pad16(cout) >= 64 and pad16(cin) >= 32) else 2.0 / 3.0
+    def share(cin_p, cout_p, one_source=True):
+        if cout_p >= 64 and cin_p >= 32:
+            return 4.0 / 9.0
+        if one_source and cout_p in (16, 32) and cin_p in (16, 32):
+            return 4.0 / 9.0
+        return 2.0 / 3.0
     executed = 3.0 * fwd_flops
     for r in table:
         if r["kind"] != L.OP_CONV or r.get("ksize", 3) != 3:
             continue
         cin = r["cin0"] + r["cin1"]
-        executed -= r["flops"] * (1.0 - share(pad16(r["cin0"]) + (pad16(r["cin1"]) if r["cin1"] else 0), r["cout"]))  # forward
+        executed -= r["flops"] * (1.0 - share(pad16(r["cin0"]) + (pad16(r["cin1"]) if r["cin1"] else 0), pad16(r["cout"]), not r["cin1"]))  # forward
         for part in (r["cin0"], r["cin1"]):  # data gradient: one conv per concat source, Cout -> part channels
             if part > 0:
-                executed -= r["flops"] * part / cin * (1.0 - share(r["cout"], part))
+                executed -= r["flops"] * part / cin * (1.0 - share(pad16(r["cout"]), pad16(part)))
+        if pad16(r["cout"]) >= 32:  # weight gradient
+            executed -= r["flops"] * (1.0 - 4.0 / 9.0)
     per_step = elapsed / args.steps
     return {
         "metric": "frames/sec training step (forward + MSE + backward + gradient all-reduce + Adam)",
@@ -629,9 +637,10 @@ def run_train(args, ctx):
         "loss_first_last": [first, last],
         "allreduce": {"arena_mb": tm.grads.numel() * 4 / 1e6, "bucket_split": tm._bucket_split, "standalone_ms": ar_ms,
                       "note": "standalone_ms = both buckets back to back with nothing to overlap (null at N = 1); in a step the tail bucket runs under the encoder's backward"},
-        "roofline": {"bound": "mfma", "kernel": "forward + data-gradient convolutions (Winograd F(2x2,3x3) / F(2,3) kernels), 3x3 weight gradients and row GEMMs, all v_mfma_f32_32x32x2_f32",
+        "roofline": {"bound": "mfma", "kernel": "forward + data-gradient convolutions and 3x3 weight gradients (Winograd F(2x2,3x3) / F(2,3) kernels) and row GEMMs, on v_mfma_f32_32x32x2_f32 / 16x16x4_f32",
                      "achieved": executed / per_step / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": executed / per_step / 1e12 / MFMA_F32_PEAK_TFLOPS,
-                     "flop_accounting": "whole step time in the denominator (loss, masks, pools, Adam, re-pack included); executed FLOPs = 3 x forward matrix FLOPs with the forward / data-gradient Winograd layers at 4/9 (F(2x2,3x3)) or 2/3 (F(2,3))",
+                     "flop_accounting": "whole step time in the denominator (loss, masks, pools, Adam, re-pack included); executed FLOPs = 3 x forward matrix FLOPs with the forward / data-gradient / weight-gradient Winograd layers at 4/9 (F(2x2,3x3)) or 2/3 (F(2,3)); direct_equivalent_tflops = 3 x forward matrix FLOPs / step time, a throughput figure",
+                     "direct_equivalent_tflops": 3.0 * fwd_flops / per_step / 1e12,
                      "forward_matrix_gflop_per_step": fwd_flops / 1e9},
     }
 
