@@ -86,6 +86,9 @@ struct ph_model {
   std::vector<ph::PackedOp> ops;
   int n_slots = 0, n_outputs = 0;
   std::vector<void*> allocs;
+  void* gather_table_dev = nullptr;           // GatherSegment table of `packed` (ph_model_set_params: one gather launch for all of them)
+  int gather_segments = 0;
+  unsigned gather_blocks = 0;
   // last forward (for ph_model_read_slot)
   ph::Plan last_plan;
   char* last_ws = nullptr;

@@ -102,8 +102,24 @@ int64_t ph_model_num_params(const ph_model* m) {
 
 int ph_model_set_params(ph_model* m, const float* params_flat_dev, void* stream) {
   PH_REQUIRE(m && params_flat_dev, "ph_model_set_params: null argument");
-  for (const PackedBuffer& pb : m->packed) {
-    int rc = launch_gather(params_flat_dev, pb.map, pb.n, pb.dst, static_cast<hipStream_t>(stream));
+  if (!m->gather_table_dev && !m->packed.empty()) {  // built once: every packed buffer of the model is a segment of one launch
+    std::vector<GatherSegment> seg;
+    unsigned blocks = 0;
+    for (const PackedBuffer& pb : m->packed) {
+      if (pb.n == 0) continue;
+      seg.push_back(GatherSegment{pb.map, pb.dst, pb.n, blocks});
+      blocks += (unsigned)((pb.n + 1023) / 1024);
+    }
+    void* t = nullptr;
+    PH_HIP_CHECK(hipMalloc(&t, seg.size() * sizeof(GatherSegment)));
+    m->allocs.push_back(t);
+    PH_HIP_CHECK(hipMemcpy(t, seg.data(), seg.size() * sizeof(GatherSegment), hipMemcpyHostToDevice));
+    m->gather_table_dev = t;
+    m->gather_segments = (int)seg.size();
+    m->gather_blocks = blocks;
+  }
+  {
+    int rc = launch_gather_multi(params_flat_dev, static_cast<const GatherSegment*>(m->gather_table_dev), m->gather_segments, m->gather_blocks, static_cast<hipStream_t>(stream));
     if (rc != PH_OK) return rc;
   }
   for (const DerivedBuffer& db : m->derived) {

@@ -43,6 +43,13 @@ int launch_wgrad_wino(const WgradArgs& a, int cin_part, int cout, int cin_total,
 int launch_input_wgrad(const void* img, int dtype, const float* dy, int B, int cin, int H, int W, int coutp, int cout, float* gw, float* scratch, hipStream_t s);
 int64_t input_wgrad_scratch_floats(int cin, int cout);
 int launch_gather(const float* canon, const int* map, size_t n, float* out, hipStream_t s);
+struct GatherSegment {  // one packed buffer of the model: out[i] = map[i] >= 0 ? canon[map[i]] : 0
+  const int* map;
+  float* dst;
+  size_t n;
+  unsigned first_block;  // prefix sum of ceil(n / 1024) over the segments before this one
+};
+int launch_gather_multi(const float* canon, const GatherSegment* seg_dev, int n_seg, unsigned total_blocks, hipStream_t s);
 
 // ---- ConvNeXt encoder ops (convnext_train_kernels.hip)
 struct RowWgradArgs {

@@ -1160,6 +1160,32 @@ __global__ __launch_bounds__(256) void gather_kernel(const float* __restrict__ c
   }
 }
 
+// All packed buffers of a model in ONE launch: block -> segment by binary search over the segments' first blocks (1024 elements per block).
+__global__ __launch_bounds__(256) void gather_multi_kernel(const float* __restrict__ canon, const GatherSegment* __restrict__ seg, int n_seg) {
+  int lo = 0, hi = n_seg - 1;
+  while (lo < hi) {  // last segment whose first_block <= blockIdx.x (block-uniform)
+    const int mid = (lo + hi + 1) >> 1;
+    if (seg[mid].first_block <= blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const GatherSegment sg = seg[lo];
+  const size_t base = (size_t)(blockIdx.x - sg.first_block) * 1024;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const size_t i = base + k * 256 + threadIdx.x;
+    if (i < sg.n) {
+      const int j = sg.map[i];
+      sg.dst[i] = j >= 0 ? canon[j] : 0.f;
+    }
+  }
+}
+
+int launch_gather_multi(const float* canon, const GatherSegment* seg_dev, int n_seg, unsigned total_blocks, hipStream_t s) {
+  if (n_seg == 0 || total_blocks == 0) return PH_OK;
+  hipLaunchKernelGGL(gather_multi_kernel, dim3(total_blocks), dim3(256), 0, s, canon, seg_dev, n_seg);
+  PH_HIP_CHECK(hipGetLastError());
+  return PH_OK;
+}
+
 int launch_gather(const float* canon, const int* map, size_t n, float* out, hipStream_t s) {
   if (n == 0) return PH_OK;
   hipLaunchKernelGGL(gather_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 16384)), dim3(256), 0, s, canon, map, n, out);
