@@ -89,6 +89,10 @@ struct ph_model {
   void* gather_table_dev = nullptr;           // GatherSegment table of `packed` (ph_model_set_params: one gather launch for all of them)
   int gather_segments = 0;
   unsigned gather_blocks = 0;
+  bool pack_tables_built = false;             // PackSegment tables of the F(2,3) [0] / F(2x2,3x3) [1] buffers in `derived`
+  void* pack_table_dev[2] = {nullptr, nullptr};
+  int pack_segments[2] = {0, 0};
+  unsigned pack_blocks[2] = {0, 0};
   // last forward (for ph_model_read_slot)
   ph::Plan last_plan;
   char* last_ws = nullptr;

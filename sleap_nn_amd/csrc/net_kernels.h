@@ -122,6 +122,15 @@ int launch_conv3x3(const ConvArgs& a, hipStream_t s);
 // wpack [panel][tap 9][bn][16] -> Winograd weights [panel][step 24][n tile][lh][lx][4] (see conv3x3_wino_persist_kernel)
 int launch_wino_pack(const float* wpack, float* wino, int panels, int bn, hipStream_t s);
 int64_t wino_pack_floats(int panels, int bn);
+struct PackSegment {  // one derived weight buffer in a multi-buffer pack launch
+  const float* src;
+  float* dst;
+  unsigned long long total;  // elements of dst
+  int bn;
+  unsigned first_block;      // prefix sum of ceil(total / 1024) over the segments before this one
+};
+int launch_wino_pack_multi(const PackSegment* seg_dev, int n_seg, unsigned total_blocks, hipStream_t s);    // F(2,3) buffers
+int launch_wino2d_pack_multi(const PackSegment* seg_dev, int n_seg, unsigned total_blocks, hipStream_t s);  // F(2x2,3x3) buffers
 int launch_stem_wino_pack(const float* w1, float* w1w, hipStream_t s);
 int launch_stem_wino2d_pack(const float* w1, float* w2, hipStream_t s);  // [tap][co][ci] -> [position 16][co][ci]  // [tap][co][ci] -> [kernel row][m index][co][ci]
 int launch_conv3x3_dma(const ConvArgs& a, hipStream_t s);

@@ -827,31 +827,47 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mfma_dma_persist_kernel(ConvAr
 //     live in THREE half-chunk slots (24 KiB each): a chunk reads (h, h+1), the next chunk's first half is fetched into h+2
 //     during steps 0..7, and after a mid-chunk barrier (every wave is done with h) its second half goes into h.  150 KiB.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void wino_pack_kernel(const float* __restrict__ src /* [panel][tap 9][bn][16] */, float* __restrict__ dst, int panels, int bn) {
+__device__ __forceinline__ float wino_pack_element(const float* __restrict__ src /* [panel][tap 9][bn][16] */, int bn, size_t i) {
   const int nt = bn / 32;
   const int per_panel = 24 * nt * 256;
-  const size_t total = (size_t)panels * per_panel;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-    const int panel = (int)(i / per_panel);
-    int r = (int)(i - (size_t)panel * per_panel);
-    const int e = r & 3, lx = (r >> 2) & 31, lh = (r >> 7) & 1;
-    r >>= 8;  // piece index q * nt + n
-    const int n = r % nt, q = r / nt;
-    const int ky = q >> 3, g = (q >> 2) & 1, xi = q & 3;
-    const int row = n * 32 + lx, kc = (2 * g + lh) * 4 + e;
-    const float* w = src + (((size_t)panel * 9 + ky * 3) * bn + row) * 16 + kc;
-    const float g0 = w[0], g1 = w[(size_t)bn * 16], g2 = w[(size_t)2 * bn * 16];
-    float v;
-    if (xi == 0)
-      v = g0;
-    else if (xi == 1)
-      v = 0.5f * ((g0 + g2) + g1);
-    else if (xi == 2)
-      v = 0.5f * ((g0 + g2) - g1);
-    else
-      v = g2;
-    dst[i] = v;
+  const int panel = (int)(i / per_panel);
+  int r = (int)(i - (size_t)panel * per_panel);
+  const int e = r & 3, lx = (r >> 2) & 31, lh = (r >> 7) & 1;
+  r >>= 8;  // piece index q * nt + n
+  const int n = r % nt, q = r / nt;
+  const int ky = q >> 3, g = (q >> 2) & 1, xi = q & 3;
+  const int row = n * 32 + lx, kc = (2 * g + lh) * 4 + e;
+  const float* w = src + (((size_t)panel * 9 + ky * 3) * bn + row) * 16 + kc;
+  const float g0 = w[0], g1 = w[(size_t)bn * 16], g2 = w[(size_t)2 * bn * 16];
+  if (xi == 0) return g0;
+  if (xi == 1) return 0.5f * ((g0 + g2) + g1);
+  if (xi == 2) return 0.5f * ((g0 + g2) - g1);
+  return g2;
+}
+__global__ __launch_bounds__(256) void wino_pack_kernel(const float* __restrict__ src, float* __restrict__ dst, int panels, int bn) {
+  const size_t total = (size_t)panels * 24 * (bn / 32) * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) dst[i] = wino_pack_element(src, bn, i);
+}
+// every F(2,3) weight buffer of a model in one launch (ph_model_set_params): block -> segment by binary search, 1024 elements per block
+__global__ __launch_bounds__(256) void wino_pack_multi_kernel(const PackSegment* __restrict__ seg, int n_seg) {
+  int lo = 0, hi = n_seg - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (seg[mid].first_block <= blockIdx.x) lo = mid; else hi = mid - 1;
   }
+  const PackSegment sg = seg[lo];
+  const size_t base = (size_t)(blockIdx.x - sg.first_block) * 1024;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const size_t i = base + k * 256 + threadIdx.x;
+    if (i < sg.total) sg.dst[i] = wino_pack_element(sg.src, sg.bn, i);
+  }
+}
+int launch_wino_pack_multi(const PackSegment* seg_dev, int n_seg, unsigned total_blocks, hipStream_t s) {
+  if (n_seg == 0 || total_blocks == 0) return PH_OK;
+  hipLaunchKernelGGL(wino_pack_multi_kernel, dim3(total_blocks), dim3(256), 0, s, seg_dev, n_seg);
+  PH_HIP_CHECK(hipGetLastError());
+  return PH_OK;
 }
 // fused stem: w1 [tap][co 16][ci 16] -> [kernel row][m index 4][co][ci]
 __global__ __launch_bounds__(256) void stem_wino_pack_kernel(const float* __restrict__ w1, float* __restrict__ w1w) {

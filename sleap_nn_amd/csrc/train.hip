@@ -122,13 +122,42 @@ int ph_model_set_params(ph_model* m, const float* params_flat_dev, void* stream)
     int rc = launch_gather_multi(params_flat_dev, static_cast<const GatherSegment*>(m->gather_table_dev), m->gather_segments, m->gather_blocks, static_cast<hipStream_t>(stream));
     if (rc != PH_OK) return rc;
   }
+  // derived buffers: the F(2,3) and F(2x2,3x3) transforms (most of them) each go in ONE table-driven launch, the rest one by one
+  if (!m->pack_tables_built) {
+    for (int kind = 0; kind < 2; ++kind) {
+      std::vector<PackSegment> seg;
+      unsigned blocks = 0;
+      for (const DerivedBuffer& db : m->derived) {
+        const bool mine = kind == 0 ? (db.kind == 0 && db.bn != 0) : db.kind == 2;
+        if (!mine) continue;
+        const unsigned long long total = (unsigned long long)(kind == 0 ? wino_pack_floats(db.panels, db.bn) : wino2d_pack_floats(db.panels, db.bn));
+        if (total == 0) continue;
+        seg.push_back(PackSegment{db.src, db.dst, total, db.bn, blocks});
+        blocks += (unsigned)((total + 1023) / 1024);
+      }
+      void* t = nullptr;
+      if (!seg.empty()) {
+        PH_HIP_CHECK(hipMalloc(&t, seg.size() * sizeof(PackSegment)));
+        m->allocs.push_back(t);
+        PH_HIP_CHECK(hipMemcpy(t, seg.data(), seg.size() * sizeof(PackSegment), hipMemcpyHostToDevice));
+      }
+      m->pack_table_dev[kind] = t;
+      m->pack_segments[kind] = (int)seg.size();
+      m->pack_blocks[kind] = blocks;
+    }
+    m->pack_tables_built = true;
+  }
+  {
+    int rc = launch_wino_pack_multi(static_cast<const PackSegment*>(m->pack_table_dev[0]), m->pack_segments[0], m->pack_blocks[0], static_cast<hipStream_t>(stream));
+    if (rc == PH_OK) rc = launch_wino2d_pack_multi(static_cast<const PackSegment*>(m->pack_table_dev[1]), m->pack_segments[1], m->pack_blocks[1], static_cast<hipStream_t>(stream));
+    if (rc != PH_OK) return rc;
+  }
   for (const DerivedBuffer& db : m->derived) {
+    if ((db.kind == 0 && db.bn != 0) || db.kind == 2) continue;  // in the two launches above
     int rc = db.kind == 1 ? launch_f16_weight_pack(db.src, db.dst, db.n_tiles, db.chunks0, db.chunks1, db.bn, db.plain, static_cast<hipStream_t>(stream))
-             : db.kind == 2 ? launch_wino2d_pack(db.src, db.dst, db.panels, db.bn, static_cast<hipStream_t>(stream))
              : db.kind == 3 ? launch_w16_pack(db.src, db.dst, db.panels, db.bn, static_cast<hipStream_t>(stream))
              : db.kind == 4 ? launch_stem_wino2d_pack(db.src, db.dst, static_cast<hipStream_t>(stream))
-             : db.bn == 0 ? launch_stem_wino_pack(db.src, db.dst, static_cast<hipStream_t>(stream))
-                          : launch_wino_pack(db.src, db.dst, db.panels, db.bn, static_cast<hipStream_t>(stream));
+                            : launch_stem_wino_pack(db.src, db.dst, static_cast<hipStream_t>(stream));
     if (rc != PH_OK) return rc;
   }
   return PH_OK;

@@ -67,29 +67,51 @@ __device__ __forceinline__ void w2_deal_tile(int id, int tiles, int nt_count, in
 }
 
 // wpack [panel][tap 9][bn][16] (pack_conv) -> U = G g G^T in LDS order [panel][g 2][xi 4][nu 4][n tile][lh 2][lx 32][4]
-__global__ __launch_bounds__(256) void wino2d_pack_kernel(const float* __restrict__ src, float* __restrict__ dst, int panels, int bn) {
+__device__ __forceinline__ float wino2d_pack_element(const float* __restrict__ src, int bn, size_t i) {
   const int nt = bn / 32;
   const int per_panel = 32 * nt * 256;
-  const size_t total = (size_t)panels * per_panel;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-    const int panel = (int)(i / per_panel);
-    int r = (int)(i - (size_t)panel * per_panel);
-    const int e = r & 3, lx = (r >> 2) & 31, lh = (r >> 7) & 1;
-    r >>= 8;
-    const int n = r % nt;
-    r /= nt;
-    const int nu = r & 3, xi = (r >> 2) & 3, g = r >> 4;
-    const int row = n * 32 + lx, kc = (2 * g + lh) * 4 + e;
-    const float* w = src + ((size_t)panel * 9 * bn + row) * 16 + kc;
-    const size_t ts = (size_t)bn * 16;  // tap stride
-    float h[3];                         // row xi of G g, per kx
+  const int panel = (int)(i / per_panel);
+  int r = (int)(i - (size_t)panel * per_panel);
+  const int e = r & 3, lx = (r >> 2) & 31, lh = (r >> 7) & 1;
+  r >>= 8;
+  const int n = r % nt;
+  r /= nt;
+  const int nu = r & 3, xi = (r >> 2) & 3, g = r >> 4;
+  const int row = n * 32 + lx, kc = (2 * g + lh) * 4 + e;
+  const float* w = src + ((size_t)panel * 9 * bn + row) * 16 + kc;
+  const size_t ts = (size_t)bn * 16;  // tap stride
+  float h[3];                         // row xi of G g, per kx
 #pragma unroll
-    for (int kx = 0; kx < 3; ++kx) {
-      const float g0 = w[(0 * 3 + kx) * ts], g1 = w[(1 * 3 + kx) * ts], g2 = w[(2 * 3 + kx) * ts];
-      h[kx] = xi == 0 ? g0 : (xi == 1 ? 0.5f * ((g0 + g2) + g1) : (xi == 2 ? 0.5f * ((g0 + g2) - g1) : g2));
-    }
-    dst[i] = nu == 0 ? h[0] : (nu == 1 ? 0.5f * ((h[0] + h[2]) + h[1]) : (nu == 2 ? 0.5f * ((h[0] + h[2]) - h[1]) : h[2]));
+  for (int kx = 0; kx < 3; ++kx) {
+    const float g0 = w[(0 * 3 + kx) * ts], g1 = w[(1 * 3 + kx) * ts], g2 = w[(2 * 3 + kx) * ts];
+    h[kx] = xi == 0 ? g0 : (xi == 1 ? 0.5f * ((g0 + g2) + g1) : (xi == 2 ? 0.5f * ((g0 + g2) - g1) : g2));
   }
+  return nu == 0 ? h[0] : (nu == 1 ? 0.5f * ((h[0] + h[2]) + h[1]) : (nu == 2 ? 0.5f * ((h[0] + h[2]) - h[1]) : h[2]));
+}
+__global__ __launch_bounds__(256) void wino2d_pack_kernel(const float* __restrict__ src, float* __restrict__ dst, int panels, int bn) {
+  const size_t total = (size_t)panels * 32 * (bn / 32) * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) dst[i] = wino2d_pack_element(src, bn, i);
+}
+// every F(2x2,3x3) weight buffer of a model in one launch (ph_model_set_params): block -> segment by binary search, 1024 elements per block
+__global__ __launch_bounds__(256) void wino2d_pack_multi_kernel(const PackSegment* __restrict__ seg, int n_seg) {
+  int lo = 0, hi = n_seg - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (seg[mid].first_block <= blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const PackSegment sg = seg[lo];
+  const size_t base = (size_t)(blockIdx.x - sg.first_block) * 1024;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const size_t i = base + k * 256 + threadIdx.x;
+    if (i < sg.total) sg.dst[i] = wino2d_pack_element(sg.src, sg.bn, i);
+  }
+}
+int launch_wino2d_pack_multi(const PackSegment* seg_dev, int n_seg, unsigned total_blocks, hipStream_t s) {
+  if (n_seg == 0 || total_blocks == 0) return PH_OK;
+  hipLaunchKernelGGL(wino2d_pack_multi_kernel, dim3(total_blocks), dim3(256), 0, s, seg_dev, n_seg);
+  PH_HIP_CHECK(hipGetLastError());
+  return PH_OK;
 }
 int64_t wino2d_pack_floats(int panels, int bn) { return (int64_t)panels * 32 * (bn / 32) * 256; }
 int launch_wino2d_pack(const float* wpack, float* wino, int panels, int bn, hipStream_t s) {
