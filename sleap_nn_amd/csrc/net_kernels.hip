@@ -1801,7 +1801,78 @@ __global__ __launch_bounds__(256) void input_conv3x3_kernel(InputConvArgs a) {
   }
 }
 
+// The common first conv (3x3, 1 or 3 input channels, 16 output channels, fp32 slots) without the generic kernel's per-tap global
+// loads, divisions and branches: an 8 x 32 pixel tile's normalised image patch goes to LDS once, a thread keeps the 9 x CIN weight
+// quads of ITS four output channels in registers (item = (pixel, channel quad): four lanes share a pixel -- LDS broadcast reads --
+// and a wave's stores are one contiguous KiB).  The training program's forward runs this (the inference plans fuse the first block).
+template <int CIN>
+__global__ __launch_bounds__(256) void input_conv3_c16_kernel(InputConvArgs a) {
+  constexpr int PW = TW + 2, PH_ = TH + 2;
+  __shared__ float sImg[CIN * PH_ * PW];
+  const int tid = threadIdx.x;
+  const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;
+  const int q4 = (tid & 3) * 4;
+  f32x4 wreg[9 * CIN];
+#pragma unroll
+  for (int t = 0; t < 9 * CIN; ++t) wreg[t] = *reinterpret_cast<const f32x4*>(a.w + t * 16 + q4);  // [tap][cin][16]
+  const f32x4 b0 = *reinterpret_cast<const f32x4*>(a.bias + q4);
+  for (int tile = blockIdx.x; tile < tiles_x * tiles_y * a.B; tile += gridDim.x) {
+    int t = tile;
+    const int tx = t % tiles_x;
+    t /= tiles_x;
+    const int ty = t % tiles_y;
+    const int b = t / tiles_y;
+    const int x0 = tx * TW, y0 = ty * TH;
+    __syncthreads();  // the previous tile's reads are done
+    for (int i = tid; i < CIN * PH_ * PW; i += 256) {
+      const int c = i / (PH_ * PW), r = i - c * (PH_ * PW);
+      const int iy = r / PW, ix = r - iy * PW;
+      const int gy = y0 + iy - 1, gx = x0 + ix - 1;
+      float v = 0.f;
+      if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
+        const size_t o = (((size_t)b * CIN + c) * a.H + gy) * a.W + gx;
+        if (a.dtype == 0)
+          v = (float)reinterpret_cast<const uint8_t*>(a.src)[o] / 255.0f;
+        else {
+          v = reinterpret_cast<const float*>(a.src)[o];
+          if (a.dtype == 2) v = v / 255.0f;
+        }
+      }
+      sImg[i] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < TH * TW / 64; ++j) {
+      const int pix = (tid >> 2) + 64 * j;
+      const int py = pix / TW, px = pix - py * TW;
+      f32x4 acc = b0;
+#pragma unroll
+      for (int c = 0; c < CIN; ++c)
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) acc += sImg[(c * PH_ + py + ky) * PW + px + kx] * wreg[(ky * 3 + kx) * CIN + c];
+      if (a.relu) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[k] = fmaxf(acc[k], 0.f);
+      }
+      const int y = y0 + py, x = x0 + px;
+      if (y < a.H && x < a.W) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.dst) + (((size_t)b * a.H + y) * a.W + x) * 16 + q4) = acc;
+    }
+  }
+}
+
 int launch_input_conv(const InputConvArgs& a, hipStream_t s) {
+  if (a.ksize == 3 && a.coutp == 16 && a.out_fmt == FMT_F32 && (a.cin == 1 || a.cin == 3)) {
+    const int tiles = ((a.W + TW - 1) / TW) * ((a.H + TH - 1) / TH) * a.B;
+    const dim3 grid(std::min(tiles, 256 * 8));
+    if (a.cin == 1)
+      hipLaunchKernelGGL(input_conv3_c16_kernel<1>, grid, dim3(256), 0, s, a);
+    else
+      hipLaunchKernelGGL(input_conv3_c16_kernel<3>, grid, dim3(256), 0, s, a);
+    PH_HIP_CHECK(hipGetLastError());
+    return PH_OK;
+  }
   const size_t total = (size_t)a.B * a.H * a.W * (a.coutp / 4);
   const int blocks = (int)std::min<size_t>((total + 255) / 256, 256 * 32);
   hipLaunchKernelGGL(input_conv3x3_kernel, dim3(blocks), dim3(256), 0, s, a);
