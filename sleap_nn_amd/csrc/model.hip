@@ -876,6 +876,7 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
   }
   size_t op_index = 0;
   bool skip_next_gelu = false;
+  int pooled_by_conv = -1;  // slot whose 2x2 max pool the producing conv's epilogue already wrote (run-time fusion of an unfused program, see PH_OP_CONV)
   for (const PackedOp& op : m->ops) {
     const ph_op_desc& d = op.d;
     if (m->profiling) PH_HIP_CHECK(hipEventRecord(m->ev[op_index], s));
@@ -1043,10 +1044,26 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
           rc = launch_gemm(g, s);
           break;
         }
+        if (m->pool_peephole && !a.dst_pool && a.relu && m->use_dma && (a.bn == 64 || m->dma32) && op_index < m->ops.size()) {
+          // An UNFUSED program (the training forward: the backward walks one op per activation) still gets the conv kernels' fused
+          // 2x2 max pool: when the next op is the pool of this conv's output, the epilogue writes both tensors and the pool op is skipped.
+          const ph_op_desc& nx = m->ops[op_index].d;
+          if (nx.kind == PH_OP_POOL && nx.src0 == d.dst) {
+            a.dst_pool = slot_ptr(nx.dst);
+            if (conv3x3_dma_is_f2x2(a))  // the F(2x2,3x3) kernels (a Winograd tile is a pool window); other kernels keep the separate pool
+              pooled_by_conv = d.dst;
+            else
+              a.dst_pool = nullptr;
+          }
+        }
         rc = (m->use_dma && (a.bn == 64 || m->dma32)) ? launch_conv3x3_dma(a, s) : launch_conv3x3(a, s);
         break;
       }
       case PH_OP_POOL: {
+        if (pooled_by_conv == d.src0) {  // written by the producing conv's epilogue
+          pooled_by_conv = -1;
+          break;
+        }
         const SlotShape& s0 = plan.slots[d.src0];
         rc = fmt == FMT_F32 ? launch_pool(slot_ptr(d.src0), slot_ptr(d.dst), batch, s0.h, s0.w, s0.cp, s)
                             : launch_pool_fmt(fmt, slot_ptr(d.src0), slot_ptr(d.dst), batch, s0.h, s0.w, s0.cp, s);
@@ -1291,6 +1308,7 @@ std::vector<OptionRef> option_table(ph_model* m) {
       {"conv_dma_stagger", &m->dma_stagger, nullptr},   // 0: SIMD-partner waves issue DMA pieces at the same step
       {"fuse_gelu_fwd", &m->fuse_gelu_fwd, nullptr},
       {"fuse_gelu_bwd", &m->fuse_gelu_bwd, nullptr},
+      {"pool_peephole", &m->pool_peephole, nullptr},    // unfused programs: a conv whose next op pools its output writes the pooled tensor from its epilogue
       {"mask_fold", &m->mask_fold, nullptr},            // ReLU mask applied by the pool backward that completes a conv output's gradient
       {"wgrad_wino", &m->wgrad_wino, nullptr},          // 3x3 weight gradients: 1 Winograd F(2x2,3x3) domain, 0 direct nine-tap kernel
       {"wgrad_rows", &m->wgrad_rows, nullptr},          // 0 32x32-tile wgrad kernel, 1 auto, 2 nine row-wgrad GEMMs

@@ -1323,6 +1323,7 @@ static int conv3x3_dma_route(const ConvArgs& a) {
   return 3;
 }
 bool conv3x3_dma_honours_mask(const ConvArgs& a) { return conv3x3_dma_route(a) == 1; }
+bool conv3x3_dma_is_f2x2(const ConvArgs& a) { const int r = conv3x3_dma_route(a); return r == 1 || r == 2; }
 
 int launch_conv3x3_dma(const ConvArgs& a, hipStream_t s) {
   const int route = conv3x3_dma_route(a);
