@@ -604,10 +604,17 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void gemm_mfma_dma_kernel(GemmAr
   // branch-free (selects only): a branch would split the scheduling region and serialise address
   // arithmetic, DMA issue and MFMAs.
   const int dr = lane & 7, dquad = (lane >> 3) ^ (wave & 1);  // p & 1 == wave & 1 (WAVES is even)
+  // The transfers go through buffer descriptors (as conv3x3_wino2d_kernel's): a row's address is a 32-bit offset from a per-tile
+  // pixel base that is fixed when the tile is set up (one per concat source: the row pitch differs), the stage's tap / channel-slice
+  // offset rides in the descriptor's (scalar) base, and masked rows (taps outside the image, quads past Cp, dummy stages) get an
+  // out-of-range offset -- the hardware's range check returns the zeros.  A stage issues its pieces with ~2 vector instructions per
+  // piece instead of ~10 (64-bit address arithmetic and selects), and unlike global_load_lds these loads do not make the
+  // compiler's LDS-read waits lgkmcnt(0).
+  constexpr unsigned OOB = 0xFFFFFF00u, RANGE = 0x80000000u;
   struct Plan {
-    unsigned a_pix[A_SLOTS];  // pixel index of the slot's row (the byte address is one v_mad_u64_u32 away at issue time)
+    unsigned a_off0[A_SLOTS], a_off1[A_SLOTS];  // byte offset of the slot's row from the tile's pixel base, per source (+ the lane's quad)
     unsigned a_mask[A_SLOTS];
-    unsigned long long w_lane;
+    long long base_pix;  // wave-uniform
     int m0, ntile;
   };
   auto setup = [&](int vid, Plan& P) __attribute__((always_inline)) {
@@ -622,19 +629,23 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void gemm_mfma_dma_kernel(GemmAr
     }
     P.m0 = t * TM;
     P.ntile = ntile;
-    P.w_lane = (unsigned long long)(a.wpack + (size_t)ntile * nstages * (B_PIECES * 256) + lane * 4);
-#pragma unroll
-    for (int s = 0; s < A_SLOTS; ++s) {
-      const int row = min(P.m0 + min(wave + WAVES * s, A_PIECES - 1) * 8 + dr, a.M - 1);
-      unsigned mask = 0x1ffu;
-      long long pix = row;
+    auto pix_of = [&](int row) -> long long {
       if (MODE == 1) {
         const int ow = a.W >> 1, oh = a.H >> 1;
         const int ox = row % ow;
         const int r2 = row / ow;
         const int oy = r2 % oh;
-        pix = ((long long)(r2 / oh) * a.H + 2 * oy) * a.W + 2 * ox;
-      } else if (MODE == 2) {
+        return ((long long)(r2 / oh) * a.H + 2 * oy) * a.W + 2 * ox;
+      }
+      return row;
+    };
+    // every row of the tile lies at or after its first row's pixel; the 3x3 taps reach one row + one pixel back
+    P.base_pix = pix_of(min(P.m0, a.M - 1)) - (MODE == 2 ? a.W + 1 : 0);
+#pragma unroll
+    for (int s = 0; s < A_SLOTS; ++s) {
+      const int row = min(P.m0 + min(wave + WAVES * s, A_PIECES - 1) * 8 + dr, a.M - 1);
+      unsigned mask = 0x1ffu;
+      if (MODE == 2) {
         const int x = row % a.W;
         const int y = (row / a.W) % a.H;
         mask = 0;
@@ -644,11 +655,13 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void gemm_mfma_dma_kernel(GemmAr
           mask |= (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) ? (1u << tap) : 0u;
         }
       }
-      P.a_pix[s] = (unsigned)pix;
+      const unsigned rel = (unsigned)(pix_of(row) - P.base_pix);
+      P.a_off0[s] = rel * (unsigned)(a.c0p * 4) + (unsigned)dquad * 16u;
+      P.a_off1[s] = rel * (unsigned)(a.c1p * 4) + (unsigned)dquad * 16u;
       P.a_mask[s] = mask;
     }
   };
-  const unsigned long long zero_addr = (unsigned long long)(a.zeros + (lane >> 3) * 4);
+  const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wpack), 0, (int)((unsigned)ntc * (unsigned)nstages * (unsigned)(B_PIECES * 1024)), 0x00020000);
 
   // PERSISTENT workgroup: it walks its tiles back to back and the stage stream (ring of three LDS stages,
   // fetch two stages ahead) simply continues into the next tile, so a tile starts with its first stages already
@@ -672,30 +685,28 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void gemm_mfma_dma_kernel(GemmAr
       const int ty = (f_tap * 11) >> 5;  // f_tap / 3 for 0..8
       toff = (ty - 1) * a.W + (f_tap - 3 * ty - 1);
     }
-    // byte address of pixel 0's quad dquad for this (source, tap, channel slice); a row adds pix * cp * 4
-    const unsigned long long sbase = (unsigned long long)((f_src ? a.src1 : a.src0) + dquad * 4) + (unsigned long long)(((long long)toff * cp + f_coff) * 4);
-    const unsigned row_bytes = (unsigned)cp * 4u;
+    // descriptor base (wave-uniform): the tile's pixel base moved by the tap, at this stage's channel slice of the source
+    const long long bpix = (f_next ? Pn.base_pix : Pc.base_pix) + toff;
+    const float* sb = (f_src ? a.src1 : a.src0) + bpix * cp + f_coff;
+    const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sb), 0, (int)RANGE, 0x00020000);
     // dummy fetches (padding stage, or no tile left) and quads past Cp (a slice may be half empty: Cp is a
-    // multiple of 16, not 32) come from the zero page
-    const unsigned tile_ok = f_next ? (unsigned)next_ok : 1u;
-    const unsigned live = ((f_idx < nstages) & (f_coff + dquad * 4 < cp)) ? tile_ok : 0u;
+    // multiple of 16, not 32) read out of range = zeros
+    const bool tile_ok = f_next ? next_ok != 0 : true;
+    const bool live = (f_idx < nstages) && tile_ok && (f_coff + dquad * 4 < cp);
 #pragma unroll
     for (int k = 0; k < A_SLOTS; ++k) {
-      const unsigned px_ = f_next ? Pn.a_pix[k] : Pc.a_pix[k];
+      const unsigned o0 = f_next ? Pn.a_off0[k] : Pc.a_off0[k], o1 = f_next ? Pn.a_off1[k] : Pc.a_off1[k];
       const unsigned mk = f_next ? Pn.a_mask[k] : Pc.a_mask[k];
-      const unsigned long long real = sbase + (unsigned long long)px_ * row_bytes;
-      const unsigned long long sel = 0ull - (unsigned long long)(live & (mk >> f_tap) & 1u);
-      const unsigned long long g = (real & sel) | (zero_addr & ~sel);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                       (__attribute__((address_space(3))) void*)(buf + min(wave + WAVES * k, A_PIECES - 1) * 256), 16, 0, 0);
+      const bool ok = MODE == 2 ? (live && ((mk >> f_tap) & 1u)) : live;
+      const unsigned vo = ok ? (f_src ? o1 : o0) : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(arsrc, (__attribute__((address_space(3))) void*)(buf + min(wave + WAVES * k, A_PIECES - 1) * 256), 16, vo, 0, 0, 0);
     }
-    const unsigned long long wl = f_next ? Pn.w_lane : Pc.w_lane;
+    const int wn_tile = f_next ? Pn.ntile : Pc.ntile;
 #pragma unroll
     for (int k = 0; k < B_SLOTS; ++k) {
       const int pb = min(wave + WAVES * k, B_PIECES - 1);
-      const unsigned long long g = wl + ((unsigned long long)(min(f_idx, nstages - 1) * B_PIECES + pb) << 10);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                       (__attribute__((address_space(3))) void*)(buf + (A_PIECES + pb) * 256), 16, 0, 0);
+      const int so = ((wn_tile * nstages + min(f_idx, nstages - 1)) * B_PIECES + pb) << 10;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)(buf + (A_PIECES + pb) * 256), 16, (unsigned)lane * 16u, so, 0, 0);
     }
     // advance (integer arithmetic only): taps innermost, then 32-channel slices, then the second source, then the next tile
     f_idx += 1;
