@@ -877,6 +877,7 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
   size_t op_index = 0;
   bool skip_next_gelu = false;
   int pooled_by_conv = -1;  // slot whose 2x2 max pool the producing conv's epilogue already wrote (run-time fusion of an unfused program, see PH_OP_CONV)
+  int fused_head = -1;      // index of a head op the producing conv's epilogue already computed (see PH_OP_CONV)
   for (const PackedOp& op : m->ops) {
     const ph_op_desc& d = op.d;
     if (m->profiling) PH_HIP_CHECK(hipEventRecord(m->ev[op_index], s));
@@ -1043,6 +1044,30 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
           g.persist2 = m->gemm_persist2;
           rc = launch_gemm(g, s);
           break;
+        }
+        if (m->head_fuse && !a.dst_pool && a.coutp == 64 && a.bn == 64 && m->use_dma) {
+          // A 1x1 head that reads this conv's 64-channel output rides in the F(2x2,3x3) kernel's epilogue (the accumulator layout is the
+          // MFMA's B operand: conv3x3_wino2d_kernel); when nothing else reads the tensor (inference plans) it never reaches HBM.
+          for (size_t j = op_index; j < m->ops.size(); ++j) {
+            const ph_op_desc& hx = m->ops[j].d;
+            if (hx.kind != PH_OP_HEAD || hx.src0 != d.dst) continue;
+            if (!(hx.flags & PH_FLAG_SOFTMAX) && hx.cout <= 32 && pad16(hx.cin0) == 64 && out_dev[hx.out_index] && conv3x3_dma_is_wino2d(a)) {
+              a.head_w = m->ops[j].w_dev;
+              a.head_b = m->ops[j].b_dev;
+              a.head_dst = out_dev[hx.out_index];
+              a.head_cout = hx.cout;
+              a.head_wcp = 64;
+              a.head_sigmoid = (hx.flags & PH_FLAG_SIGMOID) ? 1 : 0;
+              fused_head = (int)j;
+              if (plan.reuse) {  // training keeps every activation
+                bool other = false;
+                for (size_t k = 0; k < m->ops.size(); ++k)
+                  if (k != j && (m->ops[k].d.src0 == d.dst || m->ops[k].d.src1 == d.dst)) other = true;
+                if (!other) a.skip_dst = 1;
+              }
+            }
+            break;
+          }
         }
         if (m->pool_peephole && !a.dst_pool && a.relu && m->use_dma && (a.bn == 64 || m->dma32) && op_index < m->ops.size()) {
           // An UNFUSED program (the training forward: the backward walks one op per activation) still gets the conv kernels' fused
@@ -1258,6 +1283,10 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
         break;
       }
       case PH_OP_HEAD: {
+        if (fused_head == (int)op_index - 1) {  // computed by its producer's epilogue
+          fused_head = -1;
+          break;
+        }
         const SlotShape& s0 = plan.slots[d.src0];
         PH_REQUIRE(s0.c == d.cin0, "head channel mismatch");
         PH_REQUIRE(out_dev[d.out_index] != nullptr, "output %d is null", d.out_index);
@@ -1308,6 +1337,7 @@ std::vector<OptionRef> option_table(ph_model* m) {
       {"conv_dma_stagger", &m->dma_stagger, nullptr},   // 0: SIMD-partner waves issue DMA pieces at the same step
       {"fuse_gelu_fwd", &m->fuse_gelu_fwd, nullptr},
       {"fuse_gelu_bwd", &m->fuse_gelu_bwd, nullptr},
+      {"head_fuse", &m->head_fuse, nullptr},            // a 1x1 head on a 64-channel conv output is computed in that conv's F(2x2,3x3) epilogue
       {"pool_peephole", &m->pool_peephole, nullptr},    // unfused programs: a conv whose next op pools its output writes the pooled tensor from its epilogue
       {"mask_fold", &m->mask_fold, nullptr},            // ReLU mask applied by the pool backward that completes a conv output's gradient
       {"wgrad_wino", &m->wgrad_wino, nullptr},          // 3x3 weight gradients: 1 Winograd F(2x2,3x3) domain, 0 direct nine-tap kernel

@@ -30,6 +30,11 @@ struct ConvArgs {
   const float* w16 = nullptr;  // [tap][ci 16][co 16] weights for conv3x3_c16_kernel (16 -> 16 channel layers), or nullptr
   int skip_dst = 0;           // the full-resolution output is never read (inference plan, fused pool): only dst_pool is written (Winograd kernels; others ignore it)
   const float* relu_mask_src = nullptr;  // backward: NHWC tensor shaped like dst (the forward activation this gradient belongs to); the stored value is zeroed where it is <= 0 (conv3x3_w16_kernel only: ask conv3x3_dma_honours_mask)
+  // fused 1x1 head (conv3x3_wino2d_kernel, Cout = one N tile of 64): head_dst[b][o][y][x] = (sigmoid)(sum_c head_w[o][c] * out[y][x][c] + head_b[o]), NCHW fp32
+  const float* head_w = nullptr;  // [head_cout][head_wcp] row-major (the head op's own weight layout), or nullptr = no fused head
+  const float* head_b = nullptr;  // [head_cout]
+  float* head_dst = nullptr;
+  int head_cout = 0, head_wcp = 0, head_sigmoid = 0;
   float* dst_pool = nullptr;  // optional fused 2x2/2 max pool of the (ReLU'd) output, NHWC ceil(H/2) x ceil(W/2); nullptr = off
   // kernel selection, filled from the model handle's options (ph_model_set_option)
   int use_wino = 1;   // 1: Winograd F(2,3) kernel where wpack_wino exists; 2: only for the N-tile-64 layers; 0: direct 9-tap kernel
@@ -136,6 +141,7 @@ int launch_stem_wino2d_pack(const float* w1, float* w2, hipStream_t s);  // [tap
 int launch_conv3x3_dma(const ConvArgs& a, hipStream_t s);
 bool conv3x3_dma_honours_mask(const ConvArgs& a);  // launch_conv3x3_dma would run a kernel that applies relu_mask_src
 bool conv3x3_dma_is_f2x2(const ConvArgs& a);       // launch_conv3x3_dma would run one of the two F(2x2,3x3) kernels
+bool conv3x3_dma_is_wino2d(const ConvArgs& a);     // ... the wave-split one (the only kernel that takes a fused head)
 // wpack [panel][tap 9][bn][16] -> F(2x2,3x3) weights [panel][g 2][xi 4][nu 4][n tile][lh][lx][4] (see conv3x3_wino2d_kernel)
 int launch_wino2d_pack(const float* wpack, float* wino, int panels, int bn, hipStream_t s);
 int64_t wino2d_pack_floats(int panels, int bn);

@@ -1324,10 +1324,13 @@ static int conv3x3_dma_route(const ConvArgs& a) {
 }
 bool conv3x3_dma_honours_mask(const ConvArgs& a) { return conv3x3_dma_route(a) == 1; }
 bool conv3x3_dma_is_f2x2(const ConvArgs& a) { const int r = conv3x3_dma_route(a); return r == 1 || r == 2; }
+bool conv3x3_dma_is_wino2d(const ConvArgs& a) { return conv3x3_dma_route(a) == 2; }
 
 int launch_conv3x3_dma(const ConvArgs& a, hipStream_t s) {
   const int route = conv3x3_dma_route(a);
   PH_REQUIRE(!a.relu_mask_src || route == 1, "relu_mask_src is only applied by conv3x3_w16_kernel (ask conv3x3_dma_honours_mask first)");
+  PH_REQUIRE(!a.head_w || (route == 2 && !a.dst_pool && a.coutp == 64 && a.bn == 64 && a.head_cout >= 1 && a.head_cout <= 32 && a.head_wcp == 64 && a.head_b && a.head_dst),
+             "a fused head needs the F(2x2,3x3) kernel, 64 output channels and at most 32 head channels (ask conv3x3_dma_is_wino2d first)");
   if (route == 1) return launch_conv3x3_w16(a, s);
   if (route == 0) return launch_conv3x3_c16(a, s);
   if (route == 2) return launch_conv3x3_wino2d(a, s);

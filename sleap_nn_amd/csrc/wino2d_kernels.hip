@@ -39,6 +39,7 @@ namespace ph {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int W2_T = 16;                                   // output tile edge
 constexpr int W2_HW = W2_T + 2;                            // halo edge
@@ -312,6 +313,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_kernel(ConvArgs a) {
     b_issue2(1, bbuf + h * W2_BH_FLOATS);
     b_advance();
   }
+  // fused head (see the epilogue): its [32 o][64 c] weight matrix lives in the pool half of the spare (a fused head excludes a fused pool),
+  // 16-byte chunks XOR-swizzled by the row so that the A-fragment reads (lane = o, row pitch 256 B) are conflict-free; rows >= cout are zeros
+  float* const headw = spare + 8 * 256;
+  if (a.head_w) {
+    const int o = tid >> 4, chunk = tid & 15;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (o < a.head_cout) v = *reinterpret_cast<const f32x4*>(a.head_w + (size_t)o * a.head_wcp + chunk * 4);
+    *reinterpret_cast<f32x4*>(headw + (o * 16 + (chunk ^ (o & 15))) * 4) = v;
+  }
   __syncthreads();
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
@@ -517,6 +527,59 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_kernel(ConvArgs a) {
           for (int bb = 0; bb < 2; ++bb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[bb][n][r] = fmaxf(acc[bb][n][r], 0.f);
+      }
+    }
+    if (a.head_w && (xi == 0 || xi == 3)) {
+      // Fused 1x1 head (Cout = this one N tile: the lane pair (lx, lh) holds all 64 channels of its two pixels).  The accumulator layout IS
+      // the B operand of v_mfma_f32_32x32x2_f32 -- lane (n = tile lx, k = lh), register r = channel n * 32 + 8 (r >> 2) + 4 lh + (r & 3) --
+      // so head[o][tile] = sum_c W[o][c] out[c][tile] is 32 MFMAs per output column with A[i = o = lx][k = lh] = W[o][channel(r, lh)]:
+      // four consecutive r are four consecutive channels, one 16-byte LDS read of the head's [o][c] weight rows (staged once per workgroup).
+      // The matrix pipe is idle in the epilogue anyway; the 64-channel tensor need not reach HBM (skip_dst) and the head launch is gone.
+      // (the head accumulators live in acc[2][0 .. 1]: positions 2 and 3 are dead once P is formed, and the next tile's first MFMAs take C = 0)
+      static_assert(NT == 2, "the fused head borrows acc[2][0 .. 1]");
+      f32x16(&hd)[NT] = acc[2];
+#pragma unroll
+      for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) hd[bb][r] = 0.f;
+      int lo = lx;
+      asm volatile("" : "+v"(lo));  // (opaque: the eight read addresses are formed here, not hoisted out of the tile loop and spilled)
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 wq = *reinterpret_cast<const f32x4*>(headw + (lo * 16 + ((n * 8 + 2 * q + lh) ^ (lo & 15))) * 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int bb = 0; bb < 2; ++bb) hd[bb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[e], acc[bb][n][4 * q + e], hd[bb], 0, 0, 0);
+        }
+      const int oy = y0 + 2 * (4 * mh + (lx >> 3)) + arow, ox = x0 + 2 * (lx & 7);
+      if (oy < a.H && ox < a.W) {
+        const bool two = ox + 1 < a.W, pair_ok = (a.W & 1) == 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          int o = (r & 3) + 8 * (r >> 2) + 4 * lh;  // D row of this register
+          asm volatile("" : "+v"(o));                // (opaque: keeps the sixteen output addresses from being hoisted out of the tile loop and spilled)
+          if (o < a.head_cout) {
+            const float hb = a.head_b[o];
+            float v0 = hd[0][r] + hb, v1 = hd[1][r] + hb;
+            if (a.head_sigmoid) {
+              v0 = 1.f / (1.f + expf(-v0));
+              v1 = 1.f / (1.f + expf(-v1));
+            }
+            float* const hp = a.head_dst + (((size_t)b * a.head_cout + o) * a.H + oy) * a.W + ox;
+            if (two && pair_ok) {  // ox is even: with an even W the pixel pair is one aligned 8-byte store
+              f32x2 v;
+              v[0] = v0;
+              v[1] = v1;
+              *reinterpret_cast<f32x2*>(hp) = v;
+            } else {
+              hp[0] = v0;
+              if (two) hp[1] = v1;
+            }
+          }
+        }
       }
     }
     if (a.dst_pool) {  // fused 2x2/2 max pool ("same" padding: zeros beyond the image): wave 0's row maxima hop to wave 3
