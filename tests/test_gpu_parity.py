@@ -1105,3 +1105,47 @@ def test_workspace_reuse_shrinks_the_footprint_and_changes_no_bit():
     full = L.check(L.lib().ph_model_workspace_bytes(big._handle, 32, 1024, 1024))
     print(f"cfg3 x 32 frames workspace: {full / 2**30:.2f} GiB one range per slot, {shared / 2**30:.2f} GiB shared")
     assert shared < 0.5 * full
+
+
+def test_head_fused_into_the_conv_epilogue_matches_the_head_kernel_and_the_oracle():
+    """`head_fuse`: a 1x1 head that reads a 64-channel conv output is computed by that conv's F(2x2,3x3) epilogue (an MFMA on the
+    accumulator registers; the tensor itself is not stored when nothing else reads it).  Same outputs as the stand-alone head kernel
+    (different summation order: 1e-6 of the scale) and within the forward bar of the oracle: bottom-up (confidence maps fused, PAFs on a
+    128-channel tensor not), multi-class bottom-up with BOTH heads on the same 64-channel tensor (the first fused, the sigmoid-free
+    tensor still stored for the second), a sigmoid head, odd batch, and frame widths that cut tiles / break the 8-byte pixel-pair store."""
+    from sleap_nn_amd import _lib as L
+    from sleap_nn_amd.architectures.model import Model
+
+    bb = {"in_channels": 1, "kernel_size": 3, "filters": 16, "filters_rate": 2, "max_stride": 16, "stem_stride": None, "middle_block": True,
+          "up_interpolate": True, "stacks": 1, "convs_per_block": 2, "output_stride": 4}
+    names = ["a", "b", "c", "d", "e"]
+    cases = [
+        ("bottomup", {"confmaps": {"part_names": names, "output_stride": 4}, "pafs": {"edges": [[names[i], names[i + 1]] for i in range(4)], "output_stride": 8}}, (96, 160), 3),
+        ("multi_class_bottomup", {"confmaps": {"part_names": names, "output_stride": 4}, "class_maps": {"classes": ["x", "y", "z"], "output_stride": 4}}, (80, 112), 2),
+        ("multi_class_bottomup*", {"confmaps": {"part_names": names, "output_stride": 2}, "class_maps": {"classes": ["x", "y", "z"], "output_stride": 4}}, (64, 96), 2),  # the SIGMOID head is the fused one
+        ("single_instance", {"confmaps": {"part_names": names[:3], "output_stride": 4}}, (48, 176), 1),
+        ("centroid", {"confmaps": {"anchor_part": None, "output_stride": 4}}, (64, 80), 2),
+    ]
+    for mt, heads, hw, B in cases:
+        bb = dict(bb, output_stride=2 if mt.endswith("*") else 4)
+        mt = mt.rstrip("*")
+        sd = O.init_state(bb, heads, mt, seed=hw[1], head_scale=1.0)
+        g = torch.Generator().manual_seed(hw[0])
+        for k in sd:
+            if k.endswith(".bias"):
+                sd[k] = (torch.rand(sd[k].shape, generator=g) - 0.5) * 0.2
+        img = torch.randint(0, 256, (B, 1, hw[0], hw[1]), dtype=torch.uint8, generator=g)
+        ref = O.model_forward(sd, bb, heads, mt, img)
+        outs = {}
+        for fuse in (1, 0):
+            m = Model("unet", bb, heads, mt)
+            m.load_state_dict(sd)
+            m.set_option("head_fuse", fuse)
+            assert any(o.kind == L.OP_HEAD and o.cin0 == 64 for o in m.ops)  # a head on the 64-channel stride-4 tensor
+            if heads.get("class_maps", {}).get("output_stride") == 4 and heads["confmaps"]["output_stride"] == 2:
+                assert any(o.kind == L.OP_HEAD and o.cin0 == 64 and (o.flags & L.FLAG_SIGMOID) for o in m.ops)
+            outs[fuse] = {k: v.cpu() for k, v in m.to(DEV)(img.to(DEV)).items()}
+        for k, v in ref.items():
+            scale = max(1.0, v.abs().max().item())
+            assert (outs[1][k] - outs[0][k]).abs().max().item() <= 2e-6 * scale, (mt, k)
+            assert (outs[1][k] - v).abs().max().item() <= CMS_ATOL * scale, (mt, k)
