@@ -165,7 +165,139 @@ __global__ __launch_bounds__(256) void dwconv7_kernel(DwConvArgs a) {
   }
 }
 
+// dwconv7 + LayerNorm in one pass (CNBlock's first two ops; the depthwise output never reaches HBM).  A workgroup owns whole pixels:
+// 256 / (Cp / 4) strips of DW_ROWS x DW_STRIP pixels x all channel quads; after the depthwise accumulation (as dwconv7_kernel) the
+// per-pixel moments are reduced through LDS -- 16 lanes per pixel, two passes (mean, then the biased variance about it, pad channels
+// excluded) exactly like layernorm_kernel -- and the normalised, affine-transformed values are stored.
+__global__ __launch_bounds__(256) void dwconv7_ln_kernel(DwConvArgs a) {
+  constexpr int NPIX = DW_ROWS * DW_STRIP;  // pixels per strip block
+  __shared__ float red[16 * 256];           // [local strip][pixel][channel quad]: spb * NPIX * groups <= 16 * 256
+  __shared__ float stat[2 * 16 * 16];       // mean, rstd per (local strip, pixel): spb * NPIX <= 10 * 16
+  const int groups = a.cp >> 2;
+  const int spb = 256 / groups;             // strips per workgroup (>= 1: cp <= 1024)
+  const int strips = (a.W + DW_STRIP - 1) / DW_STRIP;
+  const int sgroups = (strips + spb - 1) / spb;
+  const int rblocks = (a.H + DW_ROWS - 1) / DW_ROWS;
+  const int tid = threadIdx.x;
+  const int ls = tid / groups, gq = tid - ls * groups;
+  int t = blockIdx.x;
+  const int sg = t % sgroups;
+  t /= sgroups;
+  const int rb = t % rblocks;
+  const int b = t / rblocks;
+  const int st = sg * spb + ls;
+  const bool active = ls < spb && st < strips;
+  const int x0 = st * DW_STRIP, y0 = rb * DW_ROWS;
+  f32x4 acc[DW_ROWS][DW_STRIP];
+  {
+    const f32x4 bias = (active && a.bias) ? *reinterpret_cast<const f32x4*>(a.bias + gq * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < DW_ROWS; ++r)
+#pragma unroll
+      for (int o = 0; o < DW_STRIP; ++o) acc[r][o] = bias;
+  }
+  if (active) {
+    const float* wq = a.w + gq * 4;
+#pragma unroll
+    for (int ir = 0; ir < DW_ROWS + 6; ++ir) {
+      const int iy = y0 + ir - 3;
+      if (iy < 0 || iy >= a.H) continue;
+      const float* row = a.src + ((size_t)(b * a.H + iy) * a.W) * a.cp + gq * 4;
+      f32x4 in[DW_STRIP + 6];
+#pragma unroll
+      for (int i = 0; i < DW_STRIP + 6; ++i) {
+        const int ix = x0 + i - 3;
+        const int cx = min(max(ix, 0), a.W - 1);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(row + (size_t)cx * a.cp);
+        const bool ok = ix >= 0 && ix < a.W;
+        in[i][0] = ok ? v[0] : 0.f;
+        in[i][1] = ok ? v[1] : 0.f;
+        in[i][2] = ok ? v[2] : 0.f;
+        in[i][3] = ok ? v[3] : 0.f;
+      }
+#pragma unroll
+      for (int r = 0; r < DW_ROWS; ++r) {
+        const int ky = ir - r;  // this input row is kernel row ky of output row r
+        if (ky < 0 || ky > 6) continue;
+#pragma unroll
+        for (int kx = 0; kx < 7; ++kx) {
+          const f32x4 w = *reinterpret_cast<const f32x4*>(wq + (size_t)(ky * 7 + kx) * a.cp);
+#pragma unroll
+          for (int o = 0; o < DW_STRIP; ++o) acc[r][o] += in[o + kx] * w;
+        }
+      }
+    }
+  }
+  // ---- moments per pixel: item = (local strip, pixel), 16 lanes per item
+  const float inv_c = 1.0f / (float)a.ln_c;
+  const int n_items = spb * NPIX;
+  auto reduce_items = [&](float* out /* stat + 0 or + 256 */, bool second) __attribute__((always_inline)) {
+    for (int item = tid >> 4; item < n_items; item += 16) {
+      const int sub = tid & 15;
+      float s = 0.f;
+      for (int g = sub; g < groups; g += 16) s += red[item * groups + g];
+      s += __shfl_xor(s, 8, 16);
+      s += __shfl_xor(s, 4, 16);
+      s += __shfl_xor(s, 2, 16);
+      s += __shfl_xor(s, 1, 16);
+      if (sub == 0) out[item] = second ? 1.0f / sqrtf(s * inv_c + LN_EPS) : s * inv_c;
+    }
+  };
+  if (active) {
+#pragma unroll
+    for (int r = 0; r < DW_ROWS; ++r)
+#pragma unroll
+      for (int o = 0; o < DW_STRIP; ++o) red[(ls * NPIX + r * DW_STRIP + o) * groups + gq] = (acc[r][o][0] + acc[r][o][1]) + (acc[r][o][2] + acc[r][o][3]);  // pad channels are exact zeros
+  }
+  __syncthreads();
+  reduce_items(stat, false);
+  __syncthreads();
+  if (active) {
+#pragma unroll
+    for (int r = 0; r < DW_ROWS; ++r)
+#pragma unroll
+      for (int o = 0; o < DW_STRIP; ++o) {
+        const float mean = stat[ls * NPIX + r * DW_STRIP + o];
+        float ss = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float d = acc[r][o][e] - mean;
+          ss += (gq * 4 + e < a.ln_c) ? d * d : 0.f;
+        }
+        red[(ls * NPIX + r * DW_STRIP + o) * groups + gq] = ss;
+      }
+  }
+  __syncthreads();
+  reduce_items(stat + 256, true);
+  __syncthreads();
+  if (active) {
+    const f32x4 g = *reinterpret_cast<const f32x4*>(a.ln_gamma + gq * 4), bt = *reinterpret_cast<const f32x4*>(a.ln_beta + gq * 4);
+#pragma unroll
+    for (int r = 0; r < DW_ROWS; ++r) {
+      if (y0 + r >= a.H) continue;
+      float* drow = a.dst + ((size_t)(b * a.H + y0 + r) * a.W) * a.cp + gq * 4;
+#pragma unroll
+      for (int o = 0; o < DW_STRIP; ++o)
+        if (x0 + o < a.W) {
+          const float mean = stat[ls * NPIX + r * DW_STRIP + o], rstd = stat[256 + ls * NPIX + r * DW_STRIP + o];
+          f32x4 y;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) y[e] = (acc[r][o][e] - mean) * rstd * g[e] + bt[e];
+          *reinterpret_cast<f32x4*>(drow + (size_t)(x0 + o) * a.cp) = y;
+        }
+    }
+  }
+}
+
 int launch_dwconv7(const DwConvArgs& a, hipStream_t s) {
+  if (a.ln_gamma) {
+    PH_REQUIRE(a.ln_beta && a.ln_c > 0 && !a.accumulate && a.cp <= 1024, "fused dwconv + LayerNorm: bad arguments");
+    const int groups = a.cp >> 2, spb = 256 / groups, strips = (a.W + DW_STRIP - 1) / DW_STRIP;
+    const size_t blocks = (size_t)a.B * ((a.H + DW_ROWS - 1) / DW_ROWS) * ((strips + spb - 1) / spb);
+    hipLaunchKernelGGL(dwconv7_ln_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
+    PH_HIP_CHECK(hipGetLastError());
+    return PH_OK;
+  }
   const size_t total = (size_t)a.B * ((a.H + DW_ROWS - 1) / DW_ROWS) * ((a.W + DW_STRIP - 1) / DW_STRIP) * (a.cp / 4);
   const int blocks = (int)std::min<size_t>((total + 255) / 256, 256 * 64);
   hipLaunchKernelGGL(dwconv7_kernel, dim3(blocks), dim3(256), 0, s, a);

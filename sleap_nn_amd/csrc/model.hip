@@ -878,6 +878,7 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
   bool skip_next_gelu = false;
   int pooled_by_conv = -1;  // slot whose 2x2 max pool the producing conv's epilogue already wrote (run-time fusion of an unfused program, see PH_OP_CONV)
   int fused_head = -1;      // index of a head op the producing conv's epilogue already computed (see PH_OP_CONV)
+  int fused_ln = -1;        // index of a LayerNorm op the producing depthwise conv already applied (see PH_OP_DWCONV)
   for (const PackedOp& op : m->ops) {
     const ph_op_desc& d = op.d;
     if (m->profiling) PH_HIP_CHECK(hipEventRecord(m->ev[op_index], s));
@@ -1214,10 +1215,30 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
         a.B = batch;
         a.H = s0.h;
         a.W = s0.w;
+        if (m->dw_ln_fuse && plan.reuse && fmt == FMT_F32 && op_index < m->ops.size()) {
+          // CNBlock: the LayerNorm that follows rides in the depthwise kernel (inference plans: nothing else reads the depthwise output)
+          const ph_op_desc& nx = m->ops[op_index].d;
+          if (nx.kind == PH_OP_LAYERNORM && nx.src0 == d.dst && nx.cin0 == d.cout) {
+            bool other = false;
+            for (size_t k = 0; k < m->ops.size(); ++k)
+              if (k != op_index && (m->ops[k].d.src0 == d.dst || m->ops[k].d.src1 == d.dst)) other = true;
+            if (!other) {
+              a.ln_gamma = m->ops[op_index].w_dev;
+              a.ln_beta = m->ops[op_index].b_dev;
+              a.ln_c = d.cout;
+              a.dst = slot_ptr(nx.dst);
+              fused_ln = (int)op_index;
+            }
+          }
+        }
         rc = launch_dwconv7(a, s);
         break;
       }
       case PH_OP_LAYERNORM: {
+        if (fused_ln == (int)op_index - 1) {  // applied by the depthwise conv before it
+          fused_ln = -1;
+          break;
+        }
         const SlotShape& s0 = plan.slots[d.src0];
         PH_REQUIRE(s0.c == d.cin0, "LayerNorm channel mismatch");
         rc = launch_layernorm(slot_ptr(d.src0), op.w_dev, op.b_dev, slot_ptr(d.dst), s0.c, s0.cp, (size_t)batch * s0.h * s0.w, s);
@@ -1337,6 +1358,7 @@ std::vector<OptionRef> option_table(ph_model* m) {
       {"conv_dma_stagger", &m->dma_stagger, nullptr},   // 0: SIMD-partner waves issue DMA pieces at the same step
       {"fuse_gelu_fwd", &m->fuse_gelu_fwd, nullptr},
       {"fuse_gelu_bwd", &m->fuse_gelu_bwd, nullptr},
+      {"dw_ln_fuse", &m->dw_ln_fuse, nullptr},          // ConvNeXt inference: LayerNorm fused into the depthwise 7x7 kernel
       {"head_fuse", &m->head_fuse, nullptr},            // a 1x1 head on a 64-channel conv output is computed in that conv's F(2x2,3x3) epilogue
       {"pool_peephole", &m->pool_peephole, nullptr},    // unfused programs: a conv whose next op pools its output writes the pooled tensor from its epilogue
       {"mask_fold", &m->mask_fold, nullptr},            // ReLU mask applied by the pool backward that completes a conv output's gradient

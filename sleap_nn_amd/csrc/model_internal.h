@@ -127,6 +127,7 @@ struct ph_model {
   int fuse_gelu_fwd = 1;                      // Linear -> GELU op pair: one GEMM whose epilogue writes both tensors (0: two kernels)
   int fuse_gelu_bwd = 1;                      // Linear data gradient multiplies by GELU' in its epilogue (0: separate kernel)
   int wgrad_wino = 1;                         // "wgrad_wino": 3x3 weight gradients in the Winograd F(2x2,3x3) domain (layers with >= 32 padded channels on both sides)
+  int dw_ln_fuse = 1;                         // "dw_ln_fuse"
   int head_fuse = 1;                          // "head_fuse"
   int pool_peephole = 1;                      // "pool_peephole"
   int mask_fold = 1;                          // "mask_fold": max-pool backward applies the ReLU mask of the conv it closes (no separate mask pass there)

@@ -84,6 +84,10 @@ struct DwConvArgs {
   float* dst;
   int cp, B, H, W;
   int accumulate = 0;  // dst += result (data gradient into a slot that already holds the residual branch's gradient)
+  // fused LayerNorm over the channels of the result (CNBlock: dwconv -> LayerNorm; inference plans): dst = LN(dwconv(src)); nullptr = off
+  const float* ln_gamma = nullptr;  // [cp], zero-padded
+  const float* ln_beta = nullptr;   // [cp], zero-padded
+  int ln_c = 0;                     // true channel count (pad channels are excluded from the moments and written as zeros)
 };
 
 struct GemmArgs {
