@@ -81,7 +81,97 @@ __global__ __launch_bounds__(256) void patch_stem_kernel(PatchStemArgs a) {
   }
 }
 
+// The common stem (one input channel, K x K taps, <= 128 padded output channels) without the generic kernel's per-tap global loads,
+// divisions and branches: the normalised image patch of an 8 x 32 output tile goes to LDS once, a thread keeps the K x K weight quads of
+// ITS four output channels in registers, and a pixel's channel quads are the 32 lanes of a half wave -- so an optional LayerNorm2d over
+// the channels (the op that follows the stem conv) is two 5-step shuffles away and the un-normalised tensor never reaches HBM.
+template <int K>
+__global__ __launch_bounds__(256) void patch_stem_c1_kernel(PatchStemArgs a) {
+  constexpr int TOH = 8, TOW = 32;
+  extern __shared__ float sPatch[];  // ((TOH - 1) * stride + K) x ((TOW - 1) * stride + K)
+  const int PH_ = (TOH - 1) * a.stride + K, PW = (TOW - 1) * a.stride + K;
+  const int tid = threadIdx.x, gq = tid & 31, ps = tid >> 5;
+  const int groups = a.coutp >> 2;
+  const bool act = gq < groups;
+  f32x4 wreg[K * K];
+#pragma unroll
+  for (int t = 0; t < K * K; ++t) wreg[t] = act ? *reinterpret_cast<const f32x4*>(a.w + (size_t)t * a.coutp + gq * 4) : f32x4{0.f, 0.f, 0.f, 0.f};  // [tap][ci = 1][Cp]
+  const f32x4 b0 = act ? *reinterpret_cast<const f32x4*>(a.bias + gq * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 g = {0.f, 0.f, 0.f, 0.f}, bt = {0.f, 0.f, 0.f, 0.f};
+  if (a.ln_gamma && act) {
+    g = *reinterpret_cast<const f32x4*>(a.ln_gamma + gq * 4);
+    bt = *reinterpret_cast<const f32x4*>(a.ln_beta + gq * 4);
+  }
+  const float inv_c = a.ln_c > 0 ? 1.0f / (float)a.ln_c : 0.f;
+  const int tiles_x = (a.OW + TOW - 1) / TOW, tiles_y = (a.OH + TOH - 1) / TOH;
+  for (int tile = blockIdx.x; tile < tiles_x * tiles_y * a.B; tile += gridDim.x) {
+    int t = tile;
+    const int tx = t % tiles_x;
+    t /= tiles_x;
+    const int ty = t % tiles_y;
+    const int b = t / tiles_y;
+    const int ox0 = tx * TOW, oy0 = ty * TOH;
+    __syncthreads();  // the previous tile's reads are done
+    for (int i = tid; i < PH_ * PW; i += 256) {
+      const int iy = i / PW, ix = i - iy * PW;
+      const int gy = oy0 * a.stride + iy - 1, gx = ox0 * a.stride + ix - 1;  // padding 1 (convnext.py:73-84)
+      float v = 0.f;
+      if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
+        const size_t o = ((size_t)b * a.H + gy) * a.W + gx;
+        if (a.dtype == 0)
+          v = (float)reinterpret_cast<const uint8_t*>(a.src)[o] / 255.0f;
+        else {
+          v = reinterpret_cast<const float*>(a.src)[o];
+          if (a.dtype == 2) v = v / 255.0f;
+        }
+      }
+      sPatch[i] = v;
+    }
+    __syncthreads();
+    for (int j = 0; j < TOW; ++j) {  // half wave ps walks row ps of the tile
+      const int oy = oy0 + ps, ox = ox0 + j;
+      f32x4 acc = b0;
+#pragma unroll
+      for (int ky = 0; ky < K; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx) acc += sPatch[(ps * a.stride + ky) * PW + j * a.stride + kx] * wreg[ky * K + kx];
+      if (a.ln_gamma) {  // LayerNorm2d over the channels: two-pass moments as layernorm_kernel (pad channels are exact zeros / excluded)
+        float sm = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+#pragma unroll
+        for (int d = 16; d >= 1; d >>= 1) sm += __shfl_xor(sm, d, 32);
+        const float mean = sm * inv_c;
+        float ss = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float dd = acc[e] - mean;
+          ss += (gq * 4 + e < a.ln_c) ? dd * dd : 0.f;
+        }
+#pragma unroll
+        for (int d = 16; d >= 1; d >>= 1) ss += __shfl_xor(ss, d, 32);
+        const float rstd = 1.0f / sqrtf(ss * inv_c + LN_EPS);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = (acc[e] - mean) * rstd * g[e] + bt[e];
+      }
+      if (act && oy < a.OH && ox < a.OW) *reinterpret_cast<f32x4*>(a.dst + (((size_t)b * a.OH + oy) * a.OW + ox) * a.coutp + gq * 4) = acc;
+    }
+  }
+}
+
 int launch_patch_stem(const PatchStemArgs& a, hipStream_t s) {
+  if (a.cin == 1 && a.coutp <= 128 && (a.k == 4 || a.k == 2 || a.k == 3) && a.stride >= 1 && a.stride <= 4) {
+    const int tiles = ((a.OW + 31) / 32) * ((a.OH + 7) / 8) * a.B;
+    const dim3 grid(std::min(tiles, 256 * 8));
+    const size_t lds = (size_t)(7 * a.stride + a.k) * (31 * a.stride + a.k) * sizeof(float);
+    if (a.k == 4)
+      hipLaunchKernelGGL(patch_stem_c1_kernel<4>, grid, dim3(256), lds, s, a);
+    else if (a.k == 3)
+      hipLaunchKernelGGL(patch_stem_c1_kernel<3>, grid, dim3(256), lds, s, a);
+    else
+      hipLaunchKernelGGL(patch_stem_c1_kernel<2>, grid, dim3(256), lds, s, a);
+    PH_HIP_CHECK(hipGetLastError());
+    return PH_OK;
+  }
+  PH_REQUIRE(!a.ln_gamma, "the fused LayerNorm needs the one-channel patch stem kernel");
   const size_t total = (size_t)a.B * a.OH * a.OW * (a.coutp / 4);
   const int blocks = (int)std::min<size_t>((total + 255) / 256, 256 * 32);
   hipLaunchKernelGGL(patch_stem_kernel, dim3(blocks), dim3(256), 0, s, a);

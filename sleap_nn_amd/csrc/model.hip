@@ -1200,6 +1200,22 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
         a.OW = so.w;
         a.k = d.ksize;
         a.stride = d.cmid;
+        if (m->dw_ln_fuse && plan.reuse && fmt == FMT_F32 && op_index < m->ops.size() && a.cin == 1 && a.coutp <= 128 && a.k >= 2 && a.k <= 4 && a.stride >= 1 && a.stride <= 4) {
+          // the stem's LayerNorm2d rides in the patch kernel (inference plans: nothing else reads the un-normalised tensor)
+          const ph_op_desc& nx = m->ops[op_index].d;
+          if (nx.kind == PH_OP_LAYERNORM && nx.src0 == d.dst && nx.cin0 == d.cout) {
+            bool other = false;
+            for (size_t k = 0; k < m->ops.size(); ++k)
+              if (k != op_index && (m->ops[k].d.src0 == d.dst || m->ops[k].d.src1 == d.dst)) other = true;
+            if (!other) {
+              a.ln_gamma = m->ops[op_index].w_dev;
+              a.ln_beta = m->ops[op_index].b_dev;
+              a.ln_c = d.cout;
+              a.dst = slot_ptr(nx.dst);
+              fused_ln = (int)op_index;
+            }
+          }
+        }
         rc = launch_patch_stem(a, s);
         break;
       }

@@ -75,6 +75,10 @@ struct PatchStemArgs {
   const float* bias;
   float* dst;       // NHWC coutp, OH x OW
   int dtype, cin, coutp, B, H, W, OH, OW, k, stride;
+  // fused LayerNorm2d over the channels of the result (the ConvNeXt stem: conv -> LayerNorm2d; inference plans), as DwConvArgs; nullptr = off
+  const float* ln_gamma = nullptr;
+  const float* ln_beta = nullptr;
+  int ln_c = 0;
 };
 
 struct DwConvArgs {
