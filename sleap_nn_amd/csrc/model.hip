@@ -1070,7 +1070,7 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
             break;
           }
         }
-        if (m->pool_peephole && !a.dst_pool && a.relu && m->use_dma && (a.bn == 64 || m->dma32) && op_index < m->ops.size()) {
+        if (m->pool_peephole && !a.dst_pool && !a.head_w && a.relu && m->use_dma && (a.bn == 64 || m->dma32) && op_index < m->ops.size()) {
           // An UNFUSED program (the training forward: the backward walks one op per activation) still gets the conv kernels' fused
           // 2x2 max pool: when the next op is the pool of this conv's output, the epilogue writes both tensors and the pool op is skipped.
           const ph_op_desc& nx = m->ops[op_index].d;
