@@ -611,7 +611,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void gemm_mfma_dma_tile_kernel(G
       unsigned tap_ok;
       if (MODE == 5) {
         const int yy = (int)(a_mask[k] >> 16) + f_ty - (a.ksize >> 1), xx = (int)(a_mask[k] & 0xffffu) + f_tx - (a.ksize >> 1);
-        tap_ok = ((unsigned)yy < (unsigned)a.H) & ((unsigned)xx < (unsigned)a.W) ? 1u : 0u;
+        tap_ok = (((unsigned)yy < (unsigned)a.H) & ((unsigned)xx < (unsigned)a.W)) ? 1u : 0u;
       } else {
         tap_ok = (a_mask[k] >> f_tap) & 1u;
       }

@@ -370,7 +370,6 @@ int launch_conv3x3(const ConvArgs& a, hipStream_t s) {
 constexpr int D_TH = 16, D_HALO_H = D_TH + 2;
 constexpr int D_NPIX = D_HALO_H * HALO_W;            // 612
 constexpr int D_A_PIECES = (D_NPIX + 15) / 16;       // 39
-constexpr int D_A_BYTES = D_A_PIECES * 1024;
 
 template <int BN>
 __global__ __launch_bounds__(512, 2) void conv3x3_mfma_dma_kernel(ConvArgs a) {

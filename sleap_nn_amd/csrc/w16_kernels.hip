@@ -26,7 +26,7 @@ namespace ph {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int V_TW = 16, V_TH = 32;                     // workgroup tile in pixels
-constexpr int V_HW = V_TW + 2, V_HH = V_TH + 2;         // halo 18 x 34
+constexpr int V_HH = V_TH + 2;                           // halo 18 x 34 pixels (V_TW + 2 columns: nine column pairs per parity plane)
 constexpr int V_PLANE_E = V_HH * 9;                     // 306 entries per column-parity plane
 constexpr int V_PLANE_PIECES = (V_PLANE_E + 15) / 16;   // 20 DMA pieces (16 entries x 64 B) per plane
 constexpr int V_PLANE_FLOATS = V_PLANE_PIECES * 256;    // 5120

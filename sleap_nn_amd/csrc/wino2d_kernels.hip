@@ -43,7 +43,6 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int W2_T = 16;                                   // output tile edge
 constexpr int W2_HW = W2_T + 2;                            // halo edge
-constexpr int W2_NPIX = W2_HW * W2_HW;                     // 324 halo pixels
 constexpr int W2_PP_PIECES = (W2_HW * W2_HW / 2 + 63) / 64; // 3 DMA pieces (64 pixels x one 4-channel quad, 1 KiB) per column-parity plane
 constexpr int W2_PP_FLOATS = W2_PP_PIECES * 256;           // 768
 constexpr int W2_PL_PIECES = 2 * W2_PP_PIECES;             // 6 per quad plane: a half-slot is [quad][column parity][hy * 9 + hx / 2][4] --
