@@ -351,7 +351,9 @@ int ph_model_backward(ph_model* m, const void* input_dev, int32_t in_dtype, int3
             w.B = batch;
             w.H = so.h;
             w.W = so.w;
-            if (m->wgrad_wino && w.coutp >= 32)
+            if (m->wgrad_wino && w.cxp == 16 && w.coutp == 16)
+              rc = launch_wgrad16_wino(w, parts[part], d.cout, d.cin0 + d.cin1, offs[part], grads_flat_dev + m->weight_offset[d.weight], s);
+            else if (m->wgrad_wino && w.coutp >= 32)
               rc = launch_wgrad_wino(w, parts[part], d.cout, d.cin0 + d.cin1, offs[part], grads_flat_dev + m->weight_offset[d.weight], s);
             else
               rc = launch_wgrad(w, parts[part], d.cout, d.cin0 + d.cin1, offs[part], grads_flat_dev + m->weight_offset[d.weight], s);

@@ -932,13 +932,13 @@ __global__ __launch_bounds__(1024) void wgrad_wino_reduce_kernel(const float* __
 
 // dg = G^T U' G per (ci, co), U'[xi][nu] = s(xi) s(nu) U[xi][nu] with s(3) = -1 (the loop used +dY where A dY A^T has -dY);
 // grad[(co * cin_total + ci_off + ci) * 9 + ky * 3 + kx].  One thread per (block, ci, co).
-__global__ __launch_bounds__(256) void wgrad_wino_finish_kernel(const float* __restrict__ usum, int n_blocks, int n_co_t, int co_w /* 32 NCO */, int cin, int cout,
+__global__ __launch_bounds__(256) void wgrad_wino_finish_kernel(const float* __restrict__ usum, int n_blocks, int n_co_t, int ci_w /* 32, or 16 */, int co_w /* 32 NCO, or 16 */, int cin, int cout,
                                                                 int cin_total, int ci_off, float* __restrict__ grad) {
-  const int per = 32 * co_w;
+  const int per = ci_w * co_w;
   const int idx = blockIdx.x * 256 + threadIdx.x;
   if (idx >= n_blocks * per) return;
   const int blk = idx / per, e = idx - blk * per;
-  const int ci = (blk / n_co_t) * 32 + e / co_w, co = (blk % n_co_t) * co_w + e % co_w;
+  const int ci = (blk / n_co_t) * ci_w + e / co_w, co = (blk % n_co_t) * co_w + e % co_w;
   if (ci >= cin || co >= cout) return;
   float u[4][4];
 #pragma unroll
@@ -964,6 +964,129 @@ __global__ __launch_bounds__(256) void wgrad_wino_finish_kernel(const float* __r
     g[ky * 3 + 1] = 0.5f * (w[ky][1] - w[ky][2]);
     g[ky * 3 + 2] = h + w[ky][3];
   }
+}
+
+// 16 -> 16 layers (the first encoder block at full resolution): the same Winograd-domain gradient on v_mfma_f32_16x16x4_f32 -- a K step is
+// FOUR tiles (lane quarter lg walks its quarter of a tile row, so consecutive steps are adjacent tiles and share two patch columns),
+// A[i = ci][k = lg], B[k = lg][j = co], four positions (row xi) x one 16 x 16 accumulator per wave.  Pixel tile 4 x 32, whole-row fetch
+// passes through per-frame buffer descriptors as in wgrad_wino_kernel.  Slab [slice][pos 16][ci 16][co 16].
+template <int XI>
+__device__ __forceinline__ void wgw16_tile_steps(const float* __restrict__ sX, const float* __restrict__ sY, int li, int lg, f32x4 (&acc)[4]) {
+  constexpr int TW = 32, HW = TW + 2, Q = TW / 8;  // Q: K steps per tile row (16 tile columns, four per step)
+  constexpr int RA = XI == 0 ? 0 : XI == 2 ? 2 : 1, RB = XI == 0 ? 2 : XI == 1 ? 2 : XI == 2 ? 1 : 3;
+  const float* bx = sX + (2 * Q * lg) * 16 + li;
+  const float* by = sY + (2 * Q * lg) * 16 + li;
+  auto tcol = [&](int tr, int col) __attribute__((always_inline)) {
+    const float da = bx[((2 * tr + RA) * HW + col) * 16], db = bx[((2 * tr + RB) * HW + col) * 16];
+    return XI == 1 ? da + db : da - db;
+  };
+#pragma unroll
+  for (int tr = 0; tr < 2; ++tr) {
+    float t0 = tcol(tr, 0), t1 = tcol(tr, 1);
+#pragma unroll
+    for (int s = 0; s < Q; ++s) {
+      const int c0 = 2 * s;
+      const float t2 = tcol(tr, c0 + 2), t3 = tcol(tr, c0 + 3);
+      const float v[4] = {t0 - t2, t1 + t2, t2 - t1, t1 - t3};
+      t0 = t2, t1 = t3;
+      float r[2];
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const float y0 = XI == 3 ? 0.f : by[((2 * tr) * TW + c0 + b) * 16];
+        const float y1 = XI == 0 ? 0.f : by[((2 * tr + 1) * TW + c0 + b) * 16];
+        r[b] = XI == 0 ? y0 : XI == 1 ? y0 + y1 : XI == 2 ? y0 - y1 : y1;
+      }
+      const float z[4] = {r[0], r[0] + r[1], r[0] - r[1], r[1]};
+#pragma unroll
+      for (int nu = 0; nu < 4; ++nu) acc[nu] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[nu], z[nu], acc[nu], 0, 0, 0);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void wgrad16_wino_kernel(WgradArgs a) {
+  constexpr int TW = 32, TH = 4, HH = TH + 2, HW = TW + 2;
+  __shared__ float sX[HH * HW * 16];
+  __shared__ float sY[TH * TW * 16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int slice = blockIdx.y, n_slices = gridDim.y;
+  const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;
+  const int n_tiles = tiles_x * tiles_y * a.B;
+  f32x4 acc[4];
+#pragma unroll
+  for (int nu = 0; nu < 4; ++nu) acc[nu] = f32x4{0.f, 0.f, 0.f, 0.f};
+  constexpr unsigned OOB = 0xFFFFFF00u;
+  // fetch passes: 256 threads = 64 pixels x 4 quads: X = one halo row (34 columns) per pass, dY = two tile rows (2 x 32 pixels) per pass
+  u32x4 rx[HH], ry[TH / 2];
+  const int q = tid & 3, pc = tid >> 2;  // quad, pixel column of the pass
+  const int yrow = pc >> 5, ycol = pc & 31;
+  const unsigned x_thr = (unsigned)(pc * 16 + q * 4) * 4u, y_thr = (unsigned)((yrow * a.W + ycol) * 16 + q * 4) * 4u;
+  const unsigned frame = (unsigned)(a.H * a.W) * 64u;  // bytes per frame of a 16-channel tensor
+  auto fetch = [&](int tile) __attribute__((always_inline)) {
+    int t = tile;
+    const int tx = t % tiles_x;
+    t /= tiles_x;
+    const int ty = t % tiles_y;
+    const int b = t / tiles_y;
+    const int x0 = tx * TW, y0 = ty * TH;
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x) + (size_t)b * (frame / 4), 0, (int)frame, 0x00020000);
+    const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy) + (size_t)b * (frame / 4), 0, (int)frame, 0x00020000);
+    const int gx = x0 + pc - 1;
+    const bool x_ok = pc < HW && gx >= 0 && gx < a.W;
+#pragma unroll
+    for (int j = 0; j < HH; ++j) {
+      const int gy = y0 + j - 1;
+      const unsigned row = (unsigned)((gy * a.W + x0 - 1) * 16) * 4u;
+      rx[j] = __builtin_amdgcn_raw_buffer_load_b128(xr, (x_ok && gy >= 0 && gy < a.H) ? x_thr + row : OOB, 0, 0);
+    }
+    const bool y_ok = x0 + ycol < a.W;
+#pragma unroll
+    for (int h = 0; h < TH / 2; ++h) {
+      const int gy = y0 + 2 * h + yrow;
+      const unsigned row = (unsigned)(((y0 + 2 * h) * a.W + x0) * 16) * 4u;
+      ry[h] = __builtin_amdgcn_raw_buffer_load_b128(yr, (y_ok && gy < a.H) ? y_thr + row : OOB, 0, 0);
+    }
+  };
+  auto commit = [&]() __attribute__((always_inline)) {
+    if (pc < HW) {
+#pragma unroll
+      for (int j = 0; j < HH; ++j) *reinterpret_cast<u32x4*>(sX + ((j * HW + pc) * 4 + q) * 4) = rx[j];
+    }
+#pragma unroll
+    for (int h = 0; h < TH / 2; ++h) *reinterpret_cast<u32x4*>(sY + (((2 * h + yrow) * TW + ycol) * 4 + q) * 4) = ry[h];
+  };
+  if (slice < n_tiles) fetch(slice);
+  for (int tile = slice; tile < n_tiles; tile += n_slices) {
+    commit();
+    __syncthreads();
+    if (tile + n_slices < n_tiles) fetch(tile + n_slices);
+    switch (wave) {
+      case 0: wgw16_tile_steps<0>(sX, sY, li, lg, acc); break;
+      case 1: wgw16_tile_steps<1>(sX, sY, li, lg, acc); break;
+      case 2: wgw16_tile_steps<2>(sX, sY, li, lg, acc); break;
+      default: wgw16_tile_steps<3>(sX, sY, li, lg, acc); break;
+    }
+    __syncthreads();
+  }
+  // slab[slice][pos = 4 xi + nu][ci 16][co 16];  D: row(ci) = 4 lg + r, col(co) = li
+  float* slab = a.slab + ((size_t)slice * 16 + wave * 4) * 256;
+#pragma unroll
+  for (int nu = 0; nu < 4; ++nu)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) slab[nu * 256 + (4 * lg + r) * 16 + li] = acc[nu][r];
+}
+
+int launch_wgrad16_wino(const WgradArgs& a, int cin_part, int cout, int cin_total, int ci_off, float* grad, hipStream_t s) {
+  PH_REQUIRE(a.cxp == 16 && a.coutp == 16, "wgrad16_wino: 16 padded channels on both sides");
+  PH_REQUIRE((uint64_t)a.H * a.W * 64 < 0xFFFFFF00ull, "wgrad16_wino: a %d x %d frame does not fit a 32-bit buffer descriptor", a.H, a.W);
+  const int n_slices = wgrad_slices(a.B, a.H, a.W, 1);
+  hipLaunchKernelGGL(wgrad16_wino_kernel, dim3(1, n_slices), dim3(256), 0, s, a);
+  const size_t slice_quads = 16 * 256 / 4;  // 1024 quads per slice
+  float* usum = a.slab + (size_t)n_slices * slice_quads * 4;
+  hipLaunchKernelGGL(wgrad_wino_reduce_kernel, dim3((unsigned)(slice_quads / 256)), dim3(1024), 0, s, a.slab, n_slices, slice_quads, usum);
+  hipLaunchKernelGGL(wgrad_wino_finish_kernel, dim3(1), dim3(256), 0, s, usum, 1, 1, 16, 16, cin_part, cout, cin_total, ci_off, grad);
+  PH_HIP_CHECK(hipGetLastError());
+  return PH_OK;
 }
 
 static int wgw_nco(int coutp) { return coutp >= 64 ? 2 : 1; }
@@ -995,7 +1118,7 @@ int launch_wgrad_wino(const WgradArgs& a, int cin_part, int cout, int cin_total,
   float* usum = a.slab + (size_t)n_slices * slice_quads * 4;
   hipLaunchKernelGGL(wgrad_wino_reduce_kernel, dim3((unsigned)(slice_quads / 256)), dim3(1024), 0, s, a.slab, n_slices, slice_quads, usum);
   const int n_el = blocks * 32 * co_w;
-  hipLaunchKernelGGL(wgrad_wino_finish_kernel, dim3((n_el + 255) / 256), dim3(256), 0, s, usum, blocks, n_co_t, co_w, cin_part, cout, cin_total, ci_off, grad);
+  hipLaunchKernelGGL(wgrad_wino_finish_kernel, dim3((n_el + 255) / 256), dim3(256), 0, s, usum, blocks, n_co_t, 32, co_w, cin_part, cout, cin_total, ci_off, grad);
   PH_HIP_CHECK(hipGetLastError());
   return PH_OK;
 }
