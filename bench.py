@@ -605,7 +605,7 @@ def run_train(args, ctx):
     # executed on the matrix pipe per step: forward + data gradient run the Winograd kernels where they exist -- F(2x2,3x3) (4/9 of a
     # 3x3 conv's direct FLOPs) for N tiles of 64 output channels with >= 32 input channels (conv3x3_wino2d_kernel) and for one-source
     # layers with 16 / 32 channels on both sides (conv3x3_w16_kernel), F(2,3) along x (2/3) otherwise -- the 3x3 weight gradients run in
-    # the F(2x2,3x3) domain (4/9) for >= 32 padded output channels (wgrad_wino_kernel); row GEMMs and the rest run direct
+    # the F(2x2,3x3) domain (4/9: wgrad_wino_kernel, wgrad16_wino_kernel); row GEMMs and the rest run direct
     pad16 = lambda c: (c + 15) // 16 * 16
     def share(cin_p, cout_p, one_source=True):
         if cout_p >= 64 and cin_p >= 32:
@@ -622,8 +622,7 @@ def run_train(args, ctx):
         for part in (r["cin0"], r["cin1"]):  # data gradient: one conv per concat source, Cout -> part channels
             if part > 0:
                 executed -= r["flops"] * part / cin * (1.0 - share(pad16(r["cout"]), pad16(part)))
-        if pad16(r["cout"]) >= 32:  # weight gradient
-            executed -= r["flops"] * (1.0 - 4.0 / 9.0)
+        executed -= r["flops"] * (1.0 - 4.0 / 9.0)  # weight gradient: wgrad_wino_kernel / wgrad16_wino_kernel
     per_step = elapsed / args.steps
     return {
         "metric": "frames/sec training step (forward + MSE + backward + gradient all-reduce + Adam)",
