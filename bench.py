@@ -18,17 +18,24 @@ is reported as ``h2d_inclusive`` and is never ``value``.
 Multi-GPU: one process per GPU (torch.distributed / RCCL).  ``python bench.py --gpus N`` without a launcher
 starts the N ranks ITSELF (a child ``python -m torch.distributed.run``, before this process touches the GPU)
 and fails if the job ends up with a different number of ranks.  Frames are sharded across ranks, no data-path
-collective (frames are independent).  ``--scaling weak`` (default): ``--batch`` frames per GPU per step;
-``--scaling strong``: ``--global-batch`` (32 = BASELINE cfg3) frames per step split into contiguous chunks of
-32/G per rank.  value = total frames / max-over-ranks time.
+collective (frames are independent).  At N > 1 the default is ``--scaling strong`` = BASELINE cfg3 as written ("batch=32,
+DP across 8xMI355X"): ``--global-batch`` (32) frames per step split into contiguous chunks of 32/G per
+rank; the weak-scaling figure (``--batch`` = 32 frames per GPU per step) is measured in the same launch and reported beside
+it as ``weak_scaling``.  ``--scaling weak`` makes the weak figure ``value`` (at N = 1 the two coincide).
+value = total frames / max-over-ranks time.
 
 Prints ONE JSON line on rank 0 with the contract fields plus ``roofline`` (dominant kernel = the MFMA conv3x3,
 HIP-event timed inside the timed region), ``step_ms`` (median / p10 / p90 of the per-step GPU time) and, at N=1,
 ``cpu_baseline`` (the oracle on the host cores at 1 and at all threads, with the parity of the HIP path against it
 on the very frames it timed).
 
+The default N = 1 run also carries three short extra legs, each with its own ``roofline`` (executed / direct FLOP
+accounting): ``train_cfg3`` (the cfg3 network's training step, 32 frames), ``train_cfg4`` (BASELINE cfg4: ConvNeXt-tiny
+centered-instance, 64 crops of 384x384, forward + MSE + backward + Adam) and ``infer_cfg4`` (the same network's inference
+forward, 64 crops).  They run after the headline's timed regions and never touch ``value``.
+
 ``--mode train`` times data-parallel training steps (forward + MSE + backward + gradient all-reduce + Adam) of the
-cfg3 UNet or the cfg4 ConvNeXt-tiny (``--train-config``); see run_train().
+cfg3 UNet or the cfg4 ConvNeXt-tiny (``--train-config``) as the headline of the line; see run_train().
 """
 from __future__ import annotations
 
@@ -189,7 +196,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=32, help="frames per GPU per step (weak scaling)")
     ap.add_argument("--global-batch", type=int, default=32, help="frames per step over all GPUs (strong scaling)")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default=None,
+                    help="default: strong at N > 1 (BASELINE cfg3: global batch 32 split over the GPUs; the weak figure rides along as "
+                         "`weak_scaling`), weak at N = 1 (the same thing there)")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the train_cfg3 / train_cfg4 / infer_cfg4 legs of the default N = 1 run")
+    ap.add_argument("--leg-steps", type=int, default=6, help="timed steps of each extra leg")
     ap.add_argument("--mode", choices=["infer", "train"], default="infer")
     ap.add_argument("--train-config", choices=["cfg3", "cfg4"], default="cfg3")
     ap.add_argument("--dtype", choices=["f32", "f16x3", "f16"], default="f32",
@@ -206,6 +217,12 @@ def main():
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         raise SystemExit(self_launch(args.gpus))
+    args.scaling_defaulted = args.scaling is None
+    if args.scaling is None:
+        if args.mode == "train":  # cfg4 IS a global batch of 64 (BASELINE); the cfg3 training leg keeps the reference's DP semantics (per-GPU batch fixed)
+            args.scaling = "strong" if (args.train_config == "cfg4" and args.gpus > 1) else "weak"
+        else:
+            args.scaling = "strong" if args.gpus > 1 else "weak"
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -250,13 +267,19 @@ def run_infer(args, ctx):
     from sleap_nn_amd.inference.streaming import group_scored_batch
     from sleap_nn_amd.parallel import shard_bounds
 
-    if args.scaling == "strong":
-        lo, hi = shard_bounds(args.global_batch, world, rank)  # rank-contiguous chunk of the global batch
-        B, global_batch = hi - lo, args.global_batch
-        if B <= 0:
-            raise SystemExit(f"--global-batch {args.global_batch} leaves rank {rank} of {world} without frames")
-    else:
-        B, global_batch, lo = args.batch, args.batch * world, rank * args.batch
+    def shard(scaling):
+        """(frames of this rank per step, global batch, pinned host frames) for one scaling mode."""
+        if scaling == "strong":
+            lo, hi = shard_bounds(args.global_batch, world, rank)  # rank-contiguous chunk of the global batch
+            if hi - lo <= 0:
+                raise SystemExit(f"--global-batch {args.global_batch} leaves rank {rank} of {world} without frames")
+            g = torch.Generator().manual_seed(4321)
+            allf = torch.randint(0, 256, (max(args.global_batch, 1), 1, 1, SIZE, SIZE), dtype=torch.uint8, generator=g)
+            return hi - lo, args.global_batch, allf[lo:hi].contiguous().pin_memory()
+        g = torch.Generator().manual_seed(4321 + rank)
+        return args.batch, args.batch * world, torch.randint(0, 256, (args.batch, 1, 1, SIZE, SIZE), dtype=torch.uint8, generator=g).pin_memory()
+
+    B, global_batch, host_frames = shard(args.scaling)
     PREC = {"f32": "exact", "f16x3": "split", "f16": "fp16"}
     precision = PREC[args.dtype]
     fp16 = precision != "exact"  # the conv stack runs on the fp16 matrix pipe
@@ -266,13 +289,6 @@ def run_infer(args, ctx):
     backend = HipBackend(model, str(dev), use_graph=use_graph, precision=precision)
     eager = HipBackend(model, str(dev), precision=precision) if use_graph else backend  # same model handle: the profiled steps launch kernel by kernel
     layer = BottomUpLayer(backend, PAFScorer.from_config(CFG3_HEADS), 4, 8, max_stride=32)
-    g = torch.Generator().manual_seed(4321)
-    all_frames = torch.randint(0, 256, (max(global_batch, 1), 1, 1, SIZE, SIZE), dtype=torch.uint8, generator=g) if args.scaling == "strong" else None
-    if all_frames is not None:
-        host_frames = all_frames[lo:lo + B].contiguous().pin_memory()
-    else:
-        g = torch.Generator().manual_seed(4321 + rank)
-        host_frames = torch.randint(0, 256, (B, 1, 1, SIZE, SIZE), dtype=torch.uint8, generator=g).pin_memory()
     frames = host_frames.to(dev)
     cms, pafs = rendered_heads(B, dev)
     info = PreprocInfo(original_size=(SIZE, SIZE), processed_size=(SIZE, SIZE), eff_scale=torch.ones(B), output_stride=4)
@@ -281,13 +297,15 @@ def run_infer(args, ctx):
     params = layer.grouping_params()
     pending, inflight = [], []
 
+    heads_in = {"cms": cms, "pafs": pafs, "info": info}  # rebound for the weak-scaling leg of a multi-GPU run
+
     def step(x, profiled=False):
         """Forward + peaks + PAF scoring + async D2H are enqueued for this batch; then the PREVIOUS batch's
         results (its D2H event fired long ago) are handed to the C++ grouping worker.  The GPU always has the
         next batch queued and the grouping of batch k-1 overlaps the GPU work of batch k
         (Predictor._predict_streaming_pipelined).  Every batch is grouped before the closing barrier."""
         raw = (eager if profiled else backend)(x)  # uint8 frames -> {"MultiInstanceConfmapsHead", "PartAffinityFieldsHead"}
-        inflight.append(layer._enqueue_scoring({"MultiInstanceConfmapsHead": cms, "PartAffinityFieldsHead": pafs}, info))
+        inflight.append(layer._enqueue_scoring({"MultiInstanceConfmapsHead": heads_in["cms"], "PartAffinityFieldsHead": heads_in["pafs"]}, heads_in["info"]))
         if len(inflight) > 1:
             pending.append(pool.submit(group_scored_batch, layer._finish_scoring(inflight.pop(0)), params))
         out = pending.pop(0).result() if len(pending) > 1 else None
@@ -363,6 +381,27 @@ def run_infer(args, ctx):
         barrier()
         elapsed_h2d = time.perf_counter() - t0
 
+    # ---- N > 1, default scaling: `value` above is the strong-scaling figure (BASELINE cfg3: global batch 32 split over the
+    # GPUs); the weak-scaling figure (--batch frames per GPU per step) is measured here, in the same launch
+    elapsed_weak, weak_B = None, None
+    if world > 1 and args.scaling == "strong" and args.scaling_defaulted:
+        weak_B, weak_global, weak_host = shard("weak")
+        wframes = weak_host.to(dev)
+        wcms, wpafs = rendered_heads(weak_B, dev)
+        heads_in.update(cms=wcms, pafs=wpafs, info=PreprocInfo(original_size=(SIZE, SIZE), processed_size=(SIZE, SIZE), eff_scale=torch.ones(weak_B), output_stride=4))
+        for _ in range(max(args.warmup, 2)):
+            step(wframes)
+        drain()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step(wframes)
+        drain()
+        barrier()
+        elapsed_weak = time.perf_counter() - t0
+        heads_in.update(cms=cms, pafs=pafs, info=info)
+        del wframes, wcms, wpafs
+
     # ---- extra legs (N = 1, default run only): the same steps with the convolution stack on the fp16 matrix pipe
     alt = {}
     if world == 1 and precision == "exact" and not args.no_alt_precisions:
@@ -388,10 +427,11 @@ def run_infer(args, ctx):
                        "accumulation (22-bit products; parity tests hold it to the same 1e-4 bar as the exact path); f16_autocast = the reference's autocast mode "
                        "(tolerance 5e-3).  Not part of `value`.")
 
-    t = torch.tensor([elapsed, elapsed_h2d or 0.0], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed, elapsed_h2d or 0.0, elapsed_weak or 0.0], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed, elapsed_h2d = float(t[0].item()), (float(t[1].item()) if elapsed_h2d is not None else None)
+    elapsed_weak = float(t[2].item()) if elapsed_weak is not None else None
     if rank != 0:
         return None
 
@@ -412,26 +452,15 @@ def run_infer(args, ctx):
     # conv3x3_wino_persist_kernel (F(2,3) along x: 2/3) for the rest; the input / output transforms are VALU adds.  `achieved` is
     # what the MFMA pipe EXECUTES in the launches of the dominant kernel over their duration -- the figure a roofline against the
     # MFMA peak is about; the direct-equivalent rate is reported next to it and is NOT a roofline fraction.
-    pad16 = lambda c: (c + 15) // 16 * 16
-    wino = model._options.get("conv_wino", 1.0) != 0.0
-    wino2d = wino and model._options.get("conv_wino2d", 1.0) != 0.0
-    w16 = wino and model._options.get("conv_w16", 1.0) != 0.0
-
-    def conv_kernel(r):
-        if fp16:
-            return "f16", (3.0 if precision == "split" else 1.0)
-        if not wino:
-            return "direct", 1.0
-        if wino2d and pad16(r["cout"]) >= 64 and pad16(r["cin0"]) + (pad16(r["cin1"]) if r["cin1"] else 0) >= 32:
-            return "wino2d", 4.0 / 9.0
-        if w16 and pad16(r["cout"]) == 32 and not r["cin1"] and pad16(r["cin0"]) in (16, 32):
-            return "w16", 4.0 / 9.0
-        return "wino1d", 2.0 / 3.0
-
+    # Which kernel ran each conv launch is read back from the library (ph_model_last_kernels of an eager forward), not re-derived here.
+    eager(frames)
+    kv = model.last_kernels()
+    torch.cuda.synchronize()
+    KSHORT = {L.KV_DIRECT: "direct", L.KV_WINO1D: "wino1d", L.KV_WINO2D: "wino2d", L.KV_W16: "w16", L.KV_C16: "c16", L.KV_ROWGEMM: "rowgemm", L.KV_WINO4: "wino4", L.KV_F16: "f16"}
     by_kernel = {}
-    for r, ms in conv_rows:
-        kname, share = conv_kernel(r)
-        e = by_kernel.setdefault(kname, {"launches": 0, "ms": 0.0, "direct_flops": 0.0, "executed_flops": 0.0, "bytes": 0.0})
+    for (r, ms), code in zip(conv_rows, [c for row, c in zip(table, kv) if row["kind"] == L.OP_CONV]):
+        share = (3.0 if precision == "split" else 1.0) if code == L.KV_F16 else L.KV_MFMA_SHARE[code]
+        e = by_kernel.setdefault(KSHORT[code], {"launches": 0, "ms": 0.0, "direct_flops": 0.0, "executed_flops": 0.0, "bytes": 0.0})
         e["launches"] += 1
         e["ms"] += ms
         e["direct_flops"] += r["flops"]
@@ -444,9 +473,10 @@ def run_infer(args, ctx):
     executed_all = sum(e["executed_flops"] for e in by_kernel.values())
     peak = MFMA_F16_PEAK_TFLOPS if fp16 else MFMA_F32_PEAK_TFLOPS
     KERNEL_NAMES = {"wino2d": "conv3x3_wino2d_kernel<64> (Winograd F(2x2,3x3), 4/9 of the direct MFMA work)",
+                    "wino4": "conv3x3_wino4_kernel (Winograd F(4x4,3x3), 1/4 of the direct MFMA work)",
                     "w16": "conv3x3_w16_kernel<1|2> (wave-private Winograd F(2x2,3x3) on the 16x16x4 MFMA, Cout 32, 4/9 of the direct MFMA work)",
                     "wino1d": "conv3x3_wino_persist_kernel<64|32> (Winograd F(2,3) along x, 2/3 of the direct MFMA work)",
-                    "direct": "conv3x3_mfma_dma_persist_kernel<64|32> (direct)",
+                    "direct": "conv3x3_mfma_dma_persist_kernel<64|32> (direct)", "c16": "conv3x3_c16_kernel (direct)", "rowgemm": "gemm_mfma_dma_kernel<2> (9-tap row GEMM, direct)",
                     "f16": f"conv3x3_f16_persist_kernel<64|32, {3 if precision == 'split' else 1}> (direct, fp16 matrix pipe)"}
     # HBM traffic of the conv launches: measured with rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction, WRITE_SIZE;
     # tools/summarize_pmc.py) on this same command and committed under profiles/; bench.py itself cannot read PMCs, so it
@@ -508,6 +538,10 @@ def run_infer(args, ctx):
             "profiled_forwards": n_fw,
         },
     }
+    if elapsed_weak is not None:
+        res["weak_scaling"] = {"value": weak_B * world * args.steps / elapsed_weak, "unit": "frames/s", "ms_per_step": 1e3 * elapsed_weak / args.steps,
+                               "frames_per_gpu_per_step": weak_B, "global_batch": weak_B * world,
+                               "note": "same launch, --batch frames per GPU per step (per-GPU work fixed as N grows); `value` above is the strong-scaling figure"}
     if alt:
         res["alt_precisions"] = alt
     if elapsed_h2d is not None:
@@ -515,38 +549,52 @@ def run_infer(args, ctx):
                                 "note": "same steps, uint8 frames start in pinned host memory; async H2D on a copy stream, double-buffered under the previous step"}
     if world == 1 and not args.no_cpu_baseline and not fp16:
         res["cpu_baseline"] = cpu_baseline(model, layer, cms, pafs, dev)
+    if world == 1 and not fp16 and not args.no_extra_legs and args.scaling_defaulted:
+        del backend, eager, layer, model, frames, cms, pafs
+        heads_in.clear()
+        res.update(extra_legs(args, ctx))
     return res
 
 
-def run_train(args, ctx):
-    """Data-parallel training steps: forward (unfused fp32 program) + per-head MSE + backward + two-bucket gradient all-reduce
-    (RCCL, overlapped with the backward) + Adam + re-pack of the kernel weights.  ``--train-config cfg3``: the bottom-up UNet
-    at 1024x1024 (``--batch`` frames per GPU, weak; or ``--global-batch`` split, strong); ``cfg4``: BASELINE cfg4, ConvNeXt-tiny
-    centered-instance on 384x384 crops, global batch 64 split over the ranks (``--scaling strong`` semantics by definition of
-    cfg4; ``--scaling weak`` gives every rank 64 crops)."""
+def _pad16(c):
+    return (c + 15) // 16 * 16
+
+
+def _matrix_rows(table):
+    from sleap_nn_amd import _lib as L
+
+    return [r for r in table if r["kind"] in (L.OP_CONV, L.OP_INPUT_CONV, L.OP_LINEAR, L.OP_PATCH_CONV, L.OP_PATCH_STEM)]
+
+
+def forward_executed_flops(table, codes):
+    """FLOPs the matrix cores execute in one forward, priced per launch by the kernel family the library reports it ran
+    (ph_model_last_kernels): direct kernels and row GEMMs the direct count, F(2,3) 2/3, F(2x2,3x3) 4/9, F(4x4,3x3) 1/4.
+    First convs on the VALU (input conv, patch stem) and the fused stem's VALU conv are not matrix work."""
+    from sleap_nn_amd import _lib as L
+
+    ex = 0.0
+    for r, code in zip(table, codes):
+        if r["kind"] == L.OP_STEM:
+            ex += r["mfma_flops"] * L.KV_MFMA_SHARE[L.KV_STEM]
+        elif r["kind"] in (L.OP_CONV, L.OP_LINEAR, L.OP_PATCH_CONV):
+            ex += r["flops"] * L.KV_MFMA_SHARE.get(code, 1.0)
+    return ex
+
+
+def train_leg(cfg, B, global_batch, steps, warmup, ctx, scaling="weak"):
+    """Data-parallel training steps of one configuration: forward (unfused fp32 program) + per-head MSE + backward + two-bucket
+    gradient all-reduce (RCCL, overlapped with the backward; nothing to reduce at N = 1) + Adam + re-pack of the kernel weights.
+    ``cfg`` "cfg3": the bottom-up UNet at 1024x1024; "cfg4": BASELINE cfg4, ConvNeXt-tiny centered-instance on 384x384 crops.
+    Returns the leg's dict on rank 0 (None elsewhere); also used as the headline of ``--mode train``."""
     rank, world, dev, dist = ctx["rank"], ctx["world"], ctx["dev"], ctx["dist"]
     from sleap_nn_amd import _lib as L
     from sleap_nn_amd.architectures.model import Model
     from sleap_nn_amd.data.targets import generate_multiconfmaps, generate_pafs
-    from sleap_nn_amd.parallel import shard_bounds
     from sleap_nn_amd.training.module import TrainingModule
 
-    cfg4 = args.train_config == "cfg4"
+    cfg4 = cfg == "cfg4"
     size = 384 if cfg4 else SIZE
-    if cfg4:
-        gb = 64
-        B = gb if args.scaling == "weak" else shard_bounds(gb, world, rank)[1] - shard_bounds(gb, world, rank)[0]
-        global_batch = gb * world if args.scaling == "weak" else gb
-        model = Model("convnext", CFG4_BB, CFG4_HEADS, "centered_instance")
-    else:
-        if args.scaling == "strong":
-            lo, hi = shard_bounds(args.global_batch, world, rank)
-            B, global_batch = hi - lo, args.global_batch
-        else:
-            B, global_batch = args.batch, args.batch * world
-        model = Model("unet", CFG3_BB, CFG3_HEADS, "bottomup")
-    if B <= 0:
-        raise SystemExit(f"rank {rank} of {world} has no samples")
+    model = Model("convnext", CFG4_BB, CFG4_HEADS, "centered_instance") if cfg4 else Model("unet", CFG3_BB, CFG3_HEADS, "bottomup")
     model.init_xavier_(seed=1234, head_scale=0.05)
     tm = TrainingModule(model, str(dev), lr=1e-4)
     g = torch.Generator().manual_seed(4321 + rank)
@@ -565,18 +613,19 @@ def run_train(args, ctx):
         torch.cuda.synchronize()
 
     losses = []
-    for _ in range(max(args.warmup, 2)):
+    for _ in range(max(warmup, 2)):
         losses.append(tm.training_step(batch).clone())
+    codes = model.last_kernels()  # kernels of the training program's forward (the unfused program)
     barrier()
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     t0 = time.perf_counter()
     marks[0].record()
-    for i in range(args.steps):
+    for i in range(steps):
         losses.append(tm.training_step(batch).clone())
         marks[i + 1].record()
     barrier()
     elapsed = time.perf_counter() - t0
-    step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
+    step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)]
     first, last = float(losses[0][0]), float(losses[-1][0])
     assert np.isfinite(last) and last <= first, f"training loss did not go down: {first} -> {last}"
     # the gradient exchange alone (both buckets, nothing to overlap with), for scale
@@ -596,52 +645,162 @@ def run_train(args, ctx):
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
-    if rank != 0:
-        return None
+    arena_mb, split = tm.grads.numel() * 4 / 1e6, tm._bucket_split
+    n_params = model.num_parameters()
     table = model.op_table(B, size, size)
-    mm = [r for r in table if r["kind"] in (L.OP_CONV, L.OP_INPUT_CONV, L.OP_LINEAR, L.OP_PATCH_CONV, L.OP_PATCH_STEM)]
-    fwd_flops = sum(r["flops"] for r in mm)
-    conv3 = sum(r["flops"] for r in table if r["kind"] == L.OP_CONV)
-    # executed on the matrix pipe per step: forward + data gradient run the Winograd kernels where they exist -- F(2x2,3x3) (4/9 of a
-    # 3x3 conv's direct FLOPs) for N tiles of 64 output channels with >= 32 input channels (conv3x3_wino2d_kernel) and for one-source
-    # layers with 16 / 32 channels on both sides (conv3x3_w16_kernel), F(2,3) along x (2/3) otherwise -- the 3x3 weight gradients run in
-    # the F(2x2,3x3) domain (4/9: wgrad_wino_kernel, wgrad16_wino_kernel); row GEMMs and the rest run direct
-    pad16 = lambda c: (c + 15) // 16 * 16
+    tm.close()
+    del tm, batch, targets, frames
+    if rank != 0:
+        return None, model
+    fwd_flops = sum(r["flops"] for r in _matrix_rows(table))
+    # Executed on the matrix pipe per step.  Forward: per launch by the kernel the library reports (ph_model_last_kernels).  Backward:
+    # the data gradient of a 3x3 conv is the same kernel family on swapped channel counts (one conv per concat source) -- F(2x2,3x3)
+    # (4/9) for N tiles of 64 output channels with >= 32 input channels (conv3x3_wino2d_kernel) and for one-source layers with 16 / 32
+    # channels on both sides (conv3x3_w16_kernel), F(2,3) along x (2/3) otherwise -- and every 3x3 weight gradient runs in the
+    # F(2x2,3x3) domain (4/9: wgrad_wino_kernel, wgrad16_wino_kernel); row GEMMs (Linear, 2x2/s2 convs) run direct in all three.
     def share(cin_p, cout_p, one_source=True):
         if cout_p >= 64 and cin_p >= 32:
             return 4.0 / 9.0
         if one_source and cout_p in (16, 32) and cin_p in (16, 32):
             return 4.0 / 9.0
         return 2.0 / 3.0
-    executed = 3.0 * fwd_flops
+    executed = forward_executed_flops(table, codes)
     for r in table:
-        if r["kind"] != L.OP_CONV or r.get("ksize", 3) != 3:
-            continue
-        cin = r["cin0"] + r["cin1"]
-        executed -= r["flops"] * (1.0 - share(pad16(r["cin0"]) + (pad16(r["cin1"]) if r["cin1"] else 0), pad16(r["cout"]), not r["cin1"]))  # forward
-        for part in (r["cin0"], r["cin1"]):  # data gradient: one conv per concat source, Cout -> part channels
-            if part > 0:
-                executed -= r["flops"] * part / cin * (1.0 - share(pad16(r["cout"]), pad16(part)))
-        executed -= r["flops"] * (1.0 - 4.0 / 9.0)  # weight gradient: wgrad_wino_kernel / wgrad16_wino_kernel
-    per_step = elapsed / args.steps
-    return {
+        if r["kind"] in (L.OP_LINEAR, L.OP_PATCH_CONV):
+            executed += 2.0 * r["flops"]
+        elif r["kind"] == L.OP_CONV and r.get("ksize", 3) == 3:
+            cin = r["cin0"] + r["cin1"]
+            for part in (r["cin0"], r["cin1"]):  # data gradient: one conv per concat source, Cout -> part channels
+                if part > 0:
+                    executed += r["flops"] * part / cin * share(_pad16(r["cout"]), _pad16(part))
+            executed += r["flops"] * 4.0 / 9.0  # weight gradient
+        elif r["kind"] in (L.OP_INPUT_CONV, L.OP_PATCH_STEM):
+            executed += r["flops"]  # weight gradient only (no data gradient into the image)
+    per_step = elapsed / steps
+    res = {
         "metric": "frames/sec training step (forward + MSE + backward + gradient all-reduce + Adam)",
-        "value": global_batch * args.steps / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": 1e3 * per_step, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "value": global_batch * steps / elapsed, "unit": "frames/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": 1e3 * per_step, "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": ("cfg4: ConvNeXt-tiny centered-instance, 384x384 crops, 13 nodes, output stride 2, global batch 64" if cfg4 else
                                 "cfg3 network in training: bottom-up UNet f16/r2/max_stride32/output_stride4, 1024x1024x1 frames, 13 nodes / 12 edges"),
                    "samples_per_gpu_per_step": B, "global_batch": global_batch, "parallelism": f"dp{world}: replicas, disjoint shards, two-bucket RCCL all-reduce overlapped with the backward",
-                   "params": model.num_parameters(), "optimizer": "Adam lr 1e-4", "targets": "rendered on the device by ph_render_confmaps / ph_render_pafs"},
+                   "params": n_params, "optimizer": "Adam lr 1e-4", "targets": "rendered on the device by ph_render_confmaps / ph_render_pafs"},
         "step_ms": percentiles(step_ms),
         "loss_first_last": [first, last],
-        "allreduce": {"arena_mb": tm.grads.numel() * 4 / 1e6, "bucket_split": tm._bucket_split, "standalone_ms": ar_ms,
+        "allreduce": {"arena_mb": arena_mb, "bucket_split": split, "standalone_ms": ar_ms,
                       "note": "standalone_ms = both buckets back to back with nothing to overlap (null at N = 1); in a step the tail bucket runs under the encoder's backward"},
         "roofline": {"bound": "mfma", "kernel": "forward + data-gradient convolutions and 3x3 weight gradients (Winograd F(2x2,3x3) / F(2,3) kernels) and row GEMMs, on v_mfma_f32_32x32x2_f32 / 16x16x4_f32",
                      "achieved": executed / per_step / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": executed / per_step / 1e12 / MFMA_F32_PEAK_TFLOPS,
-                     "flop_accounting": "whole step time in the denominator (loss, masks, pools, Adam, re-pack included); executed FLOPs = 3 x forward matrix FLOPs with the forward / data-gradient / weight-gradient Winograd layers at 4/9 (F(2x2,3x3)) or 2/3 (F(2,3)); direct_equivalent_tflops = 3 x forward matrix FLOPs / step time, a throughput figure",
+                     "flop_accounting": "whole step time in the denominator (loss, masks, pools, LayerNorm / GELU / depthwise, Adam, re-pack included); executed FLOPs = forward launches priced by the kernel family the library reports (ph_model_last_kernels) + data gradients of the same families + 3x3 weight gradients at 4/9 (Winograd domain) + row-GEMM gradients direct; direct_equivalent_tflops = 3 x forward matrix FLOPs / step time, a throughput figure, not a roofline fraction",
+                     "executed_gflop_per_step": executed / 1e9,
                      "direct_equivalent_tflops": 3.0 * fwd_flops / per_step / 1e12,
                      "forward_matrix_gflop_per_step": fwd_flops / 1e9},
     }
+    return res, model
+
+
+def infer_cfg4_leg(model, B, steps, warmup, dev):
+    """Inference forward of the cfg4 network (ConvNeXt-tiny centered-instance, 384x384 crops, output stride 2) on B crops: the
+    fused inference program (LayerNorms inside the depthwise / stem kernels), kernel by kernel, per-op HIP events on every step."""
+    from sleap_nn_amd import _lib as L
+
+    size = 384
+    model.bind_live_params(None)
+    model.eval().to(dev)
+    g = torch.Generator().manual_seed(4321)
+    crops = torch.randint(0, 256, (B, 1, size, size), dtype=torch.uint8, generator=g).to(dev)
+    for _ in range(max(warmup, 2)):
+        out = model(crops)
+    codes = model.last_kernels()
+    torch.cuda.synchronize()
+    assert all(torch.isfinite(v).all() for v in out.values())
+    model.set_profiling(True)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    t0 = time.perf_counter()
+    marks[0].record()
+    for i in range(steps):
+        model(crops)
+        marks[i + 1].record()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    op_ms, n_fw = model.read_profile()
+    model.set_profiling(False)
+    step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)]
+    table = model.op_table(B, size, size)
+    mm = _matrix_rows(table)
+    fwd_flops = sum(r["flops"] for r in mm)
+    executed = forward_executed_flops(table, codes)
+    per_step = elapsed / steps
+    groups = {}
+    NAMES = {L.OP_CONV: "conv3x3", L.OP_LINEAR: "linear (CNBlock MLP)", L.OP_PATCH_CONV: "conv2x2/s2", L.OP_PATCH_STEM: "patch stem (+LayerNorm2d)", L.OP_DWCONV: "depthwise 7x7 (+LayerNorm)",
+             L.OP_LAYERNORM: "layernorm", L.OP_UPSAMPLE: "bilinear x2", L.OP_POOL: "pool", L.OP_HEAD: "head"}
+    for r, ms, code in zip(table, op_ms, codes):
+        e = groups.setdefault(NAMES.get(r["kind"], str(r["kind"])), {"launches": 0, "ms": 0.0, "direct_gflop": 0.0, "executed_gflop": 0.0})
+        e["launches"] += 1 if ms > 0 else 0
+        e["ms"] += ms / max(n_fw, 1)
+        if r["kind"] in (L.OP_CONV, L.OP_LINEAR, L.OP_PATCH_CONV):
+            e["direct_gflop"] += r["flops"] / 1e9
+            e["executed_gflop"] += r["flops"] * L.KV_MFMA_SHARE.get(code, 1.0) / 1e9
+    for e in groups.values():
+        e["executed_tflops"] = e["executed_gflop"] / e["ms"] if e["ms"] > 0 else 0.0
+    matrix_ms = sum(e["ms"] for e in groups.values() if e["executed_gflop"] > 0)
+    return {
+        "metric": "crops/sec ConvNeXt-tiny centered-instance inference forward", "value": B * steps / elapsed, "unit": "crops/s", "steps": steps, "ms_per_step": 1e3 * per_step,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "cfg4 network at inference: ConvNeXt-tiny centered-instance, 384x384x1 uint8 crops, 13 nodes, output stride 2", "crops_per_step": B,
+                   "params": model.num_parameters(), "forward_launch": "kernel by kernel (per-op HIP events on every step)"},
+        "step_ms": percentiles(step_ms),
+        "roofline": {"bound": "mfma", "kernel": "row GEMMs (CNBlock MLPs, 2x2/s2 convs: gemm_mfma_dma_kernel) + decoder / middle 3x3 convs (F(2x2,3x3) and 9-tap row-GEMM forms), v_mfma_f32_32x32x2_f32",
+                     "achieved": executed / (matrix_ms * 1e-3) / 1e12 if matrix_ms > 0 else 0.0, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": executed / (matrix_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS if matrix_ms > 0 else 0.0,
+                     "flop_accounting": "achieved = FLOPs the MFMA pipe executes in the matrix launches (3x3 convs priced by the kernel family the library reports, row GEMMs direct) / their summed duration (HIP events, every step); whole_forward_frac divides by the whole forward (depthwise, LayerNorm, bilinear, head included)",
+                     "whole_forward_frac": executed / per_step / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                     "direct_equivalent_tflops": fwd_flops / per_step / 1e12, "executed_gflop_per_forward": executed / 1e9, "direct_gflop_per_forward": fwd_flops / 1e9,
+                     "matrix_ms_per_forward": matrix_ms, "forward_ms": sum(op_ms) / max(n_fw, 1), "by_op_kind": groups},
+    }
+
+
+def extra_legs(args, ctx):
+    """train_cfg3 / train_cfg4 / infer_cfg4 of the default N = 1 line (driver-timed training and ConvNeXt numbers)."""
+    dev = ctx["dev"]
+    out = {}
+    torch.cuda.empty_cache()
+    res, model = train_leg("cfg3", 32, 32, args.leg_steps, 2, ctx)
+    out["train_cfg3"] = res
+    del model
+    torch.cuda.empty_cache()
+    res, model = train_leg("cfg4", 64, 64, args.leg_steps, 2, ctx)
+    out["train_cfg4"] = res
+    torch.cuda.empty_cache()
+    out["infer_cfg4"] = infer_cfg4_leg(model, 64, max(args.leg_steps, 8), 2, dev)
+    del model
+    torch.cuda.empty_cache()
+    for leg in out.values():  # the legs share the headline's launch: drop what only a stand-alone line needs
+        for k in ("n_gpus", "warmup", "higher_is_better", "scaling", "vs_baseline"):
+            leg.pop(k, None)
+    return out
+
+
+def run_train(args, ctx):
+    """``--mode train``: the training step as the headline.  ``--train-config cfg3``: ``--batch`` frames per GPU (weak) or
+    ``--global-batch`` split (strong); ``cfg4``: global batch 64 split over the ranks (strong, by definition of BASELINE cfg4;
+    ``--scaling weak`` gives every rank 64 crops)."""
+    rank, world = ctx["rank"], ctx["world"]
+    from sleap_nn_amd.parallel import shard_bounds
+
+    if args.train_config == "cfg4":
+        gb = 64
+        B = gb if args.scaling == "weak" else shard_bounds(gb, world, rank)[1] - shard_bounds(gb, world, rank)[0]
+        global_batch = gb * world if args.scaling == "weak" else gb
+    elif args.scaling == "strong":
+        lo, hi = shard_bounds(args.global_batch, world, rank)
+        B, global_batch = hi - lo, args.global_batch
+    else:
+        B, global_batch = args.batch, args.batch * world
+    if B <= 0:
+        raise SystemExit(f"rank {rank} of {world} has no samples")
+    res, _ = train_leg(args.train_config, B, global_batch, args.steps, args.warmup, ctx, args.scaling)
+    return res
 
 
 if __name__ == "__main__":

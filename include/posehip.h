@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define PH_VERSION 101
+#define PH_VERSION 102
 
 /* error codes */
 #define PH_OK 0
@@ -227,6 +227,22 @@ int ph_model_get_option(const ph_model* m, const char* key, double* value);
 int ph_model_set_profiling(ph_model* m, int32_t enabled);
 int ph_model_profile_read(ph_model* m, double* op_ms, int32_t n_ops, int32_t* n_forwards);
 
+/* Which kernel family each op of the LAST ph_model_forward ran (codes[i] for op i, PH_KV_*; 0 for ops that are not matrix
+ * work or were folded into their producer).  bench.py prices a launch's executed MFMA FLOPs from this instead of restating
+ * the dispatch rules: direct kernels execute the direct-convolution count 2*Cin*Cout*k*k*H*W, Winograd F(2,3) 2/3 of it,
+ * F(2x2,3x3) 4/9, F(4x4,3x3) 1/4. */
+#define PH_KV_NONE 0
+#define PH_KV_DIRECT 1    /* 9-tap halo kernels on v_mfma_f32_32x32x2_f32 (conv3x3_mfma_*), conv3x3_c16 excluded */
+#define PH_KV_WINO1D 2    /* conv3x3_wino_persist_kernel: Winograd F(2,3) along x                                */
+#define PH_KV_WINO2D 3    /* conv3x3_wino2d_kernel: wave-split Winograd F(2x2,3x3)                               */
+#define PH_KV_W16 4       /* conv3x3_w16_kernel: wave-private Winograd F(2x2,3x3) on v_mfma_f32_16x16x4_f32      */
+#define PH_KV_C16 5       /* conv3x3_c16_kernel (16 -> 16 channels, direct)                                      */
+#define PH_KV_ROWGEMM 6   /* gemm_mfma_dma_*_kernel (row GEMM: Linear, 2x2/s2, k x k taps, transposed-conv phases) */
+#define PH_KV_WINO4 7     /* conv3x3_wino4_kernel: Winograd F(4x4,3x3)                                           */
+#define PH_KV_F16 8       /* conv3x3_f16_persist_kernel (fp16 matrix pipe; split precision = 3 MFMAs per product) */
+#define PH_KV_STEM 9      /* stem_fused_kernel (second conv on v_mfma_f32_16x16x4_f32; "stem_wino" picks its form) */
+int ph_model_last_kernels(const ph_model* m, int32_t* codes, int32_t n_ops);
+
 /* Diagnostic: when buf_dev != NULL every conv3x3 workgroup writes {delta s_memtime, delta
  * s_memrealtime} (2 x uint64 per workgroup, indexed by linear block id; the buffer must hold
  * the largest conv grid) so the shader clock under load can be read as
@@ -249,11 +265,13 @@ int ph_model_read_slot(ph_model* m, int32_t slot, float* out_dev, int64_t out_nu
  *   out_count: device int32[2 + 2B]: [0] = total peaks found (may exceed cap: then only the
  *   first cap rows are valid and the caller should retry), [1+b] = peaks of sample b,
  *   [1+B+b] = exclusive offset of sample b (b = 0..B, last entry = total).
+ * xy_scale: out_xy = refined (x, y) * xy_scale in one fp32 multiply -- 1 for find_local_peaks itself, the confidence
+ *   maps' output stride for callers that go on in image coordinates (`peaks * cms_output_stride`, layers/bottomup.py:111).
  * scratch_dev: >= 4*(B*H + 1 + B) bytes. */
 int ph_local_peaks(const float* cms_dev, int32_t B, int32_t C, int32_t H, int32_t W,
                    float threshold, int32_t refine, int32_t patch, float* out_xy, float* out_val,
                    int32_t* out_sample, int32_t* out_channel, int32_t* out_count, int32_t cap,
-                   void* scratch_dev, int64_t scratch_bytes, void* stream);
+                   float xy_scale, void* scratch_dev, int64_t scratch_bytes, void* stream);
 
 /* Global peak per (sample, channel): value = max; x = first column containing the max,
  * y = first row containing the max (independent, as the reference); below `threshold`

@@ -446,6 +446,14 @@ class Model:
         L.check(L.lib().ph_model_profile_read(self._handle, arr, n, C.byref(k)))
         return list(arr), k.value
 
+    def last_kernels(self):
+        """PH_KV_* code (``_lib.KV_*``) of the kernel family each op of the LAST forward ran; the library's own record of
+        its dispatch (``ph_model_last_kernels``), so FLOP accounting never restates the dispatch rules."""
+        n = len(self.ops)
+        arr = (C.c_int32 * n)()
+        L.check(L.lib().ph_model_last_kernels(self._handle, arr, n))
+        return list(arr)
+
     def op_table(self, batch: int, height: int, width: int):
         """Per op: label, kind, algorithmic FLOPs (2*Cin*Cout*k*k*Hout*Wout*B for convolutions, SURVEY
         section 8d) and algorithmic HBM bytes (input read once + output written once, logical channels)."""

@@ -30,6 +30,10 @@ void set_error(const char* fmt, ...);
     }                                \
   } while (0)
 
+// Compute units of the CURRENT device (persistent kernels launch one workgroup per CU).  Cached per device index, so a process
+// that drives two different devices gets each one's own count.
+int device_cu_count(int* out);
+
 static inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 static inline int pad16(int c) { return (c + 15) / 16 * 16; }
 

@@ -1223,11 +1223,10 @@ int launch_gemm_variant(int variant, const GemmArgs& a_in, hipStream_t s) {
   PH_REQUIRE(a.mode != 1 || (a.H >= 2 && a.W >= 2), "launch_gemm: 2x2 patches need H, W >= 2");
   PH_REQUIRE(a.mode != 2 || a.M % (a.H * a.W) == 0, "launch_gemm: conv rows must be whole images");
   PH_REQUIRE(gemm_variant_bn(variant) == a.bn, "launch_gemm: variant %d does not match the N tile %d of the packed weights", variant, a.bn);
-  static int n_cu = 0;  // persistent workgroups: one per CU (every variant needs more than half of the LDS)
-  if (!n_cu) {
-    int dev = 0;
-    PH_HIP_CHECK(hipGetDevice(&dev));
-    PH_HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+  int n_cu = 0;  // persistent workgroups: one per CU of the current device
+  {
+    const int rc_cu = device_cu_count(&n_cu);
+    if (rc_cu != PH_OK) return rc_cu;
   }
   switch (variant) {
 #define X(id, MT, NTW, WM, WN, S, W)                                                                                           \

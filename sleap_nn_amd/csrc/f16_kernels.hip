@@ -419,11 +419,10 @@ int launch_conv3x3_f16(const ConvF16Args& a, hipStream_t s) {
   PH_REQUIRE(a.prec == 1 || a.prec == 3, "conv3x3_f16: precision must be 1 (fp16) or 3 (split fp16)");
   PH_REQUIRE(a.bn == 32 || a.bn == 64, "conv3x3_f16: N tile must be 32 or 64");
   PH_REQUIRE(a.chunks0 > 0 && (a.chunks1 == 0 || a.src1), "conv3x3_f16: bad sources");
-  static int n_cu = 0;  // a device property, not a tunable
-  if (!n_cu) {
-    int dev = 0;
-    PH_HIP_CHECK(hipGetDevice(&dev));
-    PH_HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+  int n_cu = 0;  // persistent workgroups: one per CU of the current device
+  {
+    const int rc_cu = device_cu_count(&n_cu);
+    if (rc_cu != PH_OK) return rc_cu;
   }
   const int tiles = ((a.W + TW - 1) / TW) * ((a.H + TH - 1) / TH) * a.B;
   const int total = tiles * ((a.coutp + a.bn - 1) / a.bn);

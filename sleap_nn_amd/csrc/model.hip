@@ -5,6 +5,7 @@
 //  training/lightning_modules.py:1840-1848, architectures/model.py:237-261,
 //  architectures/unet.py:260-299).
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstring>
 #include <mutex>
@@ -30,6 +31,19 @@ void set_error(const char* fmt, ...) {
 }  // namespace ph
 
 namespace ph {
+
+int device_cu_count(int* out) {
+  static std::atomic<int> cache[64];  // zero-initialised; a count is a device property, racing writers store the same value
+  int dev = 0;
+  PH_HIP_CHECK(hipGetDevice(&dev));
+  int n = (dev >= 0 && dev < 64) ? cache[dev].load(std::memory_order_relaxed) : 0;
+  if (!n) {
+    PH_HIP_CHECK(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
+    if (dev >= 0 && dev < 64) cache[dev].store(n, std::memory_order_relaxed);
+  }
+  *out = n;
+  return PH_OK;
+}
 
 int upload(ph_model* m, const std::vector<float>& host, float** dev) {
   void* p = nullptr;
@@ -279,7 +293,11 @@ int build_plan(const ph_model* m, int B, int H, int W, Plan& plan, int fmt) {
   for (const PackedOp& op : m->ops) {
     const ph_op_desc& d = op.d;
     ++op_i;
-    if (reuse)  // slots whose last reader ran before this op (a slot nobody reads is released right after the op that wrote it)
+    // Run-time fusions let op i write op i + 1's dst one op early (pool_peephole: a conv's epilogue writes the pool that follows it;
+    // fuse_gelu_fwd: a Linear writes its GELU; dw_ln_fuse: a depthwise / stem conv writes its LayerNorm).  Such a dst must not land on
+    // a range op i is still reading, so the releases due before a pool / GELU / LayerNorm of the previous op's output wait one op.
+    const bool forwarded = op_i > 0 && (d.kind == PH_OP_POOL || d.kind == PH_OP_GELU || d.kind == PH_OP_LAYERNORM) && d.src0 >= 0 && d.src0 == m->ops[op_i - 1].d.dst;
+    if (reuse && !forwarded)  // slots whose last reader ran before this op (a slot nobody reads is released right after the op that wrote it)
       for (int sl = 0; sl < m->n_slots; ++sl)
         if (!released[sl] && plan.slots[sl].offset >= 0 && slot_bytes[sl] > 0 && std::max(last_use[sl], plan.slots[sl].def_op) < op_i) release(sl);
     int h, w;
@@ -875,9 +893,11 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
     if (rc != PH_OK) return rc;
   }
   size_t op_index = 0;
+  m->last_variant.assign(m->ops.size(), PH_KV_NONE);
+  int* const kv = m->last_variant.data();
   bool skip_next_gelu = false;
   int pooled_by_conv = -1;  // slot whose 2x2 max pool the producing conv's epilogue already wrote (run-time fusion of an unfused program, see PH_OP_CONV)
-  int fused_head = -1;      // index of a head op the producing conv's epilogue already computed (see PH_OP_CONV)
+  std::vector<char> head_done(m->ops.size(), 0);  // head ops the producing conv's epilogue already computed (see PH_OP_CONV)
   int fused_ln = -1;        // index of a LayerNorm op the producing depthwise conv already applied (see PH_OP_DWCONV)
   for (const PackedOp& op : m->ops) {
     const ph_op_desc& d = op.d;
@@ -923,6 +943,7 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
         a.W = width;
         a.wino = m->stem_wino;
         a.out_fmt = fmt;
+        kv[op_index - 1] = PH_KV_STEM;
         rc = launch_stem(a, s);
         break;
       }
@@ -956,6 +977,7 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
           f.prec = fmt == FMT_F16 ? 1 : 3;
           f.zeros = m->zeros_dev;
           f.clock_probe = m->clock_probe ? m->clock_probe + 2 * 1024 * (op_index - 1) : nullptr;  // one 1024-workgroup record block per op
+          kv[op_index - 1] = PH_KV_F16;
           rc = launch_conv3x3_f16(f, s);
           break;
         }
@@ -979,6 +1001,7 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
           g.W = s0.w;
           g.act = (d.flags & PH_FLAG_RELU) ? 1 : 0;
           g.late_split = m->gemm_late_split;
+          kv[op_index - 1] = PH_KV_ROWGEMM;
           rc = launch_gemm(g, s);
           if (rc == PH_OK && d.dst2 >= 0) rc = launch_pool(slot_ptr(d.dst), slot_ptr(d.dst2), batch, s0.h, s0.w, g.coutp, s);  // the fused-pool flag of the plan, unfused here
           break;
@@ -1043,6 +1066,7 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
           g.act = a.relu ? 1 : 0;
           g.late_split = m->gemm_late_split;
           g.persist2 = m->gemm_persist2;
+          kv[op_index - 1] = PH_KV_ROWGEMM;
           rc = launch_gemm(g, s);
           break;
         }
@@ -1059,7 +1083,7 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
               a.head_cout = hx.cout;
               a.head_wcp = 64;
               a.head_sigmoid = (hx.flags & PH_FLAG_SIGMOID) ? 1 : 0;
-              fused_head = (int)j;
+              head_done[j] = 1;
               if (plan.reuse) {  // training keeps every activation
                 bool other = false;
                 for (size_t k = 0; k < m->ops.size(); ++k)
@@ -1082,6 +1106,7 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
               a.dst_pool = nullptr;
           }
         }
+        kv[op_index - 1] = (m->use_dma && (a.bn == 64 || m->dma32)) ? conv3x3_dma_variant(a) : PH_KV_DIRECT;
         rc = (m->use_dma && (a.bn == 64 || m->dma32)) ? launch_conv3x3_dma(a, s) : launch_conv3x3(a, s);
         break;
       }
@@ -1132,6 +1157,7 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
             g.late_split = m->gemm_late_split;
             rc = launch_gemm(g, s);
           }
+          kv[op_index - 1] = PH_KV_ROWGEMM;
           break;
         }
         PH_REQUIRE(!op.wt_scale_dev && !(d.flags & PH_FLAG_SILU), "folded BatchNorm / SiLU on a transposed conv need the phase GEMMs (exact precision, convt_phase = 1)");
@@ -1157,6 +1183,7 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
           f.prec = fmt == FMT_F16 ? 1 : 3;
           f.zeros = m->zeros_dev;
           f.clock_probe = m->clock_probe ? m->clock_probe + 2 * 1024 * (op_index - 1) : nullptr;  // one 1024-workgroup record block per op
+          kv[op_index - 1] = PH_KV_F16;
           rc = launch_conv3x3_f16(f, s);
           break;
         }
@@ -1179,6 +1206,7 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
         a.wpack_dma = op.w_dma_dev;
         a.zeros = m->zeros_dev;
         apply_conv_options(m, a);
+        kv[op_index - 1] = (m->use_dma && (a.bn == 64 || m->dma32)) ? conv3x3_dma_variant(a) : PH_KV_DIRECT;
         rc = (m->use_dma && (a.bn == 64 || m->dma32)) ? launch_conv3x3_dma(a, s) : launch_conv3x3(a, s);
         break;
       }
@@ -1295,6 +1323,7 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
             skip_next_gelu = true;
           }
         }
+        kv[op_index - 1] = PH_KV_ROWGEMM;
         rc = launch_gemm(a, s);
         break;
       }
@@ -1320,10 +1349,7 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
         break;
       }
       case PH_OP_HEAD: {
-        if (fused_head == (int)op_index - 1) {  // computed by its producer's epilogue
-          fused_head = -1;
-          break;
-        }
+        if (head_done[op_index - 1]) break;  // computed by its producer's epilogue
         const SlotShape& s0 = plan.slots[d.src0];
         PH_REQUIRE(s0.c == d.cin0, "head channel mismatch");
         PH_REQUIRE(out_dev[d.out_index] != nullptr, "output %d is null", d.out_index);
@@ -1437,6 +1463,13 @@ int ph_model_profile_read(ph_model* m, double* op_ms, int32_t n_ops, int32_t* n_
   if (rc != PH_OK) return rc;
   for (int i = 0; i < n_ops; ++i) op_ms[i] = i < (int)m->op_ms.size() ? m->op_ms[i] : 0.0;
   *n_forwards = m->profiled_forwards;
+  return PH_OK;
+}
+
+int ph_model_last_kernels(const ph_model* m, int32_t* codes, int32_t n_ops) {
+  PH_REQUIRE(m && codes, "ph_model_last_kernels: null argument");
+  PH_REQUIRE(n_ops == (int32_t)m->ops.size(), "ph_model_last_kernels: model has %d ops", (int)m->ops.size());
+  for (int i = 0; i < n_ops; ++i) codes[i] = i < (int)m->last_variant.size() ? m->last_variant[i] : PH_KV_NONE;
   return PH_OK;
 }
 

@@ -97,6 +97,7 @@ struct ph_model {
   ph::Plan last_plan;
   char* last_ws = nullptr;
   int last_batch = 0;
+  std::vector<int> last_variant;  // PH_KV_* code of the kernel each op of the last forward ran (ph_model_last_kernels)
   // optional per-op HIP-event timing (ph_model_set_profiling)
   bool profiling = false;
   bool events_pending = false;

@@ -150,6 +150,7 @@ int launch_conv3x3_dma(const ConvArgs& a, hipStream_t s);
 bool conv3x3_dma_honours_mask(const ConvArgs& a);  // launch_conv3x3_dma would run a kernel that applies relu_mask_src
 bool conv3x3_dma_is_f2x2(const ConvArgs& a);       // launch_conv3x3_dma would run one of the two F(2x2,3x3) kernels
 bool conv3x3_dma_is_wino2d(const ConvArgs& a);     // ... the wave-split one (the only kernel that takes a fused head)
+int conv3x3_dma_variant(const ConvArgs& a);        // PH_KV_* code (posehip.h) of the kernel launch_conv3x3_dma would run
 // wpack [panel][tap 9][bn][16] -> F(2x2,3x3) weights [panel][g 2][xi 4][nu 4][n tile][lh][lx][4] (see conv3x3_wino2d_kernel)
 int launch_wino2d_pack(const float* wpack, float* wino, int panels, int bn, hipStream_t s);
 int64_t wino2d_pack_floats(int panels, int bn);

@@ -1300,16 +1300,7 @@ static int launch_conv3x3_c16(const ConvArgs& a, hipStream_t s) {
   return PH_OK;
 }
 
-static int cu_count(int* out) {
-  static int n_cu = 0;
-  if (!n_cu) {
-    int dev = 0;
-    PH_HIP_CHECK(hipGetDevice(&dev));
-    PH_HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-  }
-  *out = n_cu;
-  return PH_OK;
-}
+static int cu_count(int* out) { return device_cu_count(out); }
 
 // Kernel choice for a 3x3 "same" conv on the LDS-DMA family.  Which variant runs is decided by fields of `a` that the
 // model runtime fills from the handle's options (ph_model_set_option); there is no process-global state here.
@@ -1324,6 +1315,17 @@ static int conv3x3_dma_route(const ConvArgs& a) {
 bool conv3x3_dma_honours_mask(const ConvArgs& a) { return conv3x3_dma_route(a) == 1; }
 bool conv3x3_dma_is_f2x2(const ConvArgs& a) { const int r = conv3x3_dma_route(a); return r == 1 || r == 2; }
 bool conv3x3_dma_is_wino2d(const ConvArgs& a) { return conv3x3_dma_route(a) == 2; }
+// PH_KV_* code of the kernel launch_conv3x3_dma would run (ph_model_last_kernels)
+int conv3x3_dma_variant(const ConvArgs& a) {
+  switch (conv3x3_dma_route(a)) {
+    case 0: return PH_KV_C16;
+    case 1: return PH_KV_W16;
+    case 2: return PH_KV_WINO2D;
+    default: break;
+  }
+  const bool wino = a.use_wino && a.wpack_wino && (a.bn == 64 || a.use_wino != 2);
+  return (a.persist && wino) ? PH_KV_WINO1D : PH_KV_DIRECT;
+}
 
 int launch_conv3x3_dma(const ConvArgs& a, hipStream_t s) {
   const int route = conv3x3_dma_route(a);

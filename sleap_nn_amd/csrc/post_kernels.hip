@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256) void peaks_scan_kernel(const int* __restrict__
 // Pass 3: emit in (sample, y, x, channel) order, refine.
 __global__ __launch_bounds__(256) void peaks_emit_kernel(const float* __restrict__ cms, int C, int H, int W, float thr, int refine, int patch,
                                                          const int* __restrict__ row_offset, float* __restrict__ out_xy, float* __restrict__ out_val,
-                                                         int* __restrict__ out_sample, int* __restrict__ out_channel, int cap) {
+                                                         int* __restrict__ out_sample, int* __restrict__ out_channel, int cap, float xy_scale) {
   __shared__ int red[8];
   const int row = blockIdx.x;
   const int b = row / H, y = row - b * H;
@@ -158,8 +158,8 @@ __global__ __launch_bounds__(256) void peaks_emit_kernel(const float* __restrict
             fx += dx;
             fy += dy;
           }
-          out_xy[2 * (size_t)off] = fx;
-          out_xy[2 * (size_t)off + 1] = fy;
+          out_xy[2 * (size_t)off] = fx * xy_scale;  // one fp32 multiply after the refinement: `peaks * output_stride` of the callers
+          out_xy[2 * (size_t)off + 1] = fy * xy_scale;
           out_val[off] = plane[(size_t)y * W + x];
           out_sample[off] = b;
           out_channel[off] = c;
@@ -172,14 +172,14 @@ __global__ __launch_bounds__(256) void peaks_emit_kernel(const float* __restrict
 }
 
 int launch_local_peaks(const float* cms, int B, int C, int H, int W, float thr, int refine, int patch, float* out_xy, float* out_val,
-                       int* out_sample, int* out_channel, int* out_count, int cap, int* scratch, hipStream_t s) {
+                       int* out_sample, int* out_channel, int* out_count, int cap, float xy_scale, int* scratch, hipStream_t s) {
   const int n_rows = B * H;
   int* row_count = scratch;              // n_rows
   int* row_offset = scratch + n_rows;    // n_rows + 1
   hipLaunchKernelGGL(peaks_count_kernel, dim3(n_rows), dim3(256), 0, s, cms, C, H, W, thr, row_count);
   hipLaunchKernelGGL(peaks_scan_kernel, dim3(1), dim3(256), 0, s, row_count, row_offset, n_rows, H, B, out_count);
   hipLaunchKernelGGL(peaks_emit_kernel, dim3(n_rows), dim3(256), 0, s, cms, C, H, W, thr, refine, patch, row_offset, out_xy, out_val, out_sample,
-                     out_channel, cap);
+                     out_channel, cap, xy_scale);
   PH_HIP_CHECK(hipGetLastError());
   return PH_OK;
 }
@@ -478,13 +478,13 @@ int ph_sample_class_maps(const float* class_maps_dev, int32_t B, int32_t K, int3
 }
 
 int ph_local_peaks(const float* cms_dev, int32_t B, int32_t C, int32_t H, int32_t W, float threshold, int32_t refine, int32_t patch, float* out_xy,
-                   float* out_val, int32_t* out_sample, int32_t* out_channel, int32_t* out_count, int32_t cap, void* scratch_dev,
-                   int64_t scratch_bytes, void* stream) {
+                   float* out_val, int32_t* out_sample, int32_t* out_channel, int32_t* out_count, int32_t cap, float xy_scale,
+                   void* scratch_dev, int64_t scratch_bytes, void* stream) {
   PH_REQUIRE(cms_dev && out_xy && out_val && out_sample && out_channel && out_count && scratch_dev, "ph_local_peaks: null argument");
   PH_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && cap >= 0, "ph_local_peaks: bad shape");
   PH_REQUIRE(patch >= 1 && (patch & 1), "ph_local_peaks: integral patch must be odd");
   PH_REQUIRE(scratch_bytes >= (int64_t)4 * (2 * (int64_t)B * H + 2), "ph_local_peaks: scratch too small");
-  return launch_local_peaks(cms_dev, B, C, H, W, threshold, refine, patch, out_xy, out_val, out_sample, out_channel, out_count, cap,
+  return launch_local_peaks(cms_dev, B, C, H, W, threshold, refine, patch, out_xy, out_val, out_sample, out_channel, out_count, cap, xy_scale,
                             static_cast<int*>(scratch_dev), static_cast<hipStream_t>(stream));
 }
 

@@ -163,27 +163,30 @@ int ph_model_set_params(ph_model* m, const float* params_flat_dev, void* stream)
   return PH_OK;
 }
 
-// Smallest arena offset an op's parameters start at (-1: the op has none).
-static int64_t op_param_offset(const ph_model* m, const ph_op_desc& d) {
-  int64_t lo = -1;
+// Smallest / largest arena offset an op's parameters start at (-1: the op has none).
+static int64_t op_param_offset(const ph_model* m, const ph_op_desc& d, bool highest = false) {
+  int64_t v = -1;
   for (int idx : {d.weight, d.bias, d.weight2, d.bias2})
-    if (idx >= 0 && idx < (int)m->weight_offset.size()) lo = lo < 0 ? m->weight_offset[idx] : std::min(lo, m->weight_offset[idx]);
-  return lo;
+    if (idx >= 0 && idx < (int)m->weight_offset.size()) v = v < 0 ? m->weight_offset[idx] : (highest ? std::max(v, m->weight_offset[idx]) : std::min(v, m->weight_offset[idx]));
+  return v;
 }
 
 // The op (forward order) whose completion in the reverse sweep makes the arena tail [offset, n_params) final: the program's
 // parameters lie in op order, so the candidates are the ops at which the arena splits cleanly; the one closest to the middle wins.
 static int bucket_split_op(const ph_model* m, int64_t* offset_out) {
   const int n = (int)m->ops.size();
-  std::vector<int64_t> off(n);
-  for (int i = 0; i < n; ++i) off[i] = op_param_offset(m, m->ops[i].d);
+  std::vector<int64_t> off(n), hi(n);
+  for (int i = 0; i < n; ++i) {
+    off[i] = op_param_offset(m, m->ops[i].d);
+    hi[i] = op_param_offset(m, m->ops[i].d, true);
+  }
   int best = -1;
   int64_t best_off = m->n_params;
   for (int k = 1; k < n; ++k) {
     if (off[k] <= 0) continue;
     bool clean = true;
     for (int i = 0; i < n && clean; ++i)
-      if (off[i] >= 0) clean = i < k ? off[i] < off[k] : off[i] >= off[k];
+      if (off[i] >= 0) clean = i < k ? hi[i] < off[k] : off[i] >= off[k];  // EVERY parameter of an earlier op (weight2 / bias2 too) lies below the split
     if (!clean) continue;
     if (best < 0 || std::llabs(2 * off[k] - m->n_params) < std::llabs(2 * best_off - m->n_params)) {
       best = k;

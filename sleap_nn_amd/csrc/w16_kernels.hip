@@ -269,16 +269,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_w16_kernel(ConvArgs a) {
   }
 }
 
-static int v_cu_count(int* out) {
-  static int n_cu = 0;
-  if (!n_cu) {
-    int dev = 0;
-    PH_HIP_CHECK(hipGetDevice(&dev));
-    PH_HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-  }
-  *out = n_cu;
-  return PH_OK;
-}
+static int v_cu_count(int* out) { return device_cu_count(out); }
 
 int prepare_w16_kernels() {
   const void* ks[4] = {reinterpret_cast<const void*>(conv3x3_w16_kernel<1, 1>), reinterpret_cast<const void*>(conv3x3_w16_kernel<2, 1>),

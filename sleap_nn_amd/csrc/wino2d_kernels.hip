@@ -681,16 +681,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_kernel(ConvArgs a) {
 #endif
 }
 
-static int w2_cu_count(int* out) {
-  static int n_cu = 0;
-  if (!n_cu) {
-    int dev = 0;
-    PH_HIP_CHECK(hipGetDevice(&dev));
-    PH_HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-  }
-  *out = n_cu;
-  return PH_OK;
-}
+static int w2_cu_count(int* out) { return device_cu_count(out); }
 
 int prepare_wino2d_kernels() {
   const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wino2d_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -49,16 +49,29 @@ class BottomUpLayer(InferenceLayer):
         dev = cms.device
         peak_cap = max(self._peak_cap, B * n_nodes * 32, 1024)
         cand_cap = max(self._cand_cap, B * sc.n_edges * 256, 4096)
-        xy, vals, sb, ch, counts, _ = find_local_peaks_device(cms, pc.peak_threshold, pc.effective_refinement, pc.integral_patch_size, peak_cap)
-        xy = xy * self.cms_output_stride  # peaks * cms_output_stride (bottomup.py:111)
+        # ONE packed arena, written by the kernels themselves and copied to the host in one piece (int32 rows travel bit-cast
+        # as float32): [counts 2+2B | cand offsets B+1 | xy 2P | vals P | score Q | channel P | cand edge Q | src Q | dst Q]
+        n_head = (2 + 2 * B) + (B + 1)
+        packed = torch.empty(n_head + 4 * peak_cap + 4 * cand_cap, dtype=torch.float32, device=dev)
+        ints = packed.view(torch.int32)
+        o = n_head
+        xy = packed[o : o + 2 * peak_cap].view(peak_cap, 2)
+        o += 2 * peak_cap
+        vals = packed[o : o + peak_cap]
+        o += peak_cap
+        score = packed[o : o + cand_cap]
+        o += cand_cap
+        ch = ints[o : o + peak_cap]
+        ce, cs, cd = (ints[o + peak_cap + k * cand_cap : o + peak_cap + (k + 1) * cand_cap] for k in range(3))
+        counts, coff = ints[: 2 + 2 * B], ints[2 + 2 * B : n_head]
+        # peaks * cms_output_stride (bottomup.py:111) is the kernel's last multiply
+        find_local_peaks_device(cms, pc.peak_threshold, pc.effective_refinement, pc.integral_patch_size, peak_cap,
+                                xy_scale=float(self.cms_output_stride), out=(xy, vals, ch, counts))
         offs = counts[1 + B : 2 + 2 * B]
-        ce, cs, cd, score, coff = score_paf_lines_device(
+        score_paf_lines_device(
             pafs, xy, ch, offs, peak_cap, sc.edges_on(dev), sc.n_nodes, sc.n_points, sc.pafs_stride, sc.max_edge_length_ratio,
-            sc.dist_penalty_weight, cand_cap,
+            sc.dist_penalty_weight, cand_cap, out=(ce, cs, cd, score, coff),
         )
-        # one packed D2H (int32 rows travel bit-cast as float32): [head | xy | vals | score | ch | ce | cs | cd]
-        head = torch.cat([counts, coff])
-        packed = torch.cat([head.view(torch.float32), xy.reshape(-1), vals, score, torch.cat([ch, ce, cs, cd]).view(torch.float32)])
         key = (int(packed.numel()), dev)
         pool = self.__dict__.setdefault("_pinned", {})
         host = pool.get(key, [])
@@ -66,7 +79,7 @@ class BottomUpLayer(InferenceLayer):
         buf.copy_(packed, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(dev))
-        return {"buf": buf, "key": key, "event": ev, "B": B, "n_nodes": n_nodes, "peak_cap": int(xy.shape[0]), "cand_cap": int(score.shape[0]), "n_head": int(head.numel()),
+        return {"buf": buf, "key": key, "event": ev, "B": B, "n_nodes": n_nodes, "peak_cap": int(peak_cap), "cand_cap": int(cand_cap), "n_head": int(n_head),
                 "raw": raw_out, "info": info, "keep": packed}
 
     def _finish_scoring(self, h: dict) -> ScoredBatch:

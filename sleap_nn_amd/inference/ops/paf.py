@@ -49,10 +49,11 @@ def linear_sum_assignment(cost) -> Tuple[np.ndarray, np.ndarray]:
 
 def score_paf_lines_device(pafs_nchw: torch.Tensor, peaks_xy: torch.Tensor, peak_channel: torch.Tensor, peak_offsets: torch.Tensor,
                            n_peaks_total: int, edge_inds: torch.Tensor, n_nodes: int, n_points: int, pafs_stride: int,
-                           max_edge_length_ratio: float, dist_penalty_weight: float, capacity: int):
+                           max_edge_length_ratio: float, dist_penalty_weight: float, capacity: int, out=None):
     """Enqueue candidate enumeration + line scoring; everything stays on the device.
 
-    Returns ``(cand_edge, cand_src, cand_dst, cand_score, cand_offsets int32[B+1])``.
+    Returns ``(cand_edge, cand_src, cand_dst, cand_score, cand_offsets int32[B+1])``; ``out``: the same five as
+    pre-allocated views (a caller's packed D2H arena) the kernels write directly.
     """
     L.require_cuda(pafs_nchw, "pafs")
     pafs = pafs_nchw.detach().to(torch.float32).contiguous()
@@ -62,12 +63,16 @@ def score_paf_lines_device(pafs_nchw: torch.Tensor, peaks_xy: torch.Tensor, peak
     # max() includes the channel axis, as in the reference (paf.py:457-461)
     max_edge_length = float(max_edge_length_ratio * max(E2, W, H) * pafs_stride)
     cap = int(capacity)
-    ce = torch.empty((cap,), dtype=torch.int32, device=dev)
-    cs = torch.empty((cap,), dtype=torch.int32, device=dev)
-    cd = torch.empty((cap,), dtype=torch.int32, device=dev)
-    sc = torch.empty((cap,), dtype=torch.float32, device=dev)
-    off = torch.empty((B + 1,), dtype=torch.int32, device=dev)
-    t = torch.linspace(0, 1, steps=n_points).to(dev)  # exact torch.linspace values (paf.py:190)
+    if out is not None:
+        ce, cs, cd, sc, off = out
+        assert ce.numel() == cap and cs.numel() == cap and cd.numel() == cap and sc.numel() == cap and off.numel() == B + 1
+    else:
+        ce = torch.empty((cap,), dtype=torch.int32, device=dev)
+        cs = torch.empty((cap,), dtype=torch.int32, device=dev)
+        cd = torch.empty((cap,), dtype=torch.int32, device=dev)
+        sc = torch.empty((cap,), dtype=torch.float32, device=dev)
+        off = torch.empty((B + 1,), dtype=torch.int32, device=dev)
+    t = _linspace_on(dev, n_points)  # exact torch.linspace values (paf.py:190)
     scratch = torch.empty((n_peaks_total + B * (n_nodes + 1) + B * (n_edges + 1) + B + 16,), dtype=torch.int32, device=dev)
     with torch.cuda.device(dev):
         L.check(
@@ -80,6 +85,17 @@ def score_paf_lines_device(pafs_nchw: torch.Tensor, peaks_xy: torch.Tensor, peak
             )
         )
     return ce, cs, cd, sc, off
+
+
+_LINSPACE = {}
+
+
+def _linspace_on(dev, n_points: int) -> torch.Tensor:
+    """``torch.linspace(0, 1, n_points)`` computed once on the host (the reference's values) and kept on the device."""
+    key = (str(dev), int(n_points))
+    if key not in _LINSPACE:
+        _LINSPACE[key] = torch.linspace(0, 1, steps=n_points).to(dev)
+    return _LINSPACE[key]
 
 
 def group_batch_host(n_nodes: int, edge_inds, peaks_xy: np.ndarray, peak_vals: np.ndarray, peak_channel: np.ndarray, peak_offsets: np.ndarray,

@@ -22,29 +22,37 @@ def _refine_flag(refinement: Optional[str]) -> int:
     return 1 if refinement == "integral" else 0
 
 
-def find_local_peaks_device(cms: torch.Tensor, threshold: float = 0.2, refinement: Optional[str] = None, integral_patch_size: int = 5, capacity: Optional[int] = None):
+def find_local_peaks_device(cms: torch.Tensor, threshold: float = 0.2, refinement: Optional[str] = None, integral_patch_size: int = 5, capacity: Optional[int] = None,
+                            xy_scale: float = 1.0, out=None):
     """Device-resident result: (xy (cap,2), vals (cap,), sample (cap,), channel (cap,), counts int32[2+2B]).
 
     ``counts[0]`` = total number of peaks, ``counts[1+b]`` = peaks of sample ``b``,
     ``counts[1+B:2+2B]`` = exclusive per-sample offsets (B+1 entries); no host
     sync happens here.  Rows beyond ``counts[0]`` are undefined.
+    ``xy_scale``: the kernel multiplies the (refined) coordinates by it (``peaks * cms_output_stride`` of the bottom-up
+    layer, bottomup.py:111).  ``out``: optional pre-allocated ``(xy, vals, channel, counts)`` views (a caller's packed
+    D2H arena) the kernel writes directly.
     """
     cms = _prep(cms)
     B, Cc, H, W = cms.shape
     dev = cms.device
     cap = int(capacity) if capacity is not None else max(1024, B * Cc * 64)
-    xy = torch.empty((cap, 2), dtype=torch.float32, device=dev)
-    vals = torch.empty((cap,), dtype=torch.float32, device=dev)
+    if out is not None:
+        xy, vals, sc, counts = out
+        assert xy.numel() == 2 * cap and vals.numel() == cap and sc.numel() == cap and counts.numel() == 2 + 2 * B
+    else:
+        xy = torch.empty((cap, 2), dtype=torch.float32, device=dev)
+        vals = torch.empty((cap,), dtype=torch.float32, device=dev)
+        sc = torch.empty((cap,), dtype=torch.int32, device=dev)
+        counts = torch.empty((2 + 2 * B,), dtype=torch.int32, device=dev)
     sb = torch.empty((cap,), dtype=torch.int32, device=dev)
-    sc = torch.empty((cap,), dtype=torch.int32, device=dev)
-    counts = torch.empty((2 + 2 * B,), dtype=torch.int32, device=dev)
     scratch = torch.empty((2 * B * H + 2,), dtype=torch.int32, device=dev)
     with torch.cuda.device(dev):
         L.check(
             L.lib().ph_local_peaks(
                 C.c_void_p(cms.data_ptr()), B, Cc, H, W, float(threshold), _refine_flag(refinement), int(integral_patch_size),
                 C.c_void_p(xy.data_ptr()), C.c_void_p(vals.data_ptr()), C.c_void_p(sb.data_ptr()), C.c_void_p(sc.data_ptr()),
-                C.c_void_p(counts.data_ptr()), cap, C.c_void_p(scratch.data_ptr()), scratch.numel() * 4, L.current_stream_ptr(),
+                C.c_void_p(counts.data_ptr()), cap, float(xy_scale), C.c_void_p(scratch.data_ptr()), scratch.numel() * 4, L.current_stream_ptr(),
             )
         )
     return xy, vals, sb, sc, counts, cms

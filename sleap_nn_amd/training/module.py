@@ -136,9 +136,13 @@ class TrainingModule:
                     raise ValueError(f"is_negative has {neg.numel()} entries for a batch of {B}")
                 sw = torch.where(neg, float(self.negative_loss_weight), 1.0).to(torch.float32).contiguous()
             k = self.ohkm
-            if self._bucket_event is not None:  # (re)bind after any recompile of the handle
+            # (re)bind on every step: the handle may have been recompiled, or last used by another TrainingModule whose event
+            # is gone -- a handle never keeps an event this module does not own (NULL = no mid-sweep record)
+            if self._bucket_event is not None:
                 self._bucket_split = int(L.check(lib.ph_model_grad_bucket_split(m._handle)))
                 L.check(lib.ph_model_set_bucket_event(m._handle, C.c_void_p(self._bucket_event.cuda_event)))
+            else:
+                L.check(lib.ph_model_set_bucket_event(m._handle, None))
             L.check(
                 lib.ph_model_backward(
                     m._handle, C.c_void_p(x.data_ptr()), code, B, Cin, H, W, C.c_void_p(m._workspace.data_ptr()), C.c_void_p(self._grad_ws.data_ptr()),
@@ -194,6 +198,18 @@ class TrainingModule:
         if self.schedule is not None:
             self.lr = self.schedule.step(val_loss)
         return self.lr
+
+    def close(self) -> None:
+        """Unbind this module's bucket event from the model handle (the handle may outlive the module)."""
+        ev, self._bucket_event = self._bucket_event, None
+        if ev is not None and getattr(self.model, "_handle", None) is not None:
+            L.lib().ph_model_set_bucket_event(self.model._handle, None)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     # ------------------------------------------------------------------------------
     def named_grads(self) -> Dict[str, torch.Tensor]:

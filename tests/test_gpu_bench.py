@@ -23,13 +23,18 @@ def _run(*args):
 
 
 @pytest.mark.skipif(not torch.cuda.is_available(), reason="needs a GPU")
-def test_two_ranks_weak_and_three_ranks_strong_rehearsal():
-    d = _run("--gpus", "2", "--rehearse-on-one-gpu", "--steps", "3", "--warmup", "1", "--batch", "4", "--no-alt-precisions", "--no-h2d-leg")
-    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 3 and d["warmup"] == 1
+def test_two_ranks_default_strong_with_weak_beside_it_and_three_ranks_strong_rehearsal():
+    # N > 1 with no --scaling flag: `value` is BASELINE cfg3 as written (global batch split over the ranks), the weak figure rides along
+    d = _run("--gpus", "2", "--rehearse-on-one-gpu", "--steps", "3", "--warmup", "1", "--batch", "4", "--global-batch", "8", "--no-alt-precisions", "--no-h2d-leg")
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["steps"] == 3 and d["warmup"] == 1
     assert d["config"]["frames_per_gpu_per_step"] == 4 and d["config"]["global_batch"] == 8
     assert d["value"] > 0 and abs(d["value"] - 8 * 3 / (d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]  # whole-job frames / max-over-ranks time
-    assert "cpu_baseline" not in d and "REHEARSAL" in d["data"]  # the CPU leg belongs to N = 1
-    assert d["roofline"]["kernel"].startswith("conv3x3_wino2d_kernel") and 0 < d["roofline"]["frac"] < 1
+    w = d["weak_scaling"]
+    assert w["frames_per_gpu_per_step"] == 4 and w["global_batch"] == 8 and w["value"] > 0
+    assert "cpu_baseline" not in d and "train_cfg3" not in d and "REHEARSAL" in d["data"]  # the CPU leg and the extra legs belong to N = 1
+    assert d["roofline"]["kernel"].startswith("conv3x3_wino") and 0 < d["roofline"]["frac"] < 1
+    d = _run("--gpus", "2", "--rehearse-on-one-gpu", "--steps", "2", "--warmup", "1", "--batch", "4", "--scaling", "weak", "--no-alt-precisions", "--no-h2d-leg")
+    assert d["scaling"] == "weak" and d["config"]["global_batch"] == 8 and "weak_scaling" not in d
     d = _run("--gpus", "3", "--rehearse-on-one-gpu", "--steps", "2", "--warmup", "1", "--scaling", "strong", "--global-batch", "8", "--no-alt-precisions", "--no-h2d-leg")
     assert d["n_gpus"] == 3 and d["scaling"] == "strong" and d["config"]["global_batch"] == 8
     assert d["config"]["frames_per_gpu_per_step"] in (2, 3)  # rank 0's contiguous chunk of 8 frames over 3 ranks

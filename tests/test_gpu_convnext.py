@@ -117,13 +117,14 @@ def test_small_map_convs_row_gemm_equals_halo_kernel():
 # Training: forward + MSE + backward of the ConvNeXt program vs autograd over the oracle.
 # Tolerance: loss 1e-5 relative; every parameter gradient within 2e-4 of its tensor's max magnitude.
 # ------------------------------------------------------------------------------------------
-def _train_case(channels, depths, stem_stride, os_, hw, B, model_type="centered_instance", in_ch=1, seed=13):
+def _train_case(channels, depths, stem_stride, os_, hw, B, model_type="centered_instance", in_ch=1, seed=13, bb=None, layer_scale=0.6, n_parts=3):
     from sleap_nn_amd.architectures.model import Model
     from sleap_nn_amd.training.module import TrainingModule
 
-    bb = _bb(arch={"depths": depths, "channels": channels}, stem_patch_stride=stem_stride, output_stride=os_, in_channels=in_ch)
-    heads = {"confmaps": {"part_names": ["a", "b", "c"], "sigma": 2.5, "output_stride": os_, "loss_weight": 1.0, "anchor_part": None}}
-    sd = O.init_state_convnext(bb, heads, model_type, seed=seed, head_scale=1.0, layer_scale=0.6, randomize_affine=True)
+    if bb is None:
+        bb = _bb(arch={"depths": depths, "channels": channels}, stem_patch_stride=stem_stride, output_stride=os_, in_channels=in_ch)
+    heads = {"confmaps": {"part_names": [chr(97 + i) for i in range(n_parts)], "sigma": 2.5, "output_stride": os_, "loss_weight": 1.0, "anchor_part": None}}
+    sd = O.init_state_convnext(bb, heads, model_type, seed=seed, head_scale=1.0, layer_scale=layer_scale, randomize_affine=True)
     g = torch.Generator().manual_seed(seed)
     img = torch.randint(0, 256, (B, in_ch, hw[0], hw[1]), dtype=torch.uint8, generator=g)
     ref_out = O.model_forward(sd, bb, heads, model_type, img, backbone="convnext")
@@ -182,3 +183,120 @@ def test_convnext_adam_steps_reduce_loss_and_match_reference_optimizer():
     for k, p in opt_params.items():
         assert float((got[k].cpu() - p.detach()).abs().max()) <= 0.02 * 3 * 1e-3, k
     assert float(loss[0]) < first
+
+
+# ------------------------------------------------------------------------------------------
+# BASELINE cfg4: the ConvNeXt-TINY architecture itself (96/192/384/768 channels, depths 3/3/9/3: BN = 96 / 128 GEMM tiles,
+# an 87.9 M-parameter arena beyond the 2^24 exact-fp32 index range, nine-block stage 2) -- backward vs autograd over the
+# oracle, the full 384x384 x 64 step, and the two-stage top-down pipeline on ConvNeXt backbones.
+# ------------------------------------------------------------------------------------------
+def test_convnext_tiny_backward_matches_autograd():
+    """model_type "tiny" forward + MSE + backward at 64x96, B = 2, 13 nodes: loss 1e-5 relative, every one of the 180+ parameter
+    gradients within 2e-4 of its tensor's max magnitude (same bars as the toy architectures above)."""
+    bb = _bb(model_type="tiny", output_stride=2)
+    tm, *_ = _train_case(None, None, 2, 2, (64, 96), 2, bb=bb, layer_scale=0.3, n_parts=13, seed=41)
+    assert tm.params.numel() > 2 ** 24 * 5  # 87.9 M parameters
+
+
+def test_cfg4_full_size_training_properties():
+    """The benched cfg4 workload at FULL size -- ConvNeXt-tiny centered-instance, 64 crops of 384x384, 13 nodes, output stride 2 -- through
+    size-independent properties: every head output and gradient finite, the loss goes down over three Adam steps, the three steps are
+    bitwise repeatable from the same start, and crop 0 of the 64-crop inference forward equals the 1-crop forward of the same crop."""
+    from sleap_nn_amd.architectures.model import Model
+    from sleap_nn_amd.data.targets import generate_multiconfmaps
+    from sleap_nn_amd.training.module import TrainingModule
+
+    B, S = 64, 384
+    bb = _bb(model_type="tiny", output_stride=2)
+    heads = {"confmaps": {"part_names": [str(i) for i in range(13)], "sigma": 2.5, "output_stride": 2, "loss_weight": 1.0, "anchor_part": None}}
+    g = torch.Generator().manual_seed(4321)
+    img = torch.randint(0, 256, (B, 1, S, S), dtype=torch.uint8, generator=g).to(DEV)
+    rng = np.random.RandomState(5)
+    pts = torch.from_numpy(np.clip(S / 2 + rng.normal(0, 40, size=(B, 1, 13, 2)), 8, S - 9).astype(np.float32)).to(DEV)
+    tgt = {"CenteredInstanceConfmapsHead": generate_multiconfmaps(pts, (S, S), sigma=2.5, output_stride=2)}
+    batch = {"image": img, **tgt}
+
+    def run():
+        m = Model("convnext", bb, heads, "centered_instance")
+        m.init_xavier_(seed=1234, head_scale=0.05)
+        tm = TrainingModule(m, DEV, lr=1e-3, loss_weights=[1.0])
+        losses = [tm.training_step(batch).clone() for _ in range(3)]
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(tm.grads).all()) and bool(torch.isfinite(tm.params).all())
+        return [float(l[0]) for l in losses], tm.params.clone(), tm, m
+
+    l1, p1, tm, m = run()
+    assert all(np.isfinite(l1)) and l1[2] < l1[0], l1
+    tm.close()
+    del tm, m
+    torch.cuda.empty_cache()
+    l2, p2, tm, m = run()
+    assert l1 == l2 and torch.equal(p1, p2)  # fixed-order reductions everywhere: bitwise repeatable
+    # inference program on the trained weights: batch invariance of crop 0
+    tm.model.load_flat_params(tm.params)
+    tm.close()
+    m.bind_live_params(None)
+    m.eval().to(DEV)
+    o64 = m(img)["CenteredInstanceConfmapsHead"][:1].clone()
+    o1 = m(img[:1])["CenteredInstanceConfmapsHead"]
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(o64).all()) and torch.equal(o64, o1)
+
+
+def test_two_stage_topdown_on_convnext_backbones_matches_oracle():
+    """cfg4 at inference time: TopDownLayer with a ConvNeXt-tiny centroid model and a ConvNeXt-tiny centered-instance model --
+    centroid confmaps -> local peaks (top-k) -> bit-exact uint8 crops -> centered-instance confmaps -> global peaks -> image
+    coordinates -- against the oracle's centroid_postprocess / topdown_stage2 on the same frames and weights."""
+    from sleap_nn_amd.architectures.model import Model
+    from sleap_nn_amd.inference.backends import HipBackend
+    from sleap_nn_amd.inference.layers import CenteredInstanceLayer, CentroidLayer, PostprocessConfig, TopDownLayer
+
+    crop = 96
+    bb = _bb(model_type="tiny", output_stride=2)
+    hc = {"confmaps": {"anchor_part": None, "sigma": 2.5, "output_stride": 2}}
+    hi = {"confmaps": {"part_names": [str(i) for i in range(5)], "anchor_part": None, "sigma": 2.5, "output_stride": 2}}
+    sdc = O.init_state_convnext(bb, hc, "centroid", seed=51, head_scale=1.0, layer_scale=0.3, randomize_affine=True)
+    sdi = O.init_state_convnext(bb, hi, "centered_instance", seed=52, head_scale=1.0, layer_scale=0.3, randomize_affine=True)
+    # frames: blobs on a noisy background so that the (random-weight) centroid map has well separated maxima
+    rng = np.random.RandomState(3)
+    H, W = 192, 256
+    yy, xx = np.mgrid[0:H, 0:W]
+    frames = []
+    for b in range(2):
+        f = rng.uniform(0, 40, size=(H, W))
+        for _ in range(4):
+            cy, cx = rng.uniform(40, H - 40), rng.uniform(40, W - 40)
+            f += 200 * np.exp(-((yy - cy) ** 2 + (xx - cx) ** 2) / (2 * 9.0 ** 2))
+        frames.append(np.clip(f, 0, 255).astype(np.uint8))
+    img = torch.from_numpy(np.stack(frames))[:, None]
+    ref_c = O.model_forward(sdc, bb, hc, "centroid", img, backbone="convnext")["CentroidConfmapsHead"]
+    thr_c = float(ref_c.mean() + 2.0 * ref_c.std())
+    cp, cv = O.centroid_postprocess(ref_c, 2, thr_c, "integral", 5, max_instances=4)
+    assert int((~torch.isnan(cp[..., 0])).sum()) >= 3, "test frames must yield a few centroids"
+    fwd_i = lambda c: O.model_forward(sdi, bb, hi, "centered_instance", c, backbone="convnext")["CenteredInstanceConfmapsHead"]
+    valid = ~torch.isnan(cp).any(-1)
+    probe = fwd_i(O.crop_bboxes(img, O.make_centered_bboxes(cp[valid], crop, crop), valid.nonzero()[:, 0]))
+    thr_i = float(probe.amax(dim=(2, 3)).min()) * 0.5  # every node of every crop is above threshold: no NaN pattern to flip
+    kp, kv, crops, bboxes, pts = O.topdown_stage2(img, cp, (crop, crop), fwd_i, 2, thr_i, "integral", 5)
+
+    mc = Model("convnext", bb, hc, "centroid")
+    mc.load_state_dict(sdc, strict=True)
+    mi = Model("convnext", bb, hi, "centered_instance")
+    mi.load_state_dict(sdi, strict=True)
+    cl = CentroidLayer(HipBackend(mc, DEV), 2, max_instances=4, max_stride=32, postprocess_config=PostprocessConfig(peak_threshold=thr_c, max_instances=4))
+    il = CenteredInstanceLayer(HipBackend(mi, DEV), 2, max_stride=32, postprocess_config=PostprocessConfig(peak_threshold=thr_i))
+    raw = cl.backend(img)["CentroidConfmapsHead"].cpu()
+    scale = max(1.0, float(ref_c.abs().max()))
+    assert float((raw - ref_c).abs().max()) / scale <= ATOL
+    td = TopDownLayer(cl, il, (crop, crop), return_crops=True)
+    out = td.predict(img)
+    assert np.allclose(out.pred_centroids.cpu().numpy(), cp.numpy(), atol=1e-3, equal_nan=True)
+    assert np.allclose(out.pred_centroid_values.cpu().numpy(), cv.numpy(), atol=ATOL * scale, equal_nan=True)
+    idx = valid.nonzero().numpy()
+    got_crops = out.crops.cpu().numpy()[idx[:, 0], idx[:, 1]]
+    assert np.array_equal(got_crops, crops.numpy())  # bit-exact uint8 crops
+    k = out.pred_keypoints.cpu().numpy()
+    assert np.array_equal(np.isnan(k), np.isnan(kp.numpy()))
+    assert np.allclose(k, kp.numpy(), atol=2e-3, equal_nan=True)
+    si = max(1.0, float(probe.abs().max()))
+    assert np.allclose(out.pred_peak_values.cpu().numpy(), kv.numpy(), atol=ATOL * si, equal_nan=True)

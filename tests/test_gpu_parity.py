@@ -16,6 +16,16 @@ from tests import _golden as G
 pytestmark = pytest.mark.gpu
 
 CMS_ATOL = 1e-4
+# Heads of the synthetic-weight networks are scaled x0.05 (outputs O(1e-3)), where a bare 1e-4 absolute bar proves little: those
+# tests also hold the error to this fraction of the head's max magnitude (measured: 1-2e-6 with the F(2x2,3x3) kernels).
+HEAD_RTOL = 1e-5
+
+
+def _head_close(got, ref, key=None):
+    err = (got.cpu() - ref).abs().max().item()
+    scale = ref.abs().max().item()
+    assert err <= CMS_ATOL, (key, err, scale)
+    assert err <= HEAD_RTOL * scale, (key, err, scale)
 DEV = "cuda:0"
 
 
@@ -373,8 +383,7 @@ def test_cfg3_network_vs_oracle_one_frame():
     ref = O.model_forward(sd, bb, heads, "bottomup", img)
     out = m.to(DEV)(img.to(DEV))
     for k, v in ref.items():
-        err = (out[k].cpu() - v).abs().max().item()
-        assert err <= CMS_ATOL, (k, err, v.abs().max().item())
+        _head_close(out[k], v, k)
 
 
 _CFG3_REF = {}
@@ -399,9 +408,7 @@ def test_cfg3_benched_workload_full_size_vs_oracle_and_batch_invariance(precisio
     dev_frames = frames.to(DEV)
     out2 = {k: v.clone() for k, v in m(dev_frames[:2].contiguous()).items()}
     for k, v in ref.items():
-        err = (out2[k].cpu() - v).abs().max().item()
-        assert err <= CMS_ATOL, (k, err, v.abs().max().item())
-        assert err <= 1e-5 * v.abs().max().item(), (k, err, v.abs().max().item())  # these heads are O(1e-3): relative bar as well
+        _head_close(out2[k], v, k)  # these heads are O(1e-3): relative bar as well
     one = {k: v.clone() for k, v in m(dev_frames[:1].contiguous()).items()}
     full = m(dev_frames)
     torch.cuda.synchronize()
@@ -648,7 +655,7 @@ def test_cfg2_single_instance_512_network_and_full_size_global_peaks():
     raw = layer.backend(img)["SingleInstanceConfmapsHead"]
     ref = O.model_forward(sd, bb, heads, "single_instance", img[:2])["SingleInstanceConfmapsHead"]
     assert tuple(raw.shape) == (B, N, 256, 256)
-    assert (raw[:2].cpu() - ref).abs().max().item() <= CMS_ATOL
+    _head_close(raw[:2], ref, "cfg2")
     rng = np.random.RandomState(4)
     pts = np.stack([np.clip(rng.uniform(120, S - 120, size=(1, 1, 2)) + rng.normal(0, 45, size=(1, N, 2)), 4, S - 5) for _ in range(B)]).astype(np.float32)
     cms = torch.stack([O.render_confmaps(pts[b], S, 2, 2.5 * 2 / 2) for b in range(B)])
@@ -1105,6 +1112,30 @@ def test_workspace_reuse_shrinks_the_footprint_and_changes_no_bit():
     full = L.check(L.lib().ph_model_workspace_bytes(big._handle, 32, 1024, 1024))
     print(f"cfg3 x 32 frames workspace: {full / 2**30:.2f} GiB one range per slot, {shared / 2**30:.2f} GiB shared")
     assert shared < 0.5 * full
+
+
+def test_unfused_program_with_shared_slots_survives_forwarded_writes():
+    """run-time fusions write the NEXT op's dst one op early (pool_peephole: a conv's epilogue writes the pool that
+    follows; fuse_gelu_fwd; dw_ln_fuse), so with workspace_reuse the plan must not give that dst a range the writing op is still
+    reading.  The Python Model never builds that combination (eval fuses the pools into the program, train keeps every slot); a C-API
+    user can: UNFUSED inference programs with workspace_reuse = 1 must give the bits of the one-range-per-slot plan."""
+    import bench
+    from sleap_nn_amd.architectures.model import Model
+
+    g = torch.Generator().manual_seed(5)
+    cases = [("unet", bench.CFG3_BB, bench.CFG3_HEADS, "bottomup", (2, 1, 256, 320)), ("convnext", bench.CFG4_BB, bench.CFG4_HEADS, "centered_instance", (2, 1, 96, 128))]
+    for backbone, bb, heads, mt, shape in cases:
+        img = torch.randint(0, 256, shape, dtype=torch.uint8, generator=g).to(DEV)
+        outs = []
+        for reuse in (0, 1):
+            m = Model(backbone, bb, heads, mt).init_xavier_(seed=3, head_scale=1.0).to(DEV)
+            m.set_fusion(False)  # the op-by-op program: conv -> pool pairs, Linear -> GELU pairs stay separate ops
+            m.set_option("workspace_reuse", reuse)
+            m.set_option("pool_peephole", 1)
+            outs.append({k: v.clone() for k, v in m(img).items()})
+            assert m.get_option("workspace_reuse") == float(reuse)
+        for k in outs[0]:
+            assert torch.isfinite(outs[0][k]).all() and torch.equal(outs[0][k], outs[1][k]), (backbone, k)
 
 
 def test_head_fused_into_the_conv_epilogue_matches_the_head_kernel_and_the_oracle():

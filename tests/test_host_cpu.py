@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in posehip.h but not exported"
     assert set(L.SIGNATURES) == declared
-    assert L.lib().ph_version() == 101
+    assert L.lib().ph_version() == 102
 
 
 def test_integration_binding_struct_matches_the_library():
@@ -544,3 +544,125 @@ def test_host_grouping_under_sanitizers(tmp_path):
     env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1")  # the interpreter itself "leaks" by design
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "sanitize_host.py"), so], capture_output=True, text=True, env=env, timeout=900, cwd=root)
     assert r.returncode == 0 and "sanitized host grouping: OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+def _recording_sleap_io():
+    """A stand-in for the `sleap_io` package (absent from this image): records what the packaging code hands it."""
+    import types
+
+    class PredictedInstance:
+        def __init__(self, **kw):
+            self.__dict__.update(kw)
+
+        @classmethod
+        def from_numpy(cls, points_data, point_scores=None, score=0.0, skeleton=None, track=None, tracking_score=None):
+            return cls(points=np.array(points_data, dtype=np.float32), point_scores=np.array(point_scores, dtype=np.float32), score=float(score),
+                       skeleton=skeleton, track=track, tracking_score=tracking_score)
+
+    class LabeledFrame:
+        def __init__(self, video=None, frame_idx=0, instances=(), **extra):
+            self.video, self.frame_idx, self.instances = video, int(frame_idx), list(instances)
+            assert all(not v for v in extra.values())  # pose outputs carry no centroids / masks / rois objects
+
+    class Labels:
+        def __init__(self, labeled_frames=(), videos=(), skeletons=()):
+            self.labeled_frames, self.videos, self.skeletons, self.tracks = list(labeled_frames), list(videos), list(skeletons), []
+
+    class Skeleton:
+        def __init__(self, nodes):
+            self.nodes = list(nodes)
+
+    class Track:
+        def __init__(self, name):
+            self.name = name
+
+    m = types.ModuleType("sleap_io")
+    m.PredictedInstance, m.LabeledFrame, m.Labels, m.Skeleton, m.Track = PredictedInstance, LabeledFrame, Labels, Skeleton, Track
+    return m
+
+
+def _same_instances(a, b):
+    assert len(a) == len(b)
+    for x, y in zip(a, b):
+        assert np.array_equal(x.points, y.points, equal_nan=True) and np.array_equal(x.point_scores, y.point_scores, equal_nan=True)
+        assert x.score == y.score and x.skeleton is y.skeleton and x.track is y.track and x.tracking_score == y.tracking_score
+
+
+def test_outputs_to_instances_and_to_labels(monkeypatch):
+    """`Outputs.to_instances` / `to_labels` (outputs.py:284-477, 612-779) on a recording stand-in for sleap_io: NaN slots dropped,
+    per-instance score = instance_scores or the nansum of the node scores, centroid-only packaging at the anchor node, multi-class
+    tracks by class index (top-down) or by slot (bottom-up), frame / video indices, loud on a missing video -- and, where the
+    reference tree is present, identical to the reference's own methods on the same tensors."""
+    import sys
+
+    from sleap_nn_amd.inference.outputs import Outputs
+
+    sio = _recording_sleap_io()
+    monkeypatch.setitem(sys.modules, "sleap_io", sio)
+    skel = sio.Skeleton(["a", "b", "c"])
+    nan = float("nan")
+    kp = torch.tensor([[[[1.0, 2.0], [3.0, 4.0], [nan, nan]], [[nan, nan]] * 3, [[5.0, 6.0], [nan, nan], [7.0, 8.0]]],
+                       [[[nan, nan]] * 3] * 3])
+    pv = torch.tensor([[[0.9, 0.8, nan], [nan, nan, nan], [0.5, nan, 0.25]], [[nan] * 3] * 3])
+    cases = {
+        "bottomup": dict(pred_keypoints=kp, pred_peak_values=pv, instance_scores=torch.tensor([[2.5, nan, 1.5], [nan, nan, nan]]),
+                         frame_indices=torch.tensor([7, 8]), video_indices=torch.tensor([1, 0])),
+        "single_instance": dict(pred_keypoints=kp[:, :1], pred_peak_values=pv[:, :1]),
+        "multiclass_topdown": dict(pred_keypoints=kp, pred_peak_values=pv, instance_scores=torch.tensor([[0.7, nan, 0.6], [nan] * 3]),
+                                   pred_class_inds=torch.tensor([[[1] * 3, [-1] * 3, [0] * 3], [[-1] * 3] * 3]),
+                                   instance_tracking_scores=torch.tensor([[0.95, nan, 0.85], [nan] * 3])),
+        "multiclass_bottomup": dict(pred_keypoints=kp, pred_peak_values=pv, instance_scores=torch.tensor([[0.7, nan, 0.6], [nan] * 3]),
+                                    instance_tracking_scores=torch.tensor([[0.4, nan, 0.3], [nan] * 3])),
+        "centroid_only": dict(pred_centroids=torch.tensor([[[10.0, 20.0], [nan, nan], [30.0, 40.0]], [[nan, nan]] * 3]),
+                              pred_centroid_values=torch.tensor([[0.8, nan, nan], [nan] * 3])),
+    }
+    tracks = [sio.Track("t0"), sio.Track("t1"), sio.Track("t2")]
+    videos = ["video0", "video1"]
+    ref_cls = None
+    from oracle import ref_harness as R
+
+    if R.reference_available():
+        R.install()
+        monkeypatch.setitem(sys.modules, "sleap_io", sio)  # the harness registers its own inert stand-in: ours must win
+        import importlib
+
+        ref_cls = importlib.import_module("sleap_nn.inference.outputs").Outputs
+    for name, kw in cases.items():
+        o = Outputs(**kw)
+        tr = tracks if name.startswith("multiclass") else None
+        got = [o.to_instances(skel, b, anchor_ind=1 if name == "centroid_only" else None, tracks=tr) for b in range(2)]
+        if name == "bottomup":
+            assert [len(g) for g in got] == [2, 0] and got[0][0].score == 2.5 and got[0][1].score == 1.5
+            assert np.isnan(got[0][0].points[2]).all() and got[0][1].point_scores[2] == 0.25
+        if name == "single_instance":
+            assert len(got[0]) == 1 and abs(got[0][0].score - 1.7) < 1e-6 and got[1] == []  # nansum of the node scores
+        if name == "multiclass_topdown":
+            assert [i.track.name for i in got[0]] == ["t1", "t0"] and [i.tracking_score for i in got[0]] == [pytest.approx(0.95), pytest.approx(0.85)]
+        if name == "multiclass_bottomup":
+            assert [i.track.name for i in got[0]] == ["t0", "t2"]  # the instance slot IS the class
+        if name == "centroid_only":
+            assert len(got[0]) == 2 and np.array_equal(got[0][0].points[1], [10.0, 20.0]) and np.isnan(got[0][0].points[[0, 2]]).all()
+            assert got[0][0].score == pytest.approx(0.8) and got[0][1].score == 0.0 and np.isnan(got[0][1].point_scores).all()
+            one = sio.Skeleton(["centroid"])
+            col = o.to_instances(skel, 0, collapse_skeleton=one)
+            assert len(col) == 2 and col[0].skeleton is one and col[0].points.shape == (1, 2)
+        lab = o.to_labels(skel, videos=videos if name == "bottomup" else None, anchor_ind=1 if name == "centroid_only" else None, tracks=tr)
+        assert len(lab.labeled_frames) == 1 and lab.skeletons == [skel]
+        if name == "bottomup":
+            f = lab.labeled_frames[0]
+            assert f.frame_idx == 7 and f.video == "video1" and lab.videos == videos
+        if tr is not None:
+            assert [t.name for t in lab.tracks] == sorted({i.track.name for i in lab.labeled_frames[0].instances}, key=[i.track.name for i in lab.labeled_frames[0].instances].index)
+        assert len(o.to_labels(skel, keep_empty_frames=True).labeled_frames) == 2
+        if ref_cls is not None:
+            r = ref_cls(**kw)
+            for b in range(2):
+                _same_instances(got[b], r.to_instances(skel, b, anchor_ind=1 if name == "centroid_only" else None, tracks=tr))
+            rl = r.to_labels(skel, videos=videos if name == "bottomup" else None, anchor_ind=1 if name == "centroid_only" else None, tracks=tr)
+            assert [f.frame_idx for f in rl.labeled_frames] == [f.frame_idx for f in lab.labeled_frames] and [f.video for f in rl.labeled_frames] == [f.video for f in lab.labeled_frames]
+            assert [t.name for t in rl.tracks] == [t.name for t in lab.tracks]
+    with pytest.raises(IndexError):
+        Outputs(pred_keypoints=kp, pred_peak_values=pv, video_indices=torch.tensor([2, 0])).to_labels(skel, videos=videos)
+    with pytest.raises(ValueError):
+        Outputs(**cases["centroid_only"]).to_instances(skel, 0, anchor_ind=5)
+    assert Outputs().to_instances(skel) == []
