@@ -200,7 +200,7 @@ def test_convnext_tiny_backward_matches_autograd():
 
 def test_cfg4_full_size_training_properties():
     """The benched cfg4 workload at FULL size -- ConvNeXt-tiny centered-instance, 64 crops of 384x384, 13 nodes, output stride 2 -- through
-    size-independent properties: every head output and gradient finite, the loss goes down over three Adam steps, the three steps are
+    size-independent properties: every head output and gradient finite, the loss goes down over four Adam steps, the steps are
     bitwise repeatable from the same start, and crop 0 of the 64-crop inference forward equals the 1-crop forward of the same crop."""
     from sleap_nn_amd.architectures.model import Model
     from sleap_nn_amd.data.targets import generate_multiconfmaps
@@ -219,14 +219,14 @@ def test_cfg4_full_size_training_properties():
     def run():
         m = Model("convnext", bb, heads, "centered_instance")
         m.init_xavier_(seed=1234, head_scale=0.05)
-        tm = TrainingModule(m, DEV, lr=1e-3, loss_weights=[1.0])
-        losses = [tm.training_step(batch).clone() for _ in range(3)]
+        tm = TrainingModule(m, DEV, lr=1e-4, loss_weights=[1.0])  # bench.py's optimizer (Adam at 1e-3 overshoots on 88 M xavier-initialised parameters)
+        losses = [tm.training_step(batch).clone() for _ in range(4)]
         torch.cuda.synchronize()
         assert bool(torch.isfinite(tm.grads).all()) and bool(torch.isfinite(tm.params).all())
         return [float(l[0]) for l in losses], tm.params.clone(), tm, m
 
     l1, p1, tm, m = run()
-    assert all(np.isfinite(l1)) and l1[2] < l1[0], l1
+    assert all(np.isfinite(l1)) and l1[3] < l1[0], l1
     tm.close()
     del tm, m
     torch.cuda.empty_cache()
@@ -277,14 +277,17 @@ def test_two_stage_topdown_on_convnext_backbones_matches_oracle():
     valid = ~torch.isnan(cp).any(-1)
     probe = fwd_i(O.crop_bboxes(img, O.make_centered_bboxes(cp[valid], crop, crop), valid.nonzero()[:, 0]))
     thr_i = float(probe.amax(dim=(2, 3)).min()) * 0.5  # every node of every crop is above threshold: no NaN pattern to flip
-    kp, kv, crops, bboxes, pts = O.topdown_stage2(img, cp, (crop, crop), fwd_i, 2, thr_i, "integral", 5)
+    # stage 2 without sub-pixel refinement: random-weight confidence maps take both signs, which makes the integral offsets (ratios of
+    # 25-term sums that may cancel) arbitrarily ill-conditioned -- the refinement arithmetic has its own tests (peaks.npz); this one is
+    # about the two-stage pipeline: crops, the ConvNeXt forward on them, the global arg-max and the crop offset
+    kp, kv, crops, bboxes, pts = O.topdown_stage2(img, cp, (crop, crop), fwd_i, 2, thr_i, None, 5)
 
     mc = Model("convnext", bb, hc, "centroid")
     mc.load_state_dict(sdc, strict=True)
     mi = Model("convnext", bb, hi, "centered_instance")
     mi.load_state_dict(sdi, strict=True)
     cl = CentroidLayer(HipBackend(mc, DEV), 2, max_instances=4, max_stride=32, postprocess_config=PostprocessConfig(peak_threshold=thr_c, max_instances=4))
-    il = CenteredInstanceLayer(HipBackend(mi, DEV), 2, max_stride=32, postprocess_config=PostprocessConfig(peak_threshold=thr_i))
+    il = CenteredInstanceLayer(HipBackend(mi, DEV), 2, max_stride=32, postprocess_config=PostprocessConfig(peak_threshold=thr_i, refinement="none"))
     raw = cl.backend(img)["CentroidConfmapsHead"].cpu()
     scale = max(1.0, float(ref_c.abs().max()))
     assert float((raw - ref_c).abs().max()) / scale <= ATOL
@@ -297,6 +300,6 @@ def test_two_stage_topdown_on_convnext_backbones_matches_oracle():
     assert np.array_equal(got_crops, crops.numpy())  # bit-exact uint8 crops
     k = out.pred_keypoints.cpu().numpy()
     assert np.array_equal(np.isnan(k), np.isnan(kp.numpy()))
-    assert np.allclose(k, kp.numpy(), atol=2e-3, equal_nan=True)
+    assert np.allclose(k, kp.numpy(), atol=1e-3, equal_nan=True)
     si = max(1.0, float(probe.abs().max()))
     assert np.allclose(out.pred_peak_values.cpu().numpy(), kv.numpy(), atol=ATOL * si, equal_nan=True)
