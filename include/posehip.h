@@ -209,7 +209,8 @@ int ph_debug_gemm_bench(int32_t variant, int32_t M, int32_t K, int32_t N, int32_
  * "conv_persist", "conv_c16", "conv_dma_stagger", "fuse_gelu_fwd", "fuse_gelu_bwd", "wgrad_rows", "convt_phase", "workspace_reuse" (1: activation slots of an inference forward share memory by lifetime),
  * "conv_precision" (0 exact fp32 MFMA | 1 split-fp16 MFMA, 22-bit products | 2 plain fp16, the reference's autocast mode),
  * "gemm_late_split", "gemm_persist2", "conv_gemm_fill", "conv_gemm_fill_wino", "conv_gemm_fill_wino2d",
- * "conv_wino2d" / "conv_w16" (the Winograd F(2x2,3x3) kernels), "head_fuse" (a 1x1 head computed in its producer conv's epilogue),
+ * "conv_wino2d" / "conv_w16" (the Winograd F(2x2,3x3) kernels), "conv_wino4" (K-heavy 3x3 convs on the Winograd F(4x4,3x3) kernel: 1 inference
+ * plans | 2 every plan | 0 never), "conv_wino4_min_cin", "upsample_fold" (a bilinear x2 read only by the next conv's second source rides in that kernel's input transform), "head_fuse" (a 1x1 head computed in its producer conv's epilogue),
  * "pool_peephole" (unfused programs: a conv writes the next op's 2x2 max pool), "dw_ln_fuse" (ConvNeXt: LayerNorm inside the
  * depthwise / stem kernels), "wgrad_wino" (3x3 weight gradients in the Winograd domain), "mask_fold" (ReLU masks applied by the kernel
  * that completes a gradient).

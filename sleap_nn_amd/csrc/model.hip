@@ -197,6 +197,7 @@ int choose_bn(int coutp) { return coutp >= 64 ? 64 : 32; }
 void apply_conv_options(const ph_model* m, ConvArgs& a) {
   a.use_wino = m->conv_wino;
   a.use_wino2d = m->conv_wino2d;
+  a.wino4_min_cin = m->conv_wino4_min_cin;
   a.use_w16 = m->conv_w16;
   a.persist = m->conv_persist;
   a.use_c16 = m->conv_c16;
@@ -250,6 +251,12 @@ int build_plan(const ph_model* m, int B, int H, int W, Plan& plan, int fmt) {
       const ph_op_desc& e = m->ops[j].d;
       if (e.src0 >= 0 && e.src0 < m->n_slots) last_use[e.src0] = j;
       if (e.src1 >= 0 && e.src1 < m->n_slots) last_use[e.src1] = j;
+    }
+  if (reuse)  // a bilinear op the next conv may fold into its input transform (ph_model_forward, PH_OP_UPSAMPLE): that conv then reads the op's SOURCE
+    for (int j = 0; j + 1 < n_ops; ++j) {
+      const ph_op_desc& e = m->ops[j].d;
+      const ph_op_desc& nx = m->ops[j + 1].d;
+      if (e.kind == PH_OP_UPSAMPLE && nx.kind == PH_OP_CONV && nx.src1 == e.dst && e.src0 >= 0 && e.src0 < m->n_slots) last_use[e.src0] = std::max(last_use[e.src0], j + 1);
     }
   plan.unread.assign(m->n_slots, 0);
   if (reuse)
@@ -614,6 +621,24 @@ ph_model* ph_model_create(const ph_op_desc* ops, int32_t n_ops, const float* con
           return true;
         };
         if (ok && !tr) ok = derive_wino2(op.w_dev, d.cin0, d.cin1, d.cout, op.bn, &op.w_wino2_dev);
+        // F(4x4,3x3) weights (conv3x3_wino4_kernel) of the layers with many input channels: 4x the direct weights' bytes
+        if (ok && !tr && op.bn == 64 && pad16(d.cin0) + (d.cin1 > 0 ? pad16(d.cin1) : 0) >= 128) {
+          const int ntiles = (pad16(d.cout) + 63) / 64, nchunks = pad16(d.cin0) / 16 + (d.cin1 > 0 ? pad16(d.cin1) / 16 : 0);
+          float* w = nullptr;
+          ok = hipMalloc(&w, (size_t)wino4_pack_floats(ntiles, nchunks) * sizeof(float)) == hipSuccess;
+          if (ok) {
+            m->allocs.push_back(w);
+            ok = launch_wino4_pack(op.w_dev, w, ntiles, nchunks, nullptr) == PH_OK;
+            DerivedBuffer db;
+            db.src = op.w_dev;
+            db.dst = w;
+            db.panels = ntiles;
+            db.bn = nchunks;
+            db.kind = 5;
+            m->derived.push_back(db);
+            op.w_wino4_dev = w;
+          }
+        }
         // wave-private F(2x2,3x3) weights (conv3x3_w16_kernel: 16 / 32 output channels, 16 / 32 input channels, one source): the forward
         // conv's, and below the data-gradient convs'
         auto derive_w16 = [&](const float* src, int cin_, int cout_, int bn, float** dst) {
@@ -892,12 +917,21 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
     rc = drain_events(m);
     if (rc != PH_OK) return rc;
   }
+  if (m->wino4_stale && (m->conv_wino4 == 2 || (m->conv_wino4 == 1 && plan.reuse))) {
+    for (const DerivedBuffer& db : m->derived)
+      if (db.kind == 5) {
+        rc = launch_wino4_pack(db.src, db.dst, db.panels, db.bn, s);
+        if (rc != PH_OK) return rc;
+      }
+    m->wino4_stale = false;
+  }
   size_t op_index = 0;
   m->last_variant.assign(m->ops.size(), PH_KV_NONE);
   int* const kv = m->last_variant.data();
   bool skip_next_gelu = false;
   int pooled_by_conv = -1;  // slot whose 2x2 max pool the producing conv's epilogue already wrote (run-time fusion of an unfused program, see PH_OP_CONV)
   std::vector<char> head_done(m->ops.size(), 0);  // head ops the producing conv's epilogue already computed (see PH_OP_CONV)
+  int deferred_up = -1;     // index of a bilinear op left to the conv that follows it (see PH_OP_UPSAMPLE / PH_OP_CONV)
   int fused_ln = -1;        // index of a LayerNorm op the producing depthwise conv already applied (see PH_OP_DWCONV)
   for (const PackedOp& op : m->ops) {
     const ph_op_desc& d = op.d;
@@ -1031,6 +1065,24 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
         a.w16 = op.w16_dev;
         a.zeros = m->zeros_dev;
         apply_conv_options(m, a);
+        a.wpack_wino4 = op.w_wino4_dev;
+        a.use_wino4 = m->conv_wino4 == 2 || (m->conv_wino4 == 1 && plan.reuse);
+        if (deferred_up >= 0) {
+          // The op before this one is a bilinear x2 that only feeds this conv's second source and was not launched: the F(4x4,3x3) kernel
+          // reads the half-resolution tensor itself (the up-sampling rides in its input transform); any other kernel gets the tensor now.
+          const ph_op_desc& up = m->ops[deferred_up].d;
+          const SlotShape& sl = plan.slots[up.src0];
+          ConvArgs f = a;
+          f.src1 = slot_ptr(up.src0);
+          f.src1_lowres = 1;
+          if (m->use_dma && conv3x3_dma_is_wino4(f)) {
+            a = f;
+          } else {
+            rc = launch_upsample(slot_ptr(up.src0), slot_ptr(up.dst), batch, sl.h, sl.w, sl.cp, s);
+            if (rc != PH_OK) return rc;
+          }
+          deferred_up = -1;
+        }
         const double fill = (double)s0.h * s0.w / ((double)((s0.h + 15) / 16 * 16) * ((s0.w + 31) / 32 * 32));
         // the halo kernel pads Cout to a multiple of its N tile (64): e.g. Cout = 96 does 33 % extra MFMA work there,
         // none in the row GEMM (N tiles of 96 / 128)
@@ -1045,7 +1097,7 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
           halo_fill = (double)s0.h * s0.w / ((double)((s0.h + 15) / 16 * 16) * ((s0.w + 15) / 16 * 16));
           halo_gain = m->gemm_fill_threshold / m->gemm_fill_threshold_wino2d;
         }
-        if (m->use_dma && d.dst2 < 0 && op.w_gemm_dev && (halo_fill * halo_gain < m->gemm_fill_threshold || n_fill * halo_fill * halo_gain < 0.8 * n_fill_g)) {
+        if (m->use_dma && d.dst2 < 0 && op.w_gemm_dev && !a.src1_lowres && (halo_fill * halo_gain < m->gemm_fill_threshold || n_fill * halo_fill * halo_gain < 0.8 * n_fill_g)) {
           // small feature map (the 16x32-pixel tiles of the halo kernel would be mostly padding) or a Cout that
           // fits the halo kernel's N tile badly -> 9-tap row GEMM
           GemmArgs g{};
@@ -1122,6 +1174,19 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
       }
       case PH_OP_UPSAMPLE: {
         const SlotShape& s0 = plan.slots[d.src0];
+        if (fmt == FMT_F32 && plan.reuse && m->upsample_fold && m->conv_wino4 && m->use_dma && op_index < m->ops.size()) {
+          // inference plans: when the NEXT op is a 3x3 conv that takes this tensor as its second source and nothing else reads it, the conv
+          // decides (it may run the F(4x4,3x3) kernel, which up-samples in its input transform) -- see PH_OP_CONV
+          const PackedOp& nxo = m->ops[op_index];
+          const ph_op_desc& nx = nxo.d;
+          bool only = nx.kind == PH_OP_CONV && nx.ksize == 3 && nx.src1 == d.dst && nx.src0 != d.dst && nx.dst2 < 0 && nxo.w_wino4_dev != nullptr;
+          for (size_t k = 0; only && k < m->ops.size(); ++k)
+            if (k != op_index && (m->ops[k].d.src0 == d.dst || m->ops[k].d.src1 == d.dst)) only = false;
+          if (only) {
+            deferred_up = (int)op_index - 1;
+            break;
+          }
+        }
         rc = fmt == FMT_F32 ? launch_upsample(slot_ptr(d.src0), slot_ptr(d.dst), batch, s0.h, s0.w, s0.cp, s)
                             : launch_upsample_fmt(fmt, slot_ptr(d.src0), slot_ptr(d.dst), batch, s0.h, s0.w, s0.cp, s);
         break;
@@ -1391,6 +1456,9 @@ std::vector<OptionRef> option_table(ph_model* m) {
       {"conv_wino", &m->conv_wino, nullptr},            // 1 Winograd F(2,3) 3x3 kernels, 2 only N-tile-64 layers, 0 direct 9-tap kernels
       {"conv_w16", &m->conv_w16, nullptr},              // 1: Cout-32 / Cin-16-or-32 3x3 convs on the wave-private F(2x2,3x3) kernel; 0: F(2,3) along x
       {"conv_wino2d", &m->conv_wino2d, nullptr},        // 1: N-tile-64 3x3 convs on the F(2x2,3x3) kernel; 0: F(2,3) along x only
+      {"conv_wino4", &m->conv_wino4, nullptr},          // K-heavy 3x3 convs on the F(4x4,3x3) kernel: 1 inference plans, 2 every plan, 0 never
+      {"conv_wino4_min_cin", &m->conv_wino4_min_cin, nullptr},  // padded input channels from which a layer takes it
+      {"upsample_fold", &m->upsample_fold, nullptr},    // bilinear x2 folded into the F(4x4,3x3) input transform of the conv that consumes it
       {"stem_wino", &m->stem_wino, nullptr},            // second conv of the fused stem in Winograd form
       {"dgrad_wino", &m->dgrad_wino, nullptr},          // 0: direct 9-tap kernels for the backward's data-gradient convs
       {"conv_dma", &m->use_dma, nullptr},               // 0: register-staged 3x3 kernel instead of the LDS-DMA family

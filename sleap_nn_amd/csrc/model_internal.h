@@ -36,6 +36,7 @@ struct PackedOp {
   float* wd_w16_dev[2] = {nullptr, nullptr};  // ... and from wd_dev (data gradient)
   float* w_wino2_dev = nullptr;            // 3x3 conv, N tile 64: Winograd F(2x2,3x3) weights derived from w_dev
   float* wd_wino2_dev[2] = {nullptr, nullptr};  // ... and from wd_dev (data gradient)
+  float* w_wino4_dev = nullptr;            // 3x3 conv, N tile 64, >= 128 padded input channels: Winograd F(4x4,3x3) weights derived from w_dev
   // ConvTranspose2d(k3, s2, p1, op1) as four output-phase row GEMMs (mode 3) + its data gradient (mode 4)
   float* wt_phase_dev[4] = {nullptr, nullptr, nullptr, nullptr};
   float* bt_dev = nullptr;       // bias padded to the GEMM's N tiles
@@ -61,7 +62,7 @@ struct DerivedBuffer {
   const float* src = nullptr;
   float* dst = nullptr;
   int panels = 0, bn = 0;  // bn == 0: the fused stem's second conv (launch_stem_wino_pack)
-  int kind = 0;            // 0: Winograd transform of src; 1: fp16 weight pack of the LDS-DMA panels (launch_f16_weight_pack); 2: F(2x2,3x3) transform; 3: wave-private F(2x2,3x3) transform (panels = chunks); 4: the fused stem's F(2x2,3x3) transform
+  int kind = 0;            // 0: Winograd transform of src; 1: fp16 weight pack of the LDS-DMA panels (launch_f16_weight_pack); 2: F(2x2,3x3) transform; 3: wave-private F(2x2,3x3) transform (panels = chunks); 4: the fused stem's F(2x2,3x3) transform; 5: F(4x4,3x3) transform (panels = N tiles, bn = 16-channel chunks)
   int n_tiles = 0, chunks0 = 0, chunks1 = 0, plain = 0;  // kind 1
 };
 
@@ -110,6 +111,7 @@ struct ph_model {
   std::vector<int64_t> weight_offset;          // canonical arena offset of weights[i] (ph_model_create order)
   std::vector<int64_t> weight_numel;
   int64_t n_params = 0;
+  bool wino4_stale = false;                    // ph_model_set_params skipped the F(4x4,3x3) weights (training handle): refresh before their next use
   std::vector<ph::DerivedBuffer> derived;      // refreshed after the gathers of ph_model_set_params
   std::vector<ph::PackedBuffer> packed;        // every packed weight buffer, for ph_model_set_params
   // ---- per-handle options (ph_model_set_option); the library reads no environment variables
@@ -118,6 +120,9 @@ struct ph_model {
   int conv_wino = 1;                          // "conv_wino": Winograd F(2,3) 3x3 kernels (2: N-tile-64 layers only, 0: direct 9-tap kernels)
   int conv_w16 = 1;                           // "conv_w16": Cout-32 / Cin-16-or-32 3x3 convs on the wave-private F(2x2,3x3) kernel
   int conv_wino2d = 1;                        // "conv_wino2d": N-tile-64 3x3 convs on the F(2x2,3x3) kernel (0: the F(2,3)-along-x kernel)
+  int conv_wino4 = 1;                         // "conv_wino4": K-heavy N-tile-64 3x3 convs on the F(4x4,3x3) kernel: 1 in inference plans (workspace_reuse), 2 in every plan, 0 never
+  int conv_wino4_min_cin = 192;               // "conv_wino4_min_cin": padded input channels (both sources) from which a layer takes that kernel
+  int upsample_fold = 1;                      // "upsample_fold": a bilinear x2 whose only reader is the next conv's second source is folded into that conv's F(4x4,3x3) input transform (inference plans)
   int dgrad_wino = 1;                         // "dgrad_wino": 0 = direct 9-tap kernels for the backward's data-gradient convs (A/B: ~7 % slower cfg3 step, same gradients to the digit)
   int stem_wino = 2;                          // "stem_wino"
   int conv_persist = 1;                       // "conv_persist"

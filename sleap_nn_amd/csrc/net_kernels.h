@@ -40,6 +40,11 @@ struct ConvArgs {
   int use_wino = 1;   // 1: Winograd F(2,3) kernel where wpack_wino exists; 2: only for the N-tile-64 layers; 0: direct 9-tap kernel
   int persist = 1;    // persistent workgroups (one per CU) instead of one tile per workgroup
   int use_c16 = 1;    // 16 -> 16 channel layers on conv3x3_c16_kernel
+  // Winograd F(4x4,3x3) (conv3x3_wino4_kernel, wino4_kernels.hip): layers with at least wino4_min_cin padded input channels
+  const float* wpack_wino4 = nullptr;  // transformed weights in the kernel's private-ring order, or nullptr
+  int use_wino4 = 0;          // filled from the handle option "conv_wino4" and the kind of plan
+  int wino4_min_cin = 192;    // handle option "conv_wino4_min_cin"
+  int src1_lowres = 0;        // src1 is (B, H/2, W/2, c1p): bilinear x2 (align_corners = False) is folded into the input transform (wino4 only)
 };
 
 struct InputConvArgs {
@@ -155,6 +160,13 @@ int conv3x3_dma_variant(const ConvArgs& a);        // PH_KV_* code (posehip.h) o
 int launch_wino2d_pack(const float* wpack, float* wino, int panels, int bn, hipStream_t s);
 int64_t wino2d_pack_floats(int panels, int bn);
 int launch_conv3x3_wino2d(const ConvArgs& a, hipStream_t s);
+// wpack [panel][tap 9][64][16] -> F(4x4,3x3) weights [n tile][quarter][wave][xi pair][lane][4] (see conv3x3_wino4_kernel)
+int launch_wino4_pack(const float* wpack, float* wino, int ntiles, int nchunks, hipStream_t s);
+int64_t wino4_pack_floats(int ntiles, int nchunks);
+int launch_conv3x3_wino4(const ConvArgs& a, hipStream_t s);
+bool wino4_fits(const ConvArgs& a);
+bool conv3x3_dma_is_wino4(const ConvArgs& a);      // launch_conv3x3_dma would run the F(4x4,3x3) kernel (the only one that folds a half-resolution src1)
+int prepare_wino4_kernels();
 bool wino2d_fits(const ConvArgs& a);  // sources addressable through the kernel's 32-bit buffer descriptors
 int prepare_wino2d_kernels();
 // wpack [chunk][tap 9][32][16] -> wave-private F(2x2,3x3) weights [chunk][position][N block][kq][n][4] (see conv3x3_w16_kernel)

@@ -1304,9 +1304,10 @@ static int cu_count(int* out) { return device_cu_count(out); }
 
 // Kernel choice for a 3x3 "same" conv on the LDS-DMA family.  Which variant runs is decided by fields of `a` that the
 // model runtime fills from the handle's options (ph_model_set_option); there is no process-global state here.
-// which kernel launch_conv3x3_dma picks: 1 wave-private F(2x2,3x3), 0 conv3x3_c16, 2 wave-split F(2x2,3x3), 3 the F(2,3) / direct halo kernels
+// which kernel launch_conv3x3_dma picks: 4 F(4x4,3x3), 1 wave-private F(2x2,3x3), 0 conv3x3_c16, 2 wave-split F(2x2,3x3), 3 the F(2,3) / direct halo kernels
 static int conv3x3_dma_route(const ConvArgs& a) {
   const bool wino = a.use_wino && a.wpack_wino && (a.bn == 64 || a.use_wino != 2);  // use_wino 2: Winograd for the N-tile-64 layers only
+  if (wino && a.persist && a.use_wino4 && a.c0p + a.c1p >= a.wino4_min_cin && wino4_fits(a)) return 4;
   if (wino && a.persist && a.use_w16 && w16_fits(a)) return 1;
   if (a.use_c16 && a.w16 && a.c0p == 16 && a.coutp == 16 && !a.src1 && !a.dst_pool) return 0;
   if (wino && a.persist && a.use_wino2d && a.wpack_wino2 && a.bn == 64 && a.c0p + a.c1p >= 32 && wino2d_fits(a)) return 2;
@@ -1315,12 +1316,14 @@ static int conv3x3_dma_route(const ConvArgs& a) {
 bool conv3x3_dma_honours_mask(const ConvArgs& a) { return conv3x3_dma_route(a) == 1; }
 bool conv3x3_dma_is_f2x2(const ConvArgs& a) { const int r = conv3x3_dma_route(a); return r == 1 || r == 2; }
 bool conv3x3_dma_is_wino2d(const ConvArgs& a) { return conv3x3_dma_route(a) == 2; }
+bool conv3x3_dma_is_wino4(const ConvArgs& a) { return conv3x3_dma_route(a) == 4; }
 // PH_KV_* code of the kernel launch_conv3x3_dma would run (ph_model_last_kernels)
 int conv3x3_dma_variant(const ConvArgs& a) {
   switch (conv3x3_dma_route(a)) {
     case 0: return PH_KV_C16;
     case 1: return PH_KV_W16;
     case 2: return PH_KV_WINO2D;
+    case 4: return PH_KV_WINO4;
     default: break;
   }
   const bool wino = a.use_wino && a.wpack_wino && (a.bn == 64 || a.use_wino != 2);
@@ -1335,6 +1338,8 @@ int launch_conv3x3_dma(const ConvArgs& a, hipStream_t s) {
   if (route == 1) return launch_conv3x3_w16(a, s);
   if (route == 0) return launch_conv3x3_c16(a, s);
   if (route == 2) return launch_conv3x3_wino2d(a, s);
+  if (route == 4) return launch_conv3x3_wino4(a, s);
+  PH_REQUIRE(!a.src1_lowres, "a half-resolution second source is only taken by the F(4x4,3x3) kernel (ask conv3x3_dma_is_wino4 first)");
   const int tiles = ((a.W + TW - 1) / TW) * ((a.H + D_TH - 1) / D_TH) * a.B;
   const int ntc = (a.coutp + a.bn - 1) / a.bn;
   const bool wino = a.use_wino && a.wpack_wino && (a.bn == 64 || a.use_wino != 2);
@@ -2091,7 +2096,9 @@ int prepare_kernels() {
     return PH_E_HIP;
   }
   const int rc2 = prepare_wino2d_kernels();
-  return rc2 != PH_OK ? rc2 : prepare_w16_kernels();
+  if (rc2 != PH_OK) return rc2;
+  const int rc3 = prepare_wino4_kernels();
+  return rc3 != PH_OK ? rc3 : prepare_w16_kernels();
 }
 
 }  // namespace ph

@@ -154,6 +154,15 @@ int ph_model_set_params(ph_model* m, const float* params_flat_dev, void* stream)
   }
   for (const DerivedBuffer& db : m->derived) {
     if ((db.kind == 0 && db.bn != 0) || db.kind == 2) continue;  // in the two launches above
+    if (db.kind == 5) {  // F(4x4,3x3) weights: only inference plans read them (conv_wino4 = 1) -- a training step does not pay for the re-derivation,
+      if (m->conv_wino4 != 2 && !m->workspace_reuse) {  // the next forward that wants them refreshes them (ph_model_forward)
+        m->wino4_stale = true;
+        continue;
+      }
+      const int rc5 = launch_wino4_pack(db.src, db.dst, db.panels, db.bn, static_cast<hipStream_t>(stream));
+      if (rc5 != PH_OK) return rc5;
+      continue;
+    }
     int rc = db.kind == 1 ? launch_f16_weight_pack(db.src, db.dst, db.n_tiles, db.chunks0, db.chunks1, db.bn, db.plain, static_cast<hipStream_t>(stream))
              : db.kind == 3 ? launch_w16_pack(db.src, db.dst, db.panels, db.bn, static_cast<hipStream_t>(stream))
              : db.kind == 4 ? launch_stem_wino2d_pack(db.src, db.dst, static_cast<hipStream_t>(stream))

@@ -1,0 +1,461 @@
+// 3x3 "same" convolution as Winograd F(4x4, 3x3) on the fp32 matrix cores (gfx950), for the K-heavy decoder layers.
+//
+// Reference semantics: nn.Conv2d(k3, padding "same") + bias + ReLU of SimpleConvBlock (architectures/encoder_decoder.py:108-121,
+// 494-510) over torch.concat((skip, x)) (encoder_decoder.py:545,556) where x may be nn.Upsample(x2, bilinear, align_corners=False)
+// of a half-resolution tensor (encoder_decoder.py:431-435): the up-sampling is folded into the input transform, the
+// up-sampled tensor never exists.
+//
+//   Y = A^T [ (G g G^T) (.) (B^T d B) ] A     per 4x4 output tile, 6x6 input patch d, 3x3 filter g
+//
+// 36 multiplications per sixteen outputs instead of 144: the matrix cores execute 1/4 of the direct convolution's FLOPs
+// (F(2x2,3x3): 4/9).  fp32 throughout; the transforms have coefficients up to 8 (A), 5 (B) and 1/24 (G): measured against the fp64
+// convolution the result is ~5x further off than F(2x2,3x3) (1e-5 relative max at K = 768), which is why only
+// layers with many input channels -- where the MFMA work dominates and the heads' 1e-4 bar has room -- run here.
+//
+//   * GEMM view: per Winograd position (xi, nu) one GEMM with M = 4x4-pixel tiles, N = output channels, K = input channels.  A workgroup
+//     tile is 8 x 4 Winograd tiles (32 x 16 output pixels) x 64 channels; all 36 positions x (32 tiles x 64 channels) accumulators
+//     (288 KiB) live in the registers of TWELVE waves: wave (nu, nt) owns column nu of the transformed patch for the 32-channel N tile nt
+//     (six 32x32 accumulators, 96 registers; three waves per SIMD).  The product is accumulated transposed (weights = A operand): a lane
+//     is a tile, a register quad four consecutive channels.
+//   * K runs in QUARTERS (4 input channels = two K steps of v_mfma_f32_32x32x2_f32).  Per quarter the workgroup transforms the raw
+//     34 x 18 halo of the NEXT quarter into V[36][32 tiles][4 channels] in LDS -- thread (tile, channel, xi) computes row xi of
+//     B^T d B from the patch rows its xi combines: every thread of the 768 has one unit, nothing is computed twice -- while it multiplies
+//     the current quarter: each wave reads its six B fragments from V and its six A fragments from a PRIVATE two-slot weight ring
+//     (a wave's (nu, nt) weights are read by nobody else), 12 MFMAs.  One s_barrier per quarter.
+//   * Transfers: the raw halo (three slots, three quarters ahead) and the weights (two quarters ahead) arrive by buffer-descriptor
+//     LDS-DMA exactly as in conv3x3_wino2d_kernel: per-lane offsets fixed per tile, the quarter's channel offset in the scalar offset,
+//     out-of-image pixels out of range = hardware zeros.  Four DMA instructions per wave and quarter, s_waitcnt vmcnt(4) before the barrier.
+//   * Second source at half resolution (ConvArgs::src1_lowres): its slot holds the 18 x 10 LOW-resolution halo (index-clamped by the
+//     loader like the bilinear kernel clamps), the row pass applies B^T U (U = the 6 x 4 bilinear matrix of the patch rows, rows
+//     outside the image zeroed: the conv's padding) as four per-lane coefficients, the column pass forms the six up-sampled column
+//     samples first: 16 instead of 24 LDS reads and about the same arithmetic as a full-resolution quarter.
+//   * Epilogue: the row pass of A^T . A is register arithmetic in the owning wave (six xi -> four output rows), the column pass needs
+//     all six nu = six waves: one N tile at a time goes through LDS (96 KiB), every wave finishes its share of (row, channel quad)
+//     units: bias, ReLU, 16-byte stores.  The pipeline is drained at a tile's end (no cross-tile prefetch): the layers this kernel
+//     runs have >= 32 quarters per tile.
+#include <type_traits>
+
+#include "common.h"
+#include "net_kernels.h"
+
+namespace ph {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int W4_TX = 8, W4_TY = 4;             // Winograd tiles per workgroup tile
+constexpr int W4_PW = 4 * W4_TX;                // 32 output columns
+constexpr int W4_PH = 4 * W4_TY;                // 16 output rows
+constexpr int W4_RAW_FLOATS = 12 * 256;         // one raw halo slot: 12 DMA pieces of 64 entries x 16 B (648 entries used: [hy 18][x & 3][x >> 2: 9])
+constexpr int W4_V_FLOATS = 36 * 128;           // one V slot: [nu 6][xi pair 3][lane 64][4]
+constexpr int W4_W_FLOATS = 3 * 256;            // one private weight slot of a wave: [xi pair 3][lane 64][4]
+constexpr int W4_RAW_OFF = 0;                   // three raw slots
+constexpr int W4_V_OFF = 3 * W4_RAW_FLOATS;     // two V slots
+constexpr int W4_W_OFF = W4_V_OFF + 2 * W4_V_FLOATS;  // twelve waves x two weight slots
+constexpr int W4_LDS_FLOATS = W4_W_OFF + 12 * 2 * W4_W_FLOATS;  // 36864 floats = 144 KiB
+constexpr int W4_Q_FLOATS = 12 * W4_W_FLOATS;   // transformed weights of one (N tile, quarter): 36 positions x 64 channels x 4 input channels
+
+// wpack [panel][tap 9][bn 64][16] (pack_conv) -> U = G g G^T in the order the kernel's private weight rings take it:
+// [n tile][quarter][wave pw = nt * 6 + nu][xi pair p][lane (lh, lx)][e = (xi & 1) * 2 + j]: output channel n tile * 64 + nt * 32 + lx,
+// input channel quarter * 4 + 2 lh + j, position (xi = 2 p + (e >> 1), nu)
+__device__ __forceinline__ float wino4_pack_element(const float* __restrict__ src, int nchunks, size_t i) {
+  const int e = (int)(i & 3), lane = (int)((i >> 2) & 63);
+  size_t r = i >> 8;
+  const int p = (int)(r % 3);
+  r /= 3;
+  const int pw = (int)(r % 12);
+  r /= 12;
+  const int quarter = (int)(r % (size_t)(4 * nchunks));
+  const int ntile = (int)(r / (size_t)(4 * nchunks));
+  const int nu = pw % 6, nt = pw / 6, lx = lane & 31, lh = lane >> 5;
+  const int xi = 2 * p + (e >> 1), j = e & 1;
+  const int row = nt * 32 + lx, kc = (quarter & 3) * 4 + 2 * lh + j, chunk = quarter >> 2;
+  const float* w = src + (((size_t)ntile * nchunks + chunk) * 9 * 64 + row) * 16 + kc;
+  const size_t ts = (size_t)64 * 16;  // tap stride
+  auto grow = [](int k, float g0, float g1, float g2) -> float {  // row k of G applied to (g0, g1, g2)
+    switch (k) {
+      case 0: return 0.25f * g0;
+      case 1: return (-1.f / 6.f) * ((g0 + g2) + g1);
+      case 2: return (-1.f / 6.f) * ((g0 + g2) - g1);
+      case 3: return (1.f / 24.f) * g0 + ((1.f / 12.f) * g1 + (1.f / 6.f) * g2);
+      case 4: return (1.f / 24.f) * g0 + ((-1.f / 12.f) * g1 + (1.f / 6.f) * g2);
+      default: return g2;
+    }
+  };
+  float h[3];
+#pragma unroll
+  for (int kx = 0; kx < 3; ++kx) h[kx] = grow(xi, w[(0 * 3 + kx) * ts], w[(1 * 3 + kx) * ts], w[(2 * 3 + kx) * ts]);
+  return grow(nu, h[0], h[1], h[2]);
+}
+__global__ __launch_bounds__(256) void wino4_pack_kernel(const float* __restrict__ src, float* __restrict__ dst, int ntiles, int nchunks) {
+  const size_t total = (size_t)ntiles * 4 * nchunks * W4_Q_FLOATS;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) dst[i] = wino4_pack_element(src, nchunks, i);
+}
+int64_t wino4_pack_floats(int ntiles, int nchunks) { return (int64_t)ntiles * 4 * nchunks * W4_Q_FLOATS; }
+int launch_wino4_pack(const float* wpack, float* wino, int ntiles, int nchunks, hipStream_t s) {
+  const int64_t n = wino4_pack_floats(ntiles, nchunks);
+  hipLaunchKernelGGL(wino4_pack_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 8192)), dim3(256), 0, s, wpack, wino, ntiles, nchunks);
+  PH_HIP_CHECK(hipGetLastError());
+  return PH_OK;
+}
+
+__device__ __forceinline__ void w4_deal_tile(int id, int tiles, int nt_count, int* tile, int* ntile) {
+  // as w2_deal_tile: every XCD walks a contiguous range of pixel tiles, the N tiles of one pixel tile sit on one XCD
+  if ((tiles & 7) == 0) {
+    const int xcd = id & 7, j = id >> 3;
+    *ntile = j % nt_count;
+    *tile = xcd * (tiles >> 3) + j / nt_count;
+  } else {
+    *ntile = id % nt_count;
+    *tile = id / nt_count;
+  }
+}
+
+// v[nu] = sum_c B^T[nu][c] t[c] (shared sub-expressions: 14 operations)
+__device__ __forceinline__ void w4_col_pass(const float (&t)[6], float (&v)[6]) {
+  const float a = fmaf(-4.f, t[2], t[4]);
+  const float b = fmaf(-4.f, t[1], t[3]);
+  const float c = t[4] - t[2];
+  const float d0 = t[3] - t[1];
+  const float d = d0 + d0;
+  v[0] = fmaf(4.f, t[0], fmaf(-5.f, t[2], t[4]));
+  v[1] = a + b;
+  v[2] = a - b;
+  v[3] = c + d;
+  v[4] = c - d;
+  v[5] = fmaf(4.f, t[1], fmaf(-5.f, t[3], t[5]));
+}
+
+__global__ __launch_bounds__(768) void conv3x3_wino4_kernel(ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int pw = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave 0..11
+  // consumer role: column nu of the transformed patch, N tile nt (32 channels)
+  const int nu = pw % 6, nt = pw / 6;
+  const int lx = lane & 31, lh = lane >> 5;
+  // producer role: thread = (Winograd tile (typ, txp), channel cp of the quarter, row xip of B^T d B); a half wave = 8 tiles x 4 channels
+  const int xip = pw >> 1;
+  const int typ = 2 * (pw & 1) + (lane >> 5), txp = (lane >> 2) & 7, cp = lane & 3;
+
+  const int tiles_x = (a.W + W4_PW - 1) / W4_PW;
+  const int tiles_y = (a.H + W4_PH - 1) / W4_PH;
+  const int tiles = tiles_x * tiles_y * a.B;
+  const int ntc = (a.coutp + 63) / 64;
+  const int total = tiles * ntc;
+  const int Q0 = a.c0p / 4, Q1 = a.c1p / 4, Q = Q0 + Q1;
+  const int lowres = a.src1_lowres;
+  const int Hl = a.H >> 1, Wl = a.W >> 1;
+
+  float* const rawbuf = lds + W4_RAW_OFF;
+  float* const vbuf = lds + W4_V_OFF;
+  float* const wring = lds + W4_W_OFF + pw * 2 * W4_W_FLOATS;
+
+  // ---- producer constants.  Row pass of a full-resolution quarter: t[c] = sum_i k[i] * d[row r0 + i * rs][c], i < 3 or 4:
+  //   xi 0: rows 0 2 4, (4, -5, 1)     xi 5: rows 1 3 5, (4, -5, 1)     xi 1..4: rows 1 2 3 4, (-4 -4 1 1) (4 -4 -1 1) (-2 -1 2 1) (2 -1 -2 1)
+  const bool tri = xip == 0 || xip == 5;
+  const int r0 = xip == 0 ? 0 : 1, rs = tri ? 2 : 1;
+  float k0, k1, k2, k3;
+  switch (xip) {
+    case 0: case 5: k0 = 4.f; k1 = -5.f; k2 = 1.f; k3 = 0.f; break;
+    case 1: k0 = -4.f; k1 = -4.f; k2 = 1.f; k3 = 1.f; break;
+    case 2: k0 = 4.f; k1 = -4.f; k2 = -1.f; k3 = 1.f; break;
+    case 3: k0 = -2.f; k1 = -1.f; k2 = 2.f; k3 = 1.f; break;
+    default: k0 = 2.f; k1 = -1.f; k2 = -2.f; k3 = 1.f; break;
+  }
+  // raw slot entry of halo pixel (hy, hx): hy * 36 + (hx & 3) * 9 + (hx >> 2); patch column c of tile txp is hx = 4 txp + c
+  const int pbase_f = ((4 * typ + r0) * 36 + txp) * 4 + cp;                     // floats, row r0, column 0
+  const int prow_f = rs * 36 * 4;                                                // floats per row step
+  const int prow3_f = (tri ? 2 : 3) * prow_f;                                    // the fourth row (coefficient 0 for xi = 0, 5: re-reads the third)
+  // low-resolution slot entry of (ly, lc): ly * 18 + (lc & 1) * 9 + (lc >> 1); the tile's 4 x 4 low-resolution patch starts at (2 typ, 2 txp)
+  const int pbase_l = ((2 * typ) * 18 + txp) * 4 + cp;
+  // V write index of this thread for nu = 0: ((nu * 3 + (xi >> 1)) * 64 + (c >> 1) * 32 + tile) * 4 + (xi & 1) * 2 + (c & 1)
+  const int vw0 = (((xip >> 1)) * 64 + (cp >> 1) * 32 + typ * 8 + txp) * 4 + (xip & 1) * 2 + (cp & 1);
+  const int vr0 = (nu * 3 * 64 + lane) * 4;  // V read of (nu, xi pair 0)
+
+  struct Plan {
+    int b, x0, y0, ntile;
+  };
+  auto setup = [&](int vid, Plan& P) {
+    int t, ntile;
+    w4_deal_tile(vid, tiles, ntc, &t, &ntile);
+    const int tx = t % tiles_x;
+    t /= tiles_x;
+    const int ty = t % tiles_y;
+    P.b = t / tiles_y;
+    P.x0 = tx * W4_PW;
+    P.y0 = ty * W4_PH;
+    P.ntile = ntile;
+  };
+
+  // weights: buffer descriptor over the whole transformed tensor, wave pw moves its own 3 KiB of a quarter as three pieces
+  const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.wpack_wino4, 0, (int)((unsigned)ntc * (unsigned)Q * (unsigned)(W4_Q_FLOATS * 4)), 0x00020000);
+  const unsigned w_lane = (unsigned)(pw * W4_W_FLOATS + lane * 4) * 4u;
+
+  for (int vid = blockIdx.x; vid < total; vid += gridDim.x) {
+    Plan P;
+    setup(vid, P);
+    // ---- per-tile loader state: this lane's halo entry of source 0 (piece pw of the full-resolution layout) and of source 1
+    unsigned off0, off1;
+    {
+      const int e = pw * 64 + lane;  // entry of the raw slot (piece pw; pieces 0..10 hold the 648 entries, wave 11's piece is unused)
+      const int hy = e / 36, rem = e - hy * 36;
+      const int pl = rem / 9, k = rem - pl * 9;
+      const int hx = 4 * k + pl;
+      const int gy = P.y0 + hy - 1, gx = P.x0 + hx - 1;
+      const bool in = hy < W4_PH + 2 && hx < W4_PW + 2 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+      off0 = in ? (unsigned)((P.b * a.H + gy) * a.W + gx) * (unsigned)(a.c0p * 4) : 0xFFFFFF00u;
+      if (!lowres) {
+        off1 = (in && a.c1p > 0) ? (unsigned)((P.b * a.H + gy) * a.W + gx) * (unsigned)(a.c1p * 4) : 0xFFFFFF00u;
+      } else {
+        // low-resolution layout: entry ly * 18 + (lc & 1) * 9 + (lc >> 1), 180 entries in pieces 0..2; indices clamped (bilinear's edge rule)
+        const int ly = e / 18, rem2 = e - ly * 18;
+        const int par = rem2 / 9, kk = rem2 - par * 9;
+        const int lc = 2 * kk + par;
+        const int sy = min(max((P.y0 >> 1) - 1 + ly, 0), Hl - 1), sx = min(max((P.x0 >> 1) - 1 + lc, 0), Wl - 1);
+        off1 = (ly < W4_PH / 2 + 2) ? (unsigned)((P.b * Hl + sy) * Wl + sx) * (unsigned)(a.c1p * 4) : 0xFFFFFF00u;
+      }
+    }
+    const __amdgpu_buffer_rsrc_t rsrc0 = __builtin_amdgcn_make_buffer_rsrc((void*)a.src0, 0, (int)((unsigned)(a.B * a.H * a.W) * (unsigned)(a.c0p * 4)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc1 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.src1 ? a.src1 : a.src0), 0,
+                                                                           (int)((unsigned)(lowres ? a.B * Hl * Wl : a.B * a.H * a.W) * (unsigned)(a.c1p * 4)), 0x00020000);
+    auto issue_raw = [&](int k) {  // halo of quarter k into raw slot k % 3 (out of range beyond the tile's last quarter)
+      float* dst = rawbuf + (k % 3) * W4_RAW_FLOATS + pw * 256;
+      if (k < Q0)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc0, (__attribute__((address_space(3))) void*)dst, 16, off0, k * 16, 0, 0);
+      else if (k < Q)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc1, (__attribute__((address_space(3))) void*)dst, 16, off1, (k - Q0) * 16, 0, 0);
+      else
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc0, (__attribute__((address_space(3))) void*)dst, 16, 0xFFFFFF00u, 0, 0, 0);
+    };
+    const int w_tile = P.ntile * Q * (W4_Q_FLOATS * 4);
+    auto issue_w = [&](int k) {  // weights of quarter k into this wave's ring slot k & 1
+      __attribute__((address_space(3))) void* l = (__attribute__((address_space(3))) void*)(wring + (k & 1) * W4_W_FLOATS);
+      const unsigned lo = k < Q ? w_lane : 0xFFFFFF00u;
+      const int so = k < Q ? w_tile + k * (W4_Q_FLOATS * 4) : 0;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, l, 16, lo, so, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, l, 16, lo, so, 1024, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, l, 16, lo, so, 2048, 0);
+    };
+
+    // low-resolution row coefficients C[xip][m] = sum_r B^T[xip][r] U[r][m] of this thread's tile row (rows of the up-sampled patch that fall
+    // outside the image are the conv's zero padding) and the zero masks of patch columns 0 and 5
+    float cl0 = 0.f, cl1 = 0.f, cl2 = 0.f, cl3 = 0.f, zx0 = 1.f, zx5 = 1.f;
+    if (lowres) {
+      const float bt[6][6] = {{4, 0, -5, 0, 1, 0}, {0, -4, -4, 1, 1, 0}, {0, 4, -4, -1, 1, 0}, {0, -2, -1, 2, 1, 0}, {0, 2, -1, -2, 1, 0}, {0, 4, 0, -5, 0, 1}};
+      float cl[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {
+        const int Y = P.y0 + 4 * typ - 1 + r;
+        float btv = 0.f;
+#pragma unroll
+        for (int x = 0; x < 6; ++x) btv = xip == x ? bt[x][r] : btv;
+        if (Y < 0 || Y >= a.H) btv = 0.f;
+        const float w0 = (r & 1) ? 0.25f : 0.75f;  // r even <-> Y odd: 0.75 * l[m] + 0.25 * l[m + 1]; r odd: 0.25 / 0.75 (align_corners = False)
+        cl[r >> 1] += btv * w0;
+        cl[(r >> 1) + 1] += btv * (1.f - w0);
+      }
+      cl0 = cl[0];
+      cl1 = cl[1];
+      cl2 = cl[2];
+      cl3 = cl[3];
+      zx0 = (P.x0 + 4 * txp - 1 < 0) ? 0.f : 1.f;
+      zx5 = (P.x0 + 4 * txp + 4 >= a.W) ? 0.f : 1.f;
+    }
+
+    // ---- the input transform of quarter k (raw slot k % 3 -> V slot k & 1), split in three parts so that MFMAs can sit between them
+    float tt[6];
+    auto t_rows = [&](int k) {
+      const float* raw = rawbuf + (k % 3) * W4_RAW_FLOATS;
+      if (k >= Q0 && lowres) {
+        const float* p = raw + pbase_l;
+        float tl[4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+          const int co = ((n & 1) * 9 + (n >> 1)) * 4;
+          const float d0 = p[co], d1 = p[co + 18 * 4], d2 = p[co + 2 * 18 * 4], d3 = p[co + 3 * 18 * 4];
+          tl[n] = fmaf(cl0, d0, fmaf(cl1, d1, fmaf(cl2, d2, cl3 * d3)));
+        }
+        tt[0] = zx0 * fmaf(0.75f, tl[0], 0.25f * tl[1]);
+        tt[1] = fmaf(0.25f, tl[0], 0.75f * tl[1]);
+        tt[2] = fmaf(0.75f, tl[1], 0.25f * tl[2]);
+        tt[3] = fmaf(0.25f, tl[1], 0.75f * tl[2]);
+        tt[4] = fmaf(0.75f, tl[2], 0.25f * tl[3]);
+        tt[5] = zx5 * fmaf(0.25f, tl[2], 0.75f * tl[3]);
+      } else {
+        const float* p = raw + pbase_f;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+          const int co = ((c & 3) * 9 + (c >> 2)) * 4;
+          const float d0 = p[co], d1 = p[co + prow_f], d2 = p[co + 2 * prow_f], d3 = p[co + prow3_f];
+          tt[c] = fmaf(k0, d0, fmaf(k1, d1, fmaf(k2, d2, k3 * d3)));
+        }
+      }
+    };
+    auto t_cols_store = [&](int k) {
+      float v[6];
+      w4_col_pass(tt, v);
+      float* vw = vbuf + (k & 1) * W4_V_FLOATS + vw0;
+#pragma unroll
+      for (int n = 0; n < 6; ++n) vw[n * 3 * 64 * 4] = v[n];
+    };
+
+    // ---- prologue: raw 0..2, weights 0..1; transform quarter 0
+    issue_raw(0);
+    issue_w(0);
+    issue_raw(1);
+    issue_raw(2);
+    issue_w(1);
+    __builtin_amdgcn_s_waitcnt(0x0F78);  // vmcnt(8): raw 0 has landed (this wave's piece)
+    __builtin_amdgcn_s_barrier();
+    t_rows(0);
+    t_cols_store(0);
+    f32x16 acc[6];
+#pragma unroll
+    for (int x = 0; x < 6; ++x)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[x][r] = 0.f;
+    __builtin_amdgcn_s_waitcnt(0x0074);  // vmcnt(4) lgkmcnt(0): raw 1 and weights 0 have landed, V[0] is written; raw 2 and weights 1 stay in flight
+    __builtin_amdgcn_s_barrier();
+
+    for (int q = 0; q < Q; ++q) {
+      const float* wsl = wring + (q & 1) * W4_W_FLOATS + lane * 4;
+      const float* vrd = vbuf + (q & 1) * W4_V_FLOATS + vr0;
+      f32x4 wf[3], vf[3];
+      // (all weight fragments first: by the time the second MFMA group has waited for vf[1], every read of the weight slot has returned
+      // and the slot may take its next transfer)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) wf[p] = *reinterpret_cast<const f32x4*>(wsl + p * 256);
+#pragma unroll
+      for (int p = 0; p < 3; ++p) vf[p] = *reinterpret_cast<const f32x4*>(vrd + p * 256);
+      const bool more = q + 1 < Q;  // workgroup-uniform
+      __builtin_amdgcn_sched_barrier(0);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[0][0], vf[0][0], acc[0], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[0][1], vf[0][1], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[0][2], vf[0][2], acc[1], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[0][3], vf[0][3], acc[1], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (more) t_rows(q + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[1][0], vf[1][0], acc[2], 0, 0, 0);
+      acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[1][1], vf[1][1], acc[2], 0, 0, 0);
+      acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[1][2], vf[1][2], acc[3], 0, 0, 0);
+      acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[1][3], vf[1][3], acc[3], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      // every fragment of this quarter is in registers (the MFMAs above waited for them): the weight slot just read takes quarter q + 2,
+      // raw slot q % 3 (transformed during quarter q - 1) takes quarter q + 3
+      issue_w(q + 2);
+      issue_raw(q + 3);
+      if (more) t_cols_store(q + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      acc[4] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[2][0], vf[2][0], acc[4], 0, 0, 0);
+      acc[4] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[2][1], vf[2][1], acc[4], 0, 0, 0);
+      acc[5] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[2][2], vf[2][2], acc[5], 0, 0, 0);
+      acc[5] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[2][3], vf[2][3], acc[5], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_waitcnt(0x0074);  // vmcnt(4) lgkmcnt(0): everything but this quarter's four transfers has landed; V[(q + 1) & 1] is written
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // ---- epilogue.  Nothing real is in flight (the last two quarters issued out-of-range transfers); retire them before LDS is reused.
+    __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0) lgkmcnt(0)
+    __builtin_amdgcn_s_barrier();
+    // row pass of A^T M A in registers: Z[a] = sum_xi A^T[a][xi] M[xi] (this wave's nu), a = 0..3, left in acc[0..3]
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float m0 = acc[0][r], m1 = acc[1][r], m2 = acc[2][r], m3 = acc[3][r], m4 = acc[4][r], m5 = acc[5][r];
+      const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
+      acc[0][r] = (m0 + s12) + s34;
+      acc[1][r] = fmaf(2.f, d34, d12);
+      acc[2][r] = fmaf(4.f, s34, s12);
+      acc[3][r] = fmaf(8.f, d34, d12) + m5;
+    }
+    float* const exch = lds;  // [nu 6][a 4][k 4][lane 64][4]: 24576 floats
+    const int ty = lx >> 3, tx = lx & 7;
+#pragma unroll 1
+    for (int round = 0; round < 2; ++round) {
+      if (nt == round) {
+#pragma unroll
+        for (int aa = 0; aa < 4; ++aa)
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            f32x4 v;
+            v[0] = acc[aa][4 * k + 0];
+            v[1] = acc[aa][4 * k + 1];
+            v[2] = acc[aa][4 * k + 2];
+            v[3] = acc[aa][4 * k + 3];
+            *reinterpret_cast<f32x4*>(exch + (((nu * 4 + aa) * 4 + k) * 64 + lane) * 4) = v;
+          }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      // sixteen (output row a, channel quad k) units per round: unit u goes to wave (u + 4 * round) % 12 -- waves 0..3 take two in round 0, waves 4..7 in round 1
+#pragma unroll 1
+      for (int u = (pw + 12 - 4 * round) % 12; u < 16; u += 12) {
+        const int aa = u >> 2, k = u & 3;
+        f32x4 z[6];
+#pragma unroll
+        for (int n = 0; n < 6; ++n) z[n] = *reinterpret_cast<const f32x4*>(exch + (((n * 4 + aa) * 4 + k) * 64 + lane) * 4);
+        const int co = P.ntile * 64 + round * 32 + 8 * k + 4 * lh;
+        const f32x4 bias = *reinterpret_cast<const f32x4*>(a.bias + co);
+        const f32x4 s12 = z[1] + z[2], d12 = z[1] - z[2], s34 = z[3] + z[4], d34 = z[3] - z[4];
+        f32x4 y[4];
+        y[0] = ((z[0] + s12) + s34) + bias;
+        y[1] = (d12 + 2.f * d34) + bias;
+        y[2] = (s12 + 4.f * s34) + bias;
+        y[3] = ((d12 + 8.f * d34) + z[5]) + bias;
+        const int oy = P.y0 + 4 * ty + aa, ox = P.x0 + 4 * tx;
+        if (oy < a.H && co < a.coutp) {
+          float* const dp = a.dst + ((size_t)(P.b * a.H + oy) * a.W + ox) * a.coutp + co;
+#pragma unroll
+          for (int bb = 0; bb < 4; ++bb) {
+            if (ox + bb >= a.W) continue;
+            f32x4 v = y[bb];
+            if (a.relu) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+            *reinterpret_cast<f32x4*>(dp + (size_t)bb * a.coutp) = v;
+          }
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+  }
+}
+
+int prepare_wino4_kernels() {
+  const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wino4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS_FLOATS * (int)sizeof(float));
+  if (e != hipSuccess) {
+    set_error("hipFuncSetAttribute(wino4) failed: %s", hipGetErrorString(e));
+    return PH_E_HIP;
+  }
+  return PH_OK;
+}
+
+// Shapes the kernel takes: N tile 64, whole 4x4 Winograd tiles (H and W multiples of 4), channel counts in quarters, every tensor
+// addressable through a 32-bit buffer descriptor; no fused pool / head / accumulate / ReLU mask (those stay on the F(2x2,3x3) kernel).
+bool wino4_fits(const ConvArgs& a) {
+  if (!a.wpack_wino4 || a.bn != 64 || (a.H & 3) || (a.W & 3) || a.dst_pool || a.head_w || a.accumulate || a.relu_mask_src || a.skip_dst) return false;
+  if (a.src1_lowres && (!a.src1 || (a.H & 1) || (a.W & 1))) return false;
+  const uint64_t px = (uint64_t)a.B * a.H * a.W;
+  if (px * (uint64_t)a.c0p * 4 >= 0xFFFFFF00ull || px * (uint64_t)a.c1p * 4 >= 0xFFFFFF00ull || px >= 0x7FFFFFFFull) return false;
+  const uint64_t wbytes = (uint64_t)((a.coutp + 63) / 64) * (uint64_t)((a.c0p + a.c1p) / 4) * W4_Q_FLOATS * 4;
+  return wbytes < 0xFFFFFF00ull;
+}
+
+int launch_conv3x3_wino4(const ConvArgs& a, hipStream_t s) {
+  PH_REQUIRE(wino4_fits(a), "wino4: N tile 64, H and W multiples of 4, no fused pool / head / accumulate, tensors below 4 GiB");
+  int n_cu = 0;
+  const int rc = device_cu_count(&n_cu);
+  if (rc != PH_OK) return rc;
+  const int tiles = ((a.W + W4_PW - 1) / W4_PW) * ((a.H + W4_PH - 1) / W4_PH) * a.B;
+  const int ntc = (a.coutp + 63) / 64;
+  hipLaunchKernelGGL(conv3x3_wino4_kernel, dim3(std::min(tiles * ntc, n_cu)), dim3(768), (size_t)W4_LDS_FLOATS * sizeof(float), s, a);
+  PH_HIP_CHECK(hipGetLastError());
+  return PH_OK;
+}
+
+}  // namespace ph
