@@ -38,6 +38,10 @@
 #include "common.h"
 #include "net_kernels.h"
 
+#ifndef W4_EXP
+#define W4_EXP 0  // timing experiments of tools/w4/w4_bench.hip only (results are wrong with any bit set): 1 no weight transfers, 2 no input transform, 4 no per-quarter barrier, 8 no halo transfers, 16 no MFMAs
+#endif
+
 namespace ph {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -151,22 +155,17 @@ __global__ __launch_bounds__(768) void conv3x3_wino4_kernel(ConvArgs a) {
   float* const vbuf = lds + W4_V_OFF;
   float* const wring = lds + W4_W_OFF + pw * 2 * W4_W_FLOATS;
 
-  // ---- producer constants.  Row pass of a full-resolution quarter: t[c] = sum_i k[i] * d[row r0 + i * rs][c], i < 3 or 4:
-  //   xi 0: rows 0 2 4, (4, -5, 1)     xi 5: rows 1 3 5, (4, -5, 1)     xi 1..4: rows 1 2 3 4, (-4 -4 1 1) (4 -4 -1 1) (-2 -1 2 1) (2 -1 -2 1)
+  // ---- producer constants.  Row pass of a full-resolution quarter, one form for every xi (three operations per patch column):
+  //     t[c] = fma(beta, fma(gamma, P, Q), fma(alpha, R, S))       (P, Q, R, S = patch rows of column c)
+  //   xi 1: (d3 - 4 d1) + (d4 - 4 d2)     xi 2: -(d3 - 4 d1) + (d4 - 4 d2)     xi 3: 2 (d3 - d1) + (d4 - d2)     xi 4: -2 (d3 - d1) + (d4 - d2)
+  //   xi 0: 4 d0 + (d4 - 5 d2)            xi 5: 4 d1 + (d5 - 5 d3)             (two operations: no P, Q = the first row)
+  // Rows (P, Q, R, S) are (1, 3, 2, 4) for xi 1..4 and (-, 0, 2, 4) + (xi == 5) for xi 0 and 5: two code variants with immediate offsets.
   const bool tri = xip == 0 || xip == 5;
-  const int r0 = xip == 0 ? 0 : 1, rs = tri ? 2 : 1;
-  float k0, k1, k2, k3;
-  switch (xip) {
-    case 0: case 5: k0 = 4.f; k1 = -5.f; k2 = 1.f; k3 = 0.f; break;
-    case 1: k0 = -4.f; k1 = -4.f; k2 = 1.f; k3 = 1.f; break;
-    case 2: k0 = 4.f; k1 = -4.f; k2 = -1.f; k3 = 1.f; break;
-    case 3: k0 = -2.f; k1 = -1.f; k2 = 2.f; k3 = 1.f; break;
-    default: k0 = 2.f; k1 = -1.f; k2 = -2.f; k3 = 1.f; break;
-  }
+  const float alpha = tri ? -5.f : (xip <= 2 ? -4.f : -1.f);
+  const float gamma = tri ? 0.f : (xip <= 2 ? -4.f : -1.f);
+  const float beta = tri ? 4.f : (xip == 1 ? 1.f : (xip == 2 ? -1.f : (xip == 3 ? 2.f : -2.f)));
   // raw slot entry of halo pixel (hy, hx): hy * 36 + (hx & 3) * 9 + (hx >> 2); patch column c of tile txp is hx = 4 txp + c
-  const int pbase_f = ((4 * typ + r0) * 36 + txp) * 4 + cp;                     // floats, row r0, column 0
-  const int prow_f = rs * 36 * 4;                                                // floats per row step
-  const int prow3_f = (tri ? 2 : 3) * prow_f;                                    // the fourth row (coefficient 0 for xi = 0, 5: re-reads the third)
+  const int pbase_f = ((4 * typ + (xip == 5 ? 1 : 0)) * 36 + txp) * 4 + cp;     // floats: patch row 0 (row 1 for xi = 5), column 0
   // low-resolution slot entry of (ly, lc): ly * 18 + (lc & 1) * 9 + (lc >> 1); the tile's 4 x 4 low-resolution patch starts at (2 typ, 2 txp)
   const int pbase_l = ((2 * typ) * 18 + txp) * 4 + cp;
   // V write index of this thread for nu = 0: ((nu * 3 + (xi >> 1)) * 64 + (c >> 1) * 32 + tile) * 4 + (xi & 1) * 2 + (c & 1)
@@ -221,18 +220,21 @@ __global__ __launch_bounds__(768) void conv3x3_wino4_kernel(ConvArgs a) {
                                                                            (int)((unsigned)(lowres ? a.B * Hl * Wl : a.B * a.H * a.W) * (unsigned)(a.c1p * 4)), 0x00020000);
     auto issue_raw = [&](int k) {  // halo of quarter k into raw slot k % 3 (out of range beyond the tile's last quarter)
       float* dst = rawbuf + (k % 3) * W4_RAW_FLOATS + pw * 256;
-      if (k < Q0)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc0, (__attribute__((address_space(3))) void*)dst, 16, off0, k * 16, 0, 0);
-      else if (k < Q)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc1, (__attribute__((address_space(3))) void*)dst, 16, off1, (k - Q0) * 16, 0, 0);
+      const bool s1 = k >= Q0;
+      const unsigned off = k < Q ? (s1 ? off1 : off0) : 0xFFFFFF00u;
+      const int so = k < Q ? (s1 ? (k - Q0) * 16 : k * 16) : 0;
+      if (W4_EXP & 8) return;
+      if (s1)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc1, (__attribute__((address_space(3))) void*)dst, 16, off, so, 0, 0);
       else
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc0, (__attribute__((address_space(3))) void*)dst, 16, 0xFFFFFF00u, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc0, (__attribute__((address_space(3))) void*)dst, 16, off, so, 0, 0);
     };
     const int w_tile = P.ntile * Q * (W4_Q_FLOATS * 4);
     auto issue_w = [&](int k) {  // weights of quarter k into this wave's ring slot k & 1
       __attribute__((address_space(3))) void* l = (__attribute__((address_space(3))) void*)(wring + (k & 1) * W4_W_FLOATS);
       const unsigned lo = k < Q ? w_lane : 0xFFFFFF00u;
       const int so = k < Q ? w_tile + k * (W4_Q_FLOATS * 4) : 0;
+      if (W4_EXP & 1) return;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, l, 16, lo, so, 0, 0);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, l, 16, lo, so, 1024, 0);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, l, 16, lo, so, 2048, 0);
@@ -266,6 +268,7 @@ __global__ __launch_bounds__(768) void conv3x3_wino4_kernel(ConvArgs a) {
     // ---- the input transform of quarter k (raw slot k % 3 -> V slot k & 1), split in three parts so that MFMAs can sit between them
     float tt[6];
     auto t_rows = [&](int k) {
+      if (W4_EXP & 2) return;
       const float* raw = rawbuf + (k % 3) * W4_RAW_FLOATS;
       if (k >= Q0 && lowres) {
         const float* p = raw + pbase_l;
@@ -275,6 +278,7 @@ __global__ __launch_bounds__(768) void conv3x3_wino4_kernel(ConvArgs a) {
           const int co = ((n & 1) * 9 + (n >> 1)) * 4;
           const float d0 = p[co], d1 = p[co + 18 * 4], d2 = p[co + 2 * 18 * 4], d3 = p[co + 3 * 18 * 4];
           tl[n] = fmaf(cl0, d0, fmaf(cl1, d1, fmaf(cl2, d2, cl3 * d3)));
+          asm volatile("" : "+v"(tl[n]));
         }
         tt[0] = zx0 * fmaf(0.75f, tl[0], 0.25f * tl[1]);
         tt[1] = fmaf(0.25f, tl[0], 0.75f * tl[1]);
@@ -282,17 +286,28 @@ __global__ __launch_bounds__(768) void conv3x3_wino4_kernel(ConvArgs a) {
         tt[3] = fmaf(0.25f, tl[1], 0.75f * tl[2]);
         tt[4] = fmaf(0.75f, tl[2], 0.25f * tl[3]);
         tt[5] = zx5 * fmaf(0.25f, tl[2], 0.75f * tl[3]);
+#pragma unroll
+        for (int c = 0; c < 6; ++c) asm volatile("" : "+v"(tt[c]));
+      } else if (tri) {
+        const float* p = raw + pbase_f;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+          const int co = ((c & 3) * 9 + (c >> 2)) * 4;
+          tt[c] = fmaf(beta, p[co], fmaf(alpha, p[co + 2 * 144], p[co + 4 * 144]));
+          asm volatile("" : "+v"(tt[c]));  // one scalar chain per column: packed-fp32 VALU (and the moves that feed it) is a loss beside MFMAs
+        }
       } else {
         const float* p = raw + pbase_f;
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
           const int co = ((c & 3) * 9 + (c >> 2)) * 4;
-          const float d0 = p[co], d1 = p[co + prow_f], d2 = p[co + 2 * prow_f], d3 = p[co + prow3_f];
-          tt[c] = fmaf(k0, d0, fmaf(k1, d1, fmaf(k2, d2, k3 * d3)));
+          tt[c] = fmaf(beta, fmaf(gamma, p[co + 144], p[co + 3 * 144]), fmaf(alpha, p[co + 2 * 144], p[co + 4 * 144]));
+          asm volatile("" : "+v"(tt[c]));
         }
       }
     };
     auto t_cols_store = [&](int k) {
+      if (W4_EXP & 2) return;
       float v[6];
       w4_col_pass(tt, v);
       float* vw = vbuf + (k & 1) * W4_V_FLOATS + vw0;
@@ -318,6 +333,11 @@ __global__ __launch_bounds__(768) void conv3x3_wino4_kernel(ConvArgs a) {
     __builtin_amdgcn_s_waitcnt(0x0074);  // vmcnt(4) lgkmcnt(0): raw 1 and weights 0 have landed, V[0] is written; raw 2 and weights 1 stay in flight
     __builtin_amdgcn_s_barrier();
 
+#if W4_EXP & 16
+#define W4_MFMA(a_, b_, c_, x, y, z) (c_)
+#else
+#define W4_MFMA(a_, b_, c_, x, y, z) __builtin_amdgcn_mfma_f32_32x32x2f32(a_, b_, c_, x, y, z)
+#endif
     for (int q = 0; q < Q; ++q) {
       const float* wsl = wring + (q & 1) * W4_W_FLOATS + lane * 4;
       const float* vrd = vbuf + (q & 1) * W4_V_FLOATS + vr0;
@@ -328,33 +348,32 @@ __global__ __launch_bounds__(768) void conv3x3_wino4_kernel(ConvArgs a) {
       for (int p = 0; p < 3; ++p) wf[p] = *reinterpret_cast<const f32x4*>(wsl + p * 256);
 #pragma unroll
       for (int p = 0; p < 3; ++p) vf[p] = *reinterpret_cast<const f32x4*>(vrd + p * 256);
-      const bool more = q + 1 < Q;  // workgroup-uniform
       __builtin_amdgcn_sched_barrier(0);
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[0][0], vf[0][0], acc[0], 0, 0, 0);
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[0][1], vf[0][1], acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[0][2], vf[0][2], acc[1], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[0][3], vf[0][3], acc[1], 0, 0, 0);
+      acc[0] = W4_MFMA(wf[0][0], vf[0][0], acc[0], 0, 0, 0);
+      acc[0] = W4_MFMA(wf[0][1], vf[0][1], acc[0], 0, 0, 0);
+      acc[1] = W4_MFMA(wf[0][2], vf[0][2], acc[1], 0, 0, 0);
+      acc[1] = W4_MFMA(wf[0][3], vf[0][3], acc[1], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
-      if (more) t_rows(q + 1);
+      t_rows(q + 1);  // (after the tile's last quarter: the zero-filled slot of an out-of-range transfer -> a V slot nobody reads)
       __builtin_amdgcn_sched_barrier(0);
-      acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[1][0], vf[1][0], acc[2], 0, 0, 0);
-      acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[1][1], vf[1][1], acc[2], 0, 0, 0);
-      acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[1][2], vf[1][2], acc[3], 0, 0, 0);
-      acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[1][3], vf[1][3], acc[3], 0, 0, 0);
+      acc[2] = W4_MFMA(wf[1][0], vf[1][0], acc[2], 0, 0, 0);
+      acc[2] = W4_MFMA(wf[1][1], vf[1][1], acc[2], 0, 0, 0);
+      acc[3] = W4_MFMA(wf[1][2], vf[1][2], acc[3], 0, 0, 0);
+      acc[3] = W4_MFMA(wf[1][3], vf[1][3], acc[3], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
       // every fragment of this quarter is in registers (the MFMAs above waited for them): the weight slot just read takes quarter q + 2,
       // raw slot q % 3 (transformed during quarter q - 1) takes quarter q + 3
       issue_w(q + 2);
       issue_raw(q + 3);
-      if (more) t_cols_store(q + 1);
+      t_cols_store(q + 1);
       __builtin_amdgcn_sched_barrier(0);
-      acc[4] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[2][0], vf[2][0], acc[4], 0, 0, 0);
-      acc[4] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[2][1], vf[2][1], acc[4], 0, 0, 0);
-      acc[5] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[2][2], vf[2][2], acc[5], 0, 0, 0);
-      acc[5] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[2][3], vf[2][3], acc[5], 0, 0, 0);
+      acc[4] = W4_MFMA(wf[2][0], vf[2][0], acc[4], 0, 0, 0);
+      acc[4] = W4_MFMA(wf[2][1], vf[2][1], acc[4], 0, 0, 0);
+      acc[5] = W4_MFMA(wf[2][2], vf[2][2], acc[5], 0, 0, 0);
+      acc[5] = W4_MFMA(wf[2][3], vf[2][3], acc[5], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_waitcnt(0x0074);  // vmcnt(4) lgkmcnt(0): everything but this quarter's four transfers has landed; V[(q + 1) & 1] is written
-      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_s_waitcnt((W4_EXP & 9) ? 0x0070 : 0x0074);  // vmcnt(4) lgkmcnt(0): everything but this quarter's four transfers has landed; V[(q + 1) & 1] is written
+      if (!(W4_EXP & 4)) __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
     }
 
