@@ -473,7 +473,7 @@ def run_infer(args, ctx):
     executed_all = sum(e["executed_flops"] for e in by_kernel.values())
     peak = MFMA_F16_PEAK_TFLOPS if fp16 else MFMA_F32_PEAK_TFLOPS
     KERNEL_NAMES = {"wino2d": "conv3x3_wino2d_kernel<64> (Winograd F(2x2,3x3), 4/9 of the direct MFMA work)",
-                    "wino4": "conv3x3_wino4_kernel (Winograd F(4x4,3x3), 1/4 of the direct MFMA work)",
+                    "wino4": "conv3x3_wino4_kernel (Winograd F(4x4,3x3), 1/4 of the direct MFMA work; the decoder's bilinear x2 folded into its input transform)",
                     "w16": "conv3x3_w16_kernel<1|2> (wave-private Winograd F(2x2,3x3) on the 16x16x4 MFMA, Cout 32, 4/9 of the direct MFMA work)",
                     "wino1d": "conv3x3_wino_persist_kernel<64|32> (Winograd F(2,3) along x, 2/3 of the direct MFMA work)",
                     "direct": "conv3x3_mfma_dma_persist_kernel<64|32> (direct)", "c16": "conv3x3_c16_kernel (direct)", "rowgemm": "gemm_mfma_dma_kernel<2> (9-tap row GEMM, direct)",

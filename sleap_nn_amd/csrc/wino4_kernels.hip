@@ -333,6 +333,19 @@ __global__ __launch_bounds__(768) void conv3x3_wino4_kernel(ConvArgs a) {
     __builtin_amdgcn_s_waitcnt(0x0074);  // vmcnt(4) lgkmcnt(0): raw 1 and weights 0 have landed, V[0] is written; raw 2 and weights 1 stay in flight
     __builtin_amdgcn_s_barrier();
 
+#ifdef W4_STAMP  // diagnostic build (tools/w4/w4_bench.hip -DW4_STAMP): cycles per phase of a quarter, per wave, into ConvArgs::clock_probe
+    unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long st_mark = __builtin_amdgcn_s_memtime();
+#define W4_ST(i)                                                 \
+  {                                                              \
+    const unsigned long long t_ = __builtin_amdgcn_s_memtime();  \
+    st[i] += t_ - st_mark;                                       \
+    st_mark = t_;                                                \
+  }
+#else
+#define W4_ST(i)
+#endif
+
 #if W4_EXP & 16
 #define W4_MFMA(a_, b_, c_, x, y, z) (c_)
 #else
@@ -354,8 +367,10 @@ __global__ __launch_bounds__(768) void conv3x3_wino4_kernel(ConvArgs a) {
       acc[1] = W4_MFMA(wf[0][2], vf[0][2], acc[1], 0, 0, 0);
       acc[1] = W4_MFMA(wf[0][3], vf[0][3], acc[1], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
+      W4_ST(0)
       t_rows(q + 1);  // (after the tile's last quarter: the zero-filled slot of an out-of-range transfer -> a V slot nobody reads)
       __builtin_amdgcn_sched_barrier(0);
+      W4_ST(1)
       acc[2] = W4_MFMA(wf[1][0], vf[1][0], acc[2], 0, 0, 0);
       acc[2] = W4_MFMA(wf[1][1], vf[1][1], acc[2], 0, 0, 0);
       acc[3] = W4_MFMA(wf[1][2], vf[1][2], acc[3], 0, 0, 0);
@@ -363,19 +378,32 @@ __global__ __launch_bounds__(768) void conv3x3_wino4_kernel(ConvArgs a) {
       __builtin_amdgcn_sched_barrier(0);
       // every fragment of this quarter is in registers (the MFMAs above waited for them): the weight slot just read takes quarter q + 2,
       // raw slot q % 3 (transformed during quarter q - 1) takes quarter q + 3
+      W4_ST(2)
       issue_w(q + 2);
       issue_raw(q + 3);
+      W4_ST(3)
       t_cols_store(q + 1);
       __builtin_amdgcn_sched_barrier(0);
+      W4_ST(4)
       acc[4] = W4_MFMA(wf[2][0], vf[2][0], acc[4], 0, 0, 0);
       acc[4] = W4_MFMA(wf[2][1], vf[2][1], acc[4], 0, 0, 0);
       acc[5] = W4_MFMA(wf[2][2], vf[2][2], acc[5], 0, 0, 0);
       acc[5] = W4_MFMA(wf[2][3], vf[2][3], acc[5], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
+      W4_ST(5)
       __builtin_amdgcn_s_waitcnt((W4_EXP & 9) ? 0x0070 : 0x0074);  // vmcnt(4) lgkmcnt(0): everything but this quarter's four transfers has landed; V[(q + 1) & 1] is written
+      W4_ST(6)
       if (!(W4_EXP & 4)) __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
+      W4_ST(7)
     }
+#ifdef W4_STAMP
+    if (a.clock_probe && lane == 0 && vid == (int)blockIdx.x) {
+      unsigned long long* o = a.clock_probe + ((size_t)blockIdx.x * 12 + pw) * 8;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) o[i] = st[i];
+    }
+#endif
 
     // ---- epilogue.  Nothing real is in flight (the last two quarters issued out-of-range transfers); retire them before LDS is reused.
     __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0) lgkmcnt(0)

@@ -987,6 +987,74 @@ def test_winograd_2d_kernel_matches_oracle_and_the_other_conv_kernels(filters, m
     assert torch.equal(again.to(DEV)(img.to(DEV))["SingleInstanceConfmapsHead"].cpu(), outs["w2d"])  # run-to-run bitwise
 
 
+# Relative bar of the F(4x4,3x3) layers (conv3x3_wino4_kernel): the transforms carry coefficients up to 8 / 5 / (1/24), so the result sits ~2-3x
+# further from the fp64 convolution than F(2x2,3x3) does -- measured on these networks: heads 1.3e-6 ... 2.7e-6 of their scale (F(2x2,3x3):
+# 0.8e-6 ... 1.2e-6), single activations up to 6.3e-6 -- stated here as 1e-5 of the tensor's scale, ten times inside the 1e-4 bar.
+W4_RTOL = 1e-5
+
+
+@pytest.mark.parametrize("filters,max_stride,hw,out_stride,batch", [(32, 8, (128, 128), None, 2), (16, 32, (128, 192), 4, 3), (32, 16, (128, 160), 2, 2),
+                                                                   (64, 4, (48, 80), None, 2), (32, 8, (100, 132), None, 2), (16, 32, (256, 384), 4, 9)])
+def test_winograd_f4x4_kernel_and_folded_bilinear_match_oracle_and_the_f2x2_kernel(filters, max_stride, hw, out_stride, batch):
+    """conv3x3_wino4_kernel (Winograd F(4x4,3x3): 3x3 convs with N tile 64 and >= 128 padded input channels) with the decoder's
+    bilinear x2 folded into its input transform (inference plans: the up-sampled tensor never exists), against the oracle and the
+    F(2x2,3x3) kernel: two-source concat convs at three decoder levels (tiles at every image border: zero padding of the up-sampled
+    tensor vs the clamped low-resolution indices), one-source middle / refine convs, maps that cut the 32 x 16 workgroup tile,
+    several tiles per persistent workgroup (the 9-frame case), and a map size that is no multiple of 4 (-> the F(2x2,3x3) kernel keeps
+    the layer, the separate bilinear kernel runs).  `conv_wino4 = 2` runs the kernel WITHOUT the fold on a plan that keeps every
+    activation, so each layer's output is compared on its own."""
+    from sleap_nn_amd import _lib as L
+    from sleap_nn_amd.architectures.model import Model
+
+    os_ = out_stride or max_stride
+    bb = {"in_channels": 1, "kernel_size": 3, "filters": filters, "filters_rate": 2, "max_stride": max_stride, "stem_stride": None, "middle_block": True,
+          "up_interpolate": True, "stacks": 1, "convs_per_block": 2, "output_stride": os_}
+    heads = {"confmaps": {"part_names": ["a", "b", "c"], "output_stride": os_}}
+    sd = O.init_state(bb, heads, "single_instance", seed=filters + hw[0], head_scale=1.0)
+    g = torch.Generator().manual_seed(hw[1])
+    img = torch.randint(0, 256, (batch, 1, hw[0], hw[1]), dtype=torch.uint8, generator=g)
+    collect = {}
+    ref = O.model_forward(sd, bb, heads, "single_instance", img, collect=collect)["SingleInstanceConfmapsHead"]
+    scale = ref.abs().max().item()
+    outs, n4 = {}, {}
+    for name, opts, keep in (("fold", {}, False), ("nofold", {"upsample_fold": 0}, False), ("every_plan", {"conv_wino4": 2}, True), ("f2x2", {"conv_wino4": 0}, False)):
+        m = Model("unet", bb, heads, "single_instance")
+        m.load_state_dict(sd)
+        for k, v in opts.items():
+            m.set_option(k, v)
+        m.to(DEV).set_keep_activations(keep)
+        outs[name] = m(img.to(DEV))["SingleInstanceConfmapsHead"].cpu()
+        kv = m.last_kernels()
+        n4[name] = sum(1 for c in kv if c == L.KV_WINO4)
+        if name == "fold":
+            assert m.get_option("conv_wino4") == 1.0 and m.get_option("upsample_fold") == 1.0  # the defaults
+            ups = [i for i, op in enumerate(m.ops) if op.kind == L.OP_UPSAMPLE]
+            folded = [i for i in ups if kv[i + 1] == L.KV_WINO4]
+        if keep:
+            checked = 0
+            for lab, t in collect.items():
+                if lab not in m.backbone.labels:
+                    continue
+                try:
+                    got = m.read_activation(lab, t.shape[0], t.shape[-2:]).cpu()
+                except KeyError:
+                    continue  # fused away (stem)
+                assert (got - t).abs().max().item() <= W4_RTOL * max(t.abs().max().item(), 1e-30), lab
+                checked += 1
+            assert checked >= 6
+    whole_tiles = all((hw[0] // s) % 4 == 0 and (hw[1] // s) % 4 == 0 for s in (max_stride, max_stride // 2)) or max_stride == os_
+    if hw[0] % (4 * max_stride) == 0 and hw[1] % (4 * max_stride) == 0:
+        assert n4["fold"] >= 2 and n4["f2x2"] == 0 and n4["every_plan"] >= n4["nofold"] >= 2, n4
+        if os_ < max_stride:
+            assert folded, "a decoder's bilinear x2 must ride in the F(4x4,3x3) kernel"
+    for name in ("fold", "nofold", "every_plan", "f2x2"):
+        assert (outs[name] - ref).abs().max().item() <= W4_RTOL * scale, (name, n4)
+    assert (outs["fold"] - outs["f2x2"]).abs().max().item() <= W4_RTOL * scale
+    again = Model("unet", bb, heads, "single_instance")
+    again.load_state_dict(sd)
+    assert torch.equal(again.to(DEV)(img.to(DEV))["SingleInstanceConfmapsHead"].cpu(), outs["fold"])  # run-to-run bitwise
+
+
 @pytest.mark.parametrize("hw,max_stride", [((64, 64), 8), ((36, 44), 8), ((17, 33), 4), ((96, 80), 4), ((130, 70), 4)])
 def test_wave_private_winograd_kernel_matches_oracle_and_the_1d_kernel(hw, max_stride):
     """conv3x3_w16_kernel (Cout 32, Cin 16 / 32: the second encoder block of a filters = 16 UNet -- 16 -> 32 and 32 -> 32 + fused pool)

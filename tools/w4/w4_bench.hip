@@ -40,6 +40,12 @@ int main(int argc, char** argv) {
   a.src0 = d0; a.src1 = c1 ? d1 : nullptr; a.c0p = c0; a.c1p = c1; a.coutp = cout; a.B = B; a.H = H; a.W = W; a.relu = 1; a.bn = 64;
   a.bias = dbias; a.dst = dout; a.wpack_wino4 = dw; a.src1_lowres = c1 ? lowres : 0; a.use_wino4 = 1;
   if (!wino4_fits(a)) return printf("shape does not fit\n"), 1;
+#ifdef W4_STAMP
+  unsigned long long* probe;
+  hipMalloc(&probe, 256 * 12 * 8 * 8);
+  hipMemset(probe, 0, 256 * 12 * 8 * 8);
+  a.clock_probe = probe;
+#endif
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (int i = 0; i < 3; ++i) if (launch_conv3x3_wino4(a, 0) != PH_OK) return printf("launch failed: %s\n", g_err), 1;
   hipDeviceSynchronize();
@@ -55,6 +61,22 @@ int main(int argc, char** argv) {
   size_t ndiff = 0, nnan = 0; double sum = 0;
   for (size_t i = 0; i < no; ++i) { ndiff += memcmp(&o1[i], &o2[i], 4) != 0; nnan += o1[i] != o1[i]; sum += o1[i]; }
   printf("   determinism: %zu of %zu elements differ, %zu NaN (unwritten), checksum %.6e\n", ndiff, no, nnan, sum);
+#ifdef W4_STAMP
+  {
+    std::vector<unsigned long long> pr(256 * 12 * 8);
+    hipMemcpy(pr.data(), probe, pr.size() * 8, hipMemcpyDeviceToHost);
+    const int Q = (c0 + c1) / 4;
+    const char* names[8] = {"frags+MFMA1", "t_rows", "MFMA2", "DMA issue", "t_cols+store", "MFMA3", "waitcnt", "barrier"};
+    for (int slot = 0; slot < 3; ++slot) {
+      double acc[8] = {0}; int n = 0;
+      for (int blk = 0; blk < 256; ++blk) for (int w = slot * 4; w < slot * 4 + 4; ++w) { for (int i = 0; i < 8; ++i) acc[i] += (double)pr[((size_t)blk * 12 + w) * 8 + i]; ++n; }
+      double tot = 0; for (int i = 0; i < 8; ++i) tot += acc[i];
+      printf("   waves %d-%d (first tile of each workgroup, cycles per quarter):", slot * 4, slot * 4 + 3);
+      for (int i = 0; i < 8; ++i) printf(" %s %.0f", names[i], acc[i] / n / Q);
+      printf("  | total %.0f\n", tot / n / Q);
+    }
+  }
+#endif
   hipMemcpy(h.data(), dout, 64 * 4, hipMemcpyDeviceToHost);
   printf("B %d %dx%d %d+%d->%d lowres %d: %.4f ms  executed %.1f TFLOP/s (%.3f of 157.3)  direct-equivalent %.1f  out[0..3] %g %g %g %g\n", B, H, W, c0, c1, cout, a.src1_lowres, ms,
          direct / 4 / ms / 1e9, direct / 4 / ms / 1e9 / 157.3, direct / ms / 1e9, h[0], h[1], h[2], h[3]);
