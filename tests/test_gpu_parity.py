@@ -1203,6 +1203,7 @@ def test_unfused_program_with_shared_slots_survives_forwarded_writes():
             m.set_option("workspace_reuse", reuse)
             m.set_option("pool_peephole", 1)
             m.set_option("dw_ln_fuse", ln)
+            m.set_option("conv_wino4", 0)  # (the F(4x4,3x3) kernel is another plan-dependent choice with its own rounding: out of this comparison)
             outs.append({k: v.clone() for k, v in m(img).items()})
             assert m.get_option("workspace_reuse") == float(reuse)
         for k in outs[0]:
