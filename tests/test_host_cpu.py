@@ -666,3 +666,19 @@ def test_outputs_to_instances_and_to_labels(monkeypatch):
     with pytest.raises(ValueError):
         Outputs(**cases["centroid_only"]).to_instances(skel, 0, anchor_ind=5)
     assert Outputs().to_instances(skel) == []
+
+
+def test_wino4_transform_tables_known_answer():
+    """The arithmetic conv3x3_wino4_kernel implements -- F(4x4,3x3) with the kernel's own operation order (three-operation row chains, the
+    14-operation column pass, the A^T passes) and the bilinear x2 of the second source folded into the input transform (B^T U as four row
+    coefficients, clamped low-resolution indices, zero padding of the up-sampled tensor at every image border) -- restated in numpy
+    (tools/proto/wino4_math.py) against torch's conv2d over the concatenated, torch-up-sampled input."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("wino4_math", os.path.join(ROOT, "tools", "proto", "wino4_math.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    for seed in (0, 1):
+        err_fold, err_plain = mod.check(seed)
+        assert err_plain <= 1e-12          # float64 restatement: exact up to rounding
+        assert err_fold <= 5e-7            # (torch's interpolate runs in float32)
