@@ -365,11 +365,11 @@ __global__ __launch_bounds__(256, 2) void row_wgrad_kernel(RowWgradArgs a) {
       if (ok && cy < a.np) vy = *reinterpret_cast<const f32x4*>(a.dy + (size_t)mm * a.np + cy);
       if (ok && ck < a.kp) {
         size_t pix = (size_t)mm;
-        if (a.patch == 2) {  // 3x3 "same" conv: input pixel = output pixel + (ky - 1, kx - 1), zero outside the image
+        if (a.patch == 2) {  // k x k "same" conv: input pixel = output pixel + (ky - k / 2, kx - k / 2), zero outside the image
           const int x = mm % a.W, y = (mm / a.W) % a.H;
-          const int yy = y + a.tap / 3 - 1, xx = x + a.tap % 3 - 1;
+          const int yy = y + a.tap / a.ksize - (a.ksize >> 1), xx = x + a.tap % a.ksize - (a.ksize >> 1);
           const bool in = yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
-          pix = in ? (size_t)((long long)mm + (a.tap / 3 - 1) * a.W + (a.tap % 3 - 1)) : (size_t)mm;
+          pix = in ? (size_t)((long long)mm + (a.tap / a.ksize - (a.ksize >> 1)) * a.W + (a.tap % a.ksize - (a.ksize >> 1))) : (size_t)mm;
           if (!in) ck = a.kp;  // -> zeros
         } else if (a.patch == 1) {  // output pixel (b, oy, ox) -> input pixel (b, 2oy + dy, 2ox + dx)
           const int ow = a.W >> 1, oh = a.H >> 1;
@@ -485,11 +485,11 @@ int launch_row_wgrad_part(const RowWgradArgs& a0, int n, int k, int k_total, int
 }
 
 // ---------------------------------------------------------------------------------------
-// Patch-stem weight gradient: dW[co][ci][ky][kx] = sum_{b,oy,ox} dy[b,oy,ox,co] * img[b,ci,oy*s+ky-1,ox*s+kx-1].
+// Patch-stem / first k x k conv weight gradient: dW[co][ci][ky][kx] = sum_{b,oy,ox} dy[b,oy,ox,co] * img[b,ci,oy*s+ky-pad,ox*s+kx-pad].
 // The image patches are written once as rows [pixel][ci*k*k + tap] (im2col, <= 48 floats per pixel, padded
 // to a multiple of 16) and the gradient is one row-wgrad GEMM over them.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void patch_im2col_kernel(const void* __restrict__ img, int dtype, int B, int cin, int H, int W, int OH, int OW, int k, int stride,
+__global__ __launch_bounds__(256) void patch_im2col_kernel(const void* __restrict__ img, int dtype, int B, int cin, int H, int W, int OH, int OW, int k, int stride, int pad,
                                                            int kp, float* __restrict__ out) {
   const int kk = k * k, n_item = cin * kk;
   const size_t total = (size_t)B * OH * OW * kp;
@@ -503,7 +503,7 @@ __global__ __launch_bounds__(256) void patch_im2col_kernel(const void* __restric
       const int ox = (int)(p % OW);
       const size_t r = p / OW;
       const int oy = (int)(r % OH), b = (int)(r / OH);
-      const int yy = oy * stride + ky - 1, xx = ox * stride + kx - 1;
+      const int yy = oy * stride + ky - pad, xx = ox * stride + kx - pad;
       if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
         const size_t o = (((size_t)b * cin + ci) * H + yy) * W + xx;
         if (dtype == 0)
@@ -517,14 +517,14 @@ __global__ __launch_bounds__(256) void patch_im2col_kernel(const void* __restric
     out[idx] = v;
   }
 }
-int launch_patch_stem_wgrad(const void* img, int dtype, const float* dy, int B, int cin, int H, int W, int OH, int OW, int k, int stride, int coutp, int cout, float* gw,
+int launch_patch_stem_wgrad(const void* img, int dtype, const float* dy, int B, int cin, int H, int W, int OH, int OW, int k, int stride, int pad, int coutp, int cout, float* gw,
                             float* scratch, hipStream_t s) {
   const int n_item = cin * k * k, kp = pad16(n_item);
   const size_t npix = (size_t)B * OH * OW;
   float* patches = scratch;
   float* slab = scratch + align_up((int64_t)npix * kp, 64);
   const size_t total = npix * kp;
-  hipLaunchKernelGGL(patch_im2col_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 256 * 64)), dim3(256), 0, s, img, dtype, B, cin, H, W, OH, OW, k, stride, kp, patches);
+  hipLaunchKernelGGL(patch_im2col_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 256 * 64)), dim3(256), 0, s, img, dtype, B, cin, H, W, OH, OW, k, stride, pad, kp, patches);
   PH_HIP_CHECK(hipGetLastError());
   RowWgradArgs a{};
   a.dy = dy;

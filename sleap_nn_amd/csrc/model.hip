@@ -92,13 +92,13 @@ static int pack_upload(ph_model* m, PackFn&& pack, const float* values, const st
 // OIHW (cout, cin_total, 3, 3) -> the conv weight of the data gradient wrt channels
 // [ci_off, ci_off + cin_part): Wd[o = ci][i = co][ky][kx] = W[co][ci_off + ci][2-ky][2-kx].
 template <typename T>
-static void dgrad_weight(const T* w, int cout, int cin_total, int ci_off, int cin_part, std::vector<T>& out) {
-  out.assign((size_t)cin_part * cout * 9, T(0));
+static void dgrad_weight(const T* w, int cout, int cin_total, int ci_off, int cin_part, std::vector<T>& out, int k = 3) {
+  out.assign((size_t)cin_part * cout * k * k, T(0));
   for (int ci = 0; ci < cin_part; ++ci)
     for (int co = 0; co < cout; ++co)
-      for (int ky = 0; ky < 3; ++ky)
-        for (int kx = 0; kx < 3; ++kx)
-          out[(((size_t)ci * cout + co) * 3 + ky) * 3 + kx] = w[(((size_t)co * cin_total + ci_off + ci) * 3 + (2 - ky)) * 3 + (2 - kx)];
+      for (int ky = 0; ky < k; ++ky)
+        for (int kx = 0; kx < k; ++kx)
+          out[(((size_t)ci * cout + co) * k + ky) * k + kx] = w[(((size_t)co * cin_total + ci_off + ci) * k + (k - 1 - ky)) * k + (k - 1 - kx)];
 }
 
 // Conv2d OIHW (cout, cin0+cin1, 3, 3) or ConvTranspose2d IOHW (cin0, cout, 3, 3) ->
@@ -567,6 +567,27 @@ ph_model* ph_model_create(const ph_op_desc* ops, int32_t n_ops, const float* con
           auto pack_k = [&](const auto* w, auto& out) { pack_gemm(w, d.cout, d.cin0, d.cin1, d.ksize * d.ksize, op.bn_g, out); };
           ok = pack_upload(m, pack_k, weights[d.weight], index_array(d.weight), &op.w_gemm_dev) == PH_OK &&
                pack_upload(m, pad_vec((size_t)((coutp_k + op.bn_g - 1) / op.bn_g) * op.bn_g, d.cout), weights[d.bias], index_array(d.bias), &op.b_gemm_dev) == PH_OK;
+          if (ok && d.kind == PH_OP_CONV) {  // data-gradient weights (training): the same k x k row GEMM on the flipped, in/out-swapped taps, one per concat source
+            const int cin_total = d.cin0 + d.cin1;
+            const int parts[2] = {d.cin0, d.cin1}, offs[2] = {0, d.cin0};
+            int max_bn = 32;
+            const std::vector<double> iwk = index_array(d.weight);
+            for (int part = 0; part < 2 && ok; ++part) {
+              if (parts[part] <= 0) continue;
+              op.bn_dk[part] = gemm_choose_bn(pad16(parts[part]));
+              max_bn = std::max(max_bn, op.bn_dk[part]);
+              auto pack_dk = [&](const auto* w, auto& out) {
+                std::remove_reference_t<decltype(out)> dw;
+                dgrad_weight(w, d.cout, cin_total, offs[part], parts[part], dw, d.ksize);
+                pack_gemm(dw.data(), parts[part], d.cout, 0, d.ksize * d.ksize, op.bn_dk[part], out);
+              };
+              ok = pack_upload(m, pack_dk, weights[d.weight], iwk, &op.wdk_gemm_dev[part]) == PH_OK;
+            }
+            if (ok) {
+              std::vector<float> zb((size_t)pad16(std::max(d.cin0, d.cin1)) + 2 * max_bn, 0.f);
+              ok = upload(m, zb, &op.zero_bias_dev) == PH_OK;
+            }
+          }
           break;
         }
         if (d.kind == PH_OP_CONVT && d.cin1 != 0) return fail("transposed conv takes one source", i);

@@ -28,6 +28,8 @@ struct PackedOp {
   float* wd_dev[2] = {nullptr, nullptr};
   float* wd_dma_dev[2] = {nullptr, nullptr};
   float* zero_bias_dev = nullptr;
+  float* wdk_gemm_dev[2] = {nullptr, nullptr};  // k x k conv (k != 3): data-gradient weights (flipped taps, in/out swapped) in the row-GEMM layout, per concat source
+  int bn_dk[2] = {0, 0};
   int bn_d[2] = {0, 0};
   float* w_wino_dev = nullptr;             // 3x3 conv, N tile 64: Winograd F(2,3) weights derived on the device from w_dev
   float* wd_wino_dev[2] = {nullptr, nullptr};  // ... and from wd_dev (data gradient)

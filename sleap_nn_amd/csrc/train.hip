@@ -31,8 +31,8 @@ int build_bwd_plan(const ph_model* m, int B, int H, int W, BwdPlan& bp) {
       set_error("backward needs the unfused program (no stem / conv+pool fusion)");
       return PH_E_INVALID;
     }
-    if ((d.kind == PH_OP_CONV || d.kind == PH_OP_INPUT_CONV) && d.ksize != 3) {
-      set_error("backward supports kernel_size 3 only (kernel_size %d and stem blocks are inference-only)", d.ksize);
+    if (d.kind == PH_OP_CONV && d.ksize != 3 && !op.wdk_gemm_dev[0]) {
+      set_error("backward of a %d x %d conv needs its data-gradient GEMM weights (model built by an older ph_model_create?)", d.ksize, d.ksize);
       return PH_E_INVALID;
     }
     if (d.kind == PH_OP_CONVT) {
@@ -78,6 +78,7 @@ int build_bwd_plan(const ph_model* m, int B, int H, int W, BwdPlan& bp) {
       scratch = std::max<int64_t>(scratch, row_wgrad_slab_floats(B * s0.h * s0.w, d.cout, std::max(d.cin0, d.cin1)));
       scratch = std::max<int64_t>(scratch, bias_scratch_floats(pad16(d.cout)));
     } else if (d.kind == PH_OP_INPUT_CONV) {
+      if (d.ksize != 3) scratch = std::max<int64_t>(scratch, patch_stem_wgrad_scratch_floats(d.cin0, d.cout, d.ksize, (int64_t)B * H * W));  // im2col + one row-wgrad GEMM
       scratch = std::max<int64_t>(scratch, input_wgrad_scratch_floats(d.cin0, d.cout));
       scratch = std::max<int64_t>(scratch, bias_scratch_floats(pad16(d.cout)));
     }
@@ -332,6 +333,51 @@ int ph_model_backward(ph_model* m, const void* input_dev, int32_t in_dtype, int3
           }
         }
         const int srcs[2] = {d.src0, d.src1}, parts[2] = {d.cin0, d.cin1}, offs[2] = {0, d.cin0};
+        if (d.ksize != 3) {
+          // k x k "same" conv (kernel_size 5 / 7 / 9, the 7 x 7 convs of a stem block; encoder_decoder.py:38-141,144-225): the weight gradient is
+          // k^2 row-wgrad GEMMs (one per tap: rows = pixels, the x operand gathered at the tap's offset), the data gradient the same k^2-tap row
+          // GEMM as the forward (mode 5) on the flipped, in/out-swapped weights, accumulating where the source already has a gradient
+          for (int part = 0; part < 2; ++part) {
+            if (parts[part] <= 0 || srcs[part] < 0) continue;
+            const SlotShape& si = bp.act.slots[srcs[part]];
+            for (int tap = 0; tap < d.ksize * d.ksize; ++tap) {
+              RowWgradArgs w{};
+              w.dy = G(d.dst);
+              w.x = A(srcs[part]);
+              w.slab = scratch;
+              w.np = so.cp;
+              w.kp = si.cp;
+              w.M = (int)npix;
+              w.patch = 2;
+              w.ksize = d.ksize;
+              w.tap = tap;
+              w.H = so.h;
+              w.W = so.w;
+              rc = launch_row_wgrad_part(w, d.cout, parts[part], d.cin0 + d.cin1, offs[part], d.ksize * d.ksize, grads_flat_dev + m->weight_offset[d.weight], s);
+              if (rc != PH_OK) return rc;
+            }
+            GemmArgs g{};
+            g.src0 = G(d.dst);
+            g.c0p = so.cp;
+            g.wpack = op.wdk_gemm_dev[part];
+            g.bias = op.zero_bias_dev;
+            g.dst = G(srcs[part]);
+            g.residual = init[srcs[part]] ? G(srcs[part]) : nullptr;
+            g.zeros = m->zeros_dev;
+            g.coutp = si.cp;
+            g.bn = op.bn_dk[part];
+            g.M = (int)npix;
+            g.mode = 5;
+            g.ksize = d.ksize;
+            g.H = so.h;
+            g.W = so.w;
+            g.late_split = m->gemm_late_split;
+            rc = launch_gemm(g, s);
+            if (rc != PH_OK) return rc;
+            init[srcs[part]] = 1;
+          }
+          break;
+        }
         for (int part = 0; part < 2; ++part) {
           if (parts[part] <= 0 || srcs[part] < 0) continue;
           const SlotShape& si = bp.act.slots[srcs[part]];
@@ -482,7 +528,11 @@ int ph_model_backward(ph_model* m, const void* input_dev, int32_t in_dtype, int3
             if (rc != PH_OK) return rc;
           }
         }
-        rc = launch_input_wgrad(input_dev, in_dtype, G(d.dst), batch, d.cin0, height, width, so.cp, d.cout, grads_flat_dev + m->weight_offset[d.weight], scratch, s);
+        if (d.ksize != 3)  // first k x k "same" conv: im2col of the image + one row-wgrad GEMM (as the ConvNeXt patch stem, padding k / 2, stride 1)
+          rc = launch_patch_stem_wgrad(input_dev, in_dtype, G(d.dst), batch, d.cin0, height, width, so.h, so.w, d.ksize, 1, d.ksize / 2, so.cp, d.cout,
+                                       grads_flat_dev + m->weight_offset[d.weight], scratch, s);
+        else
+          rc = launch_input_wgrad(input_dev, in_dtype, G(d.dst), batch, d.cin0, height, width, so.cp, d.cout, grads_flat_dev + m->weight_offset[d.weight], scratch, s);
         break;
       }
       case PH_OP_POOL: {
@@ -640,7 +690,7 @@ int ph_model_backward(ph_model* m, const void* input_dev, int32_t in_dtype, int3
         PH_REQUIRE(d.cin0 == in_channels, "input has %d channels, network expects %d", in_channels, d.cin0);
         rc = launch_bias_grad(G(d.dst), (size_t)batch * so.h * so.w, so.cp, d.cout, grads_flat_dev + m->weight_offset[d.bias], scratch, s);
         if (rc != PH_OK) return rc;
-        rc = launch_patch_stem_wgrad(input_dev, in_dtype, G(d.dst), batch, d.cin0, height, width, so.h, so.w, d.ksize, d.cmid, so.cp, d.cout,
+        rc = launch_patch_stem_wgrad(input_dev, in_dtype, G(d.dst), batch, d.cin0, height, width, so.h, so.w, d.ksize, d.cmid, 1, so.cp, d.cout,
                                      grads_flat_dev + m->weight_offset[d.weight], scratch, s);
         break;
       }

@@ -58,7 +58,8 @@ struct RowWgradArgs {
   const float* x;   // input activations, kp channels (rows = pixels; patch mode gathers 2x2/stride-2 taps)
   float* slab;      // scratch: [slices][blocks][128][128]
   int np, kp, M;
-  int patch = 0, tap = 0, H = 0, W = 0;  // patch 1: 2x2/stride-2 taps (dy, dx); patch 2: 3x3 "same" conv taps; patch 3: 3x3 stride-2 pad-1 taps (rows on the H/2 x W/2 grid); H, W = size of the gathered map
+  int patch = 0, tap = 0, H = 0, W = 0;  // patch 1: 2x2/stride-2 taps (dy, dx); patch 2: k x k "same" conv taps (ksize); patch 3: 3x3 stride-2 pad-1 taps (rows on the H/2 x W/2 grid); H, W = size of the gathered map
+  int ksize = 3;                         // patch 2: odd kernel size, tap = ky * ksize + kx
 };
 int launch_gelu_fwd(const float* x, float* y, size_t n, hipStream_t s);
 int launch_gelu_bwd(const float* gy, const float* x, float* gx, int accumulate, size_t n, hipStream_t s);
@@ -72,8 +73,8 @@ int64_t dwconv7_wgrad_scratch_floats(int B, int H, int cp);
 int launch_row_wgrad(const RowWgradArgs& a, int n, int k, int taps, float* grad, hipStream_t s);
 int launch_row_wgrad_part(const RowWgradArgs& a, int n, int k, int k_total, int k_off, int taps, float* grad, hipStream_t s);
 int64_t row_wgrad_slab_floats(int M, int n, int k);
-int launch_patch_stem_wgrad(const void* img, int dtype, const float* dy, int B, int cin, int H, int W, int OH, int OW, int k, int stride, int coutp, int cout, float* gw,
-                            float* scratch, hipStream_t s);
+int launch_patch_stem_wgrad(const void* img, int dtype, const float* dy, int B, int cin, int H, int W, int OH, int OW, int k, int stride, int pad, int coutp, int cout, float* gw,
+                            float* scratch, hipStream_t s);  // pad 1: the ConvNeXt stem; pad k / 2 with stride 1: the first k x k "same" conv of a UNet
 int64_t patch_stem_wgrad_scratch_floats(int cin, int cout, int k, int64_t npix);
 int launch_class_ce(const float* p, const float* y, int B, int C, float weight, float* dz, float* loss_out, hipStream_t s);
 int launch_global_maxpool_bwd(const float* x, const float* gy, int B, int HW, int cp, int accumulate, float* gx, hipStream_t s);

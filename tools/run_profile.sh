@@ -16,7 +16,7 @@ rocprofv3 --output-format csv --pmc FETCH_SIZE --kernel-trace -d $O/pmc_FETCH_SI
 rocprofv3 --output-format csv --pmc WRITE_SIZE --kernel-trace -d $O/pmc_WRITE_SIZE -- python3 bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-alt-precisions --no-h2d-leg --no-extra-legs --no-graph > $O/pmc_write.log 2>&1
 rocprofv3 --output-format csv --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT --kernel-trace -d $O/pmc_SQ -- python3 bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-alt-precisions --no-h2d-leg --no-extra-legs --no-graph > $O/pmc_sq.log 2>&1
 mkdir -p $O/summary
-python3 tools/summarize_pmc.py $O $TAG 4 > $O/summary/traffic.txt 2>&1
+python3 tools/summarize_pmc.py $O $TAG 5 > $O/summary/traffic.txt 2>&1
 cp profiles/${TAG}_conv_traffic.json $O/conv_traffic.json 2>/dev/null
 python3 tools/pmc_table.py $O/pmc_SQ conv3x3 > $O/summary/sq_conv.txt 2>&1
 find $O -name "*.db" -delete
