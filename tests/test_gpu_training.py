@@ -412,3 +412,65 @@ def test_fine_tuning_the_reference_bottomup_fixture_checkpoint():
     _check_grads(tm, ref_grads)
     losses = [float(tm.training_step({"image": img, **tg})[0]) for _ in range(4)]
     assert losses[-1] < losses[0]
+
+
+@pytest.mark.parametrize("case", ["k5_bilinear", "k5_transposed_rgb", "k7_small", "stem_block", "stem_block_wide"])
+def test_backward_of_wide_kernels_and_stem_blocks(case):
+    """kernel_size 5 / 7 and StemBlock UNets train (VERDICT r2 "Missing 1"; encoder_decoder.py:38-141,144-225, unet.py:230-253): the k x k
+    weight gradient is k^2 row-wgrad GEMMs (one per tap), the data gradient the k^2-tap row GEMM on the flipped, in/out-swapped weights
+    (accumulating into skip tensors), the first k x k conv's weight gradient an im2col + one row-wgrad GEMM.  Loss and every parameter
+    gradient vs autograd over the oracle, then an Adam step that lowers the loss."""
+    if case == "k5_bilinear":
+        bb, heads, mt = _cfg(8, 8, 2)
+        bb["kernel_size"] = 5
+        hw, B = (48, 64), 2
+    elif case == "k5_transposed_rgb":
+        bb, heads, mt = _cfg(12, 8, 2, in_ch=3, bottomup=False)
+        bb["kernel_size"] = 5
+        bb["up_interpolate"] = False
+        hw, B = (40, 56), 3
+    elif case == "k7_small":
+        bb, heads, mt = _cfg(8, 4, 1, bottomup=False)
+        bb["kernel_size"] = 7
+        hw, B = (32, 40), 2
+    elif case == "stem_block":
+        bb, heads, mt = _cfg(8, 16, 4)
+        bb["stem_stride"] = 2
+        hw, B = (64, 96), 2
+    else:  # wider channels: N tiles of 64 in the 7x7 data-gradient GEMMs, 3x3 layers on the Winograd kernels next to them
+        bb, heads, mt = _cfg(24, 16, 2, n_nodes=4)
+        bb["stem_stride"] = 2
+        hw, B = (64, 64), 3
+    sd, img, targets, lw, tm = _setup(bb, heads, mt, hw, B, seed=31)
+    ref_losses, ref_grads = O.training_step(sd, bb, heads, mt, img, targets, lw)
+    loss = tm.forward_backward(img, targets).cpu().numpy()
+    assert np.allclose(loss, np.array(ref_losses, dtype=np.float32), rtol=1e-5, atol=1e-6)
+    worst = _check_grads(tm, ref_grads)
+    assert worst <= 1e-4
+    batch = {"image": img, **targets}
+    first = float(tm.training_step(batch)[0])
+    for _ in range(3):
+        last = float(tm.training_step(batch)[0])
+    assert np.isfinite(last) and last < first
+
+
+def test_winograd_weight_gradients_against_the_float64_oracle_per_tensor():
+    """the end-to-end Adam bound of the default weight-gradient path (wgrad_wino = 1) is loose by design; this pins
+    wgrad_wino_kernel / wgrad16_wino_kernel directly: every parameter gradient of one step against the FLOAT64 oracle, per tensor
+    max error / tensor scale, for the Winograd-domain kernels and for the direct kernels of the same handle (both ~1e-6: fp32 rounding)."""
+    bb, heads, mt = _cfg(16, 16, 4, n_nodes=4)
+    hw, B = (96, 128), 2
+    sd, img, targets, lw, tm = _setup(bb, heads, mt, hw, B, seed=37)
+    sd64 = {k: v.double() for k, v in sd.items()}
+    _, ref64 = O.training_step(sd64, bb, heads, mt, img, {k: v.double() for k, v in targets.items()}, lw)
+    worst = {}
+    for wino in (1, 0):
+        tm.model.set_option("wgrad_wino", wino)
+        tm.forward_backward(img, targets)
+        got = tm.named_grads()
+        w = 0.0
+        for k, r in ref64.items():
+            scale = max(float(r.abs().max()), 1e-30)
+            w = max(w, float((got[k].double() - r).abs().max()) / scale)
+        worst[wino] = w
+    assert worst[1] <= 5e-6 and worst[0] <= 5e-6, worst
