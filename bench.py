@@ -656,9 +656,12 @@ def train_leg(cfg, B, global_batch, steps, warmup, ctx, scaling="weak"):
     # Executed on the matrix pipe per step.  Forward: per launch by the kernel the library reports (ph_model_last_kernels).  Backward:
     # the data gradient of a 3x3 conv is the same kernel family on swapped channel counts (one conv per concat source) -- F(2x2,3x3)
     # (4/9) for N tiles of 64 output channels with >= 32 input channels (conv3x3_wino2d_kernel) and for one-source layers with 16 / 32
-    # channels on both sides (conv3x3_w16_kernel), F(2,3) along x (2/3) otherwise -- and every 3x3 weight gradient runs in the
+    # channels on both sides (conv3x3_w16_kernel), F(4x4,3x3) (1/4) from 128 input channels on, F(2,3) along x (2/3) otherwise -- and every 3x3 weight gradient runs in the
     # F(2x2,3x3) domain (4/9: wgrad_wino_kernel, wgrad16_wino_kernel); row GEMMs (Linear, 2x2/s2 convs) run direct in all three.
-    def share(cin_p, cout_p, one_source=True):
+    def share(cin_p, cout_p, one_source=True, hw=(0, 0)):
+        h, w = hw
+        if cout_p >= 64 and cin_p >= 128 and h % 4 == 0 and w % 4 == 0 and h * w * 1.3 / (-(-h // 16) * 16 * -(-w // 32) * 32) >= h * w / (-(-h // 16) * 16 * -(-w // 16) * 16):
+            return 0.25  # conv3x3_wino4_kernel (TrainingModule runs it in the training plan: conv_wino4 = 2), same route rule as wino4_fits
         if cout_p >= 64 and cin_p >= 32:
             return 4.0 / 9.0
         if one_source and cout_p in (16, 32) and cin_p in (16, 32):
@@ -672,7 +675,7 @@ def train_leg(cfg, B, global_batch, steps, warmup, ctx, scaling="weak"):
             cin = r["cin0"] + r["cin1"]
             for part in (r["cin0"], r["cin1"]):  # data gradient: one conv per concat source, Cout -> part channels
                 if part > 0:
-                    executed += r["flops"] * part / cin * share(_pad16(r["cout"]), _pad16(part))
+                    executed += r["flops"] * part / cin * share(_pad16(r["cout"]), _pad16(part), True, r.get("out_hw", (0, 0)))
             executed += r["flops"] * 4.0 / 9.0  # weight gradient
         elif r["kind"] in (L.OP_INPUT_CONV, L.OP_PATCH_STEM):
             executed += r["flops"]  # weight gradient only (no data gradient into the image)

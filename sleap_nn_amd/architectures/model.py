@@ -497,7 +497,7 @@ class Model:
             in_bytes = (1 if op.src0 < 0 else 4) * op.cin0 * h * w * batch + 4 * op.cin1 * h * w * batch
             out_bytes = 4 * cout * oh * ow * batch
             rows.append({"label": op.label.split(".")[-1], "kind": op.kind, "flops": flops, "bytes": float(in_bytes + out_bytes),
-                         "cin0": op.cin0, "cin1": op.cin1, "cout": cout, "ksize": op.ksize})
+                         "cin0": op.cin0, "cin1": op.cin1, "cout": cout, "ksize": op.ksize, "out_hw": (oh, ow)})
             if op.kind != L.OP_HEAD:
                 hw[op.dst] = (oh, ow)
             if op.kind == L.OP_CONV and op.dst2 >= 0:

@@ -643,23 +643,24 @@ ph_model* ph_model_create(const ph_op_desc* ops, int32_t n_ops, const float* con
         };
         if (ok && !tr) ok = derive_wino2(op.w_dev, d.cin0, d.cin1, d.cout, op.bn, &op.w_wino2_dev);
         // F(4x4,3x3) weights (conv3x3_wino4_kernel) of the layers with many input channels: 4x the direct weights' bytes
-        if (ok && !tr && op.bn == 64 && pad16(d.cin0) + (d.cin1 > 0 ? pad16(d.cin1) : 0) >= 128) {
-          const int ntiles = (pad16(d.cout) + 63) / 64, nchunks = pad16(d.cin0) / 16 + (d.cin1 > 0 ? pad16(d.cin1) / 16 : 0);
+        auto derive_wino4 = [&](const float* src, int cin_a, int cin_b, int cout_, int bn, float** dst) {
+          if (bn != 64 || pad16(cin_a) + (cin_b > 0 ? pad16(cin_b) : 0) < 128) return true;
+          const int ntiles = (pad16(cout_) + 63) / 64, nchunks = pad16(cin_a) / 16 + (cin_b > 0 ? pad16(cin_b) / 16 : 0);
           float* w = nullptr;
-          ok = hipMalloc(&w, (size_t)wino4_pack_floats(ntiles, nchunks) * sizeof(float)) == hipSuccess;
-          if (ok) {
-            m->allocs.push_back(w);
-            ok = launch_wino4_pack(op.w_dev, w, ntiles, nchunks, nullptr) == PH_OK;
-            DerivedBuffer db;
-            db.src = op.w_dev;
-            db.dst = w;
-            db.panels = ntiles;
-            db.bn = nchunks;
-            db.kind = 5;
-            m->derived.push_back(db);
-            op.w_wino4_dev = w;
-          }
-        }
+          if (hipMalloc(&w, (size_t)wino4_pack_floats(ntiles, nchunks) * sizeof(float)) != hipSuccess) return false;
+          m->allocs.push_back(w);
+          if (launch_wino4_pack(src, w, ntiles, nchunks, nullptr) != PH_OK) return false;
+          DerivedBuffer db;
+          db.src = src;
+          db.dst = w;
+          db.panels = ntiles;
+          db.bn = nchunks;
+          db.kind = 5;
+          m->derived.push_back(db);
+          *dst = w;
+          return true;
+        };
+        if (ok && !tr) ok = derive_wino4(op.w_dev, d.cin0, d.cin1, d.cout, op.bn, &op.w_wino4_dev);
         // wave-private F(2x2,3x3) weights (conv3x3_w16_kernel: 16 / 32 output channels, 16 / 32 input channels, one source): the forward
         // conv's, and below the data-gradient convs'
         auto derive_w16 = [&](const float* src, int cin_, int cout_, int bn, float** dst) {
@@ -754,7 +755,8 @@ ph_model* ph_model_create(const ph_op_desc* ops, int32_t n_ops, const float* con
                  pack_upload(m, pack_dd, weights[d.weight], iw, &op.wd_dma_dev[part]) == PH_OK &&
                  derive_wino(op.wd_dev[part], d.cout, 0, parts[part], op.bn_d[part], &op.wd_wino_dev[part]) &&
                  derive_wino2(op.wd_dev[part], d.cout, 0, parts[part], op.bn_d[part], &op.wd_wino2_dev[part]) &&
-                 derive_w16(op.wd_dev[part], d.cout, parts[part], op.bn_d[part], &op.wd_w16_dev[part]);
+                 derive_w16(op.wd_dev[part], d.cout, parts[part], op.bn_d[part], &op.wd_w16_dev[part]) &&
+                 derive_wino4(op.wd_dev[part], d.cout, 0, parts[part], op.bn_d[part], &op.wd_wino4_dev[part]);
           }
           if (ok) {
             std::vector<float> zb((size_t)pad16(std::max(d.cin0, d.cin1)) + max_bn, 0.f);

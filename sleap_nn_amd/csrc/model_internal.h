@@ -39,6 +39,7 @@ struct PackedOp {
   float* w_wino2_dev = nullptr;            // 3x3 conv, N tile 64: Winograd F(2x2,3x3) weights derived from w_dev
   float* wd_wino2_dev[2] = {nullptr, nullptr};  // ... and from wd_dev (data gradient)
   float* w_wino4_dev = nullptr;            // 3x3 conv, N tile 64, >= 128 padded input channels: Winograd F(4x4,3x3) weights derived from w_dev
+  float* wd_wino4_dev[2] = {nullptr, nullptr};  // ... and from wd_dev (data gradient: Cout input channels)
   // ConvTranspose2d(k3, s2, p1, op1) as four output-phase row GEMMs (mode 3) + its data gradient (mode 4)
   float* wt_phase_dev[4] = {nullptr, nullptr, nullptr, nullptr};
   float* bt_dev = nullptr;       // bias padded to the GEMM's N tiles

@@ -428,6 +428,8 @@ int ph_model_backward(ph_model* m, const void* input_dev, int32_t in_dtype, int3
           a.wpack_wino = op.wd_wino_dev[part];
           a.wpack_wino2 = op.wd_wino2_dev[part];
           a.wpack_w16 = op.wd_w16_dev[part];
+          a.wpack_wino4 = op.wd_wino4_dev[part];
+          a.use_wino4 = m->conv_wino4 == 2;  // (training plans keep every slot: the F(4x4,3x3) kernel runs in them only on request)
           a.w16 = op.wd16_dev;
           a.bias = op.zero_bias_dev;
           a.dst = G(srcs[part]);

@@ -490,7 +490,12 @@ bool wino4_fits(const ConvArgs& a) {
   const uint64_t px = (uint64_t)a.B * a.H * a.W;
   if (px * (uint64_t)a.c0p * 4 >= 0xFFFFFF00ull || px * (uint64_t)a.c1p * 4 >= 0xFFFFFF00ull || px >= 0x7FFFFFFFull) return false;
   const uint64_t wbytes = (uint64_t)((a.coutp + 63) / 64) * (uint64_t)((a.c0p + a.c1p) / 4) * W4_Q_FLOATS * 4;
-  return wbytes < 0xFFFFFF00ull;
+  if (wbytes >= 0xFFFFFF00ull) return false;
+  // small feature maps: the 32 x 16-pixel workgroup tile pads more than the F(2x2,3x3) kernel's 16 x 16 one (12 x 12 maps: 28 % against 56 % fill).  This
+  // kernel is worth ~1.3x at equal fill (measured, cfg3), so it keeps a layer only while its fill is within that factor of the other kernel's
+  const double fill4 = (double)a.H * a.W / ((double)((a.H + W4_PH - 1) / W4_PH * W4_PH) * ((a.W + W4_PW - 1) / W4_PW * W4_PW));
+  const double fill2 = (double)a.H * a.W / ((double)((a.H + 15) / 16 * 16) * ((a.W + 15) / 16 * 16));
+  return fill4 * 1.3 >= fill2;
 }
 
 int launch_conv3x3_wino4(const ConvArgs& a, hipStream_t s) {

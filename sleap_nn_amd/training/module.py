@@ -39,10 +39,12 @@ class TrainingModule:
     def __init__(self, model: Model, device: str = "cuda", lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8, amsgrad: bool = False,
                  optimizer: str = "Adam", weight_decay: Optional[float] = None,
                  loss_weights: Optional[Sequence[float]] = None, ohkm: Optional[OHKMConfig] = None,
-                 negative_loss_weight: float = 1.0, lr_scheduler=None, max_epochs: Optional[int] = None) -> None:
+                 negative_loss_weight: float = 1.0, lr_scheduler=None, max_epochs: Optional[int] = None, wino4: bool = True) -> None:
         """``negative_loss_weight``: weight of frames flagged ``is_negative`` in the train-stage MSE (lightning_modules.py:149-153,
         526-545).  ``lr_scheduler``: the reference's scheduler config (a name or ``{name: {...}}``, lightning_modules.py:765-857);
-        ``self.lr`` then follows it: one ``on_epoch_end(val_loss)`` per epoch, like Lightning steps the scheduler."""
+        ``self.lr`` then follows it: one ``on_epoch_end(val_loss)`` per epoch, like Lightning steps the scheduler.
+        ``wino4``: the K-heavy 3x3 convolutions of the forward and of the data gradients run the Winograd F(4x4,3x3) kernel in the
+        training plan too (handle option ``conv_wino4 = 2``; gradients within ~1e-5 of their tensor's scale of the F(2x2,3x3) ones)."""
         L.lib()
         if not torch.cuda.is_available():
             raise RuntimeError("TrainingModule needs an MI355X; there is no CPU fallback")
@@ -51,6 +53,7 @@ class TrainingModule:
             dev = torch.device("cuda", torch.cuda.current_device())
         self.device = dev
         self.model = model.train(True).to(dev)
+        self.model.set_option("conv_wino4", 2 if wino4 else 1)
         self.lr, self.betas, self.eps, self.amsgrad = lr, betas, eps, amsgrad
         if optimizer not in ("Adam", "AdamW"):
             raise ValueError(f"optimizer must be 'Adam' or 'AdamW' (lightning_modules.py:752-755), got {optimizer!r}")
