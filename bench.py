@@ -660,8 +660,12 @@ def train_leg(cfg, B, global_batch, steps, warmup, ctx, scaling="weak"):
     # F(2x2,3x3) domain (4/9: wgrad_wino_kernel, wgrad16_wino_kernel); row GEMMs (Linear, 2x2/s2 convs) run direct in all three.
     def share(cin_p, cout_p, one_source=True, hw=(0, 0)):
         h, w = hw
-        if cout_p >= 64 and cin_p >= 128 and h % 4 == 0 and w % 4 == 0 and h * w * 1.3 / (-(-h // 16) * 16 * -(-w // 32) * 32) >= h * w / (-(-h // 16) * 16 * -(-w // 16) * 16):
-            return 0.25  # conv3x3_wino4_kernel (TrainingModule runs it in the training plan: conv_wino4 = 2), same route rule as wino4_fits
+        if cout_p >= 64 and cin_p >= 128 and h > 0 and h % 4 == 0 and w % 4 == 0:
+            # conv3x3_wino4_kernel (TrainingModule runs it in the training plan: conv_wino4 = 2) where wino4_fits estimates it faster: rounds of the chip x time per tile
+            ntc, n_cu = -(-cout_p // 64), 256
+            t4, t2 = -(-h // 16) * -(-w // 32) * B * ntc, -(-h // 16) * -(-w // 16) * B * ntc
+            if -(-t4 // n_cu) * (2.0 / 1.3) <= -(-t2 // n_cu):
+                return 0.25
         if cout_p >= 64 and cin_p >= 32:
             return 4.0 / 9.0
         if one_source and cout_p in (16, 32) and cin_p in (16, 32):

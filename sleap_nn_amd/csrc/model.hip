@@ -940,7 +940,7 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
     rc = drain_events(m);
     if (rc != PH_OK) return rc;
   }
-  if (m->wino4_stale && (m->conv_wino4 == 2 || (m->conv_wino4 == 1 && plan.reuse))) {
+  if (m->wino4_stale && (m->conv_wino4 >= 2 || (m->conv_wino4 == 1 && plan.reuse))) {
     for (const DerivedBuffer& db : m->derived)
       if (db.kind == 5) {
         rc = launch_wino4_pack(db.src, db.dst, db.panels, db.bn, s);
@@ -1089,7 +1089,7 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
         a.zeros = m->zeros_dev;
         apply_conv_options(m, a);
         a.wpack_wino4 = op.w_wino4_dev;
-        a.use_wino4 = m->conv_wino4 == 2 || (m->conv_wino4 == 1 && plan.reuse);
+        a.use_wino4 = m->conv_wino4 == 3 ? 2 : ((m->conv_wino4 == 2 || (m->conv_wino4 == 1 && plan.reuse)) ? 1 : 0);
         if (deferred_up >= 0) {
           // The op before this one is a bilinear x2 that only feeds this conv's second source and was not launched: the F(4x4,3x3) kernel
           // reads the half-resolution tensor itself (the up-sampling rides in its input transform); any other kernel gets the tensor now.
@@ -1479,7 +1479,7 @@ std::vector<OptionRef> option_table(ph_model* m) {
       {"conv_wino", &m->conv_wino, nullptr},            // 1 Winograd F(2,3) 3x3 kernels, 2 only N-tile-64 layers, 0 direct 9-tap kernels
       {"conv_w16", &m->conv_w16, nullptr},              // 1: Cout-32 / Cin-16-or-32 3x3 convs on the wave-private F(2x2,3x3) kernel; 0: F(2,3) along x
       {"conv_wino2d", &m->conv_wino2d, nullptr},        // 1: N-tile-64 3x3 convs on the F(2x2,3x3) kernel; 0: F(2,3) along x only
-      {"conv_wino4", &m->conv_wino4, nullptr},          // K-heavy 3x3 convs on the F(4x4,3x3) kernel: 1 inference plans, 2 every plan, 0 never
+      {"conv_wino4", &m->conv_wino4, nullptr},          // K-heavy 3x3 convs on the F(4x4,3x3) kernel: 1 inference plans, 2 every plan (both: where estimated faster), 3 every plan wherever it fits, 0 never
       {"conv_wino4_min_cin", &m->conv_wino4_min_cin, nullptr},  // padded input channels from which a layer takes it
       {"upsample_fold", &m->upsample_fold, nullptr},    // bilinear x2 folded into the F(4x4,3x3) input transform of the conv that consumes it
       {"stem_wino", &m->stem_wino, nullptr},            // second conv of the fused stem in Winograd form

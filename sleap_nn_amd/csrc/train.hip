@@ -156,7 +156,7 @@ int ph_model_set_params(ph_model* m, const float* params_flat_dev, void* stream)
   for (const DerivedBuffer& db : m->derived) {
     if ((db.kind == 0 && db.bn != 0) || db.kind == 2) continue;  // in the two launches above
     if (db.kind == 5) {  // F(4x4,3x3) weights: only inference plans read them (conv_wino4 = 1) -- a training step does not pay for the re-derivation,
-      if (m->conv_wino4 != 2 && !m->workspace_reuse) {  // the next forward that wants them refreshes them (ph_model_forward)
+      if (m->conv_wino4 < 2 && !m->workspace_reuse) {  // the next forward that wants them refreshes them (ph_model_forward)
         m->wino4_stale = true;
         continue;
       }
@@ -429,7 +429,7 @@ int ph_model_backward(ph_model* m, const void* input_dev, int32_t in_dtype, int3
           a.wpack_wino2 = op.wd_wino2_dev[part];
           a.wpack_w16 = op.wd_w16_dev[part];
           a.wpack_wino4 = op.wd_wino4_dev[part];
-          a.use_wino4 = m->conv_wino4 == 2;  // (training plans keep every slot: the F(4x4,3x3) kernel runs in them only on request)
+          a.use_wino4 = m->conv_wino4 == 3 ? 2 : (m->conv_wino4 == 2 ? 1 : 0);  // (training plans keep every slot: the F(4x4,3x3) kernel runs in them only on request)
           a.w16 = op.wd16_dev;
           a.bias = op.zero_bias_dev;
           a.dst = G(srcs[part]);

@@ -491,11 +491,18 @@ bool wino4_fits(const ConvArgs& a) {
   if (px * (uint64_t)a.c0p * 4 >= 0xFFFFFF00ull || px * (uint64_t)a.c1p * 4 >= 0xFFFFFF00ull || px >= 0x7FFFFFFFull) return false;
   const uint64_t wbytes = (uint64_t)((a.coutp + 63) / 64) * (uint64_t)((a.c0p + a.c1p) / 4) * W4_Q_FLOATS * 4;
   if (wbytes >= 0xFFFFFF00ull) return false;
-  // small feature maps: the 32 x 16-pixel workgroup tile pads more than the F(2x2,3x3) kernel's 16 x 16 one (12 x 12 maps: 28 % against 56 % fill).  This
-  // kernel is worth ~1.3x at equal fill (measured, cfg3), so it keeps a layer only while its fill is within that factor of the other kernel's
-  const double fill4 = (double)a.H * a.W / ((double)((a.H + W4_PH - 1) / W4_PH * W4_PH) * ((a.W + W4_PW - 1) / W4_PW * W4_PW));
-  const double fill2 = (double)a.H * a.W / ((double)((a.H + 15) / 16 * 16) * ((a.W + 15) / 16 * 16));
-  return fill4 * 1.3 >= fill2;
+  // Against the F(2x2,3x3) kernel, which would run the layer otherwise: this kernel is worth ~1.3x per pixel at equal tile fill (measured, cfg3), but its
+  // workgroup tile is 32 x 16 pixels against 16 x 16 -- it pads more on small maps (12 x 12: 28 % against 56 % fill) and has half as many tiles to deal
+  // over the CUs (cfg3's 64 x 64 decoder level at 4 frames: 128 tiles x N tiles for 256 CUs).  Compare the two kernels' times in units of
+  // "rounds of the chip x time per tile" (one persistent workgroup per CU; a tile here costs 2 / 1.3 of a tile there).
+  if (a.use_wino4 >= 2) return true;  // forced (handle option conv_wino4 = 3: tests, the timing harness)
+  int n_cu = 0;
+  if (device_cu_count(&n_cu) != PH_OK || n_cu <= 0) n_cu = 256;
+  const long ntc = (a.coutp + 63) / 64;
+  const long t4 = (long)((a.H + W4_PH - 1) / W4_PH) * ((a.W + W4_PW - 1) / W4_PW) * a.B * ntc;
+  const long t2 = (long)((a.H + 15) / 16) * ((a.W + 15) / 16) * a.B * ntc;
+  const double cost4 = (double)((t4 + n_cu - 1) / n_cu) * (2.0 / 1.3), cost2 = (double)((t2 + n_cu - 1) / n_cu);
+  return cost4 <= cost2;
 }
 
 int launch_conv3x3_wino4(const ConvArgs& a, hipStream_t s) {

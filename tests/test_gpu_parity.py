@@ -399,6 +399,10 @@ def test_cfg3_benched_workload_full_size_vs_oracle_and_batch_invariance(precisio
     from sleap_nn_amd.architectures.model import Model
 
     m = Model("unet", bench.CFG3_BB, bench.CFG3_HEADS, "bottomup").init_xavier_(seed=1234, head_scale=0.05).to(DEV).set_precision(precision)
+    # Which kernel runs a K-heavy layer depends on the number of tiles to deal over the CUs, i.e. on the batch (at one frame F(2x2,3x3) keeps the
+    # 64 x 64 level, at 32 frames F(4x4,3x3) takes it: wino4_fits): the bit-for-bit batch invariance below is a property of ONE kernel choice, so it is
+    # pinned here -- F(4x4,3x3) wherever the shape fits, what the 32-frame bench runs
+    m.set_option("conv_wino4", 3)
     sd = m.state_dict()
     g = torch.Generator().manual_seed(4321)
     frames = torch.randint(0, 256, (32, 1, bench.SIZE, bench.SIZE), dtype=torch.uint8, generator=g)
@@ -1017,7 +1021,8 @@ def test_winograd_f4x4_kernel_and_folded_bilinear_match_oracle_and_the_f2x2_kern
     ref = O.model_forward(sd, bb, heads, "single_instance", img, collect=collect)["SingleInstanceConfmapsHead"]
     scale = ref.abs().max().item()
     outs, n4 = {}, {}
-    for name, opts, keep in (("fold", {}, False), ("nofold", {"upsample_fold": 0}, False), ("every_plan", {"conv_wino4": 2}, True), ("f2x2", {"conv_wino4": 0}, False)):
+    # (conv_wino4 = 3 forces the kernel wherever the shape fits: at these sizes the default's cost estimate -- rounds of the chip -- keeps F(2x2,3x3))
+    for name, opts, keep in (("default", {}, False), ("fold", {"conv_wino4": 3}, False), ("nofold", {"conv_wino4": 3, "upsample_fold": 0}, False), ("every_plan", {"conv_wino4": 3}, True), ("f2x2", {"conv_wino4": 0}, False)):
         m = Model("unet", bb, heads, "single_instance")
         m.load_state_dict(sd)
         for k, v in opts.items():
@@ -1026,8 +1031,9 @@ def test_winograd_f4x4_kernel_and_folded_bilinear_match_oracle_and_the_f2x2_kern
         outs[name] = m(img.to(DEV))["SingleInstanceConfmapsHead"].cpu()
         kv = m.last_kernels()
         n4[name] = sum(1 for c in kv if c == L.KV_WINO4)
+        if name == "default":
+            assert m.get_option("conv_wino4") == 1.0 and m.get_option("upsample_fold") == 1.0
         if name == "fold":
-            assert m.get_option("conv_wino4") == 1.0 and m.get_option("upsample_fold") == 1.0  # the defaults
             ups = [i for i, op in enumerate(m.ops) if op.kind == L.OP_UPSAMPLE]
             folded = [i for i in ups if kv[i + 1] == L.KV_WINO4]
         if keep:
@@ -1047,11 +1053,12 @@ def test_winograd_f4x4_kernel_and_folded_bilinear_match_oracle_and_the_f2x2_kern
         assert n4["fold"] >= 2 and n4["f2x2"] == 0 and n4["every_plan"] >= n4["nofold"] >= 2, n4
         if os_ < max_stride:
             assert folded, "a decoder's bilinear x2 must ride in the F(4x4,3x3) kernel"
-    for name in ("fold", "nofold", "every_plan", "f2x2"):
+    for name in ("default", "fold", "nofold", "every_plan", "f2x2"):
         assert (outs[name] - ref).abs().max().item() <= W4_RTOL * scale, (name, n4)
     assert (outs["fold"] - outs["f2x2"]).abs().max().item() <= W4_RTOL * scale
     again = Model("unet", bb, heads, "single_instance")
     again.load_state_dict(sd)
+    again.set_option("conv_wino4", 3)
     assert torch.equal(again.to(DEV)(img.to(DEV))["SingleInstanceConfmapsHead"].cpu(), outs["fold"])  # run-to-run bitwise
 
 

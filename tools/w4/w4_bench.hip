@@ -38,7 +38,7 @@ int main(int argc, char** argv) {
   fill(d0, n0, 1.f); if (n1) fill(d1, n1, 1.f); fill(dw, nw, 0.05f); hipMemset(dbias, 0, 4096);
   ConvArgs a{};
   a.src0 = d0; a.src1 = c1 ? d1 : nullptr; a.c0p = c0; a.c1p = c1; a.coutp = cout; a.B = B; a.H = H; a.W = W; a.relu = 1; a.bn = 64;
-  a.bias = dbias; a.dst = dout; a.wpack_wino4 = dw; a.src1_lowres = c1 ? lowres : 0; a.use_wino4 = 1;
+  a.bias = dbias; a.dst = dout; a.wpack_wino4 = dw; a.src1_lowres = c1 ? lowres : 0; a.use_wino4 = 2;
   if (!wino4_fits(a)) return printf("shape does not fit\n"), 1;
 #ifdef W4_STAMP
   unsigned long long* probe;

@@ -21,7 +21,7 @@ def net(filters, max_stride, hw, B=2, seed=0, out_stride=None, min_cin=64):
     collect = {}
     ref = O.model_forward(sd, bb, heads, "single_instance", img, collect=collect)["SingleInstanceConfmapsHead"]
     outs, kinds = {}, {}
-    for name, opts, keep in (("w4fold", {"conv_wino4": 1, "conv_wino4_min_cin": min_cin}, False), ("w4", {"conv_wino4": 2, "conv_wino4_min_cin": min_cin}, True), ("w2d", {"conv_wino4": 0}, False)):
+    for name, opts, keep in (("w4fold", {"conv_wino4": 3, "conv_wino4_min_cin": min_cin}, False), ("w4", {"conv_wino4": 3, "conv_wino4_min_cin": min_cin}, True), ("w2d", {"conv_wino4": 0}, False)):
         m = Model("unet", bb, heads, "single_instance")
         m.load_state_dict(sd)
         for k, v in opts.items():
