@@ -202,6 +202,11 @@ int ph_render_pafs(const float* points_dev, const int32_t* edges_dev, int32_t B,
 int ph_debug_gemm_bench(int32_t variant, int32_t M, int32_t K, int32_t N, int32_t mode, int32_t H, int32_t W,
                         int32_t act, int32_t iters, float* ms_out);
 
+/* Diagnostic (tools/row_wgrad_bench.py): average milliseconds of the row weight-gradient GEMM dW[n][k] = sum_m dY[m][n] X[m][k]
+ * (Linear layers of the training step, train_kernels.h launch_row_wgrad) on synthetic operands, and the largest error of 64
+ * sampled entries against a float64 sum on the host, relative to the largest of them. */
+int ph_debug_row_wgrad_bench(int32_t M, int32_t n, int32_t k, int32_t iters, float* ms_out, float* max_rel_err_out);
+
 /* Per-handle options (the library reads no environment variables and keeps no process-global
  * tunables).  Every key selects between kernel variants that compute the same result; defaults
  * are the measured-best ones.  Keys: "conv_wino" (1 Winograd F(2,3) 3x3 kernels | 2 only the

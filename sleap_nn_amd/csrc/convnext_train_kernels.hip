@@ -326,41 +326,50 @@ int64_t dwconv7_wgrad_scratch_floats(int B, int H, int cp) { return (int64_t)dwg
 //   the slices in a fixed order into the canonical gradient.
 // ---------------------------------------------------------------------------------------
 constexpr int RW_ROWS = 32;
+// LDS layout of one operand chunk: TRANSPOSED, [128 channels][32 rows], so that the four rows a lane contracts in four consecutive MFMAs are one
+// ds_read_b128 (a dword per MFMA and operand before: as many LDS instructions as MFMAs).  Row group g (4 rows = 16 B) of channel ch sits at
+// ch * 32 + 4 * (g ^ ((ch >> 1) & 7)) floats: 16 consecutive channels reading one row group touch 16 distinct 16-B slots (conflict-free).
+__device__ __forceinline__ int rw_slot(int ch, int g) { return ch * RW_ROWS + 4 * (g ^ ((ch >> 1) & 7)); }
+// TK = 2: tile 128 (n) x 128 (k), waves 2 x 2, wave tile 64 x 64.  TK = 3: tile 128 x 96, waves 4 x 1, wave tile 32 x 96 -- for operands whose channel
+// count is a multiple of 96 but not of 128 (ConvNeXt widths 96 and 192: a 128-wide tile multiplies 25 % padding).
+template <int TK>
 __global__ __launch_bounds__(256, 2) void row_wgrad_kernel(RowWgradArgs a) {
+  constexpr int TN = TK == 2 ? 2 : 1, KTILE = TK == 2 ? 128 : 96;
   __shared__ __attribute__((aligned(16))) float sY[2][RW_ROWS * 128];
   __shared__ __attribute__((aligned(16))) float sA[2][RW_ROWS * 128];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lx = lane & 31, lh = lane >> 5;
-  const int n_kt = (a.kp + 127) / 128;
+  const int n_kt = (a.kp + KTILE - 1) / KTILE;
   const int nt = blockIdx.x / n_kt, kt = blockIdx.x - nt * n_kt;
   const int slice = blockIdx.y, n_slices = gridDim.y;
-  const int wn = wave >> 1, wk = wave & 1;  // wave tile: n in [wn*64, +64), k in [wk*64, +64)
+  const int wn = TK == 2 ? wave >> 1 : wave, wk = TK == 2 ? wave & 1 : 0;  // wave tile: n in [wn * 32 TN, + 32 TN), k in [wk * 32 TK, + 32 TK)
   const int chunks = (a.M + RW_ROWS - 1) / RW_ROWS;
   const int per = (chunks + n_slices - 1) / n_slices;
   const int c_lo = slice * per, c_hi = min(chunks, c_lo + per);
 
-  f32x16 acc[2][2];
+  f32x16 acc[TN][TK];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TN; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < TK; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // staging: thread t moves float4 #(t & 31) of rows (t >> 5) + 8 * i, i = 0..3, of both operands.  The next
-  // chunk travels global -> registers (fetch) while this chunk's MFMAs run and lands in the other LDS buffer
+  // staging: thread t owns the 4 x 4 block (rows 4 g .. 4 g + 3, channels 4 sq .. 4 sq + 3) of both operands, g = t & 7, sq = t >> 3: one 16-B load per
+  // row (a wave's load instruction covers 8 rows x 128 B, whole cache lines), and the block leaves for LDS transposed -- register naming only -- as
+  // one 16-B write per channel.  The next chunk travels global -> registers (fetch) while this chunk's MFMAs run and lands in the other LDS buffer
   // afterwards (commit): the global latency is never exposed between two chunks.
-  const int sq = tid & 31, sr = tid >> 5;
-  f32x4 ry[4], ra[4];
-  auto fetch = [&](int chunk) __attribute__((always_inline)) {
+  const int sg = tid & 7, sq = tid >> 3;
+  f32x4 rys[1][4], ras[1][4];
+  auto fetch = [&](int chunk, f32x4 (&ry)[4], f32x4 (&ra)[4]) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int row = sr + 8 * i;
+      const int row = 4 * sg + i;
       const int m = chunk * RW_ROWS + row;
       const bool ok = m < a.M;
       const int mm = ok ? m : a.M - 1;
       const int cy = nt * 128 + sq * 4;
-      int ck = kt * 128 + sq * 4;
+      int ck = sq * 4 < KTILE ? kt * KTILE + sq * 4 : a.kp;
       f32x4 vy = {0.f, 0.f, 0.f, 0.f}, va = {0.f, 0.f, 0.f, 0.f};
       if (ok && cy < a.np) vy = *reinterpret_cast<const f32x4*>(a.dy + (size_t)mm * a.np + cy);
       if (ok && ck < a.kp) {
@@ -393,61 +402,125 @@ __global__ __launch_bounds__(256, 2) void row_wgrad_kernel(RowWgradArgs a) {
       ra[i] = va;
     }
   };
-  auto commit = [&](int buf) __attribute__((always_inline)) {
+  // Linear layers (patch 0, nearly all of the work): the rows of a slice are addressed through buffer descriptors based at the slice's first row -- a
+  // per-lane byte offset fixed for the whole launch plus the chunk's offset in a scalar register, no vector arithmetic per chunk (measured: the
+  // 64-bit row addressing and the range selects of the general path cost 16 % of the kernel); channels past np / kp get an offset beyond the
+  // descriptor's range and read as zeros.  (Range checking is not relied on for rows: whole chunks only.)
+  const bool fast = a.patch == 0 && (size_t)per * RW_ROWS * (size_t)max(a.np, a.kp) * 4 < 0x40000000ull;
+  __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, 0, 0x00020000), rs_a = rs_y;
+  unsigned vo_y[4], vo_a[4];
+  if (fast) {
+    const size_t row0 = (size_t)min(c_lo, chunks) * RW_ROWS;
+    const size_t left = (size_t)a.M - min(row0, (size_t)a.M);  // rows from the slice's first row to the end of the tensor
+    const size_t span = min(left, (size_t)per * RW_ROWS);
+    rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)(a.dy + row0 * a.np), 0, (int)(span * a.np * 4), 0x00020000);
+    rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + row0 * a.kp), 0, (int)(span * a.kp * 4), 0x00020000);
+    const int cy = nt * 128 + sq * 4, ck = sq * 4 < KTILE ? kt * KTILE + sq * 4 : a.kp;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int row = sr + 8 * i;
-      *reinterpret_cast<f32x4*>(&sY[buf][row * 128 + sq * 4]) = ry[i];
-      *reinterpret_cast<f32x4*>(&sA[buf][row * 128 + sq * 4]) = ra[i];
+      vo_y[i] = cy < a.np ? (unsigned)((4 * sg + i) * a.np + cy) * 4u : 0x80000000u;
+      vo_a[i] = ck < a.kp ? (unsigned)((4 * sg + i) * a.kp + ck) * 4u : 0x80000000u;
+    }
+  }
+  auto fetch_fast = [&](int chunk, f32x4 (&ry)[4], f32x4 (&ra)[4]) __attribute__((always_inline)) {
+    const int so_y = (chunk - c_lo) * RW_ROWS * a.np * 4, so_a = (chunk - c_lo) * RW_ROWS * a.kp * 4;  // scalar
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ry[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_y, vo_y[i], so_y, 0));
+      ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_a, vo_a[i], so_a, 0));
+    }
+  };
+  auto commit = [&](int buf, const f32x4 (&ry)[4], const f32x4 (&ra)[4]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) {
+      const int o = rw_slot(4 * sq + cc, sg);
+      *reinterpret_cast<f32x4*>(&sY[buf][o]) = f32x4{ry[0][cc], ry[1][cc], ry[2][cc], ry[3][cc]};
+      *reinterpret_cast<f32x4*>(&sA[buf][o]) = f32x4{ra[0][cc], ra[1][cc], ra[2][cc], ra[3][cc]};
     }
   };
 
-  if (c_lo < c_hi) {
-    fetch(c_lo);
-    commit(0);
-  }
-  __syncthreads();
-  for (int ch = c_lo; ch < c_hi; ++ch) {
-    const int buf = (ch - c_lo) & 1;
-    if (ch + 1 < c_hi) fetch(ch + 1);
-#pragma unroll 4
-    for (int s2 = 0; s2 < RW_ROWS / 2; ++s2) {
-      const int row = 2 * s2 + lh;
-      float fy[2], fa[2];
+  // fragment of MFMA step j of row-group pair q: element j of the 16 bytes at row group 2 q + lh, i.e. K rows {8 q + j, 8 q + 4 + j} over the two
+  // lane halves -- the same pairing in both operands, which is all the contraction needs
+  int chy[TN], cha[TK];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) fy[i] = sY[buf][row * 128 + wn * 64 + i * 32 + lx];
+  for (int i = 0; i < TN; ++i) chy[i] = (wn * TN + i) * 32 + lx;
 #pragma unroll
-      for (int j = 0; j < 2; ++j) fa[j] = sA[buf][row * 128 + wk * 64 + j * 32 + lx];
+  for (int j = 0; j < TK; ++j) cha[j] = (wk * TK + j) * 32 + lx;
+  auto multiply = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+    for (int q = 0; q < RW_ROWS / 8; ++q) {
+      f32x4 fy[TN], fa[TK];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fy[i], fa[j], acc[i][j], 0, 0, 0);
+      for (int i = 0; i < TN; ++i) fy[i] = *reinterpret_cast<const f32x4*>(&sY[buf][rw_slot(chy[i], 2 * q + lh)]);
+#pragma unroll
+      for (int j = 0; j < TK; ++j) fa[j] = *reinterpret_cast<const f32x4*>(&sA[buf][rw_slot(cha[j], 2 * q + lh)]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+          for (int j = 0; j < TK; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fy[i][e], fa[j][e], acc[i][j], 0, 0, 0);
     }
-    if (ch + 1 < c_hi) commit(buf ^ 1);
+  };
+  // Whole chunks of a Linear layer, [c_lo, c_full): the next chunk travels global -> registers while this chunk's MFMAs run and lands in the other LDS
+  // buffer afterwards.  (Fetching two chunks ahead with a second register set measured 10 % slower: 256 VGPRs, spills.)
+  const int c_full = fast ? max(c_lo, min(c_hi, a.M / RW_ROWS)) : c_lo;
+  if (c_lo < c_full) {
+    fetch_fast(c_lo, rys[0], ras[0]);
+    commit(0, rys[0], ras[0]);
     __syncthreads();
+    for (int ch = c_lo; ch < c_full; ch += 2) {
+      if (ch + 1 < c_full) fetch_fast(ch + 1, rys[0], ras[0]);
+      multiply(0);
+      if (ch + 1 < c_full) commit(1, rys[0], ras[0]);
+      __syncthreads();
+      if (ch + 1 >= c_full) break;
+      if (ch + 2 < c_full) fetch_fast(ch + 2, rys[0], ras[0]);
+      multiply(1);
+      if (ch + 2 < c_full) commit(0, rys[0], ras[0]);
+      __syncthreads();
+    }
+  }
+  // Everything else (gathered rows of the patch modes, a partial last chunk): the general fetch, one chunk ahead
+  if (c_full < c_hi) {
+    fetch(c_full, rys[0], ras[0]);
+    commit(0, rys[0], ras[0]);
+    __syncthreads();
+    for (int ch = c_full; ch < c_hi; ++ch) {
+      const int buf = (ch - c_full) & 1;
+      if (ch + 1 < c_hi) fetch(ch + 1, rys[0], ras[0]);
+      if (buf)
+        multiply(1);
+      else
+        multiply(0);
+      if (ch + 1 < c_hi) commit(buf ^ 1, rys[0], ras[0]);
+      __syncthreads();
+    }
   }
   // slab[slice][block][128 n][128 k];  D: row(n) = (r&3) + 8*(r>>2) + 4*lh, col(k) = lx
   float* slab = a.slab + ((size_t)slice * gridDim.x + blockIdx.x) * (128 * 128);
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TN; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < TK; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) slab[(size_t)(wn * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 128 + wk * 64 + j * 32 + lx] = acc[i][j][r];
+      for (int r = 0; r < 16; ++r) slab[(size_t)((wn * TN + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 128 + (wk * TK + j) * 32 + lx] = acc[i][j][r];
 }
 
 // grad[(n * k_total + k) * taps + tap] = sum_slices slab[...]; 1024 threads = 256 elements x 4 slice parts (a thread
 // walks a quarter of the slices, four loads in flight), the parts meet in LDS in a fixed order
+// (ktile: width of a block's k range, 128 or 96; swapped: the GEMM ran with the operands exchanged -- slab rows are k, columns n)
 __global__ __launch_bounds__(1024) void row_wgrad_reduce_kernel(const float* __restrict__ slab, int n_slices, int n_blocks, int n_kt, int n, int k, int k_total, int k_off,
-                                                                int taps, int tap, float* __restrict__ grad) {
+                                                                int taps, int tap, int ktile, int swapped, float* __restrict__ grad) {
   __shared__ float red[3 * 256];
   const int e = threadIdx.x & 255, part = threadIdx.x >> 8;
   const int i = blockIdx.x * 256 + e;
   const bool ok = i < n * k;
   const int ii = ok ? i : 0;
   const int kk = ii % k, nn = ii / k;
-  const int blk = (nn >> 7) * n_kt + (kk >> 7);
-  const float* src = slab + (size_t)blk * (128 * 128) + (size_t)(nn & 127) * 128 + (kk & 127);
+  const int row = swapped ? kk : nn, col = swapped ? nn : kk;  // position in the GEMM that ran: row = its n axis (128-tiles), col = its k axis (ktile-tiles)
+  const int blk = (row >> 7) * n_kt + col / ktile;
+  const float* src = slab + (size_t)blk * (128 * 128) + (size_t)(row & 127) * 128 + col % ktile;
   const size_t st = (size_t)n_blocks * (128 * 128);
   float s = 0.f;
   int sl = part;
@@ -462,24 +535,53 @@ __global__ __launch_bounds__(1024) void row_wgrad_reduce_kernel(const float* __r
   grad[((size_t)nn * k_total + k_off + kk) * taps + tap] = (s + red[e]) + (red[256 + e] + red[512 + e]);
 }
 
+// Tile plan of one launch: 96-wide k tiles when the k operand's (padded) channel count is a multiple of 96 but not of 128; a Linear layer whose
+// n operand is the one like that runs with the operands exchanged (the patch modes gather rows of x only, they are never exchanged).
+struct RwPlan {
+  int swapped, ktile, n_nt, n_kt;
+};
+static RwPlan rw_plan(int np, int kp, int patch) {
+  auto is96 = [](int c) { return c % 128 != 0 && c % 96 == 0; };
+  RwPlan p;
+  p.swapped = patch == 0 && !is96(kp) && is96(np) ? 1 : 0;
+  const int rn = p.swapped ? kp : np, rk = p.swapped ? np : kp;
+  p.ktile = is96(rk) ? 96 : 128;
+  p.n_nt = (rn + 127) / 128;
+  p.n_kt = (rk + p.ktile - 1) / p.ktile;
+  return p;
+}
 static int rw_slices(int M, int blocks) {
   const int chunks = (M + RW_ROWS - 1) / RW_ROWS;
   const int want = (1024 + blocks - 1) / blocks;  // ~2 workgroups per CU x 2 rounds
   return std::max(1, std::min(chunks, want));
 }
 int64_t row_wgrad_slab_floats(int M, int n, int k) {
-  const int blocks = ((pad16(n) + 127) / 128) * ((pad16(k) + 127) / 128);
-  return (int64_t)rw_slices(M, blocks) * blocks * 128 * 128;
+  // (the larger of the plans a patch mode and a Linear layer would take for these widths)
+  int64_t best = 0;
+  for (int patch = 0; patch < 2; ++patch) {
+    const RwPlan p = rw_plan(pad16(n), pad16(k), patch);
+    const int blocks = p.n_nt * p.n_kt;
+    best = std::max(best, (int64_t)rw_slices(M, blocks) * blocks * 128 * 128);
+  }
+  return best;
 }
 int launch_row_wgrad(const RowWgradArgs& a0, int n, int k, int taps, float* grad, hipStream_t s) { return launch_row_wgrad_part(a0, n, k, k, 0, taps, grad, s); }
 
 // k_total / k_off: the weight's input-channel axis is k_total wide and this operand covers [k_off, k_off + k) (concat sources)
 int launch_row_wgrad_part(const RowWgradArgs& a0, int n, int k, int k_total, int k_off, int taps, float* grad, hipStream_t s) {
   RowWgradArgs a = a0;
-  const int n_nt = (a.np + 127) / 128, n_kt = (a.kp + 127) / 128;
-  const int slices = rw_slices(a.M, n_nt * n_kt);
-  hipLaunchKernelGGL(row_wgrad_kernel, dim3(n_nt * n_kt, slices), dim3(256), 0, s, a);
-  hipLaunchKernelGGL(row_wgrad_reduce_kernel, dim3((n * k + 255) / 256), dim3(1024), 0, s, a.slab, slices, n_nt * n_kt, n_kt, n, k, k_total, k_off, taps, a.tap, grad);
+  const RwPlan p = rw_plan(a.np, a.kp, a.patch);
+  if (p.swapped) {
+    std::swap(a.dy, a.x);
+    std::swap(a.np, a.kp);
+  }
+  const int blocks = p.n_nt * p.n_kt;
+  const int slices = rw_slices(a.M, blocks);
+  if (p.ktile == 96)
+    hipLaunchKernelGGL(row_wgrad_kernel<3>, dim3(blocks, slices), dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL(row_wgrad_kernel<2>, dim3(blocks, slices), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(row_wgrad_reduce_kernel, dim3((n * k + 255) / 256), dim3(1024), 0, s, a.slab, slices, blocks, p.n_kt, n, k, k_total, k_off, taps, a.tap, p.ktile, p.swapped, grad);
   PH_HIP_CHECK(hipGetLastError());
   return PH_OK;
 }
@@ -615,3 +717,66 @@ int launch_global_maxpool_bwd(const float* x, const float* gy, int B, int HW, in
 }
 
 }  // namespace ph
+
+extern "C" {
+
+// Diagnostic: time (and spot-check) the row weight-gradient GEMM on synthetic operands.  Not a product path; tools/row_wgrad_bench.py.
+int ph_debug_row_wgrad_bench(int32_t M, int32_t n, int32_t k, int32_t iters, float* ms_out, float* max_rel_err_out) {
+  using namespace ph;
+  PH_REQUIRE(ms_out && max_rel_err_out && iters > 0 && M > 0 && n > 0 && k > 0 && n % 16 == 0 && k % 16 == 0, "ph_debug_row_wgrad_bench: bad arguments");
+  const size_t n_dy = (size_t)M * n, n_x = (size_t)M * k, n_slab = (size_t)row_wgrad_slab_floats(M, n, k), n_g = (size_t)n * k;
+  float *dy = nullptr, *x = nullptr, *slab = nullptr, *g = nullptr;
+  PH_HIP_CHECK(hipMalloc(&dy, n_dy * 4));
+  PH_HIP_CHECK(hipMalloc(&x, n_x * 4));
+  PH_HIP_CHECK(hipMalloc(&slab, n_slab * 4));
+  PH_HIP_CHECK(hipMalloc(&g, n_g * 4));
+  std::vector<float> hdy(n_dy), hx(n_x);
+  unsigned st = 777u;
+  auto rnd = [&]() {
+    st = st * 1664525u + 1013904223u;
+    return ((st >> 8) & 0xffff) / 65536.0f - 0.5f;
+  };
+  for (auto& v : hdy) v = rnd();
+  for (auto& v : hx) v = rnd();
+  PH_HIP_CHECK(hipMemcpy(dy, hdy.data(), n_dy * 4, hipMemcpyHostToDevice));
+  PH_HIP_CHECK(hipMemcpy(x, hx.data(), n_x * 4, hipMemcpyHostToDevice));
+  RowWgradArgs a{};
+  a.dy = dy;
+  a.x = x;
+  a.slab = slab;
+  a.np = n;
+  a.kp = k;
+  a.M = M;
+  hipEvent_t e0, e1;
+  PH_HIP_CHECK(hipEventCreate(&e0));
+  PH_HIP_CHECK(hipEventCreate(&e1));
+  int rc = PH_OK;
+  for (int i = 0; i < 2 && rc == PH_OK; ++i) rc = launch_row_wgrad(a, n, k, 1, g, nullptr);
+  PH_HIP_CHECK(hipEventRecord(e0, nullptr));
+  for (int i = 0; i < iters && rc == PH_OK; ++i) rc = launch_row_wgrad(a, n, k, 1, g, nullptr);
+  PH_HIP_CHECK(hipEventRecord(e1, nullptr));
+  PH_HIP_CHECK(hipEventSynchronize(e1));
+  float ms = 0.f;
+  PH_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+  *ms_out = ms / iters;
+  std::vector<float> hg(n_g);
+  PH_HIP_CHECK(hipMemcpy(hg.data(), g, n_g * 4, hipMemcpyDeviceToHost));
+  double worst = 0.0, scale = 0.0;
+  for (int t = 0; t < 64; ++t) {
+    const int nn = (int)(((unsigned)t * 2654435761u) % (unsigned)n), kk = (int)(((unsigned)t * 40503u + 17u) % (unsigned)k);
+    double ref = 0.0;
+    for (int m = 0; m < M; ++m) ref += (double)hdy[(size_t)m * n + nn] * (double)hx[(size_t)m * k + kk];
+    worst = std::max(worst, std::fabs(ref - (double)hg[(size_t)nn * k + kk]));
+    scale = std::max(scale, std::fabs(ref));
+  }
+  *max_rel_err_out = (float)(worst / std::max(scale, 1e-30));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipFree(dy);
+  (void)hipFree(x);
+  (void)hipFree(slab);
+  (void)hipFree(g);
+  return rc;
+}
+
+}  // extern "C"
