@@ -29,7 +29,7 @@ struct ConvArgs {
   int use_wino2d = 1;  // N-tile-64 layers on the F(2x2,3x3) kernel where wpack_wino2 exists (handle option "conv_wino2d")
   const float* w16 = nullptr;  // [tap][ci 16][co 16] weights for conv3x3_c16_kernel (16 -> 16 channel layers), or nullptr
   int skip_dst = 0;           // the full-resolution output is never read (inference plan, fused pool): only dst_pool is written (Winograd kernels; others ignore it)
-  const float* relu_mask_src = nullptr;  // backward: NHWC tensor shaped like dst (the forward activation this gradient belongs to); the stored value is zeroed where it is <= 0 (conv3x3_w16_kernel only: ask conv3x3_dma_honours_mask)
+  const float* relu_mask_src = nullptr;  // backward: NHWC tensor shaped like dst (the forward activation this gradient belongs to); the stored value is zeroed where it is <= 0 (the Winograd kernels' plain stores: ask conv3x3_dma_honours_mask)
   // fused 1x1 head (conv3x3_wino2d_kernel, Cout = one N tile of 64): head_dst[b][o][y][x] = (sigmoid)(sum_c head_w[o][c] * out[y][x][c] + head_b[o]), NCHW fp32
   const float* head_w = nullptr;  // [head_cout][head_wcp] row-major (the head op's own weight layout), or nullptr = no fused head
   const float* head_b = nullptr;  // [head_cout]

@@ -1313,7 +1313,10 @@ static int conv3x3_dma_route(const ConvArgs& a) {
   if (wino && a.persist && a.use_wino2d && a.wpack_wino2 && a.bn == 64 && a.c0p + a.c1p >= 32 && wino2d_fits(a)) return 2;
   return 3;
 }
-bool conv3x3_dma_honours_mask(const ConvArgs& a) { return conv3x3_dma_route(a) == 1; }
+bool conv3x3_dma_honours_mask(const ConvArgs& a) {  // the three F(2x2,3x3) / F(4x4,3x3) kernels store lane-locally; the fused pool / head epilogues are forward-only
+  const int r = conv3x3_dma_route(a);
+  return (r == 1 || r == 2 || r == 4) && !a.dst_pool && !a.head_w && !a.skip_dst;
+}
 bool conv3x3_dma_is_f2x2(const ConvArgs& a) { const int r = conv3x3_dma_route(a); return r == 1 || r == 2; }
 bool conv3x3_dma_is_wino2d(const ConvArgs& a) { return conv3x3_dma_route(a) == 2; }
 bool conv3x3_dma_is_wino4(const ConvArgs& a) { return conv3x3_dma_route(a) == 4; }
@@ -1332,7 +1335,8 @@ int conv3x3_dma_variant(const ConvArgs& a) {
 
 int launch_conv3x3_dma(const ConvArgs& a, hipStream_t s) {
   const int route = conv3x3_dma_route(a);
-  PH_REQUIRE(!a.relu_mask_src || route == 1, "relu_mask_src is only applied by conv3x3_w16_kernel (ask conv3x3_dma_honours_mask first)");
+  PH_REQUIRE(!a.relu_mask_src || ((route == 1 || route == 2 || route == 4) && !a.dst_pool && !a.head_w && !a.skip_dst),
+             "relu_mask_src is applied by the F(2x2,3x3) / F(4x4,3x3) kernels' plain stores only (ask conv3x3_dma_honours_mask first)");
   PH_REQUIRE(!a.head_w || (route == 2 && !a.dst_pool && a.coutp == 64 && a.bn == 64 && a.head_cout >= 1 && a.head_cout <= 32 && a.head_wcp == 64 && a.head_b && a.head_dst),
              "a fused head needs the F(2x2,3x3) kernel, 64 output channels and at most 32 head channels (ask conv3x3_dma_is_wino2d first)");
   if (route == 1) return launch_conv3x3_w16(a, s);

@@ -647,6 +647,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_kernel(ConvArgs a) {
 #pragma unroll
               for (int e = 0; e < 4; ++e) v[e] = acc[bb][n][4 * k + e];
               if (a.accumulate) v += *reinterpret_cast<const f32x4*>(dp + bb * a.coutp);  // gradient accumulation (the second data-gradient launch into a concat source's gradient)
+              if (a.relu_mask_src) {  // backward: this launch completes the gradient of a conv + ReLU output -- that ReLU's mask rides in the (lane-local) store
+                const f32x4 f = *reinterpret_cast<const f32x4*>(a.relu_mask_src + (dp - a.dst) + bb * a.coutp);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = f[e] > 0.f ? v[e] : 0.f;
+              }
               *reinterpret_cast<f32x4*>(dp + bb * a.coutp) = v;
             }
           }

@@ -463,6 +463,11 @@ __global__ __launch_bounds__(768) void conv3x3_wino4_kernel(ConvArgs a) {
 #pragma unroll
               for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
             }
+            if (a.relu_mask_src) {  // backward: this launch completes the gradient of a conv + ReLU output -- that ReLU's mask rides in the (lane-local) store
+              const f32x4 f = *reinterpret_cast<const f32x4*>(a.relu_mask_src + (dp - a.dst) + (size_t)bb * a.coutp);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = f[e] > 0.f ? v[e] : 0.f;
+            }
             *reinterpret_cast<f32x4*>(dp + (size_t)bb * a.coutp) = v;
           }
         }
@@ -485,7 +490,7 @@ int prepare_wino4_kernels() {
 // Shapes the kernel takes: N tile 64, whole 4x4 Winograd tiles (H and W multiples of 4), channel counts in quarters, every tensor
 // addressable through a 32-bit buffer descriptor; no fused pool / head / accumulate / ReLU mask (those stay on the F(2x2,3x3) kernel).
 bool wino4_fits(const ConvArgs& a) {
-  if (!a.wpack_wino4 || a.bn != 64 || (a.H & 3) || (a.W & 3) || a.dst_pool || a.head_w || a.accumulate || a.relu_mask_src || a.skip_dst) return false;
+  if (!a.wpack_wino4 || a.bn != 64 || (a.H & 3) || (a.W & 3) || a.dst_pool || a.head_w || a.accumulate || a.skip_dst) return false;
   if (a.src1_lowres && (!a.src1 || (a.H & 1) || (a.W & 1))) return false;
   const uint64_t px = (uint64_t)a.B * a.H * a.W;
   if (px * (uint64_t)a.c0p * 4 >= 0xFFFFFF00ull || px * (uint64_t)a.c1p * 4 >= 0xFFFFFF00ull || px >= 0x7FFFFFFFull) return false;
