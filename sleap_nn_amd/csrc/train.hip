@@ -262,7 +262,7 @@ int ph_model_backward(ph_model* m, const void* input_dev, int32_t in_dtype, int3
   // has added its share; when that consumer is a max pool, pool_bwd applies the mask itself (it reads the activation anyway) and the
   // conv's own step only reduces the bias gradient (handle option "mask_fold")
   std::vector<int> first_consumer(m->n_slots, -1), producer(m->n_slots, -1);
-  std::vector<char> masked(m->n_slots, 0);
+  std::vector<char> masked(m->n_slots, 0), bias_done(m->n_slots, 0);
   for (int oi = (int)m->ops.size() - 1; oi >= 0; --oi) {
     const ph_op_desc& d = m->ops[oi].d;
     if (d.src0 >= 0) first_consumer[d.src0] = oi;
@@ -304,18 +304,26 @@ int ph_model_backward(ph_model* m, const void* input_dev, int32_t in_dtype, int3
       case PH_OP_HEAD: {
         const SlotShape& s0 = bp.act.slots[d.src0];
         const float* dy = reinterpret_cast<const float*>(gws + bp.head_dy_off[d.out_index]);
+        // this head completes the gradient of a conv + ReLU output (its first consumer): that ReLU's mask, and the conv's bias gradient, ride in the stores
+        const int pr = producer[d.src0];
+        const bool fold = m->mask_fold && first_consumer[d.src0] == oi && pr >= 0 && m->ops[pr].d.kind == PH_OP_CONV && (m->ops[pr].d.flags & PH_FLAG_RELU) &&
+                          head_bwd_can_fold(s0.cp, s0.h * s0.w);
+        const bool sum_bias = fold && m->ops[pr].d.bias >= 0;
         rc = launch_head_bwd(dy, head_out_dev[d.out_index], (d.flags & PH_FLAG_SIGMOID) ? 1 : 0, A(d.src0), op.w_dev, batch, s0.h * s0.w, d.cin0, s0.cp, d.cout,
                              init[d.src0], G(d.src0), grads_flat_dev + m->weight_offset[d.weight], d.bias >= 0 ? grads_flat_dev + m->weight_offset[d.bias] : nullptr,
-                             scratch, s);
+                             scratch, s, fold ? A(d.src0) : nullptr, sum_bias ? grads_flat_dev + m->weight_offset[m->ops[pr].d.bias] : nullptr,
+                             sum_bias ? m->ops[pr].d.cout : 0);
         init[d.src0] = 1;
+        if (fold) masked[d.src0] = 1;
+        bias_done[d.src0] = sum_bias ? 1 : 0;
         break;
       }
       case PH_OP_CONV: {
         const SlotShape& so = bp.act.slots[d.dst];
         PH_REQUIRE(init[d.dst], "conv output slot %d received no gradient", d.dst);
         const size_t npix = (size_t)batch * so.h * so.w;
-        if (masked[d.dst]) {  // the last contributor applied the ReLU mask already
-          if (d.bias >= 0) {
+        if (masked[d.dst]) {  // the last contributor applied the ReLU mask already (and, if it was a max pool's backward, summed the bias gradient)
+          if (d.bias >= 0 && !bias_done[d.dst]) {
             rc = launch_bias_grad(G(d.dst), npix, so.cp, d.cout, grads_flat_dev + m->weight_offset[d.bias], scratch, s);
             if (rc != PH_OK) return rc;
           }
@@ -542,9 +550,14 @@ int ph_model_backward(ph_model* m, const void* input_dev, int32_t in_dtype, int3
         PH_REQUIRE(init[d.dst], "pool output slot %d received no gradient", d.dst);
         const int pr = producer[d.src0];
         const bool fold = m->mask_fold && first_consumer[d.src0] == oi && pr >= 0 && m->ops[pr].d.kind == PH_OP_CONV && (m->ops[pr].d.flags & PH_FLAG_RELU);
-        rc = launch_pool_bwd(G(d.dst), A(d.src0), batch, si.h, si.w, si.cp, init[d.src0], fold ? 1 : 0, G(d.src0), s);
+        // ... and, the gradient being complete and masked as it is stored, it is summed per channel on the way: the producer conv's bias gradient,
+        // which its own step would otherwise read the whole tensor again for
+        const bool sum_bias = fold && m->ops[pr].d.bias >= 0 && pool_bwd_can_sum_bias(si.cp);
+        rc = launch_pool_bwd(G(d.dst), A(d.src0), batch, si.h, si.w, si.cp, init[d.src0], fold ? 1 : 0, G(d.src0),
+                             sum_bias ? grads_flat_dev + m->weight_offset[m->ops[pr].d.bias] : nullptr, sum_bias ? m->ops[pr].d.cout : 0, scratch, s);
         init[d.src0] = 1;
         masked[d.src0] = fold ? 1 : 0;
+        bias_done[d.src0] = sum_bias ? 1 : 0;
         break;
       }
       case PH_OP_UPSAMPLE: {

@@ -27,10 +27,12 @@ int64_t loss_scratch_floats(int C);
 constexpr int PH_MAX_OUTPUTS = 8;
 int launch_total_loss(const float* head_loss, const float* w_host, int n, float* out, hipStream_t s);
 int launch_head_bwd(const float* dy, const float* y_out, int sigmoid, const float* x, const float* w_packed, int B, int HW, int cin, int cp, int cout,
-                    int accumulate, float* dx, float* gw, float* gb, float* scratch, hipStream_t s);
+                    int accumulate, float* dx, float* gw, float* gb, float* scratch, hipStream_t s, const float* x_mask = nullptr, float* conv_gb = nullptr, int conv_cout = 0);
+bool head_bwd_can_fold(int cp, int HW);
 int64_t head_bwd_scratch_floats(int cp, int cout, int64_t npix);
 int launch_relu_mask(float* g, const float* y, size_t n, hipStream_t s);
-int launch_pool_bwd(const float* gp, const float* x, int B, int H, int W, int cp, int accumulate, int relu_mask, float* gx, hipStream_t s);
+int launch_pool_bwd(const float* gp, const float* x, int B, int H, int W, int cp, int accumulate, int relu_mask, float* gx, float* gb, int cout, float* scratch, hipStream_t s);
+bool pool_bwd_can_sum_bias(int cp);
 int launch_upsample_bwd(const float* gy, int B, int H, int W, int cp, int accumulate, float* gx, hipStream_t s);
 int launch_bias_grad(const float* g, size_t npix, int cp, int cout, float* gb, float* scratch, hipStream_t s);
 int launch_relu_mask_bias_grad(float* g, const float* y_mask, size_t npix, int cp, int cout, float* gb, float* scratch, hipStream_t s);

@@ -169,6 +169,9 @@ int launch_total_loss(const float* head_loss, const float* w_host, int n, float*
   return PH_OK;
 }
 
+constexpr int BIAS_SLICES = 1024;  // rows of the partial table of a bias gradient (bias_partial_kernel / pool_bwd_kernel / head_bwd_dx4_kernel -> bias_final_kernel)
+__global__ __launch_bounds__(256) void bias_final_kernel(const float* __restrict__ partial, int cp, int cout, float* __restrict__ gb);
+
 // ---------------------------------------------------------------------------------------
 // 1x1 head backward.  dY: NCHW (B, Cout, HW); X: NHWC (cp); W: [Cout][cp].
 // ---------------------------------------------------------------------------------------
@@ -197,6 +200,15 @@ __global__ __launch_bounds__(256) void head_bwd_dx_kernel(const float* __restric
   }
 }
 
+// The same for FOUR consecutive pixels per thread (HW % 4 == 0: a quad never straddles two images): one 16-byte load of dY per output channel serves four
+// pixels and the weight quad is loaded once per four outputs -- 6.5 instead of 26 load instructions per 16 bytes stored (the one-pixel form is bound by
+// load issue: 0.47 ms for a 537-MB gradient).  x_mask != nullptr: x is the output of a conv + ReLU and this launch completes its gradient -- the mask
+// (x > 0) is applied to the finished value as it is stored; bias_partial != nullptr (needs x_mask, 256 % (cp / 4) == 0, BIAS_SLICES blocks): the stored
+// values are summed per channel into row blockIdx.x of the partial table (the producer conv's bias gradient), as pool_bwd_kernel does.
+__global__ __launch_bounds__(256) void head_bwd_dx4_kernel(const float* __restrict__ dy, const float* __restrict__ w, int cout, int cp, int HW, size_t npix,
+                                                           const float* __restrict__ y_out, int sigmoid, int accumulate, const float* __restrict__ x_mask,
+                                                           float* __restrict__ dx, float* __restrict__ bias_partial);
+
 // dY (NCHW, optionally times sigmoid'(y)) -> rows [pixel][cop] with zero pad channels, the operand layout of the
 // row weight-gradient GEMM and of the bias reduction.  Tile transpose through LDS: 64 pixels x cop channels.
 __global__ __launch_bounds__(256) void head_dy_rows_kernel(const float* __restrict__ dy, const float* __restrict__ y_out, int sigmoid, int cout, int cop, int HW,
@@ -224,13 +236,79 @@ __global__ __launch_bounds__(256) void head_dy_rows_kernel(const float* __restri
   }
 }
 
+__global__ __launch_bounds__(256) void head_bwd_dx4_kernel(const float* __restrict__ dy, const float* __restrict__ w, int cout, int cp, int HW, size_t npix,
+                                                           const float* __restrict__ y_out, int sigmoid, int accumulate, const float* __restrict__ x_mask,
+                                                           float* __restrict__ dx, float* __restrict__ bias_partial) {
+  __shared__ f32x4 red[256];
+  const int groups = cp >> 2;
+  const size_t total = (npix >> 2) * groups;
+  f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+    const int g = (int)(idx % groups);
+    const size_t p = (idx / groups) << 2;
+    const size_t b = p / HW, hw = p - b * HW;
+    f32x4 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int co = 0; co < cout; ++co) {
+      f32x4 d = *reinterpret_cast<const f32x4*>(dy + (b * cout + co) * HW + hw);
+      if (sigmoid) {
+        const f32x4 yv = *reinterpret_cast<const f32x4*>(y_out + (b * cout + co) * HW + hw);
+        d *= yv * (1.f - yv);
+      }
+      const f32x4 wq = *reinterpret_cast<const f32x4*>(w + (size_t)co * cp + g * 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] += d[j] * wq;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const size_t o = (p + j) * cp + g * 4;
+      f32x4 v = acc[j];
+      if (accumulate) v += *reinterpret_cast<const f32x4*>(dx + o);
+      if (x_mask) {
+        const f32x4 f = *reinterpret_cast<const f32x4*>(x_mask + o);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = f[e] > 0.f ? v[e] : 0.f;
+      }
+      *reinterpret_cast<f32x4*>(dx + o) = v;
+      bsum += v;
+    }
+  }
+  if (bias_partial) {  // kernel-uniform
+    red[threadIdx.x] = bsum;
+    __syncthreads();
+    if ((int)threadIdx.x < groups) {
+      f32x4 t = red[threadIdx.x];
+      for (int k = groups; k < 256; k += groups) t += red[k + threadIdx.x];  // fixed order
+      *reinterpret_cast<f32x4*>(bias_partial + (size_t)blockIdx.x * cp + 4 * threadIdx.x) = t;
+    }
+  }
+}
+
+// the mask / bias-gradient fusion of head_bwd_dx4_kernel applies to this shape
+bool head_bwd_can_fold(int cp, int HW) { return (HW & 3) == 0 && cp >= 4 && 256 % (cp / 4) == 0; }
+
 // Head weight / bias gradients through the row weight-gradient GEMM (MFMA, K = pixels) and the column-sum reduction.
+// x_mask (with head_bwd_can_fold): the ReLU mask of the conv that produced x, applied to the finished dx; conv_gb (needs x_mask): that conv's bias gradient
+// (conv_cout channels), summed from the stored values.
 int launch_head_bwd(const float* dy, const float* y_out, int sigmoid, const float* x, const float* w_packed, int B, int HW, int cin, int cp, int cout,
-                    int accumulate, float* dx, float* gw, float* gb, float* scratch, hipStream_t s) {
+                    int accumulate, float* dx, float* gw, float* gb, float* scratch, hipStream_t s, const float* x_mask, float* conv_gb, int conv_cout) {
   const size_t npix = (size_t)B * HW;
   const size_t total = npix * (cp / 4);
-  hipLaunchKernelGGL(head_bwd_dx_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 16384)), dim3(256), 0, s, dy, w_packed, cout, cp, HW, npix, y_out,
-                     sigmoid, accumulate, dx);
+  PH_REQUIRE(!x_mask || head_bwd_can_fold(cp, HW), "head backward: the folded ReLU mask needs HW %% 4 == 0 and 256 %% (cp / 4) == 0");
+  PH_REQUIRE(!conv_gb || x_mask, "head backward: the fused bias gradient needs the folded mask");
+  if ((HW & 3) == 0) {
+    if (conv_gb) {
+      hipLaunchKernelGGL(head_bwd_dx4_kernel, dim3(BIAS_SLICES), dim3(256), 0, s, dy, w_packed, cout, cp, HW, npix, y_out, sigmoid, accumulate, x_mask, dx, scratch);
+      hipLaunchKernelGGL(bias_final_kernel, dim3((conv_cout + 3) / 4), dim3(256), 0, s, scratch, cp, conv_cout, conv_gb);
+    } else {
+      hipLaunchKernelGGL(head_bwd_dx4_kernel, dim3((unsigned)std::min<size_t>((total / 4 + 255) / 256, 16384)), dim3(256), 0, s, dy, w_packed, cout, cp, HW, npix, y_out,
+                         sigmoid, accumulate, x_mask, dx, static_cast<float*>(nullptr));
+    }
+  } else {
+    hipLaunchKernelGGL(head_bwd_dx_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 16384)), dim3(256), 0, s, dy, w_packed, cout, cp, HW, npix, y_out,
+                       sigmoid, accumulate, dx);
+  }
   const int cop = pad16(cout);
   float* rows = scratch;
   float* rest = scratch + align_up((int64_t)npix * cop, 64);
@@ -278,10 +356,15 @@ int launch_relu_mask(float* g, const float* y, size_t n, hipStream_t s) {
 // order (ATen); windows reaching past an odd edge see the zero pad last, so a real element wins ties.
 // relu_mask: x is the output of a conv + ReLU and this is the LAST contribution to its gradient: the ReLU mask (x > 0) is applied to the
 // finished sum here, on values this kernel reads anyway, instead of in a separate read-modify-write pass over the gradient tensor.
+// bias_partial != nullptr (needs relu_mask, 256 % (cp / 4) == 0 and a grid of BIAS_SLICES blocks): the finished, masked gradient is also summed per
+// channel -- the bias gradient of the conv that produced x -- into row blockIdx.x of the BIAS_SLICES x cp partial table that bias_final_kernel adds
+// up; a thread keeps one channel quad for its whole walk (its stride is a multiple of cp / 4), so its sum stays in four registers.
 __global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__ gp, const float* __restrict__ x, int B, int H, int W, int cp, int accumulate,
-                                                       int relu_mask, float* __restrict__ gx) {
+                                                       int relu_mask, float* __restrict__ gx, float* __restrict__ bias_partial) {
+  __shared__ f32x4 red[256];
   const int Ho = (H + 1) / 2, Wo = (W + 1) / 2, groups = cp >> 2;
   const size_t total = (size_t)B * Ho * Wo * groups;
+  f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
   for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
     const int gq = (int)(idx % groups);
     size_t p = idx / groups;
@@ -325,13 +408,34 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__
           for (int e = 0; e < 4; ++e) r[e] = v[k][e] > 0.f ? r[e] : 0.f;
         }
         *dst = r;
+        bsum += r;
       }
+  }
+  if (bias_partial) {  // kernel-uniform
+    red[threadIdx.x] = bsum;
+    __syncthreads();
+    if ((int)threadIdx.x < groups) {
+      f32x4 t = red[threadIdx.x];
+      for (int k = groups; k < 256; k += groups) t += red[k + threadIdx.x];  // fixed order
+      *reinterpret_cast<f32x4*>(bias_partial + (size_t)blockIdx.x * cp + 4 * threadIdx.x) = t;
+    }
   }
 }
 
-int launch_pool_bwd(const float* gp, const float* x, int B, int H, int W, int cp, int accumulate, int relu_mask, float* gx, hipStream_t s) {
+// the bias-gradient fusion of pool_bwd_kernel applies to this shape
+bool pool_bwd_can_sum_bias(int cp) { return cp >= 4 && 256 % (cp / 4) == 0; }
+
+// gb != nullptr (with relu_mask, pool_bwd_can_sum_bias(cp)): also the bias gradient of the conv whose output x is (cout channels), via scratch (>= bias_scratch_floats(cp))
+int launch_pool_bwd(const float* gp, const float* x, int B, int H, int W, int cp, int accumulate, int relu_mask, float* gx, float* gb, int cout, float* scratch, hipStream_t s) {
   const size_t total = (size_t)B * ((H + 1) / 2) * ((W + 1) / 2) * (cp / 4);
-  hipLaunchKernelGGL(pool_bwd_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 16384)), dim3(256), 0, s, gp, x, B, H, W, cp, accumulate, relu_mask, gx);
+  if (gb) {
+    PH_REQUIRE(relu_mask && pool_bwd_can_sum_bias(cp) && scratch, "pool_bwd: the fused bias gradient needs the ReLU-mask form and 256 %% (cp / 4) == 0");
+    hipLaunchKernelGGL(pool_bwd_kernel, dim3(BIAS_SLICES), dim3(256), 0, s, gp, x, B, H, W, cp, accumulate, relu_mask, gx, scratch);
+    hipLaunchKernelGGL(bias_final_kernel, dim3((cout + 3) / 4), dim3(256), 0, s, scratch, cp, cout, gb);
+  } else {
+    hipLaunchKernelGGL(pool_bwd_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 16384)), dim3(256), 0, s, gp, x, B, H, W, cp, accumulate, relu_mask, gx,
+                       static_cast<float*>(nullptr));
+  }
   PH_HIP_CHECK(hipGetLastError());
   return PH_OK;
 }
@@ -400,7 +504,6 @@ int launch_upsample_bwd(const float* gy, int B, int H, int W, int cp, int accumu
 // ---------------------------------------------------------------------------------------
 // Bias gradient: column sums of an NHWC tensor, two stage.
 // ---------------------------------------------------------------------------------------
-constexpr int BIAS_SLICES = 1024;
 __global__ __launch_bounds__(256) void bias_partial_kernel(float* __restrict__ g, const float* __restrict__ y_mask, size_t npix, int cp,
                                                            float* __restrict__ partial /* BIAS_SLICES x cp */) {
   // y_mask != nullptr: the ReLU mask (g = 0 where the forward output y is 0) is applied on the way, in place.
