@@ -520,8 +520,10 @@ int ph_model_backward(ph_model* m, const void* input_dev, int32_t in_dtype, int3
         PH_REQUIRE(init[d.dst], "first conv output received no gradient");
         PH_REQUIRE(d.cin0 == in_channels, "input has %d channels, network expects %d", in_channels, d.cin0);
         const size_t npix = (size_t)batch * so.h * so.w;
+        // (a masked gradient and a 3 x 3 kernel: the weight-gradient launch below reads every element anyway and sums the bias gradient in a spare column)
+        const bool bias_in_wgrad = masked[d.dst] && d.bias >= 0 && d.ksize == 3 && !bias_done[d.dst];
         if (masked[d.dst]) {  // the last contributor applied the ReLU mask already
-          if (d.bias >= 0) {
+          if (d.bias >= 0 && !bias_done[d.dst] && !bias_in_wgrad) {
             rc = launch_bias_grad(G(d.dst), npix, so.cp, d.cout, grads_flat_dev + m->weight_offset[d.bias], scratch, s);
             if (rc != PH_OK) return rc;
           }
@@ -542,7 +544,8 @@ int ph_model_backward(ph_model* m, const void* input_dev, int32_t in_dtype, int3
           rc = launch_patch_stem_wgrad(input_dev, in_dtype, G(d.dst), batch, d.cin0, height, width, so.h, so.w, d.ksize, 1, d.ksize / 2, so.cp, d.cout,
                                        grads_flat_dev + m->weight_offset[d.weight], scratch, s);
         else
-          rc = launch_input_wgrad(input_dev, in_dtype, G(d.dst), batch, d.cin0, height, width, so.cp, d.cout, grads_flat_dev + m->weight_offset[d.weight], scratch, s);
+          rc = launch_input_wgrad(input_dev, in_dtype, G(d.dst), batch, d.cin0, height, width, so.cp, d.cout, grads_flat_dev + m->weight_offset[d.weight], scratch, s,
+                                  bias_in_wgrad ? grads_flat_dev + m->weight_offset[d.bias] : nullptr);
         break;
       }
       case PH_OP_POOL: {

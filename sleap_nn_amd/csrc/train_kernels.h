@@ -43,7 +43,7 @@ int launch_wgrad(const WgradArgs& a, int cin_part, int cout, int cin_total, int 
 // the same gradient in the Winograd F(2x2,3x3) domain (4/9 of the matrix work; layers with >= 32 padded channels on both sides)
 int launch_wgrad_wino(const WgradArgs& a, int cin_part, int cout, int cin_total, int ci_off, float* grad, hipStream_t s);
 int launch_wgrad16_wino(const WgradArgs& a, int cin_part, int cout, int cin_total, int ci_off, float* grad, hipStream_t s);  // 16 -> 16 layers
-int launch_input_wgrad(const void* img, int dtype, const float* dy, int B, int cin, int H, int W, int coutp, int cout, float* gw, float* scratch, hipStream_t s);
+int launch_input_wgrad(const void* img, int dtype, const float* dy, int B, int cin, int H, int W, int coutp, int cout, float* gw, float* scratch, hipStream_t s, float* gb = nullptr);
 int64_t input_wgrad_scratch_floats(int cin, int cout);
 int launch_gather(const float* canon, const int* map, size_t n, float* out, hipStream_t s);
 struct GatherSegment {  // one packed buffer of the model: out[i] = map[i] >= 0 ? canon[map[i]] : 0

@@ -1232,8 +1232,11 @@ int launch_wgrad_wino(const WgradArgs& a, int cin_part, int cout, int cin_total,
 //   pixel tiles; thread = (co, tap-ci) pair keeps one partial in a register.
 // ---------------------------------------------------------------------------------------
 constexpr int ICW_BLOCKS = 1024;
+// with_bias: column n_comb of the product (free: 9 or 27 of the 16 / 32 columns are taps) multiplies dY by 1 -- the conv's bias gradient, written after
+// the weight partials of a block (row pitch n_out + cout), so that the bias needs no pass of its own over the first layer's gradient, the largest tensor
+// of the backward.
 __global__ __launch_bounds__(256) void input_wgrad_partial_kernel(const void* __restrict__ img, int dtype, const float* __restrict__ dy, int B, int cin, int H, int W,
-                                                                  int coutp, int cout, float* __restrict__ partial /* ICW_BLOCKS x (cout*cin*9) */) {
+                                                                  int coutp, int cout, int with_bias, float* __restrict__ partial /* ICW_BLOCKS x (cout*cin*9 [+ cout]) */) {
   // A tiny GEMM per pixel tile on v_mfma_f32_16x16x4_f32: D[co 16][(ci, tap) <= 32] += dY^T[co][4 pixels] * patch[4 pixels][(ci, tap)].
   // Wave w owns pixel rows 2w, 2w+1 of the 8 x 32 tile; a lane's A operand is dY[pixel 4s + kg][co = lane & 15] (64 consecutive
   // floats per wave), its B operand the image value under tap (lane & 15) of pixel 4s + kg.
@@ -1245,12 +1248,15 @@ __global__ __launch_bounds__(256) void input_wgrad_partial_kernel(const void* __
   const int ln = lane & 15, kg = lane >> 4;
   const int tiles_x = (W + 31) / 32, tiles_y = (H + 7) / 8;
   const int n_tiles = tiles_x * tiles_y * B;
+  const int pitch = n_out + (with_bias ? cout : 0);
   int boff[2];
   bool bok[2];
+  float bone[2];  // the operand of a lane that is no tap: 1 in the bias column, 0 elsewhere
 #pragma unroll
   for (int nb = 0; nb < 2; ++nb) {
     const int comb = nb * 16 + ln;
     bok[nb] = comb < n_comb;
+    bone[nb] = (with_bias && comb == n_comb) ? 1.f : 0.f;
     const int cc = bok[nb] ? comb : 0;
     const int ci = cc / 9, tap = cc - ci * 9;
     boff[nb] = ci * 340 + (tap / 3) * 34 + tap % 3;
@@ -1296,10 +1302,10 @@ __global__ __launch_bounds__(256) void input_wgrad_partial_kernel(const void* __
         const int py = 2 * wave + (p >> 5), px = p & 31;
         const float av = sDy[(py * 32 + px) * 16 + ln];
         const int ib = py * 34 + px;
-        const float b0 = bok[0] ? sImg[boff[0] + ib] : 0.f;
+        const float b0 = bok[0] ? sImg[boff[0] + ib] : bone[0];
         acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b0, acc[0], 0, 0, 0);
-        if (n_comb > 16) {
-          const float b1 = bok[1] ? sImg[boff[1] + ib] : 0.f;
+        if (n_comb >= 16) {  // (cin = 3: taps 16 .. 26, the bias column 27)
+          const float b1 = bok[1] ? sImg[boff[1] + ib] : bone[1];
           acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b1, acc[1], 0, 0, 0);
         }
       }
@@ -1313,17 +1319,17 @@ __global__ __launch_bounds__(256) void input_wgrad_partial_kernel(const void* __
     __syncthreads();
     for (int i = tid; i < 512; i += 256) {
       const int nb = i >> 8, co = (i >> 4) & 15, comb = nb * 16 + (i & 15);
-      if (cbase + co < cout && comb < n_comb) {
+      if (cbase + co < cout && (comb < n_comb || (with_bias && comb == n_comb))) {
         const int e = (i & 255);
         const float sum = (sRed[(0 * 2 + nb) * 256 + e] + sRed[(1 * 2 + nb) * 256 + e]) + (sRed[(2 * 2 + nb) * 256 + e] + sRed[(3 * 2 + nb) * 256 + e]);
-        partial[(size_t)blockIdx.x * n_out + (size_t)(cbase + co) * n_comb + comb] = sum;
+        partial[(size_t)blockIdx.x * pitch + (comb < n_comb ? (size_t)(cbase + co) * n_comb + comb : (size_t)n_out + cbase + co)] = sum;
       }
     }
     __syncthreads();
   }
 }
 // 1024 threads = 256 outputs x 4 block parts (four loads in flight per thread); the parts meet in LDS in a fixed order
-__global__ __launch_bounds__(1024) void input_wgrad_final_kernel(const float* __restrict__ partial, int n_blocks, int n_out, float* __restrict__ gw) {
+__global__ __launch_bounds__(1024) void input_wgrad_final_kernel(const float* __restrict__ partial, int n_blocks, int n_out, int pitch, float* __restrict__ gw) {
   // The first layer's weight gradient is the worst-conditioned sum of the network (every pixel of the batch contributes a
   // signed term to each of the 9 * cin * cout outputs and they largely cancel): the per-tile partials are combined in double
   // (a few hundred adds per output, free) so that the result is as close to the exact gradient as ATen's own fp32 reduction.
@@ -1335,27 +1341,29 @@ __global__ __launch_bounds__(1024) void input_wgrad_final_kernel(const float* __
   double s = 0.0;
   int k = part;
   for (; k + 12 < n_blocks; k += 16)
-    s += ((double)src[(size_t)k * n_out] + (double)src[(size_t)(k + 4) * n_out]) + ((double)src[(size_t)(k + 8) * n_out] + (double)src[(size_t)(k + 12) * n_out]);
-  for (; k < n_blocks; k += 4) s += (double)src[(size_t)k * n_out];
+    s += ((double)src[(size_t)k * pitch] + (double)src[(size_t)(k + 4) * pitch]) + ((double)src[(size_t)(k + 8) * pitch] + (double)src[(size_t)(k + 12) * pitch]);
+  for (; k < n_blocks; k += 4) s += (double)src[(size_t)k * pitch];
   if (part) red[(part - 1) * 256 + e] = s;
   __syncthreads();
   if (part || !ok) return;
   gw[i] = (float)((s + red[e]) + (red[256 + e] + red[512 + e]));
 }
-int launch_input_wgrad(const void* img, int dtype, const float* dy, int B, int cin, int H, int W, int coutp, int cout, float* gw, float* scratch, hipStream_t s) {
+// gb != nullptr: dy is complete (masked) -- its per-channel sums, the conv's bias gradient, come out of the same launch
+int launch_input_wgrad(const void* img, int dtype, const float* dy, int B, int cin, int H, int W, int coutp, int cout, float* gw, float* scratch, hipStream_t s, float* gb) {
   if (cin > 3) {
     set_error("input wgrad: more than 3 input channels");
     return PH_E_INVALID;
   }
   const int n_tiles = ((W + 31) / 32) * ((H + 7) / 8) * B;
   const int blocks = std::min(n_tiles, ICW_BLOCKS);
-  hipLaunchKernelGGL(input_wgrad_partial_kernel, dim3(blocks), dim3(256), 0, s, img, dtype, dy, B, cin, H, W, coutp, cout, scratch);
-  const int n_out = cout * cin * 9;
-  hipLaunchKernelGGL(input_wgrad_final_kernel, dim3((n_out + 255) / 256), dim3(1024), 0, s, scratch, blocks, n_out, gw);
+  const int n_out = cout * cin * 9, pitch = n_out + (gb ? cout : 0);
+  hipLaunchKernelGGL(input_wgrad_partial_kernel, dim3(blocks), dim3(256), 0, s, img, dtype, dy, B, cin, H, W, coutp, cout, gb ? 1 : 0, scratch);
+  hipLaunchKernelGGL(input_wgrad_final_kernel, dim3((n_out + 255) / 256), dim3(1024), 0, s, scratch, blocks, n_out, pitch, gw);
+  if (gb) hipLaunchKernelGGL(input_wgrad_final_kernel, dim3((cout + 255) / 256), dim3(1024), 0, s, scratch + n_out, blocks, cout, pitch, gb);
   PH_HIP_CHECK(hipGetLastError());
   return PH_OK;
 }
-int64_t input_wgrad_scratch_floats(int cin, int cout) { return (int64_t)ICW_BLOCKS * cout * cin * 9; }
+int64_t input_wgrad_scratch_floats(int cin, int cout) { return (int64_t)ICW_BLOCKS * (cout * cin * 9 + cout); }
 
 // ---------------------------------------------------------------------------------------
 // Adam (torch.optim.Adam, weight_decay 0) and the canonical -> packed weight gather.
