@@ -430,7 +430,11 @@ __global__ __launch_bounds__(256, 2) void row_wgrad_kernel(RowWgradArgs a) {
       ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_a, vo_a[i], so_a, 0));
     }
   };
+  f32x4 bsum = {0.f, 0.f, 0.f, 0.f};  // column sums of the operand that is the layer's dY, this thread's channel quad (a.bias_sum)
+  const int bias_op = a.bias_sum == 1 && kt == 0 ? 1 : (a.bias_sum == 2 && nt == 0 ? 2 : 0);  // workgroup-uniform
   auto commit = [&](int buf, const f32x4 (&ry)[4], const f32x4 (&ra)[4]) __attribute__((always_inline)) {
+    if (bias_op == 1) bsum += (ry[0] + ry[1]) + (ry[2] + ry[3]);
+    if (bias_op == 2) bsum += (ra[0] + ra[1]) + (ra[2] + ra[3]);
 #pragma unroll
     for (int cc = 0; cc < 4; ++cc) {
       const int o = rw_slot(4 * sq + cc, sg);
@@ -497,6 +501,18 @@ __global__ __launch_bounds__(256, 2) void row_wgrad_kernel(RowWgradArgs a) {
       __syncthreads();
     }
   }
+  if (bias_op) {  // the eight row groups of a channel quad meet in LDS (free after the loop's last barrier) in a fixed order
+    f32x4* red = reinterpret_cast<f32x4*>(&sY[0][0]);
+    red[tid] = bsum;
+    __syncthreads();
+    if (sg == 0) {
+      f32x4 t = red[tid];
+#pragma unroll
+      for (int k = 1; k < 8; ++k) t += red[tid + k];
+      const int tiles = bias_op == 1 ? (int)gridDim.x / n_kt : n_kt, tile = bias_op == 1 ? nt : kt;
+      *reinterpret_cast<f32x4*>(a.bias_slab + ((size_t)slice * tiles + tile) * 128 + 4 * sq) = t;
+    }
+  }
   // slab[slice][block][128 n][128 k];  D: row(n) = (r&3) + 8*(r>>2) + 4*lh, col(k) = lx
   float* slab = a.slab + ((size_t)slice * gridDim.x + blockIdx.x) * (128 * 128);
 #pragma unroll
@@ -535,6 +551,23 @@ __global__ __launch_bounds__(1024) void row_wgrad_reduce_kernel(const float* __r
   grad[((size_t)nn * k_total + k_off + kk) * taps + tap] = (s + red[e]) + (red[256 + e] + red[512 + e]);
 }
 
+// gb[c] = sum over slices of bias_slab[slice][tile c / width][c % width] (width: channels of a tile that are real, 128 or 96); one thread per channel
+__global__ __launch_bounds__(256) void row_wgrad_bias_reduce_kernel(const float* __restrict__ slab, int n_slices, int tiles, int width, int n, float* __restrict__ gb) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= n) return;
+  const float* src = slab + (size_t)(c / width) * 128 + c % width;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int k = 0;
+  for (; k + 3 < n_slices; k += 4) {
+    s0 += src[(size_t)k * tiles * 128];
+    s1 += src[(size_t)(k + 1) * tiles * 128];
+    s2 += src[(size_t)(k + 2) * tiles * 128];
+    s3 += src[(size_t)(k + 3) * tiles * 128];
+  }
+  for (; k < n_slices; ++k) s0 += src[(size_t)k * tiles * 128];
+  gb[c] = (s0 + s1) + (s2 + s3);
+}
+
 // Tile plan of one launch: 96-wide k tiles when the k operand's (padded) channel count is a multiple of 96 but not of 128; a Linear layer whose
 // n operand is the one like that runs with the operands exchanged (the patch modes gather rows of x only, they are never exchanged).
 struct RwPlan {
@@ -561,7 +594,8 @@ int64_t row_wgrad_slab_floats(int M, int n, int k) {
   for (int patch = 0; patch < 2; ++patch) {
     const RwPlan p = rw_plan(pad16(n), pad16(k), patch);
     const int blocks = p.n_nt * p.n_kt;
-    best = std::max(best, (int64_t)rw_slices(M, blocks) * blocks * 128 * 128);
+    const int64_t slices = rw_slices(M, blocks);
+    best = std::max(best, slices * blocks * 128 * 128 + slices * std::max(p.n_nt, p.n_kt) * 128);  // + the bias-sum slab of a Linear layer
   }
   return best;
 }
@@ -577,11 +611,21 @@ int launch_row_wgrad_part(const RowWgradArgs& a0, int n, int k, int k_total, int
   }
   const int blocks = p.n_nt * p.n_kt;
   const int slices = rw_slices(a.M, blocks);
+  const bool with_bias = a.gb && a.patch == 0;
+  if (with_bias) {
+    a.bias_sum = p.swapped ? 2 : 1;
+    a.bias_slab = a.slab + (size_t)slices * blocks * 128 * 128;
+  } else {
+    a.bias_sum = 0;
+  }
   if (p.ktile == 96)
     hipLaunchKernelGGL(row_wgrad_kernel<3>, dim3(blocks, slices), dim3(256), 0, s, a);
   else
     hipLaunchKernelGGL(row_wgrad_kernel<2>, dim3(blocks, slices), dim3(256), 0, s, a);
   hipLaunchKernelGGL(row_wgrad_reduce_kernel, dim3((n * k + 255) / 256), dim3(1024), 0, s, a.slab, slices, blocks, p.n_kt, n, k, k_total, k_off, taps, a.tap, p.ktile, p.swapped, grad);
+  if (with_bias)  // dY is the n operand (128-wide tiles) or, exchanged, the k operand (ktile-wide tiles)
+    hipLaunchKernelGGL(row_wgrad_bias_reduce_kernel, dim3((a.gb_n + 255) / 256), dim3(256), 0, s, a.bias_slab, slices, p.swapped ? p.n_kt : p.n_nt, p.swapped ? p.ktile : 128,
+                       a.gb_n, a.gb);
   PH_HIP_CHECK(hipGetLastError());
   return PH_OK;
 }

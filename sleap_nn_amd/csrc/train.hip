@@ -613,9 +613,11 @@ int ph_model_backward(ph_model* m, const void* input_dev, int32_t in_dtype, int3
           }
           if (gelu_op >= 0 && (readers != 1 || init[m->ops[gelu_op].d.src0])) gelu_op = -1;
         }
+        // a Linear layer's bias gradient (column sums of dY) comes out of its weight-gradient GEMM, which stages every dY row anyway
+        const bool bias_in_wgrad = !patch && !(d.flags & PH_FLAG_RELU) && d.bias >= 0;
         if (d.flags & PH_FLAG_RELU)
           rc = launch_relu_mask_bias_grad(G(d.dst), A(d.dst), (size_t)M, so.cp, d.cout, grads_flat_dev + m->weight_offset[d.bias], scratch, s);
-        else
+        else if (!bias_in_wgrad)
           rc = launch_bias_grad(G(d.dst), (size_t)M, so.cp, d.cout, grads_flat_dev + m->weight_offset[d.bias], scratch, s);
         for (int tap = 0; tap < taps && rc == PH_OK; ++tap) {
           RowWgradArgs w{};
@@ -625,6 +627,10 @@ int ph_model_backward(ph_model* m, const void* input_dev, int32_t in_dtype, int3
           w.np = so.cp;
           w.kp = si.cp;
           w.M = M;
+          if (bias_in_wgrad) {
+            w.gb = grads_flat_dev + m->weight_offset[d.bias];
+            w.gb_n = d.cout;
+          }
           w.patch = patch ? 1 : 0;
           w.tap = tap;
           w.H = si.h;

@@ -62,6 +62,12 @@ struct RowWgradArgs {
   int np, kp, M;
   int patch = 0, tap = 0, H = 0, W = 0;  // patch 1: 2x2/stride-2 taps (dy, dx); patch 2: k x k "same" conv taps (ksize); patch 3: 3x3 stride-2 pad-1 taps (rows on the H/2 x W/2 grid); H, W = size of the gathered map
   int ksize = 3;                         // patch 2: odd kernel size, tap = ky * ksize + kx
+  // Linear layers (patch 0): gb != nullptr -> the column sums of dy (the layer's bias gradient, gb_n channels) come out of the same launch: the workgroups
+  // of the first k tile (or, operands exchanged, of the first n tile) add up the dy rows they stage anyway.  bias_sum / bias_slab are set by the launcher.
+  float* gb = nullptr;
+  int gb_n = 0;
+  int bias_sum = 0;            // 0 off, 1 the n operand's staging registers (blocks kt == 0), 2 the k operand's (blocks nt == 0)
+  float* bias_slab = nullptr;  // [slices][tiles of that operand][128]
 };
 int launch_gelu_fwd(const float* x, float* y, size_t n, hipStream_t s);
 int launch_gelu_bwd(const float* gy, const float* x, float* gx, int accumulate, size_t n, hipStream_t s);
