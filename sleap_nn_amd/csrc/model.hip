@@ -301,9 +301,9 @@ int build_plan(const ph_model* m, int B, int H, int W, Plan& plan, int fmt) {
     const ph_op_desc& d = op.d;
     ++op_i;
     // Run-time fusions let op i write op i + 1's dst one op early (pool_peephole: a conv's epilogue writes the pool that follows it;
-    // fuse_gelu_fwd: a Linear writes its GELU; dw_ln_fuse: a depthwise / stem conv writes its LayerNorm).  Such a dst must not land on
+    // fuse_gelu_fwd: a Linear writes its GELU or its layer-scale + residual; dw_ln_fuse: a depthwise / stem conv writes its LayerNorm).  Such a dst must not land on
     // a range op i is still reading, so the releases due before a pool / GELU / LayerNorm of the previous op's output wait one op.
-    const bool forwarded = op_i > 0 && (d.kind == PH_OP_POOL || d.kind == PH_OP_GELU || d.kind == PH_OP_LAYERNORM) && d.src0 >= 0 && d.src0 == m->ops[op_i - 1].d.dst;
+    const bool forwarded = op_i > 0 && (d.kind == PH_OP_POOL || d.kind == PH_OP_GELU || d.kind == PH_OP_LAYERNORM || d.kind == PH_OP_SCALE_ADD) && d.src0 >= 0 && d.src0 == m->ops[op_i - 1].d.dst;
     if (reuse && !forwarded)  // slots whose last reader ran before this op (a slot nobody reads is released right after the op that wrote it)
       for (int sl = 0; sl < m->n_slots; ++sl)
         if (!released[sl] && plan.slots[sl].offset >= 0 && slot_bytes[sl] > 0 && std::max(last_use[sl], plan.slots[sl].def_op) < op_i) release(sl);
@@ -951,7 +951,7 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
   size_t op_index = 0;
   m->last_variant.assign(m->ops.size(), PH_KV_NONE);
   int* const kv = m->last_variant.data();
-  bool skip_next_gelu = false;
+  bool skip_next_gelu = false, skip_next_scale_add = false;
   int pooled_by_conv = -1;  // slot whose 2x2 max pool the producing conv's epilogue already wrote (run-time fusion of an unfused program, see PH_OP_CONV)
   std::vector<char> head_done(m->ops.size(), 0);  // head ops the producing conv's epilogue already computed (see PH_OP_CONV)
   int deferred_up = -1;     // index of a bilinear op left to the conv that follows it (see PH_OP_UPSAMPLE / PH_OP_CONV)
@@ -1411,6 +1411,18 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
             skip_next_gelu = true;
           }
         }
+        // ... and (CNBlock's second Linear -> layer scale + residual, separate ops in a training program because the backward needs the un-scaled
+        // output): the epilogue writes the un-scaled output AND scale * output + residual, the scale-add op after it becomes a no-op
+        if (m->fuse_gelu_fwd && a.mode == 0 && a.act == 0 && !a.residual && !a.dst_pre && op_index < m->ops.size() && so.cp % a.bn == 0) {
+          const ph_op_desc& nx = m->ops[op_index].d;
+          if (nx.kind == PH_OP_SCALE_ADD && nx.src0 == d.dst && nx.dst != d.dst && nx.src1 != d.dst && nx.src1 >= 0 && nx.cin0 == d.cout) {
+            a.scale = m->ops[op_index].w_dev;
+            a.residual = slot_ptr(nx.src1);
+            a.dst_pre = a.dst;
+            a.dst = slot_ptr(nx.dst);
+            skip_next_scale_add = true;
+          }
+        }
         kv[op_index - 1] = PH_KV_ROWGEMM;
         rc = launch_gemm(a, s);
         break;
@@ -1431,6 +1443,10 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
         break;
       }
       case PH_OP_SCALE_ADD: {
+        if (skip_next_scale_add) {  // already produced by the preceding Linear's epilogue
+          skip_next_scale_add = false;
+          break;
+        }
         const SlotShape& s0 = plan.slots[d.src0];
         PH_REQUIRE(s0.c == d.cin0, "scale-add channel mismatch");
         rc = launch_scale_add_fwd(slot_ptr(d.src0), slot_ptr(d.src1), op.w_dev, slot_ptr(d.dst), s0.cp, (size_t)batch * s0.h * s0.w * s0.cp, s);
