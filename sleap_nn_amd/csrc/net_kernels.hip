@@ -1557,6 +1557,8 @@ __global__ __launch_bounds__(256, 4) void stem_fused_kernel(StemArgs a) {
     f32x4 acc[16];
 #pragma unroll
     for (int p = 0; p < 16; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m1 = -1.f;
+    asm volatile("" : "+v"(m1));  // opaque: keeps x - y as fma(y, m1, x), which packs two lanes per instruction (v_pk_fma_f32; a plain subtraction stays four v_sub_f32)
 #pragma unroll
     for (int xi = 0; xi < 4; ++xi) {
       constexpr int RA[4] = {0, 1, 2, 1}, RB[4] = {2, 2, 1, 3};
@@ -1565,9 +1567,9 @@ __global__ __launch_bounds__(256, 4) void stem_fused_kernel(StemArgs a) {
       for (int c = 0; c < 4; ++c) {
         const f32x4 da = *reinterpret_cast<const f32x4*>(sA + ((2 * wave + RA[xi]) * HALO_W + 2 * li + c) * LROW + lg * 4);
         const f32x4 db = *reinterpret_cast<const f32x4*>(sA + ((2 * wave + RB[xi]) * HALO_W + 2 * li + c) * LROW + lg * 4);
-        t[c] = xi == 1 ? da + db : da - db;
+        t[c] = xi == 1 ? da + db : db * m1 + da;
       }
-      const f32x4 av[4] = {t[0] - t[2], t[1] + t[2], t[2] - t[1], t[1] - t[3]};
+      const f32x4 av[4] = {t[2] * m1 + t[0], t[1] + t[2], t[1] * m1 + t[2], t[3] * m1 + t[1]};
 #pragma unroll
       for (int nu = 0; nu < 4; ++nu) {
         const int pos = xi * 4 + nu;
@@ -1579,20 +1581,24 @@ __global__ __launch_bounds__(256, 4) void stem_fused_kernel(StemArgs a) {
     const f32x4 bias4 = *reinterpret_cast<const f32x4*>(a.b1 + 4 * lg);
     const int Hp = (a.H + 1) / 2, Wp = (a.W + 1) / 2;
     const int x = x0 + 2 * li, y = y0 + 2 * wave;
+    // A^T M A on register quads (four channels at a time; the subtractions as fma(y, -1, x), exact, so that they pack)
     float o[2][2][4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float P[4][2];
+    {
+      f32x4 P[4][2];
 #pragma unroll
       for (int xi = 0; xi < 4; ++xi) {
-        const float m0 = acc[xi * 4 + 0][r], m1 = acc[xi * 4 + 1][r], m2 = acc[xi * 4 + 2][r], m3 = acc[xi * 4 + 3][r];
-        P[xi][0] = (m0 + m1) + m2;
-        P[xi][1] = (m1 - m2) - m3;
+        P[xi][0] = (acc[xi * 4 + 0] + acc[xi * 4 + 1]) + acc[xi * 4 + 2];
+        P[xi][1] = acc[xi * 4 + 3] * m1 + (acc[xi * 4 + 2] * m1 + acc[xi * 4 + 1]);
       }
 #pragma unroll
       for (int bb = 0; bb < 2; ++bb) {
-        o[0][bb][r] = fmaxf(((P[0][bb] + P[1][bb]) + P[2][bb]) + bias4[r], 0.f);
-        o[1][bb][r] = fmaxf(((P[1][bb] - P[2][bb]) - P[3][bb]) + bias4[r], 0.f);
+        const f32x4 o0 = ((P[0][bb] + P[1][bb]) + P[2][bb]) + bias4;
+        const f32x4 o1 = (P[3][bb] * m1 + (P[2][bb] * m1 + P[1][bb])) + bias4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          o[0][bb][r] = fmaxf(o0[r], 0.f);
+          o[1][bb][r] = fmaxf(o1[r], 0.f);
+        }
       }
     }
     float pooled[4] = {0.f, 0.f, 0.f, 0.f};  // values are >= 0 after the ReLU; out-of-image elements count as the reference's zero pad
