@@ -70,6 +70,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_w16_kernel(ConvArgs a) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, kq = lane >> 4;
+  float m1 = -1.f;
+  asm volatile("" : "+v"(m1));  // opaque: keeps x - y as fma(y, m1, x) (v_pk_fma_f32; a plain vector subtraction is compiled to one v_sub_f32 per element)
   const int tiles_x = (a.W + V_TW - 1) / V_TW;
   const int tiles_y = (a.H + V_TH - 1) / V_TH;
   const int total = tiles_x * tiles_y * a.B;
@@ -168,11 +170,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_w16_kernel(ConvArgs a) {
       for (int xi = 0; xi < 4; ++xi) {
         f32x4 t[4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) t[c] = xi == 1 ? da[c] + db[c] : da[c] - db[c];
-        av[0] = t[0] - t[2];
+        for (int c = 0; c < 4; ++c) t[c] = xi == 1 ? da[c] + db[c] : db[c] * m1 + da[c];  // (x - y as fma(y, -1, x), exact: packs two lanes per instruction)
+        av[0] = t[2] * m1 + t[0];
         av[1] = t[1] + t[2];
-        av[2] = t[2] - t[1];
-        av[3] = t[1] - t[3];
+        av[2] = t[1] * m1 + t[2];
+        av[3] = t[3] * m1 + t[1];
 #pragma unroll
         for (int c = 0; c < 4; ++c) asm volatile("" : "+v"(av[c]));
         // Pinned order of a step (one position, 8 MFMAs): its first MFMAs, then the LDS reads of the next step (and, in a row's first
@@ -214,20 +216,21 @@ __global__ __launch_bounds__(512, 2) void conv3x3_w16_kernel(ConvArgs a) {
         const int co = nb * 16 + 4 * kq;
         const f32x4 bias = *reinterpret_cast<const f32x4*>(a.bias + co);
         f32x4 y[2][2];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float P[4][2];
+        {  // A^T M A on register quads (four channels at a time), the subtractions as packed fmas
+          f32x4 P[4][2];
 #pragma unroll
           for (int xi = 0; xi < 4; ++xi) {
-            const float m0 = acc[xi * 4 + 0][nb][e], m1 = acc[xi * 4 + 1][nb][e], m2 = acc[xi * 4 + 2][nb][e], m3 = acc[xi * 4 + 3][nb][e];
-            P[xi][0] = (m0 + m1) + m2;
-            P[xi][1] = (m1 - m2) - m3;
+            P[xi][0] = (acc[xi * 4 + 0][nb] + acc[xi * 4 + 1][nb]) + acc[xi * 4 + 2][nb];
+            P[xi][1] = acc[xi * 4 + 3][nb] * m1 + (acc[xi * 4 + 2][nb] * m1 + acc[xi * 4 + 1][nb]);
           }
 #pragma unroll
           for (int bb = 0; bb < 2; ++bb) {
-            const float v0 = ((P[0][bb] + P[1][bb]) + P[2][bb]) + bias[e], v1 = ((P[1][bb] - P[2][bb]) - P[3][bb]) + bias[e];
-            y[0][bb][e] = a.relu ? fmaxf(v0, 0.f) : v0;
-            y[1][bb][e] = a.relu ? fmaxf(v1, 0.f) : v1;
+            const f32x4 v0 = ((P[0][bb] + P[1][bb]) + P[2][bb]) + bias, v1 = (P[3][bb] * m1 + (P[2][bb] * m1 + P[1][bb])) + bias;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              y[0][bb][e] = a.relu ? fmaxf(v0[e], 0.f) : v0[e];
+              y[1][bb][e] = a.relu ? fmaxf(v1[e], 0.f) : v1[e];
+            }
           }
         }
         if (!a.skip_dst) {
