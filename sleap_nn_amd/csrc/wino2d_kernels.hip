@@ -54,14 +54,17 @@ constexpr int W2_B_OFF = 4 * W2_AH_FLOATS;                 // 12288: four halo h
 constexpr int W2_S_OFF = W2_B_OFF + 3 * W2_BH_FLOATS;      // 36864: 16 KiB spare (epilogue exchange overflow)
 constexpr int W2_LDS_FLOATS = W2_S_OFF + 4096;             // 40960 floats = 160 KiB
 
-__device__ __forceinline__ void w2_deal_tile(int id, int tiles, int nt_count, int* tile, int* ntile) {
+// rot: added to the N tile (mod nt_count); the kernel passes the round (id / workgroups) when the layer's last N tile is half empty and a round covers
+// whole pixel tiles, so that the cheap half tiles go round the workgroups instead of always to the same ones (with an even workgroup count and two N
+// tiles a workgroup would otherwise see one N tile only: the ones with the full tiles would set the launch's time)
+__device__ __forceinline__ void w2_deal_tile(int id, int tiles, int nt_count, int rot, int* tile, int* ntile) {
   // same dealing as deal_tile (net_kernels.hip): every XCD walks a contiguous range of pixel tiles
   if ((tiles & 7) == 0) {
     const int xcd = id & 7, j = id >> 3;
-    *ntile = j % nt_count;
+    *ntile = (j % nt_count + rot) % nt_count;
     *tile = xcd * (tiles >> 3) + j / nt_count;
   } else {
-    *ntile = id % nt_count;
+    *ntile = (id % nt_count + rot) % nt_count;
     *tile = id / nt_count;
   }
 }
@@ -154,9 +157,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_kernel(ConvArgs a) {
   struct Plan {  // workgroup-uniform
     int b, x0, y0, ntile;
   };
+  // (a round = gridDim.x consecutive ids; it covers whole pixel tiles when its id count -- per XCD, where the dealing is XCD-aware -- is a multiple of ntc)
+  const int G = (int)gridDim.x;
+  const bool rotate = (a.coutp % BN) != 0 && (a.coutp % BN) <= 32 && ntc > 1 && (((tiles & 7) == 0) ? ((G & 7) == 0 && (G >> 3) % ntc == 0) : (G % ntc == 0));
   auto setup = [&](int vid, Plan& P) {
     int t, ntile;
-    w2_deal_tile(vid, tiles, ntc, &t, &ntile);
+    w2_deal_tile(vid, tiles, ntc, rotate ? vid / G : 0, &t, &ntile);
     const int tx = t % tiles_x;
     t /= tiles_x;
     const int ty = t % tiles_y;
@@ -347,8 +353,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_kernel(ConvArgs a) {
   while (true) {
     f32x16 acc[4][NT];
     f32x4 bf[2][NT];
-    auto half = [&](auto first_tag, bool last) {
+    // NV: 32-channel halves of this N tile that hold real output channels (1 for the last tile of a layer whose padded channel count is 32 mod 64 --
+    // ConvNeXt's 96-wide decoder level: the other half's MFMAs and weight reads, a quarter of that layer's matrix work, are skipped)
+    auto half = [&](auto first_tag, auto nv_tag, bool last) {
       constexpr bool FIRST = decltype(first_tag)::value;
+      constexpr int NV = decltype(nv_tag)::value;
       {
         const float* bcur = bbuf + kb * W2_BH_FLOATS + offB;
         const float* bnxt = bbuf + (kb == 2 ? 0 : kb + 1) * W2_BH_FLOATS + offB;
@@ -357,7 +366,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_kernel(ConvArgs a) {
         float* adst = abuf + ((ka + 3) & 3) * W2_AH_FLOATS;
         auto load_b = [&](const float* bslot, int nu, int fbuf) {
 #pragma unroll
-          for (int n = 0; n < NT; ++n) bf[fbuf][n] = *reinterpret_cast<const f32x4*>(bslot + (nu * NT + n) * 256);
+          for (int n = 0; n < NV; ++n) bf[fbuf][n] = *reinterpret_cast<const f32x4*>(bslot + (nu * NT + n) * 256);
         };
         if (FIRST) load_b(bcur, 0, 0);  // a tile's first half reads its first fragments after the epilogue's barrier; later halves get them in step 3 of the half before
         // Pinned order inside a step: its first MFMAs, THEN the LDS reads of the next step (the compiler's wait before a step's
@@ -382,7 +391,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_kernel(ConvArgs a) {
             __builtin_amdgcn_sched_barrier(0);
           }
 #pragma unroll
-          for (int n = 0; n < NT; ++n) {
+          for (int n = 0; n < NV; ++n) {
             if (FIRST) {
               f32x16 z;
 #pragma unroll
@@ -407,7 +416,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_kernel(ConvArgs a) {
           }
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int n = 0; n < NT; ++n) acc[nu][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[fcur][n][1], av[nu][1], acc[nu][n], 0, 0, 0);
+          for (int n = 0; n < NV; ++n) acc[nu][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[fcur][n][1], av[nu][1], acc[nu][n], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
           if (nu == 0) {
             b_issue2(0, bdst);
@@ -429,7 +438,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_kernel(ConvArgs a) {
 #pragma unroll
           for (int j = 2; j < 4; ++j)
 #pragma unroll
-            for (int n = 0; n < NT; ++n) acc[nu][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[fcur][n][j], av[nu][j], acc[nu][n], 0, 0, 0);
+            for (int n = 0; n < NV; ++n) acc[nu][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[fcur][n][j], av[nu][j], acc[nu][n], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
         }
         xpass(3);
@@ -438,8 +447,17 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_kernel(ConvArgs a) {
         kb = kb == 2 ? 0 : kb + 1;
       }
     };
-    half(std::true_type{}, false);
-    for (int h = 1; h < 2 * nchunks; ++h) half(std::false_type{}, h + 1 == 2 * nchunks);
+    if (P.ntile * BN + 32 >= a.coutp) {  // workgroup-uniform: only the first 32 channels of this N tile exist
+      half(std::true_type{}, std::integral_constant<int, 1>{}, false);
+      for (int h = 1; h < 2 * nchunks; ++h) half(std::false_type{}, std::integral_constant<int, 1>{}, h + 1 == 2 * nchunks);
+#pragma unroll
+      for (int nu = 0; nu < 4; ++nu)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nu][1][r] = 0.f;  // (the epilogue's arithmetic runs over both halves; its stores skip channels past coutp)
+    } else {
+      half(std::true_type{}, std::integral_constant<int, NT>{}, false);
+      for (int h = 1; h < 2 * nchunks; ++h) half(std::false_type{}, std::integral_constant<int, NT>{}, h + 1 == 2 * nchunks);
+    }
     W2_STAMP(st_loop)
     // ---- epilogue.  The product is accumulated TRANSPOSED (weights = A operand): lane (lx, lh) is tile (ty = 4 mh + (lx >> 3), tx = lx & 7)
     // and accumulator register r is channel n * 32 + (r & 3) + 8 (r >> 2) + 4 lh -- four consecutive channels per register quad, so an

@@ -107,14 +107,15 @@ int launch_wino4_pack(const float* wpack, float* wino, int ntiles, int nchunks, 
   return PH_OK;
 }
 
-__device__ __forceinline__ void w4_deal_tile(int id, int tiles, int nt_count, int* tile, int* ntile) {
-  // as w2_deal_tile: every XCD walks a contiguous range of pixel tiles, the N tiles of one pixel tile sit on one XCD
+__device__ __forceinline__ void w4_deal_tile(int id, int tiles, int nt_count, int rot, int* tile, int* ntile) {
+  // as w2_deal_tile: every XCD walks a contiguous range of pixel tiles, the N tiles of one pixel tile sit on one XCD; rot (the round, when the layer's
+  // last N tile is half empty and a round covers whole pixel tiles) sends the cheap half tiles round the workgroups
   if ((tiles & 7) == 0) {
     const int xcd = id & 7, j = id >> 3;
-    *ntile = j % nt_count;
+    *ntile = (j % nt_count + rot) % nt_count;
     *tile = xcd * (tiles >> 3) + j / nt_count;
   } else {
-    *ntile = id % nt_count;
+    *ntile = (id % nt_count + rot) % nt_count;
     *tile = id / nt_count;
   }
 }
@@ -179,9 +180,11 @@ __global__ __launch_bounds__(768) void conv3x3_wino4_kernel(ConvArgs a) {
   struct Plan {
     int b, x0, y0, ntile;
   };
+  const int G = (int)gridDim.x;
+  const bool rotate = (a.coutp & 63) != 0 && (a.coutp & 63) <= 32 && ntc > 1 && (((tiles & 7) == 0) ? ((G & 7) == 0 && (G >> 3) % ntc == 0) : (G % ntc == 0));
   auto setup = [&](int vid, Plan& P) {
     int t, ntile;
-    w4_deal_tile(vid, tiles, ntc, &t, &ntile);
+    w4_deal_tile(vid, tiles, ntc, rotate ? vid / G : 0, &t, &ntile);
     const int tx = t % tiles_x;
     t /= tiles_x;
     const int ty = t % tiles_y;
@@ -355,30 +358,38 @@ __global__ __launch_bounds__(768) void conv3x3_wino4_kernel(ConvArgs a) {
 #else
 #define W4_MFMA(a_, b_, c_, x, y, z) __builtin_amdgcn_mfma_f32_32x32x2f32(a_, b_, c_, x, y, z)
 #endif
+    // MM = false: this wave's 32 output channels do not exist (N half nt = 1 of the last N tile of a layer whose padded channel count is 32 mod 64): it
+    // keeps its producer duties -- transform, transfers, barriers -- and skips its fragment reads and MFMAs, a third to two thirds of its SIMD's matrix work
+    auto quarters = [&](auto mm_tag) __attribute__((always_inline)) {
+    constexpr bool MM = decltype(mm_tag)::value;
     for (int q = 0; q < Q; ++q) {
       const float* wsl = wring + (q & 1) * W4_W_FLOATS + lane * 4;
       const float* vrd = vbuf + (q & 1) * W4_V_FLOATS + vr0;
       f32x4 wf[3], vf[3];
       // (all weight fragments first: by the time the second MFMA group has waited for vf[1], every read of the weight slot has returned
       // and the slot may take its next transfer)
+      if constexpr (MM) {
 #pragma unroll
-      for (int p = 0; p < 3; ++p) wf[p] = *reinterpret_cast<const f32x4*>(wsl + p * 256);
+        for (int p = 0; p < 3; ++p) wf[p] = *reinterpret_cast<const f32x4*>(wsl + p * 256);
 #pragma unroll
-      for (int p = 0; p < 3; ++p) vf[p] = *reinterpret_cast<const f32x4*>(vrd + p * 256);
-      __builtin_amdgcn_sched_barrier(0);
-      acc[0] = W4_MFMA(wf[0][0], vf[0][0], acc[0], 0, 0, 0);
-      acc[0] = W4_MFMA(wf[0][1], vf[0][1], acc[0], 0, 0, 0);
-      acc[1] = W4_MFMA(wf[0][2], vf[0][2], acc[1], 0, 0, 0);
-      acc[1] = W4_MFMA(wf[0][3], vf[0][3], acc[1], 0, 0, 0);
+        for (int p = 0; p < 3; ++p) vf[p] = *reinterpret_cast<const f32x4*>(vrd + p * 256);
+        __builtin_amdgcn_sched_barrier(0);
+        acc[0] = W4_MFMA(wf[0][0], vf[0][0], acc[0], 0, 0, 0);
+        acc[0] = W4_MFMA(wf[0][1], vf[0][1], acc[0], 0, 0, 0);
+        acc[1] = W4_MFMA(wf[0][2], vf[0][2], acc[1], 0, 0, 0);
+        acc[1] = W4_MFMA(wf[0][3], vf[0][3], acc[1], 0, 0, 0);
+      }
       __builtin_amdgcn_sched_barrier(0);
       W4_ST(0)
       t_rows(q + 1);  // (after the tile's last quarter: the zero-filled slot of an out-of-range transfer -> a V slot nobody reads)
       __builtin_amdgcn_sched_barrier(0);
       W4_ST(1)
-      acc[2] = W4_MFMA(wf[1][0], vf[1][0], acc[2], 0, 0, 0);
-      acc[2] = W4_MFMA(wf[1][1], vf[1][1], acc[2], 0, 0, 0);
-      acc[3] = W4_MFMA(wf[1][2], vf[1][2], acc[3], 0, 0, 0);
-      acc[3] = W4_MFMA(wf[1][3], vf[1][3], acc[3], 0, 0, 0);
+      if constexpr (MM) {
+        acc[2] = W4_MFMA(wf[1][0], vf[1][0], acc[2], 0, 0, 0);
+        acc[2] = W4_MFMA(wf[1][1], vf[1][1], acc[2], 0, 0, 0);
+        acc[3] = W4_MFMA(wf[1][2], vf[1][2], acc[3], 0, 0, 0);
+        acc[3] = W4_MFMA(wf[1][3], vf[1][3], acc[3], 0, 0, 0);
+      }
       __builtin_amdgcn_sched_barrier(0);
       // every fragment of this quarter is in registers (the MFMAs above waited for them): the weight slot just read takes quarter q + 2,
       // raw slot q % 3 (transformed during quarter q - 1) takes quarter q + 3
@@ -389,10 +400,12 @@ __global__ __launch_bounds__(768) void conv3x3_wino4_kernel(ConvArgs a) {
       t_cols_store(q + 1);
       __builtin_amdgcn_sched_barrier(0);
       W4_ST(4)
-      acc[4] = W4_MFMA(wf[2][0], vf[2][0], acc[4], 0, 0, 0);
-      acc[4] = W4_MFMA(wf[2][1], vf[2][1], acc[4], 0, 0, 0);
-      acc[5] = W4_MFMA(wf[2][2], vf[2][2], acc[5], 0, 0, 0);
-      acc[5] = W4_MFMA(wf[2][3], vf[2][3], acc[5], 0, 0, 0);
+      if constexpr (MM) {
+        acc[4] = W4_MFMA(wf[2][0], vf[2][0], acc[4], 0, 0, 0);
+        acc[4] = W4_MFMA(wf[2][1], vf[2][1], acc[4], 0, 0, 0);
+        acc[5] = W4_MFMA(wf[2][2], vf[2][2], acc[5], 0, 0, 0);
+        acc[5] = W4_MFMA(wf[2][3], vf[2][3], acc[5], 0, 0, 0);
+      }
       __builtin_amdgcn_sched_barrier(0);
       W4_ST(5)
       __builtin_amdgcn_s_waitcnt((W4_EXP & 9) ? 0x0070 : 0x0074);  // vmcnt(4) lgkmcnt(0): everything but this quarter's four transfers has landed; V[(q + 1) & 1] is written
@@ -401,6 +414,11 @@ __global__ __launch_bounds__(768) void conv3x3_wino4_kernel(ConvArgs a) {
       __builtin_amdgcn_sched_barrier(0);
       W4_ST(7)
     }
+    };
+    if (nt == 1 && P.ntile * 64 + 32 >= a.coutp)  // wave-uniform
+      quarters(std::false_type{});
+    else
+      quarters(std::true_type{});
 #ifdef W4_STAMP
     if (a.clock_probe && lane == 0 && vid == (int)blockIdx.x) {
       unsigned long long* o = a.clock_probe + ((size_t)blockIdx.x * 12 + pw) * 8;
