@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define PH_VERSION 102
+#define PH_VERSION 103
 
 /* error codes */
 #define PH_OK 0

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in posehip.h but not exported"
     assert set(L.SIGNATURES) == declared
-    assert L.lib().ph_version() == 102
+    assert L.lib().ph_version() == 103
 
 
 def test_integration_binding_struct_matches_the_library():
