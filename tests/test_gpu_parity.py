@@ -991,6 +991,40 @@ def test_winograd_2d_kernel_matches_oracle_and_the_other_conv_kernels(filters, m
     assert torch.equal(again.to(DEV)(img.to(DEV))["SingleInstanceConfmapsHead"].cpu(), outs["w2d"])  # run-to-run bitwise
 
 
+@pytest.mark.parametrize("wino4", [0, 3])
+def test_half_empty_n_tiles_and_rotated_tile_dealing_match_oracle(wino4):
+    """filters = 24, rate 2 -> 24 / 48 / 96 / 192 channels: padded channel counts of 32 and 96 have a last N tile with only its first 32 channels real.
+    Both Winograd kernels skip that half's MFMAs (the F(4x4,3x3) kernel: the waves of N half 1) and, where a layer has several N tiles, rotate the N tiles
+    over the persistent workgroups by round -- 24 frames of 256 x 256 give the 96-channel level (64 x 64) 384 pixel tiles x 2 N tiles = three rounds of the
+    chip, so a wrong rotation (a (pixel tile, N tile) pair computed twice or never) cannot hide.  Against the oracle at the head bar and against the
+    direct kernels; run-to-run bitwise."""
+    from sleap_nn_amd import _lib as L
+    from sleap_nn_amd.architectures.model import Model
+
+    bb = {"in_channels": 1, "kernel_size": 3, "filters": 24, "filters_rate": 2, "max_stride": 8, "stem_stride": None, "middle_block": True,
+          "up_interpolate": True, "stacks": 1, "convs_per_block": 2, "output_stride": 2}
+    heads = {"confmaps": {"part_names": ["a", "b"], "output_stride": 2}}
+    sd = O.init_state(bb, heads, "single_instance", seed=91, head_scale=1.0)
+    g = torch.Generator().manual_seed(92)
+    img = torch.randint(0, 256, (24, 1, 256, 256), dtype=torch.uint8, generator=g)
+    ref = O.model_forward(sd, bb, heads, "single_instance", img[:3])["SingleInstanceConfmapsHead"]
+    outs = {}
+    for name, opts in (("wino", {"conv_wino4": wino4}), ("direct", {"conv_wino4": 0, "conv_wino2d": 0, "conv_wino": 0})):
+        m = Model("unet", bb, heads, "single_instance")
+        m.load_state_dict(sd)
+        for k, v in opts.items():
+            m.set_option(k, v)
+        m.to(DEV)
+        outs[name] = m(img.to(DEV))["SingleInstanceConfmapsHead"].cpu()
+        if name == "wino":
+            kinds = {L.KV_NAMES.get(c, "") for c in m.last_kernels()}
+            assert any("wino2d" in k for k in kinds) and (wino4 == 0 or any("wino4" in k for k in kinds)), kinds
+            assert torch.equal(m(img.to(DEV))["SingleInstanceConfmapsHead"].cpu(), outs["wino"])  # run-to-run bitwise
+    scale = max(1.0, ref.abs().max().item())
+    assert (outs["wino"][:3] - ref).abs().max().item() <= max(CMS_ATOL, W4_RTOL * scale)
+    assert (outs["wino"] - outs["direct"]).abs().max().item() <= 3e-5 * outs["direct"].abs().max().item()  # all 24 frames: every (pixel tile, N tile) pair
+
+
 # Relative bar of the F(4x4,3x3) layers (conv3x3_wino4_kernel): the transforms carry coefficients up to 8 / 5 / (1/24), so the result sits ~2-3x
 # further from the fp64 convolution than F(2x2,3x3) does -- measured on these networks: heads 1.3e-6 ... 2.7e-6 of their scale (F(2x2,3x3):
 # 0.8e-6 ... 1.2e-6), single activations up to 6.3e-6 -- stated here as 1e-5 of the tensor's scale, ten times inside the 1e-4 bar.
