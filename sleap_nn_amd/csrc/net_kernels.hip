@@ -1465,10 +1465,14 @@ __global__ __launch_bounds__(256, 4) void stem_fused_kernel(StemArgs a) {
       for (int tap = 0; tap < 9; ++tap) wreg[tap] = *reinterpret_cast<const f32x4*>(sW0 + tap * 16 + q4);
     }
     const f32x4 b0 = *reinterpret_cast<const f32x4*>(sW0 + 9 * CIN * 16 + q4);
+    // (a tile whose whole halo lies inside the image -- nearly all of them -- needs no per-pixel test: the loop is specialised on that, workgroup-uniform)
+    const bool halo_inside = y0 >= 1 && y0 + TH + 1 <= a.H && x0 >= 1 && x0 + TW + 1 <= a.W;
+    auto conv0 = [&](auto inside_tag) __attribute__((always_inline)) {
+    constexpr bool INSIDE = decltype(inside_tag)::value;
     for (int pix = tid >> 2; pix < HALO_H * HALO_W; pix += 64) {
       const int hy = pix / HALO_W, hx = pix - hy * HALO_W;
       const int gy = y0 + hy - 1, gx = x0 + hx - 1;
-      const bool in = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;  // outside the image = conv1's zero padding
+      const bool in = INSIDE || (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W);  // outside the image = conv1's zero padding
       f32x4 acc = b0;
 #pragma unroll
       for (int c = 0; c < CIN; ++c)
@@ -1484,6 +1488,11 @@ __global__ __launch_bounds__(256, 4) void stem_fused_kernel(StemArgs a) {
       for (int k = 0; k < 4; ++k) acc[k] = in ? fmaxf(acc[k], 0.f) : 0.f;
       *reinterpret_cast<f32x4*>(sA + pix * LROW + q4) = acc;
     }
+    };
+    if (halo_inside)
+      conv0(std::true_type{});
+    else
+      conv0(std::false_type{});
   }
   __syncthreads();
 
