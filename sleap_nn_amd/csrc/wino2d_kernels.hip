@@ -124,6 +124,9 @@ int launch_wino2d_pack(const float* wpack, float* wino, int panels, int bn, hipS
   return PH_OK;
 }
 
+#ifndef PH_W2_STORE_EXP
+#define PH_W2_STORE_EXP 0  // diagnostic builds only (tools/w2_store_exp.sh); 0 = the product
+#endif
 // The K loop runs in HALF chunks (8 input channels).  Half k of the workgroup's running count reads weight half-slot k % 3 and
 // the A fragments that were transformed during half k - 1 from halo half-slot k % 4; during half k the waves transform the
 // fragments of half k + 1 (slot (k + 1) % 4) and issue the LDS-DMA of the weights of half k + 2 (slot (k + 2) % 3, read
@@ -132,7 +135,9 @@ int launch_wino2d_pack(const float* wpack, float* wino, int panels, int bn, hipS
 // PREVIOUS half, so whatever half k + 1 reads is in LDS and visible -- each transfer has between one and two halves
 // (1.7 - 3.4 us) to land, and nothing issued recently is ever waited for.  The counters run on across tiles (persistent
 // workgroup): the fetch cursors walk into the next tile while the current one is still being multiplied.
-template <int BN>
+// HT: the layer's last N tile is half empty (padded channel count 32 mod 64): that tile skips its missing half's MFMAs and the N tiles rotate over the
+// workgroups by round.  A separate instantiation: the second K-loop body and the rotation cost the common case 2 % (code size, scalar registers).
+template <int BN, bool HT = false>
 __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_kernel(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int NT = BN / 32;
@@ -159,7 +164,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_kernel(ConvArgs a) {
   };
   // (a round = gridDim.x consecutive ids; it covers whole pixel tiles when its id count -- per XCD, where the dealing is XCD-aware -- is a multiple of ntc)
   const int G = (int)gridDim.x;
-  const bool rotate = (a.coutp % BN) != 0 && (a.coutp % BN) <= 32 && ntc > 1 && (((tiles & 7) == 0) ? ((G & 7) == 0 && (G >> 3) % ntc == 0) : (G % ntc == 0));
+  const bool rotate = HT && ntc > 1 && (((tiles & 7) == 0) ? ((G & 7) == 0 && (G >> 3) % ntc == 0) : (G % ntc == 0));
   auto setup = [&](int vid, Plan& P) {
     int t, ntile;
     w2_deal_tile(vid, tiles, ntc, rotate ? vid / G : 0, &t, &ntile);
@@ -295,6 +300,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_kernel(ConvArgs a) {
     asm volatile("" : "+v"(av[nu]));
   };
 
+#ifdef PH_W2_STAGGER  // diagnostic (tools/w2_store_exp.sh): spread the workgroups' phases over PH_W2_STAGGER per cent of a tile period, so that their store bursts do not coincide chip-wide
+  {
+    const int period = 2 * nchunks * 4850 + 12000;
+    const int delay = (int)(((blockIdx.x >> 3) & 31) * (unsigned)period / 32u) * PH_W2_STAGGER / 100;
+    for (int i = 0; i < delay / 6400; ++i) __builtin_amdgcn_s_sleep(100);
+  }
+#endif
   // ---- prologue: halo halves 0..2 and weight halves 0..1 of the first tile, fragments of half 0
   int vid = blockIdx.x;
   setup(vid, P);
@@ -447,7 +459,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_kernel(ConvArgs a) {
         kb = kb == 2 ? 0 : kb + 1;
       }
     };
-    if (P.ntile * BN + 32 >= a.coutp) {  // workgroup-uniform: only the first 32 channels of this N tile exist
+    if (HT && P.ntile * BN + 32 >= a.coutp) {  // workgroup-uniform: only the first 32 channels of this N tile exist
       half(std::true_type{}, std::integral_constant<int, 1>{}, false);
       for (int h = 1; h < 2 * nchunks; ++h) half(std::false_type{}, std::integral_constant<int, 1>{}, h + 1 == 2 * nchunks);
 #pragma unroll
@@ -657,9 +669,17 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_kernel(ConvArgs a) {
           for (int k = 0; k < 4; ++k) {
             const int co = ntile * BN + n * 32 + 8 * k + 4 * lh;
             if (!interior && co >= a.coutp) continue;
-            float* const dp = a.dst + ((size_t)(b * a.H + oy) * a.W + ox) * a.coutp + co;
+            float* dp = a.dst + ((size_t)(b * a.H + oy) * a.W + ox) * a.coutp + co;
+#if PH_W2_STORE_EXP == 2  // diagnostic: perfectly coalesced (WRONG) addresses, 1 KiB contiguous per store instruction
+            dp = a.dst + ((size_t)(b * a.H + y0) * a.W + x0) * a.coutp + (size_t)(wave * 16 + n * 8 + k * 2) * 256 + lane * 4;
+#endif
 #pragma unroll
             for (int bb = 0; bb < 2; ++bb) {
+#if PH_W2_STORE_EXP == 1  // diagnostic: half the stores
+              if (bb) continue;
+#elif PH_W2_STORE_EXP == 2
+              dp += bb * 256 - bb * a.coutp;
+#endif
               if (!interior && ox + bb >= a.W) continue;
               f32x4 v;
 #pragma unroll
@@ -670,7 +690,17 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_kernel(ConvArgs a) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = f[e] > 0.f ? v[e] : 0.f;
               }
+#if PH_W2_STORE_EXP == 3  // diagnostics: cache-policy bits on the store
+              asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(dp + bb * a.coutp), "v"(v) : "memory");
+#elif PH_W2_STORE_EXP == 4
+              asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dp + bb * a.coutp), "v"(v) : "memory");
+#elif PH_W2_STORE_EXP == 5
+              asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dp + bb * a.coutp), "v"(v) : "memory");
+#elif PH_W2_STORE_EXP == 6
+              asm volatile("global_store_dwordx4 %0, %1, off sc0" ::"v"(dp + bb * a.coutp), "v"(v) : "memory");
+#else
               *reinterpret_cast<f32x4*>(dp + bb * a.coutp) = v;
+#endif
             }
           }
       }
@@ -707,7 +737,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_kernel(ConvArgs a) {
 static int w2_cu_count(int* out) { return device_cu_count(out); }
 
 int prepare_wino2d_kernels() {
-  const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wino2d_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wino2d_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wino2d_kernel<64, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e != hipSuccess) {
     set_error("hipFuncSetAttribute(wino2d) failed: %s", hipGetErrorString(e));
     return PH_E_HIP;
@@ -728,7 +759,10 @@ int launch_conv3x3_wino2d(const ConvArgs& a, hipStream_t s) {
   if (rc != PH_OK) return rc;
   const int tiles = ((a.W + W2_T - 1) / W2_T) * ((a.H + W2_T - 1) / W2_T) * a.B;
   const int ntc = (a.coutp + 63) / 64;
-  hipLaunchKernelGGL(conv3x3_wino2d_kernel<64>, dim3(std::min(tiles * ntc, n_cu)), dim3(512), (size_t)W2_LDS_FLOATS * sizeof(float), s, a);
+  if ((a.coutp & 63) != 0 && (a.coutp & 63) <= 32)
+    hipLaunchKernelGGL((conv3x3_wino2d_kernel<64, true>), dim3(std::min(tiles * ntc, n_cu)), dim3(512), (size_t)W2_LDS_FLOATS * sizeof(float), s, a);
+  else
+    hipLaunchKernelGGL(conv3x3_wino2d_kernel<64>, dim3(std::min(tiles * ntc, n_cu)), dim3(512), (size_t)W2_LDS_FLOATS * sizeof(float), s, a);
   PH_HIP_CHECK(hipGetLastError());
   return PH_OK;
 }

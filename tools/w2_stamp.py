@@ -21,6 +21,7 @@ def run(cin, cout, hw, batch=32):
     x = torch.randint(0, 256, (batch, 1, hw, hw), dtype=torch.uint8).cuda()
     m.to("cuda:0")
     m.set_option("head_fuse", 0)  # (the conv's own epilogue, not the fused head's 64 extra MFMAs per finishing wave)
+    m.set_option("conv_wino4", 0)  # (this kernel, also where the F(4x4,3x3) kernel would take the layer)
     m(x); torch.cuda.synchronize()
     buf = torch.zeros(256 * 8 * 8, dtype=torch.int64, device="cuda")
     L.check(L.lib().ph_model_set_clock_probe(m._handle, C.c_void_p(buf.data_ptr())))
