@@ -137,7 +137,9 @@ int launch_wino2d_pack(const float* wpack, float* wino, int panels, int bn, hipS
 // workgroup): the fetch cursors walk into the next tile while the current one is still being multiplied.
 // HT: the layer's last N tile is half empty (padded channel count 32 mod 64): that tile skips its missing half's MFMAs and the N tiles rotate over the
 // workgroups by round.  A separate instantiation: the second K-loop body and the rotation cost the common case 2 % (code size, scalar registers).
-template <int BN, bool HT = false>
+// BWD: the backward's store options (accumulate into dst, the folded ReLU mask) are compiled in; the forward instantiations do not carry their branches
+// (~740 cycles per tile of a 64 -> 64 layer, stamp build).
+template <int BN, bool HT = false, bool BWD = false>
 __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_kernel(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int NT = BN / 32;
@@ -684,8 +686,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_kernel(ConvArgs a) {
               f32x4 v;
 #pragma unroll
               for (int e = 0; e < 4; ++e) v[e] = acc[bb][n][4 * k + e];
-              if (a.accumulate) v += *reinterpret_cast<const f32x4*>(dp + bb * a.coutp);  // gradient accumulation (the second data-gradient launch into a concat source's gradient)
-              if (a.relu_mask_src) {  // backward: this launch completes the gradient of a conv + ReLU output -- that ReLU's mask rides in the (lane-local) store
+              if (BWD && a.accumulate) v += *reinterpret_cast<const f32x4*>(dp + bb * a.coutp);  // gradient accumulation (the second data-gradient launch into a concat source's gradient)
+              if (BWD && a.relu_mask_src) {  // backward: this launch completes the gradient of a conv + ReLU output -- that ReLU's mask rides in the (lane-local) store
                 const f32x4 f = *reinterpret_cast<const f32x4*>(a.relu_mask_src + (dp - a.dst) + bb * a.coutp);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = f[e] > 0.f ? v[e] : 0.f;
@@ -737,8 +739,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_kernel(ConvArgs a) {
 static int w2_cu_count(int* out) { return device_cu_count(out); }
 
 int prepare_wino2d_kernels() {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wino2d_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wino2d_kernel<64, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  const void* ks[4] = {reinterpret_cast<const void*>(conv3x3_wino2d_kernel<64, false, false>), reinterpret_cast<const void*>(conv3x3_wino2d_kernel<64, true, false>),
+                       reinterpret_cast<const void*>(conv3x3_wino2d_kernel<64, false, true>), reinterpret_cast<const void*>(conv3x3_wino2d_kernel<64, true, true>)};
+  hipError_t e = hipSuccess;
+  for (const void* k : ks)
+    if (e == hipSuccess) e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e != hipSuccess) {
     set_error("hipFuncSetAttribute(wino2d) failed: %s", hipGetErrorString(e));
     return PH_E_HIP;
@@ -759,10 +764,17 @@ int launch_conv3x3_wino2d(const ConvArgs& a, hipStream_t s) {
   if (rc != PH_OK) return rc;
   const int tiles = ((a.W + W2_T - 1) / W2_T) * ((a.H + W2_T - 1) / W2_T) * a.B;
   const int ntc = (a.coutp + 63) / 64;
-  if ((a.coutp & 63) != 0 && (a.coutp & 63) <= 32)
-    hipLaunchKernelGGL((conv3x3_wino2d_kernel<64, true>), dim3(std::min(tiles * ntc, n_cu)), dim3(512), (size_t)W2_LDS_FLOATS * sizeof(float), s, a);
+  const bool ht = (a.coutp & 63) != 0 && (a.coutp & 63) <= 32, bwd = a.accumulate || a.relu_mask_src;
+  const dim3 grid(std::min(tiles * ntc, n_cu));
+  const size_t lds = (size_t)W2_LDS_FLOATS * sizeof(float);
+  if (ht && bwd)
+    hipLaunchKernelGGL((conv3x3_wino2d_kernel<64, true, true>), grid, dim3(512), lds, s, a);
+  else if (ht)
+    hipLaunchKernelGGL((conv3x3_wino2d_kernel<64, true, false>), grid, dim3(512), lds, s, a);
+  else if (bwd)
+    hipLaunchKernelGGL((conv3x3_wino2d_kernel<64, false, true>), grid, dim3(512), lds, s, a);
   else
-    hipLaunchKernelGGL(conv3x3_wino2d_kernel<64>, dim3(std::min(tiles * ntc, n_cu)), dim3(512), (size_t)W2_LDS_FLOATS * sizeof(float), s, a);
+    hipLaunchKernelGGL((conv3x3_wino2d_kernel<64, false, false>), grid, dim3(512), lds, s, a);
   PH_HIP_CHECK(hipGetLastError());
   return PH_OK;
 }
