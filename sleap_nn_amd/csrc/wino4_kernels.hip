@@ -135,6 +135,8 @@ __device__ __forceinline__ void w4_col_pass(const float (&t)[6], float (&v)[6]) 
   v[5] = fmaf(4.f, t[1], fmaf(-5.f, t[3], t[5]));
 }
 
+// LOWRES: the second source is the half-resolution tensor (ConvArgs::src1_lowres); the plain instantiation does not carry its row coefficients and branches
+template <bool LOWRES>
 __global__ __launch_bounds__(768) void conv3x3_wino4_kernel(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x;
@@ -153,7 +155,7 @@ __global__ __launch_bounds__(768) void conv3x3_wino4_kernel(ConvArgs a) {
   const int ntc = (a.coutp + 63) / 64;
   const int total = tiles * ntc;
   const int Q0 = a.c0p / 4, Q1 = a.c1p / 4, Q = Q0 + Q1;
-  const int lowres = a.src1_lowres;
+  constexpr int lowres = LOWRES ? 1 : 0;
   const int Hl = a.H >> 1, Wl = a.W >> 1;
 
   float* const rawbuf = lds + W4_RAW_OFF;
@@ -501,7 +503,8 @@ __global__ __launch_bounds__(768) void conv3x3_wino4_kernel(ConvArgs a) {
 }
 
 int prepare_wino4_kernels() {
-  const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wino4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS_FLOATS * (int)sizeof(float));
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wino4_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS_FLOATS * (int)sizeof(float));
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wino4_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS_FLOATS * (int)sizeof(float));
   if (e != hipSuccess) {
     set_error("hipFuncSetAttribute(wino4) failed: %s", hipGetErrorString(e));
     return PH_E_HIP;
@@ -539,7 +542,10 @@ int launch_conv3x3_wino4(const ConvArgs& a, hipStream_t s) {
   if (rc != PH_OK) return rc;
   const int tiles = ((a.W + W4_PW - 1) / W4_PW) * ((a.H + W4_PH - 1) / W4_PH) * a.B;
   const int ntc = (a.coutp + 63) / 64;
-  hipLaunchKernelGGL(conv3x3_wino4_kernel, dim3(std::min(tiles * ntc, n_cu)), dim3(768), (size_t)W4_LDS_FLOATS * sizeof(float), s, a);
+  if (a.src1_lowres)
+    hipLaunchKernelGGL(conv3x3_wino4_kernel<true>, dim3(std::min(tiles * ntc, n_cu)), dim3(768), (size_t)W4_LDS_FLOATS * sizeof(float), s, a);
+  else
+    hipLaunchKernelGGL(conv3x3_wino4_kernel<false>, dim3(std::min(tiles * ntc, n_cu)), dim3(768), (size_t)W4_LDS_FLOATS * sizeof(float), s, a);
   PH_HIP_CHECK(hipGetLastError());
   return PH_OK;
 }
