@@ -134,12 +134,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_w16_kernel(ConvArgs a) {
     const int nvid = vid + gridDim.x;
     const bool has_next = nvid < total;
     f32x4 acc[16][NB];
+    if constexpr (CHUNKS > 1) {  // (one chunk: a position's first MFMA takes C = 0 instead -- 64 NB register moves per tile that the matrix pipe waits for)
 #pragma unroll
-    for (int p = 0; p < 16; ++p)
+      for (int p = 0; p < 16; ++p)
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb)
+        for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc[p][nb][e] = 0.f;
+          for (int e = 0; e < 4; ++e) acc[p][nb][e] = 0.f;
+    }
 #pragma unroll 1
     for (int ch = 0; ch < CHUNKS; ++ch) {  // (one copy of the body: unrolled, the two-chunk variant spills)
       // the next unit's halo streams into the other buffer under this unit's MFMAs
@@ -183,7 +185,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_w16_kernel(ConvArgs a) {
         for (int nu = 0; nu < 4; ++nu) {
           const int pos = xi * 4 + nu, cur = pos & 1;
 #pragma unroll
-          for (int nb = 0; nb < NB; ++nb) acc[pos][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[cur][nb][0], av[nu][0], acc[pos][nb], 0, 0, 0);  // D[channel][tile]
+          for (int nb = 0; nb < NB; ++nb)
+            acc[pos][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[cur][nb][0], av[nu][0], CHUNKS > 1 ? acc[pos][nb] : f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);  // D[channel][tile]
           __builtin_amdgcn_sched_barrier(0);
           if (pos + 1 < 16) load_b(pos + 1, cur ^ 1);
           if (nu == 0 && xi + 1 < 4) read_rows(xi + 1);
