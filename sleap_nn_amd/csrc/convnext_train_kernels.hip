@@ -251,41 +251,55 @@ constexpr int DWG_SLICES = 512;
 __global__ __launch_bounds__(256) void dwconv7_wgrad_partial_kernel(const float* __restrict__ x, const float* __restrict__ gy, int B, int H, int W, int cp,
                                                                     float* __restrict__ partial) {
   __shared__ float red[4][64];
-  const int lane_c = threadIdx.x & 63, rsub = threadIdx.x >> 6;
+  const int lane_c = threadIdx.x & 63, rsub = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // (wave-uniform, and known to be: the row descriptors live in scalar registers)
   const int c = blockIdx.y * 64 + lane_c;
   const bool cok = c < cp;
-  const int cc = cok ? c : cp - 1;
   const int rows = B * H;
   float acc[49];
 #pragma unroll
   for (int t = 0; t < 49; ++t) acc[t] = 0.f;
+  // The 7 x 7 window lives in registers as a RING over columns: column x + d sits in slot (x + d) mod 7, so moving one pixel to the right replaces one
+  // slot per kernel row and moves nothing (the shifting window of round 2 spent 42 of its ~126 vector instructions per pixel on register moves).  The x
+  // loop is unrolled by seven so that every slot index is a compile-time constant.  Rows are addressed through per-row buffer descriptors (a wave = one
+  // output row: wave-uniform): columns right of the image and rows outside it are out of range = zeros, no clamps or selects.
+  const unsigned vc = cok ? (unsigned)c * 4u : 0x80000000u;
+  const int row_bytes = W * cp * 4, px_bytes = cp * 4;
   for (int row = blockIdx.x * 4 + rsub; row < rows; row += gridDim.x * 4) {
     const int b = row / H, y = row - b * H;
-    const float* xb = x + (size_t)b * H * W * cp + cc;
-    const float* gr = gy + ((size_t)row * W) * cp + cc;
-    float win[7][7];  // win[ky][j]: input at row y+ky-3, column (current x) + j - 3
+    __amdgpu_buffer_rsrc_t rs[7];
 #pragma unroll
-    for (int ky = 0; ky < 7; ++ky)
+    for (int ky = 0; ky < 7; ++ky) {
+      const int iy = y + ky - 3;
+      const bool ok = iy >= 0 && iy < H;
+      rs[ky] = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x + ((size_t)b * H + (ok ? iy : 0)) * W * cp), 0, ok ? row_bytes : 0, 0x00020000);
+    }
+    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gy + (size_t)row * W * cp), 0, row_bytes, 0x00020000);
+    float win[7][7];  // win[ky][slot]
 #pragma unroll
-      for (int j = 0; j < 7; ++j) {
-        const int iy = y + ky - 3, ix = j - 3 - 1;  // primed for x = -1: the loop shifts before use
-        win[ky][j] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? xb[((size_t)iy * W + ix) * cp] : 0.f;
+    for (int ky = 0; ky < 7; ++ky) {
+#pragma unroll
+      for (int j = 0; j < 7; ++j) win[ky][j] = 0.f;  // columns -3 .. -1 (slots 4 .. 6) stay zero until they are replaced; slot 3 is loaded at x = 0
+#pragma unroll
+      for (int j = 0; j < 3; ++j) win[ky][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs[ky], vc + (unsigned)(j * px_bytes), 0, 0));  // columns 0 .. 2 (beyond a narrow image: zeros)
+    }
+    for (int x0 = 0; x0 < W; x0 += 7) {
+#pragma unroll
+      for (int ph = 0; ph < 7; ++ph) {
+        const int xx = x0 + ph;
+        if (xx < W) {  // wave-uniform
+          const unsigned vnew = vc + (unsigned)((xx + 3) * px_bytes);  // column xx + 3 -> slot (ph + 3) % 7, the one column xx - 4 held
+#pragma unroll
+          for (int ky = 0; ky < 7; ++ky) win[ky][(ph + 3) % 7] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs[ky], vnew, 0, 0));
+          const float g = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rg, vc + (unsigned)(xx * px_bytes), 0, 0));
+#pragma unroll
+          for (int ky = 0; ky < 7; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 7; ++kx) {
+              acc[ky * 7 + kx] = fmaf(g, win[ky][(ph + kx + 4) % 7], acc[ky * 7 + kx]);  // column xx + kx - 3
+              asm volatile("" : "+v"(acc[ky * 7 + kx]));  // one scalar fma per tap: paired (v_pk_fma_f32) the ring's rotating slots cost 53 register moves per pixel
+            }
+        }
       }
-    for (int xx = 0; xx < W; ++xx) {
-#pragma unroll
-      for (int ky = 0; ky < 7; ++ky) {
-#pragma unroll
-        for (int j = 0; j < 6; ++j) win[ky][j] = win[ky][j + 1];
-        const int iy = y + ky - 3, ix = xx + 3;
-        const int cy = min(max(iy, 0), H - 1), cx = min(ix, W - 1);
-        const float v = xb[((size_t)cy * W + cx) * cp];
-        win[ky][6] = (iy >= 0 && iy < H && ix < W) ? v : 0.f;
-      }
-      const float g = gr[(size_t)xx * cp];
-#pragma unroll
-      for (int ky = 0; ky < 7; ++ky)
-#pragma unroll
-        for (int kx = 0; kx < 7; ++kx) acc[ky * 7 + kx] = fmaf(g, win[ky][kx], acc[ky * 7 + kx]);
     }
   }
   // combine the four row streams of the workgroup in a fixed order
