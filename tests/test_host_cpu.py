@@ -27,7 +27,16 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in posehip.h but not exported"
     assert set(L.SIGNATURES) == declared
-    assert L.lib().ph_version() == 103
+    assert L.lib().ph_version() == int(re.search(r"^#define\s+PH_VERSION\s+(\d+)", hdr, re.M).group(1))
+
+
+def test_graft_entry_build_runs_and_checks_the_declared_abi_version():
+    """The driver's build entry point must not raise on a tree whose library matches its header (round 3 shipped a stale literal)."""
+    import __graft_entry__ as g
+
+    g.build()
+    src = open(os.path.join(ROOT, "__graft_entry__.py")).read()
+    assert "PH_VERSION" in src and not re.search(r"ph_version\(\)\s*==\s*\d", src)
 
 
 def test_integration_binding_struct_matches_the_library():
