@@ -456,7 +456,7 @@ def run_infer(args, ctx):
     eager(frames)
     kv = model.last_kernels()
     torch.cuda.synchronize()
-    KSHORT = {L.KV_DIRECT: "direct", L.KV_WINO1D: "wino1d", L.KV_WINO2D: "wino2d", L.KV_W16: "w16", L.KV_C16: "c16", L.KV_ROWGEMM: "rowgemm", L.KV_WINO4: "wino4", L.KV_F16: "f16"}
+    KSHORT = {L.KV_DIRECT: "direct", L.KV_WINO1D: "wino1d", L.KV_WINO2D: "wino2d", L.KV_W16: "w16", L.KV_C16: "c16", L.KV_ROWGEMM: "rowgemm", L.KV_WINO4: "wino4", L.KV_F16: "f16", L.KV_WINO2D_KS: "wino2d"}  # (the split-K launches of small batches are the same kernel family)
     by_kernel = {}
     for (r, ms), code in zip(conv_rows, [c for row, c in zip(table, kv) if row["kind"] == L.OP_CONV]):
         share = (3.0 if precision == "split" else 1.0) if code == L.KV_F16 else L.KV_MFMA_SHARE[code]

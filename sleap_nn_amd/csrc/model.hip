@@ -202,6 +202,7 @@ void apply_conv_options(const ph_model* m, ConvArgs& a) {
   a.persist = m->conv_persist;
   a.use_c16 = m->conv_c16;
   a.dma_stagger = m->dma_stagger;
+  a.splitk = m->conv_splitk;
 }
 
 // Programs made only of the UNet-style ops can run on the fp16 matrix pipe (handle option "conv_precision"); anything
@@ -364,6 +365,11 @@ int build_plan(const ph_model* m, int B, int H, int W, Plan& plan, int fmt) {
                  h, w, s1.h, s1.w);
     }
     if (d.kind == PH_OP_CONVT) tmp = std::max<int64_t>(tmp, (int64_t)B * oh * ow * fmt_cpad(fmt, d.cin0) * bpc);
+    if (d.kind == PH_OP_CONV && d.ksize == 3 && fmt == FMT_F32 && m->conv_splitk) {  // partial-sum planes of a split-K launch (conv3x3_wino2d_kernel<.., KS>)
+      int n_cu = 0;
+      if (device_cu_count(&n_cu) != PH_OK || n_cu <= 0) n_cu = 256;
+      tmp = std::max<int64_t>(tmp, wino2d_split_scratch_bytes(B, h, w, pad16(d.cin0) + (d.src1 >= 0 ? pad16(d.cin1) : 0), pad16(d.cout), m->conv_splitk, n_cu));
+    }
     PH_REQUIRE(d.dst >= 0 && d.dst < m->n_slots, "bad dst slot %d", d.dst);
     SlotShape& s = plan.slots[d.dst];
     s.c = (d.kind == PH_OP_POOL || d.kind == PH_OP_UPSAMPLE || d.kind == PH_OP_GLOBAL_MAXPOOL) ? d.cin0 : d.cout;
@@ -663,10 +669,10 @@ ph_model* ph_model_create(const ph_op_desc* ops, int32_t n_ops, const float* con
         if (ok && !tr) ok = derive_wino4(op.w_dev, d.cin0, d.cin1, d.cout, op.bn, &op.w_wino4_dev);
         // wave-private F(2x2,3x3) weights (conv3x3_w16_kernel: 16 / 32 output channels, 16 / 32 input channels, one source): the forward
         // conv's, and below the data-gradient convs'
-        auto derive_w16 = [&](const float* src, int cin_, int cout_, int bn, float** dst) {
-          const int cip = pad16(cin_), cop = pad16(cout_);
-          if (bn != 32 || (cop != 16 && cop != 32) || (cip != 16 && cip != 32)) return true;
-          const int chunks = cip / 16, nbs = cop / 16;
+        auto derive_w16 = [&](const float* src, int cin_, int cout_, int bn, float** dst, int cin_b = 0) {
+          const int cip = pad16(cin_), cibp = cin_b > 0 ? pad16(cin_b) : 0, cop = pad16(cout_);
+          if (bn != 32 || !w16_shape_ok(cip, cibp, cop)) return true;
+          const int chunks = (cip + cibp) / 16, nbs = cop / 16;
           float* w = nullptr;
           if (hipMalloc(&w, (size_t)w16_pack_floats(chunks, nbs) * sizeof(float)) != hipSuccess) return false;
           m->allocs.push_back(w);
@@ -681,7 +687,7 @@ ph_model* ph_model_create(const ph_op_desc* ops, int32_t n_ops, const float* con
           *dst = w;
           return true;
         };
-        if (ok && !tr && d.cin1 == 0) ok = derive_w16(op.w_dev, d.cin0, d.cout, op.bn, &op.w_w16_dev);
+        if (ok && !tr) ok = derive_w16(op.w_dev, d.cin0, d.cout, op.bn, &op.w_w16_dev, d.cin1);
         if (ok && !tr) {  // row-GEMM form for feature maps too small for the 16x32-pixel tiles
           op.bn_g = gemm_choose_bn(coutp);
           auto pack_g = [&](const auto* w, auto& out) { pack_gemm(w, d.cout, d.cin0, d.cin1, 9, op.bn_g, out); };
@@ -1090,6 +1096,10 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
         apply_conv_options(m, a);
         a.wpack_wino4 = op.w_wino4_dev;
         a.use_wino4 = m->conv_wino4 == 3 ? 2 : ((m->conv_wino4 == 2 || (m->conv_wino4 == 1 && plan.reuse)) ? 1 : 0);
+        if (plan.tmp_bytes > 0) {
+          a.split_scratch = reinterpret_cast<float*>(ws + plan.tmp_offset);
+          a.split_scratch_bytes = plan.tmp_bytes;
+        }
         if (deferred_up >= 0) {
           // The op before this one is a bilinear x2 that only feeds this conv's second source and was not launched: the F(4x4,3x3) kernel
           // reads the half-resolution tensor itself (the up-sampling rides in its input transform); any other kernel gets the tensor now.
@@ -1145,18 +1155,20 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
           rc = launch_gemm(g, s);
           break;
         }
-        if (m->head_fuse && !a.dst_pool && a.coutp == 64 && a.bn == 64 && m->use_dma) {
+        if (m->head_fuse && !a.dst_pool && ((a.coutp == 64 && a.bn == 64) || ((a.coutp == 16 || a.coutp == 32) && a.bn == 32)) && m->use_dma) {
           // A 1x1 head that reads this conv's 64-channel output rides in the F(2x2,3x3) kernel's epilogue (the accumulator layout is the
           // MFMA's B operand: conv3x3_wino2d_kernel); when nothing else reads the tensor (inference plans) it never reaches HBM.
           for (size_t j = op_index; j < m->ops.size(); ++j) {
             const ph_op_desc& hx = m->ops[j].d;
             if (hx.kind != PH_OP_HEAD || hx.src0 != d.dst) continue;
-            if (!(hx.flags & PH_FLAG_SOFTMAX) && hx.cout <= 32 && pad16(hx.cin0) == 64 && out_dev[hx.out_index] && conv3x3_dma_is_wino2d(a)) {
+            const bool on_w2d = a.coutp == 64 && hx.cout <= 32 && pad16(hx.cin0) == 64 && conv3x3_dma_is_wino2d(a) && wino2d_ksplit(a) <= 1;
+            const bool on_w16 = a.coutp <= 32 && hx.cout <= 16 && pad16(hx.cin0) == a.coutp && conv3x3_dma_is_w16_head(a);  // (conv3x3_w16_kernel<.., HEAD>)
+            if (!(hx.flags & PH_FLAG_SOFTMAX) && out_dev[hx.out_index] && (on_w2d || on_w16)) {
               a.head_w = m->ops[j].w_dev;
               a.head_b = m->ops[j].b_dev;
               a.head_dst = out_dev[hx.out_index];
               a.head_cout = hx.cout;
-              a.head_wcp = 64;
+              a.head_wcp = a.coutp;
               a.head_sigmoid = (hx.flags & PH_FLAG_SIGMOID) ? 1 : 0;
               head_done[j] = 1;
               if (plan.reuse) {  // training keeps every activation
@@ -1453,7 +1465,10 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
         break;
       }
       case PH_OP_HEAD: {
-        if (head_done[op_index - 1]) break;  // computed by its producer's epilogue
+        if (head_done[op_index - 1]) {  // computed by its producer's epilogue
+          kv[op_index - 1] = PH_KV_FUSED;
+          break;
+        }
         const SlotShape& s0 = plan.slots[d.src0];
         PH_REQUIRE(s0.c == d.cin0, "head channel mismatch");
         PH_REQUIRE(out_dev[d.out_index] != nullptr, "output %d is null", d.out_index);
@@ -1497,6 +1512,7 @@ std::vector<OptionRef> option_table(ph_model* m) {
       {"conv_wino2d", &m->conv_wino2d, nullptr},        // 1: N-tile-64 3x3 convs on the F(2x2,3x3) kernel; 0: F(2,3) along x only
       {"conv_wino4", &m->conv_wino4, nullptr},          // K-heavy 3x3 convs on the F(4x4,3x3) kernel: 1 inference plans, 2 every plan (both: where estimated faster), 3 every plan wherever it fits, 0 never
       {"conv_wino4_min_cin", &m->conv_wino4_min_cin, nullptr},  // padded input channels from which a layer takes it
+      {"conv_splitk", &m->conv_splitk, nullptr},        // split K on the F(2x2,3x3) kernel for layers with fewer work units than CUs: 0 never, 1 where estimated faster, n >= 2 force n slices
       {"upsample_fold", &m->upsample_fold, nullptr},    // bilinear x2 folded into the F(4x4,3x3) input transform of the conv that consumes it
       {"stem_wino", &m->stem_wino, nullptr},            // second conv of the fused stem in Winograd form
       {"dgrad_wino", &m->dgrad_wino, nullptr},          // 0: direct 9-tap kernels for the backward's data-gradient convs

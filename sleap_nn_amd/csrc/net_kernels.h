@@ -45,6 +45,12 @@ struct ConvArgs {
   int use_wino4 = 0;          // filled from the handle option "conv_wino4" and the kind of plan: 1 = where it is estimated faster than F(2x2,3x3), 2 = wherever the shape fits
   int wino4_min_cin = 128;    // handle option "conv_wino4_min_cin"
   int src1_lowres = 0;        // src1 is (B, H/2, W/2, c1p): bilinear x2 (align_corners = False) is folded into the input transform (wino4 only)
+  // split K on the F(2x2,3x3) kernel (small batches: fewer work units than CUs), see conv3x3_wino2d_kernel<.., KS>
+  int splitk = 0;                     // handle option "conv_splitk": 0 never, 1 where estimated faster, n >= 2 force n slices
+  float* split_scratch = nullptr;     // [ksplit][B][H][W][coutp] partial sums (the plan's tmp range), or nullptr = no split
+  long long split_scratch_bytes = 0;
+  int ksplit = 1;                     // filled by the launcher for the kernel
+  long long split_stride = 0;         // floats per scratch plane
 };
 
 struct InputConvArgs {
@@ -154,7 +160,8 @@ int launch_stem_wino2d_pack(const float* w1, float* w2, hipStream_t s);  // [tap
 int launch_conv3x3_dma(const ConvArgs& a, hipStream_t s);
 bool conv3x3_dma_honours_mask(const ConvArgs& a);  // launch_conv3x3_dma would run a kernel that applies relu_mask_src
 bool conv3x3_dma_is_f2x2(const ConvArgs& a);       // launch_conv3x3_dma would run one of the two F(2x2,3x3) kernels
-bool conv3x3_dma_is_wino2d(const ConvArgs& a);     // ... the wave-split one (the only kernel that takes a fused head)
+bool conv3x3_dma_is_wino2d(const ConvArgs& a);     // ... the wave-split one (takes a fused head on a 64-channel output)
+bool conv3x3_dma_is_w16_head(const ConvArgs& a);   // ... the wave-private one on a shape whose 1x1 head (<= 16 channels) can ride in its epilogue
 int conv3x3_dma_variant(const ConvArgs& a);        // PH_KV_* code (posehip.h) of the kernel launch_conv3x3_dma would run
 // wpack [panel][tap 9][bn][16] -> F(2x2,3x3) weights [panel][g 2][xi 4][nu 4][n tile][lh][lx][4] (see conv3x3_wino2d_kernel)
 int launch_wino2d_pack(const float* wpack, float* wino, int panels, int bn, hipStream_t s);
@@ -168,12 +175,17 @@ bool wino4_fits(const ConvArgs& a);
 bool conv3x3_dma_is_wino4(const ConvArgs& a);      // launch_conv3x3_dma would run the F(4x4,3x3) kernel (the only one that folds a half-resolution src1)
 int prepare_wino4_kernels();
 bool wino2d_fits(const ConvArgs& a);  // sources addressable through the kernel's 32-bit buffer descriptors
+int wino2d_ksplit(const ConvArgs& a);  // K slices launch_conv3x3_wino2d would use for this launch (1 = the one-stage kernel)
+int wino2d_ksplit_shape(int B, int H, int W, int cinp, int coutp, int splitk, int n_cu);
+int64_t wino2d_split_scratch_bytes(int B, int H, int W, int cinp, int coutp, int splitk, int n_cu);  // scratch a plan reserves for such a layer
 int prepare_wino2d_kernels();
 // wpack [chunk][tap 9][32][16] -> wave-private F(2x2,3x3) weights [chunk][position][N block][kq][n][4] (see conv3x3_w16_kernel)
 int launch_w16_pack(const float* wpack, float* w16, int chunks, int nbs, hipStream_t s);  // nbs: N blocks of 16 output channels (1 or 2)
 int64_t w16_pack_floats(int chunks, int nbs);
 int launch_conv3x3_w16(const ConvArgs& a, hipStream_t s);
 bool w16_fits(const ConvArgs& a);
+bool w16_takes_head(const ConvArgs& a);  // the wave-private kernel would run this launch and can carry a fused 1x1 head (<= 16 head channels, head_wcp = coutp)
+bool w16_shape_ok(int c0p, int c1p, int coutp);  // channel counts the wave-private kernel takes (c1p = 0: one source)
 int prepare_w16_kernels();
 int launch_input_conv(const InputConvArgs& a, hipStream_t s);
 int launch_pool(const float* src, float* dst, int B, int H, int W, int cp, hipStream_t s);

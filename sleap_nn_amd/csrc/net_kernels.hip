@@ -1320,12 +1320,13 @@ bool conv3x3_dma_honours_mask(const ConvArgs& a) {  // the three F(2x2,3x3) / F(
 bool conv3x3_dma_is_f2x2(const ConvArgs& a) { const int r = conv3x3_dma_route(a); return r == 1 || r == 2; }
 bool conv3x3_dma_is_wino2d(const ConvArgs& a) { return conv3x3_dma_route(a) == 2; }
 bool conv3x3_dma_is_wino4(const ConvArgs& a) { return conv3x3_dma_route(a) == 4; }
+bool conv3x3_dma_is_w16_head(const ConvArgs& a) { return conv3x3_dma_route(a) == 1 && w16_takes_head(a); }
 // PH_KV_* code of the kernel launch_conv3x3_dma would run (ph_model_last_kernels)
 int conv3x3_dma_variant(const ConvArgs& a) {
   switch (conv3x3_dma_route(a)) {
     case 0: return PH_KV_C16;
     case 1: return PH_KV_W16;
-    case 2: return PH_KV_WINO2D;
+    case 2: return wino2d_ksplit(a) > 1 ? PH_KV_WINO2D_KS : PH_KV_WINO2D;
     case 4: return PH_KV_WINO4;
     default: break;
   }
@@ -1337,8 +1338,9 @@ int launch_conv3x3_dma(const ConvArgs& a, hipStream_t s) {
   const int route = conv3x3_dma_route(a);
   PH_REQUIRE(!a.relu_mask_src || ((route == 1 || route == 2 || route == 4) && !a.dst_pool && !a.head_w && !a.skip_dst),
              "relu_mask_src is applied by the F(2x2,3x3) / F(4x4,3x3) kernels' plain stores only (ask conv3x3_dma_honours_mask first)");
-  PH_REQUIRE(!a.head_w || (route == 2 && !a.dst_pool && a.coutp == 64 && a.bn == 64 && a.head_cout >= 1 && a.head_cout <= 32 && a.head_wcp == 64 && a.head_b && a.head_dst),
-             "a fused head needs the F(2x2,3x3) kernel, 64 output channels and at most 32 head channels (ask conv3x3_dma_is_wino2d first)");
+  PH_REQUIRE(!a.head_w || (route == 2 && !a.dst_pool && a.coutp == 64 && a.bn == 64 && a.head_cout >= 1 && a.head_cout <= 32 && a.head_wcp == 64 && a.head_b && a.head_dst) ||
+                 (route == 1 && w16_takes_head(a) && a.head_cout >= 1 && a.head_cout <= 16 && a.head_wcp == a.coutp && a.head_b && a.head_dst),
+             "a fused head needs the F(2x2,3x3) kernel on 64 output channels (<= 32 head channels) or the wave-private kernel on 16 -> 16 / 32 -> 32 channels (<= 16 head channels): ask conv3x3_dma_is_wino2d / _is_w16_head first");
   if (route == 1) return launch_conv3x3_w16(a, s);
   if (route == 0) return launch_conv3x3_c16(a, s);
   if (route == 2) return launch_conv3x3_wino2d(a, s);

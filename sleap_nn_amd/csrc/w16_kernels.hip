@@ -60,7 +60,14 @@ int launch_w16_pack(const float* wpack, float* w16, int chunks, int nbs, hipStre
   return PH_OK;
 }
 
-template <int CHUNKS, int NB>
+// TWO: the decoder's concat((skip, x)) (encoder_decoder.py:545,556) as two K panels: chunks [0, c0p / 16) come from src0, the rest from src1 (its own descriptor and
+// pixel stride) -- the full-resolution decoder level of an output-stride-1 filters-16 UNet (16 + 32 -> 16 channels), or the last level of a filters-8 one; they ran on the
+// N-tile-32 F(2,3) kernel with half of its N tile empty before.  (Resident weights bound the chunk count: 16 KiB per chunk and N block next to 80 KiB of halo buffers.)
+// HEAD: a 1x1 head (<= 16 output channels) on this conv's output rides in the epilogue: the lane-local result y[pixel][e] = channel 16 nb + 4 kq + e of tile li IS the B operand
+// of v_mfma_f32_16x16x4_f32 (lane = (n = tile, k = kq)), so head[o][tile] = sum_c W[o][c] y[c][tile] is 4 NB MFMAs per pixel with A[i = o][k = kq] = W[o][16 nb + 4 kq + e]
+// (one 16-byte read of the head's own [o][c] weights per N block, kept in registers); D = lane (tile, o quad kq), registers o = 4 kq + r: NCHW pixel-pair stores.  The
+// final conv of an output-stride-1 / -2 UNet (16 -> 16, 32 -> 32) then needs no head launch, and in inference plans its output never reaches HBM (skip_dst).
+template <int CHUNKS, int NB, bool TWO = false, bool HEAD = false>
 __global__ __launch_bounds__(512, 2) void conv3x3_w16_kernel(ConvArgs a) {
   constexpr int V_W_FLOATS = v_w_floats(NB);
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -78,6 +85,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_w16_kernel(ConvArgs a) {
 
   // ---- halo DMA: piece p = wave + 8 s (s = 0..4) of a buffer; lane -> entry (p % 20) * 16 + (lane >> 2) of parity plane p / 20, quad lane & 3
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.src0, 0, (int)((unsigned)(a.B * a.H * a.W) * (unsigned)(a.c0p * 4)), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc1 = __builtin_amdgcn_make_buffer_rsrc((void*)(TWO ? a.src1 : a.src0), 0, (int)((unsigned)(a.B * a.H * a.W) * (unsigned)((TWO ? a.c1p : a.c0p) * 4)), 0x00020000);
+  const int chunks0 = TWO ? a.c0p / 16 : CHUNKS;
   int hyx[5];  // the lane's halo pixel (hy << 8) | hx in DMA slot s, or -1 beyond the plane
 #pragma unroll
   for (int s = 0; s < 5; ++s) {
@@ -87,7 +96,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_w16_kernel(ConvArgs a) {
     const int hy = e / 9, hx = 2 * (e - hy * 9) + par;
     hyx[s] = e < V_PLANE_E ? (hy << 8) | hx : -1;
   }
-  unsigned fvo[5];
+  unsigned fvo[5], fvo1[5];  // (fvo1: dead unless TWO; a template-dependent array bound here makes this clang drop the host-side instantiations)
   // workgroup ids are dealt round-robin over the 8 XCDs: every XCD walks a contiguous range of tiles (neighbours' halo overlap meets in its L2)
   auto tile_of = [&](int vid) { return (total & 7) == 0 ? (vid & 7) * (total >> 3) + (vid >> 3) : vid; };
   auto point = [&](int vid) {  // per-lane offsets of tile vid's halo
@@ -104,9 +113,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_w16_kernel(ConvArgs a) {
       const int gy = y0 + hy - 1, gx = x0 + hx - 1;
       const bool in = hyx[s] >= 0 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
       fvo[s] = in ? base + (unsigned)(((hy - 1) * a.W + (hx - 1)) * a.c0p * 4 + (lane & 3) * 16) : 0xFFFFFF00u;
+      if (TWO) fvo1[s] = in ? (unsigned)(((b * a.H + gy) * a.W + gx) * a.c1p * 4 + (lane & 3) * 16) : 0xFFFFFF00u;
     }
   };
   auto dma = [&](float* buf, int chunk) {
+    if (TWO && chunk >= chunks0) {  // workgroup-uniform
+#pragma unroll
+      for (int s = 0; s < 5; ++s)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc1, (__attribute__((address_space(3))) void*)(buf + (wave + 8 * s) * 256), 16, fvo1[s], (chunk - chunks0) * 64, 0, 0);
+      return;
+    }
 #pragma unroll
     for (int s = 0; s < 5; ++s)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(buf + (wave + 8 * s) * 256), 16, fvo[s], chunk * 64, 0, 0);
@@ -124,6 +140,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_w16_kernel(ConvArgs a) {
 #pragma unroll
     for (int s = 0; s < WP; ++s)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (__attribute__((address_space(3))) void*)(wl + (wave * WP + s) * 256), 16, (unsigned)lane * 16u, (wave * WP + s) * 1024, 0, 0);
+  }
+  f32x4 hw[HEAD ? NB : 1];  // HEAD: row li of the head's weights, columns 16 nb + 4 kq .. + 3 (zeros for rows past head_cout)
+  if (HEAD) {
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      hw[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (li < a.head_cout) hw[nb] = *reinterpret_cast<const f32x4*>(a.head_w + (size_t)li * a.head_wcp + nb * 16 + 4 * kq);
+    }
   }
   int vid = blockIdx.x;
   point(vid);
@@ -214,6 +238,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_w16_kernel(ConvArgs a) {
       const bool interior = (x0 + V_TW <= a.W) && (y0 + 4 <= a.H);
       const int Hp = (a.H + 1) >> 1, Wp = (a.W + 1) >> 1;
       const int oy = y0 + 2 * (li >> 3), ox = x0 + 2 * (li & 7);
+      f32x4 hd[2][2];
+      if (HEAD) {
+#pragma unroll
+        for (int aa = 0; aa < 2; ++aa)
+#pragma unroll
+          for (int bb = 0; bb < 2; ++bb) hd[aa][bb] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
         const int co = nb * 16 + 4 * kq;
@@ -235,6 +266,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_w16_kernel(ConvArgs a) {
               y[1][bb][e] = a.relu ? fmaxf(v1[e], 0.f) : v1[e];
             }
           }
+        }
+        if (HEAD) {
+#pragma unroll
+          for (int aa = 0; aa < 2; ++aa)
+#pragma unroll
+            for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) hd[aa][bb] = __builtin_amdgcn_mfma_f32_16x16x4f32(hw[nb][e], y[aa][bb][e], hd[aa][bb], 0, 0, 0);
         }
         if (!a.skip_dst) {
 #pragma unroll
@@ -269,6 +308,37 @@ __global__ __launch_bounds__(512, 2) void conv3x3_w16_kernel(ConvArgs a) {
           if (interior || (py < Hp && px < Wp)) *reinterpret_cast<f32x4*>(a.dst_pool + ((size_t)(b * Hp + py) * Wp + px) * a.coutp + co) = pm;
         }
       }
+      if (HEAD) {  // NCHW fp32: this lane holds head channels 4 kq + r of its tile's 2 x 2 pixels; a pixel pair (ox even) is one aligned 8-byte store when W is even
+        const bool pair_ok = (a.W & 1) == 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int o = 4 * kq + r;
+          if (o < a.head_cout) {
+            const float hb = a.head_b[o];
+#pragma unroll
+            for (int aa = 0; aa < 2; ++aa) {
+              if (oy + aa >= a.H || ox >= a.W) continue;
+              float v0 = hd[aa][0][r] + hb, v1 = hd[aa][1][r] + hb;
+              if (a.head_sigmoid) {
+                v0 = 1.f / (1.f + expf(-v0));
+                v1 = 1.f / (1.f + expf(-v1));
+              }
+              float* const hp = a.head_dst + (((size_t)b * a.head_cout + o) * a.H + oy + aa) * a.W + ox;
+              const bool two = ox + 1 < a.W;
+              if (two && pair_ok) {
+                typedef float f32x2_t __attribute__((ext_vector_type(2)));
+                f32x2_t v;
+                v[0] = v0;
+                v[1] = v1;
+                *reinterpret_cast<f32x2_t*>(hp) = v;
+              } else {
+                hp[0] = v0;
+                if (two) hp[1] = v1;
+              }
+            }
+          }
+        }
+      }
     }
     if (!has_next) break;
     vid = nvid;
@@ -278,8 +348,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_w16_kernel(ConvArgs a) {
 static int v_cu_count(int* out) { return device_cu_count(out); }
 
 int prepare_w16_kernels() {
-  const void* ks[4] = {reinterpret_cast<const void*>(conv3x3_w16_kernel<1, 1>), reinterpret_cast<const void*>(conv3x3_w16_kernel<2, 1>),
-                       reinterpret_cast<const void*>(conv3x3_w16_kernel<1, 2>), reinterpret_cast<const void*>(conv3x3_w16_kernel<2, 2>)};
+  const void* ks[10] = {reinterpret_cast<const void*>(conv3x3_w16_kernel<1, 1, false, true>), reinterpret_cast<const void*>(conv3x3_w16_kernel<2, 2, false, true>),
+                        reinterpret_cast<const void*>(conv3x3_w16_kernel<1, 1>), reinterpret_cast<const void*>(conv3x3_w16_kernel<2, 1>),
+                       reinterpret_cast<const void*>(conv3x3_w16_kernel<1, 2>), reinterpret_cast<const void*>(conv3x3_w16_kernel<2, 2>),
+                       reinterpret_cast<const void*>(conv3x3_w16_kernel<2, 1, true>), reinterpret_cast<const void*>(conv3x3_w16_kernel<3, 1, true>),
+                       reinterpret_cast<const void*>(conv3x3_w16_kernel<4, 1, true>), reinterpret_cast<const void*>(conv3x3_w16_kernel<2, 2, true>)};
   for (const void* k : ks) {
     const hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) {
@@ -290,22 +363,48 @@ int prepare_w16_kernels() {
   return PH_OK;
 }
 
+// chunk budget: the transformed weights stay resident in LDS next to the two 40-KiB halo buffers -- 16 KiB per chunk and N block of 16 channels
+bool w16_shape_ok(int c0p, int c1p, int coutp) {
+  if (coutp != 16 && coutp != 32) return false;
+  const int chunks = (c0p + c1p) / 16;
+  if (c1p == 0) return c0p == 16 || c0p == 32;
+  return (c0p % 16) == 0 && (c1p % 16) == 0 && c0p > 0 && chunks >= 2 && chunks <= (coutp == 16 ? 4 : 2);
+}
 bool w16_fits(const ConvArgs& a) {
   const uint64_t px = (uint64_t)a.B * a.H * a.W;
-  return a.wpack_w16 && (a.coutp == 32 || a.coutp == 16) && a.bn == 32 && !a.src1 && a.c1p == 0 && (a.c0p == 16 || a.c0p == 32) && !a.accumulate &&
-         px * (uint64_t)a.c0p * 4 < 0xFFFFFF00ull && px < 0x7FFFFFFFull;
+  return a.wpack_w16 && a.bn == 32 && w16_shape_ok(a.c0p, a.src1 ? a.c1p : 0, a.coutp) && (a.src1 != nullptr) == (a.c1p > 0) && !a.src1_lowres && !a.accumulate &&
+         px * (uint64_t)a.c0p * 4 < 0xFFFFFF00ull && px * (uint64_t)a.c1p * 4 < 0xFFFFFF00ull && px < 0x7FFFFFFFull;
+}
+
+// shapes whose 1x1 head can ride in the epilogue (the HEAD instantiations)
+bool w16_takes_head(const ConvArgs& a) {
+  return w16_fits(a) && !a.src1 && !a.dst_pool && !a.relu_mask_src && ((a.c0p == 16 && a.coutp == 16) || (a.c0p == 32 && a.coutp == 32));
 }
 
 int launch_conv3x3_w16(const ConvArgs& a, hipStream_t s) {
-  PH_REQUIRE(w16_fits(a), "w16: Cout 16 or 32 (one N tile), 16 or 32 input channels from one source, no accumulate, source below 4 GiB");
+  PH_REQUIRE(w16_fits(a), "w16: Cout 16 or 32 (one N tile), 16 or 32 input channels from one source or 2 - 4 chunks from two, no accumulate, sources below 4 GiB");
   int n_cu = 0;
   const int rc = v_cu_count(&n_cu);
   if (rc != PH_OK) return rc;
   const int tiles = ((a.W + V_TW - 1) / V_TW) * ((a.H + V_TH - 1) / V_TH) * a.B;
-  const int chunks = a.c0p / 16, nbs = a.coutp / 16;
+  const int chunks = (a.c0p + a.c1p) / 16, nbs = a.coutp / 16;
   const size_t ldsb = (size_t)(chunks * v_w_floats(nbs) + 2 * V_HALO_FLOATS) * sizeof(float);
   const dim3 grid(std::min(tiles, n_cu));
-  if (chunks == 1 && nbs == 1)
+  if (a.head_w) {
+    PH_REQUIRE(w16_takes_head(a) && a.head_cout >= 1 && a.head_cout <= 16 && a.head_wcp == a.coutp && a.head_b && a.head_dst, "w16: a fused head needs 16 -> 16 or 32 -> 32 channels from one source, no pool, and at most 16 head channels");
+    if (nbs == 1)
+      hipLaunchKernelGGL((conv3x3_w16_kernel<1, 1, false, true>), grid, dim3(512), ldsb, s, a);
+    else
+      hipLaunchKernelGGL((conv3x3_w16_kernel<2, 2, false, true>), grid, dim3(512), ldsb, s, a);
+  } else if (a.src1 && nbs == 2)
+    hipLaunchKernelGGL((conv3x3_w16_kernel<2, 2, true>), grid, dim3(512), ldsb, s, a);
+  else if (a.src1 && chunks == 2)
+    hipLaunchKernelGGL((conv3x3_w16_kernel<2, 1, true>), grid, dim3(512), ldsb, s, a);
+  else if (a.src1 && chunks == 3)
+    hipLaunchKernelGGL((conv3x3_w16_kernel<3, 1, true>), grid, dim3(512), ldsb, s, a);
+  else if (a.src1)
+    hipLaunchKernelGGL((conv3x3_w16_kernel<4, 1, true>), grid, dim3(512), ldsb, s, a);
+  else if (chunks == 1 && nbs == 1)
     hipLaunchKernelGGL((conv3x3_w16_kernel<1, 1>), grid, dim3(512), ldsb, s, a);
   else if (chunks == 2 && nbs == 1)
     hipLaunchKernelGGL((conv3x3_w16_kernel<2, 1>), grid, dim3(512), ldsb, s, a);

@@ -139,7 +139,11 @@ int launch_wino2d_pack(const float* wpack, float* wino, int panels, int bn, hipS
 // workgroups by round.  A separate instantiation: the second K-loop body and the rotation cost the common case 2 % (code size, scalar registers).
 // BWD: the backward's store options (accumulate into dst, the folded ReLU mask) are compiled in; the forward instantiations do not carry their branches
 // (~740 cycles per tile of a 64 -> 64 layer, stamp build).
-template <int BN, bool HT = false, bool BWD = false>
+// KS (split K, the small-batch regime): a work unit is (pixel tile, N tile, K slice) -- slice ks of a.ksplit covers halves [ks NH / ksplit, (ks + 1) NH / ksplit) of the NH = 2 nchunks
+// halves (both concat sources counted through) -- and its epilogue stores the slice's RAW partial sums (no bias, no ReLU, no pool, no head) to plane ks of a scratch tensor
+// [ksplit][B][H][W][coutp]; splitk_reduce_kernel then adds the planes in the fixed order 0, 1, ... and applies bias / ReLU / pool.  A layer whose (pixel tiles x N tiles) fill a
+// fraction of the CUs (cfg1: one 16 x 16 tile x 4 N tiles for 256 CUs, 32 - 48 serial halves of ~2 us) runs on ksplit times as many CUs with ksplit times shorter K loops.
+template <int BN, bool HT = false, bool BWD = false, bool KS = false>
 __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_kernel(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int NT = BN / 32;
@@ -155,7 +159,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_kernel(ConvArgs a) {
   const int tiles_y = (a.H + W2_T - 1) / W2_T;
   const int tiles = tiles_x * tiles_y * a.B;
   const int ntc = (a.coutp + BN - 1) / BN;
-  const int total = tiles * ntc;
+  const int units = tiles * ntc;
+  const int total = KS ? units * a.ksplit : units;
   const int chunks0 = a.c0p / 16;
   const int chunks1 = a.c1p / 16;
   const int nchunks = chunks0 + chunks1;
@@ -163,12 +168,20 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_kernel(ConvArgs a) {
 
   struct Plan {  // workgroup-uniform
     int b, x0, y0, ntile;
+    int ks, h0, nh;  // KS: K slice, its first half and its number of halves
   };
   // (a round = gridDim.x consecutive ids; it covers whole pixel tiles when its id count -- per XCD, where the dealing is XCD-aware -- is a multiple of ntc)
   const int G = (int)gridDim.x;
   const bool rotate = HT && ntc > 1 && (((tiles & 7) == 0) ? ((G & 7) == 0 && (G >> 3) % ntc == 0) : (G % ntc == 0));
   auto setup = [&](int vid, Plan& P) {
     int t, ntile;
+    if (KS) {
+      const int ks = vid / units, nh_all = 2 * nchunks;
+      vid -= ks * units;
+      P.ks = ks;
+      P.h0 = ks * nh_all / a.ksplit;
+      P.nh = (ks + 1) * nh_all / a.ksplit - P.h0;
+    }
     w2_deal_tile(vid, tiles, ntc, rotate ? vid / G : 0, &t, &ntile);
     const int tx = t % tiles_x;
     t /= tiles_x;
@@ -187,7 +200,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_kernel(ConvArgs a) {
   // offset rides in the scalar offset, so a half costs no vector instruction; out-of-image pixels (and the unused tail of a
   // plane) get an offset beyond the descriptor's range and the hardware returns zeros ("same" padding).
   unsigned fa_off[2];
-  int fa_soff = 0, fa_left = 0, fa_src = 0;
+  int fa_soff = 0, fa_left = 0, fa_src = 0, fa_rem1 = 0;
   bool fa_more = false;
   Plan FA;
   __amdgpu_buffer_rsrc_t fa_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.src0, 0, (int)((unsigned)(a.B * a.H * a.W) * (unsigned)(a.c0p * 4)), 0x00020000);
@@ -209,6 +222,23 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_kernel(ConvArgs a) {
   };
   auto a_enter_tile = [&](const Plan& Q) {
     FA = Q;
+    if (KS) {  // the slice starts in either source and may run over from the first into the second
+      const int n0 = 2 * chunks0, h1 = Q.h0 + Q.nh;
+      if (Q.h0 < n0) {
+        fa_src = 0;
+        fa_left = min(h1, n0) - Q.h0;
+        fa_rem1 = max(h1 - n0, 0);
+        a_point(a.src0, a.c0p);
+        fa_soff = Q.h0 * 32;
+      } else {
+        fa_src = 1;
+        fa_left = Q.nh;
+        fa_rem1 = 0;
+        a_point(a.src1, a.c1p);
+        fa_soff = (Q.h0 - n0) * 32;
+      }
+      return;
+    }
     fa_src = 0;
     fa_left = 2 * chunks0;
     a_point(a.src0, a.c0p);
@@ -216,9 +246,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_kernel(ConvArgs a) {
   auto a_advance = [&]() {  // scalar only
     fa_soff += 32;
     if (--fa_left == 0) {  // workgroup-uniform
-      if (fa_src == 0 && chunks1 > 0) {
+      if (fa_src == 0 && (KS ? fa_rem1 > 0 : chunks1 > 0)) {
         fa_src = 1;
-        fa_left = 2 * chunks1;
+        fa_left = KS ? fa_rem1 : 2 * chunks1;
         a_point(a.src1, a.c1p);
       } else if (fa_more) {
         fa_more = false;
@@ -239,8 +269,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_kernel(ConvArgs a) {
   bool fb_more = false;
   const unsigned fb_lane = (unsigned)(wave * 1024 + lane * 4) * 4u;
   auto b_enter_tile = [&](const Plan& Q) {
-    fb_soff = Q.ntile * nchunks * (2 * W2_BH_FLOATS * 4);
-    fb_left = 2 * nchunks;
+    fb_soff = Q.ntile * nchunks * (2 * W2_BH_FLOATS * 4) + (KS ? Q.h0 * (W2_BH_FLOATS * 4) : 0);
+    fb_left = KS ? Q.nh : 2 * nchunks;
   };
   auto b_advance = [&]() {
     fb_soff += W2_BH_FLOATS * 4;
@@ -468,6 +498,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_kernel(ConvArgs a) {
       for (int nu = 0; nu < 4; ++nu)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[nu][1][r] = 0.f;  // (the epilogue's arithmetic runs over both halves; its stores skip channels past coutp)
+    } else if (KS) {
+      const int nh = P.nh;
+      half(std::true_type{}, std::integral_constant<int, NT>{}, nh == 1);
+      for (int h = 1; h < nh; ++h) half(std::false_type{}, std::integral_constant<int, NT>{}, h + 1 == nh);
     } else {
       half(std::true_type{}, std::integral_constant<int, NT>{}, false);
       for (int h = 1; h < 2 * nchunks; ++h) half(std::false_type{}, std::integral_constant<int, NT>{}, h + 1 == 2 * nchunks);
@@ -493,7 +527,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_kernel(ConvArgs a) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         f32x4 bias = {0.f, 0.f, 0.f, 0.f};
-        if (xi == 1) bias = *reinterpret_cast<const f32x4*>(a.bias + ntile * BN + n * 32 + 8 * q + 4 * lh);
+        if (!KS && xi == 1) bias = *reinterpret_cast<const f32x4*>(a.bias + ntile * BN + n * 32 + 8 * q + 4 * lh);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int r = 4 * q + e;
@@ -672,6 +706,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_kernel(ConvArgs a) {
             const int co = ntile * BN + n * 32 + 8 * k + 4 * lh;
             if (!interior && co >= a.coutp) continue;
             float* dp = a.dst + ((size_t)(b * a.H + oy) * a.W + ox) * a.coutp + co;
+            if (KS) dp += (size_t)P.ks * a.split_stride;  // the K slice's plane of the scratch tensor
 #if PH_W2_STORE_EXP == 2  // diagnostic: perfectly coalesced (WRONG) addresses, 1 KiB contiguous per store instruction
             dp = a.dst + ((size_t)(b * a.H + y0) * a.W + x0) * a.coutp + (size_t)(wave * 16 + n * 8 + k * 2) * 256 + lane * 4;
 #endif
@@ -738,9 +773,104 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_kernel(ConvArgs a) {
 
 static int w2_cu_count(int* out) { return device_cu_count(out); }
 
+// Second stage of a split-K launch: dst = act(bias + (((p_0 + p_1) + p_2) + ...)) over the K slices' planes in slice order (bitwise repeatable), and the fused 2x2 max pool of
+// that result ("same" padding: zeros beyond the image, architectures/common.py:69-107).  POOL: one thread = one pool window x four channels; otherwise one pixel x four channels.
+// The planes' loads are independent (four slices in flight per pixel), only the additions are chained.
+__device__ __forceinline__ f32x4 splitk_sum(const float* __restrict__ p, size_t stride, int ks) {
+  f32x4 v = *reinterpret_cast<const f32x4*>(p);
+  int k = 1;
+  for (; k + 4 <= ks; k += 4) {
+    const f32x4 a0 = *reinterpret_cast<const f32x4*>(p + (size_t)k * stride), a1 = *reinterpret_cast<const f32x4*>(p + (size_t)(k + 1) * stride);
+    const f32x4 a2 = *reinterpret_cast<const f32x4*>(p + (size_t)(k + 2) * stride), a3 = *reinterpret_cast<const f32x4*>(p + (size_t)(k + 3) * stride);
+    v = (((v + a0) + a1) + a2) + a3;
+  }
+  for (; k < ks; ++k) v += *reinterpret_cast<const f32x4*>(p + (size_t)k * stride);
+  return v;
+}
+template <bool POOL>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, size_t stride, int ks, const float* __restrict__ bias, float* __restrict__ dst,
+                                                            float* __restrict__ dst_pool, int B, int H, int W, int coutp, int relu) {
+  const int cq = coutp >> 2;
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const int c4 = (int)(i % cq);
+  size_t r = i / cq;
+  const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + c4 * 4);
+  if (!POOL) {
+    if (r >= (size_t)B * H * W) return;
+    const size_t idx = r * coutp + c4 * 4;
+    f32x4 v = splitk_sum(part + idx, stride, ks) + bv;
+    if (relu) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+    }
+    *reinterpret_cast<f32x4*>(dst + idx) = v;
+    return;
+  }
+  const int Hp = (H + 1) >> 1, Wp = (W + 1) >> 1;
+  if (r >= (size_t)B * Hp * Wp) return;
+  const int px = (int)(r % Wp);
+  r /= Wp;
+  const int py = (int)(r % Hp), b = (int)(r / Hp);
+  f32x4 pooled = {0.f, 0.f, 0.f, 0.f};
+  bool first = true, padded = false;
+#pragma unroll
+  for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+    for (int dx = 0; dx < 2; ++dx) {
+      const int oy = 2 * py + dy, ox = 2 * px + dx;
+      if (oy >= H || ox >= W) {
+        padded = true;
+        continue;
+      }
+      const size_t idx = ((size_t)(b * H + oy) * W + ox) * coutp + c4 * 4;
+      f32x4 v = splitk_sum(part + idx, stride, ks) + bv;
+      if (relu) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+      }
+      if (dst) *reinterpret_cast<f32x4*>(dst + idx) = v;
+      if (first) {
+        pooled = v;
+        first = false;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pooled[e] = fmaxf(pooled[e], v[e]);
+      }
+    }
+  if (padded) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) pooled[e] = fmaxf(pooled[e], 0.f);
+  }
+  *reinterpret_cast<f32x4*>(dst_pool + ((size_t)(b * Hp + py) * Wp + px) * coutp + c4 * 4) = pooled;
+}
+
+// K slices a layer of this shape takes on the F(2x2,3x3) kernel (1 = no split).  splitk: the handle option "conv_splitk" -- 0 never, 1 where the layer's work units fill less than half
+// of the CUs and a slice keeps at least three halves (a unit costs ~8 us of prologue + epilogue + a ~4-us second stage against ~2 us per half), n >= 2 forces n slices (tests).
+int wino2d_ksplit_shape(int B, int H, int W, int cinp, int coutp, int splitk, int n_cu) {
+  if (splitk <= 0 || cinp < 32) return 1;
+  if ((coutp & 63) != 0 && (coutp & 63) <= 32) return 1;  // the half-empty-N-tile instantiation has no split form
+  const long units = (long)((W + W2_T - 1) / W2_T) * ((H + W2_T - 1) / W2_T) * B * ((coutp + 63) / 64);
+  const int nh = cinp / 8;
+  if (splitk >= 2) return std::max(1, std::min(splitk, nh));
+  if (units * 2 > n_cu || nh < 8) return 1;
+  return (int)std::max<long>(1, std::min<long>(n_cu / units, nh / 3));
+}
+int64_t wino2d_split_scratch_bytes(int B, int H, int W, int cinp, int coutp, int splitk, int n_cu) {
+  const int ks = wino2d_ksplit_shape(B, H, W, cinp, coutp, splitk, n_cu);
+  return ks > 1 ? (int64_t)ks * B * H * W * coutp * 4 : 0;
+}
+int wino2d_ksplit(const ConvArgs& a) {
+  if (!a.split_scratch || a.accumulate || a.relu_mask_src || a.head_w) return 1;
+  int n_cu = 0;
+  if (device_cu_count(&n_cu) != PH_OK || n_cu <= 0) return 1;
+  const int ks = wino2d_ksplit_shape(a.B, a.H, a.W, a.c0p + a.c1p, a.coutp, a.splitk, n_cu);
+  return (ks > 1 && (int64_t)ks * a.B * a.H * a.W * a.coutp * 4 <= a.split_scratch_bytes) ? ks : 1;
+}
+
 int prepare_wino2d_kernels() {
-  const void* ks[4] = {reinterpret_cast<const void*>(conv3x3_wino2d_kernel<64, false, false>), reinterpret_cast<const void*>(conv3x3_wino2d_kernel<64, true, false>),
-                       reinterpret_cast<const void*>(conv3x3_wino2d_kernel<64, false, true>), reinterpret_cast<const void*>(conv3x3_wino2d_kernel<64, true, true>)};
+  const void* ks[5] = {reinterpret_cast<const void*>(conv3x3_wino2d_kernel<64, false, false>), reinterpret_cast<const void*>(conv3x3_wino2d_kernel<64, true, false>),
+                       reinterpret_cast<const void*>(conv3x3_wino2d_kernel<64, false, true>), reinterpret_cast<const void*>(conv3x3_wino2d_kernel<64, true, true>),
+                       reinterpret_cast<const void*>(conv3x3_wino2d_kernel<64, false, false, true>)};
   hipError_t e = hipSuccess;
   for (const void* k : ks)
     if (e == hipSuccess) e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -765,8 +895,31 @@ int launch_conv3x3_wino2d(const ConvArgs& a, hipStream_t s) {
   const int tiles = ((a.W + W2_T - 1) / W2_T) * ((a.H + W2_T - 1) / W2_T) * a.B;
   const int ntc = (a.coutp + 63) / 64;
   const bool ht = (a.coutp & 63) != 0 && (a.coutp & 63) <= 32, bwd = a.accumulate || a.relu_mask_src;
-  const dim3 grid(std::min(tiles * ntc, n_cu));
   const size_t lds = (size_t)W2_LDS_FLOATS * sizeof(float);
+  const int ksplit = wino2d_ksplit(a);
+  if (ksplit > 1) {  // split K: raw partial sums per slice, then the fixed-order second stage (bias, ReLU, pool)
+    ConvArgs k = a;
+    k.dst = a.split_scratch;
+    k.relu = 0;
+    k.dst_pool = nullptr;
+    k.skip_dst = 0;
+    k.ksplit = ksplit;
+    k.split_stride = (long long)a.B * a.H * a.W * a.coutp;
+    hipLaunchKernelGGL((conv3x3_wino2d_kernel<64, false, false, true>), dim3(std::min(tiles * ntc * ksplit, n_cu)), dim3(512), lds, s, k);
+    PH_HIP_CHECK(hipGetLastError());
+    if (a.dst_pool) {
+      const size_t threads = (size_t)a.B * ((a.H + 1) / 2) * ((a.W + 1) / 2) * (a.coutp / 4);
+      hipLaunchKernelGGL(splitk_reduce_kernel<true>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, (const float*)a.split_scratch, (size_t)k.split_stride, ksplit, a.bias,
+                         a.skip_dst ? nullptr : a.dst, a.dst_pool, a.B, a.H, a.W, a.coutp, a.relu);
+    } else {
+      const size_t threads = (size_t)a.B * a.H * a.W * (a.coutp / 4);
+      hipLaunchKernelGGL(splitk_reduce_kernel<false>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, (const float*)a.split_scratch, (size_t)k.split_stride, ksplit, a.bias, a.dst,
+                         nullptr, a.B, a.H, a.W, a.coutp, a.relu);
+    }
+    PH_HIP_CHECK(hipGetLastError());
+    return PH_OK;
+  }
+  const dim3 grid(std::min(tiles * ntc, n_cu));
   if (ht && bwd)
     hipLaunchKernelGGL((conv3x3_wino2d_kernel<64, true, true>), grid, dim3(512), lds, s, a);
   else if (ht)

@@ -392,17 +392,14 @@ _CFG3_REF = {}
 @pytest.mark.parametrize("precision", ["exact", "split"])
 def test_cfg3_benched_workload_full_size_vs_oracle_and_batch_invariance(precision):
     """The workload bench.py times -- cfg3 network, bench.py's own weights (xavier seed 1234, heads x0.05), 1024x1024 uint8
-    frames -- under parity at FULL size: two frames against the oracle (confmaps / PAFs within 1e-4), and frame 0 of a
-    32-frame launch bit-identical to the same frame launched alone (persistent-workgroup tile walk, XCD dealing and
-    workspace offsets all change with the batch; the arithmetic per output must not)."""
+    frames -- under parity at FULL size with DEFAULT options at every per-rank batch the bench's scaling runs use (32 / 8 / 4 frames, and 2 / 1):
+    two frames against the oracle (confmaps / PAFs within 1e-4 and 1e-5 of the head's scale); then, with the kernel choice pinned to the list the
+    default 32-frame forward took, frame 0 of a 32-frame launch bit-identical to the same frame launched alone (persistent-workgroup tile walk, XCD
+    dealing and workspace offsets all change with the batch; the arithmetic per output must not).
     import bench
     from sleap_nn_amd.architectures.model import Model
 
     m = Model("unet", bench.CFG3_BB, bench.CFG3_HEADS, "bottomup").init_xavier_(seed=1234, head_scale=0.05).to(DEV).set_precision(precision)
-    # Which kernel runs a K-heavy layer depends on the number of tiles to deal over the CUs, i.e. on the batch (at one frame F(2x2,3x3) keeps the
-    # 64 x 64 level, at 32 frames F(4x4,3x3) takes it: wino4_fits): the bit-for-bit batch invariance below is a property of ONE kernel choice, so it is
-    # pinned here -- F(4x4,3x3) wherever the shape fits, what the 32-frame bench runs
-    m.set_option("conv_wino4", 3)
     sd = m.state_dict()
     g = torch.Generator().manual_seed(4321)
     frames = torch.randint(0, 256, (32, 1, bench.SIZE, bench.SIZE), dtype=torch.uint8, generator=g)
@@ -410,11 +407,31 @@ def test_cfg3_benched_workload_full_size_vs_oracle_and_batch_invariance(precisio
     if ref is None:
         ref = _CFG3_REF["ref"] = O.model_forward(sd, bench.CFG3_BB, bench.CFG3_HEADS, "bottomup", frames[:2])
     dev_frames = frames.to(DEV)
+    # (1) What bench.py runs: DEFAULT options.  Which kernel takes a layer depends on the number of work units to deal over the CUs, i.e. on the batch
+    # (wino4_fits: F(4x4,3x3) vs F(2x2,3x3) by rounds of the chip; wino2d_ksplit: K split over workgroups when a layer fills less than half of them), so every
+    # per-rank batch of the bench's scaling runs is put under parity with the routing IT takes: 32 frames (N = 1), 8 (4 GPUs), 4 (8 GPUs), and 2 / 1.
+    default_kernels = {}
+    for nb in (32, 8, 4, 2, 1):
+        out = m(dev_frames[:nb].contiguous())
+        default_kernels[nb] = m.last_kernels()
+        for k, v in ref.items():
+            _head_close(out[k][: min(nb, 2)], v[: min(nb, 2)], (k, nb))  # these heads are O(1e-3): relative bar as well
+            assert torch.isfinite(out[k]).all()
+    if precision == "exact":
+        from sleap_nn_amd import _lib as L
+
+        assert L.KV_WINO4 in default_kernels[32] and L.KV_WINO2D_KS not in default_kernels[32]
+        assert L.KV_WINO2D_KS in default_kernels[1]  # the one-frame launch is in the small-batch regime
+    # (2) Bit-for-bit batch invariance is a property of ONE kernel choice, so the choice is pinned -- F(4x4,3x3) wherever the shape fits and no split K:
+    # exactly the kernel list the default 32-frame forward took (asserted), i.e. the benched kernels are the ones compared bit by bit.
+    m.set_option("conv_wino4", 3)
+    m.set_option("conv_splitk", 0)
     out2 = {k: v.clone() for k, v in m(dev_frames[:2].contiguous()).items()}
     for k, v in ref.items():
-        _head_close(out2[k], v, k)  # these heads are O(1e-3): relative bar as well
+        _head_close(out2[k], v, k)
     one = {k: v.clone() for k, v in m(dev_frames[:1].contiguous()).items()}
     full = m(dev_frames)
+    assert m.last_kernels() == default_kernels[32], (m.last_kernels(), default_kernels[32])
     torch.cuda.synchronize()
     for k in one:
         assert torch.equal(full[k][:1], one[k]), k

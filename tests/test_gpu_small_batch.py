@@ -1,0 +1,201 @@
+"""GPU parity tests of the small-batch regime: BASELINE cfg1 (B = 1, 256 x 256), the reference's published workload (its fixture bottom-up run
+directory at 320 x 560, batch 4: docs/guides/inference-performance.md:40-48) and the split-K form of the F(2x2,3x3) kernel that serves layers
+with fewer (pixel tile, N tile) work units than CUs.  Same bars as tests/test_gpu_parity.py."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cpu_ref as O
+from sleap_nn_amd import _lib as L
+from tests import _golden as G
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+CMS_ATOL = 1e-4
+HEAD_RTOL = 1e-5
+
+SI_BB = {"in_channels": 1, "kernel_size": 3, "filters": 16, "filters_rate": 2, "max_stride": 16, "stem_stride": None, "middle_block": True, "up_interpolate": True,
+         "stacks": 1, "convs_per_block": 2, "output_stride": 2}
+
+
+def _close(got, ref, key=None, rtol=HEAD_RTOL):
+    err = (got.cpu() - ref).abs().max().item()
+    scale = ref.abs().max().item()
+    assert err <= CMS_ATOL * max(1.0, scale) and err <= rtol * scale, (key, err, scale)
+
+
+def test_cfg1_single_instance_256_batch1_network_and_global_peaks():
+    """BASELINE cfg1 exactly: single-instance UNet f16/r2/max_stride 16/output_stride 2, 256 x 256 gray, 5 keypoints, ONE frame -- the batch at which
+    every persistent kernel has fewer tiles than CUs and the K-heavy layers split K (default options: asserted from the kernel record).
+    Network vs the oracle (1e-4 and 1e-5 of the head's scale), global peaks of the network's own maps vs the oracle's on the same maps (bit-exact
+    values, 1e-4 px), a second identical launch bit-identical, and the same frame inside a batch of 3 within the relative bar."""
+    from sleap_nn_amd.architectures.model import Model
+    from sleap_nn_amd.inference.backends import HipBackend
+    from sleap_nn_amd.inference.layers import SingleInstanceLayer
+    from sleap_nn_amd.inference.preprocess_info import PreprocInfo
+
+    heads = {"confmaps": {"part_names": [f"k{i}" for i in range(5)], "sigma": 2.5, "output_stride": 2, "loss_weight": 1.0}}
+    sd = O.init_state(SI_BB, heads, "single_instance", seed=11, head_scale=1.0)
+    g = torch.Generator().manual_seed(5)
+    img = torch.randint(0, 256, (3, 1, 256, 256), dtype=torch.uint8, generator=g)
+    ref = O.model_forward(sd, SI_BB, heads, "single_instance", img[:1])["SingleInstanceConfmapsHead"]
+    m = Model("unet", SI_BB, heads, "single_instance")
+    m.load_state_dict(sd)
+    for use_graph in (False, True):
+        layer = SingleInstanceLayer(HipBackend(m, DEV, use_graph=use_graph), 2, max_stride=16)
+        raw = layer.backend(img[:1])["SingleInstanceConfmapsHead"]
+        assert tuple(raw.shape) == (1, 5, 128, 128)
+        _close(raw, ref, "cfg1")
+        first = raw.cpu().clone()
+        assert torch.equal(layer.backend(img[:1])["SingleInstanceConfmapsHead"].cpu(), first)  # run-to-run bitwise (fixed-order second stage)
+    codes = m.last_kernels()
+    assert L.KV_WINO2D_KS in codes, codes  # the default routing of this batch takes the split-K form somewhere
+    out = layer.postprocess({"SingleInstanceConfmapsHead": raw}, PreprocInfo(eff_scale=torch.ones(1), output_stride=2))
+    rk, rv = O.single_instance_postprocess(first, 2)
+    assert np.allclose(out.pred_keypoints.cpu().numpy(), rk.numpy(), atol=1e-4, equal_nan=True)
+    assert np.array_equal(out.pred_peak_values.cpu().numpy(), rv.numpy())
+    raw3 = layer.backend(img)["SingleInstanceConfmapsHead"]  # other routing (more tiles): same frame within the relative bar, all three vs the oracle
+    _close(raw3[:1], ref, "cfg1 in a batch of 3")
+    m.set_option("conv_splitk", 0)
+    one_stage = m(img[:1].to(DEV))["SingleInstanceConfmapsHead"].cpu()
+    assert L.KV_WINO2D_KS not in m.last_kernels()
+    _close(one_stage, ref, "cfg1, one-stage kernels")
+    assert (one_stage - first).abs().max().item() <= 2e-5 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("filters,max_stride,hw,batch,out_stride,splitk", [(32, 8, (32, 32), 1, None, 1), (32, 8, (32, 32), 1, None, 3), (32, 16, (64, 48), 2, 2, 1), (64, 8, (40, 24), 1, None, 5),
+                                                                           (32, 8, (40, 56), 1, 4, 2), (32, 16, (48, 80), 1, 2, 7), (16, 32, (64, 64), 1, 4, 1)])
+def test_split_k_winograd_kernel_matches_the_one_stage_kernel_and_the_oracle(filters, max_stride, hw, batch, out_stride, splitk):
+    """conv3x3_wino2d_kernel<.., KS> + splitk_reduce_kernel: K slices that start / end inside either concat source (decoder convs), one-half slices
+    (forced counts up to the number of halves), the fused pool with odd sizes and image-cut tiles through the second stage, auto routing (1) and
+    forced slice counts; against the oracle, against the one-stage kernel (conv_splitk = 0) to a few ulp of the tensor's scale, intermediate
+    activations included, and bitwise repeatable."""
+    from sleap_nn_amd.architectures.model import Model
+
+    os_ = out_stride or max_stride
+    bb = dict(SI_BB, filters=filters, max_stride=max_stride, output_stride=os_)
+    heads = {"confmaps": {"part_names": ["a", "b", "c"], "output_stride": os_}}
+    sd = O.init_state(bb, heads, "single_instance", seed=filters + hw[0] + splitk, head_scale=1.0)
+    g = torch.Generator().manual_seed(hw[1])
+    img = torch.randint(0, 256, (batch, 1, hw[0], hw[1]), dtype=torch.uint8, generator=g)
+    ref = O.model_forward(sd, bb, heads, "single_instance", img)["SingleInstanceConfmapsHead"]
+    outs, kinds = {}, {}
+    for name, ks in (("split", splitk), ("one", 0)):
+        m = Model("unet", bb, heads, "single_instance")
+        m.load_state_dict(sd)
+        m.set_option("conv_splitk", ks)
+        outs[name] = m.to(DEV)(img.to(DEV))["SingleInstanceConfmapsHead"].cpu()
+        kinds[name] = m.last_kernels()
+        if name == "split":
+            again = m(img.to(DEV))["SingleInstanceConfmapsHead"].cpu()
+            assert torch.equal(again, outs[name])
+    assert L.KV_WINO2D_KS in kinds["split"] and L.KV_WINO2D_KS not in kinds["one"], kinds
+    _close(outs["split"], ref, "split")
+    assert (outs["split"] - outs["one"]).abs().max().item() <= 2e-5 * ref.abs().max().item()
+
+
+def test_split_k_second_stage_pool_padding_and_unread_full_resolution_output():
+    """The second stage writes the fused 2x2 max pool with "same" zero padding on odd sizes (common.py:69-107) and honours skip_dst (an
+    inference plan whose full-resolution conv output nobody reads): a deep encoder on a 34 x 38 map, forced split, vs the oracle's activations."""
+    from sleap_nn_amd.architectures.model import Model
+
+    bb = dict(SI_BB, filters=32, max_stride=8, output_stride=8)
+    heads = {"confmaps": {"part_names": ["a", "b"], "output_stride": 8}}
+    sd = O.init_state(bb, heads, "single_instance", seed=3, head_scale=1.0)
+    img = torch.randint(0, 256, (2, 1, 136, 152), dtype=torch.uint8, generator=torch.Generator().manual_seed(8))
+    ref = O.model_forward(sd, bb, heads, "single_instance", img)["SingleInstanceConfmapsHead"]
+    for reuse in (0, 1):
+        m = Model("unet", bb, heads, "single_instance")
+        m.load_state_dict(sd)
+        m.set_option("conv_splitk", 4)
+        m.set_option("workspace_reuse", reuse)
+        got = m.to(DEV)(img.to(DEV))["SingleInstanceConfmapsHead"].cpu()
+        assert L.KV_WINO2D_KS in m.last_kernels()
+        _close(got, ref, f"reuse={reuse}")
+
+
+def test_published_workload_fixture_bottomup_batch4_320x560():
+    """The one workload the reference publishes numbers for (docs/guides/inference-performance.md:40-48,70-77): its fixture bottom-up run directory
+    (UNet f16 / rate 1.5 / max_stride 8, transposed-conv decoder, 2 nodes / 1 edge) at 320 x 560, batch 4 (predictor.py:884,930).  The fixture's weights are
+    pinned against the reference itself by ckpt_bottomup.npz at 384 x 384; here the same run directory at the published frame size and batch: network vs
+    the oracle, then peaks / grouping of the whole layer vs the oracle's post-process on the oracle's maps."""
+    from sleap_nn_amd.inference.backends import HipBackend
+    from sleap_nn_amd.inference.layers import BottomUpLayer, PostprocessConfig
+    from sleap_nn_amd.inference.loaders import load_model_assets
+    from sleap_nn_amd.inference.ops.paf import PAFScorer
+
+    a = load_model_assets(os.path.join(G.GOLDEN_DIR, "ckpt_dirs", "minimal_instance_bottomup"))
+    m = a.build_model()
+    z = G.load("ckpt_bottomup.npz")
+    frames = torch.from_numpy(z["image"]).squeeze(1)  # (2, 1, 384, 384) real frames of the fixture video
+    img = torch.cat([frames, frames.flip(-1)], 0)[:, :, 32:352, :].repeat(1, 1, 1, 2)[..., :560].contiguous()  # (4, 1, 320, 560) of real texture
+    assert tuple(img.shape) == (4, 1, 320, 560) and img.dtype == torch.uint8
+    sd = {(k[len("model."):] if k.startswith("model.") else k): v for k, v in a.state_dict.items()}  # LightningModule keys (loaders.py:144-176)
+    ref = O.model_forward(sd, a.backbone_config, a.head_config, "bottomup", img)
+    cs, ps = a.head_config["confmaps"]["output_stride"], a.head_config["pafs"]["output_stride"]
+    for use_graph in (False, True):
+        layer = BottomUpLayer(HipBackend(m, DEV, use_graph=use_graph), PAFScorer.from_config(a.head_config), cs, ps, max_stride=a.backbone_config["max_stride"],
+                              postprocess_config=PostprocessConfig(peak_threshold=0.2))
+        raw = layer.backend(img)
+        for k, v in ref.items():
+            err = (raw[k].cpu() - v).abs().max().item()
+            assert err <= CMS_ATOL, (k, err)
+        out = layer.predict(img)
+        rk, rv, rs = O.bottomup_postprocess(ref["MultiInstanceConfmapsHead"], ref["PartAffinityFieldsHead"],
+                                            O.PAFScorerRef(a.head_config["confmaps"]["part_names"], [tuple(e) for e in a.head_config["pafs"]["edges"]], ps), cs, peak_threshold=0.2)
+        k = out.pred_keypoints.numpy()
+        assert k.shape == rk.shape and np.array_equal(np.isnan(k), np.isnan(rk))
+        assert np.allclose(k, rk, atol=1e-3, equal_nan=True)
+        assert np.isfinite(k).any()  # real detections, not an all-NaN agreement
+
+
+@pytest.mark.parametrize("filters,max_stride,hw,batch,out_stride", [(16, 4, (64, 96), 2, 1), (16, 8, (72, 40), 1, 1), (8, 8, (64, 48), 1, 2), (8, 4, (64, 80), 3, 2)])
+def test_wave_private_kernel_takes_the_two_source_decoder_conv(filters, max_stride, hw, batch, out_stride):
+    """conv3x3_w16_kernel<CHUNKS, 1, TWO>: the full-resolution decoder level of an output-stride-1 filters-16 UNet -- concat(skip 16, up-sampled 32) -> 16 channels --
+    and the last level of a filters-8 one (16 + 32 -> 16 at half resolution) as two K panels with their own descriptors; image-cut tiles, several tiles per workgroup;
+    vs the oracle and vs the F(2,3) kernel the layer ran on before (conv_w16 = 0)."""
+    from sleap_nn_amd.architectures.model import Model
+
+    bb = dict(SI_BB, filters=filters, max_stride=max_stride, output_stride=out_stride)
+    heads = {"confmaps": {"part_names": ["a", "b", "c"], "output_stride": out_stride}}
+    sd = O.init_state(bb, heads, "single_instance", seed=filters + hw[0], head_scale=1.0)
+    img = torch.randint(0, 256, (batch, 1, hw[0], hw[1]), dtype=torch.uint8, generator=torch.Generator().manual_seed(hw[1]))
+    ref = O.model_forward(sd, bb, heads, "single_instance", img)["SingleInstanceConfmapsHead"]
+    outs = {}
+    for name, w16 in (("w16", 1), ("w1d", 0)):
+        m = Model("unet", bb, heads, "single_instance")
+        m.load_state_dict(sd)
+        m.set_option("conv_w16", w16)
+        outs[name] = m.to(DEV)(img.to(DEV))["SingleInstanceConfmapsHead"].cpu()
+        codes, tab = m.last_kernels(), m.op_table(batch, hw[0], hw[1])
+        last_concat = [c for r, c in zip(tab, codes) if "refine_conv0" in r["label"]][-1]
+        assert (last_concat == L.KV_W16) == bool(w16), (name, last_concat)
+    _close(outs["w16"], ref, "two-source w16")
+    assert (outs["w16"] - outs["w1d"]).abs().max().item() <= 2e-5 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("filters,out_stride,hw,batch,nodes", [(16, 2, (64, 96), 2, 5), (16, 2, (72, 128), 1, 13), (16, 1, (32, 64), 2, 3), (8, 2, (80, 64), 1, 16), (16, 2, (64, 64), 1, 17)])
+def test_head_fused_into_the_wave_private_kernel_matches_the_head_kernel_and_the_oracle(filters, out_stride, hw, batch, nodes):
+    """conv3x3_w16_kernel<.., HEAD>: the 1x1 head behind the final 32 -> 32 (output stride 2) or 16 -> 16 (output stride 1, filters 8) conv as MFMAs on the epilogue's registers;
+    image-cut tiles, 16 head channels (the limit) and 17 (not fused: the head kernel runs); head_fuse = 0 is the separate launch."""
+    from sleap_nn_amd.architectures.model import Model
+
+    bb = dict(SI_BB, filters=filters, max_stride=4, output_stride=out_stride)
+    heads = {"confmaps": {"part_names": [f"n{i}" for i in range(nodes)], "output_stride": out_stride}}
+    sd = O.init_state(bb, heads, "single_instance", seed=nodes, head_scale=1.0)
+    img = torch.randint(0, 256, (batch, 1, hw[0], hw[1]), dtype=torch.uint8, generator=torch.Generator().manual_seed(hw[0]))
+    ref = O.model_forward(sd, bb, heads, "single_instance", img)["SingleInstanceConfmapsHead"]
+    outs = {}
+    for fuse in (1, 0):
+        m = Model("unet", bb, heads, "single_instance")
+        m.load_state_dict(sd)
+        m.set_option("head_fuse", fuse)
+        m.eval()
+        outs[fuse] = m.to(DEV)(img.to(DEV))["SingleInstanceConfmapsHead"].cpu()
+        head_codes = [c for r, c in zip(m.op_table(batch, hw[0], hw[1]), m.last_kernels()) if r["kind"] == L.OP_HEAD]
+        assert head_codes == [L.KV_FUSED if (fuse and nodes <= 16) else L.KV_NONE], (fuse, head_codes)  # a fused head's op launches nothing
+    _close(outs[1], ref, "fused head")
+    assert (outs[1] - outs[0]).abs().max().item() <= 2e-5 * ref.abs().max().item()
