@@ -395,7 +395,7 @@ def test_cfg3_benched_workload_full_size_vs_oracle_and_batch_invariance(precisio
     frames -- under parity at FULL size with DEFAULT options at every per-rank batch the bench's scaling runs use (32 / 8 / 4 frames, and 2 / 1):
     two frames against the oracle (confmaps / PAFs within 1e-4 and 1e-5 of the head's scale); then, with the kernel choice pinned to the list the
     default 32-frame forward took, frame 0 of a 32-frame launch bit-identical to the same frame launched alone (persistent-workgroup tile walk, XCD
-    dealing and workspace offsets all change with the batch; the arithmetic per output must not).
+    dealing and workspace offsets all change with the batch; the arithmetic per output must not)."""
     import bench
     from sleap_nn_amd.architectures.model import Model
 
