@@ -201,6 +201,7 @@ def main():
                          "`weak_scaling`), weak at N = 1 (the same thing there)")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the train_cfg3 / train_cfg4 / infer_cfg4 legs of the default N = 1 run")
     ap.add_argument("--leg-steps", type=int, default=6, help="timed steps of each extra leg")
+    ap.add_argument("--small-legs-only", action="store_true", help="print only the small-batch legs (infer_cfg1 / infer_cfg2 / published_workload) as one JSON object: a development shortcut, not the bench line")
     ap.add_argument("--mode", choices=["infer", "train"], default="infer")
     ap.add_argument("--train-config", choices=["cfg3", "cfg4"], default="cfg3")
     ap.add_argument("--dtype", choices=["f32", "f16x3", "f16"], default="f32",
@@ -245,6 +246,9 @@ def main():
         # ranks share the host: keep torch's CPU pool (synthetic-input rendering only) to a fair share
         torch.set_num_threads(max(1, (os.cpu_count() or world) // world))
     ctx = {"rank": rank, "world": world, "dev": dev, "dist": dist}
+    if args.small_legs_only:
+        print(json.dumps(small_batch_legs(args, ctx)))
+        return
     res = run_train(args, ctx) if args.mode == "train" else run_infer(args, ctx)
     if rank == 0:
         if args.rehearse_on_one_gpu:
@@ -427,6 +431,29 @@ def run_infer(args, ctx):
                        "accumulation (22-bit products; parity tests hold it to the same 1e-4 bar as the exact path); f16_autocast = the reference's autocast mode "
                        "(tolerance 5e-3).  Not part of `value`.")
 
+    # ---- N = 1 default run: the per-rank batches of the strong-scaling runs (global batch 32 over 8 / 4 GPUs = 4 / 8 frames per rank), measured on this one GPU with the
+    # same pipelined step -- what one rank of the driver's SCALE run does per step, without the other ranks
+    shards = {}
+    if world == 1 and precision == "exact" and not args.no_extra_legs and args.scaling_defaulted and B >= 8:
+        for sb in (8, 4):
+            scms, spafs = rendered_heads(sb, dev)
+            heads_in.update(cms=scms, pafs=spafs, info=PreprocInfo(original_size=(SIZE, SIZE), processed_size=(SIZE, SIZE), eff_scale=torch.ones(sb), output_stride=4))
+            sframes = frames[:sb].contiguous()
+            for _ in range(5):
+                step(sframes)
+            drain()
+            torch.cuda.synchronize()
+            n_s = max(args.steps, 50)
+            t1 = time.perf_counter()
+            for _ in range(n_s):
+                step(sframes)
+            drain()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t1
+            shards[f"{sb}_frames_per_rank"] = {"value": sb * n_s / dt, "unit": "frames/s per GPU", "ms_per_step": 1e3 * dt / n_s, "steps": n_s, "stands_for": f"one rank of --gpus {32 // sb} --scaling strong"}
+        heads_in.update(cms=cms, pafs=pafs, info=info)
+        del scms, spafs, sframes
+
     t = torch.tensor([elapsed, elapsed_h2d or 0.0, elapsed_weak or 0.0], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -544,6 +571,9 @@ def run_infer(args, ctx):
                                "note": "same launch, --batch frames per GPU per step (per-GPU work fixed as N grows); `value` above is the strong-scaling figure"}
     if alt:
         res["alt_precisions"] = alt
+    if shards:
+        shards["note"] = "one-GPU measurements of the per-rank batches the strong-scaling runs use (no other ranks, no barrier): not a scaling curve"
+        res["strong_scaling_shards"] = shards
     if elapsed_h2d is not None:
         res["h2d_inclusive"] = {"value": frames_total / elapsed_h2d, "unit": "frames/s", "ms_per_step": 1e3 * elapsed_h2d / args.steps,
                                 "note": "same steps, uint8 frames start in pinned host memory; async H2D on a copy stream, double-buffered under the previous step"}
@@ -553,6 +583,7 @@ def run_infer(args, ctx):
         del backend, eager, layer, model, frames, cms, pafs
         heads_in.clear()
         res.update(extra_legs(args, ctx))
+        res.update(small_batch_legs(args, ctx))
     return res
 
 
@@ -769,6 +800,182 @@ def infer_cfg4_leg(model, B, steps, warmup, dev):
                      "direct_equivalent_tflops": fwd_flops / per_step / 1e12, "executed_gflop_per_forward": executed / 1e9, "direct_gflop_per_forward": fwd_flops / 1e9,
                      "matrix_ms_per_forward": matrix_ms, "forward_ms": sum(op_ms) / max(n_fw, 1), "by_op_kind": groups},
     }
+
+
+SI_BB = {"in_channels": 1, "kernel_size": 3, "filters": 16, "filters_rate": 2, "max_stride": 16, "stem_stride": None, "middle_block": True, "up_interpolate": True,
+         "stacks": 1, "convs_per_block": 2, "output_stride": 2}
+# docs/guides/inference-performance.md:40-48,70-77: the only numbers the reference publishes, NVIDIA A40 / CUDA 12.8 / torch 2.9.1
+PUBLISHED_A40 = {"bottomup_forward_ms_per_batch4": {"eager_fp32": 3.59, "torch_compile": 2.94, "fp16_autocast": 2.32}, "bottomup_end_to_end_fps": 137.0}
+
+
+def _forward_profile(model, x, n=10):
+    """Per-op HIP-event pass of the eager forward: (op table, per-op ms, kernel codes, executed / direct matrix FLOPs, matrix ms)."""
+    from sleap_nn_amd import _lib as L
+
+    for _ in range(3):
+        model(x)
+    torch.cuda.synchronize()
+    model.set_profiling(True)
+    for _ in range(n):
+        model(x)
+    torch.cuda.synchronize()
+    op_ms, n_fw = model.read_profile()
+    model.set_profiling(False)
+    codes = model.last_kernels()
+    B, _, H, W = x.shape
+    table = model.op_table(B, H, W)
+    op_ms = [t / max(n_fw, 1) for t in op_ms]
+    executed = forward_executed_flops(table, codes)
+    direct = sum(r["flops"] for r in table)
+    matrix_ms = sum(t for r, t in zip(table, op_ms) if r["kind"] in (L.OP_CONV, L.OP_STEM, L.OP_CONVT) and t > 0)
+    kernels = {}
+    for r, t, c in zip(table, op_ms, codes):
+        if c != L.KV_NONE and c != L.KV_FUSED:
+            e = kernels.setdefault(L.KV_NAMES[c].split(" (")[0], {"launches": 0, "ms": 0.0})
+            e["launches"] += 1
+            e["ms"] += t
+    return table, op_ms, codes, executed, direct, matrix_ms, kernels
+
+
+def _small_roofline(executed, direct, matrix_ms, fwd_s, kernels, n_ops):
+    return {"bound": "mfma", "kernel": "whole conv stack of the forward (F(2x2,3x3) kernels incl. their split-K form, wave-private kernel, fused stem): at these sizes every layer has fewer work units than the "
+                                       "256 CUs, the launches are latency-bound and the figure says how far from the matrix pipe that leaves them",
+            "achieved": executed / fwd_s / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": executed / fwd_s / 1e12 / MFMA_F32_PEAK_TFLOPS,
+            "flop_accounting": "achieved = FLOPs the MFMA pipe executes in one forward (launches priced by the kernel family the library reports) / the forward's wall time (hipGraph replay, back to back); "
+                               "direct_equivalent_tflops = direct-convolution FLOPs / the same time",
+            "direct_equivalent_tflops": direct / fwd_s / 1e12, "executed_gflop_per_forward": executed / 1e9, "direct_gflop_per_forward": direct / 1e9,
+            "matrix_launch_ms_per_forward_with_events": matrix_ms, "ops_per_forward": n_ops, "kernels": kernels, "traffic": None}
+
+
+def _time_calls(fn, steps, warmup, sync_each):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    ts = []
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        t = time.perf_counter()
+        fn()
+        if sync_each:
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t)
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0, ts
+
+
+def single_instance_leg(name, size, batch, n_nodes, steps, dev, with_cpu):
+    """BASELINE cfg1 / cfg2: single-instance UNet f16/r2/max_stride 16/output_stride 2.  A step = uint8 frames (resident in HBM) -> forward (one hipGraph replay) -> global peaks +
+    integral refinement -> D2H of the keypoints.  cfg1 (one frame) is a latency workload: median / p90 of the synchronous per-frame time; cfg2 (8 frames) a throughput one."""
+    from sleap_nn_amd.architectures.model import Model
+    from sleap_nn_amd.inference.backends import HipBackend
+    from sleap_nn_amd.inference.layers import PostprocessConfig, SingleInstanceLayer
+
+    heads = {"confmaps": {"part_names": [f"k{i}" for i in range(n_nodes)], "sigma": 2.5, "output_stride": 2, "loss_weight": 1.0}}
+    model = Model("unet", SI_BB, heads, "single_instance").init_xavier_(seed=1234, head_scale=0.05).to(dev)
+    g = torch.Generator().manual_seed(4321)
+    frames = torch.randint(0, 256, (batch, 1, size, size), dtype=torch.uint8, generator=g).to(dev)
+    table, op_ms, codes, executed, direct, matrix_ms, kernels = _forward_profile(model, frames)
+    backend = HipBackend(model, str(dev), use_graph=True)
+    layer = SingleInstanceLayer(backend, 2, max_stride=16, postprocess_config=PostprocessConfig(peak_threshold=0.0))
+    x5 = frames.unsqueeze(1)
+    fwd_total, _ = _time_calls(lambda: backend(x5), max(steps, 200), 20, False)
+    fwd_s = fwd_total / max(steps, 200)
+    total, lat = _time_calls(lambda: layer.predict(frames), steps, 10, True)
+    lat_us = sorted(1e6 * t for t in lat)
+    res = {"metric": f"frames/sec single-instance UNet {size}x{size} inference (batch {batch})", "value": batch * steps / total, "unit": "frames/s", "steps": steps, "ms_per_step": 1e3 * total / steps,
+           "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"{name}: single-instance UNet f16/r2/max_stride16/output_stride2, {size}x{size}x1 uint8 frames, {n_nodes} keypoints, batch {batch}", "frames_per_step": batch,
+                      "weights": "xavier-uniform seed 1234, head x0.05", "params": model.num_parameters(), "step": "forward (hipGraph replay) + global peaks + integral refinement + D2H, synchronous per step",
+                      "inputs": "uint8 frames resident in HBM"},
+           "latency_us_per_step": {"median": lat_us[len(lat_us) // 2], "p10": lat_us[len(lat_us) // 10], "p90": lat_us[(9 * len(lat_us)) // 10]},
+           "forward_only": {"us_per_batch": 1e6 * fwd_s, "frames_per_s": batch / fwd_s, "launch": "hipGraph replay, back to back, no host sync"},
+           "roofline": _small_roofline(executed, direct, matrix_ms, fwd_s, kernels, len(table))}
+    if with_cpu:  # cfg1 IS the reference-CPU-path configuration of BASELINE.json: the oracle on this box's host cores, same weights, same frame, parity beside it
+        from oracle import cpu_ref as O
+
+        sd = model.state_dict()
+        img = frames[:1].cpu()
+        avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        out = {}
+        for th in sorted({1, min(avail, 8), min(avail, 16)}):
+            torch.set_num_threads(th)
+            with torch.inference_mode():
+                O.model_forward(sd, SI_BB, heads, "single_instance", img)
+                n, t0 = 0, time.perf_counter()
+                while n < 3 or (time.perf_counter() - t0 < 2.5 and n < 200):
+                    ref = O.model_forward(sd, SI_BB, heads, "single_instance", img)
+                    rk, rv = O.single_instance_postprocess(ref["SingleInstanceConfmapsHead"], 2)
+                    n += 1
+                out[th] = (time.perf_counter() - t0) / n
+        best = min(out, key=out.get)
+        torch.set_num_threads(avail)
+        got = model(frames[:1])["SingleInstanceConfmapsHead"].cpu()
+        res["cpu_baseline"] = {"value": 1.0 / out[best], "unit": "frames/s", "cores": best, "kind": "port", "value_1thread": 1.0 / out[1], "ms_per_frame_by_threads": {str(k): 1e3 * v for k, v in out.items()},
+                               "sample": "oracle/cpu_ref.py forward + global peaks of one 256x256 frame, ~2.5 s per thread count, torch-CPU fp32",
+                               "parity_on_this_sample": {"max_abs_confmap_diff": float((got - ref["SingleInstanceConfmapsHead"]).abs().max()), "confmap_abs_max": float(ref["SingleInstanceConfmapsHead"].abs().max())}}
+    return res
+
+
+def published_workload_leg(steps, dev):
+    """The one workload the reference publishes numbers for (docs/guides/inference-performance.md:40-48,70-77, an NVIDIA A40): its fixture bottom-up run directory (tests/golden/ckpt_dirs:
+    UNet f16 / rate 1.5 / max_stride 8, transposed-conv decoder, 2 nodes / 1 edge) at 320 x 560, batch 4 (predictor.py:884,930).  Backbone-level forward per batch (their table 1) in exact fp32
+    and in the autocast-equivalent fp16 mode, and end-to-end frames/s of Predictor.predict over 100 frames (their table 2; theirs includes video decoding, ours starts from uint8 frames in host memory)."""
+    from sleap_nn_amd.inference.backends import HipBackend
+    from sleap_nn_amd.inference.loaders import load_model_assets
+    from sleap_nn_amd.inference.predictor import Predictor
+
+    root = os.path.join(ROOT, "tests", "golden", "ckpt_dirs", "minimal_instance_bottomup")
+    model = load_model_assets(root).build_model().to(dev)
+    g = torch.Generator().manual_seed(4321)
+    frames = torch.randint(0, 256, (4, 1, 320, 560), dtype=torch.uint8, generator=g).to(dev)
+    table, op_ms, codes, executed, direct, matrix_ms, kernels = _forward_profile(model, frames)
+    fwd = {}
+    for tag, kw in (("exact_fp32", {}), ("fp16_autocast_equivalent", {"use_fp16": True})):
+        backend = HipBackend(model, str(dev), use_graph=True, **kw)
+        x5 = frames.unsqueeze(1)
+        n = max(steps, 200)
+        total, _ = _time_calls(lambda: backend(x5), n, 20, False)
+        fwd[tag] = 1e3 * total / n
+    model.set_precision("exact")
+    fwd_s = fwd["exact_fp32"] * 1e-3
+    # end to end: Predictor on 100 host frames (real texture: the fixture video's two golden frames tiled to 320 x 560), batch 4
+    z = np.load(os.path.join(ROOT, "tests", "golden", "ckpt_bottomup.npz"), allow_pickle=False)
+    two = torch.from_numpy(z["image"]).squeeze(1)
+    vid = torch.cat([two, two.flip(-1)], 0)[:, :, 32:352, :].repeat(25, 1, 1, 2)[..., :560].contiguous()  # (100, 1, 320, 560) uint8, host
+    pred = Predictor.from_model_paths([root], device=str(dev), batch_size=4, peak_threshold=0.2)
+    pred.predict(vid[:16])
+    torch.cuda.synchronize()
+    reps, t0 = 5, time.perf_counter()
+    n_inst = 0
+    for _ in range(reps):
+        outs = pred.predict(vid)
+        n_inst = sum(int((~torch.isnan(o.instance_scores)).sum()) for o in outs)
+    e2e = reps * vid.shape[0] / (time.perf_counter() - t0)
+    ref = PUBLISHED_A40
+    return {"metric": "ms per batch of 4, bottom-up backbone forward (the reference's published table)", "value": fwd["exact_fp32"], "unit": "ms/batch", "higher_is_better": False, "steps": max(steps, 200),
+            "dtype": "f32", "data": "reference fixture checkpoint (tests/golden/ckpt_dirs/minimal_instance_bottomup), synthetic uint8 frames",
+            "config": {"workload": "published: fixture bottom-up UNet (f16, rate 1.5, max_stride 8, transposed-conv decoder, 2 nodes / 1 edge), 320x560x1 uint8, batch 4", "frames_per_step": 4,
+                       "params": model.num_parameters(), "forward_launch": "hipGraph replay, back to back"},
+            "forward_ms_per_batch": fwd, "frames_per_s_forward": 4.0 / fwd_s,
+            "end_to_end": {"value": e2e, "unit": "frames/s", "frames": int(vid.shape[0]), "repeats": reps, "instances_found_per_pass": n_inst,
+                           "what": "Predictor.predict (pipelined: H2D, forward, peaks, PAF scoring, D2H, C++ grouping) over 100 uint8 frames in host memory, batch 4, exact fp32"},
+            "vs_baseline": {"forward_eager_fp32": ref["bottomup_forward_ms_per_batch4"]["eager_fp32"] / fwd["exact_fp32"], "forward_fp16": ref["bottomup_forward_ms_per_batch4"]["fp16_autocast"] / fwd["fp16_autocast_equivalent"],
+                            "end_to_end_fps": e2e / ref["bottomup_end_to_end_fps"], "reference": ref, "reference_hardware": "NVIDIA A40, CUDA 12.8, torch 2.9.1 (docs/guides/inference-performance.md:3-7,40-48,70-77)",
+                            "note": "ratios > 1 = this build faster; different hardware and (end to end) no video decoding here: a like-for-like of the workload, not of the machine"},
+            "roofline": _small_roofline(executed, direct, matrix_ms, fwd_s, kernels, len(table))}
+
+
+def small_batch_legs(args, ctx):
+    """infer_cfg1 / infer_cfg2 / published_workload of the default N = 1 line (the small-batch regime, driver-timed)."""
+    dev = ctx["dev"]
+    out = {}
+    torch.cuda.empty_cache()
+    out["infer_cfg1"] = single_instance_leg("cfg1", 256, 1, 5, 400, dev, with_cpu=not args.no_cpu_baseline)
+    out["infer_cfg2"] = single_instance_leg("cfg2", 512, 8, 13, 200, dev, with_cpu=False)
+    torch.cuda.empty_cache()
+    out["published_workload"] = published_workload_leg(200, dev)
+    torch.cuda.empty_cache()
+    return out
 
 
 def extra_legs(args, ctx):
