@@ -431,6 +431,22 @@ def run_infer(args, ctx):
                        "accumulation (22-bit products; parity tests hold it to the same 1e-4 bar as the exact path); f16_autocast = the reference's autocast mode "
                        "(tolerance 5e-3).  Not part of `value`.")
 
+    # ---- the local-maxima kernels on their own (north_star's "wavefront-reduction local-maxima kernel ... HBM GB/s"): HIP events around the two launches, on the step's rendered maps
+    peaks_us = None
+    if rank == 0:
+        from sleap_nn_amd.inference.ops.peaks import find_local_peaks_device
+
+        pc = layer.postprocess_config
+        for _ in range(5):
+            find_local_peaks_device(cms, pc.peak_threshold, pc.effective_refinement, pc.integral_patch_size, 4096, xy_scale=4.0)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(50):
+            find_local_peaks_device(cms, pc.peak_threshold, pc.effective_refinement, pc.integral_patch_size, 4096, xy_scale=4.0)
+        e1.record()
+        torch.cuda.synchronize()
+        peaks_us = 1e3 * e0.elapsed_time(e1) / 50
+
     # ---- N = 1 default run: the per-rank batches of the strong-scaling runs (global batch 32 over 8 / 4 GPUs = 4 / 8 frames per rank), measured on this one GPU with the
     # same pipelined step -- what one rank of the driver's SCALE run does per step, without the other ranks
     shards = {}
@@ -565,6 +581,12 @@ def run_infer(args, ctx):
             "profiled_forwards": n_fw,
         },
     }
+    if peaks_us is not None:
+        cm_bytes = float(cms.numel() * 4)
+        res["roofline_postprocess"] = {"bound": "hbm", "kernel": "peaks_onepass_kernel<1> + peaks_place_kernel (find_local_peaks: 3x3 strict NMS, threshold, ordered compaction, integral refinement)",
+                                       "achieved": cm_bytes / (peaks_us * 1e-6) / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": cm_bytes / (peaks_us * 1e-6) / 1e9 / 8000.0,
+                                       "algorithmic_bytes": cm_bytes, "us_per_batch": peaks_us, "launches": 2, "traffic": None,
+                                       "byte_accounting": "algorithmic bytes = the confidence maps read once (B x 13 x 256 x 256 fp32); time = HIP events around 50 back-to-back calls (both launches + the output allocation of the wrapper)"}
     if elapsed_weak is not None:
         res["weak_scaling"] = {"value": weak_B * world * args.steps / elapsed_weak, "unit": "frames/s", "ms_per_step": 1e3 * elapsed_weak / args.steps,
                                "frames_per_gpu_per_step": weak_B, "global_batch": weak_B * world,

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define PH_VERSION 103
+#define PH_VERSION 104
 
 /* error codes */
 #define PH_OK 0
@@ -275,11 +275,15 @@ int ph_model_read_slot(ph_model* m, int32_t slot, float* out_dev, int64_t out_nu
  *   [1+B+b] = exclusive offset of sample b (b = 0..B, last entry = total).
  * xy_scale: out_xy = refined (x, y) * xy_scale in one fp32 multiply -- 1 for find_local_peaks itself, the confidence
  *   maps' output stride for callers that go on in image coordinates (`peaks * cms_output_stride`, layers/bottomup.py:111).
- * scratch_dev: >= 4*(B*H + 1 + B) bytes. */
+ * scratch_dev: >= 4*(2*B*H + 2) bytes runs the three-pass kernels (count rows, scan, emit: the maps are read twice); with
+ *   ph_local_peaks_scratch_bytes(B, C, H, W) bytes the maps are read ONCE (one block per sample and eight rows finds, refines and stages its peaks in order;
+ *   a placement pass over the staged peaks puts them at their final offsets) -- same outputs bit for bit, two launches, no atomics. */
 int ph_local_peaks(const float* cms_dev, int32_t B, int32_t C, int32_t H, int32_t W,
                    float threshold, int32_t refine, int32_t patch, float* out_xy, float* out_val,
                    int32_t* out_sample, int32_t* out_channel, int32_t* out_count, int32_t cap,
                    float xy_scale, void* scratch_dev, int64_t scratch_bytes, void* stream);
+
+int64_t ph_local_peaks_scratch_bytes(int32_t B, int32_t C, int32_t H, int32_t W);
 
 /* Global peak per (sample, channel): value = max; x = first column containing the max,
  * y = first row containing the max (independent, as the reference); below `threshold`

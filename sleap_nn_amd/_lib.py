@@ -46,6 +46,7 @@ _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 SIGNATURES = {
     "ph_last_error": (C.c_char_p, []),
     "ph_version": (C.c_int, []),
+    "ph_local_peaks_scratch_bytes": (_i64, [_i32, _i32, _i32, _i32]),
     "ph_op_desc_size": (_i32, []),
     "ph_model_set_option": (C.c_int, [_vp, C.c_char_p, C.c_double]),
     "ph_model_get_option": (C.c_int, [_vp, C.c_char_p, C.POINTER(C.c_double)]),

@@ -61,8 +61,39 @@ __device__ __forceinline__ bool is_local_peak(const float* __restrict__ plane, i
   return ok;
 }
 
-// first moments over a patch x patch zero padded window centred on the integer peak
+// first moments over a patch x patch zero padded window centred on the integer peak.  PATCH > 0: compile-time size -- the window's loads are issued together (independent
+// addresses) and only the sums are chained, in the same (row, column) order as the run-time loop: same bits, one memory latency instead of patch^2 of them (the loop form
+// cost ~25 us per peak under load and set the time of the whole peak kernel).
+template <int PATCH>
+__device__ __forceinline__ void integral_offset_fixed(const float* __restrict__ plane, int H, int W, int px, int py, float* dx, float* dy) {
+  constexpr int half = PATCH / 2;
+  const float tlx = (float)px - (PATCH - 1) * 0.5f, tly = (float)py - (PATCH - 1) * 0.5f;
+  const int x0 = (int)(tlx + half) - half, y0 = (int)(tly + half) - half;
+  const float g0 = -(PATCH - 1) * 0.5f;
+  float w[PATCH][PATCH];
+#pragma unroll
+  for (int j = 0; j < PATCH; ++j)
+#pragma unroll
+    for (int i = 0; i < PATCH; ++i) {
+      const int yy = y0 + j, xx = x0 + i;
+      w[j][i] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? plane[(size_t)yy * W + xx] : 0.f;
+    }
+  float z = 0.f, sx = 0.f, sy = 0.f;
+#pragma unroll
+  for (int j = 0; j < PATCH; ++j)
+#pragma unroll
+    for (int i = 0; i < PATCH; ++i) {
+      z = __fadd_rn(z, w[j][i]);
+      sx = __fadd_rn(sx, __fmul_rn(g0 + i, w[j][i]));
+      sy = __fadd_rn(sy, __fmul_rn(g0 + j, w[j][i]));
+    }
+  *dx = sx / z;
+  *dy = sy / z;
+}
 __device__ __forceinline__ void integral_offset(const float* __restrict__ plane, int H, int W, int px, int py, int patch, float* dx, float* dy) {
+  if (patch == 5) return integral_offset_fixed<5>(plane, H, W, px, py, dx, dy);
+  if (patch == 3) return integral_offset_fixed<3>(plane, H, W, px, py, dx, dy);
+  if (patch == 7) return integral_offset_fixed<7>(plane, H, W, px, py, dx, dy);
   const int half = patch / 2;
   // top-left = trunc((p - (patch-1)/2) + half) - half  (crops.py:85-90; exact for integer p)
   const float tlx = (float)px - (patch - 1) * 0.5f, tly = (float)py - (patch - 1) * 0.5f;
@@ -171,8 +202,282 @@ __global__ __launch_bounds__(256) void peaks_emit_kernel(const float* __restrict
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// K9b: local peaks in ONE pass over the confidence maps + a placement pass over the (few) peaks found.
+//   peaks_onepass_kernel: one block per (sample, group of OP_R rows).  Every map value is loaded once by the lane that owns its column quad (1 + 2 / OP_R reads per
+//     value) and bit c of the pixel's 64-bit mask is set where the strict 3x3 test passes (peaks.py:26-63,184-259: v > threshold and v > every in-image neighbour).
+//     Then, row by row and column chunk by column chunk, block prefix sums put the peaks in the reference's (y, x, channel) order into the block's staging area
+//     (coordinates refined right there) and the block's count is stored.
+//   peaks_place_kernel: block i sums the counts of the blocks before it (fixed order: no atomics), copies its staged peaks to their final place and, in the rare case
+//     that a block found more peaks than its staging area holds, recomputes that block's rows straight into the output (the legacy emit logic) -- the result never depends
+//     on the staging capacity.  Block 0 also writes the totals and the per-sample counts / offsets.
+// Two launches, the maps read once (the legacy path: count + scan + emit, two full reads with nine loads per value each).
+// ---------------------------------------------------------------------------------------
+constexpr int OP_R = 8;      // rows per block
+constexpr int OP_STAGE = 512;  // staged peaks per block (16 B each)
+
+// NCH: 256-column chunks of a row (W <= 256 NCH).  VEC: rows are 16-byte aligned (W a multiple of 4): one 16-byte load per lane and row.
+// Wave w of the block takes the channels [w cpw, (w + 1) cpw), cpw = ceil(C / 4) <= 16: a lane owns four consecutive columns, loads the OP_R + 2 rows of a channel up
+// front (independent 16-byte loads from clamped addresses, out-of-image entries replaced by -inf: ~10 KiB in flight per wave), tests its 4 x OP_R pixels in registers
+// without a branch -- v > threshold and v > the maximum of its eight neighbours, formed separably; a neighbour outside the image counts as -inf (exactly as skipping
+// it), a NaN neighbour as +inf (`v > NaN` is false) -- (left / right neighbours of the quad's ends by wave shuffles, the wave's two edge lanes load theirs) and keeps one
+// result bit per (pixel, channel) in registers; the four waves' 16-bit channel masks meet in LDS, the block lists its peaks in order (prefix sums per row), then
+// refines and stages them one per thread.
+template <int NCH, bool VEC>
+__global__ __launch_bounds__(256) void peaks_onepass_kernel(const float* __restrict__ cms, int C, int H, int W, float thr, int refine, int patch, float xy_scale,
+                                                            int groups, int* __restrict__ blk_count, float* __restrict__ stg_xy, float* __restrict__ stg_val,
+                                                            int* __restrict__ stg_ch) {
+  __shared__ int red[8];
+  __shared__ unsigned long long sbits[4][OP_R][NCH * 64];  // [wave][row][column quad]: four 16-bit channel masks
+  __shared__ unsigned ent[OP_STAGE];                       // staged peaks of the block, in order: x | row << 12 | channel << 16
+  const int blk = blockIdx.x;
+  const int b = blk / groups, y0 = (blk - b * groups) * OP_R;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int rows = min(OP_R, H - y0);
+  const int cpw = (C + 3) >> 2, c_lo = wave * cpw, c_hi = min(C, c_lo + cpw);
+  const float ninf = -INFINITY, pinf = INFINITY;
+#pragma unroll
+  for (int k = 0; k < NCH; ++k) {
+    const int xb = k * 256;
+    const int x = xb + 4 * lane;
+    unsigned long long bits[OP_R];
+#pragma unroll
+    for (int r = 0; r < OP_R; ++r) bits[r] = 0ull;
+    if (xb < W) {  // block-uniform
+      const bool xin = x < W;
+      const int xc = xin ? x : 0;
+      for (int c = c_lo; c < c_hi; ++c) {
+        const float* plane = cms + ((size_t)b * C + c) * H * W;
+        // v: the raw values (the centre's `> threshold` test: a NaN centre is no peak); n: the same as NEIGHBOURS -- NaN replaced by +inf (a value next to a NaN is no
+        // peak: `v > NaN` is false, peaks.py's dilation propagates it), out-of-image by -inf (skipped)
+        float v[OP_R + 2][4], n[OP_R + 2][4], lf[OP_R + 2], rt[OP_R + 2];
+#pragma unroll
+        for (int j = 0; j < OP_R + 2; ++j) {
+          const int y = y0 - 1 + j;
+          const bool yin = y >= 0 && y < H;
+          const float* rp = plane + (size_t)min(max(y, 0), H - 1) * W;
+          if (VEC) {
+            const float4 q = *reinterpret_cast<const float4*>(rp + xc);
+            v[j][0] = q.x; v[j][1] = q.y; v[j][2] = q.z; v[j][3] = q.w;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[j][e] = (yin && xin) ? v[j][e] : ninf;
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float t = rp[min(x + e, W - 1)];
+              v[j][e] = (yin && x + e < W) ? t : ninf;
+            }
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) n[j][e] = v[j][e] != v[j][e] ? pinf : v[j][e];
+          float l = ninf, r = ninf;  // neighbours of the quad's ends that lie in other chunks (the wave's edge lanes; never taken when W <= 256)
+          if (NCH > 1) {
+            if (lane == 0 && yin && x > 0) l = rp[x - 1];
+            if (lane == 63 && yin && x + 4 < W) r = rp[x + 4];
+            l = l != l ? pinf : l;
+            r = r != r ? pinf : r;
+          }
+          lf[j] = l;
+          rt[j] = r;
+        }
+#pragma unroll
+        for (int j = 0; j < OP_R + 2; ++j) {
+          const float up = __shfl_up(n[j][3], 1, 64), dn = __shfl_down(n[j][0], 1, 64);
+          lf[j] = lane != 0 ? up : lf[j];
+          rt[j] = lane != 63 ? dn : rt[j];
+        }
+        // separable neighbourhood maximum (every operand is NaN-free): h3 = max(left, centre, right) of the rows above / below, h2 = max(left, right) of the own row
+        float h3[OP_R + 2][4], h2[OP_R + 2][4];
+#pragma unroll
+        for (int j = 0; j < OP_R + 2; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float l = e == 0 ? lf[j] : n[j][e - 1], r = e == 3 ? rt[j] : n[j][e + 1];
+            h2[j][e] = fmaxf(l, r);
+            h3[j][e] = fmaxf(h2[j][e], n[j][e]);
+          }
+        const int ci = c - c_lo;
+#pragma unroll
+        for (int r = 0; r < OP_R; ++r) {
+          const int j = r + 1;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float val = v[j][e];
+            const float nmax = fmaxf(fmaxf(h3[j - 1][e], h3[j + 1][e]), h2[j][e]);
+            const bool ok = (val > thr) & (val > nmax);
+            bits[r] |= (unsigned long long)(ok ? 1u : 0u) << (16 * e + ci);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < OP_R; ++r) sbits[wave][r][k * 64 + lane] = bits[r];
+  }
+  __syncthreads();
+  // phase 1 -- ordered compaction: rows ascending, columns ascending (chunk by chunk), channels ascending; the first OP_STAGE peaks are listed in LDS
+  int base = 0;
+#pragma unroll 1
+  for (int r = 0; r < rows; ++r) {
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+      if (k * 256 >= W) break;
+      const int x = k * 256 + threadIdx.x;
+      unsigned long long m = 0ull;
+      if (x < W) {
+#pragma unroll
+        for (int w = 0; w < 4; ++w) m |= ((sbits[w][r][x >> 2] >> (16 * (x & 3))) & 0xFFFFull) << (w * cpw);
+      }
+      const int cnt = __popcll(m);
+      int tot;
+      int off = base + block_exclusive_scan_256(cnt, &tot, red);
+      while (m) {
+        const int c = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        if (off < OP_STAGE) ent[off] = (unsigned)x | ((unsigned)r << 12) | ((unsigned)c << 16);
+        ++off;
+      }
+      base += tot;
+    }
+  }
+  __syncthreads();
+  // phase 2 -- refinement and staging, one peak per thread (no barrier between peaks: one memory latency for the block's whole list)
+  const size_t sbase = (size_t)blk * OP_STAGE;
+  for (int i = threadIdx.x; i < min(base, OP_STAGE); i += 256) {
+    const unsigned e = ent[i];
+    const int x = e & 0xFFF, y = y0 + ((e >> 12) & 0xF), c = e >> 16;
+    const float* plane = cms + ((size_t)b * C + c) * H * W;
+    float fx = (float)x, fy = (float)y;
+    if (refine) {
+      float dx, dy;
+      integral_offset(plane, H, W, x, y, patch, &dx, &dy);
+      fx += dx;
+      fy += dy;
+    }
+    stg_xy[2 * (sbase + i)] = fx * xy_scale;
+    stg_xy[2 * (sbase + i) + 1] = fy * xy_scale;
+    stg_val[sbase + i] = plane[(size_t)y * W + x];
+    stg_ch[sbase + i] = c;
+  }
+  if (threadIdx.x == 0) blk_count[blk] = base;
+}
+
+__global__ __launch_bounds__(256) void peaks_place_kernel(const float* __restrict__ cms, int B, int C, int H, int W, float thr, int refine, int patch, float xy_scale, int groups,
+                                                          const int* __restrict__ blk_count, const float* __restrict__ stg_xy, const float* __restrict__ stg_val,
+                                                          const int* __restrict__ stg_ch, float* __restrict__ out_xy, float* __restrict__ out_val,
+                                                          int* __restrict__ out_sample, int* __restrict__ out_channel, int* __restrict__ out_count, int cap) {
+  __shared__ int red[8];
+  __shared__ int s_off[2];
+  const int blk = blockIdx.x, n_blk = B * groups;
+  // exclusive offset of this block = sum of the counts of the blocks before it (integers: the order of the partial sums does not matter)
+  int part = 0;
+  for (int i = threadIdx.x; i < blk; i += 256) part += blk_count[i];
+  int tot;
+  block_exclusive_scan_256(part, &tot, red);
+  const int my_off = tot, my_cnt = blk_count[blk];
+  const int b = blk / groups, y0 = (blk - b * groups) * OP_R;
+  if (my_cnt <= OP_STAGE) {
+    const size_t sbase = (size_t)blk * OP_STAGE;
+    for (int i = threadIdx.x; i < my_cnt; i += 256) {
+      const int o = my_off + i;
+      if (o < cap) {
+        out_xy[2 * (size_t)o] = stg_xy[2 * (sbase + i)];
+        out_xy[2 * (size_t)o + 1] = stg_xy[2 * (sbase + i) + 1];
+        out_val[o] = stg_val[sbase + i];
+        out_sample[o] = b;
+        out_channel[o] = stg_ch[sbase + i];
+      }
+    }
+  } else {  // the staging area was too small for this block: recompute its rows into their final place (peaks_emit_kernel's logic)
+    int base = my_off;
+    for (int y = y0; y < min(y0 + OP_R, H); ++y)
+      for (int xb = 0; xb < W; xb += 256) {
+        const int x = xb + threadIdx.x;
+        int cnt = 0;
+        if (x < W)
+          for (int c = 0; c < C; ++c) cnt += is_local_peak(cms + ((size_t)b * C + c) * H * W, H, W, y, x, thr) ? 1 : 0;
+        int t2;
+        int off = base + block_exclusive_scan_256(cnt, &t2, red);
+        if (cnt > 0)
+          for (int c = 0; c < C; ++c) {
+            const float* plane = cms + ((size_t)b * C + c) * H * W;
+            if (!is_local_peak(plane, H, W, y, x, thr)) continue;
+            if (off < cap) {
+              float fx = (float)x, fy = (float)y;
+              if (refine) {
+                float dx, dy;
+                integral_offset(plane, H, W, x, y, patch, &dx, &dy);
+                fx += dx;
+                fy += dy;
+              }
+              out_xy[2 * (size_t)off] = fx * xy_scale;
+              out_xy[2 * (size_t)off + 1] = fy * xy_scale;
+              out_val[off] = plane[(size_t)y * W + x];
+              out_sample[off] = b;
+              out_channel[off] = c;
+            }
+            ++off;
+          }
+        base += t2;
+      }
+  }
+  if (blk == 0) {  // totals: out_count[0] = n, [1 + b] = peaks of sample b, [1 + B + b] = exclusive offsets (B + 1 entries); thread = sample, one block scan per 256 samples
+    __syncthreads();
+    if (threadIdx.x == 0) s_off[0] = 0;
+    __syncthreads();
+    for (int sb0 = 0; sb0 < B; sb0 += 256) {
+      const int bb = sb0 + threadIdx.x;
+      int p = 0;
+      if (bb < B)
+        for (int i = 0; i < groups; ++i) p += blk_count[bb * groups + i];
+      int t3;
+      const int ex = block_exclusive_scan_256(p, &t3, red);
+      const int carry = s_off[0];
+      if (bb < B) {
+        out_count[1 + bb] = p;
+        out_count[1 + B + bb] = carry + ex;
+      }
+      __syncthreads();
+      if (threadIdx.x == 0) s_off[0] = carry + t3;
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+      out_count[0] = s_off[0];
+      out_count[1 + 2 * B] = s_off[0];
+    }
+  }
+  (void)n_blk;
+}
+
+// scratch that lets ph_local_peaks take the one-pass path (0: the shape is outside it -- more than 64 channels or maps wider than 512 -- and the three-pass kernels run)
+int64_t local_peaks_onepass_scratch_bytes(int B, int C, int H, int W) {
+  if (C > 64 || W > 512) return 0;
+  const int64_t n_blk = (int64_t)B * ((H + OP_R - 1) / OP_R);
+  return 4 * (n_blk + 4 * n_blk * OP_STAGE);
+}
+
 int launch_local_peaks(const float* cms, int B, int C, int H, int W, float thr, int refine, int patch, float* out_xy, float* out_val,
-                       int* out_sample, int* out_channel, int* out_count, int cap, float xy_scale, int* scratch, hipStream_t s) {
+                       int* out_sample, int* out_channel, int* out_count, int cap, float xy_scale, int* scratch, int64_t scratch_bytes, hipStream_t s) {
+  const int64_t need = local_peaks_onepass_scratch_bytes(B, C, H, W);
+  if (need > 0 && scratch_bytes >= need) {
+    const int groups = (H + OP_R - 1) / OP_R, n_blk = B * groups;
+    int* blk_count = scratch;
+    float* stg_xy = reinterpret_cast<float*>(scratch + n_blk);
+    float* stg_val = stg_xy + 2 * (size_t)n_blk * OP_STAGE;
+    int* stg_ch = reinterpret_cast<int*>(stg_val + (size_t)n_blk * OP_STAGE);
+#define PH_ONEPASS(NCH_, VEC_) \
+  hipLaunchKernelGGL((peaks_onepass_kernel<NCH_, VEC_>), dim3(n_blk), dim3(256), 0, s, cms, C, H, W, thr, refine, patch, xy_scale, groups, blk_count, stg_xy, stg_val, stg_ch)
+    const bool vec = (W & 3) == 0 && (reinterpret_cast<uintptr_t>(cms) & 15) == 0;
+    if (W <= 256) {
+      if (vec) PH_ONEPASS(1, true); else PH_ONEPASS(1, false);
+    } else {
+      if (vec) PH_ONEPASS(2, true); else PH_ONEPASS(2, false);
+    }
+#undef PH_ONEPASS
+    hipLaunchKernelGGL(peaks_place_kernel, dim3(n_blk), dim3(256), 0, s, cms, B, C, H, W, thr, refine, patch, xy_scale, groups, blk_count, stg_xy, stg_val, stg_ch, out_xy, out_val,
+                       out_sample, out_channel, out_count, cap);
+    PH_HIP_CHECK(hipGetLastError());
+    return PH_OK;
+  }
   const int n_rows = B * H;
   int* row_count = scratch;              // n_rows
   int* row_offset = scratch + n_rows;    // n_rows + 1
@@ -485,7 +790,12 @@ int ph_local_peaks(const float* cms_dev, int32_t B, int32_t C, int32_t H, int32_
   PH_REQUIRE(patch >= 1 && (patch & 1), "ph_local_peaks: integral patch must be odd");
   PH_REQUIRE(scratch_bytes >= (int64_t)4 * (2 * (int64_t)B * H + 2), "ph_local_peaks: scratch too small");
   return launch_local_peaks(cms_dev, B, C, H, W, threshold, refine, patch, out_xy, out_val, out_sample, out_channel, out_count, cap, xy_scale,
-                            static_cast<int*>(scratch_dev), static_cast<hipStream_t>(stream));
+                            static_cast<int*>(scratch_dev), scratch_bytes, static_cast<hipStream_t>(stream));
+}
+
+int64_t ph_local_peaks_scratch_bytes(int32_t B, int32_t C, int32_t H, int32_t W) {
+  if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return 0;
+  return std::max<int64_t>((int64_t)4 * (2 * (int64_t)B * H + 2), local_peaks_onepass_scratch_bytes(B, C, H, W));
 }
 
 int ph_global_peaks(const float* cms_dev, int32_t B, int32_t C, int32_t H, int32_t W, float threshold, int32_t refine, int32_t patch, float* out_xy,

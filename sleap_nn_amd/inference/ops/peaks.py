@@ -46,7 +46,7 @@ def find_local_peaks_device(cms: torch.Tensor, threshold: float = 0.2, refinemen
         sc = torch.empty((cap,), dtype=torch.int32, device=dev)
         counts = torch.empty((2 + 2 * B,), dtype=torch.int32, device=dev)
     sb = torch.empty((cap,), dtype=torch.int32, device=dev)
-    scratch = torch.empty((2 * B * H + 2,), dtype=torch.int32, device=dev)
+    scratch = torch.empty((int(L.lib().ph_local_peaks_scratch_bytes(B, Cc, H, W)) // 4,), dtype=torch.int32, device=dev)  # sized for the one-pass kernels
     with torch.cuda.device(dev):
         L.check(
             L.lib().ph_local_peaks(

@@ -208,6 +208,65 @@ def test_local_peaks_capacity_retry_and_empty():
     assert e[0].shape == (0, 2) and e[1].shape == (0,)
 
 
+def _raw_local_peaks(cms, thr, refine, patch, cap, scratch_ints):
+    """ph_local_peaks through the raw C ABI with a caller-chosen scratch size: the minimum runs the three-pass kernels, ph_local_peaks_scratch_bytes the one-pass pair."""
+    import ctypes as C
+
+    from sleap_nn_amd import _lib as L
+
+    B, Cc, H, W = cms.shape
+    xy = torch.full((cap, 2), -7.0, device=DEV)
+    vals = torch.full((cap,), -7.0, device=DEV)
+    sb = torch.full((cap,), -7, dtype=torch.int32, device=DEV)
+    sc = torch.full((cap,), -7, dtype=torch.int32, device=DEV)
+    counts = torch.zeros((2 + 2 * B,), dtype=torch.int32, device=DEV)
+    scratch = torch.empty((scratch_ints,), dtype=torch.int32, device=DEV)
+    with torch.cuda.device(DEV):
+        L.check(L.lib().ph_local_peaks(C.c_void_p(cms.data_ptr()), B, Cc, H, W, float(thr), int(refine), patch, C.c_void_p(xy.data_ptr()), C.c_void_p(vals.data_ptr()), C.c_void_p(sb.data_ptr()),
+                                       C.c_void_p(sc.data_ptr()), C.c_void_p(counts.data_ptr()), cap, 1.0, C.c_void_p(scratch.data_ptr()), scratch.numel() * 4, L.current_stream_ptr()))
+    torch.cuda.synchronize()
+    n = int(counts[0])
+    return xy[: min(n, cap)].cpu(), vals[: min(n, cap)].cpu(), sb[: min(n, cap)].cpu(), sc[: min(n, cap)].cpu(), counts.cpu()
+
+
+@pytest.mark.parametrize("shape,thr", [((2, 5, 37, 70), 0.5), ((1, 13, 64, 256), 0.2), ((3, 2, 19, 300), 0.6), ((1, 3, 24, 510), 0.3), ((2, 64, 16, 40), 0.7), ((1, 2, 40, 96), -1.0),
+                                       ((1, 65, 16, 32), 0.5), ((1, 2, 8, 600), 0.5)])
+def test_one_pass_local_peaks_equal_the_three_pass_kernels_and_the_oracle(shape, thr):
+    """peaks_onepass_kernel + peaks_place_kernel (maps read once, two launches) against the three-pass kernels through the same C entry point and against the oracle:
+    identical peak lists bit for bit -- order (sample, y, x, channel), values, refined coordinates, counts and offsets.  Cases: heights that are no multiple of the
+    eight-row groups, widths in both column-chunk classes (<= 256, <= 512), with and without 16-byte-aligned rows, 64 channels (the mask width), a threshold below every value on noise (thousands of
+    peaks per block: the staging area overflows and the placement pass recomputes those blocks), ties / plateaus (strict comparison), NaN entries, capacity overflow reporting;
+    65 channels and 600 columns are outside the one-pass path (its scratch size equals the minimum) and must still work."""
+    from sleap_nn_amd import _lib as L
+
+    B, Cc, H, W = shape
+    g = torch.Generator().manual_seed(H * W + Cc)
+    cms = torch.rand(shape, generator=g)
+    cms[:, :, H // 2, : W // 2] = torch.round(cms[:, :, H // 2, : W // 2] * 4) / 4  # ties along a row
+    cms[0, 0, 0, 0] = cms[0, 0, H - 1, W - 1] = 2.0  # corners
+    cms[0, 0, 3:5, 9:11] = 3.0  # a plateau: no strict maximum
+    cms[-1, -1, 1, 2] = cms[0, 0, H - 1, 5] = float("nan")  # a NaN is no peak and neither is any pixel next to it (`v > NaN` is false; peaks.py's dilation propagates it)
+    ref = O.find_local_peaks(cms, thr, "integral", 5)
+    n_ref = ref[0].shape[0]
+    dev = cms.to(DEV)
+    min_ints = 2 * B * H + 2
+    full_ints = int(L.lib().ph_local_peaks_scratch_bytes(B, Cc, H, W)) // 4
+    assert (full_ints > min_ints) == (Cc <= 64 and W <= 512)
+    cap = n_ref + 5
+    three = _raw_local_peaks(dev, thr, 1, 5, cap, min_ints)
+    one = _raw_local_peaks(dev, thr, 1, 5, cap, full_ints)
+    for a, b_ in zip(three, one):
+        assert torch.equal(a, b_)
+    xy, vals, sb, sc, counts = one
+    assert int(counts[0]) == n_ref and int(counts[1 + 2 * B]) == n_ref
+    assert np.array_equal(sb.numpy(), ref[2].numpy()) and np.array_equal(sc.numpy(), ref[3].numpy()) and np.array_equal(vals.numpy(), ref[1].numpy())
+    assert np.allclose(xy.numpy(), ref[0].numpy(), atol=1e-4)
+    per_sample = np.bincount(ref[2].numpy(), minlength=B)
+    assert np.array_equal(counts[1 : 1 + B].numpy(), per_sample) and np.array_equal(counts[1 + B : 1 + 2 * B].numpy(), np.concatenate([[0], np.cumsum(per_sample)[:-1]]))
+    small = _raw_local_peaks(dev, thr, 1, 5, max(n_ref // 2, 1), full_ints)  # output capacity too small: the count is still the truth, the rows that fit are right
+    assert int(small[4][0]) == n_ref and torch.equal(small[1], vals[: small[1].shape[0]])
+
+
 @pytest.mark.parametrize("name", ["chain5", "tree6", "chain13", "rev4"])
 def test_paf_scoring_and_grouping_match_reference(name):
     from sleap_nn_amd.inference.ops.paf import PAFScorer
