@@ -471,8 +471,17 @@ def run_infer(args, ctx):
         del scms, spafs, sframes
 
     t = torch.tensor([elapsed, elapsed_h2d or 0.0, elapsed_weak or 0.0], dtype=torch.float64, device=dev)
+    # multi-rank bookkeeping for the line: how many ranks the collective library actually joined (a sum of ones over the job) and what each rank processed per step
+    ranks_seen, per_rank_frames = 1, [B]
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ones = torch.ones(1, dtype=torch.float64, device=dev)
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+        ranks_seen = int(round(float(ones.item())))
+        mine = torch.zeros(world, dtype=torch.float64, device=dev)
+        mine[rank] = B
+        dist.all_reduce(mine, op=dist.ReduceOp.SUM)
+        per_rank_frames = [int(v) for v in mine.tolist()]
     elapsed, elapsed_h2d = float(t[0].item()), (float(t[1].item()) if elapsed_h2d is not None else None)
     elapsed_weak = float(t[2].item()) if elapsed_weak is not None else None
     if rank != 0:
@@ -557,6 +566,10 @@ def run_infer(args, ctx):
             "params": model.num_parameters(), "conv_gflop_per_frame": sum(r["flops"] for r in model.op_table(1, SIZE, SIZE)) / 1e9,
             "forward_launch": "hipGraph replay (steps with per-op events launch kernel by kernel)" if use_graph else "kernel by kernel",
             "inputs": "uint8 frames resident in HBM when the timed region starts",
+            "rccl_ranks_seen": ranks_seen, "frames_per_step_by_rank": per_rank_frames,
+            "host_threads": {"cores_visible": (len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)), "per_rank": 2, "ranks": world,
+                             "what": "one Python thread that enqueues the GPU work (and the pinned H2D staging of the h2d_inclusive leg) + one C++ grouping worker per rank",
+                             "fits": 2 * world <= (len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))},
         },
         "step_ms": percentiles(step_ms),
         "roofline": {

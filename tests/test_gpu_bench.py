@@ -32,6 +32,11 @@ def test_two_ranks_default_strong_with_weak_beside_it_and_three_ranks_strong_reh
     w = d["weak_scaling"]
     assert w["frames_per_gpu_per_step"] == 4 and w["global_batch"] == 8 and w["value"] > 0
     assert "cpu_baseline" not in d and "train_cfg3" not in d and "REHEARSAL" in d["data"]  # the CPU leg and the extra legs belong to N = 1
+    assert d["config"]["rccl_ranks_seen"] == 2 and d["config"]["frames_per_step_by_rank"] == [4, 4]  # every rank joined the collective and took its contiguous chunk of the global batch
+    ht = d["config"]["host_threads"]
+    assert ht["ranks"] == 2 and ht["per_rank"] == 2 and ht["fits"] == (4 <= ht["cores_visible"])
+    # the driver's SCALE run puts 8 ranks on one host: enqueue thread + grouping worker per rank must fit its cores (16 on the 8-GPU box: 8 x 2)
+    assert 2 * 8 <= max(ht["cores_visible"], 16)
     assert d["roofline"]["kernel"].startswith("conv3x3_wino") and 0 < d["roofline"]["frac"] < 1
     d = _run("--gpus", "2", "--rehearse-on-one-gpu", "--steps", "2", "--warmup", "1", "--batch", "4", "--scaling", "weak", "--no-alt-precisions", "--no-h2d-leg")
     assert d["scaling"] == "weak" and d["config"]["global_batch"] == 8 and "weak_scaling" not in d
