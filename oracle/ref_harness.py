@@ -2,9 +2,8 @@
 
 TEST INFRASTRUCTURE ONLY. This module imports talmolab/sleap-nn modules straight from
 ``/root/reference`` (never copied) so that ``oracle/gen_golden.py`` can generate golden
-input/output vectors and so that ``tests/test_oracle_vs_reference.py`` can differential
--test ``oracle/cpu_ref.py`` against the real reference when the reference tree is
-present.  Nothing under ``sleap_nn_amd/`` (the product) may import this file, and it is
+input/output vectors (replayed by ``tests/test_oracle_golden.py``, which is how
+``oracle/cpu_ref.py`` is pinned against the real reference).  Nothing under ``sleap_nn_amd/`` (the product) may import this file, and it is
 never executed on the GPU box (``/root/reference`` does not exist there).
 
 The reference's package ``__init__`` files pull in loguru / sleap_io / lightning /
