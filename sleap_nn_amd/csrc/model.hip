@@ -203,6 +203,9 @@ void apply_conv_options(const ph_model* m, ConvArgs& a) {
   a.use_c16 = m->conv_c16;
   a.dma_stagger = m->dma_stagger;
   a.splitk = m->conv_splitk;
+  a.split_counters = m->split_counters_dev;
+  a.split_counters_n = m->split_counters_dev ? 4096 : 0;
+  a.splitk_finish = m->conv_splitk_finish;
 }
 
 // Programs made only of the UNet-style ops can run on the fp16 matrix pipe (handle option "conv_precision"); anything
@@ -464,6 +467,13 @@ ph_model* ph_model_create(const ph_op_desc* ops, int32_t n_ops, const float* con
       ph_model_destroy(m);
       return nullptr;
     }
+    std::vector<float> zc(4096, 0.f);  // (uploaded as floats: all-zero bits either way)
+    float* cdev = nullptr;
+    if (upload(m, zc, &cdev) != PH_OK) {
+      ph_model_destroy(m);
+      return nullptr;
+    }
+    m->split_counters_dev = reinterpret_cast<unsigned*>(cdev);
   }
   auto fail = [&](const char* msg, int i) -> ph_model* {
     set_error("ph_model_create: op %d: %s", i, msg);
@@ -1512,6 +1522,7 @@ std::vector<OptionRef> option_table(ph_model* m) {
       {"conv_wino2d", &m->conv_wino2d, nullptr},        // 1: N-tile-64 3x3 convs on the F(2x2,3x3) kernel; 0: F(2,3) along x only
       {"conv_wino4", &m->conv_wino4, nullptr},          // K-heavy 3x3 convs on the F(4x4,3x3) kernel: 1 inference plans, 2 every plan (both: where estimated faster), 3 every plan wherever it fits, 0 never
       {"conv_wino4_min_cin", &m->conv_wino4_min_cin, nullptr},  // padded input channels from which a layer takes it
+      {"conv_splitk_finish", &m->conv_splitk_finish, nullptr},  // 0: the split-K second stage as a launch of its own (A/B, tests)
       {"conv_splitk", &m->conv_splitk, nullptr},        // split K on the F(2x2,3x3) kernel for layers with fewer work units than CUs: 0 never, 1 where estimated faster, n >= 2 force n slices
       {"upsample_fold", &m->upsample_fold, nullptr},    // bilinear x2 folded into the F(4x4,3x3) input transform of the conv that consumes it
       {"stem_wino", &m->stem_wino, nullptr},            // second conv of the fused stem in Winograd form

@@ -51,6 +51,13 @@ struct ConvArgs {
   long long split_scratch_bytes = 0;
   int ksplit = 1;                     // filled by the launcher for the kernel
   long long split_stride = 0;         // floats per scratch plane
+  unsigned* split_counters = nullptr; // zeroed device counters, one per (pixel tile, N tile) of a split launch (owned by the model handle): the workgroup that stores a unit's last
+  int split_counters_n = 0;           //   K slice runs the second stage itself; nullptr = the second stage is a launch of its own (splitk_reduce_kernel)
+  int splitk_finish = 0;              // handle option "conv_splitk_finish": 1 = in-kernel second stage (measured slower: one CU's memory rate), 0 = the two-launch form
+  float* fin_dst = nullptr;           // filled by the launcher: the layer's real outputs / parameters for the in-kernel second stage
+  float* fin_dst_pool = nullptr;
+  const float* fin_bias = nullptr;
+  int fin_relu = 0;
 };
 
 struct InputConvArgs {

@@ -1581,13 +1581,14 @@ __global__ __launch_bounds__(256, 4) void stem_fused_kernel(StemArgs a) {
         t[c] = xi == 1 ? da + db : db * m1 + da;
       }
       const f32x4 av[4] = {t[2] * m1 + t[0], t[1] + t[2], t[1] * m1 + t[2], t[3] * m1 + t[1]};
+      f32x4 bw[4];  // A[i = li (output channel)][k = lg], element j = input channel 4 lg + j
 #pragma unroll
-      for (int nu = 0; nu < 4; ++nu) {
-        const int pos = xi * 4 + nu;
-        const f32x4 bw = *reinterpret_cast<const f32x4*>(a.w1w2 + (size_t)(pos * 16 + li) * 16 + lg * 4);  // A[i = li (output channel)][k = lg], element j = input channel 4 lg + j
+      for (int nu = 0; nu < 4; ++nu) bw[nu] = *reinterpret_cast<const f32x4*>(a.w1w2 + (size_t)((xi * 4 + nu) * 16 + li) * 16 + lg * 4);
+      // the four positions of a row take turns: an accumulator is touched every fourth MFMA (a dependent v_mfma_f32_16x16x4_f32 pair is 40 cycles apart, an independent one 32)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[pos] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[j], av[nu][j], acc[pos], 0, 0, 0);
-      }
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int nu = 0; nu < 4; ++nu) acc[xi * 4 + nu] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[nu][j], av[nu][j], acc[xi * 4 + nu], 0, 0, 0);
     }
     const f32x4 bias4 = *reinterpret_cast<const f32x4*>(a.b1 + 4 * lg);
     const int Hp = (a.H + 1) / 2, Wp = (a.W + 1) / 2;

@@ -139,6 +139,58 @@ int launch_wino2d_pack(const float* wpack, float* wino, int panels, int bn, hipS
 // workgroups by round.  A separate instantiation: the second K-loop body and the rotation cost the common case 2 % (code size, scalar registers).
 // BWD: the backward's store options (accumulate into dst, the folded ReLU mask) are compiled in; the forward instantiations do not carry their branches
 // (~740 cycles per tile of a 64 -> 64 layer, stamp build).
+// dst = act(bias + (((p_0 + p_1) + p_2) + ...)) of one (pixel, channel quad) over the K slices' planes, in slice order; the planes' loads are independent (four in flight),
+// only the additions are chained
+__device__ __forceinline__ f32x4 splitk_sum(const float* __restrict__ p, size_t stride, int ks) {
+  f32x4 v = *reinterpret_cast<const f32x4*>(p);
+  int k = 1;
+  for (; k + 4 <= ks; k += 4) {
+    const f32x4 a0 = *reinterpret_cast<const f32x4*>(p + (size_t)k * stride), a1 = *reinterpret_cast<const f32x4*>(p + (size_t)(k + 1) * stride);
+    const f32x4 a2 = *reinterpret_cast<const f32x4*>(p + (size_t)(k + 2) * stride), a3 = *reinterpret_cast<const f32x4*>(p + (size_t)(k + 3) * stride);
+    v = (((v + a0) + a1) + a2) + a3;
+  }
+  for (; k < ks; ++k) v += *reinterpret_cast<const f32x4*>(p + (size_t)k * stride);
+  return v;
+}
+// one 2x2 pool window (or, without a pool, just its pixels) x four channels of the second stage: sums, bias, ReLU, full-resolution stores, pooled store ("same" padding: zeros)
+__device__ __forceinline__ void splitk_finish_window(const float* __restrict__ part, size_t stride, int ks, const f32x4 bv, float* __restrict__ dst, float* __restrict__ dst_pool,
+                                                     int b, int py, int px, int c0, int H, int W, int coutp, int relu) {
+  f32x4 pooled = {0.f, 0.f, 0.f, 0.f};
+  bool first = true, padded = false;
+#pragma unroll
+  for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+    for (int dx = 0; dx < 2; ++dx) {
+      const int oy = 2 * py + dy, ox = 2 * px + dx;
+      if (oy >= H || ox >= W) {
+        padded = true;
+        continue;
+      }
+      const size_t idx = ((size_t)(b * H + oy) * W + ox) * coutp + c0;
+      f32x4 v = splitk_sum(part + idx, stride, ks) + bv;
+      if (relu) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+      }
+      if (dst) *reinterpret_cast<f32x4*>(dst + idx) = v;
+      if (first) {
+        pooled = v;
+        first = false;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pooled[e] = fmaxf(pooled[e], v[e]);
+      }
+    }
+  if (dst_pool && !first) {
+    if (padded) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) pooled[e] = fmaxf(pooled[e], 0.f);
+    }
+    const int Hp = (H + 1) >> 1, Wp = (W + 1) >> 1;
+    *reinterpret_cast<f32x4*>(dst_pool + ((size_t)(b * Hp + py) * Wp + px) * coutp + c0) = pooled;
+  }
+}
+
 // KS (split K, the small-batch regime): a work unit is (pixel tile, N tile, K slice) -- slice ks of a.ksplit covers halves [ks NH / ksplit, (ks + 1) NH / ksplit) of the NH = 2 nchunks
 // halves (both concat sources counted through) -- and its epilogue stores the slice's RAW partial sums (no bias, no ReLU, no pool, no head) to plane ks of a scratch tensor
 // [ksplit][B][H][W][coutp]; splitk_reduce_kernel then adds the planes in the fixed order 0, 1, ... and applies bias / ReLU / pool.  A layer whose (pixel tiles x N tiles) fill a
@@ -742,6 +794,55 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_kernel(ConvArgs a) {
           }
       }
     }
+    if (KS && a.split_counters) {
+      // In-kernel second stage: the workgroup that stores the LAST K slice of a (pixel tile, N tile) -- whichever that is -- adds the slices' planes in slice order
+      // (the result does not depend on who is last), applies bias / ReLU / pool and stores the layer's real output: no second launch.  Release / acquire through a
+      // device-scope counter: every workgroup fences its stores before its increment, the last one fences again before it reads the other workgroups' planes (first
+      // touched by this CU in this launch: the L1 is invalidated at kernel start); it leaves the counter at zero for the next launch (hipGraph replays included).
+      __syncthreads();  // (s_waitcnt vmcnt(0): this workgroup's partial sums have left the CU)
+      float* const flag = spare + 4095;
+      const int unit = ((P.b * tiles_y + P.y0 / W2_T) * tiles_x + P.x0 / W2_T) * ntc + P.ntile;
+      if (tid == 0) {
+        __threadfence();
+        const unsigned old = atomicAdd(a.split_counters + unit, 1u);
+        const bool last = old + 1u == (unsigned)a.ksplit;
+        if (last) a.split_counters[unit] = 0u;
+        __threadfence();
+        *flag = last ? 1.f : 0.f;
+      }
+      __syncthreads();
+      if (*flag != 0.f) {
+        const int cq = min(BN, a.coutp - P.ntile * BN) >> 2;  // channel quads of this N tile that exist
+        const float* part = a.dst;                             // (the launch's dst IS the scratch tensor)
+        if (a.fin_dst_pool) {
+          for (int i = tid; i < 64 * cq; i += 512) {
+            const int c4 = i % cq, w = i / cq;
+            const int py = (P.y0 >> 1) + (w >> 3), px = (P.x0 >> 1) + (w & 7);
+            if (2 * py < a.H && 2 * px < a.W) {
+              const int c0 = P.ntile * BN + 4 * c4;
+              splitk_finish_window(part, (size_t)a.split_stride, a.ksplit, *reinterpret_cast<const f32x4*>(a.fin_bias + c0), a.fin_dst, a.fin_dst_pool, P.b, py, px, c0, a.H, a.W, a.coutp,
+                                   a.fin_relu);
+            }
+          }
+        } else {
+          for (int i = tid; i < 256 * cq; i += 512) {
+            const int c4 = i % cq, pxl = i / cq;
+            const int oy = P.y0 + (pxl >> 4), ox = P.x0 + (pxl & 15);
+            if (oy < a.H && ox < a.W) {
+              const int c0 = P.ntile * BN + 4 * c4;
+              const size_t idx = ((size_t)(P.b * a.H + oy) * a.W + ox) * a.coutp + c0;
+              f32x4 v = splitk_sum(part + idx, (size_t)a.split_stride, a.ksplit) + *reinterpret_cast<const f32x4*>(a.fin_bias + c0);
+              if (a.fin_relu) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+              }
+              *reinterpret_cast<f32x4*>(a.fin_dst + idx) = v;
+            }
+          }
+        }
+      }
+      __syncthreads();  // (the flag word is rewritten by the next unit)
+    }
     W2_STAMP(st_e3)
 #ifdef PH_W2_STAMP
     ++st_tiles;
@@ -773,20 +874,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_kernel(ConvArgs a) {
 
 static int w2_cu_count(int* out) { return device_cu_count(out); }
 
-// Second stage of a split-K launch: dst = act(bias + (((p_0 + p_1) + p_2) + ...)) over the K slices' planes in slice order (bitwise repeatable), and the fused 2x2 max pool of
-// that result ("same" padding: zeros beyond the image, architectures/common.py:69-107).  POOL: one thread = one pool window x four channels; otherwise one pixel x four channels.
-// The planes' loads are independent (four slices in flight per pixel), only the additions are chained.
-__device__ __forceinline__ f32x4 splitk_sum(const float* __restrict__ p, size_t stride, int ks) {
-  f32x4 v = *reinterpret_cast<const f32x4*>(p);
-  int k = 1;
-  for (; k + 4 <= ks; k += 4) {
-    const f32x4 a0 = *reinterpret_cast<const f32x4*>(p + (size_t)k * stride), a1 = *reinterpret_cast<const f32x4*>(p + (size_t)(k + 1) * stride);
-    const f32x4 a2 = *reinterpret_cast<const f32x4*>(p + (size_t)(k + 2) * stride), a3 = *reinterpret_cast<const f32x4*>(p + (size_t)(k + 3) * stride);
-    v = (((v + a0) + a1) + a2) + a3;
-  }
-  for (; k < ks; ++k) v += *reinterpret_cast<const f32x4*>(p + (size_t)k * stride);
-  return v;
-}
+// Second stage of a split-K launch as a kernel of its own (used when the in-kernel finish below is not available: no counters, or more work units than counters):
+// POOL: one thread = one pool window x four channels; otherwise one pixel x four channels.
 template <bool POOL>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, size_t stride, int ks, const float* __restrict__ bias, float* __restrict__ dst,
                                                             float* __restrict__ dst_pool, int B, int H, int W, int coutp, int relu) {
@@ -905,8 +994,18 @@ int launch_conv3x3_wino2d(const ConvArgs& a, hipStream_t s) {
     k.skip_dst = 0;
     k.ksplit = ksplit;
     k.split_stride = (long long)a.B * a.H * a.W * a.coutp;
+    const bool in_kernel = a.split_counters && tiles * ntc <= a.split_counters_n && a.splitk_finish;
+    if (in_kernel) {  // the last-arriving workgroup of a (pixel tile, N tile) finishes it: one launch
+      k.fin_dst = a.skip_dst ? nullptr : a.dst;
+      k.fin_dst_pool = a.dst_pool;
+      k.fin_bias = a.bias;
+      k.fin_relu = a.relu;
+    } else {
+      k.split_counters = nullptr;
+    }
     hipLaunchKernelGGL((conv3x3_wino2d_kernel<64, false, false, true>), dim3(std::min(tiles * ntc * ksplit, n_cu)), dim3(512), lds, s, k);
     PH_HIP_CHECK(hipGetLastError());
+    if (in_kernel) return PH_OK;
     if (a.dst_pool) {
       const size_t threads = (size_t)a.B * ((a.H + 1) / 2) * ((a.W + 1) / 2) * (a.coutp / 4);
       hipLaunchKernelGGL(splitk_reduce_kernel<true>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, (const float*)a.split_scratch, (size_t)k.split_stride, ksplit, a.bias,
