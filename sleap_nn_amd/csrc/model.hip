@@ -658,6 +658,12 @@ ph_model* ph_model_create(const ph_op_desc* ops, int32_t n_ops, const float* con
           return true;
         };
         if (ok && !tr) ok = derive_wino2(op.w_dev, d.cin0, d.cin1, d.cout, op.bn, &op.w_wino2_dev);
+        if (ok && !tr && op.bn == 32 && coutp == 32 && pad16(d.cin0) + (d.cin1 > 0 ? pad16(d.cin1) : 0) >= 64) {
+          // 32 output channels, K >= 64: a second packing with an N tile of 64 (rows 32 .. 63 zero) for the F(2x2,3x3) kernel's half-empty-tile form (conv_n32_wino2d)
+          auto pack_64 = [&](const auto* w, auto& out) { pack_conv(w, false, d.cin0, d.cin1, d.cout, 64, out); };
+          ok = pack_upload(m, pack_64, weights[d.weight], iw, &op.w_n64_dev) == PH_OK && pack_upload(m, pad_vec(64, d.cout), weights[d.bias], ib, &op.b_n64_dev) == PH_OK &&
+               derive_wino2(op.w_n64_dev, d.cin0, d.cin1, d.cout, 64, &op.w_wino2_dev);
+        }
         // F(4x4,3x3) weights (conv3x3_wino4_kernel) of the layers with many input channels: 4x the direct weights' bytes
         auto derive_wino4 = [&](const float* src, int cin_a, int cin_b, int cout_, int bn, float** dst) {
           if (bn != 64 || pad16(cin_a) + (cin_b > 0 ? pad16(cin_b) : 0) < 128) return true;
@@ -1106,6 +1112,13 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
         apply_conv_options(m, a);
         a.wpack_wino4 = op.w_wino4_dev;
         a.use_wino4 = m->conv_wino4 == 3 ? 2 : ((m->conv_wino4 == 2 || (m->conv_wino4 == 1 && plan.reuse)) ? 1 : 0);
+        if (op.w_n64_dev && op.w_wino2_dev && op.w_wino_dev && m->conv_n32_wino2d && m->use_dma && m->conv_wino && m->conv_wino2d && m->conv_persist && !w16_fits(a) && wino2d_fits(a)) {
+          // Cout 32, K >= 64 (and not a shape of the wave-private kernel): N tile 64 with its upper half empty -- the F(2x2,3x3) kernel skips the missing half's MFMAs
+          a.bn = 64;
+          a.wpack = op.w_n64_dev;
+          a.bias = op.b_n64_dev;
+          a.wpack_dma = nullptr;
+        }
         if (plan.tmp_bytes > 0) {
           a.split_scratch = reinterpret_cast<float*>(ws + plan.tmp_offset);
           a.split_scratch_bytes = plan.tmp_bytes;
@@ -1522,6 +1535,7 @@ std::vector<OptionRef> option_table(ph_model* m) {
       {"conv_wino2d", &m->conv_wino2d, nullptr},        // 1: N-tile-64 3x3 convs on the F(2x2,3x3) kernel; 0: F(2,3) along x only
       {"conv_wino4", &m->conv_wino4, nullptr},          // K-heavy 3x3 convs on the F(4x4,3x3) kernel: 1 inference plans, 2 every plan (both: where estimated faster), 3 every plan wherever it fits, 0 never
       {"conv_wino4_min_cin", &m->conv_wino4_min_cin, nullptr},  // padded input channels from which a layer takes it
+      {"conv_n32_wino2d", &m->conv_n32_wino2d, nullptr},  // Cout-32 / K >= 64 layers on the F(2x2,3x3) kernel with a half-empty N tile (0: the N-tile-32 F(2,3) kernel)
       {"conv_splitk_finish", &m->conv_splitk_finish, nullptr},  // 0: the split-K second stage as a launch of its own (A/B, tests)
       {"conv_splitk", &m->conv_splitk, nullptr},        // split K on the F(2x2,3x3) kernel for layers with fewer work units than CUs: 0 never, 1 where estimated faster, n >= 2 force n slices
       {"upsample_fold", &m->upsample_fold, nullptr},    // bilinear x2 folded into the F(4x4,3x3) input transform of the conv that consumes it

@@ -112,9 +112,21 @@ class HipBackend:
             entry = (graph, static_in, static_out, self.model._workspace)
             self._graphs[key] = entry
         graph, static_in, static_out, _ws = entry
-        static_in.copy_(x, non_blocking=True)
+        if x.data_ptr() != static_in.data_ptr():  # a caller that fills ``static_input(...)`` itself (e.g. its H2D target) skips this device-to-device copy
+            static_in.copy_(x, non_blocking=True)
         graph.replay()
         return static_out
+
+    def static_input(self, shape: Tuple[int, ...], dtype: torch.dtype = torch.uint8) -> torch.Tensor:
+        """The captured graph's own input buffer for ``shape`` (4-D ``(B, C, H, W)``; captured on first use).  Writing the frames straight into it -- as the target
+        of the H2D copy, say -- and passing it to ``__call__`` makes a step ONE graph launch with no staging copy in front (a 256 x 256 frame: ~5 us of copy + ~9 us of
+        launch gap on a ~300-us forward)."""
+        if not self.use_graph:
+            raise RuntimeError("static_input needs use_graph=True")
+        x = torch.zeros(tuple(shape), dtype=dtype, device=self._device)
+        code = None if dtype == torch.uint8 else 1
+        self._forward_graph(x, code)
+        return self._graphs[(tuple(x.shape), x.dtype, code)][1]
 
     def warmup(self, input_shape: Tuple[int, ...]) -> None:
         x = torch.zeros(tuple(input_shape), dtype=torch.uint8, device=self._device)

@@ -51,6 +51,14 @@ def test_cfg1_single_instance_256_batch1_network_and_global_peaks():
         _close(raw, ref, "cfg1")
         first = raw.cpu().clone()
         assert torch.equal(layer.backend(img[:1])["SingleInstanceConfmapsHead"].cpu(), first)  # run-to-run bitwise (fixed-order second stage)
+    # zero-copy input: the graph's own input buffer, filled by the caller, goes in without a staging copy -- and a refill is seen by the next replay
+    buf = layer.backend.static_input((1, 1, 256, 256))
+    buf.copy_(img[:1])
+    assert torch.equal(layer.backend(buf)["SingleInstanceConfmapsHead"].cpu(), first)
+    buf.copy_(img[1:2])
+    other = layer.backend(buf)["SingleInstanceConfmapsHead"].cpu()
+    assert not torch.equal(other, first) and torch.equal(other, layer.backend(img[1:2])["SingleInstanceConfmapsHead"].cpu())
+    raw = layer.backend(img[:1])["SingleInstanceConfmapsHead"]
     codes = m.last_kernels()
     assert L.KV_WINO2D_KS in codes, codes  # the default routing of this batch takes the split-K form somewhere
     out = layer.postprocess({"SingleInstanceConfmapsHead": raw}, PreprocInfo(eff_scale=torch.ones(1), output_stride=2))
@@ -201,4 +209,28 @@ def test_head_fused_into_the_wave_private_kernel_matches_the_head_kernel_and_the
         head_codes = [c for r, c in zip(m.op_table(batch, hw[0], hw[1]), m.last_kernels()) if r["kind"] == L.OP_HEAD]
         assert head_codes == [L.KV_FUSED if (fuse and nodes <= 16) else L.KV_NONE], (fuse, head_codes)  # a fused head's op launches nothing
     _close(outs[1], ref, "fused head")
+    assert (outs[1] - outs[0]).abs().max().item() <= 2e-5 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("filters,max_stride,hw,batch", [(16, 16, (128, 160), 2), (16, 4, (72, 104), 1), (16, 8, (64, 64), 3)])
+def test_cout32_layers_on_the_half_empty_n_tile_of_the_winograd_kernel(filters, max_stride, hw, batch):
+    """conv_n32_wino2d: the last decoder level of an output-stride-2 filters-16 UNet (concat 32 + 64 -> 32 channels) runs on conv3x3_wino2d_kernel<64, HT> with the upper half
+    of its N tile empty (a second weight packing, zero rows 32 .. 63; stores skip the missing channels) instead of the N-tile-32 F(2,3) kernel; image-cut tiles; vs the oracle
+    and vs the old route (option 0), and the kernel record says which ran."""
+    from sleap_nn_amd.architectures.model import Model
+
+    bb = dict(SI_BB, filters=filters, max_stride=max_stride, output_stride=2)
+    heads = {"confmaps": {"part_names": ["a", "b", "c", "d"], "output_stride": 2}}
+    sd = O.init_state(bb, heads, "single_instance", seed=hw[0], head_scale=1.0)
+    img = torch.randint(0, 256, (batch, 1, hw[0], hw[1]), dtype=torch.uint8, generator=torch.Generator().manual_seed(hw[1]))
+    ref = O.model_forward(sd, bb, heads, "single_instance", img)["SingleInstanceConfmapsHead"]
+    outs = {}
+    for opt in (1, 0):
+        m = Model("unet", bb, heads, "single_instance")
+        m.load_state_dict(sd)
+        m.set_option("conv_n32_wino2d", opt)
+        outs[opt] = m.to(DEV)(img.to(DEV))["SingleInstanceConfmapsHead"].cpu()
+        last_concat = [c for r, c in zip(m.op_table(batch, hw[0], hw[1]), m.last_kernels()) if "refine_conv0" in r["label"]][-1]
+        assert last_concat == (L.KV_WINO2D if opt else L.KV_WINO1D), (opt, last_concat)
+    _close(outs[1], ref, "n32 on wino2d")
     assert (outs[1] - outs[0]).abs().max().item() <= 2e-5 * ref.abs().max().item()
