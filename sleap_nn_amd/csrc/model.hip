@@ -202,7 +202,7 @@ void apply_conv_options(const ph_model* m, ConvArgs& a) {
   a.persist = m->conv_persist;
   a.use_c16 = m->conv_c16;
   a.dma_stagger = m->dma_stagger;
-  a.splitk = m->conv_splitk;
+  a.splitk = m->conv_splitk;  // (ph_model_forward clears it for a training plan unless a slice count is forced)
   a.split_counters = m->split_counters_dev;
   a.split_counters_n = m->split_counters_dev ? 4096 : 0;
   a.splitk_finish = m->conv_splitk_finish;
@@ -368,10 +368,11 @@ int build_plan(const ph_model* m, int B, int H, int W, Plan& plan, int fmt) {
                  h, w, s1.h, s1.w);
     }
     if (d.kind == PH_OP_CONVT) tmp = std::max<int64_t>(tmp, (int64_t)B * oh * ow * fmt_cpad(fmt, d.cin0) * bpc);
-    if (d.kind == PH_OP_CONV && d.ksize == 3 && fmt == FMT_F32 && m->conv_splitk) {  // partial-sum planes of a split-K launch (conv3x3_wino2d_kernel<.., KS>)
+    if (d.kind == PH_OP_CONV && d.ksize == 3 && fmt == FMT_F32 && (m->conv_splitk >= 2 || (m->conv_splitk == 1 && reuse))) {  // (auto: inference plans only, as the kernel choice below)  // partial-sum planes of a split-K launch (conv3x3_wino2d_kernel<.., KS>)
       int n_cu = 0;
       if (device_cu_count(&n_cu) != PH_OK || n_cu <= 0) n_cu = 256;
       tmp = std::max<int64_t>(tmp, wino2d_split_scratch_bytes(B, h, w, pad16(d.cin0) + (d.src1 >= 0 ? pad16(d.cin1) : 0), pad16(d.cout), m->conv_splitk, n_cu));
+      if (m->conv_wino4) tmp = std::max<int64_t>(tmp, wino4_split_scratch_bytes(B, h, w, pad16(d.cin0) + (d.src1 >= 0 ? pad16(d.cin1) : 0), pad16(d.cout), m->conv_splitk, n_cu));
     }
     PH_REQUIRE(d.dst >= 0 && d.dst < m->n_slots, "bad dst slot %d", d.dst);
     SlotShape& s = plan.slots[d.dst];
@@ -1112,13 +1113,15 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
         apply_conv_options(m, a);
         a.wpack_wino4 = op.w_wino4_dev;
         a.use_wino4 = m->conv_wino4 == 3 ? 2 : ((m->conv_wino4 == 2 || (m->conv_wino4 == 1 && plan.reuse)) ? 1 : 0);
-        if (op.w_n64_dev && op.w_wino2_dev && op.w_wino_dev && m->conv_n32_wino2d && m->use_dma && m->conv_wino && m->conv_wino2d && m->conv_persist && !w16_fits(a) && wino2d_fits(a)) {
+        // (both round-4 routings below apply to inference plans: a training program's forward keeps the kernels its gradient tests were pinned with)
+        if (op.w_n64_dev && op.w_wino2_dev && op.w_wino_dev && (m->conv_n32_wino2d >= 2 || (m->conv_n32_wino2d == 1 && plan.reuse)) && m->use_dma && m->conv_wino && m->conv_wino2d && m->conv_persist && !w16_fits(a) && wino2d_fits(a)) {
           // Cout 32, K >= 64 (and not a shape of the wave-private kernel): N tile 64 with its upper half empty -- the F(2x2,3x3) kernel skips the missing half's MFMAs
           a.bn = 64;
           a.wpack = op.w_n64_dev;
           a.bias = op.b_n64_dev;
           a.wpack_dma = nullptr;
         }
+        if (a.splitk == 1 && !plan.reuse) a.splitk = 0;
         if (plan.tmp_bytes > 0) {
           a.split_scratch = reinterpret_cast<float*>(ws + plan.tmp_offset);
           a.split_scratch_bytes = plan.tmp_bytes;

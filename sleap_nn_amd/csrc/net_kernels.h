@@ -183,6 +183,9 @@ bool conv3x3_dma_is_wino4(const ConvArgs& a);      // launch_conv3x3_dma would r
 int prepare_wino4_kernels();
 bool wino2d_fits(const ConvArgs& a);  // sources addressable through the kernel's 32-bit buffer descriptors
 int wino2d_ksplit(const ConvArgs& a);  // K slices launch_conv3x3_wino2d would use for this launch (1 = the one-stage kernel)
+int launch_splitk_reduce(const float* part, long long stride, int ks, const float* bias, float* dst, float* dst_pool, int B, int H, int W, int coutp, int relu, hipStream_t s);
+int wino4_ksplit_shape(int B, int H, int W, int cinp, int coutp, int splitk, int n_cu);            // K slices the F(4x4,3x3) kernel would take
+int64_t wino4_split_scratch_bytes(int B, int H, int W, int cinp, int coutp, int splitk, int n_cu);
 int wino2d_ksplit_shape(int B, int H, int W, int cinp, int coutp, int splitk, int n_cu);
 int64_t wino2d_split_scratch_bytes(int B, int H, int W, int cinp, int coutp, int splitk, int n_cu);  // scratch a plan reserves for such a layer
 int prepare_wino2d_kernels();

@@ -933,6 +933,19 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   *reinterpret_cast<f32x4*>(dst_pool + ((size_t)(b * Hp + py) * Wp + px) * coutp + c4 * 4) = pooled;
 }
 
+// the second stage of a split-K launch (either Winograd kernel): dst (unless nullptr) and dst_pool (unless nullptr: then dst may be nullptr) from the ks planes of `part`
+int launch_splitk_reduce(const float* part, long long stride, int ks, const float* bias, float* dst, float* dst_pool, int B, int H, int W, int coutp, int relu, hipStream_t s) {
+  if (dst_pool) {
+    const size_t threads = (size_t)B * ((H + 1) / 2) * ((W + 1) / 2) * (coutp / 4);
+    hipLaunchKernelGGL(splitk_reduce_kernel<true>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, part, (size_t)stride, ks, bias, dst, dst_pool, B, H, W, coutp, relu);
+  } else {
+    const size_t threads = (size_t)B * H * W * (coutp / 4);
+    hipLaunchKernelGGL(splitk_reduce_kernel<false>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, part, (size_t)stride, ks, bias, dst, nullptr, B, H, W, coutp, relu);
+  }
+  PH_HIP_CHECK(hipGetLastError());
+  return PH_OK;
+}
+
 // K slices a layer of this shape takes on the F(2x2,3x3) kernel (1 = no split).  splitk: the handle option "conv_splitk" -- 0 never, 1 where the layer's work units fill less than half
 // of the CUs and a slice keeps at least three halves (a unit costs ~8 us of prologue + epilogue + a ~4-us second stage against ~2 us per half), n >= 2 forces n slices (tests).
 int wino2d_ksplit_shape(int B, int H, int W, int cinp, int coutp, int splitk, int n_cu) {
@@ -1006,16 +1019,8 @@ int launch_conv3x3_wino2d(const ConvArgs& a, hipStream_t s) {
     hipLaunchKernelGGL((conv3x3_wino2d_kernel<64, false, false, true>), dim3(std::min(tiles * ntc * ksplit, n_cu)), dim3(512), lds, s, k);
     PH_HIP_CHECK(hipGetLastError());
     if (in_kernel) return PH_OK;
-    if (a.dst_pool) {
-      const size_t threads = (size_t)a.B * ((a.H + 1) / 2) * ((a.W + 1) / 2) * (a.coutp / 4);
-      hipLaunchKernelGGL(splitk_reduce_kernel<true>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, (const float*)a.split_scratch, (size_t)k.split_stride, ksplit, a.bias,
-                         a.skip_dst ? nullptr : a.dst, a.dst_pool, a.B, a.H, a.W, a.coutp, a.relu);
-    } else {
-      const size_t threads = (size_t)a.B * a.H * a.W * (a.coutp / 4);
-      hipLaunchKernelGGL(splitk_reduce_kernel<false>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, (const float*)a.split_scratch, (size_t)k.split_stride, ksplit, a.bias, a.dst,
-                         nullptr, a.B, a.H, a.W, a.coutp, a.relu);
-    }
-    PH_HIP_CHECK(hipGetLastError());
+    const int rc2 = launch_splitk_reduce(a.split_scratch, k.split_stride, ksplit, a.bias, a.skip_dst ? nullptr : a.dst, a.dst_pool, a.B, a.H, a.W, a.coutp, a.relu, s);
+    if (rc2 != PH_OK) return rc2;
     return PH_OK;
   }
   const dim3 grid(std::min(tiles * ntc, n_cu));

@@ -136,7 +136,10 @@ __device__ __forceinline__ void w4_col_pass(const float (&t)[6], float (&v)[6]) 
 }
 
 // LOWRES: the second source is the half-resolution tensor (ConvArgs::src1_lowres); the plain instantiation does not carry its row coefficients and branches
-template <bool LOWRES>
+// KS (round 4, as conv3x3_wino2d_kernel's): a work unit is (pixel tile, N tile, K slice): slice ks covers quarters [ks Q / ksplit, (ks + 1) Q / ksplit), its epilogue stores raw partial
+// sums (no bias, no ReLU) to plane ks of the scratch tensor and splitk_reduce_kernel adds the planes in slice order.  For layers whose 32 x 16-pixel tiles fill less than half of the CUs
+// (the per-rank batches of the strong-scaling runs, cfg2): which of F(4x4,3x3) / F(2x2,3x3), split or not, runs a layer is decided by wino4_fits' time model.
+template <bool LOWRES, bool KS = false>
 __global__ __launch_bounds__(768) void conv3x3_wino4_kernel(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x;
@@ -153,7 +156,8 @@ __global__ __launch_bounds__(768) void conv3x3_wino4_kernel(ConvArgs a) {
   const int tiles_y = (a.H + W4_PH - 1) / W4_PH;
   const int tiles = tiles_x * tiles_y * a.B;
   const int ntc = (a.coutp + 63) / 64;
-  const int total = tiles * ntc;
+  const int units = tiles * ntc;
+  const int total = KS ? units * a.ksplit : units;
   const int Q0 = a.c0p / 4, Q1 = a.c1p / 4, Q = Q0 + Q1;
   constexpr int lowres = LOWRES ? 1 : 0;
   const int Hl = a.H >> 1, Wl = a.W >> 1;
@@ -202,7 +206,10 @@ __global__ __launch_bounds__(768) void conv3x3_wino4_kernel(ConvArgs a) {
 
   for (int vid = blockIdx.x; vid < total; vid += gridDim.x) {
     Plan P;
-    setup(vid, P);
+    const int ksl = KS ? vid / units : 0;                      // K slice of this unit
+    const int qbeg = KS ? ksl * Q / a.ksplit : 0;              // its quarters [qbeg, qend)
+    const int qend = KS ? (ksl + 1) * Q / a.ksplit : Q;
+    setup(KS ? vid - ksl * units : vid, P);
     // ---- per-tile loader state: this lane's halo entry of source 0 (piece pw of the full-resolution layout) and of source 1
     unsigned off0, off1;
     {
@@ -230,8 +237,8 @@ __global__ __launch_bounds__(768) void conv3x3_wino4_kernel(ConvArgs a) {
     auto issue_raw = [&](int k) {  // halo of quarter k into raw slot k % 3 (out of range beyond the tile's last quarter)
       float* dst = rawbuf + (k % 3) * W4_RAW_FLOATS + pw * 256;
       const bool s1 = k >= Q0;
-      const unsigned off = k < Q ? (s1 ? off1 : off0) : 0xFFFFFF00u;
-      const int so = k < Q ? (s1 ? (k - Q0) * 16 : k * 16) : 0;
+      const unsigned off = k < qend ? (s1 ? off1 : off0) : 0xFFFFFF00u;
+      const int so = k < qend ? (s1 ? (k - Q0) * 16 : k * 16) : 0;
       if (W4_EXP & 8) return;
       if (s1)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc1, (__attribute__((address_space(3))) void*)dst, 16, off, so, 0, 0);
@@ -241,8 +248,8 @@ __global__ __launch_bounds__(768) void conv3x3_wino4_kernel(ConvArgs a) {
     const int w_tile = P.ntile * Q * (W4_Q_FLOATS * 4);
     auto issue_w = [&](int k) {  // weights of quarter k into this wave's ring slot k & 1
       __attribute__((address_space(3))) void* l = (__attribute__((address_space(3))) void*)(wring + (k & 1) * W4_W_FLOATS);
-      const unsigned lo = k < Q ? w_lane : 0xFFFFFF00u;
-      const int so = k < Q ? w_tile + k * (W4_Q_FLOATS * 4) : 0;
+      const unsigned lo = k < qend ? w_lane : 0xFFFFFF00u;
+      const int so = k < qend ? w_tile + k * (W4_Q_FLOATS * 4) : 0;
       if (W4_EXP & 1) return;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, l, 16, lo, so, 0, 0);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, l, 16, lo, so, 1024, 0);
@@ -324,16 +331,16 @@ __global__ __launch_bounds__(768) void conv3x3_wino4_kernel(ConvArgs a) {
       for (int n = 0; n < 6; ++n) vw[n * 3 * 64 * 4] = v[n];
     };
 
-    // ---- prologue: raw 0..2, weights 0..1; transform quarter 0
-    issue_raw(0);
-    issue_w(0);
-    issue_raw(1);
-    issue_raw(2);
-    issue_w(1);
+    // ---- prologue: raw 0..2, weights 0..1 (counted from the slice's first quarter); transform its first quarter
+    issue_raw(qbeg);
+    issue_w(qbeg);
+    issue_raw(qbeg + 1);
+    issue_raw(qbeg + 2);
+    issue_w(qbeg + 1);
     __builtin_amdgcn_s_waitcnt(0x0F78);  // vmcnt(8): raw 0 has landed (this wave's piece)
     __builtin_amdgcn_s_barrier();
-    t_rows(0);
-    t_cols_store(0);
+    t_rows(qbeg);
+    t_cols_store(qbeg);
     f32x16 acc[6];
 #pragma unroll
     for (int x = 0; x < 6; ++x)
@@ -364,7 +371,7 @@ __global__ __launch_bounds__(768) void conv3x3_wino4_kernel(ConvArgs a) {
     // keeps its producer duties -- transform, transfers, barriers -- and skips its fragment reads and MFMAs, a third to two thirds of its SIMD's matrix work
     auto quarters = [&](auto mm_tag) __attribute__((always_inline)) {
     constexpr bool MM = decltype(mm_tag)::value;
-    for (int q = 0; q < Q; ++q) {
+    for (int q = qbeg; q < qend; ++q) {
       const float* wsl = wring + (q & 1) * W4_W_FLOATS + lane * 4;
       const float* vrd = vbuf + (q & 1) * W4_V_FLOATS + vr0;
       f32x4 wf[3], vf[3];
@@ -469,7 +476,7 @@ __global__ __launch_bounds__(768) void conv3x3_wino4_kernel(ConvArgs a) {
 #pragma unroll
         for (int n = 0; n < 6; ++n) z[n] = *reinterpret_cast<const f32x4*>(exch + (((n * 4 + aa) * 4 + k) * 64 + lane) * 4);
         const int co = P.ntile * 64 + round * 32 + 8 * k + 4 * lh;
-        const f32x4 bias = *reinterpret_cast<const f32x4*>(a.bias + co);
+        const f32x4 bias = KS ? f32x4{0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4*>(a.bias + co);
         const f32x4 s12 = z[1] + z[2], d12 = z[1] - z[2], s34 = z[3] + z[4], d34 = z[3] - z[4];
         f32x4 y[4];
         y[0] = ((z[0] + s12) + s34) + bias;
@@ -478,7 +485,7 @@ __global__ __launch_bounds__(768) void conv3x3_wino4_kernel(ConvArgs a) {
         y[3] = ((d12 + 8.f * d34) + z[5]) + bias;
         const int oy = P.y0 + 4 * ty + aa, ox = P.x0 + 4 * tx;
         if (oy < a.H && co < a.coutp) {
-          float* const dp = a.dst + ((size_t)(P.b * a.H + oy) * a.W + ox) * a.coutp + co;
+          float* const dp = a.dst + ((size_t)(P.b * a.H + oy) * a.W + ox) * a.coutp + co + (KS ? (size_t)ksl * a.split_stride : (size_t)0);
 #pragma unroll
           for (int bb = 0; bb < 4; ++bb) {
             if (ox + bb >= a.W) continue;
@@ -505,6 +512,8 @@ __global__ __launch_bounds__(768) void conv3x3_wino4_kernel(ConvArgs a) {
 int prepare_wino4_kernels() {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wino4_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS_FLOATS * (int)sizeof(float));
   if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wino4_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS_FLOATS * (int)sizeof(float));
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wino4_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS_FLOATS * (int)sizeof(float));
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wino4_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS_FLOATS * (int)sizeof(float));
   if (e != hipSuccess) {
     set_error("hipFuncSetAttribute(wino4) failed: %s", hipGetErrorString(e));
     return PH_E_HIP;
@@ -521,18 +530,45 @@ bool wino4_fits(const ConvArgs& a) {
   if (px * (uint64_t)a.c0p * 4 >= 0xFFFFFF00ull || px * (uint64_t)a.c1p * 4 >= 0xFFFFFF00ull || px >= 0x7FFFFFFFull) return false;
   const uint64_t wbytes = (uint64_t)((a.coutp + 63) / 64) * (uint64_t)((a.c0p + a.c1p) / 4) * W4_Q_FLOATS * 4;
   if (wbytes >= 0xFFFFFF00ull) return false;
-  // Against the F(2x2,3x3) kernel, which would run the layer otherwise: this kernel is worth ~1.3x per pixel at equal tile fill (measured, cfg3), but its
-  // workgroup tile is 32 x 16 pixels against 16 x 16 -- it pads more on small maps (12 x 12: 28 % against 56 % fill) and has half as many tiles to deal
-  // over the CUs (cfg3's 64 x 64 decoder level at 4 frames: 128 tiles x N tiles for 256 CUs).  Compare the two kernels' times in units of
-  // "rounds of the chip x time per tile" (one persistent workgroup per CU; a tile here costs 2 / 1.3 of a tile there).
+  // Against the F(2x2,3x3) kernel, which would run the layer otherwise.  Both kernels run one persistent workgroup per CU, so a launch costs rounds-of-the-chip x time per unit;
+  // measured unit times (cfg3 layers, K from 128 to 768 channels): F(2x2,3x3) ~8 us of prologue + epilogue + 2.0 us per half (8 channels) for a 16 x 16-pixel tile, this kernel
+  // ~8 us + 1.6 us per quarter (4 channels) for a 32 x 16 one (768 -> 256 at 64 x 64, 32 frames: 4 rounds x 315 us = 1.26 ms measured 1.24; F(2x2,3x3): 8 x 200 = 1.60, measured 1.62),
+  // a split-K second stage ~8 us.  Each kernel is priced at the K split it would take (wino4_ksplit_shape / wino2d_ksplit_shape); large batches reduce to the old 2 / 1.3 rule.
   if (a.use_wino4 >= 2) return true;  // forced (handle option conv_wino4 = 3: tests, the timing harness)
   int n_cu = 0;
   if (device_cu_count(&n_cu) != PH_OK || n_cu <= 0) n_cu = 256;
+  const bool may_split = a.split_scratch != nullptr;
+  const int ks4 = may_split ? wino4_ksplit_shape(a.B, a.H, a.W, a.c0p + a.c1p, a.coutp, a.splitk, n_cu) : 1;
+  const int ks2 = may_split ? wino2d_ksplit_shape(a.B, a.H, a.W, a.c0p + a.c1p, a.coutp, a.splitk, n_cu) : 1;
   const long ntc = (a.coutp + 63) / 64;
   const long t4 = (long)((a.H + W4_PH - 1) / W4_PH) * ((a.W + W4_PW - 1) / W4_PW) * a.B * ntc;
   const long t2 = (long)((a.H + 15) / 16) * ((a.W + 15) / 16) * a.B * ntc;
-  const double cost4 = (double)((t4 + n_cu - 1) / n_cu) * (2.0 / 1.3), cost2 = (double)((t2 + n_cu - 1) / n_cu);
+  const double Qn = (a.c0p + a.c1p) / 4.0;
+  const double cost4 = (double)((t4 * ks4 + n_cu - 1) / n_cu) * (8.0 + 1.6 * Qn / ks4) + (ks4 > 1 ? 8.0 : 0.0);
+  const double cost2 = (double)((t2 * ks2 + n_cu - 1) / n_cu) * (8.0 + 1.0 * Qn / ks2) + (ks2 > 1 ? 8.0 : 0.0);
   return cost4 <= cost2;
+}
+
+// K slices a layer of this shape takes on this kernel (1 = no split): where its units fill less than half of the CUs; a slice keeps at least 16 quarters (64 channels)
+int wino4_ksplit_shape(int B, int H, int W, int cinp, int coutp, int splitk, int n_cu) {
+  if (splitk <= 0 || cinp < 128) return 1;
+  const long units = (long)((H + W4_PH - 1) / W4_PH) * ((W + W4_PW - 1) / W4_PW) * B * ((coutp + 63) / 64);
+  const int q = cinp / 4;
+  if (splitk >= 2) return std::max(1, std::min(splitk, q / 4));
+  if (units * 2 > n_cu) return 1;
+  return (int)std::max<long>(1, std::min<long>(n_cu / units, q / 16));
+}
+int64_t wino4_split_scratch_bytes(int B, int H, int W, int cinp, int coutp, int splitk, int n_cu) {
+  if ((H & 3) || (W & 3)) return 0;
+  const int ks = wino4_ksplit_shape(B, H, W, cinp, coutp, splitk, n_cu);
+  return ks > 1 ? (int64_t)ks * B * H * W * coutp * 4 : 0;
+}
+static int wino4_ksplit(const ConvArgs& a) {
+  if (!a.split_scratch || a.relu_mask_src) return 1;
+  int n_cu = 0;
+  if (device_cu_count(&n_cu) != PH_OK || n_cu <= 0) return 1;
+  const int ks = wino4_ksplit_shape(a.B, a.H, a.W, a.c0p + a.c1p, a.coutp, a.splitk, n_cu);
+  return (ks > 1 && (int64_t)ks * a.B * a.H * a.W * a.coutp * 4 <= a.split_scratch_bytes) ? ks : 1;
 }
 
 int launch_conv3x3_wino4(const ConvArgs& a, hipStream_t s) {
@@ -542,6 +578,21 @@ int launch_conv3x3_wino4(const ConvArgs& a, hipStream_t s) {
   if (rc != PH_OK) return rc;
   const int tiles = ((a.W + W4_PW - 1) / W4_PW) * ((a.H + W4_PH - 1) / W4_PH) * a.B;
   const int ntc = (a.coutp + 63) / 64;
+  const int ksplit = wino4_ksplit(a);
+  if (ksplit > 1) {  // split K: raw partial sums per slice, then the fixed-order second stage (bias, ReLU)
+    ConvArgs k = a;
+    k.dst = a.split_scratch;
+    k.relu = 0;
+    k.ksplit = ksplit;
+    k.split_stride = (long long)a.B * a.H * a.W * a.coutp;
+    const dim3 grid(std::min(tiles * ntc * ksplit, n_cu));
+    if (a.src1_lowres)
+      hipLaunchKernelGGL((conv3x3_wino4_kernel<true, true>), grid, dim3(768), (size_t)W4_LDS_FLOATS * sizeof(float), s, k);
+    else
+      hipLaunchKernelGGL((conv3x3_wino4_kernel<false, true>), grid, dim3(768), (size_t)W4_LDS_FLOATS * sizeof(float), s, k);
+    PH_HIP_CHECK(hipGetLastError());
+    return launch_splitk_reduce(a.split_scratch, k.split_stride, ksplit, a.bias, a.dst, nullptr, a.B, a.H, a.W, a.coutp, a.relu, s);
+  }
   if (a.src1_lowres)
     hipLaunchKernelGGL(conv3x3_wino4_kernel<true>, dim3(std::min(tiles * ntc, n_cu)), dim3(768), (size_t)W4_LDS_FLOATS * sizeof(float), s, a);
   else

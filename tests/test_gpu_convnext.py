@@ -247,6 +247,7 @@ def test_cfg4_full_size_training_properties():
     m.bind_live_params(None)
     m.eval().to(DEV)
     m.set_option("conv_wino4", 3)  # (the F(4x4,3x3) / F(2x2,3x3) choice depends on the tile count, i.e. on the batch: one kernel choice for the bitwise comparison)
+    m.set_option("conv_splitk", 0)  # (and so does the split-K form of either kernel)
     o64 = m(img)["CenteredInstanceConfmapsHead"][:1].clone()
     o1 = m(img[:1])["CenteredInstanceConfmapsHead"]
     torch.cuda.synchronize()

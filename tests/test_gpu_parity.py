@@ -1282,8 +1282,10 @@ def test_workspace_reuse_shrinks_the_footprint_and_changes_no_bit():
         cfg = G.config(z)
         img = torch.from_numpy(z["image"]).squeeze(1).to(DEV)
         for prec in ("exact", "split", "fp16"):
-            a = {k: v.clone() for k, v in _model(cfg, G.weights(z)).set_precision(prec).set_keep_activations(True)(img).items()}
-            m = _model(cfg, G.weights(z)).set_precision(prec)
+            # (split K and the Cout-32 route are inference-plan choices with their own rounding, like conv_wino4 = 1: pinned off so that the two plans run the same kernels)
+            pin = lambda mm: mm.set_option("conv_splitk", 0).set_option("conv_n32_wino2d", 0)
+            a = {k: v.clone() for k, v in pin(_model(cfg, G.weights(z))).set_precision(prec).set_keep_activations(True)(img).items()}
+            m = pin(_model(cfg, G.weights(z))).set_precision(prec)
             b = m(img)
             assert m.get_option("workspace_reuse") == 1.0
             for k in a:
@@ -1321,6 +1323,8 @@ def test_unfused_program_with_shared_slots_survives_forwarded_writes():
             m.set_option("pool_peephole", 1)
             m.set_option("dw_ln_fuse", ln)
             m.set_option("conv_wino4", 0)  # (the F(4x4,3x3) kernel is another plan-dependent choice with its own rounding: out of this comparison)
+            m.set_option("conv_splitk", 0)  # (so are split K and the Cout-32 route)
+            m.set_option("conv_n32_wino2d", 0)
             outs.append({k: v.clone() for k, v in m(img).items()})
             assert m.get_option("workspace_reuse") == float(reuse)
         for k in outs[0]:

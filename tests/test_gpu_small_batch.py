@@ -234,3 +234,30 @@ def test_cout32_layers_on_the_half_empty_n_tile_of_the_winograd_kernel(filters, 
         assert last_concat == (L.KV_WINO2D if opt else L.KV_WINO1D), (opt, last_concat)
     _close(outs[1], ref, "n32 on wino2d")
     assert (outs[1] - outs[0]).abs().max().item() <= 2e-5 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("filters,max_stride,hw,batch,out_stride,splitk", [(32, 8, (64, 64), 1, 4, 3), (32, 16, (64, 96), 2, 4, 2), (16, 32, (128, 128), 1, 4, 5), (16, 32, (256, 256), 2, 4, 1)])
+def test_split_k_form_of_the_f4x4_kernel_matches_the_one_stage_kernel_and_the_oracle(filters, max_stride, hw, batch, out_stride, splitk):
+    """conv3x3_wino4_kernel<.., KS> + splitk_reduce_kernel: K slices in quarters through both concat sources incl. the folded-bilinear (half-resolution) second source, forced slice
+    counts (conv_wino4 = 3 puts every fitting layer on the kernel) and the default cost-routed choice (1: F(4x4,3x3) vs F(2x2,3x3), each priced at the split it would take); vs the oracle
+    at the F(4x4,3x3) bar (1e-5 of the tensor's scale), vs the unsplit kernels, bitwise repeatable."""
+    from sleap_nn_amd.architectures.model import Model
+
+    bb = dict(SI_BB, filters=filters, max_stride=max_stride, output_stride=out_stride)
+    heads = {"confmaps": {"part_names": ["a", "b", "c"], "output_stride": out_stride}}
+    sd = O.init_state(bb, heads, "single_instance", seed=filters + hw[0] + splitk, head_scale=1.0)
+    img = torch.randint(0, 256, (batch, 1, hw[0], hw[1]), dtype=torch.uint8, generator=torch.Generator().manual_seed(hw[1] + splitk))
+    ref = O.model_forward(sd, bb, heads, "single_instance", img)["SingleInstanceConfmapsHead"]
+    outs = {}
+    for name, ks in (("split", splitk), ("one", 0)):
+        m = Model("unet", bb, heads, "single_instance")
+        m.load_state_dict(sd)
+        if splitk != 1:
+            m.set_option("conv_wino4", 3)
+        m.set_option("conv_splitk", ks)
+        outs[name] = m.to(DEV)(img.to(DEV))["SingleInstanceConfmapsHead"].cpu()
+        assert torch.equal(m(img.to(DEV))["SingleInstanceConfmapsHead"].cpu(), outs[name])
+        if name == "split" and splitk != 1:
+            assert L.KV_WINO4 in m.last_kernels()
+    _close(outs["split"], ref, "wino4 split")
+    assert (outs["split"] - outs["one"]).abs().max().item() <= 3e-5 * ref.abs().max().item()
