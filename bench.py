@@ -294,6 +294,8 @@ def run_infer(args, ctx):
     eager = HipBackend(model, str(dev), precision=precision) if use_graph else backend  # same model handle: the profiled steps launch kernel by kernel
     layer = BottomUpLayer(backend, PAFScorer.from_config(CFG3_HEADS), 4, 8, max_stride=32)
     frames = host_frames.to(dev)
+    if use_graph:  # the resident frames live in the graph's own input buffer (HipBackend.static_input): a step's forward is one graph launch, no staging copy in front
+        frames = backend.static_input((B, 1, SIZE, SIZE)).copy_(frames.squeeze(1))
     cms, pafs = rendered_heads(B, dev)
     info = PreprocInfo(original_size=(SIZE, SIZE), processed_size=(SIZE, SIZE), eff_scale=torch.ones(B), output_stride=4)
 
@@ -368,7 +370,7 @@ def run_infer(args, ctx):
         def upload(k):
             with torch.cuda.stream(copy_stream):
                 copy_stream.wait_event(consumed[k & 1])  # the step that last read this buffer is done with it
-                bufs[k & 1].copy_(host_frames, non_blocking=True)
+                bufs[k & 1].copy_(host_frames.view(bufs[0].shape), non_blocking=True)
                 landed[k & 1].record(copy_stream)
 
         for e in consumed:
@@ -454,7 +456,9 @@ def run_infer(args, ctx):
         for sb in (8, 4):
             scms, spafs = rendered_heads(sb, dev)
             heads_in.update(cms=scms, pafs=spafs, info=PreprocInfo(original_size=(SIZE, SIZE), processed_size=(SIZE, SIZE), eff_scale=torch.ones(sb), output_stride=4))
-            sframes = frames[:sb].contiguous()
+            sframes = frames.reshape(B, 1, SIZE, SIZE)[:sb].contiguous()
+            if use_graph:
+                sframes = backend.static_input((sb, 1, SIZE, SIZE)).copy_(sframes)
             for _ in range(5):
                 step(sframes)
             drain()
