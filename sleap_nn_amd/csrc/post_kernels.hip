@@ -367,7 +367,7 @@ __global__ __launch_bounds__(256) void peaks_place_kernel(const float* __restric
                                                           int* __restrict__ out_sample, int* __restrict__ out_channel, int* __restrict__ out_count, int cap) {
   __shared__ int red[8];
   __shared__ int s_off[2];
-  const int blk = blockIdx.x, n_blk = B * groups;
+  const int blk = blockIdx.x;
   // exclusive offset of this block = sum of the counts of the blocks before it (integers: the order of the partial sums does not matter)
   int part = 0;
   for (int i = threadIdx.x; i < blk; i += 256) part += blk_count[i];
@@ -445,7 +445,6 @@ __global__ __launch_bounds__(256) void peaks_place_kernel(const float* __restric
       out_count[1 + 2 * B] = s_off[0];
     }
   }
-  (void)n_blk;
 }
 
 // scratch that lets ph_local_peaks take the one-pass path (0: the shape is outside it -- more than 64 channels or maps wider than 512 -- and the three-pass kernels run)

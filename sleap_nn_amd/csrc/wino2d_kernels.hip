@@ -899,38 +899,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   if (r >= (size_t)B * Hp * Wp) return;
   const int px = (int)(r % Wp);
   r /= Wp;
-  const int py = (int)(r % Hp), b = (int)(r / Hp);
-  f32x4 pooled = {0.f, 0.f, 0.f, 0.f};
-  bool first = true, padded = false;
-#pragma unroll
-  for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-    for (int dx = 0; dx < 2; ++dx) {
-      const int oy = 2 * py + dy, ox = 2 * px + dx;
-      if (oy >= H || ox >= W) {
-        padded = true;
-        continue;
-      }
-      const size_t idx = ((size_t)(b * H + oy) * W + ox) * coutp + c4 * 4;
-      f32x4 v = splitk_sum(part + idx, stride, ks) + bv;
-      if (relu) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-      }
-      if (dst) *reinterpret_cast<f32x4*>(dst + idx) = v;
-      if (first) {
-        pooled = v;
-        first = false;
-      } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) pooled[e] = fmaxf(pooled[e], v[e]);
-      }
-    }
-  if (padded) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) pooled[e] = fmaxf(pooled[e], 0.f);
-  }
-  *reinterpret_cast<f32x4*>(dst_pool + ((size_t)(b * Hp + py) * Wp + px) * coutp + c4 * 4) = pooled;
+  splitk_finish_window(part, stride, ks, bv, dst, dst_pool, (int)(r / Hp), (int)(r % Hp), px, c4 * 4, H, W, coutp, relu);
 }
 
 // the second stage of a split-K launch (either Winograd kernel): dst (unless nullptr) and dst_pool (unless nullptr: then dst may be nullptr) from the ks planes of `part`
