@@ -492,6 +492,34 @@ int launch_local_peaks(const float* cms, int B, int C, int H, int W, float thr, 
 // K11: global peaks.  One block per (sample, channel) plane: max value, then the first
 // column and (independently) the first row that contain it.
 // ---------------------------------------------------------------------------------------
+// Round 4: ONE pass with 16-byte loads.  A thread keeps (max, first column holding it, first row holding it) over its elements -- a larger value replaces all three, an equal one
+// lowers the column and the row independently -- and the (associative) combination of those triples over the block is the same "value = max, x = first column containing the max,
+// y = first row containing the max" as two passes (peaks.py:89-181); NaN compares false both ways and is skipped, as fmaxf skipped it.  Four quads per thread are in flight per trip
+// (the two-pass scalar loop streamed a 256-KiB plane at ~3 GB/s per block: 80 us for cfg2's 104 planes).
+struct GPeak {
+  float m;
+  int x, y;
+};
+__device__ __forceinline__ void gpeak_take(GPeak& p, float v, int x, int y) {
+  if (v > p.m) {
+    p.m = v;
+    p.x = x;
+    p.y = y;
+  } else if (v == p.m) {
+    p.x = min(p.x, x);
+    p.y = min(p.y, y);
+  }
+}
+__device__ __forceinline__ void gpeak_merge(GPeak& p, float m, int x, int y) {
+  if (m > p.m) {
+    p.m = m;
+    p.x = x;
+    p.y = y;
+  } else if (m == p.m) {
+    p.x = min(p.x, x);
+    p.y = min(p.y, y);
+  }
+}
 __global__ __launch_bounds__(256) void global_peaks_kernel(const float* __restrict__ cms, int H, int W, float thr, int refine, int patch,
                                                            float* __restrict__ out_xy, float* __restrict__ out_val) {
   __shared__ float smax[4];
@@ -500,33 +528,52 @@ __global__ __launch_bounds__(256) void global_peaks_kernel(const float* __restri
   const float* plane = cms + (size_t)pc * H * W;
   const int n = H * W;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float m = -INFINITY;
-  for (int i = threadIdx.x; i < n; i += 256) m = fmaxf(m, plane[i]);
+  GPeak p{-INFINITY, 0x7fffffff, 0x7fffffff};
+  if ((W & 3) == 0 && (reinterpret_cast<uintptr_t>(plane) & 15) == 0) {
+    const int nq = n >> 2, wq = W >> 2;
+    const float4* q4 = reinterpret_cast<const float4*>(plane);
+    int i = threadIdx.x;
+    for (; i + 3 * 256 < nq; i += 4 * 256) {
+      float4 v[4];
 #pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
-  if (lane == 0) smax[wave] = m;
-  __syncthreads();
-  m = fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]));
-  int mx = 0x7fffffff, my = 0x7fffffff;
-  for (int i = threadIdx.x; i < n; i += 256)
-    if (plane[i] == m) {
-      const int y = i / W, x = i - y * W;
-      mx = min(mx, x);
-      my = min(my, y);
+      for (int k = 0; k < 4; ++k) v[k] = q4[i + k * 256];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int q = i + k * 256, y = q / wq, x = 4 * (q - y * wq);
+        gpeak_take(p, v[k].x, x, y);
+        gpeak_take(p, v[k].y, x + 1, y);
+        gpeak_take(p, v[k].z, x + 2, y);
+        gpeak_take(p, v[k].w, x + 3, y);
+      }
     }
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) {
-    mx = min(mx, __shfl_xor(mx, d, 64));
-    my = min(my, __shfl_xor(my, d, 64));
+    for (; i < nq; i += 256) {
+      const float4 v = q4[i];
+      const int y = i / wq, x = 4 * (i - y * wq);
+      gpeak_take(p, v.x, x, y);
+      gpeak_take(p, v.y, x + 1, y);
+      gpeak_take(p, v.z, x + 2, y);
+      gpeak_take(p, v.w, x + 3, y);
+    }
+  } else {
+    for (int i = threadIdx.x; i < n; i += 256) {
+      const int y = i / W;
+      gpeak_take(p, plane[i], i - y * W, y);
+    }
   }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) gpeak_merge(p, __shfl_xor(p.m, d, 64), __shfl_xor(p.x, d, 64), __shfl_xor(p.y, d, 64));
   if (lane == 0) {
-    sminx[wave] = mx;
-    sminy[wave] = my;
+    smax[wave] = p.m;
+    sminx[wave] = p.x;
+    sminy[wave] = p.y;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    mx = min(min(sminx[0], sminx[1]), min(sminx[2], sminx[3]));
-    my = min(min(sminy[0], sminy[1]), min(sminy[2], sminy[3]));
+    GPeak t{smax[0], sminx[0], sminy[0]};
+#pragma unroll
+    for (int w = 1; w < 4; ++w) gpeak_merge(t, smax[w], sminx[w], sminy[w]);
+    const float m = t.m;
+    const int mx = t.x, my = t.y;
     if (m < thr || mx == 0x7fffffff) {
       const float nanv = __builtin_nanf("");
       out_xy[2 * (size_t)pc] = (m < thr) ? nanv : 0.f;

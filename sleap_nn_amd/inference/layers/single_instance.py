@@ -14,6 +14,7 @@ from sleap_nn_amd.inference.preprocess_info import PreprocInfo
 
 class SingleInstanceLayer(InferenceLayer):
     _HEAD_OUTPUT_KEY = "SingleInstanceConfmapsHead"
+    _GRAPHABLE_POSTPROCESS = True  # global peaks + refinement + the coordinate ladder: all device work (``predict_graphed``)
 
     def __init__(self, backend: ModelBackend, output_stride: int, max_stride: int = 1, preprocess_config: Optional[PreprocessConfig] = None, postprocess_config: Optional[PostprocessConfig] = None) -> None:
         super().__init__(backend, preprocess_config or PreprocessConfig(), postprocess_config or PostprocessConfig(), output_stride, max_stride)

@@ -58,9 +58,25 @@ def test_cfg1_single_instance_256_batch1_network_and_global_peaks():
     buf.copy_(img[1:2])
     other = layer.backend(buf)["SingleInstanceConfmapsHead"].cpu()
     assert not torch.equal(other, first) and torch.equal(other, layer.backend(img[1:2])["SingleInstanceConfmapsHead"].cpu())
+    # the whole step as one graph (forward + global peaks + refinement + coordinate ladder): same bits as predict, and it follows a refill of its input buffer
+    from sleap_nn_amd.inference.layers import PostprocessConfig
+
+    layer.postprocess_config = PostprocessConfig(peak_threshold=-1.0)  # (random-weight maps sit below the default threshold: every keypoint would be NaN)
+    gin = layer.graph_input((1, 1, 256, 256))
+    gin.copy_(img[:1])
+    eager_out = layer.predict(img[:1])
+    g_out = layer.predict_graphed(gin)
+    assert torch.isfinite(eager_out.pred_keypoints).all()
+    assert torch.equal(g_out.pred_keypoints, eager_out.pred_keypoints) and torch.equal(g_out.pred_peak_values, eager_out.pred_peak_values)
+    gin.copy_(img[1:2])
+    g2 = layer.predict_graphed(gin)
+    e2 = layer.predict(img[1:2])
+    assert torch.equal(g2.pred_keypoints, e2.pred_keypoints) and not torch.equal(e2.pred_keypoints, eager_out.pred_keypoints)
+    assert torch.equal(layer.predict_graphed(img[:1]).pred_keypoints, eager_out.pred_keypoints)  # a foreign tensor is copied into the graph's buffer
     raw = layer.backend(img[:1])["SingleInstanceConfmapsHead"]
     codes = m.last_kernels()
     assert L.KV_WINO2D_KS in codes, codes  # the default routing of this batch takes the split-K form somewhere
+    layer.postprocess_config = PostprocessConfig()
     out = layer.postprocess({"SingleInstanceConfmapsHead": raw}, PreprocInfo(eff_scale=torch.ones(1), output_stride=2))
     rk, rv = O.single_instance_postprocess(first, 2)
     assert np.allclose(out.pred_keypoints.cpu().numpy(), rk.numpy(), atol=1e-4, equal_nan=True)
