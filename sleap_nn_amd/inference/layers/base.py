@@ -165,7 +165,10 @@ class InferenceLayer(ABC):
             # torchvision's rgb_to_grayscale (data/normalization.py:37-51): float32 weighted sum in this order, cast back to the input dtype
             r, g, b = x.unbind(dim=-3)
             x = r.mul(0.2989).add_(g, alpha=0.587).add_(b, alpha=0.114).unsqueeze(-3).to(x.dtype)
-        if not skip_sizematcher and (cfg.max_height is not None or cfg.max_width is not None):
+        sized = not skip_sizematcher and (cfg.max_height is not None or cfg.max_width is not None)
+        if sized and (cfg.max_height is None or cfg.max_height == x.shape[-2]) and (cfg.max_width is None or cfg.max_width == x.shape[-1]):
+            sized = False  # every frame already has the target size: apply_sizematcher would hand each back untouched with scale 1 -- no per-sample loop, no re-stacking of the batch on the host
+        if sized:
             frames, effs = [], []
             for b in range(B):  # per sample, as the reference does (frames of one batch share a size here, the loop keeps its contract)
                 r, e = apply_sizematcher(x[b], cfg.max_height, cfg.max_width)
