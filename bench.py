@@ -845,7 +845,8 @@ SI_BB = {"in_channels": 1, "kernel_size": 3, "filters": 16, "filters_rate": 2, "
          "stacks": 1, "convs_per_block": 2, "output_stride": 2}
 # docs/guides/inference-performance.md:40-48,70-77: the only numbers the reference publishes, NVIDIA A40 / CUDA 12.8 / torch 2.9.1
 PUBLISHED_A40 = {"bottomup_forward_ms_per_batch4": {"eager_fp32": 3.59, "torch_compile": 2.94, "fp16_autocast": 2.32}, "bottomup_end_to_end_fps": 137.0,
-                 "single_instance_forward_ms_per_batch4": {"eager_fp32": 1.20, "torch_compile": 0.93, "fp16_autocast": 0.84}, "single_instance_end_to_end_fps": 228.0}
+                 "single_instance_forward_ms_per_batch4": {"eager_fp32": 1.20, "torch_compile": 0.93, "fp16_autocast": 0.84}, "single_instance_end_to_end_fps": 228.0,
+                 "centroid_forward_ms_per_batch4": {"eager_fp32": 2.48, "torch_compile": 1.96, "fp16_autocast": 1.61}, "topdown_end_to_end_fps": 95.0}
 
 
 def _forward_profile(model, x, n=10):
@@ -1033,6 +1034,40 @@ def published_workload_leg(steps, dev):
         si["what"] = "fixture single-instance run directory: forward on (4, 1, 160, 280) (input scale 0.5 of the 320 x 560 frames), Predictor.predict over the same 100 host frames (antialiased resize + forward + global peaks)"
     except Exception as e:  # the headline legs must not die on the extra fixture
         si = {"error": repr(e)}
+    # two-stage top-down (centroid -> crops -> centered instance) on the reference's fixture models (tests/golden/topdown.npz holds their weights and configs)
+    td = {}
+    try:
+        from sleap_nn_amd.architectures.model import Model
+        from sleap_nn_amd.inference.layers import CenteredInstanceLayer, CentroidLayer, PostprocessConfig, TopDownLayer
+
+        tz = np.load(os.path.join(ROOT, "tests", "golden", "topdown.npz"), allow_pickle=False)
+        tcfg = json.loads(str(tz["config_json"]))
+        cc, ci = tcfg["centroid"], tcfg["centered"]
+        wsel = lambda pre: {k[len(pre):]: torch.from_numpy(tz[k]) for k in tz.files if k.startswith(pre)}
+        mc = Model("unet", cc["backbone"], cc["heads"], "centroid")
+        mc.load_state_dict(wsel("wc/"))
+        mi = Model("unet", ci["backbone"], ci["heads"], "centered_instance")
+        mi.load_state_dict(wsel("wi/"))
+        cbe = HipBackend(mc, str(dev), use_graph=True)
+        cl = CentroidLayer(cbe, cc["heads"]["confmaps"]["output_stride"], max_instances=6, max_stride=cc["backbone"]["max_stride"], postprocess_config=PostprocessConfig(peak_threshold=0.03, max_instances=6))
+        il = CenteredInstanceLayer(HipBackend(mi, str(dev)), ci["heads"]["confmaps"]["output_stride"], max_stride=ci["backbone"]["max_stride"], postprocess_config=PostprocessConfig(peak_threshold=0.03))
+        tdl = TopDownLayer(cl, il, (tcfg["crop_size"], tcfg["crop_size"]))
+        tframes = torch.from_numpy(tz["image"]).to(dev)
+        tframes = tframes.reshape(-1, *tframes.shape[-3:])
+        tframes = tframes.repeat((4 + tframes.shape[0] - 1) // tframes.shape[0], 1, 1, 1)[:4].contiguous()
+        cx = cbe.static_input(tuple(tframes.shape)).copy_(tframes)
+        n = max(steps, 200)
+        tot, _ = _time_calls(lambda: cbe(cx), n, 20, False)
+        td["centroid_forward_ms_per_batch"] = 1e3 * tot / n
+        tout = tdl.predict(tframes)
+        tot, _ = _time_calls(lambda: tdl.predict(tframes), 100, 10, False)
+        td["end_to_end_ms_per_batch"] = 1e3 * tot / 100
+        td["end_to_end_fps"] = 4 * 100 / tot
+        td["instances_per_batch"] = int(torch.isfinite(tout.pred_centroids[..., 0]).sum())
+        td["vs_baseline"] = {"centroid_forward_eager_fp32": ref["centroid_forward_ms_per_batch4"]["eager_fp32"] / td["centroid_forward_ms_per_batch"], "end_to_end_fps": td["end_to_end_fps"] / ref["topdown_end_to_end_fps"]}
+        td["what"] = f"fixture top-down models (tests/golden/topdown.npz): {tuple(tframes.shape)} uint8 frames resident in HBM, centroid forward (hipGraph) and TopDownLayer.predict (centroid -> NMS peaks -> {tcfg['crop_size']} x {tcfg['crop_size']} crops -> centered-instance forward -> global peaks; three data-dependent host reads per batch)"
+    except Exception as e:
+        td = {"error": repr(e)}
     return {"metric": "ms per batch of 4, bottom-up backbone forward (the reference's published table)", "value": fwd["exact_fp32"], "unit": "ms/batch", "higher_is_better": False, "steps": max(steps, 200),
             "dtype": "f32", "data": "reference fixture checkpoint (tests/golden/ckpt_dirs/minimal_instance_bottomup), synthetic uint8 frames",
             "config": {"workload": "published: fixture bottom-up UNet (f16, rate 1.5, max_stride 8, transposed-conv decoder, 2 nodes / 1 edge), 320x560x1 uint8, batch 4", "frames_per_step": 4,
@@ -1043,7 +1078,7 @@ def published_workload_leg(steps, dev):
             "vs_baseline": {"forward_eager_fp32": ref["bottomup_forward_ms_per_batch4"]["eager_fp32"] / fwd["exact_fp32"], "forward_fp16": ref["bottomup_forward_ms_per_batch4"]["fp16_autocast"] / fwd["fp16_autocast_equivalent"],
                             "end_to_end_fps": e2e / ref["bottomup_end_to_end_fps"], "reference": ref, "reference_hardware": "NVIDIA A40, CUDA 12.8, torch 2.9.1 (docs/guides/inference-performance.md:3-7,40-48,70-77)",
                             "note": "ratios > 1 = this build faster; different hardware and (end to end) no video decoding here: a like-for-like of the workload, not of the machine"},
-            "single_instance": si,
+            "single_instance": si, "topdown": td,
             "roofline": _small_roofline(executed, direct, matrix_ms, fwd_s, kernels, len(table))}
 
 
