@@ -498,7 +498,11 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void gemm_mfma_dma_tile_kernel(G
   constexpr int STAGE_FLOATS = (A_PIECES + B_PIECES) * 256;
   static_assert((NSTAGE - 2) * NDMA < 64 && NSTAGE >= 2 && WAVES % 2 == 0, "vmcnt field overflow / odd wave count");
   constexpr int NTAPS_C = MODE == 0 ? 1 : (MODE == 1 ? 4 : 9);
-  const int NTAPS = MODE == 3 ? a.ntaps : (MODE == 5 ? a.ksize * a.ksize : NTAPS_C);  // mode 3: 1, 2 or 4 taps by output phase; mode 5: k x k
+  // mode 3 with all_phases: the four output phases of a transposed conv in ONE launch (blockIdx.y = phase: its tap count, weight pack and output offset) -- at small batches
+  // the four phase launches were four launch floors (the reference's fixture bottom-up model at 320 x 560 x 4: 76 + 54 us of a 454-us forward)
+  const int phase = (MODE == 3 && a.all_phases) ? (int)blockIdx.y : a.out_tap;
+  const float* const wpack = (MODE == 3 && a.all_phases) ? a.wpack_ph[phase] : a.wpack;
+  const int NTAPS = MODE == 3 ? (1 + (phase >> 1)) * (1 + (phase & 1)) : (MODE == 5 ? a.ksize * a.ksize : NTAPS_C);  // mode 3: 1, 2 or 4 taps by output phase; mode 5: k x k
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -518,7 +522,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void gemm_mfma_dma_tile_kernel(G
       for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
   const int nstages = ((a.c0p + 31) / 32 + (a.c1p + 31) / 32) * NTAPS;  // 32-channel slices x taps, per source
-  const float* wbase = a.wpack + (size_t)ntile * nstages * (B_PIECES * 256);
+  const float* wbase = wpack + (size_t)ntile * nstages * (B_PIECES * 256);
 
   // ---- DMA plan.  A 1-KiB piece = 8 rows x 128 B (32 channels): every row contributes one whole
   // 128-B cache line per stage (64-B half lines cost twice the L2 -> L1 traffic: each half is
@@ -555,7 +559,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void gemm_mfma_dma_tile_kernel(G
     } else if (MODE == 3) {  // transposed-conv phase: taps reach (y + dy, x + dx), dy, dx in {0, 1}; beyond the image = zero
       const int x = row % a.W;
       const int y = (row / a.W) % a.H;
-      const int py = a.out_tap >> 1, px = a.out_tap & 1;
+      const int py = phase >> 1, px = phase & 1;
       mask = 0;
 #pragma unroll
       for (int tap = 0; tap < 4; ++tap) {
@@ -595,7 +599,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void gemm_mfma_dma_tile_kernel(G
     } else if (MODE == 1) {
       toff = (f_tap >> 1) * a.W + (f_tap & 1);
     } else if (MODE == 3) {
-      const int py = a.out_tap >> 1, px = a.out_tap & 1;
+      const int py = phase >> 1, px = phase & 1;
       const int ty = px ? f_tap >> 1 : f_tap, tx = px ? f_tap & 1 : 0;
       toff = (py ? 1 - ty : 0) * a.W + (px ? 1 - tx : 0);
     } else {
@@ -765,7 +769,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void gemm_mfma_dma_tile_kernel(G
         const int ox = rr % ow;
         const int r2 = rr / ow;
         const int oy = r2 % oh;
-        opix = ((size_t)(r2 / oh) * a.out_H + 2 * oy + (a.out_tap >> 1)) * a.out_W + 2 * ox + (a.out_tap & 1);
+        opix = ((size_t)(r2 / oh) * a.out_H + 2 * oy + (phase >> 1)) * a.out_W + 2 * ox + (phase & 1);
       }
       const size_t rofs = opix * a.coutp;
 #pragma unroll
@@ -1213,7 +1217,7 @@ int launch_gemm_variant(int variant, const GemmArgs& a_in, hipStream_t s) {
   const int persist2 = a.persist2;  // handle option: persistent workgroups for the 9-tap mode too (measured 3-4 % slower than one tile per workgroup)
   PH_REQUIRE(a.M > 0 && a.c0p > 0 && a.c0p % 16 == 0 && a.c1p % 16 == 0 && a.coutp % 16 == 0 && a.mode >= 0 && a.mode <= 5, "launch_gemm: bad shape");
   PH_REQUIRE(a.mode != 5 || ((a.ksize & 1) && a.ksize >= 1 && a.ksize <= 9 && a.M % (a.H * a.W) == 0 && a.H < 65536 && a.W < 65536), "launch_gemm: k x k conv needs an odd kernel <= 9 and whole images");
-  PH_REQUIRE(a.mode != 3 || ((a.ntaps == 1 || a.ntaps == 2 || a.ntaps == 4) && a.ntaps == (1 + (a.out_tap >> 1)) * (1 + (a.out_tap & 1)) && a.out_patch && a.M % (a.H * a.W) == 0),
+  PH_REQUIRE(a.mode != 3 || (((a.all_phases && a.wpack_ph[0] && a.wpack_ph[1] && a.wpack_ph[2] && a.wpack_ph[3]) || ((a.ntaps == 1 || a.ntaps == 2 || a.ntaps == 4) && a.ntaps == (1 + (a.out_tap >> 1)) * (1 + (a.out_tap & 1)))) && a.out_patch && a.M % (a.H * a.W) == 0),
              "launch_gemm: transposed-conv phase needs ntaps matching the phase, out_patch and whole images");
   PH_REQUIRE(a.mode != 4 || (a.H % 2 == 0 && a.W % 2 == 0 && a.M % ((a.H / 2) * (a.W / 2)) == 0), "launch_gemm: stride-2 gather needs even map sizes and whole images");
   PH_REQUIRE(a.mode >= 3 || (!a.affine_first && a.act != 4 && !a.shift), "launch_gemm: affine-first / SiLU epilogues exist for modes 3 and 4 only");
@@ -1246,7 +1250,7 @@ int launch_gemm_variant(int variant, const GemmArgs& a_in, hipStream_t s) {
       if (a.mode == 2)                                                                                                         \
         hipLaunchKernelGGL((gemm_mfma_dma_tile_kernel<2, MT, NTW, WM, WN, S, W>), full, dim3(C::THREADS), C::LDS, s, a);       \
       else if (a.mode == 3)                                                                                                    \
-        hipLaunchKernelGGL((gemm_mfma_dma_tile_kernel<3, MT, NTW, WM, WN, S, W>), full, dim3(C::THREADS), C::LDS, s, a);       \
+        hipLaunchKernelGGL((gemm_mfma_dma_tile_kernel<3, MT, NTW, WM, WN, S, W>), dim3(full.x, a.all_phases ? 4 : 1), dim3(C::THREADS), C::LDS, s, a); \
       else if (a.mode == 5)                                                                                                    \
         hipLaunchKernelGGL((gemm_mfma_dma_tile_kernel<5, MT, NTW, WM, WN, S, W>), full, dim3(C::THREADS), C::LDS, s, a);       \
       else                                                                                                                     \

@@ -1257,7 +1257,7 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
         PH_REQUIRE(s0.c == d.cin0, "convT channel mismatch");
         if (fmt == FMT_F32 && m->convt_phase && op.wt_phase_dev[0]) {  // four output-phase GEMMs: 9 taps per INPUT pixel, no zero-stuffed tensor
           const SlotShape& so = plan.slots[d.dst];
-          for (int ph = 0; ph < 4 && rc == PH_OK; ++ph) {
+          for (int ph = 0; ph < (m->convt_one_launch ? 1 : 4) && rc == PH_OK; ++ph) {  // one launch for the four phases (grid.y), or four launches
             GemmArgs g{};
             g.src0 = slot_ptr(d.src0);
             g.c0p = s0.cp;
@@ -1274,6 +1274,10 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
             g.W = s0.w;
             g.out_patch = 1;
             g.out_tap = ph;
+            if (m->convt_one_launch) {
+              g.all_phases = 1;
+              for (int q = 0; q < 4; ++q) g.wpack_ph[q] = op.wt_phase_dev[q];
+            }
             g.out_H = 2 * s0.h;
             g.out_W = 2 * s0.w;
             g.act = (d.flags & PH_FLAG_SILU) ? 4 : ((d.flags & PH_FLAG_RELU) ? 1 : 0);
@@ -1558,6 +1562,7 @@ std::vector<OptionRef> option_table(ph_model* m) {
       {"wgrad_wino", &m->wgrad_wino, nullptr},          // 3x3 weight gradients: 1 Winograd F(2x2,3x3) domain, 0 direct nine-tap kernel
       {"wgrad_rows", &m->wgrad_rows, nullptr},          // 0 32x32-tile wgrad kernel, 1 auto, 2 nine row-wgrad GEMMs
       {"workspace_reuse", &m->workspace_reuse, nullptr},  // 1: activation slots share memory once their last reader has run (inference programs only)
+      {"convt_one_launch", &m->convt_one_launch, nullptr},  // 1: the four output-phase GEMMs of a transposed conv in one launch (grid.y = phase); 0: four launches
       {"convt_phase", &m->convt_phase, nullptr},        // 0: transposed convs by zero-stuffing + 3x3 conv (4x the FLOPs; A/B reference)
       {"conv_precision", &m->conv_precision, nullptr},  // 0 exact fp32 MFMA, 1 split-fp16 MFMA (22-bit products), 2 plain fp16 (autocast-equivalent)
       {"gemm_late_split", &m->gemm_late_split, nullptr},

@@ -151,6 +151,7 @@ struct ph_model {
   double gemm_fill_threshold_wino = 0.5;      // ... and the (lower) break-even when the halo kernel is the Winograd one
   double gemm_fill_threshold = 0.8;           // 3x3 convs whose maps fill the 16x32 tiles less than this run as row GEMMs
   int workspace_reuse = 0;                    // "workspace_reuse": 1 = slots of an inference program share memory by lifetime (no read-back, no backward)
+  int convt_one_launch = 1;                   // "convt_one_launch": the four output-phase GEMMs of a transposed conv as ONE launch (grid.y = phase) instead of four (four launch floors at small batches)
   int convt_phase = 1;                        // "convt_phase": transposed convs as four phase GEMMs (0: zero-stuffing + 3x3 conv, 4x the FLOPs; A/B)
   int conv_precision = 0;                     // "conv_precision": 0 exact fp32 MFMA; 1 split-fp16 MFMA (22-bit products, fp32 accumulate); 2 plain fp16 (autocast-equivalent)
 };

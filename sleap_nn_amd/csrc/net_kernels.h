@@ -132,6 +132,8 @@ struct GemmArgs {
   int late_split = 0;               // which waves issue their DMA pieces one step late (see gemm_mfma_dma_kernel)
   int persist2 = 0;                 // persistent workgroups for the 9-tap mode too (handle option "gemm_persist2")
   int ntaps = 0;                    // mode 3: taps of this output phase (1, 2 or 4)
+  int all_phases = 0;               // mode 3: ONE launch for the four output phases (grid.y = phase); wpack_ph holds the four phases' weight packs, ntaps / out_tap are ignored
+  const float* wpack_ph[4] = {nullptr, nullptr, nullptr, nullptr};
   int ksize = 0;                    // mode 5: odd kernel size (k x k "same" conv)
   const float* shift = nullptr;     // modes 3, 4 with affine_first: per-channel shift (folded BatchNorm), padded like bias
   int affine_first = 0;             // modes 3, 4: dst = act(scale * (acc + bias) + shift) instead of act(acc + bias) * scale
