@@ -198,6 +198,11 @@ int ph_render_confmaps(const float* points_dev, int32_t B, int32_t I, int32_t N,
 int ph_render_pafs(const float* points_dev, const int32_t* edges_dev, int32_t B, int32_t I, int32_t N, int32_t E,
                    int32_t img_h, int32_t img_w, int32_t stride, float sigma, float* out_dev, void* stream);
 
+/* Diagnostic / test hook (pure host arithmetic, no GPU needed): the split-K plan the 3x3 kernels would take for a layer of this shape on a chip of n_cu CUs
+ * under handle option conv_splitk = splitk (padded channel counts; section 4.1d of DESIGN.md).  out[0] = K slices on the F(2x2,3x3) kernel, out[1] = on the
+ * F(4x4,3x3) kernel (1 = no split), out[2], out[3] = KiB of partial-sum scratch each would need (0 when it does not split). */
+int ph_debug_split_plan(int32_t B, int32_t H, int32_t W, int32_t cin_padded, int32_t cout_padded, int32_t splitk, int32_t n_cu, int64_t* out4);
+
 /* Diagnostic (tools/gemm_bench.py): average milliseconds of one row-GEMM kernel variant on synthetic operands. */
 int ph_debug_gemm_bench(int32_t variant, int32_t M, int32_t K, int32_t N, int32_t mode, int32_t H, int32_t W,
                         int32_t act, int32_t iters, float* ms_out);

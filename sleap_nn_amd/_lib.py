@@ -62,6 +62,7 @@ SIGNATURES = {
     "ph_model_backward_workspace_bytes": (_i64, [_vp, _i32, _i32, _i32]),
     "ph_model_backward": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i64, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_f32), _vp, _i32, _f32,
                                     _i32, _i32, _f32, _vp, _vp, _vp]),
+    "ph_debug_split_plan": (C.c_int, [_i32, _i32, _i32, _i32, _i32, _i32, _i32, C.POINTER(C.c_int64)]),
     "ph_debug_gemm_bench": (C.c_int, [_i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, C.POINTER(C.c_float)]),
     "ph_debug_row_wgrad_bench": (C.c_int, [_i32, _i32, _i32, _i32, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "ph_render_confmaps": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp]),

@@ -1528,6 +1528,15 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
 
 int32_t ph_op_desc_size(void) { return (int32_t)sizeof(ph_op_desc); }
 
+int ph_debug_split_plan(int32_t B, int32_t H, int32_t W, int32_t cin_padded, int32_t cout_padded, int32_t splitk, int32_t n_cu, int64_t* out4) {
+  PH_REQUIRE(out4 && B > 0 && H > 0 && W > 0 && cin_padded > 0 && cout_padded > 0 && n_cu > 0 && (cin_padded % 16) == 0 && (cout_padded % 16) == 0, "ph_debug_split_plan: bad arguments");
+  out4[0] = wino2d_ksplit_shape(B, H, W, cin_padded, cout_padded, splitk, n_cu);
+  out4[1] = ((H & 3) || (W & 3)) ? 1 : wino4_ksplit_shape(B, H, W, cin_padded, cout_padded, splitk, n_cu);
+  out4[2] = wino2d_split_scratch_bytes(B, H, W, cin_padded, cout_padded, splitk, n_cu) / 1024;
+  out4[3] = wino4_split_scratch_bytes(B, H, W, cin_padded, cout_padded, splitk, n_cu) / 1024;
+  return PH_OK;
+}
+
 namespace {
 struct OptionRef {
   const char* key;

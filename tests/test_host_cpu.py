@@ -691,3 +691,31 @@ def test_wino4_transform_tables_known_answer():
         err_fold, err_plain = mod.check(seed)
         assert err_plain <= 1e-12          # float64 restatement: exact up to rounding
         assert err_fold <= 5e-7            # (torch's interpolate runs in float32)
+
+
+def test_split_k_plan_known_answers():
+    """The routing arithmetic of the small-batch regime (pure host code: wino2d_ksplit_shape / wino4_ksplit_shape through ph_debug_split_plan), on a 256-CU chip.
+    F(2x2,3x3): split only when the layer's (16 x 16 tile, N tile) units fill less than half of the CUs and K has >= 8 halves; slices = min(CUs / units, halves / 3).
+    F(4x4,3x3): units of 32 x 16 pixels, K >= 128 channels, slices = min(CUs / units, quarters / 16).  Half-empty N tiles (32 mod 64 channels) never split on F(2x2,3x3);
+    a forced count is capped by the K granularity."""
+    import ctypes as C
+
+    def plan(B, H, W, cin, cout, splitk=1, n_cu=256):
+        out = (C.c_int64 * 4)()
+        assert L.lib().ph_debug_split_plan(B, H, W, cin, cout, splitk, n_cu, out) == 0
+        return list(out)
+
+    # cfg1's stride-16 level: one 16 x 16 tile x 4 N tiles, K = 256 channels = 32 halves / 64 quarters
+    assert plan(1, 16, 16, 256, 256)[:2] == [10, 4]
+    assert plan(1, 16, 16, 256, 256)[2] == 10 * 16 * 16 * 256 * 4 // 1024
+    # cfg1's decoder concat at 32 x 32: 384 -> 128: 4 tiles x 2 N tiles = 8 units, 48 halves -> min(32, 16)
+    assert plan(1, 32, 32, 384, 128)[0] == 16
+    # cfg3 at 32 frames: every layer fills the chip -- no split on either kernel
+    assert plan(32, 64, 64, 768, 256)[:2] == [1, 1] and plan(32, 64, 64, 768, 256)[2:] == [0, 0]
+    # cfg3 at 4 frames per rank, 768 -> 256 at 64 x 64: F(2x2,3x3) has 256 units (full), F(4x4,3x3) 128 -> two slices of 96 quarters
+    assert plan(4, 64, 64, 768, 256)[:2] == [1, 2]
+    # fewer than 8 halves of K, or 32 output channels mod 64 (the half-empty-N-tile instantiation): no split; option 0: never; forced counts are capped
+    assert plan(1, 64, 64, 32, 64)[0] == 1 and plan(1, 16, 16, 256, 96)[0] == 1 and plan(1, 16, 16, 256, 256, splitk=0)[:2] == [1, 1]
+    assert plan(1, 16, 16, 64, 64, splitk=100)[0] == 8 and plan(32, 64, 64, 768, 256, splitk=3)[:2] == [3, 3]
+    # a map that is no multiple of 4 cannot run on the F(4x4,3x3) kernel at all
+    assert plan(1, 18, 18, 256, 256)[1] == 1
