@@ -39,13 +39,14 @@
 #include "net_kernels.h"
 
 #ifndef W4_EXP
-#define W4_EXP 0  // timing experiments of tools/w4/w4_bench.hip only (results are wrong with any bit set): 1 no weight transfers, 2 no input transform, 4 no per-quarter barrier, 8 no halo transfers, 16 no MFMAs
+#define W4_EXP 0  // timing experiments of tools/w4/w4_bench.hip only (results are wrong with any bit set): 1 no weight transfers, 2 no input transform, 4 no per-quarter barrier, 8 no halo transfers, 16 no MFMAs; pipelined kernel: 32 weights always of the first quarter (cache-hot), 64 halo always of the first quarter, 128 transform without its arithmetic (LDS traffic only), 256 weights loaded once per tile, 1024 halo transfers with the access pattern of a 4-quarter chunk loader (plain single-source layers only)
 #endif
 
 namespace ph {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int W4_TX = 8, W4_TY = 4;             // Winograd tiles per workgroup tile
 constexpr int W4_PW = 4 * W4_TX;                // 32 output columns
@@ -58,6 +59,9 @@ constexpr int W4_V_OFF = 3 * W4_RAW_FLOATS;     // two V slots
 constexpr int W4_W_OFF = W4_V_OFF + 2 * W4_V_FLOATS;  // twelve waves x two weight slots
 constexpr int W4_LDS_FLOATS = W4_W_OFF + 12 * 2 * W4_W_FLOATS;  // 36864 floats = 144 KiB
 constexpr int W4_Q_FLOATS = 12 * W4_W_FLOATS;   // transformed weights of one (N tile, quarter): 36 positions x 64 channels x 4 input channels
+constexpr int P4_WAVE_FLOATS = 4 * 256 + 128;   // conv3x3_wino4p_kernel: one wave's fragments of a quarter (nine positions: four position pairs of 16 B per lane + one of 8 B)
+static bool g_w4_legacy = false;                // timing harness only (tools/w4): the twelve-wave kernel and its weight order instead of the pipelined one
+void wino4_set_legacy(bool on) { g_w4_legacy = on; }
 
 // wpack [panel][tap 9][bn 64][16] (pack_conv) -> U = G g G^T in the order the kernel's private weight rings take it:
 // [n tile][quarter][wave pw = nt * 6 + nu][xi pair p][lane (lh, lx)][e = (xi & 1) * 2 + j]: output channel n tile * 64 + nt * 32 + lx,
@@ -76,6 +80,9 @@ __device__ __forceinline__ float wino4_g_row(int k, float g0, float g1, float g2
 // loads its nine taps ONCE, forms all 36 positions in registers and drops them into LDS at their place in the unit; the unit then leaves as 36 coalesced
 // 1-KiB rows.  (One thread per destination element re-read the nine taps 36 times through 4-byte loads 64 B apart: 0.48 ms for the 2304 -> 768 layer's
 // 255 MB, 3.6 ms per ConvNeXt training step, where the weights change every step.)
+// PIPE: the order of conv3x3_wino4p_kernel: [n tile][quarter][wave nt * 4 + pg][four 16-byte slots [lane][ks * 2 + (pl & 1)] of the position pairs pl = (0, 1) .. (6, 7) | one 8-byte
+// slot [lane][ks] of pl = 8], position p = xi * 6 + nu = 9 pg + pl, input channel quarter * 4 + 2 lh + ks -- the same 9,216 floats per unit
+template <bool PIPE>
 __global__ __launch_bounds__(256) void wino4_pack_kernel(const float* __restrict__ src, float* __restrict__ dst, int ntiles, int nchunks) {
   __shared__ float unit[W4_Q_FLOATS];
   const int quarter = blockIdx.x % (4 * nchunks), ntile = blockIdx.x / (4 * nchunks);
@@ -93,7 +100,15 @@ __global__ __launch_bounds__(256) void wino4_pack_kernel(const float* __restrict
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) h[kx] = wino4_g_row(xi, g[0 * 3 + kx], g[1 * 3 + kx], g[2 * 3 + kx]);
 #pragma unroll
-    for (int nu = 0; nu < 6; ++nu) unit[((((nt * 6 + nu) * 3 + (xi >> 1)) * 64 + lh * 32 + lx) << 2) + (xi & 1) * 2 + j] = wino4_g_row(nu, h[0], h[1], h[2]);
+    for (int nu = 0; nu < 6; ++nu) {
+      const float u = wino4_g_row(nu, h[0], h[1], h[2]);
+      if (PIPE) {
+        const int p = xi * 6 + nu, pgp = p / 9, pl = p % 9;
+        unit[(nt * 4 + pgp) * P4_WAVE_FLOATS + (pl < 8 ? (((pl >> 1) * 64 + lh * 32 + lx) << 2) + j * 2 + (pl & 1) : 1024 + ((lh * 32 + lx) << 1) + j)] = u;
+      } else {
+        unit[((((nt * 6 + nu) * 3 + (xi >> 1)) * 64 + lh * 32 + lx) << 2) + (xi & 1) * 2 + j] = u;
+      }
+    }
   }
   __syncthreads();
   float* out = dst + (size_t)blockIdx.x * W4_Q_FLOATS;
@@ -102,7 +117,10 @@ __global__ __launch_bounds__(256) void wino4_pack_kernel(const float* __restrict
 }
 int64_t wino4_pack_floats(int ntiles, int nchunks) { return (int64_t)ntiles * 4 * nchunks * W4_Q_FLOATS; }
 int launch_wino4_pack(const float* wpack, float* wino, int ntiles, int nchunks, hipStream_t s) {
-  hipLaunchKernelGGL(wino4_pack_kernel, dim3((unsigned)(ntiles * 4 * nchunks)), dim3(256), 0, s, wpack, wino, ntiles, nchunks);
+  if (g_w4_legacy)
+    hipLaunchKernelGGL(wino4_pack_kernel<false>, dim3((unsigned)(ntiles * 4 * nchunks)), dim3(256), 0, s, wpack, wino, ntiles, nchunks);
+  else
+    hipLaunchKernelGGL(wino4_pack_kernel<true>, dim3((unsigned)(ntiles * 4 * nchunks)), dim3(256), 0, s, wpack, wino, ntiles, nchunks);
   PH_HIP_CHECK(hipGetLastError());
   return PH_OK;
 }
@@ -509,11 +527,615 @@ __global__ __launch_bounds__(768) void conv3x3_wino4_kernel(ConvArgs a) {
   }
 }
 
+// ======================================================================================================================================================
+// conv3x3_wino4p_kernel (round 4): the same algorithm, workgroup tile, transfers and arithmetic as conv3x3_wino4_kernel above -- bit-identical results --
+// in a decomposition made for the instruction stream.  The twelve-wave form runs its matrix work and its transform in phases that every wave of a SIMD
+// enters at the same time (one barrier per quarter, identical programs), so the matrix pipe idles while the waves transform and the vector port idles while
+// they queue for the pipe: 0.54 busy.  Here a SIMD holds TWO waves whose streams are written out MFMA by MFMA with the other work between them:
+//   * eight waves; wave (nt, pg) owns the nine positions p = xi * 6 + nu = 9 pg .. 9 pg + 8 of the 32-channel N tile nt: nine 32x32 accumulators (144 registers),
+//     18 MFMAs per quarter; SIMD s holds (0, s) and (1, s), which read the same V fragments.
+//   * weights come straight from L2 into registers, one quarter ahead (five buffer loads per wave and quarter, each into the registers the MFMAs before it
+//     just read): no LDS ring, no LDS traffic for weights.
+//   * the transform of the next quarter is dealt as (16 tiles) x (xi group): waves 0..3 take an xi pair each ({1, 2} or {3, 4}: the pair shares its two
+//     row differences), waves 4..7 one of xi 0 / 5 -- a SIMD gets one of each -- and its pieces sit between the wave's MFMAs: LDS reads one MFMA ahead of
+//     their use, the row pass, the column pass, the V stores.
+//   * LDS: three raw halo slots + two V slots = 72 KiB in the loop; the epilogue sends one N tile at a time through LDS (144 KiB, all 36 positions) and
+//     waves 0..3 apply A^T . A: one thread per (tile, channel quad), eight lanes = 128 contiguous bytes of a pixel.
+template <int P, int N>
+__device__ __forceinline__ void p4_vput(float* slot, int vwq, int vwd, const float* v) {  // N transformed values of positions P .. P + N - 1 into a V slot
+  if constexpr (N > 0) {
+    constexpr int pgc = P / 9, pl = P % 9;
+    if constexpr (pl == 8) {
+      slot[pgc * P4_WAVE_FLOATS + vwd] = v[0];
+      p4_vput<P + 1, N - 1>(slot, vwq, vwd, v + 1);
+    } else if constexpr ((pl & 1) == 0 && N >= 2) {
+      *reinterpret_cast<float2*>(slot + pgc * P4_WAVE_FLOATS + (pl >> 1) * 256 + vwq) = make_float2(v[0], v[1]);
+      p4_vput<P + 2, N - 2>(slot, vwq, vwd, v + 2);
+    } else {
+      slot[pgc * P4_WAVE_FLOATS + (pl >> 1) * 256 + vwq + (pl & 1)] = v[0];
+      p4_vput<P + 1, N - 1>(slot, vwq, vwd, v + 1);
+    }
+  }
+}
+
+template <bool LOWRES, bool KS = false>
+__global__ __launch_bounds__(512) void conv3x3_wino4p_kernel(ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int pw = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave 0..7
+  // consumer role: positions 9 pg .. 9 pg + 8 of N tile nt
+  const int nt = pw >> 2, pg = pw & 3;
+  const int lx = lane & 31, lh = lane >> 5;
+  // producer role: xi group xg (0: xi 1 and 2, 1: xi 3 and 4, 2: xi 0, 3: xi 5) for the sixteen tiles typ = 2 (pw & 1) + (lane >> 5), txp; channel cp of the quarter
+  const int xg = pw < 4 ? (pw >> 1) : 2 + ((pw - 4) >> 1);
+  const int typ = 2 * (pw & 1) + (lane >> 5), txp = (lane >> 2) & 7, cp = lane & 3;
+
+  const int tiles_x = (a.W + W4_PW - 1) / W4_PW;
+  const int tiles_y = (a.H + W4_PH - 1) / W4_PH;
+  const int tiles = tiles_x * tiles_y * a.B;
+  const int ntc = (a.coutp + 63) / 64;
+  const int units = tiles * ntc;
+  const int total = KS ? units * a.ksplit : units;
+  const int Q0 = a.c0p / 4, Q1 = a.c1p / 4, Q = Q0 + Q1;
+  constexpr int lowres = LOWRES ? 1 : 0;
+  const int Hl = a.H >> 1, Wl = a.W >> 1;
+
+#ifdef W4_CLOCK  // diagnostic build: shader cycles and 100-MHz ticks of the whole workgroup into ConvArgs::clock_probe[block * 2 ..]
+  const unsigned long long clk_c0 = __builtin_amdgcn_s_memtime(), clk_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+  float* const rawbuf = lds;                      // two raw halo slots
+  float* const vbuf = lds + 2 * W4_RAW_FLOATS;    // two V slots
+
+  // ---- producer constants (the formulas of conv3x3_wino4_kernel: t[c] = fma(beta, fma(alpha, d1, d3), fma(alpha, d2, d4)) for xi 1..4, fma(4, P, fma(-5, R, S)) for xi 0 and 5)
+  const float alpha = xg == 0 ? -4.f : -1.f, beta = xg == 0 ? 1.f : 2.f, nbeta = -beta;
+  const int pbase_f = ((4 * typ + (xg == 2 ? 0 : 1)) * 36 + txp) * 4 + cp;  // first patch row this thread reads: 1 (xi 1..4: rows 1..4; xi 5: rows 1, 3, 5) or 0 (xi 0: rows 0, 2, 4)
+  const int pbase_l = ((2 * typ) * 18 + txp) * 4 + cp;
+  const int vwq = ((cp >> 1) * 32 + typ * 8 + txp) * 4 + (cp & 1) * 2;  // V write: 16-byte slots [lane (c >> 1, tile)][ks = c & 1][position parity]
+  const int vwd = 1024 + ((cp >> 1) * 32 + typ * 8 + txp) * 2 + (cp & 1);
+  const int vrq = pg * P4_WAVE_FLOATS + lane * 4, vrd = pg * P4_WAVE_FLOATS + 1024 + lane * 2;
+
+  struct Plan {
+    int b, x0, y0, ntile;
+  };
+  const int G = (int)gridDim.x;
+  const bool rotate = (a.coutp & 63) != 0 && (a.coutp & 63) <= 32 && ntc > 1 && (((tiles & 7) == 0) ? ((G & 7) == 0 && (G >> 3) % ntc == 0) : (G % ntc == 0));
+  auto setup = [&](int vid, Plan& P) {
+    int t, ntile;
+    w4_deal_tile(vid, tiles, ntc, rotate ? vid / G : 0, &t, &ntile);
+    const int tx = t % tiles_x;
+    t /= tiles_x;
+    const int ty = t % tiles_y;
+    P.b = t / tiles_y;
+    P.x0 = tx * W4_PW;
+    P.y0 = ty * W4_PH;
+    P.ntile = ntile;
+  };
+
+  const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.wpack_wino4, 0, (int)((unsigned)ntc * (unsigned)Q * (unsigned)(W4_Q_FLOATS * 4)), 0x00020000);
+  const unsigned w_lane = (unsigned)(pw * P4_WAVE_FLOATS + lane * 4) * 4u;
+  const unsigned w_lane9 = (unsigned)(pw * P4_WAVE_FLOATS + 1024 + lane * 2) * 4u;
+
+  for (int vid = blockIdx.x; vid < total; vid += gridDim.x) {
+#ifdef W4_STAMP
+    const unsigned long long tile_t0 = __builtin_amdgcn_s_memtime();
+#endif
+    Plan P;
+    const int ksl = KS ? vid / units : 0;
+    const int qbeg = KS ? ksl * Q / a.ksplit : 0;
+    const int qend = KS ? (ksl + 1) * Q / a.ksplit : Q;
+    setup(KS ? vid - ksl * units : vid, P);
+    // ---- loader state: this wave moves pieces pw and pw + 8 of a raw slot (pieces 0..10 hold the 648 halo entries; the transfers aimed at piece 11 are out of range = zeros)
+    unsigned off0[2], off1[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int e = (pw + 8 * i) * 64 + lane;
+      const int hy = e / 36, rem = e - hy * 36;
+      const int pl = rem / 9, k = rem - pl * 9;
+      const int hx = 4 * k + pl;
+      const int gy = P.y0 + hy - 1, gx = P.x0 + hx - 1;
+      const bool in = pw + 8 * i < 11 && hy < W4_PH + 2 && hx < W4_PW + 2 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+      off0[i] = in ? (unsigned)((P.b * a.H + gy) * a.W + gx) * (unsigned)(a.c0p * 4) : 0xFFFFFF00u;
+      if (!lowres) {
+        off1[i] = (in && a.c1p > 0) ? (unsigned)((P.b * a.H + gy) * a.W + gx) * (unsigned)(a.c1p * 4) : 0xFFFFFF00u;
+      } else {
+        const int ly = e / 18, rem2 = e - ly * 18;
+        const int par = rem2 / 9, kk = rem2 - par * 9;
+        const int lc = 2 * kk + par;
+        const int sy = min(max((P.y0 >> 1) - 1 + ly, 0), Hl - 1), sx = min(max((P.x0 >> 1) - 1 + lc, 0), Wl - 1);
+        off1[i] = (ly < W4_PH / 2 + 2) ? (unsigned)((P.b * Hl + sy) * Wl + sx) * (unsigned)(a.c1p * 4) : 0xFFFFFF00u;
+      }
+    }
+    const __amdgpu_buffer_rsrc_t rsrc0 = __builtin_amdgcn_make_buffer_rsrc((void*)a.src0, 0, (int)((unsigned)(a.B * a.H * a.W) * (unsigned)(a.c0p * 4)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc1 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.src1 ? a.src1 : a.src0), 0,
+                                                                           (int)((unsigned)(lowres ? a.B * Hl * Wl : a.B * a.H * a.W) * (unsigned)(a.c1p * 4)), 0x00020000);
+    // The halo goes through registers (buffer load one quarter, ds_write the next): an LDS-DMA transfer costs its wave ~150 cycles of issue beside MFMAs, a register load + ds_write_b128 ~30
+    f32x4 hreg[2] = {f32x4{1.f, 2.f, 3.f, 4.f}, f32x4{1.f, 2.f, 3.f, 4.f}};
+    const bool has1 = pw + 8 < 11;  // (wave-uniform) this wave owns a second piece of the full-resolution layout
+    auto load_raw = [&](int k) {  // halo of quarter k into this wave's registers
+      const bool s1 = k >= Q0;
+      const int so = k < qend ? ((W4_EXP & 64) ? 0 : (s1 ? (k - Q0) * 16 : k * 16)) : 0;
+      if (W4_EXP & (8 | 4096)) return;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        if (i == 1 && !has1) continue;
+        unsigned off = k < qend ? (s1 ? off1[i] : off0[i]) : 0xFFFFFF00u;
+        if (W4_EXP & 512) off = (unsigned)((pw + 8 * i) * 1024 + lane * 16);  // contiguous, cache-hot: wrong data
+        if (W4_EXP & 1024) {  // the traffic of a 4-quarter chunk loader (64 contiguous bytes per pixel, a quarter of the halo's pixels per quarter): wrong data
+          const int e = (k & 3) * 162 + (pw + 8 * i) * 16 + (lane >> 2);
+          const int hy = e / 36, rem = e - hy * 36;
+          const int hx = 4 * (rem % 9) + rem / 9;
+          const int gy = min(max(P.y0 + hy - 1, 0), a.H - 1), gx = min(max(P.x0 + hx - 1, 0), a.W - 1);
+          off = (unsigned)((P.b * a.H + gy) * a.W + gx) * (unsigned)(a.c0p * 4) + (unsigned)((k >> 2) * 64 + (lane & 3) * 16);
+          hreg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc0, off, 0, 0));
+          continue;
+        }
+        if (s1)
+          hreg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc1, off, so, 0));
+        else
+          hreg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc0, off, so, 0));
+      }
+    };
+    auto store_raw = [&](int k) {  // ... and from there into raw slot k & 1
+      float* slot = rawbuf + (k & 1) * W4_RAW_FLOATS + lane * 4;
+      if (W4_EXP & (8 | 2048)) return;
+      *reinterpret_cast<f32x4*>(slot + pw * 256) = hreg[0];
+      if (has1) *reinterpret_cast<f32x4*>(slot + (pw + 8) * 256) = hreg[1];
+    };
+    const int w_tile = P.ntile * Q * (W4_Q_FLOATS * 4);
+    f32x4 wf[4];
+    float wf9[2];
+    auto load_w = [&](int k, int j) {  // fragment slot j (0..3: 16 bytes, 4: 8 bytes) of quarter k's weights into its registers
+      const bool live = k < qend && !(W4_EXP & 1);
+      if ((W4_EXP & 256) && k != qbeg) return;
+      const int so = live ? w_tile + ((W4_EXP & 32) ? qbeg : k) * (W4_Q_FLOATS * 4) : 0;
+      if (j < 4) {
+        wf[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, live ? w_lane + (unsigned)j * 1024u : 0xFFFFFF00u, so, 0));
+      } else {
+        const f32x2 r = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(wrsrc, live ? w_lane9 : 0xFFFFFF00u, so, 0));  // (bit_cast of the whole vector: of one element it reads element 0)
+        wf9[0] = r[0];
+        wf9[1] = r[1];
+      }
+    };
+
+    // low-resolution row coefficients of this thread's tile row for its one or two xi (as in conv3x3_wino4_kernel) and the zero masks of patch columns 0 and 5
+    float cl[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    float zx0 = 1.f, zx5 = 1.f;
+    if (lowres) {
+      const float bt[6][6] = {{4, 0, -5, 0, 1, 0}, {0, -4, -4, 1, 1, 0}, {0, 4, -4, -1, 1, 0}, {0, -2, -1, 2, 1, 0}, {0, 2, -1, -2, 1, 0}, {0, 4, 0, -5, 0, 1}};
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const int xi = xg == 0 ? 1 + s : (xg == 1 ? 3 + s : (xg == 2 ? 0 : 5));
+        float c4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+          const int Y = P.y0 + 4 * typ - 1 + r;
+          float btv = 0.f;
+#pragma unroll
+          for (int x = 0; x < 6; ++x) btv = xi == x ? bt[x][r] : btv;
+          if (Y < 0 || Y >= a.H) btv = 0.f;
+          const float w0 = (r & 1) ? 0.25f : 0.75f;
+          c4[r >> 1] += btv * w0;
+          c4[(r >> 1) + 1] += btv * (1.f - w0);
+        }
+#pragma unroll
+        for (int n = 0; n < 4; ++n) cl[s][n] = c4[n];
+      }
+      zx0 = (P.x0 + 4 * txp - 1 < 0) ? 0.f : 1.f;
+      zx5 = (P.x0 + 4 * txp + 4 >= a.W) ? 0.f : 1.f;
+    }
+
+    // ---- the input transform of quarter k (raw slot k % 3 -> V slot k & 1) in pieces: reads of patch columns [c0, c1), their row pass, then per xi the column pass + stores
+    float dd[6][4];   // raw values: [patch column][row]
+    float ta[6], tb[6];
+    auto t_read = [&](auto xg_tag, auto lr_tag, const float* raw, int c0, int c1) __attribute__((always_inline)) {
+      constexpr int XG = decltype(xg_tag)::value;
+      constexpr bool LR = decltype(lr_tag)::value;
+      if (W4_EXP & 2) return;
+      if constexpr (LR) {  // (columns = the four low-resolution columns; rows = the four low-resolution rows)
+        const float* p = raw + pbase_l;
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+          if (n >= c0 && n < c1) {
+            const int co = ((n & 1) * 9 + (n >> 1)) * 4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dd[n][r] = p[co + r * 18 * 4];
+          }
+      } else {
+        const float* p = raw + pbase_f;
+#pragma unroll
+        for (int c = 0; c < 6; ++c)
+          if (c >= c0 && c < c1) {
+            const int co = ((c & 3) * 9 + (c >> 2)) * 4;
+            if constexpr (XG < 2) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) dd[c][r] = p[co + r * 144];
+            } else {
+#pragma unroll
+              for (int r = 0; r < 3; ++r) dd[c][r] = p[co + 2 * r * 144];
+            }
+          }
+      }
+    };
+    float tla[4], tlb[4];
+    auto t_rows = [&](auto xg_tag, auto lr_tag, int c0, int c1) __attribute__((always_inline)) {
+      constexpr int XG = decltype(xg_tag)::value;
+      constexpr bool LR = decltype(lr_tag)::value;
+      if (W4_EXP & 2) return;
+      if constexpr (LR) {
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+          if (n >= c0 && n < c1) {
+            tla[n] = fmaf(cl[0][0], dd[n][0], fmaf(cl[0][1], dd[n][1], fmaf(cl[0][2], dd[n][2], cl[0][3] * dd[n][3])));
+            asm volatile("" : "+v"(tla[n]));
+            if constexpr (XG < 2) {
+              tlb[n] = fmaf(cl[1][0], dd[n][0], fmaf(cl[1][1], dd[n][1], fmaf(cl[1][2], dd[n][2], cl[1][3] * dd[n][3])));
+              asm volatile("" : "+v"(tlb[n]));
+            }
+          }
+      } else {
+#pragma unroll
+        for (int c = 0; c < 6; ++c)
+          if (c >= c0 && c < c1) {
+            if (W4_EXP & 128) {
+              ta[c] = dd[c][0];
+              tb[c] = dd[c][1];
+            } else if constexpr (XG < 2) {
+              const float A = fmaf(alpha, dd[c][1], dd[c][3]);
+              const float Bv = fmaf(alpha, dd[c][0], dd[c][2]);
+              ta[c] = fmaf(beta, Bv, A);
+              tb[c] = fmaf(nbeta, Bv, A);
+              asm volatile("" : "+v"(ta[c]), "+v"(tb[c]));  // scalar chains: packed-fp32 VALU (and the moves that feed it) is a loss beside MFMAs
+            } else {
+              ta[c] = fmaf(4.f, dd[c][0], fmaf(-5.f, dd[c][1], dd[c][2]));
+              asm volatile("" : "+v"(ta[c]));
+            }
+          }
+      }
+    };
+    auto t_mix = [&](const float (&tl)[4], float (&tt)[6]) __attribute__((always_inline)) {  // low resolution: the six up-sampled column samples of a row-transformed patch
+      tt[0] = zx0 * fmaf(0.75f, tl[0], 0.25f * tl[1]);
+      tt[1] = fmaf(0.25f, tl[0], 0.75f * tl[1]);
+      tt[2] = fmaf(0.75f, tl[1], 0.25f * tl[2]);
+      tt[3] = fmaf(0.25f, tl[1], 0.75f * tl[2]);
+      tt[4] = fmaf(0.75f, tl[2], 0.25f * tl[3]);
+      tt[5] = zx5 * fmaf(0.25f, tl[2], 0.75f * tl[3]);
+#pragma unroll
+      for (int c = 0; c < 6; ++c) asm volatile("" : "+v"(tt[c]));
+    };
+    auto t_cols = [&](auto xg_tag, auto lr_tag, auto which_tag, float* vslot) __attribute__((always_inline)) {  // which = 0: the first (or only) xi of the group, 1: the second
+      constexpr int XG = decltype(xg_tag)::value;
+      constexpr bool LR = decltype(lr_tag)::value;
+      constexpr int WH = decltype(which_tag)::value;
+      if (W4_EXP & 2) return;
+      if constexpr (LR) t_mix(WH ? tlb : tla, WH ? tb : ta);
+      float v[6];
+      if (W4_EXP & 128) {
+#pragma unroll
+        for (int n = 0; n < 6; ++n) v[n] = (WH ? tb : ta)[n];
+      } else {
+        w4_col_pass(WH ? tb : ta, v);
+      }
+      constexpr int xi = XG == 0 ? 1 + WH : (XG == 1 ? 3 + WH : (XG == 2 ? 0 : 5));
+      p4_vput<xi * 6, 6>(vslot, vwq, vwd, v);
+    };
+
+    // ---- prologue: raw of the slice's first three quarters, weights of its first; transform the first quarter
+    load_raw(qbeg);
+    store_raw(qbeg);
+    load_raw(qbeg + 1);
+#pragma unroll
+    for (int j = 0; j < 5; ++j) load_w(qbeg, j);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    auto transform_all = [&](auto xg_tag, int k) __attribute__((always_inline)) {
+      const float* raw = rawbuf + (k & 1) * W4_RAW_FLOATS;
+      float* vslot = vbuf + (k & 1) * W4_V_FLOATS;
+      constexpr int XG = decltype(xg_tag)::value;
+      if (lowres && k >= Q0) {
+        t_read(xg_tag, std::true_type{}, raw, 0, 4);
+        t_rows(xg_tag, std::true_type{}, 0, 4);
+        t_cols(xg_tag, std::true_type{}, std::integral_constant<int, 0>{}, vslot);
+        if constexpr (XG < 2) t_cols(xg_tag, std::true_type{}, std::integral_constant<int, 1>{}, vslot);
+      } else {
+        t_read(xg_tag, std::false_type{}, raw, 0, 6);
+        t_rows(xg_tag, std::false_type{}, 0, 6);
+        t_cols(xg_tag, std::false_type{}, std::integral_constant<int, 0>{}, vslot);
+        if constexpr (XG < 2) t_cols(xg_tag, std::false_type{}, std::integral_constant<int, 1>{}, vslot);
+      }
+    };
+    switch (xg) {
+      case 0: transform_all(std::integral_constant<int, 0>{}, qbeg); break;
+      case 1: transform_all(std::integral_constant<int, 1>{}, qbeg); break;
+      case 2: transform_all(std::integral_constant<int, 2>{}, qbeg); break;
+      default: transform_all(std::integral_constant<int, 3>{}, qbeg); break;
+    }
+    f32x16 acc[9];
+#pragma unroll
+    for (int x = 0; x < 9; ++x)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[x][r] = 0.f;
+    store_raw(qbeg + 1);
+    load_raw(qbeg + 2);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // V of the first quarter and the halo of the second are written
+    __builtin_amdgcn_s_barrier();
+
+#if W4_EXP & 16
+#define P4_MFMA(a_, b_, c_) (c_)
+#else
+#define P4_MFMA(a_, b_, c_) __builtin_amdgcn_mfma_f32_32x32x2f32(a_, b_, c_, 0, 0, 0)
+#endif
+#define P4_SB __builtin_amdgcn_sched_barrier(0);
+#ifdef W4_STAMP  // diagnostic build (tools/w4/w4_bench.hip -DW4_STAMP): cycles per segment of a quarter, per wave, into ConvArgs::clock_probe.  The s_memtime results are only
+    // read after the quarter's own lgkmcnt(0), so the stamps add no wait of their own (an s_memtime read on the spot waits for every LDS operation in flight)
+    unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tm[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long tile_t1 = __builtin_amdgcn_s_memtime();  // prologue done
+#ifndef W4_STSEL
+#define W4_STSEL 0xFF  // which stamps are taken (few at a time: every pending result occupies an SGPR pair the compiler must not have to move)
+#endif
+#define P4_ST(i) if constexpr ((W4_STSEL >> i) & 1) { asm volatile("s_memtime %0" : "=s"(tm[i])); } P4_SB
+#define P4_ST_END                                      \
+  asm volatile("s_memtime %0" : "=s"(tm[8]));          \
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(tm[0]), "+s"(tm[1]), "+s"(tm[2]), "+s"(tm[3]), "+s"(tm[4]), "+s"(tm[5]), "+s"(tm[6]), "+s"(tm[7]), "+s"(tm[8])::"memory");   \
+  {                                                    \
+    unsigned long long prev_ = 0; bool have_ = false;  \
+    _Pragma("unroll") for (int i_ = 0; i_ < 9; ++i_) if (i_ == 8 || ((W4_STSEL >> i_) & 1)) { if (have_) st[i_ - 1] += tm[i_] - prev_; prev_ = tm[i_]; have_ = true; } \
+  }
+#else
+#define P4_ST(i)
+#define P4_ST_END
+#endif
+    // One quarter: 18 MFMAs of quarter q with the transform of quarter q + 1 (kind LR), the weight loads of q + 1 and the halo transfers of q + 3 between them.
+    // MM = false: this wave's 32 output channels do not exist (last N tile of a layer with 32 channels mod 64): producer duties only.
+    auto quarters = [&](auto xg_tag, auto mm_tag, auto lr_tag, int q0, int q1) __attribute__((always_inline)) {
+      constexpr int XG = decltype(xg_tag)::value;
+      constexpr bool MM = decltype(mm_tag)::value;
+      constexpr bool LR = decltype(lr_tag)::value;
+      constexpr bool PAIR = XG < 2;
+      constexpr int NC = LR ? 4 : 6, H1 = NC / 2;  // raw columns, read in two halves
+      const std::integral_constant<int, 0> first{};
+      const std::integral_constant<int, 1> second{};
+      for (int q = q0; q < q1; ++q) {
+        const float* raw = rawbuf + ((q + 1) & 1) * W4_RAW_FLOATS;
+        float* vslot = vbuf + ((q + 1) & 1) * W4_V_FLOATS;
+        const float* vq = vbuf + (q & 1) * W4_V_FLOATS + vrq;
+        const float* vd = vbuf + (q & 1) * W4_V_FLOATS + vrd;
+        f32x4 vf0, vf1, vf2, vf3;
+        float2 vf9;
+        P4_ST(0)
+        store_raw(q + 2);  // (loaded during quarter q - 1; slot q & 1 was transformed during quarter q - 1)
+        P4_ST(1)
+        load_raw(q + 3);
+        if constexpr (MM) {
+          vf0 = *reinterpret_cast<const f32x4*>(vq);
+          vf1 = *reinterpret_cast<const f32x4*>(vq + 256);
+        }
+        t_read(xg_tag, lr_tag, raw, 0, H1);
+        P4_SB
+        if constexpr (MM) {
+          P4_ST(2)
+          acc[0] = P4_MFMA(wf[0][0], vf0[0], acc[0]);
+          P4_ST(3)
+          acc[1] = P4_MFMA(wf[0][1], vf0[1], acc[1]);
+          vf2 = *reinterpret_cast<const f32x4*>(vq + 512);
+          acc[0] = P4_MFMA(wf[0][2], vf0[2], acc[0]);
+          acc[1] = P4_MFMA(wf[0][3], vf0[3], acc[1]);
+          load_w(q + 1, 0);
+        }
+        t_rows(xg_tag, lr_tag, 0, H1);
+        P4_SB
+        P4_ST(4)
+        if constexpr (MM) {
+          acc[2] = P4_MFMA(wf[1][0], vf1[0], acc[2]);
+          acc[3] = P4_MFMA(wf[1][1], vf1[1], acc[3]);
+        }
+        t_read(xg_tag, lr_tag, raw, H1, NC);
+        if constexpr (MM) {
+          vf3 = *reinterpret_cast<const f32x4*>(vq + 768);
+          acc[2] = P4_MFMA(wf[1][2], vf1[2], acc[2]);
+          acc[3] = P4_MFMA(wf[1][3], vf1[3], acc[3]);
+          load_w(q + 1, 1);
+        }
+        P4_SB
+        P4_ST(5)
+        if constexpr (MM) {
+          acc[4] = P4_MFMA(wf[2][0], vf2[0], acc[4]);
+          acc[5] = P4_MFMA(wf[2][1], vf2[1], acc[5]);
+        }
+        t_rows(xg_tag, lr_tag, H1, NC);
+        if constexpr (MM) {
+          vf9 = *reinterpret_cast<const float2*>(vd);
+          acc[4] = P4_MFMA(wf[2][2], vf2[2], acc[4]);
+          acc[5] = P4_MFMA(wf[2][3], vf2[3], acc[5]);
+          load_w(q + 1, 2);
+        }
+        P4_SB
+        P4_ST(6)
+        if constexpr (MM) {
+          acc[6] = P4_MFMA(wf[3][0], vf3[0], acc[6]);
+          acc[7] = P4_MFMA(wf[3][1], vf3[1], acc[7]);
+        }
+        t_cols(xg_tag, lr_tag, first, vslot);
+        P4_SB
+        if constexpr (MM) {
+          acc[8] = P4_MFMA(wf9[0], vf9.x, acc[8]);
+          acc[6] = P4_MFMA(wf[3][2], vf3[2], acc[6]);
+          acc[7] = P4_MFMA(wf[3][3], vf3[3], acc[7]);
+          load_w(q + 1, 3);
+        }
+        if constexpr (PAIR) t_cols(xg_tag, lr_tag, second, vslot);
+        P4_SB
+        if constexpr (MM) {
+          acc[8] = P4_MFMA(wf9[1], vf9.y, acc[8]);
+          load_w(q + 1, 4);
+        }
+        P4_SB
+        P4_ST(7)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // V[(q + 1) & 1] and raw[q & 1] are written
+        if (!(W4_EXP & 4)) __builtin_amdgcn_s_barrier();
+        P4_SB
+        P4_ST_END
+      }
+    };
+    // (the transform of quarter q + 1 is the low-resolution one from q = Q0 - 1 on)
+    auto run = [&](auto xg_tag, auto mm_tag) __attribute__((always_inline)) {
+      if constexpr (LOWRES) {
+        const int qs = min(max(Q0 - 1, qbeg), qend);
+        quarters(xg_tag, mm_tag, std::false_type{}, qbeg, qs);
+        quarters(xg_tag, mm_tag, std::true_type{}, qs, qend);
+      } else {
+        quarters(xg_tag, mm_tag, std::false_type{}, qbeg, qend);
+      }
+    };
+    auto run_mm = [&](auto mm_tag) __attribute__((always_inline)) {
+      switch (xg) {
+        case 0: run(std::integral_constant<int, 0>{}, mm_tag); break;
+        case 1: run(std::integral_constant<int, 1>{}, mm_tag); break;
+        case 2: run(std::integral_constant<int, 2>{}, mm_tag); break;
+        default: run(std::integral_constant<int, 3>{}, mm_tag); break;
+      }
+    };
+    if (nt == 1 && P.ntile * 64 + 32 >= a.coutp)  // wave-uniform
+      run_mm(std::false_type{});
+    else
+      run_mm(std::true_type{});
+
+#ifdef W4_STAMP
+    const unsigned long long tile_t2 = __builtin_amdgcn_s_memtime();  // loop done
+#endif
+    // ---- epilogue (the loop's last barrier has passed: every LDS read of the tile is done)
+    float* const exch = lds;  // [position 36][tile 32][channel quad 8, XOR-swizzled by the tile][4]: 144 KiB
+    auto dump = [&]() __attribute__((always_inline)) {
+      // position p = 9 pg + i at p * 1024 floats (an immediate offset per i), channel quad 2 k + lh at slot (2 k + lh) ^ (lx & 7) = slot(0) ^ 2 k: four base addresses, made here
+      // (hoisted out of the tile loop the 36 addresses were spilled and came back one scratch load at a time: 22 thousand cycles per dump)
+      int d0 = ((pg * 9 * 32 + lx) * 8 + (lh ^ (lx & 7))) << 2;
+      asm volatile("" : "+v"(d0));
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float* const dk = exch + (d0 ^ (k << 3));
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+          f32x4 v;
+          v[0] = acc[i][4 * k + 0];
+          v[1] = acc[i][4 * k + 1];
+          v[2] = acc[i][4 * k + 2];
+          v[3] = acc[i][4 * k + 3];
+          *reinterpret_cast<f32x4*>(dk + i * 1024) = v;
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
+    auto finish = [&](int round) __attribute__((always_inline)) {  // waves 0..3: one thread per (tile, channel quad) of N half `round`
+      const int tile = tid >> 3, cq = tid & 7;
+      const int ty = tile >> 3, tx = tile & 7;
+      int z0 = (tile * 8 + (cq ^ (tile & 7))) << 2;
+      asm volatile("" : "+v"(z0));
+      const float* zp = exch + z0;
+      // row pass (over xi) per nu, with the expressions of the twelve-wave kernel's owning waves: Z[a][nu]
+      f32x4 z[4][6];
+#pragma unroll
+      for (int n = 0; n < 6; ++n) {
+        f32x4 m[6];
+#pragma unroll
+        for (int x = 0; x < 6; ++x) m[x] = *reinterpret_cast<const f32x4*>(zp + (x * 6 + n) * 1024);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float s12 = m[1][e] + m[2][e], d12 = m[1][e] - m[2][e], s34 = m[3][e] + m[4][e], d34 = m[3][e] - m[4][e];
+          z[0][n][e] = (m[0][e] + s12) + s34;
+          z[1][n][e] = fmaf(2.f, d34, d12);
+          z[2][n][e] = fmaf(4.f, s34, s12);
+          z[3][n][e] = fmaf(8.f, d34, d12) + m[5][e];
+        }
+      }
+      const int co = P.ntile * 64 + round * 32 + 4 * cq;
+      const f32x4 bias = KS ? f32x4{0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4*>(a.bias + co);
+#pragma unroll
+      for (int aa = 0; aa < 4; ++aa) {
+        const f32x4 s12 = z[aa][1] + z[aa][2], d12 = z[aa][1] - z[aa][2], s34 = z[aa][3] + z[aa][4], d34 = z[aa][3] - z[aa][4];
+        f32x4 y[4];
+        y[0] = ((z[aa][0] + s12) + s34) + bias;
+        y[1] = (d12 + 2.f * d34) + bias;
+        y[2] = (s12 + 4.f * s34) + bias;
+        y[3] = ((d12 + 8.f * d34) + z[aa][5]) + bias;
+        const int oy = P.y0 + 4 * ty + aa, ox = P.x0 + 4 * tx;
+        if (oy < a.H && co < a.coutp) {
+          float* const dp = a.dst + ((size_t)(P.b * a.H + oy) * a.W + ox) * a.coutp + co + (KS ? (size_t)ksl * a.split_stride : (size_t)0);
+#pragma unroll
+          for (int bb = 0; bb < 4; ++bb) {
+            if (ox + bb >= a.W) continue;
+            f32x4 v = y[bb];
+            if (a.relu) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+            if (a.relu_mask_src) {  // backward: this launch completes the gradient of a conv + ReLU output -- that ReLU's mask rides in the (lane-local) store
+              const f32x4 f = *reinterpret_cast<const f32x4*>(a.relu_mask_src + (dp - a.dst) + (size_t)bb * a.coutp);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = f[e] > 0.f ? v[e] : 0.f;
+            }
+            *reinterpret_cast<f32x4*>(dp + (size_t)bb * a.coutp) = v;
+          }
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
+    // (two programs with the same four barriers: the waves of N half 0 are done with their accumulators after the first dump, which leaves them the registers of the output transform)
+    if (nt == 0) {
+      dump();
+      __builtin_amdgcn_s_barrier();
+#ifdef W4_STAMP
+      const unsigned long long e1 = __builtin_amdgcn_s_memtime();
+#endif
+      finish(0);
+      __builtin_amdgcn_s_barrier();
+#ifdef W4_STAMP
+      const unsigned long long e2 = __builtin_amdgcn_s_memtime();
+#endif
+      __builtin_amdgcn_s_barrier();
+#ifdef W4_STAMP
+      const unsigned long long e3 = __builtin_amdgcn_s_memtime();
+#endif
+      finish(1);
+      __builtin_amdgcn_s_barrier();
+#ifdef W4_STAMP
+      if (a.clock_probe && lane == 0 && vid == (int)blockIdx.x) {
+        unsigned long long* o = a.clock_probe + ((size_t)blockIdx.x * 12 + pw) * 8;
+        o[0] = (tile_t1 - tile_t0) * (unsigned long long)(qend - qbeg);  // (the harness divides by the quarter count)
+        o[1] = (tile_t2 - tile_t1) * 0 + st[6] + st[7];
+        o[2] = (e1 - tile_t2) * (unsigned long long)(qend - qbeg);
+        o[3] = (e2 - e1) * (unsigned long long)(qend - qbeg);
+        o[4] = (e3 - e2) * (unsigned long long)(qend - qbeg);
+        o[5] = (__builtin_amdgcn_s_memtime() - e3) * (unsigned long long)(qend - qbeg);
+        o[6] = st[6];
+        o[7] = st[7];
+      }
+#endif
+    } else {
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_s_barrier();
+      dump();
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_s_barrier();
+    }
+  }
+#ifdef W4_CLOCK
+  if (a.clock_probe && tid == 0) {
+    a.clock_probe[blockIdx.x * 2] = __builtin_amdgcn_s_memtime() - clk_c0;
+    a.clock_probe[blockIdx.x * 2 + 1] = __builtin_amdgcn_s_memrealtime() - clk_r0;
+  }
+#endif
+}
+
 int prepare_wino4_kernels() {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wino4_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS_FLOATS * (int)sizeof(float));
   if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wino4_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS_FLOATS * (int)sizeof(float));
   if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wino4_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS_FLOATS * (int)sizeof(float));
   if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wino4_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS_FLOATS * (int)sizeof(float));
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wino4p_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS_FLOATS * (int)sizeof(float));
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wino4p_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS_FLOATS * (int)sizeof(float));
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wino4p_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS_FLOATS * (int)sizeof(float));
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wino4p_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS_FLOATS * (int)sizeof(float));
   if (e != hipSuccess) {
     set_error("hipFuncSetAttribute(wino4) failed: %s", hipGetErrorString(e));
     return PH_E_HIP;
@@ -586,14 +1208,24 @@ int launch_conv3x3_wino4(const ConvArgs& a, hipStream_t s) {
     k.ksplit = ksplit;
     k.split_stride = (long long)a.B * a.H * a.W * a.coutp;
     const dim3 grid(std::min(tiles * ntc * ksplit, n_cu));
-    if (a.src1_lowres)
+    if (!g_w4_legacy) {
+      if (a.src1_lowres)
+        hipLaunchKernelGGL((conv3x3_wino4p_kernel<true, true>), grid, dim3(512), (size_t)W4_LDS_FLOATS * sizeof(float), s, k);
+      else
+        hipLaunchKernelGGL((conv3x3_wino4p_kernel<false, true>), grid, dim3(512), (size_t)W4_LDS_FLOATS * sizeof(float), s, k);
+    } else if (a.src1_lowres)
       hipLaunchKernelGGL((conv3x3_wino4_kernel<true, true>), grid, dim3(768), (size_t)W4_LDS_FLOATS * sizeof(float), s, k);
     else
       hipLaunchKernelGGL((conv3x3_wino4_kernel<false, true>), grid, dim3(768), (size_t)W4_LDS_FLOATS * sizeof(float), s, k);
     PH_HIP_CHECK(hipGetLastError());
     return launch_splitk_reduce(a.split_scratch, k.split_stride, ksplit, a.bias, a.dst, nullptr, a.B, a.H, a.W, a.coutp, a.relu, s);
   }
-  if (a.src1_lowres)
+  if (!g_w4_legacy) {
+    if (a.src1_lowres)
+      hipLaunchKernelGGL((conv3x3_wino4p_kernel<true, false>), dim3(std::min(tiles * ntc, n_cu)), dim3(512), (size_t)W4_LDS_FLOATS * sizeof(float), s, a);
+    else
+      hipLaunchKernelGGL((conv3x3_wino4p_kernel<false, false>), dim3(std::min(tiles * ntc, n_cu)), dim3(512), (size_t)W4_LDS_FLOATS * sizeof(float), s, a);
+  } else if (a.src1_lowres)
     hipLaunchKernelGGL(conv3x3_wino4_kernel<true>, dim3(std::min(tiles * ntc, n_cu)), dim3(768), (size_t)W4_LDS_FLOATS * sizeof(float), s, a);
   else
     hipLaunchKernelGGL(conv3x3_wino4_kernel<false>, dim3(std::min(tiles * ntc, n_cu)), dim3(768), (size_t)W4_LDS_FLOATS * sizeof(float), s, a);
