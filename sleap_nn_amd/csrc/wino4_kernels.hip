@@ -685,6 +685,10 @@ __global__ __launch_bounds__(512) void conv3x3_wino4p_kernel(ConvArgs a) {
     const int w_tile = P.ntile * Q * (W4_Q_FLOATS * 4);
     f32x4 wf[4];
     float wf9[2];
+    // Software pipeline: the MFMAs of positions 6..8 (fragment slots 3 and 4) of quarter q are issued at the top of quarter q + 1, behind the barrier; their operands wait in these
+    // registers.  Zeros before a tile's first quarter.
+    f32x4 vf3 = {0.f, 0.f, 0.f, 0.f};
+    float2 vf9 = make_float2(0.f, 0.f);
     auto load_w = [&](int k, int j) {  // fragment slot j (0..3: 16 bytes, 4: 8 bytes) of quarter k's weights into its registers
       const bool live = k < qend && !(W4_EXP & 1);
       if ((W4_EXP & 256) && k != qbeg) return;
@@ -825,7 +829,9 @@ __global__ __launch_bounds__(512) void conv3x3_wino4p_kernel(ConvArgs a) {
     store_raw(qbeg);
     load_raw(qbeg + 1);
 #pragma unroll
-    for (int j = 0; j < 5; ++j) load_w(qbeg, j);
+    for (int j = 0; j < 3; ++j) load_w(qbeg, j);
+    wf[3] = f32x4{0.f, 0.f, 0.f, 0.f};
+    wf9[0] = wf9[1] = 0.f;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     auto transform_all = [&](auto xg_tag, int k) __attribute__((always_inline)) {
@@ -901,78 +907,77 @@ __global__ __launch_bounds__(512) void conv3x3_wino4p_kernel(ConvArgs a) {
         float* vslot = vbuf + ((q + 1) & 1) * W4_V_FLOATS;
         const float* vq = vbuf + (q & 1) * W4_V_FLOATS + vrq;
         const float* vd = vbuf + (q & 1) * W4_V_FLOATS + vrd;
-        f32x4 vf0, vf1, vf2, vf3;
-        float2 vf9;
+        f32x4 vf0, vf1, vf2;
+        // the previous quarter's last six MFMAs come first (their operands have been in registers since before the barrier), the quarter's memory instructions between them
         P4_ST(0)
-        store_raw(q + 2);  // (loaded during quarter q - 1; slot q & 1 was transformed during quarter q - 1)
-        P4_ST(1)
-        load_raw(q + 3);
         if constexpr (MM) {
-          vf0 = *reinterpret_cast<const f32x4*>(vq);
-          vf1 = *reinterpret_cast<const f32x4*>(vq + 256);
+          acc[6] = P4_MFMA(wf[3][0], vf3[0], acc[6]);
+          acc[7] = P4_MFMA(wf[3][1], vf3[1], acc[7]);
         }
+        P4_SB
+        store_raw(q + 2);  // (loaded during quarter q - 1; slot q & 1 was transformed during quarter q - 1)
         t_read(xg_tag, lr_tag, raw, 0, H1);
         P4_SB
+        P4_ST(1)
         if constexpr (MM) {
-          P4_ST(2)
-          acc[0] = P4_MFMA(wf[0][0], vf0[0], acc[0]);
+          acc[8] = P4_MFMA(wf9[0], vf9.x, acc[8]);
+          vf0 = *reinterpret_cast<const f32x4*>(vq);
+          acc[6] = P4_MFMA(wf[3][2], vf3[2], acc[6]);
+        }
+        P4_SB
+        load_raw(q + 3);
+        P4_SB
+        P4_ST(2)
+        if constexpr (MM) {
+          acc[7] = P4_MFMA(wf[3][3], vf3[3], acc[7]);
+          load_w(q, 3);
+          vf1 = *reinterpret_cast<const f32x4*>(vq + 256);
           P4_ST(3)
+          acc[8] = P4_MFMA(wf9[1], vf9.y, acc[8]);
+          load_w(q, 4);
+        }
+        t_rows(xg_tag, lr_tag, 0, H1);
+        t_read(xg_tag, lr_tag, raw, H1, NC);
+        P4_SB
+        P4_ST(4)
+        if constexpr (MM) {
+          acc[0] = P4_MFMA(wf[0][0], vf0[0], acc[0]);
           acc[1] = P4_MFMA(wf[0][1], vf0[1], acc[1]);
           vf2 = *reinterpret_cast<const f32x4*>(vq + 512);
           acc[0] = P4_MFMA(wf[0][2], vf0[2], acc[0]);
           acc[1] = P4_MFMA(wf[0][3], vf0[3], acc[1]);
           load_w(q + 1, 0);
         }
-        t_rows(xg_tag, lr_tag, 0, H1);
+        t_rows(xg_tag, lr_tag, H1, NC);
         P4_SB
-        P4_ST(4)
+        P4_ST(5)
         if constexpr (MM) {
           acc[2] = P4_MFMA(wf[1][0], vf1[0], acc[2]);
           acc[3] = P4_MFMA(wf[1][1], vf1[1], acc[3]);
-        }
-        t_read(xg_tag, lr_tag, raw, H1, NC);
-        if constexpr (MM) {
           vf3 = *reinterpret_cast<const f32x4*>(vq + 768);
+        }
+        t_cols(xg_tag, lr_tag, first, vslot);
+        if constexpr (MM) {
           acc[2] = P4_MFMA(wf[1][2], vf1[2], acc[2]);
           acc[3] = P4_MFMA(wf[1][3], vf1[3], acc[3]);
           load_w(q + 1, 1);
         }
         P4_SB
-        P4_ST(5)
+        P4_ST(6)
         if constexpr (MM) {
           acc[4] = P4_MFMA(wf[2][0], vf2[0], acc[4]);
           acc[5] = P4_MFMA(wf[2][1], vf2[1], acc[5]);
-        }
-        t_rows(xg_tag, lr_tag, H1, NC);
-        if constexpr (MM) {
           vf9 = *reinterpret_cast<const float2*>(vd);
+        }
+        if constexpr (PAIR) t_cols(xg_tag, lr_tag, second, vslot);
+        if constexpr (MM) {
           acc[4] = P4_MFMA(wf[2][2], vf2[2], acc[4]);
           acc[5] = P4_MFMA(wf[2][3], vf2[3], acc[5]);
           load_w(q + 1, 2);
         }
         P4_SB
-        P4_ST(6)
-        if constexpr (MM) {
-          acc[6] = P4_MFMA(wf[3][0], vf3[0], acc[6]);
-          acc[7] = P4_MFMA(wf[3][1], vf3[1], acc[7]);
-        }
-        t_cols(xg_tag, lr_tag, first, vslot);
-        P4_SB
-        if constexpr (MM) {
-          acc[8] = P4_MFMA(wf9[0], vf9.x, acc[8]);
-          acc[6] = P4_MFMA(wf[3][2], vf3[2], acc[6]);
-          acc[7] = P4_MFMA(wf[3][3], vf3[3], acc[7]);
-          load_w(q + 1, 3);
-        }
-        if constexpr (PAIR) t_cols(xg_tag, lr_tag, second, vslot);
-        P4_SB
-        if constexpr (MM) {
-          acc[8] = P4_MFMA(wf9[1], vf9.y, acc[8]);
-          load_w(q + 1, 4);
-        }
-        P4_SB
         P4_ST(7)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // V[(q + 1) & 1] and raw[q & 1] are written
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // V[(q + 1) & 1] and raw[q & 1] are written, the fragments of positions 6..8 read
         if (!(W4_EXP & 4)) __builtin_amdgcn_s_barrier();
         P4_SB
         P4_ST_END
@@ -996,10 +1001,18 @@ __global__ __launch_bounds__(512) void conv3x3_wino4p_kernel(ConvArgs a) {
         default: run(std::integral_constant<int, 3>{}, mm_tag); break;
       }
     };
-    if (nt == 1 && P.ntile * 64 + 32 >= a.coutp)  // wave-uniform
+    if (nt == 1 && P.ntile * 64 + 32 >= a.coutp) {  // wave-uniform
       run_mm(std::false_type{});
-    else
+    } else {
       run_mm(std::true_type{});
+      // the last quarter's positions 6..8
+      acc[6] = P4_MFMA(wf[3][0], vf3[0], acc[6]);
+      acc[7] = P4_MFMA(wf[3][1], vf3[1], acc[7]);
+      acc[8] = P4_MFMA(wf9[0], vf9.x, acc[8]);
+      acc[6] = P4_MFMA(wf[3][2], vf3[2], acc[6]);
+      acc[7] = P4_MFMA(wf[3][3], vf3[3], acc[7]);
+      acc[8] = P4_MFMA(wf9[1], vf9.y, acc[8]);
+    }
 
 #ifdef W4_STAMP
     const unsigned long long tile_t2 = __builtin_amdgcn_s_memtime();  // loop done
@@ -1101,14 +1114,18 @@ __global__ __launch_bounds__(512) void conv3x3_wino4p_kernel(ConvArgs a) {
 #ifdef W4_STAMP
       if (a.clock_probe && lane == 0 && vid == (int)blockIdx.x) {
         unsigned long long* o = a.clock_probe + ((size_t)blockIdx.x * 12 + pw) * 8;
-        o[0] = (tile_t1 - tile_t0) * (unsigned long long)(qend - qbeg);  // (the harness divides by the quarter count)
-        o[1] = (tile_t2 - tile_t1) * 0 + st[6] + st[7];
+#ifdef W4_STTILE  // the tile's phases (the harness divides by the quarter count): prologue, one quarter, dump, output transform of N half 0, wait for the other dump, N half 1
+        o[0] = (tile_t1 - tile_t0) * (unsigned long long)(qend - qbeg);
+        o[1] = st[0] + st[1] + st[2] + st[3] + st[4] + st[5] + st[6] + st[7];
         o[2] = (e1 - tile_t2) * (unsigned long long)(qend - qbeg);
         o[3] = (e2 - e1) * (unsigned long long)(qend - qbeg);
         o[4] = (e3 - e2) * (unsigned long long)(qend - qbeg);
         o[5] = (__builtin_amdgcn_s_memtime() - e3) * (unsigned long long)(qend - qbeg);
-        o[6] = st[6];
-        o[7] = st[7];
+        o[6] = o[7] = 0;
+#else
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = st[i];
+#endif
       }
 #endif
     } else {
