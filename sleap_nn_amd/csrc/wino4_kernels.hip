@@ -541,6 +541,9 @@ __global__ __launch_bounds__(768) void conv3x3_wino4_kernel(ConvArgs a) {
 //     their use, the row pass, the column pass, the V stores.
 //   * LDS: three raw halo slots + two V slots = 72 KiB in the loop; the epilogue sends one N tile at a time through LDS (144 KiB, all 36 positions) and
 //     waves 0..3 apply A^T . A: one thread per (tile, channel quad), eight lanes = 128 contiguous bytes of a pixel.
+#ifndef P4_SOFTBAR
+#define P4_SOFTBAR 0  // 1: the loop's barrier as LDS flags (arrive / wait apart; measured 3 - 4 % slower: a poll costs what the barrier's skew did); 0: s_barrier
+#endif
 template <int P, int N>
 __device__ __forceinline__ void p4_vput(float* slot, int vwq, int vwd, const float* v) {  // N transformed values of positions P .. P + N - 1 into a V slot
   if constexpr (N > 0) {
@@ -681,6 +684,19 @@ __global__ __launch_bounds__(512) void conv3x3_wino4p_kernel(ConvArgs a) {
       if (W4_EXP & (8 | 2048)) return;
       *reinterpret_cast<f32x4*>(slot + pw * 256) = hreg[0];
       if (has1) *reinterpret_cast<f32x4*>(slot + (pw + 8) * 256) = hreg[1];
+    };
+    auto load_raw_prepare = [&]() {};
+    // The loop's barrier in two halves (gfx950 has no split s_barrier): a wave ARRIVES by writing the quarter it has finished into its word of LDS, and WAITS -- four MFMAs into the
+    // next quarter -- until all eight words say so.  A straggler costs the others nothing while it is less than those four MFMAs late.
+    typedef __attribute__((address_space(3))) volatile int lds_flag_t;  // (explicitly LDS: a generic volatile pointer compiles to flat loads that wait for every global load in flight)
+    lds_flag_t* const flags = (lds_flag_t*)(lds + 2 * W4_RAW_FLOATS + 2 * W4_V_FLOATS);
+    auto soft_arrive = [&](int q) {
+      if (lane == 0) flags[pw] = q;
+    };
+    auto soft_wait = [&](int want) {
+      if (W4_EXP & 4) return;
+      while (__builtin_amdgcn_ballot_w64(flags[lane & 7] < want) != 0) {
+      }
     };
     const int w_tile = P.ntile * Q * (W4_Q_FLOATS * 4);
     f32x4 wf[4];
@@ -825,6 +841,9 @@ __global__ __launch_bounds__(512) void conv3x3_wino4p_kernel(ConvArgs a) {
     };
 
     // ---- prologue: raw of the slice's first three quarters, weights of its first; transform the first quarter
+#if P4_SOFTBAR
+    if (tid < 8) flags[tid] = qbeg - 1;
+#endif
     load_raw(qbeg);
     store_raw(qbeg);
     load_raw(qbeg + 1);
@@ -910,6 +929,34 @@ __global__ __launch_bounds__(512) void conv3x3_wino4p_kernel(ConvArgs a) {
         f32x4 vf0, vf1, vf2;
         // the previous quarter's last six MFMAs come first (their operands have been in registers since before the barrier), the quarter's memory instructions between them
         P4_ST(0)
+#if P4_SOFTBAR
+        // four of them before this wave asks whether the others have finished quarter q - 1 (its V and halo writes, its reads of the slots about to be overwritten)
+        if constexpr (MM) {
+          acc[6] = P4_MFMA(wf[3][0], vf3[0], acc[6]);
+          acc[7] = P4_MFMA(wf[3][1], vf3[1], acc[7]);
+          acc[8] = P4_MFMA(wf9[0], vf9.x, acc[8]);
+          acc[6] = P4_MFMA(wf[3][2], vf3[2], acc[6]);
+        }
+        load_raw_prepare();
+        P4_SB
+        P4_ST(1)
+        soft_wait(q - 1);
+        P4_SB
+        P4_ST(2)
+        store_raw(q + 2);  // (loaded during quarter q - 1; slot q & 1 was transformed during quarter q - 1)
+        if constexpr (MM) vf0 = *reinterpret_cast<const f32x4*>(vq);
+        t_read(xg_tag, lr_tag, raw, 0, H1);
+        load_raw(q + 3);
+        P4_SB
+        if constexpr (MM) {
+          acc[7] = P4_MFMA(wf[3][3], vf3[3], acc[7]);
+          load_w(q, 3);
+          vf1 = *reinterpret_cast<const f32x4*>(vq + 256);
+          P4_ST(3)
+          acc[8] = P4_MFMA(wf9[1], vf9.y, acc[8]);
+          load_w(q, 4);
+        }
+#else
         if constexpr (MM) {
           acc[6] = P4_MFMA(wf[3][0], vf3[0], acc[6]);
           acc[7] = P4_MFMA(wf[3][1], vf3[1], acc[7]);
@@ -936,6 +983,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino4p_kernel(ConvArgs a) {
           acc[8] = P4_MFMA(wf9[1], vf9.y, acc[8]);
           load_w(q, 4);
         }
+#endif
         t_rows(xg_tag, lr_tag, 0, H1);
         t_read(xg_tag, lr_tag, raw, H1, NC);
         P4_SB
@@ -978,7 +1026,11 @@ __global__ __launch_bounds__(512) void conv3x3_wino4p_kernel(ConvArgs a) {
         P4_SB
         P4_ST(7)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // V[(q + 1) & 1] and raw[q & 1] are written, the fragments of positions 6..8 read
+#if P4_SOFTBAR
+        soft_arrive(q);
+#else
         if (!(W4_EXP & 4)) __builtin_amdgcn_s_barrier();
+#endif
         P4_SB
         P4_ST_END
       }
@@ -1013,6 +1065,9 @@ __global__ __launch_bounds__(512) void conv3x3_wino4p_kernel(ConvArgs a) {
       acc[7] = P4_MFMA(wf[3][3], vf3[3], acc[7]);
       acc[8] = P4_MFMA(wf9[1], vf9.y, acc[8]);
     }
+#if P4_SOFTBAR
+    __builtin_amdgcn_s_barrier();  // (every wave is out of the loop: LDS may be reused)
+#endif
 
 #ifdef W4_STAMP
     const unsigned long long tile_t2 = __builtin_amdgcn_s_memtime();  // loop done
