@@ -1074,34 +1074,45 @@ __global__ __launch_bounds__(512) void conv3x3_wino4p_kernel(ConvArgs a) {
 #endif
     // ---- epilogue (the loop's last barrier has passed: every LDS read of the tile is done)
     float* const exch = lds;  // [position 36][tile 32][channel quad 8, XOR-swizzled by the tile][4]: 144 KiB
-    auto dump = [&]() __attribute__((always_inline)) {
-      // position p = 9 pg + i at p * 1024 floats (an immediate offset per i), channel quad 2 k + lh at slot (2 k + lh) ^ (lx & 7) = slot(0) ^ 2 k: four base addresses, made here
+    // Two rounds through LDS, each with HALF of every wave's registers: round r = channel quads k = 2 r, 2 r + 1 of both N halves (144 KiB), so that the accumulators a wave still holds
+    // during the first output transform are 72, not 144.  LDS slot of (N half nt, quad k, lane half lh): nt * 4 + (k & 1) * 2 + lh, XOR-swizzled by the tile.
+    auto dump = [&](int r) __attribute__((always_inline)) {
+      // position p = 9 pg + i at p * 1024 floats (an immediate offset per i); the slot's XOR makes two base addresses per round, made here
       // (hoisted out of the tile loop the 36 addresses were spilled and came back one scratch load at a time: 22 thousand cycles per dump)
-      int d0 = ((pg * 9 * 32 + lx) * 8 + (lh ^ (lx & 7))) << 2;
+      int d0 = ((pg * 9 * 32 + lx) * 8 + ((nt * 4 + lh) ^ (lx & 7))) << 2;
       asm volatile("" : "+v"(d0));
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        float* const dk = exch + (d0 ^ (k << 3));
+      for (int kk = 0; kk < 2; ++kk) {
+        float* const dk = exch + (d0 ^ (kk << 3));
 #pragma unroll
         for (int i = 0; i < 9; ++i) {
           f32x4 v;
-          v[0] = acc[i][4 * k + 0];
-          v[1] = acc[i][4 * k + 1];
-          v[2] = acc[i][4 * k + 2];
-          v[3] = acc[i][4 * k + 3];
+          if (r == 0) {
+            v[0] = acc[i][4 * kk + 0];
+            v[1] = acc[i][4 * kk + 1];
+            v[2] = acc[i][4 * kk + 2];
+            v[3] = acc[i][4 * kk + 3];
+          } else {
+            v[0] = acc[i][8 + 4 * kk + 0];
+            v[1] = acc[i][8 + 4 * kk + 1];
+            v[2] = acc[i][8 + 4 * kk + 2];
+            v[3] = acc[i][8 + 4 * kk + 3];
+          }
           *reinterpret_cast<f32x4*>(dk + i * 1024) = v;
         }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     };
-    auto finish = [&](int round) __attribute__((always_inline)) {  // waves 0..3: one thread per (tile, channel quad) of N half `round`
-      const int tile = tid >> 3, cq = tid & 7;
+    // The output transform of a round, all eight waves: one thread per (tile, slot, row half hh): rows 2 hh and 2 hh + 1 of the 4 x 4 output tile (each reads all 36 positions)
+    auto finish = [&](int round, auto hh_tag) __attribute__((always_inline)) {
+      constexpr int HH = decltype(hh_tag)::value;
+      const int tile = (tid & 255) >> 3, cq = tid & 7;
       const int ty = tile >> 3, tx = tile & 7;
       int z0 = (tile * 8 + (cq ^ (tile & 7))) << 2;
       asm volatile("" : "+v"(z0));
       const float* zp = exch + z0;
-      // row pass (over xi) per nu, with the expressions of the twelve-wave kernel's owning waves: Z[a][nu]
-      f32x4 z[4][6];
+      // row pass (over xi) per nu, with the expressions of the twelve-wave kernel's owning waves: Z[a][nu] for this thread's two rows a
+      f32x4 z[2][6];
 #pragma unroll
       for (int n = 0; n < 6; ++n) {
         f32x4 m[6];
@@ -1110,28 +1121,33 @@ __global__ __launch_bounds__(512) void conv3x3_wino4p_kernel(ConvArgs a) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float s12 = m[1][e] + m[2][e], d12 = m[1][e] - m[2][e], s34 = m[3][e] + m[4][e], d34 = m[3][e] - m[4][e];
-          z[0][n][e] = (m[0][e] + s12) + s34;
-          z[1][n][e] = fmaf(2.f, d34, d12);
-          z[2][n][e] = fmaf(4.f, s34, s12);
-          z[3][n][e] = fmaf(8.f, d34, d12) + m[5][e];
+          if constexpr (HH == 0) {
+            z[0][n][e] = (m[0][e] + s12) + s34;
+            z[1][n][e] = fmaf(2.f, d34, d12);
+          } else {
+            z[0][n][e] = fmaf(4.f, s34, s12);
+            z[1][n][e] = fmaf(8.f, d34, d12) + m[5][e];
+          }
         }
       }
-      const int co = P.ntile * 64 + round * 32 + 4 * cq;
+      const int co = P.ntile * 64 + (cq >> 2) * 32 + round * 16 + (cq & 3) * 4;
       const f32x4 bias = KS ? f32x4{0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4*>(a.bias + co);
+      const int oy0 = P.y0 + 4 * ty, ox = P.x0 + 4 * tx;
+      const bool live = oy0 < a.H && ox < a.W && co < a.coutp;  // (H and W are multiples of 4: a 4 x 4 tile is inside the image or outside)
+      f32x4 prow[2];  // fused 2 x 2 / 2 max pool (ConvArgs::dst_pool; even H and W: no padded windows): the column-pair maxima of the window's first row
 #pragma unroll
-      for (int aa = 0; aa < 4; ++aa) {
-        const f32x4 s12 = z[aa][1] + z[aa][2], d12 = z[aa][1] - z[aa][2], s34 = z[aa][3] + z[aa][4], d34 = z[aa][3] - z[aa][4];
+      for (int a2 = 0; a2 < 2; ++a2) {
+        const int aa = 2 * HH + a2;
+        const f32x4 s12 = z[a2][1] + z[a2][2], d12 = z[a2][1] - z[a2][2], s34 = z[a2][3] + z[a2][4], d34 = z[a2][3] - z[a2][4];
         f32x4 y[4];
-        y[0] = ((z[aa][0] + s12) + s34) + bias;
+        y[0] = ((z[a2][0] + s12) + s34) + bias;
         y[1] = (d12 + 2.f * d34) + bias;
         y[2] = (s12 + 4.f * s34) + bias;
-        y[3] = ((d12 + 8.f * d34) + z[aa][5]) + bias;
-        const int oy = P.y0 + 4 * ty + aa, ox = P.x0 + 4 * tx;
-        if (oy < a.H && co < a.coutp) {
-          float* const dp = a.dst + ((size_t)(P.b * a.H + oy) * a.W + ox) * a.coutp + co + (KS ? (size_t)ksl * a.split_stride : (size_t)0);
+        y[3] = ((d12 + 8.f * d34) + z[a2][5]) + bias;
+        if (live) {
+          float* const dp = a.dst + ((size_t)(P.b * a.H + oy0 + aa) * a.W + ox) * a.coutp + co + (KS ? (size_t)ksl * a.split_stride : (size_t)0);
 #pragma unroll
           for (int bb = 0; bb < 4; ++bb) {
-            if (ox + bb >= a.W) continue;
             f32x4 v = y[bb];
             if (a.relu) {
 #pragma unroll
@@ -1142,54 +1158,74 @@ __global__ __launch_bounds__(512) void conv3x3_wino4p_kernel(ConvArgs a) {
 #pragma unroll
               for (int e = 0; e < 4; ++e) v[e] = f[e] > 0.f ? v[e] : 0.f;
             }
-            *reinterpret_cast<f32x4*>(dp + (size_t)bb * a.coutp) = v;
+            y[bb] = v;
+            if (KS || !a.skip_dst) *reinterpret_cast<f32x4*>(dp + (size_t)bb * a.coutp) = v;
+          }
+          if (!KS && a.dst_pool) {
+            f32x4 m0, m1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              m0[e] = fmaxf(y[0][e], y[1][e]);
+              m1[e] = fmaxf(y[2][e], y[3][e]);
+            }
+            if (aa & 1) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                m0[e] = fmaxf(m0[e], prow[0][e]);
+                m1[e] = fmaxf(m1[e], prow[1][e]);
+              }
+              float* const pp = a.dst_pool + ((size_t)(P.b * (a.H >> 1) + ((oy0 + aa) >> 1)) * (a.W >> 1) + (ox >> 1)) * a.coutp + co;
+              *reinterpret_cast<f32x4*>(pp) = m0;
+              *reinterpret_cast<f32x4*>(pp + a.coutp) = m1;
+            } else {
+              prow[0] = m0;
+              prow[1] = m1;
+            }
           }
         }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     };
-    // (two programs with the same four barriers: the waves of N half 0 are done with their accumulators after the first dump, which leaves them the registers of the output transform)
-    if (nt == 0) {
-      dump();
-      __builtin_amdgcn_s_barrier();
 #ifdef W4_STAMP
-      const unsigned long long e1 = __builtin_amdgcn_s_memtime();
+    unsigned long long e1 = 0, e2 = 0, e3 = 0;
+#define P4_ET(x) x = __builtin_amdgcn_s_memtime();
+#else
+#define P4_ET(x)
 #endif
-      finish(0);
-      __builtin_amdgcn_s_barrier();
+    dump(0);
+    __builtin_amdgcn_s_barrier();
+    P4_ET(e1)
+    if (nt == 0)
+      finish(0, std::integral_constant<int, 0>{});
+    else
+      finish(0, std::integral_constant<int, 1>{});
+    __builtin_amdgcn_s_barrier();
+    P4_ET(e2)
+    dump(1);
+    __builtin_amdgcn_s_barrier();
+    P4_ET(e3)
+    if (nt == 0)
+      finish(1, std::integral_constant<int, 0>{});
+    else
+      finish(1, std::integral_constant<int, 1>{});
+    __builtin_amdgcn_s_barrier();
 #ifdef W4_STAMP
-      const unsigned long long e2 = __builtin_amdgcn_s_memtime();
-#endif
-      __builtin_amdgcn_s_barrier();
-#ifdef W4_STAMP
-      const unsigned long long e3 = __builtin_amdgcn_s_memtime();
-#endif
-      finish(1);
-      __builtin_amdgcn_s_barrier();
-#ifdef W4_STAMP
-      if (a.clock_probe && lane == 0 && vid == (int)blockIdx.x) {
-        unsigned long long* o = a.clock_probe + ((size_t)blockIdx.x * 12 + pw) * 8;
-#ifdef W4_STTILE  // the tile's phases (the harness divides by the quarter count): prologue, one quarter, dump, output transform of N half 0, wait for the other dump, N half 1
-        o[0] = (tile_t1 - tile_t0) * (unsigned long long)(qend - qbeg);
-        o[1] = st[0] + st[1] + st[2] + st[3] + st[4] + st[5] + st[6] + st[7];
-        o[2] = (e1 - tile_t2) * (unsigned long long)(qend - qbeg);
-        o[3] = (e2 - e1) * (unsigned long long)(qend - qbeg);
-        o[4] = (e3 - e2) * (unsigned long long)(qend - qbeg);
-        o[5] = (__builtin_amdgcn_s_memtime() - e3) * (unsigned long long)(qend - qbeg);
-        o[6] = o[7] = 0;
+    if (a.clock_probe && lane == 0 && vid == (int)blockIdx.x) {
+      unsigned long long* o = a.clock_probe + ((size_t)blockIdx.x * 12 + pw) * 8;
+#ifdef W4_STTILE  // the tile's phases (the harness divides by the quarter count): prologue, one quarter, first dump, first output transform, second dump, second output transform
+      o[0] = (tile_t1 - tile_t0) * (unsigned long long)(qend - qbeg);
+      o[1] = st[0] + st[1] + st[2] + st[3] + st[4] + st[5] + st[6] + st[7];
+      o[2] = (e1 - tile_t2) * (unsigned long long)(qend - qbeg);
+      o[3] = (e2 - e1) * (unsigned long long)(qend - qbeg);
+      o[4] = (e3 - e2) * (unsigned long long)(qend - qbeg);
+      o[5] = (__builtin_amdgcn_s_memtime() - e3) * (unsigned long long)(qend - qbeg);
+      o[6] = o[7] = 0;
 #else
 #pragma unroll
-        for (int i = 0; i < 8; ++i) o[i] = st[i];
+      for (int i = 0; i < 8; ++i) o[i] = st[i];
 #endif
-      }
-#endif
-    } else {
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_s_barrier();
-      dump();
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_s_barrier();
     }
+#endif
   }
 #ifdef W4_CLOCK
   if (a.clock_probe && tid == 0) {
@@ -1218,7 +1254,8 @@ int prepare_wino4_kernels() {
 // Shapes the kernel takes: N tile 64, whole 4x4 Winograd tiles (H and W multiples of 4), channel counts in quarters, every tensor
 // addressable through a 32-bit buffer descriptor; no fused pool / head / accumulate / ReLU mask (those stay on the F(2x2,3x3) kernel).
 bool wino4_fits(const ConvArgs& a) {
-  if (!a.wpack_wino4 || a.bn != 64 || (a.H & 3) || (a.W & 3) || a.dst_pool || a.head_w || a.accumulate || a.skip_dst) return false;
+  if (!a.wpack_wino4 || a.bn != 64 || (a.H & 3) || (a.W & 3) || a.head_w || a.accumulate) return false;
+  if (g_w4_legacy && (a.dst_pool || a.skip_dst)) return false;  // (the fused 2 x 2 max pool and the unread full-resolution output are the pipelined kernel's)
   if (a.src1_lowres && (!a.src1 || (a.H & 1) || (a.W & 1))) return false;
   const uint64_t px = (uint64_t)a.B * a.H * a.W;
   if (px * (uint64_t)a.c0p * 4 >= 0xFFFFFF00ull || px * (uint64_t)a.c1p * 4 >= 0xFFFFFF00ull || px >= 0x7FFFFFFFull) return false;
@@ -1238,7 +1275,7 @@ bool wino4_fits(const ConvArgs& a) {
   const long t4 = (long)((a.H + W4_PH - 1) / W4_PH) * ((a.W + W4_PW - 1) / W4_PW) * a.B * ntc;
   const long t2 = (long)((a.H + 15) / 16) * ((a.W + 15) / 16) * a.B * ntc;
   const double Qn = (a.c0p + a.c1p) / 4.0;
-  const double cost4 = (double)((t4 * ks4 + n_cu - 1) / n_cu) * (8.0 + 1.6 * Qn / ks4) + (ks4 > 1 ? 8.0 : 0.0);
+  const double cost4 = (double)((t4 * ks4 + n_cu - 1) / n_cu) * (11.0 + 1.5 * Qn / ks4) + (ks4 > 1 ? 8.0 : 0.0);  // (the pipelined kernel: 3 200 cycles per quarter, 23 000 per tile outside its loop)
   const double cost2 = (double)((t2 * ks2 + n_cu - 1) / n_cu) * (8.0 + 1.0 * Qn / ks2) + (ks2 > 1 ? 8.0 : 0.0);
   return cost4 <= cost2;
 }
@@ -1266,7 +1303,7 @@ static int wino4_ksplit(const ConvArgs& a) {
 }
 
 int launch_conv3x3_wino4(const ConvArgs& a, hipStream_t s) {
-  PH_REQUIRE(wino4_fits(a), "wino4: N tile 64, H and W multiples of 4, no fused pool / head / accumulate, tensors below 4 GiB");
+  PH_REQUIRE(wino4_fits(a), "wino4: N tile 64, H and W multiples of 4, no fused head / accumulate, tensors below 4 GiB");
   int n_cu = 0;
   const int rc = device_cu_count(&n_cu);
   if (rc != PH_OK) return rc;
@@ -1277,6 +1314,8 @@ int launch_conv3x3_wino4(const ConvArgs& a, hipStream_t s) {
     ConvArgs k = a;
     k.dst = a.split_scratch;
     k.relu = 0;
+    k.dst_pool = nullptr;
+    k.skip_dst = 0;
     k.ksplit = ksplit;
     k.split_stride = (long long)a.B * a.H * a.W * a.coutp;
     const dim3 grid(std::min(tiles * ntc * ksplit, n_cu));
@@ -1290,7 +1329,7 @@ int launch_conv3x3_wino4(const ConvArgs& a, hipStream_t s) {
     else
       hipLaunchKernelGGL((conv3x3_wino4_kernel<false, true>), grid, dim3(768), (size_t)W4_LDS_FLOATS * sizeof(float), s, k);
     PH_HIP_CHECK(hipGetLastError());
-    return launch_splitk_reduce(a.split_scratch, k.split_stride, ksplit, a.bias, a.dst, nullptr, a.B, a.H, a.W, a.coutp, a.relu, s);
+    return launch_splitk_reduce(a.split_scratch, k.split_stride, ksplit, a.bias, a.skip_dst ? nullptr : a.dst, a.dst_pool, a.B, a.H, a.W, a.coutp, a.relu, s);
   }
   if (!g_w4_legacy) {
     if (a.src1_lowres)
