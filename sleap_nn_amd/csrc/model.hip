@@ -667,7 +667,7 @@ ph_model* ph_model_create(const ph_op_desc* ops, int32_t n_ops, const float* con
         }
         // F(4x4,3x3) weights (conv3x3_wino4_kernel) of the layers with many input channels: 4x the direct weights' bytes
         auto derive_wino4 = [&](const float* src, int cin_a, int cin_b, int cout_, int bn, float** dst) {
-          if (bn != 64 || pad16(cin_a) + (cin_b > 0 ? pad16(cin_b) : 0) < 128) return true;
+          if (bn != 64 || pad16(cin_a) + (cin_b > 0 ? pad16(cin_b) : 0) < 64) return true;  // (derived from 64 input channels on; which layers take the kernel is conv_wino4_min_cin + the time model)
           const int ntiles = (pad16(cout_) + 63) / 64, nchunks = pad16(cin_a) / 16 + (cin_b > 0 ? pad16(cin_b) / 16 : 0);
           float* w = nullptr;
           if (hipMalloc(&w, (size_t)wino4_pack_floats(ntiles, nchunks) * sizeof(float)) != hipSuccess) return false;
@@ -1187,7 +1187,9 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
           for (size_t j = op_index; j < m->ops.size(); ++j) {
             const ph_op_desc& hx = m->ops[j].d;
             if (hx.kind != PH_OP_HEAD || hx.src0 != d.dst) continue;
-            const bool on_w2d = a.coutp == 64 && hx.cout <= 32 && pad16(hx.cin0) == 64 && conv3x3_dma_is_wino2d(a) && wino2d_ksplit(a) <= 1;
+            ConvArgs no4 = a;  // (a fused head beats F(4x4,3x3) + a head launch on the 64-channel layers both could take: ask what runs without that kernel; head_w then keeps it off)
+            no4.use_wino4 = 0;
+            const bool on_w2d = a.coutp == 64 && hx.cout <= 32 && pad16(hx.cin0) == 64 && conv3x3_dma_is_wino2d(no4) && wino2d_ksplit(no4) <= 1;
             const bool on_w16 = a.coutp <= 32 && hx.cout <= 16 && pad16(hx.cin0) == a.coutp && conv3x3_dma_is_w16_head(a);  // (conv3x3_w16_kernel<.., HEAD>)
             if (!(hx.flags & PH_FLAG_SOFTMAX) && out_dev[hx.out_index] && (on_w2d || on_w16)) {
               a.head_w = m->ops[j].w_dev;

@@ -43,7 +43,7 @@ struct ConvArgs {
   // Winograd F(4x4,3x3) (conv3x3_wino4_kernel, wino4_kernels.hip): layers with at least wino4_min_cin padded input channels
   const float* wpack_wino4 = nullptr;  // transformed weights in the kernel's private-ring order, or nullptr
   int use_wino4 = 0;          // filled from the handle option "conv_wino4" and the kind of plan: 1 = where it is estimated faster than F(2x2,3x3), 2 = wherever the shape fits
-  int wino4_min_cin = 128;    // handle option "conv_wino4_min_cin"
+  int wino4_min_cin = 64;     // handle option "conv_wino4_min_cin"
   int src1_lowres = 0;        // src1 is (B, H/2, W/2, c1p): bilinear x2 (align_corners = False) is folded into the input transform (wino4 only)
   // split K on the F(2x2,3x3) kernel (small batches: fewer work units than CUs), see conv3x3_wino2d_kernel<.., KS>
   int splitk = 0;                     // handle option "conv_splitk": 0 never, 1 where estimated faster, n >= 2 force n slices
