@@ -176,14 +176,13 @@ int conv3x3_dma_variant(const ConvArgs& a);        // PH_KV_* code (posehip.h) o
 int launch_wino2d_pack(const float* wpack, float* wino, int panels, int bn, hipStream_t s);
 int64_t wino2d_pack_floats(int panels, int bn);
 int launch_conv3x3_wino2d(const ConvArgs& a, hipStream_t s);
-// wpack [panel][tap 9][64][16] -> F(4x4,3x3) weights [n tile][quarter][wave][xi pair][lane][4] (see conv3x3_wino4_kernel)
+// wpack [panel][tap 9][64][16] -> F(4x4,3x3) weights [n tile][quarter][wave][fragment slot][lane] (see conv3x3_wino4_kernel)
 int launch_wino4_pack(const float* wpack, float* wino, int ntiles, int nchunks, hipStream_t s);
 int64_t wino4_pack_floats(int ntiles, int nchunks);
 int launch_conv3x3_wino4(const ConvArgs& a, hipStream_t s);
 bool wino4_fits(const ConvArgs& a);
 bool conv3x3_dma_is_wino4(const ConvArgs& a);      // launch_conv3x3_dma would run the F(4x4,3x3) kernel (the only one that folds a half-resolution src1)
 int prepare_wino4_kernels();
-void wino4_set_legacy(bool on);  // timing harness (tools/w4) only: the twelve-wave kernel and its weight order
 bool wino2d_fits(const ConvArgs& a);  // sources addressable through the kernel's 32-bit buffer descriptors
 int wino2d_ksplit(const ConvArgs& a);  // K slices launch_conv3x3_wino2d would use for this launch (1 = the one-stage kernel)
 int launch_splitk_reduce(const float* part, long long stride, int ks, const float* bias, float* dst, float* dst_pool, int B, int H, int W, int coutp, int relu, hipStream_t s);

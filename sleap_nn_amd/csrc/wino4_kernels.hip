@@ -1,4 +1,4 @@
-// 3x3 "same" convolution as Winograd F(4x4, 3x3) on the fp32 matrix cores (gfx950), for the K-heavy decoder layers.
+// 3x3 "same" convolution as Winograd F(4x4, 3x3) on the fp32 matrix cores (gfx950): the N-tile-64 layers from 64 input channels on.
 //
 // Reference semantics: nn.Conv2d(k3, padding "same") + bias + ReLU of SimpleConvBlock (architectures/encoder_decoder.py:108-121,
 // 494-510) over torch.concat((skip, x)) (encoder_decoder.py:545,556) where x may be nn.Upsample(x2, bilinear, align_corners=False)
@@ -9,37 +9,41 @@
 //
 // 36 multiplications per sixteen outputs instead of 144: the matrix cores execute 1/4 of the direct convolution's FLOPs
 // (F(2x2,3x3): 4/9).  fp32 throughout; the transforms have coefficients up to 8 (A), 5 (B) and 1/24 (G): measured against the fp64
-// convolution the result is ~5x further off than F(2x2,3x3) (1e-5 relative max at K = 768), which is why only
-// layers with many input channels -- where the MFMA work dominates and the heads' 1e-4 bar has room -- run here.
+// convolution the result is ~5x further off than F(2x2,3x3) (1e-5 relative max at K = 768), inside the heads' 1e-4 bar;
+// which layers run here is decided per layer by wino4_fits' time model (a tile costs ~11 us outside its K loop).
 //
-//   * GEMM view: per Winograd position (xi, nu) one GEMM with M = 4x4-pixel tiles, N = output channels, K = input channels.  A workgroup
-//     tile is 8 x 4 Winograd tiles (32 x 16 output pixels) x 64 channels; all 36 positions x (32 tiles x 64 channels) accumulators
-//     (288 KiB) live in the registers of TWELVE waves: wave (nu, nt) owns column nu of the transformed patch for the 32-channel N tile nt
-//     (six 32x32 accumulators, 96 registers; three waves per SIMD).  The product is accumulated transposed (weights = A operand): a lane
-//     is a tile, a register quad four consecutive channels.
-//   * K runs in QUARTERS (4 input channels = two K steps of v_mfma_f32_32x32x2_f32).  Per quarter the workgroup transforms the raw
-//     34 x 18 halo of the NEXT quarter into V[36][32 tiles][4 channels] in LDS -- thread (tile, channel, xi) computes row xi of
-//     B^T d B from the patch rows its xi combines: every thread of the 768 has one unit, nothing is computed twice -- while it multiplies
-//     the current quarter: each wave reads its six B fragments from V and its six A fragments from a PRIVATE two-slot weight ring
-//     (a wave's (nu, nt) weights are read by nobody else), 12 MFMAs.  One s_barrier per quarter.
-//   * Transfers: the raw halo (three slots, three quarters ahead) and the weights (two quarters ahead) arrive by buffer-descriptor
-//     LDS-DMA exactly as in conv3x3_wino2d_kernel: per-lane offsets fixed per tile, the quarter's channel offset in the scalar offset,
-//     out-of-image pixels out of range = hardware zeros.  Four DMA instructions per wave and quarter, s_waitcnt vmcnt(4) before the barrier.
+//   * GEMM view: per Winograd position p = xi * 6 + nu one GEMM with M = 4x4-pixel tiles, N = output channels, K = input channels.  A workgroup
+//     tile is 8 x 4 Winograd tiles (32 x 16 output pixels) x 64 channels; all 36 positions x (32 tiles x 64 channels) accumulators (288 KiB)
+//     live in the registers of EIGHT waves, two per SIMD: wave (nt, pg) owns positions 9 pg .. 9 pg + 8 of the 32-channel N half nt: nine 32x32
+//     accumulators (144 registers), 18 MFMAs per quarter.  The product is accumulated transposed (weights = A operand): a lane is a tile, a
+//     register quad four consecutive channels.  SIMD s holds waves (0, s) and (1, s), which read the same V fragments.
+//   * K runs in QUARTERS (4 input channels = two K steps of v_mfma_f32_32x32x2_f32).  Per quarter the workgroup transforms the raw 34 x 18 halo
+//     of the NEXT quarter into V[36 positions][32 tiles][4 channels] in LDS while it multiplies the current one.  The fp32 MFMA runs at the
+//     vector ALUs' rate and vector instructions do not overlap with it (measured, DESIGN.md 4.1c: MFMA cycles + VALU cycles add), so the design
+//     rule is FEW vector instructions, and every other kind -- LDS, global memory, scalar -- written between the MFMAs of one wave's stream:
+//       - weights come straight from L2 into registers, one quarter ahead (five buffer loads per wave and quarter, each into the registers the
+//         MFMAs before it just read): no LDS ring, no LDS traffic, no LDS-DMA issue cost (~150 cycles per transfer beside MFMAs);
+//       - the halo goes through registers too (buffer load in one quarter, ds_write_b128 in the next): two loads per wave and quarter;
+//       - the transform is dealt as (16 tiles) x (xi group): waves 0..3 take an xi pair ({1, 2} or {3, 4}: the pair shares its two row
+//         differences), waves 4..7 one of xi 0 / 5, a SIMD one of each; LDS reads are issued one MFMA group ahead of their use;
+//       - the MFMAs of positions 6..8 of a quarter are issued at the top of the NEXT quarter, behind the barrier (their operands wait in
+//         registers), so that the matrix pipe has work while the reads that follow the barrier are in flight.
+//     One s_barrier per quarter.  LDS in the loop: two raw halo slots + two V slots = 60 KiB.
 //   * Second source at half resolution (ConvArgs::src1_lowres): its slot holds the 18 x 10 LOW-resolution halo (index-clamped by the
 //     loader like the bilinear kernel clamps), the row pass applies B^T U (U = the 6 x 4 bilinear matrix of the patch rows, rows
 //     outside the image zeroed: the conv's padding) as four per-lane coefficients, the column pass forms the six up-sampled column
-//     samples first: 16 instead of 24 LDS reads and about the same arithmetic as a full-resolution quarter.
-//   * Epilogue: the row pass of A^T . A is register arithmetic in the owning wave (six xi -> four output rows), the column pass needs
-//     all six nu = six waves: one N tile at a time goes through LDS (96 KiB), every wave finishes its share of (row, channel quad)
-//     units: bias, ReLU, 16-byte stores.  The pipeline is drained at a tile's end (no cross-tile prefetch): the layers this kernel
-//     runs have >= 32 quarters per tile.
+//     samples first: 16 instead of 24 LDS reads per thread.
+//   * Epilogue: two rounds through LDS (144 KiB each), every wave with half of its registers per round (channel quads 0, 1, then 2, 3, of both N
+//     halves); all eight waves apply A^T . A: one thread per (tile, channel quad, row half) reads the 36 positions and stores two rows of the 4 x 4
+//     tile: bias, ReLU, the backward pass' ReLU mask, the fused 2 x 2 max pool (its windows are inside a thread's rows), 16-byte stores, eight lanes =
+//     two 64-byte runs of a pixel.  (round 3's form: twelve waves, three per SIMD, weights and halo by LDS-DMA, ran the same arithmetic 6 - 8 % slower.)
 #include <type_traits>
 
 #include "common.h"
 #include "net_kernels.h"
 
 #ifndef W4_EXP
-#define W4_EXP 0  // timing experiments of tools/w4/w4_bench.hip only (results are wrong with any bit set): 1 no weight transfers, 2 no input transform, 4 no per-quarter barrier, 8 no halo transfers, 16 no MFMAs; pipelined kernel: 32 weights always of the first quarter (cache-hot), 64 halo always of the first quarter, 128 transform without its arithmetic (LDS traffic only), 256 weights loaded once per tile, 1024 halo transfers with the access pattern of a 4-quarter chunk loader (plain single-source layers only)
+#define W4_EXP 0  // timing experiments of tools/w4/w4_bench.hip only (results are wrong with any bit set): 1 no weight loads, 2 no input transform, 4 no per-quarter barrier, 8 no halo transfers, 16 no MFMAs, 32 weights always of the first quarter (cache-hot), 64 halo always of the first quarter, 128 transform without its arithmetic (LDS traffic only), 256 weights loaded once per tile, 512 no output stores.  Ablations that zero the operands (1, 8, 16) also raise the clock: compare cycles (-DW4_CLOCK), not milliseconds
 #endif
 
 namespace ph {
@@ -51,21 +55,15 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int W4_TX = 8, W4_TY = 4;             // Winograd tiles per workgroup tile
 constexpr int W4_PW = 4 * W4_TX;                // 32 output columns
 constexpr int W4_PH = 4 * W4_TY;                // 16 output rows
-constexpr int W4_RAW_FLOATS = 12 * 256;         // one raw halo slot: 12 DMA pieces of 64 entries x 16 B (648 entries used: [hy 18][x & 3][x >> 2: 9])
-constexpr int W4_V_FLOATS = 36 * 128;           // one V slot: [nu 6][xi pair 3][lane 64][4]
-constexpr int W4_W_FLOATS = 3 * 256;            // one private weight slot of a wave: [xi pair 3][lane 64][4]
-constexpr int W4_RAW_OFF = 0;                   // three raw slots
-constexpr int W4_V_OFF = 3 * W4_RAW_FLOATS;     // two V slots
-constexpr int W4_W_OFF = W4_V_OFF + 2 * W4_V_FLOATS;  // twelve waves x two weight slots
-constexpr int W4_LDS_FLOATS = W4_W_OFF + 12 * 2 * W4_W_FLOATS;  // 36864 floats = 144 KiB
-constexpr int W4_Q_FLOATS = 12 * W4_W_FLOATS;   // transformed weights of one (N tile, quarter): 36 positions x 64 channels x 4 input channels
-constexpr int P4_WAVE_FLOATS = 4 * 256 + 128;   // conv3x3_wino4p_kernel: one wave's fragments of a quarter (nine positions: four position pairs of 16 B per lane + one of 8 B)
-static bool g_w4_legacy = false;                // timing harness only (tools/w4): the twelve-wave kernel and its weight order instead of the pipelined one
-void wino4_set_legacy(bool on) { g_w4_legacy = on; }
+constexpr int W4_RAW_FLOATS = 12 * 256;         // one raw halo slot: 12 pieces of 64 entries x 16 B (648 entries used: [hy 18][x & 3][x >> 2: 9]; 11 pieces are moved)
+constexpr int W4_V_FLOATS = 36 * 128;           // one V slot: [pg 4][four 16-byte fragment slots + one 8-byte slot][lane 64]
+constexpr int W4_LDS_FLOATS = 36 * 1024;        // the epilogue's exchange: 36 positions x 32 tiles x 8 channel quads x 4 = 144 KiB (the loop uses the first 60 KiB)
+constexpr int W4_Q_FLOATS = 36 * 64 * 4;        // transformed weights of one (N tile, quarter): 36 positions x 64 channels x 4 input channels
+constexpr int P4_WAVE_FLOATS = 4 * 256 + 128;   // one wave's fragments of a quarter (nine positions: four position pairs of 16 B per lane + one of 8 B)
 
-// wpack [panel][tap 9][bn 64][16] (pack_conv) -> U = G g G^T in the order the kernel's private weight rings take it:
-// [n tile][quarter][wave pw = nt * 6 + nu][xi pair p][lane (lh, lx)][e = (xi & 1) * 2 + j]: output channel n tile * 64 + nt * 32 + lx,
-// input channel quarter * 4 + 2 lh + j, position (xi = 2 p + (e >> 1), nu)
+// wpack [panel][tap 9][bn 64][16] (pack_conv) -> U = G g G^T in the order the waves load it:
+// [n tile][quarter][wave nt * 4 + pg][four 16-byte slots [lane (lh, lx)][ks * 2 + (pl & 1)] of the position pairs pl = (0, 1) .. (6, 7) | one 8-byte slot [lane][ks] of pl = 8]:
+// output channel n tile * 64 + nt * 32 + lx, input channel quarter * 4 + 2 lh + ks, position p = xi * 6 + nu = 9 pg + pl
 __device__ __forceinline__ float wino4_g_row(int k, float g0, float g1, float g2) {  // row k of G applied to (g0, g1, g2)
   switch (k) {
     case 0: return 0.25f * g0;
@@ -80,9 +78,6 @@ __device__ __forceinline__ float wino4_g_row(int k, float g0, float g1, float g2
 // loads its nine taps ONCE, forms all 36 positions in registers and drops them into LDS at their place in the unit; the unit then leaves as 36 coalesced
 // 1-KiB rows.  (One thread per destination element re-read the nine taps 36 times through 4-byte loads 64 B apart: 0.48 ms for the 2304 -> 768 layer's
 // 255 MB, 3.6 ms per ConvNeXt training step, where the weights change every step.)
-// PIPE: the order of conv3x3_wino4p_kernel: [n tile][quarter][wave nt * 4 + pg][four 16-byte slots [lane][ks * 2 + (pl & 1)] of the position pairs pl = (0, 1) .. (6, 7) | one 8-byte
-// slot [lane][ks] of pl = 8], position p = xi * 6 + nu = 9 pg + pl, input channel quarter * 4 + 2 lh + ks -- the same 9,216 floats per unit
-template <bool PIPE>
 __global__ __launch_bounds__(256) void wino4_pack_kernel(const float* __restrict__ src, float* __restrict__ dst, int ntiles, int nchunks) {
   __shared__ float unit[W4_Q_FLOATS];
   const int quarter = blockIdx.x % (4 * nchunks), ntile = blockIdx.x / (4 * nchunks);
@@ -102,12 +97,8 @@ __global__ __launch_bounds__(256) void wino4_pack_kernel(const float* __restrict
 #pragma unroll
     for (int nu = 0; nu < 6; ++nu) {
       const float u = wino4_g_row(nu, h[0], h[1], h[2]);
-      if (PIPE) {
-        const int p = xi * 6 + nu, pgp = p / 9, pl = p % 9;
-        unit[(nt * 4 + pgp) * P4_WAVE_FLOATS + (pl < 8 ? (((pl >> 1) * 64 + lh * 32 + lx) << 2) + j * 2 + (pl & 1) : 1024 + ((lh * 32 + lx) << 1) + j)] = u;
-      } else {
-        unit[((((nt * 6 + nu) * 3 + (xi >> 1)) * 64 + lh * 32 + lx) << 2) + (xi & 1) * 2 + j] = u;
-      }
+      const int p = xi * 6 + nu, pgp = p / 9, pl = p % 9;
+      unit[(nt * 4 + pgp) * P4_WAVE_FLOATS + (pl < 8 ? (((pl >> 1) * 64 + lh * 32 + lx) << 2) + j * 2 + (pl & 1) : 1024 + ((lh * 32 + lx) << 1) + j)] = u;
     }
   }
   __syncthreads();
@@ -117,10 +108,7 @@ __global__ __launch_bounds__(256) void wino4_pack_kernel(const float* __restrict
 }
 int64_t wino4_pack_floats(int ntiles, int nchunks) { return (int64_t)ntiles * 4 * nchunks * W4_Q_FLOATS; }
 int launch_wino4_pack(const float* wpack, float* wino, int ntiles, int nchunks, hipStream_t s) {
-  if (g_w4_legacy)
-    hipLaunchKernelGGL(wino4_pack_kernel<false>, dim3((unsigned)(ntiles * 4 * nchunks)), dim3(256), 0, s, wpack, wino, ntiles, nchunks);
-  else
-    hipLaunchKernelGGL(wino4_pack_kernel<true>, dim3((unsigned)(ntiles * 4 * nchunks)), dim3(256), 0, s, wpack, wino, ntiles, nchunks);
+  hipLaunchKernelGGL(wino4_pack_kernel, dim3((unsigned)(ntiles * 4 * nchunks)), dim3(256), 0, s, wpack, wino, ntiles, nchunks);
   PH_HIP_CHECK(hipGetLastError());
   return PH_OK;
 }
@@ -153,397 +141,6 @@ __device__ __forceinline__ void w4_col_pass(const float (&t)[6], float (&v)[6]) 
   v[5] = fmaf(4.f, t[1], fmaf(-5.f, t[3], t[5]));
 }
 
-// LOWRES: the second source is the half-resolution tensor (ConvArgs::src1_lowres); the plain instantiation does not carry its row coefficients and branches
-// KS (round 4, as conv3x3_wino2d_kernel's): a work unit is (pixel tile, N tile, K slice): slice ks covers quarters [ks Q / ksplit, (ks + 1) Q / ksplit), its epilogue stores raw partial
-// sums (no bias, no ReLU) to plane ks of the scratch tensor and splitk_reduce_kernel adds the planes in slice order.  For layers whose 32 x 16-pixel tiles fill less than half of the CUs
-// (the per-rank batches of the strong-scaling runs, cfg2): which of F(4x4,3x3) / F(2x2,3x3), split or not, runs a layer is decided by wino4_fits' time model.
-template <bool LOWRES, bool KS = false>
-__global__ __launch_bounds__(768) void conv3x3_wino4_kernel(ConvArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int pw = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave 0..11
-  // consumer role: column nu of the transformed patch, N tile nt (32 channels)
-  const int nu = pw % 6, nt = pw / 6;
-  const int lx = lane & 31, lh = lane >> 5;
-  // producer role: thread = (Winograd tile (typ, txp), channel cp of the quarter, row xip of B^T d B); a half wave = 8 tiles x 4 channels
-  const int xip = pw >> 1;
-  const int typ = 2 * (pw & 1) + (lane >> 5), txp = (lane >> 2) & 7, cp = lane & 3;
-
-  const int tiles_x = (a.W + W4_PW - 1) / W4_PW;
-  const int tiles_y = (a.H + W4_PH - 1) / W4_PH;
-  const int tiles = tiles_x * tiles_y * a.B;
-  const int ntc = (a.coutp + 63) / 64;
-  const int units = tiles * ntc;
-  const int total = KS ? units * a.ksplit : units;
-  const int Q0 = a.c0p / 4, Q1 = a.c1p / 4, Q = Q0 + Q1;
-  constexpr int lowres = LOWRES ? 1 : 0;
-  const int Hl = a.H >> 1, Wl = a.W >> 1;
-
-  float* const rawbuf = lds + W4_RAW_OFF;
-  float* const vbuf = lds + W4_V_OFF;
-  float* const wring = lds + W4_W_OFF + pw * 2 * W4_W_FLOATS;
-
-  // ---- producer constants.  Row pass of a full-resolution quarter, one form for every xi (three operations per patch column):
-  //     t[c] = fma(beta, fma(gamma, P, Q), fma(alpha, R, S))       (P, Q, R, S = patch rows of column c)
-  //   xi 1: (d3 - 4 d1) + (d4 - 4 d2)     xi 2: -(d3 - 4 d1) + (d4 - 4 d2)     xi 3: 2 (d3 - d1) + (d4 - d2)     xi 4: -2 (d3 - d1) + (d4 - d2)
-  //   xi 0: 4 d0 + (d4 - 5 d2)            xi 5: 4 d1 + (d5 - 5 d3)             (two operations: no P, Q = the first row)
-  // Rows (P, Q, R, S) are (1, 3, 2, 4) for xi 1..4 and (-, 0, 2, 4) + (xi == 5) for xi 0 and 5: two code variants with immediate offsets.
-  const bool tri = xip == 0 || xip == 5;
-  const float alpha = tri ? -5.f : (xip <= 2 ? -4.f : -1.f);
-  const float gamma = tri ? 0.f : (xip <= 2 ? -4.f : -1.f);
-  const float beta = tri ? 4.f : (xip == 1 ? 1.f : (xip == 2 ? -1.f : (xip == 3 ? 2.f : -2.f)));
-  // raw slot entry of halo pixel (hy, hx): hy * 36 + (hx & 3) * 9 + (hx >> 2); patch column c of tile txp is hx = 4 txp + c
-  const int pbase_f = ((4 * typ + (xip == 5 ? 1 : 0)) * 36 + txp) * 4 + cp;     // floats: patch row 0 (row 1 for xi = 5), column 0
-  // low-resolution slot entry of (ly, lc): ly * 18 + (lc & 1) * 9 + (lc >> 1); the tile's 4 x 4 low-resolution patch starts at (2 typ, 2 txp)
-  const int pbase_l = ((2 * typ) * 18 + txp) * 4 + cp;
-  // V write index of this thread for nu = 0: ((nu * 3 + (xi >> 1)) * 64 + (c >> 1) * 32 + tile) * 4 + (xi & 1) * 2 + (c & 1)
-  const int vw0 = (((xip >> 1)) * 64 + (cp >> 1) * 32 + typ * 8 + txp) * 4 + (xip & 1) * 2 + (cp & 1);
-  const int vr0 = (nu * 3 * 64 + lane) * 4;  // V read of (nu, xi pair 0)
-
-  struct Plan {
-    int b, x0, y0, ntile;
-  };
-  const int G = (int)gridDim.x;
-  const bool rotate = (a.coutp & 63) != 0 && (a.coutp & 63) <= 32 && ntc > 1 && (((tiles & 7) == 0) ? ((G & 7) == 0 && (G >> 3) % ntc == 0) : (G % ntc == 0));
-  auto setup = [&](int vid, Plan& P) {
-    int t, ntile;
-    w4_deal_tile(vid, tiles, ntc, rotate ? vid / G : 0, &t, &ntile);
-    const int tx = t % tiles_x;
-    t /= tiles_x;
-    const int ty = t % tiles_y;
-    P.b = t / tiles_y;
-    P.x0 = tx * W4_PW;
-    P.y0 = ty * W4_PH;
-    P.ntile = ntile;
-  };
-
-  // weights: buffer descriptor over the whole transformed tensor, wave pw moves its own 3 KiB of a quarter as three pieces
-  const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.wpack_wino4, 0, (int)((unsigned)ntc * (unsigned)Q * (unsigned)(W4_Q_FLOATS * 4)), 0x00020000);
-  const unsigned w_lane = (unsigned)(pw * W4_W_FLOATS + lane * 4) * 4u;
-
-  for (int vid = blockIdx.x; vid < total; vid += gridDim.x) {
-    Plan P;
-    const int ksl = KS ? vid / units : 0;                      // K slice of this unit
-    const int qbeg = KS ? ksl * Q / a.ksplit : 0;              // its quarters [qbeg, qend)
-    const int qend = KS ? (ksl + 1) * Q / a.ksplit : Q;
-    setup(KS ? vid - ksl * units : vid, P);
-    // ---- per-tile loader state: this lane's halo entry of source 0 (piece pw of the full-resolution layout) and of source 1
-    unsigned off0, off1;
-    {
-      const int e = pw * 64 + lane;  // entry of the raw slot (piece pw; pieces 0..10 hold the 648 entries, wave 11's piece is unused)
-      const int hy = e / 36, rem = e - hy * 36;
-      const int pl = rem / 9, k = rem - pl * 9;
-      const int hx = 4 * k + pl;
-      const int gy = P.y0 + hy - 1, gx = P.x0 + hx - 1;
-      const bool in = hy < W4_PH + 2 && hx < W4_PW + 2 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-      off0 = in ? (unsigned)((P.b * a.H + gy) * a.W + gx) * (unsigned)(a.c0p * 4) : 0xFFFFFF00u;
-      if (!lowres) {
-        off1 = (in && a.c1p > 0) ? (unsigned)((P.b * a.H + gy) * a.W + gx) * (unsigned)(a.c1p * 4) : 0xFFFFFF00u;
-      } else {
-        // low-resolution layout: entry ly * 18 + (lc & 1) * 9 + (lc >> 1), 180 entries in pieces 0..2; indices clamped (bilinear's edge rule)
-        const int ly = e / 18, rem2 = e - ly * 18;
-        const int par = rem2 / 9, kk = rem2 - par * 9;
-        const int lc = 2 * kk + par;
-        const int sy = min(max((P.y0 >> 1) - 1 + ly, 0), Hl - 1), sx = min(max((P.x0 >> 1) - 1 + lc, 0), Wl - 1);
-        off1 = (ly < W4_PH / 2 + 2) ? (unsigned)((P.b * Hl + sy) * Wl + sx) * (unsigned)(a.c1p * 4) : 0xFFFFFF00u;
-      }
-    }
-    const __amdgpu_buffer_rsrc_t rsrc0 = __builtin_amdgcn_make_buffer_rsrc((void*)a.src0, 0, (int)((unsigned)(a.B * a.H * a.W) * (unsigned)(a.c0p * 4)), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsrc1 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.src1 ? a.src1 : a.src0), 0,
-                                                                           (int)((unsigned)(lowres ? a.B * Hl * Wl : a.B * a.H * a.W) * (unsigned)(a.c1p * 4)), 0x00020000);
-    auto issue_raw = [&](int k) {  // halo of quarter k into raw slot k % 3 (out of range beyond the tile's last quarter)
-      float* dst = rawbuf + (k % 3) * W4_RAW_FLOATS + pw * 256;
-      const bool s1 = k >= Q0;
-      const unsigned off = k < qend ? (s1 ? off1 : off0) : 0xFFFFFF00u;
-      const int so = k < qend ? (s1 ? (k - Q0) * 16 : k * 16) : 0;
-      if (W4_EXP & 8) return;
-      if (s1)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc1, (__attribute__((address_space(3))) void*)dst, 16, off, so, 0, 0);
-      else
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc0, (__attribute__((address_space(3))) void*)dst, 16, off, so, 0, 0);
-    };
-    const int w_tile = P.ntile * Q * (W4_Q_FLOATS * 4);
-    auto issue_w = [&](int k) {  // weights of quarter k into this wave's ring slot k & 1
-      __attribute__((address_space(3))) void* l = (__attribute__((address_space(3))) void*)(wring + (k & 1) * W4_W_FLOATS);
-      const unsigned lo = k < qend ? w_lane : 0xFFFFFF00u;
-      const int so = k < qend ? w_tile + k * (W4_Q_FLOATS * 4) : 0;
-      if (W4_EXP & 1) return;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, l, 16, lo, so, 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, l, 16, lo, so, 1024, 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, l, 16, lo, so, 2048, 0);
-    };
-
-    // low-resolution row coefficients C[xip][m] = sum_r B^T[xip][r] U[r][m] of this thread's tile row (rows of the up-sampled patch that fall
-    // outside the image are the conv's zero padding) and the zero masks of patch columns 0 and 5
-    float cl0 = 0.f, cl1 = 0.f, cl2 = 0.f, cl3 = 0.f, zx0 = 1.f, zx5 = 1.f;
-    if (lowres) {
-      const float bt[6][6] = {{4, 0, -5, 0, 1, 0}, {0, -4, -4, 1, 1, 0}, {0, 4, -4, -1, 1, 0}, {0, -2, -1, 2, 1, 0}, {0, 2, -1, -2, 1, 0}, {0, 4, 0, -5, 0, 1}};
-      float cl[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int r = 0; r < 6; ++r) {
-        const int Y = P.y0 + 4 * typ - 1 + r;
-        float btv = 0.f;
-#pragma unroll
-        for (int x = 0; x < 6; ++x) btv = xip == x ? bt[x][r] : btv;
-        if (Y < 0 || Y >= a.H) btv = 0.f;
-        const float w0 = (r & 1) ? 0.25f : 0.75f;  // r even <-> Y odd: 0.75 * l[m] + 0.25 * l[m + 1]; r odd: 0.25 / 0.75 (align_corners = False)
-        cl[r >> 1] += btv * w0;
-        cl[(r >> 1) + 1] += btv * (1.f - w0);
-      }
-      cl0 = cl[0];
-      cl1 = cl[1];
-      cl2 = cl[2];
-      cl3 = cl[3];
-      zx0 = (P.x0 + 4 * txp - 1 < 0) ? 0.f : 1.f;
-      zx5 = (P.x0 + 4 * txp + 4 >= a.W) ? 0.f : 1.f;
-    }
-
-    // ---- the input transform of quarter k (raw slot k % 3 -> V slot k & 1), split in three parts so that MFMAs can sit between them
-    float tt[6];
-    auto t_rows = [&](int k) {
-      if (W4_EXP & 2) return;
-      const float* raw = rawbuf + (k % 3) * W4_RAW_FLOATS;
-      if (k >= Q0 && lowres) {
-        const float* p = raw + pbase_l;
-        float tl[4];
-#pragma unroll
-        for (int n = 0; n < 4; ++n) {
-          const int co = ((n & 1) * 9 + (n >> 1)) * 4;
-          const float d0 = p[co], d1 = p[co + 18 * 4], d2 = p[co + 2 * 18 * 4], d3 = p[co + 3 * 18 * 4];
-          tl[n] = fmaf(cl0, d0, fmaf(cl1, d1, fmaf(cl2, d2, cl3 * d3)));
-          asm volatile("" : "+v"(tl[n]));
-        }
-        tt[0] = zx0 * fmaf(0.75f, tl[0], 0.25f * tl[1]);
-        tt[1] = fmaf(0.25f, tl[0], 0.75f * tl[1]);
-        tt[2] = fmaf(0.75f, tl[1], 0.25f * tl[2]);
-        tt[3] = fmaf(0.25f, tl[1], 0.75f * tl[2]);
-        tt[4] = fmaf(0.75f, tl[2], 0.25f * tl[3]);
-        tt[5] = zx5 * fmaf(0.25f, tl[2], 0.75f * tl[3]);
-#pragma unroll
-        for (int c = 0; c < 6; ++c) asm volatile("" : "+v"(tt[c]));
-      } else if (tri) {
-        const float* p = raw + pbase_f;
-#pragma unroll
-        for (int c = 0; c < 6; ++c) {
-          const int co = ((c & 3) * 9 + (c >> 2)) * 4;
-          tt[c] = fmaf(beta, p[co], fmaf(alpha, p[co + 2 * 144], p[co + 4 * 144]));
-          asm volatile("" : "+v"(tt[c]));  // one scalar chain per column: packed-fp32 VALU (and the moves that feed it) is a loss beside MFMAs
-        }
-      } else {
-        const float* p = raw + pbase_f;
-#pragma unroll
-        for (int c = 0; c < 6; ++c) {
-          const int co = ((c & 3) * 9 + (c >> 2)) * 4;
-          tt[c] = fmaf(beta, fmaf(gamma, p[co + 144], p[co + 3 * 144]), fmaf(alpha, p[co + 2 * 144], p[co + 4 * 144]));
-          asm volatile("" : "+v"(tt[c]));
-        }
-      }
-    };
-    auto t_cols_store = [&](int k) {
-      if (W4_EXP & 2) return;
-      float v[6];
-      w4_col_pass(tt, v);
-      float* vw = vbuf + (k & 1) * W4_V_FLOATS + vw0;
-#pragma unroll
-      for (int n = 0; n < 6; ++n) vw[n * 3 * 64 * 4] = v[n];
-    };
-
-    // ---- prologue: raw 0..2, weights 0..1 (counted from the slice's first quarter); transform its first quarter
-    issue_raw(qbeg);
-    issue_w(qbeg);
-    issue_raw(qbeg + 1);
-    issue_raw(qbeg + 2);
-    issue_w(qbeg + 1);
-    __builtin_amdgcn_s_waitcnt(0x0F78);  // vmcnt(8): raw 0 has landed (this wave's piece)
-    __builtin_amdgcn_s_barrier();
-    t_rows(qbeg);
-    t_cols_store(qbeg);
-    f32x16 acc[6];
-#pragma unroll
-    for (int x = 0; x < 6; ++x)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[x][r] = 0.f;
-    __builtin_amdgcn_s_waitcnt(0x0074);  // vmcnt(4) lgkmcnt(0): raw 1 and weights 0 have landed, V[0] is written; raw 2 and weights 1 stay in flight
-    __builtin_amdgcn_s_barrier();
-
-#ifdef W4_STAMP  // diagnostic build (tools/w4/w4_bench.hip -DW4_STAMP): cycles per phase of a quarter, per wave, into ConvArgs::clock_probe
-    unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    unsigned long long st_mark = __builtin_amdgcn_s_memtime();
-#define W4_ST(i)                                                 \
-  {                                                              \
-    const unsigned long long t_ = __builtin_amdgcn_s_memtime();  \
-    st[i] += t_ - st_mark;                                       \
-    st_mark = t_;                                                \
-  }
-#else
-#define W4_ST(i)
-#endif
-
-#if W4_EXP & 16
-#define W4_MFMA(a_, b_, c_, x, y, z) (c_)
-#else
-#define W4_MFMA(a_, b_, c_, x, y, z) __builtin_amdgcn_mfma_f32_32x32x2f32(a_, b_, c_, x, y, z)
-#endif
-    // MM = false: this wave's 32 output channels do not exist (N half nt = 1 of the last N tile of a layer whose padded channel count is 32 mod 64): it
-    // keeps its producer duties -- transform, transfers, barriers -- and skips its fragment reads and MFMAs, a third to two thirds of its SIMD's matrix work
-    auto quarters = [&](auto mm_tag) __attribute__((always_inline)) {
-    constexpr bool MM = decltype(mm_tag)::value;
-    for (int q = qbeg; q < qend; ++q) {
-      const float* wsl = wring + (q & 1) * W4_W_FLOATS + lane * 4;
-      const float* vrd = vbuf + (q & 1) * W4_V_FLOATS + vr0;
-      f32x4 wf[3], vf[3];
-      // (all weight fragments first: by the time the second MFMA group has waited for vf[1], every read of the weight slot has returned
-      // and the slot may take its next transfer)
-      if constexpr (MM) {
-#pragma unroll
-        for (int p = 0; p < 3; ++p) wf[p] = *reinterpret_cast<const f32x4*>(wsl + p * 256);
-#pragma unroll
-        for (int p = 0; p < 3; ++p) vf[p] = *reinterpret_cast<const f32x4*>(vrd + p * 256);
-        __builtin_amdgcn_sched_barrier(0);
-        acc[0] = W4_MFMA(wf[0][0], vf[0][0], acc[0], 0, 0, 0);
-        acc[0] = W4_MFMA(wf[0][1], vf[0][1], acc[0], 0, 0, 0);
-        acc[1] = W4_MFMA(wf[0][2], vf[0][2], acc[1], 0, 0, 0);
-        acc[1] = W4_MFMA(wf[0][3], vf[0][3], acc[1], 0, 0, 0);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      W4_ST(0)
-      t_rows(q + 1);  // (after the tile's last quarter: the zero-filled slot of an out-of-range transfer -> a V slot nobody reads)
-      __builtin_amdgcn_sched_barrier(0);
-      W4_ST(1)
-      if constexpr (MM) {
-        acc[2] = W4_MFMA(wf[1][0], vf[1][0], acc[2], 0, 0, 0);
-        acc[2] = W4_MFMA(wf[1][1], vf[1][1], acc[2], 0, 0, 0);
-        acc[3] = W4_MFMA(wf[1][2], vf[1][2], acc[3], 0, 0, 0);
-        acc[3] = W4_MFMA(wf[1][3], vf[1][3], acc[3], 0, 0, 0);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      // every fragment of this quarter is in registers (the MFMAs above waited for them): the weight slot just read takes quarter q + 2,
-      // raw slot q % 3 (transformed during quarter q - 1) takes quarter q + 3
-      W4_ST(2)
-      issue_w(q + 2);
-      issue_raw(q + 3);
-      W4_ST(3)
-      t_cols_store(q + 1);
-      __builtin_amdgcn_sched_barrier(0);
-      W4_ST(4)
-      if constexpr (MM) {
-        acc[4] = W4_MFMA(wf[2][0], vf[2][0], acc[4], 0, 0, 0);
-        acc[4] = W4_MFMA(wf[2][1], vf[2][1], acc[4], 0, 0, 0);
-        acc[5] = W4_MFMA(wf[2][2], vf[2][2], acc[5], 0, 0, 0);
-        acc[5] = W4_MFMA(wf[2][3], vf[2][3], acc[5], 0, 0, 0);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      W4_ST(5)
-      __builtin_amdgcn_s_waitcnt((W4_EXP & 9) ? 0x0070 : 0x0074);  // vmcnt(4) lgkmcnt(0): everything but this quarter's four transfers has landed; V[(q + 1) & 1] is written
-      W4_ST(6)
-      if (!(W4_EXP & 4)) __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-      W4_ST(7)
-    }
-    };
-    if (nt == 1 && P.ntile * 64 + 32 >= a.coutp)  // wave-uniform
-      quarters(std::false_type{});
-    else
-      quarters(std::true_type{});
-#ifdef W4_STAMP
-    if (a.clock_probe && lane == 0 && vid == (int)blockIdx.x) {
-      unsigned long long* o = a.clock_probe + ((size_t)blockIdx.x * 12 + pw) * 8;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) o[i] = st[i];
-    }
-#endif
-
-    // ---- epilogue.  Nothing real is in flight (the last two quarters issued out-of-range transfers); retire them before LDS is reused.
-    __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0) lgkmcnt(0)
-    __builtin_amdgcn_s_barrier();
-    // row pass of A^T M A in registers: Z[a] = sum_xi A^T[a][xi] M[xi] (this wave's nu), a = 0..3, left in acc[0..3]
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float m0 = acc[0][r], m1 = acc[1][r], m2 = acc[2][r], m3 = acc[3][r], m4 = acc[4][r], m5 = acc[5][r];
-      const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
-      acc[0][r] = (m0 + s12) + s34;
-      acc[1][r] = fmaf(2.f, d34, d12);
-      acc[2][r] = fmaf(4.f, s34, s12);
-      acc[3][r] = fmaf(8.f, d34, d12) + m5;
-    }
-    float* const exch = lds;  // [nu 6][a 4][k 4][lane 64][4]: 24576 floats
-    const int ty = lx >> 3, tx = lx & 7;
-#pragma unroll 1
-    for (int round = 0; round < 2; ++round) {
-      if (nt == round) {
-#pragma unroll
-        for (int aa = 0; aa < 4; ++aa)
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            f32x4 v;
-            v[0] = acc[aa][4 * k + 0];
-            v[1] = acc[aa][4 * k + 1];
-            v[2] = acc[aa][4 * k + 2];
-            v[3] = acc[aa][4 * k + 3];
-            *reinterpret_cast<f32x4*>(exch + (((nu * 4 + aa) * 4 + k) * 64 + lane) * 4) = v;
-          }
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      // sixteen (output row a, channel quad k) units per round: unit u goes to wave (u + 4 * round) % 12 -- waves 0..3 take two in round 0, waves 4..7 in round 1
-#pragma unroll 1
-      for (int u = (pw + 12 - 4 * round) % 12; u < 16; u += 12) {
-        const int aa = u >> 2, k = u & 3;
-        f32x4 z[6];
-#pragma unroll
-        for (int n = 0; n < 6; ++n) z[n] = *reinterpret_cast<const f32x4*>(exch + (((n * 4 + aa) * 4 + k) * 64 + lane) * 4);
-        const int co = P.ntile * 64 + round * 32 + 8 * k + 4 * lh;
-        const f32x4 bias = KS ? f32x4{0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4*>(a.bias + co);
-        const f32x4 s12 = z[1] + z[2], d12 = z[1] - z[2], s34 = z[3] + z[4], d34 = z[3] - z[4];
-        f32x4 y[4];
-        y[0] = ((z[0] + s12) + s34) + bias;
-        y[1] = (d12 + 2.f * d34) + bias;
-        y[2] = (s12 + 4.f * s34) + bias;
-        y[3] = ((d12 + 8.f * d34) + z[5]) + bias;
-        const int oy = P.y0 + 4 * ty + aa, ox = P.x0 + 4 * tx;
-        if (oy < a.H && co < a.coutp) {
-          float* const dp = a.dst + ((size_t)(P.b * a.H + oy) * a.W + ox) * a.coutp + co + (KS ? (size_t)ksl * a.split_stride : (size_t)0);
-#pragma unroll
-          for (int bb = 0; bb < 4; ++bb) {
-            if (ox + bb >= a.W) continue;
-            f32x4 v = y[bb];
-            if (a.relu) {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-            }
-            if (a.relu_mask_src) {  // backward: this launch completes the gradient of a conv + ReLU output -- that ReLU's mask rides in the (lane-local) store
-              const f32x4 f = *reinterpret_cast<const f32x4*>(a.relu_mask_src + (dp - a.dst) + (size_t)bb * a.coutp);
-#pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = f[e] > 0.f ? v[e] : 0.f;
-            }
-            *reinterpret_cast<f32x4*>(dp + (size_t)bb * a.coutp) = v;
-          }
-        }
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-    }
-  }
-}
-
-// ======================================================================================================================================================
-// conv3x3_wino4p_kernel (round 4): the same algorithm, workgroup tile, transfers and arithmetic as conv3x3_wino4_kernel above -- bit-identical results --
-// in a decomposition made for the instruction stream.  The twelve-wave form runs its matrix work and its transform in phases that every wave of a SIMD
-// enters at the same time (one barrier per quarter, identical programs), so the matrix pipe idles while the waves transform and the vector port idles while
-// they queue for the pipe: 0.54 busy.  Here a SIMD holds TWO waves whose streams are written out MFMA by MFMA with the other work between them:
-//   * eight waves; wave (nt, pg) owns the nine positions p = xi * 6 + nu = 9 pg .. 9 pg + 8 of the 32-channel N tile nt: nine 32x32 accumulators (144 registers),
-//     18 MFMAs per quarter; SIMD s holds (0, s) and (1, s), which read the same V fragments.
-//   * weights come straight from L2 into registers, one quarter ahead (five buffer loads per wave and quarter, each into the registers the MFMAs before it
-//     just read): no LDS ring, no LDS traffic for weights.
-//   * the transform of the next quarter is dealt as (16 tiles) x (xi group): waves 0..3 take an xi pair each ({1, 2} or {3, 4}: the pair shares its two
-//     row differences), waves 4..7 one of xi 0 / 5 -- a SIMD gets one of each -- and its pieces sit between the wave's MFMAs: LDS reads one MFMA ahead of
-//     their use, the row pass, the column pass, the V stores.
-//   * LDS: three raw halo slots + two V slots = 72 KiB in the loop; the epilogue sends one N tile at a time through LDS (144 KiB, all 36 positions) and
-//     waves 0..3 apply A^T . A: one thread per (tile, channel quad), eight lanes = 128 contiguous bytes of a pixel.
-#ifndef P4_SOFTBAR
-#define P4_SOFTBAR 0  // 1: the loop's barrier as LDS flags (arrive / wait apart; measured 3 - 4 % slower: a poll costs what the barrier's skew did); 0: s_barrier
-#endif
 template <int P, int N>
 __device__ __forceinline__ void p4_vput(float* slot, int vwq, int vwd, const float* v) {  // N transformed values of positions P .. P + N - 1 into a V slot
   if constexpr (N > 0) {
@@ -562,7 +159,7 @@ __device__ __forceinline__ void p4_vput(float* slot, int vwq, int vwd, const flo
 }
 
 template <bool LOWRES, bool KS = false>
-__global__ __launch_bounds__(512) void conv3x3_wino4p_kernel(ConvArgs a) {
+__global__ __launch_bounds__(512) void conv3x3_wino4_kernel(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -590,7 +187,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino4p_kernel(ConvArgs a) {
   float* const rawbuf = lds;                      // two raw halo slots
   float* const vbuf = lds + 2 * W4_RAW_FLOATS;    // two V slots
 
-  // ---- producer constants (the formulas of conv3x3_wino4_kernel: t[c] = fma(beta, fma(alpha, d1, d3), fma(alpha, d2, d4)) for xi 1..4, fma(4, P, fma(-5, R, S)) for xi 0 and 5)
+  // ---- producer constants (t[c] = fma(beta, fma(alpha, d1, d3), fma(alpha, d2, d4)) for xi 1..4, fma(4, P, fma(-5, R, S)) for xi 0 and 5)
   const float alpha = xg == 0 ? -4.f : -1.f, beta = xg == 0 ? 1.f : 2.f, nbeta = -beta;
   const int pbase_f = ((4 * typ + (xg == 2 ? 0 : 1)) * 36 + txp) * 4 + cp;  // first patch row this thread reads: 1 (xi 1..4: rows 1..4; xi 5: rows 1, 3, 5) or 0 (xi 0: rows 0, 2, 4)
   const int pbase_l = ((2 * typ) * 18 + txp) * 4 + cp;
@@ -653,26 +250,16 @@ __global__ __launch_bounds__(512) void conv3x3_wino4p_kernel(ConvArgs a) {
     const __amdgpu_buffer_rsrc_t rsrc1 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.src1 ? a.src1 : a.src0), 0,
                                                                            (int)((unsigned)(lowres ? a.B * Hl * Wl : a.B * a.H * a.W) * (unsigned)(a.c1p * 4)), 0x00020000);
     // The halo goes through registers (buffer load one quarter, ds_write the next): an LDS-DMA transfer costs its wave ~150 cycles of issue beside MFMAs, a register load + ds_write_b128 ~30
-    f32x4 hreg[2] = {f32x4{1.f, 2.f, 3.f, 4.f}, f32x4{1.f, 2.f, 3.f, 4.f}};
+    f32x4 hreg[2];
     const bool has1 = pw + 8 < 11;  // (wave-uniform) this wave owns a second piece of the full-resolution layout
     auto load_raw = [&](int k) {  // halo of quarter k into this wave's registers
       const bool s1 = k >= Q0;
       const int so = k < qend ? ((W4_EXP & 64) ? 0 : (s1 ? (k - Q0) * 16 : k * 16)) : 0;
-      if (W4_EXP & (8 | 4096)) return;
+      if (W4_EXP & 8) return;
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         if (i == 1 && !has1) continue;
-        unsigned off = k < qend ? (s1 ? off1[i] : off0[i]) : 0xFFFFFF00u;
-        if (W4_EXP & 512) off = (unsigned)((pw + 8 * i) * 1024 + lane * 16);  // contiguous, cache-hot: wrong data
-        if (W4_EXP & 1024) {  // the traffic of a 4-quarter chunk loader (64 contiguous bytes per pixel, a quarter of the halo's pixels per quarter): wrong data
-          const int e = (k & 3) * 162 + (pw + 8 * i) * 16 + (lane >> 2);
-          const int hy = e / 36, rem = e - hy * 36;
-          const int hx = 4 * (rem % 9) + rem / 9;
-          const int gy = min(max(P.y0 + hy - 1, 0), a.H - 1), gx = min(max(P.x0 + hx - 1, 0), a.W - 1);
-          off = (unsigned)((P.b * a.H + gy) * a.W + gx) * (unsigned)(a.c0p * 4) + (unsigned)((k >> 2) * 64 + (lane & 3) * 16);
-          hreg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc0, off, 0, 0));
-          continue;
-        }
+        const unsigned off = k < qend ? (s1 ? off1[i] : off0[i]) : 0xFFFFFF00u;
         if (s1)
           hreg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc1, off, so, 0));
         else
@@ -681,22 +268,9 @@ __global__ __launch_bounds__(512) void conv3x3_wino4p_kernel(ConvArgs a) {
     };
     auto store_raw = [&](int k) {  // ... and from there into raw slot k & 1
       float* slot = rawbuf + (k & 1) * W4_RAW_FLOATS + lane * 4;
-      if (W4_EXP & (8 | 2048)) return;
+      if (W4_EXP & 8) return;
       *reinterpret_cast<f32x4*>(slot + pw * 256) = hreg[0];
       if (has1) *reinterpret_cast<f32x4*>(slot + (pw + 8) * 256) = hreg[1];
-    };
-    auto load_raw_prepare = [&]() {};
-    // The loop's barrier in two halves (gfx950 has no split s_barrier): a wave ARRIVES by writing the quarter it has finished into its word of LDS, and WAITS -- four MFMAs into the
-    // next quarter -- until all eight words say so.  A straggler costs the others nothing while it is less than those four MFMAs late.
-    typedef __attribute__((address_space(3))) volatile int lds_flag_t;  // (explicitly LDS: a generic volatile pointer compiles to flat loads that wait for every global load in flight)
-    lds_flag_t* const flags = (lds_flag_t*)(lds + 2 * W4_RAW_FLOATS + 2 * W4_V_FLOATS);
-    auto soft_arrive = [&](int q) {
-      if (lane == 0) flags[pw] = q;
-    };
-    auto soft_wait = [&](int want) {
-      if (W4_EXP & 4) return;
-      while (__builtin_amdgcn_ballot_w64(flags[lane & 7] < want) != 0) {
-      }
     };
     const int w_tile = P.ntile * Q * (W4_Q_FLOATS * 4);
     f32x4 wf[4];
@@ -718,7 +292,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino4p_kernel(ConvArgs a) {
       }
     };
 
-    // low-resolution row coefficients of this thread's tile row for its one or two xi (as in conv3x3_wino4_kernel) and the zero masks of patch columns 0 and 5
+    // low-resolution row coefficients of this thread's tile row for its one or two xi and the zero masks of patch columns 0 and 5
     float cl[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     float zx0 = 1.f, zx5 = 1.f;
     if (lowres) {
@@ -841,9 +415,6 @@ __global__ __launch_bounds__(512) void conv3x3_wino4p_kernel(ConvArgs a) {
     };
 
     // ---- prologue: raw of the slice's first three quarters, weights of its first; transform the first quarter
-#if P4_SOFTBAR
-    if (tid < 8) flags[tid] = qbeg - 1;
-#endif
     load_raw(qbeg);
     store_raw(qbeg);
     load_raw(qbeg + 1);
@@ -929,34 +500,6 @@ __global__ __launch_bounds__(512) void conv3x3_wino4p_kernel(ConvArgs a) {
         f32x4 vf0, vf1, vf2;
         // the previous quarter's last six MFMAs come first (their operands have been in registers since before the barrier), the quarter's memory instructions between them
         P4_ST(0)
-#if P4_SOFTBAR
-        // four of them before this wave asks whether the others have finished quarter q - 1 (its V and halo writes, its reads of the slots about to be overwritten)
-        if constexpr (MM) {
-          acc[6] = P4_MFMA(wf[3][0], vf3[0], acc[6]);
-          acc[7] = P4_MFMA(wf[3][1], vf3[1], acc[7]);
-          acc[8] = P4_MFMA(wf9[0], vf9.x, acc[8]);
-          acc[6] = P4_MFMA(wf[3][2], vf3[2], acc[6]);
-        }
-        load_raw_prepare();
-        P4_SB
-        P4_ST(1)
-        soft_wait(q - 1);
-        P4_SB
-        P4_ST(2)
-        store_raw(q + 2);  // (loaded during quarter q - 1; slot q & 1 was transformed during quarter q - 1)
-        if constexpr (MM) vf0 = *reinterpret_cast<const f32x4*>(vq);
-        t_read(xg_tag, lr_tag, raw, 0, H1);
-        load_raw(q + 3);
-        P4_SB
-        if constexpr (MM) {
-          acc[7] = P4_MFMA(wf[3][3], vf3[3], acc[7]);
-          load_w(q, 3);
-          vf1 = *reinterpret_cast<const f32x4*>(vq + 256);
-          P4_ST(3)
-          acc[8] = P4_MFMA(wf9[1], vf9.y, acc[8]);
-          load_w(q, 4);
-        }
-#else
         if constexpr (MM) {
           acc[6] = P4_MFMA(wf[3][0], vf3[0], acc[6]);
           acc[7] = P4_MFMA(wf[3][1], vf3[1], acc[7]);
@@ -983,7 +526,6 @@ __global__ __launch_bounds__(512) void conv3x3_wino4p_kernel(ConvArgs a) {
           acc[8] = P4_MFMA(wf9[1], vf9.y, acc[8]);
           load_w(q, 4);
         }
-#endif
         t_rows(xg_tag, lr_tag, 0, H1);
         t_read(xg_tag, lr_tag, raw, H1, NC);
         P4_SB
@@ -1026,11 +568,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino4p_kernel(ConvArgs a) {
         P4_SB
         P4_ST(7)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // V[(q + 1) & 1] and raw[q & 1] are written, the fragments of positions 6..8 read
-#if P4_SOFTBAR
-        soft_arrive(q);
-#else
         if (!(W4_EXP & 4)) __builtin_amdgcn_s_barrier();
-#endif
         P4_SB
         P4_ST_END
       }
@@ -1065,9 +603,6 @@ __global__ __launch_bounds__(512) void conv3x3_wino4p_kernel(ConvArgs a) {
       acc[7] = P4_MFMA(wf[3][3], vf3[3], acc[7]);
       acc[8] = P4_MFMA(wf9[1], vf9.y, acc[8]);
     }
-#if P4_SOFTBAR
-    __builtin_amdgcn_s_barrier();  // (every wave is out of the loop: LDS may be reused)
-#endif
 
 #ifdef W4_STAMP
     const unsigned long long tile_t2 = __builtin_amdgcn_s_memtime();  // loop done
@@ -1111,7 +646,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino4p_kernel(ConvArgs a) {
       int z0 = (tile * 8 + (cq ^ (tile & 7))) << 2;
       asm volatile("" : "+v"(z0));
       const float* zp = exch + z0;
-      // row pass (over xi) per nu, with the expressions of the twelve-wave kernel's owning waves: Z[a][nu] for this thread's two rows a
+      // row pass (over xi) per nu, Z[a][nu] for this thread's two rows a
       f32x4 z[2][6];
 #pragma unroll
       for (int n = 0; n < 6; ++n) {
@@ -1159,7 +694,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino4p_kernel(ConvArgs a) {
               for (int e = 0; e < 4; ++e) v[e] = f[e] > 0.f ? v[e] : 0.f;
             }
             y[bb] = v;
-            if (KS || !a.skip_dst) *reinterpret_cast<f32x4*>(dp + (size_t)bb * a.coutp) = v;
+            if ((KS || !a.skip_dst) && !(W4_EXP & 512)) *reinterpret_cast<f32x4*>(dp + (size_t)bb * a.coutp) = v;  // (non-temporal stores: the output stage 2x slower)
           }
           if (!KS && a.dst_pool) {
             f32x4 m0, m1;
@@ -1236,14 +771,11 @@ __global__ __launch_bounds__(512) void conv3x3_wino4p_kernel(ConvArgs a) {
 }
 
 int prepare_wino4_kernels() {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wino4_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS_FLOATS * (int)sizeof(float));
-  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wino4_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS_FLOATS * (int)sizeof(float));
+  hipError_t e = hipSuccess;
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wino4_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS_FLOATS * (int)sizeof(float));
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wino4_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS_FLOATS * (int)sizeof(float));
   if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wino4_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS_FLOATS * (int)sizeof(float));
   if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wino4_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS_FLOATS * (int)sizeof(float));
-  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wino4p_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS_FLOATS * (int)sizeof(float));
-  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wino4p_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS_FLOATS * (int)sizeof(float));
-  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wino4p_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS_FLOATS * (int)sizeof(float));
-  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wino4p_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS_FLOATS * (int)sizeof(float));
   if (e != hipSuccess) {
     set_error("hipFuncSetAttribute(wino4) failed: %s", hipGetErrorString(e));
     return PH_E_HIP;
@@ -1255,7 +787,6 @@ int prepare_wino4_kernels() {
 // addressable through a 32-bit buffer descriptor; no fused pool / head / accumulate / ReLU mask (those stay on the F(2x2,3x3) kernel).
 bool wino4_fits(const ConvArgs& a) {
   if (!a.wpack_wino4 || a.bn != 64 || (a.H & 3) || (a.W & 3) || a.head_w || a.accumulate) return false;
-  if (g_w4_legacy && (a.dst_pool || a.skip_dst)) return false;  // (the fused 2 x 2 max pool and the unread full-resolution output are the pipelined kernel's)
   if (a.src1_lowres && (!a.src1 || (a.H & 1) || (a.W & 1))) return false;
   const uint64_t px = (uint64_t)a.B * a.H * a.W;
   if (px * (uint64_t)a.c0p * 4 >= 0xFFFFFF00ull || px * (uint64_t)a.c1p * 4 >= 0xFFFFFF00ull || px >= 0x7FFFFFFFull) return false;
@@ -1319,27 +850,17 @@ int launch_conv3x3_wino4(const ConvArgs& a, hipStream_t s) {
     k.ksplit = ksplit;
     k.split_stride = (long long)a.B * a.H * a.W * a.coutp;
     const dim3 grid(std::min(tiles * ntc * ksplit, n_cu));
-    if (!g_w4_legacy) {
-      if (a.src1_lowres)
-        hipLaunchKernelGGL((conv3x3_wino4p_kernel<true, true>), grid, dim3(512), (size_t)W4_LDS_FLOATS * sizeof(float), s, k);
-      else
-        hipLaunchKernelGGL((conv3x3_wino4p_kernel<false, true>), grid, dim3(512), (size_t)W4_LDS_FLOATS * sizeof(float), s, k);
-    } else if (a.src1_lowres)
-      hipLaunchKernelGGL((conv3x3_wino4_kernel<true, true>), grid, dim3(768), (size_t)W4_LDS_FLOATS * sizeof(float), s, k);
+    if (a.src1_lowres)
+      hipLaunchKernelGGL((conv3x3_wino4_kernel<true, true>), grid, dim3(512), (size_t)W4_LDS_FLOATS * sizeof(float), s, k);
     else
-      hipLaunchKernelGGL((conv3x3_wino4_kernel<false, true>), grid, dim3(768), (size_t)W4_LDS_FLOATS * sizeof(float), s, k);
+      hipLaunchKernelGGL((conv3x3_wino4_kernel<false, true>), grid, dim3(512), (size_t)W4_LDS_FLOATS * sizeof(float), s, k);
     PH_HIP_CHECK(hipGetLastError());
     return launch_splitk_reduce(a.split_scratch, k.split_stride, ksplit, a.bias, a.skip_dst ? nullptr : a.dst, a.dst_pool, a.B, a.H, a.W, a.coutp, a.relu, s);
   }
-  if (!g_w4_legacy) {
-    if (a.src1_lowres)
-      hipLaunchKernelGGL((conv3x3_wino4p_kernel<true, false>), dim3(std::min(tiles * ntc, n_cu)), dim3(512), (size_t)W4_LDS_FLOATS * sizeof(float), s, a);
-    else
-      hipLaunchKernelGGL((conv3x3_wino4p_kernel<false, false>), dim3(std::min(tiles * ntc, n_cu)), dim3(512), (size_t)W4_LDS_FLOATS * sizeof(float), s, a);
-  } else if (a.src1_lowres)
-    hipLaunchKernelGGL(conv3x3_wino4_kernel<true>, dim3(std::min(tiles * ntc, n_cu)), dim3(768), (size_t)W4_LDS_FLOATS * sizeof(float), s, a);
+  if (a.src1_lowres)
+    hipLaunchKernelGGL((conv3x3_wino4_kernel<true, false>), dim3(std::min(tiles * ntc, n_cu)), dim3(512), (size_t)W4_LDS_FLOATS * sizeof(float), s, a);
   else
-    hipLaunchKernelGGL(conv3x3_wino4_kernel<false>, dim3(std::min(tiles * ntc, n_cu)), dim3(768), (size_t)W4_LDS_FLOATS * sizeof(float), s, a);
+    hipLaunchKernelGGL((conv3x3_wino4_kernel<false, false>), dim3(std::min(tiles * ntc, n_cu)), dim3(512), (size_t)W4_LDS_FLOATS * sizeof(float), s, a);
   PH_HIP_CHECK(hipGetLastError());
   return PH_OK;
 }
