@@ -250,7 +250,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(ConvArgs a) {
     const __amdgpu_buffer_rsrc_t rsrc1 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.src1 ? a.src1 : a.src0), 0,
                                                                            (int)((unsigned)(lowres ? a.B * Hl * Wl : a.B * a.H * a.W) * (unsigned)(a.c1p * 4)), 0x00020000);
     // The halo goes through registers (buffer load one quarter, ds_write the next): an LDS-DMA transfer costs its wave ~150 cycles of issue beside MFMAs, a register load + ds_write_b128 ~30
-    f32x4 hreg[2];
+    f32x4 hreg[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};  // (initialised: left undefined, the register allocator spills 144 registers of the folded-bilinear instantiation instead of 20)
     const bool has1 = pw + 8 < 11;  // (wave-uniform) this wave owns a second piece of the full-resolution layout
     auto load_raw = [&](int k) {  // halo of quarter k into this wave's registers
       const bool s1 = k >= Q0;
