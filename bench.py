@@ -504,8 +504,8 @@ def run_infer(args, ctx):
     fwd_ms = sum(op_ms) / max(n_fw, 1)
     # FLOP accounting.  `direct_tflops` prices a launch at the direct-convolution count 2*Cin*Cout*9*H*W.  The kernels
     # that run are Winograd forms: conv3x3_wino4_kernel (F(4x4,3x3): 36 multiplications per sixteen outputs instead of 144, 1/4 of those FLOPs go
-    # through the matrix cores) for the N-tile-64 layers with >= 128 input channels, conv3x3_wino2d_kernel<64> (F(2x2,3x3): 4/9) for the other
-    # N-tile-64 layers, conv3x3_w16_kernel (wave-private F(2x2,3x3): 4/9) for the Cout <= 32 ones; the input / output transforms are VALU work.  `achieved` is
+    # through the matrix cores) for the N-tile-64 layers from 64 input channels on where its time model prefers it, conv3x3_wino2d_kernel<64> (F(2x2,3x3): 4/9) for the other
+    # N-tile-64 layers (and the conv whose 1x1 head rides in its epilogue), conv3x3_w16_kernel (wave-private F(2x2,3x3): 4/9) for the Cout <= 32 ones; the input / output transforms are VALU work.  `achieved` is
     # what the MFMA pipe EXECUTES in the launches of the dominant kernel over their duration -- the figure a roofline against the
     # MFMA peak is about; the direct-equivalent rate is reported next to it and is NOT a roofline fraction.
     # Which kernel ran each conv launch is read back from the library (ph_model_last_kernels of an eager forward), not re-derived here.
