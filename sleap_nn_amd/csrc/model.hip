@@ -684,6 +684,7 @@ ph_model* ph_model_create(const ph_op_desc* ops, int32_t n_ops, const float* con
           return true;
         };
         if (ok && !tr) ok = derive_wino4(op.w_dev, d.cin0, d.cin1, d.cout, op.bn, &op.w_wino4_dev);
+        if (ok && !tr && op.w_n64_dev) ok = derive_wino4(op.w_n64_dev, d.cin0, d.cin1, d.cout, 64, &op.w_wino4_dev);  // (Cout 32, K >= 64: the N-tile-64 packing above; the kernel's waves of the empty N half skip their MFMAs)
         // wave-private F(2x2,3x3) weights (conv3x3_w16_kernel: 16 / 32 output channels, 16 / 32 input channels, one source): the forward
         // conv's, and below the data-gradient convs'
         auto derive_w16 = [&](const float* src, int cin_, int cout_, int bn, float** dst, int cin_b = 0) {
