@@ -250,6 +250,15 @@ def test_cout32_layers_on_the_half_empty_n_tile_of_the_winograd_kernel(filters, 
         assert last_concat == (L.KV_WINO2D if opt else L.KV_WINO1D), (opt, last_concat)
     _close(outs[1], ref, "n32 on wino2d")
     assert (outs[1] - outs[0]).abs().max().item() <= 2e-5 * ref.abs().max().item()
+    # the same layer on the F(4x4,3x3) kernel (its N-tile-64 packing again, the waves of the empty N half skip their MFMAs, the bilinear x2 of its second source folded in):
+    # what cfg2's 96 -> 32 layer at 256 x 256 x 8 takes by the time model; forced here
+    m = Model("unet", bb, heads, "single_instance")
+    m.load_state_dict(sd)
+    m.set_option("conv_wino4", 3)
+    out4 = m.to(DEV)(img.to(DEV))["SingleInstanceConfmapsHead"].cpu()
+    last_concat = [c for r, c in zip(m.op_table(batch, hw[0], hw[1]), m.last_kernels()) if "refine_conv0" in r["label"]][-1]
+    assert last_concat == L.KV_WINO4, last_concat
+    _close(out4, ref, "n32 on wino4")
 
 
 @pytest.mark.parametrize("filters,max_stride,hw,batch,out_stride,splitk", [(32, 8, (64, 64), 1, 4, 3), (32, 16, (64, 96), 2, 4, 2), (16, 32, (128, 128), 1, 4, 5), (16, 32, (256, 256), 2, 4, 1)])
