@@ -1110,7 +1110,7 @@ W4_RTOL = 1e-5
 @pytest.mark.parametrize("filters,max_stride,hw,out_stride,batch", [(32, 8, (128, 128), None, 2), (16, 32, (128, 192), 4, 3), (32, 16, (128, 160), 2, 2),
                                                                    (64, 4, (48, 80), None, 2), (32, 8, (100, 132), None, 2), (16, 32, (256, 384), 4, 9)])
 def test_winograd_f4x4_kernel_and_folded_bilinear_match_oracle_and_the_f2x2_kernel(filters, max_stride, hw, out_stride, batch):
-    """conv3x3_wino4_kernel (Winograd F(4x4,3x3): 3x3 convs with N tile 64 and >= 128 padded input channels) with the decoder's
+    """conv3x3_wino4_kernel (Winograd F(4x4,3x3): 3x3 convs with N tile 64 and >= 64 padded input channels, the encoder's fused 2x2 max pool included) with the decoder's
     bilinear x2 folded into its input transform (inference plans: the up-sampled tensor never exists), against the oracle and the
     F(2x2,3x3) kernel: two-source concat convs at three decoder levels (tiles at every image border: zero padding of the up-sampled
     tensor vs the clamped low-resolution indices), one-source middle / refine convs, maps that cut the 32 x 16 workgroup tile,
@@ -1146,6 +1146,7 @@ def test_winograd_f4x4_kernel_and_folded_bilinear_match_oracle_and_the_f2x2_kern
         if name == "fold":
             ups = [i for i, op in enumerate(m.ops) if op.kind == L.OP_UPSAMPLE]
             folded = [i for i in ups if kv[i + 1] == L.KV_WINO4]
+            pooled4 = sum(1 for r, c in zip(m.op_table(batch, hw[0], hw[1]), kv) if "+pool" in r["label"] and c == L.KV_WINO4)  # encoder convs whose 2x2 max pool rides in the kernel's output stage
         if keep:
             checked = 0
             for lab, t in collect.items():
@@ -1163,6 +1164,8 @@ def test_winograd_f4x4_kernel_and_folded_bilinear_match_oracle_and_the_f2x2_kern
         assert n4["fold"] >= 2 and n4["f2x2"] == 0 and n4["every_plan"] >= n4["nofold"] >= 2, n4
         if os_ < max_stride:
             assert folded, "a decoder's bilinear x2 must ride in the F(4x4,3x3) kernel"
+        if filters >= 32:
+            assert pooled4 >= 1, "an encoder conv + pool with >= 64 input channels must run on the F(4x4,3x3) kernel (fused pool)"
     for name in ("default", "fold", "nofold", "every_plan", "f2x2"):
         assert (outs[name] - ref).abs().max().item() <= W4_RTOL * scale, (name, n4)
     assert (outs["fold"] - outs["f2x2"]).abs().max().item() <= W4_RTOL * scale
