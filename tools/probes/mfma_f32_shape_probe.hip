@@ -9,7 +9,8 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int SHAPE, int NV = 0, int WPS = 1>
+// KIND of the filler: 0 v_fma_f32, 1 v_pk_fma_f32 (two fp32 per lane), 2 v_add_f32, 3 ds_read_b128 (LDS), 4 v_pk_add_f32
+template <int SHAPE, int NV = 0, int WPS = 1, int KIND = 0>
 __global__ __launch_bounds__(256, WPS) void probe(const float* __restrict__ in, float* __restrict__ out, unsigned long long* __restrict__ clk, int iters) {
   const int tid = threadIdx.x + blockIdx.x * blockDim.x;
   float a[8], b[8];
@@ -21,6 +22,19 @@ __global__ __launch_bounds__(256, WPS) void probe(const float* __restrict__ in, 
   const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
   float sum = 0.f;
   float fill[8] = {1.f, 2.f, 3.f, 4.f, 5.f, 6.f, 7.f, 8.f};
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  f32x2 fill2[4], pa[4], pb[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    fill2[i] = f32x2{(float)i, 1.f};
+    pa[i] = f32x2{a[i], a[i + 4]};
+    pb[i] = f32x2{b[i], b[i + 4]};
+  }
+  __shared__ float ldsbuf[4096];
+  ldsbuf[threadIdx.x] = a[0];
+  f32x4 ldsv[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  const unsigned ldsaddr = (unsigned)(threadIdx.x & 63) * 16u;
+  __syncthreads();
   if (SHAPE == 32) {
     f32x16 acc[8];
 #pragma unroll
@@ -34,11 +48,21 @@ __global__ __launch_bounds__(256, WPS) void probe(const float* __restrict__ in, 
         for (int i = 0; i < 8; ++i) {
           acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[(i + k) & 7], b[(i * 3 + k) & 7], acc[i], 0, 0, 0);  // 32 MFMAs x 4096 FLOP
 #pragma unroll
-          for (int v = 0; v < NV; ++v) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(fill[v & 7]) : "v"(a[v & 7]), "v"(b[(v + 1) & 7]));  // NV independent vector instructions per MFMA
+          for (int v = 0; v < NV; ++v) {  // NV independent filler instructions per MFMA
+            if (KIND == 0) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(fill[v & 7]) : "v"(a[v & 7]), "v"(b[(v + 1) & 7]));
+            if (KIND == 1) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(fill2[v & 3]) : "v"(pa[v & 3]), "v"(pb[(v + 1) & 3]));
+            if (KIND == 2) asm volatile("v_add_f32 %0, %1, %0" : "+v"(fill[v & 7]) : "v"(a[v & 7]));
+            if (KIND == 3) asm volatile("ds_read_b128 %0, %1" : "=v"(ldsv[v & 1]) : "v"(ldsaddr));
+            if (KIND == 4) asm volatile("v_pk_add_f32 %0, %1, %0" : "+v"(fill2[v & 3]) : "v"(pa[v & 3]));
+          }
+          if (KIND == 3 && NV > 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
     }
 #pragma unroll
     for (int v = 0; v < 8; ++v) sum += fill[v];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) sum += fill2[v][0] + fill2[v][1];
+    sum += ldsv[0][0] + ldsv[1][3];
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -105,13 +129,15 @@ int main(int argc, char** argv) {
     }
   // do vector instructions overlap with the fp32 MFMA?  NV v_fma_f32 (independent of the MFMAs, eight separate chains) behind every v_mfma_f32_32x32x2_f32: overlapped, the time stays;
   // added, it grows by ~4 cycles (one wave per SIMD) or ~2 (two) per instruction
-  auto fillrun = [&](auto nv_tag) {
+  auto fillrun = [&](auto nv_tag, auto kind_tag) {
     constexpr int NVv = decltype(nv_tag)::value;
+    constexpr int KD = decltype(kind_tag)::value;
+    const char* kn[5] = {"v_fma_f32", "v_pk_fma_f32", "v_add_f32", "ds_read_b128", "v_pk_add_f32"};
     for (int w = 0; w < 2; ++w) {
       hipEventRecord(e0);
-      if (wps == 1) hipLaunchKernelGGL((probe<32, NVv, 1>), dim3(blocks), dim3(256), 0, 0, in, out, clk, iters);
-      else if (wps == 2) hipLaunchKernelGGL((probe<32, NVv, 2>), dim3(blocks), dim3(256), 0, 0, in, out, clk, iters);
-      else hipLaunchKernelGGL((probe<32, NVv, 3>), dim3(blocks), dim3(256), 0, 0, in, out, clk, iters);
+      if (wps == 1) hipLaunchKernelGGL((probe<32, NVv, 1, KD>), dim3(blocks), dim3(256), 0, 0, in, out, clk, iters);
+      else if (wps == 2) hipLaunchKernelGGL((probe<32, NVv, 2, KD>), dim3(blocks), dim3(256), 0, 0, in, out, clk, iters);
+      else hipLaunchKernelGGL((probe<32, NVv, 3, KD>), dim3(blocks), dim3(256), 0, 0, in, out, clk, iters);
       hipEventRecord(e1); hipEventSynchronize(e1);
     }
     float ms; hipEventElapsedTime(&ms, e0, e1);
@@ -119,12 +145,18 @@ int main(int argc, char** argv) {
     hipMemcpy(c.data(), clk, c.size() * 8, hipMemcpyDeviceToHost);
     double cyc = 0, rt = 0;
     for (int i = 0; i < blocks; ++i) { cyc += c[2 * i]; rt += c[2 * i + 1]; }
-    printf("32x32x2 + %2d v_fma_f32 per MFMA, %d wave(s) per SIMD: %.2f ms  clock %.3f GHz  SIMD cycles per MFMA %.1f\n", NVv, wps, ms, cyc / rt * 0.1, cyc / blocks / ((double)iters * 32) / wps);
+    printf("32x32x2 + %2d %s per MFMA, %d wave(s) per SIMD: %.2f ms  clock %.3f GHz\n", NVv, kn[KD], wps, ms, cyc / rt * 0.1);
   };
-  fillrun(std::integral_constant<int, 0>{});
-  fillrun(std::integral_constant<int, 2>{});
-  fillrun(std::integral_constant<int, 4>{});
-  fillrun(std::integral_constant<int, 8>{});
-  fillrun(std::integral_constant<int, 12>{});
+  fillrun(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+  fillrun(std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{});
+  fillrun(std::integral_constant<int, 4>{}, std::integral_constant<int, 0>{});
+  fillrun(std::integral_constant<int, 8>{}, std::integral_constant<int, 0>{});
+  fillrun(std::integral_constant<int, 12>{}, std::integral_constant<int, 0>{});
+  fillrun(std::integral_constant<int, 6>{}, std::integral_constant<int, 1>{});   // six packed fmas = the arithmetic of twelve scalar ones
+  fillrun(std::integral_constant<int, 12>{}, std::integral_constant<int, 1>{});
+  fillrun(std::integral_constant<int, 12>{}, std::integral_constant<int, 2>{});
+  fillrun(std::integral_constant<int, 6>{}, std::integral_constant<int, 4>{});
+  fillrun(std::integral_constant<int, 12>{}, std::integral_constant<int, 4>{});
+  // (KIND 3, ds_read_b128, waits for its data after every MFMA and so measures the LDS latency, not the issue cost: not run by default)
   return 0;
 }
