@@ -1108,7 +1108,8 @@ W4_RTOL = 1e-5
 
 
 @pytest.mark.parametrize("filters,max_stride,hw,out_stride,batch", [(32, 8, (128, 128), None, 2), (16, 32, (128, 192), 4, 3), (32, 16, (128, 160), 2, 2),
-                                                                   (64, 4, (48, 80), None, 2), (32, 8, (100, 132), None, 2), (16, 32, (256, 384), 4, 9)])
+                                                                   (64, 4, (48, 80), None, 2), (32, 8, (100, 132), None, 2), (16, 32, (256, 384), 4, 9),
+                                                                   (32, 16, (128, 192), 8, 2)])  # (output stride 8: the stride-2 / -4 encoder convs' full-resolution outputs are unread -> pool-only stores)
 def test_winograd_f4x4_kernel_and_folded_bilinear_match_oracle_and_the_f2x2_kernel(filters, max_stride, hw, out_stride, batch):
     """conv3x3_wino4_kernel (Winograd F(4x4,3x3): 3x3 convs with N tile 64 and >= 64 padded input channels, the encoder's fused 2x2 max pool included) with the decoder's
     bilinear x2 folded into its input transform (inference plans: the up-sampled tensor never exists), against the oracle and the
