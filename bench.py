@@ -189,6 +189,141 @@ def percentiles(ms):
     return {"median": float(np.median(a)), "p10": float(np.percentile(a, 10)), "p90": float(np.percentile(a, 90)), "n": int(a.size)}
 
 
+CONTRACT_LINE_MAX = 4096
+LEG_KEYS = ("train_cfg3", "train_cfg4", "infer_cfg4", "infer_cfg1", "infer_cfg2", "infer_cfg5", "published_workload", "alt_precisions",
+            "strong_scaling_shards", "weak_scaling", "roofline_postprocess")
+
+
+def _num(x, nd=4):
+    """Round a float to `nd` significant-ish decimals for the contract line (None / non-finite stay None: strict JSON has no NaN)."""
+    if x is None:
+        return None
+    if isinstance(x, bool) or isinstance(x, int):
+        return x
+    x = float(x)
+    if not np.isfinite(x):
+        return None
+    return float(f"{x:.{nd + 2}g}")
+
+
+def _pick(d, *path, default=None):
+    for k in path:
+        if not isinstance(d, dict) or k not in d:
+            return default
+        d = d[k]
+    return d
+
+
+def legs_summary(full: dict) -> dict:
+    """One number (or a short tuple of numbers) per extra leg: what the line says about them; the legs themselves live in the legs file."""
+    s = {}
+    for k in ("train_cfg3", "train_cfg4", "infer_cfg4", "infer_cfg1", "infer_cfg2", "infer_cfg5"):
+        if isinstance(full.get(k), dict):
+            leg = full[k]
+            s[k] = {"value": _num(leg.get("value")), "unit": leg.get("unit"), "ms_per_step": _num(leg.get("ms_per_step")), "mfma_frac": _num(_pick(leg, "roofline", "frac"))}
+    pw = full.get("published_workload")
+    if isinstance(pw, dict):
+        s["published_workload"] = {"forward_ms_per_batch4": _num(pw.get("value")), "forward_frames_per_s": _num(pw.get("frames_per_s_forward")),
+                                   "end_to_end_frames_per_s": _num(_pick(pw, "end_to_end", "value")), "topdown_end_to_end_frames_per_s": _num(_pick(pw, "topdown", "end_to_end_fps")),
+                                   "single_instance_end_to_end_frames_per_s": _num(_pick(pw, "single_instance", "end_to_end_fps"))}
+    alt = full.get("alt_precisions")
+    if isinstance(alt, dict):
+        s["alt_precisions_frames_per_s"] = {k: _num(v.get("value")) for k, v in alt.items() if isinstance(v, dict)}
+    sh = full.get("strong_scaling_shards")
+    if isinstance(sh, dict):
+        s["one_gpu_shard_frames_per_s"] = {k: _num(v.get("value")) for k, v in sh.items() if isinstance(v, dict)}
+    ws = full.get("weak_scaling")
+    if isinstance(ws, dict):
+        s["weak_scaling_frames_per_s"] = _num(ws.get("value"))
+    pp = full.get("roofline_postprocess")
+    if isinstance(pp, dict):
+        s["peaks_kernel"] = {"bound": "hbm", "achieved_GBps": _num(pp.get("achieved")), "peak_GBps": pp.get("peak"), "frac": _num(pp.get("frac")),
+                             "us_per_batch": _num(pp.get("us_per_batch")), "traffic": _num(pp.get("traffic"))}
+    return s
+
+
+def contract_line(full: dict, legs_file: str | None = None) -> str:
+    """The ONE stdout line of the bench contract, built from the full record: only the contract fields + `roofline` + `cpu_baseline` +
+    a one-number-per-leg summary.  Strict JSON (no NaN / Infinity), at most CONTRACT_LINE_MAX bytes; raises if it cannot be met, so a
+    record that would not parse on the driver's side never leaves this process looking like a success."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+    line = {k: (_num(full[k], 6) if isinstance(full.get(k), float) else full.get(k)) for k in keep if k in full}
+    cfg = full.get("config", {})
+    line["config"] = {k: cfg[k] for k in ("workload", "frames_per_gpu_per_step", "global_batch", "parallelism", "inputs", "forward_launch", "rccl_ranks_seen",
+                                          "frames_per_step_by_rank", "params", "crops_per_gpu_per_step") if k in cfg}
+    if isinstance(cfg.get("conv_gflop_per_frame"), float):
+        line["config"]["conv_gflop_per_frame"] = _num(cfg["conv_gflop_per_frame"])
+    if isinstance(full.get("step_ms"), dict):
+        line["step_ms"] = {k: _num(v) for k, v in full["step_ms"].items()}
+    if isinstance(full.get("h2d_inclusive"), dict):
+        line["h2d_inclusive"] = {"value": _num(full["h2d_inclusive"].get("value"), 6), "unit": full["h2d_inclusive"].get("unit"), "ms_per_step": _num(full["h2d_inclusive"].get("ms_per_step")),
+                                 "what": "SURVEY 8(d) frame time: the same steps with the uint8 frames starting in pinned host memory"}
+    r = full.get("roofline")
+    if isinstance(r, dict):
+        rl = {"bound": r.get("bound"), "kernel": str(r.get("kernel", "")).split(" (")[0].split(",")[0], "achieved": _num(r.get("achieved")), "peak": r.get("peak"), "unit": r.get("unit"),
+              "frac": _num(r.get("frac")), "traffic": _num(r.get("traffic"), 6)}
+        for k_out, k_in in (("traffic_source", "traffic_source"), ("algorithmic_bytes_per_launch", "algorithmic_bytes_per_launch"), ("avg_launch_ms", "dominant_kernel_avg_launch_ms"),
+                            ("launches_per_forward", "launches_per_forward"), ("dominant_kernel_ms_per_forward", "dominant_kernel_ms_per_forward"),
+                            ("executed_gflop_per_forward", "algorithmic_gflop_per_forward"), ("direct_gflop_per_forward", "direct_gflop_per_forward"),
+                            ("conv_kernel_ms_per_forward", "kernel_ms_per_forward"), ("forward_ms", "forward_ms"), ("direct_equivalent_tflops", "direct_equivalent_tflops"),
+                            ("conv_stack_frac", "conv_stack_frac"), ("conv_stack_ms_per_forward", "conv_stack_ms_per_forward"), ("executed_gflop_per_step", "executed_gflop_per_step")):
+            if r.get(k_in) is not None:
+                rl[k_out] = _num(r[k_in], 6) if isinstance(r[k_in], float) else r[k_in]
+        if isinstance(r.get("kernels"), dict):
+            rl["kernels"] = {k.split("<")[0]: {"launches": e.get("launches_per_forward"), "ms": _num(e.get("ms_per_forward")), "frac": _num(e.get("frac_of_peak"))} for k, e in r["kernels"].items()}
+        rl["accounting"] = "achieved = FLOPs the MFMA pipe EXECUTES in `kernel`'s launches (Winograd forms execute 1/4 or 4/9 of the direct count) / their HIP-event time inside the timed region"
+        line["roofline"] = rl
+    c = full.get("cpu_baseline")
+    if isinstance(c, dict):
+        line["cpu_baseline"] = {"value": _num(c.get("value")), "unit": c.get("unit"), "cores": c.get("cores"), "kind": c.get("kind"), "value_1thread": _num(c.get("value_1thread")),
+                                "sample": str(c.get("sample", ""))[:260], "parity_on_this_sample": {k: (_num(v) if isinstance(v, float) else v) for k, v in (c.get("parity_on_this_sample") or {}).items()}}
+    summ = legs_summary(full)
+    if summ:
+        line["legs_summary"] = summ
+    if legs_file:
+        line["legs_file"] = legs_file
+    text = json.dumps(line, allow_nan=False, separators=(",", ":"))
+    if len(text.encode()) > CONTRACT_LINE_MAX and "legs_summary" in line:  # never at the expense of the contract fields
+        line["legs_summary"] = {"dropped": "summary did not fit; see legs_file"}
+        text = json.dumps(line, allow_nan=False, separators=(",", ":"))
+    if len(text.encode()) > CONTRACT_LINE_MAX:
+        raise RuntimeError(f"bench.py: contract line is {len(text.encode())} bytes > {CONTRACT_LINE_MAX}")
+    json.loads(text)
+    return text
+
+
+def _json_safe(o):
+    """The full record with non-finite floats as null, so the legs file is strict JSON too."""
+    if isinstance(o, dict):
+        return {str(k): _json_safe(v) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [_json_safe(v) for v in o]
+    if isinstance(o, (float, np.floating)):
+        return float(o) if np.isfinite(o) else None
+    if isinstance(o, np.integer):
+        return int(o)
+    return o
+
+
+def emit(res: dict, legs_file: str | None = None) -> None:
+    """Full record -> legs file (+ one line on stderr); contract line -> stdout, LAST, flushed, nothing after it."""
+    if legs_file is None:
+        d = os.path.join(ROOT, "gpurun_out")
+        legs_file = os.path.join(d if os.path.isdir(d) else ROOT, "bench_legs.json")
+    full = _json_safe(res)
+    rel = None
+    try:
+        with open(legs_file, "w") as f:
+            json.dump(full, f, allow_nan=False, indent=1)
+        rel = os.path.relpath(legs_file, ROOT)
+    except OSError as e:  # a read-only tree must not cost the bench line
+        print(f"bench.py: could not write {legs_file}: {e}", file=sys.stderr)
+    print("bench.py full record: " + json.dumps(full, allow_nan=False), file=sys.stderr)
+    sys.stderr.flush()
+    sys.stdout.flush()
+    print(contract_line(full, rel), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -210,6 +345,9 @@ def main():
     ap.add_argument("--no-alt-precisions", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch the forward kernel by kernel instead of replaying one hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--legs-file", default=None,
+                    help="where the FULL record (every leg, every per-op table) goes; default gpurun_out/bench_legs.json when gpurun_out/ exists, "
+                         "else bench_legs.json next to bench.py.  stdout carries only the <= 4 KB contract line")
     ap.add_argument("--no-h2d-leg", action="store_true")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="REHEARSAL of the multi-rank code path on a one-GPU box: all ranks share cuda:0 and synchronise over gloo "
@@ -253,7 +391,7 @@ def main():
     if rank == 0:
         if args.rehearse_on_one_gpu:
             res["data"] = "REHEARSAL: %d ranks on one GPU over gloo -- not a measurement" % world
-        print(json.dumps(res))
+        emit(res, args.legs_file)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -593,6 +731,9 @@ def run_infer(args, ctx):
             "avg_launch_ms": conv_ms / max(len(conv_rows), 1), "launches_per_forward": len(conv_rows),
             "dominant_kernel_ms_per_forward": D["ms"], "dominant_kernel_avg_launch_ms": D["ms"] / max(D["launches"], 1),
             "conv_stack_direct_equivalent_tflops": stack_flops / (stack_ms * 1e-3) / 1e12 if stack_ms > 0 else 0.0,
+            # every conv launch of the forward incl. the fused stem (its MFMA conv priced by its own share; its VALU first conv is not matrix work)
+            "conv_stack_frac": (executed_all + sum(r.get("mfma_flops", 0.0) * L.KV_MFMA_SHARE[L.KV_STEM] for r, _ in stack_rows if r["kind"] == L.OP_STEM)) / (stack_ms * 1e-3) / 1e12 / peak if stack_ms > 0 else 0.0,
+            "conv_stack_ms_per_forward": stack_ms,
             "forward_ms": fwd_ms, "forward_frames_per_s": B / (fwd_ms * 1e-3) if fwd_ms > 0 else 0.0,
             "per_op_ms": {r["label"]: round(ms / max(n_fw, 1), 4) for r, ms in zip(table, op_ms)},
             "profiled_forwards": n_fw,

@@ -74,16 +74,23 @@ class HipBackend:
         x = x.to(self._device, non_blocking=True)
         if x.dim() == 5:
             x = x.squeeze(1)
-        code = None
-        if x.dtype != torch.uint8:
-            x = x.to(torch.float32)
-            code = 2 if bool(x.max() > 1.0) else 1  # normalize_on_gpu's data-dependent branch
+        x, code = self.input_code(x)
         out = self._forward_graph(x, code) if self.use_graph else self.model.forward(x, in_dtype=code)
         if isinstance(out, torch.Tensor):
             out = {"output": out}
         if not isinstance(out, dict):
             raise TypeError(f"unexpected model output type {type(out).__name__}")
         return out
+
+    @staticmethod
+    def input_code(x: torch.Tensor):
+        """``(x, in_dtype code)`` for a batch already on the device: uint8 frames keep their dtype (code None: the first kernel divides by 255);
+        float frames become fp32 and take ``normalize_on_gpu``'s data-dependent branch (data/normalization.py:32): code 2 (divide by 255) when
+        ``max() > 1``, code 1 (as is) otherwise.  One host read of one scalar."""
+        if x.dtype == torch.uint8:
+            return x, None
+        x = x.to(torch.float32)
+        return x, (2 if bool(x.max() > 1.0) else 1)
 
     def _forward_graph(self, x: torch.Tensor, code) -> Dict[str, torch.Tensor]:
         """A captured graph holds raw pointers into the model's workspace and packed weights.  Each entry therefore keeps

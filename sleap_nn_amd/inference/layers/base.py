@@ -3,6 +3,7 @@
 from __future__ import annotations
 
 from abc import ABC, abstractmethod
+from dataclasses import replace
 from typing import Tuple, Union
 
 import numpy as np
@@ -71,40 +72,48 @@ class InferenceLayer(ABC):
         if not self._GRAPHABLE_POSTPROCESS or not hasattr(self.backend, "model"):
             raise RuntimeError(f"{type(self).__name__} on {type(self.backend).__name__} cannot run as one graph (host stage in its post-process, or a foreign backend)")
         x, info = self.preprocess(image)
-        entry = self._graph_entry(x, info)
+        x = x.to(torch.device(self.backend.device), non_blocking=True)
+        x, code = self.backend.input_code(x)  # float frames: the same max() > 1 test HipBackend.__call__ makes, per call
+        entry = self._graph_entry(x, info, code)
         graph, static_in, out = entry[0], entry[1], entry[2]
         if x.data_ptr() != static_in.data_ptr():
             static_in.copy_(x, non_blocking=True)
         graph.replay()
-        return out
+        # the graph bakes in shapes / scales, not the sizes of THIS call's frames (two original sizes can pad to one shape): same static tensors, this call's record
+        return out if out.preprocess_info is info else replace(out, preprocess_info=info)
 
     def graph_input(self, shape) -> torch.Tensor:
         """The input buffer of ``predict_graphed``'s graph for preprocessed frames of ``shape`` ((B, C, H, W) uint8; captured on first use)."""
         x, info = self.preprocess(torch.zeros(tuple(shape), dtype=torch.uint8, device=self.backend.device))
-        return self._graph_entry(x, info)[1].squeeze(1)
+        return self._graph_entry(x.to(torch.device(self.backend.device)), info, None)[1].squeeze(1)
 
-    def _graph_entry(self, x: torch.Tensor, info: PreprocInfo):
+    def _graph_entry(self, x: torch.Tensor, info: PreprocInfo, code):
+        """``(graph, static input, static Outputs, workspace)`` for device frames ``x`` with input code ``code`` (HipBackend.input_code).  Same stale-pointer discipline as
+        ``HipBackend._forward_graph``: entries die with the model generation they were captured under -- also when it is the warm-up of a NEW shape that grew the workspace."""
         be = self.backend
         dev = torch.device(be.device)
-        x = x.to(dev, non_blocking=True)
         graphs = self.__dict__.setdefault("_step_graphs", {})
         if self.__dict__.get("_step_graph_generation") != be.model.generation:  # weights / options / workspace changed: captured pointers are stale
             graphs.clear()
-        # (everything the captured launches bake in: shapes, the preprocessing record, the post-process parameters)
-        key = (tuple(x.shape), x.dtype, tuple(float(v) for v in info.eff_scale.flatten().tolist()), float(info.input_scale), int(info.output_stride), repr(self.postprocess_config))
+            self.__dict__["_step_graph_generation"] = be.model.generation
+        # (everything the captured launches bake in: shapes, the input normalisation, the preprocessing scales, the post-process parameters)
+        key = (tuple(x.shape), x.dtype, code, tuple(float(v) for v in info.eff_scale.flatten().tolist()), float(info.input_scale), int(info.output_stride), repr(self.postprocess_config))
         entry = graphs.get(key)
         if entry is None:
             static_in = x.clone()
             side = torch.cuda.Stream(dev)
             side.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(side):  # warm-up outside the capture: handle creation, workspace allocation, lazy weight packs
-                self.postprocess(be.model.forward(static_in.squeeze(1)), info)
+                self.postprocess(be.model.forward(static_in.squeeze(1), in_dtype=code), info)
             torch.cuda.current_stream(dev).wait_stream(side)
             torch.cuda.synchronize(dev)
+            if self.__dict__["_step_graph_generation"] != be.model.generation:  # the warm-up grew the workspace / rebuilt the handle: older entries point into the old one
+                graphs.clear()
+                self.__dict__["_step_graph_generation"] = be.model.generation
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
-                out = self.postprocess(be.model.forward(static_in.squeeze(1)), info)
-            self.__dict__["_step_graph_generation"] = be.model.generation
+                out = self.postprocess(be.model.forward(static_in.squeeze(1), in_dtype=code), info)
+            assert be.model.generation == self.__dict__["_step_graph_generation"], "capture must not reallocate"
             entry = (graph, static_in, out, be.model._workspace)
             graphs[key] = entry
         return entry

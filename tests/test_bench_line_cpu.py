@@ -1,0 +1,96 @@
+"""The bench contract line: <= 4 KB, strict JSON, contract fields + roofline + cpu_baseline, whatever the legs hold.
+
+Canned input: tests/golden/bench_full_record_r4.json = the full 25 KB record round 4's bench produced (the one the
+driver could not parse); the line builder must cut it down to a line the driver can."""
+import copy
+import io
+import json
+import os
+import sys
+from contextlib import redirect_stderr, redirect_stdout
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def bench():
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.fixture()
+def full():
+    return json.load(open(os.path.join(ROOT, "tests", "golden", "bench_full_record_r4.json")))
+
+
+def strict(text):
+    def no_constants(name):
+        raise ValueError(f"non-strict JSON constant {name}")
+
+    return json.loads(text, parse_constant=no_constants)
+
+
+def test_contract_line_is_small_strict_and_complete(bench, full):
+    assert len(json.dumps(full)) > 20000  # the record that broke the driver's parse
+    text = bench.contract_line(full, "gpurun_out/bench_legs.json")
+    assert "\n" not in text and len(text.encode()) < 4096
+    line = strict(text)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in line, k
+    assert line["value"] == pytest.approx(full["value"], rel=1e-6) and line["ms_per_step"] == pytest.approx(full["ms_per_step"], rel=1e-6)
+    assert line["dtype"] == "f32" and line["config"]["workload"].startswith("cfg3") and "model" not in line["config"]
+    r = line["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["frac"] == pytest.approx(r["achieved"] / r["peak"], rel=1e-4)
+    assert r["traffic"] == pytest.approx(full["roofline"]["traffic"], rel=1e-5) and r["kernel"] == "conv3x3_wino4_kernel"
+    c = line["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 16 and c["value"] == pytest.approx(full["cpu_baseline"]["value"], rel=1e-4) and c["parity_on_this_sample"]["peak_indices_equal"] is True
+    s = line["legs_summary"]
+    assert s["infer_cfg1"]["value"] == pytest.approx(full["infer_cfg1"]["value"], rel=1e-4) and s["published_workload"]["end_to_end_frames_per_s"] > 0
+    assert line["h2d_inclusive"]["value"] == pytest.approx(full["h2d_inclusive"]["value"], rel=1e-6)
+    for leg in bench.LEG_KEYS:  # no leg body in the line
+        assert leg not in line
+
+
+def test_contract_line_survives_nan_and_oversized_legs(bench, full):
+    big = copy.deepcopy(full)
+    big["roofline"]["traffic"] = float("nan")
+    big["cpu_baseline"]["sample"] = "x" * 5000
+    big["train_cfg4"]["value"] = float("inf")
+    big["roofline"]["per_op_ms"] = {f"op{i}": 0.1 for i in range(2000)}
+    for i in range(40):
+        big[f"infer_extra_{i}"] = {"value": 1.0, "blob": "y" * 1000}
+    text = bench.contract_line(big, None)
+    assert len(text.encode()) < 4096
+    line = strict(text)
+    assert line["roofline"]["traffic"] is None and line["legs_summary"]["train_cfg4"]["value"] is None and len(line["cpu_baseline"]["sample"]) <= 260
+
+
+def test_contract_line_refuses_to_exceed_the_bound(bench, full):
+    bad = copy.deepcopy(full)
+    bad["config"]["workload"] = "w" * 5000
+    with pytest.raises(RuntimeError):
+        bench.contract_line(bad, None)
+
+
+def test_emit_prints_the_contract_line_last_and_writes_the_legs_file(bench, full, tmp_path):
+    out, err = io.StringIO(), io.StringIO()
+    legs = tmp_path / "legs.json"
+    with redirect_stdout(out), redirect_stderr(err):
+        bench.emit(full, str(legs))
+    lines = out.getvalue().splitlines()
+    assert len(lines) == 1 and len(lines[0]) < 4096 and strict(lines[0])["value"] == pytest.approx(full["value"], rel=1e-6)
+    rec = strict(legs.read_text())
+    assert set(bench.LEG_KEYS) - {"weak_scaling"} <= set(rec) and rec["infer_cfg5"]["value"] == full["infer_cfg5"]["value"]
+    assert err.getvalue().startswith("bench.py full record: ")
+
+
+def test_training_headline_goes_through_the_same_line(bench, full):
+    leg = dict(full["train_cfg4"], n_gpus=1, warmup=2, higher_is_better=True, scaling="strong", vs_baseline=None)
+    line = strict(bench.contract_line(leg, None))
+    assert line["metric"].startswith("frames/sec training step") and line["roofline"]["frac"] == pytest.approx(full["train_cfg4"]["roofline"]["frac"], rel=1e-4)

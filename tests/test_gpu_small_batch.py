@@ -73,6 +73,16 @@ def test_cfg1_single_instance_256_batch1_network_and_global_peaks():
     e2 = layer.predict(img[1:2])
     assert torch.equal(g2.pred_keypoints, e2.pred_keypoints) and not torch.equal(e2.pred_keypoints, eager_out.pred_keypoints)
     assert torch.equal(layer.predict_graphed(img[:1]).pred_keypoints, eager_out.pred_keypoints)  # a foreign tensor is copied into the graph's buffer
+    # float frames take normalize_on_gpu's data-dependent branch in the graphed step exactly as in predict: 0..255 floats are divided by 255, 0..1 floats are not
+    f255 = img[:1].to(torch.float32)
+    f01 = f255 / 255.0
+    for fin in (f255, f01):
+        assert torch.equal(layer.predict_graphed(fin).pred_keypoints, layer.predict(fin).pred_keypoints)
+    assert torch.equal(layer.predict_graphed(f255).pred_keypoints, eager_out.pred_keypoints)
+    assert (layer.predict_graphed(f01).pred_keypoints - eager_out.pred_keypoints).abs().max().item() <= 0.05  # (x / 255 on the host first: rounding-level differences of the maps)
+    # frames of another original size that pad to the same shape share the graph but get their own preprocessing record
+    small = layer.predict_graphed(img[:1, :, :250, :250])
+    assert small.preprocess_info.original_size == (250, 250) and layer.predict_graphed(img[:1]).preprocess_info.original_size == (256, 256)
     raw = layer.backend(img[:1])["SingleInstanceConfmapsHead"]
     codes = m.last_kernels()
     assert L.KV_WINO2D_KS in codes, codes  # the default routing of this batch takes the split-K form somewhere
