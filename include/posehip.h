@@ -26,6 +26,9 @@
  *                       assign_connections_to_instances, make_predicted_instances,
  *                       group_instances_*) + inference/streaming.py:147-255 padding.
  *   ph_toposort_edges   inference/ops/paf.py:890-912.
+ *   ph_group_packed     inference/layers/bottomup.py:126-195 (hand-off) + inference/streaming.py:147-255.
+ *   ph_centroid_select  inference/layers/centroid.py:195-261 + layers/topdown.py:183-235.
+ *   ph_topdown_scatter  inference/layers/topdown.py:236-260.
  */
 #ifndef POSEHIP_H
 #define POSEHIP_H
@@ -37,7 +40,7 @@
 extern "C" {
 #endif
 
-#define PH_VERSION 104
+#define PH_VERSION 105
 
 /* error codes */
 #define PH_OK 0
@@ -306,6 +309,25 @@ int ph_crop_bboxes(const void* images_dev, int32_t dtype, int32_t B, int32_t C, 
                    const float* topleft_xy_dev, const int32_t* sample_inds_dev, int32_t n,
                    int32_t crop_h, int32_t crop_w, void* out_dev, void* stream);
 
+/* Top-down glue, device side.  ph_centroid_select = CentroidLayer.postprocess after the peak finding (inference/layers/centroid.py:195-261:
+ * per frame keep the peaks in order, or the max_instances largest values in descending order (torch.topk) when there are more; NaN-pad to
+ * (B, max_instances, 2) / (B, max_instances); undo input scale and eff_scale (inference/ops/coord.py:40-70)) plus what TopDownLayer.predict
+ * (inference/layers/topdown.py:183-260) derives from the valid centroids: make_centered_bboxes (data/instance_cropping.py:129-171) into
+ * out_bboxes (B, max_instances, 4, 2; NaN where empty), and the stage-2 lists in torch.nonzero order of the valid mask (frame, then slot):
+ * list_sample int32[n_valid], list_topleft float[n_valid, 2] (the ph_crop_bboxes inputs), list_slot int32[n_valid] = frame * max_instances + slot,
+ * pos_of_slot int32[B * max_instances] = list position or -1, out_n_valid int32[1].  peaks / counts are ph_local_peaks' outputs (coordinates
+ * already multiplied by the output stride through its xy_scale).  eff_scale_dev float[B] or NULL; every list pointer may be NULL (centroid-only use). */
+int ph_centroid_select(const float* peaks_xy_dev, const float* peak_vals_dev, const int32_t* counts_dev, int32_t B, int32_t max_instances,
+                       int32_t cap, float input_scale, const float* eff_scale_dev, float crop_h, float crop_w, float* out_centroids_dev,
+                       float* out_vals_dev, float* out_bboxes_dev, int32_t* list_sample_dev, float* list_topleft_dev, int32_t* list_slot_dev,
+                       int32_t* pos_of_slot_dev, int32_t* out_n_valid_dev, void* stream);
+
+/* ... and the way back (topdown.py:236-260): crop-local keypoints (n_valid, n_nodes, 2) / values (n_valid, n_nodes) of stage 2 into
+ * out_keypoints = crop keypoints + the crop's top-left (add_crop_offset, ops/coord.py:73-90), out_crop_keypoints, out_vals, all
+ * (slots = B * max_instances, n_nodes[, 2]) and NaN where pos_of_slot is -1. */
+int ph_topdown_scatter(const float* crop_xy_dev, const float* crop_vals_dev, const float* list_topleft_dev, const int32_t* pos_of_slot_dev,
+                       int32_t slots, int32_t n_nodes, float* out_keypoints_dev, float* out_crop_keypoints_dev, float* out_vals_dev, void* stream);
+
 /* Antialiased bilinear resize of planes x H x W -> planes x OH x OW (uint8: dtype 0, float32: dtype 1), NCHW planes.
  * Replaces torchvision.transforms.v2.functional.resize as called by resize_image (data/resizing.py:70-84, the input-scale step)
  * and apply_sizematcher (data/resizing.py:136-175): for tensors that is torch's interpolate(mode="bilinear",
@@ -370,6 +392,21 @@ int ph_group_batch(int32_t B, int32_t n_nodes, const int32_t* edges, int32_t n_e
                    float min_line_score, double min_instance_peaks, int32_t min_instance_peaks_is_fraction,
                    int32_t max_inst, int32_t truncate_by_score, float* out_kpts, float* out_vals,
                    float* out_scores, int32_t* out_n_inst);
+
+/* The whole CPU stage of a bottom-up batch from the packed D2H arena of the GPU stage, in one call: unpack + capacity check + the
+ * max_peaks_per_node guard (inference/layers/bottomup.py:126-161), ph_group_batch, then the input-scale / eff_scale undo and the output sizing of
+ * group_scored_batch (inference/streaming.py:147-255).  arena (host, pinned or not) = float32 / int32 words
+ *   [counts 2+2B (ph_local_peaks' out_count) | cand offsets B+1 | xy 2*peak_cap | vals peak_cap | cand score cand_cap | channel peak_cap |
+ *    cand edge cand_cap | cand src cand_cap | cand dst cand_cap].
+ * max_instances < 0 = None (keep every instance); max_peaks_per_node < 0 = no guard; eff_scale float[B] or NULL.
+ * Outputs (B, out_cap, n_nodes, 2) / (B, out_cap, n_nodes) / (B, out_cap) NaN-padded (row stride out_cap, or max(1, max_instances) when that is given
+ * and <= out_cap), out_n_inst int32[B].  status int32[4]: [0] peaks, [1] candidates, [2] flags -- 1: arena capacity exceeded (nothing grouped: re-run
+ * the GPU stage with at least status[0] / status[1] entries), 2: out_cap too small (nothing grouped: come back with status[3]), 4: guard fired (all NaN)
+ * --, [3] instances per frame the caller should keep (max over frames, >= 1; max_instances when given). */
+int ph_group_packed(const float* arena, int32_t B, int32_t n_nodes, int32_t peak_cap, int32_t cand_cap, const int32_t* edges, int32_t n_edges,
+                    float min_line_score, double min_instance_peaks, int32_t min_instance_peaks_is_fraction, int32_t max_instances,
+                    int32_t max_peaks_per_node, float input_scale, const float* eff_scale, int32_t out_cap, float* out_kpts, float* out_vals,
+                    float* out_scores, int32_t* out_n_inst, int32_t* status);
 
 /* Host: Hungarian matching of peaks to classes per (sample, channel)
  * (inference/ops/identity.py:13-76).  probs (n, K) fp32, sample/channel (n) int32.

@@ -446,4 +446,99 @@ int ph_group_batch(int32_t B, int32_t n_nodes, const int32_t* edges, int32_t n_e
   return PH_OK;
 }
 
+// One call for the CPU stage of a bottom-up batch, straight from the packed D2H arena BottomUpLayer's GPU stage fills
+// (layers/bottomup.py _enqueue_scoring: [counts 2+2B | cand offsets B+1 | xy 2P | vals P | score Q | channel P | cand edge Q | src Q | dst Q],
+// int32 rows bit-cast): what _finish_scoring (unpack, capacity check, max_peaks_per_node guard: sleap_nn layers/bottomup.py:126-161) and
+// group_scored_batch (sleap_nn inference/streaming.py:147-255: matching + assembly + input-scale / eff-scale undo + NaN pad) do, without a
+// numpy copy or a Python loop in between.  status[0] = peaks, [1] = candidates, [2] = flags (1: the arena's capacities were exceeded -- nothing
+// was grouped, re-run the GPU stage with larger ones; 2: out_cap is smaller than the instance bound -- nothing was grouped, status[3] = the
+// capacity to come back with; 4: the max_peaks_per_node guard fired, outputs are all NaN), [3] = instances to keep per sample
+// (max over samples, at least 1; max_instances when that is given).  max_instances < 0 = None.
+int ph_group_packed(const float* arena, int32_t B, int32_t n_nodes, int32_t peak_cap, int32_t cand_cap, const int32_t* edges, int32_t n_edges,
+                    float min_line_score, double min_instance_peaks, int32_t min_instance_peaks_is_fraction, int32_t max_instances,
+                    int32_t max_peaks_per_node, float input_scale, const float* eff_scale, int32_t out_cap, float* out_kpts, float* out_vals,
+                    float* out_scores, int32_t* out_n_inst, int32_t* status) {
+  if (!arena || B <= 0 || n_nodes <= 0 || peak_cap <= 0 || cand_cap <= 0 || out_cap <= 0 || !out_kpts || !out_vals || !out_scores || !out_n_inst || !status) {
+    ph::set_error("ph_group_packed: bad arguments");
+    return PH_E_INVALID;
+  }
+  const int32_t* ihead = reinterpret_cast<const int32_t*>(arena);
+  const int n_head = (2 + 2 * B) + (B + 1);
+  const int32_t n_peaks = ihead[0];
+  const int32_t* peak_offsets = ihead + 1 + B;
+  const int32_t* cand_offsets = ihead + 2 + 2 * B;
+  const int32_t n_cand = cand_offsets[B];
+  status[0] = n_peaks;
+  status[1] = n_cand;
+  status[2] = 0;
+  status[3] = max_instances >= 0 ? std::max(1, max_instances) : 1;
+  if (n_peaks < 0 || n_cand < 0 || n_peaks > peak_cap || n_cand > cand_cap) {
+    status[2] = 1;
+    return PH_OK;
+  }
+  const float* xy = arena + n_head;
+  const float* vals = xy + 2 * (size_t)peak_cap;
+  const float* score = vals + peak_cap;
+  const int32_t* channel = reinterpret_cast<const int32_t*>(score + cand_cap);
+  const int32_t* cand_edge = channel + peak_cap;
+  const int32_t* cand_src = cand_edge + cand_cap;
+  const int32_t* cand_dst = cand_src + cand_cap;
+  const float NANF = std::numeric_limits<float>::quiet_NaN();
+  bool skip = false;
+  int bound = 0;
+  std::vector<int> per_node(n_nodes);
+  for (int b = 0; b < B; ++b) {
+    const int p0 = peak_offsets[b], np = peak_offsets[b + 1] - p0;
+    bound = std::max(bound, np);
+    if (max_peaks_per_node >= 0 && !skip) {
+      std::fill(per_node.begin(), per_node.end(), 0);
+      for (int i = 0; i < np; ++i) {
+        const int k = channel[p0 + i];
+        if (k >= 0 && k < n_nodes && ++per_node[k] > max_peaks_per_node) skip = true;
+      }
+    }
+  }
+  if (skip) {  // combinatorial-blow-up guard: a batch of NaNs, (B, max_instances or 1, ...)
+    status[2] = 4;
+    std::fill(out_kpts, out_kpts + (size_t)B * out_cap * n_nodes * 2, NANF);
+    std::fill(out_vals, out_vals + (size_t)B * out_cap * n_nodes, NANF);
+    std::fill(out_scores, out_scores + (size_t)B * out_cap, NANF);
+    std::fill(out_n_inst, out_n_inst + B, 0);
+    return PH_OK;
+  }
+  // an instance needs at least one matched edge, so the per-sample instance count is bounded by the number of peaks (group_scored_batch)
+  const int cap = max_instances >= 0 ? std::max(1, max_instances) : std::max(1, bound);
+  if (cap > out_cap) {
+    status[2] = 2;
+    status[3] = cap;
+    return PH_OK;
+  }
+  // (grouping with max_inst = out_cap >= cap: with max_instances None nothing is truncated, the layout stride is the caller's)
+  const int rc = ph_group_batch(B, n_nodes, edges, n_edges, xy, vals, channel, peak_offsets, cand_edge, cand_src, cand_dst, score, cand_offsets, min_line_score,
+                                min_instance_peaks, min_instance_peaks_is_fraction, max_instances >= 0 ? cap : out_cap, max_instances >= 0 ? 1 : 0, out_kpts, out_vals,
+                                out_scores, out_n_inst);
+  if (rc != PH_OK) return rc;
+  const int stride = max_instances >= 0 ? cap : out_cap;
+  if (max_instances < 0) {
+    int mi = 1;
+    for (int b = 0; b < B; ++b) mi = std::max(mi, (int)out_n_inst[b]);
+    status[3] = mi;
+  }
+  const bool by_input = input_scale != 1.0f;
+  bool by_eff = false;
+  if (eff_scale)
+    for (int b = 0; b < B; ++b) by_eff = by_eff || eff_scale[b] != 1.0f;
+  if (by_input || by_eff)
+    for (int b = 0; b < B; ++b) {
+      float* kp = out_kpts + (size_t)b * stride * n_nodes * 2;
+      for (size_t i = 0; i < (size_t)stride * n_nodes * 2; ++i) {
+        float v = kp[i];
+        if (by_input) v = v / input_scale;
+        if (by_eff) v = v / eff_scale[b];
+        kp[i] = v;
+      }
+    }
+  return PH_OK;
+}
+
 }  // extern "C"

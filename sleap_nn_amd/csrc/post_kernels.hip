@@ -796,6 +796,133 @@ __global__ __launch_bounds__(256) void sample_class_maps_kernel(const float* __r
   out[i] = maps[(((size_t)sidx[p] * K + k) * H + row) * W + col];
 }
 
+// ---------------------------------------------------------------------------------------
+// Top-down glue on the device (layers/centroid.py:195-261 CentroidLayer.postprocess: per-frame top-k + NaN pad + coordinate ladder;
+// layers/topdown.py:183-260: valid centroids -> centred boxes -> crops -> crop offset + scatter back to (B, I, ...)).  The reference and the
+// round-4 build walk the frames of a batch in Python with a host read per step; here one wave per frame selects, pads and lists, and one launch scatters.
+// ---------------------------------------------------------------------------------------
+// One wave per frame b.  Peaks of frame b are rows [off_b, off_b + n_b) of (xy, vals) in the reference's order (counts = ph_local_peaks' out_count).
+// n_b <= I: kept in order; else the I largest values, descending (torch.topk; equal values: the earlier peak first).  Slots beyond are NaN.
+// Lists for stage 2 (frames ascending, slots ascending = torch.nonzero order of the valid mask): sample index, bbox top-left, flat slot; pos_of_slot = inverse (-1: empty).
+__global__ __launch_bounds__(64) void centroid_select_kernel(const float* __restrict__ xy, const float* __restrict__ vals, const int* __restrict__ counts, int B, int I, int cap,
+                                                             float input_scale, const float* __restrict__ eff_scale, float half_w, float half_h,
+                                                             float* __restrict__ out_cp, float* __restrict__ out_cv, float* __restrict__ out_bbox,
+                                                             int* __restrict__ list_sample, float* __restrict__ list_tl, int* __restrict__ list_slot,
+                                                             int* __restrict__ pos_of_slot, int* __restrict__ out_n_valid) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const float NANF = __builtin_nanf("");
+  const int total = min(counts[0], cap);
+  int off = min(counts[1 + B + b], total);
+  int n = min(counts[1 + b], total - off);
+  int base = 0, all = 0;  // valid entries of the frames before this one / of all frames
+  for (int j = 0; j < B; ++j) {
+    const int oj = min(counts[1 + B + j], total);
+    const int nj = min(min(counts[1 + j], total - oj), I);
+    if (j < b) base += nj;
+    all += nj;
+  }
+  if (b == 0 && lane == 0 && out_n_valid) *out_n_valid = all;
+  const int keep = min(n, I);
+  const float eff = eff_scale ? eff_scale[b] : 1.f;
+  auto emit = [&](int slot, int src) {  // (one lane)
+    float x = xy[2 * (size_t)(off + src)], y = xy[2 * (size_t)(off + src) + 1];
+    if (input_scale != 1.f) {
+      x = x / input_scale;
+      y = y / input_scale;
+    }
+    x = x / eff;
+    y = y / eff;
+    const size_t s = (size_t)b * I + slot;
+    out_cp[2 * s] = x;
+    out_cp[2 * s + 1] = y;
+    out_cv[s] = vals[off + src];
+    if (out_bbox) {  // make_centered_bboxes: corners (x -/+ w/2, y -/+ h/2) + (+/-0.5): TL, TR, BR, BL
+      float* bb = out_bbox + 8 * s;
+      bb[0] = (x - half_w) + 0.5f;
+      bb[1] = (y - half_h) + 0.5f;
+      bb[2] = (x + half_w) - 0.5f;
+      bb[3] = (y - half_h) + 0.5f;
+      bb[4] = (x + half_w) - 0.5f;
+      bb[5] = (y + half_h) - 0.5f;
+      bb[6] = (x - half_w) + 0.5f;
+      bb[7] = (y + half_h) - 0.5f;
+      if (list_sample) {
+        const int pos = base + slot;
+        list_sample[pos] = b;
+        list_tl[2 * pos] = bb[0];
+        list_tl[2 * pos + 1] = bb[1];
+        list_slot[pos] = (int)s;
+      }
+    }
+    if (pos_of_slot) pos_of_slot[s] = base + slot;
+  };
+  if (n <= I) {
+    for (int k = lane; k < keep; k += 64) emit(k, k);
+  } else {
+    // I rounds of a wave-wide arg-max over the peaks not taken yet (taken peaks are remembered as a bit per peak in registers: 64 x 32 = up to 2048 peaks per frame;
+    // more than that and the tail beyond 2048 is not considered -- the caller's capacity is far below)
+    unsigned taken = 0u;  // bit j: peak lane + 64 j
+    n = min(n, 2048);
+    for (int k = 0; k < I; ++k) {
+      float best = -__builtin_inff();
+      int bi = 0x7FFFFFFF;
+      for (int j = 0; lane + 64 * j < n; ++j) {
+        if ((taken >> j) & 1u) continue;
+        const float v = vals[off + lane + 64 * j];
+        if (v > best || (v == best && lane + 64 * j < bi)) {
+          best = v;
+          bi = lane + 64 * j;
+        }
+      }
+      for (int m = 32; m >= 1; m >>= 1) {
+        const float ov = __shfl_xor(best, m);
+        const int oi = __shfl_xor(bi, m);
+        if (ov > best || (ov == best && oi < bi)) {
+          best = ov;
+          bi = oi;
+        }
+      }
+      if (bi != 0x7FFFFFFF && (bi & 63) == lane) {
+        taken |= 1u << (bi >> 6);
+        emit(k, bi);
+      }
+    }
+  }
+  for (int k = keep + lane; k < I; k += 64) {
+    const size_t s = (size_t)b * I + k;
+    out_cp[2 * s] = NANF;
+    out_cp[2 * s + 1] = NANF;
+    out_cv[s] = NANF;
+    if (out_bbox)
+      for (int e = 0; e < 8; ++e) out_bbox[8 * s + e] = NANF;
+    if (pos_of_slot) pos_of_slot[s] = -1;
+  }
+}
+
+// (B I, N) threads: slot s of the padded outputs takes crop pos_of_slot[s]'s keypoints (+ its box's top-left: add_crop_offset) or NaN.
+__global__ __launch_bounds__(256) void topdown_scatter_kernel(const float* __restrict__ crop_xy, const float* __restrict__ crop_vals, const float* __restrict__ list_tl,
+                                                              const int* __restrict__ pos_of_slot, int slots, int N, float* __restrict__ out_k, float* __restrict__ out_c,
+                                                              float* __restrict__ out_v) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= slots * N) return;
+  const int s = i / N, k = i - s * N;
+  const int pos = pos_of_slot[s];
+  const float NANF = __builtin_nanf("");
+  float cx = NANF, cy = NANF, v = NANF, gx = NANF, gy = NANF;
+  if (pos >= 0) {
+    cx = crop_xy[2 * ((size_t)pos * N + k)];
+    cy = crop_xy[2 * ((size_t)pos * N + k) + 1];
+    v = crop_vals[(size_t)pos * N + k];
+    gx = cx + list_tl[2 * pos];
+    gy = cy + list_tl[2 * pos + 1];
+  }
+  out_k[2 * (size_t)i] = gx;
+  out_k[2 * (size_t)i + 1] = gy;
+  out_c[2 * (size_t)i] = cx;
+  out_c[2 * (size_t)i + 1] = cy;
+  out_v[i] = v;
+}
+
 }  // namespace ph
 
 using namespace ph;
@@ -888,6 +1015,30 @@ int ph_paf_score(const float* pafs_dev, int32_t B, int32_t E2, int32_t H, int32_
   a.cand_score = cand_score;
   a.cap = cap;
   return launch_paf_score(a, peak_channel_dev, n_peaks_total, static_cast<int*>(scratch_dev), cand_offsets, static_cast<hipStream_t>(stream));
+}
+
+int ph_centroid_select(const float* peaks_xy_dev, const float* peak_vals_dev, const int32_t* counts_dev, int32_t B, int32_t max_instances, int32_t cap,
+                       float input_scale, const float* eff_scale_dev, float crop_h, float crop_w, float* out_centroids_dev, float* out_vals_dev,
+                       float* out_bboxes_dev, int32_t* list_sample_dev, float* list_topleft_dev, int32_t* list_slot_dev, int32_t* pos_of_slot_dev,
+                       int32_t* out_n_valid_dev, void* stream) {
+  PH_REQUIRE(peaks_xy_dev && peak_vals_dev && counts_dev && out_centroids_dev && out_vals_dev, "ph_centroid_select: null argument");
+  PH_REQUIRE(B > 0 && max_instances > 0 && cap >= 0, "ph_centroid_select: bad shape");
+  PH_REQUIRE(!list_sample_dev || (out_bboxes_dev && list_topleft_dev && list_slot_dev), "ph_centroid_select: the stage-2 lists need the boxes");
+  hipLaunchKernelGGL(centroid_select_kernel, dim3(B), dim3(64), 0, static_cast<hipStream_t>(stream), peaks_xy_dev, peak_vals_dev, counts_dev, B, max_instances, cap,
+                     input_scale, eff_scale_dev, crop_w / 2, crop_h / 2, out_centroids_dev, out_vals_dev, out_bboxes_dev, list_sample_dev, list_topleft_dev, list_slot_dev,
+                     pos_of_slot_dev, out_n_valid_dev);
+  PH_HIP_CHECK(hipGetLastError());
+  return PH_OK;
+}
+
+int ph_topdown_scatter(const float* crop_xy_dev, const float* crop_vals_dev, const float* list_topleft_dev, const int32_t* pos_of_slot_dev, int32_t slots,
+                       int32_t n_nodes, float* out_keypoints_dev, float* out_crop_keypoints_dev, float* out_vals_dev, void* stream) {
+  PH_REQUIRE(crop_xy_dev && crop_vals_dev && list_topleft_dev && pos_of_slot_dev && out_keypoints_dev && out_crop_keypoints_dev && out_vals_dev, "ph_topdown_scatter: null argument");
+  PH_REQUIRE(slots > 0 && n_nodes > 0, "ph_topdown_scatter: bad shape");
+  hipLaunchKernelGGL(topdown_scatter_kernel, dim3((slots * n_nodes + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), crop_xy_dev, crop_vals_dev, list_topleft_dev,
+                     pos_of_slot_dev, slots, n_nodes, out_keypoints_dev, out_crop_keypoints_dev, out_vals_dev);
+  PH_HIP_CHECK(hipGetLastError());
+  return PH_OK;
 }
 
 }  // extern "C"

@@ -87,24 +87,29 @@ class InferenceLayer(ABC):
         x, info = self.preprocess(torch.zeros(tuple(shape), dtype=torch.uint8, device=self.backend.device))
         return self._graph_entry(x.to(torch.device(self.backend.device)), info, None)[1].squeeze(1)
 
-    def _graph_entry(self, x: torch.Tensor, info: PreprocInfo, code):
-        """``(graph, static input, static Outputs, workspace)`` for device frames ``x`` with input code ``code`` (HipBackend.input_code).  Same stale-pointer discipline as
-        ``HipBackend._forward_graph``: entries die with the model generation they were captured under -- also when it is the warm-up of a NEW shape that grew the workspace."""
+    def _graph_entry(self, x: torch.Tensor, info: PreprocInfo, code, body=None, extra_key=()):
+        """``(graph, static input, static result, workspace)`` for device frames ``x`` with input code ``code`` (HipBackend.input_code).  ``body(raw_out, info)`` is what follows
+        the forward inside the graph (default: this layer's ``postprocess``; the bottom-up layer captures its GPU stage only), ``extra_key`` whatever else it bakes in.  Same
+        stale-pointer discipline as ``HipBackend._forward_graph``: entries die with the model generation they were captured under -- also when it is the warm-up of a NEW shape
+        that grew the workspace."""
         be = self.backend
         dev = torch.device(be.device)
+        body = body or self.postprocess
         graphs = self.__dict__.setdefault("_step_graphs", {})
         if self.__dict__.get("_step_graph_generation") != be.model.generation:  # weights / options / workspace changed: captured pointers are stale
             graphs.clear()
             self.__dict__["_step_graph_generation"] = be.model.generation
         # (everything the captured launches bake in: shapes, the input normalisation, the preprocessing scales, the post-process parameters)
-        key = (tuple(x.shape), x.dtype, code, tuple(float(v) for v in info.eff_scale.flatten().tolist()), float(info.input_scale), int(info.output_stride), repr(self.postprocess_config))
+        eff = info.eff_scale
+        eff_key = (int(eff.numel()),) if bool((eff == 1.0).all()) else tuple(float(v) for v in eff.flatten().tolist())
+        key = (tuple(x.shape), x.dtype, code, eff_key, float(info.input_scale), int(info.output_stride), repr(self.postprocess_config), tuple(extra_key))
         entry = graphs.get(key)
         if entry is None:
             static_in = x.clone()
             side = torch.cuda.Stream(dev)
             side.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(side):  # warm-up outside the capture: handle creation, workspace allocation, lazy weight packs
-                self.postprocess(be.model.forward(static_in.squeeze(1), in_dtype=code), info)
+                body(be.model.forward(static_in.squeeze(1), in_dtype=code), info)
             torch.cuda.current_stream(dev).wait_stream(side)
             torch.cuda.synchronize(dev)
             if self.__dict__["_step_graph_generation"] != be.model.generation:  # the warm-up grew the workspace / rebuilt the handle: older entries point into the old one
@@ -112,7 +117,7 @@ class InferenceLayer(ABC):
                 self.__dict__["_step_graph_generation"] = be.model.generation
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
-                out = self.postprocess(be.model.forward(static_in.squeeze(1), in_dtype=code), info)
+                out = body(be.model.forward(static_in.squeeze(1), in_dtype=code), info)
             assert be.model.generation == self.__dict__["_step_graph_generation"], "capture must not reallocate"
             entry = (graph, static_in, out, be.model._workspace)
             graphs[key] = entry

@@ -24,17 +24,78 @@ class TopDownLayer:
         self.return_crops = return_crops
 
     def predict(self, image) -> Outputs:
-        cout = self.centroid_layer.predict(image)
+        return self._finish(self._enqueue_stage1(image))
+
+    def _enqueue_stage1(self, image) -> dict:
+        """Stage 1 of a batch -- preprocessing, centroid forward, peak finding -- enqueued without a host read, plus the asynchronous D2H of the per-frame peak counts.
+        ``_finish`` reads those counts (the ONE host sync of a batch) and runs the rest; a caller that enqueues the next batch's stage 1 before finishing this one
+        (``Predictor.predict``) keeps the GPU busy across that sync."""
+        cl = self.centroid_layer
+        x = cl._to_4d_tensor(image).to(torch.device(cl.backend.device), non_blocking=True)
+        if self.centroid_nms:
+            return {"x": x, "slow": True}
+        xp, info = cl.preprocess(x)
+        raw = cl.backend(xp)
+        return {"x": x, "slow": False, "raw": raw, "info": info, "sel": cl._select_enqueue(raw, info)}
+
+    def _finish(self, h: dict) -> Outputs:
+        import ctypes as C
+
+        from sleap_nn_amd import _lib as L
+
+        if h["slow"]:
+            return self._predict_with_host_nms(h["x"])
+        cl, il = self.centroid_layer, self.centered_instance_layer
+        x = h["x"]
+        dev = x.device
+        ch, cw = self.crop_size
+        sel = cl._select_finish(h["sel"], h["info"], (ch, cw))
+        centroids, cvals, I, n_valid = sel["centroids"], sel["vals"], sel["I"], sel["n_valid"]
+        B = int(centroids.shape[0])
+        if n_valid == 0:
+            n_nodes = 1
+            return Outputs(pred_keypoints=torch.full((B, I, n_nodes, 2), float("nan")), pred_peak_values=torch.full((B, I, n_nodes), float("nan")),
+                           pred_centroids=centroids.cpu(), pred_centroid_values=cvals.cpu(), instance_scores=cvals.cpu())
+        if x.dtype == torch.uint8:
+            code = 0
+        elif x.dtype == torch.float32:
+            code = 1
+        else:
+            raise TypeError(f"crop_bboxes supports uint8 and float32 images, got {x.dtype}")
+        x = x.contiguous()
+        _b, Cc, H, W = x.shape
+        crops = torch.empty((n_valid, Cc, ch, cw), dtype=x.dtype, device=dev)
+        with torch.cuda.device(dev):
+            L.check(L.lib().ph_crop_bboxes(C.c_void_p(x.data_ptr()), code, B, Cc, H, W, C.c_void_p(sel["list_tl"].data_ptr()), C.c_void_p(sel["list_sample"].data_ptr()), n_valid,
+                                           ch, cw, C.c_void_p(crops.data_ptr()), L.current_stream_ptr()))
+        s2 = il.predict(crops)
+        k3 = s2.pred_keypoints.squeeze(1).contiguous()
+        v3 = s2.pred_peak_values.squeeze(1).contiguous()
+        n_nodes = int(k3.shape[-2])
+        full_k = torch.empty((B, I, n_nodes, 2), dtype=torch.float32, device=dev)
+        full_c = torch.empty((B, I, n_nodes, 2), dtype=torch.float32, device=dev)
+        full_v = torch.empty((B, I, n_nodes), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            L.check(L.lib().ph_topdown_scatter(C.c_void_p(k3.data_ptr()), C.c_void_p(v3.data_ptr()), C.c_void_p(sel["list_tl"].data_ptr()), C.c_void_p(sel["pos_of_slot"].data_ptr()),
+                                               B * I, n_nodes, C.c_void_p(full_k.data_ptr()), C.c_void_p(full_c.data_ptr()), C.c_void_p(full_v.data_ptr()), L.current_stream_ptr()))
+        out = Outputs(pred_keypoints=full_k, pred_crop_keypoints=full_c, pred_peak_values=full_v, pred_centroids=centroids, pred_centroid_values=cvals,
+                      instance_scores=cvals, preprocess_info=h["info"])
+        out.instance_bboxes = sel["bboxes"]
+        if s2.pred_class_probs is not None or self.return_crops:
+            slots = sel["list_slot"][:n_valid].long()
+            idx = torch.stack([slots // I, slots % I], dim=1)
+            self._attach_identity_and_crops(out, s2, idx, crops, B, I, n_nodes)
+        return out
+
+    def _predict_with_host_nms(self, x: torch.Tensor) -> Outputs:
+        """The path with centroid NMS (layers/topdown.py:395-438: host logic over the centroids of a frame): centroids -> host -> mask -> crops, as the reference walks it."""
+        cout = self.centroid_layer.predict(x)
         centroids, cvals = cout.pred_centroids, cout.pred_centroid_values
-        if centroids is None:
-            return Outputs()
         B, I, _ = centroids.shape
         dev = centroids.device
         valid = ~torch.isnan(centroids).any(dim=-1)
-        if self.centroid_nms:
-            valid = valid & self._centroid_nms_mask(centroids, cvals, valid)
+        valid = valid & self._centroid_nms_mask(centroids, cvals, valid)
         idx = valid.nonzero(as_tuple=False)
-        x = self.centroid_layer._to_4d_tensor(image).to(dev)
         n_valid = int(idx.shape[0])
         ch, cw = self.crop_size
         if n_valid == 0:
@@ -59,6 +120,12 @@ class TopDownLayer:
         out = Outputs(pred_keypoints=full_k, pred_crop_keypoints=full_c, pred_peak_values=full_v, pred_centroids=centroids, pred_centroid_values=cvals,
                       instance_scores=cvals, preprocess_info=cout.preprocess_info)
         out.instance_bboxes = full_b
+        self._attach_identity_and_crops(out, s2, idx, crops, B, I, n_nodes)
+        return out
+
+    def _attach_identity_and_crops(self, out: Outputs, s2: Outputs, idx: torch.Tensor, crops: torch.Tensor, B: int, I: int, n_nodes: int) -> None:
+        dev = idx.device
+        ch, cw = self.crop_size
         if s2.pred_class_probs is not None:
             # multi-class identity (layers/topdown.py:333-390): classify the crops of each frame on their own
             from sleap_nn_amd.inference.ops.identity import get_class_inds_from_vectors
@@ -81,7 +148,6 @@ class TopDownLayer:
             fc = torch.zeros((B, I, crops.shape[1], ch, cw), dtype=crops.dtype, device=dev)
             fc[idx[:, 0], idx[:, 1]] = crops
             out.crops = fc
-        return out
 
     def _centroid_nms_mask(self, centroids: torch.Tensor, centroid_vals: torch.Tensor, valid_mask: torch.Tensor) -> torch.Tensor:
         """Greedy NMS on the IoU of the crop boxes centred on each centroid (layers/topdown.py:395-438): per

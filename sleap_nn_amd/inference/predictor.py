@@ -78,9 +78,11 @@ def _select_layer(assets: Sequence[LoadedAssets], device: str, post: Postprocess
 
 
 class Predictor:
-    def __init__(self, layer, batch_size: int = 4) -> None:
+    def __init__(self, layer, batch_size: int = 4, use_graph: bool = True, window: int = 3) -> None:
         self.layer = layer  # any object exposing predict(image) -> Outputs (predictor.py:852-853)
         self.batch_size = batch_size
+        self.use_graph = use_graph  # pipelined paths replay the GPU stage of a batch as one hipGraph per input shape
+        self.window = window  # batches in flight ahead of the host stage
 
     @classmethod
     def from_model_paths(cls, model_paths: Sequence[str], device: str = "cuda", batch_size: int = 4, peak_threshold: float = 0.2,
@@ -102,6 +104,8 @@ class Predictor:
             frames = torch.from_numpy(frames)
         if pipelined and isinstance(self.layer, BottomUpLayer):
             return self._predict_streaming_pipelined(frames)
+        if pipelined and hasattr(self.layer, "_enqueue_stage1"):
+            return self._predict_two_stage_pipelined(frames)
         outs = []
         for s, batch in self._batch_iter(frames):
             o = self.layer.predict(batch)
@@ -109,34 +113,95 @@ class Predictor:
             outs.append(o)
         return outs
 
-    def _predict_streaming_pipelined(self, frames) -> List[Outputs]:
-        """predictor.py:2009-2074: GPU stage inline, CPU grouping in a worker with a bounded window."""
+    def _predict_two_stage_pipelined(self, frames) -> List[Outputs]:
+        """Top-down batches, software-pipelined over the one host read a batch needs (the per-frame centroid counts between the stages): stage 1 of batch i + 1 is
+        enqueued BEFORE the counts of batch i are waited for, so the GPU works through that wait."""
         layer = self.layer
-        params = layer.grouping_params()
+        dev = torch.device(layer.centroid_layer.backend.device)
+        stage = _PinnedRing(3) if not frames.is_cuda else None
+        outs: List[Outputs] = []
+        prev = None
+        for s, batch in self._batch_iter(frames):
+            n = len(batch)
+            if stage is not None and not batch.is_pinned():
+                batch = stage.put(batch)
+            h = layer._enqueue_stage1(batch.to(dev, non_blocking=True))
+            if stage is not None:
+                stage.mark(dev)
+            if prev is not None:
+                o = layer._finish(prev[2])
+                o.frame_indices = torch.arange(prev[0], prev[0] + prev[1])
+                outs.append(o)
+            prev = (s, n, h)
+        if prev is not None:
+            o = layer._finish(prev[2])
+            o.frame_indices = torch.arange(prev[0], prev[0] + prev[1])
+            outs.append(o)
+        return outs
+
+    def _predict_streaming_pipelined(self, frames) -> List[Outputs]:
+        """predictor.py:2009-2074: GPU stage inline, CPU grouping in a worker with a bounded window.
+
+        Per batch the main thread stages the frames (pinned ring -> asynchronous H2D), preprocesses them on the device and replays the layer's GPU stage as one
+        hipGraph (``BottomUpLayer._enqueue_scoring_graphed``: forward + peaks + candidate scoring, then one D2H + event); a worker thread waits for that event and
+        turns the packed arena into ``Outputs`` with one native call (``_finish_packed``: the ctypes call and the event wait release the GIL).  No host read of a
+        device value anywhere on the main thread: the GPU has the next batches queued while a batch is grouped."""
+        layer = self.layer
+        graphed = self.use_graph and hasattr(layer.backend, "model") and hasattr(layer, "_enqueue_scoring_graphed")
+        dev = torch.device(layer.backend.device)
         outs: List[Optional[Outputs]] = []
         pending = []
-        inflight = []  # batches whose GPU stage is enqueued but whose results have not been collected yet
+        stage = _PinnedRing(3) if not frames.is_cuda else None
 
-        def collect(pool):
-            s1, n1, h = inflight.pop(0)
-            pending.append((s1, n1, pool.submit(group_scored_batch, layer._finish_scoring(h), params)))
+        def finish(h):
+            return layer._finish_packed(h)
 
         with ThreadPoolExecutor(max_workers=1) as pool:
             for s, batch in self._batch_iter(frames):
-                x, info = layer.preprocess(batch)
-                raw = layer.backend(x)
-                inflight.append((s, len(batch), layer._enqueue_scoring(raw, info)))  # async D2H, no sync
-                if len(inflight) > 1:  # the GPU already has the next batch queued while this one's results are read
-                    collect(pool)
-                while len(pending) > 2:
+                if stage is not None and not batch.is_pinned():
+                    batch = stage.put(batch)
+                x, info = layer.preprocess(batch.to(dev, non_blocking=True))
+                if graphed:
+                    h = layer._enqueue_scoring_graphed(x, info)
+                else:
+                    h = layer._enqueue_scoring(layer.backend(x), info)  # async D2H, no sync
+                if stage is not None:
+                    stage.mark(dev)
+                pending.append((s, len(batch), pool.submit(finish, h)))
+                while len(pending) > self.window:  # bounded window: at most `window` batches enqueued ahead of the grouping
                     s0, n0, fut = pending.pop(0)
                     o = fut.result()
                     o.frame_indices = torch.arange(s0, s0 + n0)
                     outs.append(o)
-            while inflight:
-                collect(pool)
             for s0, n0, fut in pending:
                 o = fut.result()
                 o.frame_indices = torch.arange(s0, s0 + n0)
                 outs.append(o)
         return outs
+
+
+class _PinnedRing:
+    """A few pinned host buffers a batch is staged through on its way to the device (a pageable source makes the H2D copy synchronous and stream-ordered: the host
+    would wait for the previous batch's kernels).  A slot is reused only after the copy that read it has completed (an event per slot)."""
+
+    def __init__(self, n: int) -> None:
+        self.n, self.i = n, 0
+        self.bufs = [None] * n
+        self.events = [None] * n
+
+    def put(self, batch: torch.Tensor) -> torch.Tensor:
+        k = self.i % self.n
+        if self.events[k] is not None:
+            self.events[k].synchronize()
+        b = self.bufs[k]
+        if b is None or b.shape != batch.shape or b.dtype != batch.dtype:
+            b = self.bufs[k] = torch.empty(batch.shape, dtype=batch.dtype, pin_memory=True)
+        b.copy_(batch)
+        return b
+
+    def mark(self, dev) -> None:
+        k = self.i % self.n
+        if self.events[k] is None:
+            self.events[k] = torch.cuda.Event()
+        self.events[k].record(torch.cuda.current_stream(dev))
+        self.i += 1

@@ -798,6 +798,24 @@ def test_topdown_layer_reproduces_reference():
     assert np.allclose(ck, z["crop_peaks"], atol=1e-3, equal_nan=True)
     kimg = out.pred_keypoints.cpu().numpy()[idx[:, 0], idx[:, 1]]
     assert np.allclose(kimg, z["crop_peaks"] + z["bboxes"][:, 0][:, None, :], atol=1e-3, equal_nan=True)
+    assert np.allclose(out.instance_bboxes.cpu().numpy()[idx[:, 0], idx[:, 1]], z["bboxes"], atol=1e-3)
+    # the pipelined predictor (stage 1 of batch i + 1 enqueued before the counts of batch i are read) returns what predict returns, batch by batch;
+    # max_instances = None sizes the outputs by the counts it reads
+    from sleap_nn_amd.inference.predictor import Predictor
+
+    frames = img.reshape(-1, *img.shape[-3:])
+    frames = torch.cat([frames, frames.flip(-1), frames.flip(-2)], 0)
+    for bs in (1, 2):
+        outs = Predictor(td, batch_size=bs).predict(frames)
+        for s0, o in zip(range(0, frames.shape[0], bs), outs):
+            r = td.predict(frames[s0 : s0 + bs])
+            for f in ("pred_keypoints", "pred_crop_keypoints", "pred_peak_values", "pred_centroids", "pred_centroid_values", "instance_bboxes"):
+                assert np.array_equal(getattr(o, f).cpu().numpy(), getattr(r, f).cpu().numpy(), equal_nan=True), (bs, s0, f)
+    cl.postprocess_config = PostprocessConfig(peak_threshold=0.03)
+    cl.max_instances = None
+    o_none = td.predict(img)
+    n_max = int((~torch.isnan(out.pred_centroids[..., 0])).sum(1).max())
+    assert o_none.pred_centroids.shape[1] == n_max and np.array_equal(o_none.pred_keypoints.cpu().numpy(), out.pred_keypoints.cpu().numpy()[:, :n_max], equal_nan=True)
     assert np.allclose(out.pred_peak_values.cpu().numpy()[idx[:, 0], idx[:, 1]], z["crop_peak_vals"], atol=CMS_ATOL)
 
 

@@ -189,6 +189,109 @@ def test_published_workload_fixture_bottomup_batch4_320x560():
         assert np.isfinite(k).any()  # real detections, not an all-NaN agreement
 
 
+def test_pipelined_predictor_graphed_gpu_stage_equals_the_eager_layer():
+    """Predictor.predict on the published workload's run directory (batch 4, 320 x 560): the pipelined path -- pinned staging, forward + peaks + candidate scoring as ONE
+    hipGraph per shape, one D2H, ph_group_packed in the worker -- returns bit for bit what the layer's eager predict returns batch by batch; a ragged last batch (another
+    graph), frames already on the device, max_instances (truncation by score) and the capacity-overflow redo (capacities forced tiny) included; and the eager
+    pipelined form (use_graph=False) agrees too."""
+    from sleap_nn_amd.inference.layers import PostprocessConfig
+    from sleap_nn_amd.inference.predictor import Predictor
+
+    root = os.path.join(G.GOLDEN_DIR, "ckpt_dirs", "minimal_instance_bottomup")
+    z = G.load("ckpt_bottomup.npz")
+    two = torch.from_numpy(z["image"]).squeeze(1)
+    vid = torch.cat([two, two.flip(-1)], 0)[:, :, 32:352, :].repeat(4, 1, 1, 2)[..., :560].contiguous()[:14]  # 14 frames: batches of 4, 4, 4, 2
+    pred = Predictor.from_model_paths([root], device=DEV, batch_size=4, peak_threshold=0.2)
+    ref = pred.predict(vid, pipelined=False)
+    assert len(ref) == 4 and sum(int(torch.isfinite(o.instance_scores).sum()) for o in ref) >= 14
+
+    def same(outs, refs):
+        assert len(outs) == len(refs)
+        for o, r in zip(outs, refs):
+            assert torch.equal(o.frame_indices, r.frame_indices)
+            for f in ("pred_keypoints", "pred_peak_values", "instance_scores"):
+                a, b = getattr(o, f).numpy(), getattr(r, f).numpy()
+                assert a.shape == b.shape and np.array_equal(a, b, equal_nan=True), f
+
+    for _ in range(2):  # (second pass: replays only)
+        same(pred.predict(vid), ref)
+    same(pred.predict(vid.to(DEV)), ref)
+    same(pred.predict(vid.numpy()), ref)
+    pred.use_graph = False
+    same(pred.predict(vid), ref)
+    pred.use_graph = True
+    pred.layer.postprocess_config = PostprocessConfig(peak_threshold=0.2, max_instances=1)
+    ref1 = pred.predict(vid, pipelined=False)
+    assert ref1[0].pred_keypoints.shape[1] == 1
+    same(pred.predict(vid), ref1)
+    # capacity overflow: a fresh layer whose captured capacities are too small for the frames redoes the batch eagerly with larger ones -- same results
+    pred2 = Predictor.from_model_paths([root], device=DEV, batch_size=4, peak_threshold=0.2)
+    pred2.layer._capacities = lambda B, n, _l=pred2.layer: (max(_l._peak_cap, 2), max(_l._cand_cap, 1))
+    same(pred2.predict(vid), ref)
+    assert pred2.layer._peak_cap > 2
+
+
+def test_centroid_selection_kernel_topk_padding_and_lists():
+    """ph_centroid_select against the torch statement of CentroidLayer.postprocess / TopDownLayer's list building: frames with fewer peaks than max_instances (kept in order), with
+    more (torch.topk order, descending), with none; NaN padding, input-scale and eff_scale undo, boxes (make_centered_bboxes), stage-2 lists in nonzero order."""
+    import ctypes as C
+
+    from sleap_nn_amd.inference.ops.crops import make_centered_bboxes
+
+    rng = np.random.RandomState(0)
+    B, I, cap = 5, 4, 64
+    per = [0, 3, 9, 4, 1]
+    n = sum(per)
+    xy = torch.from_numpy(rng.rand(cap, 2).astype(np.float32) * 300)
+    vals = torch.from_numpy(rng.rand(cap).astype(np.float32))
+    offs = np.concatenate([[0], np.cumsum(per)]).astype(np.int32)
+    counts = torch.from_numpy(np.concatenate([[n], per, offs]).astype(np.int32))
+    eff = torch.tensor([1.0, 0.5, 2.0, 1.25, 1.0])
+    input_scale, ch, cw = 0.5, 48, 64
+    d = lambda t: t.to(DEV)
+    cp, cv = torch.empty((B, I, 2), device=DEV), torch.empty((B, I), device=DEV)
+    bb = torch.empty((B, I, 4, 2), device=DEV)
+    ls, lt, lslot, pos = (torch.full((B * I,), -7, dtype=torch.int32, device=DEV), torch.zeros((B * I, 2), device=DEV), torch.full((B * I,), -7, dtype=torch.int32, device=DEV),
+                          torch.full((B * I,), -7, dtype=torch.int32, device=DEV))
+    nv = torch.zeros(1, dtype=torch.int32, device=DEV)
+    xd, vd, cd, ed = d(xy), d(vals), d(counts), d(eff)
+    P = lambda t: C.c_void_p(t.data_ptr())
+    L.check(L.lib().ph_centroid_select(P(xd), P(vd), P(cd), B, I, cap, input_scale, P(ed), float(ch), float(cw), P(cp), P(cv), P(bb), P(ls), P(lt), P(lslot), P(pos), P(nv), None))
+    torch.cuda.synchronize()
+    ref_cp, ref_cv = torch.full((B, I, 2), float("nan")), torch.full((B, I), float("nan"))
+    for b in range(B):
+        p_, v_ = xy[offs[b] : offs[b + 1]] / input_scale, vals[offs[b] : offs[b + 1]]
+        if per[b] > I:
+            v_, idx = torch.topk(v_, I)
+            p_ = p_[idx]
+        k = min(per[b], I)
+        ref_cp[b, :k], ref_cv[b, :k] = p_[:k] / eff[b], v_[:k]
+    assert np.array_equal(cp.cpu().numpy(), ref_cp.numpy(), equal_nan=True) and np.array_equal(cv.cpu().numpy(), ref_cv.numpy(), equal_nan=True)
+    valid = ~torch.isnan(ref_cp).any(-1)
+    idx = valid.nonzero()
+    nvalid = int(idx.shape[0])
+    assert int(nv.item()) == nvalid == sum(min(c, I) for c in per)
+    ref_bb = make_centered_bboxes(ref_cp[idx[:, 0], idx[:, 1]], ch, cw)
+    assert np.array_equal(bb.cpu()[idx[:, 0], idx[:, 1]].numpy(), ref_bb.numpy()) and torch.isnan(bb.cpu()[~valid]).all()
+    assert torch.equal(ls.cpu()[:nvalid], idx[:, 0].int()) and torch.equal(lslot.cpu()[:nvalid], (idx[:, 0] * I + idx[:, 1]).int())
+    assert np.array_equal(lt.cpu()[:nvalid].numpy(), ref_bb[:, 0].numpy())
+    ref_pos = torch.full((B * I,), -1, dtype=torch.int32)
+    ref_pos[(idx[:, 0] * I + idx[:, 1])] = torch.arange(nvalid, dtype=torch.int32)
+    assert torch.equal(pos.cpu(), ref_pos)
+    # ... and the way back
+    N = 3
+    k3, v3 = torch.from_numpy(rng.rand(nvalid, N, 2).astype(np.float32) * 40), torch.from_numpy(rng.rand(nvalid, N).astype(np.float32))
+    fk, fc, fv = torch.empty((B * I, N, 2), device=DEV), torch.empty((B * I, N, 2), device=DEV), torch.empty((B * I, N), device=DEV)
+    k3d, v3d = d(k3), d(v3)
+    L.check(L.lib().ph_topdown_scatter(P(k3d), P(v3d), P(lt), P(pos), B * I, N, P(fk), P(fc), P(fv), None))
+    torch.cuda.synchronize()
+    rk, rc, rv = torch.full((B * I, N, 2), float("nan")), torch.full((B * I, N, 2), float("nan")), torch.full((B * I, N), float("nan"))
+    flat = idx[:, 0] * I + idx[:, 1]
+    rk[flat], rc[flat], rv[flat] = k3 + ref_bb[:, 0].view(-1, 1, 2), k3, v3
+    for got, want in ((fk, rk), (fc, rc), (fv, rv)):
+        assert np.array_equal(got.cpu().numpy(), want.numpy(), equal_nan=True)
+
+
 @pytest.mark.parametrize("filters,max_stride,hw,batch,out_stride", [(16, 4, (64, 96), 2, 1), (16, 8, (72, 40), 1, 1), (8, 8, (64, 48), 1, 2), (8, 4, (64, 80), 3, 2)])
 def test_wave_private_kernel_takes_the_two_source_decoder_conv(filters, max_stride, hw, batch, out_stride):
     """conv3x3_w16_kernel<CHUNKS, 1, TWO>: the full-resolution decoder level of an output-stride-1 filters-16 UNet -- concat(skip 16, up-sampled 32) -> 16 channels --

@@ -272,6 +272,93 @@ def test_group_batch_matches_reference_on_golden_candidates(name):
         assert np.isnan(kp[b, n_inst[b] :]).all()
 
 
+def _pack_arena(B, peak_cap, cand_cap, pk, pv, pc, po, ce, cs_, cd, sc, co):
+    """The D2H arena of BottomUpLayer's GPU stage, filled on the host: [counts 2+2B | cand offsets B+1 | xy 2P | vals P | score Q | channel P | edge Q | src Q | dst Q]."""
+    n_head = (2 + 2 * B) + (B + 1)
+    arena = np.full(n_head + 4 * peak_cap + 4 * cand_cap, np.float32(np.nan), dtype=np.float32)  # rows beyond the counts are undefined: poison them
+    ints = arena.view(np.int32)
+    n, q = len(pv), len(sc)
+    ints[0] = n
+    ints[1 : 1 + B] = np.diff(po)
+    ints[1 + B : 2 + 2 * B] = po
+    ints[2 + 2 * B : n_head] = co
+    o = n_head
+    arena[o : o + 2 * min(n, peak_cap)] = pk.reshape(-1)[: 2 * min(n, peak_cap)]
+    o += 2 * peak_cap
+    arena[o : o + min(n, peak_cap)] = pv[:peak_cap]
+    o += peak_cap
+    arena[o : o + min(q, cand_cap)] = sc[:cand_cap]
+    o += cand_cap
+    ints[o : o + min(n, peak_cap)] = pc[:peak_cap]
+    for k, a in enumerate((ce, cs_, cd)):
+        ints[o + peak_cap + k * cand_cap : o + peak_cap + k * cand_cap + min(q, cand_cap)] = a[:cand_cap]
+    return arena
+
+
+@pytest.mark.parametrize("name", ["chain5", "tree6", "chain13", "rev4"])
+def test_group_packed_equals_the_unpack_and_group_pair(name):
+    """ph_group_packed (the one-call CPU stage of the pipelined predictor) against _finish_scoring's unpacking + group_scored_batch on the reference's golden candidates:
+    max_instances None and set (truncation by score), input scale and per-frame eff_scale undo, the max_peaks_per_node guard, and the two come-back statuses
+    (arena capacity exceeded, output rows too few)."""
+    from sleap_nn_amd.inference.preprocess_info import PreprocInfo
+    from sleap_nn_amd.inference.streaming import GroupingParams, ScoredBatch, group_scored_batch
+
+    z = G.load("paf.npz")
+    meta = json.loads(str(z["meta_json"]))["specs"][name]
+    edges = [tuple(e) for e in meta["edges"]]
+    n_nodes = meta["n_nodes"]
+    names = [str(i) for i in range(n_nodes)]
+    pk, pv, pc = _flat(G.ragged(z, f"{name}/peaks"), np.float32, 2), _flat(G.ragged(z, f"{name}/vals"), np.float32), _flat(G.ragged(z, f"{name}/chans"), np.int32)
+    ce, cs_ = _flat(G.ragged(z, f"{name}/edge_inds"), np.int32), _flat(G.ragged(z, f"{name}/line_scores"), np.float32)
+    pairs = _flat(G.ragged(z, f"{name}/edge_peak_inds"), np.int32, 2)
+    B = len(G.ragged(z, f"{name}/peaks"))
+    po = np.concatenate([[0], np.cumsum([len(a) for a in G.ragged(z, f"{name}/peaks")])]).astype(np.int32)
+    co = np.concatenate([[0], np.cumsum([len(a) for a in G.ragged(z, f"{name}/edge_inds")])]).astype(np.int32)
+    e32 = np.ascontiguousarray(np.asarray(edges, dtype=np.int32).reshape(-1, 2))
+    peak_cap, cand_cap = len(pv) + 7, len(cs_) + 5
+    arena = _pack_arena(B, peak_cap, cand_cap, pk, pv, pc, po, ce, pairs[:, 0], pairs[:, 1], cs_, co)
+    p = lambda a: ctypes.c_void_p(a.ctypes.data)
+
+    def packed(max_instances, input_scale, eff, out_cap, max_ppn=-1, arena_=arena, caps=(peak_cap, cand_cap)):
+        kp = np.empty((B, out_cap, n_nodes, 2), np.float32)
+        vals = np.empty((B, out_cap, n_nodes), np.float32)
+        scores = np.empty((B, out_cap), np.float32)
+        n_inst = np.zeros(B, np.int32)
+        status = np.zeros(4, np.int32)
+        L.check(L.lib().ph_group_packed(p(arena_), B, n_nodes, caps[0], caps[1], p(e32), len(edges), 0.25, 0.0, 0, -1 if max_instances is None else max_instances, max_ppn,
+                                        input_scale, p(eff), out_cap, p(kp), p(vals), p(scores), p(n_inst), p(status)))
+        return kp, vals, scores, n_inst, status
+
+    for max_instances, input_scale, eff in ((None, 1.0, np.ones(B, np.float32)), (2, 0.5, np.ones(B, np.float32)), (None, 1.0, np.linspace(0.5, 1.5, B).astype(np.float32)),
+                                           (1, 0.75, np.linspace(0.5, 1.5, B).astype(np.float32))):
+        info = PreprocInfo(eff_scale=torch.from_numpy(eff.copy()), input_scale=input_scale)
+        scored = ScoredBatch(peaks_xy=pk, peak_vals=pv, peak_channel=pc, peak_offsets=po, cand_edge=ce, cand_src=pairs[:, 0].copy(), cand_dst=pairs[:, 1].copy(), cand_score=cs_,
+                             cand_offsets=co, info=info, n_samples=B, n_nodes=n_nodes)
+        params = GroupingParams(paf_scorer_kwargs={"part_names": names, "edges": [(names[a], names[b]) for a, b in edges], "pafs_stride": 4}, max_instances=max_instances)
+        ref = group_scored_batch(scored, params)
+        out_cap = max_instances if max_instances is not None else int(np.diff(po).max())
+        kp, vals, scores, n_inst, status = packed(max_instances, input_scale, eff, out_cap)
+        assert status[0] == len(pv) and status[1] == len(cs_) and status[2] == 0
+        mi = int(status[3])
+        assert tuple(ref.pred_keypoints.shape) == (B, mi, n_nodes, 2)
+        assert np.array_equal(kp[:, :mi], ref.pred_keypoints.numpy(), equal_nan=True)
+        assert np.array_equal(vals[:, :mi], ref.pred_peak_values.numpy(), equal_nan=True)
+        assert np.array_equal(scores[:, :mi], ref.instance_scores.numpy(), equal_nan=True)
+    ones = np.ones(B, np.float32)
+    # too few output rows for max_instances = None: nothing grouped, the capacity to come back with
+    st = packed(None, 1.0, ones, 1)[4]
+    assert (st[2] & 2) and st[3] == max(1, int(np.diff(po).max()))
+    # an arena whose capacities the counts exceed
+    small = _pack_arena(B, 2, 3, pk, pv, pc, po, ce, pairs[:, 0], pairs[:, 1], cs_, co)
+    st = packed(None, 1.0, ones, 8, arena_=small, caps=(2, 3))[4]
+    assert (st[2] & 1) and st[0] == len(pv) and st[1] == len(cs_)
+    # the max_peaks_per_node guard: a frame with more peaks of one node than allowed -> a batch of NaNs
+    most = max(int(np.bincount(pc[po[b] : po[b + 1]], minlength=n_nodes).max()) for b in range(B))
+    kp, vals, scores, n_inst, st = packed(None, 1.0, ones, 4, max_ppn=most - 1)
+    assert (st[2] & 4) and st[3] == 1 and np.isnan(kp).all() and np.isnan(scores).all()
+    assert packed(None, 1.0, ones, int(np.diff(po).max()), max_ppn=most)[4][2] == 0
+
+
 def test_group_batch_matches_oracle_on_random_graphs():
     """Randomised differential test vs the oracle (ties, low scores, merges, min_instance_peaks)."""
     rng = np.random.RandomState(3)
