@@ -1139,9 +1139,9 @@ def published_workload_leg(steps, dev):
     two = torch.from_numpy(z["image"]).squeeze(1)
     vid = torch.cat([two, two.flip(-1)], 0)[:, :, 32:352, :].repeat(25, 1, 1, 2)[..., :560].contiguous()  # (100, 1, 320, 560) uint8, host
     pred = Predictor.from_model_paths([root], device=str(dev), batch_size=4, peak_threshold=0.2)
-    pred.predict(vid[:16])
+    pred.predict(vid)  # (untimed: graph capture of the batch shape, pinned buffers, the host-stage worker)
     torch.cuda.synchronize()
-    reps, t0 = 5, time.perf_counter()
+    reps, t0 = 10, time.perf_counter()
     n_inst = 0
     for _ in range(reps):
         outs = pred.predict(vid)
@@ -1162,7 +1162,7 @@ def published_workload_leg(steps, dev):
             si.setdefault("forward_ms_per_batch", {})[tag] = 1e3 * tot / n
         si_model.set_precision("exact")
         sp = Predictor.from_model_paths([si_root], device=str(dev), batch_size=4, peak_threshold=0.2)
-        sp.predict(vid[:16])
+        sp.predict(vid)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for _ in range(reps):
@@ -1202,11 +1202,23 @@ def published_workload_leg(steps, dev):
         td["centroid_forward_ms_per_batch"] = 1e3 * tot / n
         tout = tdl.predict(tframes)
         tot, _ = _time_calls(lambda: tdl.predict(tframes), 100, 10, False)
-        td["end_to_end_ms_per_batch"] = 1e3 * tot / 100
-        td["end_to_end_fps"] = 4 * 100 / tot
+        td["layer_predict_ms_per_batch"] = 1e3 * tot / 100
+        td["layer_predict_fps"] = 4 * 100 / tot
         td["instances_per_batch"] = int(torch.isfinite(tout.pred_centroids[..., 0]).sum())
+        # end to end as for the bottom-up model: Predictor.predict over 100 uint8 frames in host memory, batch 4 (stage 1 of batch i + 1 enqueued before the one host read of batch i)
+        tvid = tframes.cpu().repeat(25, 1, 1, 1).contiguous()
+        tp = Predictor(tdl, batch_size=4)
+        tp.predict(tvid)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        for _ in range(reps):
+            touts = tp.predict(tvid)
+            touts[-1].pred_keypoints.cpu()
+        tot = time.perf_counter() - t2
+        td["end_to_end_ms_per_batch"] = 1e3 * tot / (reps * 25)
+        td["end_to_end_fps"] = reps * tvid.shape[0] / tot
         td["vs_baseline"] = {"centroid_forward_eager_fp32": ref["centroid_forward_ms_per_batch4"]["eager_fp32"] / td["centroid_forward_ms_per_batch"], "end_to_end_fps": td["end_to_end_fps"] / ref["topdown_end_to_end_fps"]}
-        td["what"] = f"fixture top-down models (tests/golden/topdown.npz): {tuple(tframes.shape)} uint8 frames resident in HBM, centroid forward (hipGraph) and TopDownLayer.predict (centroid -> NMS peaks -> {tcfg['crop_size']} x {tcfg['crop_size']} crops -> centered-instance forward -> global peaks; three data-dependent host reads per batch)"
+        td["what"] = f"fixture top-down models (tests/golden/topdown.npz): {tuple(tframes.shape)} uint8 frames resident in HBM, centroid forward (hipGraph) and TopDownLayer.predict (centroid -> NMS peaks -> device-side selection -> {tcfg['crop_size']} x {tcfg['crop_size']} crops -> centered-instance forward -> global peaks -> scatter; ONE host read per batch: the per-frame centroid counts); end_to_end = Predictor.predict over 100 host frames, pipelined over that read"
     except Exception as e:
         td = {"error": repr(e)}
     return {"metric": "ms per batch of 4, bottom-up backbone forward (the reference's published table)", "value": fwd["exact_fp32"], "unit": "ms/batch", "higher_is_better": False, "steps": max(steps, 200),
@@ -1215,7 +1227,7 @@ def published_workload_leg(steps, dev):
                        "params": model.num_parameters(), "forward_launch": "hipGraph replay, back to back"},
             "forward_ms_per_batch": fwd, "frames_per_s_forward": 4.0 / fwd_s,
             "end_to_end": {"value": e2e, "unit": "frames/s", "frames": int(vid.shape[0]), "repeats": reps, "instances_found_per_pass": n_inst,
-                           "what": "Predictor.predict (pipelined: H2D, forward, peaks, PAF scoring, D2H, C++ grouping) over 100 uint8 frames in host memory, batch 4, exact fp32"},
+                           "what": "Predictor.predict (pipelined: pinned staging + H2D, forward + peaks + PAF scoring as one hipGraph, D2H, one-call C++ grouping in a worker) over 100 uint8 frames in host memory, batch 4, exact fp32"},
             "vs_baseline": {"forward_eager_fp32": ref["bottomup_forward_ms_per_batch4"]["eager_fp32"] / fwd["exact_fp32"], "forward_fp16": ref["bottomup_forward_ms_per_batch4"]["fp16_autocast"] / fwd["fp16_autocast_equivalent"],
                             "end_to_end_fps": e2e / ref["bottomup_end_to_end_fps"], "reference": ref, "reference_hardware": "NVIDIA A40, CUDA 12.8, torch 2.9.1 (docs/guides/inference-performance.md:3-7,40-48,70-77)",
                             "note": "ratios > 1 = this build faster; different hardware and (end to end) no video decoding here: a like-for-like of the workload, not of the machine"},

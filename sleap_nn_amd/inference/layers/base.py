@@ -116,7 +116,8 @@ class InferenceLayer(ABC):
                 graphs.clear()
                 self.__dict__["_step_graph_generation"] = be.model.generation
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            # (thread_local: a host-stage worker thread of the pipelined predictor may wait on an event or recycle a pinned buffer while this thread captures)
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                 out = body(be.model.forward(static_in.squeeze(1), in_dtype=code), info)
             assert be.model.generation == self.__dict__["_step_graph_generation"], "capture must not reallocate"
             entry = (graph, static_in, out, be.model._workspace)
@@ -183,14 +184,10 @@ class InferenceLayer(ABC):
         if sized and (cfg.max_height is None or cfg.max_height == x.shape[-2]) and (cfg.max_width is None or cfg.max_width == x.shape[-1]):
             sized = False  # every frame already has the target size: apply_sizematcher would hand each back untouched with scale 1 -- no per-sample loop, no re-stacking of the batch on the host
         if sized:
-            frames, effs = [], []
-            for b in range(B):  # per sample, as the reference does (frames of one batch share a size here, the loop keeps its contract)
-                r, e = apply_sizematcher(x[b], cfg.max_height, cfg.max_width)
-                frames.append(r)
-                effs.append(float(e))
-            dev = next((f.device for f in frames if f.is_cuda), frames[0].device)
-            x = torch.stack([f.to(dev) for f in frames], dim=0)
-            eff_scale = torch.tensor(effs, dtype=torch.float32)
+            # the reference walks the samples (resizing.py:136-175 per frame); the frames of one batch share a size, so the resize + pad of each is the same call on
+            # its planes: ONE resize launch and ONE pad for the batch, one eff_scale value repeated
+            x, e = apply_sizematcher(x, cfg.max_height, cfg.max_width)
+            eff_scale = torch.full((B,), float(e), dtype=torch.float32)
         else:
             eff_scale = torch.ones(B, dtype=torch.float32)
         if cfg.scale != 1.0:

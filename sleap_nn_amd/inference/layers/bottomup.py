@@ -7,6 +7,7 @@ packed result arena to pinned host memory, synchronises once, and hands a flatte
 """
 from __future__ import annotations
 
+import threading
 from typing import Optional
 
 import numpy as np
@@ -34,6 +35,7 @@ class BottomUpLayer(InferenceLayer):
         self.max_peaks_per_node = max_peaks_per_node
         self._peak_cap = 0
         self._cand_cap = 0
+        self._gpu_lock = threading.RLock()
 
     # -- GPU stage ------------------------------------------------------------------------
     def _capacities(self, B: int, n_nodes: int):
@@ -107,28 +109,31 @@ class BottomUpLayer(InferenceLayer):
         x, code = be.input_code(x)
         B = int(x.shape[0])
         n_nodes = self.paf_scorer.n_nodes
-        peak_cap, cand_cap = self._capacities(B, n_nodes)
-        keep = {}
+        with self._gpu_lock:  # (a worker redoing an overflowed batch issues GPU work too: never while this thread captures or replays)
+            peak_cap, cand_cap = self._capacities(B, n_nodes)
 
-        def body(raw, _info):
-            keep["raw"] = raw
-            return self._scoring_launches(raw, peak_cap, cand_cap)
+            def body(raw, _info):
+                return self._scoring_launches(raw, peak_cap, cand_cap)
 
-        graph, static_in, packed, _ws = self._graph_entry(x, info, code, body=body, extra_key=("gpu stage", int(peak_cap), int(cand_cap), self.cms_output_stride))
-        if x.data_ptr() != static_in.data_ptr():
-            static_in.copy_(x, non_blocking=True)
-        graph.replay()
-        buf, key, ev = self._to_host_async(packed)
+            graph, static_in, packed, _ws = self._graph_entry(x, info, code, body=body, extra_key=("gpu stage", int(peak_cap), int(cand_cap), self.cms_output_stride))
+            if x.data_ptr() != static_in.data_ptr():
+                static_in.copy_(x, non_blocking=True)
+            graph.replay()
+            buf, key, ev = self._to_host_async(packed)
         return {"buf": buf, "key": key, "event": ev, "B": B, "n_nodes": n_nodes, "peak_cap": int(peak_cap), "cand_cap": int(cand_cap), "n_head": int((2 + 2 * B) + (B + 1)),
                 "raw": None, "x": x, "code": code, "info": info, "keep": packed}
 
     def _redo_eagerly(self, h: dict) -> dict:
-        """A handle whose capacities were exceeded: the GPU stage again, kernel by kernel, with capacities grown from the counts it reported."""
-        raw = h["raw"]
-        if raw is None:  # a graphed handle holds no head tensors (the graph's static ones have been overwritten since): run the forward again
-            raw = self.backend.model.forward(h["x"].squeeze(1) if h["x"].dim() == 5 else h["x"], in_dtype=h["code"])
-        self._pinned[h["key"]] = []
-        return self._enqueue_scoring(raw, h["info"])
+        """A handle whose capacities were exceeded (or whose maps are wanted back): the GPU stage again, kernel by kernel, with capacities grown from the counts it reported.
+        May run on the host-stage worker thread: serialised against the enqueueing thread's captures / replays by ``_gpu_lock``, and complete (synchronised) on return."""
+        with self._gpu_lock:
+            raw = h["raw"]
+            if raw is None:  # a graphed handle holds no head tensors (the graph's static ones have been overwritten since): run the forward again
+                raw = self.backend.model.forward(h["x"].squeeze(1) if h["x"].dim() == 5 else h["x"], in_dtype=h["code"])
+            self._pinned[h["key"]] = []
+            h2 = self._enqueue_scoring(raw, h["info"])
+            h2["event"].synchronize()
+        return h2
 
     def _finish_packed(self, h: dict) -> Outputs:
         """Handle -> ``Outputs`` through ONE native call (``ph_group_packed``: unpack, capacity check, max_peaks_per_node guard, matching + assembly, scale undo, NaN pad) --

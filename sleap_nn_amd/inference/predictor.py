@@ -93,6 +93,12 @@ class Predictor:
                                  max_instances=max_instances, return_confmaps=return_confmaps)
         return cls(_select_layer(assets, device, post, max_instances, **paf_kw), batch_size)
 
+    def _staging(self) -> "_PinnedRing":
+        ring = self.__dict__.get("_ring")
+        if ring is None:
+            ring = self.__dict__["_ring"] = _PinnedRing(self.window + 1)
+        return ring
+
     def _batch_iter(self, frames) -> Iterator:
         n = len(frames)
         for s in range(0, n, self.batch_size):
@@ -118,16 +124,15 @@ class Predictor:
         enqueued BEFORE the counts of batch i are waited for, so the GPU works through that wait."""
         layer = self.layer
         dev = torch.device(layer.centroid_layer.backend.device)
-        stage = _PinnedRing(3) if not frames.is_cuda else None
+        stage = self._staging() if not frames.is_cuda else None
         outs: List[Outputs] = []
         prev = None
         for s, batch in self._batch_iter(frames):
             n = len(batch)
             if stage is not None and not batch.is_pinned():
-                batch = stage.put(batch)
-            h = layer._enqueue_stage1(batch.to(dev, non_blocking=True))
-            if stage is not None:
+                batch = stage.put(batch).to(dev, non_blocking=True)
                 stage.mark(dev)
+            h = layer._enqueue_stage1(batch.to(dev, non_blocking=True))
             if prev is not None:
                 o = layer._finish(prev[2])
                 o.frame_indices = torch.arange(prev[0], prev[0] + prev[1])
@@ -151,32 +156,36 @@ class Predictor:
         dev = torch.device(layer.backend.device)
         outs: List[Optional[Outputs]] = []
         pending = []
-        stage = _PinnedRing(3) if not frames.is_cuda else None
+        stage = self._staging() if not frames.is_cuda else None
 
         def finish(h):
             return layer._finish_packed(h)
 
-        with ThreadPoolExecutor(max_workers=1) as pool:
-            for s, batch in self._batch_iter(frames):
-                if stage is not None and not batch.is_pinned():
-                    batch = stage.put(batch)
-                x, info = layer.preprocess(batch.to(dev, non_blocking=True))
-                if graphed:
-                    h = layer._enqueue_scoring_graphed(x, info)
-                else:
-                    h = layer._enqueue_scoring(layer.backend(x), info)  # async D2H, no sync
-                if stage is not None:
-                    stage.mark(dev)
-                pending.append((s, len(batch), pool.submit(finish, h)))
-                while len(pending) > self.window:  # bounded window: at most `window` batches enqueued ahead of the grouping
-                    s0, n0, fut = pending.pop(0)
-                    o = fut.result()
-                    o.frame_indices = torch.arange(s0, s0 + n0)
-                    outs.append(o)
-            for s0, n0, fut in pending:
+        pool = self.__dict__.get("_pool")
+        if pool is None:  # one host-stage worker for the predictor's lifetime (a thread start and the first pinned allocations cost milliseconds: not per call)
+            pool = self.__dict__["_pool"] = ThreadPoolExecutor(max_workers=1, thread_name_prefix="posehip-host-stage")
+        for s, batch in self._batch_iter(frames):
+            n = len(batch)
+            if stage is not None and not batch.is_pinned():
+                batch = stage.put(batch).to(dev, non_blocking=True)
+                stage.mark(dev)  # (the slot is free again as soon as this copy has run)
+            else:
+                batch = batch.to(dev, non_blocking=True)
+            x, info = layer.preprocess(batch)
+            if graphed:
+                h = layer._enqueue_scoring_graphed(x, info)
+            else:
+                h = layer._enqueue_scoring(layer.backend(x), info)  # async D2H, no sync
+            pending.append((s, n, pool.submit(finish, h)))
+            while len(pending) > self.window:  # bounded window: at most `window` batches enqueued ahead of the grouping
+                s0, n0, fut = pending.pop(0)
                 o = fut.result()
                 o.frame_indices = torch.arange(s0, s0 + n0)
                 outs.append(o)
+        for s0, n0, fut in pending:
+            o = fut.result()
+            o.frame_indices = torch.arange(s0, s0 + n0)
+            outs.append(o)
         return outs
 
 
@@ -196,7 +205,10 @@ class _PinnedRing:
         b = self.bufs[k]
         if b is None or b.shape != batch.shape or b.dtype != batch.dtype:
             b = self.bufs[k] = torch.empty(batch.shape, dtype=batch.dtype, pin_memory=True)
-        b.copy_(batch)
+        if batch.is_contiguous():  # one memcpy on this thread (Tensor.copy_ fans a 700-KB copy out over the intra-op pool: milliseconds when that pool is cold or contended)
+            np.copyto(b.numpy(), batch.numpy())
+        else:
+            b.copy_(batch)
         return b
 
     def mark(self, dev) -> None:
