@@ -250,7 +250,7 @@ def contract_line(full: dict, legs_file: str | None = None) -> str:
     line = {k: (_num(full[k], 6) if isinstance(full.get(k), float) else full.get(k)) for k in keep if k in full}
     cfg = full.get("config", {})
     line["config"] = {k: cfg[k] for k in ("workload", "frames_per_gpu_per_step", "global_batch", "parallelism", "inputs", "forward_launch", "rccl_ranks_seen",
-                                          "frames_per_step_by_rank", "params", "crops_per_gpu_per_step") if k in cfg}
+                                          "frames_per_step_by_rank", "params", "crops_per_gpu_per_step", "samples_per_gpu_per_step") if k in cfg}
     if isinstance(cfg.get("conv_gflop_per_frame"), float):
         line["config"]["conv_gflop_per_frame"] = _num(cfg["conv_gflop_per_frame"])
     if isinstance(full.get("step_ms"), dict):

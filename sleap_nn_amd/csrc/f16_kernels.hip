@@ -557,32 +557,54 @@ __global__ __launch_bounds__(256) void head1x1_mfma_kernel(const void* __restric
       ok[n] = pix[n] < npix;
       pix[n] = ok[n] ? pix[n] : npix - 1;
     }
-    for (int g = 0; g < wcp / 8; ++g) {
-      f32x4 xb[2];
+    // K in chunks of four groups = 32 channels = ONE 128-byte line per pixel (fp32): the eight loads of a chunk (two pixels per lane) are issued together, one chunk ahead of
+    // the MFMAs that read them.  (One load per group and pixel, each waited for before its four MFMAs, left a wave with one request in flight: the launch ran at the memory
+    // LATENCY -- 0.10 ms for cfg3's PAF head -- and every line was fetched four times, 16 bytes per visit, from whatever level still held it.)
+    const int n_g = wcp / 8;
+    auto load_chunk = [&](int g0, f32x4 (&dst)[4][2]) __attribute__((always_inline)) {
 #pragma unroll
-      for (int n = 0; n < 2; ++n) {
-        const int c0 = 8 * g + 4 * lh;
-        if constexpr (FMT == FMT_F32) {
-          xb[n] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(src) + pix[n] * cp + c0);
-        } else if constexpr (FMT == FMT_SPLIT) {
-          const char* p = reinterpret_cast<const char*>(src) + (pix[n] * cp + (size_t)(c0 >> 4) * 16) * 4 + ((c0 >> 3) & 1) * 16 + (c0 & 7) * 2;
-          const f16x4 hi = *reinterpret_cast<const f16x4*>(p), lo = *reinterpret_cast<const f16x4*>(p + 32);
+      for (int gi = 0; gi < 4; ++gi)
 #pragma unroll
-          for (int k = 0; k < 4; ++k) xb[n][k] = (float)hi[k] + (float)lo[k] * SPLIT_INV;
-        } else {
-          const f16x4 h = *reinterpret_cast<const f16x4*>(reinterpret_cast<const char*>(src) + (pix[n] * cp + c0) * 2);
+        for (int n = 0; n < 2; ++n) {
+          const int g = min(g0 + gi, n_g - 1);  // (a chunk past the end re-reads the last group: its MFMAs are skipped)
+          const int c0 = 8 * g + 4 * lh;
+          if constexpr (FMT == FMT_F32) {
+            dst[gi][n] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(src) + pix[n] * cp + c0);
+          } else if constexpr (FMT == FMT_SPLIT) {
+            const char* p = reinterpret_cast<const char*>(src) + (pix[n] * cp + (size_t)(c0 >> 4) * 16) * 4 + ((c0 >> 3) & 1) * 16 + (c0 & 7) * 2;
+            const f16x4 hi = *reinterpret_cast<const f16x4*>(p), lo = *reinterpret_cast<const f16x4*>(p + 32);
 #pragma unroll
-          for (int k = 0; k < 4; ++k) xb[n][k] = (float)h[k];
+            for (int k = 0; k < 4; ++k) dst[gi][n][k] = (float)hi[k] + (float)lo[k] * SPLIT_INV;
+          } else {
+            const f16x4 h = *reinterpret_cast<const f16x4*>(reinterpret_cast<const char*>(src) + (pix[n] * cp + c0) * 2);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) dst[gi][n][k] = (float)h[k];
+          }
+        }
+    };
+    auto mfma_chunk = [&](int g0, const f32x4 (&xb)[4][2]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int gi = 0; gi < 4; ++gi) {
+        const int g = g0 + gi;
+        if (g < n_g) {  // (wave-uniform)
+#pragma unroll
+          for (int m = 0; m < MT; ++m) {
+            const f32x4 wa = *reinterpret_cast<const f32x4*>(lds + (m * 32 + lx) * ldw + 8 * g + 4 * lh);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+              for (int n = 0; n < 2; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[j], xb[gi][n][j], acc[m][n], 0, 0, 0);
+          }
         }
       }
-#pragma unroll
-      for (int m = 0; m < MT; ++m) {
-        const f32x4 wa = *reinterpret_cast<const f32x4*>(lds + (m * 32 + lx) * ldw + 8 * g + 4 * lh);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int n = 0; n < 2; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[j], xb[n][j], acc[m][n], 0, 0, 0);
-      }
+    };
+    f32x4 xa[4][2], xc[4][2];
+    load_chunk(0, xa);
+    for (int g0 = 0; g0 < n_g; g0 += 8) {
+      if (g0 + 4 < n_g) load_chunk(g0 + 4, xc);
+      mfma_chunk(g0, xa);
+      if (g0 + 8 < n_g) load_chunk(g0 + 8, xa);
+      if (g0 + 4 < n_g) mfma_chunk(g0 + 4, xc);
     }
 #pragma unroll
     for (int n = 0; n < 2; ++n) {

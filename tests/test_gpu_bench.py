@@ -14,33 +14,39 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _run(*args):
+    """(contract line, full record): stdout must END with exactly one strict-JSON line of at most 4 KB from rank 0; the legs file holds everything else."""
+    import tempfile
+
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stderr[-2000:]
-    lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
-    assert len(lines) == 1, r.stdout[-1000:]  # exactly one line, from rank 0
-    return json.loads(lines[0])
+    with tempfile.TemporaryDirectory() as tmp:
+        legs = os.path.join(tmp, "legs.json")
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args, "--legs-file", legs], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+        assert len(lines) == 1 and r.stdout.rstrip().endswith(lines[0]), r.stdout[-1000:]  # exactly one line, from rank 0, and the last thing on stdout
+        assert len(lines[0].encode()) < 4096
+        return json.loads(lines[0]), json.load(open(legs))
 
 
 @pytest.mark.skipif(not torch.cuda.is_available(), reason="needs a GPU")
 def test_two_ranks_default_strong_with_weak_beside_it_and_three_ranks_strong_rehearsal():
     # N > 1 with no --scaling flag: `value` is BASELINE cfg3 as written (global batch split over the ranks), the weak figure rides along
-    d = _run("--gpus", "2", "--rehearse-on-one-gpu", "--steps", "3", "--warmup", "1", "--batch", "4", "--global-batch", "8", "--no-alt-precisions", "--no-h2d-leg")
+    d, full = _run("--gpus", "2", "--rehearse-on-one-gpu", "--steps", "3", "--warmup", "1", "--batch", "4", "--global-batch", "8", "--no-alt-precisions", "--no-h2d-leg")
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["steps"] == 3 and d["warmup"] == 1
     assert d["config"]["frames_per_gpu_per_step"] == 4 and d["config"]["global_batch"] == 8
     assert d["value"] > 0 and abs(d["value"] - 8 * 3 / (d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]  # whole-job frames / max-over-ranks time
-    w = d["weak_scaling"]
-    assert w["frames_per_gpu_per_step"] == 4 and w["global_batch"] == 8 and w["value"] > 0
-    assert "cpu_baseline" not in d and "train_cfg3" not in d and "REHEARSAL" in d["data"]  # the CPU leg and the extra legs belong to N = 1
+    w = full["weak_scaling"]
+    assert w["frames_per_gpu_per_step"] == 4 and w["global_batch"] == 8 and w["value"] > 0 and d["legs_summary"]["weak_scaling_frames_per_s"] == pytest.approx(w["value"], rel=1e-3)
+    assert "cpu_baseline" not in d and "train_cfg3" not in full and "REHEARSAL" in d["data"]  # the CPU leg and the extra legs belong to N = 1
     assert d["config"]["rccl_ranks_seen"] == 2 and d["config"]["frames_per_step_by_rank"] == [4, 4]  # every rank joined the collective and took its contiguous chunk of the global batch
-    ht = d["config"]["host_threads"]
+    ht = full["config"]["host_threads"]
     assert ht["ranks"] == 2 and ht["per_rank"] == 2 and ht["fits"] == (4 <= ht["cores_visible"])
     # the driver's SCALE run puts 8 ranks on one host: enqueue thread + grouping worker per rank must fit its cores (16 on the 8-GPU box: 8 x 2)
     assert 2 * 8 <= max(ht["cores_visible"], 16)
     assert d["roofline"]["kernel"].startswith("conv3x3_wino") and 0 < d["roofline"]["frac"] < 1
-    d = _run("--gpus", "2", "--rehearse-on-one-gpu", "--steps", "2", "--warmup", "1", "--batch", "4", "--scaling", "weak", "--no-alt-precisions", "--no-h2d-leg")
-    assert d["scaling"] == "weak" and d["config"]["global_batch"] == 8 and "weak_scaling" not in d
-    d = _run("--gpus", "3", "--rehearse-on-one-gpu", "--steps", "2", "--warmup", "1", "--scaling", "strong", "--global-batch", "8", "--no-alt-precisions", "--no-h2d-leg")
+    d, full = _run("--gpus", "2", "--rehearse-on-one-gpu", "--steps", "2", "--warmup", "1", "--batch", "4", "--scaling", "weak", "--no-alt-precisions", "--no-h2d-leg")
+    assert d["scaling"] == "weak" and d["config"]["global_batch"] == 8 and "weak_scaling" not in full
+    d, full = _run("--gpus", "3", "--rehearse-on-one-gpu", "--steps", "2", "--warmup", "1", "--scaling", "strong", "--global-batch", "8", "--no-alt-precisions", "--no-h2d-leg")
     assert d["n_gpus"] == 3 and d["scaling"] == "strong" and d["config"]["global_batch"] == 8
     assert d["config"]["frames_per_gpu_per_step"] in (2, 3)  # rank 0's contiguous chunk of 8 frames over 3 ranks
 
@@ -49,9 +55,9 @@ def test_two_ranks_default_strong_with_weak_beside_it_and_three_ranks_strong_reh
 def test_two_ranks_training_rehearsal():
     """--mode train with two ranks: identical initial arenas, disjoint shards, the two-bucket gradient all-reduce overlapped with the
     backward (gloo here), Adam on every rank -- the loss must be finite and move, the line must say what it measured."""
-    d = _run("--gpus", "2", "--rehearse-on-one-gpu", "--mode", "train", "--steps", "3", "--warmup", "1", "--batch", "2")
-    assert d["n_gpus"] == 2 and d["config"]["samples_per_gpu_per_step"] == 2 and d["config"]["global_batch"] == 4
-    first, last = d["loss_first_last"]
+    d, full = _run("--gpus", "2", "--rehearse-on-one-gpu", "--mode", "train", "--steps", "3", "--warmup", "1", "--batch", "2")
+    assert d["n_gpus"] == 2 and full["config"]["samples_per_gpu_per_step"] == 2 and d["config"]["global_batch"] == 4
+    first, last = full["loss_first_last"]
     assert first > 0 and last > 0 and first == first and last == last and last != first
-    assert d["allreduce"]["bucket_split"] is not None and d["allreduce"]["arena_mb"] > 30  # 7.8 M parameters in one flat arena
+    assert full["allreduce"]["bucket_split"] is not None and full["allreduce"]["arena_mb"] > 30  # 7.8 M parameters in one flat arena
     assert "REHEARSAL" in d["data"] and 0 < d["roofline"]["frac"] < 1
