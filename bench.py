@@ -741,10 +741,11 @@ def run_infer(args, ctx):
     }
     if peaks_us is not None:
         cm_bytes = float(cms.numel() * 4)
-        res["roofline_postprocess"] = {"bound": "hbm", "kernel": "peaks_onepass_kernel<1> + peaks_place_kernel (find_local_peaks: 3x3 strict NMS, threshold, ordered compaction, integral refinement)",
+        res["roofline_postprocess"] = {"bound": "hbm", "kernel": "peaks_onepass_kernel<1> + peaks_place_kernel (find_local_peaks: threshold over the streamed maps, 3x3 strict NMS + integral refinement of the candidates, ordered placement)",
                                        "achieved": cm_bytes / (peaks_us * 1e-6) / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": cm_bytes / (peaks_us * 1e-6) / 1e9 / 8000.0,
                                        "algorithmic_bytes": cm_bytes, "us_per_batch": peaks_us, "launches": 2, "traffic": None,
-                                       "byte_accounting": "algorithmic bytes = the confidence maps read once (B x 13 x 256 x 256 fp32); time = HIP events around 50 back-to-back calls (both launches + the output allocation of the wrapper)"}
+                                       "byte_accounting": "algorithmic bytes = the confidence maps read once (B x 13 x 256 x 256 fp32); time = HIP events around 50 back-to-back calls (both launches + the output allocation of the wrapper); "
+                                                          "a bare read of the same 109 MB (tools/probes/hbm_read_probe.hip) takes 15.9 us on this GPU = 0.86 of 8 TB/s, launch included"}
     if elapsed_weak is not None:
         res["weak_scaling"] = {"value": weak_B * world * args.steps / elapsed_weak, "unit": "frames/s", "ms_per_step": 1e3 * elapsed_weak / args.steps,
                                "frames_per_gpu_per_step": weak_B, "global_batch": weak_B * world,

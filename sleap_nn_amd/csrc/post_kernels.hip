@@ -61,6 +61,64 @@ __device__ __forceinline__ bool is_local_peak(const float* __restrict__ plane, i
   return ok;
 }
 
+// the same test with the eight neighbours requested together (clamped addresses, out-of-image ones masked afterwards): one memory latency per candidate
+__device__ __forceinline__ bool is_local_peak_of_candidate(const float* __restrict__ plane, int H, int W, int y, int x, float v) {
+  float nb[3][3];
+#pragma unroll
+  for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+    for (int dx = -1; dx <= 1; ++dx) nb[dy + 1][dx + 1] = plane[(size_t)min(max(y + dy, 0), H - 1) * W + min(max(x + dx, 0), W - 1)];
+  bool ok = true;
+#pragma unroll
+  for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+    for (int dx = -1; dx <= 1; ++dx) {
+      if (dx == 0 && dy == 0) continue;
+      const bool in = y + dy >= 0 && y + dy < H && x + dx >= 0 && x + dx < W;
+      ok = ok & (!in | (v > nb[dy + 1][dx + 1]));  // (v > NaN is false: a value next to a NaN is no peak)
+    }
+  return ok;
+}
+
+// The neighbourhood test AND the integral refinement of a candidate from ONE window of loads (PATCH x PATCH >= 3 x 3 around the pixel, clamped addresses, all requested
+// together): the test reads the window's centre 3 x 3 with out-of-image neighbours skipped, the refinement its zero-padded values -- the same arithmetic, in the same order,
+// as is_local_peak_of_candidate + integral_offset_fixed<PATCH>.
+template <int PATCH>
+__device__ __forceinline__ bool test_and_refine(const float* __restrict__ plane, int H, int W, int px, int py, float* val, float* dx, float* dy) {
+  constexpr int half = PATCH / 2;
+  const float g0 = -(PATCH - 1) * 0.5f;
+  float w[PATCH][PATCH];
+#pragma unroll
+  for (int j = 0; j < PATCH; ++j)
+#pragma unroll
+    for (int i = 0; i < PATCH; ++i) w[j][i] = plane[(size_t)min(max(py - half + j, 0), H - 1) * W + min(max(px - half + i, 0), W - 1)];
+  const float v = w[half][half];
+  bool ok = true;
+#pragma unroll
+  for (int dj = -1; dj <= 1; ++dj)
+#pragma unroll
+    for (int di = -1; di <= 1; ++di) {
+      if (di == 0 && dj == 0) continue;
+      const bool in = py + dj >= 0 && py + dj < H && px + di >= 0 && px + di < W;
+      ok = ok & (!in | (v > w[half + dj][half + di]));
+    }
+  float z = 0.f, sx = 0.f, sy = 0.f;
+#pragma unroll
+  for (int j = 0; j < PATCH; ++j)
+#pragma unroll
+    for (int i = 0; i < PATCH; ++i) {
+      const int yy = py - half + j, xx = px - half + i;
+      const float t = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? w[j][i] : 0.f;
+      z = __fadd_rn(z, t);
+      sx = __fadd_rn(sx, __fmul_rn(g0 + i, t));
+      sy = __fadd_rn(sy, __fmul_rn(g0 + j, t));
+    }
+  *val = v;
+  *dx = sx / z;
+  *dy = sy / z;
+  return ok;
+}
+
 // first moments over a patch x patch zero padded window centred on the integer peak.  PATCH > 0: compile-time size -- the window's loads are issued together (independent
 // addresses) and only the sums are chained, in the same (row, column) order as the run-time loop: same bits, one memory latency instead of patch^2 of them (the loop form
 // cost ~25 us per peak under load and set the time of the whole peak kernel).
@@ -204,164 +262,170 @@ __global__ __launch_bounds__(256) void peaks_emit_kernel(const float* __restrict
 
 // ---------------------------------------------------------------------------------------
 // K9b: local peaks in ONE pass over the confidence maps + a placement pass over the (few) peaks found.
-//   peaks_onepass_kernel: one block per (sample, group of OP_R rows).  Every map value is loaded once by the lane that owns its column quad (1 + 2 / OP_R reads per
-//     value) and bit c of the pixel's 64-bit mask is set where the strict 3x3 test passes (peaks.py:26-63,184-259: v > threshold and v > every in-image neighbour).
-//     Then, row by row and column chunk by column chunk, block prefix sums put the peaks in the reference's (y, x, channel) order into the block's staging area
-//     (coordinates refined right there) and the block's count is stored.
+//   peaks_onepass_kernel: one block per (sample, group of OP_R rows).  Every map value is loaded exactly once by the lane that owns its column quad and bit c of the
+//     pixel's 64-bit mask is set where it exceeds the threshold; the few candidates then take the strict 3x3 test (peaks.py:26-63,184-259: v > every in-image
+//     neighbour).  Wave prefix sums put the peaks in the reference's (y, x, channel) order into the block's staging area (coordinates refined right there) and the
+//     block's count is stored.
 //   peaks_place_kernel: block i sums the counts of the blocks before it (fixed order: no atomics), copies its staged peaks to their final place and, in the rare case
 //     that a block found more peaks than its staging area holds, recomputes that block's rows straight into the output (the legacy emit logic) -- the result never depends
 //     on the staging capacity.  Block 0 also writes the totals and the per-sample counts / offsets.
 // Two launches, the maps read once (the legacy path: count + scan + emit, two full reads with nine loads per value each).
 // ---------------------------------------------------------------------------------------
+#ifndef PH_PEAKS_EXP
+#define PH_PEAKS_EXP 0  // timing experiments only (results wrong with any bit set): 1 = a block ends behind its loads + threshold test, 2 = no neighbourhood test (every window takes the short way)
+#endif
 constexpr int OP_R = 8;      // rows per block (4: 34.0 us, 8: 30.9 us per 32 cfg3 frames; 16 does not fit the registers)
 constexpr int OP_STAGE = 512;  // staged peaks per block (16 B each)
+constexpr int OP_CAND = 2048;  // candidates a block lists (more: its peaks are counted and the placement kernel lists them)
+constexpr int OP_RECOMPUTE = 1 << 30;  // flag on a block's count: nothing is staged, the placement kernel recomputes the block's rows
 
 // NCH: 256-column chunks of a row (W <= 256 NCH).  VEC: rows are 16-byte aligned (W a multiple of 4): one 16-byte load per lane and row.
-// Wave w of the block takes the channels [w cpw, (w + 1) cpw), cpw = ceil(C / 4) <= 16: a lane owns four consecutive columns, loads the OP_R + 2 rows of a channel up
-// front (independent 16-byte loads from clamped addresses, out-of-image entries replaced by -inf: ~10 KiB in flight per wave), tests its 4 x OP_R pixels in registers
-// without a branch -- v > threshold and v > the maximum of its eight neighbours, formed separably; a neighbour outside the image counts as -inf (exactly as skipping
-// it), a NaN neighbour as +inf (`v > NaN` is false) -- (left / right neighbours of the quad's ends by wave shuffles, the wave's two edge lanes load theirs) and keeps one
-// result bit per (pixel, channel) in registers; the four waves' 16-bit channel masks meet in LDS, the block lists its peaks in order (prefix sums per row), then
-// refines and stages them one per thread.
+// Everything after the read is proportional to the CANDIDATES (in-image values above the threshold: the pixels of a few Gaussian blobs), not to the pixels:
+//   streaming -- wave w of the block takes the channels [w cpw, (w + 1) cpw), cpw = ceil(C / 4): a lane owns four consecutive columns, loads the block's OP_R rows of a
+//     channel (independent 16-byte loads, 8 KiB per wave in flight), compares them with the threshold and pushes the (rare) candidates on an unordered LDS list.  Every map
+//     value is read exactly once and nothing else happens to it: the phase runs at the rate of a plain read (tools/probes/hbm_read_probe.hip: 16 us for cfg3's 109 MB);
+//   listing -- one candidate per thread: its eight neighbours (peaks.py:26-63,184-259: v > every in-image neighbour, `v > NaN` false) and its refinement window are requested
+//     together, ONE memory latency for the block's whole list; a surviving peak's place in the reference's (row, column, channel) order is the number of survivors with a
+//     smaller key (a few compares); its thread stages it.
+// (Round 4 formed the 3x3 neighbourhood maximum of every pixel in registers, ~430 vector instructions per lane and channel, read two halo rows per block for it and listed
+// the peaks with per-pixel prefix sums over the block: 30 us.  PH_PEAKS_EXP builds of round 5 say where that went: plain streaming 17 us, +6 us for the windows that hold a
+// blob, +7 us for the listing -- vector instructions of four resident blocks per CU that all reach the same phase at the same time.)
 template <int NCH, bool VEC>
 __global__ __launch_bounds__(256) void peaks_onepass_kernel(const float* __restrict__ cms, int C, int H, int W, float thr, int refine, int patch, float xy_scale,
                                                             int groups, int* __restrict__ blk_count, float* __restrict__ stg_xy, float* __restrict__ stg_val,
                                                             int* __restrict__ stg_ch) {
-  __shared__ int red[8];
-  __shared__ unsigned long long sbits[4][OP_R][NCH * 64];  // [wave][row][column quad]: four 16-bit channel masks
-  __shared__ unsigned ent[OP_STAGE];                       // staged peaks of the block, in order: x | row << 12 | channel << 16
-  // Workgroups go round the eight XCDs: block id -> (sample, row group) so that an XCD walks CONSECUTIVE row groups -- the two halo rows a group shares with each neighbour are then
-  // hits in that XCD's L2 instead of a second HBM read (137 -> 112 MB fetched per 32 cfg3 frames).  Everything the block writes is indexed by blk, the logical id.
+  __shared__ unsigned cand[OP_CAND];  // candidates, unordered: key = row << 16 | column << 6 | channel
+  __shared__ unsigned pkey[OP_STAGE];  // surviving peaks, unordered: key
+  __shared__ float4 pres[OP_STAGE];    // ... and (x, y, value, -)
+  __shared__ int n_cand, n_pass;
+  // Workgroups go round the eight XCDs: block id -> (sample, row group) so that an XCD walks CONSECUTIVE row groups (the candidates' neighbour rows in the next group are
+  // then in that XCD's L2).  Everything the block writes is indexed by blk, the logical id.
   const int n_blk = (int)gridDim.x;
   const int blk = (n_blk & 7) == 0 ? ((int)blockIdx.x & 7) * (n_blk >> 3) + ((int)blockIdx.x >> 3) : (int)blockIdx.x;
   const int b = blk / groups, y0 = (blk - b * groups) * OP_R;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int rows = min(OP_R, H - y0);
   const int cpw = (C + 3) >> 2, c_lo = wave * cpw, c_hi = min(C, c_lo + cpw);
-  const float ninf = -INFINITY, pinf = INFINITY;
+  if (threadIdx.x == 0) {
+    n_cand = 0;
+    n_pass = 0;
+  }
+  __syncthreads();
 #pragma unroll
   for (int k = 0; k < NCH; ++k) {
     const int xb = k * 256;
     const int x = xb + 4 * lane;
-    unsigned long long bits[OP_R];
-#pragma unroll
-    for (int r = 0; r < OP_R; ++r) bits[r] = 0ull;
     if (xb < W) {  // block-uniform
-      const bool xin = x < W;
-      const int xc = xin ? x : 0;
+      const int xc = x < W ? x : 0;
       for (int c = c_lo; c < c_hi; ++c) {
         const float* plane = cms + ((size_t)b * C + c) * H * W;
-        // v: the raw values (the centre's `> threshold` test: a NaN centre is no peak); n: the same as NEIGHBOURS -- NaN replaced by +inf (a value next to a NaN is no
-        // peak: `v > NaN` is false, peaks.py's dilation propagates it), out-of-image by -inf (skipped)
-        float v[OP_R + 2][4], n[OP_R + 2][4], lf[OP_R + 2], rt[OP_R + 2];
-#pragma unroll
-        for (int j = 0; j < OP_R + 2; ++j) {
-          const int y = y0 - 1 + j;
-          const bool yin = y >= 0 && y < H;
-          const float* rp = plane + (size_t)min(max(y, 0), H - 1) * W;
-          if (VEC) {
-            const float4 q = *reinterpret_cast<const float4*>(rp + xc);
-            v[j][0] = q.x; v[j][1] = q.y; v[j][2] = q.z; v[j][3] = q.w;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[j][e] = (yin && xin) ? v[j][e] : ninf;
-          } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const float t = rp[min(x + e, W - 1)];
-              v[j][e] = (yin && x + e < W) ? t : ninf;
-            }
-          }
-#pragma unroll
-          for (int e = 0; e < 4; ++e) n[j][e] = v[j][e] != v[j][e] ? pinf : v[j][e];
-          float l = ninf, r = ninf;  // neighbours of the quad's ends that lie in other chunks (the wave's edge lanes; never taken when W <= 256)
-          if (NCH > 1) {
-            if (lane == 0 && yin && x > 0) l = rp[x - 1];
-            if (lane == 63 && yin && x + 4 < W) r = rp[x + 4];
-            l = l != l ? pinf : l;
-            r = r != r ? pinf : r;
-          }
-          lf[j] = l;
-          rt[j] = r;
-        }
-#pragma unroll
-        for (int j = 0; j < OP_R + 2; ++j) {
-          const float up = __shfl_up(n[j][3], 1, 64), dn = __shfl_down(n[j][0], 1, 64);
-          lf[j] = lane != 0 ? up : lf[j];
-          rt[j] = lane != 63 ? dn : rt[j];
-        }
-        // separable neighbourhood maximum (every operand is NaN-free): h3 = max(left, centre, right) of the rows above / below, h2 = max(left, right) of the own row
-        float h3[OP_R + 2][4], h2[OP_R + 2][4];
-#pragma unroll
-        for (int j = 0; j < OP_R + 2; ++j)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float l = e == 0 ? lf[j] : n[j][e - 1], r = e == 3 ? rt[j] : n[j][e + 1];
-            h2[j][e] = fmaxf(l, r);
-            h3[j][e] = fmaxf(h2[j][e], n[j][e]);
-          }
-        const int ci = c - c_lo;
+        float q[OP_R][4];  // rows y0 .. y0 + OP_R - 1 of channel c, from clamped addresses (a row / column outside the image repeats the nearest inside one: masked below)
 #pragma unroll
         for (int r = 0; r < OP_R; ++r) {
-          const int j = r + 1;
+          const float* rp = plane + (size_t)min(y0 + r, H - 1) * W;
+          if (VEC) {
+            const float4 t = *reinterpret_cast<const float4*>(rp + xc);
+            q[r][0] = t.x; q[r][1] = t.y; q[r][2] = t.z; q[r][3] = t.w;
+          } else {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float val = v[j][e];
-            const float nmax = fmaxf(fmaxf(h3[j - 1][e], h3[j + 1][e]), h2[j][e]);
-            const bool ok = (val > thr) & (val > nmax);
-            bits[r] |= (unsigned long long)(ok ? 1u : 0u) << (16 * e + ci);
+            for (int e = 0; e < 4; ++e) q[r][e] = rp[min(x + e, W - 1)];
+          }
+        }
+        bool hit = false;
+#pragma unroll
+        for (int r = 0; r < OP_R; ++r)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) hit = hit | (q[r][e] > thr);
+        if (!(PH_PEAKS_EXP & 2) && __ballot(hit) != 0ull) {  // (wave-uniform; most windows of a confidence map hold no value above the threshold)
+          // the wave's candidates go on the list with ONE atomic: bit (4 r + e) of a lane's mask, a wave prefix sum of the lanes' counts, then plain stores
+          unsigned msk = 0u;
+#pragma unroll
+          for (int r = 0; r < OP_R; ++r)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) msk |= ((q[r][e] > thr) & (r < rows) & (x + e < W)) ? (1u << (4 * r + e)) : 0u;
+          const int cnt = __popc(msk);
+          int inc = cnt;
+#pragma unroll
+          for (int d = 1; d < 64; d <<= 1) {
+            const int t = __shfl_up(inc, d, 64);
+            if (lane >= d) inc += t;
+          }
+          const int total = __shfl(inc, 63, 64);
+          int base = 0;
+          if (lane == 0 && total > 0) base = atomicAdd(&n_cand, total);
+          base = __shfl(base, 0, 64);
+          int at = base + inc - cnt;
+          while (msk) {
+            const int bit = __ffs((int)msk) - 1;
+            msk &= msk - 1;
+            if (at < OP_CAND) cand[at] = ((unsigned)(bit >> 2) << 16) | ((unsigned)(x + (bit & 3)) << 6) | (unsigned)c;
+            ++at;
           }
         }
       }
     }
-#pragma unroll
-    for (int r = 0; r < OP_R; ++r) sbits[wave][r][k * 64 + lane] = bits[r];
   }
   __syncthreads();
-  // phase 1 -- ordered compaction: rows ascending, columns ascending (chunk by chunk), channels ascending; the first OP_STAGE peaks are listed in LDS
-  int base = 0;
+  const int nc = n_cand;
+  if ((PH_PEAKS_EXP & 1) || nc == 0) {  // a block without a candidate -- most of them -- is done here
+    if (threadIdx.x == 0) blk_count[blk] = 0;
+    return;
+  }
+  if (nc > OP_CAND) {
+    // More candidates than the list holds (a map that is above the threshold nearly everywhere): count this block's peaks exactly -- every thread walks its column --
+    // and leave the listing to the placement kernel's recompute path (flagged count).
+    int mine = 0;
+    for (int r = 0; r < rows; ++r)
+      for (int xx = threadIdx.x; xx < W; xx += 256)
+        for (int c = 0; c < C; ++c) mine += is_local_peak(cms + ((size_t)b * C + c) * H * W, H, W, y0 + r, xx, thr) ? 1 : 0;
+    if (mine) atomicAdd(&n_pass, mine);
+    __syncthreads();
+    if (threadIdx.x == 0) blk_count[blk] = n_pass | OP_RECOMPUTE;
+    return;
+  }
 #pragma unroll 1
-  for (int r = 0; r < rows; ++r) {
-#pragma unroll
-    for (int k = 0; k < NCH; ++k) {
-      if (k * 256 >= W) break;
-      const int x = k * 256 + threadIdx.x;
-      unsigned long long m = 0ull;
-      if (x < W) {
-#pragma unroll
-        for (int w = 0; w < 4; ++w) m |= ((sbits[w][r][x >> 2] >> (16 * (x & 3))) & 0xFFFFull) << (w * cpw);
+  for (int i = threadIdx.x; i < nc; i += 256) {
+    const unsigned key = cand[i];
+    const int x = (key >> 6) & 0x3FF, y = y0 + (int)(key >> 16), c = key & 63;
+    const float* plane = cms + ((size_t)b * C + c) * H * W;
+    float val, dx = 0.f, dy = 0.f;
+    bool pass;
+    if (refine && patch == 5 && !(PH_PEAKS_EXP & 16)) {  // (the refinement of a candidate that turns out to be no peak is a few wasted loads)
+      pass = test_and_refine<5>(plane, H, W, x, y, &val, &dx, &dy);
+    } else if (refine && patch == 3 && !(PH_PEAKS_EXP & 16)) {
+      pass = test_and_refine<3>(plane, H, W, x, y, &val, &dx, &dy);
+    } else if (refine && patch == 7 && !(PH_PEAKS_EXP & 16)) {
+      pass = test_and_refine<7>(plane, H, W, x, y, &val, &dx, &dy);
+    } else {
+      val = plane[(size_t)y * W + x];
+      pass = is_local_peak_of_candidate(plane, H, W, y, x, val);
+      if (refine && !(PH_PEAKS_EXP & 16)) integral_offset(plane, H, W, x, y, patch, &dx, &dy);
+    }
+    const float fx = (float)x + dx, fy = (float)y + dy;
+    if (pass) {
+      const int j = atomicAdd(&n_pass, 1);
+      if (j < OP_STAGE) {
+        pkey[j] = key;
+        pres[j] = make_float4(fx * xy_scale, fy * xy_scale, val, 0.f);
       }
-      const int cnt = __popcll(m);
-      int tot;
-      int off = base + block_exclusive_scan_256(cnt, &tot, red);
-      while (m) {
-        const int c = __ffsll((long long)m) - 1;
-        m &= m - 1;
-        if (off < OP_STAGE) ent[off] = (unsigned)x | ((unsigned)r << 12) | ((unsigned)c << 16);
-        ++off;
-      }
-      base += tot;
     }
   }
   __syncthreads();
-  // phase 2 -- refinement and staging, one peak per thread (no barrier between peaks: one memory latency for the block's whole list)
-  const size_t sbase = (size_t)blk * OP_STAGE;
-  for (int i = threadIdx.x; i < min(base, OP_STAGE); i += 256) {
-    const unsigned e = ent[i];
-    const int x = e & 0xFFF, y = y0 + ((e >> 12) & 0xF), c = e >> 16;
-    const float* plane = cms + ((size_t)b * C + c) * H * W;
-    float fx = (float)x, fy = (float)y;
-    if (refine) {
-      float dx, dy;
-      integral_offset(plane, H, W, x, y, patch, &dx, &dy);
-      fx += dx;
-      fy += dy;
+  const int np = n_pass;
+  if (np <= OP_STAGE) {  // (more: nothing is staged, the placement kernel recomputes the block from its count)
+    const size_t sbase = (size_t)blk * OP_STAGE;
+    for (int j = threadIdx.x; j < np; j += 256) {
+      const unsigned key = pkey[j];
+      int rank = 0;
+      for (int t = 0; t < np; ++t) rank += pkey[t] < key ? 1 : 0;  // (keys are distinct: one per (pixel, channel))
+      const float4 p = pres[j];
+      stg_xy[2 * (sbase + rank)] = p.x;
+      stg_xy[2 * (sbase + rank) + 1] = p.y;
+      stg_val[sbase + rank] = p.z;
+      stg_ch[sbase + rank] = (int)(key & 63);
     }
-    stg_xy[2 * (sbase + i)] = fx * xy_scale;
-    stg_xy[2 * (sbase + i) + 1] = fy * xy_scale;
-    stg_val[sbase + i] = plane[(size_t)y * W + x];
-    stg_ch[sbase + i] = c;
   }
-  if (threadIdx.x == 0) blk_count[blk] = base;
+  if (threadIdx.x == 0) blk_count[blk] = np;
 }
 
 __global__ __launch_bounds__(256) void peaks_place_kernel(const float* __restrict__ cms, int B, int C, int H, int W, float thr, int refine, int patch, float xy_scale, int groups,
@@ -373,12 +437,13 @@ __global__ __launch_bounds__(256) void peaks_place_kernel(const float* __restric
   const int blk = blockIdx.x;
   // exclusive offset of this block = sum of the counts of the blocks before it (integers: the order of the partial sums does not matter)
   int part = 0;
-  for (int i = threadIdx.x; i < blk; i += 256) part += blk_count[i];
+  for (int i = threadIdx.x; i < blk; i += 256) part += blk_count[i] & (OP_RECOMPUTE - 1);
   int tot;
   block_exclusive_scan_256(part, &tot, red);
-  const int my_off = tot, my_cnt = blk_count[blk];
+  const int my_off = tot, my_cnt = blk_count[blk] & (OP_RECOMPUTE - 1);
+  const bool staged = !(blk_count[blk] & OP_RECOMPUTE) && my_cnt <= OP_STAGE;
   const int b = blk / groups, y0 = (blk - b * groups) * OP_R;
-  if (my_cnt <= OP_STAGE) {
+  if (staged) {
     const size_t sbase = (size_t)blk * OP_STAGE;
     for (int i = threadIdx.x; i < my_cnt; i += 256) {
       const int o = my_off + i;
@@ -431,7 +496,7 @@ __global__ __launch_bounds__(256) void peaks_place_kernel(const float* __restric
       const int bb = sb0 + threadIdx.x;
       int p = 0;
       if (bb < B)
-        for (int i = 0; i < groups; ++i) p += blk_count[bb * groups + i];
+        for (int i = 0; i < groups; ++i) p += blk_count[bb * groups + i] & (OP_RECOMPUTE - 1);
       int t3;
       const int ex = block_exclusive_scan_256(p, &t3, red);
       const int carry = s_off[0];
