@@ -638,80 +638,77 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(ConvArgs a) {
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     };
-    // The output transform of a round, all eight waves: one thread per (tile, slot, row half hh): rows 2 hh and 2 hh + 1 of the 4 x 4 output tile (each reads all 36 positions)
-    auto finish = [&](int round, auto hh_tag) __attribute__((always_inline)) {
-      constexpr int HH = decltype(hh_tag)::value;
-      const int tile = (tid & 255) >> 3, cq = tid & 7;
+    // The output transform of a round, all eight waves: one thread per (tile, slot, channel PAIR of the slot): it reads the 36 positions of its two channels (8 bytes each: every
+    // value of the exchange is read exactly once -- the round-4 form, one thread per (tile, slot, row half), read every value twice and formed the shared row differences in both
+    // halves) and stores all four rows of the 4 x 4 output tile.
+    auto finish = [&](int round) __attribute__((always_inline)) {
+      const int tile = tid >> 4, cq = (tid >> 1) & 7, hc = tid & 1;
       const int ty = tile >> 3, tx = tile & 7;
-      int z0 = (tile * 8 + (cq ^ (tile & 7))) << 2;
+      int z0 = ((tile * 8 + (cq ^ (tile & 7))) << 2) + 2 * hc;
       asm volatile("" : "+v"(z0));
       const float* zp = exch + z0;
-      // row pass (over xi) per nu, Z[a][nu] for this thread's two rows a
-      f32x4 z[2][6];
+      // row pass (over xi) per nu: Z[a][nu] for the four output rows a
+      f32x2 z[4][6];
 #pragma unroll
       for (int n = 0; n < 6; ++n) {
-        f32x4 m[6];
+        f32x2 m[6];
 #pragma unroll
-        for (int x = 0; x < 6; ++x) m[x] = *reinterpret_cast<const f32x4*>(zp + (x * 6 + n) * 1024);
+        for (int x = 0; x < 6; ++x) m[x] = *reinterpret_cast<const f32x2*>(zp + (x * 6 + n) * 1024);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < 2; ++e) {
           const float s12 = m[1][e] + m[2][e], d12 = m[1][e] - m[2][e], s34 = m[3][e] + m[4][e], d34 = m[3][e] - m[4][e];
-          if constexpr (HH == 0) {
-            z[0][n][e] = (m[0][e] + s12) + s34;
-            z[1][n][e] = fmaf(2.f, d34, d12);
-          } else {
-            z[0][n][e] = fmaf(4.f, s34, s12);
-            z[1][n][e] = fmaf(8.f, d34, d12) + m[5][e];
-          }
+          z[0][n][e] = (m[0][e] + s12) + s34;
+          z[1][n][e] = fmaf(2.f, d34, d12);
+          z[2][n][e] = fmaf(4.f, s34, s12);
+          z[3][n][e] = fmaf(8.f, d34, d12) + m[5][e];
         }
       }
-      const int co = P.ntile * 64 + (cq >> 2) * 32 + round * 16 + (cq & 3) * 4;
-      const f32x4 bias = KS ? f32x4{0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4*>(a.bias + co);
+      const int co = P.ntile * 64 + (cq >> 2) * 32 + round * 16 + (cq & 3) * 4 + 2 * hc;
+      const f32x2 bias = KS ? f32x2{0.f, 0.f} : *reinterpret_cast<const f32x2*>(a.bias + co);
       const int oy0 = P.y0 + 4 * ty, ox = P.x0 + 4 * tx;
-      const bool live = oy0 < a.H && ox < a.W && co < a.coutp;  // (H and W are multiples of 4: a 4 x 4 tile is inside the image or outside)
-      f32x4 prow[2];  // fused 2 x 2 / 2 max pool (ConvArgs::dst_pool; even H and W: no padded windows): the column-pair maxima of the window's first row
+      const bool live = oy0 < a.H && ox < a.W && co < a.coutp;  // (H and W are multiples of 4: a 4 x 4 tile is inside the image or outside; channel counts are even)
+      f32x2 prow[2];  // fused 2 x 2 / 2 max pool (ConvArgs::dst_pool; even H and W: no padded windows): the column-pair maxima of the window's first row
 #pragma unroll
-      for (int a2 = 0; a2 < 2; ++a2) {
-        const int aa = 2 * HH + a2;
-        const f32x4 s12 = z[a2][1] + z[a2][2], d12 = z[a2][1] - z[a2][2], s34 = z[a2][3] + z[a2][4], d34 = z[a2][3] - z[a2][4];
-        f32x4 y[4];
-        y[0] = ((z[a2][0] + s12) + s34) + bias;
+      for (int aa = 0; aa < 4; ++aa) {
+        const f32x2 s12 = z[aa][1] + z[aa][2], d12 = z[aa][1] - z[aa][2], s34 = z[aa][3] + z[aa][4], d34 = z[aa][3] - z[aa][4];
+        f32x2 y[4];
+        y[0] = ((z[aa][0] + s12) + s34) + bias;
         y[1] = (d12 + 2.f * d34) + bias;
         y[2] = (s12 + 4.f * s34) + bias;
-        y[3] = ((d12 + 8.f * d34) + z[a2][5]) + bias;
+        y[3] = ((d12 + 8.f * d34) + z[aa][5]) + bias;
         if (live) {
           float* const dp = a.dst + ((size_t)(P.b * a.H + oy0 + aa) * a.W + ox) * a.coutp + co + (KS ? (size_t)ksl * a.split_stride : (size_t)0);
 #pragma unroll
           for (int bb = 0; bb < 4; ++bb) {
-            f32x4 v = y[bb];
+            f32x2 v = y[bb];
             if (a.relu) {
 #pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+              for (int e = 0; e < 2; ++e) v[e] = fmaxf(v[e], 0.f);
             }
             if (a.relu_mask_src) {  // backward: this launch completes the gradient of a conv + ReLU output -- that ReLU's mask rides in the (lane-local) store
-              const f32x4 f = *reinterpret_cast<const f32x4*>(a.relu_mask_src + (dp - a.dst) + (size_t)bb * a.coutp);
+              const f32x2 f = *reinterpret_cast<const f32x2*>(a.relu_mask_src + (dp - a.dst) + (size_t)bb * a.coutp);
 #pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = f[e] > 0.f ? v[e] : 0.f;
+              for (int e = 0; e < 2; ++e) v[e] = f[e] > 0.f ? v[e] : 0.f;
             }
             y[bb] = v;
-            if ((KS || !a.skip_dst) && !(W4_EXP & 512)) *reinterpret_cast<f32x4*>(dp + (size_t)bb * a.coutp) = v;  // (non-temporal stores: the output stage 2x slower)
+            if ((KS || !a.skip_dst) && !(W4_EXP & 512)) *reinterpret_cast<f32x2*>(dp + (size_t)bb * a.coutp) = v;  // (non-temporal stores: the output stage 2x slower)
           }
           if (!KS && a.dst_pool) {
-            f32x4 m0, m1;
+            f32x2 m0, m1;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
+            for (int e = 0; e < 2; ++e) {
               m0[e] = fmaxf(y[0][e], y[1][e]);
               m1[e] = fmaxf(y[2][e], y[3][e]);
             }
             if (aa & 1) {
 #pragma unroll
-              for (int e = 0; e < 4; ++e) {
+              for (int e = 0; e < 2; ++e) {
                 m0[e] = fmaxf(m0[e], prow[0][e]);
                 m1[e] = fmaxf(m1[e], prow[1][e]);
               }
               float* const pp = a.dst_pool + ((size_t)(P.b * (a.H >> 1) + ((oy0 + aa) >> 1)) * (a.W >> 1) + (ox >> 1)) * a.coutp + co;
-              *reinterpret_cast<f32x4*>(pp) = m0;
-              *reinterpret_cast<f32x4*>(pp + a.coutp) = m1;
+              *reinterpret_cast<f32x2*>(pp) = m0;
+              *reinterpret_cast<f32x2*>(pp + a.coutp) = m1;
             } else {
               prow[0] = m0;
               prow[1] = m1;
@@ -730,19 +727,13 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(ConvArgs a) {
     dump(0);
     __builtin_amdgcn_s_barrier();
     P4_ET(e1)
-    if (nt == 0)
-      finish(0, std::integral_constant<int, 0>{});
-    else
-      finish(0, std::integral_constant<int, 1>{});
+    finish(0);
     __builtin_amdgcn_s_barrier();
     P4_ET(e2)
     dump(1);
     __builtin_amdgcn_s_barrier();
     P4_ET(e3)
-    if (nt == 0)
-      finish(1, std::integral_constant<int, 0>{});
-    else
-      finish(1, std::integral_constant<int, 1>{});
+    finish(1);
     __builtin_amdgcn_s_barrier();
 #ifdef W4_STAMP
     if (a.clock_probe && lane == 0 && vid == (int)blockIdx.x) {
