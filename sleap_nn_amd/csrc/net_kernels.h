@@ -42,6 +42,7 @@ struct ConvArgs {
   int use_c16 = 1;    // 16 -> 16 channel layers on conv3x3_c16_kernel
   // Winograd F(4x4,3x3) (conv3x3_wino4_kernel, wino4_kernels.hip): layers with at least wino4_min_cin padded input channels
   const float* wpack_wino4 = nullptr;  // transformed weights in the kernel's private-ring order, or nullptr
+  const float* wpack_wino4s = nullptr; // (tools/w4/wino4s_experiment.inc only: weights in the order of the sixteen-tile experiment kernel)
   int use_wino4 = 0;          // filled from the handle option "conv_wino4" and the kind of plan: 1 = where it is estimated faster than F(2x2,3x3), 2 = wherever the shape fits
   int wino4_min_cin = 64;     // handle option "conv_wino4_min_cin"
   int src1_lowres = 0;        // src1 is (B, H/2, W/2, c1p): bilinear x2 (align_corners = False) is folded into the input transform (wino4 only)

@@ -8,6 +8,9 @@
 #include <cmath>
 #include <algorithm>
 #include "../../sleap_nn_amd/csrc/wino4_kernels.hip"
+#ifdef W4S
+#include "wino4s_experiment.inc"
+#endif
 
 namespace ph {
 static thread_local char g_err[512];
@@ -57,6 +60,27 @@ int main(int argc, char** argv) {
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   const double direct = 2.0 * (c0 + c1) * cout * 9.0 * H * W * B;
   std::vector<float> o1(no), o2(no);
+#ifdef W4S  // the sixteen-tile kernel on the same problem: its own weight order, its result compared with the eight-wave kernel's, then timed in its place
+  std::vector<float> ref(no);
+  {
+    float* dws;
+    hipMalloc(&dws, nw * 4);
+    if (prepare_wino4s() != PH_OK || launch_wino4s_pack(dwp, dws, ntiles, nchunks, 0) != PH_OK) return printf("pack (s) failed\n"), 1;
+    a.wpack_wino4s = dws;
+    hipMemset(dout, 0xff, no * 4);
+    if (launch_conv3x3_wino4(a, 0) != PH_OK) return printf("launch failed: %s\n", g_err), 1;
+    hipMemcpy(ref.data(), dout, no * 4, hipMemcpyDeviceToHost);
+    hipMemset(dout, 0xff, no * 4);
+    if (launch_conv3x3_wino4s(a, 0) != PH_OK) return printf("launch (s) failed: %s\n", g_err), 1;
+    if (hipDeviceSynchronize() != hipSuccess) return printf("kernel (s) failed: %s\n", hipGetErrorString(hipGetLastError())), 1;
+    std::vector<float> got(no);
+    hipMemcpy(got.data(), dout, no * 4, hipMemcpyDeviceToHost);
+    double md = 0, mx = 0; size_t nn = 0;
+    for (size_t i = 0; i < no; ++i) { if (got[i] != got[i]) { ++nn; continue; } md = std::max(md, (double)fabsf(got[i] - ref[i])); mx = std::max(mx, (double)fabsf(ref[i])); }
+    printf("sixteen-tile kernel vs eight-wave kernel: max |diff| %.3e (scale %.3e), %zu NaN\n", md, mx, nn);
+  }
+#define launch_conv3x3_wino4 launch_conv3x3_wino4s
+#endif
   for (int i = 0; i < 3; ++i) if (launch_conv3x3_wino4(a, 0) != PH_OK) return printf("launch failed: %s\n", g_err), 1;
   if (hipDeviceSynchronize() != hipSuccess) return printf("kernel failed: %s\n", hipGetErrorString(hipGetLastError())), 1;
   hipEventRecord(e0);
