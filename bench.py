@@ -1069,7 +1069,15 @@ def single_instance_leg(name, size, batch, n_nodes, steps, dev, with_cpu):
     ref_out = layer.predict(frames)
     got_out = layer.predict_graphed(gframes)
     assert torch.equal(torch.nan_to_num(ref_out.pred_keypoints), torch.nan_to_num(got_out.pred_keypoints)) and torch.equal(ref_out.pred_peak_values, got_out.pred_peak_values)
-    total, lat = _time_calls(lambda: layer.predict_graphed(gframes), steps, 10, True)
+    kp_host = torch.empty(tuple(got_out.pred_keypoints.shape), dtype=torch.float32, pin_memory=True)
+    pv_host = torch.empty(tuple(got_out.pred_peak_values.shape), dtype=torch.float32, pin_memory=True)
+
+    def latency_step():  # ends with the keypoints and their values in (pinned) host memory, as the CPU baseline beside it does
+        o = layer.predict_graphed(gframes)
+        kp_host.copy_(o.pred_keypoints, non_blocking=True)
+        pv_host.copy_(o.pred_peak_values, non_blocking=True)
+
+    total, lat = _time_calls(latency_step, steps, 10, True)
     lat_us = sorted(1e6 * t for t in lat)
     # throughput: the same steps enqueued back to back (the layer's outputs stay on the device: no host sync inside a step), one sync at the end
     total_q, _ = _time_calls(lambda: layer.predict_graphed(gframes), steps, 10, False)
@@ -1082,7 +1090,7 @@ def single_instance_leg(name, size, batch, n_nodes, steps, dev, with_cpu):
            "queued_steps_frames_per_s": batch * steps / total_q, "queued_steps_frames_per_s_two_launch_groups": batch * steps / total_eager_q,
            "dtype": "f32", "data": "synthetic",
            "config": {"workload": f"{name}: single-instance UNet f16/r2/max_stride16/output_stride2, {size}x{size}x1 uint8 frames, {n_nodes} keypoints, batch {batch}", "frames_per_step": batch,
-                      "weights": "xavier-uniform seed 1234, head x0.05", "params": model.num_parameters(), "step": "forward + global peaks + integral refinement + coordinate ladder as ONE hipGraph launch (InferenceLayer.predict_graphed), outputs left on the device; `value`: one frame = synchronous steps (latency), a batch = steps queued back to back; queued_steps_frames_per_s_two_launch_groups = layer.predict (forward graph, then the post-process launches)",
+                      "weights": "xavier-uniform seed 1234, head x0.05", "params": model.num_parameters(), "step": "forward + global peaks + integral refinement + coordinate ladder as ONE hipGraph launch (InferenceLayer.predict_graphed); the synchronous (latency) steps end with the D2H of keypoints and values into pinned memory, the queued (throughput) steps leave them on the device; `value`: one frame = synchronous steps, a batch = steps queued back to back; queued_steps_frames_per_s_two_launch_groups = layer.predict (forward graph, then the post-process launches)",
                       "inputs": "uint8 frames resident in HBM"},
            "latency_us_per_step": {"median": lat_us[len(lat_us) // 2], "p10": lat_us[len(lat_us) // 10], "p90": lat_us[(9 * len(lat_us)) // 10]},
            "forward_only": {"us_per_batch": 1e6 * fwd_s, "frames_per_s": batch / fwd_s, "launch": "hipGraph replay, back to back, no host sync"},

@@ -1114,7 +1114,10 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
         apply_conv_options(m, a);
         a.wpack_wino4 = op.w_wino4_dev;
         a.use_wino4 = m->conv_wino4 == 3 ? 2 : ((m->conv_wino4 == 2 || (m->conv_wino4 == 1 && plan.reuse)) ? 1 : 0);
-        // (both round-4 routings below apply to inference plans: a training program's forward keeps the kernels its gradient tests were pinned with)
+        // (the two round-4 routings below -- Cout-32 layers on the N-tile-64 kernels, split K -- apply to inference plans only: a training program's forward keeps the kernels its
+        // gradient tests were pinned with.  The wave-private kernel's two-source (16 + 32 -> 16) and fused-head forms are NOT gated that way: they are shapes of conv_w16 itself and
+        // run in every plan; tests/test_gpu_training.py's default network (filters 8, output stride 2: concat 16 + 32 -> 16) trains through the two-source form, its gradients are
+        // compared with autograd's)
         if (op.w_n64_dev && op.w_wino2_dev && op.w_wino_dev && (m->conv_n32_wino2d >= 2 || (m->conv_n32_wino2d == 1 && plan.reuse)) && m->use_dma && m->conv_wino && m->conv_wino2d && m->conv_persist && !w16_fits(a) && wino2d_fits(a)) {
           // Cout 32, K >= 64 (and not a shape of the wave-private kernel): N tile 64 with its upper half empty -- the F(2x2,3x3) kernel skips the missing half's MFMAs
           a.bn = 64;
