@@ -1198,10 +1198,18 @@ def published_workload_leg(steps, dev):
         mc.load_state_dict(wsel("wc/"))
         mi = Model("unet", ci["backbone"], ci["heads"], "centered_instance")
         mi.load_state_dict(wsel("wi/"))
-        cbe = HipBackend(mc, str(dev), use_graph=True)
-        cl = CentroidLayer(cbe, cc["heads"]["confmaps"]["output_stride"], max_instances=6, max_stride=cc["backbone"]["max_stride"], postprocess_config=PostprocessConfig(peak_threshold=0.03, max_instances=6))
-        il = CenteredInstanceLayer(HipBackend(mi, str(dev)), ci["heads"]["confmaps"]["output_stride"], max_stride=ci["backbone"]["max_stride"], postprocess_config=PostprocessConfig(peak_threshold=0.03))
-        tdl = TopDownLayer(cl, il, (tcfg["crop_size"], tcfg["crop_size"]))
+        def make_tdl(mc_, mi_):
+            cbe_ = HipBackend(mc_, str(dev), use_graph=True)
+            cl_ = CentroidLayer(cbe_, cc["heads"]["confmaps"]["output_stride"], max_instances=6, max_stride=cc["backbone"]["max_stride"], postprocess_config=PostprocessConfig(peak_threshold=0.03, max_instances=6))
+            il_ = CenteredInstanceLayer(HipBackend(mi_, str(dev)), ci["heads"]["confmaps"]["output_stride"], max_stride=ci["backbone"]["max_stride"], postprocess_config=PostprocessConfig(peak_threshold=0.03))
+            return cbe_, TopDownLayer(cl_, il_, (tcfg["crop_size"], tcfg["crop_size"]))
+
+        cbe, tdl = make_tdl(mc, mi)
+        mc2 = Model("unet", cc["backbone"], cc["heads"], "centroid")
+        mc2.load_state_dict(wsel("wc/"))
+        mi2 = Model("unet", ci["backbone"], ci["heads"], "centered_instance")
+        mi2.load_state_dict(wsel("wi/"))
+        _cbe2, tdl2 = make_tdl(mc2, mi2)  # a second copy of the pair (own handles): Predictor's second stream
         tframes = torch.from_numpy(tz["image"]).to(dev)
         tframes = tframes.reshape(-1, *tframes.shape[-3:])
         tframes = tframes.repeat((4 + tframes.shape[0] - 1) // tframes.shape[0], 1, 1, 1)[:4].contiguous()
@@ -1216,7 +1224,7 @@ def published_workload_leg(steps, dev):
         td["instances_per_batch"] = int(torch.isfinite(tout.pred_centroids[..., 0]).sum())
         # end to end as for the bottom-up model: Predictor.predict over 100 uint8 frames in host memory, batch 4 (stage 1 of batch i + 1 enqueued before the one host read of batch i)
         tvid = tframes.cpu().repeat(25, 1, 1, 1).contiguous()
-        tp = Predictor(tdl, batch_size=4)
+        tp = Predictor(tdl, batch_size=4, replicas=[tdl2])
         tp.predict(tvid)
         torch.cuda.synchronize()
         t2 = time.perf_counter()
@@ -1227,7 +1235,7 @@ def published_workload_leg(steps, dev):
         td["end_to_end_ms_per_batch"] = 1e3 * tot / (reps * 25)
         td["end_to_end_fps"] = reps * tvid.shape[0] / tot
         td["vs_baseline"] = {"centroid_forward_eager_fp32": ref["centroid_forward_ms_per_batch4"]["eager_fp32"] / td["centroid_forward_ms_per_batch"], "end_to_end_fps": td["end_to_end_fps"] / ref["topdown_end_to_end_fps"]}
-        td["what"] = f"fixture top-down models (tests/golden/topdown.npz): {tuple(tframes.shape)} uint8 frames resident in HBM, centroid forward (hipGraph) and TopDownLayer.predict (centroid -> NMS peaks -> device-side selection -> {tcfg['crop_size']} x {tcfg['crop_size']} crops -> centered-instance forward -> global peaks -> scatter; ONE host read per batch: the per-frame centroid counts); end_to_end = Predictor.predict over 100 host frames, pipelined over that read"
+        td["what"] = f"fixture top-down models (tests/golden/topdown.npz): {tuple(tframes.shape)} uint8 frames resident in HBM, centroid forward (hipGraph) and TopDownLayer.predict (centroid -> NMS peaks -> device-side selection -> {tcfg['crop_size']} x {tcfg['crop_size']} crops -> centered-instance forward -> global peaks -> scatter; ONE host read per batch: the per-frame centroid counts); end_to_end = Predictor.predict over 100 host frames, pipelined over that read, two copies of the layer pair on two HIP streams"
     except Exception as e:
         td = {"error": repr(e)}
     return {"metric": "ms per batch of 4, bottom-up backbone forward (the reference's published table)", "value": fwd["exact_fp32"], "unit": "ms/batch", "higher_is_better": False, "steps": max(steps, 200),
@@ -1236,7 +1244,7 @@ def published_workload_leg(steps, dev):
                        "params": model.num_parameters(), "forward_launch": "hipGraph replay, back to back"},
             "forward_ms_per_batch": fwd, "frames_per_s_forward": 4.0 / fwd_s,
             "end_to_end": {"value": e2e, "unit": "frames/s", "frames": int(vid.shape[0]), "repeats": reps, "instances_found_per_pass": n_inst,
-                           "what": "Predictor.predict (pipelined: pinned staging + H2D, forward + peaks + PAF scoring as one hipGraph, D2H, one-call C++ grouping in a worker) over 100 uint8 frames in host memory, batch 4, exact fp32"},
+                           "what": "Predictor.predict (pipelined: pinned staging + H2D, resize / pad + forward + peaks + PAF scoring as one hipGraph, D2H, one-call C++ grouping in a worker; consecutive batches alternate between two copies of the layer on two HIP streams, Predictor.from_model_paths(streams=2)) over 100 uint8 frames in host memory, batch 4, exact fp32"},
             "vs_baseline": {"forward_eager_fp32": ref["bottomup_forward_ms_per_batch4"]["eager_fp32"] / fwd["exact_fp32"], "forward_fp16": ref["bottomup_forward_ms_per_batch4"]["fp16_autocast"] / fwd["fp16_autocast_equivalent"],
                             "end_to_end_fps": e2e / ref["bottomup_end_to_end_fps"], "reference": ref, "reference_hardware": "NVIDIA A40, CUDA 12.8, torch 2.9.1 (docs/guides/inference-performance.md:3-7,40-48,70-77)",
                             "note": "ratios > 1 = this build faster; different hardware and (end to end) no video decoding here: a like-for-like of the workload, not of the machine"},

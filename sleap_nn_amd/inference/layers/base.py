@@ -4,7 +4,7 @@ from __future__ import annotations
 
 from abc import ABC, abstractmethod
 from dataclasses import replace
-from typing import Tuple, Union
+from typing import Optional, Tuple, Union
 
 import numpy as np
 import torch
@@ -87,11 +87,13 @@ class InferenceLayer(ABC):
         x, info = self.preprocess(torch.zeros(tuple(shape), dtype=torch.uint8, device=self.backend.device))
         return self._graph_entry(x.to(torch.device(self.backend.device)), info, None)[1].squeeze(1)
 
-    def _graph_entry(self, x: torch.Tensor, info: PreprocInfo, code, body=None, extra_key=()):
-        """``(graph, static input, static result, workspace)`` for device frames ``x`` with input code ``code`` (HipBackend.input_code).  ``body(raw_out, info)`` is what follows
-        the forward inside the graph (default: this layer's ``postprocess``; the bottom-up layer captures its GPU stage only), ``extra_key`` whatever else it bakes in.  Same
-        stale-pointer discipline as ``HipBackend._forward_graph``: entries die with the model generation they were captured under -- also when it is the warm-up of a NEW shape
-        that grew the workspace."""
+    def _graph_entry(self, x: torch.Tensor, info: Optional[PreprocInfo], code, body=None, extra_key=(), pre=None):
+        """``(graph, static input, static result, workspace, info)`` for device frames ``x`` with input code ``code`` (HipBackend.input_code).  ``body(raw_out, info)`` is what follows
+        the forward inside the graph (default: this layer's ``postprocess``; the bottom-up layer captures its GPU stage only), ``extra_key`` whatever else it bakes in.
+        ``pre`` (with ``info=None``): ``x`` is the batch BEFORE preprocessing and ``pre(static_in) -> (frames, info)`` -- channel coercion, sizematcher, input scale, stride
+        padding: launches that depend on the batch's shape only -- runs inside the graph too; its info record (a function of shapes and the preprocessing config) is kept with the entry.
+        Same stale-pointer discipline as ``HipBackend._forward_graph``: entries die with the model generation they were captured under -- also when it is the warm-up of a NEW
+        shape that grew the workspace."""
         be = self.backend
         dev = torch.device(be.device)
         body = body or self.postprocess
@@ -99,17 +101,25 @@ class InferenceLayer(ABC):
         if self.__dict__.get("_step_graph_generation") != be.model.generation:  # weights / options / workspace changed: captured pointers are stale
             graphs.clear()
             self.__dict__["_step_graph_generation"] = be.model.generation
-        # (everything the captured launches bake in: shapes, the input normalisation, the preprocessing scales, the post-process parameters)
-        eff = info.eff_scale
-        eff_key = (int(eff.numel()),) if bool((eff == 1.0).all()) else tuple(float(v) for v in eff.flatten().tolist())
-        key = (tuple(x.shape), x.dtype, code, eff_key, float(info.input_scale), int(info.output_stride), repr(self.postprocess_config), tuple(extra_key))
+        # (everything the captured launches bake in: shapes, the input normalisation, the preprocessing scales or config, the post-process parameters)
+        if pre is None:
+            eff = info.eff_scale
+            eff_key = (int(eff.numel()),) if bool((eff == 1.0).all()) else tuple(float(v) for v in eff.flatten().tolist())
+            key = (tuple(x.shape), x.dtype, code, eff_key, float(info.input_scale), int(info.output_stride), repr(self.postprocess_config), tuple(extra_key))
+        else:
+            key = (tuple(x.shape), x.dtype, code, "raw", repr(self.preprocess_config), int(self.max_stride), int(self.output_stride), repr(self.postprocess_config), tuple(extra_key))
         entry = graphs.get(key)
         if entry is None:
             static_in = x.clone()
+
+            def run():
+                xp, inf = pre(static_in) if pre is not None else (static_in, info)
+                return body(be.model.forward(xp.squeeze(1) if xp.dim() == 5 else xp, in_dtype=code), inf), inf
+
             side = torch.cuda.Stream(dev)
             side.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(side):  # warm-up outside the capture: handle creation, workspace allocation, lazy weight packs
-                body(be.model.forward(static_in.squeeze(1), in_dtype=code), info)
+                run()
             torch.cuda.current_stream(dev).wait_stream(side)
             torch.cuda.synchronize(dev)
             if self.__dict__["_step_graph_generation"] != be.model.generation:  # the warm-up grew the workspace / rebuilt the handle: older entries point into the old one
@@ -118,9 +128,9 @@ class InferenceLayer(ABC):
             graph = torch.cuda.CUDAGraph()
             # (thread_local: a host-stage worker thread of the pipelined predictor may wait on an event or recycle a pinned buffer while this thread captures)
             with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-                out = body(be.model.forward(static_in.squeeze(1), in_dtype=code), info)
+                out, inf = run()
             assert be.model.generation == self.__dict__["_step_graph_generation"], "capture must not reallocate"
-            entry = (graph, static_in, out, be.model._workspace)
+            entry = (graph, static_in, out, be.model._workspace, inf)
             graphs[key] = entry
         return entry
 

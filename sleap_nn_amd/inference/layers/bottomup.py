@@ -99,13 +99,20 @@ class BottomUpLayer(InferenceLayer):
         return {"buf": buf, "key": key, "event": ev, "B": B, "n_nodes": n_nodes, "peak_cap": int(peak_cap), "cand_cap": int(cand_cap), "n_head": int((2 + 2 * B) + (B + 1)),
                 "raw": raw_out, "info": info, "keep": packed}
 
-    def _enqueue_scoring_graphed(self, x: torch.Tensor, info: PreprocInfo) -> dict:
+    def _enqueue_scoring_graphed(self, x: torch.Tensor, info: Optional[PreprocInfo] = None) -> dict:
         """The whole GPU stage of a batch -- forward, peak finding, candidate scoring -- as ONE hipGraph replay per preprocessed input shape (``InferenceLayer._graph_entry``),
-        then the same asynchronous D2H as ``_enqueue_scoring``.  ``x``: preprocessed frames on the device.  Per batch the host issues a copy into the graph's input buffer, one
+        then the same asynchronous D2H as ``_enqueue_scoring``.  ``x``: preprocessed frames on the device with their ``info`` -- or, with ``info=None``, the uint8 batch BEFORE
+        preprocessing: its resize / pad launches are captured in front of the forward (they depend on the batch's shape only).  Per batch the host issues a copy into the graph's input buffer, one
         graph launch, one D2H and one event -- at batch 4 of a small network the ~25 kernel launches of the eager stage cost more host time than the GPU needs to run them.
         The handle finishes through ``_finish_packed`` (or ``_finish_scoring``); a batch whose peaks overflow the captured capacities is redone eagerly with larger ones, and the
         next capture takes those."""
         be = self.backend
+        pre = None
+        if info is None:
+            if x.dtype != torch.uint8:  # (float frames take normalize_on_gpu's data-dependent branch: a host read per batch; they are preprocessed outside the graph)
+                x, info = self.preprocess(x)
+            else:
+                pre = self.preprocess
         x, code = be.input_code(x)
         B = int(x.shape[0])
         n_nodes = self.paf_scorer.n_nodes
@@ -115,13 +122,13 @@ class BottomUpLayer(InferenceLayer):
             def body(raw, _info):
                 return self._scoring_launches(raw, peak_cap, cand_cap)
 
-            graph, static_in, packed, _ws = self._graph_entry(x, info, code, body=body, extra_key=("gpu stage", int(peak_cap), int(cand_cap), self.cms_output_stride))
+            graph, static_in, packed, _ws, info = self._graph_entry(x, info, code, body=body, extra_key=("gpu stage", int(peak_cap), int(cand_cap), self.cms_output_stride), pre=pre)
             if x.data_ptr() != static_in.data_ptr():
                 static_in.copy_(x, non_blocking=True)
             graph.replay()
             buf, key, ev = self._to_host_async(packed)
         return {"buf": buf, "key": key, "event": ev, "B": B, "n_nodes": n_nodes, "peak_cap": int(peak_cap), "cand_cap": int(cand_cap), "n_head": int((2 + 2 * B) + (B + 1)),
-                "raw": None, "x": x, "code": code, "info": info, "keep": packed}
+                "raw": None, "x": x, "pre": pre is not None, "code": code, "info": info, "keep": packed}
 
     def _redo_eagerly(self, h: dict) -> dict:
         """A handle whose capacities were exceeded (or whose maps are wanted back): the GPU stage again, kernel by kernel, with capacities grown from the counts it reported.
@@ -129,7 +136,8 @@ class BottomUpLayer(InferenceLayer):
         with self._gpu_lock:
             raw = h["raw"]
             if raw is None:  # a graphed handle holds no head tensors (the graph's static ones have been overwritten since): run the forward again
-                raw = self.backend.model.forward(h["x"].squeeze(1) if h["x"].dim() == 5 else h["x"], in_dtype=h["code"])
+                xin = self.preprocess(h["x"])[0] if h.get("pre") else h["x"]
+                raw = self.backend.model.forward(xin.squeeze(1) if xin.dim() == 5 else xin, in_dtype=h["code"])
             self._pinned[h["key"]] = []
             h2 = self._enqueue_scoring(raw, h["info"])
             h2["event"].synchronize()

@@ -8,6 +8,7 @@ worker thread; the ctypes call releases the GIL) with the GPU work of batch *i+1
 """
 from __future__ import annotations
 
+import contextlib
 from concurrent.futures import ThreadPoolExecutor
 from typing import Iterator, List, Optional, Sequence
 
@@ -77,21 +78,36 @@ def _select_layer(assets: Sequence[LoadedAssets], device: str, post: Postprocess
     raise ValueError(f"unsupported combination of model types: {sorted(by_type)}")
 
 
+_REPLICA_MAX_PARAMS = 16_000_000
+
+
 class Predictor:
-    def __init__(self, layer, batch_size: int = 4, use_graph: bool = True, window: int = 3) -> None:
+    def __init__(self, layer, batch_size: int = 4, use_graph: bool = True, window: int = 3, replicas: Sequence = ()) -> None:
         self.layer = layer  # any object exposing predict(image) -> Outputs (predictor.py:852-853)
         self.batch_size = batch_size
         self.use_graph = use_graph  # pipelined paths replay the GPU stage of a batch as one hipGraph per input shape
         self.window = window  # batches in flight ahead of the host stage
+        # Further copies of the layer (own model handle = own workspace, own graphs): the pipelined bottom-up path sends consecutive batches to the copies in turn, each on a HIP
+        # stream of its own.  A small network at batch 4 is a chain of launches with fewer work units than CUs (0.40 ms per batch whatever the frame size): two independent batches
+        # in flight fill the chip where one cannot, and one batch's H2D / D2H runs under the other's kernels.
+        self.replicas = list(replicas)
 
     @classmethod
     def from_model_paths(cls, model_paths: Sequence[str], device: str = "cuda", batch_size: int = 4, peak_threshold: float = 0.2,
                          integral_refinement: Optional[str] = "integral", integral_patch_size: int = 5, max_instances: Optional[int] = None,
-                         return_confmaps: bool = False, **paf_kw) -> "Predictor":
+                         return_confmaps: bool = False, streams: int = 2, **paf_kw) -> "Predictor":
+        """``streams``: bottom-up and top-down run directories of small networks (<= 16 M parameters) are loaded ``streams`` times; the pipelined ``predict`` keeps that many batches in flight
+        on streams of their own (see ``replicas``)."""
         assets = [load_model_assets(p) for p in model_paths]
         post = PostprocessConfig(peak_threshold=peak_threshold, refinement=integral_refinement or "none", integral_patch_size=integral_patch_size,
                                  max_instances=max_instances, return_confmaps=return_confmaps)
-        return cls(_select_layer(assets, device, post, max_instances, **paf_kw), batch_size)
+        layer = _select_layer(assets, device, post, max_instances, **paf_kw)
+        replicas = []
+        small = lambda l: l.backend.model.num_parameters() <= _REPLICA_MAX_PARAMS
+        if streams > 1 and ((isinstance(layer, BottomUpLayer) and small(layer)) or
+                            (isinstance(layer, TopDownLayer) and small(layer.centroid_layer) and small(layer.centered_instance_layer))):
+            replicas = [_select_layer(assets, device, post, max_instances, **paf_kw) for _ in range(streams - 1)]
+        return cls(layer, batch_size, replicas=replicas)
 
     def _staging(self) -> "_PinnedRing":
         ring = self.__dict__.get("_ring")
@@ -121,27 +137,54 @@ class Predictor:
 
     def _predict_two_stage_pipelined(self, frames) -> List[Outputs]:
         """Top-down batches, software-pipelined over the one host read a batch needs (the per-frame centroid counts between the stages): stage 1 of batch i + 1 is
-        enqueued BEFORE the counts of batch i are waited for, so the GPU works through that wait."""
-        layer = self.layer
+        enqueued BEFORE the counts of batch i are waited for, so the GPU works through that wait.  With ``replicas`` consecutive batches go to the copies in turn, each on a
+        stream of its own: the second stage of one batch runs beside the first stage of the next."""
+        layers = [self.layer] + list(self.replicas)
+        layer = layers[0]
+        for rep in layers[1:]:  # the copies follow whatever was set on the predictor's layer since they were made
+            for attr in ("crop_size", "centroid_nms", "centroid_nms_threshold", "return_crops"):
+                setattr(rep, attr, getattr(layer, attr))
+            for sub in ("centroid_layer", "centered_instance_layer"):
+                for attr in ("preprocess_config", "postprocess_config", "max_stride", "output_stride"):
+                    setattr(getattr(rep, sub), attr, getattr(getattr(layer, sub), attr))
+            rep.centroid_layer.max_instances = layer.centroid_layer.max_instances
         dev = torch.device(layer.centroid_layer.backend.device)
         stage = self._staging() if not frames.is_cuda else None
+        streams = self.__dict__.get("_streams")
+        if len(layers) > 1 and (streams is None or len(streams) != len(layers)):
+            streams = self.__dict__["_streams"] = [torch.cuda.Stream(dev) for _ in layers]
+        caller = torch.cuda.current_stream(dev)
+        if len(layers) > 1:
+            for st in streams:
+                st.wait_stream(caller)
+        on = (lambda k: torch.cuda.stream(streams[k])) if len(layers) > 1 else (lambda k: contextlib.nullcontext())
         outs: List[Outputs] = []
         prev = None
-        for s, batch in self._batch_iter(frames):
-            n = len(batch)
-            if stage is not None and not batch.is_pinned():
-                batch = stage.put(batch).to(dev, non_blocking=True)
-                stage.mark(dev)
-            h = layer._enqueue_stage1(batch.to(dev, non_blocking=True))
-            if prev is not None:
-                o = layer._finish(prev[2])
-                o.frame_indices = torch.arange(prev[0], prev[0] + prev[1])
-                outs.append(o)
-            prev = (s, n, h)
-        if prev is not None:
-            o = layer._finish(prev[2])
-            o.frame_indices = torch.arange(prev[0], prev[0] + prev[1])
+
+        def finish(p):
+            with on(p[3]):
+                o = layers[p[3]]._finish(p[2])
+            o.frame_indices = torch.arange(p[0], p[0] + p[1])
             outs.append(o)
+
+        for bi, (s, batch) in enumerate(self._batch_iter(frames)):
+            n = len(batch)
+            k = bi % len(layers)
+            with on(k):
+                if stage is not None and not batch.is_pinned():
+                    batch = stage.put(batch).to(dev, non_blocking=True)
+                    stage.mark(dev)
+                elif len(layers) > 1 and batch.is_cuda:
+                    batch.record_stream(streams[k])
+                h = layers[k]._enqueue_stage1(batch.to(dev, non_blocking=True))
+            if prev is not None:
+                finish(prev)
+            prev = (s, n, h, k)
+        if prev is not None:
+            finish(prev)
+        if len(layers) > 1:
+            for st in streams:
+                caller.wait_stream(st)
         return outs
 
     def _predict_streaming_pipelined(self, frames) -> List[Outputs]:
@@ -151,32 +194,49 @@ class Predictor:
         hipGraph (``BottomUpLayer._enqueue_scoring_graphed``: forward + peaks + candidate scoring, then one D2H + event); a worker thread waits for that event and
         turns the packed arena into ``Outputs`` with one native call (``_finish_packed``: the ctypes call and the event wait release the GIL).  No host read of a
         device value anywhere on the main thread: the GPU has the next batches queued while a batch is grouped."""
-        layer = self.layer
+        layers = [self.layer] + list(self.replicas)
+        layer = layers[0]
+        for rep in layers[1:]:  # the copies follow whatever was set on the predictor's layer since they were made
+            for attr in ("preprocess_config", "postprocess_config", "max_instances", "max_peaks_per_node", "paf_scorer", "cms_output_stride", "pafs_output_stride", "output_stride", "max_stride"):
+                setattr(rep, attr, getattr(layer, attr))
         graphed = self.use_graph and hasattr(layer.backend, "model") and hasattr(layer, "_enqueue_scoring_graphed")
+        if not graphed:
+            layers = layers[:1]
         dev = torch.device(layer.backend.device)
         outs: List[Optional[Outputs]] = []
         pending = []
         stage = self._staging() if not frames.is_cuda else None
+        streams = self.__dict__.get("_streams")
+        if len(layers) > 1 and (streams is None or len(streams) != len(layers)):
+            streams = self.__dict__["_streams"] = [torch.cuda.Stream(dev) for _ in layers]
+        caller = torch.cuda.current_stream(dev)
+        if len(layers) > 1:
+            for st in streams:
+                st.wait_stream(caller)  # (whatever the caller enqueued before predict() is done before the replicas' streams start)
 
-        def finish(h):
-            return layer._finish_packed(h)
+        def finish(k, h):
+            return layers[k]._finish_packed(h)
 
         pool = self.__dict__.get("_pool")
         if pool is None:  # one host-stage worker for the predictor's lifetime (a thread start and the first pinned allocations cost milliseconds: not per call)
             pool = self.__dict__["_pool"] = ThreadPoolExecutor(max_workers=1, thread_name_prefix="posehip-host-stage")
-        for s, batch in self._batch_iter(frames):
+        for bi, (s, batch) in enumerate(self._batch_iter(frames)):
             n = len(batch)
-            if stage is not None and not batch.is_pinned():
-                batch = stage.put(batch).to(dev, non_blocking=True)
-                stage.mark(dev)  # (the slot is free again as soon as this copy has run)
-            else:
-                batch = batch.to(dev, non_blocking=True)
-            x, info = layer.preprocess(batch)
-            if graphed:
-                h = layer._enqueue_scoring_graphed(x, info)
-            else:
-                h = layer._enqueue_scoring(layer.backend(x), info)  # async D2H, no sync
-            pending.append((s, n, pool.submit(finish, h)))
+            k = bi % len(layers)
+            with torch.cuda.stream(streams[k]) if len(layers) > 1 else contextlib.nullcontext():
+                if stage is not None and not batch.is_pinned():
+                    batch = stage.put(batch).to(dev, non_blocking=True)
+                    stage.mark(dev)  # (the slot is free again as soon as this copy has run)
+                else:
+                    if len(layers) > 1 and batch.is_cuda:
+                        batch.record_stream(streams[k])
+                    batch = batch.to(dev, non_blocking=True)
+                if graphed:
+                    h = layers[k]._enqueue_scoring_graphed(batch)  # (uint8 batches: preprocessing launches captured in front of the forward)
+                else:
+                    x, info = layer.preprocess(batch)
+                    h = layer._enqueue_scoring(layer.backend(x), info)  # async D2H, no sync
+            pending.append((s, n, pool.submit(finish, k, h)))
             while len(pending) > self.window:  # bounded window: at most `window` batches enqueued ahead of the grouping
                 s0, n0, fut = pending.pop(0)
                 o = fut.result()
@@ -186,6 +246,9 @@ class Predictor:
             o = fut.result()
             o.frame_indices = torch.arange(s0, s0 + n0)
             outs.append(o)
+        if len(layers) > 1:
+            for st in streams:
+                caller.wait_stream(st)
         return outs
 
 

@@ -805,8 +805,17 @@ def test_topdown_layer_reproduces_reference():
 
     frames = img.reshape(-1, *img.shape[-3:])
     frames = torch.cat([frames, frames.flip(-1), frames.flip(-2)], 0)
-    for bs in (1, 2):
-        outs = Predictor(td, batch_size=bs).predict(frames)
+    # (a second copy of the layer pair: with it consecutive batches alternate between two HIP streams)
+    mc2 = Model("unet", cc["backbone"], cc["heads"], "centroid")
+    mc2.load_state_dict(_wz(z, "wc/"))
+    mi2 = Model("unet", ci["backbone"], ci["heads"], "centered_instance")
+    mi2.load_state_dict(_wz(z, "wi/"))
+    td2 = TopDownLayer(CentroidLayer(HipBackend(mc2, DEV), cc["heads"]["confmaps"]["output_stride"], max_instances=6, max_stride=cc["backbone"]["max_stride"], postprocess_config=pc),
+                       CenteredInstanceLayer(HipBackend(mi2, DEV), ci["heads"]["confmaps"]["output_stride"], max_stride=ci["backbone"]["max_stride"], postprocess_config=PostprocessConfig(peak_threshold=0.03)),
+                       (cfg["crop_size"], cfg["crop_size"]), return_crops=True)
+    for bs, reps in ((1, []), (2, []), (1, [td2]), (2, [td2])):
+        outs = Predictor(td, batch_size=bs, replicas=reps).predict(frames)
+        assert len(outs) == (frames.shape[0] + bs - 1) // bs
         for s0, o in zip(range(0, frames.shape[0], bs), outs):
             r = td.predict(frames[s0 : s0 + bs])
             for f in ("pred_keypoints", "pred_crop_keypoints", "pred_peak_values", "pred_centroids", "pred_centroid_values", "instance_bboxes"):

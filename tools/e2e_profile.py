@@ -54,3 +54,38 @@ t0 = time.perf_counter()
 pred.predict(vid)
 dt = time.perf_counter() - t0
 print(f"pass with timed worker: {dt * 1e3:.1f} ms; worker: event wait {acc['sync'] * 1e3:.1f} ms, finish {acc['finish'] * 1e3:.1f} ms over {acc['n']} batches")
+
+# GPU time of the pieces of one pipelined batch (HIP events, 200 repetitions each)
+layer._finish_packed = orig_finish
+dev = torch.device("cuda:0")
+batch = vid[:4].pin_memory()
+bd = batch.to(dev)
+h = layer._enqueue_scoring_graphed(bd)
+torch.cuda.synchronize()
+entry = [e for e in layer._step_graphs.values() if e[1].shape == bd.shape][0]
+graph, static_in, packed = entry[0], entry[1], entry[2]
+host = torch.empty(packed.numel(), dtype=torch.float32, pin_memory=True)
+
+
+def gpu_us(fn, n=200):
+    for _ in range(10):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return 1e3 * e0.elapsed_time(e1) / n
+
+
+print(f"graph replay (resize + pad + forward at {tuple(entry[4].processed_size)} + peaks + PAF scoring): {gpu_us(graph.replay):.1f} us")
+print(f"H2D of the batch ({batch.numel() / 1e3:.0f} KB, pinned -> graph input): {gpu_us(lambda: static_in.copy_(batch, non_blocking=True)):.1f} us")
+print(f"D2H of the arena ({packed.numel() * 4 / 1e3:.0f} KB): {gpu_us(lambda: host.copy_(packed, non_blocking=True)):.1f} us")
+xp, info = layer.preprocess(bd)
+be = layer.backend
+print(f"preprocess alone (resize + pad): {gpu_us(lambda: layer.preprocess(bd)):.1f} us (host-bound if > the kernels)")
+fg = torch.cuda.CUDAGraph()
+with torch.cuda.graph(fg):
+    raw = be.model.forward(xp.squeeze(1))
+print(f"forward alone at {tuple(xp.shape)} (graph): {gpu_us(fg.replay):.1f} us")
