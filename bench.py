@@ -40,6 +40,7 @@ cfg3 UNet or the cfg4 ConvNeXt-tiny (``--train-config``) as the headline of the 
 from __future__ import annotations
 
 import argparse
+import contextlib
 import json
 import os
 import socket
@@ -221,6 +222,8 @@ def legs_summary(full: dict) -> dict:
         if isinstance(full.get(k), dict):
             leg = full[k]
             s[k] = {"value": _num(leg.get("value")), "unit": leg.get("unit"), "ms_per_step": _num(leg.get("ms_per_step")), "mfma_frac": _num(_pick(leg, "roofline", "frac"))}
+            if _pick(leg, "two_streams", "value") is not None:
+                s[k]["two_streams"] = _num(_pick(leg, "two_streams", "value"))
     pw = full.get("published_workload")
     if isinstance(pw, dict):
         s["published_workload"] = {"forward_ms_per_batch4": _num(pw.get("value")), "forward_frames_per_s": _num(pw.get("frames_per_s_forward")),
@@ -232,6 +235,8 @@ def legs_summary(full: dict) -> dict:
     sh = full.get("strong_scaling_shards")
     if isinstance(sh, dict):
         s["one_gpu_shard_frames_per_s"] = {k: _num(v.get("value")) for k, v in sh.items() if isinstance(v, dict)}
+        if any(isinstance(v, dict) and "two_streams" in v for v in sh.values()):
+            s["one_gpu_shard_two_streams_frames_per_s"] = {k: _num(_pick(v, "two_streams", "value")) for k, v in sh.items() if isinstance(v, dict)}
     ws = full.get("weak_scaling")
     if isinstance(ws, dict):
         s["weak_scaling_frames_per_s"] = _num(ws.get("value"))
@@ -440,6 +445,16 @@ def run_infer(args, ctx):
     pool = ThreadPoolExecutor(max_workers=1)
     params = layer.grouping_params()
     pending, inflight = [], []
+    # Multi-GPU strong scaling leaves a rank a few frames per step (4 at 8 GPUs): most launches of such a step have fewer work units than CUs.  Consecutive steps then alternate
+    # between TWO copies of the network on two HIP streams (as Predictor.from_model_paths(streams=2) does for small networks): +3.5 % at 8 frames, +7 % at 4 on one GPU
+    # (strong_scaling_shards.*.two_streams).  Never at N = 1 / 32 frames per step: there every launch fills the chip.
+    lanes = [(backend, layer, None)]
+    if world > 1 and use_graph and B <= 8:
+        model_b = Model("unet", CFG3_BB, CFG3_HEADS, "bottomup")
+        model_b.init_xavier_(seed=1234, head_scale=0.05)
+        backend_b = HipBackend(model_b, str(dev), use_graph=True, precision=precision)
+        lanes = [(backend, layer, torch.cuda.Stream(dev)), (backend_b, BottomUpLayer(backend_b, PAFScorer.from_config(CFG3_HEADS), 4, 8, max_stride=32), torch.cuda.Stream(dev))]
+    step_no, last_stream = [0], [None]
 
     heads_in = {"cms": cms, "pafs": pafs, "info": info}  # rebound for the weak-scaling leg of a multi-GPU run
 
@@ -448,16 +463,22 @@ def run_infer(args, ctx):
         results (its D2H event fired long ago) are handed to the C++ grouping worker.  The GPU always has the
         next batch queued and the grouping of batch k-1 overlaps the GPU work of batch k
         (Predictor._predict_streaming_pipelined).  Every batch is grouped before the closing barrier."""
-        raw = (eager if profiled else backend)(x)  # uint8 frames -> {"MultiInstanceConfmapsHead", "PartAffinityFieldsHead"}
-        inflight.append(layer._enqueue_scoring({"MultiInstanceConfmapsHead": heads_in["cms"], "PartAffinityFieldsHead": heads_in["pafs"]}, heads_in["info"]))
-        if len(inflight) > 1:
-            pending.append(pool.submit(group_scored_batch, layer._finish_scoring(inflight.pop(0)), params))
+        be_k, layer_k, stream_k = lanes[0 if (profiled or len(lanes) == 1 or x.shape[0] > 8) else step_no[0] % len(lanes)]
+        step_no[0] += 1
+        last_stream[0] = stream_k if stream_k is not None else torch.cuda.current_stream(dev)
+        with torch.cuda.stream(stream_k) if stream_k is not None else contextlib.nullcontext():
+            raw = (eager if profiled else be_k)(x)  # uint8 frames -> {"MultiInstanceConfmapsHead", "PartAffinityFieldsHead"}
+            inflight.append((layer_k, layer_k._enqueue_scoring({"MultiInstanceConfmapsHead": heads_in["cms"], "PartAffinityFieldsHead": heads_in["pafs"]}, heads_in["info"])))
+        if len(inflight) > len(lanes):
+            ly, h = inflight.pop(0)
+            pending.append(pool.submit(group_scored_batch, ly._finish_scoring(h), params))
         out = pending.pop(0).result() if len(pending) > 1 else None
         return raw, out
 
     def drain():
         while inflight:
-            pending.append(pool.submit(group_scored_batch, layer._finish_scoring(inflight.pop(0)), params))
+            ly, h = inflight.pop(0)
+            pending.append(pool.submit(group_scored_batch, ly._finish_scoring(h), params))
         outs = [f.result() for f in pending]
         pending.clear()
         return outs
@@ -518,9 +539,10 @@ def run_infer(args, ctx):
         t0 = time.perf_counter()
         for i in range(args.steps):
             upload(i + 1)  # rides under step i's kernels
-            torch.cuda.current_stream().wait_event(landed[i & 1])
+            for _be, _ly, st in lanes:  # (whichever stream runs the step)
+                (st if st is not None else torch.cuda.current_stream()).wait_event(landed[i & 1])
             step(bufs[i & 1])
-            consumed[i & 1].record()
+            consumed[i & 1].record(last_stream[0])
         drain()
         barrier()
         elapsed_h2d = time.perf_counter() - t0
@@ -609,7 +631,54 @@ def run_infer(args, ctx):
             torch.cuda.synchronize()
             dt = time.perf_counter() - t1
             shards[f"{sb}_frames_per_rank"] = {"value": sb * n_s / dt, "unit": "frames/s per GPU", "ms_per_step": 1e3 * dt / n_s, "steps": n_s, "stands_for": f"one rank of --gpus {32 // sb} --scaling strong"}
+            # the same steps alternating between TWO copies of the network on two HIP streams (what Predictor.from_model_paths(streams=2) does for small networks): a step of a few
+            # frames leaves CUs idle in most launches, two independent steps in flight fill them
+            if use_graph:
+                if "lane2" not in heads_in:
+                    model2 = Model("unet", CFG3_BB, CFG3_HEADS, "bottomup")
+                    model2.init_xavier_(seed=1234, head_scale=0.05)
+                    backend2 = HipBackend(model2, str(dev), use_graph=True, precision=precision)
+                    heads_in["lane2"] = (backend2, BottomUpLayer(backend2, PAFScorer.from_config(CFG3_HEADS), 4, 8, max_stride=32), [torch.cuda.Stream(dev), torch.cuda.Stream(dev)])
+                backend2, layer2, lanes_st = heads_in["lane2"]
+                sframes2 = backend2.static_input((sb, 1, SIZE, SIZE)).copy_(sframes)
+                lanes = ((backend, layer, sframes), (backend2, layer2, sframes2))
+                fl, futs = [], []
+
+                def step2(i):
+                    k = i & 1
+                    be_k, ly_k, x_k = lanes[k]
+                    with torch.cuda.stream(lanes_st[k]):
+                        be_k(x_k)
+                        fl.append((ly_k, ly_k._enqueue_scoring({"MultiInstanceConfmapsHead": heads_in["cms"], "PartAffinityFieldsHead": heads_in["pafs"]}, heads_in["info"])))
+                    if len(fl) > 2:
+                        ly0, h0 = fl.pop(0)
+                        futs.append(pool.submit(group_scored_batch, ly0._finish_scoring(h0), params))
+                    if len(futs) > 2:
+                        futs.pop(0).result()
+
+                def drain2():
+                    while fl:
+                        ly0, h0 = fl.pop(0)
+                        futs.append(pool.submit(group_scored_batch, ly0._finish_scoring(h0), params))
+                    for f in futs:
+                        f.result()
+                    futs.clear()
+
+                torch.cuda.synchronize()
+                for i in range(6):
+                    step2(i)
+                drain2()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for i in range(n_s):
+                    step2(i)
+                drain2()
+                torch.cuda.synchronize()
+                dt2 = time.perf_counter() - t1
+                shards[f"{sb}_frames_per_rank"]["two_streams"] = {"value": sb * n_s / dt2, "unit": "frames/s per GPU", "ms_per_step": 1e3 * dt2 / n_s,
+                                                                 "what": "consecutive steps alternate between two copies of the network on two HIP streams"}
         heads_in.update(cms=cms, pafs=pafs, info=info)
+        heads_in.pop("lane2", None)
         del scms, spafs, sframes
 
     t = torch.tensor([elapsed, elapsed_h2d or 0.0, elapsed_weak or 0.0], dtype=torch.float64, device=dev)
@@ -708,7 +777,7 @@ def run_infer(args, ctx):
             "params": model.num_parameters(), "conv_gflop_per_frame": sum(r["flops"] for r in model.op_table(1, SIZE, SIZE)) / 1e9,
             "forward_launch": "hipGraph replay (steps with per-op events launch kernel by kernel)" if use_graph else "kernel by kernel",
             "inputs": "uint8 frames resident in HBM when the timed region starts",
-            "rccl_ranks_seen": ranks_seen, "frames_per_step_by_rank": per_rank_frames,
+            "rccl_ranks_seen": ranks_seen, "frames_per_step_by_rank": per_rank_frames, "streams_per_rank": len(lanes),
             "host_threads": {"cores_visible": (len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)), "per_rank": 2, "ranks": world,
                              "what": "one Python thread that enqueues the GPU work (and the pinned H2D staging of the h2d_inclusive leg) + one C++ grouping worker per rank",
                              "fits": 2 * world <= (len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))},
@@ -1082,8 +1151,27 @@ def single_instance_leg(name, size, batch, n_nodes, steps, dev, with_cpu):
     # throughput: the same steps enqueued back to back (the layer's outputs stay on the device: no host sync inside a step), one sync at the end
     total_q, _ = _time_calls(lambda: layer.predict_graphed(gframes), steps, 10, False)
     total_eager_q, _ = _time_calls(lambda: layer.predict(frames), steps, 10, False)
+    two = None
     if batch > 1:  # a batch is a throughput workload (`value` = queued steps); one frame is a latency workload (`value` = 1 / median synchronous step)
         total = total_q
+        # ... and the same queued steps alternating between TWO copies of the network on two HIP streams: most launches of an 8-frame step have fewer work units than CUs
+        model2 = Model("unet", SI_BB, heads, "single_instance").init_xavier_(seed=1234, head_scale=0.05).to(dev)
+        layer2 = SingleInstanceLayer(HipBackend(model2, str(dev), use_graph=True), 2, max_stride=16, postprocess_config=PostprocessConfig(peak_threshold=0.0))
+        g2 = layer2.graph_input(tuple(frames.shape)).copy_(frames)
+        assert torch.equal(torch.nan_to_num(layer2.predict_graphed(g2).pred_keypoints), torch.nan_to_num(got_out.pred_keypoints))
+        sts = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+        pair = ((layer, gframes), (layer2, g2))
+        cnt = [0]
+
+        def step2():
+            k = cnt[0] & 1
+            cnt[0] += 1
+            with torch.cuda.stream(sts[k]):
+                pair[k][0].predict_graphed(pair[k][1])
+
+        total_2, _ = _time_calls(step2, steps, 10, False)
+        two = {"value": batch * steps / total_2, "unit": "frames/s", "what": "the queued steps alternating between two copies of the network on two HIP streams (outputs left on the device)"}
+        del layer2, model2
     else:
         total = steps * lat_us[len(lat_us) // 2] * 1e-6
     res = {"metric": f"frames/sec single-instance UNet {size}x{size} inference (batch {batch})", "value": batch * steps / total, "unit": "frames/s", "steps": steps, "ms_per_step": 1e3 * total / steps,
@@ -1095,6 +1183,8 @@ def single_instance_leg(name, size, batch, n_nodes, steps, dev, with_cpu):
            "latency_us_per_step": {"median": lat_us[len(lat_us) // 2], "p10": lat_us[len(lat_us) // 10], "p90": lat_us[(9 * len(lat_us)) // 10]},
            "forward_only": {"us_per_batch": 1e6 * fwd_s, "frames_per_s": batch / fwd_s, "launch": "hipGraph replay, back to back, no host sync"},
            "roofline": _small_roofline(executed, direct, matrix_ms, fwd_s, kernels, len(table))}
+    if two is not None:
+        res["two_streams"] = two
     if with_cpu:  # cfg1 IS the reference-CPU-path configuration of BASELINE.json: the oracle on this box's host cores, same weights, same frame, parity beside it
         from oracle import cpu_ref as O
 

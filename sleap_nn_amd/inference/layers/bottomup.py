@@ -97,7 +97,7 @@ class BottomUpLayer(InferenceLayer):
         packed = self._scoring_launches(raw_out, peak_cap, cand_cap)
         buf, key, ev = self._to_host_async(packed)
         return {"buf": buf, "key": key, "event": ev, "B": B, "n_nodes": n_nodes, "peak_cap": int(peak_cap), "cand_cap": int(cand_cap), "n_head": int((2 + 2 * B) + (B + 1)),
-                "raw": raw_out, "info": info, "keep": packed}
+                "raw": raw_out, "info": info, "keep": packed, "stream": torch.cuda.current_stream(cms.device)}
 
     def _enqueue_scoring_graphed(self, x: torch.Tensor, info: Optional[PreprocInfo] = None) -> dict:
         """The whole GPU stage of a batch -- forward, peak finding, candidate scoring -- as ONE hipGraph replay per preprocessed input shape (``InferenceLayer._graph_entry``),
@@ -128,12 +128,12 @@ class BottomUpLayer(InferenceLayer):
             graph.replay()
             buf, key, ev = self._to_host_async(packed)
         return {"buf": buf, "key": key, "event": ev, "B": B, "n_nodes": n_nodes, "peak_cap": int(peak_cap), "cand_cap": int(cand_cap), "n_head": int((2 + 2 * B) + (B + 1)),
-                "raw": None, "x": x, "pre": pre is not None, "code": code, "info": info, "keep": packed}
+                "raw": None, "x": x, "pre": pre is not None, "code": code, "info": info, "keep": packed, "stream": torch.cuda.current_stream(x.device)}
 
     def _redo_eagerly(self, h: dict) -> dict:
         """A handle whose capacities were exceeded (or whose maps are wanted back): the GPU stage again, kernel by kernel, with capacities grown from the counts it reported.
         May run on the host-stage worker thread: serialised against the enqueueing thread's captures / replays by ``_gpu_lock``, and complete (synchronised) on return."""
-        with self._gpu_lock:
+        with self._gpu_lock, torch.cuda.stream(h["stream"]):  # (on the stream the batch was enqueued on: the handle's workspace is in use there)
             raw = h["raw"]
             if raw is None:  # a graphed handle holds no head tensors (the graph's static ones have been overwritten since): run the forward again
                 xin = self.preprocess(h["x"])[0] if h.get("pre") else h["x"]

@@ -224,6 +224,14 @@ def test_pipelined_predictor_graphed_gpu_stage_equals_the_eager_layer():
     ref1 = pred.predict(vid, pipelined=False)
     assert ref1[0].pred_keypoints.shape[1] == 1
     same(pred.predict(vid), ref1)
+    # a caller that wants the maps back: the worker redoes such a batch eagerly on the stream it was enqueued on (two copies of the layer on two streams here)
+    pc = Predictor.from_model_paths([root], device=DEV, batch_size=4, peak_threshold=0.2, return_confmaps=True)
+    assert len(pc.replicas) == 1
+    refc = pc.predict(vid, pipelined=False)
+    gotc = pc.predict(vid)
+    same(gotc, refc)
+    for o, r in zip(gotc, refc):
+        assert o.pred_confmaps is not None and torch.equal(o.pred_confmaps, r.pred_confmaps.cpu())
     # capacity overflow: a fresh layer whose captured capacities are too small for the frames redoes the batch eagerly with larger ones -- same results
     pred2 = Predictor.from_model_paths([root], device=DEV, batch_size=4, peak_threshold=0.2)
     pred2.layer._capacities = lambda B, n, _l=pred2.layer: (max(_l._peak_cap, 2), max(_l._cand_cap, 1))
