@@ -128,11 +128,47 @@ class Predictor:
             return self._predict_streaming_pipelined(frames)
         if pipelined and hasattr(self.layer, "_enqueue_stage1"):
             return self._predict_two_stage_pipelined(frames)
+        if pipelined and hasattr(self.layer, "_enqueue_postprocess"):
+            return self._predict_host_stage_pipelined(frames)
         outs = []
         for s, batch in self._batch_iter(frames):
             o = self.layer.predict(batch)
             o.frame_indices = torch.arange(s, s + len(batch))
             outs.append(o)
+        return outs
+
+    def _predict_host_stage_pipelined(self, frames) -> List[Outputs]:
+        """Layers whose post-process splits into a GPU stage that ends in one asynchronous D2H (``_enqueue_postprocess``) and a host stage (``_finish_postprocess``) -- multi-class
+        bottom-up: Hungarian matching by class --: the host stage of batch i runs in the worker while the GPU stage of batch i + 1 is enqueued."""
+        layer = self.layer
+        dev = torch.device(layer.backend.device)
+        stage = self._staging() if not frames.is_cuda else None
+        pool = self.__dict__.get("_pool")
+        if pool is None:
+            pool = self.__dict__["_pool"] = ThreadPoolExecutor(max_workers=1, thread_name_prefix="posehip-host-stage")
+        outs: List[Outputs] = []
+        pending = []
+
+        def collect():
+            s0, n0, fut = pending.pop(0)
+            o = fut.result()
+            o.frame_indices = torch.arange(s0, s0 + n0)
+            outs.append(o)
+
+        for s, batch in self._batch_iter(frames):
+            n = len(batch)
+            if stage is not None and not batch.is_pinned():
+                batch = stage.put(batch).to(dev, non_blocking=True)
+                stage.mark(dev)
+            else:
+                batch = batch.to(dev, non_blocking=True)
+            x, info = layer.preprocess(batch)
+            h = layer._enqueue_postprocess(layer.backend(x), info)
+            pending.append((s, n, pool.submit(layer._finish_postprocess, h)))
+            while len(pending) > self.window:
+                collect()
+        while pending:
+            collect()
         return outs
 
     def _predict_two_stage_pipelined(self, frames) -> List[Outputs]:

@@ -849,6 +849,17 @@ def test_multiclass_bottomup_layer_reproduces_reference_golden():
     assert np.array_equal(np.isnan(k), np.isnan(z["gold_peaks"]))
     assert np.allclose(k, z["gold_peaks"], atol=1e-3, equal_nan=True)
     assert np.allclose(out.pred_peak_values.numpy(), z["peak_vals"], atol=CMS_ATOL, equal_nan=True)
+    # the pipelined predictor (GPU stage of batch i + 1 enqueued before the host stage of batch i is collected) returns what predict returns, batch by batch
+    from sleap_nn_amd.inference.predictor import Predictor
+
+    frames = torch.from_numpy(z["image"]).squeeze(1)
+    frames = torch.cat([frames, frames.flip(-1), frames.flip(-2)], 0)
+    outs = Predictor(layer, batch_size=2).predict(frames)
+    assert len(outs) == (frames.shape[0] + 1) // 2
+    for s0, o in zip(range(0, frames.shape[0], 2), outs):
+        r = layer.predict(frames[s0 : s0 + 2])
+        for f in ("pred_keypoints", "pred_peak_values", "instance_scores", "instance_tracking_scores"):
+            assert np.array_equal(getattr(o, f).numpy(), getattr(r, f).numpy(), equal_nan=True), (s0, f)
     # randomized KAT (ties, .5 coordinates) straight through the ops
     p, v, c = classify_peaks_from_maps(torch.from_numpy(z["kat/class_maps"]).to(DEV), torch.from_numpy(z["kat/pts"]).to(DEV), torch.from_numpy(z["kat/vals"]).to(DEV),
                                        torch.from_numpy(z["kat/sb"]).to(DEV), torch.from_numpy(z["kat/sc"]).to(DEV), 4)
