@@ -204,7 +204,7 @@ void apply_conv_options(const ph_model* m, ConvArgs& a) {
   a.dma_stagger = m->dma_stagger;
   a.splitk = m->conv_splitk;  // (ph_model_forward clears it for a training plan unless a slice count is forced)
   a.split_counters = m->split_counters_dev;
-  a.split_counters_n = m->split_counters_dev ? 4096 : 0;
+  a.split_counters_n = m->split_counters_dev ? 4096 : 0;  // (units; the buffer holds three words per unit)
   a.splitk_finish = m->conv_splitk_finish;
 }
 
@@ -468,7 +468,7 @@ ph_model* ph_model_create(const ph_op_desc* ops, int32_t n_ops, const float* con
       ph_model_destroy(m);
       return nullptr;
     }
-    std::vector<float> zc(4096, 0.f);  // (uploaded as floats: all-zero bits either way)
+    std::vector<float> zc(3 * 4096, 0.f);  // (uploaded as floats: all-zero bits either way; arrivals | claimed shares | departures per split-K unit)
     float* cdev = nullptr;
     if (upload(m, zc, &cdev) != PH_OK) {
       ph_model_destroy(m);

@@ -114,7 +114,7 @@ struct ph_model {
   hipEvent_t bucket_event = nullptr;          // recorded mid-backward when the arena tail is final (ph_model_set_bucket_event)
   float* zeros_dev = nullptr;                 // zero page for LDS-DMA halo padding
   unsigned* split_counters_dev = nullptr;     // PH_SPLIT_COUNTERS zeroed counters of the split-K launches' in-kernel second stage (a handle's forwards are serialised, as its plan / profiling state already requires)
-  int conv_splitk_finish = 0;                 // "conv_splitk_finish": 1 = the last-arriving workgroup of a split-K unit runs the second stage in the same launch, 0 (default) = splitk_reduce_kernel as a launch of its own.  Measured (cfg1): the in-kernel form is SLOWER, 391 vs 322 us per forward -- one workgroup adds up to 24 planes of its 64-KiB tile at one CU's memory rate (10 - 20 us), the separate launch spreads the same bytes over the whole chip in ~6 us
+  int conv_splitk_finish = 0;                 // "conv_splitk_finish": 0 (default) = splitk_reduce_kernel as a launch of its own; 1 = the last-arriving workgroup of a split-K unit runs the second stage in the same launch; 2 (round 5) = the unit's workgroups wait (bounded) for all slices and SHARE the second stage (claimed by atomic bits; the last arriver sweeps unclaimed shares: no deadlock).  All three bit-identical.  Measured (cfg1 forward): 299 us (0) / 391 (1: one workgroup adds up to 24 planes of its 64-KiB tile at one CU's memory rate) / 370 (2: the wait for the slowest slice + device-scope fences + remote reads of the other XCDs' planes cost more than the ~6-us launch that spreads the same bytes over the chip)
   std::vector<int64_t> weight_offset;          // canonical arena offset of weights[i] (ph_model_create order)
   std::vector<int64_t> weight_numel;
   int64_t n_params = 0;

@@ -54,7 +54,7 @@ struct ConvArgs {
   long long split_stride = 0;         // floats per scratch plane
   unsigned* split_counters = nullptr; // zeroed device counters, one per (pixel tile, N tile) of a split launch (owned by the model handle): the workgroup that stores a unit's last
   int split_counters_n = 0;           //   K slice runs the second stage itself; nullptr = the second stage is a launch of its own (splitk_reduce_kernel)
-  int splitk_finish = 0;              // handle option "conv_splitk_finish": 1 = in-kernel second stage (measured slower: one CU's memory rate), 0 = the two-launch form
+  int splitk_finish = 0;              // handle option "conv_splitk_finish": 0 = the two-launch form (default, fastest), 1 = in-kernel second stage by the last arriver, 2 = shared by the unit's workgroups (both measured slower)
   float* fin_dst = nullptr;           // filled by the launcher: the layer's real outputs / parameters for the in-kernel second stage
   float* fin_dst_pool = nullptr;
   const float* fin_bias = nullptr;

@@ -795,27 +795,51 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_kernel(ConvArgs a) {
       }
     }
     if (KS && a.split_counters) {
-      // In-kernel second stage: the workgroup that stores the LAST K slice of a (pixel tile, N tile) -- whichever that is -- adds the slices' planes in slice order
-      // (the result does not depend on who is last), applies bias / ReLU / pool and stores the layer's real output: no second launch.  Release / acquire through a
-      // device-scope counter: every workgroup fences its stores before its increment, the last one fences again before it reads the other workgroups' planes (first
-      // touched by this CU in this launch: the L1 is invalidated at kernel start); it leaves the counter at zero for the next launch (hipGraph replays included).
+      // In-kernel second stage (no second launch).  Release / acquire through device-scope counters: every workgroup fences its stores before its increment, whoever reads other
+      // workgroups' planes fences again before it does (first touched by this CU in this launch: the L1 is invalidated at kernel start).  The planes are added in slice order
+      // whoever adds them: the result does not depend on who does which part.
+      //   splitk_finish 1: the workgroup that stores the LAST K slice of a (pixel tile, N tile) does the whole second stage (up to 24 planes of a 64-KiB tile at ONE CU's memory rate:
+      //     measured slower than the separate launch).
+      //   splitk_finish 2 (round 5): the unit's ksplit workgroups SHARE it.  A workgroup that has stored its slice waits -- bounded: ~25 us -- until all slices have arrived, then
+      //     claims share `its slice index` of the tile's items (an atomic bit per share) and reduces it; the last arriver, which never waits, also sweeps every share nobody has
+      //     claimed by then (a workgroup that gave up waiting, e.g. because its siblings were not resident yet beside another stream's kernel, leaves without claiming: no
+      //     deadlock, every share is done exactly once).  The last workgroup to LEAVE the unit zeroes its three words for the next launch (hipGraph replays included).
       __syncthreads();  // (s_waitcnt vmcnt(0): this workgroup's partial sums have left the CU)
-      float* const flag = spare + 4095;
+      int* const flags = reinterpret_cast<int*>(spare + 4092);  // [0] all slices arrived, [1] this workgroup is the last arriver, [2] share claimed
       const int unit = ((P.b * tiles_y + P.y0 / W2_T) * tiles_x + P.x0 / W2_T) * ntc + P.ntile;
+      const bool shared = a.splitk_finish >= 2 && a.ksplit <= 32 && total <= (int)gridDim.x;
+      unsigned* const cnt = a.split_counters + unit;
+      unsigned* const claimed = a.split_counters + a.split_counters_n + unit;
+      unsigned* const departed = a.split_counters + 2 * a.split_counters_n + unit;
       if (tid == 0) {
         __threadfence();
-        const unsigned old = atomicAdd(a.split_counters + unit, 1u);
+        const unsigned old = atomicAdd(cnt, 1u);
         const bool last = old + 1u == (unsigned)a.ksplit;
-        if (last) a.split_counters[unit] = 0u;
+        bool complete = last;
+        if (shared && !last) {
+          const long long t0 = (long long)__builtin_amdgcn_s_memtime();
+          while (true) {
+            if (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)a.ksplit) {
+              complete = true;
+              break;
+            }
+            if ((long long)__builtin_amdgcn_s_memtime() - t0 > 50000ll) break;
+            __builtin_amdgcn_s_sleep(8);
+          }
+        }
+        if (!shared && last) *cnt = 0u;
         __threadfence();
-        *flag = last ? 1.f : 0.f;
+        flags[0] = complete ? 1 : 0;
+        flags[1] = last ? 1 : 0;
       }
       __syncthreads();
-      if (*flag != 0.f) {
-        const int cq = min(BN, a.coutp - P.ntile * BN) >> 2;  // channel quads of this N tile that exist
-        const float* part = a.dst;                             // (the launch's dst IS the scratch tensor)
+      const bool complete = flags[0] != 0, last = flags[1] != 0;
+      const int cq = min(BN, a.coutp - P.ntile * BN) >> 2;  // channel quads of this N tile that exist
+      const float* part = a.dst;                             // (the launch's dst IS the scratch tensor)
+      // items [i0, i1) of the unit's second stage: 2 x 2 pool windows (or pixels) x channel quads
+      auto reduce_items = [&](int i0, int i1) __attribute__((always_inline)) {
         if (a.fin_dst_pool) {
-          for (int i = tid; i < 64 * cq; i += 512) {
+          for (int i = i0 + tid; i < i1; i += 512) {
             const int c4 = i % cq, w = i / cq;
             const int py = (P.y0 >> 1) + (w >> 3), px = (P.x0 >> 1) + (w & 7);
             if (2 * py < a.H && 2 * px < a.W) {
@@ -825,7 +849,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_kernel(ConvArgs a) {
             }
           }
         } else {
-          for (int i = tid; i < 256 * cq; i += 512) {
+          for (int i = i0 + tid; i < i1; i += 512) {
             const int c4 = i % cq, pxl = i / cq;
             const int oy = P.y0 + (pxl >> 4), ox = P.x0 + (pxl & 15);
             if (oy < a.H && ox < a.W) {
@@ -840,8 +864,33 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_kernel(ConvArgs a) {
             }
           }
         }
+      };
+      const int n_items = (a.fin_dst_pool ? 64 : 256) * cq;
+      if (!shared) {
+        if (last) reduce_items(0, n_items);
+      } else {
+        if (complete) {
+          for (int sh = 0; sh < a.ksplit; ++sh) {  // own share first; the last arriver then offers itself for every other one
+            const int share = (P.ks + sh) % a.ksplit;
+            if (sh > 0 && !last) break;
+            __syncthreads();
+            if (tid == 0) flags[2] = ((atomicOr(claimed, 1u << share) >> share) & 1u) ? 0 : 1;
+            __syncthreads();
+            if (flags[2]) reduce_items((int)((long long)share * n_items / a.ksplit), (int)((long long)(share + 1) * n_items / a.ksplit));
+          }
+        }
+        __syncthreads();
+        if (tid == 0) {
+          __threadfence();
+          if (atomicAdd(departed, 1u) + 1u == (unsigned)a.ksplit) {  // the last one out zeroes the unit's words
+            *cnt = 0u;
+            *claimed = 0u;
+            *departed = 0u;
+            __threadfence();
+          }
+        }
       }
-      __syncthreads();  // (the flag word is rewritten by the next unit)
+      __syncthreads();  // (the flag words are rewritten by the next unit)
     }
     W2_STAMP(st_e3)
 #ifdef PH_W2_STAMP
@@ -976,7 +1025,7 @@ int launch_conv3x3_wino2d(const ConvArgs& a, hipStream_t s) {
     k.skip_dst = 0;
     k.ksplit = ksplit;
     k.split_stride = (long long)a.B * a.H * a.W * a.coutp;
-    const bool in_kernel = a.split_counters && tiles * ntc <= a.split_counters_n && a.splitk_finish;
+    const bool in_kernel = a.split_counters && tiles * ntc <= a.split_counters_n && a.splitk_finish;  // (split_counters holds 3 x split_counters_n words: arrivals, claimed shares, departures)
     if (in_kernel) {  // the last-arriving workgroup of a (pixel tile, N tile) finishes it: one launch
       k.fin_dst = a.skip_dst ? nullptr : a.dst;
       k.fin_dst_pool = a.dst_pool;

@@ -117,11 +117,11 @@ def test_split_k_winograd_kernel_matches_the_one_stage_kernel_and_the_oracle(fil
     img = torch.randint(0, 256, (batch, 1, hw[0], hw[1]), dtype=torch.uint8, generator=g)
     ref = O.model_forward(sd, bb, heads, "single_instance", img)["SingleInstanceConfmapsHead"]
     outs, kinds = {}, {}
-    for name, ks, finish in (("split", splitk, 0), ("in_kernel", splitk, 1), ("one", 0, 0)):
+    for name, ks, finish in (("split", splitk, 0), ("in_kernel", splitk, 1), ("shared", splitk, 2), ("one", 0, 0)):
         m = Model("unet", bb, heads, "single_instance")
         m.load_state_dict(sd)
         m.set_option("conv_splitk", ks)
-        m.set_option("conv_splitk_finish", finish)  # 0 (default): splitk_reduce_kernel; 1: the workgroup that stores a unit's last K slice runs the second stage
+        m.set_option("conv_splitk_finish", finish)  # 0: splitk_reduce_kernel; 1: the workgroup that stores a unit's last K slice runs the second stage; 2: the unit's workgroups share it
         outs[name] = m.to(DEV)(img.to(DEV))["SingleInstanceConfmapsHead"].cpu()
         kinds[name] = m.last_kernels()
         if name != "one":
@@ -129,7 +129,7 @@ def test_split_k_winograd_kernel_matches_the_one_stage_kernel_and_the_oracle(fil
                 again = m(img.to(DEV))["SingleInstanceConfmapsHead"].cpu()
                 assert torch.equal(again, outs[name])
     assert L.KV_WINO2D_KS in kinds["split"] and L.KV_WINO2D_KS not in kinds["one"], kinds
-    assert torch.equal(outs["split"], outs["in_kernel"])  # the same sums in the same slice order, whichever workgroup arrives last
+    assert torch.equal(outs["split"], outs["in_kernel"]) and torch.equal(outs["split"], outs["shared"])  # the same sums in the same slice order, whichever workgroup adds them
     _close(outs["split"], ref, "split")
     assert (outs["split"] - outs["one"]).abs().max().item() <= 2e-5 * ref.abs().max().item()
 
