@@ -641,12 +641,12 @@ def run_infer(args, ctx):
                     heads_in["lane2"] = (backend2, BottomUpLayer(backend2, PAFScorer.from_config(CFG3_HEADS), 4, 8, max_stride=32), [torch.cuda.Stream(dev), torch.cuda.Stream(dev)])
                 backend2, layer2, lanes_st = heads_in["lane2"]
                 sframes2 = backend2.static_input((sb, 1, SIZE, SIZE)).copy_(sframes)
-                lanes = ((backend, layer, sframes), (backend2, layer2, sframes2))
+                shard_lanes = ((backend, layer, sframes), (backend2, layer2, sframes2))
                 fl, futs = [], []
 
                 def step2(i):
                     k = i & 1
-                    be_k, ly_k, x_k = lanes[k]
+                    be_k, ly_k, x_k = shard_lanes[k]
                     with torch.cuda.stream(lanes_st[k]):
                         be_k(x_k)
                         fl.append((ly_k, ly_k._enqueue_scoring({"MultiInstanceConfmapsHead": heads_in["cms"], "PartAffinityFieldsHead": heads_in["pafs"]}, heads_in["info"])))

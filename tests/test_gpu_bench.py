@@ -61,3 +61,18 @@ def test_two_ranks_training_rehearsal():
     assert first > 0 and last > 0 and first == first and last == last and last != first
     assert full["allreduce"]["bucket_split"] is not None and full["allreduce"]["arena_mb"] > 30  # 7.8 M parameters in one flat arena
     assert "REHEARSAL" in d["data"] and 0 < d["roofline"]["frac"] < 1
+
+
+@pytest.mark.skipif(not torch.cuda.is_available(), reason="needs a GPU")
+def test_default_single_gpu_line_with_every_leg():
+    """`python bench.py` as the driver runs it (fewer steps): every leg runs, the line carries the contract fields + roofline + cpu_baseline and stays under 4 KB."""
+    d, full = _run("--steps", "6", "--warmup", "3", "--leg-steps", "2")
+    assert d["n_gpus"] == 1 and d["steps"] == 6 and d["scaling"] == "weak" and d["dtype"] == "f32" and d["config"]["workload"].startswith("cfg3")
+    assert d["value"] == pytest.approx(32 * 6 / (d["ms_per_step"] * 6e-3), rel=1e-6) and d["vs_baseline"] is None
+    r, c = d["roofline"], d["cpu_baseline"]
+    assert r["bound"] == "mfma" and r["kernel"] == "conv3x3_wino4_kernel" and 0.3 < r["frac"] < 1 and r["traffic"] and 0.3 < r["conv_stack_frac"] < 1
+    assert c["kind"] == "port" and c["value"] > 0 and c["parity_on_this_sample"]["peak_indices_equal"] and c["parity_on_this_sample"]["grouping_equal"]
+    for leg in ("train_cfg3", "train_cfg4", "infer_cfg4", "infer_cfg1", "infer_cfg2", "infer_cfg5", "published_workload", "alt_precisions", "strong_scaling_shards", "roofline_postprocess"):
+        assert leg in full, leg
+    s = d["legs_summary"]
+    assert s["published_workload"]["end_to_end_frames_per_s"] > 0 and s["infer_cfg5"]["value"] > 0 and s["one_gpu_shard_two_streams_frames_per_s"]["4_frames_per_rank"] > 0
