@@ -220,6 +220,13 @@ def test_pipelined_predictor_graphed_gpu_stage_equals_the_eager_layer():
     pred.use_graph = False
     same(pred.predict(vid), ref)
     pred.use_graph = True
+    # frames without a single peak (all-NaN outputs of one instance slot), an empty list of frames, a single frame
+    blank = torch.zeros_like(vid[:6])
+    refb = pred.predict(blank, pipelined=False)
+    assert all(torch.isnan(o.pred_keypoints).all() and o.pred_keypoints.shape[1] == 1 for o in refb)
+    same(pred.predict(blank), refb)
+    assert pred.predict(vid[:0]) == []
+    same(pred.predict(vid[:1]), pred.predict(vid[:1], pipelined=False))
     pred.layer.postprocess_config = PostprocessConfig(peak_threshold=0.2, max_instances=1)
     ref1 = pred.predict(vid, pipelined=False)
     assert ref1[0].pred_keypoints.shape[1] == 1
