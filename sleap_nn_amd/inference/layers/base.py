@@ -63,18 +63,24 @@ class InferenceLayer(ABC):
     # layers whose post-process is device-only work (no host stage, no data-dependent host branch) set this: forward + post-process can then be ONE captured graph
     _GRAPHABLE_POSTPROCESS = False
 
-    def predict_graphed(self, image: ImageInput) -> Outputs:
+    def predict_graphed(self, image: ImageInput, raw: bool = False) -> Outputs:
         """``predict`` as one hipGraph launch: the backend's forward AND this layer's post-process kernels (peak finding, refinement, the coordinate ladder) are captured
         together per preprocessed input shape, so a step has no launch gaps between them -- at one small frame the three post-process launches and their gaps are ~10 % of a
         ~0.3-ms step.  Same results as ``predict`` (same kernels, same order).  The returned ``Outputs`` holds the graph's STATIC device tensors: valid until the next call with
         the same shape.  Passing the tensor ``graph_input(shape)`` returned (the graph's own input buffer) skips the staging copy.  Needs a layer whose post-process is device-only
-        (``_GRAPHABLE_POSTPROCESS``) on a ``HipBackend``."""
+        (``_GRAPHABLE_POSTPROCESS``) on a ``HipBackend``.  ``raw=True`` (uint8 device batches): the preprocessing is captured as well -- one launch per batch."""
         if not self._GRAPHABLE_POSTPROCESS or not hasattr(self.backend, "model"):
             raise RuntimeError(f"{type(self).__name__} on {type(self.backend).__name__} cannot run as one graph (host stage in its post-process, or a foreign backend)")
-        x, info = self.preprocess(image)
-        x = x.to(torch.device(self.backend.device), non_blocking=True)
-        x, code = self.backend.input_code(x)  # float frames: the same max() > 1 test HipBackend.__call__ makes, per call
-        entry = self._graph_entry(x, info, code)
+        if raw and torch.is_tensor(image) and image.is_cuda and image.dtype == torch.uint8:
+            # the batch as it arrives: its preprocessing launches (resizes, pads: functions of the shape) are captured in front of the forward
+            x, code = image, None
+            entry = self._graph_entry(x, None, code, pre=self.preprocess)
+            info = entry[4]
+        else:
+            x, info = self.preprocess(image)
+            x = x.to(torch.device(self.backend.device), non_blocking=True)
+            x, code = self.backend.input_code(x)  # float frames: the same max() > 1 test HipBackend.__call__ makes, per call
+            entry = self._graph_entry(x, info, code)
         graph, static_in, out = entry[0], entry[1], entry[2]
         if x.data_ptr() != static_in.data_ptr():
             static_in.copy_(x, non_blocking=True)

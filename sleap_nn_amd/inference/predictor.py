@@ -104,7 +104,7 @@ class Predictor:
         layer = _select_layer(assets, device, post, max_instances, **paf_kw)
         replicas = []
         small = lambda l: l.backend.model.num_parameters() <= _REPLICA_MAX_PARAMS
-        if streams > 1 and ((isinstance(layer, BottomUpLayer) and small(layer)) or
+        if streams > 1 and ((isinstance(layer, (BottomUpLayer, SingleInstanceLayer)) and small(layer)) or
                             (isinstance(layer, TopDownLayer) and small(layer.centroid_layer) and small(layer.centered_instance_layer))):
             replicas = [_select_layer(assets, device, post, max_instances, **paf_kw) for _ in range(streams - 1)]
         return cls(layer, batch_size, replicas=replicas)
@@ -130,11 +130,54 @@ class Predictor:
             return self._predict_two_stage_pipelined(frames)
         if pipelined and hasattr(self.layer, "_enqueue_postprocess"):
             return self._predict_host_stage_pipelined(frames)
+        if pipelined and self.use_graph and getattr(self.layer, "_GRAPHABLE_POSTPROCESS", False) and hasattr(getattr(self.layer, "backend", None), "model") \
+                and frames.dtype == torch.uint8 and not self.layer.postprocess_config.return_confmaps:
+            return self._predict_graphed_pipelined(frames)
         outs = []
         for s, batch in self._batch_iter(frames):
             o = self.layer.predict(batch)
             o.frame_indices = torch.arange(s, s + len(batch))
             outs.append(o)
+        return outs
+
+    def _predict_graphed_pipelined(self, frames) -> List[Outputs]:
+        """Layers whose whole step is device work (single instance: forward + global peaks + refinement + coordinate ladder): one hipGraph launch per batch
+        (``InferenceLayer.predict_graphed(raw=True)``: preprocessing included), the small result tensors copied out of the graph's static buffers; with ``replicas`` consecutive
+        batches alternate between the copies on streams of their own.  No host read anywhere: the caller's first use of a result synchronises."""
+        layers = [self.layer] + list(self.replicas)
+        layer = layers[0]
+        for rep in layers[1:]:
+            for attr in ("preprocess_config", "postprocess_config", "output_stride", "max_stride"):
+                setattr(rep, attr, getattr(layer, attr))
+        dev = torch.device(layer.backend.device)
+        stage = self._staging() if not frames.is_cuda else None
+        streams = self.__dict__.get("_streams")
+        if len(layers) > 1 and (streams is None or len(streams) != len(layers)):
+            streams = self.__dict__["_streams"] = [torch.cuda.Stream(dev) for _ in layers]
+        caller = torch.cuda.current_stream(dev)
+        if len(layers) > 1:
+            for st in streams:
+                st.wait_stream(caller)
+        outs: List[Outputs] = []
+        for bi, (s, batch) in enumerate(self._batch_iter(frames)):
+            n = len(batch)
+            k = bi % len(layers)
+            with torch.cuda.stream(streams[k]) if len(layers) > 1 else contextlib.nullcontext():
+                if stage is not None and not batch.is_pinned():
+                    batch = stage.put(batch).to(dev, non_blocking=True)
+                    stage.mark(dev)
+                else:
+                    if len(layers) > 1 and batch.is_cuda:
+                        batch.record_stream(streams[k])
+                    batch = batch.to(dev, non_blocking=True)
+                o = layers[k].predict_graphed(batch, raw=True)
+                keep = {f: getattr(o, f).clone() for f in ("pred_keypoints", "pred_peak_values", "pred_crop_keypoints") if getattr(o, f) is not None}
+            o = Outputs(preprocess_info=o.preprocess_info, **keep)
+            o.frame_indices = torch.arange(s, s + n)
+            outs.append(o)
+        if len(layers) > 1:
+            for st in streams:
+                caller.wait_stream(st)
         return outs
 
     def _predict_host_stage_pipelined(self, frames) -> List[Outputs]:
