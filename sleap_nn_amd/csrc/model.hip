@@ -206,6 +206,7 @@ void apply_conv_options(const ph_model* m, ConvArgs& a) {
   a.split_counters = m->split_counters_dev;
   a.split_counters_n = m->split_counters_dev ? 4096 : 0;  // (units; the buffer holds three words per unit)
   a.splitk_finish = m->conv_splitk_finish;
+  a.use_sm = 0;  // (ph_model_forward: the kind of plan decides)
 }
 
 // Programs made only of the UNet-style ops can run on the fp16 matrix pipe (handle option "conv_precision"); anything
@@ -706,6 +707,24 @@ ph_model* ph_model_create(const ph_op_desc* ops, int32_t n_ops, const float* con
           return true;
         };
         if (ok && !tr) ok = derive_w16(op.w_dev, d.cin0, d.cout, op.bn, &op.w_w16_dev, d.cin1);
+        if (ok && !tr) {  // small-map F(2x2,3x3) weights (conv3x3_sm_kernel): 16/9 of the direct weights' bytes, every 3x3 conv
+          const int nblocks = coutp / 16, chunks16 = pad16(d.cin0) / 16 + (d.cin1 > 0 ? pad16(d.cin1) / 16 : 0);
+          float* w = nullptr;
+          ok = hipMalloc(&w, (size_t)sm_pack_floats(nblocks, chunks16) * sizeof(float)) == hipSuccess;
+          if (ok) {
+            m->allocs.push_back(w);
+            ok = launch_sm_pack(op.w_dev, w, nblocks, chunks16, op.bn, nullptr) == PH_OK;
+            DerivedBuffer db;
+            db.src = op.w_dev;
+            db.dst = w;
+            db.panels = nblocks;
+            db.bn = chunks16;
+            db.n_tiles = op.bn;
+            db.kind = 6;
+            m->derived.push_back(db);
+            op.w_sm_dev = w;
+          }
+        }
         if (ok && !tr) {  // row-GEMM form for feature maps too small for the 16x32-pixel tiles
           op.bn_g = gemm_choose_bn(coutp);
           auto pack_g = [&](const auto* w, auto& out) { pack_gemm(w, d.cout, d.cin0, d.cin1, 9, op.bn_g, out); };
@@ -964,10 +983,10 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
     rc = drain_events(m);
     if (rc != PH_OK) return rc;
   }
-  if (m->wino4_stale && (m->conv_wino4 >= 2 || (m->conv_wino4 == 1 && plan.reuse))) {
+  if (m->wino4_stale && (m->conv_wino4 >= 2 || (m->conv_wino4 == 1 && plan.reuse) || m->conv_smallmap >= 2 || (m->conv_smallmap == 1 && plan.reuse))) {  // (the inference-only weight forms: F(4x4,3x3), small-map)
     for (const DerivedBuffer& db : m->derived)
-      if (db.kind == 5) {
-        rc = launch_wino4_pack(db.src, db.dst, db.panels, db.bn, s);
+      if (db.kind == 5 || db.kind == 6) {
+        rc = db.kind == 5 ? launch_wino4_pack(db.src, db.dst, db.panels, db.bn, s) : launch_sm_pack(db.src, db.dst, db.panels, db.bn, db.n_tiles, s);
         if (rc != PH_OK) return rc;
       }
     m->wino4_stale = false;
@@ -1112,6 +1131,8 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
         a.w16 = op.w16_dev;
         a.zeros = m->zeros_dev;
         apply_conv_options(m, a);
+        a.wpack_sm = op.w_sm_dev;
+        a.use_sm = m->conv_smallmap >= 2 ? 2 : ((m->conv_smallmap == 1 && m->conv_splitk == 1 && plan.reuse && m->use_dma) ? 1 : 0);
         a.wpack_wino4 = op.w_wino4_dev;
         a.use_wino4 = m->conv_wino4 == 3 ? 2 : ((m->conv_wino4 == 2 || (m->conv_wino4 == 1 && plan.reuse)) ? 1 : 0);
         // (the two round-4 routings below -- Cout-32 layers on the N-tile-64 kernels, split K -- apply to inference plans only: a training program's forward keeps the kernels its
@@ -1138,13 +1159,18 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
           ConvArgs f = a;
           f.src1 = slot_ptr(up.src0);
           f.src1_lowres = 1;
-          if (m->use_dma && conv3x3_dma_is_wino4(f)) {
+          if ((m->use_dma && conv3x3_dma_is_wino4(f)) || conv3x3_takes_sm(f)) {
             a = f;
           } else {
             rc = launch_upsample(slot_ptr(up.src0), slot_ptr(up.dst), batch, sl.h, sl.w, sl.cp, s);
             if (rc != PH_OK) return rc;
           }
           deferred_up = -1;
+        }
+        if (conv3x3_takes_sm(a)) {  // small maps at small batches: (8 x 8 pixels, 16 channels) units, one launch, no split K (conv3x3_sm_kernel)
+          kv[op_index - 1] = PH_KV_SMALLMAP;
+          rc = launch_conv3x3_sm(a, s);
+          break;
         }
         const double fill = (double)s0.h * s0.w / ((double)((s0.h + 15) / 16 * 16) * ((s0.w + 31) / 32 * 32));
         // the halo kernel pads Cout to a multiple of its N tile (64): e.g. Cout = 96 does 33 % extra MFMA work there,
@@ -1241,12 +1267,12 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
       }
       case PH_OP_UPSAMPLE: {
         const SlotShape& s0 = plan.slots[d.src0];
-        if (fmt == FMT_F32 && plan.reuse && m->upsample_fold && m->conv_wino4 && m->use_dma && op_index < m->ops.size()) {
+        if (fmt == FMT_F32 && plan.reuse && m->upsample_fold && (m->conv_wino4 || m->conv_smallmap) && m->use_dma && op_index < m->ops.size()) {
           // inference plans: when the NEXT op is a 3x3 conv that takes this tensor as its second source and nothing else reads it, the conv
           // decides (it may run the F(4x4,3x3) kernel, which up-samples in its input transform) -- see PH_OP_CONV
           const PackedOp& nxo = m->ops[op_index];
           const ph_op_desc& nx = nxo.d;
-          bool only = nx.kind == PH_OP_CONV && nx.ksize == 3 && nx.src1 == d.dst && nx.src0 != d.dst && nx.dst2 < 0 && nxo.w_wino4_dev != nullptr;
+          bool only = nx.kind == PH_OP_CONV && nx.ksize == 3 && nx.src1 == d.dst && nx.src0 != d.dst && nx.dst2 < 0 && (nxo.w_wino4_dev != nullptr || nxo.w_sm_dev != nullptr);
           for (size_t k = 0; only && k < m->ops.size(); ++k)
             if (k != op_index && (m->ops[k].d.src0 == d.dst || m->ops[k].d.src1 == d.dst)) only = false;
           if (only) {
@@ -1559,6 +1585,7 @@ std::vector<OptionRef> option_table(ph_model* m) {
       {"conv_wino4_min_cin", &m->conv_wino4_min_cin, nullptr},  // padded input channels from which a layer takes it
       {"conv_n32_wino2d", &m->conv_n32_wino2d, nullptr},  // Cout-32 / K >= 64 layers on the F(2x2,3x3) kernel with a half-empty N tile (0: the N-tile-32 F(2,3) kernel)
       {"conv_splitk_finish", &m->conv_splitk_finish, nullptr},  // 0: the split-K second stage as a launch of its own (A/B, tests)
+      {"conv_smallmap", &m->conv_smallmap, nullptr},    // conv3x3_sm_kernel for small maps at small batches: 0 never, 1 where estimated faster (inference plans, conv_splitk = 1), 2 wherever the shape fits
       {"conv_splitk", &m->conv_splitk, nullptr},        // split K on the F(2x2,3x3) kernel for layers with fewer work units than CUs: 0 never, 1 where estimated faster, n >= 2 force n slices
       {"upsample_fold", &m->upsample_fold, nullptr},    // bilinear x2 folded into the F(4x4,3x3) input transform of the conv that consumes it
       {"stem_wino", &m->stem_wino, nullptr},            // second conv of the fused stem in Winograd form

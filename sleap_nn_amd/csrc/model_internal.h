@@ -40,6 +40,7 @@ struct PackedOp {
   float* wd_wino2_dev[2] = {nullptr, nullptr};  // ... and from wd_dev (data gradient)
   float* w_n64_dev = nullptr;              // 3x3 conv with 32 output channels and >= 64 input channels: the weights packed once more for an N tile of 64 (upper half zeros) ...
   float* b_n64_dev = nullptr;              // ... with a 64-entry bias, so that the layer can run on the F(2x2,3x3) kernel's half-empty-N-tile form (w_wino2_dev is derived from w_n64_dev)
+  float* w_sm_dev = nullptr;               // 3x3 conv: small-map F(2x2,3x3) weights derived from w_dev (conv3x3_sm_kernel)
   float* w_wino4_dev = nullptr;            // 3x3 conv, N tile 64, >= 128 padded input channels: Winograd F(4x4,3x3) weights derived from w_dev
   float* wd_wino4_dev[2] = {nullptr, nullptr};  // ... and from wd_dev (data gradient: Cout input channels)
   // ConvTranspose2d(k3, s2, p1, op1) as four output-phase row GEMMs (mode 3) + its data gradient (mode 4)
@@ -67,7 +68,7 @@ struct DerivedBuffer {
   const float* src = nullptr;
   float* dst = nullptr;
   int panels = 0, bn = 0;  // bn == 0: the fused stem's second conv (launch_stem_wino_pack)
-  int kind = 0;            // 0: Winograd transform of src; 1: fp16 weight pack of the LDS-DMA panels (launch_f16_weight_pack); 2: F(2x2,3x3) transform; 3: wave-private F(2x2,3x3) transform (panels = chunks); 4: the fused stem's F(2x2,3x3) transform; 5: F(4x4,3x3) transform (panels = N tiles, bn = 16-channel chunks)
+  int kind = 0;            // 0: Winograd transform of src; 1: fp16 weight pack of the LDS-DMA panels (launch_f16_weight_pack); 2: F(2x2,3x3) transform; 3: wave-private F(2x2,3x3) transform (panels = chunks); 4: the fused stem's F(2x2,3x3) transform; 5: F(4x4,3x3) transform (panels = N tiles, bn = 16-channel chunks); 6: small-map F(2x2,3x3) transform (panels = N blocks of 16, bn = 16-channel chunks, n_tiles = the source packing's N tile)
   int n_tiles = 0, chunks0 = 0, chunks1 = 0, plain = 0;  // kind 1
 };
 
@@ -130,6 +131,7 @@ struct ph_model {
   int conv_wino4 = 1;                         // "conv_wino4": K-heavy N-tile-64 3x3 convs on the F(4x4,3x3) kernel: 1 in inference plans (workspace_reuse), 2 in every plan -- both where wino4_fits estimates it faster than F(2x2,3x3) --, 3 every plan and wherever the shape fits, 0 never
   int conv_wino4_min_cin = 64;                // "conv_wino4_min_cin": padded input channels (both sources) from which a layer takes that kernel
   int conv_n32_wino2d = 1;                    // "conv_n32_wino2d" (1: inference plans, 2: every plan, 0: never): Cout-32 layers with >= 64 input channels (the last decoder level of an output-stride-2 UNet: 96 -> 32) on the F(2x2,3x3) kernel with a half-empty N tile of 64 instead of the N-tile-32 F(2,3) kernel
+  int conv_smallmap = 1;                      // "conv_smallmap" (1: inference plans with conv_splitk = 1 (the automatic small-batch routing), where estimated faster; 2: every fp32 3x3 conv whose shape fits, any plan; 0: never): conv3x3_sm_kernel
   int conv_splitk = 1;                        // "conv_splitk" (1: where estimated faster, inference plans only; n >= 2: force n slices in every plan; 0: never): F(2x2,3x3) layers with fewer (pixel tile, N tile) units than half the CUs split K over workgroups + a fixed-order second stage (small batches); n >= 2 forces n slices, 0 never
   int upsample_fold = 1;                      // "upsample_fold": a bilinear x2 whose only reader is the next conv's second source is folded into that conv's F(4x4,3x3) input transform (inference plans)
   int dgrad_wino = 1;                         // "dgrad_wino": 0 = direct 9-tap kernels for the backward's data-gradient convs (A/B: ~7 % slower cfg3 step, same gradients to the digit)

@@ -26,6 +26,8 @@ struct ConvArgs {
   const float* wpack_wino2 = nullptr; // Winograd F(2x2,3x3) weights in LDS order (conv3x3_wino2d_kernel, N tile 64), or nullptr
   const float* wpack_w16 = nullptr;   // wave-private F(2x2,3x3) weights (conv3x3_w16_kernel: Cout 16 / 32, Cin 16 / 32), or nullptr
   int use_w16 = 1;     // handle option "conv_w16"
+  const float* wpack_sm = nullptr;    // small-map F(2x2,3x3) weights (conv3x3_sm_kernel, smallmap_kernels.hip), or nullptr
+  int use_sm = 0;      // filled from the handle option "conv_smallmap" and the kind of plan: 1 = where estimated faster than the kernel that would run otherwise, 2 = wherever the shape fits
   int use_wino2d = 1;  // N-tile-64 layers on the F(2x2,3x3) kernel where wpack_wino2 exists (handle option "conv_wino2d")
   const float* w16 = nullptr;  // [tap][ci 16][co 16] weights for conv3x3_c16_kernel (16 -> 16 channel layers), or nullptr
   int skip_dst = 0;           // the full-resolution output is never read (inference plan, fused pool): only dst_pool is written (Winograd kernels; others ignore it)
@@ -200,6 +202,13 @@ bool w16_fits(const ConvArgs& a);
 bool w16_takes_head(const ConvArgs& a);  // the wave-private kernel would run this launch and can carry a fused 1x1 head (<= 16 head channels, head_wcp = coutp)
 bool w16_shape_ok(int c0p, int c1p, int coutp);  // channel counts the wave-private kernel takes (c1p = 0: one source)
 int prepare_w16_kernels();
+// wpack [n tile][chunk][tap 9][bn][16] -> small-map F(2x2,3x3) weights [N block of 16][chunk of 32][pair][wave][half][lane][4] (see conv3x3_sm_kernel)
+int launch_sm_pack(const float* wpack, float* dst, int nblocks, int chunks16, int bn, hipStream_t s);
+int64_t sm_pack_floats(int nblocks, int chunks16);
+int launch_conv3x3_sm(const ConvArgs& a, hipStream_t s);
+bool sm_fits(const ConvArgs& a);
+double sm_cost_us(const ConvArgs& a, int n_cu);
+bool conv3x3_takes_sm(const ConvArgs& a);  // the small-map kernel runs this launch (inference plans: where its estimate beats the kernel launch_conv3x3_dma would pick); it also folds a half-resolution src1
 int launch_input_conv(const InputConvArgs& a, hipStream_t s);
 int launch_pool(const float* src, float* dst, int B, int H, int W, int cp, hipStream_t s);
 int launch_upsample(const float* src, float* dst, int B, int H, int W, int cp, hipStream_t s);

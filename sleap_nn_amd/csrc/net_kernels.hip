@@ -1313,6 +1313,34 @@ static int conv3x3_dma_route(const ConvArgs& a) {
   if (wino && a.persist && a.use_wino2d && a.wpack_wino2 && a.bn == 64 && a.c0p + a.c1p >= 32 && wino2d_fits(a)) return 2;
   return 3;
 }
+// The small-map kernel (conv3x3_sm_kernel) against the kernel launch_conv3x3_dma would run, both priced in microseconds of launch body as in wino4_fits (rounds of the chip x unit time,
+// + ~8 us per extra launch: a split-K second stage, a bilinear x2 the other kernel cannot fold).  use_sm = 2 forces it wherever the shape fits (tests, A/B).
+bool conv3x3_takes_sm(const ConvArgs& a) {
+  if (!a.use_sm || !sm_fits(a)) return false;
+  if (a.use_sm >= 2) return true;
+  int n_cu = 0;
+  if (device_cu_count(&n_cu) != PH_OK || n_cu <= 0) n_cu = 256;
+  ConvArgs hi = a;  // what runs otherwise takes the up-sampled tensor, unless it is the F(4x4,3x3) kernel
+  hi.src1_lowres = 0;
+  const int r = a.src1_lowres && conv3x3_dma_route(a) == 4 ? 4 : conv3x3_dma_route(hi);
+  const double extra = (a.src1_lowres && r != 4) ? 6.0 : 0.0;
+  const double Qn = (a.c0p + a.c1p) / 4.0;
+  const long ntc = (a.coutp + 63) / 64;
+  const bool may_split = a.split_scratch != nullptr;
+  double other;
+  if (r == 4) {
+    const int ks = may_split ? wino4_ksplit_shape(a.B, a.H, a.W, a.c0p + a.c1p, a.coutp, a.splitk, n_cu) : 1;
+    const long t4 = (long)((a.H + 15) / 16) * ((a.W + 31) / 32) * a.B * ntc;
+    other = (double)((t4 * ks + n_cu - 1) / n_cu) * (11.0 + 1.5 * Qn / ks) + (ks > 1 ? 8.0 : 0.0);
+  } else if (r == 2) {
+    const int ks = may_split ? wino2d_ksplit_shape(a.B, a.H, a.W, a.c0p + a.c1p, a.coutp, a.splitk, n_cu) : 1;
+    const long t2 = (long)((a.H + 15) / 16) * ((a.W + 15) / 16) * a.B * ntc;
+    other = (double)((t2 * ks + n_cu - 1) / n_cu) * (8.0 + 1.0 * Qn / ks) + (ks > 1 ? 8.0 : 0.0);
+  } else {
+    return false;  // the wave-private / 16 -> 16 / F(2,3) kernels keep their layers
+  }
+  return sm_cost_us(a, n_cu) < other + extra;
+}
 bool conv3x3_dma_honours_mask(const ConvArgs& a) {  // the three F(2x2,3x3) / F(4x4,3x3) kernels store lane-locally; the fused pool / head epilogues are forward-only
   const int r = conv3x3_dma_route(a);
   return (r == 1 || r == 2 || r == 4) && !a.dst_pool && !a.head_w && !a.skip_dst;

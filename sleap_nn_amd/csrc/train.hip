@@ -155,12 +155,12 @@ int ph_model_set_params(ph_model* m, const float* params_flat_dev, void* stream)
   }
   for (const DerivedBuffer& db : m->derived) {
     if ((db.kind == 0 && db.bn != 0) || db.kind == 2) continue;  // in the two launches above
-    if (db.kind == 5) {  // F(4x4,3x3) weights: only inference plans read them (conv_wino4 = 1) -- a training step does not pay for the re-derivation,
-      if (m->conv_wino4 < 2 && !m->workspace_reuse) {  // the next forward that wants them refreshes them (ph_model_forward)
+    if (db.kind == 5 || db.kind == 6) {  // F(4x4,3x3) / small-map weights: only inference plans read them (conv_wino4 = conv_smallmap = 1) -- a training step does not pay for the re-derivation,
+      if ((db.kind == 5 ? m->conv_wino4 : m->conv_smallmap) < 2 && !m->workspace_reuse) {  // the next forward that wants them refreshes them (ph_model_forward)
         m->wino4_stale = true;
         continue;
       }
-      const int rc5 = launch_wino4_pack(db.src, db.dst, db.panels, db.bn, static_cast<hipStream_t>(stream));
+      const int rc5 = db.kind == 5 ? launch_wino4_pack(db.src, db.dst, db.panels, db.bn, static_cast<hipStream_t>(stream)) : launch_sm_pack(db.src, db.dst, db.panels, db.bn, db.n_tiles, static_cast<hipStream_t>(stream));
       if (rc5 != PH_OK) return rc5;
       continue;
     }

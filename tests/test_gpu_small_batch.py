@@ -85,7 +85,7 @@ def test_cfg1_single_instance_256_batch1_network_and_global_peaks():
     assert small.preprocess_info.original_size == (250, 250) and layer.predict_graphed(img[:1]).preprocess_info.original_size == (256, 256)
     raw = layer.backend(img[:1])["SingleInstanceConfmapsHead"]
     codes = m.last_kernels()
-    assert L.KV_WINO2D_KS in codes, codes  # the default routing of this batch takes the split-K form somewhere
+    assert codes.count(L.KV_SMALLMAP) >= 10 and L.KV_WINO2D_KS not in codes, codes  # the default routing of this batch: the stride >= 4 levels on conv3x3_sm_kernel, one launch per layer
     layer.postprocess_config = PostprocessConfig()
     out = layer.postprocess({"SingleInstanceConfmapsHead": raw}, PreprocInfo(eff_scale=torch.ones(1), output_stride=2))
     rk, rv = O.single_instance_postprocess(first, 2)
@@ -93,11 +93,15 @@ def test_cfg1_single_instance_256_batch1_network_and_global_peaks():
     assert np.array_equal(out.pred_peak_values.cpu().numpy(), rv.numpy())
     raw3 = layer.backend(img)["SingleInstanceConfmapsHead"]  # other routing (more tiles): same frame within the relative bar, all three vs the oracle
     _close(raw3[:1], ref, "cfg1 in a batch of 3")
+    m.set_option("conv_smallmap", 0)
+    split = m(img[:1].to(DEV))["SingleInstanceConfmapsHead"].cpu()
+    assert L.KV_WINO2D_KS in m.last_kernels() and L.KV_SMALLMAP not in m.last_kernels()  # without the small-map kernel: K split over workgroups + a second stage
+    _close(split, ref, "cfg1, split-K kernels")
     m.set_option("conv_splitk", 0)
     one_stage = m(img[:1].to(DEV))["SingleInstanceConfmapsHead"].cpu()
-    assert L.KV_WINO2D_KS not in m.last_kernels()
+    assert L.KV_WINO2D_KS not in m.last_kernels() and L.KV_SMALLMAP not in m.last_kernels()
     _close(one_stage, ref, "cfg1, one-stage kernels")
-    assert (one_stage - first).abs().max().item() <= 2e-5 * ref.abs().max().item()
+    assert (one_stage - first).abs().max().item() <= 2e-5 * ref.abs().max().item() and (split - first).abs().max().item() <= 2e-5 * ref.abs().max().item()
 
 
 @pytest.mark.parametrize("filters,max_stride,hw,batch,out_stride,splitk", [(32, 8, (32, 32), 1, None, 1), (32, 8, (32, 32), 1, None, 3), (32, 16, (64, 48), 2, 2, 1), (64, 8, (40, 24), 1, None, 5),
@@ -121,6 +125,7 @@ def test_split_k_winograd_kernel_matches_the_one_stage_kernel_and_the_oracle(fil
         m = Model("unet", bb, heads, "single_instance")
         m.load_state_dict(sd)
         m.set_option("conv_splitk", ks)
+        m.set_option("conv_smallmap", 0)  # (the small-map kernel would take these layers from the split form under the automatic routing)
         m.set_option("conv_splitk_finish", finish)  # 0: splitk_reduce_kernel; 1: the workgroup that stores a unit's last K slice runs the second stage; 2: the unit's workgroups share it
         outs[name] = m.to(DEV)(img.to(DEV))["SingleInstanceConfmapsHead"].cpu()
         kinds[name] = m.last_kernels()
@@ -132,6 +137,34 @@ def test_split_k_winograd_kernel_matches_the_one_stage_kernel_and_the_oracle(fil
     assert torch.equal(outs["split"], outs["in_kernel"]) and torch.equal(outs["split"], outs["shared"])  # the same sums in the same slice order, whichever workgroup adds them
     _close(outs["split"], ref, "split")
     assert (outs["split"] - outs["one"]).abs().max().item() <= 2e-5 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("filters,max_stride,hw,batch,out_stride,reuse", [(16, 16, (64, 64), 1, 2, 1), (16, 16, (80, 96), 2, 2, 1), (32, 8, (40, 24), 3, 2, 1), (16, 32, (96, 160), 1, 4, 1),
+                                                                          (8, 16, (48, 80), 2, 1, 1), (16, 16, (48, 112), 2, 2, 1), (24, 8, (40, 56), 1, 4, 1), (16, 16, (80, 96), 2, 2, 0), (32, 16, (32, 48), 1, 16, 1)])
+def test_small_map_kernel_on_every_3x3_conv_matches_the_oracle(filters, max_stride, hw, batch, out_stride, reuse):
+    """conv3x3_sm_kernel forced onto every 3x3 conv whose shape it takes (conv_smallmap = 2): one and two sources, the concat boundary inside a 32-channel chunk (16 + 32,
+    24 -> 32-padded + 64 channels), the bilinear x2 folded into the loader (inference plans) and as a tensor (workspace_reuse = 0), fused pool, an
+    unread full-resolution output, maps that cut the 8 x 8-pixel units, three frames; against the oracle, against the kernels that run otherwise, bitwise repeatable."""
+    from sleap_nn_amd.architectures.model import Model
+
+    bb = dict(SI_BB, filters=filters, max_stride=max_stride, output_stride=out_stride)
+    heads = {"confmaps": {"part_names": ["a", "b", "c"], "output_stride": out_stride}}
+    sd = O.init_state(bb, heads, "single_instance", seed=filters + hw[0], head_scale=1.0)
+    img = torch.randint(0, 256, (batch, 1, hw[0], hw[1]), dtype=torch.uint8, generator=torch.Generator().manual_seed(hw[1]))
+    ref = O.model_forward(sd, bb, heads, "single_instance", img)["SingleInstanceConfmapsHead"]
+    outs, kinds = {}, {}
+    for name, mode in (("sm", 2), ("other", 0)):
+        m = Model("unet", bb, heads, "single_instance")
+        m.load_state_dict(sd)
+        m.set_option("conv_smallmap", mode)
+        m.set_option("workspace_reuse", reuse)
+        outs[name] = m.to(DEV)(img.to(DEV))["SingleInstanceConfmapsHead"].cpu()
+        kinds[name] = m.last_kernels()
+        assert torch.equal(m(img.to(DEV))["SingleInstanceConfmapsHead"].cpu(), outs[name])
+    n_conv = sum(1 for c in kinds["other"] if c in (L.KV_WINO2D, L.KV_WINO2D_KS, L.KV_W16, L.KV_WINO4, L.KV_C16, L.KV_WINO1D, L.KV_DIRECT, L.KV_ROWGEMM))
+    assert kinds["sm"].count(L.KV_SMALLMAP) >= n_conv - 1 and L.KV_SMALLMAP not in kinds["other"], (kinds, n_conv)  # (all but a conv that carries a fused head)
+    _close(outs["sm"], ref, "small-map kernel")
+    assert (outs["sm"] - outs["other"]).abs().max().item() <= 2e-5 * ref.abs().max().item()
 
 
 def test_split_k_second_stage_pool_padding_and_unread_full_resolution_output():
@@ -373,6 +406,7 @@ def test_cout32_layers_on_the_half_empty_n_tile_of_the_winograd_kernel(filters, 
         m = Model("unet", bb, heads, "single_instance")
         m.load_state_dict(sd)
         m.set_option("conv_n32_wino2d", opt)
+        m.set_option("conv_smallmap", 0)  # (at these batch sizes the small-map kernel would take the layer under test)
         outs[opt] = m.to(DEV)(img.to(DEV))["SingleInstanceConfmapsHead"].cpu()
         last_concat = [c for r, c in zip(m.op_table(batch, hw[0], hw[1]), m.last_kernels()) if "refine_conv0" in r["label"]][-1]
         assert last_concat == (L.KV_WINO2D if opt else L.KV_WINO1D), (opt, last_concat)
@@ -383,6 +417,7 @@ def test_cout32_layers_on_the_half_empty_n_tile_of_the_winograd_kernel(filters, 
     m = Model("unet", bb, heads, "single_instance")
     m.load_state_dict(sd)
     m.set_option("conv_wino4", 3)
+    m.set_option("conv_smallmap", 0)
     out4 = m.to(DEV)(img.to(DEV))["SingleInstanceConfmapsHead"].cpu()
     last_concat = [c for r, c in zip(m.op_table(batch, hw[0], hw[1]), m.last_kernels()) if "refine_conv0" in r["label"]][-1]
     assert last_concat == L.KV_WINO4, last_concat
@@ -408,6 +443,7 @@ def test_split_k_form_of_the_f4x4_kernel_matches_the_one_stage_kernel_and_the_or
         if splitk != 1:
             m.set_option("conv_wino4", 3)
         m.set_option("conv_splitk", ks)
+        m.set_option("conv_smallmap", 0)  # (this test is about the split forms; the small-map kernel has its own)
         outs[name] = m.to(DEV)(img.to(DEV))["SingleInstanceConfmapsHead"].cpu()
         assert torch.equal(m(img.to(DEV))["SingleInstanceConfmapsHead"].cpu(), outs[name])
         if name == "split" and splitk != 1:
