@@ -10,11 +10,14 @@
 // bilinear): 17.5 + 5.4 (+ 5.7) us per layer whatever its size (profiles/r5_cfg1_trace_before.txt), 5.2 us of each launch being the dispatch floor.  Here a work
 // unit is (8 x 8 output pixels = 16 Winograd tiles, 16 output channels): the 16 x 16 map with 256 channels is 64 workgroups, a 32 x 32 one with 128 is 128, and
 // nobody shares an accumulator, so there is no reduction, the result is bitwise repeatable, and the bilinear / pool / bias / ReLU are part of the one launch.
-//   * Workgroup = 4 waves.  Wave w owns Winograd row xi = w: positions (w, nu), nu = 0..3, i.e. 4 accumulators of 4 registers; D[m = output channel][n = tile]:
-//     A[m = lane & 15][k = lane >> 4] is a transformed weight, B[k = lane >> 4][n = lane & 15] a transformed input value of tile n.
-//   * K runs in chunks of 32 input channels of the concatenated (src0 | src1) channel axis.  The raw 10 x 10-pixel halo of a chunk is loaded with 16-byte loads
-//     (out-of-image pixels: zeros; a half-resolution src1: four loads and the bilinear weights of ATen's upsample_bilinear2d), staged in LDS as [row][12][34]
-//     floats (the pads make the fragment reads below conflict-free), double-buffered, one chunk ahead of the MFMAs.
+//   * Workgroup = 4 MFMA waves + 4 loader waves (one of each per SIMD).  MFMA wave w owns Winograd row xi = w: positions (w, nu), nu = 0..3, i.e. 4 accumulators of
+//     4 registers; D[m = output channel][n = tile]: A[m = lane & 15][k = lane >> 4] is a transformed weight, B[k = lane >> 4][n = lane & 15] a transformed input
+//     value of tile n.
+//   * K runs in chunks of 32 input channels of the concatenated (src0 | src1) channel axis.  The loader waves bring the raw 10 x 10-pixel halo of a chunk with
+//     16-byte loads (out-of-image pixels: zeros; a half-resolution src1: four loads and the bilinear weights of ATen's upsample_bilinear2d) into LDS as
+//     [row][12][34] floats (the pads make the fragment reads below conflict-free), double-buffered; their loads are requested two chunks before the store, on
+//     their own vmcnt, so the memory latency (every chunk's bytes are first touched by all workgroups at once: ~2 us against ~0.6 us of MFMAs) runs beside the
+//     MFMA waves instead of in front of them.  One workgroup barrier per chunk.
 //   * Per "pair" of K steps (8 channels: lane group g holds channels 8j + 2g, 8j + 2g + 1) a lane reads the two patch rows its Winograd row combines
 //     (8 ds_read_b64), 8 packed adds give B operands of the 4 positions x 2 K steps = 8 MFMAs.  Weights come straight from L2 into registers (32 bytes per lane
 //     and pair, laid out [N block][chunk][pair][wave][half][lane][4] by sm_pack_kernel), two chunks ahead in three register sets.
@@ -31,7 +34,6 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int SM_RS = 12;                         // halo row stride in pixels (10 + 2 pad)
 constexpr int SM_CS = 34;                         // floats per halo pixel (32 channels + 2 pad): 2 * 34 = 4 (mod 64), 2 * 12 * 34 = 48 (mod 64) -> the 16 tiles x 2 lane groups of a half-wave hit 64 different banks
 constexpr int SM_BUF = 10 * SM_RS * SM_CS;        // 4080 floats per halo buffer
-constexpr int SM_LOW = 36 * 32;                   // the 6 x 6-pixel half-resolution patch of a chunk (bilinear x2 in the loader)
 constexpr int SM_PAIR_FLOATS = 4 * 2 * 64 * 4;    // [wave][half][lane][4]
 constexpr int SM_CHUNK_FLOATS = 4 * SM_PAIR_FLOATS;  // 8192 floats (32 KiB) per (N block, chunk)
 
@@ -70,12 +72,12 @@ int launch_sm_pack(const float* wpack, float* dst, int nblocks, int chunks16, in
   return PH_OK;
 }
 
-__global__ __launch_bounds__(256) void conv3x3_sm_kernel(ConvArgs a) {
-  __shared__ __attribute__((aligned(16))) float lds[2 * SM_BUF + SM_LOW];  // two halo buffers (the exchange tile of the epilogue, 4096 floats, lies over them) + the half-resolution patch
+template <bool LOWRES>
+__global__ __launch_bounds__(512) void conv3x3_sm_kernel(ConvArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * SM_BUF];  // two halo buffers; the exchange tile of the epilogue (4096 floats) lies over them
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int n = lane & 15, g = lane >> 4;
   const int nblocks = a.coutp >> 4;
   const int tiles_x = (a.W + 7) >> 3, tiles_y = (a.H + 7) >> 3;
   // consecutive workgroup ids are dealt over the 8 XCDs: with the N block as the fastest index an XCD's L2 holds the weights of one or two N blocks
@@ -88,106 +90,117 @@ __global__ __launch_bounds__(256) void conv3x3_sm_kernel(ConvArgs a) {
   const int b = u / tiles_y;
   const int y0 = ty * 8, x0 = tx * 8;
   const int Kp = a.c0p + a.c1p, nch = (Kp + 31) >> 5;
-  const bool lowres = a.src1_lowres != 0;
-  const int Hl = a.H >> 1, Wl = a.W >> 1;
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
 
-  // ---- loader: piece p = tid + 256 s of a chunk is (halo pixel p >> 3, channel quad q = tid & 7: the same for the thread's four pieces)
-  const int q = tid & 7;
-  int pix_off[4];    // pixel index in the full-resolution sources, -1 = outside the image (zeros), -2 = no such piece
-  int lds_off[4];
-  int gyx[4];        // (gy << 8) | gx - (4 * (tile) - 1 patch origin folded in below): only used with a half-resolution src1
+  if (wave >= 4) {
+    // ================= loader waves: global -> registers (two chunks in flight) -> LDS halo buffer, one chunk ahead of the MFMA waves =================
+    // piece p = lt + 256 s of a chunk is (halo pixel p >> 3, channel quad q = lt & 7: the same for the thread's four pieces)
+    const int lt = tid - 256;
+    const int q = lt & 7;
+    int pix_off[4];  // pixel index in the full-resolution sources, -1 = outside the image (zeros), -2 = no such piece
+    int lds_off[4];
+    int gyx[4];      // LOWRES: (gy << 16) | gx of an in-image piece
 #pragma unroll
-  for (int s = 0; s < 4; ++s) {
-    const int p = tid + 256 * s;
-    const int pix = p >> 3;
-    const int hy = pix / 10, hx = pix - hy * 10;
-    const int gy = y0 + hy - 1, gx = x0 + hx - 1;
-    const bool in = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-    pix_off[s] = p >= 800 ? -2 : (in ? (b * a.H + gy) * a.W + gx : -1);
-    lds_off[s] = (hy * SM_RS + hx) * SM_CS + 4 * q;
-    gyx[s] = in ? (gy << 16) | gx : 0;
-  }
-  // half-resolution src1: the 10 x 10 halo needs the 6 x 6 low-resolution pixels from (4 ty - 1, 4 tx - 1) (clamped to the map: ATen clamps the second tap, the first never leaves it).
-  // Patch piece (pixel pp, quad q): thread tid loads pp = tid >> 3 and, the first 32 threads, pp = 32 + (tid >> 3).
-  int plo[2];
+    for (int s = 0; s < 4; ++s) {
+      const int p = lt + 256 * s;
+      const int pix = p >> 3;
+      const int hy = pix / 10, hx = pix - hy * 10;
+      const int gy = y0 + hy - 1, gx = x0 + hx - 1;
+      const bool in = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+      pix_off[s] = p >= 800 ? -2 : (in ? (b * a.H + gy) * a.W + gx : -1);
+      lds_off[s] = (hy * SM_RS + hx) * SM_CS + 4 * q;
+      gyx[s] = in ? (gy << 16) | gx : 0;
+    }
+    constexpr int NT = LOWRES ? 4 : 1;  // registers per piece: the four bilinear taps of a half-resolution source
+    f32x4 st[2][4][NT];
+    bool st_low[2] = {false, false};
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    // ATen upsample_bilinear2d(align_corners=False), scale 2: source coordinate max((dst + 0.5) / 2 - 0.5, 0), second tap clamped to the last row / column
+    auto tap = [&](int gcoord, int nlow, int& i0, int& i1, float& l) {
+      const float sc = fmaxf(((float)gcoord + 0.5f) * 0.5f - 0.5f, 0.f);
+      i0 = (int)sc;
+      i1 = min(i0 + 1, nlow - 1);
+      l = sc - (float)i0;
+    };
+    // every piece loads from a valid address (an out-of-image / missing piece from pixel 0 of the frame) and is zeroed when it goes to LDS: no branches around the loads
+    auto fetch = [&](int c, auto S) {
+      constexpr int r = decltype(S)::value;
+      const int k = 32 * c + 4 * q;
+      st_low[r] = false;
+      if (k < a.c0p) {
 #pragma unroll
-  for (int s = 0; s < 2; ++s) {
-    const int pp = (tid >> 3) + 32 * s;
-    const int pr = pp / 6, pc = pp - pr * 6;
-    const int iy = min(max(4 * ty - 1 + pr, 0), max(Hl - 1, 0)), ix = min(max(4 * tx - 1 + pc, 0), max(Wl - 1, 0));
-    plo[s] = pp < 36 ? (b * Hl + iy) * Wl + ix : -1;
-  }
-  f32x4 st[4];
-  int st_role = 0;  // of the chunk in st: 0 full-resolution pieces (or zeros), 2 low-resolution patch pieces
-  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-  auto fetch_raw = [&](int c) {
-    const int k = 32 * c + 4 * q;
-    st_role = 0;
-    if (k < a.c0p) {
+        for (int s = 0; s < 4; ++s) st[r][s][0] = *reinterpret_cast<const f32x4*>(a.src0 + (size_t)max(pix_off[s], b * a.H * a.W) * a.c0p + k);
+      } else if (k < Kp) {
+        const int k1 = k - a.c0p;
+        if (LOWRES) {
+          st_low[r] = true;
+          const int Hl = a.H >> 1, Wl = a.W >> 1;
+          const float* const p = a.src1 + (size_t)b * Hl * Wl * a.c1p + k1;
 #pragma unroll
-      for (int s = 0; s < 4; ++s) st[s] = pix_off[s] >= 0 ? *reinterpret_cast<const f32x4*>(a.src0 + (size_t)pix_off[s] * a.c0p + k) : zero4;
-    } else if (k < Kp) {
-      const int k1 = k - a.c0p;
-      if (lowres) {
-        st_role = 2;
+          for (int s = 0; s < 4; ++s) {
+            int iy0, iy1, ix0, ix1;
+            float ly, lx;
+            tap(gyx[s] >> 16, Hl, iy0, iy1, ly);
+            tap(gyx[s] & 0xFFFF, Wl, ix0, ix1, lx);
+            st[r][s][0] = *reinterpret_cast<const f32x4*>(p + (size_t)(iy0 * Wl + ix0) * a.c1p);
+            st[r][s][NT > 1 ? 1 : 0] = *reinterpret_cast<const f32x4*>(p + (size_t)(iy0 * Wl + ix1) * a.c1p);
+            st[r][s][NT > 1 ? 2 : 0] = *reinterpret_cast<const f32x4*>(p + (size_t)(iy1 * Wl + ix0) * a.c1p);
+            st[r][s][NT > 1 ? 3 : 0] = *reinterpret_cast<const f32x4*>(p + (size_t)(iy1 * Wl + ix1) * a.c1p);
+          }
+        } else {
 #pragma unroll
-        for (int s = 0; s < 2; ++s) st[s] = plo[s] >= 0 ? *reinterpret_cast<const f32x4*>(a.src1 + (size_t)plo[s] * a.c1p + k1) : zero4;
+          for (int s = 0; s < 4; ++s) st[r][s][0] = *reinterpret_cast<const f32x4*>(a.src1 + (size_t)max(pix_off[s], b * a.H * a.W) * a.c1p + k1);
+        }
       } else {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) st[s] = pix_off[s] >= 0 ? *reinterpret_cast<const f32x4*>(a.src1 + (size_t)pix_off[s] * a.c1p + k1) : zero4;
+        for (int s = 0; s < 4; ++s) st[r][s][0] = zero4;
       }
-    } else {
+    };
+    auto store = [&](int buf, auto S) {
+      constexpr int r = decltype(S)::value;
+      float* const base = lds + buf * SM_BUF;
 #pragma unroll
-      for (int s = 0; s < 4; ++s) st[s] = zero4;
-    }
-  };
-  float* const lowbuf = lds + 2 * SM_BUF;  // [36 pixels][32 channels]
-  auto store_raw = [&](int buf) {
-    float* const base = lds + buf * SM_BUF;
-    if (st_role == 2) {
-      *reinterpret_cast<f32x4*>(lowbuf + (tid >> 3) * 32 + 4 * q) = st[0];
-      if (tid < 32) *reinterpret_cast<f32x4*>(lowbuf + (32 + (tid >> 3)) * 32 + 4 * q) = st[1];
-      return;
-    }
+      for (int s = 0; s < 4; ++s) {
+        f32x4 v = st[r][s][0];
+        if (LOWRES && st_low[r]) {  // the arithmetic of upsample2x_kernel
+          int i0, i1;
+          float ly, lx;
+          tap(gyx[s] >> 16, a.H >> 1, i0, i1, ly);
+          tap(gyx[s] & 0xFFFF, a.W >> 1, i0, i1, lx);
+          const float hy = 1.f - ly, hx = 1.f - lx;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      if (pix_off[s] == -2) continue;
-      *reinterpret_cast<f32x2*>(base + lds_off[s]) = f32x2{st[s][0], st[s][1]};
-      *reinterpret_cast<f32x2*>(base + lds_off[s] + 2) = f32x2{st[s][2], st[s][3]};
-    }
-  };
-  // ATen upsample_bilinear2d(align_corners=False), scale 2: source coordinate max((dst + 0.5) / 2 - 0.5, 0), second tap clamped to the last row / column; the arithmetic of upsample2x_kernel
-  auto tap = [&](int gcoord, int nlow, int origin, int& i0, int& i1, float& l) {
-    const float sc = fmaxf(((float)gcoord + 0.5f) * 0.5f - 0.5f, 0.f);
-    const int f = (int)sc;
-    l = sc - (float)f;
-    i0 = f - origin;
-    i1 = min(f + 1, nlow - 1) - origin;
-  };
-  auto interp = [&](int buf) {  // the threads whose quad came from the low-resolution patch write their four halo pieces
-    if (st_role != 2) return;
-    float* const base = lds + buf * SM_BUF;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      if (pix_off[s] == -2) continue;
-      f32x4 v = zero4;
-      if (pix_off[s] >= 0) {
-        int r0, r1, c0, c1;
-        float ly, lx;
-        tap(gyx[s] >> 16, Hl, 4 * ty - 1, r0, r1, ly);
-        tap(gyx[s] & 0xFFFF, Wl, 4 * tx - 1, c0, c1, lx);
-        const float hy = 1.f - ly, hx = 1.f - lx;
-        const f32x4 v00 = *reinterpret_cast<const f32x4*>(lowbuf + (r0 * 6 + c0) * 32 + 4 * q), v01 = *reinterpret_cast<const f32x4*>(lowbuf + (r0 * 6 + c1) * 32 + 4 * q);
-        const f32x4 v10 = *reinterpret_cast<const f32x4*>(lowbuf + (r1 * 6 + c0) * 32 + 4 * q), v11 = *reinterpret_cast<const f32x4*>(lowbuf + (r1 * 6 + c1) * 32 + 4 * q);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = hy * (hx * v00[e] + lx * v01[e]) + ly * (hx * v10[e] + lx * v11[e]);
+          for (int e = 0; e < 4; ++e) v[e] = hy * (hx * st[r][s][0][e] + lx * st[r][s][NT > 1 ? 1 : 0][e]) + ly * (hx * st[r][s][NT > 1 ? 2 : 0][e] + lx * st[r][s][NT > 1 ? 3 : 0][e]);
+        }
+        if (pix_off[s] < 0) v = zero4;
+        if (pix_off[s] != -2) {
+          *reinterpret_cast<f32x2*>(base + lds_off[s]) = f32x2{v[0], v[1]};
+          *reinterpret_cast<f32x2*>(base + lds_off[s] + 2) = f32x2{v[2], v[3]};
+        }
       }
-      *reinterpret_cast<f32x2*>(base + lds_off[s]) = f32x2{v[0], v[1]};
-      *reinterpret_cast<f32x2*>(base + lds_off[s] + 2) = f32x2{v[2], v[3]};
+    };
+    // chunk x travels in register set x & 1: requested two iterations before the one that stores it
+    fetch(0, I0{});
+    if (nch > 1) fetch(1, I1{});
+    store(0, I0{});
+    if (nch > 2) fetch(2, I0{});
+    __syncthreads();
+    auto step = [&](int c, auto Snext) {  // during the MFMAs of chunk c: chunk c + 1 (set Snext) goes to LDS, chunk c + 3 is requested into the freed set
+      if (c + 1 < nch) store((c + 1) & 1, Snext);
+      if (c + 3 < nch) fetch(c + 3, Snext);
+      __syncthreads();
+    };
+    for (int c = 0; c < nch; c += 2) {
+      step(c, I1{});
+      if (c + 1 < nch) step(c + 1, I0{});
     }
-  };
-  auto low_chunk = [&](int c) { return lowres && 32 * c + 32 > a.c0p; };  // workgroup-uniform: some quad of chunk c comes from the half-resolution source
+    __syncthreads();  // (the exchange of the epilogue)
+    return;
+  }
 
+  // ================= MFMA waves =================
+  const int n = lane & 15, g = lane >> 4;
   // ---- weights: three register sets, two chunks ahead
   f32x4 wr[3][4][2];
   const float* const wbase = a.wpack_sm + (size_t)nb * nch * SM_CHUNK_FLOATS + wave * 512 + lane * 4;
@@ -201,7 +214,7 @@ __global__ __launch_bounds__(256) void conv3x3_sm_kernel(ConvArgs a) {
     }
   };
 
-  // ---- MFMA side: wave = Winograd row xi combines patch rows (ra, rb): t = d[ra] + sg d[rb]
+  // ---- wave = Winograd row xi combines patch rows (ra, rb): t = d[ra] + sg d[rb]
   const int ra = wave == 0 ? 0 : (wave == 2 ? 2 : 1);
   const int rb = wave == 0 ? 2 : (wave == 1 ? 2 : (wave == 2 ? 1 : 3));
   const float sg = wave == 1 ? 1.f : -1.f;
@@ -236,29 +249,12 @@ __global__ __launch_bounds__(256) void conv3x3_sm_kernel(ConvArgs a) {
     }
   };
 
-  using I0 = std::integral_constant<int, 0>;
-  using I1 = std::integral_constant<int, 1>;
-  using I2 = std::integral_constant<int, 2>;
-  fetch_raw(0);
   fetch_w(0, I0{});
   if (nch > 1) fetch_w(1, I1{});
-  store_raw(0);
-  if (low_chunk(0)) {
-    __syncthreads();
-    interp(0);
-  }
   __syncthreads();
   auto body = [&](int c, auto S, auto S2) {  // chunk c from register set S; the weights of chunk c + 2 go to set S2 = (S + 2) % 3
-    if (c + 1 < nch) fetch_raw(c + 1);
     if (c + 2 < nch) fetch_w(c + 2, S2);
     compute(c & 1, S);
-    if (c + 1 < nch) {
-      store_raw((c + 1) & 1);
-      if (low_chunk(c + 1)) {
-        __syncthreads();
-        interp((c + 1) & 1);
-      }
-    }
     __syncthreads();
   };
   for (int c = 0; c < nch; c += 3) {
@@ -334,7 +330,10 @@ double sm_cost_us(const ConvArgs& a, int n_cu) {
 int launch_conv3x3_sm(const ConvArgs& a, hipStream_t s) {
   PH_REQUIRE(sm_fits(a), "conv3x3_sm_kernel does not take this shape (ask sm_fits first)");
   const unsigned units = (unsigned)a.B * ((a.H + 7) / 8) * ((a.W + 7) / 8) * (a.coutp / 16);
-  hipLaunchKernelGGL(conv3x3_sm_kernel, dim3(units), dim3(256), 0, s, a);
+  if (a.src1_lowres)
+    hipLaunchKernelGGL(conv3x3_sm_kernel<true>, dim3(units), dim3(512), 0, s, a);
+  else
+    hipLaunchKernelGGL(conv3x3_sm_kernel<false>, dim3(units), dim3(512), 0, s, a);
   PH_HIP_CHECK(hipGetLastError());
   return PH_OK;
 }
