@@ -1167,11 +1167,7 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
           }
           deferred_up = -1;
         }
-        if (conv3x3_takes_sm(a)) {  // small maps at small batches: (8 x 8 pixels, 16 channels) units, one launch, no split K (conv3x3_sm_kernel)
-          kv[op_index - 1] = PH_KV_SMALLMAP;
-          rc = launch_conv3x3_sm(a, s);
-          break;
-        }
+        const bool on_sm = conv3x3_takes_sm(a);  // small maps at small batches: (8 x 8 pixels, 16 channels) units, one launch, no split K (conv3x3_sm_kernel)
         const double fill = (double)s0.h * s0.w / ((double)((s0.h + 15) / 16 * 16) * ((s0.w + 31) / 32 * 32));
         // the halo kernel pads Cout to a multiple of its N tile (64): e.g. Cout = 96 does 33 % extra MFMA work there,
         // none in the row GEMM (N tiles of 96 / 128)
@@ -1186,7 +1182,7 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
           halo_fill = (double)s0.h * s0.w / ((double)((s0.h + 15) / 16 * 16) * ((s0.w + 15) / 16 * 16));
           halo_gain = m->gemm_fill_threshold / m->gemm_fill_threshold_wino2d;
         }
-        if (m->use_dma && d.dst2 < 0 && op.w_gemm_dev && !a.src1_lowres && (halo_fill * halo_gain < m->gemm_fill_threshold || n_fill * halo_fill * halo_gain < 0.8 * n_fill_g)) {
+        if (!on_sm && m->use_dma && d.dst2 < 0 && op.w_gemm_dev && !a.src1_lowres && (halo_fill * halo_gain < m->gemm_fill_threshold || n_fill * halo_fill * halo_gain < 0.8 * n_fill_g)) {
           // small feature map (the 16x32-pixel tiles of the halo kernel would be mostly padding) or a Cout that
           // fits the halo kernel's N tile badly -> 9-tap row GEMM
           GemmArgs g{};
@@ -1221,7 +1217,8 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
             no4.use_wino4 = 0;
             const bool on_w2d = a.coutp == 64 && hx.cout <= 32 && pad16(hx.cin0) == 64 && conv3x3_dma_is_wino2d(no4) && wino2d_ksplit(no4) <= 1;
             const bool on_w16 = a.coutp <= 32 && hx.cout <= 16 && pad16(hx.cin0) == a.coutp && conv3x3_dma_is_w16_head(a);  // (conv3x3_w16_kernel<.., HEAD>)
-            if (!(hx.flags & PH_FLAG_SOFTMAX) && out_dev[hx.out_index] && (on_w2d || on_w16)) {
+            const bool sm_head = on_sm && a.coutp <= 32 && pad16(hx.cin0) == a.coutp;  // (conv3x3_sm_kernel: the workgroup holds every channel of its pixels)
+            if (!(hx.flags & PH_FLAG_SOFTMAX) && out_dev[hx.out_index] && (sm_head || (!on_sm && (on_w2d || on_w16)))) {
               a.head_w = m->ops[j].w_dev;
               a.head_b = m->ops[j].b_dev;
               a.head_dst = out_dev[hx.out_index];
@@ -1250,6 +1247,11 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
             else
               a.dst_pool = nullptr;
           }
+        }
+        if (on_sm) {
+          kv[op_index - 1] = PH_KV_SMALLMAP;
+          rc = launch_conv3x3_sm(a, s);
+          break;
         }
         kv[op_index - 1] = (m->use_dma && (a.bn == 64 || m->dma32)) ? conv3x3_dma_variant(a) : PH_KV_DIRECT;
         rc = (m->use_dma && (a.bn == 64 || m->dma32)) ? launch_conv3x3_dma(a, s) : launch_conv3x3(a, s);

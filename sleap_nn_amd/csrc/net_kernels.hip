@@ -1336,8 +1336,11 @@ bool conv3x3_takes_sm(const ConvArgs& a) {
     const int ks = may_split ? wino2d_ksplit_shape(a.B, a.H, a.W, a.c0p + a.c1p, a.coutp, a.splitk, n_cu) : 1;
     const long t2 = (long)((a.H + 15) / 16) * ((a.W + 15) / 16) * a.B * ntc;
     other = (double)((t2 * ks + n_cu - 1) / n_cu) * (8.0 + 1.0 * Qn / ks) + (ks > 1 ? 8.0 : 0.0);
+  } else if (r == 1) {  // the wave-private kernel: 16 x 32-pixel tiles, ~9 us + 3 us per 16 input channels (cfg1's 128 x 128 levels: 32 workgroups, 9 - 15 us)
+    const long t1 = (long)((a.H + 31) / 32) * ((a.W + 15) / 16) * a.B;
+    other = (double)((t1 + n_cu - 1) / n_cu) * (6.0 + 3.0 * (a.c0p + a.c1p) / 16.0);
   } else {
-    return false;  // the wave-private / 16 -> 16 / F(2,3) kernels keep their layers
+    return false;  // the 16 -> 16 / F(2,3) / direct kernels keep their layers
   }
   return sm_cost_us(a, n_cu) < other + extra;
 }

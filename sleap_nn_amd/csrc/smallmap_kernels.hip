@@ -72,13 +72,17 @@ int launch_sm_pack(const float* wpack, float* dst, int nblocks, int chunks16, in
   return PH_OK;
 }
 
-template <bool LOWRES>
+// NB: N blocks of 16 output channels per workgroup.  2 (Cout a multiple of 32, more units than CUs: the 128 x 128 levels of cfg1) halves the units and shares the halo and its
+// transform between the blocks; the weights of a chunk are then 64 registers, kept one chunk ahead in two sets instead of two ahead in three.
+template <bool LOWRES, int NB>
 __global__ __launch_bounds__(512) void conv3x3_sm_kernel(ConvArgs a) {
-  __shared__ __attribute__((aligned(16))) float lds[2 * SM_BUF];  // two halo buffers; the exchange tile of the epilogue (4096 floats) lies over them
+  constexpr int EXCH = 4096 * NB > 2 * SM_BUF ? 4096 * NB : 2 * SM_BUF;
+  __shared__ __attribute__((aligned(16))) float lds[EXCH + 64 * (16 * NB + 1)];  // two halo buffers (the exchange tile of the epilogue, 4096 NB floats, lies over them) + the output tile a fused head reads
+  constexpr int NSETS = NB == 2 ? 2 : 3;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nblocks = a.coutp >> 4;
+  const int nblocks = (a.coutp >> 4) / NB;
   const int tiles_x = (a.W + 7) >> 3, tiles_y = (a.H + 7) >> 3;
   // consecutive workgroup ids are dealt over the 8 XCDs: with the N block as the fastest index an XCD's L2 holds the weights of one or two N blocks
   int u = blockIdx.x;
@@ -195,22 +199,22 @@ __global__ __launch_bounds__(512) void conv3x3_sm_kernel(ConvArgs a) {
       step(c, I1{});
       if (c + 1 < nch) step(c + 1, I0{});
     }
-    __syncthreads();  // (the exchange of the epilogue)
-    return;
-  }
-
+  } else {
   // ================= MFMA waves =================
   const int n = lane & 15, g = lane >> 4;
-  // ---- weights: three register sets, two chunks ahead
-  f32x4 wr[3][4][2];
-  const float* const wbase = a.wpack_sm + (size_t)nb * nch * SM_CHUNK_FLOATS + wave * 512 + lane * 4;
+  // ---- weights: NSETS register sets, NSETS - 1 chunks ahead
+  f32x4 wr[NSETS][NB][4][2];
+  const float* const wbase = a.wpack_sm + (size_t)nb * NB * nch * SM_CHUNK_FLOATS + wave * 512 + lane * 4;
   auto fetch_w = [&](int c, auto S) {
     constexpr int s = decltype(S)::value;
-    const float* p = wbase + (size_t)c * SM_CHUNK_FLOATS;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      wr[s][j][0] = *reinterpret_cast<const f32x4*>(p + j * SM_PAIR_FLOATS);
-      wr[s][j][1] = *reinterpret_cast<const f32x4*>(p + j * SM_PAIR_FLOATS + 256);
+    for (int ib = 0; ib < NB; ++ib) {
+      const float* p = wbase + ((size_t)ib * nch + c) * SM_CHUNK_FLOATS;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        wr[s][ib][j][0] = *reinterpret_cast<const f32x4*>(p + j * SM_PAIR_FLOATS);
+        wr[s][ib][j][1] = *reinterpret_cast<const f32x4*>(p + j * SM_PAIR_FLOATS + 256);
+      }
     }
   };
 
@@ -221,9 +225,11 @@ __global__ __launch_bounds__(512) void conv3x3_sm_kernel(ConvArgs a) {
   const int tty = n >> 2, ttx = n & 3;
   const int offa = ((2 * tty + ra) * SM_RS + 2 * ttx) * SM_CS + 2 * g;
   const int offb = ((2 * tty + rb) * SM_RS + 2 * ttx) * SM_CS + 2 * g;
-  f32x4 acc[4];
+  f32x4 acc[NB][4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int ib = 0; ib < NB; ++ib)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[ib][i] = f32x4{0.f, 0.f, 0.f, 0.f};
   auto compute = [&](int buf, auto S) {
     constexpr int s = decltype(S)::value;
     const float* const base = lds + buf * SM_BUF;
@@ -237,48 +243,63 @@ __global__ __launch_bounds__(512) void conv3x3_sm_kernel(ConvArgs a) {
         t[c] = da + sg * db;
       }
       const f32x2 v0 = t[0] - t[2], v1 = t[1] + t[2], v2 = t[2] - t[1], v3 = t[1] - t[3];
-      const f32x4 w0 = wr[s][j][0], w1 = wr[s][j][1];
-      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[0], v0[0], acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[2], v1[0], acc[1], 0, 0, 0);
-      acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[0], v2[0], acc[2], 0, 0, 0);
-      acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[2], v3[0], acc[3], 0, 0, 0);
-      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[1], v0[1], acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[3], v1[1], acc[1], 0, 0, 0);
-      acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[1], v2[1], acc[2], 0, 0, 0);
-      acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[3], v3[1], acc[3], 0, 0, 0);
+#pragma unroll
+      for (int ib = 0; ib < NB; ++ib) {
+        const f32x4 w0 = wr[s][ib][j][0], w1 = wr[s][ib][j][1];
+        acc[ib][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[0], v0[0], acc[ib][0], 0, 0, 0);
+        acc[ib][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[2], v1[0], acc[ib][1], 0, 0, 0);
+        acc[ib][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[0], v2[0], acc[ib][2], 0, 0, 0);
+        acc[ib][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[2], v3[0], acc[ib][3], 0, 0, 0);
+        acc[ib][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[1], v0[1], acc[ib][0], 0, 0, 0);
+        acc[ib][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[3], v1[1], acc[ib][1], 0, 0, 0);
+        acc[ib][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[1], v2[1], acc[ib][2], 0, 0, 0);
+        acc[ib][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[3], v3[1], acc[ib][3], 0, 0, 0);
+      }
     }
   };
 
   fetch_w(0, I0{});
-  if (nch > 1) fetch_w(1, I1{});
+  if (NSETS == 3 && nch > 1) fetch_w(1, I1{});
   __syncthreads();
-  auto body = [&](int c, auto S, auto S2) {  // chunk c from register set S; the weights of chunk c + 2 go to set S2 = (S + 2) % 3
-    if (c + 2 < nch) fetch_w(c + 2, S2);
+  auto body = [&](int c, auto S, auto S2) {  // chunk c from register set S; the weights of chunk c + NSETS - 1 go to set S2 = (S + NSETS - 1) % NSETS
+    if (c + NSETS - 1 < nch) fetch_w(c + NSETS - 1, S2);
     compute(c & 1, S);
     __syncthreads();
   };
-  for (int c = 0; c < nch; c += 3) {
-    body(c, I0{}, I2{});
-    if (c + 1 < nch) body(c + 1, I1{}, I0{});
-    if (c + 2 < nch) body(c + 2, I2{}, I1{});
+  if constexpr (NSETS == 3) {
+    for (int c = 0; c < nch; c += 3) {
+      body(c, I0{}, I2{});
+      if (c + 1 < nch) body(c + 1, I1{}, I0{});
+      if (c + 2 < nch) body(c + 2, I2{}, I1{});
+    }
+  } else {
+    for (int c = 0; c < nch; c += 2) {
+      body(c, I0{}, I1{});
+      if (c + 1 < nch) body(c + 1, I1{}, I0{});
+    }
   }
 
-  // ---- epilogue: exchange [position][tile][16 channels] (the barrier that closed the last chunk has every wave out of the halo buffers)
+  // ---- exchange [position][tile][16 NB channels] (the barrier that closed the last chunk has every wave out of the halo buffers)
 #pragma unroll
-  for (int nu = 0; nu < 4; ++nu) *reinterpret_cast<f32x4*>(lds + ((4 * wave + nu) * 16 + n) * 16 + 4 * g) = acc[nu];
+  for (int ib = 0; ib < NB; ++ib)
+#pragma unroll
+    for (int nu = 0; nu < 4; ++nu) *reinterpret_cast<f32x4*>(lds + ((4 * wave + nu) * 16 + n) * (16 * NB) + 16 * ib + 4 * g) = acc[ib][nu];
+  }
   __syncthreads();
-  {
-    const int c = tid & 15, tile = tid >> 4;
+  // ---- epilogue, all eight waves: thread (tile, channel) of the 16 tiles x 16 NB channels
+  if (tid < 256 * NB) {
+    constexpr int CW = 16 * NB;
+    const int c = tid & (CW - 1), tile = tid / CW;
     float m[16];
 #pragma unroll
-    for (int p = 0; p < 16; ++p) m[p] = lds[(p * 16 + tile) * 16 + c];
+    for (int p = 0; p < 16; ++p) m[p] = lds[(p * 16 + tile) * CW + c];
     float s0[4], s1[4];
 #pragma unroll
     for (int nu = 0; nu < 4; ++nu) {
       s0[nu] = (m[0 * 4 + nu] + m[1 * 4 + nu]) + m[2 * 4 + nu];
       s1[nu] = (m[1 * 4 + nu] - m[2 * 4 + nu]) - m[3 * 4 + nu];
     }
-    const float bias = a.bias[16 * nb + c];
+    const float bias = a.bias[CW * nb + c];
     float y[2][2];
     y[0][0] = (s0[0] + s0[1]) + s0[2] + bias;
     y[0][1] = (s0[1] - s0[2]) - s0[3] + bias;
@@ -294,8 +315,9 @@ __global__ __launch_bounds__(512) void conv3x3_sm_kernel(ConvArgs a) {
         float v = y[i][jx];
         if (a.relu) v = fmaxf(v, 0.f);
         const bool in = py + i < a.H && px + jx < a.W;
+        if (a.head_w) lds[EXCH + ((2 * (tile >> 2) + i) * 8 + 2 * (tile & 3) + jx) * (CW + 1) + c] = v;
         if (in) {
-          if (!a.skip_dst) a.dst[((size_t)(b * a.H + py + i) * a.W + px + jx) * a.coutp + 16 * nb + c] = v;
+          if (!a.skip_dst) a.dst[((size_t)(b * a.H + py + i) * a.W + px + jx) * a.coutp + CW * nb + c] = v;
           pooled = first ? v : fmaxf(pooled, v);
           first = false;
         } else {
@@ -305,15 +327,34 @@ __global__ __launch_bounds__(512) void conv3x3_sm_kernel(ConvArgs a) {
     if (a.dst_pool && py < a.H && px < a.W) {
       if (any_out) pooled = fmaxf(pooled, 0.f);
       const int Hp = (a.H + 1) >> 1, Wp = (a.W + 1) >> 1;
-      a.dst_pool[((size_t)(b * Hp + (py >> 1)) * Wp + (px >> 1)) * a.coutp + 16 * nb + c] = pooled;
+      a.dst_pool[((size_t)(b * Hp + (py >> 1)) * Wp + (px >> 1)) * a.coutp + CW * nb + c] = pooled;
+    }
+  }
+  // ---- fused 1x1 head (the workgroup holds every channel of its 64 pixels: Cout = 16 NB): head_dst[b][o][y][x] = (sigmoid)(sum_c head_w[o][c] out[y][x][c] + head_b[o]), NCHW;
+  // wave = head channel (its weights are wave-uniform scalar loads), lane = pixel
+  if (a.head_w) {  // (workgroup-uniform)
+    constexpr int CW = 16 * NB;
+    __syncthreads();
+    const int pl = tid & 63;
+    const int py = y0 + (pl >> 3), px = x0 + (pl & 7);
+    const float* const yrow = lds + EXCH + pl * (CW + 1);
+    for (int o = wave; o < a.head_cout; o += 8) {
+      const float* const hw = a.head_w + (size_t)o * a.head_wcp;
+      float sum = 0.f;
+#pragma unroll
+      for (int cc = 0; cc < CW; ++cc) sum = fmaf(hw[cc], yrow[cc], sum);
+      sum += a.head_b[o];
+      if (a.head_sigmoid) sum = 1.f / (1.f + expf(-sum));
+      if (py < a.H && px < a.W) a.head_dst[(((size_t)b * a.head_cout + o) * a.H + py) * a.W + px] = sum;
     }
   }
 }
 
 // Shapes the kernel takes: exact fp32, any H x W (whole 2 x 2 tiles are computed, stores are masked), channel counts padded to 16; fused pool, unread full-resolution
-// output, two sources, a half-resolution second source (even H, W).  No fused head, no accumulate, no ReLU mask (inference plans only).
+// output, two sources, a half-resolution second source (even H, W), a fused 1x1 head behind a conv of at most 32 output channels.  No accumulate, no ReLU mask (inference plans only).
 bool sm_fits(const ConvArgs& a) {
-  if (!a.wpack_sm || a.head_w || a.accumulate || a.relu_mask_src || (a.coutp & 15) || (a.c0p & 15) || (a.c1p & 15) || a.coutp < 16 || a.c0p < 16) return false;
+  if (a.head_w && !(a.coutp <= 32 && a.head_wcp == a.coutp && a.head_cout >= 1 && a.head_b && a.head_dst)) return false;  // a fused head needs every channel of a pixel in one workgroup
+  if (!a.wpack_sm || a.accumulate || a.relu_mask_src || (a.coutp & 15) || (a.c0p & 15) || (a.c1p & 15) || a.coutp < 16 || a.c0p < 16) return false;
   if (a.src1_lowres && (!a.src1 || (a.H & 1) || (a.W & 1))) return false;
   if (!a.src1 && a.c1p) return false;
   const uint64_t px = (uint64_t)a.B * a.H * a.W;
@@ -322,18 +363,34 @@ bool sm_fits(const ConvArgs& a) {
   return units < 0x7FFFFFFFull;
 }
 // Estimated launch body in microseconds (the dispatch floor excluded, as in wino4_fits): rounds of the chip x (prologue + epilogue ~2.5 us + ~0.8 us per 32-channel chunk)
+static int sm_nb(const ConvArgs& a, int n_cu) {  // N blocks per workgroup
+  const long units1 = (long)a.B * ((a.H + 7) / 8) * ((a.W + 7) / 8) * (a.coutp / 16);
+  if (a.head_w) return a.coutp / 16;  // (sm_fits: Cout <= 32)
+  return ((a.coutp & 31) == 0 && units1 > n_cu) ? 2 : 1;
+}
+// Estimated launch body in microseconds (the dispatch floor excluded, as in wino4_fits): rounds of the chip x (prologue + epilogue ~2.3 us + ~0.95 us per 32-channel chunk, ~1.5 us
+// for a chunk of the half-resolution source; two N blocks: 1.3 / 1.9); calibrated on cfg1's eleven layers (profiles/r5_cfg1_smallmap.txt)
 double sm_cost_us(const ConvArgs& a, int n_cu) {
-  const double units = (double)a.B * ((a.H + 7) / 8) * ((a.W + 7) / 8) * (a.coutp / 16);
+  const int nb = sm_nb(a, n_cu);
+  const double units = (double)a.B * ((a.H + 7) / 8) * ((a.W + 7) / 8) * (a.coutp / 16 / nb);
   const int nch = (a.c0p + a.c1p + 31) / 32;
-  return std::max(1.0, units / (double)n_cu) * (2.5 + 0.8 * nch);
+  const int nlow = a.src1_lowres ? nch - a.c0p / 32 : 0;
+  return std::max(1.0, units / (double)n_cu) * (2.3 + (nb == 2 ? 1.3 : 0.95) * (nch - nlow) + (nb == 2 ? 1.9 : 1.5) * nlow);
 }
 int launch_conv3x3_sm(const ConvArgs& a, hipStream_t s) {
   PH_REQUIRE(sm_fits(a), "conv3x3_sm_kernel does not take this shape (ask sm_fits first)");
-  const unsigned units = (unsigned)a.B * ((a.H + 7) / 8) * ((a.W + 7) / 8) * (a.coutp / 16);
-  if (a.src1_lowres)
-    hipLaunchKernelGGL(conv3x3_sm_kernel<true>, dim3(units), dim3(512), 0, s, a);
+  int n_cu = 0;
+  if (device_cu_count(&n_cu) != PH_OK || n_cu <= 0) n_cu = 256;
+  const int nb = sm_nb(a, n_cu);
+  const unsigned units = (unsigned)a.B * ((a.H + 7) / 8) * ((a.W + 7) / 8) * (a.coutp / 16 / nb);
+  if (a.src1_lowres && nb == 2)
+    hipLaunchKernelGGL((conv3x3_sm_kernel<true, 2>), dim3(units), dim3(512), 0, s, a);
+  else if (a.src1_lowres)
+    hipLaunchKernelGGL((conv3x3_sm_kernel<true, 1>), dim3(units), dim3(512), 0, s, a);
+  else if (nb == 2)
+    hipLaunchKernelGGL((conv3x3_sm_kernel<false, 2>), dim3(units), dim3(512), 0, s, a);
   else
-    hipLaunchKernelGGL(conv3x3_sm_kernel<false>, dim3(units), dim3(512), 0, s, a);
+    hipLaunchKernelGGL((conv3x3_sm_kernel<false, 1>), dim3(units), dim3(512), 0, s, a);
   PH_HIP_CHECK(hipGetLastError());
   return PH_OK;
 }

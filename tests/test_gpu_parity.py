@@ -480,7 +480,7 @@ def test_cfg3_benched_workload_full_size_vs_oracle_and_batch_invariance(precisio
         from sleap_nn_amd import _lib as L
 
         assert L.KV_WINO4 in default_kernels[32] and L.KV_WINO2D_KS not in default_kernels[32]
-        assert L.KV_WINO2D_KS in default_kernels[1]  # the one-frame launch is in the small-batch regime
+        assert L.KV_SMALLMAP in default_kernels[1] or L.KV_WINO2D_KS in default_kernels[1]  # the one-frame launch is in the small-batch regime (conv3x3_sm_kernel / split K)
     # (2) Bit-for-bit batch invariance is a property of ONE kernel choice, so the choice is pinned -- F(4x4,3x3) wherever the shape fits and no split K:
     # exactly the kernel list the default 32-frame forward took (asserted), i.e. the benched kernels are the ones compared bit by bit.
     m.set_option("conv_wino4", 3)
@@ -1185,7 +1185,7 @@ def test_winograd_f4x4_kernel_and_folded_bilinear_match_oracle_and_the_f2x2_kern
     scale = ref.abs().max().item()
     outs, n4 = {}, {}
     # (conv_wino4 = 3 forces the kernel wherever the shape fits: at these sizes the default's cost estimate -- rounds of the chip -- keeps F(2x2,3x3))
-    for name, opts, keep in (("default", {}, False), ("fold", {"conv_wino4": 3}, False), ("nofold", {"conv_wino4": 3, "upsample_fold": 0}, False), ("every_plan", {"conv_wino4": 3}, True), ("f2x2", {"conv_wino4": 0}, False)):
+    for name, opts, keep in (("default", {}, False), ("fold", {"conv_wino4": 3, "conv_smallmap": 0}, False), ("nofold", {"conv_wino4": 3, "upsample_fold": 0, "conv_smallmap": 0}, False), ("every_plan", {"conv_wino4": 3, "conv_smallmap": 0}, True), ("f2x2", {"conv_wino4": 0, "conv_smallmap": 0}, False)):  # (conv_smallmap = 0: this test is about the F(4x4,3x3) kernel; the small-map kernel would take these layers from it at these batch sizes)
         m = Model("unet", bb, heads, "single_instance")
         m.load_state_dict(sd)
         for k, v in opts.items():
@@ -1224,7 +1224,7 @@ def test_winograd_f4x4_kernel_and_folded_bilinear_match_oracle_and_the_f2x2_kern
     assert (outs["fold"] - outs["f2x2"]).abs().max().item() <= W4_RTOL * scale
     again = Model("unet", bb, heads, "single_instance")
     again.load_state_dict(sd)
-    again.set_option("conv_wino4", 3)
+    again.set_option("conv_wino4", 3).set_option("conv_smallmap", 0)
     assert torch.equal(again.to(DEV)(img.to(DEV))["SingleInstanceConfmapsHead"].cpu(), outs["fold"])  # run-to-run bitwise
 
 

@@ -148,7 +148,7 @@ def test_small_map_kernel_on_every_3x3_conv_matches_the_oracle(filters, max_stri
     from sleap_nn_amd.architectures.model import Model
 
     bb = dict(SI_BB, filters=filters, max_stride=max_stride, output_stride=out_stride)
-    heads = {"confmaps": {"part_names": ["a", "b", "c"], "output_stride": out_stride}}
+    heads = {"confmaps": {"part_names": [f"n{i}" for i in range(3 + (hw[1] // 8) % 17)], "output_stride": out_stride}}  # (3 .. 19 head channels: fused behind a conv of <= 32 channels)
     sd = O.init_state(bb, heads, "single_instance", seed=filters + hw[0], head_scale=1.0)
     img = torch.randint(0, 256, (batch, 1, hw[0], hw[1]), dtype=torch.uint8, generator=torch.Generator().manual_seed(hw[1]))
     ref = O.model_forward(sd, bb, heads, "single_instance", img)["SingleInstanceConfmapsHead"]
@@ -162,7 +162,9 @@ def test_small_map_kernel_on_every_3x3_conv_matches_the_oracle(filters, max_stri
         kinds[name] = m.last_kernels()
         assert torch.equal(m(img.to(DEV))["SingleInstanceConfmapsHead"].cpu(), outs[name])
     n_conv = sum(1 for c in kinds["other"] if c in (L.KV_WINO2D, L.KV_WINO2D_KS, L.KV_W16, L.KV_WINO4, L.KV_C16, L.KV_WINO1D, L.KV_DIRECT, L.KV_ROWGEMM))
-    assert kinds["sm"].count(L.KV_SMALLMAP) >= n_conv - 1 and L.KV_SMALLMAP not in kinds["other"], (kinds, n_conv)  # (all but a conv that carries a fused head)
+    assert kinds["sm"].count(L.KV_SMALLMAP) == n_conv and L.KV_SMALLMAP not in kinds["other"], (kinds, n_conv)
+    fused = L.KV_FUSED in kinds["sm"]
+    assert fused == (filters * 2 ** {1: 0, 2: 1, 4: 2, 8: 3, 16: 4}[out_stride] <= 32), kinds["sm"]  # the head rides in the last conv's epilogue when that conv has <= 32 channels
     _close(outs["sm"], ref, "small-map kernel")
     assert (outs["sm"] - outs["other"]).abs().max().item() <= 2e-5 * ref.abs().max().item()
 
@@ -357,6 +359,7 @@ def test_wave_private_kernel_takes_the_two_source_decoder_conv(filters, max_stri
         m = Model("unet", bb, heads, "single_instance")
         m.load_state_dict(sd)
         m.set_option("conv_w16", w16)
+        m.set_option("conv_smallmap", 0)  # (the small-map kernel would take the layer at these sizes)
         outs[name] = m.to(DEV)(img.to(DEV))["SingleInstanceConfmapsHead"].cpu()
         codes, tab = m.last_kernels(), m.op_table(batch, hw[0], hw[1])
         last_concat = [c for r, c in zip(tab, codes) if "refine_conv0" in r["label"]][-1]
@@ -381,6 +384,7 @@ def test_head_fused_into_the_wave_private_kernel_matches_the_head_kernel_and_the
         m = Model("unet", bb, heads, "single_instance")
         m.load_state_dict(sd)
         m.set_option("head_fuse", fuse)
+        m.set_option("conv_smallmap", 0)  # (the small-map kernel, which would run these convs and carries heads of any width, has its own test)
         m.eval()
         outs[fuse] = m.to(DEV)(img.to(DEV))["SingleInstanceConfmapsHead"].cpu()
         head_codes = [c for r, c in zip(m.op_table(batch, hw[0], hw[1]), m.last_kernels()) if r["kind"] == L.OP_HEAD]
