@@ -1342,6 +1342,7 @@ bool conv3x3_takes_sm(const ConvArgs& a) {
   } else {
     return false;  // the 16 -> 16 / F(2,3) / direct kernels keep their layers
   }
+  if ((r == 4 || r == 2) && (a.coutp & 63) != 0 && (a.coutp & 63) <= 32) other *= 0.6;  // the half-empty N tile: the waves of the missing half skip their MFMAs (published workload, 96 -> 32 at 160 x 280 x 4: 55 us measured, 94 modelled)
   return sm_cost_us(a, n_cu) < other + extra;
 }
 bool conv3x3_dma_honours_mask(const ConvArgs& a) {  // the three F(2x2,3x3) / F(4x4,3x3) kernels store lane-locally; the fused pool / head epilogues are forward-only
