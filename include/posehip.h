@@ -224,6 +224,8 @@ int ph_debug_row_wgrad_bench(int32_t M, int32_t n, int32_t k, int32_t iters, flo
  * "gemm_late_split", "gemm_persist2", "conv_gemm_fill", "conv_gemm_fill_wino", "conv_gemm_fill_wino2d",
  * "conv_wino2d" / "conv_w16" (the Winograd F(2x2,3x3) kernels), "conv_wino4" (K-heavy 3x3 convs on the Winograd F(4x4,3x3) kernel: 1 inference
  * plans | 2 every plan | 0 never), "conv_wino4_min_cin", "upsample_fold" (a bilinear x2 read only by the next conv's second source rides in that kernel's input transform), "head_fuse" (a 1x1 head computed in its producer conv's epilogue),
+ * "conv_splitk" / "conv_splitk_finish" / "conv_n32_wino2d" / "conv_smallmap" (the small-batch routings: K split over workgroups, Cout-32 layers on the N-tile-64 kernels,
+ * conv3x3_sm_kernel on (8 x 8 pixels, 16 channels) units for small maps: 1 inference plans where estimated faster | 2 wherever the shape fits | 0 never),
  * "pool_peephole" (unfused programs: a conv writes the next op's 2x2 max pool), "dw_ln_fuse" (ConvNeXt: LayerNorm inside the
  * depthwise / stem kernels), "wgrad_wino" (3x3 weight gradients in the Winograd domain), "mask_fold" (ReLU masks applied by the kernel
  * that completes a gradient).
