@@ -1,0 +1,24 @@
+"""BASELINE cfg1 as a synchronous step (InferenceLayer.predict_graphed + a host sync per frame): what the GPU runs per step under
+`rocprofv3 --kernel-trace -- python3 tools/cfg1_step_probe.py` + tools/trace_gaps.py -- the forward's 15 launches, global_peaks_kernel, one elementwise
+kernel (undo_stride) and ~35 - 48 us of launch + sync latency between steps."""
+import sys, time
+sys.path.insert(0, ".")
+import torch, bench
+from sleap_nn_amd.architectures.model import Model
+from sleap_nn_amd.inference.backends import HipBackend
+from sleap_nn_amd.inference.layers import PostprocessConfig, SingleInstanceLayer
+dev = torch.device("cuda", 0)
+heads = {"confmaps": {"part_names": [f"k{i}" for i in range(5)], "sigma": 2.5, "output_stride": 2, "loss_weight": 1.0}}
+model = Model("unet", bench.SI_BB, heads, "single_instance").init_xavier_(seed=1234, head_scale=0.05).to(dev)
+backend = HipBackend(model, str(dev), use_graph=True)
+layer = SingleInstanceLayer(backend, 2, max_stride=16, postprocess_config=PostprocessConfig(peak_threshold=0.0))
+frames = torch.randint(0, 256, (1, 1, 256, 256), dtype=torch.uint8, device=dev)
+g = layer.graph_input((1, 1, 256, 256)).copy_(frames)
+for _ in range(20):
+    o = layer.predict_graphed(g)
+torch.cuda.synchronize()
+t = time.perf_counter()
+for _ in range(200):
+    o = layer.predict_graphed(g)
+    torch.cuda.synchronize()
+print("sync step us", (time.perf_counter() - t) / 200 * 1e6)
