@@ -71,6 +71,11 @@ class InferenceLayer(ABC):
         (``_GRAPHABLE_POSTPROCESS``) on a ``HipBackend``.  ``raw=True`` (uint8 device batches): the preprocessing is captured as well -- one launch per batch."""
         if not self._GRAPHABLE_POSTPROCESS or not hasattr(self.backend, "model"):
             raise RuntimeError(f"{type(self).__name__} on {type(self.backend).__name__} cannot run as one graph (host stage in its post-process, or a foreign backend)")
+        fast = self.__dict__.get("_graph_fast")
+        if fast is not None and image is fast[0] and self.backend.model.generation == self.__dict__.get("_step_graph_generation") and self.postprocess_config is fast[2] and self.preprocess_config is fast[3]:
+            # the caller refilled the graph's own input buffer (``graph_input``): nothing to preprocess, stage or look up -- a latency loop's step is the replay (~20 us less host time per frame)
+            fast[1][0].replay()
+            return fast[1][2]
         if raw and torch.is_tensor(image) and image.is_cuda and image.dtype == torch.uint8:
             # the batch as it arrives: its preprocessing launches (resizes, pads: functions of the shape) are captured in front of the forward
             x, code = image, None
@@ -91,7 +96,11 @@ class InferenceLayer(ABC):
     def graph_input(self, shape) -> torch.Tensor:
         """The input buffer of ``predict_graphed``'s graph for preprocessed frames of ``shape`` ((B, C, H, W) uint8; captured on first use)."""
         x, info = self.preprocess(torch.zeros(tuple(shape), dtype=torch.uint8, device=self.backend.device))
-        return self._graph_entry(x.to(torch.device(self.backend.device)), info, None)[1].squeeze(1)
+        entry = self._graph_entry(x.to(torch.device(self.backend.device)), info, None)
+        buf = entry[1].squeeze(1)
+        # (the tensor object handed out, its entry and the configs the entry was keyed on: ``predict_graphed(buf)`` replays without recomputing any of it while they are the same objects)
+        self.__dict__["_graph_fast"] = (buf, entry, self.postprocess_config, self.preprocess_config) if tuple(x.shape[-2:]) == tuple(shape)[-2:] and x.dtype == torch.uint8 else None
+        return buf
 
     def _graph_entry(self, x: torch.Tensor, info: Optional[PreprocInfo], code, body=None, extra_key=(), pre=None):
         """``(graph, static input, static result, workspace, info)`` for device frames ``x`` with input code ``code`` (HipBackend.input_code).  ``body(raw_out, info)`` is what follows

@@ -73,6 +73,13 @@ def test_cfg1_single_instance_256_batch1_network_and_global_peaks():
     e2 = layer.predict(img[1:2])
     assert torch.equal(g2.pred_keypoints, e2.pred_keypoints) and not torch.equal(e2.pred_keypoints, eager_out.pred_keypoints)
     assert torch.equal(layer.predict_graphed(img[:1]).pred_keypoints, eager_out.pred_keypoints)  # a foreign tensor is copied into the graph's buffer
+    # the graph's own buffer takes the fast path (replay only): it must notice a replaced post-process config and a refilled buffer all the same
+    gin.copy_(img[:1])
+    assert torch.equal(layer.predict_graphed(gin).pred_keypoints, eager_out.pred_keypoints)
+    layer.postprocess_config = PostprocessConfig(peak_threshold=10.0)  # nothing passes
+    assert torch.isnan(layer.predict_graphed(gin).pred_keypoints).all() and torch.isnan(layer.predict(img[:1]).pred_keypoints).all()
+    layer.postprocess_config = PostprocessConfig(peak_threshold=-1.0)
+    assert torch.equal(layer.predict_graphed(gin).pred_keypoints, eager_out.pred_keypoints)
     # float frames take normalize_on_gpu's data-dependent branch in the graphed step exactly as in predict: 0..255 floats are divided by 255, 0..1 floats are not
     f255 = img[:1].to(torch.float32)
     f01 = f255 / 255.0

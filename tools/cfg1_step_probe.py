@@ -22,3 +22,19 @@ for _ in range(200):
     o = layer.predict_graphed(g)
     torch.cuda.synchronize()
 print("sync step us", (time.perf_counter() - t) / 200 * 1e6)
+# host cost of one call (enqueue only): the loop returns long before the GPU is done
+torch.cuda.synchronize()
+t = time.perf_counter()
+for _ in range(200):
+    o = layer.predict_graphed(g)
+host = (time.perf_counter() - t) / 200 * 1e6
+torch.cuda.synchronize()
+print("host us per call (enqueue only)", host)
+import cProfile, pstats
+pr = cProfile.Profile()
+pr.enable()
+for _ in range(300):
+    o = layer.predict_graphed(g)
+pr.disable()
+torch.cuda.synchronize()
+pstats.Stats(pr).sort_stats("cumulative").print_stats(14)
