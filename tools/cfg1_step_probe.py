@@ -38,3 +38,16 @@ for _ in range(300):
 pr.disable()
 torch.cuda.synchronize()
 pstats.Stats(pr).sort_stats("cumulative").print_stats(14)
+# the same step launched kernel by kernel (InferenceLayer.predict: preprocessing, one ctypes call for the forward's launches, the post-process ops), synchronous
+for fn, name in ((lambda: layer.predict(frames), "predict (eager launches)"), (lambda: layer.predict_graphed(g), "predict_graphed (own buffer)")):
+    for _ in range(20):
+        fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(300):
+        t = time.perf_counter()
+        fn()
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t)
+    ts.sort()
+    print(name, "sync step us: median", ts[150] * 1e6, "p10", ts[30] * 1e6)
