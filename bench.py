@@ -402,6 +402,24 @@ def main():
         dist.destroy_process_group()
 
 
+def conv_kernel_short_names():
+    """PH_KV_* code of a 3x3 conv launch -> the key its launches are summed under in `roofline.kernels` (tests/test_bench_line_cpu.py: every conv family the library can report has one)."""
+    from sleap_nn_amd import _lib as L
+
+    return {L.KV_DIRECT: "direct", L.KV_WINO1D: "wino1d", L.KV_WINO2D: "wino2d", L.KV_W16: "w16", L.KV_C16: "c16", L.KV_ROWGEMM: "rowgemm", L.KV_WINO4: "wino4", L.KV_F16: "f16",
+            L.KV_WINO2D_KS: "wino2d", L.KV_SMALLMAP: "smallmap"}  # (the split-K launches of small batches are the same kernel family)
+
+
+def conv_kernel_long_names(precision="exact"):
+    return {"wino2d": "conv3x3_wino2d_kernel<64> (Winograd F(2x2,3x3), 4/9 of the direct MFMA work)",
+            "wino4": "conv3x3_wino4_kernel (Winograd F(4x4,3x3), 1/4 of the direct MFMA work; the decoder's bilinear x2 folded into its input transform)",
+            "w16": "conv3x3_w16_kernel<1|2> (wave-private Winograd F(2x2,3x3) on the 16x16x4 MFMA, Cout 32, 4/9 of the direct MFMA work)",
+            "wino1d": "conv3x3_wino_persist_kernel<64|32> (Winograd F(2,3) along x, 2/3 of the direct MFMA work)",
+            "direct": "conv3x3_mfma_dma_persist_kernel<64|32> (direct)", "c16": "conv3x3_c16_kernel (direct)", "rowgemm": "gemm_mfma_dma_kernel<2> (9-tap row GEMM, direct)",
+            "smallmap": "conv3x3_sm_kernel (Winograd F(2x2,3x3) on 8x8-pixel x 16-channel units: small maps at small per-rank batches, 4/9 of the direct MFMA work)",
+            "f16": f"conv3x3_f16_persist_kernel<64|32, {3 if precision == 'split' else 1}> (direct, fp16 matrix pipe)"}
+
+
 def run_infer(args, ctx):
     rank, world, dev, dist = ctx["rank"], ctx["world"], ctx["dev"], ctx["dist"]
     from concurrent.futures import ThreadPoolExecutor
@@ -719,7 +737,7 @@ def run_infer(args, ctx):
     eager(frames)
     kv = model.last_kernels()
     torch.cuda.synchronize()
-    KSHORT = {L.KV_DIRECT: "direct", L.KV_WINO1D: "wino1d", L.KV_WINO2D: "wino2d", L.KV_W16: "w16", L.KV_C16: "c16", L.KV_ROWGEMM: "rowgemm", L.KV_WINO4: "wino4", L.KV_F16: "f16", L.KV_WINO2D_KS: "wino2d", L.KV_SMALLMAP: "smallmap"}  # (the split-K launches of small batches are the same kernel family)
+    KSHORT = conv_kernel_short_names()
     by_kernel = {}
     for (r, ms), code in zip(conv_rows, [c for row, c in zip(table, kv) if row["kind"] == L.OP_CONV]):
         share = (3.0 if precision == "split" else 1.0) if code == L.KV_F16 else L.KV_MFMA_SHARE[code]
@@ -735,13 +753,7 @@ def run_infer(args, ctx):
     achieved = D["executed_flops"] / (D["ms"] * 1e-3) / 1e12 if D["ms"] > 0 else 0.0
     executed_all = sum(e["executed_flops"] for e in by_kernel.values())
     peak = MFMA_F16_PEAK_TFLOPS if fp16 else MFMA_F32_PEAK_TFLOPS
-    KERNEL_NAMES = {"wino2d": "conv3x3_wino2d_kernel<64> (Winograd F(2x2,3x3), 4/9 of the direct MFMA work)",
-                    "wino4": "conv3x3_wino4_kernel (Winograd F(4x4,3x3), 1/4 of the direct MFMA work; the decoder's bilinear x2 folded into its input transform)",
-                    "w16": "conv3x3_w16_kernel<1|2> (wave-private Winograd F(2x2,3x3) on the 16x16x4 MFMA, Cout 32, 4/9 of the direct MFMA work)",
-                    "wino1d": "conv3x3_wino_persist_kernel<64|32> (Winograd F(2,3) along x, 2/3 of the direct MFMA work)",
-                    "direct": "conv3x3_mfma_dma_persist_kernel<64|32> (direct)", "c16": "conv3x3_c16_kernel (direct)", "rowgemm": "gemm_mfma_dma_kernel<2> (9-tap row GEMM, direct)",
-                    "smallmap": "conv3x3_sm_kernel (Winograd F(2x2,3x3) on 8x8-pixel x 16-channel units: small maps at small per-rank batches, 4/9 of the direct MFMA work)",
-                    "f16": f"conv3x3_f16_persist_kernel<64|32, {3 if precision == 'split' else 1}> (direct, fp16 matrix pipe)"}
+    KERNEL_NAMES = conv_kernel_long_names(precision)
     # HBM traffic of the conv launches: measured with rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction, WRITE_SIZE;
     # tools/summarize_pmc.py) on this same command and committed under profiles/; bench.py itself cannot read PMCs, so it
     # reports the newest committed figure whose launch count matches this run.

@@ -94,3 +94,15 @@ def test_training_headline_goes_through_the_same_line(bench, full):
     leg = dict(full["train_cfg4"], n_gpus=1, warmup=2, higher_is_better=True, scaling="strong", vs_baseline=None)
     line = strict(bench.contract_line(leg, None))
     assert line["metric"].startswith("frames/sec training step") and line["roofline"]["frac"] == pytest.approx(full["train_cfg4"]["roofline"]["frac"], rel=1e-4)
+
+
+def test_every_conv_kernel_family_the_library_reports_has_a_name_in_the_bench():
+    """A per-rank batch of a multi-GPU run can route layers to kernel families the 32-frame forward never takes (round 5: conv3x3_sm_kernel at 2 - 3 frames per rank):
+    the bench's per-kernel accounting must know every PH_KV_* code a 3x3 conv can come back with."""
+    import bench
+    from sleap_nn_amd import _lib as L
+
+    short, long_ = bench.conv_kernel_short_names(), bench.conv_kernel_long_names()
+    conv_codes = {v for k, v in vars(L).items() if k.startswith("KV_") and isinstance(v, int)} - {L.KV_NONE, L.KV_FUSED, L.KV_STEM}
+    assert conv_codes <= set(short), sorted(conv_codes - set(short))
+    assert set(short.values()) <= set(long_) and set(L.KV_NAMES) >= conv_codes and set(L.KV_MFMA_SHARE) >= conv_codes
