@@ -24,6 +24,11 @@ struct ConvF16Args {
   int bn = 64;                   // N tile (= the tile the weights were packed for)
   int prec = 3;                  // 3 split fp16, 1 plain fp16
   const float* zeros = nullptr;  // >= 64 B of zeros in HBM
+  // fused 1x1 head (prec 1, bn 64, coutp 64, no pool): head_dst[b][o][y][x] = (sigmoid)(sum_c head_w[o][c] out[y][x][c] + head_b[o]) on the fp16-rounded output, NCHW fp32
+  const float* head_w = nullptr;  // [head_cout][head_wcp] fp32 (the head op's own weights), or nullptr
+  const float* head_b = nullptr;
+  float* head_dst = nullptr;
+  int head_cout = 0, head_wcp = 0, head_sigmoid = 0;
   unsigned long long* clock_probe = nullptr;  // diagnostic (ph_model_set_clock_probe): per workgroup {d s_memtime, d s_memrealtime}; nullptr = off
 };
 

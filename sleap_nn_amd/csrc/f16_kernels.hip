@@ -45,7 +45,7 @@ __device__ __forceinline__ float lane_xor1(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));
 }
 
-template <int BN, int PREC>
+template <int BN, int PREC, bool HEAD = false>
 __global__ __launch_bounds__(512, 2) void conv3x3_f16_persist_kernel(ConvF16Args a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int NT = BN / 32;
@@ -145,6 +145,30 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16_persist_kernel(ConvF16Args
     }
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)(buf + p * 256), 16, 0, 0);
   };
+
+  // fused head: its weights as fp16 (hi, lo' = (w - hi) 2^11) fragments behind the two ring buffers, [hi | lo'][K step 4][K block lh 2][head channel 32][8]: 8 KiB, written once
+  // (the barrier in front of the K loop publishes them)
+  _Float16* const hw_lds = reinterpret_cast<_Float16*>(lds + 2 * BUF_FLOATS);
+  if constexpr (HEAD) {
+    if (tid < 256) {
+      const int ks = tid >> 6, hh = (tid >> 5) & 1, o = tid & 31;
+      f32x4 w0 = {0.f, 0.f, 0.f, 0.f}, w1 = w0;
+      if (o < a.head_cout) {
+        w0 = *reinterpret_cast<const f32x4*>(a.head_w + (size_t)o * a.head_wcp + 16 * ks + 8 * hh);
+        w1 = *reinterpret_cast<const f32x4*>(a.head_w + (size_t)o * a.head_wcp + 16 * ks + 8 * hh + 4);
+      }
+      f16x8 hi, lo;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        hi[k] = split_hi(w0[k]);
+        lo[k] = split_lo(w0[k], hi[k]);
+        hi[4 + k] = split_hi(w1[k]);
+        lo[4 + k] = split_lo(w1[k], hi[4 + k]);
+      }
+      *reinterpret_cast<f16x8*>(hw_lds + tid * 8) = hi;
+      *reinterpret_cast<f16x8*>(hw_lds + 2048 + tid * 8) = lo;
+    }
+  }
 
   // fragment read offsets (floats, buffer-relative): pixel (row 2w + rr, x + kx) quad lh (+ 2 g)
   int offA[4][3];
@@ -280,9 +304,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16_persist_kernel(ConvF16Args
         if constexpr (DST_FMT == FMT_SPLIT) lo[k] = split_lo(src4[k], h);
       }
     };
+    // fused 1x1 head (plain fp16, one N tile of 64 = every channel of a pixel in this workgroup): the staged fp16 row [32 pixels][64 channels] of the wave is the B operand of eight
+    // v_mfma_f32_32x32x16_f16 (lane = pixel lx, K block lh: one ds_read_b128 per K step), the head's fp32 weights [o][c] -- converted on the way, rows beyond head_cout zero -- the A
+    // operand; D = lane (pixel, head channels 8 (i >> 2) + 4 lh + (i & 3)): NCHW stores, 32 consecutive pixels per head channel
+    constexpr bool fused_head = HEAD && PREC == 1 && BN == 64;  // (its own instantiation: the sixteen accumulator registers of the head cost the plain kernel eleven spills)
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
-      if (a.skip_dst) break;  // nobody reads the full-resolution output: only the pooled one below
+      if (a.skip_dst && !fused_head) break;  // nobody reads the full-resolution output: only the pooled one below
       const int y = y0 + 2 * wave + m;
 #pragma unroll
       for (int n = 0; n < NT; ++n)
@@ -299,6 +327,31 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16_persist_kernel(ConvF16Args
           }
         }
       const bool y_ok = y < a.H;
+      if constexpr (fused_head) {
+        {
+          f32x16 hacc, haccx;  // weights as (hi, lo' = (w - hi) 2^11): the separate head kernel multiplies the same fp16-rounded activations by fp32 weights
+#pragma unroll
+          for (int r = 0; r < 16; ++r) hacc[r] = haccx[r] = 0.f;
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks) {
+            const f16x8 yv = *reinterpret_cast<const f16x8*>(my + lx * SEGP + (16 * ks + 8 * lh) * 2);
+            const f16x8 hw = *reinterpret_cast<const f16x8*>(hw_lds + ((ks * 2 + lh) * 32 + lx) * 8);
+            const f16x8 hwl = *reinterpret_cast<const f16x8*>(hw_lds + 2048 + ((ks * 2 + lh) * 32 + lx) * 8);
+            hacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(hw, yv, hacc, 0, 0, 0);
+            haccx = __builtin_amdgcn_mfma_f32_32x32x16_f16(hwl, yv, haccx, 0, 0, 0);
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int o = 8 * (r >> 2) + 4 * lh + (r & 3);
+            if (o < a.head_cout && y_ok && x_ok) {
+              float hv = hacc[r] + haccx[r] * SPLIT_INV + a.head_b[o];
+              if (a.head_sigmoid) hv = 1.f / (1.f + expf(-hv));
+              a.head_dst[(((size_t)b * a.head_cout + o) * a.H + y) * a.W + x] = hv;
+            }
+          }
+        }
+      }
+      if (a.skip_dst) continue;
       char* const drow = reinterpret_cast<char*>(a.dst) + ((size_t)(b * a.H + (y_ok ? y : 0)) * a.W + x0) * rsb + (size_t)ntile * SEG;
 #pragma unroll
       for (int it = 0; it < 32 * PER / 64; ++it) {
@@ -310,7 +363,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16_persist_kernel(ConvF16Args
         if (y_ok && x0 + pp < a.W && c_first < a.coutp) __builtin_nontemporal_store(piece, reinterpret_cast<f32x4*>(drow + (size_t)pp * rsb + j * 16));
       }
     }
-    if (a.dst_pool) {  // fused 2x2/2 max pool ("same": zeros beyond the image; values are >= 0 after the ReLU)
+    if (!fused_head && a.dst_pool) {  // (a fused head excludes the pool: launch_conv3x3_f16)  fused 2x2/2 max pool ("same": zeros beyond the image; values are >= 0 after the ReLU)
       const int Hp = (a.H + 1) >> 1, Wp = (a.W + 1) >> 1;
       const int yt = y0 + 2 * wave;
       const bool y1_ok = yt + 1 < a.H;
@@ -419,6 +472,8 @@ int launch_conv3x3_f16(const ConvF16Args& a, hipStream_t s) {
   PH_REQUIRE(a.prec == 1 || a.prec == 3, "conv3x3_f16: precision must be 1 (fp16) or 3 (split fp16)");
   PH_REQUIRE(a.bn == 32 || a.bn == 64, "conv3x3_f16: N tile must be 32 or 64");
   PH_REQUIRE(a.chunks0 > 0 && (a.chunks1 == 0 || a.src1), "conv3x3_f16: bad sources");
+  PH_REQUIRE(!a.head_w || (a.prec == 1 && a.bn == 64 && a.coutp == 64 && !a.dst_pool && a.head_cout >= 1 && a.head_cout <= 32 && a.head_wcp == 64 && a.head_b && a.head_dst),
+             "conv3x3_f16: a fused head needs the plain fp16 precision on ONE N tile of 64 output channels, at most 32 head channels, no fused pool");
   int n_cu = 0;  // persistent workgroups: one per CU of the current device
   {
     const int rc_cu = device_cu_count(&n_cu);
@@ -426,12 +481,14 @@ int launch_conv3x3_f16(const ConvF16Args& a, hipStream_t s) {
   }
   const int tiles = ((a.W + TW - 1) / TW) * ((a.H + TH - 1) / TH) * a.B;
   const int total = tiles * ((a.coutp + a.bn - 1) / a.bn);
-  const size_t lds = (size_t)2 * (A_PIECES + 9 * a.bn / 16) * 1024;
+  const size_t lds = (size_t)2 * (A_PIECES + 9 * a.bn / 16) * 1024 + (a.head_w ? 8192 : 0);  // (+ the fused head's weight fragments)
   const dim3 grid(std::min(total, n_cu));
   if (a.bn == 64 && a.prec == 3)
     hipLaunchKernelGGL((conv3x3_f16_persist_kernel<64, 3>), grid, dim3(512), lds, s, a);
   else if (a.bn == 32 && a.prec == 3)
     hipLaunchKernelGGL((conv3x3_f16_persist_kernel<32, 3>), grid, dim3(512), lds, s, a);
+  else if (a.bn == 64 && a.head_w)
+    hipLaunchKernelGGL((conv3x3_f16_persist_kernel<64, 1, true>), grid, dim3(512), lds, s, a);
   else if (a.bn == 64)
     hipLaunchKernelGGL((conv3x3_f16_persist_kernel<64, 1>), grid, dim3(512), lds, s, a);
   else
@@ -704,6 +761,7 @@ int prepare_f16_kernels() {
   if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_f16_persist_kernel<32, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_f16_persist_kernel<64, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_f16_persist_kernel<32, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_f16_persist_kernel<64, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e != hipSuccess) {
     set_error("hipFuncSetAttribute(conv f16) failed: %s", hipGetErrorString(e));
     return PH_E_HIP;

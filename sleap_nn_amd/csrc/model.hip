@@ -1077,6 +1077,29 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
           f.prec = fmt == FMT_F16 ? 1 : 3;
           f.zeros = m->zeros_dev;
           f.clock_probe = m->clock_probe ? m->clock_probe + 2 * 1024 * (op_index - 1) : nullptr;  // one 1024-workgroup record block per op
+          if (m->head_fuse && fmt == FMT_F16 && !f.dst_pool && op.bn == 64 && so.cp == 64) {
+            // plain fp16: a 1x1 head that reads this conv's 64-channel output rides in its epilogue (four MFMAs on the staged fp16 row); when nothing else reads the tensor it never reaches HBM
+            for (size_t j = op_index; j < m->ops.size(); ++j) {
+              const ph_op_desc& hx = m->ops[j].d;
+              if (hx.kind != PH_OP_HEAD || hx.src0 != d.dst) continue;
+              if (!(hx.flags & PH_FLAG_SOFTMAX) && out_dev[hx.out_index] && hx.cout <= 32 && pad16(hx.cin0) == 64) {
+                f.head_w = m->ops[j].w_dev;
+                f.head_b = m->ops[j].b_dev;
+                f.head_dst = out_dev[hx.out_index];
+                f.head_cout = hx.cout;
+                f.head_wcp = 64;
+                f.head_sigmoid = (hx.flags & PH_FLAG_SIGMOID) ? 1 : 0;
+                head_done[j] = 1;
+                if (plan.reuse) {
+                  bool other = false;
+                  for (size_t k = 0; k < m->ops.size(); ++k)
+                    if (k != j && (m->ops[k].d.src0 == d.dst || m->ops[k].d.src1 == d.dst)) other = true;
+                  if (!other) f.skip_dst = 1;
+                }
+              }
+              break;
+            }
+          }
           kv[op_index - 1] = PH_KV_F16;
           rc = launch_conv3x3_f16(f, s);
           break;
@@ -1347,6 +1370,29 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
           f.prec = fmt == FMT_F16 ? 1 : 3;
           f.zeros = m->zeros_dev;
           f.clock_probe = m->clock_probe ? m->clock_probe + 2 * 1024 * (op_index - 1) : nullptr;  // one 1024-workgroup record block per op
+          if (m->head_fuse && fmt == FMT_F16 && !f.dst_pool && op.bn == 64 && so.cp == 64) {
+            // plain fp16: a 1x1 head that reads this conv's 64-channel output rides in its epilogue (four MFMAs on the staged fp16 row); when nothing else reads the tensor it never reaches HBM
+            for (size_t j = op_index; j < m->ops.size(); ++j) {
+              const ph_op_desc& hx = m->ops[j].d;
+              if (hx.kind != PH_OP_HEAD || hx.src0 != d.dst) continue;
+              if (!(hx.flags & PH_FLAG_SOFTMAX) && out_dev[hx.out_index] && hx.cout <= 32 && pad16(hx.cin0) == 64) {
+                f.head_w = m->ops[j].w_dev;
+                f.head_b = m->ops[j].b_dev;
+                f.head_dst = out_dev[hx.out_index];
+                f.head_cout = hx.cout;
+                f.head_wcp = 64;
+                f.head_sigmoid = (hx.flags & PH_FLAG_SIGMOID) ? 1 : 0;
+                head_done[j] = 1;
+                if (plan.reuse) {
+                  bool other = false;
+                  for (size_t k = 0; k < m->ops.size(); ++k)
+                    if (k != j && (m->ops[k].d.src0 == d.dst || m->ops[k].d.src1 == d.dst)) other = true;
+                  if (!other) f.skip_dst = 1;
+                }
+              }
+              break;
+            }
+          }
           kv[op_index - 1] = PH_KV_F16;
           rc = launch_conv3x3_f16(f, s);
           break;

@@ -579,6 +579,36 @@ def test_fp16_pipe_odd_sizes_pool_padding_and_bitwise_determinism():
         assert torch.equal(a, b), prec
 
 
+@pytest.mark.parametrize("hw,batch,nodes,out_stride", [((96, 128), 2, 17, 4), ((104, 72), 1, 5, 4), ((64, 160), 3, 32, 4), ((64, 64), 1, 33, 4)])
+def test_head_fused_into_the_fp16_conv_epilogue_matches_the_head_kernel_and_the_oracle(hw, batch, nodes, out_stride):
+    """Plain fp16 (autocast mode): the 1x1 head behind the last decoder conv of 64 channels (filters 16, output stride 4) as four v_mfma_f32_32x32x16_f16 on the conv kernel's staged
+    fp16 row -- image-cut tiles, 1 .. 32 head channels (33: not fused, the head kernel runs), an inference plan (the conv's own output never reaches HBM) and a keep-everything plan;
+    vs the separate head launch (head_fuse = 0: the same fp16-rounded activations, another summation order) and vs the oracle at the fp16 bar."""
+    from sleap_nn_amd.architectures.model import Model
+    from sleap_nn_amd import _lib as L
+
+    bb = {"in_channels": 1, "kernel_size": 3, "filters": 16, "filters_rate": 2, "max_stride": 8, "stem_stride": None, "middle_block": True, "up_interpolate": True,
+          "stacks": 1, "convs_per_block": 2, "output_stride": out_stride}
+    heads = {"confmaps": {"part_names": [f"n{i}" for i in range(nodes)], "output_stride": out_stride}}
+    sd = O.init_state(bb, heads, "single_instance", seed=nodes, head_scale=1.0)
+    img = torch.randint(0, 256, (batch, 1, hw[0], hw[1]), dtype=torch.uint8, generator=torch.Generator().manual_seed(hw[1]))
+    ref = O.model_forward(sd, bb, heads, "single_instance", img)["SingleInstanceConfmapsHead"]
+    outs = {}
+    for fuse, reuse in ((1, 1), (1, 0), (0, 1)):
+        m = Model("unet", bb, heads, "single_instance")
+        m.load_state_dict(sd)
+        m.set_option("head_fuse", fuse).set_option("workspace_reuse", reuse)
+        m.to(DEV).set_precision("fp16")
+        outs[(fuse, reuse)] = m(img.to(DEV))["SingleInstanceConfmapsHead"].cpu()
+        head_codes = [c for r, c in zip(m.op_table(batch, hw[0], hw[1]), m.last_kernels()) if r["kind"] == L.OP_HEAD]
+        assert head_codes == [L.KV_FUSED if (fuse and nodes <= 32) else L.KV_NONE], (fuse, head_codes)
+        assert torch.equal(m(img.to(DEV))["SingleInstanceConfmapsHead"].cpu(), outs[(fuse, reuse)])
+    scale = ref.abs().max().item()
+    assert (outs[(1, 1)] - ref).abs().max().item() <= FP16_ATOL
+    assert torch.equal(outs[(1, 1)], outs[(1, 0)])  # the unread-output form stores nothing else
+    assert (outs[(1, 1)] - outs[(0, 1)]).abs().max().item() <= 2e-6 * max(scale, 1.0)  # same fp16 operands, fp32 accumulation in another order
+
+
 def test_training_module_keeps_exact_fp32_while_inference_runs_split():
     """A model set to "split" for inference switches to the exact fp32 program for training (the backward needs fp32
     activations) and back; ph_model_backward refuses activations of an fp16-pipe forward."""
