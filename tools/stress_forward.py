@@ -1,6 +1,6 @@
 """Randomised forward parity sweep (UNet + ConvNeXt configs with awkward channel counts / sizes) vs the oracle.
 
-    python tools/stress_forward.py [n_cases] [seed]
+    python tools/stress_forward.py [n_cases] [seed] [option=value ...]     (handle options, e.g. conv_smallmap=2 forces conv3x3_sm_kernel onto every 3x3 conv it takes)
 """
 import sys
 
@@ -11,8 +11,11 @@ sys.path.insert(0, ".")
 from oracle import cpu_ref as O
 from sleap_nn_amd.architectures.model import Model
 
-n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 30
-rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+pos = [a for a in sys.argv[1:] if "=" not in a]
+opts = {a.split("=")[0]: float(a.split("=")[1]) for a in sys.argv[1:] if "=" in a}
+n_cases = int(pos[0]) if len(pos) > 0 else 30
+rng = np.random.default_rng(int(pos[1]) if len(pos) > 1 else 0)
+kinds_seen = {}
 worst = 0.0
 for case in range(n_cases):
     if case % 3 != 2:
@@ -54,9 +57,13 @@ for case in range(n_cases):
         ref = O.model_forward(sd, bb, heads, mt, img, backbone=kind)
         m = Model(kind, bb, heads, mt)
         m.load_state_dict(sd)
+        for k_, v_ in opts.items():
+            m.set_option(k_, v_)
         m.to("cuda:0")
         out = m(img.to("cuda:0"))
         torch.cuda.synchronize()
+        for c_ in m.last_kernels():
+            kinds_seen[c_] = kinds_seen.get(c_, 0) + 1
     except Exception as e:  # configs the product rejects on purpose must be rejected by a clear error
         print(f"case {case}: {kind} {type(e).__name__}: {str(e)[:120]}")
         continue
@@ -64,5 +71,8 @@ for case in range(n_cases):
     worst = max(worst, err)
     flag = "" if err <= 1e-4 else "   <-- FAIL"
     print(f"case {case}: {kind} {mt} B={B} {H}x{W} bb={ {k: v for k, v in bb.items() if k in ('filters', 'filters_rate', 'max_stride', 'output_stride', 'convs_per_block', 'up_interpolate', 'arch', 'stem_patch_kernel', 'stem_patch_stride')} } err={err:.2e}{flag}")
+from sleap_nn_amd import _lib as L
+
+print("kernel families over the sweep:", {L.KV_NAMES[c].split(" ")[0]: n for c, n in sorted(kinds_seen.items()) if c})
 print("worst", worst)
 sys.exit(0 if worst <= 1e-4 else 1)
