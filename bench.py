@@ -471,7 +471,10 @@ def run_infer(args, ctx):
         model_b = Model("unet", CFG3_BB, CFG3_HEADS, "bottomup")
         model_b.init_xavier_(seed=1234, head_scale=0.05)
         backend_b = HipBackend(model_b, str(dev), use_graph=True, precision=precision)
-        lanes = [(backend, layer, torch.cuda.Stream(dev)), (backend_b, BottomUpLayer(backend_b, PAFScorer.from_config(CFG3_HEADS), 4, 8, max_stride=32), torch.cuda.Stream(dev))]
+        from sleap_nn_amd.inference.predictor import concurrent_streams
+
+        lane_st = concurrent_streams(dev, 2)  # (two streams on ONE hardware queue would run in order: chosen by a measured overlap)
+        lanes = [(backend, layer, lane_st[0]), (backend_b, BottomUpLayer(backend_b, PAFScorer.from_config(CFG3_HEADS), 4, 8, max_stride=32), lane_st[1])]
     step_no, last_stream = [0], [None]
 
     heads_in = {"cms": cms, "pafs": pafs, "info": info}  # rebound for the weak-scaling leg of a multi-GPU run
@@ -656,7 +659,9 @@ def run_infer(args, ctx):
                     model2 = Model("unet", CFG3_BB, CFG3_HEADS, "bottomup")
                     model2.init_xavier_(seed=1234, head_scale=0.05)
                     backend2 = HipBackend(model2, str(dev), use_graph=True, precision=precision)
-                    heads_in["lane2"] = (backend2, BottomUpLayer(backend2, PAFScorer.from_config(CFG3_HEADS), 4, 8, max_stride=32), [torch.cuda.Stream(dev), torch.cuda.Stream(dev)])
+                    from sleap_nn_amd.inference.predictor import concurrent_streams
+
+                    heads_in["lane2"] = (backend2, BottomUpLayer(backend2, PAFScorer.from_config(CFG3_HEADS), 4, 8, max_stride=32), concurrent_streams(dev, 2))
                 backend2, layer2, lanes_st = heads_in["lane2"]
                 sframes2 = backend2.static_input((sb, 1, SIZE, SIZE)).copy_(sframes)
                 shard_lanes = ((backend, layer, sframes), (backend2, layer2, sframes2))
@@ -1175,7 +1180,9 @@ def single_instance_leg(name, size, batch, n_nodes, steps, dev, with_cpu):
         layer2 = SingleInstanceLayer(HipBackend(model2, str(dev), use_graph=True), 2, max_stride=16, postprocess_config=PostprocessConfig(peak_threshold=0.0))
         g2 = layer2.graph_input(tuple(frames.shape)).copy_(frames)
         assert torch.equal(torch.nan_to_num(layer2.predict_graphed(g2).pred_keypoints), torch.nan_to_num(got_out.pred_keypoints))
-        sts = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+        from sleap_nn_amd.inference.predictor import concurrent_streams
+
+        sts = concurrent_streams(dev, 2)
         pair = ((layer, gframes), (layer2, g2))
         cnt = [0]
 

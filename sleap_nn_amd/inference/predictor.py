@@ -24,6 +24,42 @@ from sleap_nn_amd.inference.outputs import Outputs
 from sleap_nn_amd.inference.streaming import group_scored_batch
 
 
+def concurrent_streams(dev, n: int) -> List["torch.cuda.Stream"]:
+    """``n`` HIP streams that demonstrably run side by side.  The runtime maps streams onto a handful of hardware queues; two streams that land on one queue execute in order, and
+    which streams those are depends on how many the process created before (measured, ``tools/stream_probe.py``: the same top-down predictor 10 300 frames/s or 5 800 depending
+    on the count of streams made earlier in the process).  So the lanes are CHOSEN: a candidate joins when a short launch on it finishes while every lane chosen so far is still
+    busy with a ~0.5-ms spin; a dozen candidates at most, a few milliseconds once per predictor.  Falls back to plain consecutive streams when the probe is unavailable."""
+    first = torch.cuda.Stream(dev)
+    chosen = [first]
+    if n <= 1 or not hasattr(torch.cuda, "_sleep"):
+        return chosen + [torch.cuda.Stream(dev) for _ in range(n - 1)]
+    spare = []
+    tiny = torch.zeros(64, device=dev)
+    for _ in range(12):
+        if len(chosen) == n:
+            break
+        cand = torch.cuda.Stream(dev)
+        busy = []
+        for st in chosen:
+            with torch.cuda.stream(st):
+                torch.cuda._sleep(1_000_000)
+                ev = torch.cuda.Event()
+                ev.record(st)
+                busy.append(ev)
+        done = torch.cuda.Event()
+        with torch.cuda.stream(cand):
+            tiny.add_(1.0)
+            done.record(cand)
+        done.synchronize()
+        side_by_side = not any(ev.query() for ev in busy)
+        for ev in busy:
+            ev.synchronize()
+        (chosen if side_by_side else spare).append(cand)
+    while len(chosen) < n:  # (never seen: every candidate queued behind a chosen lane)
+        chosen.append(spare.pop(0) if spare else torch.cuda.Stream(dev))
+    return chosen
+
+
 def _select_layer(assets: Sequence[LoadedAssets], device: str, post: PostprocessConfig, max_instances: Optional[int], **paf_kw):
     """predictor.py:600 (``_select_layer``) for the model types of the hot path."""
     by_type = {a.model_type: a for a in assets}
@@ -153,7 +189,7 @@ class Predictor:
         stage = self._staging() if not frames.is_cuda else None
         streams = self.__dict__.get("_streams")
         if len(layers) > 1 and (streams is None or len(streams) != len(layers)):
-            streams = self.__dict__["_streams"] = [torch.cuda.Stream(dev) for _ in layers]
+            streams = self.__dict__["_streams"] = concurrent_streams(dev, len(layers))
         caller = torch.cuda.current_stream(dev)
         if len(layers) > 1:
             for st in streams:
@@ -231,7 +267,7 @@ class Predictor:
         stage = self._staging() if not frames.is_cuda else None
         streams = self.__dict__.get("_streams")
         if len(layers) > 1 and (streams is None or len(streams) != len(layers)):
-            streams = self.__dict__["_streams"] = [torch.cuda.Stream(dev) for _ in layers]
+            streams = self.__dict__["_streams"] = concurrent_streams(dev, len(layers))
         caller = torch.cuda.current_stream(dev)
         if len(layers) > 1:
             for st in streams:
@@ -287,7 +323,7 @@ class Predictor:
         stage = self._staging() if not frames.is_cuda else None
         streams = self.__dict__.get("_streams")
         if len(layers) > 1 and (streams is None or len(streams) != len(layers)):
-            streams = self.__dict__["_streams"] = [torch.cuda.Stream(dev) for _ in layers]
+            streams = self.__dict__["_streams"] = concurrent_streams(dev, len(layers))
         caller = torch.cuda.current_stream(dev)
         if len(layers) > 1:
             for st in streams:

@@ -461,3 +461,32 @@ def test_split_k_form_of_the_f4x4_kernel_matches_the_one_stage_kernel_and_the_or
             assert L.KV_WINO4 in m.last_kernels()
     _close(outs["split"], ref, "wino4 split")
     assert (outs["split"] - outs["one"]).abs().max().item() <= 3e-5 * ref.abs().max().item()
+
+
+def test_lane_streams_are_chosen_by_a_measured_overlap():
+    """predictor.concurrent_streams: the lanes of a two-stream predictor must not share a hardware queue whatever number of streams the process created before (the runtime deals
+    streams over a handful of queues): a short launch on one lane finishes while the other spins, for several counts of earlier streams."""
+    from sleap_nn_amd.inference.predictor import concurrent_streams
+
+    dev = torch.device(DEV)
+    keep = []
+    for before in (0, 1, 2, 3):
+        keep += [torch.cuda.Stream(dev) for _ in range(before)]
+        for st in keep:
+            with torch.cuda.stream(st):
+                torch.zeros(8, device=dev).add_(1)
+        a, b = concurrent_streams(dev, 2)
+        assert a != b
+        x = torch.zeros(64, device=dev)
+        torch.cuda.synchronize()
+        for first, second in ((a, b), (b, a)):
+            busy, done = torch.cuda.Event(), torch.cuda.Event()
+            with torch.cuda.stream(first):
+                torch.cuda._sleep(4_000_000)
+                busy.record(first)
+            with torch.cuda.stream(second):
+                x.add_(1.0)
+                done.record(second)
+            done.synchronize()
+            assert not busy.query(), f"lane streams run in order ({before} streams made before)"
+            busy.synchronize()
