@@ -464,7 +464,7 @@ def run_infer(args, ctx):
     params = layer.grouping_params()
     pending, inflight = [], []
     # Multi-GPU strong scaling leaves a rank a few frames per step (4 at 8 GPUs): most launches of such a step have fewer work units than CUs.  Consecutive steps then alternate
-    # between TWO copies of the network on two HIP streams (as Predictor.from_model_paths(streams=2) does for small networks): +3.5 % at 8 frames, +7 % at 4 on one GPU
+    # between TWO copies of the network on two HIP streams (as Predictor.from_model_paths does for small networks, with three): +3.5 % at 8 frames, +7 % at 4 on one GPU
     # (strong_scaling_shards.*.two_streams).  Never at N = 1 / 32 frames per step: there every launch fills the chip.
     lanes = [(backend, layer, None)]
     if world > 1 and use_graph and B <= 8:
@@ -652,7 +652,7 @@ def run_infer(args, ctx):
             torch.cuda.synchronize()
             dt = time.perf_counter() - t1
             shards[f"{sb}_frames_per_rank"] = {"value": sb * n_s / dt, "unit": "frames/s per GPU", "ms_per_step": 1e3 * dt / n_s, "steps": n_s, "stands_for": f"one rank of --gpus {32 // sb} --scaling strong"}
-            # the same steps alternating between TWO copies of the network on two HIP streams (what Predictor.from_model_paths(streams=2) does for small networks): a step of a few
+            # the same steps alternating between TWO copies of the network on two HIP streams (what Predictor.from_model_paths does for small networks, with three): a step of a few
             # frames leaves CUs idle in most launches, two independent steps in flight fill them
             if use_graph:
                 if "lane2" not in heads_in:
@@ -1232,6 +1232,9 @@ def single_instance_leg(name, size, batch, n_nodes, steps, dev, with_cpu):
     return res
 
 
+PUBLISHED_LANES = 3  # copies of a small network Predictor keeps in flight on as many HIP streams (Predictor.from_model_paths(streams=...)' default)
+
+
 def published_workload_leg(steps, dev):
     """The one workload the reference publishes numbers for (docs/guides/inference-performance.md:40-48,70-77, an NVIDIA A40): its fixture bottom-up run directory (tests/golden/ckpt_dirs:
     UNet f16 / rate 1.5 / max_stride 8, transposed-conv decoder, 2 nodes / 1 edge) at 320 x 560, batch 4 (predictor.py:884,930).  Backbone-level forward per batch (their table 1) in exact fp32
@@ -1258,7 +1261,7 @@ def published_workload_leg(steps, dev):
     z = np.load(os.path.join(ROOT, "tests", "golden", "ckpt_bottomup.npz"), allow_pickle=False)
     two = torch.from_numpy(z["image"]).squeeze(1)
     vid = torch.cat([two, two.flip(-1)], 0)[:, :, 32:352, :].repeat(25, 1, 1, 2)[..., :560].contiguous()  # (100, 1, 320, 560) uint8, host
-    pred = Predictor.from_model_paths([root], device=str(dev), batch_size=4, peak_threshold=0.2)
+    pred = Predictor.from_model_paths([root], device=str(dev), batch_size=4, peak_threshold=0.2, streams=PUBLISHED_LANES)
     pred.predict(vid)  # (untimed: graph capture of the batch shape, pinned buffers, the host-stage worker)
     torch.cuda.synchronize()
     reps, t0 = 10, time.perf_counter()
@@ -1281,7 +1284,7 @@ def published_workload_leg(steps, dev):
             tot, _ = _time_calls(lambda: be(xb), n, 20, False)
             si.setdefault("forward_ms_per_batch", {})[tag] = 1e3 * tot / n
         si_model.set_precision("exact")
-        sp = Predictor.from_model_paths([si_root], device=str(dev), batch_size=4, peak_threshold=0.2)
+        sp = Predictor.from_model_paths([si_root], device=str(dev), batch_size=4, peak_threshold=0.2, streams=PUBLISHED_LANES)
         sp.predict(vid)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
@@ -1316,11 +1319,13 @@ def published_workload_leg(steps, dev):
             return cbe_, TopDownLayer(cl_, il_, (tcfg["crop_size"], tcfg["crop_size"]))
 
         cbe, tdl = make_tdl(mc, mi)
-        mc2 = Model("unet", cc["backbone"], cc["heads"], "centroid")
-        mc2.load_state_dict(wsel("wc/"))
-        mi2 = Model("unet", ci["backbone"], ci["heads"], "centered_instance")
-        mi2.load_state_dict(wsel("wi/"))
-        _cbe2, tdl2 = make_tdl(mc2, mi2)  # a second copy of the pair (own handles): Predictor's second stream
+        td_replicas = []
+        for _ in range(PUBLISHED_LANES - 1):  # further copies of the pair (own handles): Predictor's other lanes
+            mc2 = Model("unet", cc["backbone"], cc["heads"], "centroid")
+            mc2.load_state_dict(wsel("wc/"))
+            mi2 = Model("unet", ci["backbone"], ci["heads"], "centered_instance")
+            mi2.load_state_dict(wsel("wi/"))
+            td_replicas.append(make_tdl(mc2, mi2)[1])
         tframes = torch.from_numpy(tz["image"]).to(dev)
         tframes = tframes.reshape(-1, *tframes.shape[-3:])
         tframes = tframes.repeat((4 + tframes.shape[0] - 1) // tframes.shape[0], 1, 1, 1)[:4].contiguous()
@@ -1335,7 +1340,7 @@ def published_workload_leg(steps, dev):
         td["instances_per_batch"] = int(torch.isfinite(tout.pred_centroids[..., 0]).sum())
         # end to end as for the bottom-up model: Predictor.predict over 100 uint8 frames in host memory, batch 4 (stage 1 of batch i + 1 enqueued before the one host read of batch i)
         tvid = tframes.cpu().repeat(25, 1, 1, 1).contiguous()
-        tp = Predictor(tdl, batch_size=4, replicas=[tdl2])
+        tp = Predictor(tdl, batch_size=4, replicas=td_replicas)
         tp.predict(tvid)
         torch.cuda.synchronize()
         t2 = time.perf_counter()
@@ -1355,7 +1360,7 @@ def published_workload_leg(steps, dev):
                        "params": model.num_parameters(), "forward_launch": "hipGraph replay, back to back"},
             "forward_ms_per_batch": fwd, "frames_per_s_forward": 4.0 / fwd_s,
             "end_to_end": {"value": e2e, "unit": "frames/s", "frames": int(vid.shape[0]), "repeats": reps, "instances_found_per_pass": n_inst,
-                           "what": "Predictor.predict (pipelined: pinned staging + H2D, resize / pad + forward + peaks + PAF scoring as one hipGraph, D2H, one-call C++ grouping in a worker; consecutive batches alternate between two copies of the layer on two HIP streams, Predictor.from_model_paths(streams=2)) over 100 uint8 frames in host memory, batch 4, exact fp32"},
+                           "what": "Predictor.predict (pipelined: pinned staging + H2D, resize / pad + forward + peaks + PAF scoring as one hipGraph, D2H, one-call C++ grouping in a worker; consecutive batches alternate between three copies of the layer on three HIP streams, Predictor.from_model_paths(streams=3)) over 100 uint8 frames in host memory, batch 4, exact fp32"},
             "vs_baseline": {"forward_eager_fp32": ref["bottomup_forward_ms_per_batch4"]["eager_fp32"] / fwd["exact_fp32"], "forward_fp16": ref["bottomup_forward_ms_per_batch4"]["fp16_autocast"] / fwd["fp16_autocast_equivalent"],
                             "end_to_end_fps": e2e / ref["bottomup_end_to_end_fps"], "reference": ref, "reference_hardware": "NVIDIA A40, CUDA 12.8, torch 2.9.1 (docs/guides/inference-performance.md:3-7,40-48,70-77)",
                             "note": "ratios > 1 = this build faster; different hardware and (end to end) no video decoding here: a like-for-like of the workload, not of the machine"},

@@ -131,9 +131,11 @@ class Predictor:
     @classmethod
     def from_model_paths(cls, model_paths: Sequence[str], device: str = "cuda", batch_size: int = 4, peak_threshold: float = 0.2,
                          integral_refinement: Optional[str] = "integral", integral_patch_size: int = 5, max_instances: Optional[int] = None,
-                         return_confmaps: bool = False, streams: int = 2, **paf_kw) -> "Predictor":
+                         return_confmaps: bool = False, streams: int = 3, **paf_kw) -> "Predictor":
         """``streams``: bottom-up and top-down run directories of small networks (<= 16 M parameters) are loaded ``streams`` times; the pipelined ``predict`` keeps that many batches in flight
-        on streams of their own (see ``replicas``)."""
+        on streams of their own (see ``replicas``).  Measured on the reference's fixture models at batch 4 (``tools/streams_n_probe.py``, frames/s end to end with 1 / 2 / 3 / 4 lanes):
+        bottom-up 8 000 / 12 700 / 13 300 / 14 700, top-down 7 100 / 10 700 / 12 800 / 11 300, single instance 32 900 / 43 500 / 42 400 / 47 000 -- three is the default (the runtime has
+        four hardware queues: the lanes are chosen so that they do not share one, ``concurrent_streams``)."""
         assets = [load_model_assets(p) for p in model_paths]
         post = PostprocessConfig(peak_threshold=peak_threshold, refinement=integral_refinement or "none", integral_patch_size=integral_patch_size,
                                  max_instances=max_instances, return_confmaps=return_confmaps)

@@ -924,10 +924,10 @@ def test_predictor_from_run_directory_matches_golden():
     ps.layer.preprocess_config = PreprocessConfig()  # the golden frames are the reference's ALREADY preprocessed 160x280 model inputs
     o = ps.predict(torch.from_numpy(zs["image"]).squeeze(1))[0]
     assert np.allclose(o.pred_keypoints[:, 0].cpu().numpy() / 0.5, zs["gold_peaks"], atol=1e-3, equal_nan=True)
-    # the pipelined path of a device-only layer (one hipGraph launch per batch incl. the preprocessing, two copies of the layer on two streams) against the plain loop:
+    # the pipelined path of a device-only layer (one hipGraph launch per batch incl. the preprocessing, copies of the layer on streams of their own) against the plain loop:
     # the run directory's own preprocessing (sizematcher to 320 x 560, input scale 0.5) on 7 frames of another size, batches of 2 -- ragged last batch
     ps2 = Predictor.from_model_paths([os.path.join(root, "minimal_instance_single_instance")], device=DEV, batch_size=2, peak_threshold=0.0)
-    assert len(ps2.replicas) == 1
+    assert len(ps2.replicas) == 2  # (from_model_paths(streams=3): three copies of a small network)
     g = torch.Generator().manual_seed(3)
     vid = torch.randint(0, 256, (7, 1, 300, 500), dtype=torch.uint8, generator=g)
     ref_outs = ps2.predict(vid, pipelined=False)

@@ -273,9 +273,9 @@ def test_pipelined_predictor_graphed_gpu_stage_equals_the_eager_layer():
     ref1 = pred.predict(vid, pipelined=False)
     assert ref1[0].pred_keypoints.shape[1] == 1
     same(pred.predict(vid), ref1)
-    # a caller that wants the maps back: the worker redoes such a batch eagerly on the stream it was enqueued on (two copies of the layer on two streams here)
+    # a caller that wants the maps back: the worker redoes such a batch eagerly on the stream it was enqueued on (three copies of the layer on three streams here)
     pc = Predictor.from_model_paths([root], device=DEV, batch_size=4, peak_threshold=0.2, return_confmaps=True)
-    assert len(pc.replicas) == 1
+    assert len(pc.replicas) == 2  # (from_model_paths(streams=3): three copies of a small network)
     refc = pc.predict(vid, pipelined=False)
     gotc = pc.predict(vid)
     same(gotc, refc)
