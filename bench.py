@@ -464,17 +464,20 @@ def run_infer(args, ctx):
     params = layer.grouping_params()
     pending, inflight = [], []
     # Multi-GPU strong scaling leaves a rank a few frames per step (4 at 8 GPUs): most launches of such a step have fewer work units than CUs.  Consecutive steps then alternate
-    # between TWO copies of the network on two HIP streams (as Predictor.from_model_paths does for small networks, with three): +3.5 % at 8 frames, +7 % at 4 on one GPU
+    # between TWO (8 frames) or THREE (4 frames) copies of the network on HIP streams of their own (as Predictor.from_model_paths does for small networks): +3.5 % at 8 frames, +8 % at 4 on one GPU
     # (strong_scaling_shards.*.two_streams).  Never at N = 1 / 32 frames per step: there every launch fills the chip.
     lanes = [(backend, layer, None)]
     if world > 1 and use_graph and B <= 8:
-        model_b = Model("unet", CFG3_BB, CFG3_HEADS, "bottomup")
-        model_b.init_xavier_(seed=1234, head_scale=0.05)
-        backend_b = HipBackend(model_b, str(dev), use_graph=True, precision=precision)
         from sleap_nn_amd.inference.predictor import concurrent_streams
 
-        lane_st = concurrent_streams(dev, 2)  # (two streams on ONE hardware queue would run in order: chosen by a measured overlap)
-        lanes = [(backend, layer, lane_st[0]), (backend_b, BottomUpLayer(backend_b, PAFScorer.from_config(CFG3_HEADS), 4, 8, max_stride=32), lane_st[1])]
+        n_lanes = SHARD_LANES_4 if B <= 4 else 2
+        lane_st = concurrent_streams(dev, n_lanes)  # (two streams on ONE hardware queue would run in order: chosen by a measured overlap)
+        lanes = [(backend, layer, lane_st[0])]
+        for k in range(1, n_lanes):
+            model_b = Model("unet", CFG3_BB, CFG3_HEADS, "bottomup")
+            model_b.init_xavier_(seed=1234, head_scale=0.05)
+            backend_b = HipBackend(model_b, str(dev), use_graph=True, precision=precision)
+            lanes.append((backend_b, BottomUpLayer(backend_b, PAFScorer.from_config(CFG3_HEADS), 4, 8, max_stride=32), lane_st[k]))
     step_no, last_stream = [0], [None]
 
     heads_in = {"cms": cms, "pafs": pafs, "info": info}  # rebound for the weak-scaling leg of a multi-GPU run
@@ -656,24 +659,27 @@ def run_infer(args, ctx):
             # frames leaves CUs idle in most launches, two independent steps in flight fill them
             if use_graph:
                 if "lane2" not in heads_in:
-                    model2 = Model("unet", CFG3_BB, CFG3_HEADS, "bottomup")
-                    model2.init_xavier_(seed=1234, head_scale=0.05)
-                    backend2 = HipBackend(model2, str(dev), use_graph=True, precision=precision)
                     from sleap_nn_amd.inference.predictor import concurrent_streams
 
-                    heads_in["lane2"] = (backend2, BottomUpLayer(backend2, PAFScorer.from_config(CFG3_HEADS), 4, 8, max_stride=32), concurrent_streams(dev, 2))
-                backend2, layer2, lanes_st = heads_in["lane2"]
-                sframes2 = backend2.static_input((sb, 1, SIZE, SIZE)).copy_(sframes)
-                shard_lanes = ((backend, layer, sframes), (backend2, layer2, sframes2))
+                    extra = []
+                    for _ in range(max(SHARD_LANES_4, 2) - 1):
+                        model2 = Model("unet", CFG3_BB, CFG3_HEADS, "bottomup")
+                        model2.init_xavier_(seed=1234, head_scale=0.05)
+                        backend2 = HipBackend(model2, str(dev), use_graph=True, precision=precision)
+                        extra.append((backend2, BottomUpLayer(backend2, PAFScorer.from_config(CFG3_HEADS), 4, 8, max_stride=32)))
+                    heads_in["lane2"] = (extra, concurrent_streams(dev, max(SHARD_LANES_4, 2)))
+                extra, lanes_st = heads_in["lane2"]
+                n_copies = SHARD_LANES_4 if sb <= 4 else 2  # what a rank of bench.py --gpus N runs with (lanes above)
+                shard_lanes = [(backend, layer, sframes)] + [(be2, ly2, be2.static_input((sb, 1, SIZE, SIZE)).copy_(sframes)) for be2, ly2 in extra[: n_copies - 1]]
                 fl, futs = [], []
 
                 def step2(i):
-                    k = i & 1
+                    k = i % n_copies
                     be_k, ly_k, x_k = shard_lanes[k]
                     with torch.cuda.stream(lanes_st[k]):
                         be_k(x_k)
                         fl.append((ly_k, ly_k._enqueue_scoring({"MultiInstanceConfmapsHead": heads_in["cms"], "PartAffinityFieldsHead": heads_in["pafs"]}, heads_in["info"])))
-                    if len(fl) > 2:
+                    if len(fl) > n_copies:
                         ly0, h0 = fl.pop(0)
                         futs.append(pool.submit(group_scored_batch, ly0._finish_scoring(h0), params))
                     if len(futs) > 2:
@@ -699,7 +705,8 @@ def run_infer(args, ctx):
                 torch.cuda.synchronize()
                 dt2 = time.perf_counter() - t1
                 shards[f"{sb}_frames_per_rank"]["two_streams"] = {"value": sb * n_s / dt2, "unit": "frames/s per GPU", "ms_per_step": 1e3 * dt2 / n_s,
-                                                                 "what": "consecutive steps alternate between two copies of the network on two HIP streams"}
+                                                                 "copies": n_copies,
+                                                                 "what": "consecutive steps alternate between copies of the network on HIP streams of their own (`copies`)"}
         heads_in.update(cms=cms, pafs=pafs, info=info)
         heads_in.pop("lane2", None)
         del scms, spafs, sframes
@@ -1232,6 +1239,7 @@ def single_instance_leg(name, size, batch, n_nodes, steps, dev, with_cpu):
     return res
 
 
+SHARD_LANES_4 = 3     # copies of the cfg3 network a rank with <= 4 frames per step alternates between (8 frames: 2); whole pipelined step on one GPU, tools/shard_lanes_ab.py: 2 637 -> 2 671 frames/s
 PUBLISHED_LANES = 3  # copies of a small network Predictor keeps in flight on as many HIP streams (Predictor.from_model_paths(streams=...)' default)
 
 
