@@ -1447,7 +1447,9 @@ __device__ __forceinline__ void stem_store4(const StemArgs& a, void* base, size_
 }
 
 template <int CIN, int WINO>  // WINO: 0 direct second conv, 1 Winograd F(2,3) along x, 2 Winograd F(2x2,3x3)
-__global__ __launch_bounds__(256, 4) void stem_fused_kernel(StemArgs a) {
+// (five workgroups per CU -- what the 29.5 KiB of LDS allow -- for the gray-image F(2x2,3x3) instantiation of the headline: 96 registers with nine spills, measured 1.095 -> 1.064 ms on cfg3's
+// 32 frames; the kernel is a chain of cold loads and two barriers per 8 x 32-pixel tile, i.e. bound by latency x occupancy rather than by its vector instructions)
+__global__ __launch_bounds__(256, (CIN == 1 && WINO == 2) ? 5 : 4) void stem_fused_kernel(StemArgs a) {
   constexpr int IMG_W = TW + 4, IMG_H = TH + 4;   // image patch incl. both halos
   __shared__ __attribute__((aligned(16))) float sA[HALO_H * HALO_W * LROW];   // conv0 output (conv1 input halo)
   __shared__ float sImg[CIN * IMG_H * IMG_W];
