@@ -262,10 +262,11 @@ int ph_model_profile_read(ph_model* m, double* op_ms, int32_t n_ops, int32_t* n_
 #define PH_KV_FUSED 11    /* no launch of its own: a 1x1 head computed in the epilogue of the conv that produces its input */
 int ph_model_last_kernels(const ph_model* m, int32_t* codes, int32_t n_ops);
 
-/* Diagnostic: when buf_dev != NULL every conv3x3 workgroup writes {delta s_memtime, delta
- * s_memrealtime} (2 x uint64 per workgroup, indexed by linear block id; the buffer must hold
- * the largest conv grid) so the shader clock under load can be read as
- * d_memtime / d_memrealtime * 100 MHz.  NULL turns it off (default). */
+/* Diagnostic: when buf_dev != NULL the conv3x3 kernels that carry a probe write into the record block of
+ * their op -- 32768 x uint64 per op of the program, op i at buf_dev + 32768 i words (the buffer must hold
+ * 32768 x n_ops words) -- e.g. {delta s_memtime, delta s_memrealtime} per workgroup (fp16 pipe; the F(4x4,3x3)
+ * kernel in -DW4_CLOCK builds): the shader clock under load is d_memtime / d_memrealtime * 100 MHz
+ * (tools/clockprobe_f16.py, tools/clockprobe_layers.py).  NULL turns it off (default). */
 int ph_model_set_clock_probe(ph_model* m, void* buf_dev);
 
 /* Debug/parity helper: copy activation slot `slot` of the last forward (NHWC, padded

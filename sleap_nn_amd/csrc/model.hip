@@ -15,6 +15,9 @@
 #include "model_internal.h"
 #include "train_kernels.h"
 
+// diagnostic clock probe (ph_model_set_clock_probe): 64-bit words reserved per op of the program -- the largest writer (the F(2x2,3x3) kernel's stamps) takes 256 x 8 x 8
+static constexpr size_t PH_PROBE_WORDS_PER_OP = 32768;
+
 namespace ph {
 
 static thread_local std::string g_err;
@@ -1076,7 +1079,7 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
           f.bn = op.bn;
           f.prec = fmt == FMT_F16 ? 1 : 3;
           f.zeros = m->zeros_dev;
-          f.clock_probe = m->clock_probe ? m->clock_probe + 2 * 1024 * (op_index - 1) : nullptr;  // one 1024-workgroup record block per op
+          f.clock_probe = m->clock_probe ? m->clock_probe + PH_PROBE_WORDS_PER_OP * (op_index - 1) : nullptr;  // one record block per op
           if (m->head_fuse && fmt == FMT_F16 && !f.dst_pool && op.bn == 64 && so.cp == 64) {
             // plain fp16: a 1x1 head that reads this conv's 64-channel output rides in its epilogue (four MFMAs on the staged fp16 row); when nothing else reads the tensor it never reaches HBM
             for (size_t j = op_index; j < m->ops.size(); ++j) {
@@ -1144,7 +1147,7 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
         a.W = s0.w;
         a.relu = (d.flags & PH_FLAG_RELU) ? 1 : 0;
         a.bn = op.bn;
-        a.clock_probe = m->clock_probe;
+        a.clock_probe = m->clock_probe ? m->clock_probe + PH_PROBE_WORDS_PER_OP * (op_index - 1) : nullptr;  // one record block per op (diagnostic builds / kernels that stamp)
         a.dst_pool = d.dst2 >= 0 ? slot_ptr(d.dst2) : nullptr;
         a.skip_dst = (a.dst_pool && plan.reuse && !plan.unread.empty() && plan.unread[d.dst]) ? 1 : 0;  // e.g. cfg3's second encoder block: 1 GiB per 32 frames nobody reads
         a.wpack_dma = op.w_dma_dev;
@@ -1369,7 +1372,7 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
           f.bn = op.bn;
           f.prec = fmt == FMT_F16 ? 1 : 3;
           f.zeros = m->zeros_dev;
-          f.clock_probe = m->clock_probe ? m->clock_probe + 2 * 1024 * (op_index - 1) : nullptr;  // one 1024-workgroup record block per op
+          f.clock_probe = m->clock_probe ? m->clock_probe + PH_PROBE_WORDS_PER_OP * (op_index - 1) : nullptr;  // one record block per op
           if (m->head_fuse && fmt == FMT_F16 && !f.dst_pool && op.bn == 64 && so.cp == 64) {
             // plain fp16: a 1x1 head that reads this conv's 64-channel output rides in its epilogue (four MFMAs on the staged fp16 row); when nothing else reads the tensor it never reaches HBM
             for (size_t j = op_index; j < m->ops.size(); ++j) {

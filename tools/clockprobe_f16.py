@@ -8,11 +8,12 @@ prec = sys.argv[1] if len(sys.argv) > 1 else "split"
 m = Model("unet", bench.CFG3_BB, bench.CFG3_HEADS, "bottomup").init_xavier_(seed=1234, head_scale=0.05).to("cuda:0").set_precision(prec)
 x = torch.randint(0, 256, (32, 1, 1024, 1024), dtype=torch.uint8).cuda()
 m(x); torch.cuda.synchronize()
-buf = torch.zeros(2 * 1024 * len(m.ops), dtype=torch.int64, device="cuda")
+W = 32768  # words per op (posehip.h: ph_model_set_clock_probe)
+buf = torch.zeros(W * len(m.ops), dtype=torch.int64, device="cuda")
 L.check(L.lib().ph_model_set_clock_probe(m._handle, C.c_void_p(buf.data_ptr())))
 for _ in range(10): m(x)
 torch.cuda.synchronize()
-b = buf.cpu().numpy().reshape(len(m.ops), 1024, 2)
+b = buf.cpu().numpy().reshape(len(m.ops), W)[:, : 2 * 1024].reshape(len(m.ops), 1024, 2)
 for i, op in enumerate(m.ops):
     nz = b[i, :, 1] > 0
     if nz.sum() == 0: continue
