@@ -23,13 +23,14 @@ def run(cin, cout, hw, batch=32):
     m.set_option("head_fuse", 0)  # (the conv's own epilogue, not the fused head's 64 extra MFMAs per finishing wave)
     m.set_option("conv_wino4", 0)  # (this kernel, also where the F(4x4,3x3) kernel would take the layer)
     m(x); torch.cuda.synchronize()
-    buf = torch.zeros(256 * 8 * 8, dtype=torch.int64, device="cuda")
+    W = 32768  # words per op (posehip.h: ph_model_set_clock_probe); the conv is op 1 of this program
+    buf = torch.zeros(W * len(m.ops), dtype=torch.int64, device="cuda")
     L.check(L.lib().ph_model_set_clock_probe(m._handle, C.c_void_p(buf.data_ptr())))
     m.set_profiling(True)
     for _ in range(5): m(x)
     ms, n = m.read_profile()
     torch.cuda.synchronize()
-    b = buf.cpu().numpy().reshape(256, 8, 8).astype(np.float64)
+    b = buf.cpu().numpy().reshape(len(m.ops), W)[1, : 256 * 8 * 8].reshape(256, 8, 8).astype(np.float64)
     clk = np.median(b[:, :, 4] / np.maximum(b[:, :, 6], 1)) * 0.1
     tiles = np.median(b[:, :, 5]); nh = np.median(b[:, :, 7])
     fl = 2.0 * cin * cout * 9 * hw * hw * batch
