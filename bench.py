@@ -167,7 +167,28 @@ def cpu_baseline(model, layer, cms_dev, pafs_dev, dev, budget_s: float = 24.0):
     }
 
 
-PROFILE_EVERY = 10
+PROFILE_MIN_SAMPLES = 6  # forwards of the timed region that launch kernel by kernel with per-op HIP events
+
+
+def profile_steps(steps: int) -> list:
+    """The steps of a timed region whose forward is event-profiled: never step 0 or 1 (right behind the barrier, on an idle GPU), every
+    max(2, steps // PROFILE_MIN_SAMPLES)-th step from step 2 on -- six samples at the driver's --steps 20 as at the default 50."""
+    return list(range(2, steps, max(2, steps // PROFILE_MIN_SAMPLES)))
+
+
+def summarize_op_samples(samples, stack_idx, step_ms_median):
+    """Per-op MEDIAN over the profiled forwards (a sample = the per-op milliseconds of ONE forward), and the check that makes the figure usable: the summed conv-stack
+    time of the medians may exceed the median step time by at most 3 % (kernel-by-kernel launches carry a boundary per op the hipGraph replay does not); beyond that
+    the sampling was disturbed (a cold first sample, a host stall between launches) and the result says so instead of passing for a roofline."""
+    if not samples:
+        return {"op_ms": [], "n": 0, "sampling": "none", "stack_ms": 0.0, "stack_ms_by_sample": []}
+    a = np.asarray(samples, dtype=np.float64)
+    med = np.median(a, axis=0)
+    stack = float(med[list(stack_idx)].sum()) if len(stack_idx) else 0.0
+    ok = step_ms_median is None or step_ms_median <= 0 or stack <= 1.03 * step_ms_median
+    return {"op_ms": [float(v) for v in med], "n": int(a.shape[0]), "sampling": "ok" if ok else "inflated", "stack_ms": stack,
+            "stack_ms_by_sample": [round(float(r[list(stack_idx)].sum()), 4) for r in a]}
+
 
 
 def _free_port() -> int:
@@ -526,20 +547,41 @@ def run_infer(args, ctx):
     model.set_profiling(True)
     model.set_profiling(False)
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    prof_at = set(profile_steps(args.steps))
+    op_samples, sample_pending = [], False
+
+    def collect_sample():  # the events of the previous profiled forward completed steps ago: reading them stalls nothing
+        ms, n = model.read_profile()
+        if n > 0:
+            op_samples.append([v / n for v in ms])
+
     barrier()
     t0 = time.perf_counter()
     marks[0].record()
     for i in range(args.steps):
-        prof = i % PROFILE_EVERY == 0
-        model.set_profiling(prof, resume=True)
+        prof = i in prof_at
+        if prof:
+            if sample_pending:
+                collect_sample()
+            model.set_profiling(True)  # (clears: one sample = one forward)
+            sample_pending = True
+        else:
+            model.set_profiling(False, resume=True)
         step(frames, profiled=prof)
         marks[i + 1].record()
     drain()
     barrier()
     elapsed = time.perf_counter() - t0
-    op_ms, n_fw = model.read_profile()
+    if sample_pending:
+        collect_sample()
     model.set_profiling(False)
     step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
+    _tab0 = model.op_table(B, SIZE, SIZE)
+    from sleap_nn_amd import _lib as _L0
+
+    op_summary = summarize_op_samples(op_samples, [j for j, r in enumerate(_tab0) if r["kind"] in (_L0.OP_CONV, _L0.OP_STEM, _L0.OP_INPUT_CONV)],
+                                      float(np.median([m for j, m in enumerate(step_ms) if j not in prof_at])) if len(step_ms) > len(prof_at) else None)
+    op_ms, n_fw = (op_summary["op_ms"] or [0.0] * len(_tab0)), 1
 
     # ---- timed region 2: the same steps with the uint8 frames coming from pinned host memory (H2D on a copy stream, double
     # buffered, overlapped with the previous step's kernels)
@@ -830,7 +872,9 @@ def run_infer(args, ctx):
             "conv_stack_ms_per_forward": stack_ms,
             "forward_ms": fwd_ms, "forward_frames_per_s": B / (fwd_ms * 1e-3) if fwd_ms > 0 else 0.0,
             "per_op_ms": {r["label"]: round(ms / max(n_fw, 1), 4) for r, ms in zip(table, op_ms)},
-            "profiled_forwards": n_fw,
+            "profiled_forwards": op_summary["n"], "sampling": op_summary["sampling"], "conv_stack_ms_by_sample": op_summary["stack_ms_by_sample"],
+            "sampling_rule": "per-op MEDIAN over the profiled forwards (steps " + ",".join(str(v) for v in sorted(prof_at)) + " of the timed region; never steps 0 / 1); "
+                             "'inflated' = the conv stack of the medians exceeds 1.03 x the median un-profiled step, the figure is then not a roofline",
         },
     }
     if peaks_us is not None:

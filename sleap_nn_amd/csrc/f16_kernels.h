@@ -30,10 +30,20 @@ struct ConvF16Args {
   float* head_dst = nullptr;
   int head_cout = 0, head_wcp = 0, head_sigmoid = 0;
   unsigned long long* clock_probe = nullptr;  // diagnostic (ph_model_set_clock_probe): per workgroup {d s_memtime, d s_memrealtime}; nullptr = off
+  // conv3x3_f16_rows_kernel (f16_rows_kernels.hip; prec 1, bn 64 weights): src1 may be the HALF-resolution tensor (the bilinear x2 rides in the loader);
+  // the tile plan below is filled by f16_rows_plan
+  int src1_lowres = 0;
+  int rows_r = 0, rows_wt = 0, rows_mt = 0, rows_mg = 0;   // tile = rows_r rows x rows_wt columns <= 16 rows_mt rows_mg pixels; rows_mg pixel groups x 8 / rows_mg channel slices
+  int rows_hp16 = 0, rows_xb = 0, rows_lc16 = 0, rows_lowp = 0, rows_lds = 0;  // halo pitch (16-pixel pieces), staging extension (bytes), low tile pitch / pieces, LDS bytes
+  int rows_inv_wt = 0, rows_inv_pw = 0, rows_inv_cc = 0;   // ceil(2^20 / d) for d = rows_wt, rows_wt / 2, rows_wt / 2 + 1
 };
 
 int prepare_f16_kernels();
 int launch_conv3x3_f16(const ConvF16Args& a, hipStream_t s);
+double f16_conv_cost(const ConvF16Args& a, int n_cu);   // estimated launch body of conv3x3_f16_persist_kernel, shader cycles
+double f16_upsample_cost(int B, int H, int W, int cp, int n_cu);  // ... of upsample2x_fmt_kernel producing the (2H, 2W) tensor from (B, H, W, cp)
+double f16_rows_plan(ConvF16Args& a, int n_cu);         // fills the rows_* plan; estimated launch body in shader cycles, < 0: the shape is not taken
+int launch_conv3x3_f16_rows(const ConvF16Args& a, hipStream_t s);
 int64_t f16_weight_pack_floats(int n_tiles, int chunks0, int chunks1, int bn, int plain);
 int launch_f16_weight_pack(const float* w_dma_f32, float* dst, int n_tiles, int chunks0, int chunks1, int bn, int plain, hipStream_t s);
 int launch_upsample_fmt(int fmt, const void* src, void* dst, int B, int H, int W, int cp, hipStream_t s);

@@ -21,6 +21,8 @@
 // of the fp32 kernel serves unchanged.  The product is accumulated TRANSPOSED (weights are the A operand): a lane owns
 // one pixel and each accumulator register quad is four consecutive output channels, which the epilogue converts and
 // stores as one 8-byte piece of the destination's format.
+#include <algorithm>
+#include <cmath>
 #include <type_traits>
 
 #include "act_format.h"
@@ -466,6 +468,24 @@ int launch_f16_weight_pack(const float* w_dma_f32, float* dst, int n_tiles, int 
                      plain);
   PH_HIP_CHECK(hipGetLastError());
   return PH_OK;
+}
+
+// Estimated launch body of conv3x3_f16_persist_kernel in shader cycles (the routing weighs conv3x3_f16_rows_kernel's plan against it): rounds of the chip x (fixed
+// tile cost + cycles per K chunk), calibrated on the per-op table of the cfg5 forward (profiles/r4z_f16_cfg5_per_op.txt: 2 chunks 12.5 k, 8 chunks 68 k per unit),
+// and never below the time the layer's algorithmic bytes take at ~5 TB/s (2,500 bytes per shader cycle chip-wide at 2 GHz)
+double f16_conv_cost(const ConvF16Args& a, int n_cu) {
+  const double tiles = (double)((a.W + TW - 1) / TW) * ((a.H + TH - 1) / TH) * a.B;
+  const double units = tiles * ((a.coutp + a.bn - 1) / a.bn);
+  const double rounds = std::ceil(units / n_cu);
+  const int nch = a.chunks0 + a.chunks1;
+  const double px = (double)a.B * a.H * a.W;
+  const double bytes = px * 64.0 * nch + (a.skip_dst ? 0.0 : px * a.coutp * 2.0) + (a.dst_pool ? px * a.coutp * 0.5 : 0.0);
+  return std::max(rounds * (6000.0 + 7800.0 * nch * (a.bn == 64 ? 1.0 : 0.6)), bytes / 2500.0);
+}
+// ... of upsample2x_fmt_kernel on a (B, H, W, cp) fp16 source: 1.25 x the output bytes at ~5 TB/s + the launch boundary
+double f16_upsample_cost(int B, int H, int W, int cp, int n_cu) {
+  (void)n_cu;
+  return (double)B * H * W * cp * 2.0 * 5.0 / 2500.0 + 3000.0;
 }
 
 int launch_conv3x3_f16(const ConvF16Args& a, hipStream_t s) {

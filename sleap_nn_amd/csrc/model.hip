@@ -1080,17 +1080,18 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
           f.prec = fmt == FMT_F16 ? 1 : 3;
           f.zeros = m->zeros_dev;
           f.clock_probe = m->clock_probe ? m->clock_probe + PH_PROBE_WORDS_PER_OP * (op_index - 1) : nullptr;  // one record block per op
-          if (m->head_fuse && fmt == FMT_F16 && !f.dst_pool && op.bn == 64 && so.cp == 64) {
+          if (m->head_fuse && fmt == FMT_F16 && !f.dst_pool && op.bn == 64 && (so.cp == 64 || (so.cp == 128 && m->conv_f16_rows))) {
             // plain fp16: a 1x1 head that reads this conv's 64-channel output rides in its epilogue (four MFMAs on the staged fp16 row); when nothing else reads the tensor it never reaches HBM
+            // (128 channels: only conv3x3_f16_rows_kernel holds both N tiles of a pixel in one workgroup -- undone below if that kernel does not take the layer)
             for (size_t j = op_index; j < m->ops.size(); ++j) {
               const ph_op_desc& hx = m->ops[j].d;
               if (hx.kind != PH_OP_HEAD || hx.src0 != d.dst) continue;
-              if (!(hx.flags & PH_FLAG_SOFTMAX) && out_dev[hx.out_index] && hx.cout <= 32 && pad16(hx.cin0) == 64) {
+              if (!(hx.flags & PH_FLAG_SOFTMAX) && out_dev[hx.out_index] && hx.cout <= 32 && fmt_cpad(FMT_F16, hx.cin0) == so.cp) {
                 f.head_w = m->ops[j].w_dev;
                 f.head_b = m->ops[j].b_dev;
                 f.head_dst = out_dev[hx.out_index];
                 f.head_cout = hx.cout;
-                f.head_wcp = 64;
+                f.head_wcp = so.cp;
                 f.head_sigmoid = (hx.flags & PH_FLAG_SIGMOID) ? 1 : 0;
                 head_done[j] = 1;
                 if (plan.reuse) {
@@ -1101,6 +1102,48 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
                 }
               }
               break;
+            }
+          }
+          if (deferred_up >= 0 || (fmt == FMT_F16 && m->conv_f16_rows)) {
+            // conv3x3_f16_rows_kernel (row tiles, loader waves, weights L2 -> registers; f16_rows_kernels.hip) where its plan is estimated faster ("conv_f16_rows" 2: wherever
+            // the shape fits).  A bilinear x2 in front of this conv that only feeds its second source was not launched (PH_OP_UPSAMPLE): the kernel reads the
+            // half-resolution tensor itself; if it does not take the layer, the tensor is produced now.
+            int n_cu = 0;
+            if (device_cu_count(&n_cu) != PH_OK || n_cu <= 0) n_cu = 256;
+            bool on_rows = false;
+            if (fmt == FMT_F16 && m->conv_f16_rows) {
+              ConvF16Args r = f;
+              if (deferred_up >= 0) {
+                const ph_op_desc& up = m->ops[deferred_up].d;
+                r.src1 = slot_ptr(up.src0);
+                r.rs1 = plan.slots[up.src0].cp / rs_div;
+                r.src1_lowres = 1;
+              }
+              const double c_rows = f16_rows_plan(r, n_cu);
+              double c_old = f16_conv_cost(f, n_cu);
+              if (deferred_up >= 0) c_old += f16_upsample_cost(batch, s0.h / 2, s0.w / 2, plan.slots[d.src1].cp, n_cu);
+              if (c_rows >= 0 && (m->conv_f16_rows >= 2 || c_rows < c_old)) {
+                f = r;
+                on_rows = true;
+              }
+            }
+            if (deferred_up >= 0 && !on_rows) {
+              const ph_op_desc& up = m->ops[deferred_up].d;
+              const SlotShape& sl = plan.slots[up.src0];
+              rc = launch_upsample_fmt(fmt, slot_ptr(up.src0), slot_ptr(up.dst), batch, sl.h, sl.w, sl.cp, s);
+              if (rc != PH_OK) return rc;
+            }
+            deferred_up = -1;
+            if (on_rows) {
+              kv[op_index - 1] = PH_KV_F16_ROWS;
+              rc = launch_conv3x3_f16_rows(f, s);
+              break;
+            }
+            if (f.head_w && (f.bn != 64 || f.coutp != 64)) {  // (a head only the row-tile kernel fuses: leave it to its own launch)
+              for (size_t j = op_index; j < m->ops.size(); ++j)
+                if (m->ops[j].d.kind == PH_OP_HEAD && m->ops[j].d.src0 == d.dst && head_done[j]) head_done[j] = 0;
+              f.head_w = nullptr;
+              f.skip_dst = (f.dst_pool && plan.reuse && !plan.unread.empty() && plan.unread[d.dst]) ? 1 : 0;
             }
           }
           kv[op_index - 1] = PH_KV_F16;
@@ -1301,6 +1344,18 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
           const PackedOp& nxo = m->ops[op_index];
           const ph_op_desc& nx = nxo.d;
           bool only = nx.kind == PH_OP_CONV && nx.ksize == 3 && nx.src1 == d.dst && nx.src0 != d.dst && nx.dst2 < 0 && (nxo.w_wino4_dev != nullptr || nxo.w_sm_dev != nullptr);
+          for (size_t k = 0; only && k < m->ops.size(); ++k)
+            if (k != op_index && (m->ops[k].d.src0 == d.dst || m->ops[k].d.src1 == d.dst)) only = false;
+          if (only) {
+            deferred_up = (int)op_index - 1;
+            break;
+          }
+        }
+        if (fmt == FMT_F16 && plan.reuse && m->upsample_fold && m->conv_f16_rows && op_index < m->ops.size()) {
+          // the same on the fp16 pipe: conv3x3_f16_rows_kernel's loader waves blend the half-resolution tensor into the halo
+          const PackedOp& nxo = m->ops[op_index];
+          const ph_op_desc& nx = nxo.d;
+          bool only = nx.kind == PH_OP_CONV && nx.ksize == 3 && nx.src1 == d.dst && nx.src0 != d.dst && nxo.bn == 64 && plan.slots[nx.src0].h == 2 * s0.h && plan.slots[nx.src0].w == 2 * s0.w;
           for (size_t k = 0; only && k < m->ops.size(); ++k)
             if (k != op_index && (m->ops[k].d.src0 == d.dst || m->ops[k].d.src1 == d.dst)) only = false;
           if (only) {
@@ -1636,6 +1691,7 @@ std::vector<OptionRef> option_table(ph_model* m) {
       {"conv_wino4_min_cin", &m->conv_wino4_min_cin, nullptr},  // padded input channels from which a layer takes it
       {"conv_n32_wino2d", &m->conv_n32_wino2d, nullptr},  // Cout-32 / K >= 64 layers on the F(2x2,3x3) kernel with a half-empty N tile (0: the N-tile-32 F(2,3) kernel)
       {"conv_splitk_finish", &m->conv_splitk_finish, nullptr},  // 0: the split-K second stage as a launch of its own (A/B, tests)
+      {"conv_f16_rows", &m->conv_f16_rows, nullptr},    // plain-fp16 precision: conv3x3_f16_rows_kernel 0 never, 1 where its plan is estimated faster than conv3x3_f16_persist_kernel, 2 wherever the shape fits
       {"conv_smallmap", &m->conv_smallmap, nullptr},    // conv3x3_sm_kernel for small maps at small batches: 0 never, 1 where estimated faster (inference plans, conv_splitk = 1), 2 wherever the shape fits
       {"conv_splitk", &m->conv_splitk, nullptr},        // split K on the F(2x2,3x3) kernel for layers with fewer work units than CUs: 0 never, 1 where estimated faster, n >= 2 force n slices
       {"upsample_fold", &m->upsample_fold, nullptr},    // bilinear x2 folded into the F(4x4,3x3) input transform of the conv that consumes it

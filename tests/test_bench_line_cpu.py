@@ -106,3 +106,23 @@ def test_every_conv_kernel_family_the_library_reports_has_a_name_in_the_bench():
     conv_codes = {v for k, v in vars(L).items() if k.startswith("KV_") and isinstance(v, int)} - {L.KV_NONE, L.KV_FUSED, L.KV_STEM}
     assert conv_codes <= set(short), sorted(conv_codes - set(short))
     assert set(short.values()) <= set(long_) and set(L.KV_NAMES) >= conv_codes and set(L.KV_MFMA_SHARE) >= conv_codes
+
+
+def test_per_op_sampling_takes_medians_never_the_first_steps_and_flags_an_inflated_stack(bench):
+    """the driver's 20-step run left two event-profiled forwards, one of them step 0 behind a barrier on an idle GPU, and the line's roofline was
+    the mean of the two (conv stack 11.40 ms beside a 10.83-ms step).  Now: >= 5 samples at --steps 20 and 50, none of them step 0 / 1; the per-op figure is the
+    MEDIAN over the samples, so ONE inflated sample changes nothing; and a stack that still exceeds 1.03 x the median step is marked, not published as a roofline."""
+    for steps in (20, 50, 200):
+        at = bench.profile_steps(steps)
+        assert len(at) >= 5 and min(at) >= 2 and max(at) < steps and len(set(at)) == len(at), (steps, at)
+    assert bench.profile_steps(3) == [2] and bench.profile_steps(2) == []
+    good = [1.00, 0.40, 0.40, 0.10]            # per-op ms of a forward: stem, two convs, a head
+    samples = [[1.9, 0.55, 0.52, 0.30]] + [[g * (1 + 0.004 * k) for g in good] for k in range(5)]   # the first sample is cold
+    s = bench.summarize_op_samples(samples, [0, 1, 2], step_ms_median=1.95)
+    assert s["n"] == 6 and s["sampling"] == "ok"
+    assert all(abs(m - g * 1.01) < 0.011 * g for m, g in zip(s["op_ms"], good)), s["op_ms"]      # the medians sit on the warm samples
+    assert abs(s["stack_ms"] - 1.8 * 1.01) < 0.02 and s["stack_ms_by_sample"][0] > 2.9
+    # the mean would have been pulled up by the cold sample -- and a stack above 1.03 x the step is flagged
+    assert sum(r[0] for r in samples) / 6 > 1.14
+    assert bench.summarize_op_samples(samples, [0, 1, 2], step_ms_median=1.70)["sampling"] == "inflated"
+    assert bench.summarize_op_samples([], [0], 1.0)["sampling"] == "none"
