@@ -33,6 +33,7 @@ struct ConvF16Args {
   // conv3x3_f16_rows_kernel (f16_rows_kernels.hip; prec 1, bn 64 weights): src1 may be the HALF-resolution tensor (the bilinear x2 rides in the loader);
   // the tile plan below is filled by f16_rows_plan
   int src1_lowres = 0;
+  int rows_blend16 = 0;  // the folded bilinear x2 in packed fp16 arithmetic (one more fp16 rounding than upsample2x_fmt_kernel's fp32 form)
   int rows_r = 0, rows_wt = 0, rows_mt = 0, rows_mg = 0;   // tile = rows_r rows x rows_wt columns <= 16 rows_mt rows_mg pixels; rows_mg pixel groups x 8 / rows_mg channel slices
   int rows_hp16 = 0, rows_xb = 0, rows_lc16 = 0, rows_lowp = 0, rows_lds = 0;  // halo pitch (16-pixel pieces), staging extension (bytes), low tile pitch / pieces, LDS bytes
   int rows_inv_wt = 0, rows_inv_pw = 0, rows_inv_cc = 0;   // ceil(2^20 / d) for d = rows_wt, rows_wt / 2, rows_wt / 2 + 1
@@ -46,7 +47,7 @@ double f16_rows_plan(ConvF16Args& a, int n_cu);         // fills the rows_* plan
 int launch_conv3x3_f16_rows(const ConvF16Args& a, hipStream_t s);
 int64_t f16_weight_pack_floats(int n_tiles, int chunks0, int chunks1, int bn, int plain);
 int launch_f16_weight_pack(const float* w_dma_f32, float* dst, int n_tiles, int chunks0, int chunks1, int bn, int plain, hipStream_t s);
-int launch_upsample_fmt(int fmt, const void* src, void* dst, int B, int H, int W, int cp, hipStream_t s);
+int launch_upsample_fmt(int fmt, const void* src, void* dst, int B, int H, int W, int cp, hipStream_t s, int f16math = 0);  // f16math: plain fp16 only, see upsample2x_fmt_kernel
 int launch_pool_fmt(int fmt, const void* src, void* dst, int B, int H, int W, int cp, hipStream_t s);
 int launch_head_fmt(int fmt, const void* src, const float* w, const float* bias, float* dst, int B, int HW, int cp, int wcp, int cout, int sigmoid, hipStream_t s);
 int launch_slot_to_nchw_fmt(int fmt, const void* src, float* dst, int B, int HW, int cp, int c, hipStream_t s);

@@ -523,8 +523,12 @@ int launch_conv3x3_f16(const ConvF16Args& a, hipStream_t s) {
 
 // bilinear x2, align_corners=False (ATen upsample_bilinear2d: src = max(0, (dst + 0.5) * 0.5 - 0.5)); one thread = 8 channels x
 // the 2x2 output pixels between input pixels (i..i+1, j..j+1), i, j from -1 (see upsample2x_kernel in net_kernels.hip)
+// `f16math` (plain fp16 only; handle option "upsample_f16math"): the blend in packed fp16 arithmetic with ATen's scale-2 weights as constants -- 3/4 of the nearer
+// source pixel, 1/4 of the farther one (at the border both taps are the same clamped pixel, so the constants reproduce the border rule); fma(a, 3/4, b / 4) is the
+// exact one-dimensional blend rounded once, the horizontal result is rounded to fp16 before the vertical blend.  The arithmetic, operation for operation, of the
+// blend conv3x3_f16_rows_kernel's loader waves do when the up-sampling is folded into the conv (f16_rows_kernels.hip: blend16): either plan gives the same bits.
 template <int FMT>
-__global__ __launch_bounds__(256) void upsample2x_fmt_kernel(const void* __restrict__ src, void* __restrict__ dst, int B, int H, int W, int cp) {
+__global__ __launch_bounds__(256) void upsample2x_fmt_kernel(const void* __restrict__ src, void* __restrict__ dst, int B, int H, int W, int cp, int f16math) {
   const int Ho = 2 * H, Wo = 2 * W, groups = cp >> 3;
   const int nI = H + 1, nJ = W + 1;
   const size_t total = (size_t)B * nI * nJ * groups;
@@ -537,6 +541,33 @@ __global__ __launch_bounds__(256) void upsample2x_fmt_kernel(const void* __restr
     const int b = (int)(p / nI);
     const int r0 = max(i, 0), r1 = min(i + 1, H - 1), c0 = max(j, 0), c1 = min(j + 1, W - 1);
     const size_t base = (size_t)b * H * W;
+    if constexpr (FMT == FMT_F16) {
+      if (f16math) {
+        auto at = [&](int r, int c) { return *reinterpret_cast<const f16x8*>(reinterpret_cast<const char*>(src) + ((base + (size_t)r * W + c) * cp + 8 * g) * 2); };
+        const f16x8 h00 = at(r0, c0), h01 = at(r0, c1), h10 = at(r1, c0), h11 = at(r1, c1);
+        f16x8 c75, c25;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          c75[k] = (_Float16)0.75f;
+          c25[k] = (_Float16)0.25f;
+        }
+        const f16x8 q00 = h00 * c25, q01 = h01 * c25, q10 = h10 * c25, q11 = h11 * c25;
+        const f16x8 t0[2] = {__builtin_elementwise_fma(h00, c75, q01), __builtin_elementwise_fma(h01, c75, q00)};
+        const f16x8 t1[2] = {__builtin_elementwise_fma(h10, c75, q11), __builtin_elementwise_fma(h11, c75, q10)};
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+          const int x = 2 * j + 1 + dx;
+          const f16x8 o0 = __builtin_elementwise_fma(t0[dx], c75, t1[dx] * c25), o1 = __builtin_elementwise_fma(t1[dx], c75, t0[dx] * c25);
+#pragma unroll
+          for (int dy = 0; dy < 2; ++dy) {
+            const int y = 2 * i + 1 + dy;
+            if (y >= 0 && y < Ho && x >= 0 && x < Wo)
+              *reinterpret_cast<f16x8*>(reinterpret_cast<char*>(dst) + ((((size_t)b * Ho + y) * Wo + x) * cp + 8 * g) * 2) = dy ? o1 : o0;
+          }
+        }
+        continue;
+      }
+    }
     float v00[8], v01[8], v10[8], v11[8];
     load8<FMT>(src, base + (size_t)r0 * W + c0, cp, g, v00);
     load8<FMT>(src, base + (size_t)r0 * W + c1, cp, g, v01);
@@ -725,10 +756,10 @@ __global__ void slot_to_nchw_fmt_kernel(const void* __restrict__ src, float* __r
     default: { constexpr int F = FMT_F32; CALL; break; }          \
   }
 
-int launch_upsample_fmt(int fmt, const void* src, void* dst, int B, int H, int W, int cp, hipStream_t s) {
+int launch_upsample_fmt(int fmt, const void* src, void* dst, int B, int H, int W, int cp, hipStream_t s, int f16math) {
   const size_t total = (size_t)B * (H + 1) * (W + 1) * (cp / 8);
   const int blocks = (int)std::min<size_t>((total + 255) / 256, 256 * 32);
-  PH_FMT_DISPATCH(fmt, hipLaunchKernelGGL(upsample2x_fmt_kernel<F>, dim3(blocks), dim3(256), 0, s, src, dst, B, H, W, cp));
+  PH_FMT_DISPATCH(fmt, hipLaunchKernelGGL(upsample2x_fmt_kernel<F>, dim3(blocks), dim3(256), 0, s, src, dst, B, H, W, cp, f16math));
   PH_HIP_CHECK(hipGetLastError());
   return PH_OK;
 }

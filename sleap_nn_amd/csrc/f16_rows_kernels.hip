@@ -190,11 +190,53 @@ __global__ __launch_bounds__(768) void conv3x3_f16_rows_kernel(ConvF16Args a) {
         }
       }
     };
+    // the same in packed fp16 arithmetic (`rows_blend16`; v_pk_fma_f16, two channels per instruction, no conversions: 64 instead of ~180 vector operations per
+    // item): with ATen's scale-2 weights -- 3/4 of the nearer source pixel, 1/4 of the farther one; at the image border both taps are the SAME clamped pixel, so the
+    // constant weights reproduce the border rule -- a one-dimensional blend fma(a, 3/4, b / 4) is the exact value rounded ONCE (b / 4 is exact in fp16).  The
+    // horizontal result is rounded to fp16 before the vertical blend, where the fp32 form above rounds once at the end: at most one more half-ulp on these tensors.
+    auto blend16 = [&](int y0, int x0, int lowb, int bufb) {
+      const int CR = (R >> 1) + 1, CC = (Wt >> 1) + 1, items = CR * CC * 4;
+      const int lt = tid - 512;
+      f16x8 c75, c25, zero8;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        c75[k] = (_Float16)0.75f;
+        c25[k] = (_Float16)0.25f;
+        zero8[k] = (_Float16)0.f;
+      }
+      for (int it = lt; it < items; it += 256) {
+        const int q = it & 3, cell = it >> 2;
+        const int ci = (cell * a.rows_inv_cc) >> 20, cj = cell - ci * CC;
+        auto lowat = [&](int li, int lj) { return *reinterpret_cast<const f16x8*>(smem + lowb + (li * LC16 + (lj >> 4)) * 1024 + q * 256 + (lj & 15) * 16); };
+        const f16x8 h00 = lowat(ci, cj), h01 = lowat(ci, cj + 1), h10 = lowat(ci + 1, cj), h11 = lowat(ci + 1, cj + 1);
+        // horizontal: halo column 2 cj (dx 0) is nearer to source column cj + 1?  gx = x0 - 1 + 2 cj + dx, source coordinate (gx + 0.5) / 2 - 0.5 = (j0 + cj) + 0.25 (dx 0) / + 0.75 (dx 1)
+        // with j0 + cj the cell's left source column: dx 0 takes 3/4 of the LEFT pixel, dx 1 3/4 of the RIGHT one
+        const f16x8 q00 = h00 * c25, q01 = h01 * c25, q10 = h10 * c25, q11 = h11 * c25;
+        const f16x8 t0[2] = {__builtin_elementwise_fma(h00, c75, q01), __builtin_elementwise_fma(h01, c75, q00)};  // upper source row, dx 0 / 1
+        const f16x8 t1[2] = {__builtin_elementwise_fma(h10, c75, q11), __builtin_elementwise_fma(h11, c75, q10)};  // lower source row
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+          const int hxp = 2 * cj + dx, gx = x0 - 1 + hxp;
+          const f16x8 o0 = __builtin_elementwise_fma(t0[dx], c75, t1[dx] * c25);  // dy 0: 3/4 of the upper row
+          const f16x8 o1 = __builtin_elementwise_fma(t1[dx], c75, t0[dx] * c25);  // dy 1: 3/4 of the lower row
+#pragma unroll
+          for (int dy = 0; dy < 2; ++dy) {
+            const int gy = y0 - 1 + 2 * ci + dy;
+            const bool in = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+            if (hxp < HP16 * 16) *reinterpret_cast<f16x8*>(smem + bufb + ((2 * ci + dy) * HP16 + (hxp >> 4)) * 1024 + q * 256 + (hxp & 15) * 16) = in ? (dy ? o1 : o0) : zero8;
+          }
+        }
+      }
+    };
     auto is_low = [&](int ch) { return a.src1_lowres && ch >= a.chunks0; };
     // chunk `ch` of a tile into halo buffer `bufb` (a low-resolution chunk must already lie in its low buffer)
     auto fill = [&](int ch, int b, int y0, int x0, int bufb) {
-      if (is_low(ch))
-        blend(y0, x0, off_low + ((ch - a.chunks0) & 1) * LOWB, bufb);
+      if (is_low(ch)) {
+        if (a.rows_blend16)
+          blend16(y0, x0, off_low + ((ch - a.chunks0) & 1) * LOWB, bufb);
+        else
+          blend(y0, x0, off_low + ((ch - a.chunks0) & 1) * LOWB, bufb);
+      }
       else if (ch < a.chunks0)
         fill_dma(a.src0, a.rs0, ch * 16, b, y0, x0, bufb);
       else
@@ -520,11 +562,18 @@ double f16_rows_plan(ConvF16Args& a, int n_cu) {
         const double tiles = (double)a.B * ((a.H + R - 1) / R) * ((a.W + Wt - 1) / Wt);
         const double units = tiles * ntc;
         const double rounds = std::ceil(units / n_cu);
-        const double mfma = 9.0 * MT * 2 * 16 * 2;                                         // two MFMA waves per SIMD
-        const double load = NP / 4.0 * 130 + (a.src1_lowres ? px * 1.5 : 0.0);                // LDS-DMA issue; the blend's vector work
+        // calibrated on the cfg5 forward (profiles/r6_f16_rows_*): a chunk takes 1.45 x its MFMA issue time (two MFMA waves per SIMD) or the loaders' time, whichever is
+        // longer -- LDS-DMA ~130 cycles of issue per piece and loader wave; a pass of the blend over 256 items ~1,800 cycles in packed fp16, ~4,500 in fp32 beside
+        // the MFMA waves --; per tile ~3,000 cycles + its stores at ~10 B per cycle and CU; ~8,000 cycles per launch
+        const double mfma = 1.45 * 9.0 * MT * 2 * 16 * 2;
+        const double load_full = NP / 4.0 * 130;
+        const double items = ((R >> 1) + 1.0) * ((Wt >> 1) + 1.0) * 4;
+        const double load_low = std::ceil(items / 256.0) * (a.rows_blend16 ? 1800.0 : 4500.0) + lowp / 4.0 * 130;
+        const int n_low = a.src1_lowres ? a.chunks1 : 0;
+        const double tile = 3000.0 + px * BN * 2.0 / 10.0 * (a.skip_dst ? 0.3 : 1.0) + (a.dst_pool ? px * BN * 0.5 / 10.0 : 0.0);
         const double pxl = (double)a.B * a.H * a.W;
         const double bytes = pxl * 64.0 * (a.chunks0 + (a.src1_lowres ? 0.25 : 1.0) * a.chunks1) + (a.skip_dst ? 0.0 : pxl * a.coutp * 2.0) + (a.dst_pool ? pxl * a.coutp * 0.5 : 0.0);
-        const double cost = std::max(rounds * (nch * std::max(mfma, load) + 3500.0 + px * 4.0), bytes / 2500.0);
+        const double cost = std::max(8000.0 + rounds * ((nch - n_low) * std::max(mfma, load_full) + n_low * std::max(mfma, load_low) + tile), bytes / 2500.0);
         if (best < 0 || cost < best) {
           best = cost;
           a.rows_r = R;

@@ -1118,6 +1118,7 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
                 r.src1 = slot_ptr(up.src0);
                 r.rs1 = plan.slots[up.src0].cp / rs_div;
                 r.src1_lowres = 1;
+                r.rows_blend16 = m->upsample_f16math ? 1 : 0;
               }
               const double c_rows = f16_rows_plan(r, n_cu);
               double c_old = f16_conv_cost(f, n_cu);
@@ -1130,7 +1131,7 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
             if (deferred_up >= 0 && !on_rows) {
               const ph_op_desc& up = m->ops[deferred_up].d;
               const SlotShape& sl = plan.slots[up.src0];
-              rc = launch_upsample_fmt(fmt, slot_ptr(up.src0), slot_ptr(up.dst), batch, sl.h, sl.w, sl.cp, s);
+              rc = launch_upsample_fmt(fmt, slot_ptr(up.src0), slot_ptr(up.dst), batch, sl.h, sl.w, sl.cp, s, (fmt == FMT_F16 && m->upsample_f16math) ? 1 : 0);
               if (rc != PH_OK) return rc;
             }
             deferred_up = -1;
@@ -1364,7 +1365,7 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
           }
         }
         rc = fmt == FMT_F32 ? launch_upsample(slot_ptr(d.src0), slot_ptr(d.dst), batch, s0.h, s0.w, s0.cp, s)
-                            : launch_upsample_fmt(fmt, slot_ptr(d.src0), slot_ptr(d.dst), batch, s0.h, s0.w, s0.cp, s);
+                            : launch_upsample_fmt(fmt, slot_ptr(d.src0), slot_ptr(d.dst), batch, s0.h, s0.w, s0.cp, s, (fmt == FMT_F16 && m->upsample_f16math) ? 1 : 0);
         break;
       }
       case PH_OP_CONVT: {
@@ -1691,6 +1692,7 @@ std::vector<OptionRef> option_table(ph_model* m) {
       {"conv_wino4_min_cin", &m->conv_wino4_min_cin, nullptr},  // padded input channels from which a layer takes it
       {"conv_n32_wino2d", &m->conv_n32_wino2d, nullptr},  // Cout-32 / K >= 64 layers on the F(2x2,3x3) kernel with a half-empty N tile (0: the N-tile-32 F(2,3) kernel)
       {"conv_splitk_finish", &m->conv_splitk_finish, nullptr},  // 0: the split-K second stage as a launch of its own (A/B, tests)
+      {"upsample_f16math", &m->upsample_f16math, nullptr},  // a bilinear x2 folded into conv3x3_f16_rows_kernel blends in packed fp16 arithmetic (1) or in fp32 as upsample2x_fmt_kernel does (0)
       {"conv_f16_rows", &m->conv_f16_rows, nullptr},    // plain-fp16 precision: conv3x3_f16_rows_kernel 0 never, 1 where its plan is estimated faster than conv3x3_f16_persist_kernel, 2 wherever the shape fits
       {"conv_smallmap", &m->conv_smallmap, nullptr},    // conv3x3_sm_kernel for small maps at small batches: 0 never, 1 where estimated faster (inference plans, conv_splitk = 1), 2 wherever the shape fits
       {"conv_splitk", &m->conv_splitk, nullptr},        // split K on the F(2x2,3x3) kernel for layers with fewer work units than CUs: 0 never, 1 where estimated faster, n >= 2 force n slices

@@ -9,7 +9,7 @@ from sleap_nn_amd.architectures.model import Model
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 S = int(sys.argv[2]) if len(sys.argv) > 2 else 768
 timing = len(sys.argv) > 3
-modes = (2,) if (len(sys.argv) > 3 and sys.argv[3] in ('only2', 'pmc')) else (0, 2, 1)
+modes = (2,) if (len(sys.argv) > 3 and sys.argv[3] in ('only2', 'pmc')) else ((1,) if (len(sys.argv) > 3 and sys.argv[3] == 'only1') else (0, 2, 1))
 if len(sys.argv) > 3 and sys.argv[3] == 'pmc':
     timing = False
 dev = torch.device("cuda", 0)
@@ -17,6 +17,8 @@ heads = {"confmaps": {"part_names": [f"k{i}" for i in range(17)], "sigma": 2.5, 
          "class_maps": {"classes": [f"id{i}" for i in range(4)], "sigma": 12.5, "output_stride": 8, "loss_weight": 1.0}}
 m = Model("unet", dict(bench.CFG3_BB), heads, "multi_class_bottomup").init_xavier_(seed=1234, head_scale=1.0).to(dev).set_precision("fp16")
 x = torch.randint(0, 256, (B, 1, S, S), dtype=torch.uint8, device=dev)
+if len(sys.argv) > 4:
+    m.set_option('upsample_f16math', float(sys.argv[4]))
 outs = {}
 for mode in modes:
     m.set_option("conv_f16_rows", mode)
