@@ -39,6 +39,8 @@ struct ConvF16Args {
   int rows_inv_wt = 0, rows_inv_pw = 0, rows_inv_cc = 0;   // ceil(2^20 / d) for d = rows_wt, rows_wt / 2, rows_wt / 2 + 1
 };
 
+struct StemArgs;
+int launch_stem_f16(const StemArgs& a, hipStream_t s);  // stem_f16_kernel: the fused first encoder block, both convs on the fp16 matrix pipe (plain fp16 outputs)
 int prepare_f16_kernels();
 int launch_conv3x3_f16(const ConvF16Args& a, hipStream_t s);
 double f16_conv_cost(const ConvF16Args& a, int n_cu);   // estimated launch body of conv3x3_f16_persist_kernel, shader cycles

@@ -28,6 +28,7 @@
 #include "act_format.h"
 #include "common.h"
 #include "f16_kernels.h"
+#include "net_kernels.h"
 
 namespace ph {
 
@@ -803,6 +804,257 @@ int launch_slot_to_nchw_fmt(int fmt, const void* src, float* dst, int B, int HW,
   const size_t total = (size_t)B * HW * ((c + 7) / 8);
   const int blocks = (int)std::min<size_t>((total + 255) / 256, 8192);
   PH_FMT_DISPATCH(fmt, hipLaunchKernelGGL(slot_to_nchw_fmt_kernel<F>, dim3(blocks), dim3(256), 0, s, src, dst, B, HW, cp, c));
+  PH_HIP_CHECK(hipGetLastError());
+  return PH_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// Fused first encoder block in the plain-fp16 precision, both convolutions on the matrix cores (handle option "stem_f16mfma"; stem_fused_kernel<CIN, 3> of
+// net_kernels.hip computes the first conv with ~36 vector FMAs per pixel and 4-channel group and converts its fp32 result as the second conv reads it:
+// ~620 vector instructions around 36 MFMAs per 64 pixels, 219 us of BASELINE cfg5's 1.39-ms forward).
+//   uint8 / float image tile -> / 255 -> fp16 (autocast's cast of the conv input, torch_backend.py:113-143) -> conv3x3(Cin -> 16) as an im2col product on
+//   v_mfma_f32_16x16x16_f16 (K = 9 Cin taps padded to 16 / 32: a lane gathers its four taps of its pixel from the LDS image) + bias + ReLU -> fp16 halo tile in
+//   LDS (zeros outside the image: the second conv's padding) -> conv3x3(16 -> 16) on v_mfma_f32_16x16x32_f16, two taps per MFMA (K = 2 x 16 channels) + bias +
+//   ReLU -> 2x2 max pool in registers -> pooled NHWC store (+ the full-resolution tensor if somebody reads it).
+// Reference: encoder_decoder.py:108-121 (SimpleConvBlock), common.py:69-107 (MaxPool2dWithSamePadding), lightning_modules.py:1840-1848 (/ 255).
+// Tile 8 rows x 32 columns per 256-thread workgroup as stem_fused_kernel; wave w owns output rows 2w, 2w + 1 (four 16-pixel M tiles).
+// ---------------------------------------------------------------------------------------
+namespace {
+constexpr int S_TH = 8, S_TW = 32, S_HW = S_TW + 2, S_HH = S_TH + 2, S_IW = S_TW + 4, S_IH = S_TH + 4;
+}
+
+// Persistent: a workgroup walks tiles with stride gridDim.x; the weight operands, the lane's tap offsets and the halo geometry of its M tiles are set up once; the image
+// bytes of the NEXT tile are requested before the current tile's first conv and land in registers behind its matrix work (a tile is ~1 us of instructions behind ~2 us of
+// cold-load latency otherwise).  Two barriers per tile: image patch written / halo tile written; the halo tile is double-buffered so that a wave may start the next tile's
+// first conv while another still reads this tile's.
+__device__ __forceinline__ void stem_barrier_lds() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+template <int CIN>
+__global__ __launch_bounds__(256, 4) void stem_f16_kernel(StemArgs a) {
+  constexpr int NK = (9 * CIN + 15) / 16;      // K steps of 16 of the first conv
+  constexpr int NP0 = S_HH * S_HW;             // 340 halo pixels of the first conv's output
+  constexpr int NMT = (NP0 + 15) / 16;         // 22 M tiles of the first conv
+  constexpr int MT_W = (NMT + 3) / 4;          // per wave
+  constexpr int NIMG = CIN * S_IH * S_IW;      // image patch elements
+  constexpr int IMG_IT = (NIMG + 255) / 256;
+  __shared__ _Float16 sImg[NIMG + 8];
+  __shared__ __attribute__((aligned(16))) _Float16 sA[2][(NP0 + 4) * 16];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int tiles_x = (a.W + S_TW - 1) / S_TW, tiles_y = (a.H + S_TH - 1) / S_TH, tiles = tiles_x * tiles_y * a.B;
+  const int per_xcd = (tiles + 7) >> 3;  // every XCD gets a contiguous range of tiles (neighbouring tiles share image lines)
+  const int nvirt = 8 * per_xcd;
+
+  // ---- operands that do not depend on the tile: first conv A[i = li (output channel)][k = 16 s + 4 lg + j], k = tap * CIN + c (zero beyond 9 CIN); the lane's tap
+  // offsets into the image patch; second conv A of tap pair pp: lanes lg 0, 1 hold tap 2 pp (input channels 8 (lg & 1) ..), lg 2, 3 tap 2 pp + 1
+  f16x4 wa0[NK];
+  int koff[NK][4];
+#pragma unroll
+  for (int s = 0; s < NK; ++s)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = 16 * s + 4 * lg + j;
+      const bool real = k < 9 * CIN;
+      const int tap = real ? k / CIN : 0, c = real ? k - tap * CIN : 0;
+      wa0[s][j] = real ? (_Float16)a.w0[(size_t)(tap * CIN + c) * 16 + li] : (_Float16)0.f;
+      koff[s][j] = c * (S_IH * S_IW) + (tap / 3) * S_IW + (tap % 3);
+    }
+  f16x8 wb[5];
+  int tapoff[5];
+#pragma unroll
+  for (int pp = 0; pp < 5; ++pp) {
+    const int tap = 2 * pp + (lg >> 1);
+    const bool real = tap < 9;
+    const int tp = real ? tap : 8;
+    const float* w = a.w1 + (size_t)(tp * 16 + li) * 16 + 8 * (lg & 1);
+    const f32x4 w_lo = *reinterpret_cast<const f32x4*>(w), w_hi = *reinterpret_cast<const f32x4*>(w + 4);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      wb[pp][k] = real ? (_Float16)w_lo[k] : (_Float16)0.f;
+      wb[pp][4 + k] = real ? (_Float16)w_hi[k] : (_Float16)0.f;
+    }
+    tapoff[pp] = ((tp / 3) * S_HW + (tp % 3)) * 16 + 8 * (lg & 1);  // in fp16 elements of the halo tile
+  }
+  const f32x4 b0 = *reinterpret_cast<const f32x4*>(a.b0 + 4 * lg);
+  const f32x4 bias4 = *reinterpret_cast<const f32x4*>(a.b1 + 4 * lg);
+  // the lane's pixel in each of its wave's M tiles of the first conv: image-patch offset and halo coordinates (hy << 8 | hx), the same for every tile
+  int m_base[MT_W], m_yx[MT_W];
+#pragma unroll
+  for (int i = 0; i < MT_W; ++i) {
+    const int p = (wave + 4 * i) * 16 + li;
+    const int pc = p < NP0 ? p : NP0 - 1;
+    const int hy = pc / S_HW, hx = pc - hy * S_HW;
+    m_base[i] = hy * S_IW + hx;
+    m_yx[i] = (hy << 8) | hx;
+  }
+  // image patch elements of this thread (element e = tid + 256 it): patch coordinates
+  int e_yx[IMG_IT];
+#pragma unroll
+  for (int it = 0; it < IMG_IT; ++it) {
+    const int e = min(tid + 256 * it, NIMG - 1);
+    const int c = e / (S_IH * S_IW), r = e - c * (S_IH * S_IW);
+    const int iy = r / S_IW, ix = r - iy * S_IW;
+    e_yx[it] = (c << 16) | (iy << 8) | ix;
+  }
+  auto tile_of = [&](int vid, int& b, int& y0, int& x0) {
+    int t = (vid & 7) * per_xcd + (vid >> 3);
+    const bool ok = vid < nvirt && t < tiles;
+    t = ok ? t : 0;
+    const int tx = t % tiles_x;
+    t /= tiles_x;
+    const int ty = t % tiles_y;
+    b = t / tiles_y;
+    x0 = tx * S_TW;
+    y0 = ty * S_TH;
+    return ok;
+  };
+  float img[IMG_IT];
+  auto fetch = [&](int b, int y0, int x0) {
+#pragma unroll
+    for (int it = 0; it < IMG_IT; ++it) {
+      const int c = e_yx[it] >> 16, iy = (e_yx[it] >> 8) & 255, ix = e_yx[it] & 255;
+      const int gy = y0 + iy - 2, gx = x0 + ix - 2;
+      float v = 0.f;
+      if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
+        const size_t o = (((size_t)b * CIN + c) * a.H + gy) * a.W + gx;
+        if (a.dtype == 0)
+          v = (float)reinterpret_cast<const uint8_t*>(a.src)[o];
+        else
+          v = reinterpret_cast<const float*>(a.src)[o];
+      }
+      img[it] = v;
+    }
+  };
+  const int Hp = (a.H + 1) / 2, Wp = (a.W + 1) / 2;
+  f16x4 zero4;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) zero4[r] = (_Float16)0.f;
+
+  int vid = blockIdx.x;
+  int b, y0, x0;
+  bool ok = tile_of(vid, b, y0, x0);  // (workgroup-uniform)
+  if (ok) fetch(b, y0, x0);
+  int par = 0;
+  while (ok) {
+    // ---- image patch -> fp16 in LDS (/ 255 for integer-valued inputs)
+#pragma unroll
+    for (int it = 0; it < IMG_IT; ++it)
+      if (tid + 256 * it < NIMG) sImg[tid + 256 * it] = (_Float16)(a.dtype == 1 ? img[it] : img[it] / 255.0f);
+    stem_barrier_lds();  // (not __syncthreads(): its vmcnt(0) would wait for the next tile's image loads here)
+    const int nvid = vid + gridDim.x;
+    int nb, ny0, nx0;
+    const bool nok = tile_of(nvid, nb, ny0, nx0);
+    if (nok) fetch(nb, ny0, nx0);  // lands behind this tile's matrix work
+    _Float16* const A = sA[par];
+    const bool interior = y0 >= 1 && y0 + S_TH + 1 <= a.H && x0 >= 1 && x0 + S_TW + 1 <= a.W;  // the whole halo lies inside the image (workgroup-uniform)
+
+    // ---- first conv: M tile = 16 consecutive halo pixels (row-major over the 10 x 34 halo), transposed product D[channel 4 lg + r][pixel li]
+#pragma unroll
+    for (int i = 0; i < MT_W; ++i) {
+      const int mt = wave + 4 * i;
+      if (mt < NMT) {  // (wave-uniform)
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < NK; ++s) {
+          f16x4 xb;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) xb[j] = sImg[m_base[i] + koff[s][j]];
+          acc = __builtin_amdgcn_mfma_f32_16x16x16f16(wa0[s], xb, acc, 0, 0, 0);
+        }
+        bool in = true;
+        if (!interior) {
+          const int gy = y0 + (m_yx[i] >> 8) - 1, gx = x0 + (m_yx[i] & 255) - 1;
+          in = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;  // outside the image = the second conv's zero padding
+        }
+        f16x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = in ? (_Float16)fmaxf(acc[r] + b0[r], 0.f) : (_Float16)0.f;
+        const int p = mt * 16 + li;
+        if (p < NP0) *reinterpret_cast<f16x4*>(A + p * 16 + 4 * lg) = o;
+      }
+    }
+    stem_barrier_lds();  // (not __syncthreads(): its vmcnt(0) would wait for the next tile's image loads here)
+
+    // ---- second conv: two taps per MFMA
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) acc[m][h] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int pp = 0; pp < 5; ++pp)
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const f16x8 xb = *reinterpret_cast<const f16x8*>(A + ((2 * wave + m) * S_HW + h * 16 + li) * 16 + tapoff[pp]);
+          acc[m][h] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[pp], xb, acc[m][h], 0, 0, 0);
+        }
+    const bool whole = y0 + S_TH <= a.H && x0 + S_TW <= a.W;  // no output pixel beyond the image (workgroup-uniform)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int x = x0 + h * 16 + li;
+      float pooled[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pooled[r] = 0.f;  // values are >= 0 after the ReLU; out-of-image elements count as the reference's zero pad
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const int y = y0 + 2 * wave + m;
+        const bool in = whole || ((y < a.H) && (x < a.W));
+        float o[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = fmaxf(acc[m][h][r] + bias4[r], 0.f);
+        if (a.dst_full && in) {  // 16 logical channels in the 32-channel fp16 format: the upper 16 are written as zeros (nobody else would)
+          f16x4 oh;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) oh[r] = (_Float16)o[r];
+          _Float16* d = reinterpret_cast<_Float16*>(a.dst_full) + (((size_t)b * a.H + y) * a.W + x) * 32 + 4 * lg;
+          *reinterpret_cast<f16x4*>(d) = oh;
+          *reinterpret_cast<f16x4*>(d + 16) = zero4;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pooled[r] = fmaxf(pooled[r], in ? o[r] : 0.f);
+      }
+      f16x4 ph;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {  // the x neighbour of the pool window sits in lane li ^ 1
+        const int pi = __builtin_bit_cast(int, pooled[r]);
+        pooled[r] = fmaxf(pooled[r], __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(pi, pi, 0xB1, 0xF, 0xF, false)));
+        ph[r] = (_Float16)pooled[r];
+      }
+      const int py = (y0 >> 1) + wave, px = (x0 >> 1) + h * 8 + (li >> 1);
+      if (!(li & 1) && (whole || (py < Hp && px < Wp))) {
+        _Float16* d = reinterpret_cast<_Float16*>(a.dst_pool) + (((size_t)b * Hp + py) * Wp + px) * 32 + 4 * lg;
+        *reinterpret_cast<f16x4*>(d) = ph;
+        *reinterpret_cast<f16x4*>(d + 16) = zero4;
+      }
+    }
+    par ^= 1;
+    vid = nvid;
+    ok = nok;
+    b = nb, y0 = ny0, x0 = nx0;
+  }
+}
+
+int launch_stem_f16(const StemArgs& a, hipStream_t s) {
+  PH_REQUIRE(a.out_fmt == FMT_F16 && (a.cin == 1 || a.cin == 3), "stem_f16_kernel: plain fp16 outputs, 1 or 3 input channels");
+  int n_cu = 0;
+  {
+    const int rc_cu = device_cu_count(&n_cu);
+    if (rc_cu != PH_OK) return rc_cu;
+  }
+  const int tiles = ((a.W + S_TW - 1) / S_TW) * ((a.H + S_TH - 1) / S_TH) * a.B;
+  const int grid = std::min(8 * ((tiles + 7) / 8), 4 * n_cu);  // persistent: four workgroups per CU -- 128 registers: at six the tile loop spills -- (a multiple of 8: the XCD dealing of the virtual tile ids)
+  if (a.cin == 1)
+    hipLaunchKernelGGL((stem_f16_kernel<1>), dim3(grid), dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL((stem_f16_kernel<3>), dim3(grid), dim3(256), 0, s, a);
   PH_HIP_CHECK(hipGetLastError());
   return PH_OK;
 }

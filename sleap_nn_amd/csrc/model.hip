@@ -1045,6 +1045,7 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
         a.H = height;
         a.W = width;
         a.wino = m->stem_wino;
+        a.f16_mfma = m->stem_f16mfma;
         a.out_fmt = fmt;
         kv[op_index - 1] = PH_KV_STEM;
         rc = launch_stem(a, s);
@@ -1692,6 +1693,7 @@ std::vector<OptionRef> option_table(ph_model* m) {
       {"conv_wino4_min_cin", &m->conv_wino4_min_cin, nullptr},  // padded input channels from which a layer takes it
       {"conv_n32_wino2d", &m->conv_n32_wino2d, nullptr},  // Cout-32 / K >= 64 layers on the F(2x2,3x3) kernel with a half-empty N tile (0: the N-tile-32 F(2,3) kernel)
       {"conv_splitk_finish", &m->conv_splitk_finish, nullptr},  // 0: the split-K second stage as a launch of its own (A/B, tests)
+      {"stem_f16mfma", &m->stem_f16mfma, nullptr},      // plain fp16: the fused first block with BOTH convs on the fp16 matrix pipe (stem_f16_kernel) instead of stem_fused_kernel<CIN, 3>
       {"upsample_f16math", &m->upsample_f16math, nullptr},  // a bilinear x2 folded into conv3x3_f16_rows_kernel blends in packed fp16 arithmetic (1) or in fp32 as upsample2x_fmt_kernel does (0)
       {"conv_f16_rows", &m->conv_f16_rows, nullptr},    // plain-fp16 precision: conv3x3_f16_rows_kernel 0 never, 1 where its plan is estimated faster than conv3x3_f16_persist_kernel, 2 wherever the shape fits
       {"conv_smallmap", &m->conv_smallmap, nullptr},    // conv3x3_sm_kernel for small maps at small batches: 0 never, 1 where estimated faster (inference plans, conv_splitk = 1), 2 wherever the shape fits

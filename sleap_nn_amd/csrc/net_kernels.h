@@ -88,6 +88,7 @@ struct StemArgs {
   int dtype, cin, B, H, W;
   int out_fmt = 0;     // ActFmt of the outputs (act_format.h)
   int wino = 2;        // second conv: 2 Winograd F(2x2,3x3), 1 F(2,3) along x, 0 direct (handle option "stem_wino")
+  int f16_mfma = 1;    // plain fp16 outputs: stem_f16_kernel (both convs on the fp16 matrix pipe; handle option "stem_f16mfma") instead of stem_fused_kernel<CIN, 3>
 };
 
 struct PatchStemArgs {

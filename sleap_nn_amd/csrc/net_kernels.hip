@@ -19,6 +19,7 @@
 #include "act_format.h"
 #include "common.h"
 #include "net_kernels.h"
+#include "f16_kernels.h"
 
 namespace ph {
 
@@ -1780,6 +1781,7 @@ int launch_stem(const StemArgs& a, hipStream_t s) {
   const int tiles = ((a.W + TW - 1) / TW) * ((a.H + TH - 1) / TH) * a.B;
   const int grid = 8 * ((tiles + 7) / 8);  // the kernel deals tiles to XCDs in contiguous ranges
   const int wino = (a.out_fmt == FMT_F16 && a.wino >= 2) ? 3 : (a.wino >= 2 && a.w1w2) ? 2 : ((a.wino && a.w1w) ? 1 : 0);
+  if (wino == 3 && a.f16_mfma && (a.cin == 1 || a.cin == 3)) return launch_stem_f16(a, s);
   if (a.cin == 1 && wino == 3)
     hipLaunchKernelGGL((stem_fused_kernel<1, 3>), dim3(grid), dim3(256), 0, s, a);
   else if (a.cin == 3 && wino == 3)

@@ -17,8 +17,11 @@ heads = {"confmaps": {"part_names": [f"k{i}" for i in range(17)], "sigma": 2.5, 
          "class_maps": {"classes": [f"id{i}" for i in range(4)], "sigma": 12.5, "output_stride": 8, "loss_weight": 1.0}}
 m = Model("unet", dict(bench.CFG3_BB), heads, "multi_class_bottomup").init_xavier_(seed=1234, head_scale=1.0).to(dev).set_precision("fp16")
 x = torch.randint(0, 256, (B, 1, S, S), dtype=torch.uint8, device=dev)
-if len(sys.argv) > 4:
-    m.set_option('upsample_f16math', float(sys.argv[4]))
+for kv in sys.argv[4:]:
+    if '=' in kv:
+        m.set_option(kv.split('=')[0], float(kv.split('=')[1]))
+    else:
+        m.set_option('upsample_f16math', float(kv))
 outs = {}
 for mode in modes:
     m.set_option("conv_f16_rows", mode)
