@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define PH_VERSION 105
+#define PH_VERSION 106
 
 /* error codes */
 #define PH_OK 0
@@ -317,9 +317,10 @@ int ph_crop_bboxes(const void* images_dev, int32_t dtype, int32_t B, int32_t C, 
 /* Top-down glue, device side.  ph_centroid_select = CentroidLayer.postprocess after the peak finding (inference/layers/centroid.py:195-261:
  * per frame keep the peaks in order, or the max_instances largest values in descending order (torch.topk) when there are more; NaN-pad to
  * (B, max_instances, 2) / (B, max_instances); undo input scale and eff_scale (inference/ops/coord.py:40-70)) plus what TopDownLayer.predict
- * (inference/layers/topdown.py:183-260) derives from the valid centroids: make_centered_bboxes (data/instance_cropping.py:129-171) into
- * out_bboxes (B, max_instances, 4, 2; NaN where empty), and the stage-2 lists in torch.nonzero order of the valid mask (frame, then slot):
- * list_sample int32[n_valid], list_topleft float[n_valid, 2] (the ph_crop_bboxes inputs), list_slot int32[n_valid] = frame * max_instances + slot,
+ * (inference/layers/topdown.py:127-150, 183-267) derives from the valid centroids IN SIZED SPACE (centroid * eff_scale: the crops are cut from the
+ * sizematched frame): make_centered_bboxes (data/instance_cropping.py:129-171) around the sized centroid -- out_bboxes (B, max_instances, 4, 2; NaN where
+ * empty) holds those boxes / eff_scale (image space, as the reference stores them) --, and the stage-2 lists in torch.nonzero order of the valid mask
+ * (frame, then slot): list_sample int32[n_valid], list_topleft float[n_valid, 2] (sized space: the ph_crop_bboxes inputs), list_slot int32[n_valid] = frame * max_instances + slot,
  * pos_of_slot int32[B * max_instances] = list position or -1, out_n_valid int32[1].  peaks / counts are ph_local_peaks' outputs (coordinates
  * already multiplied by the output stride through its xy_scale).  eff_scale_dev float[B] or NULL; every list pointer may be NULL (centroid-only use). */
 int ph_centroid_select(const float* peaks_xy_dev, const float* peak_vals_dev, const int32_t* counts_dev, int32_t B, int32_t max_instances,
@@ -327,11 +328,13 @@ int ph_centroid_select(const float* peaks_xy_dev, const float* peak_vals_dev, co
                        float* out_vals_dev, float* out_bboxes_dev, int32_t* list_sample_dev, float* list_topleft_dev, int32_t* list_slot_dev,
                        int32_t* pos_of_slot_dev, int32_t* out_n_valid_dev, void* stream);
 
-/* ... and the way back (topdown.py:236-260): crop-local keypoints (n_valid, n_nodes, 2) / values (n_valid, n_nodes) of stage 2 into
- * out_keypoints = crop keypoints + the crop's top-left (add_crop_offset, ops/coord.py:73-90), out_crop_keypoints, out_vals, all
- * (slots = B * max_instances, n_nodes[, 2]) and NaN where pos_of_slot is -1. */
+/* ... and the way back (topdown.py:236-267): crop-local keypoints (n_valid, n_nodes, 2) / values (n_valid, n_nodes) of stage 2 into
+ * out_keypoints = (crop keypoints + the crop's top-left (add_crop_offset, ops/coord.py:73-90)) / eff_scale of the slot's frame (sized space ->
+ * image space; eff_scale_dev float[slots / max_instances] or NULL = 1), out_crop_keypoints, out_vals, all (slots = B * max_instances,
+ * n_nodes[, 2]) and NaN where pos_of_slot is -1. */
 int ph_topdown_scatter(const float* crop_xy_dev, const float* crop_vals_dev, const float* list_topleft_dev, const int32_t* pos_of_slot_dev,
-                       int32_t slots, int32_t n_nodes, float* out_keypoints_dev, float* out_crop_keypoints_dev, float* out_vals_dev, void* stream);
+                       int32_t slots, int32_t n_nodes, const float* eff_scale_dev, int32_t max_instances, float* out_keypoints_dev,
+                       float* out_crop_keypoints_dev, float* out_vals_dev, void* stream);
 
 /* Antialiased bilinear resize of planes x H x W -> planes x OH x OW (uint8: dtype 0, float32: dtype 1), NCHW planes.
  * Replaces torchvision.transforms.v2.functional.resize as called by resize_image (data/resizing.py:70-84, the input-scale step)

@@ -85,7 +85,7 @@ SIGNATURES = {
     "ph_lsap": (C.c_int, [_vp, _i32, _i32, _vp, _vp]),
     "ph_toposort_edges": (C.c_int, [_vp, _i32, _vp]),
     "ph_centroid_select": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "ph_topdown_scatter": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "ph_topdown_scatter": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp]),
     "ph_group_packed": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _i32, _f32, C.c_double, _i32, _i32, _i32, _f32, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
     "ph_group_batch": (C.c_int, [_i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, C.c_double, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
 }

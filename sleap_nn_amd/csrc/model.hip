@@ -1345,7 +1345,7 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
           // decides (it may run the F(4x4,3x3) kernel, which up-samples in its input transform) -- see PH_OP_CONV
           const PackedOp& nxo = m->ops[op_index];
           const ph_op_desc& nx = nxo.d;
-          bool only = nx.kind == PH_OP_CONV && nx.ksize == 3 && nx.src1 == d.dst && nx.src0 != d.dst && nx.dst2 < 0 && (nxo.w_wino4_dev != nullptr || nxo.w_sm_dev != nullptr);
+          bool only = nx.kind == PH_OP_CONV && nx.ksize == 3 && nx.src1 == d.dst && nx.src0 != d.dst && nx.dst2 < 0 && ((m->conv_wino4 && nxo.w_wino4_dev != nullptr) || (m->conv_smallmap && nxo.w_sm_dev != nullptr));  // (a form that is switched off does not defer the launch)
           for (size_t k = 0; only && k < m->ops.size(); ++k)
             if (k != op_index && (m->ops[k].d.src0 == d.dst || m->ops[k].d.src1 == d.dst)) only = false;
           if (only) {

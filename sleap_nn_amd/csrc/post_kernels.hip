@@ -901,21 +901,27 @@ __global__ __launch_bounds__(64) void centroid_select_kernel(const float* __rest
     out_cp[2 * s] = x;
     out_cp[2 * s + 1] = y;
     out_cv[s] = vals[off + src];
-    if (out_bbox) {  // make_centered_bboxes: corners (x -/+ w/2, y -/+ h/2) + (+/-0.5): TL, TR, BR, BL
+    if (out_bbox) {
+      // TopDownLayer.predict (layers/topdown.py:127-150, 262-267): stage 2 works in SIZED space -- the centroid (original-image space above) times eff_scale is the box centre,
+      // the crops are cut from the sizematched frame at that box, and boxes / keypoints are divided by eff_scale afterwards (ph_topdown_scatter).  make_centered_bboxes:
+      // corners (x -/+ w/2, y -/+ h/2) + (+/-0.5): TL, TR, BR, BL
+      const float sx = x * eff, sy = y * eff;
+      float sb[8];
+      sb[0] = (sx - half_w) + 0.5f;
+      sb[1] = (sy - half_h) + 0.5f;
+      sb[2] = (sx + half_w) - 0.5f;
+      sb[3] = (sy - half_h) + 0.5f;
+      sb[4] = (sx + half_w) - 0.5f;
+      sb[5] = (sy + half_h) - 0.5f;
+      sb[6] = (sx - half_w) + 0.5f;
+      sb[7] = (sy + half_h) - 0.5f;
       float* bb = out_bbox + 8 * s;
-      bb[0] = (x - half_w) + 0.5f;
-      bb[1] = (y - half_h) + 0.5f;
-      bb[2] = (x + half_w) - 0.5f;
-      bb[3] = (y - half_h) + 0.5f;
-      bb[4] = (x + half_w) - 0.5f;
-      bb[5] = (y + half_h) - 0.5f;
-      bb[6] = (x - half_w) + 0.5f;
-      bb[7] = (y + half_h) - 0.5f;
+      for (int e = 0; e < 8; ++e) bb[e] = sb[e] / eff;  // (debug output: image space)
       if (list_sample) {
         const int pos = base + slot;
         list_sample[pos] = b;
-        list_tl[2 * pos] = bb[0];
-        list_tl[2 * pos + 1] = bb[1];
+        list_tl[2 * pos] = sb[0];   // sized space: what ph_crop_bboxes cuts the sizematched frame with, and add_crop_offset's offset
+        list_tl[2 * pos + 1] = sb[1];
         list_slot[pos] = (int)s;
       }
     }
@@ -924,15 +930,15 @@ __global__ __launch_bounds__(64) void centroid_select_kernel(const float* __rest
   if (n <= I) {
     for (int k = lane; k < keep; k += 64) emit(k, k);
   } else {
-    // I rounds of a wave-wide arg-max over the peaks not taken yet (taken peaks are remembered as a bit per peak in registers: 64 x 32 = up to 2048 peaks per frame;
-    // more than that and the tail beyond 2048 is not considered -- the caller's capacity is far below)
-    unsigned taken = 0u;  // bit j: peak lane + 64 j
-    n = min(n, 2048);
+    // I rounds of a wave-wide arg-max over the peaks not taken yet (taken peaks are remembered as a bit per peak in registers: 64 x 64 = up to 4096 peaks per frame;
+    // more than that and the tail beyond 4096 is not considered -- CentroidLayer's row capacity max(1024, 256 B) is far below unless one frame holds them all)
+    unsigned long long taken = 0ull;  // bit j: peak lane + 64 j
+    n = min(n, 4096);
     for (int k = 0; k < I; ++k) {
       float best = -__builtin_inff();
       int bi = 0x7FFFFFFF;
       for (int j = 0; lane + 64 * j < n; ++j) {
-        if ((taken >> j) & 1u) continue;
+        if ((taken >> j) & 1ull) continue;
         const float v = vals[off + lane + 64 * j];
         if (v > best || (v == best && lane + 64 * j < bi)) {
           best = v;
@@ -948,7 +954,7 @@ __global__ __launch_bounds__(64) void centroid_select_kernel(const float* __rest
         }
       }
       if (bi != 0x7FFFFFFF && (bi & 63) == lane) {
-        taken |= 1u << (bi >> 6);
+        taken |= 1ull << (bi >> 6);
         emit(k, bi);
       }
     }
@@ -966,8 +972,8 @@ __global__ __launch_bounds__(64) void centroid_select_kernel(const float* __rest
 
 // (B I, N) threads: slot s of the padded outputs takes crop pos_of_slot[s]'s keypoints (+ its box's top-left: add_crop_offset) or NaN.
 __global__ __launch_bounds__(256) void topdown_scatter_kernel(const float* __restrict__ crop_xy, const float* __restrict__ crop_vals, const float* __restrict__ list_tl,
-                                                              const int* __restrict__ pos_of_slot, int slots, int N, float* __restrict__ out_k, float* __restrict__ out_c,
-                                                              float* __restrict__ out_v) {
+                                                              const int* __restrict__ pos_of_slot, int slots, int N, const float* __restrict__ eff_scale, int I,
+                                                              float* __restrict__ out_k, float* __restrict__ out_c, float* __restrict__ out_v) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= slots * N) return;
   const int s = i / N, k = i - s * N;
@@ -978,8 +984,9 @@ __global__ __launch_bounds__(256) void topdown_scatter_kernel(const float* __res
     cx = crop_xy[2 * ((size_t)pos * N + k)];
     cy = crop_xy[2 * ((size_t)pos * N + k) + 1];
     v = crop_vals[(size_t)pos * N + k];
-    gx = cx + list_tl[2 * pos];
-    gy = cy + list_tl[2 * pos + 1];
+    const float eff = eff_scale ? eff_scale[s / I] : 1.f;  // sized space -> image space (topdown.py:262-264)
+    gx = (cx + list_tl[2 * pos]) / eff;
+    gy = (cy + list_tl[2 * pos + 1]) / eff;
   }
   out_k[2 * (size_t)i] = gx;
   out_k[2 * (size_t)i + 1] = gy;
@@ -1097,11 +1104,12 @@ int ph_centroid_select(const float* peaks_xy_dev, const float* peak_vals_dev, co
 }
 
 int ph_topdown_scatter(const float* crop_xy_dev, const float* crop_vals_dev, const float* list_topleft_dev, const int32_t* pos_of_slot_dev, int32_t slots,
-                       int32_t n_nodes, float* out_keypoints_dev, float* out_crop_keypoints_dev, float* out_vals_dev, void* stream) {
+                       int32_t n_nodes, const float* eff_scale_dev, int32_t max_instances, float* out_keypoints_dev, float* out_crop_keypoints_dev, float* out_vals_dev,
+                       void* stream) {
   PH_REQUIRE(crop_xy_dev && crop_vals_dev && list_topleft_dev && pos_of_slot_dev && out_keypoints_dev && out_crop_keypoints_dev && out_vals_dev, "ph_topdown_scatter: null argument");
-  PH_REQUIRE(slots > 0 && n_nodes > 0, "ph_topdown_scatter: bad shape");
+  PH_REQUIRE(slots > 0 && n_nodes > 0 && (!eff_scale_dev || (max_instances > 0 && slots % max_instances == 0)), "ph_topdown_scatter: bad shape");
   hipLaunchKernelGGL(topdown_scatter_kernel, dim3((slots * n_nodes + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), crop_xy_dev, crop_vals_dev, list_topleft_dev,
-                     pos_of_slot_dev, slots, n_nodes, out_keypoints_dev, out_crop_keypoints_dev, out_vals_dev);
+                     pos_of_slot_dev, slots, n_nodes, eff_scale_dev, max_instances > 0 ? max_instances : 1, out_keypoints_dev, out_crop_keypoints_dev, out_vals_dev);
   PH_HIP_CHECK(hipGetLastError());
   return PH_OK;
 }

@@ -162,6 +162,8 @@ class BottomUpLayer(InferenceLayer):
         max_instances = getattr(pc, "max_instances", None)
         if max_instances is None:
             max_instances = self.max_instances
+        if not max_instances:  # 0 = no cap, as `params.max_instances or _infer_max_instances(...)` in group_scored_batch (streaming.py:147-255): the fallback path reads it the same way
+            max_instances = None
         info = h["info"]
         eff = info.eff_scale.detach().to("cpu", torch.float32).contiguous()
         edges = self.__dict__.get("_edges_i32")

@@ -27,7 +27,7 @@ class CentroidLayer(InferenceLayer):
         self.anchor_ind = anchor_ind
         self.use_gt_centroids = False
 
-    def _select_enqueue(self, raw_out: dict, info: PreprocInfo, cap: int = 0) -> dict:
+    def _select_enqueue(self, raw_out: dict, info: PreprocInfo, cap: int = 0, frames=None) -> dict:
         """Peak finding on the device (``ph_local_peaks``, coordinates x output stride) + the asynchronous D2H of its counts into pinned memory; no host sync."""
         cms = self._extract_confmaps(raw_out)
         pc = self.postprocess_config
@@ -40,7 +40,9 @@ class CentroidLayer(InferenceLayer):
         host.copy_(counts, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(cms.device))
-        return {"xy": xy, "vals": vals, "counts": counts, "counts_host": host, "event": ev, "B": B, "cap": cap, "raw": raw_out, "cms": cms_c}
+        # `frames`: the preprocessed frames of this batch.  A graphed backend hands out its STATIC outputs, which the next batch's forward overwrites: the (rare) redo with more
+        # peak rows in _select_finish then re-runs the forward on the frames instead of re-reading `raw_out` (BottomUpLayer._redo_eagerly does the same)
+        return {"xy": xy, "vals": vals, "counts": counts, "counts_host": host, "event": ev, "B": B, "cap": cap, "raw": raw_out, "cms": cms_c, "frames": frames}
 
     def _select_finish(self, h: dict, info: PreprocInfo, crop_size=None, need_counts: bool = True) -> dict:
         """Per-frame selection on the device (``ph_centroid_select``).  Returns the padded centroids / values (device) and -- with ``crop_size`` -- the boxes and the
@@ -59,7 +61,10 @@ class CentroidLayer(InferenceLayer):
             h["event"].synchronize()  # the one sync of the stage
             counts_h = h["counts_host"]
             if int(counts_h[0]) > h["cap"]:  # rare: more peaks than rows -> once more with room for all of them
-                h2 = self._select_enqueue(h["raw"], info, cap=int(counts_h[0]))
+                raw = h["raw"]
+                if h.get("frames") is not None and getattr(self.backend, "use_graph", False):
+                    raw = self.backend(h["frames"])  # (the static outputs may already hold the next batch)
+                h2 = self._select_enqueue(raw, info, cap=int(counts_h[0]), frames=h.get("frames"))
                 return self._select_finish(h2, info, crop_size, need_counts)
             per_frame = counts_h[1 : 1 + B].clone()
             self._pinned_counts[B].append(counts_h)
@@ -77,7 +82,7 @@ class CentroidLayer(InferenceLayer):
                 eff = ones[(B, dev)] = torch.ones(B, dtype=torch.float32, device=dev)
         else:
             eff = info.eff_scale.to(dev, torch.float32).contiguous()
-        res = {"centroids": cp, "vals": cv, "I": I}
+        res = {"centroids": cp, "vals": cv, "I": I, "eff": eff}
         if lists:
             res["bboxes"] = torch.empty((B, I, 4, 2), dtype=torch.float32, device=dev)
             res["list_sample"] = torch.empty((B * I,), dtype=torch.int32, device=dev)

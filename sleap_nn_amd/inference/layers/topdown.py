@@ -36,7 +36,20 @@ class TopDownLayer:
             return {"x": x, "slow": True}
         xp, info = cl.preprocess(x)
         raw = cl.backend(xp)
-        return {"x": x, "slow": False, "raw": raw, "info": info, "sel": cl._select_enqueue(raw, info)}
+        return {"x": x, "slow": False, "raw": raw, "info": info, "sel": cl._select_enqueue(raw, info, frames=xp)}
+
+    def _sized_frames(self, x: torch.Tensor, info) -> torch.Tensor:
+        """The frames stage 2 is cut from (layers/topdown.py:127-150, ``_sizematch_like_centroid_layer``): the RAW frames through the centroid layer's sizematcher
+        -- no channel coercion, no input scale, no pad to stride.  The centered-instance model was trained on crops of sized frames."""
+        cfg = self.centroid_layer.preprocess_config
+        if cfg.max_height is None and cfg.max_width is None:
+            return x
+        if (cfg.max_height is None or cfg.max_height == x.shape[-2]) and (cfg.max_width is None or cfg.max_width == x.shape[-1]):
+            return x
+        from sleap_nn_amd.data.resizing import apply_sizematcher
+
+        sized, _e = apply_sizematcher(x, cfg.max_height, cfg.max_width)
+        return sized
 
     def _finish(self, h: dict) -> Outputs:
         import ctypes as C
@@ -53,9 +66,14 @@ class TopDownLayer:
         centroids, cvals, I, n_valid = sel["centroids"], sel["vals"], sel["I"], sel["n_valid"]
         B = int(centroids.shape[0])
         if n_valid == 0:
-            n_nodes = 1
-            return Outputs(pred_keypoints=torch.full((B, I, n_nodes, 2), float("nan")), pred_peak_values=torch.full((B, I, n_nodes), float("nan")),
-                           pred_centroids=centroids.cpu(), pred_centroid_values=cvals.cpu(), instance_scores=cvals.cpu())
+            # (layers/topdown.py:213-230: all-NaN keypoints of the right shape, on the centroid model's device, like every other batch of the video)
+            n_nodes = self._infer_n_nodes()
+            out = Outputs(pred_keypoints=torch.full((B, I, n_nodes, 2), float("nan"), device=dev), pred_peak_values=torch.full((B, I, n_nodes), float("nan"), device=dev),
+                          pred_centroids=centroids, pred_centroid_values=cvals, instance_scores=cvals, preprocess_info=h["info"])
+            out.pred_crop_keypoints = torch.full((B, I, n_nodes, 2), float("nan"), device=dev)
+            out.instance_bboxes = torch.full((B, I, 4, 2), float("nan"), device=dev)
+            return out
+        x = self._sized_frames(x, h["info"])
         if x.dtype == torch.uint8:
             code = 0
         elif x.dtype == torch.float32:
@@ -77,7 +95,8 @@ class TopDownLayer:
         full_v = torch.empty((B, I, n_nodes), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             L.check(L.lib().ph_topdown_scatter(C.c_void_p(k3.data_ptr()), C.c_void_p(v3.data_ptr()), C.c_void_p(sel["list_tl"].data_ptr()), C.c_void_p(sel["pos_of_slot"].data_ptr()),
-                                               B * I, n_nodes, C.c_void_p(full_k.data_ptr()), C.c_void_p(full_c.data_ptr()), C.c_void_p(full_v.data_ptr()), L.current_stream_ptr()))
+                                               B * I, n_nodes, C.c_void_p(sel["eff"].data_ptr()), I, C.c_void_p(full_k.data_ptr()), C.c_void_p(full_c.data_ptr()),
+                                               C.c_void_p(full_v.data_ptr()), L.current_stream_ptr()))
         out = Outputs(pred_keypoints=full_k, pred_crop_keypoints=full_c, pred_peak_values=full_v, pred_centroids=centroids, pred_centroid_values=cvals,
                       instance_scores=cvals, preprocess_info=h["info"])
         out.instance_bboxes = sel["bboxes"]
@@ -86,6 +105,14 @@ class TopDownLayer:
             idx = torch.stack([slots // I, slots % I], dim=1)
             self._attach_identity_and_crops(out, s2, idx, crops, B, I, n_nodes)
         return out
+
+    def _infer_n_nodes(self) -> int:
+        """Node count of the centered-instance model (its confidence-map head's channels), for the all-NaN outputs of a batch without centroids."""
+        model = getattr(self.centered_instance_layer.backend, "model", None)
+        for head in getattr(model, "heads", None) or []:
+            if type(head).__name__ == "CenteredInstanceConfmapsHead":
+                return int(head.channels)
+        return 1
 
     def _predict_with_host_nms(self, x: torch.Tensor) -> Outputs:
         """The path with centroid NMS (layers/topdown.py:395-438: host logic over the centroids of a frame): centroids -> host -> mask -> crops, as the reference walks it."""
@@ -98,16 +125,23 @@ class TopDownLayer:
         idx = valid.nonzero(as_tuple=False)
         n_valid = int(idx.shape[0])
         ch, cw = self.crop_size
+        info = cout.preprocess_info
         if n_valid == 0:
-            n_nodes = 1
-            return Outputs(pred_keypoints=torch.full((B, I, n_nodes, 2), float("nan")), pred_peak_values=torch.full((B, I, n_nodes), float("nan")),
-                           pred_centroids=centroids.cpu(), pred_centroid_values=cvals.cpu(), instance_scores=cvals.cpu())
-        vc = centroids[idx[:, 0], idx[:, 1]]
+            n_nodes = self._infer_n_nodes()
+            out = Outputs(pred_keypoints=torch.full((B, I, n_nodes, 2), float("nan"), device=dev), pred_peak_values=torch.full((B, I, n_nodes), float("nan"), device=dev),
+                          pred_centroids=centroids, pred_centroid_values=cvals, instance_scores=cvals, preprocess_info=info)
+            out.pred_crop_keypoints = torch.full((B, I, n_nodes, 2), float("nan"), device=dev)
+            out.instance_bboxes = torch.full((B, I, 4, 2), float("nan"), device=dev)
+            return out
+        eff = info.eff_scale.to(dev, torch.float32)
+        per_crop_eff = eff[idx[:, 0]].view(-1, 1, 1)
+        vc = centroids[idx[:, 0], idx[:, 1]] * per_crop_eff.view(-1, 1)  # sized space (layers/topdown.py:147)
         bboxes = make_centered_bboxes(vc, ch, cw)
-        crops = crop_bboxes(x, bboxes, idx[:, 0])
+        crops = crop_bboxes(self._sized_frames(x, info), bboxes, idx[:, 0])
         s2 = self.centered_instance_layer.predict(crops)
         k3 = s2.pred_keypoints.squeeze(1)
-        kimg = add_crop_offset(k3, bboxes[:, 0, :])
+        kimg = add_crop_offset(k3, bboxes[:, 0, :]) / per_crop_eff
+        bboxes = bboxes / per_crop_eff
         n_nodes = kimg.shape[-2]
         full_k = torch.full((B, I, n_nodes, 2), float("nan"), device=dev)
         full_c = torch.full((B, I, n_nodes, 2), float("nan"), device=dev)

@@ -328,10 +328,15 @@ def test_centroid_selection_kernel_topk_padding_and_lists():
     idx = valid.nonzero()
     nvalid = int(idx.shape[0])
     assert int(nv.item()) == nvalid == sum(min(c, I) for c in per)
-    ref_bb = make_centered_bboxes(ref_cp[idx[:, 0], idx[:, 1]], ch, cw)
+    # stage 2 works in SIZED space (reference layers/topdown.py:127-150, 262-267): boxes around centroid * eff_scale, top-left list in sized space (the crops are cut
+    # from the sizematched frame), the stored boxes / eff_scale; eff_scale here is 0.5 / 2 / 1.25 on three of the five frames (the round-5 kernel boxed the
+    # image-space centroid, i.e. cut stage-2 crops at another scale than the reference whenever the sizematcher was active)
+    per_eff = eff[idx[:, 0]].view(-1, 1, 1)
+    ref_bb_sized = make_centered_bboxes(ref_cp[idx[:, 0], idx[:, 1]] * per_eff.view(-1, 1), ch, cw)
+    ref_bb = ref_bb_sized / per_eff
     assert np.array_equal(bb.cpu()[idx[:, 0], idx[:, 1]].numpy(), ref_bb.numpy()) and torch.isnan(bb.cpu()[~valid]).all()
     assert torch.equal(ls.cpu()[:nvalid], idx[:, 0].int()) and torch.equal(lslot.cpu()[:nvalid], (idx[:, 0] * I + idx[:, 1]).int())
-    assert np.array_equal(lt.cpu()[:nvalid].numpy(), ref_bb[:, 0].numpy())
+    assert np.array_equal(lt.cpu()[:nvalid].numpy(), ref_bb_sized[:, 0].numpy())
     ref_pos = torch.full((B * I,), -1, dtype=torch.int32)
     ref_pos[(idx[:, 0] * I + idx[:, 1])] = torch.arange(nvalid, dtype=torch.int32)
     assert torch.equal(pos.cpu(), ref_pos)
@@ -340,11 +345,11 @@ def test_centroid_selection_kernel_topk_padding_and_lists():
     k3, v3 = torch.from_numpy(rng.rand(nvalid, N, 2).astype(np.float32) * 40), torch.from_numpy(rng.rand(nvalid, N).astype(np.float32))
     fk, fc, fv = torch.empty((B * I, N, 2), device=DEV), torch.empty((B * I, N, 2), device=DEV), torch.empty((B * I, N), device=DEV)
     k3d, v3d = d(k3), d(v3)
-    L.check(L.lib().ph_topdown_scatter(P(k3d), P(v3d), P(lt), P(pos), B * I, N, P(fk), P(fc), P(fv), None))
+    L.check(L.lib().ph_topdown_scatter(P(k3d), P(v3d), P(lt), P(pos), B * I, N, P(ed), I, P(fk), P(fc), P(fv), None))
     torch.cuda.synchronize()
     rk, rc, rv = torch.full((B * I, N, 2), float("nan")), torch.full((B * I, N, 2), float("nan")), torch.full((B * I, N), float("nan"))
     flat = idx[:, 0] * I + idx[:, 1]
-    rk[flat], rc[flat], rv[flat] = k3 + ref_bb[:, 0].view(-1, 1, 2), k3, v3
+    rk[flat], rc[flat], rv[flat] = (k3 + ref_bb_sized[:, 0].view(-1, 1, 2)) / per_eff, k3, v3  # add_crop_offset in sized space, then / eff_scale
     for got, want in ((fk, rk), (fc, rc), (fv, rv)):
         assert np.array_equal(got.cpu().numpy(), want.numpy(), equal_nan=True)
 

@@ -25,3 +25,8 @@ torch.cuda.synchronize()
 dt = (time.perf_counter() - t) / n
 fl = 3 * sum(r["flops"] for r in m.op_table(1, S, S)) * B
 print(f"train step B={B} {S}x{S}: {dt*1e3:.1f} ms = {B/dt:.1f} frames/s; ~{fl/dt/1e12:.1f} TFLOP/s (3x fwd conv FLOPs); loss {loss.cpu().numpy()}")
+from sleap_nn_amd import _lib as L
+names = bench.conv_kernel_short_names()
+kv = m.last_kernels()
+tab = m.op_table(B, S, S)
+print("forward kernels of the training plan:", [(r["label"].replace("stack0_", ""), names.get(c, c)) for r, c in zip(tab, kv) if r["kind"] == L.OP_CONV])
