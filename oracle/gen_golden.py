@@ -436,6 +436,84 @@ def topdown_fixture():
     save("topdown.npz", **arrs)
 
 
+def topdown_sized_fixture():
+    """The reference's own TopDownLayer.predict (layers/topdown.py:36-466) on the fixture checkpoints WITH the centroid layer's sizematcher active (frames resized and
+    padded to max_height x max_width: eff_scale != 1): pins the sized-space handling of stage 2 -- boxes around centroid * eff_scale, crops cut from the sizematched
+    frame, keypoints and boxes divided by eff_scale (topdown.py:127-150, 262-267) -- which the stage-by-stage `topdown.npz` (eff_scale = 1) cannot see."""
+    import torch.nn as nn
+
+    from sleap_nn.inference.layers.backends.torch_backend import TorchBackend
+    from sleap_nn.inference.layers.centered_instance import CenteredInstanceLayer
+    from sleap_nn.inference.layers.centroid import CentroidLayer
+    from sleap_nn.inference.layers.configs import PostprocessConfig, PreprocessConfig
+    from sleap_nn.inference.layers.topdown import TopDownLayer
+
+    class Fwd(nn.Module):  # the LightningModule forward preamble (lightning_modules.py:1840-1848): squeeze the n_samples axis, normalize
+        def __init__(self, m):
+            super().__init__()
+            self.m = m
+
+        def forward(self, x):
+            x = torch.squeeze(x, dim=1)
+            if x.dtype == torch.uint8 or x.max() > 1.0:
+                x = x.float() / 255.0
+            return self.m(x.float())
+
+    # torchvision (pyproject.toml:40, torchvision>=0.20.0) is absent from this image and stubbed by the harness; the ONE call the sizematcher makes into it,
+    # transforms.v2.functional.resize on a tensor, is the torch operator interpolate(bilinear, antialias=True) (uint8 natively) -- the statement oracle/cpu_ref.py:1221 and
+    # tests/test_oracle_golden.py:323 already rest on.  Everything else below is the reference's own code.
+    import torch.nn.functional as F
+
+    import sleap_nn.data.resizing as rresizing
+
+    def tv_resize(image, size, **_kw):
+        x = image if image.dim() == 4 else image[None]
+        y = F.interpolate(x if x.dtype == torch.uint8 else x.float(), size=tuple(size), mode="bilinear", align_corners=False, antialias=True)
+        return y if image.dim() == 4 else y[0]
+
+    rresizing.tvf.resize = tv_resize
+    mc, sdc, bbc, hc, cfgc = _load_ckpt_model("centroid", "centroid")
+    mi, sdi, bbi, hi, cfgi = _load_ckpt_model("centered_instance", "centered_instance")
+    gold = rh.load_pickle_tolerant(f"{REF}/tests/inference/parity_golden/topdown.pkl")
+    frames = np.stack([gold[0]["image"][0], gold[1]["image"][0]])
+    H, W = frames.shape[-2:]
+    crop = int(cfgi["data_config"]["preprocessing"]["crop_size"])
+    arrs = {"image": frames}
+    # (the fixture model is not scale-invariant: a mild up-scaling and a mild down-scaling, both height-bound fits with padding on the right)
+    # The reference infers the crop size from its FIRST box in float32 (ops/crops.py:66-67: int(|y_bl - y_tl|) + 1), which comes out one short of crop_size for about half
+    # of all fractional box centres; with return_crops=True such a batch raises in its scatter (topdown.py:300-310).  The candidates are tried in turn and the first up-
+    # and the first down-scaling whose crops have the configured size are kept -- the product always cuts crop_size x crop_size.
+    candidates = {"up": [(H + 64, W + 96), (H + 48, W + 64), (H + 96, W + 128), (H + 32, W + 64), (H + 80, W + 96)], "down": [(H - 32, W), (H - 48, W), (H - 16, W), (H - 64, W - 32)]}
+    cases = {}
+    for tag, (mh, mw) in [(t, c) for t, cs in candidates.items() for c in cs]:
+        if tag in cases:
+            continue
+        cl = CentroidLayer(TorchBackend(Fwd(mc), device="cpu"), hc["confmaps"]["output_stride"], max_instances=6, max_stride=bbc["max_stride"],
+                           preprocess_config=PreprocessConfig(max_height=mh, max_width=mw), postprocess_config=PostprocessConfig(peak_threshold=0.03, max_instances=6))
+        il = CenteredInstanceLayer(TorchBackend(Fwd(mi), device="cpu"), hi["confmaps"]["output_stride"], max_stride=bbi["max_stride"],
+                                   postprocess_config=PostprocessConfig(peak_threshold=0.03))
+        td = TopDownLayer(cl, il, (crop, crop), return_crops=True)
+        try:
+            with torch.inference_mode():
+                out = td.predict(torch.from_numpy(frames))
+        except RuntimeError as e:
+            print(f"topdown_sized[{tag}] max {mh} x {mw}: reference raised ({str(e)[:80]}...) -- next candidate")
+            continue
+        if int((~torch.isnan(out.pred_centroids[..., 0])).sum()) < 2:
+            continue
+        cases[tag] = (mh, mw)
+        eff = out.preprocess_info.eff_scale if getattr(out, "preprocess_info", None) is not None else None
+        arrs[f"{tag}/max_hw"] = np.array([mh, mw])
+        for f in ("pred_keypoints", "pred_crop_keypoints", "pred_peak_values", "pred_centroids", "pred_centroid_values", "instance_bboxes", "crops", "instance_scores"):
+            v = getattr(out, f, None)
+            if v is not None:
+                arrs[f"{tag}/{f}"] = _np(v)
+        n = int((~torch.isnan(out.pred_centroids[..., 0])).sum())
+        print(f"topdown_sized[{tag}]: max {mh} x {mw}, {n} instances, eff_scale {None if eff is None else _np(eff)}")
+    assert set(cases) == {"up", "down"}, cases
+    save("topdown_sized.npz", **arrs)
+
+
 def multiclass_fixture():
     from sleap_nn.inference.ops.identity import classify_peaks_from_maps
 
@@ -806,6 +884,8 @@ if __name__ == "__main__":
         core_fixtures()
     if not only or "topdown" in only:
         topdown_fixture()
+    if not only or "topdown_sized" in only:
+        topdown_sized_fixture()
     if not only or "multiclass" in only:
         multiclass_fixture()
     if not only or "targets" in only:

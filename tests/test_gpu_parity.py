@@ -858,6 +858,42 @@ def test_topdown_layer_reproduces_reference():
     assert np.allclose(out.pred_peak_values.cpu().numpy()[idx[:, 0], idx[:, 1]], z["crop_peak_vals"], atol=CMS_ATOL)
 
 
+@pytest.mark.parametrize("tag", ["up", "down"])
+def test_topdown_layer_with_an_active_sizematcher_reproduces_the_reference_layer(tag):
+    """the reference's TopDownLayer.predict with the centroid layer's sizematcher ACTIVE (eff_scale 1.125 / 0.9167: frames resized and padded to
+    max_height x max_width) -- `topdown_sized.npz` holds what the reference layer itself returns (oracle/gen_golden.py::topdown_sized_fixture).  Stage 2 works in sized space:
+    boxes around centroid * eff_scale, crops cut from the SIZED frame (bit-exact uint8), keypoints = (crop keypoints + sized top-left) / eff_scale, boxes / eff_scale
+    (layers/topdown.py:127-150, 262-267).  The round-5 device path boxed the image-space centroid and cropped the raw frame: another scale than the reference's."""
+    from sleap_nn_amd.architectures.model import Model
+    from sleap_nn_amd.inference.backends import HipBackend
+    from sleap_nn_amd.inference.layers import CenteredInstanceLayer, CentroidLayer, PostprocessConfig, PreprocessConfig, TopDownLayer
+
+    z0, z = G.load("topdown.npz"), G.load("topdown_sized.npz")
+    cfg = G.config(z0)
+    cc, ci = cfg["centroid"], cfg["centered"]
+    mc = Model("unet", cc["backbone"], cc["heads"], "centroid")
+    mc.load_state_dict(_wz(z0, "wc/"))
+    mi = Model("unet", ci["backbone"], ci["heads"], "centered_instance")
+    mi.load_state_dict(_wz(z0, "wi/"))
+    mh, mw = (int(v) for v in z[f"{tag}/max_hw"])
+    cl = CentroidLayer(HipBackend(mc, DEV), cc["heads"]["confmaps"]["output_stride"], max_instances=6, max_stride=cc["backbone"]["max_stride"],
+                       preprocess_config=PreprocessConfig(max_height=mh, max_width=mw), postprocess_config=PostprocessConfig(peak_threshold=0.03, max_instances=6))
+    il = CenteredInstanceLayer(HipBackend(mi, DEV), ci["heads"]["confmaps"]["output_stride"], max_stride=ci["backbone"]["max_stride"], postprocess_config=PostprocessConfig(peak_threshold=0.03))
+    td = TopDownLayer(cl, il, (cfg["crop_size"], cfg["crop_size"]), return_crops=True)
+    img = torch.from_numpy(z["image"])
+    for out in (td.predict(img), td._predict_with_host_nms(img.to(DEV))):  # the device path and the reference-shaped path (centroid NMS off: same result)
+        assert float(out.preprocess_info.eff_scale[0]) != 1.0
+        valid = ~np.isnan(z[f"{tag}/pred_centroids"][..., 0])
+        assert np.array_equal(~np.isnan(out.pred_centroids.cpu().numpy()[..., 0]), valid) and valid.sum() >= 4
+        assert np.allclose(out.pred_centroids.cpu().numpy(), z[f"{tag}/pred_centroids"], atol=2e-3, equal_nan=True)
+        assert np.allclose(out.pred_centroid_values.cpu().numpy(), z[f"{tag}/pred_centroid_values"], atol=CMS_ATOL, equal_nan=True)
+        assert np.allclose(out.instance_bboxes.cpu().numpy(), z[f"{tag}/instance_bboxes"], atol=2e-3, equal_nan=True)
+        assert np.array_equal(out.crops.cpu().numpy()[valid], z[f"{tag}/crops"][valid])  # bit-exact uint8 crops of the sizematched frame
+        assert np.allclose(out.pred_crop_keypoints.cpu().numpy(), z[f"{tag}/pred_crop_keypoints"], atol=1e-3, equal_nan=True)
+        assert np.allclose(out.pred_keypoints.cpu().numpy(), z[f"{tag}/pred_keypoints"], atol=2e-3, equal_nan=True)
+        assert np.allclose(out.pred_peak_values.cpu().numpy(), z[f"{tag}/pred_peak_values"], atol=CMS_ATOL, equal_nan=True)
+
+
 def test_multiclass_bottomup_layer_reproduces_reference_golden():
     from sleap_nn_amd.architectures.model import Model
     from sleap_nn_amd.inference.backends import HipBackend
