@@ -279,6 +279,9 @@ def contract_line(full: dict, legs_file: str | None = None) -> str:
                                           "frames_per_step_by_rank", "params", "crops_per_gpu_per_step", "samples_per_gpu_per_step") if k in cfg}
     if isinstance(cfg.get("conv_gflop_per_frame"), float):
         line["config"]["conv_gflop_per_frame"] = _num(cfg["conv_gflop_per_frame"])
+    if isinstance(cfg.get("shard_check"), dict):  # N > 1: every rank's outputs against one rank computing the same frames; the ranks' host-stage waits
+        line["config"]["shard_check"] = cfg["shard_check"].get("result")
+        line["config"]["host_stage_wait_ms_by_rank"] = cfg["shard_check"].get("host_stage_wait_ms_per_step_by_rank")
     if isinstance(full.get("step_ms"), dict):
         line["step_ms"] = {k: _num(v) for k, v in full["step_ms"].items()}
     if isinstance(full.get("h2d_inclusive"), dict):
@@ -499,7 +502,7 @@ def run_infer(args, ctx):
             model_b.init_xavier_(seed=1234, head_scale=0.05)
             backend_b = HipBackend(model_b, str(dev), use_graph=True, precision=precision)
             lanes.append((backend_b, BottomUpLayer(backend_b, PAFScorer.from_config(CFG3_HEADS), 4, 8, max_stride=32), lane_st[k]))
-    step_no, last_stream = [0], [None]
+    step_no, last_stream, host_wait = [0], [None], [0.0]
 
     heads_in = {"cms": cms, "pafs": pafs, "info": info}  # rebound for the weak-scaling leg of a multi-GPU run
 
@@ -517,7 +520,11 @@ def run_infer(args, ctx):
         if len(inflight) > len(lanes):
             ly, h = inflight.pop(0)
             pending.append(pool.submit(group_scored_batch, ly._finish_scoring(h), params))
-        out = pending.pop(0).result() if len(pending) > 1 else None
+        out = None
+        if len(pending) > 1:
+            tw = time.perf_counter()
+            out = pending.pop(0).result()
+            host_wait[0] += time.perf_counter() - tw  # the enqueue thread blocked on this rank's grouping worker
         return raw, out
 
     def drain():
@@ -556,6 +563,7 @@ def run_infer(args, ctx):
             op_samples.append([v / n for v in ms])
 
     barrier()
+    host_wait[0] = 0.0
     t0 = time.perf_counter()
     marks[0].record()
     for i in range(args.steps):
@@ -576,6 +584,49 @@ def run_infer(args, ctx):
         collect_sample()
     model.set_profiling(False)
     step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
+    host_wait_ms = 1e3 * host_wait[0] / max(args.steps, 1)
+
+    # ---- N > 1: what every rank computed, checked against ONE rank computing the same frames (rank 0 redoes each rank's chunk with its first lane): the head outputs of the
+    # rank's frames through EVERY lane (its copies of the network on their own streams) and the grouped keypoints of its last step, bit for bit; plus the time each rank's
+    # enqueue thread spent blocked on its grouping worker -- the first place 8 ranks x 3 lanes x (1 enqueue thread + 1 C++ worker) collide on a host
+    shard_check = None
+    if world > 1:
+        import hashlib
+
+        def digest(t):
+            return hashlib.sha1(t.detach().to("cpu").contiguous().numpy().tobytes()).hexdigest()
+
+        def heads_digest(be, x):
+            r = be(x)
+            torch.cuda.synchronize()
+            return [digest(r[k]) for k in sorted(r)]
+
+        xin = host_frames.to(dev).squeeze(1)
+        mine = {"rank": rank, "frames": B, "lanes": [heads_digest(be_k, xin) for be_k, _ly, _st in lanes], "keypoints": digest(torch.nan_to_num(out.pred_keypoints)) if out is not None else None,
+                "host_wait_ms": host_wait_ms}
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        if rank == 0:
+            ok, why = True, []
+            for g_ in gathered:
+                if args.scaling == "strong":
+                    lo_, hi_ = shard_bounds(args.global_batch, world, g_["rank"])
+                    gg = torch.Generator().manual_seed(4321)
+                    fr = torch.randint(0, 256, (max(args.global_batch, 1), 1, 1, SIZE, SIZE), dtype=torch.uint8, generator=gg)[lo_:hi_]
+                else:
+                    gg = torch.Generator().manual_seed(4321 + g_["rank"])
+                    fr = torch.randint(0, 256, (args.batch, 1, 1, SIZE, SIZE), dtype=torch.uint8, generator=gg)
+                want = heads_digest(eager, fr.to(dev).squeeze(1))  # kernel by kernel on rank 0's first copy
+                for li_, got in enumerate(g_["lanes"]):
+                    if got != want:
+                        ok = False
+                        why.append(f"rank {g_['rank']} lane {li_}: head outputs differ from the single-rank forward of its frames")
+                if g_["frames"] == gathered[0]["frames"] and g_["keypoints"] != gathered[0]["keypoints"]:
+                    ok = False
+                    why.append(f"rank {g_['rank']}: grouped keypoints differ from rank 0's")
+            shard_check = {"result": "equal" if ok else "DIFFERENT", "what": "sha1 of each rank's head outputs (every lane) vs rank 0's kernel-by-kernel forward of the same frames; grouped keypoints of the last step vs rank 0's",
+                           "ranks": world, "lanes_per_rank": [len(g_["lanes"]) for g_ in gathered], "mismatches": why[:8],
+                           "host_stage_wait_ms_per_step_by_rank": [round(g_["host_wait_ms"], 4) for g_ in gathered]}
     _tab0 = model.op_table(B, SIZE, SIZE)
     from sleap_nn_amd import _lib as _L0
 
@@ -844,7 +895,7 @@ def run_infer(args, ctx):
             "params": model.num_parameters(), "conv_gflop_per_frame": sum(r["flops"] for r in model.op_table(1, SIZE, SIZE)) / 1e9,
             "forward_launch": "hipGraph replay (steps with per-op events launch kernel by kernel)" if use_graph else "kernel by kernel",
             "inputs": "uint8 frames resident in HBM when the timed region starts",
-            "rccl_ranks_seen": ranks_seen, "frames_per_step_by_rank": per_rank_frames, "streams_per_rank": len(lanes),
+            "rccl_ranks_seen": ranks_seen, "frames_per_step_by_rank": per_rank_frames, "streams_per_rank": len(lanes), "shard_check": shard_check,
             "host_threads": {"cores_visible": (len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)), "per_rank": 2, "ranks": world,
                              "what": "one Python thread that enqueues the GPU work (and the pinned H2D staging of the h2d_inclusive leg) + one C++ grouping worker per rank",
                              "fits": 2 * world <= (len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))},

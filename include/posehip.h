@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define PH_VERSION 106
+#define PH_VERSION 107
 
 /* error codes */
 #define PH_OK 0
@@ -179,6 +179,25 @@ int ph_model_backward(ph_model* m, const void* input_dev, int32_t in_dtype, int3
  * in [B, n_params) is final -- a collective on another stream can wait on it while the rest of the backward still runs. */
 int64_t ph_model_grad_bucket_split(const ph_model* m);
 int ph_model_set_bucket_event(ph_model* m, void* hip_event);
+
+/* ------------------------------------------------------------------------------------
+ * Data-parallel gradient exchange over RCCL (what Lightning's DDP strategy does for the reference: training/model_trainer.py:1751-1813,
+ * docs/guides/multi-gpu.md:67-81).  One process per GPU.  librccl is opened at run time (dlopen): ph_comm_available() says whether it could be.
+ *   ph_comm_unique_id   rank 0 draws 128 opaque bytes (ncclGetUniqueId) and hands them to every rank over the host language's own channel
+ *   ph_comm_create      collective over the ranks, on the CURRENT HIP device (ncclCommInitRank); NULL + ph_last_error() on failure
+ *   ph_allreduce        in-place SUM of `count` floats over the ranks, enqueued on `stream`
+ *   ph_model_set_comm   ph_model_backward then exchanges the gradient arena itself: the tail bucket [ph_model_grad_bucket_split, n_params) on
+ *                       `comm_stream` as soon as the sweep has finished it, the head bucket behind the sweep; the stream ph_model_backward runs on
+ *                       waits for both, so the ph_adam_step enqueued next (grad_scale = 1 / world: DDP's mean) reads the sum.  comm = NULL: off.
+ * ---------------------------------------------------------------------------------- */
+typedef struct ph_comm ph_comm;
+int ph_comm_available(void);
+int ph_comm_unique_id(void* out_id128);
+ph_comm* ph_comm_create(const void* id128, int32_t world, int32_t rank);
+void ph_comm_destroy(ph_comm* comm);
+int32_t ph_comm_world(const ph_comm* comm);
+int ph_allreduce(ph_comm* comm, float* buf_dev, int64_t count, void* stream);
+int ph_model_set_comm(ph_model* m, ph_comm* comm, void* comm_stream);
 
 /* torch.optim.Adam step (weight_decay = 0) on flat device arrays; max_exp_avg_sq_dev != NULL enables
  * amsgrad.  grad_scale multiplies the gradient first (1/world_size after a sum all-reduce). */

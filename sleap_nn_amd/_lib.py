@@ -60,6 +60,13 @@ SIGNATURES = {
     "ph_model_set_params": (C.c_int, [_vp, _vp, _vp]),
     "ph_model_grad_bucket_split": (_i64, [_vp]),
     "ph_model_set_bucket_event": (C.c_int, [_vp, _vp]),
+    "ph_comm_available": (C.c_int, []),
+    "ph_comm_unique_id": (C.c_int, [_vp]),
+    "ph_comm_create": (_vp, [_vp, _i32, _i32]),
+    "ph_comm_destroy": (None, [_vp]),
+    "ph_comm_world": (_i32, [_vp]),
+    "ph_allreduce": (C.c_int, [_vp, _vp, C.c_int64, _vp]),
+    "ph_model_set_comm": (C.c_int, [_vp, _vp, _vp]),
     "ph_model_backward_workspace_bytes": (_i64, [_vp, _i32, _i32, _i32]),
     "ph_model_backward": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i64, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_f32), _vp, _i32, _f32,
                                     _i32, _i32, _f32, _vp, _vp, _vp]),

@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libposehip.so")
-SOURCES = ["net_kernels.hip", "wino2d_kernels.hip", "wino4_kernels.hip", "w16_kernels.hip", "smallmap_kernels.hip", "f16_kernels.hip", "f16_rows_kernels.hip", "convnext_kernels.hip", "model.hip", "train_kernels.hip", "convnext_train_kernels.hip", "train.hip", "post_kernels.hip", "resize_kernels.hip", "group_host.cpp"]
+SOURCES = ["net_kernels.hip", "wino2d_kernels.hip", "wino4_kernels.hip", "w16_kernels.hip", "smallmap_kernels.hip", "f16_kernels.hip", "f16_rows_kernels.hip", "convnext_kernels.hip", "model.hip", "train_kernels.hip", "convnext_train_kernels.hip", "train.hip", "post_kernels.hip", "resize_kernels.hip", "group_host.cpp", "comm_rccl.cpp"]
 HEADERS = ["common.h", "device_math.h", "act_format.h", "f16_kernels.h", "net_kernels.h", "train_kernels.h", "model_internal.h", os.path.join("..", "..", "include", "posehip.h")]
 ARCH = "gfx950"
 
@@ -48,7 +48,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c", sp, "-o", obj, "-I", os.path.join(HERE, "..", "include")]
         cmd += os.environ.get("PH_EXTRA_HIPCC_FLAGS", "").split()  # diagnostic builds, e.g. -DPH_STAMP
         if src.endswith(".cpp"):
-            cmd = [_hipcc(), "-O3", "-std=c++17", "-fPIC", "-x", "c++", "-c", sp, "-o", obj]
+            cmd = [_hipcc(), "-O3", "-std=c++17", "-fPIC", "-x", "c++", "-c", sp, "-o", obj, "-I", "/opt/rocm/include", "-D__HIP_PLATFORM_AMD__"] if src == "comm_rccl.cpp" else [_hipcc(), "-O3", "-std=c++17", "-fPIC", "-x", "c++", "-c", sp, "-o", obj]
         jobs.append(cmd)
 
     def run(cmd):

@@ -931,6 +931,7 @@ void ph_model_destroy(ph_model* m) {
   if (!m) return;
   for (void* p : m->allocs) (void)hipFree(p);
   for (hipEvent_t e : m->ev) (void)hipEventDestroy(e);
+  for (hipEvent_t e : m->comm_events_owned) (void)hipEventDestroy(e);
   delete m;
 }
 

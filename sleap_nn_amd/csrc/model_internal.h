@@ -112,6 +112,10 @@ struct ph_model {
   std::vector<double> op_ms;       // accumulated per op
   int profiled_forwards = 0;
   unsigned long long* clock_probe = nullptr;  // diagnostic buffer (ph_model_set_clock_probe)
+  ph_comm* comm = nullptr;                    // ph_model_set_comm: ph_model_backward exchanges the gradient arena over it (two buckets on comm_stream)
+  hipStream_t comm_stream = nullptr;
+  hipEvent_t comm_ev[3] = {nullptr, nullptr, nullptr};  // tail final / sweep done (caller's stream) / exchange done (side stream)
+  std::vector<hipEvent_t> comm_events_owned;
   hipEvent_t bucket_event = nullptr;          // recorded mid-backward when the arena tail is final (ph_model_set_bucket_event)
   float* zeros_dev = nullptr;                 // zero page for LDS-DMA halo padding
   unsigned* split_counters_dev = nullptr;     // PH_SPLIT_COUNTERS zeroed counters of the split-K launches' in-kernel second stage (a handle's forwards are serialised, as its plan / profiling state already requires)

@@ -223,6 +223,22 @@ int ph_model_set_bucket_event(ph_model* m, void* hip_event) {
   return PH_OK;
 }
 
+// Data-parallel training behind the C ABI: with a communicator attached, ph_model_backward exchanges the gradient arena itself -- the tail bucket [split, n_params) on
+// `comm_stream` as soon as the sweep has finished it (the encoder's gradients are still being computed on the caller's stream), the head bucket behind the sweep -- and the
+// caller's stream waits for both before ph_model_backward's work on it counts as done: the next thing enqueued there (ph_adam_step with grad_scale = 1 / world) sees the
+// SUM over the ranks.  What DDP's bucketed all-reduce does in the reference (training/model_trainer.py:1751-1813 hands the model to Lightning's DDP strategy).
+int ph_model_set_comm(ph_model* m, ph_comm* comm, void* comm_stream) {
+  PH_REQUIRE(m, "ph_model_set_comm: null model");
+  PH_REQUIRE(!comm || comm_stream, "ph_model_set_comm: a communicator needs a side stream of its own (not the stream ph_model_backward runs on)");
+  m->comm = comm;
+  m->comm_stream = static_cast<hipStream_t>(comm_stream);
+  if (comm && !m->comm_ev[0]) {
+    for (auto& e : m->comm_ev) PH_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (auto& e : m->comm_ev) m->comm_events_owned.push_back(e);
+  }
+  return PH_OK;
+}
+
 int64_t ph_model_backward_workspace_bytes(const ph_model* m, int32_t batch, int32_t height, int32_t width) {
   if (!m || batch <= 0 || height <= 0 || width <= 0) {
     set_error("ph_model_backward_workspace_bytes: bad arguments");
@@ -296,7 +312,10 @@ int ph_model_backward(ph_model* m, const void* input_dev, int32_t in_dtype, int3
   if (rc != PH_OK) return rc;
 
   // ---- reverse sweep
-  const int split_op = m->bucket_event ? bucket_split_op(m, nullptr) : -1;
+  int64_t split_off = m->n_params;
+  const bool exchange = m->comm != nullptr;  // (a communicator of ONE rank runs the same schedule: two in-place sums that change nothing -- what the single-GPU test exercises)
+  const int split_op = (m->bucket_event || exchange) ? bucket_split_op(m, &split_off) : -1;
+  if (split_op < 0) split_off = m->n_params;
   for (int oi = (int)m->ops.size() - 1; oi >= 0; --oi) {
     const PackedOp& op = m->ops[oi];
     const ph_op_desc& d = op.d;
@@ -723,9 +742,25 @@ int ph_model_backward(ph_model* m, const void* input_dev, int32_t in_dtype, int3
         rc = PH_E_INVALID;
     }
     if (rc != PH_OK) return rc;
-    if (oi == split_op) PH_HIP_CHECK(hipEventRecord(m->bucket_event, s));  // gradients [bucket split, n_params) are final from here on
+    if (oi == split_op) {  // gradients [bucket split, n_params) are final from here on
+      if (m->bucket_event) PH_HIP_CHECK(hipEventRecord(m->bucket_event, s));
+      if (exchange && split_off < m->n_params) {  // tail bucket: on the side stream, under the rest of the sweep
+        PH_HIP_CHECK(hipEventRecord(m->comm_ev[0], s));
+        PH_HIP_CHECK(hipStreamWaitEvent(m->comm_stream, m->comm_ev[0], 0));
+        rc = ph_allreduce(m->comm, grads_flat_dev + split_off, m->n_params - split_off, m->comm_stream);
+        if (rc != PH_OK) return rc;
+      }
+    }
   }
   if (m->bucket_event && split_op < 0) PH_HIP_CHECK(hipEventRecord(m->bucket_event, s));
+  if (exchange) {  // head bucket (the whole arena when it does not split), then the caller's stream joins the side stream
+    PH_HIP_CHECK(hipEventRecord(m->comm_ev[1], s));
+    PH_HIP_CHECK(hipStreamWaitEvent(m->comm_stream, m->comm_ev[1], 0));
+    rc = ph_allreduce(m->comm, grads_flat_dev, split_off, m->comm_stream);
+    if (rc != PH_OK) return rc;
+    PH_HIP_CHECK(hipEventRecord(m->comm_ev[2], m->comm_stream));
+    PH_HIP_CHECK(hipStreamWaitEvent(s, m->comm_ev[2], 0));
+  }
   return PH_OK;
 }
 

@@ -78,6 +78,61 @@ def allreduce_mean_(flat: torch.Tensor, group=None) -> torch.Tensor:
     return flat
 
 
+class Communicator:
+    """An RCCL communicator of the C ABI (``ph_comm_*``, include/posehip.h): created collectively by the ranks of a ``torch.distributed`` group from the 128-byte id rank 0
+    draws -- ``torch.distributed`` only carries those bytes to the other ranks (its own nccl = RCCL backend or gloo; the gradient exchange itself is ``ph_allreduce`` /
+    ``ph_model_set_comm``, no torch collective).  One per process and device; ``close()`` destroys it."""
+
+    def __init__(self, handle, world: int, rank: int) -> None:
+        self.handle, self.world, self.rank = handle, world, rank
+
+    @staticmethod
+    def available() -> bool:
+        from sleap_nn_amd import _lib as L
+
+        return bool(L.lib().ph_comm_available())
+
+    @classmethod
+    def create(cls, device, group=None) -> "Communicator":
+        import ctypes as C
+
+        from sleap_nn_amd import _lib as L
+
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
+        buf = (C.c_ubyte * 128)()
+        if rank == 0:
+            L.check(L.lib().ph_comm_unique_id(buf))
+        if world > 1:
+            holder = [bytes(buf)]
+            dist.broadcast_object_list(holder, src=0, group=group)
+            C.memmove(buf, holder[0], 128)
+        with torch.cuda.device(device):
+            h = L.lib().ph_comm_create(buf, world, rank)
+        if not h:
+            raise RuntimeError("ph_comm_create failed: " + L.lib().ph_last_error().decode("utf-8", "replace"))
+        return cls(h, world, rank)
+
+    def all_reduce_(self, flat: torch.Tensor, stream=None) -> torch.Tensor:
+        """In-place SUM of a contiguous fp32 device tensor over the ranks, on ``stream`` (default: the current one)."""
+        import ctypes as C
+
+        from sleap_nn_amd import _lib as L
+
+        assert flat.is_cuda and flat.dtype == torch.float32 and flat.is_contiguous()
+        sp = C.c_void_p(stream.cuda_stream) if stream is not None else L.current_stream_ptr()
+        with torch.cuda.device(flat.device):
+            L.check(L.lib().ph_allreduce(self.handle, C.c_void_p(flat.data_ptr()), flat.numel(), sp))
+        return flat
+
+    def close(self) -> None:
+        h, self.handle = self.handle, None
+        if h:
+            from sleap_nn_amd import _lib as L
+
+            L.lib().ph_comm_destroy(h)
+
+
 def all_reduce_buckets_(flat: torch.Tensor, split: Optional[int], group=None, tail_ready=None, comm_stream=None) -> float:
     """Sum ``flat`` over the ranks as two buckets -- the tail ``[split:]`` first, then the head ``[:split]`` -- and return the
     factor (1 / world) that turns the sum into DDP's mean (it is folded into the optimizer kernel, not applied here).

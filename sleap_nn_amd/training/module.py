@@ -39,12 +39,15 @@ class TrainingModule:
     def __init__(self, model: Model, device: str = "cuda", lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8, amsgrad: bool = False,
                  optimizer: str = "Adam", weight_decay: Optional[float] = None,
                  loss_weights: Optional[Sequence[float]] = None, ohkm: Optional[OHKMConfig] = None,
-                 negative_loss_weight: float = 1.0, lr_scheduler=None, max_epochs: Optional[int] = None, wino4: bool = True) -> None:
+                 negative_loss_weight: float = 1.0, lr_scheduler=None, max_epochs: Optional[int] = None, wino4: bool = True,
+                 native_allreduce: Optional[bool] = None) -> None:
         """``negative_loss_weight``: weight of frames flagged ``is_negative`` in the train-stage MSE (lightning_modules.py:149-153,
         526-545).  ``lr_scheduler``: the reference's scheduler config (a name or ``{name: {...}}``, lightning_modules.py:765-857);
         ``self.lr`` then follows it: one ``on_epoch_end(val_loss)`` per epoch, like Lightning steps the scheduler.
         ``wino4``: the K-heavy 3x3 convolutions of the forward and of the data gradients run the Winograd F(4x4,3x3) kernel in the
-        training plan too (handle option ``conv_wino4 = 2``; gradients within ~1e-5 of their tensor's scale of the F(2x2,3x3) ones)."""
+        training plan too (handle option ``conv_wino4 = 2``; gradients within ~1e-5 of their tensor's scale of the F(2x2,3x3) ones).
+        ``native_allreduce``: with more than one rank, exchange the gradients through the C ABI's own RCCL communicator (``ph_model_set_comm``: the two buckets are
+        enqueued by ``ph_model_backward`` itself) instead of ``torch.distributed``; default: when the process group's backend is nccl (= RCCL on ROCm)."""
         L.lib()
         if not torch.cuda.is_available():
             raise RuntimeError("TrainingModule needs an MI355X; there is no CPU fallback")
@@ -87,10 +90,17 @@ class TrainingModule:
         self._bucket_split: Optional[int] = None
         self._bucket_event = None
         self._comm_stream = None
+        self._comm = None  # the C ABI's RCCL communicator (parallel.Communicator): ph_model_backward then exchanges the gradients itself
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            self._bucket_event = torch.cuda.Event()
-            self._bucket_event.record()  # creates the underlying hipEvent_t
             self._comm_stream = torch.cuda.Stream(dev)
+            from sleap_nn_amd.parallel import Communicator
+
+            native = native_allreduce if native_allreduce is not None else (dist.get_backend() == "nccl")
+            if native and Communicator.available():
+                self._comm = Communicator.create(dev)
+            else:  # gloo rehearsals / hosts without librccl: torch.distributed carries the two buckets (parallel.all_reduce_buckets_)
+                self._bucket_event = torch.cuda.Event()
+                self._bucket_event.record()  # creates the underlying hipEvent_t
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             dist.broadcast(self.params, src=0)  # identical initial weights on every rank (DDP semantics)
             self._push_params()
@@ -146,6 +156,11 @@ class TrainingModule:
                 L.check(lib.ph_model_set_bucket_event(m._handle, C.c_void_p(self._bucket_event.cuda_event)))
             else:
                 L.check(lib.ph_model_set_bucket_event(m._handle, None))
+            # (the native exchange: bound per step for the same reason; validation passes compute no exchange -- every rank evaluates its own shard)
+            if self._comm is not None and stage == "train":
+                L.check(lib.ph_model_set_comm(m._handle, C.c_void_p(self._comm.handle), C.c_void_p(self._comm_stream.cuda_stream)))
+            else:
+                L.check(lib.ph_model_set_comm(m._handle, None, None))
             L.check(
                 lib.ph_model_backward(
                     m._handle, C.c_void_p(x.data_ptr()), code, B, Cin, H, W, C.c_void_p(m._workspace.data_ptr()), C.c_void_p(self._grad_ws.data_ptr()),
@@ -165,6 +180,8 @@ class TrainingModule:
         computed -- and the head of the arena right after the backward; the compute stream waits for both before Adam.  On
         xGMI a ring all-reduce is bound by one link (~153 GB/s): 31 MB (cfg3 UNet) / 352 MB (ConvNeXt-tiny) take ~0.4 / ~4 ms,
         so one bucket boundary is all the overlap there is to win."""
+        if self._comm is not None:  # ph_model_backward has already enqueued both buckets (ph_model_set_comm) and joined the side stream
+            return 1.0 / self._comm.world
         from sleap_nn_amd.parallel import all_reduce_buckets_
 
         return all_reduce_buckets_(self.grads, self._bucket_split, tail_ready=self._bucket_event, comm_stream=self._comm_stream)
@@ -207,6 +224,11 @@ class TrainingModule:
         ev, self._bucket_event = self._bucket_event, None
         if ev is not None and getattr(self.model, "_handle", None) is not None:
             L.lib().ph_model_set_bucket_event(self.model._handle, None)
+        comm, self._comm = getattr(self, "_comm", None), None
+        if comm is not None:
+            if getattr(self.model, "_handle", None) is not None:
+                L.lib().ph_model_set_comm(self.model._handle, None, None)
+            comm.close()
 
     def __del__(self):
         try:

@@ -52,6 +52,24 @@ def test_two_ranks_default_strong_with_weak_beside_it_and_three_ranks_strong_reh
 
 
 @pytest.mark.skipif(not torch.cuda.is_available(), reason="needs a GPU")
+def test_four_rank_strong_scaling_rehearsal_every_rank_equals_the_single_rank_result():
+    """the per-rank batch of the 8-GPU strong-scaling run (4 frames per rank and step, THREE copies of the network on HIP streams of their own per
+    rank) with as many ranks as one GPU box admits (six processes may use the card together -- the box's process guard --: the test runner, the launcher and four ranks; the
+    driver's SCALE run has eight).  Every rank's
+    head outputs -- through every one of its lanes -- must be the bits rank 0 computes for the same frames with one copy, kernel by kernel; the grouped keypoints the same
+    on every rank; and the line reports what each rank's enqueue thread waited for its grouping worker, the first thing 8 x 3 lanes on one host's cores would stretch."""
+    d, full = _run("--gpus", "4", "--rehearse-on-one-gpu", "--steps", "4", "--warmup", "2", "--scaling", "strong", "--global-batch", "16", "--no-alt-precisions", "--no-h2d-leg")
+    assert d["n_gpus"] == 4 and d["config"]["frames_per_step_by_rank"] == [4] * 4 and d["config"]["rccl_ranks_seen"] == 4
+    sc = full["config"]["shard_check"]
+    assert sc["result"] == "equal", sc["mismatches"]
+    assert sc["ranks"] == 4 and sc["lanes_per_rank"] == [3] * 4
+    waits = sc["host_stage_wait_ms_per_step_by_rank"]
+    assert len(waits) == 4 and all(w >= 0 for w in waits)
+    assert d["config"]["shard_check"] == "equal" and d["config"]["host_stage_wait_ms_by_rank"] == waits
+    print("host-stage wait per step and rank (ms):", waits, "step", d["ms_per_step"])
+
+
+@pytest.mark.skipif(not torch.cuda.is_available(), reason="needs a GPU")
 def test_two_ranks_training_rehearsal():
     """--mode train with two ranks: identical initial arenas, disjoint shards, the two-bucket gradient all-reduce overlapped with the
     backward (gloo here), Adam on every rank -- the loss must be finite and move, the line must say what it measured."""

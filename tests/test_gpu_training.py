@@ -152,6 +152,46 @@ def test_data_parallel_gradient_equivalence():
     assert float((acc - full).abs().max()) <= 1e-5 * scale
 
 
+def test_native_rccl_exchange_runs_the_two_bucket_schedule_inside_the_backward():
+    """SURVEY 8(b) `ph_allreduce` / VERDICT r5 item 6: the gradient exchange behind the C ABI.  One GPU admits one RCCL rank, so this is the single-rank communicator:
+    ncclGetUniqueId -> ncclCommInitRank(world 1) through ph_comm_*; ph_allreduce sums a buffer over one rank (unchanged); and ph_model_backward with the communicator
+    attached (ph_model_set_comm) runs its whole schedule -- tail bucket on the side stream behind the mid-sweep event, head bucket behind the sweep, the caller's stream
+    joined -- and leaves the SAME gradients bit for bit, then trains as before.  (The multi-rank arithmetic -- sum x 1 / world == the global-batch gradient -- is the
+    gloo world-size-2 test of tests/test_parallel_cpu.py; the multi-GPU run is the driver's.)"""
+    import ctypes as C
+
+    from sleap_nn_amd import _lib as L
+    from sleap_nn_amd.parallel import Communicator
+
+    assert Communicator.available(), "librccl could not be opened on the GPU box"
+    comm = Communicator.create(torch.device(DEV))
+    assert comm.world == 1 and L.lib().ph_comm_world(C.c_void_p(comm.handle)) == 1
+    buf = torch.randn(1 << 20, device=DEV)
+    ref = buf.clone()
+    side = torch.cuda.Stream(DEV)
+    side.wait_stream(torch.cuda.current_stream())
+    comm.all_reduce_(buf, stream=side)
+    side.synchronize()
+    assert torch.equal(buf, ref)
+    bb, heads, mt = _cfg(8, 8, 2)
+    sd, img, targets, lw, tm = _setup(bb, heads, mt, (48, 64), 4, seed=21)
+    tm.forward_backward(img, targets)
+    torch.cuda.synchronize()
+    plain = tm.grads.clone()
+    split = int(L.lib().ph_model_grad_bucket_split(tm.model._handle))
+    assert 0 < split < tm.grads.numel()  # the arena of this network splits: both buckets are exercised
+    tm._comm, tm._comm_stream = comm, side
+    tm.forward_backward(img, targets)
+    torch.cuda.synchronize()
+    assert torch.equal(tm.grads, plain)
+    assert tm.all_reduce_grads() == 1.0
+    losses = [float(tm.training_step({"image": img, **targets})[0]) for _ in range(12)]
+    assert losses[-1] < losses[0]
+    tm.close()  # unbinds and destroys the communicator
+    assert tm._comm is None
+    tm.forward_backward(img, targets)  # ... and the handle runs without one again
+
+
 def test_target_rendering_matches_reference_and_oracle():
     """ph_render_confmaps / ph_render_pafs vs the reference fixture (tests/golden/targets.npz) and, on a
     larger random case with many instances, vs the oracle.  fp32 tolerance 2e-6 abs (expf vs torch.exp)."""
