@@ -431,7 +431,7 @@ def conv_kernel_short_names():
     from sleap_nn_amd import _lib as L
 
     return {L.KV_DIRECT: "direct", L.KV_WINO1D: "wino1d", L.KV_WINO2D: "wino2d", L.KV_W16: "w16", L.KV_C16: "c16", L.KV_ROWGEMM: "rowgemm", L.KV_WINO4: "wino4", L.KV_F16: "f16",
-            L.KV_WINO2D_KS: "wino2d", L.KV_SMALLMAP: "smallmap"}  # (the split-K launches of small batches are the same kernel family)
+            L.KV_WINO2D_KS: "wino2d", L.KV_SMALLMAP: "smallmap", L.KV_F16_ROWS: "f16rows", L.KV_F16_BLOCK: "f16block"}  # (the split-K launches of small batches are the same kernel family)
 
 
 def conv_kernel_long_names(precision="exact"):
@@ -441,7 +441,9 @@ def conv_kernel_long_names(precision="exact"):
             "wino1d": "conv3x3_wino_persist_kernel<64|32> (Winograd F(2,3) along x, 2/3 of the direct MFMA work)",
             "direct": "conv3x3_mfma_dma_persist_kernel<64|32> (direct)", "c16": "conv3x3_c16_kernel (direct)", "rowgemm": "gemm_mfma_dma_kernel<2> (9-tap row GEMM, direct)",
             "smallmap": "conv3x3_sm_kernel (Winograd F(2x2,3x3) on 8x8-pixel x 16-channel units: small maps at small per-rank batches, 4/9 of the direct MFMA work)",
-            "f16": f"conv3x3_f16_persist_kernel<64|32, {3 if precision == 'split' else 1}> (direct, fp16 matrix pipe)"}
+            "f16": f"conv3x3_f16_persist_kernel<64|32, {3 if precision == 'split' else 1}> (direct, fp16 matrix pipe)",
+            "f16rows": "conv3x3_f16_rows_kernel (direct, plain fp16 on v_mfma_f32_16x16x32_f16: row tiles, loader waves, weights L2 -> registers, folded bilinear x2)",
+            "f16block": "block2_c32_f16_kernel (the two convs of a 32-channel encoder block in one launch, plain fp16)"}
 
 
 def run_infer(args, ctx):
@@ -844,8 +846,17 @@ def run_infer(args, ctx):
     torch.cuda.synchronize()
     KSHORT = conv_kernel_short_names()
     by_kernel = {}
+    prev_key = None
     for (r, ms), code in zip(conv_rows, [c for row, c in zip(table, kv) if row["kind"] == L.OP_CONV]):
+        if code == L.KV_FUSED and prev_key is not None:  # a conv computed inside the launch of the conv in front of it (block2_c32_f16_kernel): its work belongs to that launch
+            e = by_kernel[prev_key]
+            e["ms"] += ms
+            e["direct_flops"] += r["flops"]
+            e["executed_flops"] += r["flops"]
+            e["bytes"] += r["bytes"]
+            continue
         share = (3.0 if precision == "split" else 1.0) if code == L.KV_F16 else L.KV_MFMA_SHARE[code]
+        prev_key = KSHORT[code]
         e = by_kernel.setdefault(KSHORT[code], {"launches": 0, "ms": 0.0, "direct_flops": 0.0, "executed_flops": 0.0, "bytes": 0.0})
         e["launches"] += 1
         e["ms"] += ms

@@ -41,6 +41,20 @@ struct ConvF16Args {
 
 struct StemArgs;
 int launch_stem_f16(const StemArgs& a, hipStream_t s);  // stem_f16_kernel: the fused first encoder block, both convs on the fp16 matrix pipe (plain fp16 outputs)
+// the two-conv encoder block kernel's arguments (block2_c32_f16_kernel, f16_kernels.hip)
+struct Block2Args {
+  const void* src;      // FMT_F16, 32-channel pixels (the upper 16 channels are not read), B x H x W
+  const float* wa;      // first conv: f16_weight_pack_kernel pieces for bn 32, one chunk: [tap 9][n 2][quad 4][row 16][8 f16]
+  const float* wb;      // second conv: the same layout
+  const float* ba;      // fp32 bias, 32
+  const float* bb;
+  void* dst_full;       // FMT_F16 32 channels, B x H x W, or nullptr
+  void* dst_pool;       // FMT_F16 32 channels, ceil(H/2) x ceil(W/2), or nullptr
+  int B, H, W;
+  int relu_a, relu_b;
+  const float* zeros;
+};
+int launch_block2_c32_f16(const Block2Args& a, hipStream_t s);  // block2_c32_f16_kernel: conv(<= 16 -> 32) + conv(32 -> 32) (+ pool) of an encoder block in one launch
 int prepare_f16_kernels();
 int launch_conv3x3_f16(const ConvF16Args& a, hipStream_t s);
 double f16_conv_cost(const ConvF16Args& a, int n_cu);   // estimated launch body of conv3x3_f16_persist_kernel, shader cycles

@@ -1059,6 +1059,279 @@ int launch_stem_f16(const StemArgs& a, hipStream_t s) {
   return PH_OK;
 }
 
+// ---------------------------------------------------------------------------------------
+// Two 3x3 convolutions of a 32-channel encoder block in ONE launch, plain fp16 (handle option "block_fuse"): conv(<= 16 -> 32) + ReLU -> the fp16 halo tile stays in LDS
+// -> conv(32 -> 32) + ReLU (+ 2x2 max pool).  BASELINE cfg5's second encoder block (384 x 384, 16 frames) is 75 + 83 us as two launches of conv3x3_f16_persist_kernel --
+// 4 x the MFMA time and 2 x the time of their algorithmic bytes: one K chunk per tile leaves nothing to overlap the tile's loads with -- and the 32-channel intermediate
+// (151 MB at cfg5, 537 MB at cfg3's 32 frames) is written and read back in between.  Here it never reaches HBM.
+// Reference: encoder_decoder.py:108-121 (SimpleConvBlock: two Conv2d + ReLU), common.py:69-107 (MaxPool2dWithSamePadding).
+//   Persistent 256-thread workgroups, tile 8 rows x 32 columns (as the fused stem).  Per tile: the 12 x 36-pixel input halo (the 16 real channels: 32 B per pixel) arrives by
+//   LDS-DMA one tile ahead (double-buffered); first conv = 22 M tiles of 16 consecutive halo pixels x two 16-channel N tiles x 9 taps on v_mfma_f32_16x16x16_f16 (weights in
+//   registers), + bias + ReLU, zeros outside the image (the second conv's padding), fp16 -> LDS [pixel][32 channels] at a 96-byte pitch (conflict-free b128 fragment reads);
+//   second conv = wave w's rows 2w, 2w + 1 (four M tiles) x two N tiles x 9 taps on v_mfma_f32_16x16x32_f16, weights from LDS (f16_weight_pack_kernel's pieces ARE the A
+//   operand), + bias + ReLU, the 2x2 max pool in registers, pooled and (if anybody reads it) full-resolution stores.
+// ---------------------------------------------------------------------------------------
+namespace {
+constexpr int B2_IN_PX = S_IH * S_IW;        // 432 input halo pixels, 32 B each (channels 0 .. 15 of the 32-channel fp16 pixel)
+constexpr int B2_IN_BYTES = ((B2_IN_PX * 32 + 1023) / 1024) * 1024;  // 14 KiB (whole 1-KiB DMA pieces)
+constexpr int B2_MID_PX = S_HH * S_HW;       // 340
+constexpr int B2_MID_PITCH = 96;             // bytes per intermediate pixel (64 + 32 pad)
+constexpr int B2_WB_BYTES = 18 * 1024;
+constexpr int B2_LDS = 2 * B2_IN_BYTES + (B2_MID_PX + 2) * B2_MID_PITCH + B2_WB_BYTES;
+}  // namespace
+
+
+__global__ __launch_bounds__(256, 2) void block2_c32_f16_kernel(Block2Args a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const sIn = smem;
+  char* const sMid = smem + 2 * B2_IN_BYTES;
+  char* const sWB = sMid + (B2_MID_PX + 2) * B2_MID_PITCH;
+  constexpr int NMT = (B2_MID_PX + 15) / 16;  // 22
+  constexpr int MT_W = (NMT + 3) / 4;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lg = lane >> 4;
+  const int tiles_x = (a.W + S_TW - 1) / S_TW, tiles_y = (a.H + S_TH - 1) / S_TH, tiles = tiles_x * tiles_y * a.B;
+  const int per_xcd = (tiles + 7) >> 3;
+  const int nvirt = 8 * per_xcd;
+  auto tile_of = [&](int vid, int& b, int& y0, int& x0) {
+    int t = (vid & 7) * per_xcd + (vid >> 3);
+    const bool ok = vid < nvirt && t < tiles;
+    t = ok ? t : 0;
+    const int tx = t % tiles_x;
+    t /= tiles_x;
+    const int ty = t % tiles_y;
+    b = t / tiles_y;
+    x0 = tx * S_TW;
+    y0 = ty * S_TH;
+    return ok;
+  };
+  // input halo by LDS-DMA: piece p (1 KiB) = 32 consecutive halo pixels x 32 B; lane -> (pixel p 32 + lane / 2, 16-byte half lane % 2)
+  auto stage_in = [&](int b, int y0, int x0, int buf) {
+    for (int p = wave; p * 32 < B2_IN_PX; p += 4) {
+      const int pix = p * 32 + (lane >> 1);
+      const int iy = pix / S_IW, ix = pix - iy * S_IW;
+      const int gy = y0 + iy - 2, gx = x0 + ix - 2;
+      const bool in = pix < B2_IN_PX && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+      const char* g = in ? reinterpret_cast<const char*>(a.src) + (((size_t)b * a.H + gy) * a.W + gx) * 64 + (lane & 1) * 16 : reinterpret_cast<const char*>(a.zeros);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)(sIn + buf * B2_IN_BYTES + p * 1024), 16, 0, 0);
+    }
+  };
+  // ---- operands that do not depend on the tile
+  for (int i = tid; i < B2_WB_BYTES / 16; i += 256) reinterpret_cast<f32x4*>(sWB)[i] = reinterpret_cast<const f32x4*>(a.wb)[i];
+  // first conv on v_mfma_f32_16x16x32_f16 (v_mfma_f32_16x16x16_f16 takes the same 16 cycles for half the K): two taps per MFMA -- lanes lg 0, 1 hold tap 2 pp
+  // (input channels 8 (lg & 1) ..), lg 2, 3 tap 2 pp + 1 (zero weights for the missing tenth tap); A[i = li (output channel 16 n + li)][k]
+  f16x8 wa[5][2];
+#pragma unroll
+  for (int pp = 0; pp < 5; ++pp)
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      const int tap = 2 * pp + (lg >> 1);
+      const f16x8 w = *reinterpret_cast<const f16x8*>(reinterpret_cast<const char*>(a.wa) + ((tap < 9 ? tap : 8) * 2 + n) * 1024 + (lg & 1) * 256 + li * 16);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) wa[pp][n][k] = tap < 9 ? w[k] : (_Float16)0.f;
+    }
+  int tapA[5], tapB[9];
+#pragma unroll
+  for (int pp = 0; pp < 5; ++pp) {
+    const int tap = min(2 * pp + (lg >> 1), 8);
+    tapA[pp] = ((tap / 3) * S_IW + (tap % 3)) * 32 + (lg & 1) * 16;
+  }
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) tapB[tap] = ((tap / 3) * S_HW + (tap % 3)) * B2_MID_PITCH + lg * 16;
+  f32x4 ba4[2], bb4[2];
+#pragma unroll
+  for (int n = 0; n < 2; ++n) {
+    ba4[n] = *reinterpret_cast<const f32x4*>(a.ba + 16 * n + 4 * lg);
+    bb4[n] = *reinterpret_cast<const f32x4*>(a.bb + 16 * n + 4 * lg);
+  }
+  int m_base[MT_W], m_yx[MT_W];
+#pragma unroll
+  for (int i = 0; i < MT_W; ++i) {
+    const int p = (wave + 4 * i) * 16 + li;
+    const int pc = p < B2_MID_PX ? p : B2_MID_PX - 1;
+    const int hy = pc / S_HW, hx = pc - hy * S_HW;
+    m_base[i] = (hy * S_IW + hx) * 32;
+    m_yx[i] = (hy << 8) | hx;
+  }
+  const int Hp = (a.H + 1) / 2, Wp = (a.W + 1) / 2;
+  const float lo_a = a.relu_a ? 0.f : -__builtin_inff(), lo_b = a.relu_b ? 0.f : -__builtin_inff();
+  f16x4 zero4;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) zero4[r] = (_Float16)0.f;
+
+  int vid = blockIdx.x;
+  int b, y0, x0;
+  bool ok = tile_of(vid, b, y0, x0);  // (workgroup-uniform)
+  if (ok) stage_in(b, y0, x0, 0);
+  int par = 0;
+  while (ok) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // this tile's input (and, first time round, the weights) landed
+    __builtin_amdgcn_s_barrier();                                // ... everywhere; every wave is out of the previous tile's intermediate
+    asm volatile("" ::: "memory");
+    const int nvid = vid + gridDim.x;
+    int nb, ny0, nx0;
+    const bool nok = tile_of(nvid, nb, ny0, nx0);
+    if (nok) stage_in(nb, ny0, nx0, par ^ 1);  // (the other input buffer: its readers passed the barrier above a tile ago)
+    const char* const In = sIn + par * B2_IN_BYTES;
+    const bool interior = y0 >= 1 && y0 + S_TH + 1 <= a.H && x0 >= 1 && x0 + S_TW + 1 <= a.W;
+
+    // ---- first conv: D[channel 16 n + 4 lg + r][pixel li] of M tile mt = 16 consecutive halo pixels.  The nine fragment reads of M tile i + 1 are issued in front of the
+    // MFMAs of M tile i (left to itself the compiler reads a pair of taps, waits, issues four MFMAs: the LDS latency shows eighteen times per tile and wave)
+    f16x8 xa[2][5];
+    auto read_a = [&](int i, int buf) __attribute__((always_inline)) {
+#pragma unroll
+      for (int pp = 0; pp < 5; ++pp) xa[buf][pp] = *reinterpret_cast<const f16x8*>(In + m_base[i] + tapA[pp]);
+    };
+    // (order per M tile: its 18 MFMAs; the wait for the NEXT tile's fragments -- requested a whole tile ago --; the requests of the tile after next into the registers just
+    // consumed; this tile's epilogue.  hipcc waits lgkmcnt(0) at a fragment's first use, i.e. also for whatever was requested just before: requests must not sit there)
+    read_a(0, 0);
+    if (MT_W > 1) read_a(1, 1);
+#pragma unroll
+    for (int i = 0; i < MT_W; ++i) {
+      const int mt = wave + 4 * i;
+      f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+      for (int pp = 0; pp < 5; ++pp) {
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[pp][0], xa[i & 1][pp], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[pp][1], xa[i & 1][pp], acc[1], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (i + 1 < MT_W) {
+#pragma unroll
+        for (int pp = 0; pp < 5; ++pp) asm volatile("" ::"v"(xa[(i + 1) & 1][pp]));
+      }
+      if (i + 2 < MT_W) read_a(i + 2, i & 1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (mt < NMT) {  // (wave-uniform)
+        const int p = mt * 16 + li;
+        f16x4 o[2];
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[n][r] = (_Float16)fmaxf(acc[n][r] + ba4[n][r], lo_a);  // (lo: 0 with a ReLU, -inf without)
+        if (!interior) {  // (workgroup-uniform: only tiles at the image border test their halo pixels) outside the image = the second conv's zero padding
+          const int gy = y0 + (m_yx[i] >> 8) - 1, gx = x0 + (m_yx[i] & 255) - 1;
+          if (!(gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)) o[0] = o[1] = zero4;
+        }
+        if (p < B2_MID_PX) {
+          *reinterpret_cast<f16x4*>(sMid + p * B2_MID_PITCH + (4 * lg) * 2) = o[0];
+          *reinterpret_cast<f16x4*>(sMid + p * B2_MID_PITCH + (16 + 4 * lg) * 2) = o[1];
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
+    // ---- second conv
+    f32x4 acc[2][2][2];  // [row m][half h][n]
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc[m][h][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // (the six fragments of tap t + 1 -- two weight, four pixel -- are requested in front of the eight MFMAs of tap t)
+    f16x8 wq[2][2], xq[2][4];
+    auto read_b = [&](int tap, int buf) __attribute__((always_inline)) {
+      wq[buf][0] = *reinterpret_cast<const f16x8*>(sWB + (tap * 2 + 0) * 1024 + lane * 16);
+      wq[buf][1] = *reinterpret_cast<const f16x8*>(sWB + (tap * 2 + 1) * 1024 + lane * 16);
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) xq[buf][2 * m + h] = *reinterpret_cast<const f16x8*>(sMid + ((2 * wave + m) * S_HW + h * 16 + li) * B2_MID_PITCH + tapB[tap]);
+    };
+    read_b(0, 0);
+    read_b(1, 1);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          acc[m][h][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wq[tap & 1][0], xq[tap & 1][2 * m + h], acc[m][h][0], 0, 0, 0);
+          acc[m][h][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wq[tap & 1][1], xq[tap & 1][2 * m + h], acc[m][h][1], 0, 0, 0);
+        }
+      __builtin_amdgcn_sched_barrier(0);
+      if (tap + 1 < 9) {
+        asm volatile("" ::"v"(wq[(tap + 1) & 1][0]), "v"(wq[(tap + 1) & 1][1]));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) asm volatile("" ::"v"(xq[(tap + 1) & 1][k]));
+      }
+      if (tap + 2 < 9) read_b(tap + 2, tap & 1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    const bool whole = y0 + S_TH <= a.H && x0 + S_TW <= a.W;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int x = x0 + h * 16 + li;
+#pragma unroll
+      for (int n = 0; n < 2; ++n) {
+        float pooled[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pooled[r] = -__builtin_inff();
+        bool any_out = false;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          const int y = y0 + 2 * wave + m;
+          const bool in = whole || ((y < a.H) && (x < a.W));
+          any_out |= !in;
+          float o[4];
+          f16x4 oh;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            oh[r] = (_Float16)fmaxf(acc[m][h][n][r] + bb4[n][r], lo_b);
+            o[r] = (float)oh[r];
+          }
+          if (a.dst_full && in) *reinterpret_cast<f16x4*>(reinterpret_cast<_Float16*>(a.dst_full) + (((size_t)b * a.H + y) * a.W + x) * 32 + 16 * n + 4 * lg) = oh;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) pooled[r] = in ? fmaxf(pooled[r], o[r]) : pooled[r];
+        }
+        if (a.dst_pool) {  // "same" pooling: a window that reaches past the image includes the zero pad (common.py:93-96)
+          const bool xn_in = whole || (x + ((li & 1) ? -1 : 1) < a.W);  // (the x neighbour of the window, lane li ^ 1)
+          f16x4 ph;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float v = any_out ? fmaxf(pooled[r], 0.f) : pooled[r];
+            const int pi = __builtin_bit_cast(int, v);
+            const float nb_v = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(pi, pi, 0xB1, 0xF, 0xF, false));
+            v = fmaxf(v, xn_in ? nb_v : 0.f);
+            ph[r] = (_Float16)v;
+          }
+          const int py = (y0 >> 1) + wave, px = (x0 >> 1) + h * 8 + (li >> 1);
+          if (!(li & 1) && (whole || (py < Hp && px < Wp && x < a.W)))
+            *reinterpret_cast<f16x4*>(reinterpret_cast<_Float16*>(a.dst_pool) + (((size_t)b * Hp + py) * Wp + px) * 32 + 16 * n + 4 * lg) = ph;
+        }
+      }
+    }
+    par ^= 1;
+    vid = nvid;
+    ok = nok;
+    b = nb, y0 = ny0, x0 = nx0;
+  }
+}
+
+int launch_block2_c32_f16(const Block2Args& a, hipStream_t s) {
+  PH_REQUIRE(a.src && a.wa && a.wb && a.ba && a.bb && (a.dst_full || a.dst_pool) && a.zeros && a.B > 0 && a.H > 0 && a.W > 0, "block2_c32_f16_kernel: bad arguments");
+  int n_cu = 0;
+  {
+    const int rc_cu = device_cu_count(&n_cu);
+    if (rc_cu != PH_OK) return rc_cu;
+  }
+  static bool attr_done = false;
+  if (!attr_done) {
+    PH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(block2_c32_f16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, B2_LDS));
+    attr_done = true;
+  }
+  const int tiles = ((a.W + S_TW - 1) / S_TW) * ((a.H + S_TH - 1) / S_TH) * a.B;
+  const int grid = std::min(8 * ((tiles + 7) / 8), 2 * n_cu);
+  hipLaunchKernelGGL(block2_c32_f16_kernel, dim3(grid), dim3(256), (size_t)B2_LDS, s, a);
+  PH_HIP_CHECK(hipGetLastError());
+  return PH_OK;
+}
+
 int prepare_f16_kernels() {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_f16_persist_kernel<64, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_f16_persist_kernel<32, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

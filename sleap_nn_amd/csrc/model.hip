@@ -1001,6 +1001,7 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
   bool skip_next_gelu = false, skip_next_scale_add = false;
   int pooled_by_conv = -1;  // slot whose 2x2 max pool the producing conv's epilogue already wrote (run-time fusion of an unfused program, see PH_OP_CONV)
   std::vector<char> head_done(m->ops.size(), 0);  // head ops the producing conv's epilogue already computed (see PH_OP_CONV)
+  std::vector<char> conv_done(m->ops.size(), 0);  // conv ops the conv in front of them already computed (two-conv block kernel, see PH_OP_CONV)
   int deferred_up = -1;     // index of a bilinear op left to the conv that follows it (see PH_OP_UPSAMPLE / PH_OP_CONV)
   int fused_ln = -1;        // index of a LayerNorm op the producing depthwise conv already applied (see PH_OP_DWCONV)
   for (const PackedOp& op : m->ops) {
@@ -1054,9 +1055,45 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
       }
       case PH_OP_CONV: {
         const SlotShape& s0 = plan.slots[d.src0];
+        if (conv_done[op_index - 1]) {  // computed by the conv in front of it (block2_c32_f16_kernel, below)
+          kv[op_index - 1] = PH_KV_FUSED;
+          break;
+        }
         if (fmt != FMT_F32) {
           PH_REQUIRE(s0.c == d.cin0 && (d.src1 < 0 || plan.slots[d.src1].c == d.cin1), "conv channel mismatch");
           const SlotShape& so = plan.slots[d.dst];
+          if (fmt == FMT_F16 && m->block_fuse && plan.reuse && d.src1 < 0 && d.ksize == 3 && d.dst2 < 0 && op.bn == 32 && so.cp == 32 && s0.cp == 32 && d.cin0 <= 16 &&
+              op_index < m->ops.size()) {
+            // inference plans, plain fp16: conv(<= 16 -> 32) + ReLU whose only reader is the next op, a conv(32 -> 32) (+ ReLU, + pool): both in ONE launch, the intermediate
+            // tensor stays in LDS (block2_c32_f16_kernel)
+            const PackedOp& nxo = m->ops[op_index];
+            const ph_op_desc& nx = nxo.d;
+            bool fuse = nx.kind == PH_OP_CONV && nx.ksize == 3 && nx.src0 == d.dst && nx.src1 < 0 && nxo.bn == 32 && plan.slots[nx.dst].cp == 32 && nx.cin0 == d.cout && nxo.w_f16_dev[1] &&
+                        op.w_f16_dev[1];
+            for (size_t k = 0; fuse && k < m->ops.size(); ++k)
+              if (k != op_index && (m->ops[k].d.src0 == d.dst || m->ops[k].d.src1 == d.dst)) fuse = false;
+            if (fuse) {
+              Block2Args b2{};
+              b2.src = slot_ptr(d.src0);
+              b2.wa = op.w_f16_dev[1];
+              b2.wb = nxo.w_f16_dev[1];
+              b2.ba = op.b_dev;
+              b2.bb = nxo.b_dev;
+              const bool full_unread = nx.dst2 >= 0 && !plan.unread.empty() && plan.unread[nx.dst];
+              b2.dst_full = full_unread ? nullptr : slot_ptr(nx.dst);
+              b2.dst_pool = nx.dst2 >= 0 ? slot_ptr(nx.dst2) : nullptr;
+              b2.B = batch;
+              b2.H = s0.h;
+              b2.W = s0.w;
+              b2.relu_a = (d.flags & PH_FLAG_RELU) ? 1 : 0;
+              b2.relu_b = (nx.flags & PH_FLAG_RELU) ? 1 : 0;
+              b2.zeros = m->zeros_dev;
+              conv_done[op_index] = 1;
+              kv[op_index - 1] = PH_KV_F16_BLOCK;
+              rc = launch_block2_c32_f16(b2, s);
+              break;
+            }
+          }
           const int cdiv = fmt == FMT_F16 ? 32 : 16;
           ConvF16Args f{};
           f.src0 = slot_ptr(d.src0);
@@ -1694,6 +1731,7 @@ std::vector<OptionRef> option_table(ph_model* m) {
       {"conv_wino4_min_cin", &m->conv_wino4_min_cin, nullptr},  // padded input channels from which a layer takes it
       {"conv_n32_wino2d", &m->conv_n32_wino2d, nullptr},  // Cout-32 / K >= 64 layers on the F(2x2,3x3) kernel with a half-empty N tile (0: the N-tile-32 F(2,3) kernel)
       {"conv_splitk_finish", &m->conv_splitk_finish, nullptr},  // 0: the split-K second stage as a launch of its own (A/B, tests)
+      {"block_fuse", &m->block_fuse, nullptr},          // plain fp16, inference plans: the two convs of a 32-channel encoder block in one launch (block2_c32_f16_kernel)
       {"stem_f16mfma", &m->stem_f16mfma, nullptr},      // plain fp16: the fused first block with BOTH convs on the fp16 matrix pipe (stem_f16_kernel) instead of stem_fused_kernel<CIN, 3>
       {"upsample_f16math", &m->upsample_f16math, nullptr},  // a bilinear x2 folded into conv3x3_f16_rows_kernel blends in packed fp16 arithmetic (1) or in fp32 as upsample2x_fmt_kernel does (0)
       {"conv_f16_rows", &m->conv_f16_rows, nullptr},    // plain-fp16 precision: conv3x3_f16_rows_kernel 0 never, 1 where its plan is estimated faster than conv3x3_f16_persist_kernel, 2 wherever the shape fits

@@ -135,6 +135,7 @@ struct ph_model {
   int conv_wino4 = 1;                         // "conv_wino4": K-heavy N-tile-64 3x3 convs on the F(4x4,3x3) kernel: 1 in inference plans (workspace_reuse), 2 in every plan -- both where wino4_fits estimates it faster than F(2x2,3x3) --, 3 every plan and wherever the shape fits, 0 never
   int conv_wino4_min_cin = 64;                // "conv_wino4_min_cin": padded input channels (both sources) from which a layer takes that kernel
   int conv_n32_wino2d = 1;                    // "conv_n32_wino2d" (1: inference plans, 2: every plan, 0: never): Cout-32 layers with >= 64 input channels (the last decoder level of an output-stride-2 UNet: 96 -> 32) on the F(2x2,3x3) kernel with a half-empty N tile of 64 instead of the N-tile-32 F(2,3) kernel
+  int block_fuse = 1;                         // "block_fuse"
   int stem_f16mfma = 1;                       // "stem_f16mfma"
   int upsample_f16math = 1;                   // "upsample_f16math"
   int conv_f16_rows = 1;                      // "conv_f16_rows" (plain fp16: the row-tile kernel of f16_rows_kernels.hip; 1 where estimated faster, 2 wherever it fits, 0 never)

@@ -9,7 +9,7 @@ from sleap_nn_amd.architectures.model import Model
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 S = int(sys.argv[2]) if len(sys.argv) > 2 else 768
 timing = len(sys.argv) > 3
-modes = (2,) if (len(sys.argv) > 3 and sys.argv[3] in ('only2', 'pmc')) else ((1,) if (len(sys.argv) > 3 and sys.argv[3] == 'only1') else (0, 2, 1))
+modes = (2,) if (len(sys.argv) > 3 and sys.argv[3] in ('only2',)) else (1,) if (len(sys.argv) > 3 and sys.argv[3] == 'pmc') else ((1,) if (len(sys.argv) > 3 and sys.argv[3] == 'only1') else (0, 2, 1))
 if len(sys.argv) > 3 and sys.argv[3] == 'pmc':
     timing = False
 dev = torch.device("cuda", 0)
