@@ -843,6 +843,7 @@ __global__ __launch_bounds__(256, 4) void stem_f16_kernel(StemArgs a) {
   constexpr int IMG_IT = (NIMG + 255) / 256;
   __shared__ _Float16 sImg[NIMG + 8];
   __shared__ __attribute__((aligned(16))) _Float16 sA[2][(NP0 + 4) * 16];
+  __shared__ _Float16 sLut[256];  // uint8 frames: fp16(v / 255), the correctly rounded division done ONCE per value (a v_div sequence per pixel was ~10 % of the tile's vector instructions)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -850,6 +851,7 @@ __global__ __launch_bounds__(256, 4) void stem_f16_kernel(StemArgs a) {
   const int tiles_x = (a.W + S_TW - 1) / S_TW, tiles_y = (a.H + S_TH - 1) / S_TH, tiles = tiles_x * tiles_y * a.B;
   const int per_xcd = (tiles + 7) >> 3;  // every XCD gets a contiguous range of tiles (neighbouring tiles share image lines)
   const int nvirt = 8 * per_xcd;
+  sLut[tid] = (_Float16)((float)tid / 255.0f);  // (published by the first barrier of the tile loop)
 
   // ---- operands that do not depend on the tile: first conv A[i = li (output channel)][k = 16 s + 4 lg + j], k = tap * CIN + c (zero beyond 9 CIN); the lane's tap
   // offsets into the image patch; second conv A of tap pair pp: lanes lg 0, 1 hold tap 2 pp (input channels 8 (lg & 1) ..), lg 2, 3 tap 2 pp + 1
@@ -914,17 +916,17 @@ __global__ __launch_bounds__(256, 4) void stem_f16_kernel(StemArgs a) {
     y0 = ty * S_TH;
     return ok;
   };
-  float img[IMG_IT];
+  float img[IMG_IT];  // float frames: the value; uint8 frames: the byte (as an int's bits)
   auto fetch = [&](int b, int y0, int x0) {
 #pragma unroll
     for (int it = 0; it < IMG_IT; ++it) {
       const int c = e_yx[it] >> 16, iy = (e_yx[it] >> 8) & 255, ix = e_yx[it] & 255;
       const int gy = y0 + iy - 2, gx = x0 + ix - 2;
-      float v = 0.f;
+      float v = 0.f;  // (the bits of integer 0 too)
       if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
         const size_t o = (((size_t)b * CIN + c) * a.H + gy) * a.W + gx;
         if (a.dtype == 0)
-          v = (float)reinterpret_cast<const uint8_t*>(a.src)[o];
+          v = __builtin_bit_cast(float, (int)reinterpret_cast<const uint8_t*>(a.src)[o]);
         else
           v = reinterpret_cast<const float*>(a.src)[o];
       }
@@ -943,9 +945,21 @@ __global__ __launch_bounds__(256, 4) void stem_f16_kernel(StemArgs a) {
   int par = 0;
   while (ok) {
     // ---- image patch -> fp16 in LDS (/ 255 for integer-valued inputs)
+    if (a.dtype == 0) {  // (workgroup-uniform)
+      if (vid != (int)blockIdx.x) {
 #pragma unroll
-    for (int it = 0; it < IMG_IT; ++it)
-      if (tid + 256 * it < NIMG) sImg[tid + 256 * it] = (_Float16)(a.dtype == 1 ? img[it] : img[it] / 255.0f);
+        for (int it = 0; it < IMG_IT; ++it)
+          if (tid + 256 * it < NIMG) sImg[tid + 256 * it] = sLut[__builtin_bit_cast(int, img[it])];
+      } else {  // first tile: the table is not published yet
+#pragma unroll
+        for (int it = 0; it < IMG_IT; ++it)
+          if (tid + 256 * it < NIMG) sImg[tid + 256 * it] = (_Float16)((float)__builtin_bit_cast(int, img[it]) / 255.0f);
+      }
+    } else {
+#pragma unroll
+      for (int it = 0; it < IMG_IT; ++it)
+        if (tid + 256 * it < NIMG) sImg[tid + 256 * it] = (_Float16)(a.dtype == 1 ? img[it] : img[it] / 255.0f);
+    }
     stem_barrier_lds();  // (not __syncthreads(): its vmcnt(0) would wait for the next tile's image loads here)
     const int nvid = vid + gridDim.x;
     int nb, ny0, nx0;
@@ -967,14 +981,13 @@ __global__ __launch_bounds__(256, 4) void stem_f16_kernel(StemArgs a) {
           for (int j = 0; j < 4; ++j) xb[j] = sImg[m_base[i] + koff[s][j]];
           acc = __builtin_amdgcn_mfma_f32_16x16x16f16(wa0[s], xb, acc, 0, 0, 0);
         }
-        bool in = true;
-        if (!interior) {
-          const int gy = y0 + (m_yx[i] >> 8) - 1, gx = x0 + (m_yx[i] & 255) - 1;
-          in = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;  // outside the image = the second conv's zero padding
-        }
         f16x4 o;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = in ? (_Float16)fmaxf(acc[r] + b0[r], 0.f) : (_Float16)0.f;
+        for (int r = 0; r < 4; ++r) o[r] = (_Float16)fmaxf(acc[r] + b0[r], 0.f);
+        if (!interior) {  // (workgroup-uniform: only tiles at the image border test their halo pixels) outside the image = the second conv's zero padding
+          const int gy = y0 + (m_yx[i] >> 8) - 1, gx = x0 + (m_yx[i] & 255) - 1;
+          if (!(gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)) o = zero4;
+        }
         const int p = mt * 16 + li;
         if (p < NP0) *reinterpret_cast<f16x4*>(A + p * 16 + 4 * lg) = o;
       }
