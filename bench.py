@@ -245,6 +245,8 @@ def legs_summary(full: dict) -> dict:
             s[k] = {"value": _num(leg.get("value")), "unit": leg.get("unit"), "ms_per_step": _num(leg.get("ms_per_step")), "mfma_frac": _num(_pick(leg, "roofline", "frac"))}
             if _pick(leg, "two_streams", "value") is not None:
                 s[k]["two_streams"] = _num(_pick(leg, "two_streams", "value"))
+            if k == "infer_cfg5":  # HBM bytes per forward (PMC evidence file named in the legs file)
+                s[k]["traffic"] = _num(_pick(leg, "roofline", "traffic"))
     pw = full.get("published_workload")
     if isinstance(pw, dict):
         s["published_workload"] = {"forward_ms_per_batch4": _num(pw.get("value")), "forward_frames_per_s": _num(pw.get("frames_per_s_forward")),
@@ -424,6 +426,35 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def _peaks_traffic(conv_traffic_json, batch):
+    """HBM bytes per find_local_peaks call (both launches) from the PMC passes of tools/run_profile.sh (FETCH_SIZE x 2 + WRITE_SIZE, per launch): bench.py cannot read
+    PMCs and quotes the newest committed file, which is for the 32-frame step."""
+    if not conv_traffic_json or batch != 32:
+        return None
+    try:
+        ks = json.load(open(conv_traffic_json))["kernels"]
+        tot = 0.0
+        for k, e in ks.items():
+            if "peaks_onepass" in k or "peaks_place" in k:
+                tot += e.get("fetch_bytes_per_launch", 0.0) + e.get("write_bytes_per_launch", 0.0)
+        return tot or None
+    except Exception:
+        return None
+
+
+def _cfg5_traffic():
+    """(HBM bytes of one cfg5 forward, source file) from the newest profiles/*_f16_cfg5_conv_traffic.json (tools/run_profile_f16_cfg5.sh), or (None, None)."""
+    import glob
+
+    c = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_f16_cfg5_conv_traffic.json")))
+    if not c:
+        return None, None
+    try:
+        return float(json.load(open(c[-1]))["forward"]["hbm_bytes"]), os.path.relpath(c[-1], ROOT)
+    except Exception:
+        return None, None
 
 
 def conv_kernel_short_names():
@@ -943,7 +974,7 @@ def run_infer(args, ctx):
         cm_bytes = float(cms.numel() * 4)
         res["roofline_postprocess"] = {"bound": "hbm", "kernel": "peaks_onepass_kernel<1> + peaks_place_kernel (find_local_peaks: threshold over the streamed maps, 3x3 strict NMS + integral refinement of the candidates, ordered placement)",
                                        "achieved": cm_bytes / (peaks_us * 1e-6) / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": cm_bytes / (peaks_us * 1e-6) / 1e9 / 8000.0,
-                                       "algorithmic_bytes": cm_bytes, "us_per_batch": peaks_us, "launches": 2, "traffic": None,
+                                       "algorithmic_bytes": cm_bytes, "us_per_batch": peaks_us, "launches": 2, "traffic": _peaks_traffic(cands[-1] if cands else None, B), "traffic_source": os.path.relpath(cands[-1], ROOT) if cands else None,
                                        "byte_accounting": "algorithmic bytes = the confidence maps read once (B x 13 x 256 x 256 fp32); time = HIP events around 50 back-to-back calls (both launches + the output allocation of the wrapper); "
                                                           "a bare read of the same 109 MB (tools/probes/hbm_read_probe.hip) takes 15.9 us on this GPU = 0.86 of 8 TB/s, launch included"}
     if elapsed_weak is not None:
@@ -1562,10 +1593,11 @@ def infer_cfg5_leg(steps, dev):
             "synchronous_steps": {"value": B * n / total_sync, "unit": "frames/s", "ms_per_step": 1e3 * total_sync / n, "what": "the same step with a host sync behind each (round 4's definition of this leg)"},
             "forward_only": {"ms_per_batch": 1e3 * fwd_s, "frames_per_s": B / fwd_s},
             "max_abs_head_diff_vs_exact_fp32": drift, "head_abs_max": {k: float(v.abs().max()) for k, v in exact.items()},
-            "roofline": {"bound": "mfma", "kernel": "conv3x3_f16_persist_kernel<64|32, 1> (direct 3x3 on v_mfma_f32_32x32x16_f16) over the whole forward", "achieved": direct / fwd_s / 1e12, "peak": MFMA_F16_PEAK_TFLOPS,
+            "roofline": {"bound": "mfma", "kernel": "stem_f16_kernel + block2_c32_f16_kernel + conv3x3_f16_rows_kernel / conv3x3_f16_persist_kernel (direct 3x3 on v_mfma_f32_16x16x32_f16 / 32x32x16_f16; bilinear x2 and both heads folded) over the whole forward", "achieved": direct / fwd_s / 1e12, "peak": MFMA_F16_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": direct / fwd_s / 1e12 / MFMA_F16_PEAK_TFLOPS, "direct_gflop_per_forward": direct / 1e9,
                          "flop_accounting": "direct-convolution FLOPs of the forward (this pipe runs the direct form: executed = direct) / the forward's wall time (hipGraph replay, back to back), against the dense fp16 MFMA peak",
-                         "traffic": None}}
+                         "traffic": _cfg5_traffic()[0], "traffic_source": _cfg5_traffic()[1], "traffic_unit": "HBM bytes per forward (PMC: FETCH_SIZE x 2 + WRITE_SIZE, separate passes)",
+                         "algorithmic_bytes_per_forward": sum(r["bytes"] for r in table)}}
 
 
 def small_batch_legs(args, ctx):

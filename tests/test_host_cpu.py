@@ -839,3 +839,19 @@ def test_hot_conv_kernels_keep_their_registers(tmp_path):
     assert seen == 4
     spills = {m.group(1): int(m.group(2)) for m in re.finditer(r"\.name:\s+(_ZN2ph20conv3x3_wino4_kernel\w+).*?\.vgpr_spill_count:\s+(\d+)", text, re.S)}
     assert len(spills) == 4 and max(spills.values()) <= 40, spills
+
+
+def test_unverified_stream_lanes_warn_once_per_process():
+    """when the overlap of the predictor's lanes cannot be verified (no torch.cuda._sleep, or every candidate stream queued behind a chosen
+    lane) the multi-lane predictor silently loses up to a third of its throughput -- now a RuntimeWarning says so, once."""
+    import warnings
+
+    from sleap_nn_amd.inference import predictor as P
+
+    P._lane_warning_given[0] = False
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        P._warn_unverified_lanes(3, "the probe is unavailable")
+        P._warn_unverified_lanes(2, "again")
+    assert len(w) == 1 and issubclass(w[0].category, RuntimeWarning) and "3 concurrent HIP streams" in str(w[0].message) and "serialise" in str(w[0].message)
+    P._lane_warning_given[0] = False

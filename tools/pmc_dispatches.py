@@ -21,7 +21,10 @@ for f in glob.glob(f"{d}/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         dur[int(r["Dispatch_Id"])] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
 ids = [i for i in sorted(per) if flt in names[i]]
-if last:
+if last < 0:  # the last forward: from its last stem launch on
+    stems = [i for i in sorted(per) if "stem" in names[i]]
+    ids = [i for i in ids if not stems or i >= stems[-1]]
+elif last:
     ids = ids[-last:]
 cols = sorted({c for i in ids for c in per[i]})
 print("dispatch  us       " + " ".join(f"{c[-18:]:>18s}" for c in cols) + "   mfma_busy  clock_GHz  name")
