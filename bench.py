@@ -445,10 +445,10 @@ def _peaks_traffic(conv_traffic_json, batch):
 
 
 def _cfg5_traffic():
-    """(HBM bytes of one cfg5 forward, source file) from the newest profiles/*_f16_cfg5_conv_traffic.json (tools/run_profile_f16_cfg5.sh), or (None, None)."""
+    """(HBM bytes of one cfg5 forward, source file) from the newest profiles/*_f16_cfg5_traffic.json (tools/run_profile_f16_cfg5.sh), or (None, None)."""
     import glob
 
-    c = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_f16_cfg5_conv_traffic.json")))
+    c = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_f16_cfg5_traffic.json")))
     if not c:
         return None, None
     try:

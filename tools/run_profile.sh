@@ -7,7 +7,7 @@ export PYTHONPATH=$GRAFT_REPO_ROOT
 O=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 rm -rf $O; mkdir -p $O
 cd $GRAFT_REPO_ROOT
-python3 bench.py > $O/bench.log 2>&1
+python3 bench.py --legs-file $O/bench_legs.json > $O/bench.log 2>&1
 tail -1 $O/bench.log > $O/bench.json
 rocprofv3 --output-format csv --kernel-trace --stats -d $O/trace -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-alt-precisions --no-h2d-leg --no-extra-legs > $O/trace.log 2>&1
 grep '^{"metric"' $O/trace.log | tail -1 > $O/bench_under_rocprof.json

@@ -15,8 +15,8 @@ for C in "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_
   rocprofv3 --output-format csv --pmc $C --kernel-trace -d $O/pmc_$N -- python3 tools/f16_rows_check.py 16 768 pmc 1 > $O/pmc_$N.log 2>&1
 done
 python3 tools/pmc_dispatches.py $O/pmc_GRBM_GUI_ACTIVE "" -1 > $O/summary/sq_counters.txt 2>&1
-python3 tools/summarize_f16_traffic.py $O 18 > $O/summary/conv_traffic.json 2> $O/summary/conv_traffic.err
+python3 tools/summarize_f16_traffic.py $O 18 > $O/summary/traffic.json 2> $O/summary/traffic.err
 find $O -name "*.db" -delete
 find $O -name "*kernel_trace.csv" -delete
 find $O -name "*counter_collection.csv" -delete
-ls -la $O/summary; head -c 600 $O/summary/conv_traffic.json
+ls -la $O/summary; head -c 600 $O/summary/traffic.json
