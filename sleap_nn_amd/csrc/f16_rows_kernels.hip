@@ -573,7 +573,10 @@ double f16_rows_plan(ConvF16Args& a, int n_cu) {
         const double tile = 3000.0 + px * BN * 2.0 / 10.0 * (a.skip_dst ? 0.3 : 1.0) + (a.dst_pool ? px * BN * 0.5 / 10.0 : 0.0);
         const double pxl = (double)a.B * a.H * a.W;
         const double bytes = pxl * 64.0 * (a.chunks0 + (a.src1_lowres ? 0.25 : 1.0) * a.chunks1) + (a.skip_dst ? 0.0 : pxl * a.coutp * 2.0) + (a.dst_pool ? pxl * a.coutp * 0.5 : 0.0);
-        const double cost = std::max(8000.0 + rounds * ((nch - n_low) * std::max(mfma, load_full) + n_low * std::max(mfma, load_low) + tile), bytes / 2500.0);
+        // (tiles of one or two chunks: the un-overlapped prologue / epilogue of a tile weighs more than the model's tile term says -- measured on cfg5's 192 x 192 layers,
+        // where the round-2 kernel is 2 - 13 % faster: enc2 39 / 68 us against 45 / 71, the last decoder conv 80 against 87)
+        const double short_k = nch <= 2 ? 1.25 : 1.0;
+        const double cost = std::max(8000.0 + short_k * rounds * ((nch - n_low) * std::max(mfma, load_full) + n_low * std::max(mfma, load_low) + tile), bytes / 2500.0);
         if (best < 0 || cost < best) {
           best = cost;
           a.rows_r = R;
