@@ -973,7 +973,7 @@ __global__ __launch_bounds__(256, 4) void stem_f16_kernel(StemArgs a) {
     for (int i = 0; i < MT_W; ++i) {
       const int mt = wave + 4 * i;
       if (mt < NMT) {  // (wave-uniform)
-        f32x4 acc = b0;  // (the bias as the MFMA's C operand)
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < NK; ++s) {
           f16x4 xb;
@@ -983,7 +983,7 @@ __global__ __launch_bounds__(256, 4) void stem_f16_kernel(StemArgs a) {
         }
         f32x4 t;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) t[r] = fmaxf(acc[r], 0.f);
+        for (int r = 0; r < 4; ++r) t[r] = fmaxf(acc[r] + b0[r], 0.f);
         f16x4 o = __builtin_convertvector(t, f16x4);
         if (!interior) {  // (workgroup-uniform: only tiles at the image border test their halo pixels) outside the image = the second conv's zero padding
           const int gy = y0 + (m_yx[i] >> 8) - 1, gx = x0 + (m_yx[i] & 255) - 1;
@@ -1000,7 +1000,7 @@ __global__ __launch_bounds__(256, 4) void stem_f16_kernel(StemArgs a) {
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
-      for (int h = 0; h < 2; ++h) acc[m][h] = bias4;  // (the bias as the MFMA's C operand)
+      for (int h = 0; h < 2; ++h) acc[m][h] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int pp = 0; pp < 5; ++pp)
 #pragma unroll
@@ -1023,7 +1023,7 @@ __global__ __launch_bounds__(256, 4) void stem_f16_kernel(StemArgs a) {
         const bool in = whole || ((y < a.H) && (x < a.W));
         float o[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = fmaxf(acc[m][h][r], 0.f);
+        for (int r = 0; r < 4; ++r) o[r] = fmaxf(acc[m][h][r] + bias4[r], 0.f);
         if (a.dst_full && in) {  // 16 logical channels in the 32-channel fp16 format: the upper 16 are written as zeros (nobody else would)
           const f16x4 oh = __builtin_convertvector(f32x4{o[0], o[1], o[2], o[3]}, f16x4);
           _Float16* d = reinterpret_cast<_Float16*>(a.dst_full) + (((size_t)b * a.H + y) * a.W + x) * 32 + 4 * lg;
@@ -1202,7 +1202,7 @@ __global__ __launch_bounds__(256, 2) void block2_c32_f16_kernel(Block2Args a) {
 #pragma unroll
     for (int i = 0; i < MT_W; ++i) {
       const int mt = wave + 4 * i;
-      f32x4 acc[2] = {ba4[0], ba4[1]};  // (the bias as the MFMA's C operand)
+      f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
       for (int pp = 0; pp < 5; ++pp) {
         acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[pp][0], xa[i & 1][pp], acc[0], 0, 0, 0);
@@ -1222,7 +1222,7 @@ __global__ __launch_bounds__(256, 2) void block2_c32_f16_kernel(Block2Args a) {
         for (int n = 0; n < 2; ++n) {
           f32x4 t;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) t[r] = fmaxf(acc[n][r], lo_a);  // (lo: 0 with a ReLU, -inf without)
+          for (int r = 0; r < 4; ++r) t[r] = fmaxf(acc[n][r] + ba4[n][r], lo_a);  // (lo: 0 with a ReLU, -inf without)
           o[n] = __builtin_convertvector(t, f16x4);
         }
         if (!interior) {  // (workgroup-uniform: only tiles at the image border test their halo pixels) outside the image = the second conv's zero padding
@@ -1240,13 +1240,13 @@ __global__ __launch_bounds__(256, 2) void block2_c32_f16_kernel(Block2Args a) {
     asm volatile("" ::: "memory");
 
     // ---- second conv
-    f32x4 acc[2][2][2];  // [row m][half h][n], from the bias
+    f32x4 acc[2][2][2];  // [row m][half h][n]
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
       for (int h = 0; h < 2; ++h)
 #pragma unroll
-        for (int n = 0; n < 2; ++n) acc[m][h][n] = bb4[n];
+        for (int n = 0; n < 2; ++n) acc[m][h][n] = f32x4{0.f, 0.f, 0.f, 0.f};
     // (the six fragments of tap t + 1 -- two weight, four pixel -- are requested in front of the eight MFMAs of tap t)
     f16x8 wq[2][2], xq[2][4];
     auto read_b = [&](int tap, int buf) __attribute__((always_inline)) {
@@ -1295,7 +1295,7 @@ __global__ __launch_bounds__(256, 2) void block2_c32_f16_kernel(Block2Args a) {
           float o[4];
           f32x4 t;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) t[r] = fmaxf(acc[m][h][n][r], lo_b);
+          for (int r = 0; r < 4; ++r) t[r] = fmaxf(acc[m][h][n][r] + bb4[n][r], lo_b);
           const f16x4 oh = __builtin_convertvector(t, f16x4);
 #pragma unroll
           for (int r = 0; r < 4; ++r) o[r] = (float)oh[r];

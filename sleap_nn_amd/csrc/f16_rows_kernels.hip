@@ -355,16 +355,9 @@ __global__ __launch_bounds__(768) void conv3x3_f16_rows_kernel(ConvF16Args a) {
         for (int kx = 0; kx < 3; ++kx) ak[m][kx] = (r * HP16 + ((c + kx) >> 4)) * 1024 + ((c + kx) & 15) * 16 + lq * 256;
       }
     }
-    // (the accumulators start from the bias: the MFMA's C operand adds it for free -- 8 MT vector adds per tile less in the epilogue)
     f32x4 acc[MT][2];
-    {
-      const f32x4 b0v = *reinterpret_cast<const f32x4*>(a.bias + ntile * BN + sn * 32 + 4 * lq), b1v = *reinterpret_cast<const f32x4*>(a.bias + ntile * BN + sn * 32 + 16 + 4 * lq);
 #pragma unroll
-      for (int m = 0; m < MT; ++m) {
-        acc[m][0] = b0v;
-        acc[m][1] = b1v;
-      }
-    }
+    for (int m = 0; m < MT; ++m) acc[m][0] = acc[m][1] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int ch = 0; ch < nch; ++ch) {
       const int bufb = (g & 1) ? off_b1 : 0;
       const float* const wnxt = ch + 1 < nch ? wcur + WCH : wnext_tile;
@@ -410,6 +403,10 @@ __global__ __launch_bounds__(768) void conv3x3_f16_rows_kernel(ConvF16Args a) {
     const int sb = ((g - 1) & 1) ? BUF : 0;
     char* const stage = smem + sb;
     {
+      // (bias added AFTER the accumulation, in fp32, like every other fp16 conv kernel: the plans that differ only in which kernel runs a layer stay bit-identical)
+      f32x4 bias4[2];
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) bias4[nt] = *reinterpret_cast<const f32x4*>(a.bias + ntile * BN + sn * 32 + nt * 16 + 4 * lq);
       const float lo = a.relu ? 0.f : -__builtin_inff();
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
@@ -418,7 +415,7 @@ __global__ __launch_bounds__(768) void conv3x3_f16_rows_kernel(ConvF16Args a) {
         for (int nt = 0; nt < 2; ++nt) {
           f32x4 t;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) t[r] = fmaxf(acc[m][nt][r], lo);
+          for (int r = 0; r < 4; ++r) t[r] = fmaxf(acc[m][nt][r] + bias4[nt][r], lo);
           const f16x4 h = __builtin_convertvector(t, f16x4);  // (v_cvt_pk_f16_f32: two values per instruction, round to nearest even)
           if (p < npx) *reinterpret_cast<f16x4*>(stage + p * SP + (sn * 32 + nt * 16 + 4 * lq) * 2) = h;
         }

@@ -262,34 +262,40 @@ __global__ __launch_bounds__(256) void peaks_emit_kernel(const float* __restrict
 
 // ---------------------------------------------------------------------------------------
 // K9b: local peaks in ONE pass over the confidence maps + a placement pass over the (few) peaks found.
-//   peaks_onepass_kernel: one block per (sample, group of OP_R rows).  Every map value is loaded exactly once by the lane that owns its column quad and bit c of the
-//     pixel's 64-bit mask is set where it exceeds the threshold; the few candidates then take the strict 3x3 test (peaks.py:26-63,184-259: v > every in-image
-//     neighbour).  Wave prefix sums put the peaks in the reference's (y, x, channel) order into the block's staging area (coordinates refined right there) and the
-//     block's count is stored.
+//   peaks_onepass_kernel: one block per (sample, group of OP_R rows).  Every map value is loaded exactly once by the lane that owns its column quad; the few values
+//     that are above the threshold and beat the neighbours their wave holds take the strict 3x3 test (peaks.py:26-63,184-259: v > every in-image neighbour) and the
+//     integral refinement from one window of loads; the survivors are ranked into the reference's (y, x, channel) order in the block's staging area and the block's
+//     count is stored.
 //   peaks_place_kernel: block i sums the counts of the blocks before it (fixed order: no atomics), copies its staged peaks to their final place and, in the rare case
 //     that a block found more peaks than its staging area holds, recomputes that block's rows straight into the output (the legacy emit logic) -- the result never depends
 //     on the staging capacity.  Block 0 also writes the totals and the per-sample counts / offsets.
 // Two launches, the maps read once (the legacy path: count + scan + emit, two full reads with nine loads per value each).
 // ---------------------------------------------------------------------------------------
 #ifndef PH_PEAKS_EXP
-#define PH_PEAKS_EXP 0  // timing experiments only (results wrong with any bit set): 1 = a block ends behind its loads + threshold test, 2 = no neighbourhood test (every window takes the short way)
+#define PH_PEAKS_EXP 0  // timing experiments only (results wrong with any bit set): 1 = a block ends behind its loads + threshold test + candidate push, 16 = no refinement, 64 = the loads and the threshold test alone (nothing is pushed)
 #endif
-constexpr int OP_R = 8;      // rows per block (4: 34.0 us, 8: 30.9 us per 32 cfg3 frames; 16 does not fit the registers)
+constexpr int OP_R = 8;      // rows per block
+constexpr int OP_HALF = 4;   // rows per streaming item (a wave keeps two items = 8 KiB in flight)
 constexpr int OP_STAGE = 512;  // staged peaks per block (16 B each)
 constexpr int OP_CAND = 2048;  // candidates a block lists (more: its peaks are counted and the placement kernel lists them)
 constexpr int OP_RECOMPUTE = 1 << 30;  // flag on a block's count: nothing is staged, the placement kernel recomputes the block's rows
 
 // NCH: 256-column chunks of a row (W <= 256 NCH).  VEC: rows are 16-byte aligned (W a multiple of 4): one 16-byte load per lane and row.
-// Everything after the read is proportional to the CANDIDATES (in-image values above the threshold: the pixels of a few Gaussian blobs), not to the pixels:
-//   streaming -- wave w of the block takes the channels [w cpw, (w + 1) cpw), cpw = ceil(C / 4): a lane owns four consecutive columns, loads the block's OP_R rows of a
-//     channel (independent 16-byte loads, 8 KiB per wave in flight), compares them with the threshold and pushes the (rare) candidates on an unordered LDS list.  Every map
-//     value is read exactly once and nothing else happens to it: the phase runs at the rate of a plain read (tools/probes/hbm_read_probe.hip: 16 us for cfg3's 109 MB);
+//   streaming -- the block's work items are (channel, upper / lower OP_HALF rows); wave w takes items w, w + 4, ... (13 channels: 7 / 7 / 6 / 6 items) and has the NEXT
+//     item's four 16-byte loads in flight while it tests one.  Every map value is read exactly once.  A window without a value above the threshold -- three in four -- is
+//     done after 16 compares and a ballot; in the others the 3x3 neighbourhood maximum is formed in registers and only the values that beat it go on the (unordered) LDS
+//     list: one or two per Gaussian blob instead of every pixel of it above the threshold;
 //   listing -- one candidate per thread: its eight neighbours (peaks.py:26-63,184-259: v > every in-image neighbour, `v > NaN` false) and its refinement window are requested
 //     together, ONE memory latency for the block's whole list; a surviving peak's place in the reference's (row, column, channel) order is the number of survivors with a
 //     smaller key (a few compares); its thread stages it.
-// (Round 4 formed the 3x3 neighbourhood maximum of every pixel in registers, ~430 vector instructions per lane and channel, read two halo rows per block for it and listed
-// the peaks with per-pixel prefix sums over the block: 30 us.  PH_PEAKS_EXP builds of round 5 say where that went: plain streaming 17 us, +6 us for the windows that hold a
-// blob, +7 us for the listing -- vector instructions of four resident blocks per CU that all reach the same phase at the same time.)
+// Where the time goes (round 6, PH_PEAKS_EXP builds + `tools/peaks_bench.py zeros|sparse`, cfg3's 32 x 13 x 256 x 256 maps, rocprofv3 kernel durations): the loads and
+// the threshold test alone 17.1 us (a bare read of the same bytes: 15.9), + 3.0 us for the windows that hold a blob, + 2.0 us for the listing (5.0 before the register
+// filter: every pixel of a blob above the threshold had its 5x5 window loaded), + 4.8 us for the placement launch.  The + 3.0 is vector-instruction THROUGHPUT, not a
+// tail: with blobs in one frame of eight the kernel takes what it takes on all-zero maps (20.8 vs 20.7 us per call), with blobs in every frame the four blocks of a CU all
+// execute window code on the same four SIMDs.  The placement launch costs 4.8 us whatever it does (1 024 blocks summing 1 024 counts, the same with one memory latency
+// less, or 33 blocks: 4.8 - 5.0 us) and folding it into a last-block-done merge was built and measured: slots of `epoch << 32 | count` that every finishing block
+// publishes and scans (no spin, no shared counter, safe on uninitialised scratch) -- 49 us: a million cache-bypassing 8-byte loads on 8 KiB of slots, and the merging
+// block's chain (publish, scan, acquire, copy) is as long as the launch it replaces.  Kept: two launches.
 template <int NCH, bool VEC>
 __global__ __launch_bounds__(256) void peaks_onepass_kernel(const float* __restrict__ cms, int C, int H, int W, float thr, int refine, int patch, float xy_scale,
                                                             int groups, int* __restrict__ blk_count, float* __restrict__ stg_xy, float* __restrict__ stg_val,
@@ -301,28 +307,34 @@ __global__ __launch_bounds__(256) void peaks_onepass_kernel(const float* __restr
   // Workgroups go round the eight XCDs: block id -> (sample, row group) so that an XCD walks CONSECUTIVE row groups (the candidates' neighbour rows in the next group are
   // then in that XCD's L2).  Everything the block writes is indexed by blk, the logical id.
   const int n_blk = (int)gridDim.x;
+#ifdef PH_PEAKS_NOREMAP
+  const int blk = (int)blockIdx.x;
+#else
   const int blk = (n_blk & 7) == 0 ? ((int)blockIdx.x & 7) * (n_blk >> 3) + ((int)blockIdx.x >> 3) : (int)blockIdx.x;
+#endif
   const int b = blk / groups, y0 = (blk - b * groups) * OP_R;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int rows = min(OP_R, H - y0);
-  const int cpw = (C + 3) >> 2, c_lo = wave * cpw, c_hi = min(C, c_lo + cpw);
   if (threadIdx.x == 0) {
     n_cand = 0;
     n_pass = 0;
   }
   __syncthreads();
+  const int n_items = 2 * C;  // (channel, upper / lower OP_HALF rows)
+  const float* const sample = cms + (size_t)b * C * H * W;
 #pragma unroll
   for (int k = 0; k < NCH; ++k) {
     const int xb = k * 256;
     const int x = xb + 4 * lane;
     if (xb < W) {  // block-uniform
       const int xc = x < W ? x : 0;
-      for (int c = c_lo; c < c_hi; ++c) {
-        const float* plane = cms + ((size_t)b * C + c) * H * W;
-        float q[OP_R][4];  // rows y0 .. y0 + OP_R - 1 of channel c, from clamped addresses (a row / column outside the image repeats the nearest inside one: masked below)
+      // rows y0 + OP_HALF (it & 1) .. + OP_HALF - 1 of channel it >> 1, from clamped addresses (a row / column outside the image repeats the nearest inside one: masked below)
+      auto fetch = [&](int it, float (&q)[OP_HALF][4]) {
+        const float* plane = sample + (size_t)(it >> 1) * H * W;
+        const int r0 = y0 + (it & 1) * OP_HALF;
 #pragma unroll
-        for (int r = 0; r < OP_R; ++r) {
-          const float* rp = plane + (size_t)min(y0 + r, H - 1) * W;
+        for (int r = 0; r < OP_HALF; ++r) {
+          const float* rp = plane + (size_t)min(r0 + r, H - 1) * W;
           if (VEC) {
             const float4 t = *reinterpret_cast<const float4*>(rp + xc);
             q[r][0] = t.x; q[r][1] = t.y; q[r][2] = t.z; q[r][3] = t.w;
@@ -331,36 +343,86 @@ __global__ __launch_bounds__(256) void peaks_onepass_kernel(const float* __restr
             for (int e = 0; e < 4; ++e) q[r][e] = rp[min(x + e, W - 1)];
           }
         }
+      };
+      auto test = [&](int it, const float (&q)[OP_HALF][4]) {
         bool hit = false;
 #pragma unroll
-        for (int r = 0; r < OP_R; ++r)
+        for (int r = 0; r < OP_HALF; ++r)
 #pragma unroll
           for (int e = 0; e < 4; ++e) hit = hit | (q[r][e] > thr);
-        if (!(PH_PEAKS_EXP & 2) && __ballot(hit) != 0ull) {  // (wave-uniform; most windows of a confidence map hold no value above the threshold)
-          // the wave's candidates go on the list with ONE atomic: bit (4 r + e) of a lane's mask, a wave prefix sum of the lanes' counts, then plain stores
+        if (PH_PEAKS_EXP & 64) {  // (timing: the loads stay alive, nothing is pushed)
+          if (__ballot(hit) == 0x123456789ull) blk_count[0] = 1;
+        } else if (__ballot(hit) != 0ull) {  // (wave-uniform; most windows of a confidence map hold no value above the threshold)
+          // A value with a larger-or-equal neighbour among the ones this wave holds cannot be a peak: the 3x3 neighbourhood maximum of the window is formed from
+          // registers (columns x - 1 / x + 4 from the neighbour lanes; what the wave does not hold -- the rows above / below the item's four, the columns beyond the
+          // 256-column chunk -- and what is outside the image counts as -inf, and v_max skips a NaN: the filter only ever keeps too many, the listing below applies the
+          // reference's exact test to whatever it keeps).  ~15 - 60 values per Gaussian blob are above the threshold, one or two survive: the list, the listing's
+          // window loads and its latency shrink by that factor.  ~120 vector instructions, in the windows that hold a blob only, with the next item's loads in flight.
+          // (Four in-lane compares per value and a branch per survivor instead: 23.4 us against 22.0.)
+          const int rb = (it & 1) * OP_HALF, c = it >> 1;
+          const float ninf = -__builtin_inff();
+          const bool has_l = lane > 0, has_r = lane < 63 && x + 4 < W;
+          float fp[4], fc[4], fn[4], hc[4], hn[4];
+          auto hrow = [&](const float (&row)[4], bool in_rows, float (&f)[4], float (&h)[4]) {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (in_rows & (x + e < W)) ? row[e] : ninf;
+            float l = __shfl_up(v[3], 1, 64), rt = __shfl_down(v[0], 1, 64);
+            l = has_l ? l : ninf;
+            rt = has_r ? rt : ninf;
+            h[0] = fmaxf(l, v[1]);
+            h[1] = fmaxf(v[0], v[2]);
+            h[2] = fmaxf(v[1], v[3]);
+            h[3] = fmaxf(v[2], rt);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) f[e] = fmaxf(h[e], v[e]);
+          };
+#pragma unroll
+          for (int e = 0; e < 4; ++e) fp[e] = ninf;
+          hrow(q[0], rb < rows, fc, hc);
           unsigned msk = 0u;
 #pragma unroll
-          for (int r = 0; r < OP_R; ++r)
+          for (int r = 0; r < OP_HALF; ++r) {
+            if (r + 1 < OP_HALF) {
+              hrow(q[r + 1], rb + r + 1 < rows, fn, hn);
+            } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) msk |= ((q[r][e] > thr) & (r < rows) & (x + e < W)) ? (1u << (4 * r + e)) : 0u;
-          const int cnt = __popc(msk);
-          int inc = cnt;
+              for (int e = 0; e < 4; ++e) fn[e] = ninf;
+            }
 #pragma unroll
-          for (int d = 1; d < 64; d <<= 1) {
-            const int t = __shfl_up(inc, d, 64);
-            if (lane >= d) inc += t;
+            for (int e = 0; e < 4; ++e) {
+              const float nb = fmaxf(fmaxf(hc[e], fp[e]), fn[e]);
+              msk |= ((q[r][e] > fmaxf(thr, nb)) & (rb + r < rows) & (x + e < W)) ? (1u << (4 * r + e)) : 0u;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              fp[e] = fc[e];
+              fc[e] = fn[e];
+              hc[e] = hn[e];
+            }
           }
-          const int total = __shfl(inc, 63, 64);
-          int base = 0;
-          if (lane == 0 && total > 0) base = atomicAdd(&n_cand, total);
-          base = __shfl(base, 0, 64);
-          int at = base + inc - cnt;
+          // the list is unordered: a lane with candidates reserves its places with its own LDS atomic (a lane or two per blob)
+          int at = 0;
+          if (msk) at = atomicAdd(&n_cand, __popc(msk));
           while (msk) {
             const int bit = __ffs((int)msk) - 1;
             msk &= msk - 1;
-            if (at < OP_CAND) cand[at] = ((unsigned)(bit >> 2) << 16) | ((unsigned)(x + (bit & 3)) << 6) | (unsigned)c;
+            if (at < OP_CAND) cand[at] = ((unsigned)(rb + (bit >> 2)) << 16) | ((unsigned)(x + (bit & 3)) << 6) | (unsigned)c;
             ++at;
           }
+        }
+      };
+      // wave w takes items w, w + 4, ... (13 channels: 7 / 7 / 6 / 6 -- by whole channels it was 4 / 4 / 4 / 1) and has the NEXT item's loads in flight while it tests one
+      float qa[OP_HALF][4], qb[OP_HALF][4];
+      int it = wave;
+      if (it < n_items) fetch(it, qa);
+      for (; it < n_items; it += 8) {
+        const bool more = it + 4 < n_items;
+        if (more) fetch(it + 4, qb);
+        test(it, qa);
+        if (more) {
+          if (it + 8 < n_items) fetch(it + 8, qa);
+          test(it + 4, qb);
         }
       }
     }
@@ -383,8 +445,9 @@ __global__ __launch_bounds__(256) void peaks_onepass_kernel(const float* __restr
     if (threadIdx.x == 0) blk_count[blk] = n_pass | OP_RECOMPUTE;
     return;
   }
+  // (a short list -- the usual case -- is one wave's work: wave blk & 3 takes it, so that the four blocks of a CU list on four different SIMDs)
 #pragma unroll 1
-  for (int i = threadIdx.x; i < nc; i += 256) {
+  for (int i = (threadIdx.x + 64 * (blk & 3)) & 255; i < nc; i += 256) {
     const unsigned key = cand[i];
     const int x = (key >> 6) & 0x3FF, y = y0 + (int)(key >> 16), c = key & 63;
     const float* plane = cms + ((size_t)b * C + c) * H * W;

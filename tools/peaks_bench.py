@@ -11,6 +11,11 @@ from sleap_nn_amd import _lib as L
 dev = torch.device("cuda", 0)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 cms, _ = bench.rendered_heads(B, dev)
+if "sparse" in sys.argv:  # blobs in one frame of eight only: is the cost of the windows that hold a blob per window or per launch?
+    cms = cms.clone()
+    cms[torch.arange(B, device=dev) % 8 != 0] = 0
+if "zeros" in sys.argv:  # nothing above the threshold: the streaming phase alone
+    cms = torch.zeros_like(cms)
 Bc, Cc, H, W = cms.shape
 cap = 4096
 xy = torch.empty((cap, 2), device=dev); vals = torch.empty((cap,), device=dev)
