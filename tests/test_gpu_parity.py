@@ -267,6 +267,44 @@ def test_one_pass_local_peaks_equal_the_three_pass_kernels_and_the_oracle(shape,
     assert int(small[4][0]) == n_ref and torch.equal(small[1], vals[: small[1].shape[0]])
 
 
+def test_one_pass_local_peaks_on_row_item_lane_and_chunk_boundaries():
+    """The one-pass kernel drops values that lose against a neighbour its WAVE holds before they reach the candidate list (a 3x3 maximum formed in registers: rows of a
+    four-row item, columns of the lane's quad and of the two neighbour lanes); what the wave does not hold must count as unknown, never as smaller.  Smooth blobs -- the
+    shape the filter is made for -- centred ON every such boundary (rows 3|4 of an item, 7|8 of a block, columns 3|4 of a lane, 255|256 of a column chunk, the image
+    border), pairs of EQUAL values facing each other across each of them (no strict maximum: no peak on either side), and a larger value just across a boundary from a
+    would-be peak: the list must equal the oracle's, bit for bit, with and without 16-byte-aligned rows."""
+    from sleap_nn_amd import _lib as L
+
+    for W in (520 - 8, 300, 259):  # two column chunks (aligned), two chunks (W a multiple of 4), one odd width
+        H, Cc = 29, 3
+        yy, xx = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+        cms = torch.zeros((2, Cc, H, W))
+        centres = [(3, 3), (4, 4), (7, 20), (8, 31), (15, 32), (16, 255), (12, 256), (11, 257), (0, 100), (H - 1, 64), (20, 0), (23, W - 1), (24, 128), (19, 127), (3, 200), (4, 231)]
+        for i, (cy, cx) in enumerate(centres):
+            if cx < W:
+                cms[i % 2, i % Cc] += (0.5 + 0.02 * i) * torch.exp(-((yy - cy) ** 2 + (xx - cx) ** 2) / (2 * 1.25**2))
+        ties = [((3, 40), (4, 40)), ((7, 50), (8, 50)), ((10, 63), (10, 64)), ((13, 255), (13, 256)), ((3, 67), (4, 68)), ((7, 71), (8, 72)), ((20, 255), (21, 256)), ((26, 3), (26, 4))]
+        for (y0, x0), (y1, x1) in ties:
+            if max(x0, x1) < W:
+                cms[1, 2, y0, x0] = cms[1, 2, y1, x1] = 0.9
+        for (y0, x0), (y1, x1) in (((11, 80), (12, 80)), ((15, 83), (16, 84)), ((22, 87), (22, 88)), ((18, 255), (18, 256))):  # a larger value right across the boundary
+            if max(x0, x1) < W:
+                cms[0, 1, y0, x0], cms[0, 1, y1, x1] = 0.7, 0.8
+        ref = O.find_local_peaks(cms, 0.2, "integral", 5)
+        n_ref = ref[0].shape[0]
+        assert n_ref > 15
+        dev = cms.to(DEV)
+        full_ints = int(L.lib().ph_local_peaks_scratch_bytes(2, Cc, H, W)) // 4
+        assert full_ints > 2 * 2 * H + 2
+        xy, vals, sb, sc, counts = _raw_local_peaks(dev, 0.2, 1, 5, n_ref + 8, full_ints)
+        assert int(counts[0]) == n_ref
+        assert np.array_equal(sb.numpy(), ref[2].numpy()) and np.array_equal(sc.numpy(), ref[3].numpy()) and np.array_equal(vals.numpy(), ref[1].numpy())
+        assert np.allclose(xy.numpy(), ref[0].numpy(), atol=1e-4, equal_nan=True)
+        three = _raw_local_peaks(dev, 0.2, 1, 5, n_ref + 8, 2 * 2 * H + 2)
+        for a, b_ in zip(three, (xy, vals, sb, sc, counts)):
+            assert torch.equal(a, b_)
+
+
 @pytest.mark.parametrize("name", ["chain5", "tree6", "chain13", "rev4"])
 def test_paf_scoring_and_grouping_match_reference(name):
     from sleap_nn_amd.inference.ops.paf import PAFScorer
