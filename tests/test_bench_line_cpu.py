@@ -71,6 +71,23 @@ def test_contract_line_survives_nan_and_oversized_legs(bench, full):
     assert line["roofline"]["traffic"] is None and line["legs_summary"]["train_cfg4"]["value"] is None and len(line["cpu_baseline"]["sample"]) <= 260
 
 
+def test_a_line_that_outgrows_the_bound_sheds_prose_before_the_per_leg_summary(bench):
+    """Round 6's own record (tests/golden/bench_full_record_r6.json: every leg present, the line 3 999 bytes) with a shard check of eight ranks on top -- the
+    N = 8 shape of the line: it must stay under the bound by dropping explanatory strings, and keep `roofline.sampling`, `roofline.traffic` and the per-leg numbers."""
+    full = json.load(open(os.path.join(ROOT, "tests", "golden", "bench_full_record_r6.json")))
+    base = strict(bench.contract_line(copy.deepcopy(full), "gpurun_out/bench_legs.json"))
+    assert base["roofline"]["sampling"] == "ok" and base["roofline"]["traffic"] > 0 and base["legs_summary"]["peaks_kernel"]["traffic"] > 0
+    assert base["legs_summary"]["infer_cfg5"]["mfma_frac"] > 0.3 and "accounting" in base["roofline"]
+    fat = copy.deepcopy(full)
+    fat["config"]["frames_per_step_by_rank"] = [4] * 8
+    fat["config"]["shard_check"] = {"result": "8 ranks x 3 lanes: head outputs and keypoints equal the single-rank recompute" + "; rank detail" * 20, "host_stage_wait_ms_per_step_by_rank": [0.123456] * 8}
+    text = bench.contract_line(fat, "gpurun_out/bench_legs.json")
+    assert len(text.encode()) <= 4096
+    line = strict(text)
+    assert "accounting" not in line["roofline"] and line["roofline"]["sampling"] == "ok"
+    assert line["legs_summary"]["infer_cfg5"]["mfma_frac"] == base["legs_summary"]["infer_cfg5"]["mfma_frac"] and line["config"]["shard_check"].startswith("8 ranks")
+
+
 def test_contract_line_refuses_to_exceed_the_bound(bench, full):
     bad = copy.deepcopy(full)
     bad["config"]["workload"] = "w" * 5000
