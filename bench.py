@@ -55,43 +55,13 @@ if ROOT not in sys.path:
 import numpy as np
 import torch
 
-CFG3_BB = {"in_channels": 1, "kernel_size": 3, "filters": 16, "filters_rate": 2, "max_stride": 32, "stem_stride": None,
-           "middle_block": True, "up_interpolate": True, "stacks": 1, "convs_per_block": 2, "output_stride": 4}
-NODES = [f"n{i}" for i in range(13)]
-CFG3_HEADS = {"confmaps": {"part_names": NODES, "sigma": 2.5, "output_stride": 4, "loss_weight": 1.0},
-              "pafs": {"edges": [[NODES[i], NODES[i + 1]] for i in range(12)], "sigma": 75.0, "output_stride": 8, "loss_weight": 1.0}}
-SIZE = 1024
-MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32-input MFMA = 64 FLOP/clk/SIMD * 1024 SIMDs * 2.4 GHz
-MFMA_F16_PEAK_TFLOPS = 2516.6  # MI355X_MICROARCH.md: dense fp16/bf16 MFMA (no sparsity)
-
-CFG4_BB = {"in_channels": 1, "model_type": "tiny", "arch": None, "stem_patch_kernel": 4, "stem_patch_stride": 2, "kernel_size": 3, "filters_rate": 2,
-           "convs_per_block": 2, "up_interpolate": True, "output_stride": 2, "max_stride": 32}
-CFG4_HEADS = {"confmaps": {"part_names": NODES, "sigma": 2.5, "output_stride": 2, "loss_weight": 1.0, "anchor_part": None}}
-
-
-def synthetic_instances(batch: int, distinct: int = 8, size: int = SIZE) -> torch.Tensor:
-    """(B, 6, 13, 2) keypoints: per frame 6 animals, centres U(150, S-150), node offsets N(0, 40 px), seed 777+b
-    (BASELINE.md section 3); `distinct` different frames, repeated to fill the batch."""
-    pts = []
-    for b in range(min(batch, distinct)):
-        rng = np.random.RandomState(777 + b)
-        centres = rng.uniform(min(150, size / 4), size - min(150, size / 4), size=(6, 1, 2))
-        pts.append(np.clip(centres + rng.normal(0, 40, size=(6, 13, 2)), 8, size - 9).astype(np.float32))
-    reps = (batch + len(pts) - 1) // len(pts)
-    return torch.from_numpy(np.stack(pts)).repeat(reps, 1, 1, 1)[:batch].contiguous()
-
-
-def rendered_heads(batch: int, device):
-    """Rendered head outputs for the post-process stage, drawn by the product's own target renderers (the
-    reference's generate_multiconfmaps / generate_pafs semantics): confmaps (B,13,256,256) with sigma 2.5 at
-    stride 4, PAFs (B,24,128,128) with sigma 75 at stride 8, 6 instances per frame."""
-    from sleap_nn_amd.data.targets import generate_multiconfmaps, generate_pafs
-
-    pts = synthetic_instances(batch).to(device)
-    edges = [(i, i + 1) for i in range(12)]
-    cms = generate_multiconfmaps(pts, (SIZE, SIZE), sigma=2.5 * 4 / 2 / 4, output_stride=4)  # sigma * stride = 5 px
-    pafs = generate_pafs(pts, (SIZE, SIZE), sigma=75.0, output_stride=8, edge_inds=edges)
-    return cms, pafs
+from benchlegs.common import (CFG3_BB, CFG3_HEADS, CFG4_BB, CFG4_HEADS, MFMA_F16_PEAK_TFLOPS, MFMA_F32_PEAK_TFLOPS, NODES, SIZE, _cfg5_traffic, _forward_profile, _matrix_rows,  # noqa: F401  (re-exported: tests and tools import them from bench)
+                              _pad16, _small_roofline, _time_calls, conv_kernel_long_names, conv_kernel_short_names, forward_executed_flops, percentiles, rendered_heads, synthetic_instances)
+from benchlegs.infer_cfg4 import infer_cfg4_leg
+from benchlegs.infer_cfg5 import infer_cfg5_leg
+from benchlegs.published import PUBLISHED_A40, PUBLISHED_LANES, published_workload_leg  # noqa: F401
+from benchlegs.single_instance import SI_BB, single_instance_leg  # noqa: F401
+from benchlegs.train import train_leg
 
 
 def cpu_baseline(model, layer, cms_dev, pafs_dev, dev, budget_s: float = 24.0):
@@ -190,7 +160,6 @@ def summarize_op_samples(samples, stack_idx, step_ms_median):
             "stack_ms_by_sample": [round(float(r[list(stack_idx)].sum()), 4) for r in a]}
 
 
-
 def _free_port() -> int:
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -204,11 +173,6 @@ def self_launch(n: int) -> int:
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     return subprocess.call(cmd, env=env)
-
-
-def percentiles(ms):
-    a = np.asarray(ms, dtype=np.float64)
-    return {"median": float(np.median(a)), "p10": float(np.percentile(a, 10)), "p90": float(np.percentile(a, 90)), "n": int(a.size)}
 
 
 CONTRACT_LINE_MAX = 4096
@@ -450,39 +414,6 @@ def _peaks_traffic(conv_traffic_json, batch):
         return tot or None
     except Exception:
         return None
-
-
-def _cfg5_traffic():
-    """(HBM bytes of one cfg5 forward, source file) from the newest profiles/*_f16_cfg5_traffic.json (tools/run_profile_f16_cfg5.sh), or (None, None)."""
-    import glob
-
-    c = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_f16_cfg5_traffic.json")))
-    if not c:
-        return None, None
-    try:
-        return float(json.load(open(c[-1]))["forward"]["hbm_bytes"]), os.path.relpath(c[-1], ROOT)
-    except Exception:
-        return None, None
-
-
-def conv_kernel_short_names():
-    """PH_KV_* code of a 3x3 conv launch -> the key its launches are summed under in `roofline.kernels` (tests/test_bench_line_cpu.py: every conv family the library can report has one)."""
-    from sleap_nn_amd import _lib as L
-
-    return {L.KV_DIRECT: "direct", L.KV_WINO1D: "wino1d", L.KV_WINO2D: "wino2d", L.KV_W16: "w16", L.KV_C16: "c16", L.KV_ROWGEMM: "rowgemm", L.KV_WINO4: "wino4", L.KV_F16: "f16",
-            L.KV_WINO2D_KS: "wino2d", L.KV_SMALLMAP: "smallmap", L.KV_F16_ROWS: "f16rows", L.KV_F16_BLOCK: "f16block"}  # (the split-K launches of small batches are the same kernel family)
-
-
-def conv_kernel_long_names(precision="exact"):
-    return {"wino2d": "conv3x3_wino2d_kernel<64> (Winograd F(2x2,3x3), 4/9 of the direct MFMA work)",
-            "wino4": "conv3x3_wino4_kernel (Winograd F(4x4,3x3), 1/4 of the direct MFMA work; the decoder's bilinear x2 folded into its input transform)",
-            "w16": "conv3x3_w16_kernel<1|2> (wave-private Winograd F(2x2,3x3) on the 16x16x4 MFMA, Cout 32, 4/9 of the direct MFMA work)",
-            "wino1d": "conv3x3_wino_persist_kernel<64|32> (Winograd F(2,3) along x, 2/3 of the direct MFMA work)",
-            "direct": "conv3x3_mfma_dma_persist_kernel<64|32> (direct)", "c16": "conv3x3_c16_kernel (direct)", "rowgemm": "gemm_mfma_dma_kernel<2> (9-tap row GEMM, direct)",
-            "smallmap": "conv3x3_sm_kernel (Winograd F(2x2,3x3) on 8x8-pixel x 16-channel units: small maps at small per-rank batches, 4/9 of the direct MFMA work)",
-            "f16": f"conv3x3_f16_persist_kernel<64|32, {3 if precision == 'split' else 1}> (direct, fp16 matrix pipe)",
-            "f16rows": "conv3x3_f16_rows_kernel (direct, plain fp16 on v_mfma_f32_16x16x32_f16: row tiles, loader waves, weights L2 -> registers, folded bilinear x2)",
-            "f16block": "block2_c32_f16_kernel (the two convs of a 32-channel encoder block in one launch, plain fp16)"}
 
 
 def run_infer(args, ctx):
@@ -1007,605 +938,7 @@ def run_infer(args, ctx):
     return res
 
 
-def _pad16(c):
-    return (c + 15) // 16 * 16
-
-
-def _matrix_rows(table):
-    from sleap_nn_amd import _lib as L
-
-    return [r for r in table if r["kind"] in (L.OP_CONV, L.OP_INPUT_CONV, L.OP_LINEAR, L.OP_PATCH_CONV, L.OP_PATCH_STEM)]
-
-
-def forward_executed_flops(table, codes):
-    """FLOPs the matrix cores execute in one forward, priced per launch by the kernel family the library reports it ran
-    (ph_model_last_kernels): direct kernels and row GEMMs the direct count, F(2,3) 2/3, F(2x2,3x3) 4/9, F(4x4,3x3) 1/4.
-    First convs on the VALU (input conv, patch stem) and the fused stem's VALU conv are not matrix work."""
-    from sleap_nn_amd import _lib as L
-
-    ex = 0.0
-    for r, code in zip(table, codes):
-        if r["kind"] == L.OP_STEM:
-            ex += r["mfma_flops"] * L.KV_MFMA_SHARE[L.KV_STEM]
-        elif r["kind"] in (L.OP_CONV, L.OP_LINEAR, L.OP_PATCH_CONV):
-            ex += r["flops"] * L.KV_MFMA_SHARE.get(code, 1.0)
-    return ex
-
-
-def train_leg(cfg, B, global_batch, steps, warmup, ctx, scaling="weak"):
-    """Data-parallel training steps of one configuration: forward (unfused fp32 program) + per-head MSE + backward + two-bucket
-    gradient all-reduce (RCCL, overlapped with the backward; nothing to reduce at N = 1) + Adam + re-pack of the kernel weights.
-    ``cfg`` "cfg3": the bottom-up UNet at 1024x1024; "cfg4": BASELINE cfg4, ConvNeXt-tiny centered-instance on 384x384 crops.
-    Returns the leg's dict on rank 0 (None elsewhere); also used as the headline of ``--mode train``."""
-    rank, world, dev, dist = ctx["rank"], ctx["world"], ctx["dev"], ctx["dist"]
-    from sleap_nn_amd import _lib as L
-    from sleap_nn_amd.architectures.model import Model
-    from sleap_nn_amd.data.targets import generate_multiconfmaps, generate_pafs
-    from sleap_nn_amd.training.module import TrainingModule
-
-    cfg4 = cfg == "cfg4"
-    size = 384 if cfg4 else SIZE
-    model = Model("convnext", CFG4_BB, CFG4_HEADS, "centered_instance") if cfg4 else Model("unet", CFG3_BB, CFG3_HEADS, "bottomup")
-    model.init_xavier_(seed=1234, head_scale=0.05)
-    tm = TrainingModule(model, str(dev), lr=1e-4)
-    g = torch.Generator().manual_seed(4321 + rank)
-    frames = torch.randint(0, 256, (B, 1, size, size), dtype=torch.uint8, generator=g).to(dev)
-    pts = synthetic_instances(B, size=size).to(dev)
-    if cfg4:
-        targets = {"CenteredInstanceConfmapsHead": generate_multiconfmaps(pts[:, :1], (size, size), sigma=2.5 * 2 / 2 / 2, output_stride=2)}
-    else:
-        targets = {"MultiInstanceConfmapsHead": generate_multiconfmaps(pts, (SIZE, SIZE), sigma=2.5 * 4 / 2 / 4, output_stride=4),
-                   "PartAffinityFieldsHead": generate_pafs(pts, (SIZE, SIZE), sigma=75.0, output_stride=8, edge_inds=[(i, i + 1) for i in range(12)])}
-    batch = {"image": frames, **targets}
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    losses = []
-    for _ in range(max(warmup, 2)):
-        losses.append(tm.training_step(batch).clone())
-    codes = model.last_kernels()  # kernels of the training program's forward (the unfused program)
-    barrier()
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
-    t0 = time.perf_counter()
-    marks[0].record()
-    for i in range(steps):
-        losses.append(tm.training_step(batch).clone())
-        marks[i + 1].record()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)]
-    first, last = float(losses[0][0]), float(losses[-1][0])
-    assert np.isfinite(last) and last <= first, f"training loss did not go down: {first} -> {last}"
-    # the gradient exchange alone (both buckets, nothing to overlap with), for scale
-    ar_ms = None
-    if world > 1:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        for _ in range(3):
-            tm.all_reduce_grads()
-        barrier()
-        e0.record()
-        for _ in range(10):
-            tm.all_reduce_grads()
-        e1.record()
-        barrier()
-        ar_ms = e0.elapsed_time(e1) / 10
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
-    arena_mb, split = tm.grads.numel() * 4 / 1e6, tm._bucket_split
-    n_params = model.num_parameters()
-    table = model.op_table(B, size, size)
-    tm.close()
-    del tm, batch, targets, frames
-    if rank != 0:
-        return None, model
-    fwd_flops = sum(r["flops"] for r in _matrix_rows(table))
-    # Executed on the matrix pipe per step.  Forward: per launch by the kernel the library reports (ph_model_last_kernels).  Backward:
-    # the data gradient of a 3x3 conv is the same kernel family on swapped channel counts (one conv per concat source) -- F(2x2,3x3)
-    # (4/9) for N tiles of 64 output channels with >= 32 input channels (conv3x3_wino2d_kernel) and for one-source layers with 16 / 32
-    # channels on both sides (conv3x3_w16_kernel), F(4x4,3x3) (1/4) from 128 input channels on, F(2,3) along x (2/3) otherwise -- and every 3x3 weight gradient runs in the
-    # F(2x2,3x3) domain (4/9: wgrad_wino_kernel, wgrad16_wino_kernel); row GEMMs (Linear, 2x2/s2 convs) run direct in all three.
-    def share(cin_p, cout_p, one_source=True, hw=(0, 0)):
-        h, w = hw
-        if cout_p >= 64 and cin_p >= 128 and h > 0 and h % 4 == 0 and w % 4 == 0:
-            # conv3x3_wino4_kernel (TrainingModule runs it in the training plan: conv_wino4 = 2) where wino4_fits estimates it faster: rounds of the chip x time per tile
-            ntc, n_cu = -(-cout_p // 64), 256
-            t4, t2 = -(-h // 16) * -(-w // 32) * B * ntc, -(-h // 16) * -(-w // 16) * B * ntc
-            if -(-t4 // n_cu) * (2.0 / 1.3) <= -(-t2 // n_cu):
-                return 0.25
-        if cout_p >= 64 and cin_p >= 32:
-            return 4.0 / 9.0
-        if one_source and cout_p in (16, 32) and cin_p in (16, 32):
-            return 4.0 / 9.0
-        return 2.0 / 3.0
-    executed = forward_executed_flops(table, codes)
-    for r in table:
-        if r["kind"] in (L.OP_LINEAR, L.OP_PATCH_CONV):
-            executed += 2.0 * r["flops"]
-        elif r["kind"] == L.OP_CONV and r.get("ksize", 3) == 3:
-            cin = r["cin0"] + r["cin1"]
-            for part in (r["cin0"], r["cin1"]):  # data gradient: one conv per concat source, Cout -> part channels
-                if part > 0:
-                    executed += r["flops"] * part / cin * share(_pad16(r["cout"]), _pad16(part), True, r.get("out_hw", (0, 0)))
-            executed += r["flops"] * 4.0 / 9.0  # weight gradient
-        elif r["kind"] in (L.OP_INPUT_CONV, L.OP_PATCH_STEM):
-            executed += r["flops"]  # weight gradient only (no data gradient into the image)
-    per_step = elapsed / steps
-    res = {
-        "metric": "frames/sec training step (forward + MSE + backward + gradient all-reduce + Adam)",
-        "value": global_batch * steps / elapsed, "unit": "frames/s", "n_gpus": world, "steps": steps, "warmup": warmup,
-        "ms_per_step": 1e3 * per_step, "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": ("cfg4: ConvNeXt-tiny centered-instance, 384x384 crops, 13 nodes, output stride 2, global batch 64" if cfg4 else
-                                "cfg3 network in training: bottom-up UNet f16/r2/max_stride32/output_stride4, 1024x1024x1 frames, 13 nodes / 12 edges"),
-                   "samples_per_gpu_per_step": B, "global_batch": global_batch, "parallelism": f"dp{world}: replicas, disjoint shards, two-bucket RCCL all-reduce overlapped with the backward",
-                   "params": n_params, "optimizer": "Adam lr 1e-4", "targets": "rendered on the device by ph_render_confmaps / ph_render_pafs"},
-        "step_ms": percentiles(step_ms),
-        "loss_first_last": [first, last],
-        "allreduce": {"arena_mb": arena_mb, "bucket_split": split, "standalone_ms": ar_ms,
-                      "note": "standalone_ms = both buckets back to back with nothing to overlap (null at N = 1); in a step the tail bucket runs under the encoder's backward"},
-        "roofline": {"bound": "mfma", "kernel": "forward + data-gradient convolutions and 3x3 weight gradients (Winograd F(2x2,3x3) / F(2,3) kernels) and row GEMMs, on v_mfma_f32_32x32x2_f32 / 16x16x4_f32",
-                     "achieved": executed / per_step / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": executed / per_step / 1e12 / MFMA_F32_PEAK_TFLOPS,
-                     "flop_accounting": "whole step time in the denominator (loss, masks, pools, LayerNorm / GELU / depthwise, Adam, re-pack included); executed FLOPs = forward launches priced by the kernel family the library reports (ph_model_last_kernels) + data gradients of the same families + 3x3 weight gradients at 4/9 (Winograd domain) + row-GEMM gradients direct; direct_equivalent_tflops = 3 x forward matrix FLOPs / step time, a throughput figure, not a roofline fraction",
-                     "executed_gflop_per_step": executed / 1e9,
-                     "direct_equivalent_tflops": 3.0 * fwd_flops / per_step / 1e12,
-                     "forward_matrix_gflop_per_step": fwd_flops / 1e9},
-    }
-    return res, model
-
-
-def infer_cfg4_leg(model, B, steps, warmup, dev):
-    """Inference forward of the cfg4 network (ConvNeXt-tiny centered-instance, 384x384 crops, output stride 2) on B crops: the
-    fused inference program (LayerNorms inside the depthwise / stem kernels), kernel by kernel (one event per timed step; per-op HIP events in a separate untimed pass)."""
-    from sleap_nn_amd import _lib as L
-
-    size = 384
-    model.bind_live_params(None)
-    model.eval().to(dev)
-    g = torch.Generator().manual_seed(4321)
-    crops = torch.randint(0, 256, (B, 1, size, size), dtype=torch.uint8, generator=g).to(dev)
-    for _ in range(max(warmup, 2)):
-        out = model(crops)
-    codes = model.last_kernels()
-    torch.cuda.synchronize()
-    assert all(torch.isfinite(v).all() for v in out.values())
-    # timed steps: kernel by kernel, one event per step; the per-op events (two per op, ~100 ops) ride in a second, untimed pass
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
-    t0 = time.perf_counter()
-    marks[0].record()
-    for i in range(steps):
-        model(crops)
-        marks[i + 1].record()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    model.set_profiling(True)
-    for _ in range(max(steps // 2, 3)):
-        model(crops)
-    torch.cuda.synchronize()
-    op_ms, n_fw = model.read_profile()
-    model.set_profiling(False)
-    step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)]
-    table = model.op_table(B, size, size)
-    mm = _matrix_rows(table)
-    fwd_flops = sum(r["flops"] for r in mm)
-    executed = forward_executed_flops(table, codes)
-    per_step = elapsed / steps
-    groups = {}
-    NAMES = {L.OP_CONV: "conv3x3", L.OP_LINEAR: "linear (CNBlock MLP)", L.OP_PATCH_CONV: "conv2x2/s2", L.OP_PATCH_STEM: "patch stem (+LayerNorm2d)", L.OP_DWCONV: "depthwise 7x7 (+LayerNorm)",
-             L.OP_LAYERNORM: "layernorm", L.OP_UPSAMPLE: "bilinear x2", L.OP_POOL: "pool", L.OP_HEAD: "head"}
-    for r, ms, code in zip(table, op_ms, codes):
-        e = groups.setdefault(NAMES.get(r["kind"], str(r["kind"])), {"launches": 0, "ms": 0.0, "direct_gflop": 0.0, "executed_gflop": 0.0})
-        e["launches"] += 1 if ms > 0 else 0
-        e["ms"] += ms / max(n_fw, 1)
-        if r["kind"] in (L.OP_CONV, L.OP_LINEAR, L.OP_PATCH_CONV):
-            e["direct_gflop"] += r["flops"] / 1e9
-            e["executed_gflop"] += r["flops"] * L.KV_MFMA_SHARE.get(code, 1.0) / 1e9
-    for e in groups.values():
-        e["executed_tflops"] = e["executed_gflop"] / e["ms"] if e["ms"] > 0 else 0.0
-    matrix_ms = sum(e["ms"] for e in groups.values() if e["executed_gflop"] > 0)
-    return {
-        "metric": "crops/sec ConvNeXt-tiny centered-instance inference forward", "value": B * steps / elapsed, "unit": "crops/s", "steps": steps, "ms_per_step": 1e3 * per_step,
-        "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "cfg4 network at inference: ConvNeXt-tiny centered-instance, 384x384x1 uint8 crops, 13 nodes, output stride 2", "crops_per_step": B,
-                   "params": model.num_parameters(), "forward_launch": "kernel by kernel; per-op HIP events in a separate untimed pass"},
-        "step_ms": percentiles(step_ms),
-        "roofline": {"bound": "mfma", "kernel": "row GEMMs (CNBlock MLPs, 2x2/s2 convs: gemm_mfma_dma_kernel) + decoder / middle 3x3 convs (F(2x2,3x3) and 9-tap row-GEMM forms), v_mfma_f32_32x32x2_f32",
-                     "achieved": executed / (matrix_ms * 1e-3) / 1e12 if matrix_ms > 0 else 0.0, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": executed / (matrix_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS if matrix_ms > 0 else 0.0,
-                     "flop_accounting": "achieved = FLOPs the MFMA pipe executes in the matrix launches (3x3 convs priced by the kernel family the library reports, row GEMMs direct) / their summed duration (per-op HIP events of the untimed profiling pass); whole_forward_frac divides by the whole forward (depthwise, LayerNorm, bilinear, head included)",
-                     "whole_forward_frac": executed / per_step / 1e12 / MFMA_F32_PEAK_TFLOPS,
-                     "direct_equivalent_tflops": fwd_flops / per_step / 1e12, "executed_gflop_per_forward": executed / 1e9, "direct_gflop_per_forward": fwd_flops / 1e9,
-                     "matrix_ms_per_forward": matrix_ms, "forward_ms": sum(op_ms) / max(n_fw, 1), "by_op_kind": groups},
-    }
-
-
-SI_BB = {"in_channels": 1, "kernel_size": 3, "filters": 16, "filters_rate": 2, "max_stride": 16, "stem_stride": None, "middle_block": True, "up_interpolate": True,
-         "stacks": 1, "convs_per_block": 2, "output_stride": 2}
-# docs/guides/inference-performance.md:40-48,70-77 (BASELINE.md section 1): the only numbers the reference publishes, NVIDIA A40 / CUDA 12.8 / torch 2.9.1
-PUBLISHED_A40 = {"bottomup_forward_ms_per_batch4": {"eager_fp32": 3.59, "torch_compile": 2.94, "fp16_autocast": 2.32}, "bottomup_end_to_end_fps": 137.0,
-                 "single_instance_forward_ms_per_batch4": {"eager_fp32": 1.20, "torch_compile": 0.93, "fp16_autocast": 0.84}, "single_instance_end_to_end_fps": 228.0,
-                 "centroid_forward_ms_per_batch4": {"eager_fp32": 2.48, "torch_compile": 1.96, "fp16_autocast": 1.61}, "topdown_end_to_end_fps": 95.0}
-
-
-def _forward_profile(model, x, n=10):
-    """Per-op HIP-event pass of the eager forward: (op table, per-op ms, kernel codes, executed / direct matrix FLOPs, matrix ms)."""
-    from sleap_nn_amd import _lib as L
-
-    for _ in range(3):
-        model(x)
-    torch.cuda.synchronize()
-    model.set_profiling(True)
-    for _ in range(n):
-        model(x)
-    torch.cuda.synchronize()
-    op_ms, n_fw = model.read_profile()
-    model.set_profiling(False)
-    codes = model.last_kernels()
-    B, _, H, W = x.shape
-    table = model.op_table(B, H, W)
-    op_ms = [t / max(n_fw, 1) for t in op_ms]
-    executed = forward_executed_flops(table, codes)
-    direct = sum(r["flops"] for r in table)
-    matrix_ms = sum(t for r, t in zip(table, op_ms) if r["kind"] in (L.OP_CONV, L.OP_STEM, L.OP_CONVT) and t > 0)
-    kernels = {}
-    for r, t, c in zip(table, op_ms, codes):
-        if c != L.KV_NONE and c != L.KV_FUSED:
-            e = kernels.setdefault(L.KV_NAMES[c].split(" (")[0], {"launches": 0, "ms": 0.0})
-            e["launches"] += 1
-            e["ms"] += t
-    return table, op_ms, codes, executed, direct, matrix_ms, kernels
-
-
-def _small_roofline(executed, direct, matrix_ms, fwd_s, kernels, n_ops):
-    return {"bound": "mfma", "kernel": "whole conv stack of the forward (F(2x2,3x3) kernels incl. their split-K form, wave-private kernel, fused stem): at these sizes every layer has fewer work units than the "
-                                       "256 CUs, the launches are latency-bound and the figure says how far from the matrix pipe that leaves them",
-            "achieved": executed / fwd_s / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": executed / fwd_s / 1e12 / MFMA_F32_PEAK_TFLOPS,
-            "flop_accounting": "achieved = FLOPs the MFMA pipe executes in one forward (launches priced by the kernel family the library reports) / the forward's wall time (hipGraph replay, back to back); "
-                               "direct_equivalent_tflops = direct-convolution FLOPs / the same time",
-            "direct_equivalent_tflops": direct / fwd_s / 1e12, "executed_gflop_per_forward": executed / 1e9, "direct_gflop_per_forward": direct / 1e9,
-            "matrix_launch_ms_per_forward_with_events": matrix_ms, "ops_per_forward": n_ops, "kernels": kernels, "traffic": None}
-
-
-def _time_calls(fn, steps, warmup, sync_each):
-    for _ in range(warmup):
-        fn()
-    torch.cuda.synchronize()
-    ts = []
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        t = time.perf_counter()
-        fn()
-        if sync_each:
-            torch.cuda.synchronize()
-            ts.append(time.perf_counter() - t)
-    torch.cuda.synchronize()
-    return time.perf_counter() - t0, ts
-
-
-def single_instance_leg(name, size, batch, n_nodes, steps, dev, with_cpu):
-    """BASELINE cfg1 / cfg2: single-instance UNet f16/r2/max_stride 16/output_stride 2.  A step = uint8 frames (resident in HBM) -> forward (one hipGraph replay) -> global peaks +
-    integral refinement -> D2H of the keypoints.  cfg1 (one frame) is a latency workload: median / p90 of the synchronous per-frame time; cfg2 (8 frames) a throughput one."""
-    from sleap_nn_amd.architectures.model import Model
-    from sleap_nn_amd.inference.backends import HipBackend
-    from sleap_nn_amd.inference.layers import PostprocessConfig, SingleInstanceLayer
-
-    heads = {"confmaps": {"part_names": [f"k{i}" for i in range(n_nodes)], "sigma": 2.5, "output_stride": 2, "loss_weight": 1.0}}
-    model = Model("unet", SI_BB, heads, "single_instance").init_xavier_(seed=1234, head_scale=0.05).to(dev)
-    g = torch.Generator().manual_seed(4321)
-    frames = torch.randint(0, 256, (batch, 1, size, size), dtype=torch.uint8, generator=g).to(dev)
-    table, op_ms, codes, executed, direct, matrix_ms, kernels = _forward_profile(model, frames)
-    backend = HipBackend(model, str(dev), use_graph=True)
-    layer = SingleInstanceLayer(backend, 2, max_stride=16, postprocess_config=PostprocessConfig(peak_threshold=0.0))
-    # the frames live in the graph's own input buffer (HipBackend.static_input: where a pipeline's H2D copy would land them): a step is one graph launch, no staging copy
-    frames = backend.static_input(tuple(frames.shape)).copy_(frames)
-    fwd_total, _ = _time_calls(lambda: backend(frames), max(steps, 200), 20, False)
-    fwd_s = fwd_total / max(steps, 200)
-    # a step = InferenceLayer.predict_graphed: forward AND post-process (global peaks, refinement, coordinate ladder) captured as one graph, fed from the graph's own input buffer
-    gframes = layer.graph_input(tuple(frames.shape)).copy_(frames)
-    ref_out = layer.predict(frames)
-    got_out = layer.predict_graphed(gframes)
-    assert torch.equal(torch.nan_to_num(ref_out.pred_keypoints), torch.nan_to_num(got_out.pred_keypoints)) and torch.equal(ref_out.pred_peak_values, got_out.pred_peak_values)
-    kp_host = torch.empty(tuple(got_out.pred_keypoints.shape), dtype=torch.float32, pin_memory=True)
-    pv_host = torch.empty(tuple(got_out.pred_peak_values.shape), dtype=torch.float32, pin_memory=True)
-
-    def latency_step():  # ends with the keypoints and their values in (pinned) host memory, as the CPU baseline beside it does
-        o = layer.predict_graphed(gframes)
-        kp_host.copy_(o.pred_keypoints, non_blocking=True)
-        pv_host.copy_(o.pred_peak_values, non_blocking=True)
-
-    total, lat = _time_calls(latency_step, steps, 10, True)
-    lat_us = sorted(1e6 * t for t in lat)
-    # throughput: the same steps enqueued back to back (the layer's outputs stay on the device: no host sync inside a step), one sync at the end
-    total_q, _ = _time_calls(lambda: layer.predict_graphed(gframes), steps, 10, False)
-    total_eager_q, _ = _time_calls(lambda: layer.predict(frames), steps, 10, False)
-    two = None
-    if batch > 1:  # a batch is a throughput workload (`value` = queued steps); one frame is a latency workload (`value` = 1 / median synchronous step)
-        total = total_q
-    else:
-        total = steps * lat_us[len(lat_us) // 2] * 1e-6
-    if True:
-        # ... and the same queued steps alternating between TWO copies of the network on two HIP streams: most launches of a small step have fewer work units than CUs
-        model2 = Model("unet", SI_BB, heads, "single_instance").init_xavier_(seed=1234, head_scale=0.05).to(dev)
-        layer2 = SingleInstanceLayer(HipBackend(model2, str(dev), use_graph=True), 2, max_stride=16, postprocess_config=PostprocessConfig(peak_threshold=0.0))
-        g2 = layer2.graph_input(tuple(frames.shape)).copy_(frames)
-        assert torch.equal(torch.nan_to_num(layer2.predict_graphed(g2).pred_keypoints), torch.nan_to_num(got_out.pred_keypoints))
-        from sleap_nn_amd.inference.predictor import concurrent_streams
-
-        sts = concurrent_streams(dev, 2)
-        pair = ((layer, gframes), (layer2, g2))
-        cnt = [0]
-
-        def step2():
-            k = cnt[0] & 1
-            cnt[0] += 1
-            with torch.cuda.stream(sts[k]):
-                pair[k][0].predict_graphed(pair[k][1])
-
-        total_2, _ = _time_calls(step2, steps, 10, False)
-        two = {"value": batch * steps / total_2, "unit": "frames/s", "what": "the queued steps alternating between two copies of the network on two HIP streams (outputs left on the device): a throughput figure"}
-        del layer2, model2
-    res = {"metric": f"frames/sec single-instance UNet {size}x{size} inference (batch {batch})", "value": batch * steps / total, "unit": "frames/s", "steps": steps, "ms_per_step": 1e3 * total / steps,
-           "queued_steps_frames_per_s": batch * steps / total_q, "queued_steps_frames_per_s_two_launch_groups": batch * steps / total_eager_q,
-           "dtype": "f32", "data": "synthetic",
-           "config": {"workload": f"{name}: single-instance UNet f16/r2/max_stride16/output_stride2, {size}x{size}x1 uint8 frames, {n_nodes} keypoints, batch {batch}", "frames_per_step": batch,
-                      "weights": "xavier-uniform seed 1234, head x0.05", "params": model.num_parameters(), "step": "forward + global peaks + integral refinement + coordinate ladder as ONE hipGraph launch (InferenceLayer.predict_graphed); the synchronous (latency) steps end with the D2H of keypoints and values into pinned memory, the queued (throughput) steps leave them on the device; `value`: one frame = synchronous steps, a batch = steps queued back to back; queued_steps_frames_per_s_two_launch_groups = layer.predict (forward graph, then the post-process launches)",
-                      "inputs": "uint8 frames resident in HBM"},
-           "latency_us_per_step": {"median": lat_us[len(lat_us) // 2], "p10": lat_us[len(lat_us) // 10], "p90": lat_us[(9 * len(lat_us)) // 10]},
-           "forward_only": {"us_per_batch": 1e6 * fwd_s, "frames_per_s": batch / fwd_s, "launch": "hipGraph replay, back to back, no host sync"},
-           "roofline": _small_roofline(executed, direct, matrix_ms, fwd_s, kernels, len(table))}
-    if two is not None:
-        res["two_streams"] = two
-    if with_cpu:  # cfg1 IS the reference-CPU-path configuration of BASELINE.json: the oracle on this box's host cores, same weights, same frame, parity beside it
-        from oracle import cpu_ref as O
-
-        sd = model.state_dict()
-        img = frames[:1].cpu()
-        avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-        out = {}
-        for th in sorted({1, min(avail, 8), min(avail, 16)}):
-            torch.set_num_threads(th)
-            with torch.inference_mode():
-                O.model_forward(sd, SI_BB, heads, "single_instance", img)
-                n, t0 = 0, time.perf_counter()
-                while n < 3 or (time.perf_counter() - t0 < 2.5 and n < 200):
-                    ref = O.model_forward(sd, SI_BB, heads, "single_instance", img)
-                    rk, rv = O.single_instance_postprocess(ref["SingleInstanceConfmapsHead"], 2)
-                    n += 1
-                out[th] = (time.perf_counter() - t0) / n
-        best = min(out, key=out.get)
-        torch.set_num_threads(avail)
-        got = model(frames[:1])["SingleInstanceConfmapsHead"].cpu()
-        res["cpu_baseline"] = {"value": 1.0 / out[best], "unit": "frames/s", "cores": best, "kind": "port", "value_1thread": 1.0 / out[1], "ms_per_frame_by_threads": {str(k): 1e3 * v for k, v in out.items()},
-                               "sample": "oracle/cpu_ref.py forward + global peaks of one 256x256 frame, ~2.5 s per thread count, torch-CPU fp32",
-                               "parity_on_this_sample": {"max_abs_confmap_diff": float((got - ref["SingleInstanceConfmapsHead"]).abs().max()), "confmap_abs_max": float(ref["SingleInstanceConfmapsHead"].abs().max())}}
-    return res
-
-
 SHARD_LANES_4 = 3     # copies of the cfg3 network a rank with <= 4 frames per step alternates between (8 frames: 2); whole pipelined step on one GPU, tools/shard_lanes_ab.py: 2 637 -> 2 671 frames/s
-PUBLISHED_LANES = 3  # copies of a small network Predictor keeps in flight on as many HIP streams (Predictor.from_model_paths(streams=...)' default)
-
-
-def published_workload_leg(steps, dev):
-    """The one workload the reference publishes numbers for (docs/guides/inference-performance.md:40-48,70-77, an NVIDIA A40): its fixture bottom-up run directory (tests/golden/ckpt_dirs:
-    UNet f16 / rate 1.5 / max_stride 8, transposed-conv decoder, 2 nodes / 1 edge) at 320 x 560, batch 4 (predictor.py:884,930).  Backbone-level forward per batch (their table 1) in exact fp32
-    and in the autocast-equivalent fp16 mode, and end-to-end frames/s of Predictor.predict over 100 frames (their table 2; theirs includes video decoding, ours starts from uint8 frames in host memory)."""
-    from sleap_nn_amd.inference.backends import HipBackend
-    from sleap_nn_amd.inference.loaders import load_model_assets
-    from sleap_nn_amd.inference.predictor import Predictor
-
-    root = os.path.join(ROOT, "tests", "golden", "ckpt_dirs", "minimal_instance_bottomup")
-    model = load_model_assets(root).build_model().to(dev)
-    g = torch.Generator().manual_seed(4321)
-    frames = torch.randint(0, 256, (4, 1, 320, 560), dtype=torch.uint8, generator=g).to(dev)
-    table, op_ms, codes, executed, direct, matrix_ms, kernels = _forward_profile(model, frames)
-    fwd = {}
-    for tag, kw in (("exact_fp32", {}), ("fp16_autocast_equivalent", {"use_fp16": True})):
-        backend = HipBackend(model, str(dev), use_graph=True, **kw)
-        x5 = backend.static_input(tuple(frames.shape)).copy_(frames)
-        n = max(steps, 200)
-        total, _ = _time_calls(lambda: backend(x5), n, 20, False)
-        fwd[tag] = 1e3 * total / n
-    model.set_precision("exact")
-    fwd_s = fwd["exact_fp32"] * 1e-3
-    # end to end: Predictor on 100 host frames (real texture: the fixture video's two golden frames tiled to 320 x 560), batch 4
-    z = np.load(os.path.join(ROOT, "tests", "golden", "ckpt_bottomup.npz"), allow_pickle=False)
-    two = torch.from_numpy(z["image"]).squeeze(1)
-    vid = torch.cat([two, two.flip(-1)], 0)[:, :, 32:352, :].repeat(25, 1, 1, 2)[..., :560].contiguous()  # (100, 1, 320, 560) uint8, host
-    pred = Predictor.from_model_paths([root], device=str(dev), batch_size=4, peak_threshold=0.2, streams=PUBLISHED_LANES)
-    pred.predict(vid)  # (untimed: graph capture of the batch shape, pinned buffers, the host-stage worker)
-    torch.cuda.synchronize()
-    reps, t0 = 10, time.perf_counter()
-    n_inst = 0
-    for _ in range(reps):
-        outs = pred.predict(vid)
-        n_inst = sum(int((~torch.isnan(o.instance_scores)).sum()) for o in outs)
-    e2e = reps * vid.shape[0] / (time.perf_counter() - t0)
-    ref = PUBLISHED_A40
-    # the same two measurements for the reference's single-instance fixture (its run directory carries input scale 0.5: the 320 x 560 frames reach the backbone as 160 x 280)
-    si_root = os.path.join(ROOT, "tests", "golden", "ckpt_dirs", "minimal_instance_single_instance")
-    si = {}
-    try:
-        si_model = load_model_assets(si_root).build_model().to(dev)
-        si_frames = torch.randint(0, 256, (4, 1, 160, 280), dtype=torch.uint8, generator=g).to(dev)
-        for tag, kw in (("exact_fp32", {}), ("fp16_autocast_equivalent", {"use_fp16": True})):
-            be = HipBackend(si_model, str(dev), use_graph=True, **kw)
-            xb = be.static_input(tuple(si_frames.shape)).copy_(si_frames)
-            n = max(steps, 200)
-            tot, _ = _time_calls(lambda: be(xb), n, 20, False)
-            si.setdefault("forward_ms_per_batch", {})[tag] = 1e3 * tot / n
-        si_model.set_precision("exact")
-        sp = Predictor.from_model_paths([si_root], device=str(dev), batch_size=4, peak_threshold=0.2, streams=PUBLISHED_LANES)
-        sp.predict(vid)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(reps):
-            souts = sp.predict(vid)
-            souts[-1].pred_keypoints.cpu()
-        si["end_to_end_fps"] = reps * vid.shape[0] / (time.perf_counter() - t1)
-        si["vs_baseline"] = {"forward_eager_fp32": ref["single_instance_forward_ms_per_batch4"]["eager_fp32"] / si["forward_ms_per_batch"]["exact_fp32"],
-                             "forward_fp16": ref["single_instance_forward_ms_per_batch4"]["fp16_autocast"] / si["forward_ms_per_batch"]["fp16_autocast_equivalent"],
-                             "end_to_end_fps": si["end_to_end_fps"] / ref["single_instance_end_to_end_fps"]}
-        si["what"] = "fixture single-instance run directory: forward on (4, 1, 160, 280) (input scale 0.5 of the 320 x 560 frames), Predictor.predict over the same 100 host frames (antialiased resize + forward + global peaks)"
-    except Exception as e:  # the headline legs must not die on the extra fixture
-        si = {"error": repr(e)}
-    # two-stage top-down (centroid -> crops -> centered instance) on the reference's fixture models (tests/golden/topdown.npz holds their weights and configs)
-    td = {}
-    try:
-        from sleap_nn_amd.architectures.model import Model
-        from sleap_nn_amd.inference.layers import CenteredInstanceLayer, CentroidLayer, PostprocessConfig, TopDownLayer
-
-        tz = np.load(os.path.join(ROOT, "tests", "golden", "topdown.npz"), allow_pickle=False)
-        tcfg = json.loads(str(tz["config_json"]))
-        cc, ci = tcfg["centroid"], tcfg["centered"]
-        wsel = lambda pre: {k[len(pre):]: torch.from_numpy(tz[k]) for k in tz.files if k.startswith(pre)}
-        mc = Model("unet", cc["backbone"], cc["heads"], "centroid")
-        mc.load_state_dict(wsel("wc/"))
-        mi = Model("unet", ci["backbone"], ci["heads"], "centered_instance")
-        mi.load_state_dict(wsel("wi/"))
-        def make_tdl(mc_, mi_):
-            cbe_ = HipBackend(mc_, str(dev), use_graph=True)
-            cl_ = CentroidLayer(cbe_, cc["heads"]["confmaps"]["output_stride"], max_instances=6, max_stride=cc["backbone"]["max_stride"], postprocess_config=PostprocessConfig(peak_threshold=0.03, max_instances=6))
-            il_ = CenteredInstanceLayer(HipBackend(mi_, str(dev)), ci["heads"]["confmaps"]["output_stride"], max_stride=ci["backbone"]["max_stride"], postprocess_config=PostprocessConfig(peak_threshold=0.03))
-            return cbe_, TopDownLayer(cl_, il_, (tcfg["crop_size"], tcfg["crop_size"]))
-
-        cbe, tdl = make_tdl(mc, mi)
-        td_replicas = []
-        for _ in range(PUBLISHED_LANES - 1):  # further copies of the pair (own handles): Predictor's other lanes
-            mc2 = Model("unet", cc["backbone"], cc["heads"], "centroid")
-            mc2.load_state_dict(wsel("wc/"))
-            mi2 = Model("unet", ci["backbone"], ci["heads"], "centered_instance")
-            mi2.load_state_dict(wsel("wi/"))
-            td_replicas.append(make_tdl(mc2, mi2)[1])
-        tframes = torch.from_numpy(tz["image"]).to(dev)
-        tframes = tframes.reshape(-1, *tframes.shape[-3:])
-        tframes = tframes.repeat((4 + tframes.shape[0] - 1) // tframes.shape[0], 1, 1, 1)[:4].contiguous()
-        cx = cbe.static_input(tuple(tframes.shape)).copy_(tframes)
-        n = max(steps, 200)
-        tot, _ = _time_calls(lambda: cbe(cx), n, 20, False)
-        td["centroid_forward_ms_per_batch"] = 1e3 * tot / n
-        tout = tdl.predict(tframes)
-        tot, _ = _time_calls(lambda: tdl.predict(tframes), 100, 10, False)
-        td["layer_predict_ms_per_batch"] = 1e3 * tot / 100
-        td["layer_predict_fps"] = 4 * 100 / tot
-        td["instances_per_batch"] = int(torch.isfinite(tout.pred_centroids[..., 0]).sum())
-        # end to end as for the bottom-up model: Predictor.predict over 100 uint8 frames in host memory, batch 4 (stage 1 of batch i + 1 enqueued before the one host read of batch i)
-        tvid = tframes.cpu().repeat(25, 1, 1, 1).contiguous()
-        tp = Predictor(tdl, batch_size=4, replicas=td_replicas)
-        tp.predict(tvid)
-        torch.cuda.synchronize()
-        t2 = time.perf_counter()
-        for _ in range(reps):
-            touts = tp.predict(tvid)
-            touts[-1].pred_keypoints.cpu()
-        tot = time.perf_counter() - t2
-        td["end_to_end_ms_per_batch"] = 1e3 * tot / (reps * 25)
-        td["end_to_end_fps"] = reps * tvid.shape[0] / tot
-        td["vs_baseline"] = {"centroid_forward_eager_fp32": ref["centroid_forward_ms_per_batch4"]["eager_fp32"] / td["centroid_forward_ms_per_batch"], "end_to_end_fps": td["end_to_end_fps"] / ref["topdown_end_to_end_fps"]}
-        td["what"] = f"fixture top-down models (tests/golden/topdown.npz): {tuple(tframes.shape)} uint8 frames resident in HBM, centroid forward (hipGraph) and TopDownLayer.predict (centroid -> NMS peaks -> device-side selection -> {tcfg['crop_size']} x {tcfg['crop_size']} crops -> centered-instance forward -> global peaks -> scatter; ONE host read per batch: the per-frame centroid counts); end_to_end = Predictor.predict over 100 host frames, pipelined over that read, two copies of the layer pair on two HIP streams"
-    except Exception as e:
-        td = {"error": repr(e)}
-    return {"metric": "ms per batch of 4, bottom-up backbone forward (the reference's published table)", "value": fwd["exact_fp32"], "unit": "ms/batch", "higher_is_better": False, "steps": max(steps, 200),
-            "dtype": "f32", "data": "reference fixture checkpoint (tests/golden/ckpt_dirs/minimal_instance_bottomup), synthetic uint8 frames",
-            "config": {"workload": "published: fixture bottom-up UNet (f16, rate 1.5, max_stride 8, transposed-conv decoder, 2 nodes / 1 edge), 320x560x1 uint8, batch 4", "frames_per_step": 4,
-                       "params": model.num_parameters(), "forward_launch": "hipGraph replay, back to back"},
-            "forward_ms_per_batch": fwd, "frames_per_s_forward": 4.0 / fwd_s,
-            "end_to_end": {"value": e2e, "unit": "frames/s", "frames": int(vid.shape[0]), "repeats": reps, "instances_found_per_pass": n_inst,
-                           "what": "Predictor.predict (pipelined: pinned staging + H2D, resize / pad + forward + peaks + PAF scoring as one hipGraph, D2H, one-call C++ grouping in a worker; consecutive batches alternate between three copies of the layer on three HIP streams, Predictor.from_model_paths(streams=3)) over 100 uint8 frames in host memory, batch 4, exact fp32"},
-            "vs_baseline": {"forward_eager_fp32": ref["bottomup_forward_ms_per_batch4"]["eager_fp32"] / fwd["exact_fp32"], "forward_fp16": ref["bottomup_forward_ms_per_batch4"]["fp16_autocast"] / fwd["fp16_autocast_equivalent"],
-                            "end_to_end_fps": e2e / ref["bottomup_end_to_end_fps"], "reference": ref, "reference_hardware": "NVIDIA A40, CUDA 12.8, torch 2.9.1 (docs/guides/inference-performance.md:3-7,40-48,70-77)",
-                            "note": "ratios > 1 = this build faster; different hardware and (end to end) no video decoding here: a like-for-like of the workload, not of the machine"},
-            "single_instance": si, "topdown": td,
-            "roofline": _small_roofline(executed, direct, matrix_ms, fwd_s, kernels, len(table))}
-
-
-def infer_cfg5_leg(steps, dev):
-    """BASELINE cfg5: multi-class bottom-up, 768 x 768, 4 classes x 17 keypoints, fp16 MFMA, batch 16.  The reference has no HRNet: the backbone is its UNet
-    (the cfg3 architecture) with a class-maps head; the forward runs in the autocast-equivalent fp16 precision (fp16 storage and MFMA operands, fp32 accumulation and head outputs,
-    torch_backend.py:113-143).  A step = forward (hipGraph replay) + local peaks + class-map sampling + D2H + host grouping by class, on rendered heads (one animal per class), synchronous."""
-    from sleap_nn_amd.architectures.model import Model
-    from sleap_nn_amd.data.targets import generate_multiconfmaps
-    from sleap_nn_amd.inference.backends import HipBackend
-    from sleap_nn_amd.inference.layers import BottomUpMultiClassLayer, PostprocessConfig
-    from sleap_nn_amd.inference.preprocess_info import PreprocInfo
-
-    S, N, K, B = 768, 17, 4, 16
-    heads = {"confmaps": {"part_names": [f"k{i}" for i in range(N)], "sigma": 2.5, "output_stride": 4, "loss_weight": 1.0},
-             "class_maps": {"classes": [f"id{i}" for i in range(K)], "sigma": 12.5, "output_stride": 8, "loss_weight": 1.0}}
-    model = Model("unet", dict(CFG3_BB), heads, "multi_class_bottomup").init_xavier_(seed=1234, head_scale=0.05).to(dev)
-    g = torch.Generator().manual_seed(4321)
-    frames = torch.randint(0, 256, (B, 1, S, S), dtype=torch.uint8, generator=g).to(dev)
-    exact = {k: v.clone() for k, v in model(frames[:2]).items()}
-    backend = HipBackend(model, str(dev), use_graph=True, use_fp16=True)
-    layer = BottomUpMultiClassLayer(backend, 4, 8, max_stride=32, postprocess_config=PostprocessConfig(peak_threshold=0.2))
-    got = backend(frames[:2].contiguous())
-    drift = {k: float((got[k] - exact[k]).abs().max()) for k in exact}
-    # rendered heads: one animal per class, 17 nodes each; class maps = blobs around that animal's nodes
-    rng = np.random.RandomState(3)
-    pts = np.stack([np.clip(rng.uniform(120, S - 120, size=(K, 1, 2)) + rng.normal(0, 35, size=(K, N, 2)), 6, S - 7) for _ in range(B)]).astype(np.float32)
-    cms = generate_multiconfmaps(torch.from_numpy(pts).to(dev), (S, S), sigma=2.5 * 4 / 2 / 4, output_stride=4)  # as rendered_heads: sigma * stride = 5 px
-    yy, xx = torch.meshgrid(torch.arange(0, S, 8, dtype=torch.float32, device=dev), torch.arange(0, S, 8, dtype=torch.float32, device=dev), indexing="ij")
-    tp = torch.from_numpy(pts).to(dev)
-    d2 = (xx[None, None, None] - tp[..., 0, None, None]) ** 2 + (yy[None, None, None] - tp[..., 1, None, None]) ** 2
-    cmaps = torch.exp(-d2 / (2 * 50.0**2)).amax(2)
-    info = PreprocInfo(eff_scale=torch.ones(B))
-    fb = backend.static_input(tuple(frames.shape)).copy_(frames)
-
-    def step():
-        backend(fb)
-        return layer.postprocess({"MultiInstanceConfmapsHead": cms, "ClassMapsHead": cmaps}, info)
-
-    out = step()
-    found = int((~torch.isnan(out.pred_keypoints[..., 0])).sum())
-    n = max(steps, 50)
-    fwd_total, _ = _time_calls(lambda: backend(fb), n, 10, False)
-    total_sync, lat = _time_calls(step, n, 5, True)
-    # pipelined, as the bottom-up predictor runs its batches: the GPU stage of step i + 1 (forward + peaks + class-map sampling + async D2H) is enqueued before the host
-    # stage of step i (Hungarian matching by class in a worker thread) is collected
-    from concurrent.futures import ThreadPoolExecutor
-
-    pool = ThreadPoolExecutor(max_workers=1)
-    futs = []
-
-    def pstep():
-        backend(fb)
-        futs.append(pool.submit(layer._finish_postprocess, layer._enqueue_postprocess({"MultiInstanceConfmapsHead": cms, "ClassMapsHead": cmaps}, info)))
-        if len(futs) > 2:
-            futs.pop(0).result()
-
-    for _ in range(5):
-        pstep()
-    last = [f.result() for f in futs][-1]
-    futs.clear()
-    assert torch.equal(torch.nan_to_num(last.pred_keypoints), torch.nan_to_num(out.pred_keypoints))
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    for _ in range(n):
-        pstep()
-    for f in futs:
-        f.result()
-    torch.cuda.synchronize()
-    total = time.perf_counter() - t1
-    futs.clear()
-    pool.shutdown()
-    fwd_s = fwd_total / n
-    table = model.op_table(B, S, S)
-    direct = sum(r["flops"] for r in table)
-    return {"metric": "frames/sec multi-class bottom-up UNet 768x768 inference, fp16 MFMA (batch 16)", "value": B * n / total, "unit": "frames/s", "steps": n, "ms_per_step": 1e3 * total / n,
-            "dtype": "f16 (f32 accumulate)", "data": "synthetic",
-            "config": {"workload": "cfg5: multi-class bottom-up, UNet f16/r2/max_stride32/output_stride4 backbone (the reference has no HRNet), 768x768x1 uint8 frames, 4 classes x 17 keypoints, batch 16",
-                       "frames_per_step": B, "params": model.num_parameters(), "postprocess_input": "rendered heads, one animal per class", "keypoints_found_per_step": found,
-                       "step": "forward (hipGraph replay, fp16 pipe) + local peaks + class-map sampling + async D2H, host grouping by class in a worker thread; steps pipelined (the next GPU stage is enqueued before this step's host stage is collected), every step grouped before the clock stops"},
-            "synchronous_steps": {"value": B * n / total_sync, "unit": "frames/s", "ms_per_step": 1e3 * total_sync / n, "what": "the same step with a host sync behind each (round 4's definition of this leg)"},
-            "forward_only": {"ms_per_batch": 1e3 * fwd_s, "frames_per_s": B / fwd_s},
-            "max_abs_head_diff_vs_exact_fp32": drift, "head_abs_max": {k: float(v.abs().max()) for k, v in exact.items()},
-            "roofline": {"bound": "mfma", "kernel": "stem_f16_kernel + block2_c32_f16_kernel + conv3x3_f16_rows_kernel / conv3x3_f16_persist_kernel (direct 3x3 on v_mfma_f32_16x16x32_f16 / 32x32x16_f16; bilinear x2 and both heads folded) over the whole forward", "achieved": direct / fwd_s / 1e12, "peak": MFMA_F16_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": direct / fwd_s / 1e12 / MFMA_F16_PEAK_TFLOPS, "direct_gflop_per_forward": direct / 1e9,
-                         "flop_accounting": "direct-convolution FLOPs of the forward (this pipe runs the direct form: executed = direct) / the forward's wall time (hipGraph replay, back to back), against the dense fp16 MFMA peak",
-                         "traffic": _cfg5_traffic()[0], "traffic_source": _cfg5_traffic()[1], "traffic_unit": "HBM bytes per forward (PMC: FETCH_SIZE x 2 + WRITE_SIZE, separate passes)",
-                         "algorithmic_bytes_per_forward": sum(r["bytes"] for r in table)}}
 
 
 def small_batch_legs(args, ctx):
