@@ -280,6 +280,7 @@ int ph_model_profile_read(ph_model* m, double* op_ms, int32_t n_ops, int32_t* n_
 #define PH_KV_SMALLMAP 12 /* conv3x3_sm_kernel: Winograd F(2x2,3x3) on 8 x 8-pixel x 16-channel units (small maps, small batches)      */
 #define PH_KV_F16_ROWS 13 /* conv3x3_f16_rows_kernel: plain fp16 on v_mfma_f32_16x16x32_f16, row tiles, loader waves, folded bilinear x2 */
 #define PH_KV_F16_BLOCK 14 /* block2_c32_f16_kernel: conv(<= 16 -> 32) + conv(32 -> 32) (+ pool) of an encoder block in one launch (plain fp16); the second conv reports PH_KV_FUSED */
+#define PH_KV_MLP 15      /* cnblock_mlp_kernel: Linear(C, 4C) + GELU + Linear(4C, C) + layer scale + residual of a CNBlock in one launch (both Linear ops report it; the second has no launch of its own) */
 #define PH_KV_FUSED 11    /* no launch of its own: a 1x1 head computed in the epilogue of the conv that produces its input */
 int ph_model_last_kernels(const ph_model* m, int32_t* codes, int32_t n_ops);
 

@@ -19,7 +19,7 @@ OP_PATCH_STEM, OP_DWCONV, OP_LAYERNORM, OP_LINEAR, OP_PATCH_CONV, OP_GELU, OP_SC
 FLAG_RELU, FLAG_SIGMOID, FLAG_GELU, FLAG_SCALE_RESIDUAL, FLAG_SOFTMAX, FLAG_SILU = 1, 2, 4, 8, 16, 32
 # PH_KV_*: kernel family an op of the last forward ran (ph_model_last_kernels) and the share of its direct-convolution
 # FLOPs that family puts through the matrix cores
-KV_NONE, KV_DIRECT, KV_WINO1D, KV_WINO2D, KV_W16, KV_C16, KV_ROWGEMM, KV_WINO4, KV_F16, KV_STEM, KV_WINO2D_KS, KV_FUSED, KV_SMALLMAP, KV_F16_ROWS, KV_F16_BLOCK = range(15)
+KV_NONE, KV_DIRECT, KV_WINO1D, KV_WINO2D, KV_W16, KV_C16, KV_ROWGEMM, KV_WINO4, KV_F16, KV_STEM, KV_WINO2D_KS, KV_FUSED, KV_SMALLMAP, KV_F16_ROWS, KV_F16_BLOCK, KV_MLP = range(16)
 KV_NAMES = {KV_NONE: "none", KV_DIRECT: "conv3x3_mfma_dma_persist_kernel (direct)", KV_WINO1D: "conv3x3_wino_persist_kernel (Winograd F(2,3) along x)",
             KV_WINO2D: "conv3x3_wino2d_kernel<64> (Winograd F(2x2,3x3))", KV_W16: "conv3x3_w16_kernel (wave-private Winograd F(2x2,3x3), 16x16x4 MFMA)",
             KV_C16: "conv3x3_c16_kernel (direct)", KV_ROWGEMM: "gemm_mfma_dma_kernel (row GEMM, direct)", KV_WINO4: "conv3x3_wino4_kernel (Winograd F(4x4,3x3))",
@@ -27,8 +27,9 @@ KV_NAMES = {KV_NONE: "none", KV_DIRECT: "conv3x3_mfma_dma_persist_kernel (direct
             KV_WINO2D_KS: "conv3x3_wino2d_kernel<64, split K> + splitk_reduce_kernel", KV_FUSED: "fused into its producer's epilogue",
             KV_SMALLMAP: "conv3x3_sm_kernel (Winograd F(2x2,3x3), small maps)",
             KV_F16_ROWS: "conv3x3_f16_rows_kernel (direct, plain fp16 on v_mfma_f32_16x16x32_f16: row tiles, loader waves, folded bilinear x2)",
-            KV_F16_BLOCK: "block2_c32_f16_kernel (two convs of a 32-channel encoder block in one launch, plain fp16)"}
-KV_MFMA_SHARE = {KV_NONE: 0.0, KV_DIRECT: 1.0, KV_WINO1D: 2.0 / 3.0, KV_WINO2D: 4.0 / 9.0, KV_W16: 4.0 / 9.0, KV_C16: 1.0, KV_ROWGEMM: 1.0, KV_WINO4: 0.25, KV_F16: 1.0, KV_STEM: 4.0 / 9.0, KV_WINO2D_KS: 4.0 / 9.0, KV_FUSED: 0.0, KV_SMALLMAP: 4.0 / 9.0, KV_F16_ROWS: 1.0, KV_F16_BLOCK: 1.0}
+            KV_F16_BLOCK: "block2_c32_f16_kernel (two convs of a 32-channel encoder block in one launch, plain fp16)",
+            KV_MLP: "cnblock_mlp_kernel (CNBlock MLP: Linear + GELU + Linear + layer scale + residual in one launch, chained MFMA products)"}
+KV_MFMA_SHARE = {KV_NONE: 0.0, KV_DIRECT: 1.0, KV_WINO1D: 2.0 / 3.0, KV_WINO2D: 4.0 / 9.0, KV_W16: 4.0 / 9.0, KV_C16: 1.0, KV_ROWGEMM: 1.0, KV_WINO4: 0.25, KV_F16: 1.0, KV_STEM: 4.0 / 9.0, KV_WINO2D_KS: 4.0 / 9.0, KV_FUSED: 0.0, KV_SMALLMAP: 4.0 / 9.0, KV_F16_ROWS: 1.0, KV_F16_BLOCK: 1.0, KV_MLP: 1.0}
 
 
 class OpDesc(C.Structure):

@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libposehip.so")
-SOURCES = ["net_kernels.hip", "wino2d_kernels.hip", "wino4_kernels.hip", "w16_kernels.hip", "smallmap_kernels.hip", "f16_kernels.hip", "f16_rows_kernels.hip", "convnext_kernels.hip", "model.hip", "train_kernels.hip", "convnext_train_kernels.hip", "train.hip", "post_kernels.hip", "resize_kernels.hip", "group_host.cpp", "comm_rccl.cpp"]
+SOURCES = ["net_kernels.hip", "wino2d_kernels.hip", "wino4_kernels.hip", "w16_kernels.hip", "smallmap_kernels.hip", "f16_kernels.hip", "f16_rows_kernels.hip", "convnext_kernels.hip", "cnblock_mlp_kernels.hip", "model.hip", "train_kernels.hip", "convnext_train_kernels.hip", "train.hip", "post_kernels.hip", "resize_kernels.hip", "group_host.cpp", "comm_rccl.cpp"]
 HEADERS = ["common.h", "device_math.h", "act_format.h", "f16_kernels.h", "net_kernels.h", "train_kernels.h", "model_internal.h", os.path.join("..", "..", "include", "posehip.h")]
 ARCH = "gfx950"
 

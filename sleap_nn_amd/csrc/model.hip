@@ -171,6 +171,31 @@ static void repack_dma(const std::vector<T>& in, int bn, std::vector<T>& out) {
 // [n_tile][stage][piece = n / 8][slot][row n % 8][4]; a stage is 32 channels of one source at one tap,
 // stage order = source, 32-channel slice, tap (taps innermost); slot = channel quad ^ (piece & 1)
 // (the LDS image the kernel's DMA writes); zero-padded channels / rows.
+// CNBlock MLP, first Linear (4C, C) -> [hidden block hb][piece q: C / 8][lane (i = lane & 31, h = lane >> 5)][t]: W1[hb 32 + i][h C / 2 + 4 q + t]
+// (the A operand of K step s = 4 q + t of cnblock_mlp_kernel's first product: channels (s, C / 2 + s) in the two lane halves)
+template <typename T>
+static void pack_mlp_w1(const T* w, int c, std::vector<T>& out) {
+  const int nhb = 4 * c / 32, p1 = c / 8;
+  out.assign((size_t)nhb * p1 * 256, T(0));
+  for (int hb = 0; hb < nhb; ++hb)
+    for (int q = 0; q < p1; ++q)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int t = 0; t < 4; ++t) out[(((size_t)hb * p1 + q) * 64 + lane) * 4 + t] = w[(size_t)(hb * 32 + (lane & 31)) * c + (lane >> 5) * (c / 2) + 4 * q + t];
+}
+// ... second Linear (C, 4C) -> [hb][piece nb 4 + g][lane (n = lane & 31, h)][t]: W2[nb 32 + n][hb 32 + 8 g + 4 h + t]: K step r = 4 g + t of the chained product is
+// the pair of hidden channels that accumulator register r of the first product holds in the two lane halves
+template <typename T>
+static void pack_mlp_w2(const T* w, int c, std::vector<T>& out) {
+  const int nhb = 4 * c / 32, nb_ = c / 32;
+  out.assign((size_t)nhb * nb_ * 4 * 256, T(0));
+  for (int hb = 0; hb < nhb; ++hb)
+    for (int nb = 0; nb < nb_; ++nb)
+      for (int g = 0; g < 4; ++g)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int t = 0; t < 4; ++t)
+            out[((((size_t)hb * nb_ + nb) * 4 + g) * 64 + lane) * 4 + t] = w[(size_t)(nb * 32 + (lane & 31)) * (4 * c) + hb * 32 + 8 * g + 4 * (lane >> 5) + t];
+}
+
 template <typename T>
 static void pack_gemm(const T* w, int cout, int cin0, int cin1, int taps, int bn, std::vector<T>& out) {
   const int c0p = pad16(cin0), c1p = cin1 > 0 ? pad16(cin1) : 0, coutp = pad16(cout);
@@ -887,6 +912,13 @@ ph_model* ph_model_create(const ph_op_desc* ops, int32_t n_ops, const float* con
         auto pack_g = [&](const auto* w, auto& out) { pack_gemm(w, d.cout, d.cin0, 0, segs, op.bn, out); };
         ok = pack_upload(m, pack_g, weights[d.weight], index_array(d.weight), &op.w_dma_dev) == PH_OK &&
              pack_upload(m, pad_vec(npad, d.cout), weights[d.bias], index_array(d.bias), &op.b_dev) == PH_OK;
+        if (ok && d.kind == PH_OP_LINEAR && (d.flags & PH_FLAG_GELU) && cnblock_mlp_fits(d.cin0, pad16(d.cin0), d.cout)) {  // inference programs: the first Linear of a CNBlock MLP ...
+          auto pack_1 = [&](const auto* w, auto& out) { pack_mlp_w1(w, d.cin0, out); };
+          ok = pack_upload(m, pack_1, weights[d.weight], index_array(d.weight), &op.w_mlp_dev) == PH_OK;
+        } else if (ok && d.kind == PH_OP_LINEAR && (d.flags & PH_FLAG_SCALE_RESIDUAL) && cnblock_mlp_fits(d.cout, pad16(d.cout), d.cin0)) {  // ... and the second
+          auto pack_2 = [&](const auto* w, auto& out) { pack_mlp_w2(w, d.cout, out); };
+          ok = pack_upload(m, pack_2, weights[d.weight], index_array(d.weight), &op.w_mlp_dev) == PH_OK;
+        }
         if (ok) {  // data-gradient weights (training): dX = dY * W, one transposed matrix per tap, + a zero bias
           const int cinp = pad16(d.cin0);
           op.bn_dg = gemm_choose_bn(cinp);
@@ -998,7 +1030,7 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
   size_t op_index = 0;
   m->last_variant.assign(m->ops.size(), PH_KV_NONE);
   int* const kv = m->last_variant.data();
-  bool skip_next_gelu = false, skip_next_scale_add = false;
+  bool skip_next_gelu = false, skip_next_scale_add = false, skip_next_linear = false;
   int pooled_by_conv = -1;  // slot whose 2x2 max pool the producing conv's epilogue already wrote (run-time fusion of an unfused program, see PH_OP_CONV)
   std::vector<char> head_done(m->ops.size(), 0);  // head ops the producing conv's epilogue already computed (see PH_OP_CONV)
   std::vector<char> conv_done(m->ops.size(), 0);  // conv ops the conv in front of them already computed (two-conv block kernel, see PH_OP_CONV)
@@ -1600,9 +1632,41 @@ int ph_model_forward(ph_model* m, const void* input_dev, int32_t in_dtype, int32
       }
       case PH_OP_LINEAR:
       case PH_OP_PATCH_CONV: {
+        if (skip_next_linear) {  // the second Linear of a CNBlock MLP that cnblock_mlp_kernel computed with the first
+          skip_next_linear = false;
+          kv[op_index - 1] = PH_KV_MLP;
+          break;
+        }
         const SlotShape& s0 = plan.slots[d.src0];
         const SlotShape& so = plan.slots[d.dst];
         PH_REQUIRE(s0.c == d.cin0, "GEMM channel mismatch");
+        // CNBlock's MLP in one launch (inference plans that recycle slots: the 4C-wide hidden tensor is nobody else's business): Linear + GELU whose only reader is a
+        // Linear with layer scale + residual, both at a width cnblock_mlp_kernel takes
+        if (m->mlp_fuse && d.kind == PH_OP_LINEAR && (d.flags & PH_FLAG_GELU) && op.w_mlp_dev && plan.reuse && op_index < m->ops.size()) {
+          const PackedOp& nxo = m->ops[op_index];
+          const ph_op_desc& nx = nxo.d;
+          bool pair = nx.kind == PH_OP_LINEAR && (nx.flags & PH_FLAG_SCALE_RESIDUAL) && nxo.w_mlp_dev && nx.src0 == d.dst && nx.src1 >= 0 && nx.src1 != d.dst && nx.cin0 == d.cout && nx.cout == d.cin0 &&
+                      s0.cp == d.cin0 && plan.slots[nx.dst].cp == nx.cout && plan.slots[nx.src1].cp == nx.cout;
+          for (size_t k = 0; pair && k < m->ops.size(); ++k)
+            if (k != op_index && (m->ops[k].d.src0 == d.dst || m->ops[k].d.src1 == d.dst)) pair = false;
+          if (pair) {
+            MlpArgs f{};
+            f.x = slot_ptr(d.src0);
+            f.w1img = op.w_mlp_dev;
+            f.w2img = nxo.w_mlp_dev;
+            f.b1 = op.b_dev;
+            f.b2 = nxo.b_dev;
+            f.scale = nxo.w2_dev;
+            f.residual = slot_ptr(nx.src1);
+            f.dst = slot_ptr(nx.dst);
+            f.M = batch * so.h * so.w;
+            f.C = d.cin0;
+            kv[op_index - 1] = PH_KV_MLP;
+            skip_next_linear = true;
+            rc = launch_cnblock_mlp(f, s);
+            break;
+          }
+        }
         GemmArgs a{};
         a.src0 = slot_ptr(d.src0);
         a.wpack = op.w_dma_dev;
@@ -1733,6 +1797,7 @@ std::vector<OptionRef> option_table(ph_model* m) {
       {"conv_wino4_min_cin", &m->conv_wino4_min_cin, nullptr},  // padded input channels from which a layer takes it
       {"conv_n32_wino2d", &m->conv_n32_wino2d, nullptr},  // Cout-32 / K >= 64 layers on the F(2x2,3x3) kernel with a half-empty N tile (0: the N-tile-32 F(2,3) kernel)
       {"conv_splitk_finish", &m->conv_splitk_finish, nullptr},  // 0: the split-K second stage as a launch of its own (A/B, tests)
+      {"mlp_fuse", &m->mlp_fuse, nullptr},                // inference plans: CNBlock's two Linears (+ GELU, layer scale, residual) in one launch (cnblock_mlp_kernel)
       {"block_fuse", &m->block_fuse, nullptr},          // plain fp16, inference plans: the two convs of a 32-channel encoder block in one launch (block2_c32_f16_kernel)
       {"stem_f16mfma", &m->stem_f16mfma, nullptr},      // plain fp16: the fused first block with BOTH convs on the fp16 matrix pipe (stem_f16_kernel) instead of stem_fused_kernel<CIN, 3>
       {"upsample_f16math", &m->upsample_f16math, nullptr},  // a bilinear x2 folded into conv3x3_f16_rows_kernel blends in packed fp16 arithmetic (1) or in fp32 as upsample2x_fmt_kernel does (0)

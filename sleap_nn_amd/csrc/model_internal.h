@@ -17,6 +17,7 @@ struct PackedOp {
   float* w2_dev = nullptr;
   float* b2_dev = nullptr;
   float* w_dma_dev = nullptr;  // conv weights in the LDS-DMA (quad-major piece) layout
+  float* w_mlp_dev = nullptr;  // Linear of a CNBlock MLP pair (inference programs): its weight as cnblock_mlp_kernel's LDS images
   int bn = 0;
   float* wd_gemm_dev[4] = {nullptr, nullptr, nullptr, nullptr};  // Linear / 2x2 conv: transposed weights (per tap) for the data gradient
   int bn_dg = 0;
@@ -136,6 +137,7 @@ struct ph_model {
   int conv_wino4_min_cin = 64;                // "conv_wino4_min_cin": padded input channels (both sources) from which a layer takes that kernel
   int conv_n32_wino2d = 1;                    // "conv_n32_wino2d" (1: inference plans, 2: every plan, 0: never): Cout-32 layers with >= 64 input channels (the last decoder level of an output-stride-2 UNet: 96 -> 32) on the F(2x2,3x3) kernel with a half-empty N tile of 64 instead of the N-tile-32 F(2,3) kernel
   int block_fuse = 1;                         // "block_fuse"
+  int mlp_fuse = 1;                           // "mlp_fuse": CNBlock's Linear -> GELU -> Linear -> scale + residual in one launch (cnblock_mlp_kernel) where the width fits
   int stem_f16mfma = 1;                       // "stem_f16mfma"
   int upsample_f16math = 1;                   // "upsample_f16math"
   int conv_f16_rows = 1;                      // "conv_f16_rows" (plain fp16: the row-tile kernel of f16_rows_kernels.hip; 1 where estimated faster, 2 wherever it fits, 0 never)

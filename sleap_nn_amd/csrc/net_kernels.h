@@ -150,6 +150,20 @@ int launch_patch_stem(const PatchStemArgs& a, hipStream_t s);
 int launch_dwconv7(const DwConvArgs& a, hipStream_t s);
 int launch_layernorm(const float* src, const float* gamma, const float* beta, float* dst, int c, int cp, size_t npix, hipStream_t s);
 int launch_gemm(const GemmArgs& a, hipStream_t s);
+// CNBlock's MLP in one launch (cnblock_mlp_kernels.hip): dst = residual + scale * (W2 gelu(W1 x + b1) + b2) over (M, C) rows
+struct MlpArgs {
+  const float* x = nullptr;         // (M, C): the LayerNorm output
+  const float* w1img = nullptr;     // Linear(C, 4C) weight as [hidden block][C / 8 pieces of [lane][4]] (model.hip: pack_mlp_w1)
+  const float* w2img = nullptr;     // Linear(4C, C) weight as [hidden block][C / 8 pieces of [lane][4]] in the K order of the chained product (pack_mlp_w2)
+  const float* b1 = nullptr;        // >= 4C
+  const float* b2 = nullptr;        // >= C
+  const float* scale = nullptr;     // layer scale (>= C) or nullptr
+  const float* residual = nullptr;  // (M, C) or nullptr
+  float* dst = nullptr;             // (M, C)
+  int M = 0, C = 0;
+};
+bool cnblock_mlp_fits(int c, int cp, int hidden);
+int launch_cnblock_mlp(const MlpArgs& a, hipStream_t s);
 int gemm_choose_bn(int coutp);
 int prepare_convnext_kernels();
 int launch_stem(const StemArgs& a, hipStream_t s);

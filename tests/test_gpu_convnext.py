@@ -82,6 +82,39 @@ def test_convnext_tiny_centered_instance_rgb_float():
     _run(bb, _heads(13, 2), "centered_instance", img, layer_scale=0.3, check_blocks=False)
 
 
+def test_cnblock_mlp_in_one_launch_equals_the_two_row_gemms_and_the_oracle():
+    """Inference plans run a 96-channel CNBlock's Linear -> GELU -> Linear -> layer scale + residual as ONE launch (cnblock_mlp_kernel: the second product reads the first one's
+    accumulator registers as its B operand, K orders permuted to match): against the oracle at the path's tolerance, against the two-GEMM plan (`mlp_fuse` 0) at fp32
+    summation-order noise, over several tiles and frames; both Linear ops of a fused pair report
+    PH_KV_MLP, the plan that keeps activations (hidden tensor readable) does not fuse."""
+    from sleap_nn_amd import _lib as L
+    from sleap_nn_amd.architectures.model import Model
+
+    bb = _bb(arch={"depths": [2, 1, 1, 1], "channels": [96, 192, 384, 768]}, stem_patch_stride=2, output_stride=2)
+    heads = _heads(4, 2)
+    g = torch.Generator().manual_seed(23)
+    img = torch.randint(0, 256, (3, 1, 64, 96), dtype=torch.uint8, generator=g)  # stage 0: 3 x 32 x 48 pixels = 18 tiles of 256 rows (a valid input's pixel count is always a multiple of 256 at this stage)
+    sd = O.init_state_convnext(bb, heads, "single_instance", seed=5, head_scale=1.0, layer_scale=0.5, randomize_affine=True)
+    ref = O.model_forward(sd, bb, heads, "single_instance", img, backbone="convnext")
+    outs = {}
+    for fuse in (1, 0):
+        m = Model("convnext", bb, heads, "single_instance")
+        m.load_state_dict(sd, strict=True)
+        m.to(DEV).set_option("mlp_fuse", fuse)
+        outs[fuse] = {k: v.clone() for k, v in m(img.to(DEV)).items()}
+        codes = list(m.last_kernels())
+        assert codes.count(L.KV_MLP) == (4 if fuse else 0), codes  # two blocks x two Linear ops at 96 channels; the wider stages stay on the row GEMM
+    kept = Model("convnext", bb, heads, "single_instance")
+    kept.load_state_dict(sd, strict=True)
+    kept.to(DEV).set_keep_activations(True)
+    kept(img.to(DEV))
+    assert list(kept.last_kernels()).count(L.KV_MLP) == 0
+    for k, t in ref.items():
+        scale = max(1.0, t.abs().max().item())
+        assert (outs[1][k].cpu() - t).abs().max().item() / scale <= ATOL, k
+        assert (outs[1][k] - outs[0][k]).abs().max().item() / scale <= 2e-5, k
+
+
 def test_convnext_rows_not_multiple_of_tile_and_gray_to_rgb():
     """M (pixels) not a multiple of the 256-row GEMM tile at every stage; gray input into an RGB model."""
     bb = _bb(arch={"depths": [1, 1, 1, 1], "channels": [16, 32, 64, 128]}, in_channels=3)
