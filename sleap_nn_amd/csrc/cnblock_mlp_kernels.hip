@@ -12,9 +12,10 @@
 //     Linear are packed in that order, and GELU(D1 + b1) goes from the accumulator registers straight into the second product: no LDS, no HBM, no shuffle.
 //   * x stays in registers for the whole tile (lane (j, h) holds channels [h C / 2, (h + 1) C / 2) of pixel j: C / 2 registers; the first product's K order is chosen
 //     for THAT: step s = channels (s, C / 2 + s)), the output accumulators (C / 32 blocks of 16 registers) too.
-//   * Weights: per block of 32 hidden channels one LDS image [W1 part: C / 8 pieces | W2 part: C / 8 pieces] of 1-KiB pieces that ARE the A operands
-//     ([4 K steps][lane][4 floats]: one ds_read_b128 feeds four MFMAs), brought by LDS-DMA one hidden block ahead (double-buffered), shared by the eight waves of the
-//     workgroup: C = 96: 24 KiB per hidden block and buffer.  One barrier per hidden block (96 MFMAs per wave).
+//   * Weights come straight from L2 into the A-operand registers: per block of 32 hidden channels 24 pieces of 1 KiB ([4 K steps][lane][4 floats]: one 16-byte load
+//     per lane feeds four MFMAs) in the order the wave consumes them, a ring of eight pieces (32 registers) ahead of their use -- ~2 000 MFMA cycles of cover.  No LDS
+//     for the weights, no barrier anywhere in the loop: the eight waves of a workgroup drift apart and fill each other's gaps.  (First version: the pieces by LDS-DMA
+//     into a double-buffered LDS image shared by the workgroup, one barrier per hidden block: 3.37 ms per stage-0 block at cfg4 against 3.92 for the two GEMMs.)
 //   * Persistent workgroups (one per CU, eight waves = 256 pixels per tile); the epilogue adds b2, applies the layer scale and the residual with 16-byte accesses
 //     (a lane's register quad = four consecutive channels of its pixel).
 // Summation order differs from the two-GEMM path (K permuted): fp32 rounding only; the ConvNeXt parity tests hold both at the same tolerance.
@@ -27,6 +28,10 @@ namespace ph {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+#ifndef PH_MLP_EXP
+#define PH_MLP_EXP 0  // timing experiments only (wrong results): 1 = no GELU arithmetic, 2 = the weight ring is never refilled
+#endif
+
 // C: channels (a multiple of 32; x and the output are (M, C) rows).  Hidden = 4 C.
 template <int C>
 __global__ __launch_bounds__(512, 2) void cnblock_mlp_kernel(MlpArgs a) {
@@ -34,27 +39,32 @@ __global__ __launch_bounds__(512, 2) void cnblock_mlp_kernel(MlpArgs a) {
   constexpr int KS1 = C / 2;             // K steps of the first product
   constexpr int NB = C / 32;             // output blocks
   constexpr int P1 = C / 8, P2 = C / 8;  // 1-KiB pieces per hidden block: W1 part, W2 part
-  constexpr int IMG = (P1 + P2) * 1024;  // bytes per hidden block
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][IMG] weights | b1 [4 C floats]
-  float* const sB1 = reinterpret_cast<float*>(smem + 2 * IMG);
+  constexpr int NP = P1 + P2;            // pieces a wave consumes per hidden block, in this order: W1 q = 0 .. P1 - 1, then W2 (g, nb) = (0, 0), (0, 1), ...
+  constexpr int RING = C > 96 ? 4 : 8;   // (192 channels: x and the output accumulators take 192 registers; four pieces ahead is what is left)
+  static_assert(NP % RING == 0 && P1 % 4 == 0, "ring slots must be static");
+  __shared__ float sB1[4 * C];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 31, h = lane >> 5;
   for (int i = tid; i < 4 * C; i += 512) sB1[i] = a.b1[i];
+  __syncthreads();
 
-  auto stage = [&](int hb, int buf) {  // hidden block hb's image into buffer buf: pieces wave, wave + 8, ...
-    char* const dst = smem + buf * IMG;
-#pragma unroll
-    for (int p = wave; p < P1 + P2; p += 8) {
-      const char* g = p < P1 ? reinterpret_cast<const char*>(a.w1img) + ((size_t)hb * P1 + p) * 1024 : reinterpret_cast<const char*>(a.w2img) + ((size_t)hb * P2 + (p - P1)) * 1024;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + lane * 16), (__attribute__((address_space(3))) void*)(dst + p * 1024), 16, 0, 0);
-    }
+  const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc((void*)a.w1img, 0, NHB * P1 * 1024, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc((void*)a.w2img, 0, NHB * P2 * 1024, 0x00020000);
+  const unsigned lane_off = (unsigned)lane * 16u;
+  // piece u (consumption order) of hidden block hb
+  auto fetch = [&](int u, int hb) __attribute__((always_inline)) -> f32x4 {
+    if (u < P1) return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r1, lane_off, (hb * P1 + u) * 1024, 0));
+    const int g = (u - P1) / NB, nb = (u - P1) % NB;
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r2, lane_off, (hb * P2 + nb * 4 + g) * 1024, 0));
   };
+  f32x4 ring[RING];
+#pragma unroll
+  for (int u = 0; u < RING; ++u) ring[u] = fetch(u, 0);
 
   const int tiles = (a.M + 255) >> 8;
   for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
     const int row = tile * 256 + wave * 32 + j;
     const int rowc = row < a.M ? row : a.M - 1;
-    stage(0, 0);
     // x of this wave's 32 pixels: lane (j, h) takes channels [h C / 2, (h + 1) C / 2) of pixel j
     float x[KS1];
     {
@@ -73,21 +83,18 @@ __global__ __launch_bounds__(512, 2) void cnblock_mlp_kernel(MlpArgs a) {
 
 #pragma unroll 1
     for (int hb = 0; hb < NHB; ++hb) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of block hb (and x, first time round) landed
-      __syncthreads();                                   // ... everybody's; every wave is out of the other buffer
-      if (hb + 1 < NHB) stage(hb + 1, (hb + 1) & 1);
-      const char* const img = smem + (hb & 1) * IMG;
+      const int nhb = hb + 1 < NHB ? hb + 1 : 0;  // (the ring runs on into the next tile's first block)
       // ---- first product: D1[hidden 8 (r / 4) + 4 h + (r % 4)][pixel j], K step s = channels (s, C / 2 + s)
       f32x16 acc1;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc1[r] = 0.f;
-      f32x4 wq[2];
-      wq[0] = *reinterpret_cast<const f32x4*>(img + lane * 16);
 #pragma unroll
-      for (int q = 0; q < KS1 / 4; ++q) {
-        if (q + 1 < KS1 / 4) wq[(q + 1) & 1] = *reinterpret_cast<const f32x4*>(img + (q + 1) * 1024 + lane * 16);
+      for (int u = 0; u < P1; ++u) {
+        const f32x4 w = ring[u % RING];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[q & 1][t], x[4 * q + t], acc1, 0, 0, 0);
+        for (int t = 0; t < 4; ++t) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[t], x[4 * u + t], acc1, 0, 0, 0);
+        if (!(PH_MLP_EXP & 2)) ring[u % RING] = u + RING < NP ? fetch(u + RING, hb) : fetch(u + RING - NP, nhb);
+        __builtin_amdgcn_sched_barrier(0);
       }
       // ---- GELU(D1 + b1): the accumulator registers become the second product's B operands
       float hid[16];
@@ -95,19 +102,22 @@ __global__ __launch_bounds__(512, 2) void cnblock_mlp_kernel(MlpArgs a) {
       for (int g = 0; g < 4; ++g) {
         const f32x4 b = *reinterpret_cast<const f32x4*>(sB1 + hb * 32 + 8 * g + 4 * h);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) hid[4 * g + t] = gelu_f(acc1[4 * g + t] + b[t]);
+        for (int t = 0; t < 4; t += 2) {  // (packed fp32: two values per instruction, gelu_f's bits)
+          const ph_f32x2 s2 = ph_f32x2{acc1[4 * g + t], acc1[4 * g + t + 1]} + ph_f32x2{b[t], b[t + 1]};
+          const ph_f32x2 v = (PH_MLP_EXP & 1) ? s2 : gelu_f2(s2);
+          hid[4 * g + t] = v[0];
+          hid[4 * g + t + 1] = v[1];
+        }
       }
       // ---- second product: D2[out channel][pixel j] += W2[out][hidden] hid, K step r = the hidden channels register r holds in the two lane halves
-      const char* const img2 = img + P1 * 1024;
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        f32x4 w2[NB];
+      for (int u = P1; u < NP; ++u) {
+        const int g = (u - P1) / NB, nb = (u - P1) % NB;
+        const f32x4 w = ring[u % RING];
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) w2[nb] = *reinterpret_cast<const f32x4*>(img2 + (nb * 4 + g) * 1024 + lane * 16);
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-          for (int nb = 0; nb < NB; ++nb) acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(w2[nb][t], hid[4 * g + t], acc2[nb], 0, 0, 0);
+        for (int t = 0; t < 4; ++t) acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[t], hid[4 * g + t], acc2[nb], 0, 0, 0);
+        if (!(PH_MLP_EXP & 2)) ring[u % RING] = u + RING < NP ? fetch(u + RING, hb) : fetch(u + RING - NP, nhb);
+        if (nb == NB - 1) __builtin_amdgcn_sched_barrier(0);
       }
     }
     // ---- epilogue: y = residual + scale * (D2 + b2); lane (j, h), block nb, register quad g = channels nb 32 + 8 g + 4 h .. + 3 of pixel j
@@ -134,11 +144,10 @@ __global__ __launch_bounds__(512, 2) void cnblock_mlp_kernel(MlpArgs a) {
           *reinterpret_cast<f32x4*>(a.dst + (size_t)row * C + c0) = v;
         }
     }
-    __syncthreads();  // (the next tile's stage(0, 0) refills buffer 0: every wave must be out of the last hidden blocks' buffers)
   }
 }
 
-bool cnblock_mlp_fits(int c, int cp, int hidden) { return c == cp && hidden == 4 * c && c == 96; }
+bool cnblock_mlp_fits(int c, int cp, int hidden) { return c == cp && hidden == 4 * c && (c == 96 || c == 192); }
 int64_t cnblock_mlp_w_floats(int c) { return (int64_t)4 * c * c; }  // each of the two images holds its 4 C x C matrix once
 
 int launch_cnblock_mlp(const MlpArgs& a, hipStream_t s) {
@@ -149,15 +158,11 @@ int launch_cnblock_mlp(const MlpArgs& a, hipStream_t s) {
     const int rc_cu = device_cu_count(&n_cu);
     if (rc_cu != PH_OK) return rc_cu;
   }
-  constexpr int C = 96;
-  const size_t lds = 2 * (C / 4) * 1024 + 4 * C * 4;
-  static bool attr_done = false;
-  if (!attr_done) {
-    PH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(cnblock_mlp_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_done = true;
-  }
   const int tiles = (a.M + 255) >> 8;
-  hipLaunchKernelGGL(cnblock_mlp_kernel<C>, dim3(std::min(tiles, n_cu)), dim3(512), lds, s, a);
+  if (a.C == 96)
+    hipLaunchKernelGGL(cnblock_mlp_kernel<96>, dim3(std::min(tiles, n_cu)), dim3(512), 0, s, a);
+  else
+    hipLaunchKernelGGL(cnblock_mlp_kernel<192>, dim3(std::min(tiles, n_cu)), dim3(512), 0, s, a);
   PH_HIP_CHECK(hipGetLastError());
   return PH_OK;
 }

@@ -83,7 +83,7 @@ def test_convnext_tiny_centered_instance_rgb_float():
 
 
 def test_cnblock_mlp_in_one_launch_equals_the_two_row_gemms_and_the_oracle():
-    """Inference plans run a 96-channel CNBlock's Linear -> GELU -> Linear -> layer scale + residual as ONE launch (cnblock_mlp_kernel: the second product reads the first one's
+    """Inference plans run a 96- or 192-channel CNBlock's Linear -> GELU -> Linear -> layer scale + residual as ONE launch (cnblock_mlp_kernel: the second product reads the first one's
     accumulator registers as its B operand, K orders permuted to match): against the oracle at the path's tolerance, against the two-GEMM plan (`mlp_fuse` 0) at fp32
     summation-order noise, over several tiles and frames; both Linear ops of a fused pair report
     PH_KV_MLP, the plan that keeps activations (hidden tensor readable) does not fuse."""
@@ -103,7 +103,7 @@ def test_cnblock_mlp_in_one_launch_equals_the_two_row_gemms_and_the_oracle():
         m.to(DEV).set_option("mlp_fuse", fuse)
         outs[fuse] = {k: v.clone() for k, v in m(img.to(DEV)).items()}
         codes = list(m.last_kernels())
-        assert codes.count(L.KV_MLP) == (4 if fuse else 0), codes  # two blocks x two Linear ops at 96 channels; the wider stages stay on the row GEMM
+        assert codes.count(L.KV_MLP) == (6 if fuse else 0), codes  # (two blocks at 96 channels + one at 192) x two Linear ops; the wider stages stay on the row GEMM
     kept = Model("convnext", bb, heads, "single_instance")
     kept.load_state_dict(sd, strict=True)
     kept.to(DEV).set_keep_activations(True)
