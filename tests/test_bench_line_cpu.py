@@ -120,7 +120,8 @@ def test_every_conv_kernel_family_the_library_reports_has_a_name_in_the_bench():
     from sleap_nn_amd import _lib as L
 
     short, long_ = bench.conv_kernel_short_names(), bench.conv_kernel_long_names()
-    conv_codes = {v for k, v in vars(L).items() if k.startswith("KV_") and isinstance(v, int)} - {L.KV_NONE, L.KV_FUSED, L.KV_STEM}
+    conv_codes = {v for k, v in vars(L).items() if k.startswith("KV_") and isinstance(v, int)} - {L.KV_NONE, L.KV_FUSED, L.KV_STEM, L.KV_MLP}  # (KV_MLP: a pair of Linear ops, never a 3x3 conv)
+    assert L.KV_MLP in L.KV_NAMES and L.KV_MFMA_SHARE[L.KV_MLP] == 1.0
     assert conv_codes <= set(short), sorted(conv_codes - set(short))
     assert set(short.values()) <= set(long_) and set(L.KV_NAMES) >= conv_codes and set(L.KV_MFMA_SHARE) >= conv_codes
 
