@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define PH_VERSION 107
+#define PH_VERSION 108
 
 /* error codes */
 #define PH_OK 0
