@@ -16,6 +16,7 @@
 //     per lane feeds four MFMAs) in the order the wave consumes them, a ring of eight pieces (32 registers) ahead of their use -- ~2 000 MFMA cycles of cover.  No LDS
 //     for the weights, no barrier anywhere in the loop: the eight waves of a workgroup drift apart and fill each other's gaps.  (First version: the pieces by LDS-DMA
 //     into a double-buffered LDS image shared by the workgroup, one barrier per hidden block: 3.37 ms per stage-0 block at cfg4 against 3.92 for the two GEMMs.)
+//     Two accumulator chains in the first product (alternate K steps) instead of one: the same 3.06 ms per 96-channel block.
 //   * Persistent workgroups (one per CU, eight waves = 256 pixels per tile); the epilogue adds b2, applies the layer scale and the residual with 16-byte accesses
 //     (a lane's register quad = four consecutive channels of its pixel).
 // Summation order differs from the two-GEMM path (K permuted): fp32 rounding only; the ConvNeXt parity tests hold both at the same tolerance.
