@@ -34,19 +34,19 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #endif
 
 // C: channels (a multiple of 32; x and the output are (M, C) rows).  Hidden = 4 C.
-template <int C>
-__global__ __launch_bounds__(512, 2) void cnblock_mlp_kernel(MlpArgs a) {
+template <int C, int NW>
+__global__ __launch_bounds__(64 * NW, NW / 4) void cnblock_mlp_kernel(MlpArgs a) {
   constexpr int NHB = 4 * C / 32;        // hidden blocks of 32 channels
   constexpr int KS1 = C / 2;             // K steps of the first product
   constexpr int NB = C / 32;             // output blocks
   constexpr int P1 = C / 8, P2 = C / 8;  // 1-KiB pieces per hidden block: W1 part, W2 part
   constexpr int NP = P1 + P2;            // pieces a wave consumes per hidden block, in this order: W1 q = 0 .. P1 - 1, then W2 (g, nb) = (0, 0), (0, 1), ...
-  constexpr int RING = C > 96 ? 4 : 8;   // (192 channels: x and the output accumulators take 192 registers; four pieces ahead is what is left)
+  constexpr int RING = (C > 96 || NW > 8) ? 4 : 8;   // (192 channels: x and the output accumulators take 192 registers; four pieces ahead is what is left)
   static_assert(NP % RING == 0 && P1 % 4 == 0, "ring slots must be static");
   __shared__ float sB1[4 * C];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 31, h = lane >> 5;
-  for (int i = tid; i < 4 * C; i += 512) sB1[i] = a.b1[i];
+  for (int i = tid; i < 4 * C; i += 64 * NW) sB1[i] = a.b1[i];
   __syncthreads();
 
   const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc((void*)a.w1img, 0, NHB * P1 * 1024, 0x00020000);
@@ -62,9 +62,10 @@ __global__ __launch_bounds__(512, 2) void cnblock_mlp_kernel(MlpArgs a) {
 #pragma unroll
   for (int u = 0; u < RING; ++u) ring[u] = fetch(u, 0);
 
-  const int tiles = (a.M + 255) >> 8;
+  constexpr int TR = 32 * NW;  // rows per tile
+  const int tiles = (a.M + TR - 1) / TR;
   for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-    const int row = tile * 256 + wave * 32 + j;
+    const int row = tile * TR + wave * 32 + j;
     const int rowc = row < a.M ? row : a.M - 1;
     // x of this wave's 32 pixels: lane (j, h) takes channels [h C / 2, (h + 1) C / 2) of pixel j
     float x[KS1];
@@ -159,11 +160,16 @@ int launch_cnblock_mlp(const MlpArgs& a, hipStream_t s) {
     const int rc_cu = device_cu_count(&n_cu);
     if (rc_cu != PH_OK) return rc_cu;
   }
-  const int tiles = (a.M + 255) >> 8;
-  if (a.C == 96)
-    hipLaunchKernelGGL(cnblock_mlp_kernel<96>, dim3(std::min(tiles, n_cu)), dim3(512), 0, s, a);
-  else
-    hipLaunchKernelGGL(cnblock_mlp_kernel<192>, dim3(std::min(tiles, n_cu)), dim3(512), 0, s, a);
+#ifndef PH_MLP_NW96
+#define PH_MLP_NW96 8  // (12 waves = three per SIMD with a ring of four: 3.08 ms per 96-channel block against 3.06 -- the same)
+#endif
+  if (a.C == 96) {
+    const int tiles = (a.M + 32 * PH_MLP_NW96 - 1) / (32 * PH_MLP_NW96);
+    hipLaunchKernelGGL((cnblock_mlp_kernel<96, PH_MLP_NW96>), dim3(std::min(tiles, n_cu)), dim3(64 * PH_MLP_NW96), 0, s, a);
+  } else {
+    const int tiles = (a.M + 255) >> 8;
+    hipLaunchKernelGGL((cnblock_mlp_kernel<192, 8>), dim3(std::min(tiles, n_cu)), dim3(512), 0, s, a);
+  }
   PH_HIP_CHECK(hipGetLastError());
   return PH_OK;
 }
