@@ -833,8 +833,11 @@ __device__ __forceinline__ void stem_barrier_lds() {
   asm volatile("" ::: "memory");
 }
 
+#ifndef PH_STEM_OCC
+#define PH_STEM_OCC 4  // waves per SIMD the register budget allows = workgroups per CU (cfg5, tools/f16_ab.sh: 3 -> 180 us, 4 -> 161, 5 -> 225: the tile loop spills)
+#endif
 template <int CIN>
-__global__ __launch_bounds__(256, 4) void stem_f16_kernel(StemArgs a) {
+__global__ __launch_bounds__(256, PH_STEM_OCC) void stem_f16_kernel(StemArgs a) {
   constexpr int NK = (9 * CIN + 15) / 16;      // K steps of 16 of the first conv
   constexpr int NP0 = S_HH * S_HW;             // 340 halo pixels of the first conv's output
   constexpr int NMT = (NP0 + 15) / 16;         // 22 M tiles of the first conv
@@ -1061,7 +1064,7 @@ int launch_stem_f16(const StemArgs& a, hipStream_t s) {
     if (rc_cu != PH_OK) return rc_cu;
   }
   const int tiles = ((a.W + S_TW - 1) / S_TW) * ((a.H + S_TH - 1) / S_TH) * a.B;
-  const int grid = std::min(8 * ((tiles + 7) / 8), 4 * n_cu);  // persistent: four workgroups per CU -- 128 registers: at six the tile loop spills -- (a multiple of 8: the XCD dealing of the virtual tile ids)
+  const int grid = std::min(8 * ((tiles + 7) / 8), PH_STEM_OCC * n_cu);  // persistent: four workgroups per CU -- 128 registers: at six the tile loop spills -- (a multiple of 8: the XCD dealing of the virtual tile ids)
   if (a.cin == 1)
     hipLaunchKernelGGL((stem_f16_kernel<1>), dim3(grid), dim3(256), 0, s, a);
   else
