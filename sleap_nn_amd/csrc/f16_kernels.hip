@@ -834,7 +834,8 @@ __device__ __forceinline__ void stem_barrier_lds() {
 }
 
 #ifndef PH_STEM_OCC
-#define PH_STEM_OCC 4  // waves per SIMD the register budget allows = workgroups per CU (cfg5, tools/f16_ab.sh: 3 -> 180 us, 4 -> 161, 5 -> 225: the tile loop spills)
+#define PH_STEM_OCC 4  // waves per SIMD the register budget allows = workgroups per CU (cfg5, tools/f16_ab.sh: 3 -> 180 us, 4 -> 161, 5 -> 225: the tile loop spills; with the biases and the
+                       // per-M-tile pixel offsets in LDS tables instead of 20 registers the kernel needs 95 registers and 5 -> 155 us, 4 -> 168, 6 -> 194: a 3 % gain at the noise level, not kept)
 #endif
 template <int CIN>
 __global__ __launch_bounds__(256, PH_STEM_OCC) void stem_f16_kernel(StemArgs a) {
