@@ -113,6 +113,18 @@ def test_cnblock_mlp_in_one_launch_equals_the_two_row_gemms_and_the_oracle():
         scale = max(1.0, t.abs().max().item())
         assert (outs[1][k].cpu() - t).abs().max().item() / scale <= ATOL, k
         assert (outs[1][k] - outs[0][k]).abs().max().item() / scale <= 2e-5, k
+    # the fused kernel's weight images are rebuilt from a device parameter arena too (ph_model_set_params' gather maps: what an evaluation in the middle of training runs on)
+    sd2 = O.init_state_convnext(bb, heads, "single_instance", seed=6, head_scale=1.0, layer_scale=0.4, randomize_affine=True)
+    ref2 = O.model_forward(sd2, bb, heads, "single_instance", img, backbone="convnext")
+    donor = Model("convnext", bb, heads, "single_instance")
+    donor.load_state_dict(sd2, strict=True)
+    live = Model("convnext", bb, heads, "single_instance")
+    live.load_state_dict(sd, strict=True)  # (the handle is created from THESE weights, then re-packed from the arena)
+    live.bind_live_params(donor.flat_params().to(DEV))
+    out2 = live.to(DEV)(img.to(DEV))
+    assert list(live.last_kernels()).count(L.KV_MLP) == 6
+    for k, t in ref2.items():
+        assert (out2[k].cpu() - t).abs().max().item() / max(1.0, t.abs().max().item()) <= ATOL, k
 
 
 def test_convnext_rows_not_multiple_of_tile_and_gray_to_rgb():
