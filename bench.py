@@ -534,6 +534,13 @@ def run_infer(args, ctx):
         if n > 0:
             op_samples.append([v / n for v in ms])
 
+    # The contract's W warm-up steps ran above; everything the host had to do since (asserts with a device read-back, event creation) left the GPU idle for milliseconds, and the
+    # first two steps of the timed region then ran 1.5 - 1.7 ms slow each (`step_ms_profiled_vs_replayed.by_step` of a 20-step run: 12.39, 12.14, 10.83, 10.67 ...: the clocks of an
+    # idle GPU).  Two more UNTIMED steps close that gap: the synchronisation below ends microseconds before the first timed launch, as the contract's bracket wants it.
+    for _ in range(2):
+        step(frames)
+    drain()
+    torch.cuda.synchronize()
     barrier()
     host_wait[0] = 0.0
     t0 = time.perf_counter()
@@ -847,13 +854,15 @@ def run_infer(args, ctx):
     import glob
 
     cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_conv_traffic.json")))
-    if cands and B == 32 and not fp16:
-        try:
-            tj = json.load(open(cands[-1]))["conv3x3_mfma"]
-            if int(round(tj["launches_per_forward"])) == len(conv_rows):
-                traffic, traffic_src = tj["hbm_bytes_per_launch"], os.path.relpath(cands[-1], ROOT)
-        except Exception:
-            pass
+    if B == 32 and not fp16:
+        for cand in reversed(cands):  # newest first; files of another leg (the fp16 pipe's cfg5 set) or of another launch count are stepped over, not an error
+            try:
+                tj = json.load(open(cand))["conv3x3_mfma"]
+                if int(round(tj["launches_per_forward"])) == len(conv_rows):
+                    traffic, traffic_src = tj["hbm_bytes_per_launch"], os.path.relpath(cand, ROOT)
+                    break
+            except Exception:
+                continue
     conv_bytes = sum(r["bytes"] for r, _ in conv_rows)
     frames_total = global_batch * args.steps
     res = {
@@ -882,6 +891,10 @@ def run_infer(args, ctx):
                              "fits": 2 * world <= (len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))},
         },
         "step_ms": percentiles(step_ms),
+        "untimed_steps_before_timing": max(args.warmup, 2) + 2,  # --warmup steps + two more right in front of the timed region's synchronisation (the GPU would idle through the host-side checks otherwise and start the region at idle clocks)
+        "step_ms_profiled_vs_replayed": {"profiled_mean": float(np.mean([v for i, v in enumerate(step_ms) if i in prof_at])) if prof_at else None,
+                                         "replayed_mean": float(np.mean([v for i, v in enumerate(step_ms) if i not in prof_at])) if len(prof_at) < len(step_ms) else None,
+                                         "by_step": [round(float(v), 3) for v in step_ms]},
         "roofline": {
             "bound": "mfma",
             "kernel": KERNEL_NAMES[dom] + f", {D['launches']} of the {len(conv_rows)} conv launches of a forward; the first encoder block runs in the fused stem kernel",
@@ -911,9 +924,15 @@ def run_infer(args, ctx):
     }
     if peaks_us is not None:
         cm_bytes = float(cms.numel() * 4)
+        peaks_traffic, peaks_traffic_src = None, None
+        for cand in reversed(cands):  # the newest committed PMC file that holds the peak kernels
+            peaks_traffic = _peaks_traffic(cand, B)
+            if peaks_traffic:
+                peaks_traffic_src = os.path.relpath(cand, ROOT)
+                break
         res["roofline_postprocess"] = {"bound": "hbm", "kernel": "peaks_onepass_kernel<1> + peaks_place_kernel (find_local_peaks: threshold over the streamed maps, 3x3 strict NMS + integral refinement of the candidates, ordered placement)",
                                        "achieved": cm_bytes / (peaks_us * 1e-6) / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": cm_bytes / (peaks_us * 1e-6) / 1e9 / 8000.0,
-                                       "algorithmic_bytes": cm_bytes, "us_per_batch": peaks_us, "launches": 2, "traffic": _peaks_traffic(cands[-1] if cands else None, B), "traffic_source": os.path.relpath(cands[-1], ROOT) if cands else None,
+                                       "algorithmic_bytes": cm_bytes, "us_per_batch": peaks_us, "launches": 2, "traffic": peaks_traffic, "traffic_source": peaks_traffic_src,
                                        "byte_accounting": "algorithmic bytes = the confidence maps read once (B x 13 x 256 x 256 fp32); time = HIP events around 50 back-to-back calls (both launches + the output allocation of the wrapper); "
                                                           "a bare read of the same 109 MB (tools/probes/hbm_read_probe.hip) takes 15.9 us on this GPU = 0.86 of 8 TB/s, launch included"}
     if elapsed_weak is not None:
