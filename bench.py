@@ -416,6 +416,23 @@ def _peaks_traffic(conv_traffic_json, batch):
         return None
 
 
+def warm_up(fn, min_calls: int, min_ms: float = None, finish=None) -> None:
+    """Untimed calls in front of a timed loop: at least `min_calls`, and for at least `min_ms` (default benchlegs.common.WARM_MS) of wall time, so that the loop does not start at the
+    clocks of a GPU that idled through the host-side set-up before it."""
+    from benchlegs.common import WARM_MS
+
+    lim = WARM_MS if min_ms is None else min_ms
+    t_w, k = time.perf_counter(), 0
+    while k < min_calls or 1e3 * (time.perf_counter() - t_w) < lim:
+        fn()
+        k += 1
+        if k % 8 == 0:
+            torch.cuda.synchronize()
+    if finish is not None:
+        finish()
+    torch.cuda.synchronize()
+
+
 def run_infer(args, ctx):
     rank, world, dev, dist = ctx["rank"], ctx["world"], ctx["dev"], ctx["dist"]
     from concurrent.futures import ThreadPoolExecutor
@@ -670,10 +687,7 @@ def run_infer(args, ctx):
         ref_heads = {k: v.clone() for k, v in eager(frames[:2]).items()}
         for tag, prec in (("f16x3_split", "split"), ("f16_autocast", "fp16")):
             model.set_precision(prec)
-            for _ in range(3):
-                step(frames)
-            drain()
-            torch.cuda.synchronize()
+            warm_up(lambda: step(frames), 3, finish=drain)
             t1 = time.perf_counter()
             for _ in range(args.steps):
                 step(frames)
@@ -695,6 +709,8 @@ def run_infer(args, ctx):
         from sleap_nn_amd.inference.ops.peaks import find_local_peaks_device
 
         pc = layer.postprocess_config
+        # (five warm-up calls, not a time-based warm-up: this leg runs right behind the steps above, as the kernel does in the pipeline; 20 ms of NOTHING BUT these 26-us launches lets the chip
+        # drop its memory-side clocks -- the same 50 calls then take 40 us each instead of 26)
         for _ in range(5):
             find_local_peaks_device(cms, pc.peak_threshold, pc.effective_refinement, pc.integral_patch_size, 4096, xy_scale=4.0)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -715,10 +731,7 @@ def run_infer(args, ctx):
             sframes = frames.reshape(B, 1, SIZE, SIZE)[:sb].contiguous()
             if use_graph:
                 sframes = backend.static_input((sb, 1, SIZE, SIZE)).copy_(sframes)
-            for _ in range(5):
-                step(sframes)
-            drain()
-            torch.cuda.synchronize()
+            warm_up(lambda: step(sframes), 5, finish=drain)
             n_s = max(args.steps, 50)
             t1 = time.perf_counter()
             for _ in range(n_s):

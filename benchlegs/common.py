@@ -9,7 +9,7 @@ import time
 import numpy as np
 import torch
 
-__all__ = ['CFG3_BB', 'NODES', 'CFG3_HEADS', 'SIZE', 'MFMA_F32_PEAK_TFLOPS', 'MFMA_F16_PEAK_TFLOPS', 'CFG4_BB', 'CFG4_HEADS', 'synthetic_instances', 'rendered_heads', 'percentiles', 'conv_kernel_short_names', 'conv_kernel_long_names', 'forward_executed_flops', 'ROOT']
+__all__ = ['WARM_MS', 'CFG3_BB', 'NODES', 'CFG3_HEADS', 'SIZE', 'MFMA_F32_PEAK_TFLOPS', 'MFMA_F16_PEAK_TFLOPS', 'CFG4_BB', 'CFG4_HEADS', 'synthetic_instances', 'rendered_heads', 'percentiles', 'conv_kernel_short_names', 'conv_kernel_long_names', 'forward_executed_flops', 'ROOT']
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
@@ -169,9 +169,17 @@ def _small_roofline(executed, direct, matrix_ms, fwd_s, kernels, n_ops):
             "matrix_launch_ms_per_forward_with_events": matrix_ms, "ops_per_forward": n_ops, "kernels": kernels, "traffic": None}
 
 
+WARM_MS = 60.0  # untimed calls in front of a timed loop run at least this long: a leg starts after seconds of host-side set-up, i.e. on a GPU at idle clocks, and a handful of
+                # sub-millisecond warm-up calls end before the clocks are back (the headline's first two 10.6-ms steps ran 1.5 ms slow each for the same reason: DESIGN section 5)
+
+
 def _time_calls(fn, steps, warmup, sync_each):
-    for _ in range(warmup):
+    t_w, k = time.perf_counter(), 0
+    while k < warmup or 1e3 * (time.perf_counter() - t_w) < WARM_MS:
         fn()
+        k += 1
+        if k % 16 == 0:
+            torch.cuda.synchronize()  # (the wall clock above should see GPU time, not the depth of the launch queue)
     torch.cuda.synchronize()
     ts = []
     t0 = time.perf_counter()
