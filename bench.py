@@ -492,6 +492,7 @@ def run_infer(args, ctx):
             backend_b = HipBackend(model_b, str(dev), use_graph=True, precision=precision)
             lanes.append((backend_b, BottomUpLayer(backend_b, PAFScorer.from_config(CFG3_HEADS), 4, 8, max_stride=32), lane_st[k]))
     step_no, last_stream, host_wait = [0], [None], [0.0]
+    split_marks = None  # (diagnostic: PH_BENCH_SPLIT=1 records an event behind the forward of the first timed steps)
 
     heads_in = {"cms": cms, "pafs": pafs, "info": info}  # rebound for the weak-scaling leg of a multi-GPU run
 
@@ -505,6 +506,10 @@ def run_infer(args, ctx):
         last_stream[0] = stream_k if stream_k is not None else torch.cuda.current_stream(dev)
         with torch.cuda.stream(stream_k) if stream_k is not None else contextlib.nullcontext():
             raw = (eager if profiled else be_k)(x)  # uint8 frames -> {"MultiInstanceConfmapsHead", "PartAffinityFieldsHead"}
+            if split_marks is not None and len(split_marks) < 8:
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record()
+                split_marks.append(ev)
             inflight.append((layer_k, layer_k._enqueue_scoring({"MultiInstanceConfmapsHead": heads_in["cms"], "PartAffinityFieldsHead": heads_in["pafs"]}, heads_in["info"])))
         if len(inflight) > len(lanes):
             ly, h = inflight.pop(0)
@@ -562,6 +567,8 @@ def run_infer(args, ctx):
     torch.cuda.synchronize()
     barrier()
     host_wait[0] = 0.0
+    if os.environ.get("PH_BENCH_SPLIT"):
+        split_marks = []
     t0 = time.perf_counter()
     marks[0].record()
     for i in range(args.steps):
@@ -582,6 +589,9 @@ def run_infer(args, ctx):
         collect_sample()
     model.set_profiling(False)
     step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
+    if split_marks:
+        print("forward / rest of the first timed steps (ms):", [(round(marks[i].elapsed_time(split_marks[i]), 3), round(split_marks[i].elapsed_time(marks[i + 1]), 3)) for i in range(min(len(split_marks), args.steps))], file=sys.stderr)
+        split_marks = None
     host_wait_ms = 1e3 * host_wait[0] / max(args.steps, 1)
 
     # ---- N > 1: what every rank computed, checked against ONE rank computing the same frames (rank 0 redoes each rank's chunk with its first lane): the head outputs of the
