@@ -247,7 +247,9 @@ int ph_debug_row_wgrad_bench(int32_t M, int32_t n, int32_t k, int32_t iters, flo
  * conv3x3_sm_kernel on (8 x 8 pixels, 16 channels) units for small maps: 1 inference plans where estimated faster | 2 wherever the shape fits | 0 never),
  * "pool_peephole" (unfused programs: a conv writes the next op's 2x2 max pool), "dw_ln_fuse" (ConvNeXt: LayerNorm inside the
  * depthwise / stem kernels), "wgrad_wino" (3x3 weight gradients in the Winograd domain), "mask_fold" (ReLU masks applied by the kernel
- * that completes a gradient).
+ * that completes a gradient), "conv_f16_rows" (plain fp16: conv3x3_f16_rows_kernel 1 where its plan is estimated faster | 2 wherever the shape fits | 0 never), "upsample_f16math"
+ * (plain fp16: the bilinear x2 blended in packed fp16 arithmetic, folded or standalone: same bits), "stem_f16mfma" (plain fp16: stem_f16_kernel), "block_fuse" (plain fp16, inference plans:
+ * the two convs of a 32-channel encoder block in one launch), "mlp_fuse" (inference plans: CNBlock's Linear + GELU + Linear + layer scale + residual in one launch at 96 / 192 channels).
  * Unknown key -> PH_E_INVALID. */
 int ph_model_set_option(ph_model* m, const char* key, double value);
 int ph_model_get_option(const ph_model* m, const char* key, double* value);
