@@ -33,15 +33,16 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define PH_MLP_EXP 0  // timing experiments only (wrong results): 1 = no GELU arithmetic, 2 = the weight ring is never refilled
 #endif
 
-// C: channels (a multiple of 32; x and the output are (M, C) rows).  Hidden = 4 C.
-template <int C, int NW>
+// C: channels (a multiple of 32; x and the output are (M, C) rows).  Hidden = 4 C.  NW: waves per workgroup.  PXB: 32-pixel blocks per wave (2: every weight piece feeds eight
+// MFMAs on two independent accumulator sets instead of four on one: half the weight traffic per FLOP, and a wave that is alone on its SIMD for a while still has two chains to issue).
+template <int C, int NW, int PXB>
 __global__ __launch_bounds__(64 * NW, NW / 4) void cnblock_mlp_kernel(MlpArgs a) {
   constexpr int NHB = 4 * C / 32;        // hidden blocks of 32 channels
   constexpr int KS1 = C / 2;             // K steps of the first product
   constexpr int NB = C / 32;             // output blocks
   constexpr int P1 = C / 8, P2 = C / 8;  // 1-KiB pieces per hidden block: W1 part, W2 part
   constexpr int NP = P1 + P2;            // pieces a wave consumes per hidden block, in this order: W1 q = 0 .. P1 - 1, then W2 (g, nb) = (0, 0), (0, 1), ...
-  constexpr int RING = (C > 96 || NW > 8) ? 4 : 8;   // (192 channels: x and the output accumulators take 192 registers; four pieces ahead is what is left)
+  constexpr int RING = (C > 96 || NW > 8 || PXB > 1) ? 4 : 8;   // (192 channels / two pixel blocks: x and the output accumulators take 192 registers; four pieces ahead is what is left)
   static_assert(NP % RING == 0 && P1 % 4 == 0, "ring slots must be static");
   __shared__ float sB1[4 * C];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -62,54 +63,64 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void cnblock_mlp_kernel(MlpArgs a)
 #pragma unroll
   for (int u = 0; u < RING; ++u) ring[u] = fetch(u, 0);
 
-  constexpr int TR = 32 * NW;  // rows per tile
+  constexpr int TR = 32 * NW * PXB;  // rows per tile
   const int tiles = (a.M + TR - 1) / TR;
   for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-    const int row = tile * TR + wave * 32 + j;
-    const int rowc = row < a.M ? row : a.M - 1;
-    // x of this wave's 32 pixels: lane (j, h) takes channels [h C / 2, (h + 1) C / 2) of pixel j
-    float x[KS1];
-    {
+    int row[PXB];
+    // x of this wave's pixels: lane (j, h) takes channels [h C / 2, (h + 1) C / 2) of pixel j of each of its blocks
+    float x[PXB][KS1];
+#pragma unroll
+    for (int pb = 0; pb < PXB; ++pb) {
+      row[pb] = tile * TR + (wave * PXB + pb) * 32 + j;
+      const int rowc = row[pb] < a.M ? row[pb] : a.M - 1;
       const f32x4* xp = reinterpret_cast<const f32x4*>(a.x + (size_t)rowc * C + h * KS1);
 #pragma unroll
       for (int q = 0; q < KS1 / 4; ++q) {
         const f32x4 t = xp[q];
-        x[4 * q] = t[0]; x[4 * q + 1] = t[1]; x[4 * q + 2] = t[2]; x[4 * q + 3] = t[3];
+        x[pb][4 * q] = t[0]; x[pb][4 * q + 1] = t[1]; x[pb][4 * q + 2] = t[2]; x[pb][4 * q + 3] = t[3];
       }
     }
-    f32x16 acc2[NB];
+    f32x16 acc2[PXB][NB];
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
+    for (int pb = 0; pb < PXB; ++pb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc2[nb][r] = 0.f;
+      for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[pb][nb][r] = 0.f;
 
 #pragma unroll 1
     for (int hb = 0; hb < NHB; ++hb) {
       const int nhb = hb + 1 < NHB ? hb + 1 : 0;  // (the ring runs on into the next tile's first block)
       // ---- first product: D1[hidden 8 (r / 4) + 4 h + (r % 4)][pixel j], K step s = channels (s, C / 2 + s)
-      f32x16 acc1;
+      f32x16 acc1[PXB];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc1[r] = 0.f;
+      for (int pb = 0; pb < PXB; ++pb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc1[pb][r] = 0.f;
 #pragma unroll
       for (int u = 0; u < P1; ++u) {
         const f32x4 w = ring[u % RING];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[t], x[4 * u + t], acc1, 0, 0, 0);
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int pb = 0; pb < PXB; ++pb) acc1[pb] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[t], x[pb][4 * u + t], acc1[pb], 0, 0, 0);
         if (!(PH_MLP_EXP & 2)) ring[u % RING] = u + RING < NP ? fetch(u + RING, hb) : fetch(u + RING - NP, nhb);
         __builtin_amdgcn_sched_barrier(0);
       }
       // ---- GELU(D1 + b1): the accumulator registers become the second product's B operands
-      float hid[16];
+      float hid[PXB][16];
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const f32x4 b = *reinterpret_cast<const f32x4*>(sB1 + hb * 32 + 8 * g + 4 * h);
 #pragma unroll
-        for (int t = 0; t < 4; t += 2) {  // (packed fp32: two values per instruction, gelu_f's bits)
-          const ph_f32x2 s2 = ph_f32x2{acc1[4 * g + t], acc1[4 * g + t + 1]} + ph_f32x2{b[t], b[t + 1]};
-          const ph_f32x2 v = (PH_MLP_EXP & 1) ? s2 : gelu_f2(s2);
-          hid[4 * g + t] = v[0];
-          hid[4 * g + t + 1] = v[1];
-        }
+        for (int pb = 0; pb < PXB; ++pb)
+#pragma unroll
+          for (int t = 0; t < 4; t += 2) {  // (packed fp32: two values per instruction, gelu_f's bits)
+            const ph_f32x2 s2 = ph_f32x2{acc1[pb][4 * g + t], acc1[pb][4 * g + t + 1]} + ph_f32x2{b[t], b[t + 1]};
+            const ph_f32x2 v = (PH_MLP_EXP & 1) ? s2 : gelu_f2(s2);
+            hid[pb][4 * g + t] = v[0];
+            hid[pb][4 * g + t + 1] = v[1];
+          }
       }
       // ---- second product: D2[out channel][pixel j] += W2[out][hidden] hid, K step r = the hidden channels register r holds in the two lane halves
 #pragma unroll
@@ -117,35 +128,39 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void cnblock_mlp_kernel(MlpArgs a)
         const int g = (u - P1) / NB, nb = (u - P1) % NB;
         const f32x4 w = ring[u % RING];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[t], hid[4 * g + t], acc2[nb], 0, 0, 0);
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int pb = 0; pb < PXB; ++pb) acc2[pb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[t], hid[pb][4 * g + t], acc2[pb][nb], 0, 0, 0);
         if (!(PH_MLP_EXP & 2)) ring[u % RING] = u + RING < NP ? fetch(u + RING, hb) : fetch(u + RING - NP, nhb);
         if (nb == NB - 1) __builtin_amdgcn_sched_barrier(0);
       }
     }
     // ---- epilogue: y = residual + scale * (D2 + b2); lane (j, h), block nb, register quad g = channels nb 32 + 8 g + 4 h .. + 3 of pixel j
-    if (row < a.M) {
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb)
+    for (int pb = 0; pb < PXB; ++pb)
+      if (row[pb] < a.M) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int c0 = nb * 32 + 8 * g + 4 * h;
-          const f32x4 b2 = *reinterpret_cast<const f32x4*>(a.b2 + c0);
-          f32x4 v;
+        for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-          for (int t = 0; t < 4; ++t) v[t] = acc2[nb][4 * g + t] + b2[t];
-          if (a.scale) {
-            const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + c0);
+          for (int g = 0; g < 4; ++g) {
+            const int c0 = nb * 32 + 8 * g + 4 * h;
+            const f32x4 b2 = *reinterpret_cast<const f32x4*>(a.b2 + c0);
+            f32x4 v;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) v[t] *= sc[t];
+            for (int t = 0; t < 4; ++t) v[t] = acc2[pb][nb][4 * g + t] + b2[t];
+            if (a.scale) {
+              const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + c0);
+#pragma unroll
+              for (int t = 0; t < 4; ++t) v[t] *= sc[t];
+            }
+            if (a.residual) {
+              const f32x4 rs = *reinterpret_cast<const f32x4*>(a.residual + (size_t)row[pb] * C + c0);
+#pragma unroll
+              for (int t = 0; t < 4; ++t) v[t] += rs[t];
+            }
+            *reinterpret_cast<f32x4*>(a.dst + (size_t)row[pb] * C + c0) = v;
           }
-          if (a.residual) {
-            const f32x4 rs = *reinterpret_cast<const f32x4*>(a.residual + (size_t)row * C + c0);
-#pragma unroll
-            for (int t = 0; t < 4; ++t) v[t] += rs[t];
-          }
-          *reinterpret_cast<f32x4*>(a.dst + (size_t)row * C + c0) = v;
-        }
-    }
+      }
   }
 }
 
@@ -160,15 +175,15 @@ int launch_cnblock_mlp(const MlpArgs& a, hipStream_t s) {
     const int rc_cu = device_cu_count(&n_cu);
     if (rc_cu != PH_OK) return rc_cu;
   }
-#ifndef PH_MLP_NW96
-#define PH_MLP_NW96 8  // (12 waves = three per SIMD with a ring of four: 3.08 ms per 96-channel block against 3.06 -- the same)
+#ifndef PH_MLP_PXB96
+#define PH_MLP_PXB96 1  // (2 = 64 pixels per wave, ring of four, 19 registers spilled: 3.15 - 3.18 ms per 96-channel block against 3.06)
 #endif
   if (a.C == 96) {
-    const int tiles = (a.M + 32 * PH_MLP_NW96 - 1) / (32 * PH_MLP_NW96);
-    hipLaunchKernelGGL((cnblock_mlp_kernel<96, PH_MLP_NW96>), dim3(std::min(tiles, n_cu)), dim3(64 * PH_MLP_NW96), 0, s, a);
+    const int tiles = (a.M + 256 * PH_MLP_PXB96 - 1) / (256 * PH_MLP_PXB96);
+    hipLaunchKernelGGL((cnblock_mlp_kernel<96, 8, PH_MLP_PXB96>), dim3(std::min(tiles, n_cu)), dim3(512), 0, s, a);
   } else {
     const int tiles = (a.M + 255) >> 8;
-    hipLaunchKernelGGL((cnblock_mlp_kernel<192, 8>), dim3(std::min(tiles, n_cu)), dim3(512), 0, s, a);
+    hipLaunchKernelGGL((cnblock_mlp_kernel<192, 8, 1>), dim3(std::min(tiles, n_cu)), dim3(512), 0, s, a);
   }
   PH_HIP_CHECK(hipGetLastError());
   return PH_OK;
